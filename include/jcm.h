@@ -1,0 +1,107 @@
+/* libjcm -- C ABI of the MI355X-native joint-heat-map inference path.
+ *
+ * The reference (max-andr/joint-cnn-mrf) has no FFI layer: the path is four module-level
+ * Python functions in main.py evaluated by TensorFlow at sess.run (main.py:280,406).  Each
+ * entry point below cites the reference interface it replaces; the Python host module
+ * `joint-cnn-mrf_amd/main.py` binds them through ctypes and keeps the reference's names.
+ *
+ * Conventions
+ *   - every tensor pointer is DEVICE memory owned by the caller (a torch-ROCm allocation),
+ *     fp32, dense NHWC exactly as the reference lays it out; coords are int32;
+ *   - images are H rows x W cols (480 x 720, data.py:10), heat maps 60 x 90 (data.py:12);
+ *   - calls enqueue asynchronously on the stream given to jcm_create and do not synchronise;
+ *     one handle per (device, stream); a handle is not thread-safe;
+ *   - every function returns 0 on success, non-zero on error; jcm_last_error() returns a
+ *     thread-local message for the last failing call;
+ *   - the library owns only its packed weights, precomputed spatial-model tables and its
+ *     workspace arena; all are released by jcm_destroy.
+ */
+#ifndef JCM_H
+#define JCM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct jcm_ctx* jcm_handle;
+
+#define JCM_OK 0
+#define JCM_ERR_ARG 1      /* bad shape / name / null pointer                      */
+#define JCM_ERR_STATE 2    /* parameter missing, handle not finalised, ...          */
+#define JCM_ERR_HIP 3      /* a HIP runtime call or kernel launch failed            */
+
+#define JCM_PRECISION_F32 0   /* fp32 MFMA (v_mfma_f32_32x32x2_f32): the parity path */
+#define JCM_PRECISION_BF16 1  /* bf16 operands, fp32 accumulate: the roofline path   */
+
+/* -- lifecycle --------------------------------------------------------------------------
+ * Replaces tf.Session(config, graph) / sess.close (main.py:606-608,677-680). `stream` is a
+ * hipStream_t (NULL = the device's default stream). */
+int jcm_create(int device, void* stream, jcm_handle* out);
+int jcm_destroy(jcm_handle h);
+const char* jcm_last_error(void);
+int jcm_abi_version(void);
+
+/* -- options ------------------------------------------------------------------------------
+ * "precision": JCM_PRECISION_*  (the reference is fp32 throughout)
+ * "n_joints" : K, default 9      (main.py:458)
+ * Must be set before jcm_finalize. */
+int jcm_set_option(jcm_handle h, const char* key, int64_t value);
+
+/* -- parameters -----------------------------------------------------------------------------
+ * Replaces tf.get_variable + Saver.restore (main.py:147,153,484,487,612).  `name` is the
+ * reference's TF variable name:
+ *   "<scope>/weights" [k,k,Cin,Cout] HWIO      "<scope>/biases" [Cout]
+ *   "<scope>/BatchNorm/{gamma,beta,moving_mean,moving_variance}" [Cout]
+ *     scopes conv{1..4}_{fullres,halfres,quarterres}, conv5, conv6 (main.py:44-72), bn_sm (:112)
+ *   "energy_<j>_<c>" [1,120,180,1]   "bias_<j>_<c>" [1,60,90,1]    (main.py:484,487)
+ * `data` may be a host or a device pointer (fp32); the library copies it. */
+int jcm_set_tensor(jcm_handle h, const char* name, const float* data, const int64_t* shape, int ndim);
+/* Packs weights for the MFMA kernels, folds BatchNorm (inference mode, flag_train=False,
+ * main.py:406) into per-channel scale/shift, and precomputes softplus(energy),
+ * softplus(bias) (main.py:120,122 are batch-independent).  Call after the last set_tensor. */
+int jcm_finalize(jcm_handle h);
+
+/* -- part detector ----------------------------------------------------------------------------
+ * conv_layer(x, size, stride, n_in, n_out, name, last_layer) (main.py:156-169):
+ * BN(relu(conv_SAME(x,w)+b)), or conv+b for the last layer.  x [B,H,W,Cin] -> out
+ * [B,ceil(H/s),ceil(W/s),Cout]; size and channel counts come from the stored "<scope>/weights".
+ * Kernels exist for the shapes the model uses: (size 5, stride 2, Cin 3) and (size 5|9,
+ * stride 1, Cin % 16 == 0); anything else returns JCM_ERR_ARG. */
+int jcm_conv_layer(jcm_handle h, const char* scope, int stride, int last_layer, const float* x, int B, int H, int W,
+                   float* out);
+/* max_pool_layer(x, 2, 2) (main.py:172-174): 2x2/2 SAME. [B,H,W,C] -> [B,ceil(H/2),ceil(W/2),C] */
+int jcm_max_pool(jcm_handle h, const float* x, int B, int H, int W, int C, float* out);
+/* tf.image.resize_images(x, [OH,OW]) (main.py:51,58,60,67,89): TF-1.x legacy bilinear. */
+int jcm_resize_bilinear(jcm_handle h, const float* x, int B, int H, int W, int C, int OH, int OW, float* out);
+/* model(x, n_joints) (main.py:29-74): x [B,H,W,3] -> logits [B,H/8,W/8,K]. */
+int jcm_pd_forward(jcm_handle h, const float* x, int B, int H, int W, float* logits_out);
+
+/* -- heat-map ops ------------------------------------------------------------------------------
+ * spatial_softmax(hm) (main.py:212-217): softmax over the HW pixels of every (b,k) map. */
+int jcm_spatial_softmax(jcm_handle h, const float* in, int B, int HW, int K, float* out);
+/* conv_mrf(A, B) (main.py:77-91): A [1,120,180,1] prior, Bmaps [B,60,90,1] -> out [B,60,90,1]. */
+int jcm_conv_mrf(jcm_handle h, const float* A, const float* Bmaps, int B, float* out);
+/* spatial_model(heat_map) (main.py:94-125): hm10 [B,60,90,K+1] -> logits [B,60,90,K]. */
+int jcm_sm_forward(jcm_handle h, const float* hm10, int B, float* logits_out);
+/* get_joints_coords / argmax_hm (evaluation.py:15-24, main.py:389-397): first-occurrence
+ * flat argmax per (b,k); coords[b,0,k] = row, coords[b,1,k] = col.  hm [B,HH,WW,K]. */
+int jcm_argmax_coords(jcm_handle h, const float* hm, int B, int HH, int WW, int K, int32_t* coords);
+
+/* -- the whole tower ----------------------------------------------------------------------------
+ * The graph of main.py:522-531: model -> spatial_softmax -> concat torso -> spatial_model ->
+ * spatial_softmax -> argmax.  x [B,H,W,3]; torso [B,60,90,1] = y_in[...,K:] (main.py:528),
+ * may be NULL when use_sm == 0.  Any output pointer may be NULL:
+ *   pd_prob, sm_prob [B,60,90,K] fp32;  pd_coords, sm_coords [B,2,K] int32. */
+int jcm_forward(jcm_handle h, const float* x, const float* torso, int B, int H, int W, int use_sm,
+                float* pd_prob, float* sm_prob, int32_t* pd_coords, int32_t* sm_coords);
+
+/* -- introspection (used by bench.py for the roofline object) ------------------------------------
+ * Bytes currently held by the workspace arena / packed parameters. */
+int64_t jcm_workspace_bytes(jcm_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JCM_H */

@@ -1,0 +1,69 @@
+"""ctypes binding of libjcm.so (include/jcm.h).  There is no fallback: if the HIP library
+is missing or a call fails, this raises -- the product path never routes around the kernels."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libjcm.so')
+
+JCM_PRECISION_F32 = 0
+JCM_PRECISION_BF16 = 1
+
+_c_float_p = ctypes.c_void_p      # device pointers travel as integers
+_c_i32_p = ctypes.c_void_p
+_handle = ctypes.c_void_p
+
+# name -> (restype, argtypes); exactly the declarations of include/jcm.h
+SIGNATURES = {
+    'jcm_create': (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(_handle)]),
+    'jcm_destroy': (ctypes.c_int, [_handle]),
+    'jcm_last_error': (ctypes.c_char_p, []),
+    'jcm_abi_version': (ctypes.c_int, []),
+    'jcm_set_option': (ctypes.c_int, [_handle, ctypes.c_char_p, ctypes.c_int64]),
+    'jcm_set_tensor': (ctypes.c_int, [_handle, ctypes.c_char_p, _c_float_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]),
+    'jcm_finalize': (ctypes.c_int, [_handle]),
+    'jcm_conv_layer': (ctypes.c_int, [_handle, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, _c_float_p,
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p]),
+    'jcm_max_pool': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p]),
+    'jcm_resize_bilinear': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, _c_float_p]),
+    'jcm_pd_forward': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p]),
+    'jcm_spatial_softmax': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p]),
+    'jcm_conv_mrf': (ctypes.c_int, [_handle, _c_float_p, _c_float_p, ctypes.c_int, _c_float_p]),
+    'jcm_sm_forward': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, _c_float_p]),
+    'jcm_argmax_coords': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i32_p]),
+    'jcm_forward': (ctypes.c_int, [_handle, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   _c_float_p, _c_float_p, _c_i32_p, _c_i32_p]),
+    'jcm_workspace_bytes': (ctypes.c_int64, [_handle]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libjcm.so (once) and attach the jcm.h prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'libjcm.so is not built (%s). Run `python -c "import __graft_entry__ as g; g.build()"` or '
+            '`make -C joint-cnn-mrf_amd/csrc`; there is no CPU fallback for this path.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here = header/library drift
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    msg = load().jcm_last_error()
+    return msg.decode('utf-8', 'replace') if msg else ''
+
+
+def check(status, what):
+    """int status + thread-local message -> RuntimeError (SURVEY.md 8b 'Errors')."""
+    if status != 0:
+        raise RuntimeError('%s failed (status %d): %s' % (what, status, last_error()))

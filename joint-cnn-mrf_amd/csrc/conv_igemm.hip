@@ -1,0 +1,255 @@
+// Implicit-GEMM SAME convolution (stride 1, 5x5 / 9x9) for gfx950 on fp32-input MFMA.
+//
+// GEMM view: M = output pixels, N = Cout, K = k*k*Cin.  A workgroup owns a
+// TH x TW pixel patch (128 pixels) x BN output channels and walks K as
+//     for 16-channel chunk c:   stage the (TH+k-1) x (TW+k-1) input halo of chunk c in LDS once
+//       for tap stage s:        stage TPS taps of packed weights [unit][BN][4 ch] (double buffer)
+//         v_mfma_f32_32x32x2_f32 over the stage, A read from the halo at the tap's offset
+// so every input element is fetched from HBM/L2 once per chunk and reused by all k*k taps out
+// of LDS; only the weight slab streams.  v_mfma_f32_32x32x2_f32 is an exact-f32 FMA chain
+// (this is the parity path: no reduced-precision operand anywhere).
+//
+// LDS images are [16-byte unit][slot][4 floats]: a lane's ds_read_b128 delivers 4 consecutive
+// K values of its row/column, and lanes of one 16-lane read group hit 16 distinct 16-B slots
+// (halo rows are padded to a multiple of 16 slots), i.e. conflict-free ds_read_b128.
+// The K order inside a 32-channel... inside an 8-channel step is permuted (half-wave h takes
+// channels 4h..4h+3) identically for A and B, which MFMA permits because K is a contraction.
+#include "kernels.h"
+
+namespace jcm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int KS_, int TH_, int TW_, int BN_, int WM_, int WN_, int TPS_>
+struct Cfg {
+  static constexpr int KS = KS_, TH = TH_, TW = TW_, BN = BN_, WM = WM_, WN = WN_, TPS = TPS_;
+  static constexpr int U = 4;                       // 16-B units per chunk = 16 fp32 channels
+  static constexpr int PAD = (KS - 1) / 2;          // SAME, stride 1: symmetric
+  static constexpr int HH = TH + KS - 1;
+  static constexpr int WH = TW + KS - 1;
+  static constexpr int WHP = (WH + 15) / 16 * 16;   // halo row pitch in slots (bank-conflict-free reads)
+  static constexpr int PLANE = HH * WHP + 2;        // +2 slots: spreads the 4 unit planes over banks on the write side
+  static constexpr int BM = TH * TW;
+  static constexpr int MR = BM / WM / 32;
+  static constexpr int NR = BN / WN / 32;
+  static constexpr int HALO_F4 = U * PLANE;
+  static constexpr int WSTAGE_F4 = TPS * U * BN;
+  static constexpr int NSTAGE = KS * KS / TPS;
+  static constexpr int WREG = (WSTAGE_F4 + 255) / 256;
+  static constexpr int LDS_BYTES = (HALO_F4 + 2 * WSTAGE_F4) * 16;
+  static_assert(BM == 128 && WM * WN == 4, "4 waves per 128-pixel patch");
+  static_assert(KS * KS % TPS == 0, "stages must tile the taps");
+};
+
+template <class C>
+__global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs a, int tiles_x, int tiles_y, int mtiles, int nN) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* halo = reinterpret_cast<f32x4*>(smem);
+  f32x4* wbuf = halo + C::HALO_F4;
+
+  // ---- block -> (pixel tile, channel tile).  Blocks b and b+8 run on the same XCD; give an XCD
+  // a single channel tile so its private L2 streams only 1/nN of the packed weights.
+  const int L = blockIdx.x;
+  int mt, nt;
+  if ((8 % nN) == 0) {
+    const int xcd = L & 7, q = L >> 3, per = 8 / nN;
+    nt = xcd % nN;
+    mt = q * per + xcd / nN;
+  } else {
+    nt = L % nN;
+    mt = L / nN;
+  }
+  if (mt >= mtiles) return;
+  const int tx = mt % tiles_x;
+  const int ty = (mt / tiles_x) % tiles_y;
+  const int b = mt / (tiles_x * tiles_y);
+  const int y0 = ty * C::TH, x0 = tx * C::TW, n0 = nt * C::BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / C::WN, wn = wid % C::WN;
+  const int h = lane >> 5, l31 = lane & 31;
+
+  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, CoutP = a.CoutP;
+  const float* __restrict__ xb = static_cast<const float*>(a.x) + (size_t)b * H * W * Cin;
+  const float* __restrict__ wp = static_cast<const float*>(a.wp);
+
+  int aslot[C::MR], bcol[C::NR];
+#pragma unroll
+  for (int f = 0; f < C::MR; ++f) {
+    const int r = (wm * C::MR + f) * 32 + l31;
+    aslot[f] = (r / C::TW) * C::WHP + (r % C::TW);
+  }
+#pragma unroll
+  for (int g = 0; g < C::NR; ++g) bcol[g] = (wn * C::NR + g) * 32 + l31;
+
+  f32x16 acc[C::MR][C::NR];
+#pragma unroll
+  for (int f = 0; f < C::MR; ++f)
+#pragma unroll
+    for (int g = 0; g < C::NR; ++g)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[f][g][i] = 0.f;
+
+  const int cin4 = Cin >> 2;
+  f32x4 wreg[C::WREG];
+
+  auto wload = [&](int chunk, int s) {
+#pragma unroll
+    for (int i = 0; i < C::WREG; ++i) {
+      const int idx = tid + i * 256;
+      if ((C::WSTAGE_F4 % 256 == 0) || idx < C::WSTAGE_F4) {
+        const int co = idx % C::BN;
+        const int tu = idx / C::BN;
+        const int u = tu % C::U, tp = tu / C::U;
+        const int tap = s * C::TPS + tp;
+        wreg[i] = *reinterpret_cast<const f32x4*>(wp + (((size_t)tap * cin4 + chunk * C::U + u) * CoutP + n0 + co) * 4);
+      }
+    }
+  };
+  auto wstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < C::WREG; ++i) {
+      const int idx = tid + i * 256;
+      if ((C::WSTAGE_F4 % 256 == 0) || idx < C::WSTAGE_F4) wbuf[buf * C::WSTAGE_F4 + idx] = wreg[i];
+    }
+  };
+
+  const int nchunk = Cin >> 4;
+  int buf = 0;
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    __syncthreads();  // every wave is done reading the previous chunk's halo and weight buffers
+    // ---- input halo of this 16-channel chunk -> LDS (zero fill = SAME padding)
+    for (int idx = tid; idx < C::U * C::HH * C::WH; idx += 256) {
+      const int u = idx & (C::U - 1);
+      const int pix = idx >> 2;
+      const int hy = pix / C::WH, hx = pix - hy * C::WH;
+      const int gy = y0 - C::PAD + hy, gx = x0 - C::PAD + hx;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+        v = *reinterpret_cast<const f32x4*>(xb + ((size_t)gy * W + gx) * Cin + chunk * 16 + u * 4);
+      halo[u * C::PLANE + hy * C::WHP + hx] = v;
+    }
+    wload(chunk, 0);
+    for (int s = 0; s < C::NSTAGE; ++s) {
+      wstore(buf);
+      __syncthreads();
+      if (s + 1 < C::NSTAGE) wload(chunk, s + 1);  // in flight behind this stage's MFMAs
+      const f32x4* wb = wbuf + buf * C::WSTAGE_F4;
+      const int tap0 = s * C::TPS;
+#pragma unroll
+      for (int tp = 0; tp < C::TPS; ++tp) {
+        const int tap = tap0 + tp;
+        const int ky = tap / C::KS, kx = tap - ky * C::KS;
+        const int toff = ky * C::WHP + kx;
+#pragma unroll
+        for (int st = 0; st < C::U / 2; ++st) {
+          const int u = st * 2 + h;
+          f32x4 af[C::MR], bf[C::NR];
+#pragma unroll
+          for (int f = 0; f < C::MR; ++f) af[f] = halo[u * C::PLANE + aslot[f] + toff];
+#pragma unroll
+          for (int g = 0; g < C::NR; ++g) bf[g] = wb[(tp * C::U + u) * C::BN + bcol[g]];
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int f = 0; f < C::MR; ++f)
+#pragma unroll
+              for (int g = 0; g < C::NR; ++g)
+                acc[f][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[f][t], bf[g][t], acc[f][g], 0, 0, 0);
+        }
+      }
+      buf ^= 1;
+    }
+  }
+
+  // ---- epilogue: bias (+ ReLU + folded BatchNorm), NHWC store.  C/D layout of the 32x32 MFMA:
+  // col = lane&31 (channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel).
+  float* __restrict__ ob = static_cast<float*>(a.out) + (size_t)b * H * W * Cout;
+#pragma unroll
+  for (int g = 0; g < C::NR; ++g) {
+    const int co = n0 + bcol[g];
+    if (co >= Cout) continue;
+    const float bi = a.bias[co];
+    float sc = 1.f, sh = 0.f;
+    if (a.relu_bn) { sc = a.scale[co]; sh = a.shift[co]; }
+#pragma unroll
+    for (int f = 0; f < C::MR; ++f) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = (wm * C::MR + f) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int y = y0 + r / C::TW, x = x0 + r % C::TW;
+        if (y < H && x < W) {
+          float v = acc[f][g][i] + bi;
+          if (a.relu_bn) v = fmaxf(v, 0.f) * sc + sh;
+          ob[((size_t)y * W + x) * Cout + co] = v;
+        }
+      }
+    }
+  }
+}
+
+template <class C>
+static hipError_t launch(const ConvArgs& a, hipStream_t st) {
+  const int tiles_x = (a.W + C::TW - 1) / C::TW, tiles_y = (a.H + C::TH - 1) / C::TH;
+  const int mtiles = tiles_x * tiles_y * a.B;
+  const int nN = a.CoutP / C::BN;
+  int blocks;
+  if ((8 % nN) == 0) {
+    const int per = 8 / nN;
+    blocks = (mtiles + per - 1) / per * 8;
+  } else {
+    blocks = mtiles * nN;
+  }
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_f32_kernel<C>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(conv_igemm_f32_kernel<C>, dim3(blocks), dim3(256), C::LDS_BYTES, st, a, tiles_x, tiles_y, mtiles, nN);
+  return hipGetLastError();
+}
+
+int conv_igemm_bn(int Cout) { return Cout >= 128 ? 128 : (Cout > 32 ? 64 : 32); }
+
+// Patch shape: 4x32 tiles a 60x90 map with 6 % padding; 8x16 suits the smaller / odd maps.
+hipError_t conv_igemm_f32(const ConvArgs& a, int ks, hipStream_t st) {
+  const int bn = conv_igemm_bn(a.Cout);
+  const bool wide = (a.W >= 64) && (a.H % 4 == 0);
+  if (ks == 9) {
+    if (bn == 128) return wide ? launch<Cfg<9, 4, 32, 128, 2, 2, 1>>(a, st) : launch<Cfg<9, 8, 16, 128, 2, 2, 1>>(a, st);
+    if (bn == 64) return wide ? launch<Cfg<9, 4, 32, 64, 2, 2, 3>>(a, st) : launch<Cfg<9, 8, 16, 64, 2, 2, 3>>(a, st);
+    return wide ? launch<Cfg<9, 4, 32, 32, 4, 1, 9>>(a, st) : launch<Cfg<9, 8, 16, 32, 4, 1, 9>>(a, st);
+  }
+  if (ks == 5) {
+    if (bn == 128) return wide ? launch<Cfg<5, 4, 32, 128, 2, 2, 1>>(a, st) : launch<Cfg<5, 8, 16, 128, 2, 2, 1>>(a, st);
+    if (bn == 64) return wide ? launch<Cfg<5, 4, 32, 64, 2, 2, 5>>(a, st) : launch<Cfg<5, 8, 16, 64, 2, 2, 5>>(a, st);
+    return wide ? launch<Cfg<5, 4, 32, 32, 4, 1, 5>>(a, st) : launch<Cfg<5, 8, 16, 32, 4, 1, 5>>(a, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+// HWIO [k,k,Cin,Cout] -> [tap][Cin/4][CoutP][4], zero-padded channels.
+__global__ void pack_weights_f32_kernel(const float* __restrict__ w, float* __restrict__ wp, int taps, int Cin, int Cout, int CoutP) {
+  const size_t n = (size_t)taps * Cin * CoutP;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int k4 = i & 3;
+    size_t r = i >> 2;
+    const int co = r % CoutP; r /= CoutP;
+    const int c4 = r % (Cin >> 2);
+    const int tap = r / (Cin >> 2);
+    const int ci = c4 * 4 + k4;
+    wp[i] = co < Cout ? w[((size_t)tap * Cin + ci) * Cout + co] : 0.f;
+  }
+}
+
+hipError_t pack_weights_f32(const float* w_hwio, float* wp, int ks, int Cin, int Cout, int CoutP, hipStream_t st) {
+  hipLaunchKernelGGL(pack_weights_f32_kernel, dim3(2048), dim3(256), 0, st, w_hwio, wp, ks * ks, Cin, Cout, CoutP);
+  return hipGetLastError();
+}
+
+}  // namespace jcm

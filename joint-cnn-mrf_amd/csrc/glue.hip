@@ -1,0 +1,241 @@
+// HBM-bound glue of the part detector and the heat-map ops: 2x2/2 SAME max-pool
+// (main.py:172-174), TF-1.x legacy bilinear resize (main.py:51,58,60,67,89), the three-branch
+// merge (main.py:58,67,69-70), spatial softmax (main.py:212-217) and per-joint argmax
+// (evaluation.py:15-24, main.py:389-397).  All NHWC fp32, 16-byte accesses along channels.
+#include "kernels.h"
+
+namespace jcm {
+
+// ------------------------------------------------------------------------------ max pool
+// SAME with k=2,s=2: out = ceil(in/2); padding (0 before, in%2 after) never wins the max.
+__global__ void max_pool_kernel(const float4* __restrict__ x, float4* __restrict__ out, int H, int W, int C4,
+                                int Ho, int Wo, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % C4;
+    size_t r = i / C4;
+    const int ox = r % Wo; r /= Wo;
+    const int oy = r % Ho;
+    const size_t b = r / Ho;
+    const int iy = oy * 2, ix = ox * 2;
+    const float4* base = x + (b * H * W) * C4 + c;
+    float4 m = base[((size_t)iy * W + ix) * C4];
+    const bool hx = ix + 1 < W, hy = iy + 1 < H;
+    if (hx) { const float4 v = base[((size_t)iy * W + ix + 1) * C4]; m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w); }
+    if (hy) { const float4 v = base[((size_t)(iy + 1) * W + ix) * C4]; m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w); }
+    if (hx && hy) { const float4 v = base[((size_t)(iy + 1) * W + ix + 1) * C4]; m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w); }
+    out[i] = m;
+  }
+}
+
+static inline int grid_for(size_t total, int block = 256) {
+  size_t g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+hipError_t max_pool_2x2(const float* x, float* out, int B, int H, int W, int C, hipStream_t st) {
+  if (C % 4) return hipErrorInvalidValue;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const size_t total = (size_t)B * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(max_pool_kernel, dim3(grid_for(total)), dim3(256), 0, st, reinterpret_cast<const float4*>(x),
+                     reinterpret_cast<float4*>(out), H, W, C / 4, Ho, Wo, total);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ bilinear
+// TF-1.x ResizeBilinear, align_corners=False: scale = in/float(out); src = i*scale (float32);
+// lo = floor(src); hi = min(lo+1, in-1); lerp = src-lo.  Lerp along x, then along y.
+struct Tap { int lo, hi; float t; };
+__device__ __forceinline__ Tap tf1_tap(int i, int in_size, float scale) {
+  const float src = (float)i * scale;
+  Tap r;
+  r.lo = (int)floorf(src);
+  r.hi = min(r.lo + 1, in_size - 1);
+  r.t = src - (float)r.lo;
+  return r;
+}
+__device__ __forceinline__ float lerp2(float tl, float tr, float bl, float br, float tx, float ty) {
+  const float top = tl + (tr - tl) * tx;
+  const float bot = bl + (br - bl) * tx;
+  return top + (bot - top) * ty;
+}
+__device__ __forceinline__ float4 bilinear4(const float4* base, int W, int C4, Tap ty, Tap tx) {
+  const float4 tl = base[((size_t)ty.lo * W + tx.lo) * C4], tr = base[((size_t)ty.lo * W + tx.hi) * C4];
+  const float4 bl = base[((size_t)ty.hi * W + tx.lo) * C4], br = base[((size_t)ty.hi * W + tx.hi) * C4];
+  float4 o;
+  o.x = lerp2(tl.x, tr.x, bl.x, br.x, tx.t, ty.t);
+  o.y = lerp2(tl.y, tr.y, bl.y, br.y, tx.t, ty.t);
+  o.z = lerp2(tl.z, tr.z, bl.z, br.z, tx.t, ty.t);
+  o.w = lerp2(tl.w, tr.w, bl.w, br.w, tx.t, ty.t);
+  return o;
+}
+
+__global__ void resize_kernel_c4(const float4* __restrict__ x, float4* __restrict__ out, int H, int W, int C4, int OH,
+                                 int OW, float sy, float sx, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % C4;
+    size_t r = i / C4;
+    const int ox = r % OW; r /= OW;
+    const int oy = r % OH;
+    const size_t b = r / OH;
+    out[i] = bilinear4(x + b * H * W * C4 + c, W, C4, tf1_tap(oy, H, sy), tf1_tap(ox, W, sx));
+  }
+}
+__global__ void resize_kernel_c1(const float* __restrict__ x, float* __restrict__ out, int H, int W, int C, int OH,
+                                 int OW, float sy, float sx, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    size_t r = i / C;
+    const int ox = r % OW; r /= OW;
+    const int oy = r % OH;
+    const size_t b = r / OH;
+    const Tap ty = tf1_tap(oy, H, sy), tx = tf1_tap(ox, W, sx);
+    const float* base = x + b * H * W * C + c;
+    out[i] = lerp2(base[((size_t)ty.lo * W + tx.lo) * C], base[((size_t)ty.lo * W + tx.hi) * C],
+                   base[((size_t)ty.hi * W + tx.lo) * C], base[((size_t)ty.hi * W + tx.hi) * C], tx.t, ty.t);
+  }
+}
+
+hipError_t resize_bilinear(const float* x, float* out, int B, int H, int W, int C, int OH, int OW, hipStream_t st) {
+  if (H == OH && W == OW)   // tf.image.resize_images returns the input unchanged
+    return hipMemcpyAsync(out, x, (size_t)B * H * W * C * sizeof(float), hipMemcpyDeviceToDevice, st);
+  const float sy = (float)H / (float)OH, sx = (float)W / (float)OW;
+  if (C % 4 == 0) {
+    const size_t total = (size_t)B * OH * OW * (C / 4);
+    hipLaunchKernelGGL(resize_kernel_c4, dim3(grid_for(total)), dim3(256), 0, st, reinterpret_cast<const float4*>(x),
+                       reinterpret_cast<float4*>(out), H, W, C / 4, OH, OW, sy, sx, total);
+  } else {
+    const size_t total = (size_t)B * OH * OW * C;
+    hipLaunchKernelGGL(resize_kernel_c1, dim3(grid_for(total)), dim3(256), 0, st, x, out, H, W, C, OH, OW, sy, sx, total);
+  }
+  return hipGetLastError();
+}
+
+// x = (x1 + up(x2) + up(x3)) / 3 in the reference's association order ((x1+x2)+x3), then /3.
+__global__ void upsample_merge3_kernel(const float4* __restrict__ x1, const float4* __restrict__ x2, int H2, int W2,
+                                       const float4* __restrict__ x3, int H3, int W3, float4* __restrict__ out, int H,
+                                       int W, int C4, float sy2, float sx2, float sy3, float sx3, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % C4;
+    size_t r = i / C4;
+    const int ox = r % W; r /= W;
+    const int oy = r % H;
+    const size_t b = r / H;
+    const float4 a = x1[i];
+    const float4 u2 = (H2 == H && W2 == W) ? x2[i]
+                                           : bilinear4(x2 + b * H2 * W2 * C4 + c, W2, C4, tf1_tap(oy, H2, sy2), tf1_tap(ox, W2, sx2));
+    const float4 u3 = (H3 == H && W3 == W) ? x3[i]
+                                           : bilinear4(x3 + b * H3 * W3 * C4 + c, W3, C4, tf1_tap(oy, H3, sy3), tf1_tap(ox, W3, sx3));
+    float4 o;
+    o.x = ((a.x + u2.x) + u3.x) / 3.0f;
+    o.y = ((a.y + u2.y) + u3.y) / 3.0f;
+    o.z = ((a.z + u2.z) + u3.z) / 3.0f;
+    o.w = ((a.w + u2.w) + u3.w) / 3.0f;
+    out[i] = o;
+  }
+}
+
+hipError_t upsample_merge3(const float* x1, const float* x2, int H2, int W2, const float* x3, int H3, int W3,
+                           float* out, int B, int H, int W, int C, hipStream_t st) {
+  if (C % 4) return hipErrorInvalidValue;
+  const size_t total = (size_t)B * H * W * (C / 4);
+  hipLaunchKernelGGL(upsample_merge3_kernel, dim3(grid_for(total)), dim3(256), 0, st,
+                     reinterpret_cast<const float4*>(x1), reinterpret_cast<const float4*>(x2), H2, W2,
+                     reinterpret_cast<const float4*>(x3), H3, W3, reinterpret_cast<float4*>(out), H, W, C / 4,
+                     (float)H2 / (float)H, (float)W2 / (float)W, (float)H3 / (float)H, (float)W3 / (float)W, total);
+  return hipGetLastError();
+}
+
+// tf.concat([a, b], axis=3) on [N,Ca] / [N,Cb] rows (main.py:528: append the torso channel).
+__global__ void concat_channels_kernel(const float* __restrict__ a, int Ca, const float* __restrict__ b, int Cb,
+                                       float* __restrict__ out, size_t total) {
+  const int C = Ca + Cb;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    const size_t n = i / C;
+    out[i] = c < Ca ? a[n * Ca + c] : b[n * Cb + (c - Ca)];
+  }
+}
+hipError_t concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, size_t N, hipStream_t st) {
+  const size_t total = N * (Ca + Cb);
+  hipLaunchKernelGGL(concat_channels_kernel, dim3(grid_for(total)), dim3(256), 0, st, a, Ca, b, Cb, out, total);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ softmax / argmax
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// One workgroup per (b,k) map: max, sum of exp(z-max), normalise -- tf.nn.softmax(dim=1) on
+// the [B, HW, K] view.
+__global__ __launch_bounds__(256) void spatial_softmax_kernel(const float* __restrict__ in, float* __restrict__ out, int HW, int K) {
+  __shared__ float red[4];
+  const int b = blockIdx.x / K, k = blockIdx.x % K;
+  const float* src = in + (size_t)b * HW * K + k;
+  float* dst = out + (size_t)b * HW * K + k;
+  const int tid = threadIdx.x;
+  float m = -INFINITY;
+  for (int p = tid; p < HW; p += 256) m = fmaxf(m, src[(size_t)p * K]);
+  m = wave_max(m);
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int p = tid; p < HW; p += 256) s += expf(src[(size_t)p * K] - m);
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  s = (red[0] + red[1]) + (red[2] + red[3]);
+  for (int p = tid; p < HW; p += 256) dst[(size_t)p * K] = expf(src[(size_t)p * K] - m) / s;
+}
+
+hipError_t spatial_softmax(const float* in, float* out, int B, int HW, int K, hipStream_t st) {
+  hipLaunchKernelGGL(spatial_softmax_kernel, dim3(B * K), dim3(256), 0, st, in, out, HW, K);
+  return hipGetLastError();
+}
+
+// First-occurrence argmax (np.argmax / tf.argmax): larger value wins, ties go to the lower index.
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ hm, int32_t* __restrict__ coords, int HW, int WW, int K) {
+  __shared__ float rv[4];
+  __shared__ int ri[4];
+  const int b = blockIdx.x / K, k = blockIdx.x % K;
+  const float* src = hm + (size_t)b * HW * K + k;
+  const int tid = threadIdx.x;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int p = tid; p < HW; p += 256) {
+    const float v = src[(size_t)p * K];
+    if (v > bv || (v == bv && p < bi)) { bv = v; bi = p; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if ((tid & 63) == 0) { rv[tid >> 6] = bv; ri[tid >> 6] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
+    if (bi == 0x7fffffff) bi = 0;   // all -inf / NaN map: np.argmax returns 0
+    const int row = bi / WW;
+    coords[((size_t)b * 2 + 0) * K + k] = row;
+    coords[((size_t)b * 2 + 1) * K + k] = bi - row * WW;
+  }
+}
+
+hipError_t argmax_coords(const float* hm, int32_t* coords, int B, int HW, int WW, int K, hipStream_t st) {
+  hipLaunchKernelGGL(argmax_kernel, dim3(B * K), dim3(256), 0, st, hm, coords, HW, WW, K);
+  return hipGetLastError();
+}
+
+}  // namespace jcm

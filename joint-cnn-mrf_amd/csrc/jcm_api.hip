@@ -1,0 +1,526 @@
+// libjcm C ABI (include/jcm.h): context, parameter store, weight packing, workspace arena and
+// the forward graph of main.py:29-74,94-125,522-531 as a sequence of kernel launches on one
+// HIP stream.  No tensor library types cross this boundary -- plain pointers and sizes.
+#include "../../include/jcm.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace jcm;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess)                                                                               \
+      return fail(JCM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+  } while (0)
+#define JCM_TRY(expr)          \
+  do {                         \
+    int r_ = (expr);           \
+    if (r_ != JCM_OK) return r_; \
+  } while (0)
+
+// main.py:18 -- channel order of the heat maps and of the pair tables.
+const char* const kJointNames[10] = {"lsho", "lelb", "lwri", "rsho", "relb", "rwri", "lhip", "rhip", "nose", "torso"};
+constexpr int kC = 10;            // heat-map channels seen by the spatial model (9 joints + torso)
+constexpr float kBnEps = 1e-3f;   // tf.contrib.layers.batch_norm default epsilon
+constexpr int kHmH = 60, kHmW = 90, kHmHW = kHmH * kHmW;
+constexpr int kPrH = 120, kPrW = 180;
+constexpr int kCH = 61, kCW = 91;
+
+struct Tensor {
+  std::vector<int64_t> shape;
+  float* d = nullptr;
+  size_t n = 0;
+};
+
+struct ConvLayer {
+  int ks = 0, cin = 0, cout = 0, coutp = 0;
+  bool has_bn = false;
+  const float* w_raw = nullptr;   // HWIO (conv1 kernel reads it directly)
+  float* wp = nullptr;            // packed for conv_igemm
+  const float* bias = nullptr;
+  float* scale = nullptr;
+  float* shift = nullptr;
+};
+
+}  // namespace
+
+struct jcm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int precision = JCM_PRECISION_F32;
+  int K = 9;
+  bool finalized = false;
+  std::map<std::string, Tensor> params;
+  std::map<std::string, ConvLayer> convs;
+  std::vector<void*> owned;   // device allocations made at finalize
+  // spatial model tables
+  bool has_sm = false;
+  float* sp_energy = nullptr;   // [P][120*180]
+  float* sp_bias = nullptr;     // [P][5400]
+  float* bn_sm_scale = nullptr; // [10]
+  float* bn_sm_shift = nullptr;
+  int* cond = nullptr;          // [P] conditioning channel of pair p
+  int* cond0 = nullptr;         // single zero (jcm_conv_mrf)
+  // workspace arena (stack allocator, grown on demand between forwards)
+  char* arena = nullptr;
+  size_t arena_cap = 0, arena_off = 0, arena_peak = 0;
+  bool dry = false;             // sizing pass: allocate offsets only, launch nothing
+  size_t param_bytes = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    (void)hipGetDevice(&prev);
+    if (prev != dev) (void)hipSetDevice(dev);
+    else prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+template <class T>
+T* arena_alloc(jcm_ctx* c, size_t count) {
+  const size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
+  const size_t off = c->arena_off;
+  c->arena_off += bytes;
+  if (c->arena_off > c->arena_peak) c->arena_peak = c->arena_off;
+  return reinterpret_cast<T*>(c->arena + off);   // in a dry pass arena may be null: offsets only
+}
+
+int arena_reserve(jcm_ctx* c, size_t bytes) {
+  if (bytes <= c->arena_cap) return JCM_OK;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->arena) HIP_TRY(hipFree(c->arena));
+  c->arena = nullptr;
+  c->arena_cap = 0;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->arena), bytes));
+  c->arena_cap = bytes;
+  return JCM_OK;
+}
+
+int dev_alloc(jcm_ctx* c, void** p, size_t bytes) {
+  HIP_TRY(hipMalloc(p, bytes));
+  c->owned.push_back(*p);
+  c->param_bytes += bytes;
+  return JCM_OK;
+}
+
+const Tensor* find(jcm_ctx* c, const std::string& name) {
+  auto it = c->params.find(name);
+  return it == c->params.end() ? nullptr : &it->second;
+}
+
+int fetch_host(jcm_ctx* c, const std::string& name, size_t n, std::vector<float>& out) {
+  const Tensor* t = find(c, name);
+  if (!t) return fail(JCM_ERR_STATE, "missing parameter '" + name + "'");
+  if (t->n != n) return fail(JCM_ERR_STATE, "parameter '" + name + "' has " + std::to_string(t->n) + " elements, expected " + std::to_string(n));
+  out.resize(n);
+  HIP_TRY(hipMemcpyAsync(out.data(), t->d, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return JCM_OK;
+}
+
+// Inference BatchNorm folded to y = x*scale + shift:  scale = gamma*rsqrt(var+eps), shift = beta-mean*scale.
+int fold_bn(jcm_ctx* c, const std::string& scope, int n, float** scale, float** shift) {
+  std::vector<float> g, b, m, v;
+  JCM_TRY(fetch_host(c, scope + "/BatchNorm/gamma", n, g));
+  JCM_TRY(fetch_host(c, scope + "/BatchNorm/beta", n, b));
+  JCM_TRY(fetch_host(c, scope + "/BatchNorm/moving_mean", n, m));
+  JCM_TRY(fetch_host(c, scope + "/BatchNorm/moving_variance", n, v));
+  std::vector<float> sc(n), sh(n);
+  for (int i = 0; i < n; ++i) {
+    sc[i] = g[i] * (1.0f / std::sqrt(v[i] + kBnEps));
+    sh[i] = b[i] - m[i] * sc[i];
+  }
+  JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(scale), n * sizeof(float)));
+  JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(shift), n * sizeof(float)));
+  HIP_TRY(hipMemcpyAsync(*scale, sc.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(*shift, sh.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));   // sc/sh are stack-local
+  return JCM_OK;
+}
+
+int check(jcm_handle h, bool need_final) {
+  if (!h) return fail(JCM_ERR_ARG, "null handle");
+  if (need_final && !h->finalized) return fail(JCM_ERR_STATE, "jcm_finalize has not been called");
+  return JCM_OK;
+}
+
+const ConvLayer* conv_of(jcm_ctx* c, const std::string& scope) {
+  auto it = c->convs.find(scope);
+  return it == c->convs.end() ? nullptr : &it->second;
+}
+
+int run_conv(jcm_ctx* c, const std::string& scope, int stride, const float* x, int B, int H, int W, int sub, float* out) {
+  const ConvLayer* L = conv_of(c, scope);
+  if (!L) return fail(JCM_ERR_STATE, "no conv layer '" + scope + "' (set '" + scope + "/weights' and finalize)");
+  if (c->dry) return JCM_OK;
+  if (stride == 2) {
+    if (!(L->ks == 5 && L->cin == 3 && L->has_bn))
+      return fail(JCM_ERR_ARG, "stride-2 kernel exists for 5x5, Cin=3, BN layers only (" + scope + ")");
+    HIP_TRY(conv1_5x5s2(x, L->w_raw, L->bias, L->scale, L->shift, out, B, H, W, sub, L->cout, c->stream));
+    return JCM_OK;
+  }
+  if (stride != 1 || !L->wp) return fail(JCM_ERR_ARG, "no kernel for layer '" + scope + "' with stride " + std::to_string(stride));
+  ConvArgs a;
+  a.x = x; a.wp = L->wp; a.bias = L->bias; a.scale = L->scale; a.shift = L->shift; a.out = out;
+  a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout; a.CoutP = L->coutp; a.relu_bn = L->has_bn ? 1 : 0;
+  HIP_TRY(conv_igemm_f32(a, L->ks, c->stream));
+  return JCM_OK;
+}
+
+inline int cdiv2(int v) { return (v + 1) / 2; }
+
+// model(x, n_joints), main.py:29-74.
+int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logits) {
+  static const char* const kRes[3] = {"fullres", "halfres", "quarterres"};
+  const ConvLayer* L4 = conv_of(c, "conv4_fullres");
+  const ConvLayer* L5 = conv_of(c, "conv5");
+  if (!L4 || !L5 || !conv_of(c, "conv6")) return fail(JCM_ERR_STATE, "part-detector parameters incomplete");
+  float* x4[3];
+  int h4[3], w4[3];
+  // branch outputs survive the per-branch scratch, so carve them first
+  for (int r = 0; r < 3; ++r) {
+    const int sub = 1 << r;
+    const int hin = H / sub, win = W / sub;                      // resize_images(x, [H//2, W//2]) main.py:51,60
+    h4[r] = cdiv2(cdiv2(cdiv2(hin)));
+    w4[r] = cdiv2(cdiv2(cdiv2(win)));
+    x4[r] = arena_alloc<float>(c, (size_t)B * h4[r] * w4[r] * L4->cout);
+  }
+  for (int r = 0; r < 3; ++r) {
+    const size_t mark = c->arena_off;
+    const std::string res = kRes[r];
+    const int sub = 1 << r;
+    const int hin = H / sub, win = W / sub;
+    const ConvLayer* L1 = conv_of(c, "conv1_" + res);
+    const ConvLayer* L2 = conv_of(c, "conv2_" + res);
+    const ConvLayer* L3 = conv_of(c, "conv3_" + res);
+    if (!L1 || !L2 || !L3) return fail(JCM_ERR_STATE, "part-detector parameters incomplete (" + res + ")");
+    const float* xin = x;
+    int xh = H, xw = W, xsub = sub;
+    if (H % sub || W % sub) {   // non-integer scale: a real bilinear resize, not sub-sampling
+      float* xr = arena_alloc<float>(c, (size_t)B * hin * win * 3);
+      if (!c->dry) HIP_TRY(resize_bilinear(x, xr, B, H, W, 3, hin, win, c->stream));
+      xin = xr; xh = hin; xw = win; xsub = 1;
+    }
+    const int h1 = cdiv2(hin), w1 = cdiv2(win);
+    float* c1 = arena_alloc<float>(c, (size_t)B * h1 * w1 * L1->cout);
+    JCM_TRY(run_conv(c, "conv1_" + res, 2, xin, B, xh, xw, xsub, c1));                  // main.py:44,52,61
+    const int h2 = cdiv2(h1), w2 = cdiv2(w1);
+    float* p1 = arena_alloc<float>(c, (size_t)B * h2 * w2 * L1->cout);
+    if (!c->dry) HIP_TRY(max_pool_2x2(c1, p1, B, h1, w1, L1->cout, c->stream));            // :45,53,62
+    float* c2 = arena_alloc<float>(c, (size_t)B * h2 * w2 * L2->cout);
+    JCM_TRY(run_conv(c, "conv2_" + res, 1, p1, B, h2, w2, 1, c2));                       // :46,54,63
+    const int h3 = cdiv2(h2), w3 = cdiv2(w2);
+    float* p2 = arena_alloc<float>(c, (size_t)B * h3 * w3 * L2->cout);
+    if (!c->dry) HIP_TRY(max_pool_2x2(c2, p2, B, h2, w2, L2->cout, c->stream));            // :47,55,64
+    float* c3 = arena_alloc<float>(c, (size_t)B * h3 * w3 * L3->cout);
+    JCM_TRY(run_conv(c, "conv3_" + res, 1, p2, B, h3, w3, 1, c3));                       // :48,56,65
+    JCM_TRY(run_conv(c, "conv4_" + res, 1, c3, B, h3, w3, 1, x4[r]));                    // :49,57,66
+    c->arena_off = mark;
+  }
+  const int hh = h4[0], ww = w4[0];
+  float* merged = arena_alloc<float>(c, (size_t)B * hh * ww * L4->cout);
+  if (!c->dry)
+    HIP_TRY(upsample_merge3(x4[0], x4[1], h4[1], w4[1], x4[2], h4[2], w4[2], merged, B, hh, ww, L4->cout, c->stream));  // :58,67,69-70
+  float* c5 = arena_alloc<float>(c, (size_t)B * hh * ww * L5->cout);
+  JCM_TRY(run_conv(c, "conv5", 1, merged, B, hh, ww, 1, c5));                            // :71
+  JCM_TRY(run_conv(c, "conv6", 1, c5, B, hh, ww, 1, logits));                            // :72
+  return JCM_OK;
+}
+
+// spatial_model(heat_map), main.py:94-125.
+int sm_forward_impl(jcm_ctx* c, const float* hm10, int B, float* logits) {
+  if (!c->has_sm) return fail(JCM_ERR_STATE, "spatial-model parameters (bn_sm, energy_*, bias_*) were not set");
+  const int P = c->K * (kC - 1);
+  float* lik = arena_alloc<float>(c, (size_t)B * kC * kHmH * 96);
+  float* cpre = arena_alloc<float>(c, (size_t)B * P * kCH * kCW);
+  if (c->dry) return JCM_OK;
+  HIP_TRY(sm_likelihood(hm10, c->bn_sm_scale, c->bn_sm_shift, lik, B, kC, c->stream));
+  HIP_TRY(sm_pair_conv(c->sp_energy, lik, c->cond, cpre, B, P, kC, c->stream));
+  HIP_TRY(sm_finish(lik, cpre, c->sp_bias, logits, B, c->K, kC, c->stream));
+  return JCM_OK;
+}
+
+// Sizing pass then the real pass, so the arena never reallocates mid-graph.
+template <class F>
+int with_arena(jcm_ctx* c, F&& body) {
+  c->dry = true;
+  c->arena_off = 0;
+  c->arena_peak = 0;
+  int r = body();
+  c->dry = false;
+  if (r != JCM_OK) return r;
+  JCM_TRY(arena_reserve(c, c->arena_peak));
+  c->arena_off = 0;
+  return body();
+}
+
+}  // namespace
+
+extern "C" {
+
+int jcm_abi_version(void) { return 1; }
+
+const char* jcm_last_error(void) { return g_err.c_str(); }
+
+int jcm_create(int device, void* stream, jcm_handle* out) {
+  if (!out) return fail(JCM_ERR_ARG, "null out pointer");
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) return fail(JCM_ERR_ARG, "device " + std::to_string(device) + " out of range (" + std::to_string(n) + " visible)");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(JCM_ERR_HIP, std::string("libjcm is built for gfx950 (MI355X) only; device reports ") + prop.gcnArchName);
+  jcm_ctx* c = new jcm_ctx();
+  c->device = device;
+  c->stream = static_cast<hipStream_t>(stream);
+  *out = c;
+  return JCM_OK;
+}
+
+int jcm_destroy(jcm_handle h) {
+  if (!h) return JCM_OK;
+  DeviceGuard g(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  for (auto& kv : h->params) (void)hipFree(kv.second.d);
+  for (void* p : h->owned) (void)hipFree(p);
+  if (h->arena) (void)hipFree(h->arena);
+  delete h;
+  return JCM_OK;
+}
+
+int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
+  JCM_TRY(check(h, false));
+  if (h->finalized) return fail(JCM_ERR_STATE, "options must be set before jcm_finalize");
+  const std::string k = key ? key : "";
+  if (k == "precision") {
+    if (value != JCM_PRECISION_F32 && value != JCM_PRECISION_BF16) return fail(JCM_ERR_ARG, "precision must be 0 (f32) or 1 (bf16)");
+    if (value == JCM_PRECISION_BF16) return fail(JCM_ERR_ARG, "bf16 kernels are not built into this library version");
+    h->precision = (int)value;
+  } else if (k == "n_joints") {
+    if (value < 1 || value > 9) return fail(JCM_ERR_ARG, "n_joints must be in [1,9]");
+    h->K = (int)value;
+  } else {
+    return fail(JCM_ERR_ARG, "unknown option '" + k + "'");
+  }
+  return JCM_OK;
+}
+
+int jcm_set_tensor(jcm_handle h, const char* name, const float* data, const int64_t* shape, int ndim) {
+  JCM_TRY(check(h, false));
+  if (h->finalized) return fail(JCM_ERR_STATE, "parameters must be set before jcm_finalize");
+  if (!name || !data || !shape || ndim < 1 || ndim > 4) return fail(JCM_ERR_ARG, "bad set_tensor arguments");
+  DeviceGuard g(h->device);
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    if (shape[i] <= 0) return fail(JCM_ERR_ARG, std::string("non-positive dimension in '") + name + "'");
+    n *= (size_t)shape[i];
+  }
+  Tensor& t = h->params[name];
+  if (t.d) { (void)hipFree(t.d); h->param_bytes -= t.n * sizeof(float); }
+  t.shape.assign(shape, shape + ndim);
+  t.n = n;
+  t.d = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t.d), n * sizeof(float)));
+  h->param_bytes += n * sizeof(float);
+  HIP_TRY(hipMemcpyAsync(t.d, data, n * sizeof(float), hipMemcpyDefault, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));   // the caller may free `data` on return
+  return JCM_OK;
+}
+
+int jcm_finalize(jcm_handle h) {
+  JCM_TRY(check(h, false));
+  if (h->finalized) return fail(JCM_ERR_STATE, "already finalized");
+  DeviceGuard g(h->device);
+  jcm_ctx* c = h;
+  // ---- conv layers: every "<scope>/weights" of rank 4
+  for (auto& kv : c->params) {
+    const std::string& name = kv.first;
+    const std::string suffix = "/weights";
+    if (name.size() <= suffix.size() || name.compare(name.size() - suffix.size(), suffix.size(), suffix) != 0) continue;
+    const Tensor& w = kv.second;
+    if (w.shape.size() != 4 || w.shape[0] != w.shape[1]) return fail(JCM_ERR_ARG, "'" + name + "' must be [k,k,Cin,Cout]");
+    const std::string scope = name.substr(0, name.size() - suffix.size());
+    ConvLayer L;
+    L.ks = (int)w.shape[0]; L.cin = (int)w.shape[2]; L.cout = (int)w.shape[3];
+    L.w_raw = w.d;
+    const Tensor* b = find(c, scope + "/biases");
+    if (!b || b->n != (size_t)L.cout) return fail(JCM_ERR_STATE, "missing or mis-sized '" + scope + "/biases'");
+    L.bias = b->d;
+    L.has_bn = find(c, scope + "/BatchNorm/gamma") != nullptr;
+    if (L.has_bn) JCM_TRY(fold_bn(c, scope, L.cout, &L.scale, &L.shift));
+    if ((L.ks == 5 || L.ks == 9) && L.cin % 16 == 0) {
+      const int bn = conv_igemm_bn(L.cout);
+      L.coutp = (L.cout + bn - 1) / bn * bn;
+      const size_t n = (size_t)L.ks * L.ks * L.cin * L.coutp;
+      JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&L.wp), n * sizeof(float)));
+      HIP_TRY(pack_weights_f32(w.d, L.wp, L.ks, L.cin, L.cout, L.coutp, c->stream));
+    }
+    c->convs[scope] = L;
+  }
+  // ---- spatial model tables (main.py:477-487): pairs in graph order
+  if (find(c, "bn_sm/BatchNorm/gamma")) {
+    const int P = c->K * (kC - 1);
+    JCM_TRY(fold_bn(c, "bn_sm", kC, &c->bn_sm_scale, &c->bn_sm_shift));
+    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->sp_energy), (size_t)P * kPrH * kPrW * sizeof(float)));
+    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->sp_bias), (size_t)P * kHmHW * sizeof(float)));
+    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->cond), (size_t)P * sizeof(int)));
+    std::vector<int> cond(P);
+    int p = 0;
+    for (int j = 0; j < c->K; ++j) {
+      for (int cc = 0; cc < kC; ++cc) {
+        if (cc == j) continue;
+        const std::string key = std::string(kJointNames[j]) + "_" + kJointNames[cc];
+        const Tensor* e = find(c, "energy_" + key);
+        const Tensor* bi = find(c, "bias_" + key);
+        if (!e || e->n != (size_t)kPrH * kPrW) return fail(JCM_ERR_STATE, "missing or mis-sized 'energy_" + key + "' (want [1,120,180,1])");
+        if (!bi || bi->n != (size_t)kHmHW) return fail(JCM_ERR_STATE, "missing or mis-sized 'bias_" + key + "' (want [1,60,90,1])");
+        HIP_TRY(sm_softplus5(e->d, c->sp_energy + (size_t)p * kPrH * kPrW, (int64_t)kPrH * kPrW, c->stream));   // main.py:120
+        HIP_TRY(sm_softplus5(bi->d, c->sp_bias + (size_t)p * kHmHW, kHmHW, c->stream));                          // main.py:122
+        cond[p++] = cc;
+      }
+    }
+    HIP_TRY(hipMemcpyAsync(c->cond, cond.data(), P * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->has_sm = true;
+  }
+  JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->cond0), sizeof(int)));
+  HIP_TRY(hipMemsetAsync(c->cond0, 0, sizeof(int), c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->finalized = true;
+  return JCM_OK;
+}
+
+int jcm_conv_layer(jcm_handle h, const char* scope, int stride, int last_layer, const float* x, int B, int H, int W, float* out) {
+  JCM_TRY(check(h, true));
+  if (!scope || !x || !out || B < 1 || H < 1 || W < 1) return fail(JCM_ERR_ARG, "bad conv_layer arguments");
+  DeviceGuard g(h->device);
+  const ConvLayer* L = conv_of(h, scope);
+  if (!L) return fail(JCM_ERR_STATE, std::string("no conv layer '") + scope + "'");
+  if ((last_layer != 0) == L->has_bn)
+    return fail(JCM_ERR_ARG, std::string("last_layer flag disagrees with the BatchNorm parameters stored for '") + scope + "'");
+  return run_conv(h, scope, stride, x, B, H, W, 1, out);
+}
+
+int jcm_max_pool(jcm_handle h, const float* x, int B, int H, int W, int C, float* out) {
+  JCM_TRY(check(h, false));
+  if (!x || !out || B < 1 || H < 1 || W < 1 || C < 1 || C % 4) return fail(JCM_ERR_ARG, "bad max_pool arguments (C must be a multiple of 4)");
+  DeviceGuard g(h->device);
+  HIP_TRY(max_pool_2x2(x, out, B, H, W, C, h->stream));
+  return JCM_OK;
+}
+
+int jcm_resize_bilinear(jcm_handle h, const float* x, int B, int H, int W, int C, int OH, int OW, float* out) {
+  JCM_TRY(check(h, false));
+  if (!x || !out || B < 1 || H < 1 || W < 1 || C < 1 || OH < 1 || OW < 1) return fail(JCM_ERR_ARG, "bad resize arguments");
+  DeviceGuard g(h->device);
+  HIP_TRY(resize_bilinear(x, out, B, H, W, C, OH, OW, h->stream));
+  return JCM_OK;
+}
+
+int jcm_pd_forward(jcm_handle h, const float* x, int B, int H, int W, float* logits_out) {
+  JCM_TRY(check(h, true));
+  if (!x || !logits_out || B < 1 || H < 8 || W < 8) return fail(JCM_ERR_ARG, "bad pd_forward arguments");
+  DeviceGuard g(h->device);
+  return with_arena(h, [&] { return pd_forward_impl(h, x, B, H, W, logits_out); });
+}
+
+int jcm_spatial_softmax(jcm_handle h, const float* in, int B, int HW, int K, float* out) {
+  JCM_TRY(check(h, false));
+  if (!in || !out || B < 1 || HW < 1 || K < 1) return fail(JCM_ERR_ARG, "bad spatial_softmax arguments");
+  DeviceGuard g(h->device);
+  HIP_TRY(spatial_softmax(in, out, B, HW, K, h->stream));
+  return JCM_OK;
+}
+
+int jcm_conv_mrf(jcm_handle h, const float* A, const float* Bmaps, int B, float* out) {
+  JCM_TRY(check(h, true));
+  if (!A || !Bmaps || !out || B < 1) return fail(JCM_ERR_ARG, "bad conv_mrf arguments");
+  DeviceGuard g(h->device);
+  jcm_ctx* c = h;
+  return with_arena(c, [&] {
+    float* rev = arena_alloc<float>(c, (size_t)B * kHmH * 96);
+    float* cpre = arena_alloc<float>(c, (size_t)B * kCH * kCW);
+    if (c->dry) return (int)JCM_OK;
+    HIP_TRY(sm_likelihood(Bmaps, nullptr, nullptr, rev, B, 1, c->stream));     // reversed, padded copy
+    HIP_TRY(sm_pair_conv(A, rev, c->cond0, cpre, B, 1, 1, c->stream));         // main.py:83-87
+    HIP_TRY(sm_resize_only(cpre, out, B, c->stream));                          // main.py:89
+    return (int)JCM_OK;
+  });
+}
+
+int jcm_sm_forward(jcm_handle h, const float* hm10, int B, float* logits_out) {
+  JCM_TRY(check(h, true));
+  if (!hm10 || !logits_out || B < 1) return fail(JCM_ERR_ARG, "bad sm_forward arguments");
+  DeviceGuard g(h->device);
+  return with_arena(h, [&] { return sm_forward_impl(h, hm10, B, logits_out); });
+}
+
+int jcm_argmax_coords(jcm_handle h, const float* hm, int B, int HH, int WW, int K, int32_t* coords) {
+  JCM_TRY(check(h, false));
+  if (!hm || !coords || B < 1 || HH < 1 || WW < 1 || K < 1) return fail(JCM_ERR_ARG, "bad argmax arguments");
+  DeviceGuard g(h->device);
+  HIP_TRY(argmax_coords(hm, coords, B, HH * WW, WW, K, h->stream));
+  return JCM_OK;
+}
+
+int jcm_forward(jcm_handle h, const float* x, const float* torso, int B, int H, int W, int use_sm,
+                float* pd_prob, float* sm_prob, int32_t* pd_coords, int32_t* sm_coords) {
+  JCM_TRY(check(h, true));
+  if (!x || B < 1 || H < 8 || W < 8) return fail(JCM_ERR_ARG, "bad forward arguments");
+  if (use_sm && !torso) return fail(JCM_ERR_ARG, "use_sm needs the torso heat map (y_in[...,K:], main.py:528)");
+  if (use_sm && (cdiv2(cdiv2(cdiv2(H))) != kHmH || cdiv2(cdiv2(cdiv2(W))) != kHmW))
+    return fail(JCM_ERR_ARG, "the spatial model is defined for 60x90 heat maps (480x720 images) only");
+  DeviceGuard g(h->device);
+  jcm_ctx* c = h;
+  const int K = c->K;
+  return with_arena(c, [&] {
+    const int hh = cdiv2(cdiv2(cdiv2(H))), ww = cdiv2(cdiv2(cdiv2(W)));
+    const size_t n = (size_t)B * hh * ww * K;
+    float* logits = arena_alloc<float>(c, n);
+    float* prob = pd_prob ? pd_prob : arena_alloc<float>(c, n);
+    const size_t mark = c->arena_off;
+    JCM_TRY(pd_forward_impl(c, x, B, H, W, logits));                                      // main.py:522
+    c->arena_off = mark;
+    if (!c->dry) HIP_TRY(spatial_softmax(logits, prob, B, hh * ww, K, c->stream));           // main.py:523
+    if (pd_coords && !c->dry) HIP_TRY(argmax_coords(prob, pd_coords, B, hh * ww, ww, K, c->stream));
+    if (use_sm) {
+      float* hm10 = arena_alloc<float>(c, (size_t)B * hh * ww * (K + 1));
+      float* sml = arena_alloc<float>(c, n);
+      float* smp = sm_prob ? sm_prob : arena_alloc<float>(c, n);
+      if (K + 1 != kC) return fail(JCM_ERR_ARG, "use_sm requires n_joints == 9 (10-channel spatial model)");
+      if (!c->dry) HIP_TRY(concat_channels(prob, K, torso, 1, hm10, (size_t)B * hh * ww, c->stream));   // main.py:528
+      JCM_TRY(sm_forward_impl(c, hm10, B, sml));                                          // main.py:530
+      if (!c->dry) HIP_TRY(spatial_softmax(sml, smp, B, hh * ww, K, c->stream));           // main.py:531
+      if (sm_coords && !c->dry) HIP_TRY(argmax_coords(smp, sm_coords, B, hh * ww, ww, K, c->stream));
+    }
+    return (int)JCM_OK;
+  });
+}
+
+int64_t jcm_workspace_bytes(jcm_handle h) { return h ? (int64_t)(h->arena_cap + h->param_bytes) : 0; }
+
+}  // extern "C"

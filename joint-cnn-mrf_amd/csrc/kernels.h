@@ -1,0 +1,58 @@
+// Internal launcher prototypes of libjcm (gfx950 only).  Every launcher enqueues on `st`
+// and returns the hipError_t of the launch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace jcm {
+
+// ---- conv_igemm.hip : implicit-GEMM stride-1 SAME convolution on MFMA ----------------------
+// x NHWC [B,H,W,Cin] (Cin % 16 == 0), packed weights [k*k][Cin/4][CoutP][4] (fp32) or
+// [k*k][Cin/8][CoutP][8] (bf16), epilogue relu_bn ? max(z+bias,0)*scale+shift : z+bias.
+struct ConvArgs {
+  const void* x;
+  const void* wp;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  void* out;
+  int B, H, W, Cin, Cout, CoutP;
+  int relu_bn;
+};
+int conv_igemm_bn(int Cout);                     // N-tile the dispatcher will use for this Cout
+hipError_t conv_igemm_f32(const ConvArgs& a, int ks, hipStream_t st);
+hipError_t pack_weights_f32(const float* w_hwio, float* wp, int ks, int Cin, int Cout, int CoutP, hipStream_t st);
+
+// ---- conv1.hip : 5x5 stride-2 SAME convolution of the (sub-sampled) RGB image ---------------
+// x [B,H0,W0,3]; the branch input is x[:, ::sub, ::sub] (TF-1.x bilinear with an integer scale
+// is pure sub-sampling, main.py:51,60); w HWIO [5,5,3,Cout]; out [B,Ho,Wo,Cout].
+hipError_t conv1_5x5s2(const float* x, const float* w, const float* bias, const float* scale, const float* shift,
+                       float* out, int B, int H0, int W0, int sub, int Cout, hipStream_t st);
+
+// ---- glue.hip ----------------------------------------------------------------------------------
+hipError_t max_pool_2x2(const float* x, float* out, int B, int H, int W, int C, hipStream_t st);
+hipError_t resize_bilinear(const float* x, float* out, int B, int H, int W, int C, int OH, int OW, hipStream_t st);
+// out = (x1 + resize(x2) + resize(x3)) / 3   (main.py:58,67,69-70); x1 [B,H,W,C]
+hipError_t upsample_merge3(const float* x1, const float* x2, int H2, int W2, const float* x3, int H3, int W3,
+                           float* out, int B, int H, int W, int C, hipStream_t st);
+hipError_t concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, size_t N, hipStream_t st);
+hipError_t spatial_softmax(const float* in, float* out, int B, int HW, int K, hipStream_t st);
+hipError_t argmax_coords(const float* hm, int32_t* coords, int B, int HW, int WW, int K, hipStream_t st);
+
+// ---- spatial_model.hip -----------------------------------------------------------------------------
+// softplus5 tables of the batch-independent operands (main.py:120,122)
+hipError_t sm_softplus5(const float* in, float* out, int64_t n, hipStream_t st);
+// hm [B,5400,C] NHWC -> lik [B][C][5400] planar = softplus5(bn(hm))
+hipError_t sm_likelihood(const float* hm, const float* bn_scale, const float* bn_shift, float* lik,
+                         int B, int C, hipStream_t st);
+// cpre[b][p][61*91] = valid true convolution of prior p (120x180, already softplus'd) with
+// maps[b][cond[p]] (60x90 planar)           (main.py:83-87)
+hipError_t sm_pair_conv(const float* priors, const float* maps, const int* cond, float* cpre,
+                        int B, int P, int C, hipStream_t st);
+// E[b,pix,j] = log(lik[b][j][pix]+d) + sum_{pairs of j, graph order} log(R(cpre)[pix] + spb[p][pix] + d)
+hipError_t sm_finish(const float* lik, const float* cpre, const float* spbias, float* logits,
+                     int B, int K, int C, hipStream_t st);
+// out[b,pix] = R(cpre[b][0])[pix]   (the resize of main.py:89 on its own, for jcm_conv_mrf)
+hipError_t sm_resize_only(const float* cpre, float* out, int B, hipStream_t st);
+
+}  // namespace jcm

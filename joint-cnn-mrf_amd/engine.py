@@ -1,0 +1,201 @@
+"""Handle object over the C ABI: one Engine per (device, stream) holds the packed weights,
+spatial-model tables and workspace that the reference keeps as module globals + a
+tf.Session (SURVEY.md 8b 'Implicit state').  torch is used only to own device buffers."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _hm_size(n):
+    """Three SAME stride-2 stages (conv1 + two max-pools): ceil(ceil(ceil(n/2)/2)/2)."""
+    for _ in range(3):
+        n = (n + 1) // 2
+    return n
+
+
+class Engine:
+    """Owns a jcm_handle.  All tensor arguments are torch CUDA float32 NHWC, contiguous."""
+
+    def __init__(self, device=0, precision='fp32', n_joints=9, stream=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError('joint-cnn-mrf_amd needs an MI355X (gfx950) GPU; torch.cuda.is_available() is False '
+                               'and there is no CPU path')
+        self._lib = _lib.load()
+        self.device = torch.device('cuda', device if isinstance(device, int) else torch.device(device).index or 0)
+        self.n_joints = int(n_joints)
+        self.precision = precision
+        self._stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.jcm_create(self.device.index, ctypes.c_void_p(self._stream.cuda_stream), ctypes.byref(h)),
+                   'jcm_create')
+        self._h = h
+        self._finalized = False
+        prec = {'fp32': _lib.JCM_PRECISION_F32, 'f32': _lib.JCM_PRECISION_F32, 'bf16': _lib.JCM_PRECISION_BF16}[precision]
+        _lib.check(self._lib.jcm_set_option(self._h, b'precision', prec), 'jcm_set_option(precision)')
+        _lib.check(self._lib.jcm_set_option(self._h, b'n_joints', self.n_joints), 'jcm_set_option(n_joints)')
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            self._lib.jcm_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ parameters
+    def set_tensor(self, name, value):
+        """`name` is the reference's TF variable name; `value` numpy or torch (host or device)."""
+        if isinstance(value, torch.Tensor):
+            t = value.detach().to(torch.float32).contiguous()
+            ptr, shape, keep = t.data_ptr(), tuple(t.shape), t
+        else:
+            a = np.ascontiguousarray(value, dtype=np.float32)
+            ptr, shape, keep = a.ctypes.data, a.shape, a
+        if len(shape) == 0:
+            raise ValueError('scalar parameter %r' % name)
+        arr = (ctypes.c_int64 * len(shape))(*shape)
+        _lib.check(self._lib.jcm_set_tensor(self._h, name.encode(), ctypes.c_void_p(ptr), arr, len(shape)),
+                   'jcm_set_tensor(%s)' % name)
+        del keep
+
+    def load_params(self, params, finalize=True):
+        for name, value in params.items():
+            self.set_tensor(name, value)
+        if finalize:
+            self.finalize()
+        return self
+
+    def finalize(self):
+        _lib.check(self._lib.jcm_finalize(self._h), 'jcm_finalize')
+        self._finalized = True
+
+    # ------------------------------------------------------------------ helpers
+    def _chk(self, t, ndim, name, dtype=torch.float32):
+        if not isinstance(t, torch.Tensor):
+            raise TypeError('%s must be a torch tensor' % name)
+        if t.device != self.device:
+            raise ValueError('%s is on %s, engine is on %s' % (name, t.device, self.device))
+        if t.dtype != dtype:
+            raise TypeError('%s must be %s, got %s' % (name, dtype, t.dtype))
+        if t.dim() != ndim:
+            raise ValueError('%s must have %d dims (NHWC), got shape %s' % (name, ndim, tuple(t.shape)))
+        if not t.is_contiguous():
+            raise ValueError('%s must be contiguous (NHWC)' % name)
+        return t
+
+    def _new(self, *shape, dtype=torch.float32):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    @staticmethod
+    def _p(t):
+        return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+    # ------------------------------------------------------------------ ops (main.py names)
+    def conv_layer(self, x, name, stride, last_layer=False, n_out=None):
+        """main.py:156-169."""
+        self._chk(x, 4, 'x')
+        B, H, W, _ = x.shape
+        if n_out is None:
+            raise ValueError('n_out is required to size the output')
+        out = self._new(B, -(-H // stride), -(-W // stride), n_out)
+        _lib.check(self._lib.jcm_conv_layer(self._h, name.encode(), stride, int(bool(last_layer)), self._p(x), B, H, W,
+                                            self._p(out)), 'jcm_conv_layer(%s)' % name)
+        return out
+
+    def max_pool(self, x):
+        """main.py:172-174."""
+        self._chk(x, 4, 'x')
+        B, H, W, C = x.shape
+        out = self._new(B, (H + 1) // 2, (W + 1) // 2, C)
+        _lib.check(self._lib.jcm_max_pool(self._h, self._p(x), B, H, W, C, self._p(out)), 'jcm_max_pool')
+        return out
+
+    def resize_bilinear(self, x, oh, ow):
+        """tf.image.resize_images, TF-1.x legacy bilinear (main.py:51,58,60,67,89)."""
+        self._chk(x, 4, 'x')
+        B, H, W, C = x.shape
+        out = self._new(B, oh, ow, C)
+        _lib.check(self._lib.jcm_resize_bilinear(self._h, self._p(x), B, H, W, C, oh, ow, self._p(out)), 'jcm_resize_bilinear')
+        return out
+
+    def model(self, x):
+        """main.py:29-74: [B,H,W,3] -> logits [B,H/8,W/8,K]."""
+        self._chk(x, 4, 'x')
+        B, H, W, C = x.shape
+        if C != 3:
+            raise ValueError('x must be [B,H,W,3], got %s' % (tuple(x.shape),))
+        out = self._new(B, _hm_size(H), _hm_size(W), self.n_joints)
+        _lib.check(self._lib.jcm_pd_forward(self._h, self._p(x), B, H, W, self._p(out)), 'jcm_pd_forward')
+        return out
+
+    def spatial_softmax(self, hm):
+        """main.py:212-217."""
+        self._chk(hm, 4, 'hm')
+        B, H, W, K = hm.shape
+        out = torch.empty_like(hm)
+        _lib.check(self._lib.jcm_spatial_softmax(self._h, self._p(hm), B, H * W, K, self._p(out)), 'jcm_spatial_softmax')
+        return out
+
+    def conv_mrf(self, A, Bm):
+        """main.py:77-91: A [1,120,180,1], B [b,60,90,1] -> [b,60,90,1]."""
+        self._chk(A, 4, 'A')
+        self._chk(Bm, 4, 'B')
+        if tuple(A.shape) != (1, 120, 180, 1) or tuple(Bm.shape[1:]) != (60, 90, 1):
+            raise ValueError('conv_mrf expects A [1,120,180,1] and B [b,60,90,1]; got %s, %s' % (tuple(A.shape), tuple(Bm.shape)))
+        out = torch.empty_like(Bm)
+        _lib.check(self._lib.jcm_conv_mrf(self._h, self._p(A), self._p(Bm), Bm.shape[0], self._p(out)), 'jcm_conv_mrf')
+        return out
+
+    def spatial_model(self, heat_map):
+        """main.py:94-125: [B,60,90,K+1] -> [B,60,90,K]."""
+        self._chk(heat_map, 4, 'heat_map')
+        B = heat_map.shape[0]
+        if tuple(heat_map.shape[1:]) != (60, 90, self.n_joints + 1):
+            raise ValueError('spatial_model expects [B,60,90,%d], got %s' % (self.n_joints + 1, tuple(heat_map.shape)))
+        out = self._new(B, 60, 90, self.n_joints)
+        _lib.check(self._lib.jcm_sm_forward(self._h, self._p(heat_map), B, self._p(out)), 'jcm_sm_forward')
+        return out
+
+    def argmax_coords(self, hm):
+        """evaluation.py:15-24: [B,H,W,K] -> int32 [B,2,K] (row, col)."""
+        self._chk(hm, 4, 'hm')
+        B, H, W, K = hm.shape
+        out = self._new(B, 2, K, dtype=torch.int32)
+        _lib.check(self._lib.jcm_argmax_coords(self._h, self._p(hm), B, H, W, K, self._p(out)), 'jcm_argmax_coords')
+        return out
+
+    def forward(self, x, torso=None, use_sm=True, want_prob=True):
+        """The tower of main.py:522-531 in one C call.  Returns a dict with 'pd_coords',
+        'sm_coords' (int32 [B,2,K]) and, if want_prob, 'pd_prob' / 'sm_prob' [B,60,90,K]."""
+        self._chk(x, 4, 'x')
+        B, H, W, C = x.shape
+        if C != 3:
+            raise ValueError('x must be [B,H,W,3]')
+        if use_sm:
+            if torso is None:
+                raise ValueError('use_sm=True needs the torso heat map y_in[..., 9:] (main.py:528)')
+            self._chk(torso, 4, 'torso')
+            if tuple(torso.shape) != (B, 60, 90, 1):
+                raise ValueError('torso must be [B,60,90,1], got %s' % (tuple(torso.shape),))
+        hh, ww, K = _hm_size(H), _hm_size(W), self.n_joints
+        r = {'pd_coords': self._new(B, 2, K, dtype=torch.int32)}
+        if want_prob:
+            r['pd_prob'] = self._new(B, hh, ww, K)
+        if use_sm:
+            r['sm_coords'] = self._new(B, 2, K, dtype=torch.int32)
+            if want_prob:
+                r['sm_prob'] = self._new(B, hh, ww, K)
+        _lib.check(self._lib.jcm_forward(self._h, self._p(x), self._p(torso if use_sm else None), B, H, W, int(bool(use_sm)),
+                                         self._p(r.get('pd_prob')), self._p(r.get('sm_prob')),
+                                         self._p(r['pd_coords']), self._p(r.get('sm_coords'))), 'jcm_forward')
+        return r
+
+    def workspace_bytes(self):
+        return int(self._lib.jcm_workspace_bytes(self._h))

@@ -1,0 +1,62 @@
+"""CPU-side checks of the drop-in boundary: libjcm.so loads, exports every symbol that
+include/jcm.h declares, and fails loudly (no fallback) without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import joint_cnn_mrf_amd  # noqa: F401
+from joint_cnn_mrf_amd import _lib
+
+
+def _declared(repo_root):
+    text = open(os.path.join(repo_root, 'include', 'jcm.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(jcm_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol(repo_root):
+    names = _declared(repo_root)
+    assert len(names) >= 15
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), 'include/jcm.h declares %s but libjcm.so does not export it' % n
+
+
+def test_binding_covers_the_header(repo_root):
+    assert sorted(_lib.SIGNATURES) == _declared(repo_root)
+    lib = _lib.load()
+    assert lib.jcm_abi_version() == 1
+
+
+def test_error_path_without_compute():
+    """Status code + thread-local message -> RuntimeError; no compute call is made."""
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    status = lib.jcm_create(10 ** 6, None, ctypes.byref(h))
+    assert status != 0
+    with pytest.raises(RuntimeError) as ei:
+        _lib.check(status, 'jcm_create')
+    assert 'jcm_create failed' in str(ei.value)
+    assert lib.jcm_set_option(None, b'precision', 0) != 0
+    assert 'null handle' in _lib.last_error()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU behaviour')
+def test_engine_fails_loudly_without_gpu():
+    from joint_cnn_mrf_amd.engine import Engine
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        Engine(device=0)
+
+
+def test_reference_surface_names():
+    """The host module keeps main.py's names and flags."""
+    from joint_cnn_mrf_amd import main as M
+    for name in ('model', 'conv_mrf', 'spatial_model', 'spatial_softmax', 'conv_layer', 'max_pool_layer'):
+        assert callable(getattr(M, name))
+    assert list(M.joint_names) == ['lsho', 'lelb', 'lwri', 'rsho', 'relb', 'rwri', 'lhip', 'rhip', 'nose', 'torso']
+    assert M.joint_dependence['lwri'][0] == 'lsho' and len(M.joint_dependence['lwri']) == 9
+    a = M.build_parser().parse_args(['--gpus', '0', '1', '--use_sm', '--batch_size', '64', '--debug'])
+    assert a.gpus == [0, 1] and a.use_sm and a.batch_size == 64 and a.debug and not a.train and not a.restore

@@ -1,0 +1,167 @@
+"""Parity of the HIP path (through the C ABI) against the float64 oracle on the same seeded
+inputs, at sizes the oracle finishes in seconds (debug-size filters, main.py:40-41).
+
+Tolerances (north star): heat maps |d| <= 1e-4 in fp32, argmax coordinates bit-exact.
+1e-4 on softmax outputs (values <= 1, typically ~1e-3) is loose, so logits are additionally
+held to 2e-4 * max(1, max|logit|)."""
+import numpy as np
+import pytest
+import torch
+
+import joint_cnn_mrf_amd  # noqa: F401
+from joint_cnn_mrf_amd import synth
+from oracle import jcm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+HM_TOL = 1e-4
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device='cuda:0')
+
+
+def logit_tol(ref):
+    return 2e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.fixture(scope='module')
+def debug_setup():
+    from joint_cnn_mrf_amd.engine import Engine
+    p = synth.make_pd_params(debug=True, bn='trained', conv6_gain=8.0)
+    p.update(synth.make_sm_params(synth.synthetic_priors(), kind='trained'))
+    eng = Engine(device=0).load_params(p)
+    yield eng, p
+    eng.close()
+
+
+def test_conv1_stride2_asymmetric_padding(debug_setup):
+    eng, p = debug_setup
+    x = synth.make_images(2, seed=3)
+    for res, sub in (('fullres', 1), ('halfres', 2), ('quarterres', 4)):
+        xin = x[:, ::sub, ::sub]
+        ref = O.conv_layer(xin, p, 5, 2, 'conv1_' + res)
+        got = eng.conv_layer(dev(xin), 'conv1_' + res, 2, n_out=16).cpu().numpy()
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got, ref, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize('scope,size,hw', [
+    ('conv2_fullres', 5, (120, 180)), ('conv3_fullres', 5, (60, 90)), ('conv4_fullres', 9, (60, 90)),
+    ('conv3_halfres', 5, (30, 45)), ('conv4_halfres', 9, (30, 45)), ('conv4_quarterres', 9, (15, 23)),
+    ('conv5', 9, (60, 90)),
+])
+def test_conv_layers_igemm(debug_setup, scope, size, hw):
+    eng, p = debug_setup
+    cin, cout = p[scope + '/weights'].shape[2:]
+    x = np.random.RandomState(hash(scope) % 1000).standard_normal((2, hw[0], hw[1], cin)).astype(np.float32)
+    ref = O.conv_layer(x, p, size, 1, scope)
+    got = eng.conv_layer(dev(x), scope, 1, n_out=cout).cpu().numpy()
+    np.testing.assert_allclose(got, ref, atol=1e-4, rtol=1e-4)
+
+
+def test_conv6_last_layer_is_linear(debug_setup):
+    eng, p = debug_setup
+    x = np.random.RandomState(6).standard_normal((2, 60, 90, 128)).astype(np.float32)
+    ref = O.conv_layer(x, p, 9, 1, 'conv6', last_layer=True)
+    got = eng.conv_layer(dev(x), 'conv6', 1, last_layer=True, n_out=9).cpu().numpy()
+    np.testing.assert_allclose(got, ref, atol=logit_tol(ref), rtol=0)
+    with pytest.raises(RuntimeError, match='last_layer'):
+        eng.conv_layer(dev(x), 'conv6', 1, last_layer=False, n_out=9)
+
+
+def test_max_pool_and_resize(debug_setup):
+    eng, _ = debug_setup
+    x = np.random.RandomState(7).standard_normal((2, 30, 45, 32)).astype(np.float32)
+    np.testing.assert_array_equal(eng.max_pool(dev(x)).cpu().numpy(), O.max_pool_same(x))
+    x2 = np.random.RandomState(8).standard_normal((2, 240, 360, 16)).astype(np.float32)
+    np.testing.assert_array_equal(eng.max_pool(dev(x2)).cpu().numpy(), O.max_pool_same(x2))
+    for (h, w, c, oh, ow) in [(30, 45, 32, 60, 90), (15, 23, 32, 60, 90), (61, 91, 1, 60, 90), (48, 72, 3, 24, 36), (60, 90, 8, 60, 90)]:
+        xr = np.random.RandomState(h).standard_normal((2, h, w, c)).astype(np.float32)
+        got = eng.resize_bilinear(dev(xr), oh, ow).cpu().numpy()
+        np.testing.assert_allclose(got, O.resize_bilinear_tf1(xr.astype(np.float64), oh, ow), atol=2e-6, rtol=0)
+
+
+def test_model_fused_equals_layerwise_and_oracle(debug_setup):
+    eng, p = debug_setup
+    from joint_cnn_mrf_amd import main as M
+    M._engine, M.hps.debug = eng, True
+    x = synth.make_images(2, seed=21)
+    ref = O.model(x, p)
+    fused = M.model(dev(x), 9).cpu().numpy()
+    layer = M.model_layerwise(dev(x), 9).cpu().numpy()
+    M._engine = None
+    assert fused.shape == (2, 60, 90, 9)
+    np.testing.assert_allclose(fused, ref, atol=logit_tol(ref), rtol=0)
+    np.testing.assert_allclose(layer, fused, atol=1e-5, rtol=0)
+
+
+def test_spatial_softmax_and_argmax(debug_setup):
+    eng, _ = debug_setup
+    hm = (np.random.RandomState(10).standard_normal((3, 60, 90, 9)) * 6).astype(np.float32)
+    got = eng.spatial_softmax(dev(hm)).cpu().numpy()
+    ref = O.spatial_softmax(hm.astype(np.float64))
+    np.testing.assert_allclose(got, ref, atol=1e-7, rtol=2e-5)
+    np.testing.assert_allclose(got.sum(axis=(1, 2)), 1.0, rtol=1e-5)
+    np.testing.assert_array_equal(eng.argmax_coords(dev(hm)).cpu().numpy(), O.argmax_coords(hm))
+    tie = np.zeros((1, 60, 90, 2), np.float32)
+    tie[0, 10, 20, 0] = tie[0, 10, 21, 0] = tie[0, 40, 3, 0] = 1.0
+    tie[0, 59, 89, 1] = 2.0
+    c = eng.argmax_coords(dev(tie)).cpu().numpy()
+    assert c.dtype == np.int32 and tuple(c[0, :, 0]) == (10, 20) and tuple(c[0, :, 1]) == (59, 89)
+
+
+def test_conv_mrf_delta_and_random(debug_setup):
+    eng, _ = debug_setup
+    rs = np.random.RandomState(12)
+    A = rs.random_sample((1, 120, 180, 1)).astype(np.float32)
+    Bm = np.zeros((3, 60, 90, 1), np.float32)
+    Bm[0, 0, 0, 0] = Bm[1, 59, 89, 0] = Bm[2, 17, 42, 0] = 1.0          # KAT1
+    got = eng.conv_mrf(dev(A), dev(Bm)).cpu().numpy()
+    np.testing.assert_allclose(got, O.conv_mrf(A.astype(np.float64), Bm.astype(np.float64)), atol=1e-6, rtol=0)
+    Br = rs.random_sample((2, 60, 90, 1)).astype(np.float32)
+    ref = O.conv_mrf(A.astype(np.float64), Br.astype(np.float64))
+    got = eng.conv_mrf(dev(A), dev(Br)).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=3e-6, atol=0)
+
+
+@pytest.mark.parametrize('kind', ['init', 'trained'])
+def test_spatial_model(kind):
+    from joint_cnn_mrf_amd.engine import Engine
+    p = synth.make_sm_params(synth.synthetic_priors(), kind=kind)
+    eng = Engine(device=0).load_params(p)
+    rs = np.random.RandomState(14)
+    hm10 = np.concatenate([O.spatial_softmax(rs.standard_normal((2, 60, 90, 9)) * 4), synth.make_torso(2)], axis=3).astype(np.float32)
+    ref = O.spatial_model(hm10.astype(np.float64), p)
+    got = eng.spatial_model(dev(hm10)).cpu().numpy()
+    eng.close()
+    np.testing.assert_allclose(got, ref, atol=logit_tol(ref), rtol=0)
+    np.testing.assert_allclose(O.spatial_softmax(got.astype(np.float64)), O.spatial_softmax(ref), atol=HM_TOL, rtol=0)
+
+
+def test_full_tower_debug_size(debug_setup):
+    """Config-2 shape at debug width: part detector + spatial model + argmax, B=4."""
+    eng, p = debug_setup
+    x, torso = synth.make_images(4, seed=31), synth.make_torso(4, seed=32)
+    ref = O.forward(x, torso, p)
+    r = eng.forward(dev(x), dev(torso), use_sm=True)
+    for k in ('pd_prob', 'sm_prob'):
+        np.testing.assert_allclose(r[k].cpu().numpy(), ref[k], atol=HM_TOL, rtol=0)
+        np.testing.assert_allclose(r[k].cpu().numpy(), ref[k], rtol=2e-3, atol=1e-9)
+    for k in ('pd_coords', 'sm_coords'):
+        np.testing.assert_array_equal(r[k].cpu().numpy(), ref[k])
+    r2 = eng.forward(dev(x), None, use_sm=False, want_prob=False)
+    np.testing.assert_array_equal(r2['pd_coords'].cpu().numpy(), ref['pd_coords'])
+    assert 'sm_coords' not in r2
+
+
+def test_shim_validates_before_the_call(debug_setup):
+    eng, _ = debug_setup
+    with pytest.raises(ValueError):
+        eng.model(torch.zeros(1, 480, 720, 4, device='cuda:0'))
+    with pytest.raises(TypeError):
+        eng.model(torch.zeros(1, 480, 720, 3, device='cuda:0', dtype=torch.float16))
+    with pytest.raises(ValueError):
+        eng.model(torch.zeros(1, 3, 480, 720, device='cuda:0').permute(0, 2, 3, 1))
+    with pytest.raises(ValueError):
+        eng.forward(torch.zeros(1, 480, 720, 3, device='cuda:0'), None, use_sm=True)
