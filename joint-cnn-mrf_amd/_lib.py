@@ -49,6 +49,10 @@ def load():
         raise RuntimeError(
             'libjcm.so is not built (%s). Run `python -c "import __graft_entry__ as g; g.build()"` or '
             '`make -C joint-cnn-mrf_amd/csrc`; there is no CPU fallback for this path.' % LIB_PATH)
+    # One HIP runtime per process: torch bundles its own libamdhip64.so (SONAME libamdhip64.so.7,
+    # same as /opt/rocm's).  Importing torch first makes libjcm's NEEDED entry bind to the copy
+    # torch already loaded; the other order loads two runtimes and the second sees no device.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError here = header/library drift

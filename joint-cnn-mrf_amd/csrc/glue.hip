@@ -46,7 +46,7 @@ hipError_t max_pool_2x2(const float* x, float* out, int B, int H, int W, int C, 
 // lo = floor(src); hi = min(lo+1, in-1); lerp = src-lo.  Lerp along x, then along y.
 struct Tap { int lo, hi; float t; };
 __device__ __forceinline__ Tap tf1_tap(int i, int in_size, float scale) {
-  const float src = (float)i * scale;
+  const float src = __fmul_rn((float)i, scale);   // rounded product, as TF computes `in = i * scale`; no FMA with the subtract below
   Tap r;
   r.lo = (int)floorf(src);
   r.hi = min(r.lo + 1, in_size - 1);

@@ -134,7 +134,7 @@ hipError_t sm_pair_conv(const float* priors, const float* maps, const int* cond,
 // TF-1.x bilinear 61x91 -> 60x90 at one output pixel (main.py:89).
 __device__ __forceinline__ float resize_61x91(const float* __restrict__ c, int oy, int ox) {
   const float sy = (float)SM_CH / (float)SM_H, sx = (float)SM_CW / (float)SM_W;
-  const float fy = (float)oy * sy, fx = (float)ox * sx;
+  const float fy = __fmul_rn((float)oy, sy), fx = __fmul_rn((float)ox, sx);   // rounded, never fused into the lerp-weight subtract
   const int ylo = (int)floorf(fy), xlo = (int)floorf(fx);
   const int yhi = min(ylo + 1, SM_CH - 1), xhi = min(xlo + 1, SM_CW - 1);
   const float ty = fy - (float)ylo, tx = fx - (float)xlo;
