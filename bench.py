@@ -1,0 +1,139 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of the part-detector + spatial-model forward (ending in
+argmax coordinates on the device) on 480x720x3 synthetic images, K=9, on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A step = one pass of the whole path over one batch per GPU (BASELINE.json configs[1]: batch 64,
+fp32) with inputs already resident in HBM.  Ranks shard by batch (images are independent);
+the only collective is the all-gather of [B,2,9] int32 coordinates (main.py:573-574 -> RCCL).
+Prints ONE JSON line on rank 0 with the driver's contract keys plus `roofline` (dominant
+kernel = the conv5 MFMA implicit-GEMM launch, timed live with HIP events on its stream) and
+`cpu_baseline` (the CPU restatement timed on the host cores; TensorFlow is unavailable).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import joint_cnn_mrf_amd  # noqa: E402,F401
+from joint_cnn_mrf_amd import dist as jdist  # noqa: E402
+from joint_cnn_mrf_amd import synth  # noqa: E402
+from joint_cnn_mrf_amd.engine import Engine  # noqa: E402
+
+# Algorithmic FLOPs (2*MAC) per image, SURVEY.md 8d / BASELINE.md section 2.
+FLOPS_PD_SM = 413_188_758_480
+FLOPS_CONV5 = 229_323_571_200           # 60*90 * 512 * (81*512) * 2: the dominant kernel's launch
+PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def cpu_baseline(n_images, params):
+    """The oracle's torch-CPU formulation (fp32) on the host cores: the stand-in for the
+    reference's TF-CPU path, which cannot run here (no TensorFlow).  Bounded sample."""
+    from oracle import jcm_oracle_torch as T
+    x, torso = synth.make_images(n_images, seed=99), synth.make_torso(n_images, seed=98)
+    T.forward(x[:1], torso[:1], params, dtype=torch.float32)          # warm-up (thread pools, oneDNN primitives)
+    t0 = time.time()
+    T.forward(x, torso, params, dtype=torch.float32)
+    dt = time.time() - t0
+    return {'value': n_images / dt, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d synthetic 480x720 images, full-size network, PD+SM, fp32 torch-CPU/oneDNN restatement '
+                      '(TensorFlow unavailable); host has %d logical CPUs' % (n_images, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=64, help='images per GPU per step (configs[1]: 64)')
+    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'])
+    ap.add_argument('--no-sm', action='store_true', help='part detector only')
+    ap.add_argument('--debug', action='store_true', help='filters/4 (main.py:40-41); not the headline config')
+    ap.add_argument('--cpu-images', type=int, default=4, help='size of the cpu_baseline sample (0 = skip)')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    if args.gpus != world and rank == 0:
+        print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    use_sm = not args.no_sm
+
+    params = synth.make_pd_params(debug=args.debug)                    # He init, BN identity (main.py:138-153)
+    if use_sm:
+        params.update(synth.make_sm_params(synth.synthetic_priors(), kind='init'))   # main.py:477-487
+    eng = Engine(device=local_rank, precision=args.dtype).load_params(params)
+
+    B = args.batch
+    x = torch.as_tensor(synth.make_images(B, seed=1234 + rank), device=dev)          # resident in HBM
+    torso = torch.as_tensor(synth.make_torso(B, seed=4321 + rank), device=dev)
+
+    def step():
+        r = eng.forward(x, torso if use_sm else None, use_sm=use_sm, want_prob=False)
+        return jdist.allgather_coords(r['sm_coords' if use_sm else 'pd_coords'])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    eng.set_profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        coords = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.set_profile(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert coords.shape == (world * B, 2, 9)
+
+    if rank == 0:
+        ms5, n5 = eng.profile_read('conv5')
+        conv5_ms = ms5 / max(n5, 1)
+        flops5 = FLOPS_CONV5 / (16 if args.debug else 1) * B
+        achieved = flops5 / (conv5_ms * 1e-3) / 1e12 if n5 else None
+        peak = PEAK_TFLOPS[args.dtype]
+        value = world * B * args.steps / dt
+        out = {
+            'metric': 'images/sec (720x480, K=9 joints) part-detector+spatial-model fwd',
+            'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32' if args.dtype == 'fp32' else 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: batch=%d/GPU synthetic 480x720x3, part detector%s forward + argmax, %s%s'
+                                   % (B, ' + spatial model' if use_sm else '', args.dtype, ', DEBUG filters/4' if args.debug else ''),
+                       'batch_per_gpu': B, 'global_batch': world * B, 'use_sm': use_sm, 'collective': 'all_gather coords int32 [B,2,9]'},
+            'path_tflops': value * FLOPS_PD_SM / (16 if args.debug else 1) / 1e12,
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm (conv5: 60x90, 512->512, 9x9)', 'achieved': achieved, 'peak': peak,
+                         'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None, 'traffic': None,
+                         'launch_ms': conv5_ms, 'launches': n5, 'flops_per_launch': flops5},
+        }
+        if args.cpu_images > 0:
+            out['cpu_baseline'] = cpu_baseline(args.cpu_images, params)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -46,7 +46,9 @@ int jcm_abi_version(void);
 /* -- options ------------------------------------------------------------------------------
  * "precision": JCM_PRECISION_*  (the reference is fp32 throughout)
  * "n_joints" : K, default 9      (main.py:458)
- * Must be set before jcm_finalize. */
+ * Both must be set before jcm_finalize.
+ * "profile"  : 0/1, any time: bracket every MFMA conv launch with HIP events on the launch
+ *              stream; read the totals back with jcm_profile_read. */
 int jcm_set_option(jcm_handle h, const char* key, int64_t value);
 
 /* -- parameters -----------------------------------------------------------------------------
@@ -98,7 +100,10 @@ int jcm_forward(jcm_handle h, const float* x, const float* torso, int B, int H, 
                 float* pd_prob, float* sm_prob, int32_t* pd_coords, int32_t* sm_coords);
 
 /* -- introspection (used by bench.py for the roofline object) ------------------------------------
- * Bytes currently held by the workspace arena / packed parameters. */
+ * Sum of the HIP-event durations (ms) and the number of launches recorded for conv layer
+ * `scope` since the last read; synchronises the stream and clears the record. */
+int jcm_profile_read(jcm_handle h, const char* scope, double* total_ms, int* launches);
+/* Bytes currently held by the workspace arena + packed parameters. */
 int64_t jcm_workspace_bytes(jcm_handle h);
 
 #ifdef __cplusplus

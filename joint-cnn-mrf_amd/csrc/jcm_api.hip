@@ -83,6 +83,9 @@ struct jcm_ctx {
   size_t arena_cap = 0, arena_off = 0, arena_peak = 0;
   bool dry = false;             // sizing pass: allocate offsets only, launch nothing
   size_t param_bytes = 0;
+  // per-layer HIP-event timing on the launch stream (bench.py roofline object)
+  bool profile = false;
+  std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
 };
 
 namespace {
@@ -183,10 +186,20 @@ int run_conv(jcm_ctx* c, const std::string& scope, int stride, const float* x, i
     return JCM_OK;
   }
   if (stride != 1 || !L->wp) return fail(JCM_ERR_ARG, "no kernel for layer '" + scope + "' with stride " + std::to_string(stride));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c->profile) {
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, c->stream));
+  }
   ConvArgs a;
   a.x = x; a.wp = L->wp; a.bias = L->bias; a.scale = L->scale; a.shift = L->shift; a.out = out;
   a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout; a.CoutP = L->coutp; a.relu_bn = L->has_bn ? 1 : 0;
   HIP_TRY(conv_igemm_f32(a, L->ks, c->stream));
+  if (c->profile) {
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    c->prof[scope].emplace_back(e0, e1);
+  }
   return JCM_OK;
 }
 
@@ -314,8 +327,12 @@ int jcm_destroy(jcm_handle h) {
 
 int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
   JCM_TRY(check(h, false));
-  if (h->finalized) return fail(JCM_ERR_STATE, "options must be set before jcm_finalize");
   const std::string k = key ? key : "";
+  if (k == "profile") {   // allowed at any time
+    h->profile = value != 0;
+    return JCM_OK;
+  }
+  if (h->finalized) return fail(JCM_ERR_STATE, "options must be set before jcm_finalize");
   if (k == "precision") {
     if (value != JCM_PRECISION_F32 && value != JCM_PRECISION_BF16) return fail(JCM_ERR_ARG, "precision must be 0 (f32) or 1 (bf16)");
     if (value == JCM_PRECISION_BF16) return fail(JCM_ERR_ARG, "bf16 kernels are not built into this library version");
@@ -519,6 +536,30 @@ int jcm_forward(jcm_handle h, const float* x, const float* torso, int B, int H, 
     }
     return (int)JCM_OK;
   });
+}
+
+int jcm_profile_read(jcm_handle h, const char* scope, double* total_ms, int* launches) {
+  JCM_TRY(check(h, false));
+  if (!scope || !total_ms || !launches) return fail(JCM_ERR_ARG, "bad profile_read arguments");
+  DeviceGuard g(h->device);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  double tot = 0;
+  int n = 0;
+  auto it = h->prof.find(scope);
+  if (it != h->prof.end()) {
+    for (auto& ev : it->second) {
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+      tot += ms;
+      ++n;
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
+    h->prof.erase(it);
+  }
+  *total_ms = tot;
+  *launches = n;
+  return JCM_OK;
 }
 
 int64_t jcm_workspace_bytes(jcm_handle h) { return h ? (int64_t)(h->arena_cap + h->param_bytes) : 0; }

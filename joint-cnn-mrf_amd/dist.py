@@ -1,0 +1,40 @@
+"""Batch sharding across GPUs: the inference side of the reference's tower loop.
+
+The reference slices the batch into `batch_size // n_gpus` contiguous pieces, one per
+in-graph tower, and concatenates the per-tower heat maps on axis 0 (main.py:511-517,573-574).
+Images are independent in inference (BatchNorm uses moving statistics, main.py:406), so
+here every rank (one process per GPU) runs the whole path on its slice with no data-path
+collective, and only the argmax coordinates -- [B_local,2,K] int32, 72 B/image -- are
+all-gathered (RCCL over xGMI via torch.distributed 'nccl'; 'gloo' in the CPU tests)."""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(batch_size, world_size, rank):
+    """main.py:511,516: imgs_per_gpu = batch_size // n_gpus; id_from, id_to = i*per, i*per+per.
+    (Like the reference, a remainder batch_size % n_gpus is dropped.)"""
+    per = batch_size // world_size
+    return rank * per, rank * per + per
+
+
+def shard_batch(x, world_size=None, rank=None):
+    """The rank's contiguous slice of a global batch tensor (first axis)."""
+    world_size = dist.get_world_size() if world_size is None else world_size
+    rank = dist.get_rank() if rank is None else rank
+    lo, hi = shard_bounds(x.shape[0], world_size, rank)
+    return x[lo:hi]
+
+
+def allgather_coords(local_coords, group=None):
+    """[B_local,2,K] int32 per rank -> [world*B_local,2,K] on every rank, rank-major order,
+    i.e. the order tf.concat(hms_pred, axis=0) gives (main.py:573-574)."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local_coords
+    if local_coords.dtype != torch.int32:
+        raise TypeError('coords must be int32')
+    world = dist.get_world_size(group)
+    local_coords = local_coords.contiguous()
+    out = torch.empty((world * local_coords.shape[0],) + tuple(local_coords.shape[1:]), dtype=local_coords.dtype,
+                      device=local_coords.device)
+    dist.all_gather_into_tensor(out, local_coords, group=group)
+    return out

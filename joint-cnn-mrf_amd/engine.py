@@ -197,5 +197,14 @@ class Engine:
                                          self._p(r['pd_coords']), self._p(r.get('sm_coords'))), 'jcm_forward')
         return r
 
+    def set_profile(self, on):
+        _lib.check(self._lib.jcm_set_option(self._h, b'profile', int(bool(on))), 'jcm_set_option(profile)')
+
+    def profile_read(self, scope):
+        """(total_ms, launches) of the HIP-event-bracketed launches of conv layer `scope`."""
+        ms, n = ctypes.c_double(0), ctypes.c_int(0)
+        _lib.check(self._lib.jcm_profile_read(self._h, scope.encode(), ctypes.byref(ms), ctypes.byref(n)), 'jcm_profile_read')
+        return ms.value, n.value
+
     def workspace_bytes(self):
         return int(self._lib.jcm_workspace_bytes(self._h))

