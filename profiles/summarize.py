@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Turn rocprofv3's rocpd SQLite output (gpurun_out/...) into the small text summaries that
+are committed under profiles/.
+
+  python profiles/summarize.py stats gpurun_out/prof_r1/r1_results.db  > profiles/rNN_kernel_stats.csv
+  python profiles/summarize.py pmc   gpurun_out/pmc_x/x_results.db ... > profiles/rNN_pmc.csv
+
+`stats` = per-kernel calls / total / average / share (what `--kernel-trace --stats` tabulates);
+`pmc`   = per-kernel, per-counter mean value per dispatch (one --pmc pass per database).
+Durations are nanoseconds in the database and are written as microseconds."""
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r'\(.*$', '', name)
+    return name.replace('void ', '').replace('jcm::', '')
+
+
+def stats(db):
+    con = sqlite3.connect(db)
+    rows = con.execute('select name, count(*), sum(duration), avg(duration), min(duration), max(duration) '
+                       'from kernels group by name order by sum(duration) desc').fetchall()
+    tot = sum(r[2] for r in rows)
+    print('kernel,calls,total_us,avg_us,min_us,max_us,percent')
+    for n, c, s, a, mn, mx in rows:
+        print('"%s",%d,%.1f,%.1f,%.1f,%.1f,%.2f' % (short(n), c, s / 1e3, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * s / tot))
+
+
+def pmc(dbs):
+    print('kernel,counter,dispatches,mean_value_per_dispatch,mean_duration_us')
+    for db in dbs:
+        con = sqlite3.connect(db)
+        rows = con.execute('select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection '
+                           'group by kernel_name, counter_name order by avg(duration)*count(*) desc').fetchall()
+        for n, cn, c, v, d in rows:
+            if d * c < 2e5:      # skip kernels below 0.2 ms total
+                continue
+            print('"%s",%s,%d,%.6g,%.1f' % (short(n), cn, c, v, d / 1e3))
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == 'stats':
+        stats(sys.argv[2])
+    else:
+        pmc(sys.argv[2:])
