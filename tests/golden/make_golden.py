@@ -1,0 +1,174 @@
+#!/usr/bin/env python
+"""Generates the committed golden vectors.  Runs ONLY in the build container (it reads
+/root/reference); the tests read the small .npy/.json files it writes next to itself.
+
+  python tests/golden/make_golden.py [--skip-reference-check]
+
+1. flic_train_cells.npy  [3987,10,2] uint8 -- heat-map cell (row, col) of the 9 joints + torso
+   for every FLIC training example, obtained by building the 60x90 heat maps exactly as
+   data.py:88-189 does from data_FLIC.mat (no JPEGs needed) and taking the arg-max cell the
+   way prepare_pairwise_distribution.py:39-42 reads it back.
+   The reference's own prepare_pairwise_distribution.py is then executed (runpy, in a temp
+   dir holding the generated y_train_flic.npy) and its pickle must equal
+   joint_cnn_mrf_amd.priors.build_pairwise_distributions(cells) bit for bit.
+2. full_*.npy -- float64-oracle outputs of the FULL-SIZE network on 2 seeded images
+   (inputs/weights are regenerated from seeds by the tests, only outputs are stored):
+   pd_logits, sm_logits for FLIC priors with init / trained-like SM parameters, coords.
+   The generator asserts a top-2 logit margin far above fp32 noise so argmax is well posed.
+3. conv_mrf_*.npy -- one pair's pre-resize (61x91) and post-resize (60x90) maps.
+4. layer_stats.json -- per-layer mean / abs-max of the full-size activations (for bisecting).
+"""
+import json
+import os
+import pickle
+import runpy
+import sys
+import tempfile
+
+import numpy as np
+from scipy.io import loadmat
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = '/root/reference'
+
+import joint_cnn_mrf_amd  # noqa: E402,F401
+from joint_cnn_mrf_amd import priors, synth  # noqa: E402
+from oracle import jcm_oracle as O  # noqa: E402
+
+GOLDEN_SEEDS = dict(weights=7, images=2024, torso=2025, sm=11, conv6_gain=24.0)
+
+
+def flic_heat_maps(split='train'):
+    """data.py:88-189 restricted to the heat-map half (the image half needs the JPEGs)."""
+    data_FLIC = loadmat(os.path.join(REF, 'data_FLIC.mat'))['examples'][0]
+    joint_ids = ['lsho', 'lelb', 'lwri', 'rsho', 'relb', 'rwri', 'lhip', 'rhip', 'nose']            # data.py:95
+    dict_ = {'lsho': 0, 'lelb': 1, 'lwri': 2, 'rsho': 3, 'relb': 4, 'rwri': 5, 'lhip': 6, 'lkne': 7, 'lank': 8,
+             'rhip': 9, 'rkne': 10, 'rank': 11, 'leye': 12, 'reye': 13, 'lear': 14, 'rear': 15, 'nose': 16,
+             'msho': 17, 'mhip': 18, 'mear': 19, 'mtorso': 20, 'mluarm': 21, 'mruarm': 22, 'mllarm': 23,
+             'mrlarm': 24, 'mluleg': 25, 'mruleg': 26, 'mllleg': 27, 'torso': 28}                    # data.py:96-100
+    is_train = np.array([data_FLIC[i][7][0, 0] for i in range(len(data_FLIC))])                      # data.py:101-102
+    index = np.where(is_train == (1 if split == 'train' else 0))[0]
+    coefs = np.array([[1, 2, 1]], dtype=np.float32) / 4                                              # data.py:112
+    kernel = coefs.T @ coefs
+    temp = round((len(kernel) - 1) / 2)
+    pad = 5
+    orig_h, orig_w = 480, 720
+    hmaps = []
+    for i in index:
+        flic_coords = data_FLIC[i][2]
+        # flip_backward_poses, data.py:35-49, with the reference's view (not copy) semantics
+        hip_left, hip_right = dict_['lhip'], dict_['rhip']
+        if flic_coords[:, hip_left][0] < flic_coords[:, hip_right][0]:
+            for jl, jr in zip(['lwri', 'lelb', 'lhip', 'lsho'], ['rwri', 'relb', 'rhip', 'rsho']):
+                jl, jr = dict_[jl], dict_[jr]
+                coords_left_joint = flic_coords[:, jl]
+                coords_right_joint = flic_coords[:, jr]
+                flic_coords[:, jl] = coords_right_joint
+                flic_coords[:, jr] = coords_left_joint
+        torso = (flic_coords[:, dict_['lsho']] + flic_coords[:, dict_['rhip']] + flic_coords[:, dict_['rsho']] +
+                 flic_coords[:, dict_['lhip']]) / 4                                                  # data.py:165-167
+        flic_coords[:, dict_['torso']] = torso
+        hmap = []
+        for joint in joint_ids + ['torso']:
+            coords = np.copy(flic_coords[:, dict_[joint]])
+            coords[0], coords[1] = max(min(coords[1], orig_h), 0), max(min(coords[0], orig_w), 0)    # data.py:171
+            coords /= 8
+            heat_map = np.zeros([60, 90], dtype=np.float32)
+            heat_map = np.pad(heat_map, ((pad, pad), (pad, pad)), "constant", constant_values=0)   # np.lib.pad in data.py:177
+            coords = coords + pad
+            h1_k, h2_k = int(coords[0] - temp), int(coords[0] + temp + 1)
+            w1_k, w2_k = int(coords[1] - temp), int(coords[1] + temp + 1)
+            heat_map[h1_k:h2_k, w1_k:w2_k] = kernel
+            hmap.append(heat_map[pad:pad + 60, pad:pad + 90])
+        hmaps.append(np.stack(hmap, axis=2))
+    return np.array(hmaps, dtype=np.float32)
+
+
+def cells_from_heat_maps(y):
+    """prepare_pairwise_distribution.py:39-42: np.where(img == np.max(img)); must be unique."""
+    n = y.shape[0]
+    cells = np.zeros((n, 10, 2), np.uint8)
+    flat = y.reshape(n, 60 * 90, 10)
+    mx = flat.max(axis=1, keepdims=True)
+    assert ((flat == mx).sum(axis=1) == 1).all(), 'a heat map has a non-unique maximum'
+    idx = flat.argmax(axis=1)
+    cells[:, :, 0] = idx // 90
+    cells[:, :, 1] = idx % 90
+    return cells
+
+
+def run_reference_prior_builder(y_train):
+    """Execute /root/reference/prepare_pairwise_distribution.py itself on y_train."""
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as td:
+        np.save(os.path.join(td, 'y_train_flic.npy'), y_train)
+        os.chdir(td)
+        try:
+            runpy.run_path(os.path.join(REF, 'prepare_pairwise_distribution.py'), run_name='__main__')
+        finally:
+            os.chdir(cwd)
+        with open(os.path.join(td, 'pairwise_distribution.pickle'), 'rb') as fh:
+            return pickle.load(fh)
+
+
+def top2_margin(logits):
+    flat = np.sort(logits.reshape(logits.shape[0], -1, logits.shape[3]), axis=1)
+    return float((flat[:, -1] - flat[:, -2]).min())
+
+
+def main():
+    skip_ref = '--skip-reference-check' in sys.argv
+    y_train = flic_heat_maps('train')
+    print('y_train', y_train.shape, float(y_train.sum(axis=(1, 2)).mean()))
+    cells = cells_from_heat_maps(y_train)
+    np.save(os.path.join(HERE, 'flic_train_cells.npy'), cells)
+    pri = priors.build_pairwise_distributions(cells)
+    if not skip_ref:
+        ref = run_reference_prior_builder(y_train)
+        assert sorted(ref) == sorted(pri) and len(ref) == 90
+        for k in ref:
+            assert ref[k].dtype == np.float64 and np.array_equal(ref[k], pri[k]), k
+        print('priors: identical to the reference script output for all 90 pairs')
+    del y_train
+
+    g = GOLDEN_SEEDS
+    p = synth.make_pd_params(debug=False, seed=g['weights'], bn='trained', conv6_gain=g['conv6_gain'])
+    x = synth.make_images(2, seed=g['images'])
+    torso = synth.make_torso(2, seed=g['torso'])
+    taps = {}
+    pd_logits = O.model(x, p, taps=taps)
+    pd_prob = O.spatial_softmax(pd_logits)
+    out = {'full_pd_logits': pd_logits, 'full_pd_coords': O.argmax_coords(pd_prob)}
+    stats = {k: {'mean': float(v.mean()), 'absmax': float(np.abs(v).max()), 'shape': list(v.shape)} for k, v in taps.items()}
+    stats['pd_top2_margin'] = top2_margin(pd_logits)
+    stats['pd_prob_max'] = float(pd_prob.max())
+    assert stats['pd_top2_margin'] > 1e-2, stats['pd_top2_margin']
+    hm10 = np.concatenate([pd_prob, torso.astype(np.float64)], axis=3)
+    for kind in ('init', 'trained'):
+        sp = synth.make_sm_params(pri, kind=kind, seed=g['sm'])
+        sm_logits = O.spatial_model(hm10, sp)
+        out['full_sm_logits_' + kind] = sm_logits
+        out['full_sm_coords_' + kind] = O.argmax_coords(O.spatial_softmax(sm_logits))
+        stats['sm_top2_margin_' + kind] = top2_margin(sm_logits)
+        assert stats['sm_top2_margin_' + kind] > 2e-3, (kind, stats['sm_top2_margin_' + kind])
+        if kind == 'trained':
+            key = 'lwri_lelb'
+            prior = O.softplus5(np.asarray(sp['energy_' + key], np.float64))
+            lik = O.softplus5(O.bn_infer(hm10, sp, 'bn_sm')[:, :, :, 1:2])
+            out['conv_mrf_prior'] = prior
+            out['conv_mrf_lik'] = lik
+            out['conv_mrf_pre'] = O.conv_mrf_pre(prior, lik)
+            out['conv_mrf_post'] = O.conv_mrf(prior, lik)
+    for k, v in out.items():
+        v = np.asarray(v)
+        np.save(os.path.join(HERE, k + '.npy'), v.astype(np.float32) if v.dtype == np.float64 else v)
+    stats['seeds'] = g
+    with open(os.path.join(HERE, 'layer_stats.json'), 'w') as fh:
+        json.dump(stats, fh, indent=1, sort_keys=True)
+    print(json.dumps({k: v for k, v in stats.items() if 'margin' in k or 'max' in k}))
+
+
+if __name__ == '__main__':
+    main()

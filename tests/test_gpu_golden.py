@@ -1,0 +1,44 @@
+"""FULL-SIZE parity on the GPU against the committed float64 golden vectors (2 images,
+512-channel network, FLIC-derived priors): heat maps within 1e-4, argmax bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import flic_priors, full_inputs, load, seeds
+from joint_cnn_mrf_amd import synth
+from oracle import jcm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device='cuda:0')
+
+
+@pytest.mark.parametrize('kind', ['init', 'trained'])
+def test_full_size_tower_vs_golden(kind):
+    from joint_cnn_mrf_amd.engine import Engine
+    x, torso, p = full_inputs()
+    p.update(synth.make_sm_params(flic_priors(), kind=kind, seed=seeds()['sm']))
+    eng = Engine(device=0).load_params(p)
+    logits = eng.model(dev(x)).cpu().numpy()
+    r = eng.forward(dev(x), dev(torso), use_sm=True)
+    eng.close()
+    ref_pd = load('full_pd_logits')
+    assert np.abs(logits - ref_pd).max() <= 2e-4 * max(1.0, np.abs(ref_pd).max())
+    ref_pd_prob = O.spatial_softmax(ref_pd.astype(np.float64))
+    ref_sm_prob = O.spatial_softmax(load('full_sm_logits_' + kind).astype(np.float64))
+    np.testing.assert_allclose(r['pd_prob'].cpu().numpy(), ref_pd_prob, atol=1e-4, rtol=0)
+    np.testing.assert_allclose(r['sm_prob'].cpu().numpy(), ref_sm_prob, atol=1e-4, rtol=0)
+    np.testing.assert_allclose(r['sm_prob'].cpu().numpy(), ref_sm_prob, rtol=5e-3, atol=1e-9)
+    np.testing.assert_array_equal(r['pd_coords'].cpu().numpy(), load('full_pd_coords'))
+    np.testing.assert_array_equal(r['sm_coords'].cpu().numpy(), load('full_sm_coords_' + kind))
+
+
+def test_conv_mrf_vs_golden():
+    from joint_cnn_mrf_amd.engine import Engine
+    eng = Engine(device=0)
+    eng.finalize()
+    got = eng.conv_mrf(dev(load('conv_mrf_prior')), dev(load('conv_mrf_lik'))).cpu().numpy()
+    eng.close()
+    np.testing.assert_allclose(got, load('conv_mrf_post'), rtol=2e-5, atol=0)
