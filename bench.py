@@ -30,8 +30,23 @@ from joint_cnn_mrf_amd.engine import Engine  # noqa: E402
 
 # Algorithmic FLOPs (2*MAC) per image, SURVEY.md 8d / BASELINE.md section 2.
 FLOPS_PD_SM = 413_188_758_480
-FLOPS_CONV5 = 229_323_571_200           # 60*90 * 512 * (81*512) * 2: the dominant kernel's launch
+# The dominant kernel is one instantiation of conv_igemm (9x9 taps, 4x32 pixel patch, 128-channel
+# N-tile); per step it is launched twice: conv4_fullres (256->512) and conv5 (512->512), both on
+# 60x90 maps.  Algorithmic FLOPs per image of each launch = 60*90 * Cout * 81*Cin * 2:
+FLOPS_DOMINANT = {'conv4_fullres': 114_661_785_600, 'conv5': 229_323_571_200}
 PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def pmc_traffic(key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) KB, FETCH doubled per the gfx950
+    correction in MI355X_MICROARCH.md).  PMC cannot be read from inside the timed run, so the
+    value is the last profiled one for this (dtype, batch), else null."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
+            return json.load(fh).get(key, {}).get('traffic_bytes_per_launch')
+    except OSError:
+        return None
 
 
 def cpu_baseline(n_images, params):
@@ -109,11 +124,15 @@ def main():
     assert coords.shape == (world * B, 2, 9)
 
     if rank == 0:
-        ms5, n5 = eng.profile_read('conv5')
-        conv5_ms = ms5 / max(n5, 1)
-        flops5 = FLOPS_CONV5 / (16 if args.debug else 1) * B
-        achieved = flops5 / (conv5_ms * 1e-3) / 1e12 if n5 else None
+        tot_ms, tot_n, tot_flops = 0.0, 0, 0.0
+        for scope, fl in FLOPS_DOMINANT.items():
+            ms, n = eng.profile_read(scope)
+            tot_ms, tot_n, tot_flops = tot_ms + ms, tot_n + n, tot_flops + n * fl / (16 if args.debug else 1) * B
+        launch_ms = tot_ms / max(tot_n, 1)                     # average launch duration (HIP events, launch stream)
+        flops_launch = tot_flops / max(tot_n, 1)               # average algorithmic FLOPs per launch
+        achieved = flops_launch / (launch_ms * 1e-3) / 1e12 if tot_n else None
         peak = PEAK_TFLOPS[args.dtype]
+        traffic = pmc_traffic('%s_b%d' % (args.dtype, B)) if not args.debug else None
         value = world * B * args.steps / dt
         out = {
             'metric': 'images/sec (720x480, K=9 joints) part-detector+spatial-model fwd',
@@ -124,9 +143,9 @@ def main():
                                    % (B, ' + spatial model' if use_sm else '', args.dtype, ', DEBUG filters/4' if args.debug else ''),
                        'batch_per_gpu': B, 'global_batch': world * B, 'use_sm': use_sm, 'collective': 'all_gather coords int32 [B,2,9]'},
             'path_tflops': value * FLOPS_PD_SM / (16 if args.debug else 1) / 1e12,
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm (conv5: 60x90, 512->512, 9x9)', 'achieved': achieved, 'peak': peak,
-                         'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None, 'traffic': None,
-                         'launch_ms': conv5_ms, 'launches': n5, 'flops_per_launch': flops5},
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm 9x9 / 4x32 patch / 128-ch tile (conv4_fullres + conv5 launches)',
+                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None,
+                         'traffic': traffic, 'launch_ms': launch_ms, 'launches': tot_n, 'flops_per_launch': flops_launch},
         }
         if args.cpu_images > 0:
             out['cpu_baseline'] = cpu_baseline(args.cpu_images, params)

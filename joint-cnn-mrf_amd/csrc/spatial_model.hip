@@ -94,6 +94,12 @@ __global__ __launch_bounds__(PC_THREADS) void sm_pair_conv_kernel(const float* _
 #pragma unroll
   for (int j = 0; j < PC_XT; ++j) acc[j] = 0.f;
   for (int u = 0; u < SM_H; ++u) {
+    // Two-level summation: a likelihood row (90 terms) accumulates into a fresh partial, the 60
+    // partials into the total.  A single 5400-term fp32 chain of near-constant positive terms
+    // drifts by ~3e-5 relative (correlated roundings); this keeps it at the 1e-6 level.
+    float racc[PC_XT];
+#pragma unroll
+    for (int j = 0; j < PC_XT; ++j) racc[j] = 0.f;
     const float* arow = pl + (y + SM_H - 1 - u) * SM_PP + x0;
     const float* hrow = lk + u * SM_LP;
     float win[2 * PC_XT];
@@ -107,11 +113,13 @@ __global__ __launch_bounds__(PC_THREADS) void sm_pair_conv_kernel(const float* _
       for (int i = 0; i < PC_XT; ++i) {
         const float hv = hrow[tb * 8 + i];   // uniform -> scalar load
 #pragma unroll
-        for (int j = 0; j < PC_XT; ++j) acc[j] = fmaf(hv, win[i + j], acc[j]);
+        for (int j = 0; j < PC_XT; ++j) racc[j] = fmaf(hv, win[i + j], racc[j]);
       }
 #pragma unroll
       for (int j = 0; j < PC_XT; ++j) win[j] = win[j + 8];
     }
+#pragma unroll
+    for (int j = 0; j < PC_XT; ++j) acc[j] += racc[j];
   }
   float* o = cpre + ((size_t)b * P + p) * SM_CHW + y * SM_CW + x0;
 #pragma unroll

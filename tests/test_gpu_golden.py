@@ -41,4 +41,4 @@ def test_conv_mrf_vs_golden():
     eng.finalize()
     got = eng.conv_mrf(dev(load('conv_mrf_prior')), dev(load('conv_mrf_lik'))).cpu().numpy()
     eng.close()
-    np.testing.assert_allclose(got, load('conv_mrf_post'), rtol=2e-5, atol=0)
+    np.testing.assert_allclose(got, load("conv_mrf_post"), rtol=3e-6, atol=0)   # two-level fp32 summation
