@@ -16,9 +16,12 @@ namespace jcm {
 constexpr int C1_PT = 8;                      // output patch edge
 constexpr int C1_IN = 2 * (C1_PT - 1) + 5;    // 19 input rows/cols per patch
 
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <class TO>
 __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                     const float* __restrict__ bias, const float* __restrict__ scale,
-                                                    const float* __restrict__ shift, float* __restrict__ out,
+                                                    const float* __restrict__ shift, TO* __restrict__ out,
                                                     int H0, int W0, int sub, int Hin, int Win, int Ho, int Wo,
                                                     int pad_t, int pad_l, int Cout) {
   __shared__ float patch[C1_IN * C1_IN * 3];
@@ -60,31 +63,40 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
   }
   const int oy = oy0 + py, ox = ox0 + px;
   if (oy < Ho && ox < Wo) {
-    float* o = out + (((size_t)b * Ho + oy) * Wo + ox) * Cout + co0;
+    TO* o = out + (((size_t)b * Ho + oy) * Wo + ox) * Cout + co0;
 #pragma unroll
     for (int j = 0; j < 16; j += 4) {
-      float4 v;
-      float* vp = reinterpret_cast<float*>(&v);
+      float vp[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int co = co0 + j + t;
         vp[t] = fmaxf(acc[j + t] + bias[co], 0.f) * scale[co] + shift[co];
       }
-      *reinterpret_cast<float4*>(o + j) = v;
+      if constexpr (sizeof(TO) == 4) {
+        *reinterpret_cast<float4*>(o + j) = make_float4(vp[0], vp[1], vp[2], vp[3]);
+      } else {
+        bf16x4 v;
+        v[0] = (__bf16)vp[0]; v[1] = (__bf16)vp[1]; v[2] = (__bf16)vp[2]; v[3] = (__bf16)vp[3];
+        *reinterpret_cast<bf16x4*>(o + j) = v;
+      }
     }
   }
 }
 
 hipError_t conv1_5x5s2(const float* x, const float* w, const float* bias, const float* scale, const float* shift,
-                       float* out, int B, int H0, int W0, int sub, int Cout, hipStream_t st) {
+                       void* out, bool out_bf16, int B, int H0, int W0, int sub, int Cout, hipStream_t st) {
   if (Cout % 16 != 0 || Cout > 64 || H0 % sub != 0 || W0 % sub != 0) return hipErrorInvalidValue;
   const int Hin = H0 / sub, Win = W0 / sub;
   const int Ho = (Hin + 1) / 2, Wo = (Win + 1) / 2;
   const int tot_h = (Ho - 1) * 2 + 5 - Hin, tot_w = (Wo - 1) * 2 + 5 - Win;
   const int pad_t = (tot_h > 0 ? tot_h : 0) / 2, pad_l = (tot_w > 0 ? tot_w : 0) / 2;
   dim3 grid((Wo + C1_PT - 1) / C1_PT, (Ho + C1_PT - 1) / C1_PT, B);
-  hipLaunchKernelGGL(conv1_kernel, grid, dim3(64 * (Cout / 16)), 0, st, x, w, bias, scale, shift, out,
-                     H0, W0, sub, Hin, Win, Ho, Wo, pad_t, pad_l, Cout);
+  if (out_bf16)
+    hipLaunchKernelGGL(conv1_kernel<__bf16>, grid, dim3(64 * (Cout / 16)), 0, st, x, w, bias, scale, shift,
+                       static_cast<__bf16*>(out), H0, W0, sub, Hin, Win, Ho, Wo, pad_t, pad_l, Cout);
+  else
+    hipLaunchKernelGGL(conv1_kernel<float>, grid, dim3(64 * (Cout / 16)), 0, st, x, w, bias, scale, shift,
+                       static_cast<float*>(out), H0, W0, sub, Hin, Win, Ho, Wo, pad_t, pad_l, Cout);
   return hipGetLastError();
 }
 

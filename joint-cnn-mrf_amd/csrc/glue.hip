@@ -1,15 +1,48 @@
 // HBM-bound glue of the part detector and the heat-map ops: 2x2/2 SAME max-pool
 // (main.py:172-174), TF-1.x legacy bilinear resize (main.py:51,58,60,67,89), the three-branch
 // merge (main.py:58,67,69-70), spatial softmax (main.py:212-217) and per-joint argmax
-// (evaluation.py:15-24, main.py:389-397).  All NHWC fp32, 16-byte accesses along channels.
+// (evaluation.py:15-24, main.py:389-397).  NHWC; activations are fp32 (parity path) or bf16
+// (roofline path); arithmetic is always fp32; accesses are 4-channel vectors (16 B / 8 B).
 #include "kernels.h"
 
 namespace jcm {
 
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// 4 consecutive channels, loaded/stored as one vector
+template <class T> struct V4;
+template <> struct V4<float> {
+  using type = float4;
+  static __device__ __forceinline__ float4 ld(const float4* p) { return *p; }
+  static __device__ __forceinline__ void st(float4* p, float4 v) { *p = v; }
+};
+template <> struct V4<__bf16> {
+  using type = bf16x4;
+  static __device__ __forceinline__ float4 ld(const bf16x4* p) {
+    const bf16x4 v = *p;
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  }
+  static __device__ __forceinline__ void st(bf16x4* p, float4 v) {
+    bf16x4 o;
+    o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    *p = o;
+  }
+};
+
+static inline int grid_for(size_t total, int block = 256) {
+  size_t g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+__device__ __forceinline__ float4 max4(float4 a, float4 b) {
+  return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+
 // ------------------------------------------------------------------------------ max pool
 // SAME with k=2,s=2: out = ceil(in/2); padding (0 before, in%2 after) never wins the max.
-__global__ void max_pool_kernel(const float4* __restrict__ x, float4* __restrict__ out, int H, int W, int C4,
-                                int Ho, int Wo, size_t total) {
+template <class T>
+__global__ void max_pool_kernel(const typename V4<T>::type* __restrict__ x, typename V4<T>::type* __restrict__ out,
+                                int H, int W, int C4, int Ho, int Wo, size_t total) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = i % C4;
     size_t r = i / C4;
@@ -17,27 +50,26 @@ __global__ void max_pool_kernel(const float4* __restrict__ x, float4* __restrict
     const int oy = r % Ho;
     const size_t b = r / Ho;
     const int iy = oy * 2, ix = ox * 2;
-    const float4* base = x + (b * H * W) * C4 + c;
-    float4 m = base[((size_t)iy * W + ix) * C4];
+    const auto* base = x + (b * H * W) * C4 + c;
+    float4 m = V4<T>::ld(base + ((size_t)iy * W + ix) * C4);
     const bool hx = ix + 1 < W, hy = iy + 1 < H;
-    if (hx) { const float4 v = base[((size_t)iy * W + ix + 1) * C4]; m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w); }
-    if (hy) { const float4 v = base[((size_t)(iy + 1) * W + ix) * C4]; m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w); }
-    if (hx && hy) { const float4 v = base[((size_t)(iy + 1) * W + ix + 1) * C4]; m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w); }
-    out[i] = m;
+    if (hx) m = max4(m, V4<T>::ld(base + ((size_t)iy * W + ix + 1) * C4));
+    if (hy) m = max4(m, V4<T>::ld(base + ((size_t)(iy + 1) * W + ix) * C4));
+    if (hx && hy) m = max4(m, V4<T>::ld(base + ((size_t)(iy + 1) * W + ix + 1) * C4));
+    V4<T>::st(out + i, m);
   }
 }
 
-static inline int grid_for(size_t total, int block = 256) {
-  size_t g = (total + block - 1) / block;
-  return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
-}
-
-hipError_t max_pool_2x2(const float* x, float* out, int B, int H, int W, int C, hipStream_t st) {
+hipError_t max_pool_2x2(const void* x, void* out, bool bf16, int B, int H, int W, int C, hipStream_t st) {
   if (C % 4) return hipErrorInvalidValue;
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const size_t total = (size_t)B * Ho * Wo * (C / 4);
-  hipLaunchKernelGGL(max_pool_kernel, dim3(grid_for(total)), dim3(256), 0, st, reinterpret_cast<const float4*>(x),
-                     reinterpret_cast<float4*>(out), H, W, C / 4, Ho, Wo, total);
+  if (bf16)
+    hipLaunchKernelGGL(max_pool_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, static_cast<const bf16x4*>(x),
+                       static_cast<bf16x4*>(out), H, W, C / 4, Ho, Wo, total);
+  else
+    hipLaunchKernelGGL(max_pool_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, static_cast<const float4*>(x),
+                       static_cast<float4*>(out), H, W, C / 4, Ho, Wo, total);
   return hipGetLastError();
 }
 
@@ -46,7 +78,7 @@ hipError_t max_pool_2x2(const float* x, float* out, int B, int H, int W, int C, 
 // lo = floor(src); hi = min(lo+1, in-1); lerp = src-lo.  Lerp along x, then along y.
 struct Tap { int lo, hi; float t; };
 __device__ __forceinline__ Tap tf1_tap(int i, int in_size, float scale) {
-  const float src = __fmul_rn((float)i, scale);   // rounded product, as TF computes `in = i * scale`; no FMA with the subtract below
+  const float src = __fmul_rn((float)i, scale);   // rounded product, as TF computes `in = i * scale`
   Tap r;
   r.lo = (int)floorf(src);
   r.hi = min(r.lo + 1, in_size - 1);
@@ -58,15 +90,12 @@ __device__ __forceinline__ float lerp2(float tl, float tr, float bl, float br, f
   const float bot = bl + (br - bl) * tx;
   return top + (bot - top) * ty;
 }
-__device__ __forceinline__ float4 bilinear4(const float4* base, int W, int C4, Tap ty, Tap tx) {
-  const float4 tl = base[((size_t)ty.lo * W + tx.lo) * C4], tr = base[((size_t)ty.lo * W + tx.hi) * C4];
-  const float4 bl = base[((size_t)ty.hi * W + tx.lo) * C4], br = base[((size_t)ty.hi * W + tx.hi) * C4];
-  float4 o;
-  o.x = lerp2(tl.x, tr.x, bl.x, br.x, tx.t, ty.t);
-  o.y = lerp2(tl.y, tr.y, bl.y, br.y, tx.t, ty.t);
-  o.z = lerp2(tl.z, tr.z, bl.z, br.z, tx.t, ty.t);
-  o.w = lerp2(tl.w, tr.w, bl.w, br.w, tx.t, ty.t);
-  return o;
+template <class T>
+__device__ __forceinline__ float4 bilinear4(const typename V4<T>::type* base, int W, int C4, Tap ty, Tap tx) {
+  const float4 tl = V4<T>::ld(base + ((size_t)ty.lo * W + tx.lo) * C4), tr = V4<T>::ld(base + ((size_t)ty.lo * W + tx.hi) * C4);
+  const float4 bl = V4<T>::ld(base + ((size_t)ty.hi * W + tx.lo) * C4), br = V4<T>::ld(base + ((size_t)ty.hi * W + tx.hi) * C4);
+  return make_float4(lerp2(tl.x, tr.x, bl.x, br.x, tx.t, ty.t), lerp2(tl.y, tr.y, bl.y, br.y, tx.t, ty.t),
+                     lerp2(tl.z, tr.z, bl.z, br.z, tx.t, ty.t), lerp2(tl.w, tr.w, bl.w, br.w, tx.t, ty.t));
 }
 
 __global__ void resize_kernel_c4(const float4* __restrict__ x, float4* __restrict__ out, int H, int W, int C4, int OH,
@@ -77,7 +106,7 @@ __global__ void resize_kernel_c4(const float4* __restrict__ x, float4* __restric
     const int ox = r % OW; r /= OW;
     const int oy = r % OH;
     const size_t b = r / OH;
-    out[i] = bilinear4(x + b * H * W * C4 + c, W, C4, tf1_tap(oy, H, sy), tf1_tap(ox, W, sx));
+    out[i] = bilinear4<float>(x + b * H * W * C4 + c, W, C4, tf1_tap(oy, H, sy), tf1_tap(ox, W, sx));
   }
 }
 __global__ void resize_kernel_c1(const float* __restrict__ x, float* __restrict__ out, int H, int W, int C, int OH,
@@ -111,37 +140,40 @@ hipError_t resize_bilinear(const float* x, float* out, int B, int H, int W, int 
 }
 
 // x = (x1 + up(x2) + up(x3)) / 3 in the reference's association order ((x1+x2)+x3), then /3.
-__global__ void upsample_merge3_kernel(const float4* __restrict__ x1, const float4* __restrict__ x2, int H2, int W2,
-                                       const float4* __restrict__ x3, int H3, int W3, float4* __restrict__ out, int H,
-                                       int W, int C4, float sy2, float sx2, float sy3, float sx3, size_t total) {
+template <class T>
+__global__ void upsample_merge3_kernel(const typename V4<T>::type* __restrict__ x1, const typename V4<T>::type* __restrict__ x2,
+                                       int H2, int W2, const typename V4<T>::type* __restrict__ x3, int H3, int W3,
+                                       typename V4<T>::type* __restrict__ out, int H, int W, int C4, float sy2, float sx2,
+                                       float sy3, float sx3, size_t total) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = i % C4;
     size_t r = i / C4;
     const int ox = r % W; r /= W;
     const int oy = r % H;
     const size_t b = r / H;
-    const float4 a = x1[i];
-    const float4 u2 = (H2 == H && W2 == W) ? x2[i]
-                                           : bilinear4(x2 + b * H2 * W2 * C4 + c, W2, C4, tf1_tap(oy, H2, sy2), tf1_tap(ox, W2, sx2));
-    const float4 u3 = (H3 == H && W3 == W) ? x3[i]
-                                           : bilinear4(x3 + b * H3 * W3 * C4 + c, W3, C4, tf1_tap(oy, H3, sy3), tf1_tap(ox, W3, sx3));
-    float4 o;
-    o.x = ((a.x + u2.x) + u3.x) / 3.0f;
-    o.y = ((a.y + u2.y) + u3.y) / 3.0f;
-    o.z = ((a.z + u2.z) + u3.z) / 3.0f;
-    o.w = ((a.w + u2.w) + u3.w) / 3.0f;
-    out[i] = o;
+    const float4 a = V4<T>::ld(x1 + i);
+    const float4 u2 = (H2 == H && W2 == W) ? V4<T>::ld(x2 + i)
+                                           : bilinear4<T>(x2 + b * H2 * W2 * C4 + c, W2, C4, tf1_tap(oy, H2, sy2), tf1_tap(ox, W2, sx2));
+    const float4 u3 = (H3 == H && W3 == W) ? V4<T>::ld(x3 + i)
+                                           : bilinear4<T>(x3 + b * H3 * W3 * C4 + c, W3, C4, tf1_tap(oy, H3, sy3), tf1_tap(ox, W3, sx3));
+    V4<T>::st(out + i, make_float4(((a.x + u2.x) + u3.x) / 3.0f, ((a.y + u2.y) + u3.y) / 3.0f,
+                                   ((a.z + u2.z) + u3.z) / 3.0f, ((a.w + u2.w) + u3.w) / 3.0f));
   }
 }
 
-hipError_t upsample_merge3(const float* x1, const float* x2, int H2, int W2, const float* x3, int H3, int W3,
-                           float* out, int B, int H, int W, int C, hipStream_t st) {
+hipError_t upsample_merge3(const void* x1, const void* x2, int H2, int W2, const void* x3, int H3, int W3,
+                           void* out, bool bf16, int B, int H, int W, int C, hipStream_t st) {
   if (C % 4) return hipErrorInvalidValue;
   const size_t total = (size_t)B * H * W * (C / 4);
-  hipLaunchKernelGGL(upsample_merge3_kernel, dim3(grid_for(total)), dim3(256), 0, st,
-                     reinterpret_cast<const float4*>(x1), reinterpret_cast<const float4*>(x2), H2, W2,
-                     reinterpret_cast<const float4*>(x3), H3, W3, reinterpret_cast<float4*>(out), H, W, C / 4,
-                     (float)H2 / (float)H, (float)W2 / (float)W, (float)H3 / (float)H, (float)W3 / (float)W, total);
+  const float sy2 = (float)H2 / (float)H, sx2 = (float)W2 / (float)W, sy3 = (float)H3 / (float)H, sx3 = (float)W3 / (float)W;
+  if (bf16)
+    hipLaunchKernelGGL(upsample_merge3_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, static_cast<const bf16x4*>(x1),
+                       static_cast<const bf16x4*>(x2), H2, W2, static_cast<const bf16x4*>(x3), H3, W3,
+                       static_cast<bf16x4*>(out), H, W, C / 4, sy2, sx2, sy3, sx3, total);
+  else
+    hipLaunchKernelGGL(upsample_merge3_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, static_cast<const float4*>(x1),
+                       static_cast<const float4*>(x2), H2, W2, static_cast<const float4*>(x3), H3, W3,
+                       static_cast<float4*>(out), H, W, C / 4, sy2, sx2, sy3, sx3, total);
   return hipGetLastError();
 }
 

@@ -53,7 +53,9 @@ struct ConvLayer {
   int ks = 0, cin = 0, cout = 0, coutp = 0;
   bool has_bn = false;
   const float* w_raw = nullptr;   // HWIO (conv1 kernel reads it directly)
-  float* wp = nullptr;            // packed for conv_igemm
+  float* wp = nullptr;            // packed for conv_igemm_f32
+  void* wp_bf16 = nullptr;        // packed for conv_igemm_bf16
+  int coutp_bf16 = 0;
   const float* bias = nullptr;
   float* scale = nullptr;
   float* shift = nullptr;
@@ -175,17 +177,22 @@ const ConvLayer* conv_of(jcm_ctx* c, const std::string& scope) {
   return it == c->convs.end() ? nullptr : &it->second;
 }
 
-int run_conv(jcm_ctx* c, const std::string& scope, int stride, const float* x, int B, int H, int W, int sub, float* out) {
+// One conv layer.  Activations are fp32, or bf16 when the handle runs the bf16 path (`act_bf16`);
+// `out_f32` forces an fp32 result (the logits layer).
+int run_conv(jcm_ctx* c, const std::string& scope, int stride, const void* x, int B, int H, int W, int sub, void* out,
+             bool act_bf16, bool out_f32) {
   const ConvLayer* L = conv_of(c, scope);
   if (!L) return fail(JCM_ERR_STATE, "no conv layer '" + scope + "' (set '" + scope + "/weights' and finalize)");
   if (c->dry) return JCM_OK;
   if (stride == 2) {
     if (!(L->ks == 5 && L->cin == 3 && L->has_bn))
       return fail(JCM_ERR_ARG, "stride-2 kernel exists for 5x5, Cin=3, BN layers only (" + scope + ")");
-    HIP_TRY(conv1_5x5s2(x, L->w_raw, L->bias, L->scale, L->shift, out, B, H, W, sub, L->cout, c->stream));
+    HIP_TRY(conv1_5x5s2(static_cast<const float*>(x), L->w_raw, L->bias, L->scale, L->shift, out, act_bf16, B, H, W, sub,
+                        L->cout, c->stream));
     return JCM_OK;
   }
-  if (stride != 1 || !L->wp) return fail(JCM_ERR_ARG, "no kernel for layer '" + scope + "' with stride " + std::to_string(stride));
+  const void* wp = act_bf16 ? L->wp_bf16 : static_cast<const void*>(L->wp);
+  if (stride != 1 || !wp) return fail(JCM_ERR_ARG, "no kernel for layer '" + scope + "' with stride " + std::to_string(stride));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->profile) {
     HIP_TRY(hipEventCreate(&e0));
@@ -193,9 +200,15 @@ int run_conv(jcm_ctx* c, const std::string& scope, int stride, const float* x, i
     HIP_TRY(hipEventRecord(e0, c->stream));
   }
   ConvArgs a;
-  a.x = x; a.wp = L->wp; a.bias = L->bias; a.scale = L->scale; a.shift = L->shift; a.out = out;
-  a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout; a.CoutP = L->coutp; a.relu_bn = L->has_bn ? 1 : 0;
-  HIP_TRY(conv_igemm_f32(a, L->ks, c->stream));
+  a.x = x; a.wp = wp; a.bias = L->bias; a.scale = L->scale; a.shift = L->shift; a.out = out;
+  a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout; a.relu_bn = L->has_bn ? 1 : 0;
+  if (act_bf16) {
+    a.CoutP = L->coutp_bf16;
+    HIP_TRY(conv_igemm_bf16(a, L->ks, out_f32, c->stream));
+  } else {
+    a.CoutP = L->coutp;
+    HIP_TRY(conv_igemm_f32(a, L->ks, c->stream));
+  }
   if (c->profile) {
     HIP_TRY(hipEventRecord(e1, c->stream));
     c->prof[scope].emplace_back(e0, e1);
@@ -205,13 +218,16 @@ int run_conv(jcm_ctx* c, const std::string& scope, int stride, const float* x, i
 
 inline int cdiv2(int v) { return (v + 1) / 2; }
 
-// model(x, n_joints), main.py:29-74.
+// model(x, n_joints), main.py:29-74.  x fp32 NHWC; intermediate activations fp32 or bf16.
 int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logits) {
   static const char* const kRes[3] = {"fullres", "halfres", "quarterres"};
   const ConvLayer* L4 = conv_of(c, "conv4_fullres");
   const ConvLayer* L5 = conv_of(c, "conv5");
   if (!L4 || !L5 || !conv_of(c, "conv6")) return fail(JCM_ERR_STATE, "part-detector parameters incomplete");
-  float* x4[3];
+  const bool bf = c->precision == JCM_PRECISION_BF16;
+  const size_t es = bf ? 2 : 4;
+  auto act = [&](size_t elems) { return static_cast<void*>(arena_alloc<char>(c, elems * es)); };
+  void* x4[3];
   int h4[3], w4[3];
   // branch outputs survive the per-branch scratch, so carve them first
   for (int r = 0; r < 3; ++r) {
@@ -219,7 +235,7 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
     const int hin = H / sub, win = W / sub;                      // resize_images(x, [H//2, W//2]) main.py:51,60
     h4[r] = cdiv2(cdiv2(cdiv2(hin)));
     w4[r] = cdiv2(cdiv2(cdiv2(win)));
-    x4[r] = arena_alloc<float>(c, (size_t)B * h4[r] * w4[r] * L4->cout);
+    x4[r] = act((size_t)B * h4[r] * w4[r] * L4->cout);
   }
   for (int r = 0; r < 3; ++r) {
     const size_t mark = c->arena_off;
@@ -238,28 +254,28 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
       xin = xr; xh = hin; xw = win; xsub = 1;
     }
     const int h1 = cdiv2(hin), w1 = cdiv2(win);
-    float* c1 = arena_alloc<float>(c, (size_t)B * h1 * w1 * L1->cout);
-    JCM_TRY(run_conv(c, "conv1_" + res, 2, xin, B, xh, xw, xsub, c1));                  // main.py:44,52,61
+    void* c1 = act((size_t)B * h1 * w1 * L1->cout);
+    JCM_TRY(run_conv(c, "conv1_" + res, 2, xin, B, xh, xw, xsub, c1, bf, false));         // main.py:44,52,61
     const int h2 = cdiv2(h1), w2 = cdiv2(w1);
-    float* p1 = arena_alloc<float>(c, (size_t)B * h2 * w2 * L1->cout);
-    if (!c->dry) HIP_TRY(max_pool_2x2(c1, p1, B, h1, w1, L1->cout, c->stream));            // :45,53,62
-    float* c2 = arena_alloc<float>(c, (size_t)B * h2 * w2 * L2->cout);
-    JCM_TRY(run_conv(c, "conv2_" + res, 1, p1, B, h2, w2, 1, c2));                       // :46,54,63
+    void* p1 = act((size_t)B * h2 * w2 * L1->cout);
+    if (!c->dry) HIP_TRY(max_pool_2x2(c1, p1, bf, B, h1, w1, L1->cout, c->stream));         // :45,53,62
+    void* c2 = act((size_t)B * h2 * w2 * L2->cout);
+    JCM_TRY(run_conv(c, "conv2_" + res, 1, p1, B, h2, w2, 1, c2, bf, false));              // :46,54,63
     const int h3 = cdiv2(h2), w3 = cdiv2(w2);
-    float* p2 = arena_alloc<float>(c, (size_t)B * h3 * w3 * L2->cout);
-    if (!c->dry) HIP_TRY(max_pool_2x2(c2, p2, B, h2, w2, L2->cout, c->stream));            // :47,55,64
-    float* c3 = arena_alloc<float>(c, (size_t)B * h3 * w3 * L3->cout);
-    JCM_TRY(run_conv(c, "conv3_" + res, 1, p2, B, h3, w3, 1, c3));                       // :48,56,65
-    JCM_TRY(run_conv(c, "conv4_" + res, 1, c3, B, h3, w3, 1, x4[r]));                    // :49,57,66
+    void* p2 = act((size_t)B * h3 * w3 * L2->cout);
+    if (!c->dry) HIP_TRY(max_pool_2x2(c2, p2, bf, B, h2, w2, L2->cout, c->stream));         // :47,55,64
+    void* c3 = act((size_t)B * h3 * w3 * L3->cout);
+    JCM_TRY(run_conv(c, "conv3_" + res, 1, p2, B, h3, w3, 1, c3, bf, false));              // :48,56,65
+    JCM_TRY(run_conv(c, "conv4_" + res, 1, c3, B, h3, w3, 1, x4[r], bf, false));           // :49,57,66
     c->arena_off = mark;
   }
   const int hh = h4[0], ww = w4[0];
-  float* merged = arena_alloc<float>(c, (size_t)B * hh * ww * L4->cout);
+  void* merged = act((size_t)B * hh * ww * L4->cout);
   if (!c->dry)
-    HIP_TRY(upsample_merge3(x4[0], x4[1], h4[1], w4[1], x4[2], h4[2], w4[2], merged, B, hh, ww, L4->cout, c->stream));  // :58,67,69-70
-  float* c5 = arena_alloc<float>(c, (size_t)B * hh * ww * L5->cout);
-  JCM_TRY(run_conv(c, "conv5", 1, merged, B, hh, ww, 1, c5));                            // :71
-  JCM_TRY(run_conv(c, "conv6", 1, c5, B, hh, ww, 1, logits));                            // :72
+    HIP_TRY(upsample_merge3(x4[0], x4[1], h4[1], w4[1], x4[2], h4[2], w4[2], merged, bf, B, hh, ww, L4->cout, c->stream));  // :58,67,69-70
+  void* c5 = act((size_t)B * hh * ww * L5->cout);
+  JCM_TRY(run_conv(c, "conv5", 1, merged, B, hh, ww, 1, c5, bf, false));                   // :71
+  JCM_TRY(run_conv(c, "conv6", 1, c5, B, hh, ww, 1, logits, bf, true));                    // :72
   return JCM_OK;
 }
 
@@ -335,7 +351,6 @@ int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
   if (h->finalized) return fail(JCM_ERR_STATE, "options must be set before jcm_finalize");
   if (k == "precision") {
     if (value != JCM_PRECISION_F32 && value != JCM_PRECISION_BF16) return fail(JCM_ERR_ARG, "precision must be 0 (f32) or 1 (bf16)");
-    if (value == JCM_PRECISION_BF16) return fail(JCM_ERR_ARG, "bf16 kernels are not built into this library version");
     h->precision = (int)value;
   } else if (k == "n_joints") {
     if (value < 1 || value > 9) return fail(JCM_ERR_ARG, "n_joints must be in [1,9]");
@@ -389,12 +404,20 @@ int jcm_finalize(jcm_handle h) {
     L.bias = b->d;
     L.has_bn = find(c, scope + "/BatchNorm/gamma") != nullptr;
     if (L.has_bn) JCM_TRY(fold_bn(c, scope, L.cout, &L.scale, &L.shift));
-    if ((L.ks == 5 || L.ks == 9) && L.cin % 16 == 0) {
+    if ((L.ks == 5 || L.ks == 9) && L.cin % 16 == 0 && c->precision == JCM_PRECISION_F32) {
       const int bn = conv_igemm_bn(L.cout);
       L.coutp = (L.cout + bn - 1) / bn * bn;
       const size_t n = (size_t)L.ks * L.ks * L.cin * L.coutp;
       JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&L.wp), n * sizeof(float)));
       HIP_TRY(pack_weights_f32(w.d, L.wp, L.ks, L.cin, L.cout, L.coutp, c->stream));
+    }
+    if ((L.ks == 5 || L.ks == 9) && c->precision == JCM_PRECISION_BF16 && L.cin != 3) {
+      if (L.cin % 32 != 0) return fail(JCM_ERR_ARG, "bf16 path needs Cin % 32 == 0 ('" + scope + "' has " + std::to_string(L.cin) + ")");
+      const int bn = conv_igemm_bf16_bn(L.cout, L.ks);
+      L.coutp_bf16 = (L.cout + bn - 1) / bn * bn;
+      const size_t n = (size_t)L.ks * L.ks * L.cin * L.coutp_bf16;
+      JCM_TRY(dev_alloc(c, &L.wp_bf16, n * 2));
+      HIP_TRY(pack_weights_bf16(w.d, L.wp_bf16, L.ks, L.cin, L.cout, L.coutp_bf16, c->stream));
     }
     c->convs[scope] = L;
   }
@@ -439,14 +462,16 @@ int jcm_conv_layer(jcm_handle h, const char* scope, int stride, int last_layer, 
   if (!L) return fail(JCM_ERR_STATE, std::string("no conv layer '") + scope + "'");
   if ((last_layer != 0) == L->has_bn)
     return fail(JCM_ERR_ARG, std::string("last_layer flag disagrees with the BatchNorm parameters stored for '") + scope + "'");
-  return run_conv(h, scope, stride, x, B, H, W, 1, out);
+  if (h->precision != JCM_PRECISION_F32)
+    return fail(JCM_ERR_STATE, "per-layer entry points exchange fp32 activations; a bf16 handle runs jcm_pd_forward / jcm_forward");
+  return run_conv(h, scope, stride, x, B, H, W, 1, out, false, false);
 }
 
 int jcm_max_pool(jcm_handle h, const float* x, int B, int H, int W, int C, float* out) {
   JCM_TRY(check(h, false));
   if (!x || !out || B < 1 || H < 1 || W < 1 || C < 1 || C % 4) return fail(JCM_ERR_ARG, "bad max_pool arguments (C must be a multiple of 4)");
   DeviceGuard g(h->device);
-  HIP_TRY(max_pool_2x2(x, out, B, H, W, C, h->stream));
+  HIP_TRY(max_pool_2x2(x, out, false, B, H, W, C, h->stream));
   return JCM_OK;
 }
 

@@ -23,18 +23,26 @@ int conv_igemm_bn(int Cout);                     // N-tile the dispatcher will u
 hipError_t conv_igemm_f32(const ConvArgs& a, int ks, hipStream_t st);
 hipError_t pack_weights_f32(const float* w_hwio, float* wp, int ks, int Cin, int Cout, int CoutP, hipStream_t st);
 
+// ---- conv_igemm_bf16.hip : the same dataflow on v_mfma_f32_32x32x16_bf16 ---------------------
+// x bf16 NHWC (Cin % 32 == 0), packed weights bf16 [k*k][Cin/8][CoutP][8], out bf16 (fp32 when
+// out_f32: the logits layer).
+int conv_igemm_bf16_bn(int Cout, int ks);
+hipError_t conv_igemm_bf16(const ConvArgs& a, int ks, bool out_f32, hipStream_t st);
+hipError_t pack_weights_bf16(const float* w_hwio, void* wp, int ks, int Cin, int Cout, int CoutP, hipStream_t st);
+
 // ---- conv1.hip : 5x5 stride-2 SAME convolution of the (sub-sampled) RGB image ---------------
-// x [B,H0,W0,3]; the branch input is x[:, ::sub, ::sub] (TF-1.x bilinear with an integer scale
-// is pure sub-sampling, main.py:51,60); w HWIO [5,5,3,Cout]; out [B,Ho,Wo,Cout].
+// x [B,H0,W0,3] fp32; the branch input is x[:, ::sub, ::sub] (TF-1.x bilinear with an integer
+// scale is pure sub-sampling, main.py:51,60); w HWIO [5,5,3,Cout]; out [B,Ho,Wo,Cout] fp32 or bf16.
 hipError_t conv1_5x5s2(const float* x, const float* w, const float* bias, const float* scale, const float* shift,
-                       float* out, int B, int H0, int W0, int sub, int Cout, hipStream_t st);
+                       void* out, bool out_bf16, int B, int H0, int W0, int sub, int Cout, hipStream_t st);
 
 // ---- glue.hip ----------------------------------------------------------------------------------
-hipError_t max_pool_2x2(const float* x, float* out, int B, int H, int W, int C, hipStream_t st);
+// `bf16`: activations are bf16 instead of fp32 (arithmetic stays fp32).
+hipError_t max_pool_2x2(const void* x, void* out, bool bf16, int B, int H, int W, int C, hipStream_t st);
 hipError_t resize_bilinear(const float* x, float* out, int B, int H, int W, int C, int OH, int OW, hipStream_t st);
 // out = (x1 + resize(x2) + resize(x3)) / 3   (main.py:58,67,69-70); x1 [B,H,W,C]
-hipError_t upsample_merge3(const float* x1, const float* x2, int H2, int W2, const float* x3, int H3, int W3,
-                           float* out, int B, int H, int W, int C, hipStream_t st);
+hipError_t upsample_merge3(const void* x1, const void* x2, int H2, int W2, const void* x3, int H3, int W3,
+                           void* out, bool bf16, int B, int H, int W, int C, hipStream_t st);
 hipError_t concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, size_t N, hipStream_t st);
 hipError_t spatial_softmax(const float* in, float* out, int B, int HW, int K, hipStream_t st);
 hipError_t argmax_coords(const float* hm, int32_t* coords, int B, int HW, int WW, int K, hipStream_t st);
