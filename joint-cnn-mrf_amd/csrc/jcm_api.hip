@@ -80,6 +80,9 @@ struct jcm_ctx {
   float* bn_sm_shift = nullptr;
   int* cond = nullptr;          // [P] conditioning channel of pair p
   int* cond0 = nullptr;         // single zero (jcm_conv_mrf)
+  int sm_algo = 0;              // 0 = FFT (rocFFT), 1 = direct sliding-window VALU kernel
+  SmFft* fft = nullptr;
+  float2* prior_spec = nullptr; // [P][120*91] spectra of softplus5(energy)
   // workspace arena (stack allocator, grown on demand between forwards)
   char* arena = nullptr;
   size_t arena_cap = 0, arena_off = 0, arena_peak = 0;
@@ -279,16 +282,39 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
   return JCM_OK;
 }
 
+#define FFT_TRY(expr)                                                                 \
+  do {                                                                                \
+    const char* fe_ = (expr);                                                         \
+    if (fe_) return fail(JCM_ERR_HIP, std::string(#expr) + ": " + fe_);              \
+  } while (0)
+
+constexpr size_t kFrame = (size_t)kPrH * kPrW;          // 120*180 real
+constexpr size_t kSpec = (size_t)kPrH * (kPrW / 2 + 1); // 120*91 complex
+
 // spatial_model(heat_map), main.py:94-125.
 int sm_forward_impl(jcm_ctx* c, const float* hm10, int B, float* logits) {
   if (!c->has_sm) return fail(JCM_ERR_STATE, "spatial-model parameters (bn_sm, energy_*, bias_*) were not set");
   const int P = c->K * (kC - 1);
-  float* lik = arena_alloc<float>(c, (size_t)B * kC * kHmH * 96);
-  float* cpre = arena_alloc<float>(c, (size_t)B * P * kCH * kCW);
+  if (c->sm_algo == 1) {   // direct convolution
+    float* lik = arena_alloc<float>(c, (size_t)B * kC * kHmH * 96);
+    float* cpre = arena_alloc<float>(c, (size_t)B * P * kCH * kCW);
+    if (c->dry) return JCM_OK;
+    HIP_TRY(sm_likelihood(hm10, c->bn_sm_scale, c->bn_sm_shift, lik, B, kC, c->stream));
+    HIP_TRY(sm_pair_conv(c->sp_energy, lik, c->cond, cpre, B, P, kC, c->stream));
+    HIP_TRY(sm_finish(lik, cpre, c->sp_bias, logits, B, c->K, kC, c->stream));
+    return JCM_OK;
+  }
+  // FFT: 10 forward transforms + 81 products + 81 inverse transforms per image
+  float* frame = arena_alloc<float>(c, (size_t)B * kC * kFrame);
+  float2* lhat = arena_alloc<float2>(c, (size_t)B * kC * kSpec);
+  float2* spec = arena_alloc<float2>(c, (size_t)B * P * kSpec);
+  float* cfull = arena_alloc<float>(c, (size_t)B * P * kFrame);
   if (c->dry) return JCM_OK;
-  HIP_TRY(sm_likelihood(hm10, c->bn_sm_scale, c->bn_sm_shift, lik, B, kC, c->stream));
-  HIP_TRY(sm_pair_conv(c->sp_energy, lik, c->cond, cpre, B, P, kC, c->stream));
-  HIP_TRY(sm_finish(lik, cpre, c->sp_bias, logits, B, c->K, kC, c->stream));
+  HIP_TRY(sm_pad_frame(hm10, c->bn_sm_scale, c->bn_sm_shift, frame, B, kC, c->stream));
+  FFT_TRY(sm_fft_r2c(c->fft, frame, lhat, B * kC));
+  HIP_TRY(sm_spec_mul(lhat, c->prior_spec, c->cond, spec, B, kC, P, c->stream));
+  FFT_TRY(sm_fft_c2r(c->fft, spec, cfull, B * P));
+  HIP_TRY(sm_finish_fft(frame, cfull, c->sp_bias, logits, B, c->K, kC, c->stream));
   return JCM_OK;
 }
 
@@ -326,6 +352,7 @@ int jcm_create(int device, void* stream, jcm_handle* out) {
   jcm_ctx* c = new jcm_ctx();
   c->device = device;
   c->stream = static_cast<hipStream_t>(stream);
+  c->fft = sm_fft_create(c->stream);
   *out = c;
   return JCM_OK;
 }
@@ -334,6 +361,7 @@ int jcm_destroy(jcm_handle h) {
   if (!h) return JCM_OK;
   DeviceGuard g(h->device);
   (void)hipStreamSynchronize(h->stream);
+  sm_fft_destroy(h->fft);
   for (auto& kv : h->params) (void)hipFree(kv.second.d);
   for (void* p : h->owned) (void)hipFree(p);
   if (h->arena) (void)hipFree(h->arena);
@@ -346,6 +374,11 @@ int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
   const std::string k = key ? key : "";
   if (k == "profile") {   // allowed at any time
     h->profile = value != 0;
+    return JCM_OK;
+  }
+  if (k == "sm_algo") {   // allowed at any time
+    if (value != 0 && value != 1) return fail(JCM_ERR_ARG, "sm_algo must be 0 (fft) or 1 (direct)");
+    h->sm_algo = (int)value;
     return JCM_OK;
   }
   if (h->finalized) return fail(JCM_ERR_STATE, "options must be set before jcm_finalize");
@@ -444,6 +477,8 @@ int jcm_finalize(jcm_handle h) {
       }
     }
     HIP_TRY(hipMemcpyAsync(c->cond, cond.data(), P * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->prior_spec), (size_t)P * kSpec * sizeof(float2)));
+    FFT_TRY(sm_fft_r2c(c->fft, c->sp_energy, c->prior_spec, P));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->has_sm = true;
   }
@@ -504,12 +539,27 @@ int jcm_conv_mrf(jcm_handle h, const float* A, const float* Bmaps, int B, float*
   DeviceGuard g(h->device);
   jcm_ctx* c = h;
   return with_arena(c, [&] {
-    float* rev = arena_alloc<float>(c, (size_t)B * kHmH * 96);
-    float* cpre = arena_alloc<float>(c, (size_t)B * kCH * kCW);
+    if (c->sm_algo == 1) {
+      float* rev = arena_alloc<float>(c, (size_t)B * kHmH * 96);
+      float* cpre = arena_alloc<float>(c, (size_t)B * kCH * kCW);
+      if (c->dry) return (int)JCM_OK;
+      HIP_TRY(sm_likelihood(Bmaps, nullptr, nullptr, rev, B, 1, c->stream));     // reversed, padded copy
+      HIP_TRY(sm_pair_conv(A, rev, c->cond0, cpre, B, 1, 1, c->stream));         // main.py:83-87
+      HIP_TRY(sm_resize_only(cpre, out, B, c->stream));                          // main.py:89
+      return (int)JCM_OK;
+    }
+    float* frame = arena_alloc<float>(c, (size_t)B * kFrame);
+    float2* lhat = arena_alloc<float2>(c, (size_t)B * kSpec);
+    float2* ahat = arena_alloc<float2>(c, kSpec);
+    float2* spec = arena_alloc<float2>(c, (size_t)B * kSpec);
+    float* cfull = arena_alloc<float>(c, (size_t)B * kFrame);
     if (c->dry) return (int)JCM_OK;
-    HIP_TRY(sm_likelihood(Bmaps, nullptr, nullptr, rev, B, 1, c->stream));     // reversed, padded copy
-    HIP_TRY(sm_pair_conv(A, rev, c->cond0, cpre, B, 1, 1, c->stream));         // main.py:83-87
-    HIP_TRY(sm_resize_only(cpre, out, B, c->stream));                          // main.py:89
+    HIP_TRY(sm_pad_frame(Bmaps, nullptr, nullptr, frame, B, 1, c->stream));
+    FFT_TRY(sm_fft_r2c(c->fft, frame, lhat, B));
+    FFT_TRY(sm_fft_r2c(c->fft, A, ahat, 1));
+    HIP_TRY(sm_spec_mul(lhat, ahat, c->cond0, spec, B, 1, 1, c->stream));        // main.py:83-87
+    FFT_TRY(sm_fft_c2r(c->fft, spec, cfull, B));
+    HIP_TRY(sm_resize_frame(cfull, out, B, c->stream));                          // main.py:89
     return (int)JCM_OK;
   });
 }

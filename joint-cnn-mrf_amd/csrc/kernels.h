@@ -63,4 +63,18 @@ hipError_t sm_finish(const float* lik, const float* cpre, const float* spbias, f
 // out[b,pix] = R(cpre[b][0])[pix]   (the resize of main.py:89 on its own, for jcm_conv_mrf)
 hipError_t sm_resize_only(const float* cpre, float* out, int B, hipStream_t st);
 
+// ---- sm_fft.hip : the pairwise convolutions through rocFFT (hipFFT API) ----------------------------
+// Frames are 120x180 real; spectra 120x91 complex.  sm_fft_* return nullptr or an error string.
+struct SmFft;
+SmFft* sm_fft_create(hipStream_t st);
+void sm_fft_destroy(SmFft* f);
+const char* sm_fft_r2c(SmFft* f, const float* in, float2* out, int n);
+const char* sm_fft_c2r(SmFft* f, float2* in, float* out, int n);
+// frame[b][c] = softplus5(bn(hm[b,:,:,c])) in the top-left 60x90 of a zero 120x180 frame (sc null: raw)
+hipError_t sm_pad_frame(const float* hm, const float* sc, const float* sh, float* frame, int B, int C, hipStream_t st);
+// spec[b][p] = lhat[b][cond[p]] * phat[p] / (120*180)
+hipError_t sm_spec_mul(const float2* lhat, const float2* phat, const int* cond, float2* spec, int B, int C, int P, hipStream_t st);
+hipError_t sm_finish_fft(const float* frame, const float* cfull, const float* spbias, float* logits, int B, int K, int C, hipStream_t st);
+hipError_t sm_resize_frame(const float* cfull, float* out, int B, hipStream_t st);
+
 }  // namespace jcm

@@ -197,6 +197,11 @@ class Engine:
                                          self._p(r['pd_coords']), self._p(r.get('sm_coords'))), 'jcm_forward')
         return r
 
+    def set_sm_algo(self, algo):
+        """Pairwise-convolution algorithm of the spatial model: 'fft' (rocFFT, default) or
+        'direct' (LDS sliding-window VALU kernel).  Both are HIP paths; bench/profiles compare them."""
+        _lib.check(self._lib.jcm_set_option(self._h, b'sm_algo', {'fft': 0, 'direct': 1}[algo]), 'jcm_set_option(sm_algo)')
+
     def set_profile(self, on):
         _lib.check(self._lib.jcm_set_option(self._h, b'profile', int(bool(on))), 'jcm_set_option(profile)')
 

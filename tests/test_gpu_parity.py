@@ -112,25 +112,30 @@ def test_spatial_softmax_and_argmax(debug_setup):
     assert c.dtype == np.int32 and tuple(c[0, :, 0]) == (10, 20) and tuple(c[0, :, 1]) == (59, 89)
 
 
-def test_conv_mrf_delta_and_random(debug_setup):
+@pytest.mark.parametrize('algo', ['fft', 'direct'])
+def test_conv_mrf_delta_and_random(debug_setup, algo):
     eng, _ = debug_setup
+    eng.set_sm_algo(algo)
     rs = np.random.RandomState(12)
     A = rs.random_sample((1, 120, 180, 1)).astype(np.float32)
     Bm = np.zeros((3, 60, 90, 1), np.float32)
     Bm[0, 0, 0, 0] = Bm[1, 59, 89, 0] = Bm[2, 17, 42, 0] = 1.0          # KAT1
     got = eng.conv_mrf(dev(A), dev(Bm)).cpu().numpy()
-    np.testing.assert_allclose(got, O.conv_mrf(A.astype(np.float64), Bm.astype(np.float64)), atol=1e-6, rtol=0)
+    np.testing.assert_allclose(got, O.conv_mrf(A.astype(np.float64), Bm.astype(np.float64)), atol=2e-6, rtol=0)
     Br = rs.random_sample((2, 60, 90, 1)).astype(np.float32)
     ref = O.conv_mrf(A.astype(np.float64), Br.astype(np.float64))
     got = eng.conv_mrf(dev(A), dev(Br)).cpu().numpy()
-    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=0)   # 5400-term fp32 sums
+    eng.set_sm_algo('fft')
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=0)   # 5400-term fp32 sums / fp32 FFT
 
 
+@pytest.mark.parametrize('algo', ['fft', 'direct'])
 @pytest.mark.parametrize('kind', ['init', 'trained'])
-def test_spatial_model(kind):
+def test_spatial_model(kind, algo):
     from joint_cnn_mrf_amd.engine import Engine
     p = synth.make_sm_params(synth.synthetic_priors(), kind=kind)
     eng = Engine(device=0).load_params(p)
+    eng.set_sm_algo(algo)
     rs = np.random.RandomState(14)
     hm10 = np.concatenate([O.spatial_softmax(rs.standard_normal((2, 60, 90, 9)) * 4), synth.make_torso(2)], axis=3).astype(np.float32)
     ref = O.spatial_model(hm10.astype(np.float64), p)
