@@ -139,11 +139,13 @@ def main():
             'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32' if args.dtype == 'fp32' else 'bf16', 'data': 'synthetic',
-            'config': {'workload': 'configs[1]: batch=%d/GPU synthetic 480x720x3, part detector%s forward + argmax, %s%s'
-                                   % (B, ' + spatial model' if use_sm else '', args.dtype, ', DEBUG filters/4' if args.debug else ''),
+            'config': {'workload': '%s: batch=%d/GPU synthetic 480x720x3, part detector%s forward + argmax, %s%s'
+                                   % ('configs[1]' if args.dtype == 'fp32' else 'configs[2]', B, ' + spatial model' if use_sm else '',
+                                      args.dtype, ', DEBUG filters/4' if args.debug else ''),
                        'batch_per_gpu': B, 'global_batch': world * B, 'use_sm': use_sm, 'collective': 'all_gather coords int32 [B,2,9]'},
             'path_tflops': value * FLOPS_PD_SM / (16 if args.debug else 1) / 1e12,
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm 9x9 / 4x32 patch / 128-ch tile (conv4_fullres + conv5 launches)',
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm 9x9, 60x90 maps (conv4_fullres + conv5 launches; %s)'
+                                   % ('fp32 MFMA 32x32x2, 4x32 patch x 128 ch' if args.dtype == 'fp32' else 'bf16 MFMA 32x32x16, 6x32 patch x 256 ch'),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None,
                          'traffic': traffic, 'launch_ms': launch_ms, 'launches': tot_n, 'flops_per_launch': flops_launch},
         }

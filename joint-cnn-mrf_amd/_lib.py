@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libjcm.so')
+LIB_PATH = os.environ.get('JCM_LIB') or os.path.join(_HERE, 'libjcm.so')   # JCM_LIB: alternate build (kernel A/B experiments)
 
 JCM_PRECISION_F32 = 0
 JCM_PRECISION_BF16 = 1
