@@ -63,37 +63,10 @@ def cpu_baseline(n_images, params):
                       '(TensorFlow unavailable); host has %d logical CPUs' % (n_images, os.cpu_count())}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=64, help='images per GPU per step (configs[1]: 64)')
-    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'])
-    ap.add_argument('--no-sm', action='store_true', help='part detector only')
-    ap.add_argument('--debug', action='store_true', help='filters/4 (main.py:40-41); not the headline config')
-    ap.add_argument('--cpu-images', type=int, default=4, help='size of the cpu_baseline sample (0 = skip)')
-    args = ap.parse_args()
-
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    if args.gpus != world and rank == 0:
-        print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
-    dev = torch.device('cuda', local_rank)
-    torch.cuda.set_device(dev)
-    use_sm = not args.no_sm
-
-    params = synth.make_pd_params(debug=args.debug)                    # He init, BN identity (main.py:138-153)
-    if use_sm:
-        params.update(synth.make_sm_params(synth.synthetic_priors(), kind='init'))   # main.py:477-487
-    eng = Engine(device=local_rank, precision=args.dtype).load_params(params)
-
-    B = args.batch
+def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm):
+    """Time `args.steps` steps of one (dtype, batch) configuration; returns the result dict on
+    rank 0 (None elsewhere).  Timed region: barrier + synchronize on both sides, max over ranks."""
+    eng = Engine(device=local_rank, precision=dtype).load_params(params)
     x = torch.as_tensor(synth.make_images(B, seed=1234 + rank), device=dev)          # resident in HBM
     torso = torch.as_tensor(synth.make_torso(B, seed=4321 + rank), device=dev)
 
@@ -122,7 +95,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert coords.shape == (world * B, 2, 9)
-
+    out = None
     if rank == 0:
         tot_ms, tot_n, tot_flops = 0.0, 0, 0.0
         for scope, fl in FLOPS_DOMINANT.items():
@@ -131,24 +104,74 @@ def main():
         launch_ms = tot_ms / max(tot_n, 1)                     # average launch duration (HIP events, launch stream)
         flops_launch = tot_flops / max(tot_n, 1)               # average algorithmic FLOPs per launch
         achieved = flops_launch / (launch_ms * 1e-3) / 1e12 if tot_n else None
-        peak = PEAK_TFLOPS[args.dtype]
-        traffic = pmc_traffic('%s_b%d' % (args.dtype, B)) if not args.debug else None
+        peak = PEAK_TFLOPS[dtype]
         value = world * B * args.steps / dt
         out = {
-            'metric': 'images/sec (720x480, K=9 joints) part-detector+spatial-model fwd',
-            'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32' if args.dtype == 'fp32' else 'bf16', 'data': 'synthetic',
+            'value': value, 'ms_per_step': dt / args.steps * 1e3, 'dtype': 'f32' if dtype == 'fp32' else 'bf16',
             'config': {'workload': '%s: batch=%d/GPU synthetic 480x720x3, part detector%s forward + argmax, %s%s'
-                                   % ('configs[1]' if args.dtype == 'fp32' else 'configs[2]', B, ' + spatial model' if use_sm else '',
-                                      args.dtype, ', DEBUG filters/4' if args.debug else ''),
-                       'batch_per_gpu': B, 'global_batch': world * B, 'use_sm': use_sm, 'collective': 'all_gather coords int32 [B,2,9]'},
+                                   % ('configs[1]' if dtype == 'fp32' else 'configs[2]', B, ' + spatial model' if use_sm else '',
+                                      dtype, ', DEBUG filters/4' if args.debug else ''),
+                       'batch_per_gpu': B, 'global_batch': world * B, 'use_sm': use_sm,
+                       'collective': 'all_gather coords int32 [B,2,9]'},
             'path_tflops': value * FLOPS_PD_SM / (16 if args.debug else 1) / 1e12,
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm 9x9, 60x90 maps (conv4_fullres + conv5 launches; %s)'
-                                   % ('fp32 MFMA 32x32x2, 4x32 patch x 128 ch' if args.dtype == 'fp32' else 'bf16 MFMA 32x32x16, 6x32 patch x 256 ch'),
+                                   % ('fp32 MFMA 32x32x2, 4x32 patch x 128 ch' if dtype == 'fp32' else 'bf16 MFMA 32x32x16, 12x32 patch x 256 ch'),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None,
-                         'traffic': traffic, 'launch_ms': launch_ms, 'launches': tot_n, 'flops_per_launch': flops_launch},
+                         'traffic': pmc_traffic('%s_b%d' % (dtype, B)) if not args.debug else None,
+                         'launch_ms': launch_ms, 'launches': tot_n, 'flops_per_launch': flops_launch},
         }
+    eng.close()
+    del x, torso
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (default: 64 fp32 / 256 bf16)')
+    ap.add_argument('--dtype', default=None, choices=['fp32', 'bf16'],
+                    help='default: the headline line is configs[1] (fp32, batch 64) and configs[2] (bf16, batch 256) '
+                         'is measured too and reported under "bf16_config2"')
+    ap.add_argument('--no-sm', action='store_true', help='part detector only')
+    ap.add_argument('--debug', action='store_true', help='filters/4 (main.py:40-41); not the headline config, fp32 only')
+    ap.add_argument('--cpu-images', type=int, default=4, help='size of the cpu_baseline sample (0 = skip)')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    if args.gpus != world and rank == 0:
+        print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    use_sm = not args.no_sm
+
+    params = synth.make_pd_params(debug=args.debug)                    # He init, BN identity (main.py:138-153)
+    if use_sm:
+        params.update(synth.make_sm_params(synth.synthetic_priors(), kind='init'))   # main.py:477-487
+
+    head_dtype = args.dtype or 'fp32'
+    head_batch = args.batch or (64 if head_dtype == 'fp32' else 256)
+    head = run_config(args, head_dtype, head_batch, params, world, rank, local_rank, dev, use_sm)
+    second = None
+    if args.dtype is None and not args.debug:
+        second = run_config(args, 'bf16', args.batch or 256, params, world, rank, local_rank, dev, use_sm)
+
+    if rank == 0:
+        out = {'metric': 'images/sec (720x480, K=9 joints) part-detector+spatial-model fwd',
+               'value': head['value'], 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': head['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': head['dtype'], 'data': 'synthetic', 'config': head['config'], 'path_tflops': head['path_tflops'],
+               'roofline': head['roofline']}
+        if second is not None:
+            out['bf16_config2'] = second
         if args.cpu_images > 0:
             out['cpu_baseline'] = cpu_baseline(args.cpu_images, params)
         print(json.dumps(out))

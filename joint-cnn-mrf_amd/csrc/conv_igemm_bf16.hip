@@ -70,11 +70,7 @@ __device__ __forceinline__ void stage_steps(f32x4 (&fa)[2][C::MR], f32x4 (&fb)[2
   if constexpr (STEP < NSTEP) {
     constexpr int cur = STEP & 1;
     if constexpr (STEP + 1 < NSTEP) {
-#ifndef EXP_NOREAD
       frag_load<C, STEP + 1>(fa[cur ^ 1], fb[cur ^ 1], aaddr, baddr);
-#else
-      if (aaddr[0] == 0xffffffffu) frag_load<C, STEP + 1>(fa[cur ^ 1], fb[cur ^ 1], aaddr, baddr);
-#endif
       asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(C::MR + C::NR) : "memory");
     } else {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -127,9 +123,6 @@ __device__ __forceinline__ void rot_g(f32x4 (&fa)[2][C::MR], f32x4 (&fb)[C::NR],
       acc[f][G] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cur][f]),
                                                           __builtin_bit_cast(bf16x8, fb[G]), acc[f][G], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-#ifdef EXP_NOREAD
-    if (baddr[0] == 0xffffffffu)
-#endif
     if constexpr (more) b_load<C, STEP + 1>(fb[G], baddr[G]);
     rot_g<C, STEP, G + 1>(fa, fb, baddr, acc);
   }
@@ -139,9 +132,6 @@ __device__ __forceinline__ void stage_steps_rot(f32x4 (&fa)[2][C::MR], f32x4 (&f
                                                 const unsigned (&baddr)[C::NR], f32x16 (&acc)[C::MR][C::NR]) {
   constexpr int NSTEP = C::TPS * (C::U / 2);
   if constexpr (STEP < NSTEP) {
-#ifdef EXP_NOREAD
-    if (baddr[0] == 0xffffffffu)
-#endif
     if constexpr (STEP + 1 < NSTEP) a_load<C, STEP + 1>(fa[(STEP & 1) ^ 1], aaddr);
     rot_g<C, STEP, 0>(fa, fb, baddr, acc);
     stage_steps_rot<C, STEP + 1>(fa, fb, aaddr, baddr, acc);
@@ -251,9 +241,6 @@ __global__ __launch_bounds__(C::NT, (C::NT + 255) / 256) void conv_igemm_bf16_ke
   wdma(0, 0);
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     __syncthreads();   // every wave is done reading the previous chunk's halo
-#ifdef EXP_NOHALO
-    if (chunk == 0)
-#endif
     for (int idx = tid; idx < C::U * C::HH * C::WH; idx += C::NT) {
       const int u = idx & (C::U - 1);
       const int pix = idx >> 2;
@@ -267,13 +254,7 @@ __global__ __launch_bounds__(C::NT, (C::NT + 255) / 256) void conv_igemm_bf16_ke
     for (int s = 0; s < C::NSTAGE; ++s) {
       const int g = chunk * C::NSTAGE + s;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage g have landed
-#ifdef EXP_NOBAR
-      if (g < 2)
-#endif
       __syncthreads();                                      // ... and everyone's; buf^1 (stage g-1) is free
-#ifdef EXP_NODMA
-      if (g < 1)
-#endif
       if (g + 1 < nstage_total) wdma(g + 1, buf ^ 1);       // in flight behind this stage's MFMAs
       // ---- one stage = TPS taps x 2 k16-steps.  Fragment reads are software pipelined one step
       // ahead with hand-counted waits: hipcc sinks prefetched ds_reads back next to their MFMAs
