@@ -96,6 +96,11 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm):
         dt = float(t.item())
     assert coords.shape == (world * B, 2, 9)
     out = None
+    if rank == 0 and args.layer_times:
+        for scope, _k, _s, cin, cout, _l in synth.conv_scopes(args.debug):
+            if cin != 3:
+                ms, n = eng.profile_read(scope)     # destructive read: the roofline object below then sees no launches
+                print('layer %-18s %8.3f ms/launch  (%d launches)' % (scope, ms / max(n, 1), n), file=sys.stderr)
     if rank == 0:
         tot_ms, tot_n, tot_flops = 0.0, 0, 0.0
         for scope, fl in FLOPS_DOMINANT.items():
@@ -138,6 +143,7 @@ def main():
     ap.add_argument('--no-sm', action='store_true', help='part detector only')
     ap.add_argument('--debug', action='store_true', help='filters/4 (main.py:40-41); not the headline config, fp32 only')
     ap.add_argument('--cpu-images', type=int, default=4, help='size of the cpu_baseline sample (0 = skip)')
+    ap.add_argument('--layer-times', action='store_true', help='print the HIP-event time of every MFMA conv layer to stderr')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
