@@ -171,3 +171,38 @@ def test_shim_validates_before_the_call(debug_setup):
         eng.model(torch.zeros(1, 3, 480, 720, device='cuda:0').permute(0, 2, 3, 1))
     with pytest.raises(ValueError):
         eng.forward(torch.zeros(1, 480, 720, 3, device='cuda:0'), None, use_sm=True)
+
+
+def test_other_resolution_and_batch_shapes(debug_setup):
+    """The part detector is fully convolutional (main.py:34 only documents 480x720): a 240x368
+    image gives 30x46 maps, the quarter branch runs on 60x92 -> 8x12 with the SAME pool padding
+    in play; batch 1 and an odd batch go through the same kernels."""
+    eng, p = debug_setup
+    x = synth.make_images(3, seed=41, height=240, width=368)
+    ref = O.model(x, p)
+    got = eng.model(dev(x)).cpu().numpy()
+    assert got.shape == ref.shape == (3, 30, 46, 9)
+    np.testing.assert_allclose(got, ref, atol=logit_tol(ref), rtol=0)
+    one = eng.model(dev(x[:1])).cpu().numpy()
+    np.testing.assert_allclose(one, got[:1], atol=1e-6, rtol=0)       # batch-size independent (no cross-image term)
+    r = eng.forward(dev(x), None, use_sm=False)
+    np.testing.assert_array_equal(r['pd_coords'].cpu().numpy(), O.argmax_coords(O.spatial_softmax(ref)))
+    with pytest.raises(RuntimeError, match='60x90'):
+        eng.forward(dev(x), dev(synth.make_torso(3)), use_sm=True)      # the spatial model is 60x90-only
+
+
+def test_missing_parameters_fail_loudly():
+    from joint_cnn_mrf_amd.engine import Engine
+    p = synth.make_pd_params(debug=True)
+    del p['conv5/biases']
+    with pytest.raises(RuntimeError, match='conv5/biases'):
+        Engine(device=0).load_params(p)
+    eng = Engine(device=0).load_params(synth.make_pd_params(debug=True))
+    with pytest.raises(RuntimeError, match='spatial-model parameters'):
+        eng.spatial_model(torch.zeros(1, 60, 90, 10, device='cuda:0'))
+    with pytest.raises(RuntimeError, match='finalize'):
+        Engine(device=0).model(torch.zeros(1, 480, 720, 3, device='cuda:0'))
+    sm = synth.make_sm_params(synth.synthetic_priors())
+    del sm['energy_nose_torso']
+    with pytest.raises(RuntimeError, match='energy_nose_torso'):
+        Engine(device=0).load_params(sm)
