@@ -1,0 +1,138 @@
+// conv1 on the bf16 path: 5x5 stride-2 SAME convolution 3 -> 64 of the (sub-sampled) RGB image
+// fused with bias + ReLU + inference BatchNorm AND the 2x2/2 max-pool that follows it
+// (main.py:44-45, 52-53, 61-62), on v_mfma_f32_32x32x16_bf16.
+//
+// GEMM view: M = conv-output pixels, N = 64 channels, K = 5 kernel rows x 16 (the 5 px x 3 ch
+// = 15 contiguous input values of one kernel row, zero-padded to 16).  A workgroup owns a
+// 16x16 patch of conv outputs (-> 8x8 pooled pixels): the 35x35x3 input window goes to LDS as
+// bf16 once, every MFMA A fragment is 8 consecutive bf16 of a window row (4-byte aligned, read
+// as 4 ds_read_b32; 12-byte lane stride = conflict-free), B fragments come from a 10 KB packed
+// filter image.  The 32x32 accumulator layout keeps all four members of every 2x2 pooling
+// window in one lane, so the pool is register-local and only the pooled map is written:
+// 2.8 MB/image instead of 22 MB + 22 MB + 5.5 MB for the unfused conv1 -> pool pair.
+#include "kernels.h"
+
+namespace jcm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CM_T = 16;                        // conv-output patch edge
+constexpr int CM_IN = 2 * (CM_T - 1) + 5;       // 35 input rows / cols
+constexpr int CM_ROW = 112;                     // bf16 row pitch of the LDS window (35*3 = 105 -> 112)
+constexpr int CM_WQ_F4 = 5 * 2 * 64;            // packed filter: [ky][h][co] x 16 B
+
+__global__ __launch_bounds__(256) void conv1_mfma_pool_kernel(const float* __restrict__ x, const f32x4* __restrict__ wq,
+                                                              const float* __restrict__ bias, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, __bf16* __restrict__ out,
+                                                              int H0, int W0, int sub, int Hin, int Win, int Hp, int Wp,
+                                                              int pad_t, int pad_l, int tiles_x) {
+  __shared__ __attribute__((aligned(16))) __bf16 win[CM_IN * CM_ROW];
+  __shared__ __attribute__((aligned(16))) f32x4 wl[CM_WQ_F4];
+  const int b = blockIdx.y;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int oy0 = ty * CM_T, ox0 = tx * CM_T;
+  const int tid = threadIdx.x;
+  const float* xb = x + (size_t)b * H0 * W0 * 3;
+  for (int i = tid; i < CM_IN * CM_ROW; i += 256) {
+    const int iy = i / CM_ROW, e = i - iy * CM_ROW;
+    float v = 0.f;
+    if (e < CM_IN * 3) {
+      const int ix = e / 3, c = e - ix * 3;
+      const int gy = oy0 * 2 - pad_t + iy, gx = ox0 * 2 - pad_l + ix;
+      if ((unsigned)gy < (unsigned)Hin && (unsigned)gx < (unsigned)Win) v = xb[((size_t)(gy * sub) * W0 + gx * sub) * 3 + c];
+    }
+    win[i] = (__bf16)v;
+  }
+  for (int i = tid; i < CM_WQ_F4; i += 256) wl[i] = wq[i];
+  __syncthreads();
+
+  const int lane = tid & 63, wid = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int px = l31 & 15, pr = l31 >> 4;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[f][g][i] = 0.f;
+  const unsigned* win32 = reinterpret_cast<const unsigned*>(win);
+#pragma unroll
+  for (int ky = 0; ky < 5; ++ky) {
+    bf16x8 af[2], bf[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int py = 2 * (2 * wid + f) + pr;                                  // conv row inside the patch
+      const int e0 = ((2 * py + ky) * CM_ROW + 6 * px + 8 * h) >> 1;          // dword index (4-byte aligned)
+      u32x4 v;
+      v[0] = win32[e0]; v[1] = win32[e0 + 1]; v[2] = win32[e0 + 2]; v[3] = win32[e0 + 3];
+      af[f] = __builtin_bit_cast(bf16x8, v);
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) bf[g] = __builtin_bit_cast(bf16x8, wl[(ky * 2 + h) * 64 + g * 32 + l31]);
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) acc[f][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[f], bf[g], acc[f][g], 0, 0, 0);
+  }
+  // epilogue.  Accumulator reg i of lane (h, co) is fragment pixel r = (i&3) + 8*(i>>2) + 4*h, i.e.
+  // patch row (r>>4), column (r&15): regs {i, i+1} are horizontal neighbours (i even) and
+  // {i, i+8} vertical ones, so one lane holds whole 2x2 windows: pooled column q = (r&15)>>1.
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int co = g * 32 + l31;
+    const float bi = bias[co], sc = scale[co], sh = shift[co];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int PY = (oy0 >> 1) + 2 * wid + f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {                 // j -> regs (i0, i0+1, i0+8, i0+9), i0 = (j&1)*2 + (j>>1)*4
+        const int i0 = (j & 1) * 2 + (j >> 1) * 4;
+        const float v0 = fmaxf(acc[f][g][i0] + bi, 0.f) * sc + sh;
+        const float v1 = fmaxf(acc[f][g][i0 + 1] + bi, 0.f) * sc + sh;
+        const float v2 = fmaxf(acc[f][g][i0 + 8] + bi, 0.f) * sc + sh;
+        const float v3 = fmaxf(acc[f][g][i0 + 9] + bi, 0.f) * sc + sh;
+        const int r = (i0 & 3) + 8 * (i0 >> 2) + 4 * h;     // fragment pixel of reg i0 (row 0 of the pair)
+        const int PX = (ox0 >> 1) + ((r & 15) >> 1);
+        if (PY < Hp && PX < Wp)
+          out[(((size_t)b * Hp + PY) * Wp + PX) * 64 + co] = (__bf16)fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+      }
+    }
+  }
+}
+
+// HWIO [5,5,3,64] fp32 -> [ky][h][co][8] bf16, k' = 8h+i = 3*kx + c, k' = 15 is the zero pad.
+__global__ void pack_conv1_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wq) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= CM_WQ_F4 * 8) return;
+  const int e = i & 7, co = (i >> 3) & 63, h = (i >> 9) & 1, ky = i >> 10;
+  const int k = 8 * h + e;
+  float v = 0.f;
+  if (k < 15) v = w[(((size_t)ky * 5 + k / 3) * 3 + k % 3) * 64 + co];
+  wq[i] = (__bf16)v;
+}
+
+hipError_t pack_conv1_bf16(const float* w_hwio, void* wq, hipStream_t st) {
+  hipLaunchKernelGGL(pack_conv1_bf16_kernel, dim3((CM_WQ_F4 * 8 + 255) / 256), dim3(256), 0, st, w_hwio, static_cast<__bf16*>(wq));
+  return hipGetLastError();
+}
+
+// x [B,H0,W0,3] fp32 -> out [B,Hp,Wp,64] bf16 with Hp = (H0/sub)/4, Wp = (W0/sub)/4 (conv s2 then pool s2).
+// Requires H0/sub and W0/sub divisible by 4 (all three branches of the 480x720 model).
+hipError_t conv1_mfma_pool(const float* x, const void* wq, const float* bias, const float* scale, const float* shift,
+                           void* out, int B, int H0, int W0, int sub, hipStream_t st) {
+  if (H0 % (4 * sub) != 0 || W0 % (4 * sub) != 0) return hipErrorInvalidValue;
+  const int Hin = H0 / sub, Win = W0 / sub;
+  const int Ho = Hin / 2, Wo = Win / 2;
+  const int tot_h = (Ho - 1) * 2 + 5 - Hin, tot_w = (Wo - 1) * 2 + 5 - Win;     // SAME: 3 -> (1 before, 2 after)
+  const int pad_t = tot_h / 2, pad_l = tot_w / 2;
+  const int tiles_x = (Wo + CM_T - 1) / CM_T, tiles_y = (Ho + CM_T - 1) / CM_T;
+  hipLaunchKernelGGL(conv1_mfma_pool_kernel, dim3(tiles_x * tiles_y, B), dim3(256), 0, st, x, static_cast<const f32x4*>(wq), bias,
+                     scale, shift, static_cast<__bf16*>(out), H0, W0, sub, Hin, Win, Ho / 2, Wo / 2, pad_t, pad_l, tiles_x);
+  return hipGetLastError();
+}
+
+}  // namespace jcm

@@ -55,6 +55,7 @@ struct ConvLayer {
   const float* w_raw = nullptr;   // HWIO (conv1 kernel reads it directly)
   float* wp = nullptr;            // packed for conv_igemm_f32
   void* wp_bf16 = nullptr;        // packed for conv_igemm_bf16
+  void* wq1_bf16 = nullptr;       // packed for conv1_mfma_pool (5x5, Cin=3, Cout=64)
   int coutp_bf16 = 0;
   const float* bias = nullptr;
   float* scale = nullptr;
@@ -257,11 +258,19 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
       xin = xr; xh = hin; xw = win; xsub = 1;
     }
     const int h1 = cdiv2(hin), w1 = cdiv2(win);
-    void* c1 = act((size_t)B * h1 * w1 * L1->cout);
-    JCM_TRY(run_conv(c, "conv1_" + res, 2, xin, B, xh, xw, xsub, c1, bf, false));         // main.py:44,52,61
     const int h2 = cdiv2(h1), w2 = cdiv2(w1);
-    void* p1 = act((size_t)B * h2 * w2 * L1->cout);
-    if (!c->dry) HIP_TRY(max_pool_2x2(c1, p1, bf, B, h1, w1, L1->cout, c->stream));         // :45,53,62
+    void* p1;
+    if (bf && L1->wq1_bf16 && xh % (4 * xsub) == 0 && xw % (4 * xsub) == 0) {
+      // bf16 path: conv1 + ReLU/BN + pool1 in one MFMA kernel; only the pooled map touches HBM
+      p1 = act((size_t)B * h2 * w2 * L1->cout);
+      if (!c->dry)
+        HIP_TRY(conv1_mfma_pool(xin, L1->wq1_bf16, L1->bias, L1->scale, L1->shift, p1, B, xh, xw, xsub, c->stream));  // :44-45,52-53,61-62
+    } else {
+      void* c1 = act((size_t)B * h1 * w1 * L1->cout);
+      JCM_TRY(run_conv(c, "conv1_" + res, 2, xin, B, xh, xw, xsub, c1, bf, false));       // main.py:44,52,61
+      p1 = act((size_t)B * h2 * w2 * L1->cout);
+      if (!c->dry) HIP_TRY(max_pool_2x2(c1, p1, bf, B, h1, w1, L1->cout, c->stream));       // :45,53,62
+    }
     void* c2 = act((size_t)B * h2 * w2 * L2->cout);
     JCM_TRY(run_conv(c, "conv2_" + res, 1, p1, B, h2, w2, 1, c2, bf, false));              // :46,54,63
     const int h3 = cdiv2(h2), w3 = cdiv2(w2);
@@ -443,6 +452,10 @@ int jcm_finalize(jcm_handle h) {
       const size_t n = (size_t)L.ks * L.ks * L.cin * L.coutp;
       JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&L.wp), n * sizeof(float)));
       HIP_TRY(pack_weights_f32(w.d, L.wp, L.ks, L.cin, L.cout, L.coutp, c->stream));
+    }
+    if (L.ks == 5 && L.cin == 3 && L.cout == 64 && L.has_bn && c->precision == JCM_PRECISION_BF16) {
+      JCM_TRY(dev_alloc(c, &L.wq1_bf16, 5 * 2 * 64 * 16));
+      HIP_TRY(pack_conv1_bf16(w.d, L.wq1_bf16, c->stream));
     }
     if ((L.ks == 5 || L.ks == 9) && c->precision == JCM_PRECISION_BF16 && L.cin != 3) {
       if (L.cin % 32 != 0) return fail(JCM_ERR_ARG, "bf16 path needs Cin % 32 == 0 ('" + scope + "' has " + std::to_string(L.cin) + ")");

@@ -36,6 +36,12 @@ hipError_t pack_weights_bf16(const float* w_hwio, void* wp, int ks, int Cin, int
 hipError_t conv1_5x5s2(const float* x, const float* w, const float* bias, const float* scale, const float* shift,
                        void* out, bool out_bf16, int B, int H0, int W0, int sub, int Cout, hipStream_t st);
 
+// ---- conv1_mfma.hip : conv1 + bias/ReLU/BN + 2x2 max-pool fused, bf16 MFMA (bf16 path only) ----
+// x [B,H0,W0,3] fp32 (branch input = x[:, ::sub, ::sub]) -> out [B,(H0/sub)/4,(W0/sub)/4,64] bf16
+hipError_t pack_conv1_bf16(const float* w_hwio, void* wq, hipStream_t st);
+hipError_t conv1_mfma_pool(const float* x, const void* wq, const float* bias, const float* scale, const float* shift,
+                           void* out, int B, int H0, int W0, int sub, hipStream_t st);
+
 // ---- glue.hip ----------------------------------------------------------------------------------
 // `bf16`: activations are bf16 instead of fp32 (arithmetic stays fp32).
 hipError_t max_pool_2x2(const void* x, void* out, bool bf16, int B, int H, int W, int C, hipStream_t st);
