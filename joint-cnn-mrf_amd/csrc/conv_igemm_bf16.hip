@@ -19,10 +19,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int KS_, int TH_, int TW_, int BN_, int WM_, int WN_, int TPS_, bool ROT_ = false>
+template <int KS_, int TH_, int TW_, int BN_, int WM_, int WN_, int TPS_, bool ROT_ = false, bool FLAT_ = false>
 struct CfgB {
   static constexpr int KS = KS_, TH = TH_, TW = TW_, BN = BN_, WM = WM_, WN = WN_, TPS = TPS_;
   static constexpr bool ROT = ROT_;                 // rotating-B fragment schedule (big tiles, see stage_steps_rot)
+  // FLAT: the M tile is R whole rows of a NARROW map (30x45, 15x23) flattened to TH*TW pixel slots
+  // (R = floor(TH*TW / W), chosen at launch) instead of a TH x TW patch: a 12x16 patch wastes
+  // 28 % / 120 % of its slots on those maps, whole rows waste 14 % / 11 %.
+  static constexpr bool FLAT = FLAT_;
   static constexpr int NT = WM * WN * 64;           // threads
   static constexpr int U = 4;                       // 16-B units per chunk = 32 bf16 channels
   static constexpr int PAD = (KS - 1) / 2;
@@ -31,7 +35,7 @@ struct CfgB {
   // halo row pitch in 16-B slots: a 32-pixel fragment lies in one row (any pitch is conflict-free);
   // a 16-pixel-wide patch puts 2 rows in a fragment and needs the pitch to be a multiple of 16.
   static constexpr int WHP = TW == 32 ? WH : (WH + 15) / 16 * 16;
-  static constexpr int PLANE = HH * WHP + 2;
+  static constexpr int PLANE = FLAT ? 850 : HH * WHP + 2;   // FLAT: (R+k-1) x (W+k-1) <= 16x53 / 23x31 slots
   static constexpr int BM = TH * TW;
   static constexpr int MR = BM / WM / 32;
   static constexpr int NR = BN / WN / 32;
@@ -155,10 +159,12 @@ __global__ __launch_bounds__(C::NT, (C::NT + 255) / 256) void conv_igemm_bf16_ke
     mt = L / nN;
   }
   if (mt >= mtiles) return;
-  const int tx = mt % tiles_x;
-  const int ty = (mt / tiles_x) % tiles_y;
-  const int b = mt / (tiles_x * tiles_y);
-  const int y0 = ty * C::TH, x0 = tx * C::TW, n0 = nt * C::BN;
+  // FLAT tiles: `tiles_x` carries R (rows per tile), there is one tile across
+  const int flat_r = C::FLAT ? tiles_x : 0;
+  const int tx = C::FLAT ? 0 : mt % tiles_x;
+  const int ty = C::FLAT ? mt % tiles_y : (mt / tiles_x) % tiles_y;
+  const int b = C::FLAT ? mt / tiles_y : mt / (tiles_x * tiles_y);
+  const int y0 = ty * (C::FLAT ? flat_r : C::TH), x0 = tx * C::TW, n0 = nt * C::BN;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -170,11 +176,21 @@ __global__ __launch_bounds__(C::NT, (C::NT + 255) / 256) void conv_igemm_bf16_ke
   const __bf16* __restrict__ xb = static_cast<const __bf16*>(a.x) + (size_t)b * H * W * Cin;
   const __bf16* __restrict__ wp = static_cast<const __bf16*>(a.wp);
 
+  // halo geometry: compile-time for patches, per-launch for FLAT tiles
+  const int whp = C::FLAT ? W + C::KS - 1 : C::WHP;
+  const int wh = C::FLAT ? W + C::KS - 1 : C::WH;
+  const int hh = C::FLAT ? flat_r + C::KS - 1 : C::HH;
   int aslot[C::MR], bcol[C::NR];
 #pragma unroll
   for (int f = 0; f < C::MR; ++f) {
     const int r = (wm * C::MR + f) * 32 + l31;
-    aslot[f] = (r / C::TW) * C::WHP + (r % C::TW);
+    if constexpr (C::FLAT) {
+      const int rr = r < flat_r * W ? r : 0;          // padding slots compute on pixel 0 and are dropped
+      const int yy = rr / W;
+      aslot[f] = yy * whp + (rr - yy * W);
+    } else {
+      aslot[f] = (r / C::TW) * C::WHP + (r % C::TW);
+    }
   }
 #pragma unroll
   for (int g = 0; g < C::NR; ++g) bcol[g] = (wn * C::NR + g) * 32 + l31;
@@ -241,28 +257,26 @@ __global__ __launch_bounds__(C::NT, (C::NT + 255) / 256) void conv_igemm_bf16_ke
   wdma(0, 0);
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     __syncthreads();   // every wave is done reading the previous chunk's halo
-    for (int idx = tid; idx < C::U * C::HH * C::WH; idx += C::NT) {
+    for (int idx = tid; idx < C::U * hh * wh; idx += C::NT) {
       const int u = idx & (C::U - 1);
       const int pix = idx >> 2;
-      const int hy = pix / C::WH, hx = pix - hy * C::WH;
+      const int hy = pix / wh, hx = pix - hy * wh;
       const int gy = y0 - C::PAD + hy, gx = x0 - C::PAD + hx;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
         v = *reinterpret_cast<const f32x4*>(xb + ((size_t)gy * W + gx) * Cin + chunk * 32 + u * 8);
-      halo[u * C::PLANE + hy * C::WHP + hx] = v;
+      halo[u * C::PLANE + hy * whp + hx] = v;
     }
+    __syncthreads();   // halo visible before any wave's (pre-barrier) step-0 A reads
     for (int s = 0; s < C::NSTAGE; ++s) {
       const int g = chunk * C::NSTAGE + s;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage g have landed
-      __syncthreads();                                      // ... and everyone's; buf^1 (stage g-1) is free
-      if (g + 1 < nstage_total) wdma(g + 1, buf ^ 1);       // in flight behind this stage's MFMAs
       // ---- one stage = TPS taps x 2 k16-steps.  Fragment reads are software pipelined one step
       // ahead with hand-counted waits: hipcc sinks prefetched ds_reads back next to their MFMAs
       // and only ever waits lgkmcnt(0) here, which exposes a full LDS round trip per step, so
       // the reads are inline asm (the compiler then tracks none of them) and every wait is ours.
       const int tap0 = s * C::TPS;
       const int ky = tap0 / C::KS, kx0 = tap0 - ky * C::KS;      // TPS divides KS: one kernel row per stage
-      const unsigned tbytes = (unsigned)(ky * C::WHP + kx0) * 16u;
+      const unsigned tbytes = (unsigned)(ky * whp + kx0) * 16u;
       const unsigned wbytes = (unsigned)(C::HALO_F4 + buf * C::WSTAGE_F4) * 16u;
       unsigned aaddr[C::MR], baddr[C::NR];
 #pragma unroll
@@ -271,11 +285,23 @@ __global__ __launch_bounds__(C::NT, (C::NT + 255) / 256) void conv_igemm_bf16_ke
       for (int gq = 0; gq < C::NR; ++gq) baddr[gq] = bbase[gq] + wbytes;
       if constexpr (C::ROT) {
         f32x4 fa[2][C::MR], fb[C::NR];
+        // Stage boundary, ordered so that nothing waits idle: the A fragments of step 0 come from
+        // the halo (stable for the whole chunk) and are requested BEFORE the barrier; the weight
+        // DMA of the next stage is issued while the step-0 reads are in flight.
         a_load<C, 0>(fa[0], aaddr);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage g have landed
+        __builtin_amdgcn_s_barrier();                        // ... and everyone's; buf^1 (stage g-1) is free
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int gq = 0; gq < C::NR; ++gq) b_load<C, 0>(fb[gq], baddr[gq]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < nstage_total) wdma(g + 1, buf ^ 1);      // in flight behind this stage's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
         stage_steps_rot<C, 0>(fa, fb, aaddr, baddr, acc);
       } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (g + 1 < nstage_total) wdma(g + 1, buf ^ 1);
         f32x4 fa[2][C::MR], fb[2][C::NR];
         frag_load<C, 0>(fa[0], fb[0], aaddr, baddr);
         stage_steps<C, 0>(fa, fb, aaddr, baddr, acc);
@@ -297,8 +323,17 @@ __global__ __launch_bounds__(C::NT, (C::NT + 255) / 256) void conv_igemm_bf16_ke
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int r = (wm * C::MR + f) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        const int y = y0 + r / C::TW, x = x0 + r % C::TW;
-        if (y < H && x < W) {
+        int y, x;
+        bool ok;
+        if constexpr (C::FLAT) {
+          const int yy = r / W;
+          y = y0 + yy; x = r - yy * W;
+          ok = r < flat_r * W && y < H;
+        } else {
+          y = y0 + r / C::TW; x = x0 + r % C::TW;
+          ok = y < H && x < W;
+        }
+        if (ok) {
           float v = acc[f][g][i] + bi;
           if (a.relu_bn) v = fmaxf(v, 0.f) * sc + sh;
           const size_t o = (((size_t)b * H + y) * W + x) * Cout + co;
@@ -312,8 +347,16 @@ __global__ __launch_bounds__(C::NT, (C::NT + 255) / 256) void conv_igemm_bf16_ke
 
 template <class C, bool OUT_F32>
 static hipError_t launch_b(const ConvArgs& a, hipStream_t st) {
-  const int tiles_x = (a.W + C::TW - 1) / C::TW, tiles_y = (a.H + C::TH - 1) / C::TH;
-  const int mtiles = tiles_x * tiles_y * a.B;
+  int tiles_x = (a.W + C::TW - 1) / C::TW, tiles_y = (a.H + C::TH - 1) / C::TH;
+  int mtiles = tiles_x * tiles_y * a.B;
+  if constexpr (C::FLAT) {
+    int R = C::BM / a.W;
+    if (R > a.H) R = a.H;
+    if (R < 1 || (R + C::KS - 1) * (a.W + C::KS - 1) + 2 > C::PLANE) return hipErrorInvalidValue;
+    tiles_y = (a.H + R - 1) / R;
+    tiles_x = R;                      // the kernel reads R from this slot
+    mtiles = tiles_y * a.B;
+  }
   const int nN = a.CoutP / C::BN;
   int blocks;
   if ((8 % nN) == 0) {
@@ -348,6 +391,9 @@ hipError_t conv_igemm_bf16(const ConvArgs& a, int ks, bool out_f32, hipStream_t 
     // 60x90 / 120x180 maps: 12x32 patch x 256 channels, rotating-B schedule (half the weight stream
     // per FLOP of the 6x32 tile, 7 instead of 10 fragment reads per 12 MFMAs)
     if (bn == 256 && wide && a.H % 12 == 0) return launch_b<CfgB<9, 12, 32, 256, 4, 2, 3, true>, false>(a, st);
+    // narrow maps (30x45, 15x23): whole-row tiles, same rotating-B schedule
+    if (bn == 256 && !wide && (384 / a.W + 8) * (a.W + 8) + 2 <= 850 && a.W <= 48)
+      return launch_b<CfgB<9, 12, 32, 256, 4, 2, 3, true, true>, false>(a, st);
     if (bn == 256) return wide ? launch_b<CfgB<9, 6, 32, 256, 2, 4, 3>, false>(a, st) : launch_b<CfgB<9, 12, 16, 256, 2, 4, 3>, false>(a, st);
     if (bn == 128) return wide ? launch_b<CfgB<9, 6, 32, 128, 2, 4, 3>, false>(a, st) : launch_b<CfgB<9, 12, 16, 128, 2, 4, 3>, false>(a, st);
     if (bn == 64) return wide ? launch_b<CfgB<9, 6, 32, 64, 2, 2, 9>, false>(a, st) : launch_b<CfgB<9, 12, 16, 64, 2, 2, 9>, false>(a, st);
