@@ -91,7 +91,7 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm):
     dt = time.perf_counter() - t0
     eng.set_profile(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert coords.shape == (world * B, 2, 9)
@@ -149,10 +149,18 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # JCM_BENCH_BACKEND=gloo is a plumbing test of the N>1 flow on a single-GPU box (ranks share
+    # cuda:0, coords cross through host memory); the real multi-GPU run is nccl = RCCL over xGMI.
+    backend = os.environ.get('JCM_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0:
         print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
     dev = torch.device('cuda', local_rank)

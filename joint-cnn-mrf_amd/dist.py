@@ -34,7 +34,10 @@ def allgather_coords(local_coords, group=None):
         raise TypeError('coords must be int32')
     world = dist.get_world_size(group)
     local_coords = local_coords.contiguous()
+    dev = local_coords.device
+    if dist.get_backend(group) != 'nccl' and dev.type != 'cpu':
+        local_coords = local_coords.cpu()            # gloo moves host memory (CPU tests / plumbing runs)
     out = torch.empty((world * local_coords.shape[0],) + tuple(local_coords.shape[1:]), dtype=local_coords.dtype,
                       device=local_coords.device)
     dist.all_gather_into_tensor(out, local_coords, group=group)
-    return out
+    return out.to(dev)
