@@ -69,3 +69,36 @@ def test_bf16_path_vs_golden():
     assert (np.abs(sm_c - ref_sm).max(axis=1) <= 1).mean() >= 0.85
     with pytest.raises(RuntimeError, match='fp32 activations'):
         Engine(device=0, precision='bf16').load_params(p).conv_layer(dev(np.zeros((1, 60, 90, 512))), 'conv5', 1, n_out=512)
+
+
+def test_config2_batch64_properties():
+    """BASELINE configs[1] at its full size (batch 64, fp32, full-width network, FLIC priors),
+    checked through size-independent properties: the first two images reproduce the goldens
+    (no cross-image term: BatchNorm is in inference mode), every heat map is a distribution,
+    and the returned coordinates are the first-occurrence arg-max of the returned maps."""
+    from joint_cnn_mrf_amd.engine import Engine
+    x2, torso2, p = full_inputs()
+    p.update(synth.make_sm_params(flic_priors(), kind='trained', seed=seeds()['sm']))
+    eng = Engine(device=0).load_params(p)
+    B = 64
+    x = np.concatenate([x2, synth.make_images(B - 2, seed=77)], axis=0)
+    torso = np.concatenate([torso2, synth.make_torso(B - 2, seed=78)], axis=0)
+    r = eng.forward(dev(x), dev(torso), use_sm=True)
+    eng.close()
+    pd, sm = r['pd_prob'].cpu().numpy(), r['sm_prob'].cpu().numpy()
+    assert pd.shape == sm.shape == (B, 60, 90, 9)
+    np.testing.assert_allclose(pd.sum(axis=(1, 2)), 1.0, rtol=2e-5)
+    np.testing.assert_allclose(sm.sum(axis=(1, 2)), 1.0, rtol=2e-5)
+    assert np.isfinite(pd).all() and np.isfinite(sm).all() and pd.min() >= 0 and sm.min() >= 0
+    np.testing.assert_array_equal(r['pd_coords'].cpu().numpy(), O.argmax_coords(pd))
+    np.testing.assert_array_equal(r['sm_coords'].cpu().numpy(), O.argmax_coords(sm))
+    np.testing.assert_array_equal(r['pd_coords'].cpu().numpy()[:2], load('full_pd_coords'))
+    np.testing.assert_array_equal(r['sm_coords'].cpu().numpy()[:2], load('full_sm_coords_trained'))
+    np.testing.assert_allclose(sm[:2], O.spatial_softmax(load('full_sm_logits_trained').astype(np.float64)), atol=1e-4, rtol=0)
+    # images further down the batch went through other workgroups/XCDs: spot-check one against a
+    # single-image forward of the same engine parameters
+    eng1 = Engine(device=0).load_params(p)
+    one = eng1.forward(dev(x[37:38]), dev(torso[37:38]), use_sm=True)
+    eng1.close()
+    np.testing.assert_allclose(one['sm_prob'].cpu().numpy(), sm[37:38], atol=1e-6, rtol=0)
+    np.testing.assert_array_equal(one['sm_coords'].cpu().numpy(), r['sm_coords'].cpu().numpy()[37:38])
