@@ -57,6 +57,7 @@ struct ConvLayer {
   void* wp_bf16 = nullptr;        // packed for conv_igemm_bf16
   void* wq1_bf16 = nullptr;       // packed for conv1_mfma_pool (5x5, Cin=3, Cout=64)
   int coutp_bf16 = 0;
+  bool thin = false;              // fp32: conv_thin_f32 instead of conv_igemm_f32
   const float* bias = nullptr;
   float* scale = nullptr;
   float* shift = nullptr;
@@ -212,7 +213,8 @@ int run_conv(jcm_ctx* c, const std::string& scope, int stride, const void* x, in
     HIP_TRY(conv_igemm_bf16(a, L->ks, out_f32, c->stream));
   } else {
     a.CoutP = L->coutp;
-    HIP_TRY(conv_igemm_f32(a, L->ks, c->stream));
+    if (L->thin) HIP_TRY(conv_thin_f32(a, c->stream));
+    else HIP_TRY(conv_igemm_f32(a, L->ks, c->stream));
   }
   if (c->profile) {
     HIP_TRY(hipEventRecord(e1, c->stream));
@@ -459,7 +461,8 @@ int jcm_finalize(jcm_handle h) {
     L.has_bn = find(c, scope + "/BatchNorm/gamma") != nullptr;
     if (L.has_bn) JCM_TRY(fold_bn(c, scope, L.cout, &L.scale, &L.shift));
     if ((L.ks == 5 || L.ks == 9) && L.cin % 16 == 0 && c->precision == JCM_PRECISION_F32) {
-      const int bn = conv_igemm_bn(L.cout);
+      L.thin = L.ks == 9 && L.cout <= 12;            // logits layer: 4x4x1_16b MFMA kernel, channels padded to 16
+      const int bn = L.thin ? 16 : conv_igemm_bn(L.cout);
       L.coutp = (L.cout + bn - 1) / bn * bn;
       const size_t n = (size_t)L.ks * L.ks * L.cin * L.coutp;
       JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&L.wp), n * sizeof(float)));

@@ -23,6 +23,10 @@ int conv_igemm_bn(int Cout);                     // N-tile the dispatcher will u
 hipError_t conv_igemm_f32(const ConvArgs& a, int ks, hipStream_t st);
 hipError_t pack_weights_f32(const float* w_hwio, float* wp, int ks, int Cin, int Cout, int CoutP, hipStream_t st);
 
+// ---- conv_thin_f32.hip : 9x9 conv with Cout <= 12 (the logits layer) on v_mfma_f32_4x4x1_16b_f32 ----
+// weights packed by pack_weights_f32 with CoutP = 16
+hipError_t conv_thin_f32(const ConvArgs& a, hipStream_t st);
+
 // ---- conv_igemm_bf16.hip : the same dataflow on v_mfma_f32_32x32x16_bf16 ---------------------
 // x bf16 NHWC (Cin % 32 == 0), packed weights bf16 [k*k][Cin/8][CoutP][8], out bf16 (fp32 when
 // out_f32: the logits layer).
