@@ -36,15 +36,22 @@ __global__ __launch_bounds__(256) void conv1_mfma_pool_kernel(const float* __res
   const int oy0 = ty * CM_T, ox0 = tx * CM_T;
   const int tid = threadIdx.x;
   const float* xb = x + (size_t)b * H0 * W0 * 3;
-  for (int i = tid; i < CM_IN * CM_ROW; i += 256) {
-    const int iy = i / CM_ROW, e = i - iy * CM_ROW;
-    float v = 0.f;
-    if (e < CM_IN * 3) {
-      const int ix = e / 3, c = e - ix * 3;
-      const int gy = oy0 * 2 - pad_t + iy, gx = ox0 * 2 - pad_l + ix;
-      if ((unsigned)gy < (unsigned)Hin && (unsigned)gx < (unsigned)Win) v = xb[((size_t)(gy * sub) * W0 + gx * sub) * 3 + c];
+  // window -> LDS as bf16, one pixel (3 contiguous floats = one dwordx3 load) per thread-iteration;
+  // the 7-element tail of every 112-element row is zeroed once (it only ever meets zero weights)
+  for (int i = tid; i < CM_IN * CM_IN; i += 256) {
+    const int iy = i / CM_IN, ix = i - iy * CM_IN;
+    const int gy = oy0 * 2 - pad_t + iy, gx = ox0 * 2 - pad_l + ix;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+    if ((unsigned)gy < (unsigned)Hin && (unsigned)gx < (unsigned)Win) {
+      const float* px3 = xb + ((size_t)(gy * sub) * W0 + gx * sub) * 3;
+      v0 = px3[0]; v1 = px3[1]; v2 = px3[2];
     }
-    win[i] = (__bf16)v;
+    __bf16* w3 = win + iy * CM_ROW + ix * 3;
+    w3[0] = (__bf16)v0; w3[1] = (__bf16)v1; w3[2] = (__bf16)v2;
+  }
+  for (int i = tid; i < CM_IN * (CM_ROW - CM_IN * 3); i += 256) {
+    const int iy = i / (CM_ROW - CM_IN * 3), e = i - iy * (CM_ROW - CM_IN * 3);
+    win[iy * CM_ROW + CM_IN * 3 + e] = (__bf16)0.f;
   }
   for (int i = tid; i < CM_WQ_F4; i += 256) wl[i] = wq[i];
   __syncthreads();
