@@ -1,0 +1,69 @@
+"""Parameter-file format (TF variable naming) and Hypothesis property tests between the two
+oracle formulations on small random shapes."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import given, settings, strategies as st
+
+import joint_cnn_mrf_amd  # noqa: F401
+from joint_cnn_mrf_amd import checkpoint, synth
+from oracle import jcm_oracle as O
+from oracle import jcm_oracle_torch as T
+
+
+def test_npz_roundtrip_and_validation(tmp_path):
+    p = synth.make_pd_params(debug=True)
+    p.update(synth.make_sm_params(synth.synthetic_priors()))
+    p['n_iters'] = np.zeros((), np.float32)                    # saved by the reference, not read by inference
+    p['conv5/weights/Adam'] = np.zeros((9, 9, 128, 128), np.float32)
+    path = str(tmp_path / 'model.npz')
+    checkpoint.save_npz(path, p)
+    q = checkpoint.load_npz(path, debug=True)
+    want = checkpoint.expected_shapes(debug=True)
+    assert sorted(q) == sorted(want) and len(want) == 6 * 13 + 2 + 4 + 162
+    for k in want:
+        np.testing.assert_array_equal(q[k], p[k])
+    assert want['conv1_halfres/weights'] == (5, 5, 3, 16) and want['energy_lsho_torso'] == (1, 120, 180, 1)
+    bad = dict(p)
+    del bad['conv6/biases']
+    bad['bias_nose_lwri'] = np.zeros((60, 90), np.float32)
+    checkpoint.save_npz(path, bad)
+    with pytest.raises(ValueError) as ei:
+        checkpoint.load_npz(path, debug=True)
+    assert 'missing conv6/biases' in str(ei.value) and 'bias_nose_lwri' in str(ei.value)
+    with pytest.raises(ValueError):
+        checkpoint.load_npz(path, debug=False)                  # full-size model expects 64..512 filters
+
+
+@settings(max_examples=25, deadline=None)
+@given(h=st.integers(5, 23), w=st.integers(5, 23), cin=st.integers(1, 4), cout=st.integers(1, 4),
+       k=st.sampled_from([5, 9]), stride=st.sampled_from([1, 2]), seed=st.integers(0, 10 ** 6))
+def test_conv_same_padding_property(h, w, cin, cout, k, stride, seed):
+    """NumPy slicing conv == torch conv with explicit asymmetric padding, any size / stride."""
+    rs = np.random.RandomState(seed)
+    x = rs.standard_normal((2, h, w, cin))
+    wt = rs.standard_normal((k, k, cin, cout))
+    a = O.conv2d_same(x, wt, stride)
+    b = T.conv2d_same(torch.as_tensor(x).permute(0, 3, 1, 2), torch.as_tensor(wt), stride).permute(0, 2, 3, 1).numpy()
+    assert a.shape == (2, -(-h // stride), -(-w // stride), cout)
+    np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-10)
+
+
+@settings(max_examples=25, deadline=None)
+@given(h=st.integers(1, 31), w=st.integers(1, 31), oh=st.integers(1, 40), ow=st.integers(1, 40), seed=st.integers(0, 10 ** 6))
+def test_resize_property(h, w, oh, ow, seed):
+    x = np.random.RandomState(seed).standard_normal((1, h, w, 2))
+    a = O.resize_bilinear_tf1(x, oh, ow)
+    b = T.resize_bilinear_tf1(torch.as_tensor(x).permute(0, 3, 1, 2), oh, ow).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-12)
+    assert a.min() >= x.min() - 1e-12 and a.max() <= x.max() + 1e-12      # bilinear is a convex combination
+
+
+@settings(max_examples=20, deadline=None)
+@given(h=st.integers(1, 17), w=st.integers(1, 17), seed=st.integers(0, 10 ** 6))
+def test_pool_property(h, w, seed):
+    x = np.random.RandomState(seed).standard_normal((1, h, w, 3))
+    a = O.max_pool_same(x)
+    b = T.max_pool_same(torch.as_tensor(x).permute(0, 3, 1, 2)).permute(0, 2, 3, 1).numpy()
+    assert a.shape == (1, (h + 1) // 2, (w + 1) // 2, 3)
+    np.testing.assert_array_equal(a, b)
