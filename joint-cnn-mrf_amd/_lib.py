@@ -46,6 +46,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and not os.environ.get('JCM_LIB'):
+        # A source-only checkout (the .so is git-ignored): compile the HIP library in place.  This
+        # builds the product, it is not a fallback -- without hipcc the load still fails below.
+        hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+        if os.path.exists(hipcc):
+            import subprocess
+            subprocess.call(['make', '-C', os.path.join(_HERE, 'csrc'), '-j8'],
+                            env=dict(os.environ, HIPCC=hipcc), stdout=subprocess.DEVNULL)
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             'libjcm.so is not built (%s). Run `python -c "import __graft_entry__ as g; g.build()"` or '
