@@ -58,6 +58,7 @@ struct ConvLayer {
   void* wq1_bf16 = nullptr;       // packed for conv1_mfma_pool (5x5, Cin=3, Cout=64)
   int coutp_bf16 = 0;
   bool thin = false;              // fp32: conv_thin_f32 instead of conv_igemm_f32
+  bool thin_bf16 = false;         // bf16: conv_thin_bf16 (fp32 output) instead of conv_igemm_bf16
   const float* bias = nullptr;
   float* scale = nullptr;
   float* shift = nullptr;
@@ -210,7 +211,8 @@ int run_conv(jcm_ctx* c, const std::string& scope, int stride, const void* x, in
   a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout; a.relu_bn = L->has_bn ? 1 : 0;
   if (act_bf16) {
     a.CoutP = L->coutp_bf16;
-    HIP_TRY(conv_igemm_bf16(a, L->ks, out_f32, c->stream));
+    if (L->thin_bf16 && out_f32) HIP_TRY(conv_thin_bf16(a, c->stream));
+    else HIP_TRY(conv_igemm_bf16(a, L->ks, out_f32, c->stream));
   } else {
     a.CoutP = L->coutp;
     if (L->thin) HIP_TRY(conv_thin_f32(a, c->stream));
@@ -474,7 +476,8 @@ int jcm_finalize(jcm_handle h) {
     }
     if ((L.ks == 5 || L.ks == 9) && c->precision == JCM_PRECISION_BF16 && L.cin != 3) {
       if (L.cin % 32 != 0) return fail(JCM_ERR_ARG, "bf16 path needs Cin % 32 == 0 ('" + scope + "' has " + std::to_string(L.cin) + ")");
-      const int bn = conv_igemm_bf16_bn(L.cout, L.ks);
+      L.thin_bf16 = L.ks == 9 && L.cout <= 16 && !L.has_bn;   // logits layer: 16x16x32 MFMA kernel, fp32 out
+      const int bn = L.thin_bf16 ? 16 : conv_igemm_bf16_bn(L.cout, L.ks);
       L.coutp_bf16 = (L.cout + bn - 1) / bn * bn;
       const size_t n = (size_t)L.ks * L.ks * L.cin * L.coutp_bf16;
       JCM_TRY(dev_alloc(c, &L.wp_bf16, n * 2));

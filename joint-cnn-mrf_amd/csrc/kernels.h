@@ -27,6 +27,10 @@ hipError_t pack_weights_f32(const float* w_hwio, float* wp, int ks, int Cin, int
 // weights packed by pack_weights_f32 with CoutP = 16
 hipError_t conv_thin_f32(const ConvArgs& a, hipStream_t st);
 
+// ---- conv_thin_bf16.hip : the logits layer on v_mfma_f32_16x16x32_bf16 (bf16 in, fp32 out, Cout <= 16) ----
+// weights packed by pack_weights_bf16 with CoutP = 16
+hipError_t conv_thin_bf16(const ConvArgs& a, hipStream_t st);
+
 // ---- conv_igemm_bf16.hip : the same dataflow on v_mfma_f32_32x32x16_bf16 ---------------------
 // x bf16 NHWC (Cin % 32 == 0), packed weights bf16 [k*k][Cin/8][CoutP][8], out bf16 (fp32 when
 // out_f32: the logits layer).
