@@ -12,7 +12,7 @@
 // LDS images are [16-byte unit][slot][4 floats]: a lane's ds_read_b128 delivers 4 consecutive
 // K values of its row/column, and lanes of one 16-lane read group hit 16 distinct 16-B slots
 // (halo rows are padded to a multiple of 16 slots), i.e. conflict-free ds_read_b128.
-// The K order inside a 32-channel... inside an 8-channel step is permuted (half-wave h takes
+// The K order inside an 8-channel step is permuted (half-wave h takes
 // channels 4h..4h+3) identically for A and B, which MFMA permits because K is a contraction.
 #include "kernels.h"
 
@@ -21,9 +21,12 @@ namespace jcm {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int KS_, int TH_, int TW_, int BN_, int WM_, int WN_, int TPS_>
+template <int KS_, int TH_, int TW_, int BN_, int WM_, int WN_, int TPS_, bool FLAT_ = false>
 struct Cfg {
   static constexpr int KS = KS_, TH = TH_, TW = TW_, BN = BN_, WM = WM_, WN = WN_, TPS = TPS_;
+  // FLAT: the 128 pixel slots are R whole rows of a narrow map (R = floor(128 / W), set at launch)
+  // instead of a TH x TW patch: a 15x23 map costs 3 tiles x 128 slots instead of 4 x 128.
+  static constexpr bool FLAT = FLAT_;
   static constexpr int U = 4;                       // 16-B units per chunk = 16 fp32 channels
   static constexpr int PAD = (KS - 1) / 2;          // SAME, stride 1: symmetric
   static constexpr int HH = TH + KS - 1;
@@ -61,10 +64,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs a, int 
     mt = L / nN;
   }
   if (mt >= mtiles) return;
-  const int tx = mt % tiles_x;
-  const int ty = (mt / tiles_x) % tiles_y;
-  const int b = mt / (tiles_x * tiles_y);
-  const int y0 = ty * C::TH, x0 = tx * C::TW, n0 = nt * C::BN;
+  const int flat_r = C::FLAT ? tiles_x : 0;        // FLAT: `tiles_x` carries R, one tile across
+  const int tx = C::FLAT ? 0 : mt % tiles_x;
+  const int ty = C::FLAT ? mt % tiles_y : (mt / tiles_x) % tiles_y;
+  const int b = C::FLAT ? mt / tiles_y : mt / (tiles_x * tiles_y);
+  const int y0 = ty * (C::FLAT ? flat_r : C::TH), x0 = tx * C::TW, n0 = nt * C::BN;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -76,11 +80,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs a, int 
   const float* __restrict__ xb = static_cast<const float*>(a.x) + (size_t)b * H * W * Cin;
   const float* __restrict__ wp = static_cast<const float*>(a.wp);
 
+  const int whp = C::FLAT ? W + C::KS - 1 : C::WHP;
+  const int wh = C::FLAT ? W + C::KS - 1 : C::WH;
+  const int hh = C::FLAT ? flat_r + C::KS - 1 : C::HH;
   int aslot[C::MR], bcol[C::NR];
 #pragma unroll
   for (int f = 0; f < C::MR; ++f) {
     const int r = (wm * C::MR + f) * 32 + l31;
-    aslot[f] = (r / C::TW) * C::WHP + (r % C::TW);
+    if constexpr (C::FLAT) {
+      const int rr = r < flat_r * W ? r : 0;          // padding slots compute on pixel 0 and are dropped
+      const int yy = rr / W;
+      aslot[f] = yy * whp + (rr - yy * W);
+    } else {
+      aslot[f] = (r / C::TW) * C::WHP + (r % C::TW);
+    }
   }
 #pragma unroll
   for (int g = 0; g < C::NR; ++g) bcol[g] = (wn * C::NR + g) * 32 + l31;
@@ -122,15 +135,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs a, int 
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     __syncthreads();  // every wave is done reading the previous chunk's halo and weight buffers
     // ---- input halo of this 16-channel chunk -> LDS (zero fill = SAME padding)
-    for (int idx = tid; idx < C::U * C::HH * C::WH; idx += 256) {
+    for (int idx = tid; idx < C::U * hh * wh; idx += 256) {
       const int u = idx & (C::U - 1);
       const int pix = idx >> 2;
-      const int hy = pix / C::WH, hx = pix - hy * C::WH;
+      const int hy = pix / wh, hx = pix - hy * wh;
       const int gy = y0 - C::PAD + hy, gx = x0 - C::PAD + hx;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
         v = *reinterpret_cast<const f32x4*>(xb + ((size_t)gy * W + gx) * Cin + chunk * 16 + u * 4);
-      halo[u * C::PLANE + hy * C::WHP + hx] = v;
+      halo[u * C::PLANE + hy * whp + hx] = v;
     }
     wload(chunk, 0);
     for (int s = 0; s < C::NSTAGE; ++s) {
@@ -143,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs a, int 
       for (int tp = 0; tp < C::TPS; ++tp) {
         const int tap = tap0 + tp;
         const int ky = tap / C::KS, kx = tap - ky * C::KS;
-        const int toff = ky * C::WHP + kx;
+        const int toff = ky * whp + kx;
 #pragma unroll
         for (int st = 0; st < C::U / 2; ++st) {
           const int u = st * 2 + h;
@@ -180,8 +193,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs a, int 
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int r = (wm * C::MR + f) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        const int y = y0 + r / C::TW, x = x0 + r % C::TW;
-        if (y < H && x < W) {
+        int y, x;
+        bool ok;
+        if constexpr (C::FLAT) {
+          const int yy = r / W;
+          y = y0 + yy; x = r - yy * W;
+          ok = r < flat_r * W && y < H;
+        } else {
+          y = y0 + r / C::TW; x = x0 + r % C::TW;
+          ok = y < H && x < W;
+        }
+        if (ok) {
           float v = acc[f][g][i] + bi;
           if (a.relu_bn) v = fmaxf(v, 0.f) * sc + sh;
           ob[((size_t)y * W + x) * Cout + co] = v;
@@ -193,8 +215,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs a, int 
 
 template <class C>
 static hipError_t launch(const ConvArgs& a, hipStream_t st) {
-  const int tiles_x = (a.W + C::TW - 1) / C::TW, tiles_y = (a.H + C::TH - 1) / C::TH;
-  const int mtiles = tiles_x * tiles_y * a.B;
+  int tiles_x = (a.W + C::TW - 1) / C::TW, tiles_y = (a.H + C::TH - 1) / C::TH;
+  int mtiles = tiles_x * tiles_y * a.B;
+  if constexpr (C::FLAT) {
+    int R = C::BM / a.W;
+    if (R > a.H) R = a.H;
+    if (R < 1 || (R + C::KS - 1) * (a.W + C::KS - 1) + 2 > C::PLANE) return hipErrorInvalidValue;
+    tiles_y = (a.H + R - 1) / R;
+    tiles_x = R;
+    mtiles = tiles_y * a.B;
+  }
   const int nN = a.CoutP / C::BN;
   int blocks;
   if ((8 % nN) == 0) {
@@ -217,9 +247,22 @@ static hipError_t launch(const ConvArgs& a, hipStream_t st) {
 int conv_igemm_bn(int Cout) { return Cout >= 128 ? 128 : (Cout > 32 ? 64 : 32); }
 
 // Patch shape: 4x32 tiles a 60x90 map with 6 % padding; 8x16 suits the smaller / odd maps.
+// slots an 8x16-patch tiling / a whole-row (FLAT) tiling spends on an H x W map
+static inline int slots_patch(int H, int W) { return ((H + 7) / 8) * ((W + 15) / 16) * 128; }
+static inline int slots_flat(int H, int W, int ks) {
+  int R = 128 / W;
+  if (R > H) R = H;
+  if (R < 1 || (R + ks - 1) * (W + ks - 1) + 2 > (8 + ks - 1) * 32 + 2) return 1 << 30;
+  return ((H + R - 1) / R) * 128;
+}
+
 hipError_t conv_igemm_f32(const ConvArgs& a, int ks, hipStream_t st) {
   const int bn = conv_igemm_bn(a.Cout);
   const bool wide = (a.W >= 64) && (a.H % 4 == 0);
+  if (!wide && bn == 128 && slots_flat(a.H, a.W, ks) < slots_patch(a.H, a.W)) {   // e.g. 15x23: 3 tiles instead of 4
+    if (ks == 9) return launch<Cfg<9, 8, 16, 128, 2, 2, 1, true>>(a, st);
+    if (ks == 5) return launch<Cfg<5, 8, 16, 128, 2, 2, 1, true>>(a, st);
+  }
   if (ks == 9) {
     if (bn == 128) return wide ? launch<Cfg<9, 4, 32, 128, 2, 2, 1>>(a, st) : launch<Cfg<9, 8, 16, 128, 2, 2, 1>>(a, st);
     if (bn == 64) return wide ? launch<Cfg<9, 4, 32, 64, 2, 2, 3>>(a, st) : launch<Cfg<9, 8, 16, 64, 2, 2, 3>>(a, st);
