@@ -161,9 +161,57 @@ __global__ void upsample_merge3_kernel(const typename V4<T>::type* __restrict__ 
   }
 }
 
+// bf16 activations, 8 channels (16 bytes) per thread: the merge is pure HBM streaming (2.8 GB at
+// B=256) and 16-B accesses halve the instruction count of the generic 4-channel kernel.
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+struct F8 { float v[8]; };
+__device__ __forceinline__ F8 ld8(const bf16x8v* p) {
+  const bf16x8v t = *p;
+  F8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = (float)t[i];
+  return r;
+}
+__device__ __forceinline__ F8 bilinear8(const bf16x8v* base, int W, int C8, Tap ty, Tap tx) {
+  const F8 tl = ld8(base + ((size_t)ty.lo * W + tx.lo) * C8), tr = ld8(base + ((size_t)ty.lo * W + tx.hi) * C8);
+  const F8 bl = ld8(base + ((size_t)ty.hi * W + tx.lo) * C8), br = ld8(base + ((size_t)ty.hi * W + tx.hi) * C8);
+  F8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = lerp2(tl.v[i], tr.v[i], bl.v[i], br.v[i], tx.t, ty.t);
+  return r;
+}
+__global__ void upsample_merge3_bf16x8_kernel(const bf16x8v* __restrict__ x1, const bf16x8v* __restrict__ x2, int H2, int W2,
+                                              const bf16x8v* __restrict__ x3, int H3, int W3, bf16x8v* __restrict__ out,
+                                              int H, int W, int C8, float sy2, float sx2, float sy3, float sx3, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % C8;
+    size_t r = i / C8;
+    const int ox = r % W; r /= W;
+    const int oy = r % H;
+    const size_t b = r / H;
+    const F8 a = ld8(x1 + i);
+    const F8 u2 = (H2 == H && W2 == W) ? ld8(x2 + i)
+                                       : bilinear8(x2 + b * H2 * W2 * C8 + c, W2, C8, tf1_tap(oy, H2, sy2), tf1_tap(ox, W2, sx2));
+    const F8 u3 = (H3 == H && W3 == W) ? ld8(x3 + i)
+                                       : bilinear8(x3 + b * H3 * W3 * C8 + c, W3, C8, tf1_tap(oy, H3, sy3), tf1_tap(ox, W3, sx3));
+    bf16x8v o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (__bf16)(((a.v[k] + u2.v[k]) + u3.v[k]) / 3.0f);
+    out[i] = o;
+  }
+}
+
 hipError_t upsample_merge3(const void* x1, const void* x2, int H2, int W2, const void* x3, int H3, int W3,
                            void* out, bool bf16, int B, int H, int W, int C, hipStream_t st) {
   if (C % 4) return hipErrorInvalidValue;
+  if (bf16 && C % 8 == 0) {
+    const size_t total8 = (size_t)B * H * W * (C / 8);
+    hipLaunchKernelGGL(upsample_merge3_bf16x8_kernel, dim3(grid_for(total8)), dim3(256), 0, st, static_cast<const bf16x8v*>(x1),
+                       static_cast<const bf16x8v*>(x2), H2, W2, static_cast<const bf16x8v*>(x3), H3, W3,
+                       static_cast<bf16x8v*>(out), H, W, C / 8, (float)H2 / (float)H, (float)W2 / (float)W,
+                       (float)H3 / (float)H, (float)W3 / (float)W, total8);
+    return hipGetLastError();
+  }
   const size_t total = (size_t)B * H * W * (C / 4);
   const float sy2 = (float)H2 / (float)H, sx2 = (float)W2 / (float)W, sy3 = (float)H3 / (float)H, sx3 = (float)W3 / (float)W;
   if (bf16)

@@ -119,26 +119,32 @@ hipError_t sm_pad_frame(const float* hm, const float* sc, const float* sh, float
 }
 
 // spec[b][p] = lhat[b][cond[p]] * phat[p] * scale       (scale = 1/(120*180): hipFFT is unnormalised)
-__global__ void sm_spec_mul_kernel(const float2* __restrict__ lhat, const float2* __restrict__ phat, const int* __restrict__ cond,
-                                   float2* __restrict__ spec, int C, int P, float scale, int64_t total) {
+// two complex values (16 bytes) per thread; F_HWC = 120*91 is even
+__global__ void sm_spec_mul_kernel(const float4* __restrict__ lhat, const float4* __restrict__ phat, const int* __restrict__ cond,
+                                   float4* __restrict__ spec, int C, int P, float scale, int64_t total) {
+  constexpr int HALF = F_HWC / 2;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int k = i % F_HWC;
-    int64_t r = i / F_HWC;
+    const int k = i % HALF;
+    int64_t r = i / HALF;
     const int p = r % P;
     const int64_t b = r / P;
-    const float2 l = lhat[(b * C + cond[p]) * F_HWC + k];
-    const float2 q = phat[(int64_t)p * F_HWC + k];
-    float2 o;
+    const float4 l = lhat[(b * C + cond[p]) * HALF + k];
+    const float4 q = phat[(int64_t)p * HALF + k];
+    float4 o;
     o.x = (l.x * q.x - l.y * q.y) * scale;
     o.y = (l.x * q.y + l.y * q.x) * scale;
+    o.z = (l.z * q.z - l.w * q.w) * scale;
+    o.w = (l.z * q.w + l.w * q.z) * scale;
     spec[i] = o;
   }
 }
 hipError_t sm_spec_mul(const float2* lhat, const float2* phat, const int* cond, float2* spec, int B, int C, int P, hipStream_t st) {
-  const int64_t total = (int64_t)B * P * F_HWC;
+  static_assert(F_HWC % 2 == 0, "two complex values per thread");
+  const int64_t total = (int64_t)B * P * (F_HWC / 2);
   int64_t g = (total + 255) / 256;
-  hipLaunchKernelGGL(sm_spec_mul_kernel, dim3((int)(g > 32768 ? 32768 : g)), dim3(256), 0, st, lhat, phat, cond, spec, C, P,
-                     1.0f / (float)F_HW, total);
+  hipLaunchKernelGGL(sm_spec_mul_kernel, dim3((int)(g > 32768 ? 32768 : g)), dim3(256), 0, st,
+                     reinterpret_cast<const float4*>(lhat), reinterpret_cast<const float4*>(phat), cond,
+                     reinterpret_cast<float4*>(spec), C, P, 1.0f / (float)F_HW, total);
   return hipGetLastError();
 }
 
