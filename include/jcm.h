@@ -99,6 +99,17 @@ int jcm_argmax_coords(jcm_handle h, const float* hm, int B, int HH, int WW, int 
 int jcm_forward(jcm_handle h, const float* x, const float* torso, int B, int H, int W, int use_sm,
                 float* pd_prob, float* sm_prob, int32_t* pd_coords, int32_t* sm_coords);
 
+/* -- multi-scale test-time evaluation (the caller of the tower, main.py:326-425) ---------------------
+ * One pad-or-crop window per output, then skimage.transform.resize(window, [OH,OW]) with the
+ * 0.13.x defaults the reference relies on (bilinear, half-pixel centres, zeros outside, clip to
+ * the window's [min,max]): get_different_scales (main.py:326-348) and scale_hm_back (:351-379).
+ * src [nsrc,H,W,C] device fp32; windows HOST int32 [NW][5] = (source index, y0, x0, h, w), a
+ * window may extend beyond the image (= np.lib.pad with zeros); out [NW,OH,OW,C] device fp32. */
+int jcm_window_resize(jcm_handle h, const float* src, int nsrc, int H, int W, int C, const int32_t* windows, int NW,
+                      int OH, int OW, float* out);
+/* np.average over the G scale copies of each image (main.py:413-414): in [n*G, M] -> out [n, M]. */
+int jcm_group_mean(jcm_handle h, const float* in, int n, int G, int64_t M, float* out);
+
 /* -- introspection (used by bench.py for the roofline object) ------------------------------------
  * Sum of the HIP-event durations (ms) and the number of launches recorded for conv layer
  * `scope` since the last read; synchronises the stream and clears the record. */

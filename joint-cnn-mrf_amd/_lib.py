@@ -34,6 +34,9 @@ SIGNATURES = {
     'jcm_argmax_coords': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i32_p]),
     'jcm_forward': (ctypes.c_int, [_handle, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                    _c_float_p, _c_float_p, _c_i32_p, _c_i32_p]),
+    'jcm_window_resize': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p]),
+    'jcm_group_mean': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, _c_float_p]),
     'jcm_profile_read': (ctypes.c_int, [_handle, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     'jcm_workspace_bytes': (ctypes.c_int64, [_handle]),
 }

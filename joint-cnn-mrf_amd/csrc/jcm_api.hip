@@ -644,6 +644,36 @@ int jcm_forward(jcm_handle h, const float* x, const float* torso, int B, int H, 
   });
 }
 
+int jcm_window_resize(jcm_handle h, const float* src, int nsrc, int H, int W, int C, const int32_t* windows, int NW,
+                      int OH, int OW, float* out) {
+  JCM_TRY(check(h, false));
+  if (!src || !windows || !out || nsrc < 1 || H < 1 || W < 1 || C < 1 || NW < 1 || OH < 1 || OW < 1)
+    return fail(JCM_ERR_ARG, "bad window_resize arguments");
+  for (int i = 0; i < NW; ++i) {
+    const int32_t* w = windows + i * 5;
+    if (w[0] < 0 || w[0] >= nsrc || w[3] < 1 || w[4] < 1) return fail(JCM_ERR_ARG, "bad window " + std::to_string(i));
+  }
+  DeviceGuard g(h->device);
+  jcm_ctx* c = h;
+  return with_arena(c, [&] {
+    int* wdev = arena_alloc<int>(c, (size_t)NW * 5);
+    float2* mm = arena_alloc<float2>(c, NW);
+    if (c->dry) return (int)JCM_OK;
+    HIP_TRY(hipMemcpyAsync(wdev, windows, (size_t)NW * 5 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(window_resize(src, H, W, C, wdev, NW, mm, OH, OW, out, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // `windows` is caller-owned host memory
+    return (int)JCM_OK;
+  });
+}
+
+int jcm_group_mean(jcm_handle h, const float* in, int n, int G, int64_t M, float* out) {
+  JCM_TRY(check(h, false));
+  if (!in || !out || n < 1 || G < 1 || M < 1) return fail(JCM_ERR_ARG, "bad group_mean arguments");
+  DeviceGuard g(h->device);
+  HIP_TRY(group_mean(in, out, n, G, (size_t)M, h->stream));
+  return JCM_OK;
+}
+
 int jcm_profile_read(jcm_handle h, const char* scope, double* total_ms, int* launches) {
   JCM_TRY(check(h, false));
   if (!scope || !total_ms || !launches) return fail(JCM_ERR_ARG, "bad profile_read arguments");

@@ -91,4 +91,10 @@ hipError_t sm_spec_mul(const float2* lhat, const float2* phat, const int* cond, 
 hipError_t sm_finish_fft(const float* frame, const float* cfull, const float* spbias, float* logits, int B, int K, int C, hipStream_t st);
 hipError_t sm_resize_frame(const float* cfull, float* out, int B, hipStream_t st);
 
+// ---- multiscale.hip : crop/pad window + skimage-style bilinear resize, mean over scale copies ------
+// windows_dev: int32 [NW][5] = (source image, y0, x0, h, w); mm_scratch: float2 [NW]
+hipError_t window_resize(const float* src, int H, int W, int C, const int* windows_dev, int NW, float2* mm_scratch,
+                         int OH, int OW, float* out, hipStream_t st);
+hipError_t group_mean(const float* in, float* out, int n, int G, size_t M, hipStream_t st);
+
 }  // namespace jcm

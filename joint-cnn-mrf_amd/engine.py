@@ -197,6 +197,30 @@ class Engine:
                                          self._p(r['pd_coords']), self._p(r.get('sm_coords'))), 'jcm_forward')
         return r
 
+    def window_resize(self, src, windows, oh, ow):
+        """Pad-or-crop `windows` [(src_index, y0, x0, h, w), ...] of src [N,H,W,C], each resized to
+        (oh, ow) with skimage.transform.resize's 0.13.x defaults (main.py:326-379)."""
+        self._chk(src, 4, 'src')
+        N, H, W, C = src.shape
+        wins = np.ascontiguousarray(np.asarray(windows, dtype=np.int32).reshape(-1, 5))
+        out = self._new(wins.shape[0], int(oh), int(ow), C)
+        _lib.check(self._lib.jcm_window_resize(self._h, self._p(src), N, H, W, C,
+                                               wins.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), wins.shape[0],
+                                               int(oh), int(ow), self._p(out)), 'jcm_window_resize')
+        return out
+
+    def group_mean(self, x, group):
+        """np.average over consecutive groups of `group` leading entries (main.py:413-414)."""
+        if x.shape[0] % group:
+            raise ValueError('leading dimension %d is not a multiple of %d' % (x.shape[0], group))
+        n = x.shape[0] // group
+        out = self._new(n, *x.shape[1:])
+        m = 1
+        for d in x.shape[1:]:
+            m *= int(d)
+        _lib.check(self._lib.jcm_group_mean(self._h, self._p(x.contiguous()), n, group, m, self._p(out)), 'jcm_group_mean')
+        return out
+
     def set_sm_algo(self, algo):
         """Pairwise-convolution algorithm of the spatial model: 'fft' (rocFFT, default) or
         'direct' (LDS sliding-window VALU kernel).  Both are HIP paths; bench/profiles compare them."""
