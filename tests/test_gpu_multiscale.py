@@ -55,12 +55,18 @@ def test_get_predictions_matches_oracle(eng):
         r = O.forward(xs, ys[:, :, :, 9:], p)
         return r['pd_prob'], r['sm_prob']
 
+    # the same pipeline step by step, to compare the averaged maps themselves
+    xs = MS.get_different_scales(eng, dev(X), MS.PAD_ARRAY, MS.CROP_ARRAY, 480, 720)
+    torso = dev(Y[:, :, :, 9:]).repeat_interleave(8, dim=0).contiguous()
+    r = eng.forward(xs, torso, use_sm=True)
+    g_pd = eng.group_mean(MS.scale_hm_back(eng, r['pd_prob'], MS.PAD_ARRAY, MS.CROP_ARRAY, 60, 90), 8).cpu().numpy()
+    g_sm = eng.group_mean(MS.scale_hm_back(eng, r['sm_prob'], MS.PAD_ARRAY, MS.CROP_ARRAY, 60, 90), 8).cpu().numpy()
     for i in range(2):
         c_pd, c_sm, hm_pd, hm_sm = MO.predict_one(X[i], Y[i], forward)
-        # argmax is taken on an average of 8 flat-ish maps; require equality where the oracle's own
-        # top-2 margin is above fp32 noise
-        for got, ref, hm in ((pd[:, :, i], c_pd, hm_pd), (sm[:, :, i], c_sm, hm_sm)):
-            flat = np.sort(hm.reshape(5400, 9), axis=0)
-            clear = (flat[-1] - flat[-2]) > 1e-7
-            np.testing.assert_array_equal(got[:, clear], ref[:, clear])
-            assert clear.sum() >= 7
+        for got_c, ref_c, got_hm, ref_hm in ((pd[:, :, i], c_pd, g_pd[i], hm_pd[0]), (sm[:, :, i], c_sm, g_sm[i], hm_sm[0])):
+            err = np.abs(got_hm - ref_hm).max()
+            assert err <= 1e-4 and err <= 2e-3 * ref_hm.max()                 # heat-map bar, and a relative one
+            flat = np.sort(ref_hm.reshape(5400, 9), axis=0)
+            clear = (flat[-1] - flat[-2]) > 4 * err                          # arg-max is well posed there
+            np.testing.assert_array_equal(got_c[:, clear], ref_c[:, clear])
+            assert clear.sum() >= 5
