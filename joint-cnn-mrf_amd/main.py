@@ -182,6 +182,25 @@ def tower(x, hm_target, use_sm=None):
     return hm_pred_pd, hm_pred_sm
 
 
+def get_different_scales(x, pad_array, crop_array, orig_h, orig_w):
+    """main.py:326-348: the 4 padded + 4 cropped copies of an image, resized back to orig_h x orig_w."""
+    from . import multiscale
+    return multiscale.get_different_scales(engine(), x, pad_array, crop_array, orig_h, orig_w)
+
+
+def scale_hm_back(hms, pad_array, crop_array, orig_h, orig_w):
+    """main.py:351-379: undo the pad / crop on the 8 heat maps of an image."""
+    from . import multiscale
+    return multiscale.scale_hm_back(engine(), hms, pad_array, crop_array, orig_h, orig_w)
+
+
+def get_predictions(X_np, Y_np, sess=None):
+    """main.py:382-425 (multi-scale test-time evaluation) -> (pred_coords_pd, pred_coords_sm), each
+    [2, n_joints, N]; `sess` is accepted for signature compatibility and ignored."""
+    from . import multiscale
+    return multiscale.get_predictions(engine(), X_np, Y_np, use_sm=hps.use_sm)
+
+
 def main(argv=None):
     global hps
     args = build_parser().parse_args(argv)
