@@ -102,3 +102,26 @@ def test_config2_batch64_properties():
     eng1.close()
     np.testing.assert_allclose(one['sm_prob'].cpu().numpy(), sm[37:38], atol=1e-6, rtol=0)
     np.testing.assert_array_equal(one['sm_coords'].cpu().numpy(), r['sm_coords'].cpu().numpy()[37:38])
+
+
+@pytest.mark.parametrize('precision,batch', [('bf16', 24), ('fp32', 6)])
+def test_repeatability_soak(precision, batch):
+    """The MFMA kernels use hand-counted waits, LDS-DMA and barriers; a missed wait shows up as
+    run-to-run differences long before it shows up as a wrong answer.  Every kernel is
+    deterministic (no atomics), so repeated forwards must be bit-identical -- also while the
+    GPU is busy with other work queued behind them."""
+    from joint_cnn_mrf_amd.engine import Engine
+    _, _, p = full_inputs()
+    p.update(synth.make_sm_params(flic_priors(), kind='trained', seed=seeds()['sm']))
+    eng = Engine(device=0, precision=precision).load_params(p)
+    x, torso = dev(synth.make_images(batch, seed=91)), dev(synth.make_torso(batch, seed=92))
+    first = eng.forward(x, torso, use_sm=True)
+    ref_pd, ref_sm = first['pd_prob'].clone(), first['sm_prob'].clone()
+    noise = torch.randn(4096, 4096, device='cuda:0')
+    for it in range(12):
+        if it % 3 == 0:
+            noise = noise @ noise.clamp(-1e-3, 1e-3)          # unrelated load on the same stream
+        r = eng.forward(x, torso, use_sm=True)
+        assert torch.equal(r['pd_prob'], ref_pd), 'part-detector output changed on repeat %d' % it
+        assert torch.equal(r['sm_prob'], ref_sm), 'spatial-model output changed on repeat %d' % it
+    eng.close()
