@@ -83,10 +83,11 @@ struct jcm_ctx {
   float* bn_sm_shift = nullptr;
   int* cond = nullptr;          // [P] conditioning channel of pair p
   int* cond0 = nullptr;         // single zero (jcm_conv_mrf)
-  int sm_algo = 0;              // 0 = FFT (rocFFT), 1 = direct sliding-window VALU kernel
+  int sm_algo = 2;              // 0 = FFT (2-D rocFFT), 1 = direct sliding-window VALU kernel, 2 = FFT with split row-pruned inverse
   int sm_chunk = 16;            // images per FFT slice
   SmFft* fft = nullptr;
   float2* prior_spec = nullptr; // [P][120*91] spectra of softplus5(energy)
+  float2* prior_spec_t = nullptr; // the same, transposed [P][91][120] (split inverse)
   // workspace arena (stack allocator, grown on demand between forwards)
   char* arena = nullptr;
   size_t arena_cap = 0, arena_off = 0, arena_peak = 0;
@@ -318,6 +319,29 @@ int sm_forward_impl(jcm_ctx* c, const float* hm10, int B, float* logits) {
     HIP_TRY(sm_finish(lik, cpre, c->sp_bias, logits, B, c->K, kC, c->stream));
     return JCM_OK;
   }
+  if (c->sm_algo == 2) {   // FFT with a split, row-pruned inverse
+    const int Bc = B < c->sm_chunk ? B : c->sm_chunk;
+    constexpr int WC = kPrW / 2 + 1;                      // 91
+    float* frame = arena_alloc<float>(c, (size_t)Bc * kC * kFrame);
+    float2* lhat = arena_alloc<float2>(c, (size_t)Bc * kC * kSpec);
+    float2* lhat_t = arena_alloc<float2>(c, (size_t)Bc * kC * kSpec);
+    float2* spec_t = arena_alloc<float2>(c, (size_t)Bc * P * kSpec);          // [pair][91][120]
+    float2* rows_c = arena_alloc<float2>(c, (size_t)Bc * P * kCH * WC);       // [pair][61][91]
+    float* rows_r = arena_alloc<float>(c, (size_t)Bc * P * kCH * kPrW);       // [pair][61][180]
+    if (c->dry) return JCM_OK;
+    for (int b0 = 0; b0 < B; b0 += Bc) {
+      const int nb = B - b0 < Bc ? B - b0 : Bc;
+      HIP_TRY(sm_pad_frame(hm10 + (size_t)b0 * kHmHW * kC, c->bn_sm_scale, c->bn_sm_shift, frame, nb, kC, c->stream));
+      FFT_TRY(sm_fft_r2c(c->fft, frame, lhat, nb * kC));
+      HIP_TRY(sm_transpose(lhat, lhat_t, nb * kC, kPrH, WC, 0, WC, c->stream));
+      HIP_TRY(sm_spec_mul(lhat_t, c->prior_spec_t, c->cond, spec_t, nb, kC, P, c->stream));      // elementwise: layout-agnostic
+      FFT_TRY(sm_fft_cols(c->fft, spec_t, nb * P * WC));
+      HIP_TRY(sm_transpose(spec_t, rows_c, nb * P, WC, kPrH, kPrH - kCH, kCH, c->stream));   // keep m = 59..119
+      FFT_TRY(sm_fft_rows(c->fft, rows_c, rows_r, nb * P * kCH));
+      HIP_TRY(sm_finish_rows(frame, rows_r, c->sp_bias, logits + (size_t)b0 * kHmHW * c->K, nb, c->K, kC, c->stream));
+    }
+    return JCM_OK;
+  }
   // FFT: 10 forward transforms + 81 products + 81 inverse transforms per image, run in batch
   // slices of `sm_chunk` images: one slice's spectra + frames (14 MB/image) then stay inside the
   // 256 MB Infinity Cache between rocFFT's passes instead of making 4 round trips to HBM.
@@ -402,7 +426,7 @@ int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
     return JCM_OK;
   }
   if (k == "sm_algo") {   // allowed at any time
-    if (value != 0 && value != 1) return fail(JCM_ERR_ARG, "sm_algo must be 0 (fft) or 1 (direct)");
+    if (value < 0 || value > 2) return fail(JCM_ERR_ARG, "sm_algo must be 0 (fft), 1 (direct) or 2 (fft_split)");
     h->sm_algo = (int)value;
     return JCM_OK;
   }
@@ -510,6 +534,8 @@ int jcm_finalize(jcm_handle h) {
     HIP_TRY(hipMemcpyAsync(c->cond, cond.data(), P * sizeof(int), hipMemcpyHostToDevice, c->stream));
     JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->prior_spec), (size_t)P * kSpec * sizeof(float2)));
     FFT_TRY(sm_fft_r2c(c->fft, c->sp_energy, c->prior_spec, P));
+    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->prior_spec_t), (size_t)P * kSpec * sizeof(float2)));
+    HIP_TRY(sm_transpose(c->prior_spec, c->prior_spec_t, P, kPrH, kPrW / 2 + 1, 0, kPrW / 2 + 1, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->has_sm = true;
   }

@@ -90,6 +90,12 @@ hipError_t sm_pad_frame(const float* hm, const float* sc, const float* sh, float
 hipError_t sm_spec_mul(const float2* lhat, const float2* phat, const int* cond, float2* spec, int B, int C, int P, hipStream_t st);
 hipError_t sm_finish_fft(const float* frame, const float* cfull, const float* spbias, float* logits, int B, int K, int C, hipStream_t st);
 hipError_t sm_resize_frame(const float* cfull, float* out, int B, hipStream_t st);
+// split inverse (sm_algo = 2): spectra kept transposed [n][91][120]; columns by 1-D C2C, then only rows
+// 59..119 are transposed back ([n][61][91]) and go through a 1-D C2R
+const char* sm_fft_cols(SmFft* f, float2* data, int n);
+const char* sm_fft_rows(SmFft* f, float2* in, float* out, int n);
+hipError_t sm_transpose(const float2* in, float2* out, int N, int R, int C, int c0, int C_out, hipStream_t st);   // out[n][c][r] = in[n][r][c0+c]
+hipError_t sm_finish_rows(const float* frame, const float* rows, const float* spbias, float* logits, int B, int K, int C, hipStream_t st);
 
 // ---- multiscale.hip : crop/pad window + skimage-style bilinear resize, mean over scale copies ------
 // windows_dev: int32 [NW][5] = (source image, y0, x0, h, w); mm_scratch: float2 [NW]

@@ -23,7 +23,8 @@ constexpr int F_HW = F_H * F_W, F_HWC = F_H * F_WC;
 constexpr int FM_H = 60, FM_W = 90, FM_HW = FM_H * FM_W;
 
 struct SmFft {
-  std::map<int, hipfftHandle> fwd, inv;   // batch -> plan
+  std::map<int, hipfftHandle> fwd, inv;   // batch -> plan (2-D R2C / C2R)
+  std::map<int, hipfftHandle> col, row;   // batch -> plan (1-D C2C length 120 / 1-D C2R length 180)
   hipStream_t stream = nullptr;
 };
 
@@ -51,6 +52,8 @@ void sm_fft_destroy(SmFft* f) {
   if (!f) return;
   for (auto& kv : f->fwd) hipfftDestroy(kv.second);
   for (auto& kv : f->inv) hipfftDestroy(kv.second);
+  for (auto& kv : f->col) hipfftDestroy(kv.second);
+  for (auto& kv : f->row) hipfftDestroy(kv.second);
   delete f;
 }
 
@@ -82,6 +85,63 @@ const char* sm_fft_c2r(SmFft* f, float2* in, float* out, int n) {
   if (const char* e = get_plan(f, f->inv, HIPFFT_C2R, n, &p)) return e;
   hipfftResult r = hipfftExecC2R(p, reinterpret_cast<hipfftComplex*>(in), out);
   return r == HIPFFT_SUCCESS ? nullptr : fft_err(r);
+}
+
+// ---- split inverse: columns (1-D C2C, length 120) then only the 61 needed rows (1-D C2R, 180) ----
+static const char* get_plan_1d(SmFft* f, std::map<int, hipfftHandle>& cache, int n, hipfftType type, int batch, hipfftHandle* out) {
+  auto it = cache.find(batch);
+  if (it != cache.end()) { *out = it->second; return nullptr; }
+  hipfftHandle p;
+  hipfftResult r = hipfftPlanMany(&p, 1, &n, nullptr, 1, 0, nullptr, 1, 0, type, batch);
+  if (r != HIPFFT_SUCCESS) return fft_err(r);
+  r = hipfftSetStream(p, f->stream);
+  if (r != HIPFFT_SUCCESS) return fft_err(r);
+  cache[batch] = p;
+  *out = p;
+  return nullptr;
+}
+// in place, [n][120] complex, unnormalised inverse
+const char* sm_fft_cols(SmFft* f, float2* data, int n) {
+  hipfftHandle p;
+  if (const char* e = get_plan_1d(f, f->col, F_H, HIPFFT_C2C, n, &p)) return e;
+  hipfftResult r = hipfftExecC2C(p, reinterpret_cast<hipfftComplex*>(data), reinterpret_cast<hipfftComplex*>(data), HIPFFT_BACKWARD);
+  return r == HIPFFT_SUCCESS ? nullptr : fft_err(r);
+}
+// [n][91] complex -> [n][180] real, unnormalised
+const char* sm_fft_rows(SmFft* f, float2* in, float* out, int n) {
+  hipfftHandle p;
+  if (const char* e = get_plan_1d(f, f->row, F_W, HIPFFT_C2R, n, &p)) return e;
+  hipfftResult r = hipfftExecC2R(p, reinterpret_cast<hipfftComplex*>(in), out);
+  return r == HIPFFT_SUCCESS ? nullptr : fft_err(r);
+}
+
+// out[n][c][r] = in[n][r][c0 + c] for c < C_out: a (column-pruning) transpose of [n][R][C] complex
+// matrices through 32x32 LDS tiles, coalesced on both sides.
+__global__ __launch_bounds__(256) void sm_transpose_kernel(const float2* __restrict__ in, float2* __restrict__ out, int R, int C,
+                                                           int c0, int C_out, int tiles_r, int tiles_c) {
+  __shared__ float2 tile[32][33];
+  const int n = blockIdx.x / (tiles_r * tiles_c);
+  const int t = blockIdx.x % (tiles_r * tiles_c);
+  const int tr = t / tiles_c, tc = t % tiles_c;
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;       // 32 x 8
+  const float2* src = in + (size_t)n * R * C;
+  float2* dst = out + (size_t)n * C_out * R;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = tr * 32 + ly + 8 * k, c = tc * 32 + lx;
+    if (r < R && c < C_out) tile[ly + 8 * k][lx] = src[(size_t)r * C + c0 + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = tc * 32 + ly + 8 * k, r = tr * 32 + lx;
+    if (r < R && c < C_out) dst[(size_t)c * R + r] = tile[lx][ly + 8 * k];
+  }
+}
+hipError_t sm_transpose(const float2* in, float2* out, int N, int R, int C, int c0, int C_out, hipStream_t st) {
+  const int tiles_r = (R + 31) / 32, tiles_c = (C_out + 31) / 32;
+  hipLaunchKernelGGL(sm_transpose_kernel, dim3(N * tiles_r * tiles_c), dim3(256), 0, st, in, out, R, C, c0, C_out, tiles_r, tiles_c);
+  return hipGetLastError();
 }
 
 __device__ __forceinline__ float softplus5f(float x) {
@@ -188,6 +248,45 @@ hipError_t sm_finish_fft(const float* frame, const float* cfull, const float* sp
   const int64_t total = (int64_t)B * K * FM_HW;
   int64_t g = (total + 255) / 256;
   hipLaunchKernelGGL(sm_finish_fft_kernel, dim3((int)(g > 16384 ? 16384 : g)), dim3(256), 0, st, frame, cfull, spbias, logits, K, C, total);
+  return hipGetLastError();
+}
+
+// the same epilogue on the split path: rows[b][p] is [61][180] = frame rows 59..119, window = columns 89..179
+__device__ __forceinline__ float resize_from_rows(const float* __restrict__ rw, int oy, int ox) {
+  const float sy = 61.0f / 60.0f, sx = 91.0f / 90.0f;
+  const float fy = __fmul_rn((float)oy, sy), fx = __fmul_rn((float)ox, sx);
+  const int ylo = (int)floorf(fy), xlo = (int)floorf(fx);
+  const int yhi = min(ylo + 1, 60), xhi = min(xlo + 1, 90);
+  const float ty = fy - (float)ylo, tx = fx - (float)xlo;
+  const float* w = rw + 89;
+  const float tl = w[ylo * F_W + xlo], tr = w[ylo * F_W + xhi];
+  const float bl = w[yhi * F_W + xlo], br = w[yhi * F_W + xhi];
+  const float top = tl + (tr - tl) * tx;
+  const float bot = bl + (br - bl) * tx;
+  return top + (bot - top) * ty;
+}
+__global__ void sm_finish_rows_kernel(const float* __restrict__ frame, const float* __restrict__ rows, const float* __restrict__ spb,
+                                      float* __restrict__ logits, int K, int C, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int pix = i % FM_HW;
+    int64_t r = i / FM_HW;
+    const int j = r % K;
+    const int64_t b = r / K;
+    const int oy = pix / FM_W, ox = pix - oy * FM_W;
+    float e = logf(frame[((b * C + j) * F_H + oy) * F_W + ox] + 1e-6f);
+    const int PJ = C - 1, P = K * PJ;
+    for (int q = 0; q < PJ; ++q) {
+      const int p = j * PJ + q;
+      const float cv = resize_from_rows(rows + (b * P + p) * (61 * F_W), oy, ox);
+      e += logf((cv + spb[(size_t)p * FM_HW + pix]) + 1e-6f);
+    }
+    logits[(b * FM_HW + pix) * K + j] = e;
+  }
+}
+hipError_t sm_finish_rows(const float* frame, const float* rows, const float* spbias, float* logits, int B, int K, int C, hipStream_t st) {
+  const int64_t total = (int64_t)B * K * FM_HW;
+  int64_t g = (total + 255) / 256;
+  hipLaunchKernelGGL(sm_finish_rows_kernel, dim3((int)(g > 16384 ? 16384 : g)), dim3(256), 0, st, frame, rows, spbias, logits, K, C, total);
   return hipGetLastError();
 }
 

@@ -222,9 +222,10 @@ class Engine:
         return out
 
     def set_sm_algo(self, algo):
-        """Pairwise-convolution algorithm of the spatial model: 'fft' (rocFFT, default) or
-        'direct' (LDS sliding-window VALU kernel).  Both are HIP paths; bench/profiles compare them."""
-        _lib.check(self._lib.jcm_set_option(self._h, b'sm_algo', {'fft': 0, 'direct': 1}[algo]), 'jcm_set_option(sm_algo)')
+        """Pairwise-convolution algorithm of the spatial model: 'fft' (rocFFT 2-D), 'fft_split'
+        (rocFFT 1-D columns, then only the 61 rows the VALID window needs) or 'direct' (LDS sliding-window
+        VALU kernel).  All are HIP paths; bench/profiles compare them."""
+        _lib.check(self._lib.jcm_set_option(self._h, b'sm_algo', {'fft': 0, 'direct': 1, 'fft_split': 2}[algo]), 'jcm_set_option(sm_algo)')
 
     def set_profile(self, on):
         _lib.check(self._lib.jcm_set_option(self._h, b'profile', int(bool(on))), 'jcm_set_option(profile)')
