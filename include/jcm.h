@@ -117,6 +117,39 @@ int jcm_profile_read(jcm_handle h, const char* scope, double* total_ms, int* lau
 /* Bytes currently held by the workspace arena + packed parameters. */
 int64_t jcm_workspace_bytes(jcm_handle h);
 
+/* -- joint training step (main.py:511-577,644) ------------------------------------
+ * One `sess.run(train_step, {flag_train: True})` of one tower, split at the point where the
+ * reference averages the tower gradients (average_gradients, main.py:243-267) so that the host
+ * can all-reduce between the two calls:
+ *
+ *   jcm_train_loss_grads : forward with batch-statistics BatchNorm (is_training=True, main.py:113,129;
+ *       the moving_mean / moving_variance update ops of main.py:557 run here, decay 0.9), loss_tower =
+ *       CE(pd) + CE(sm) + lmbd * weight_decay('weights') (main.py:538-540), and opt.compute_gradients
+ *       (main.py:560) into one flat caller-owned buffer laid out by jcm_train_param_info.
+ *   jcm_train_apply      : grad_renorm(., clip_norm) = tf.clip_by_global_norm (main.py:302-309,576) and
+ *       opt.apply_gradients (main.py:577) with tf.train.AdamOptimizer (beta 0.9/0.999, eps 1e-8) or
+ *       MomentumOptimizer(0.9) (main.py:501-504); then every derived table (packed weights, folded BN,
+ *       prior spectra) is rebuilt, so inference entry points see the new parameters.
+ *
+ * Trainable tensors are all parameters except the BatchNorm moving statistics, in ascending name
+ * order.  fp32 handles only. */
+#define JCM_OPT_ADAM 0
+#define JCM_OPT_MOMENTUM 1
+int jcm_train_begin(jcm_handle h);                       /* after jcm_finalize: allocates optimizer slots, n_iters = 0 */
+int jcm_train_param_count(jcm_handle h, int64_t* n_tensors, int64_t* n_elements);
+int jcm_train_param_info(jcm_handle h, int64_t index, char* name, int name_cap, int64_t* offset, int64_t* count);
+/* x [B,H,W,3], y = y_in [B,60,90,K+1] target heat maps (main.py:488); grads: device fp32 [n_elements];
+ * losses: device fp32 [4] = loss_tower, loss_pd, loss_sm, weight_decay('weights'). */
+int jcm_train_loss_grads(jcm_handle h, const float* x, const float* y, int B, int H, int W, int use_sm, float lmbd,
+                         float* grads, float* losses);
+/* grads: the (tower-averaged) gradients, same layout; lr: the value of lr_tf for this update
+ * (main.py:492); clip_norm <= 0 disables the clip; grad_norm_out (host, may be NULL) receives the
+ * global norm before clipping and makes the call synchronise. */
+int jcm_train_apply(jcm_handle h, const float* grads, int optimizer, float lr, float clip_norm, float* grad_norm_out);
+int jcm_train_steps(jcm_handle h, int64_t* n_iters);     /* n_iters_tf (main.py:491) */
+/* Saver.save side (main.py:666): copy a stored parameter out (host or device pointer). */
+int jcm_get_tensor(jcm_handle h, const char* name, float* out, int64_t count);
+
 #ifdef __cplusplus
 }
 #endif

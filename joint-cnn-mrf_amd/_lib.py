@@ -8,6 +8,8 @@ LIB_PATH = os.environ.get('JCM_LIB') or os.path.join(_HERE, 'libjcm.so')   # JCM
 
 JCM_PRECISION_F32 = 0
 JCM_PRECISION_BF16 = 1
+JCM_OPT_ADAM = 0
+JCM_OPT_MOMENTUM = 1
 
 _c_float_p = ctypes.c_void_p      # device pointers travel as integers
 _c_i32_p = ctypes.c_void_p
@@ -39,6 +41,15 @@ SIGNATURES = {
     'jcm_group_mean': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, _c_float_p]),
     'jcm_profile_read': (ctypes.c_int, [_handle, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     'jcm_workspace_bytes': (ctypes.c_int64, [_handle]),
+    'jcm_train_begin': (ctypes.c_int, [_handle]),
+    'jcm_train_param_count': (ctypes.c_int, [_handle, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    'jcm_train_param_info': (ctypes.c_int, [_handle, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int,
+                                            ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    'jcm_train_loss_grads': (ctypes.c_int, [_handle, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_float, _c_float_p, _c_float_p]),
+    'jcm_train_apply': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.POINTER(ctypes.c_float)]),
+    'jcm_train_steps': (ctypes.c_int, [_handle, ctypes.POINTER(ctypes.c_int64)]),
+    'jcm_get_tensor': (ctypes.c_int, [_handle, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64]),
 }
 
 _lib = None

@@ -1,0 +1,156 @@
+// Internal context of libjcm shared by the translation units behind include/jcm.h
+// (jcm_api.hip: inference graph; jcm_train.hip: training step).  Not part of the ABI.
+#pragma once
+#include "../../include/jcm.h"
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace jcm {
+
+int fail(int code, const std::string& msg);     // sets the thread-local message of jcm_last_error()
+
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess)                                                                               \
+      return ::jcm::fail(JCM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
+  } while (0)
+#define JCM_TRY(expr)          \
+  do {                         \
+    int r_ = (expr);           \
+    if (r_ != JCM_OK) return r_; \
+  } while (0)
+#define FFT_TRY(expr)                                                                 \
+  do {                                                                                \
+    const char* fe_ = (expr);                                                         \
+    if (fe_) return ::jcm::fail(JCM_ERR_HIP, std::string(#expr) + ": " + fe_);        \
+  } while (0)
+
+// main.py:18 -- channel order of the heat maps and of the pair tables.
+extern const char* const kJointNames[10];
+constexpr int kC = 10;            // heat-map channels seen by the spatial model (9 joints + torso)
+constexpr float kBnEps = 1e-3f;   // tf.contrib.layers.batch_norm default epsilon
+constexpr int kHmH = 60, kHmW = 90, kHmHW = kHmH * kHmW;
+constexpr int kPrH = 120, kPrW = 180;
+constexpr int kCH = 61, kCW = 91;
+constexpr size_t kFrame = (size_t)kPrH * kPrW;          // 120*180 real
+constexpr size_t kSpec = (size_t)kPrH * (kPrW / 2 + 1); // 120*91 complex
+
+struct Tensor {
+  std::vector<int64_t> shape;
+  float* d = nullptr;
+  size_t n = 0;
+};
+
+struct ConvLayer {
+  int ks = 0, cin = 0, cout = 0, coutp = 0;
+  bool has_bn = false;
+  const float* w_raw = nullptr;   // HWIO (conv1 kernel reads it directly)
+  float* wp = nullptr;            // packed for conv_igemm_f32
+  void* wp_bf16 = nullptr;        // packed for conv_igemm_bf16
+  void* wq1_bf16 = nullptr;       // packed for conv1_mfma_pool (5x5, Cin=3, Cout=64)
+  int coutp_bf16 = 0;
+  bool thin = false;              // fp32: conv_thin_f32 instead of conv_igemm_f32
+  bool thin_bf16 = false;         // bf16: conv_thin_bf16 (fp32 output) instead of conv_igemm_bf16
+  const float* bias = nullptr;
+  float* scale = nullptr;
+  float* shift = nullptr;
+};
+
+struct TrainState;   // jcm_train.hip
+}  // namespace jcm
+struct jcm_ctx;
+namespace jcm {
+void train_destroy(jcm_ctx* c);
+
+}  // namespace jcm
+
+struct jcm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int precision = JCM_PRECISION_F32;
+  int K = 9;
+  bool finalized = false;
+  std::map<std::string, jcm::Tensor> params;
+  std::map<std::string, jcm::ConvLayer> convs;
+  std::vector<void*> owned;   // device allocations made at finalize
+  // spatial model tables
+  bool has_sm = false;
+  float* sp_energy = nullptr;   // [P][120*180]
+  float* sp_bias = nullptr;     // [P][5400]
+  float* bn_sm_scale = nullptr; // [10]
+  float* bn_sm_shift = nullptr;
+  int* cond = nullptr;          // [P] conditioning channel of pair p
+  int* cond0 = nullptr;         // single zero (jcm_conv_mrf)
+  int sm_algo = 2;              // 0 = FFT (2-D rocFFT), 1 = direct sliding-window VALU kernel, 2 = FFT with split row-pruned inverse
+  int sm_chunk = 16;            // images per FFT slice
+  jcm::SmFft* fft = nullptr;
+  float2* prior_spec = nullptr; // [P][120*91] spectra of softplus5(energy)
+  float2* prior_spec_t = nullptr; // the same, transposed [P][91][120] (split inverse)
+  // workspace arena (stack allocator, grown on demand between forwards)
+  char* arena = nullptr;
+  size_t arena_cap = 0, arena_off = 0, arena_peak = 0;
+  bool dry = false;             // sizing pass: allocate offsets only, launch nothing
+  size_t param_bytes = 0;
+  // per-layer HIP-event timing on the launch stream (bench.py roofline object)
+  bool profile = false;
+  std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
+  jcm::TrainState* train = nullptr;   // created by jcm_train_begin
+};
+
+namespace jcm {
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    (void)hipGetDevice(&prev);
+    if (prev != dev) (void)hipSetDevice(dev);
+    else prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+template <class T>
+T* arena_alloc(jcm_ctx* c, size_t count) {
+  const size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
+  const size_t off = c->arena_off;
+  c->arena_off += bytes;
+  if (c->arena_off > c->arena_peak) c->arena_peak = c->arena_off;
+  return reinterpret_cast<T*>(c->arena + off);   // in a dry pass arena may be null: offsets only
+}
+
+int arena_reserve(jcm_ctx* c, size_t bytes);
+int dev_alloc(jcm_ctx* c, void** p, size_t bytes);
+const Tensor* find(jcm_ctx* c, const std::string& name);
+int check(jcm_handle h, bool need_final);
+const ConvLayer* conv_of(jcm_ctx* c, const std::string& scope);
+int fold_bn(jcm_ctx* c, const std::string& scope, int n, float** scale, float** shift);
+// Rebuild every derived table (packed weights, folded BN, softplus'd priors and their spectra) from
+// the parameter store; called by jcm_finalize and after each optimizer update.
+int refresh_derived(jcm_ctx* c, bool first);
+int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int stride, const void* x, int B, int H, int W, int sub,
+                   void* out, bool act_bf16, bool out_f32);
+
+inline int cdiv2(int v) { return (v + 1) / 2; }
+
+// Sizing pass then the real pass, so the arena never reallocates mid-graph.
+template <class F>
+int with_arena(jcm_ctx* c, F&& body) {
+  c->dry = true;
+  c->arena_off = 0;
+  c->arena_peak = 0;
+  int r = body();
+  c->dry = false;
+  if (r != JCM_OK) return r;
+  JCM_TRY(arena_reserve(c, c->arena_peak));
+  c->arena_off = 0;
+  return body();
+}
+
+}  // namespace jcm

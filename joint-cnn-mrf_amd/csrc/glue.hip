@@ -318,4 +318,19 @@ hipError_t argmax_coords(const float* hm, int32_t* coords, int B, int HW, int WW
   return hipGetLastError();
 }
 
+// Inference BatchNorm folded to one multiply-add per channel (tf.contrib batch_norm with moving statistics).
+__global__ void bn_fold_kernel(const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ m,
+                               const float* __restrict__ v, float eps, float* __restrict__ scale, float* __restrict__ shift, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float sc = __fmul_rn(g[i], __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(v[i], eps))));
+  scale[i] = sc;
+  shift[i] = __fsub_rn(b[i], __fmul_rn(m[i], sc));
+}
+hipError_t bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale, float* shift,
+                   int n, hipStream_t st) {
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, st, gamma, beta, mean, var, eps, scale, shift, n);
+  return hipGetLastError();
+}
+
 }  // namespace jcm

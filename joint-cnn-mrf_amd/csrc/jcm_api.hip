@@ -1,124 +1,25 @@
 // libjcm C ABI (include/jcm.h): context, parameter store, weight packing, workspace arena and
 // the forward graph of main.py:29-74,94-125,522-531 as a sequence of kernel launches on one
 // HIP stream.  No tensor library types cross this boundary -- plain pointers and sizes.
-#include "../../include/jcm.h"
-
 #include <cmath>
 #include <cstdio>
 #include <cstring>
-#include <map>
-#include <string>
-#include <vector>
 
-#include "kernels.h"
+#include "ctx.h"
 
 using namespace jcm;
 
 namespace {
-
 thread_local std::string g_err;
+}
+
+namespace jcm {
+
+const char* const kJointNames[10] = {"lsho", "lelb", "lwri", "rsho", "relb", "rwri", "lhip", "rhip", "nose", "torso"};
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
-}
-
-#define HIP_TRY(expr)                                                                                   \
-  do {                                                                                                  \
-    hipError_t e_ = (expr);                                                                             \
-    if (e_ != hipSuccess)                                                                               \
-      return fail(JCM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                      \
-  } while (0)
-#define JCM_TRY(expr)          \
-  do {                         \
-    int r_ = (expr);           \
-    if (r_ != JCM_OK) return r_; \
-  } while (0)
-
-// main.py:18 -- channel order of the heat maps and of the pair tables.
-const char* const kJointNames[10] = {"lsho", "lelb", "lwri", "rsho", "relb", "rwri", "lhip", "rhip", "nose", "torso"};
-constexpr int kC = 10;            // heat-map channels seen by the spatial model (9 joints + torso)
-constexpr float kBnEps = 1e-3f;   // tf.contrib.layers.batch_norm default epsilon
-constexpr int kHmH = 60, kHmW = 90, kHmHW = kHmH * kHmW;
-constexpr int kPrH = 120, kPrW = 180;
-constexpr int kCH = 61, kCW = 91;
-
-struct Tensor {
-  std::vector<int64_t> shape;
-  float* d = nullptr;
-  size_t n = 0;
-};
-
-struct ConvLayer {
-  int ks = 0, cin = 0, cout = 0, coutp = 0;
-  bool has_bn = false;
-  const float* w_raw = nullptr;   // HWIO (conv1 kernel reads it directly)
-  float* wp = nullptr;            // packed for conv_igemm_f32
-  void* wp_bf16 = nullptr;        // packed for conv_igemm_bf16
-  void* wq1_bf16 = nullptr;       // packed for conv1_mfma_pool (5x5, Cin=3, Cout=64)
-  int coutp_bf16 = 0;
-  bool thin = false;              // fp32: conv_thin_f32 instead of conv_igemm_f32
-  bool thin_bf16 = false;         // bf16: conv_thin_bf16 (fp32 output) instead of conv_igemm_bf16
-  const float* bias = nullptr;
-  float* scale = nullptr;
-  float* shift = nullptr;
-};
-
-}  // namespace
-
-struct jcm_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  int precision = JCM_PRECISION_F32;
-  int K = 9;
-  bool finalized = false;
-  std::map<std::string, Tensor> params;
-  std::map<std::string, ConvLayer> convs;
-  std::vector<void*> owned;   // device allocations made at finalize
-  // spatial model tables
-  bool has_sm = false;
-  float* sp_energy = nullptr;   // [P][120*180]
-  float* sp_bias = nullptr;     // [P][5400]
-  float* bn_sm_scale = nullptr; // [10]
-  float* bn_sm_shift = nullptr;
-  int* cond = nullptr;          // [P] conditioning channel of pair p
-  int* cond0 = nullptr;         // single zero (jcm_conv_mrf)
-  int sm_algo = 2;              // 0 = FFT (2-D rocFFT), 1 = direct sliding-window VALU kernel, 2 = FFT with split row-pruned inverse
-  int sm_chunk = 16;            // images per FFT slice
-  SmFft* fft = nullptr;
-  float2* prior_spec = nullptr; // [P][120*91] spectra of softplus5(energy)
-  float2* prior_spec_t = nullptr; // the same, transposed [P][91][120] (split inverse)
-  // workspace arena (stack allocator, grown on demand between forwards)
-  char* arena = nullptr;
-  size_t arena_cap = 0, arena_off = 0, arena_peak = 0;
-  bool dry = false;             // sizing pass: allocate offsets only, launch nothing
-  size_t param_bytes = 0;
-  // per-layer HIP-event timing on the launch stream (bench.py roofline object)
-  bool profile = false;
-  std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
-};
-
-namespace {
-
-struct DeviceGuard {
-  int prev = -1;
-  explicit DeviceGuard(int dev) {
-    (void)hipGetDevice(&prev);
-    if (prev != dev) (void)hipSetDevice(dev);
-    else prev = -1;
-  }
-  ~DeviceGuard() {
-    if (prev >= 0) (void)hipSetDevice(prev);
-  }
-};
-
-template <class T>
-T* arena_alloc(jcm_ctx* c, size_t count) {
-  const size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
-  const size_t off = c->arena_off;
-  c->arena_off += bytes;
-  if (c->arena_off > c->arena_peak) c->arena_peak = c->arena_off;
-  return reinterpret_cast<T*>(c->arena + off);   // in a dry pass arena may be null: offsets only
 }
 
 int arena_reserve(jcm_ctx* c, size_t bytes) {
@@ -144,33 +45,20 @@ const Tensor* find(jcm_ctx* c, const std::string& name) {
   return it == c->params.end() ? nullptr : &it->second;
 }
 
-int fetch_host(jcm_ctx* c, const std::string& name, size_t n, std::vector<float>& out) {
-  const Tensor* t = find(c, name);
-  if (!t) return fail(JCM_ERR_STATE, "missing parameter '" + name + "'");
-  if (t->n != n) return fail(JCM_ERR_STATE, "parameter '" + name + "' has " + std::to_string(t->n) + " elements, expected " + std::to_string(n));
-  out.resize(n);
-  HIP_TRY(hipMemcpyAsync(out.data(), t->d, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return JCM_OK;
-}
-
 // Inference BatchNorm folded to y = x*scale + shift:  scale = gamma*rsqrt(var+eps), shift = beta-mean*scale.
+// Buffers are allocated on the first call and rewritten in place afterwards (training refresh).
 int fold_bn(jcm_ctx* c, const std::string& scope, int n, float** scale, float** shift) {
-  std::vector<float> g, b, m, v;
-  JCM_TRY(fetch_host(c, scope + "/BatchNorm/gamma", n, g));
-  JCM_TRY(fetch_host(c, scope + "/BatchNorm/beta", n, b));
-  JCM_TRY(fetch_host(c, scope + "/BatchNorm/moving_mean", n, m));
-  JCM_TRY(fetch_host(c, scope + "/BatchNorm/moving_variance", n, v));
-  std::vector<float> sc(n), sh(n);
-  for (int i = 0; i < n; ++i) {
-    sc[i] = g[i] * (1.0f / std::sqrt(v[i] + kBnEps));
-    sh[i] = b[i] - m[i] * sc[i];
+  const Tensor* t[4];
+  static const char* const kNames[4] = {"gamma", "beta", "moving_mean", "moving_variance"};
+  for (int i = 0; i < 4; ++i) {
+    const std::string name = scope + "/BatchNorm/" + kNames[i];
+    t[i] = find(c, name);
+    if (!t[i]) return fail(JCM_ERR_STATE, "missing parameter '" + name + "'");
+    if (t[i]->n != (size_t)n) return fail(JCM_ERR_STATE, "parameter '" + name + "' has " + std::to_string(t[i]->n) + " elements, expected " + std::to_string(n));
   }
-  JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(scale), n * sizeof(float)));
-  JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(shift), n * sizeof(float)));
-  HIP_TRY(hipMemcpyAsync(*scale, sc.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(*shift, sh.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));   // sc/sh are stack-local
+  if (!*scale) JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(scale), n * sizeof(float)));
+  if (!*shift) JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(shift), n * sizeof(float)));
+  HIP_TRY(bn_fold(t[0]->d, t[1]->d, t[2]->d, t[3]->d, kBnEps, *scale, *shift, n, c->stream));
   return JCM_OK;
 }
 
@@ -187,10 +75,8 @@ const ConvLayer* conv_of(jcm_ctx* c, const std::string& scope) {
 
 // One conv layer.  Activations are fp32, or bf16 when the handle runs the bf16 path (`act_bf16`);
 // `out_f32` forces an fp32 result (the logits layer).
-int run_conv(jcm_ctx* c, const std::string& scope, int stride, const void* x, int B, int H, int W, int sub, void* out,
-             bool act_bf16, bool out_f32) {
-  const ConvLayer* L = conv_of(c, scope);
-  if (!L) return fail(JCM_ERR_STATE, "no conv layer '" + scope + "' (set '" + scope + "/weights' and finalize)");
+int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int stride, const void* x, int B, int H, int W, int sub,
+                   void* out, bool act_bf16, bool out_f32) {
   if (c->dry) return JCM_OK;
   if (stride == 2) {
     if (!(L->ks == 5 && L->cin == 3 && L->has_bn))
@@ -226,7 +112,107 @@ int run_conv(jcm_ctx* c, const std::string& scope, int stride, const void* x, in
   return JCM_OK;
 }
 
-inline int cdiv2(int v) { return (v + 1) / 2; }
+}  // namespace jcm
+
+namespace jcm {
+
+int refresh_derived(jcm_ctx* c, bool first) {
+  // ---- conv layers: every "<scope>/weights" of rank 4
+  for (auto& kv : c->params) {
+    const std::string& name = kv.first;
+    const std::string suffix = "/weights";
+    if (name.size() <= suffix.size() || name.compare(name.size() - suffix.size(), suffix.size(), suffix) != 0) continue;
+    const Tensor& w = kv.second;
+    if (w.shape.size() != 4 || w.shape[0] != w.shape[1]) return fail(JCM_ERR_ARG, "'" + name + "' must be [k,k,Cin,Cout]");
+    const std::string scope = name.substr(0, name.size() - suffix.size());
+    ConvLayer L;
+    if (!first) {
+      auto it = c->convs.find(scope);
+      if (it == c->convs.end()) return fail(JCM_ERR_STATE, "conv layer '" + scope + "' appeared after jcm_finalize");
+      L = it->second;
+    }
+    L.ks = (int)w.shape[0]; L.cin = (int)w.shape[2]; L.cout = (int)w.shape[3];
+    L.w_raw = w.d;
+    const Tensor* b = find(c, scope + "/biases");
+    if (!b || b->n != (size_t)L.cout) return fail(JCM_ERR_STATE, "missing or mis-sized '" + scope + "/biases'");
+    L.bias = b->d;
+    L.has_bn = find(c, scope + "/BatchNorm/gamma") != nullptr;
+    if (L.has_bn) JCM_TRY(fold_bn(c, scope, L.cout, &L.scale, &L.shift));
+    if ((L.ks == 5 || L.ks == 9) && L.cin % 16 == 0 && c->precision == JCM_PRECISION_F32) {
+      L.thin = L.ks == 9 && L.cout <= 12;            // logits layer: 4x4x1_16b MFMA kernel, channels padded to 16
+      const int bn = L.thin ? 16 : conv_igemm_bn(L.cout);
+      L.coutp = (L.cout + bn - 1) / bn * bn;
+      const size_t n = (size_t)L.ks * L.ks * L.cin * L.coutp;
+      if (!L.wp) JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&L.wp), n * sizeof(float)));
+      HIP_TRY(pack_weights_f32(w.d, L.wp, L.ks, L.cin, L.cout, L.coutp, c->stream));
+    }
+    if (L.ks == 5 && L.cin == 3 && L.cout == 64 && L.has_bn && c->precision == JCM_PRECISION_BF16) {
+      if (!L.wq1_bf16) JCM_TRY(dev_alloc(c, &L.wq1_bf16, 5 * 2 * 64 * 16));
+      HIP_TRY(pack_conv1_bf16(w.d, L.wq1_bf16, c->stream));
+    }
+    if ((L.ks == 5 || L.ks == 9) && c->precision == JCM_PRECISION_BF16 && L.cin != 3) {
+      if (L.cin % 32 != 0) return fail(JCM_ERR_ARG, "bf16 path needs Cin % 32 == 0 ('" + scope + "' has " + std::to_string(L.cin) + ")");
+      L.thin_bf16 = L.ks == 9 && L.cout <= 16 && !L.has_bn;   // logits layer: 16x16x32 MFMA kernel, fp32 out
+      const int bn = L.thin_bf16 ? 16 : conv_igemm_bf16_bn(L.cout, L.ks);
+      L.coutp_bf16 = (L.cout + bn - 1) / bn * bn;
+      const size_t n = (size_t)L.ks * L.ks * L.cin * L.coutp_bf16;
+      if (!L.wp_bf16) JCM_TRY(dev_alloc(c, &L.wp_bf16, n * 2));
+      HIP_TRY(pack_weights_bf16(w.d, L.wp_bf16, L.ks, L.cin, L.cout, L.coutp_bf16, c->stream));
+    }
+    c->convs[scope] = L;
+  }
+  // ---- spatial model tables (main.py:477-487): pairs in graph order
+  if (find(c, "bn_sm/BatchNorm/gamma")) {
+    const int P = c->K * (kC - 1);
+    JCM_TRY(fold_bn(c, "bn_sm", kC, &c->bn_sm_scale, &c->bn_sm_shift));
+    if (first) {
+      JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->sp_energy), (size_t)P * kPrH * kPrW * sizeof(float)));
+      JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->sp_bias), (size_t)P * kHmHW * sizeof(float)));
+      JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->cond), (size_t)P * sizeof(int)));
+      JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->prior_spec), (size_t)P * kSpec * sizeof(float2)));
+      JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->prior_spec_t), (size_t)P * kSpec * sizeof(float2)));
+    }
+    std::vector<int> cond(P);
+    int p = 0;
+    for (int j = 0; j < c->K; ++j) {
+      for (int cc = 0; cc < kC; ++cc) {
+        if (cc == j) continue;
+        const std::string key = std::string(kJointNames[j]) + "_" + kJointNames[cc];
+        const Tensor* e = find(c, "energy_" + key);
+        const Tensor* bi = find(c, "bias_" + key);
+        if (!e || e->n != (size_t)kPrH * kPrW) return fail(JCM_ERR_STATE, "missing or mis-sized 'energy_" + key + "' (want [1,120,180,1])");
+        if (!bi || bi->n != (size_t)kHmHW) return fail(JCM_ERR_STATE, "missing or mis-sized 'bias_" + key + "' (want [1,60,90,1])");
+        HIP_TRY(sm_softplus5(e->d, c->sp_energy + (size_t)p * kPrH * kPrW, (int64_t)kPrH * kPrW, c->stream));   // main.py:120
+        HIP_TRY(sm_softplus5(bi->d, c->sp_bias + (size_t)p * kHmHW, kHmHW, c->stream));                          // main.py:122
+        cond[p++] = cc;
+      }
+    }
+    if (first) {
+      HIP_TRY(hipMemcpyAsync(c->cond, cond.data(), P * sizeof(int), hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));   // cond is stack-local
+    }
+    FFT_TRY(sm_fft_r2c(c->fft, c->sp_energy, c->prior_spec, P));
+    HIP_TRY(sm_transpose(c->prior_spec, c->prior_spec_t, P, kPrH, kPrW / 2 + 1, 0, kPrW / 2 + 1, c->stream));
+    c->has_sm = true;
+  }
+  if (first) {
+    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->cond0), sizeof(int)));
+    HIP_TRY(hipMemsetAsync(c->cond0, 0, sizeof(int), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  return JCM_OK;
+}
+
+}  // namespace jcm
+
+namespace {
+
+int run_conv(jcm_ctx* c, const std::string& scope, int stride, const void* x, int B, int H, int W, int sub, void* out,
+             bool act_bf16, bool out_f32) {
+  const ConvLayer* L = conv_of(c, scope);
+  if (!L) return fail(JCM_ERR_STATE, "no conv layer '" + scope + "' (set '" + scope + "/weights' and finalize)");
+  return run_conv_layer(c, L, scope, stride, x, B, H, W, sub, out, act_bf16, out_f32);
+}
 
 // model(x, n_joints), main.py:29-74.  x fp32 NHWC; intermediate activations fp32 or bf16.
 int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logits) {
@@ -297,15 +283,6 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
   return JCM_OK;
 }
 
-#define FFT_TRY(expr)                                                                 \
-  do {                                                                                \
-    const char* fe_ = (expr);                                                         \
-    if (fe_) return fail(JCM_ERR_HIP, std::string(#expr) + ": " + fe_);              \
-  } while (0)
-
-constexpr size_t kFrame = (size_t)kPrH * kPrW;          // 120*180 real
-constexpr size_t kSpec = (size_t)kPrH * (kPrW / 2 + 1); // 120*91 complex
-
 // spatial_model(heat_map), main.py:94-125.
 int sm_forward_impl(jcm_ctx* c, const float* hm10, int B, float* logits) {
   if (!c->has_sm) return fail(JCM_ERR_STATE, "spatial-model parameters (bn_sm, energy_*, bias_*) were not set");
@@ -338,7 +315,7 @@ int sm_forward_impl(jcm_ctx* c, const float* hm10, int B, float* logits) {
       FFT_TRY(sm_fft_cols(c->fft, spec_t, nb * P * WC));
       HIP_TRY(sm_transpose(spec_t, rows_c, nb * P, WC, kPrH, kPrH - kCH, kCH, c->stream));   // keep m = 59..119
       FFT_TRY(sm_fft_rows(c->fft, rows_c, rows_r, nb * P * kCH));
-      HIP_TRY(sm_finish_rows(frame, rows_r, c->sp_bias, logits + (size_t)b0 * kHmHW * c->K, nb, c->K, kC, c->stream));
+      HIP_TRY(sm_finish_rows(frame, rows_r, c->sp_bias, logits + (size_t)b0 * kHmHW * c->K, nullptr, nb, c->K, kC, c->stream));
     }
     return JCM_OK;
   }
@@ -360,20 +337,6 @@ int sm_forward_impl(jcm_ctx* c, const float* hm10, int B, float* logits) {
     HIP_TRY(sm_finish_fft(frame, cfull, c->sp_bias, logits + (size_t)b0 * kHmHW * c->K, nb, c->K, kC, c->stream));
   }
   return JCM_OK;
-}
-
-// Sizing pass then the real pass, so the arena never reallocates mid-graph.
-template <class F>
-int with_arena(jcm_ctx* c, F&& body) {
-  c->dry = true;
-  c->arena_off = 0;
-  c->arena_peak = 0;
-  int r = body();
-  c->dry = false;
-  if (r != JCM_OK) return r;
-  JCM_TRY(arena_reserve(c, c->arena_peak));
-  c->arena_off = 0;
-  return body();
 }
 
 }  // namespace
@@ -406,6 +369,7 @@ int jcm_destroy(jcm_handle h) {
   DeviceGuard g(h->device);
   (void)hipStreamSynchronize(h->stream);
   sm_fft_destroy(h->fft);
+  if (h->train) train_destroy(h);
   for (auto& kv : h->params) (void)hipFree(kv.second.d);
   for (void* p : h->owned) (void)hipFree(p);
   if (h->arena) (void)hipFree(h->arena);
@@ -469,80 +433,8 @@ int jcm_finalize(jcm_handle h) {
   JCM_TRY(check(h, false));
   if (h->finalized) return fail(JCM_ERR_STATE, "already finalized");
   DeviceGuard g(h->device);
-  jcm_ctx* c = h;
-  // ---- conv layers: every "<scope>/weights" of rank 4
-  for (auto& kv : c->params) {
-    const std::string& name = kv.first;
-    const std::string suffix = "/weights";
-    if (name.size() <= suffix.size() || name.compare(name.size() - suffix.size(), suffix.size(), suffix) != 0) continue;
-    const Tensor& w = kv.second;
-    if (w.shape.size() != 4 || w.shape[0] != w.shape[1]) return fail(JCM_ERR_ARG, "'" + name + "' must be [k,k,Cin,Cout]");
-    const std::string scope = name.substr(0, name.size() - suffix.size());
-    ConvLayer L;
-    L.ks = (int)w.shape[0]; L.cin = (int)w.shape[2]; L.cout = (int)w.shape[3];
-    L.w_raw = w.d;
-    const Tensor* b = find(c, scope + "/biases");
-    if (!b || b->n != (size_t)L.cout) return fail(JCM_ERR_STATE, "missing or mis-sized '" + scope + "/biases'");
-    L.bias = b->d;
-    L.has_bn = find(c, scope + "/BatchNorm/gamma") != nullptr;
-    if (L.has_bn) JCM_TRY(fold_bn(c, scope, L.cout, &L.scale, &L.shift));
-    if ((L.ks == 5 || L.ks == 9) && L.cin % 16 == 0 && c->precision == JCM_PRECISION_F32) {
-      L.thin = L.ks == 9 && L.cout <= 12;            // logits layer: 4x4x1_16b MFMA kernel, channels padded to 16
-      const int bn = L.thin ? 16 : conv_igemm_bn(L.cout);
-      L.coutp = (L.cout + bn - 1) / bn * bn;
-      const size_t n = (size_t)L.ks * L.ks * L.cin * L.coutp;
-      JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&L.wp), n * sizeof(float)));
-      HIP_TRY(pack_weights_f32(w.d, L.wp, L.ks, L.cin, L.cout, L.coutp, c->stream));
-    }
-    if (L.ks == 5 && L.cin == 3 && L.cout == 64 && L.has_bn && c->precision == JCM_PRECISION_BF16) {
-      JCM_TRY(dev_alloc(c, &L.wq1_bf16, 5 * 2 * 64 * 16));
-      HIP_TRY(pack_conv1_bf16(w.d, L.wq1_bf16, c->stream));
-    }
-    if ((L.ks == 5 || L.ks == 9) && c->precision == JCM_PRECISION_BF16 && L.cin != 3) {
-      if (L.cin % 32 != 0) return fail(JCM_ERR_ARG, "bf16 path needs Cin % 32 == 0 ('" + scope + "' has " + std::to_string(L.cin) + ")");
-      L.thin_bf16 = L.ks == 9 && L.cout <= 16 && !L.has_bn;   // logits layer: 16x16x32 MFMA kernel, fp32 out
-      const int bn = L.thin_bf16 ? 16 : conv_igemm_bf16_bn(L.cout, L.ks);
-      L.coutp_bf16 = (L.cout + bn - 1) / bn * bn;
-      const size_t n = (size_t)L.ks * L.ks * L.cin * L.coutp_bf16;
-      JCM_TRY(dev_alloc(c, &L.wp_bf16, n * 2));
-      HIP_TRY(pack_weights_bf16(w.d, L.wp_bf16, L.ks, L.cin, L.cout, L.coutp_bf16, c->stream));
-    }
-    c->convs[scope] = L;
-  }
-  // ---- spatial model tables (main.py:477-487): pairs in graph order
-  if (find(c, "bn_sm/BatchNorm/gamma")) {
-    const int P = c->K * (kC - 1);
-    JCM_TRY(fold_bn(c, "bn_sm", kC, &c->bn_sm_scale, &c->bn_sm_shift));
-    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->sp_energy), (size_t)P * kPrH * kPrW * sizeof(float)));
-    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->sp_bias), (size_t)P * kHmHW * sizeof(float)));
-    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->cond), (size_t)P * sizeof(int)));
-    std::vector<int> cond(P);
-    int p = 0;
-    for (int j = 0; j < c->K; ++j) {
-      for (int cc = 0; cc < kC; ++cc) {
-        if (cc == j) continue;
-        const std::string key = std::string(kJointNames[j]) + "_" + kJointNames[cc];
-        const Tensor* e = find(c, "energy_" + key);
-        const Tensor* bi = find(c, "bias_" + key);
-        if (!e || e->n != (size_t)kPrH * kPrW) return fail(JCM_ERR_STATE, "missing or mis-sized 'energy_" + key + "' (want [1,120,180,1])");
-        if (!bi || bi->n != (size_t)kHmHW) return fail(JCM_ERR_STATE, "missing or mis-sized 'bias_" + key + "' (want [1,60,90,1])");
-        HIP_TRY(sm_softplus5(e->d, c->sp_energy + (size_t)p * kPrH * kPrW, (int64_t)kPrH * kPrW, c->stream));   // main.py:120
-        HIP_TRY(sm_softplus5(bi->d, c->sp_bias + (size_t)p * kHmHW, kHmHW, c->stream));                          // main.py:122
-        cond[p++] = cc;
-      }
-    }
-    HIP_TRY(hipMemcpyAsync(c->cond, cond.data(), P * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->prior_spec), (size_t)P * kSpec * sizeof(float2)));
-    FFT_TRY(sm_fft_r2c(c->fft, c->sp_energy, c->prior_spec, P));
-    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->prior_spec_t), (size_t)P * kSpec * sizeof(float2)));
-    HIP_TRY(sm_transpose(c->prior_spec, c->prior_spec_t, P, kPrH, kPrW / 2 + 1, 0, kPrW / 2 + 1, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->has_sm = true;
-  }
-  JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->cond0), sizeof(int)));
-  HIP_TRY(hipMemsetAsync(c->cond0, 0, sizeof(int), c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  c->finalized = true;
+  JCM_TRY(refresh_derived(h, true));
+  h->finalized = true;
   return JCM_OK;
 }
 

@@ -1,0 +1,574 @@
+// Joint training step behind include/jcm.h (main.py:511-577): forward in
+// training mode (batch-statistics BatchNorm + moving-average update), the two soft-label spatial
+// cross-entropies + weight decay, the backward pass of the part detector and the spatial model,
+// and tf.train-style clip + Adam / momentum.  fp32 throughout; every convolution (forward, data
+// gradient, weight gradient) runs on v_mfma_f32_32x32x2_f32.
+#include <cmath>
+#include <cstring>
+
+#include "ctx.h"
+
+using namespace jcm;
+
+namespace jcm {
+
+struct BnSave {
+  float* mean = nullptr;   // [C] batch mean
+  float* rstd = nullptr;   // [C] 1/sqrt(biased var + eps)
+};
+
+struct DgradW {
+  float* wd = nullptr;     // packed flipped/transposed weights for conv_igemm_f32
+  int cinp = 0;            // dZ channel stride the kernel reads (= Cout rounded up to 16)
+  int coutp = 0;           // packed N extent (= Cin rounded up to the kernel's N tile)
+};
+
+struct Slot {
+  std::string name;
+  float* w;
+  size_t n, off;
+};
+
+struct TrainState {
+  std::vector<Slot> slots;             // trainable tensors, sorted by name
+  std::map<std::string, size_t> index; // name -> slot
+  size_t total = 0;
+  float* opt_m = nullptr;              // Adam m / momentum accumulator, flat [total]
+  float* opt_v = nullptr;              // Adam v, flat [total]
+  float* ones = nullptr;               // [maxC] identity epilogue scale
+  float* zeros = nullptr;              // [maxC]
+  std::map<std::string, DgradW> dgrad;
+  std::map<std::string, BnSave> bn;
+  float* scratch_flip = nullptr;       // largest flipped HWIO weight
+  double* red = nullptr;               // per-channel reduction scratch
+  double* sumsq = nullptr;             // [2]: grad sum of squares, weight sum of squares (l2)
+  float* small = nullptr;              // [2*maxC + 64] misc
+  // spatial model: per-pair parameter pointers / flat-gradient offsets, graph order
+  const float** e_ptr = nullptr;
+  const float** b_ptr = nullptr;
+  int64_t* e_off = nullptr;
+  int64_t* b_off = nullptr;
+  int maxC = 0;
+  long step = 0;                       // optimizer updates applied (n_iters, main.py:491)
+};
+
+}  // namespace jcm
+
+namespace {
+
+bool ends_with(const std::string& s, const char* suf) {
+  const size_t n = std::strlen(suf);
+  return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+bool trainable(const std::string& name) { return !ends_with(name, "moving_mean") && !ends_with(name, "moving_variance"); }
+
+int repack_dgrad(jcm_ctx* c) {
+  TrainState* t = c->train;
+  for (auto& kv : t->dgrad) {
+    const ConvLayer* L = conv_of(c, kv.first);
+    DgradW& d = kv.second;
+    HIP_TRY(flip_transpose_weights(L->w_raw, t->scratch_flip, L->ks, L->cin, L->cout, d.cinp, c->stream));
+    HIP_TRY(pack_weights_f32(t->scratch_flip, d.wd, L->ks, d.cinp, L->cin, d.coutp, c->stream));
+  }
+  return JCM_OK;
+}
+
+float* grad_of(TrainState* t, float* grads, const std::string& name) {
+  auto it = t->index.find(name);
+  return it == t->index.end() ? nullptr : grads + t->slots[it->second].off;
+}
+
+// ---- one conv layer in training mode: r = relu(conv + b) [or conv + b], batch stats, y = BN(r)
+struct LayerFwd {
+  std::string scope;
+  const ConvLayer* L = nullptr;
+  const float* in = nullptr;   // input activation (stride-1 layers) or the image (conv1)
+  int H = 0, W = 0;            // output map
+  float* r = nullptr;
+  float* y = nullptr;
+};
+
+int conv_train_fwd(jcm_ctx* c, LayerFwd& f, int stride, const float* x, int B, int Hin, int Win, int sub) {
+  TrainState* t = c->train;
+  f.L = conv_of(c, f.scope);
+  if (!f.L) return fail(JCM_ERR_STATE, "no conv layer '" + f.scope + "'");
+  f.in = x;
+  f.H = stride == 2 ? cdiv2(Hin / sub) : Hin;
+  f.W = stride == 2 ? cdiv2(Win / sub) : Win;
+  const size_t N = (size_t)B * f.H * f.W;
+  f.r = arena_alloc<float>(c, N * f.L->cout);
+  ConvLayer L = *f.L;
+  L.scale = t->ones;       // epilogue = relu(z + b) * 1 + 0
+  L.shift = t->zeros;
+  JCM_TRY(run_conv_layer(c, &L, f.scope, stride, x, B, Hin, Win, sub, f.r, false, false));
+  if (!f.L->has_bn) { f.y = f.r; return JCM_OK; }
+  f.y = arena_alloc<float>(c, N * f.L->cout);
+  if (c->dry) return JCM_OK;
+  BnSave& s = t->bn[f.scope];
+  Tensor& mm = c->params[f.scope + "/BatchNorm/moving_mean"];
+  Tensor& mv = c->params[f.scope + "/BatchNorm/moving_variance"];
+  HIP_TRY(bn_batch_stats(f.r, N, f.L->cout, kBnEps, 0.9f, s.mean, s.rstd, mm.d, mv.d, t->red, c->stream));   // main.py:129,557
+  HIP_TRY(bn_apply(f.r, s.mean, s.rstd, find(c, f.scope + "/BatchNorm/gamma")->d, find(c, f.scope + "/BatchNorm/beta")->d, f.y, N,
+                   f.L->cout, c->stream));
+  return JCM_OK;
+}
+
+// ---- backward of one BN(relu(conv+b)) layer given dy (scaled by dy_scale): fills the parameter
+// gradients, returns dz (arena) for the caller to push through wgrad / dgrad
+int conv_train_bwd_pre(jcm_ctx* c, const LayerFwd& f, const float* dy, float dy_scale, int B, float* grads, float** dz_out) {
+  TrainState* t = c->train;
+  const size_t N = (size_t)B * f.H * f.W;
+  const int C = f.L->cout;
+  float* dz = arena_alloc<float>(c, N * C);
+  *dz_out = dz;
+  if (c->dry) return JCM_OK;
+  const BnSave& s = t->bn[f.scope];
+  float* sums = t->small;   // [2C] <= 1024 floats
+  HIP_TRY(bn_bwd_reduce(dy, dy_scale, f.r, s.mean, s.rstd, N, C, sums, grad_of(t, grads, f.scope + "/BatchNorm/gamma"),
+                        grad_of(t, grads, f.scope + "/BatchNorm/beta"), t->red, c->stream));
+  HIP_TRY(bn_bwd_apply(dy, dy_scale, f.r, s.mean, s.rstd, find(c, f.scope + "/BatchNorm/gamma")->d, sums, N, C, 1, dz, c->stream));
+  HIP_TRY(col_sum(dz, N, C, grad_of(t, grads, f.scope + "/biases"), t->red, c->stream));
+  return JCM_OK;
+}
+
+// dW (+ lmbd*W) of a stride-1 layer: x = layer input [B,H,W,Cin], dz [B,H,W,ldz]
+int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const float* dz, int ldz, int B, float lmbd, float* grads) {
+  TrainState* t = c->train;
+  const ConvLayer* L = f.L;
+  const size_t n = (size_t)L->ks * L->ks * L->cin * L->cout;
+  const int splits = wgrad_splits(L->ks, L->cin, L->cout, B, f.H);
+  const size_t mark = c->arena_off;
+  float* partial = arena_alloc<float>(c, n * splits);
+  if (!c->dry) {
+    HIP_TRY(wgrad_f32(f.in, dz, partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream));
+    HIP_TRY(wgrad_reduce(partial, splits, n, L->w_raw, lmbd, grad_of(t, grads, f.scope + "/weights"), c->stream));
+  }
+  c->arena_off = mark;
+  return JCM_OK;
+}
+
+// dX = conv_SAME(dZ, flipped weights): [B,H,W,ldz] -> [B,H,W,Cin]
+int conv_dgrad(jcm_ctx* c, const LayerFwd& f, const float* dz, int B, float* dx) {
+  if (c->dry) return JCM_OK;
+  TrainState* t = c->train;
+  const DgradW& d = t->dgrad[f.scope];
+  ConvArgs a;
+  a.x = dz; a.wp = d.wd; a.bias = t->zeros; a.scale = t->ones; a.shift = t->zeros; a.out = dx;
+  a.B = B; a.H = f.H; a.W = f.W; a.Cin = d.cinp; a.Cout = f.L->cin; a.CoutP = d.coutp; a.relu_bn = 0;
+  HIP_TRY(conv_igemm_f32(a, f.L->ks, c->stream));
+  return JCM_OK;
+}
+
+__global__ void finish_losses_kernel(const float* __restrict__ ce_pd, const float* __restrict__ ce_sm, int n, const double* __restrict__ wsq,
+                                     float lmbd, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double a = 0.0, b = 0.0;
+  for (int i = 0; i < n; ++i) { a += ce_pd[i]; b += ce_sm[i]; }
+  a /= n; b /= n;
+  const double l2 = 0.5 * *wsq;
+  out[0] = (float)(a + b + (double)lmbd * l2);   // loss_tower (main.py:540)
+  out[1] = (float)a;                             // loss_pd
+  out[2] = (float)b;                             // loss_sm
+  out[3] = (float)l2;                            // weight_decay('weights')
+}
+
+int sm_train_impl(jcm_ctx* c, const float* pd_prob, const float* y, int B, float gscale, float* ce_sm, float* dlogits, float* grads);
+
+// forward + backward of one tower (main.py:522-541,559-560)
+int loss_grads_impl(jcm_ctx* c, const float* x, const float* y, int B, int H, int W, int use_sm, float lmbd, float* grads, float* losses) {
+  TrainState* t = c->train;
+  static const char* const kRes[3] = {"fullres", "halfres", "quarterres"};
+  const int K = c->K;
+  LayerFwd l1[3], l2[3], l3[3], l4[3], l5, l6;
+  float *p1[3], *p2[3];
+  for (int r = 0; r < 3; ++r) {
+    const int sub = 1 << r;
+    if (H % sub || W % sub) return fail(JCM_ERR_ARG, "training needs image sizes divisible by 4");
+    const std::string res = kRes[r];
+    l1[r].scope = "conv1_" + res; l2[r].scope = "conv2_" + res; l3[r].scope = "conv3_" + res; l4[r].scope = "conv4_" + res;
+    JCM_TRY(conv_train_fwd(c, l1[r], 2, x, B, H, W, sub));                                     // main.py:44,52,61
+    const int C1 = l1[r].L->cout;
+    const int h2 = cdiv2(l1[r].H), w2 = cdiv2(l1[r].W);
+    p1[r] = arena_alloc<float>(c, (size_t)B * h2 * w2 * C1);
+    if (!c->dry) HIP_TRY(max_pool_2x2(l1[r].y, p1[r], false, B, l1[r].H, l1[r].W, C1, c->stream));   // :45,53,62
+    JCM_TRY(conv_train_fwd(c, l2[r], 1, p1[r], B, h2, w2, 1));                                  // :46,54,63
+    const int C2 = l2[r].L->cout;
+    const int h3 = cdiv2(h2), w3 = cdiv2(w2);
+    p2[r] = arena_alloc<float>(c, (size_t)B * h3 * w3 * C2);
+    if (!c->dry) HIP_TRY(max_pool_2x2(l2[r].y, p2[r], false, B, h2, w2, C2, c->stream));            // :47,55,64
+    JCM_TRY(conv_train_fwd(c, l3[r], 1, p2[r], B, h3, w3, 1));                                  // :48,56,65
+    JCM_TRY(conv_train_fwd(c, l4[r], 1, l3[r].y, B, h3, w3, 1));                                // :49,57,66
+  }
+  const int hh = l4[0].H, ww = l4[0].W, C4 = l4[0].L->cout;
+  const size_t NP = (size_t)B * hh * ww;
+  float* merged = arena_alloc<float>(c, NP * C4);
+  if (!c->dry)
+    HIP_TRY(upsample_merge3(l4[0].y, l4[1].y, l4[1].H, l4[1].W, l4[2].y, l4[2].H, l4[2].W, merged, false, B, hh, ww, C4, c->stream));  // :58,67,69-70
+  l5.scope = "conv5"; l6.scope = "conv6";
+  JCM_TRY(conv_train_fwd(c, l5, 1, merged, B, hh, ww, 1));                                      // :71
+  JCM_TRY(conv_train_fwd(c, l6, 1, l5.y, B, hh, ww, 1));                                        // :72 (no ReLU / BN)
+  if (l6.L && (l6.L->has_bn || l6.L->cout != K)) return fail(JCM_ERR_STATE, "conv6 must be the K-channel logits layer");
+  float* logits = l6.r;
+
+  // ---- losses and the gradient w.r.t. the part-detector logits, kept with a 16-channel stride
+  constexpr int LDZ = 16;
+  float* dlog = arena_alloc<float>(c, NP * LDZ);
+  float* ce_pd = arena_alloc<float>(c, (size_t)B * K);
+  float* ce_sm = arena_alloc<float>(c, (size_t)B * K);
+  const float gscale = 1.0f / (float)(B * K);                                                  // reduce_mean over (image, joint), main.py:240
+  if (!c->dry) {
+    HIP_TRY(hipMemsetAsync(dlog, 0, NP * LDZ * sizeof(float), c->stream));
+    // use_sm == 0: hm_pred_sm_logit is hm_pred_pd_logit (main.py:535), so the same term counts twice
+    HIP_TRY(softmax_ce(logits, y, B, hh * ww, K, K + 1, use_sm ? gscale : 2.0f * gscale, ce_pd, dlog, LDZ, 0, c->stream));   // main.py:538
+  }
+  if (use_sm) {
+    if (hh != kHmH || ww != kHmW || K + 1 != kC) return fail(JCM_ERR_ARG, "the spatial model is defined for 60x90 heat maps and 9 joints");
+    float* prob = arena_alloc<float>(c, NP * K);
+    if (!c->dry) HIP_TRY(spatial_softmax(logits, prob, B, hh * ww, K, c->stream));             // main.py:523
+    JCM_TRY(sm_train_impl(c, prob, y, B, gscale, ce_sm, dlog, grads));                          // main.py:528-531,539 + backward
+  } else if (!c->dry) {
+    HIP_TRY(hipMemcpyAsync(ce_sm, ce_pd, (size_t)B * K * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  }
+  if (!c->dry) {
+    // weight_decay('weights') (main.py:195-205): sum of l2_loss over the conv weights
+    bool first = true;
+    for (const Slot& s : t->slots) {
+      if (s.name.find("weights") == std::string::npos) continue;
+      HIP_TRY(sum_squares(s.w, s.n, t->sumsq + 1, first ? 0 : 1, t->red, c->stream));
+      first = false;
+    }
+    hipLaunchKernelGGL(finish_losses_kernel, dim3(1), dim3(64), 0, c->stream, ce_pd, ce_sm, B * K, t->sumsq + 1, lmbd, losses);
+    HIP_TRY(hipGetLastError());
+  }
+
+  // ---- backward of the part detector
+  // conv6: z = conv(y5) + b
+  if (!c->dry) {
+    HIP_TRY(col_sum(dlog, NP, LDZ, t->small, t->red, c->stream));
+    HIP_TRY(hipMemcpyAsync(grad_of(t, grads, "conv6/biases"), t->small, K * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  }
+  JCM_TRY(conv_wgrad(c, l6, dlog, LDZ, B, lmbd, grads));
+  float* dy5 = arena_alloc<float>(c, NP * l5.L->cout);
+  JCM_TRY(conv_dgrad(c, l6, dlog, B, dy5));
+  float* dz5;
+  JCM_TRY(conv_train_bwd_pre(c, l5, dy5, 1.0f, B, grads, &dz5));
+  JCM_TRY(conv_wgrad(c, l5, dz5, l5.L->cout, B, lmbd, grads));
+  float* dmerged = dy5;                         // dy5 is dead once dz5 exists; same size when C4 == C5
+  if (l5.L->cin != l5.L->cout) dmerged = arena_alloc<float>(c, NP * C4);
+  JCM_TRY(conv_dgrad(c, l5, dz5, B, dmerged));
+  for (int r = 0; r < 3; ++r) {
+    const size_t mark = c->arena_off;
+    // merge: x = (x1 + up(x2) + up(x3)) / 3
+    const float* dy4 = dmerged;
+    float sc = 1.0f / 3.0f;
+    if (l4[r].H != hh || l4[r].W != ww) {
+      float* d = arena_alloc<float>(c, (size_t)B * l4[r].H * l4[r].W * C4);
+      if (!c->dry) HIP_TRY(resize_bilinear_bwd(dmerged, d, B, l4[r].H, l4[r].W, hh, ww, C4, 1.0f / 3.0f, c->stream));
+      dy4 = d;
+      sc = 1.0f;
+    }
+    float *dz4, *dz3, *dz2, *dz1;
+    JCM_TRY(conv_train_bwd_pre(c, l4[r], dy4, sc, B, grads, &dz4));
+    JCM_TRY(conv_wgrad(c, l4[r], dz4, C4, B, lmbd, grads));
+    const size_t n3 = (size_t)B * l3[r].H * l3[r].W;
+    float* dy3 = arena_alloc<float>(c, n3 * l3[r].L->cout);
+    JCM_TRY(conv_dgrad(c, l4[r], dz4, B, dy3));
+    JCM_TRY(conv_train_bwd_pre(c, l3[r], dy3, 1.0f, B, grads, &dz3));
+    JCM_TRY(conv_wgrad(c, l3[r], dz3, l3[r].L->cout, B, lmbd, grads));
+    float* dp2 = arena_alloc<float>(c, n3 * l2[r].L->cout);
+    JCM_TRY(conv_dgrad(c, l3[r], dz3, B, dp2));
+    const size_t n2 = (size_t)B * l2[r].H * l2[r].W;
+    float* dy2 = arena_alloc<float>(c, n2 * l2[r].L->cout);
+    if (!c->dry) HIP_TRY(max_pool_bwd(l2[r].y, dp2, dy2, B, l2[r].H, l2[r].W, l2[r].L->cout, c->stream));
+    JCM_TRY(conv_train_bwd_pre(c, l2[r], dy2, 1.0f, B, grads, &dz2));
+    JCM_TRY(conv_wgrad(c, l2[r], dz2, l2[r].L->cout, B, lmbd, grads));
+    float* dp1 = arena_alloc<float>(c, n2 * l1[r].L->cout);
+    JCM_TRY(conv_dgrad(c, l2[r], dz2, B, dp1));
+    const size_t n1 = (size_t)B * l1[r].H * l1[r].W;
+    const int C1 = l1[r].L->cout;
+    float* dy1 = arena_alloc<float>(c, n1 * C1);
+    if (!c->dry) HIP_TRY(max_pool_bwd(l1[r].y, dp1, dy1, B, l1[r].H, l1[r].W, C1, c->stream));
+    JCM_TRY(conv_train_bwd_pre(c, l1[r], dy1, 1.0f, B, grads, &dz1));
+    {
+      const size_t n = (size_t)25 * 3 * C1;
+      const int nb = wgrad_conv1_blocks();
+      float* partial = arena_alloc<float>(c, n * nb);
+      if (!c->dry) {
+        HIP_TRY(wgrad_conv1(x, dz1, partial, B, H, W, 1 << r, C1, c->stream));
+        HIP_TRY(wgrad_reduce(partial, nb, n, l1[r].L->w_raw, lmbd, grad_of(t, grads, l1[r].scope + "/weights"), c->stream));
+      }
+    }
+    c->arena_off = mark;
+  }
+  return JCM_OK;
+}
+
+// spatial model in training mode + its backward (main.py:528-531,539).  pd_prob [B,5400,K]; y [B,5400,K+1];
+// adds d loss_sm / d pd_logits into dlog [B,5400,16] and fills the bn_sm / energy / bias gradients.
+int sm_train_impl(jcm_ctx* c, const float* pd_prob, const float* y, int B, float gscale, float* ce_sm, float* dlog, float* grads) {
+  TrainState* t = c->train;
+  const int K = c->K, P = K * (kC - 1);
+  constexpr int WC = kPrW / 2 + 1;
+  const size_t N = (size_t)B * kHmHW;
+  float* hm10 = arena_alloc<float>(c, N * kC);
+  float* sc = arena_alloc<float>(c, 16);
+  float* sh = arena_alloc<float>(c, 16);
+  float* frame = arena_alloc<float>(c, (size_t)B * kC * kFrame);
+  float2* lhat = arena_alloc<float2>(c, (size_t)B * kC * kSpec);
+  float* tsave = arena_alloc<float>(c, (size_t)B * P * kHmHW);
+  float* sml = arena_alloc<float>(c, N * K);
+  float* G = arena_alloc<float>(c, N * K);
+  float* dh = arena_alloc<float>(c, N * kC);
+  float2* dA_hat = arena_alloc<float2>(c, (size_t)P * kSpec);
+  float* dspb = arena_alloc<float>(c, (size_t)P * kHmHW);
+  const int Bc = B < c->sm_chunk ? B : c->sm_chunk;
+  const size_t mark = c->arena_off;
+  BnSave* bs = c->dry ? nullptr : &t->bn["bn_sm"];
+  // ---- forward
+  {
+    float2* lhat_t = arena_alloc<float2>(c, (size_t)Bc * kC * kSpec);
+    float2* spec_t = arena_alloc<float2>(c, (size_t)Bc * P * kSpec);
+    float2* rows_c = arena_alloc<float2>(c, (size_t)Bc * P * kCH * WC);
+    float* rows_r = arena_alloc<float>(c, (size_t)Bc * P * kCH * kPrW);
+    if (!c->dry) {
+      HIP_TRY(sm_concat_target(pd_prob, y, hm10, N, K, kC, c->stream));                                        // main.py:528
+      HIP_TRY(bn_batch_stats(hm10, N, kC, kBnEps, 0.9f, bs->mean, bs->rstd, c->params["bn_sm/BatchNorm/moving_mean"].d,
+                             c->params["bn_sm/BatchNorm/moving_variance"].d, t->red, c->stream));              // main.py:113
+      HIP_TRY(bn_fold_stats(bs->mean, bs->rstd, find(c, "bn_sm/BatchNorm/gamma")->d, find(c, "bn_sm/BatchNorm/beta")->d, sc, sh, kC, c->stream));
+      for (int b0 = 0; b0 < B; b0 += Bc) {
+        const int nb = B - b0 < Bc ? B - b0 : Bc;
+        float* fr = frame + (size_t)b0 * kC * kFrame;
+        float2* lh = lhat + (size_t)b0 * kC * kSpec;
+        HIP_TRY(sm_pad_frame(hm10 + (size_t)b0 * kHmHW * kC, sc, sh, fr, nb, kC, c->stream));
+        FFT_TRY(sm_fft_r2c(c->fft, fr, lh, nb * kC));
+        HIP_TRY(sm_transpose(lh, lhat_t, nb * kC, kPrH, WC, 0, WC, c->stream));
+        HIP_TRY(sm_spec_mul(lhat_t, c->prior_spec_t, c->cond, spec_t, nb, kC, P, c->stream));
+        FFT_TRY(sm_fft_cols(c->fft, spec_t, nb * P * WC));
+        HIP_TRY(sm_transpose(spec_t, rows_c, nb * P, WC, kPrH, kPrH - kCH, kCH, c->stream));
+        FFT_TRY(sm_fft_rows(c->fft, rows_c, rows_r, nb * P * kCH));
+        HIP_TRY(sm_finish_rows(fr, rows_r, c->sp_bias, sml + (size_t)b0 * kHmHW * K, tsave + (size_t)b0 * P * kHmHW, nb, K, kC, c->stream));
+      }
+      HIP_TRY(softmax_ce(sml, y, B, kHmHW, K, K + 1, gscale, ce_sm, G, K, 0, c->stream));                      // main.py:539
+    }
+  }
+  c->arena_off = mark;
+  // ---- backward
+  {
+    float* D = arena_alloc<float>(c, (size_t)(Bc > 1 ? Bc : 1) * P * kFrame);      // also holds the 81 dA frames at the end
+    float2* Dhat = arena_alloc<float2>(c, (size_t)Bc * P * kSpec);
+    float2* dLhat = arena_alloc<float2>(c, (size_t)Bc * kC * kSpec);
+    float* dLframe = arena_alloc<float>(c, (size_t)Bc * kC * kFrame);
+    float* dhm = arena_alloc<float>(c, N * kC);
+    if (!c->dry) {
+      for (int b0 = 0; b0 < B; b0 += Bc) {
+        const int nb = B - b0 < Bc ? B - b0 : Bc;
+        const float* Gb = G + (size_t)b0 * kHmHW * K;
+        const float* Tb = tsave + (size_t)b0 * P * kHmHW;
+        HIP_TRY(sm_bwd_dbias(Gb, Tb, dspb, nb, K, P, b0 > 0, c->stream));
+        HIP_TRY(sm_bwd_dframe(Gb, Tb, D, nb, K, P, c->stream));
+        FFT_TRY(sm_fft_r2c(c->fft, D, Dhat, nb * P));
+        HIP_TRY(sm_bwd_spec_da(Dhat, lhat + (size_t)b0 * kC * kSpec, c->cond, dA_hat, nb, kC, P, b0 > 0, c->stream));
+        HIP_TRY(sm_bwd_spec_dl(Dhat, c->prior_spec, dLhat, nb, K, kC, c->stream));
+        FFT_TRY(sm_fft_c2r(c->fft, dLhat, dLframe, nb * kC));
+        HIP_TRY(sm_bwd_dh(dLframe, Gb, frame + (size_t)b0 * kC * kFrame, hm10 + (size_t)b0 * kHmHW * kC, sc, sh,
+                          dh + (size_t)b0 * kHmHW * kC, nb, K, kC, c->stream));
+      }
+      FFT_TRY(sm_fft_c2r(c->fft, dA_hat, D, P));
+      HIP_TRY(sm_bwd_params(D, dspb, t->e_ptr, t->b_ptr, t->e_off, t->b_off, grads, P, c->stream));
+      float* sums = t->small;
+      HIP_TRY(bn_bwd_reduce(dh, 1.0f, hm10, bs->mean, bs->rstd, N, kC, sums, grad_of(t, grads, "bn_sm/BatchNorm/gamma"),
+                            grad_of(t, grads, "bn_sm/BatchNorm/beta"), t->red, c->stream));
+      HIP_TRY(bn_bwd_apply(dh, 1.0f, hm10, bs->mean, bs->rstd, find(c, "bn_sm/BatchNorm/gamma")->d, sums, N, kC, 0, dhm, c->stream));
+      HIP_TRY(softmax_bwd(pd_prob, dhm, B, kHmHW, K, kC, dlog, 16, c->stream));                                // through main.py:523
+    }
+  }
+  c->arena_off = mark;
+  return JCM_OK;
+}
+
+int need_train(jcm_handle h) {
+  JCM_TRY(check(h, true));
+  if (!h->train) return fail(JCM_ERR_STATE, "jcm_train_begin has not been called");
+  return JCM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int jcm_train_begin(jcm_handle h) {
+  JCM_TRY(check(h, true));
+  if (h->train) return fail(JCM_ERR_STATE, "jcm_train_begin was already called");
+  if (h->precision != JCM_PRECISION_F32) return fail(JCM_ERR_STATE, "the training step is fp32 (create the handle with precision f32)");
+  DeviceGuard g(h->device);
+  jcm_ctx* c = h;
+  TrainState* t = new TrainState();
+  c->train = t;
+  for (auto& kv : c->params) {       // std::map: sorted by name
+    if (!trainable(kv.first)) continue;
+    t->index[kv.first] = t->slots.size();
+    t->slots.push_back(Slot{kv.first, kv.second.d, kv.second.n, t->total});
+    t->total += kv.second.n;
+  }
+  size_t max_w = 0;
+  for (auto& kv : c->convs) {
+    const ConvLayer& L = kv.second;
+    if (L.cout > t->maxC) t->maxC = L.cout;
+    if (L.cin > t->maxC) t->maxC = L.cin;
+    if (L.cin == 3) continue;        // conv1: no data gradient (the image is the input)
+    if (L.cin % 16 || !(L.ks == 5 || L.ks == 9)) return fail(JCM_ERR_ARG, "no training kernels for layer '" + kv.first + "'");
+    DgradW d;
+    d.cinp = (L.cout + 15) / 16 * 16;
+    const int bn = conv_igemm_bn(L.cin);
+    d.coutp = (L.cin + bn - 1) / bn * bn;
+    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&d.wd), (size_t)L.ks * L.ks * d.cinp * d.coutp * sizeof(float)));
+    const size_t nf = (size_t)L.ks * L.ks * d.cinp * L.cin;
+    if (nf > max_w) max_w = nf;
+    t->dgrad[kv.first] = d;
+  }
+  if (t->maxC < 16) t->maxC = 16;
+  JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->scratch_flip), max_w * sizeof(float)));
+  JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->opt_m), t->total * sizeof(float)));
+  JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->opt_v), t->total * sizeof(float)));
+  HIP_TRY(hipMemsetAsync(t->opt_m, 0, t->total * sizeof(float), c->stream));
+  HIP_TRY(hipMemsetAsync(t->opt_v, 0, t->total * sizeof(float), c->stream));
+  JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->ones), t->maxC * sizeof(float)));
+  JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->zeros), t->maxC * sizeof(float)));
+  {
+    std::vector<float> one(t->maxC, 1.0f);
+    HIP_TRY(hipMemcpyAsync(t->ones, one.data(), t->maxC * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(t->zeros, 0, t->maxC * sizeof(float), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  for (auto& kv : c->convs) {
+    if (!kv.second.has_bn) continue;
+    BnSave s;
+    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&s.mean), kv.second.cout * sizeof(float)));
+    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&s.rstd), kv.second.cout * sizeof(float)));
+    t->bn[kv.first] = s;
+  }
+  if (c->has_sm) {
+    BnSave s;
+    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&s.mean), kC * sizeof(float)));
+    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&s.rstd), kC * sizeof(float)));
+    t->bn["bn_sm"] = s;
+  }
+  if (c->has_sm) {
+    const int P = c->K * (kC - 1);
+    std::vector<const float*> ep(P), bp(P);
+    std::vector<int64_t> eo(P), bo(P);
+    int p = 0;
+    for (int j = 0; j < c->K; ++j)
+      for (int cc = 0; cc < kC; ++cc) {
+        if (cc == j) continue;
+        const std::string key = std::string(kJointNames[j]) + "_" + kJointNames[cc];
+        ep[p] = find(c, "energy_" + key)->d;
+        bp[p] = find(c, "bias_" + key)->d;
+        eo[p] = (int64_t)t->slots[t->index["energy_" + key]].off;
+        bo[p] = (int64_t)t->slots[t->index["bias_" + key]].off;
+        ++p;
+      }
+    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->e_ptr), P * sizeof(float*)));
+    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->b_ptr), P * sizeof(float*)));
+    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->e_off), P * sizeof(int64_t)));
+    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->b_off), P * sizeof(int64_t)));
+    HIP_TRY(hipMemcpyAsync(t->e_ptr, ep.data(), P * sizeof(float*), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(t->b_ptr, bp.data(), P * sizeof(float*), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(t->e_off, eo.data(), P * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(t->b_off, bo.data(), P * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->red), train_reduce_scratch_doubles(t->maxC) * sizeof(double)));
+  JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->sumsq), 2 * sizeof(double)));
+  JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->small), (size_t)(2 * t->maxC + 64) * sizeof(float)));
+  JCM_TRY(repack_dgrad(c));
+  return JCM_OK;
+}
+
+int jcm_train_param_count(jcm_handle h, int64_t* n_tensors, int64_t* n_elements) {
+  JCM_TRY(need_train(h));
+  if (n_tensors) *n_tensors = (int64_t)h->train->slots.size();
+  if (n_elements) *n_elements = (int64_t)h->train->total;
+  return JCM_OK;
+}
+
+int jcm_train_param_info(jcm_handle h, int64_t index, char* name, int name_cap, int64_t* offset, int64_t* count) {
+  JCM_TRY(need_train(h));
+  if (index < 0 || index >= (int64_t)h->train->slots.size()) return fail(JCM_ERR_ARG, "parameter index out of range");
+  const Slot& s = h->train->slots[(size_t)index];
+  if (name) {
+    if ((int)s.name.size() + 1 > name_cap) return fail(JCM_ERR_ARG, "name buffer too small");
+    std::memcpy(name, s.name.c_str(), s.name.size() + 1);
+  }
+  if (offset) *offset = (int64_t)s.off;
+  if (count) *count = (int64_t)s.n;
+  return JCM_OK;
+}
+
+int jcm_train_loss_grads(jcm_handle h, const float* x, const float* y, int B, int H, int W, int use_sm, float lmbd, float* grads,
+                         float* losses) {
+  JCM_TRY(need_train(h));
+  if (!x || !y || !grads || !losses || B < 1 || H < 8 || W < 8) return fail(JCM_ERR_ARG, "bad train_loss_grads arguments");
+  if (use_sm && !h->has_sm) return fail(JCM_ERR_STATE, "use_sm needs the spatial-model parameters");
+  DeviceGuard g(h->device);
+  jcm_ctx* c = h;
+  HIP_TRY(hipMemsetAsync(grads, 0, c->train->total * sizeof(float), c->stream));   // tensors the loss does not reach keep a zero gradient
+  return with_arena(c, [&] { return loss_grads_impl(c, x, y, B, H, W, use_sm, lmbd, grads, losses); });
+}
+
+int jcm_train_apply(jcm_handle h, const float* grads, int optimizer, float lr, float clip_norm, float* grad_norm_out) {
+  JCM_TRY(need_train(h));
+  if (!grads || !(lr >= 0.f)) return fail(JCM_ERR_ARG, "bad train_apply arguments");
+  if (optimizer != JCM_OPT_ADAM && optimizer != JCM_OPT_MOMENTUM) return fail(JCM_ERR_ARG, "wrong optimizer");   // main.py:506
+  DeviceGuard g(h->device);
+  jcm_ctx* c = h;
+  TrainState* t = c->train;
+  const bool clip = clip_norm > 0.f;
+  HIP_TRY(sum_squares(grads, t->total, t->sumsq, 0, t->red, c->stream));         // tf.clip_by_global_norm (main.py:302-309)
+  t->step += 1;
+  const double b1 = 0.9, b2 = 0.999;
+  const float lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow(b2, (double)t->step)) / (1.0 - std::pow(b1, (double)t->step)));
+  for (const Slot& s : t->slots) {
+    if (optimizer == JCM_OPT_ADAM)
+      HIP_TRY(adam_update(s.w, grads + s.off, t->opt_m + s.off, t->opt_v + s.off, s.n, clip ? t->sumsq : nullptr, clip_norm, lr_t, 0.9f,
+                          0.999f, 1e-8f, c->stream));
+    else
+      HIP_TRY(momentum_update(s.w, grads + s.off, t->opt_m + s.off, s.n, clip ? t->sumsq : nullptr, clip_norm, lr, 0.9f, c->stream));
+  }
+  if (grad_norm_out) {
+    double ss = 0.0;
+    HIP_TRY(hipMemcpyAsync(&ss, t->sumsq, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *grad_norm_out = (float)std::sqrt(ss);
+  }
+  JCM_TRY(refresh_derived(c, false));   // packed weights, folded moving statistics, softplus'd priors + spectra
+  JCM_TRY(repack_dgrad(c));
+  return JCM_OK;
+}
+
+int jcm_train_steps(jcm_handle h, int64_t* n_iters) {
+  JCM_TRY(need_train(h));
+  if (n_iters) *n_iters = h->train->step;
+  return JCM_OK;
+}
+
+int jcm_get_tensor(jcm_handle h, const char* name, float* out, int64_t count) {
+  JCM_TRY(check(h, false));
+  if (!name || !out) return fail(JCM_ERR_ARG, "bad get_tensor arguments");
+  const Tensor* t = find(h, name);
+  if (!t) return fail(JCM_ERR_STATE, std::string("no parameter '") + name + "'");
+  if ((int64_t)t->n != count) return fail(JCM_ERR_ARG, std::string("'") + name + "' has " + std::to_string(t->n) + " elements");
+  DeviceGuard g(h->device);
+  HIP_TRY(hipMemcpyAsync(out, t->d, t->n * sizeof(float), hipMemcpyDefault, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return JCM_OK;
+}
+
+}  // extern "C"
+
+namespace jcm {
+void train_destroy(jcm_ctx* c) {
+  delete c->train;      // device buffers are in c->owned
+  c->train = nullptr;
+}
+}  // namespace jcm

@@ -60,6 +60,9 @@ hipError_t upsample_merge3(const void* x1, const void* x2, int H2, int W2, const
 hipError_t concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, size_t N, hipStream_t st);
 hipError_t spatial_softmax(const float* in, float* out, int B, int HW, int K, hipStream_t st);
 hipError_t argmax_coords(const float* hm, int32_t* coords, int B, int HW, int WW, int K, hipStream_t st);
+// scale = gamma / sqrt(var + eps), shift = beta - mean * scale
+hipError_t bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale, float* shift,
+                   int n, hipStream_t st);
 
 // ---- spatial_model.hip -----------------------------------------------------------------------------
 // softplus5 tables of the batch-independent operands (main.py:120,122)
@@ -95,12 +98,64 @@ hipError_t sm_resize_frame(const float* cfull, float* out, int B, hipStream_t st
 const char* sm_fft_cols(SmFft* f, float2* data, int n);
 const char* sm_fft_rows(SmFft* f, float2* in, float* out, int n);
 hipError_t sm_transpose(const float2* in, float2* out, int N, int R, int C, int c0, int C_out, hipStream_t st);   // out[n][c][r] = in[n][r][c0+c]
-hipError_t sm_finish_rows(const float* frame, const float* rows, const float* spbias, float* logits, int B, int K, int C, hipStream_t st);
+// tsave (may be null): [B][P][5400] the argument of every pairwise log, kept for the training backward
+hipError_t sm_finish_rows(const float* frame, const float* rows, const float* spbias, float* logits, float* tsave, int B, int K, int C,
+                          hipStream_t st);
 
 // ---- multiscale.hip : crop/pad window + skimage-style bilinear resize, mean over scale copies ------
 // windows_dev: int32 [NW][5] = (source image, y0, x0, h, w); mm_scratch: float2 [NW]
 hipError_t window_resize(const float* src, int H, int W, int C, const int* windows_dev, int NW, float2* mm_scratch,
                          int OH, int OW, float* out, hipStream_t st);
 hipError_t group_mean(const float* in, float* out, int n, int G, size_t M, hipStream_t st);
+
+// ---- train_kernels.hip : training-step kernels other than convolutions (fp32 NHWC) ------------------
+size_t train_reduce_scratch_doubles(int C);      // scratch the per-channel reductions below need
+// batch mean / 1/sqrt(biased var + eps) of x [N,C]; moving stats (may be null) updated with `decay`
+hipError_t bn_batch_stats(const float* x, size_t N, int C, float eps, float decay, float* mean, float* rstd, float* mov_mean,
+                          float* mov_var, double* scratch, hipStream_t st);
+hipError_t bn_apply(const float* r, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y, size_t N,
+                    int C, hipStream_t st);
+// sums [2][C] = (sum dy, sum dy*(r-mean)) with dy pre-scaled by dy_scale; dgamma / dbeta may be null
+hipError_t bn_bwd_reduce(const float* dy, float dy_scale, const float* r, const float* mean, const float* rstd, size_t N, int C,
+                         float* sums, float* dgamma, float* dbeta, double* scratch, hipStream_t st);
+hipError_t bn_bwd_apply(const float* dy, float dy_scale, const float* r, const float* mean, const float* rstd, const float* gamma,
+                        const float* sums, size_t N, int C, int relu, float* dz, hipStream_t st);
+hipError_t col_sum(const float* x, size_t N, int C, float* out, double* scratch, hipStream_t st);
+hipError_t max_pool_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, hipStream_t st);
+// dx [B,h,w,C] = scale * adjoint of the TF-1.x bilinear resize h x w -> H x W applied to dy [B,H,W,C]
+hipError_t resize_bilinear_bwd(const float* dy, float* dx, int B, int h, int w, int H, int W, int C, float scale, hipStream_t st);
+hipError_t softmax_ce(const float* logits, const float* target, int B, int HW, int K, int Kt, float gscale, float* loss, float* dz,
+                      int ldz, int accumulate, hipStream_t st);
+hipError_t softmax_bwd(const float* p, const float* g, int B, int HW, int K, int ldg, float* dz, int ldz, hipStream_t st);
+hipError_t sum_squares(const float* x, size_t n, double* out, int accumulate, double* scratch, hipStream_t st);
+hipError_t adam_update(float* w, const float* g, float* m, float* v, size_t n, const double* sumsq, float clip, float lr_t, float b1,
+                       float b2, float eps, hipStream_t st);
+hipError_t momentum_update(float* w, const float* g, float* acc, size_t n, const double* sumsq, float clip, float lr, float mom,
+                           hipStream_t st);
+hipError_t scale_copy(const float* a, float s, float* out, size_t n, hipStream_t st);
+
+// ---- wgrad.hip : weight gradients on MFMA, data-gradient weight transform ------------------------------
+int wgrad_splits(int ks, int Cin, int Cout, int B, int H);
+hipError_t wgrad_f32(const float* x, const float* dz, float* partial, int splits, int ks, int B, int H, int W, int Cin, int Cout, int ldz,
+                     hipStream_t st);
+hipError_t wgrad_reduce(const float* partial, int splits, size_t n, const float* w, float lmbd, float* dw, hipStream_t st);
+int wgrad_conv1_blocks(void);
+hipError_t wgrad_conv1(const float* x, const float* dz, float* partial, int B, int H0, int W0, int sub, int Cout, hipStream_t st);
+hipError_t flip_transpose_weights(const float* w_hwio, float* wd, int ks, int Cin, int Cout, int CoP, hipStream_t st);
+
+// ---- sm_train.hip : backward of the spatial model (frequency-domain correlations) -----------------------
+hipError_t bn_fold_stats(const float* mean, const float* rstd, const float* gamma, const float* beta, float* sc, float* sh, int n,
+                         hipStream_t st);
+hipError_t sm_concat_target(const float* prob, const float* y, float* out, size_t N, int K, int C, hipStream_t st);
+// G [nb,5400,K] = dL/dE, T [nb][P][5400] saved log arguments
+hipError_t sm_bwd_dbias(const float* G, const float* T, float* dspb, int nb, int K, int P, int accumulate, hipStream_t st);
+hipError_t sm_bwd_dframe(const float* G, const float* T, float* D, int nb, int K, int P, hipStream_t st);
+hipError_t sm_bwd_spec_da(const float2* Dhat, const float2* Lhat, const int* cond, float2* dA, int nb, int C, int P, int accumulate,
+                          hipStream_t st);
+hipError_t sm_bwd_spec_dl(const float2* Dhat, const float2* Ahat, float2* dL, int nb, int K, int C, hipStream_t st);
+hipError_t sm_bwd_dh(const float* dLframe, const float* G, const float* frame, const float* hm, const float* sc, const float* sh, float* dh,
+                     int nb, int K, int C, hipStream_t st);
+hipError_t sm_bwd_params(const float* dAframe, const float* dspb, const float* const* e_ptr, const float* const* b_ptr, const int64_t* e_off,
+                         const int64_t* b_off, float* grads, int P, hipStream_t st);
 
 }  // namespace jcm

@@ -266,7 +266,7 @@ __device__ __forceinline__ float resize_from_rows(const float* __restrict__ rw, 
   return top + (bot - top) * ty;
 }
 __global__ void sm_finish_rows_kernel(const float* __restrict__ frame, const float* __restrict__ rows, const float* __restrict__ spb,
-                                      float* __restrict__ logits, int K, int C, int64_t total) {
+                                      float* __restrict__ logits, float* __restrict__ tsave, int K, int C, int64_t total) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int pix = i % FM_HW;
     int64_t r = i / FM_HW;
@@ -278,15 +278,18 @@ __global__ void sm_finish_rows_kernel(const float* __restrict__ frame, const flo
     for (int q = 0; q < PJ; ++q) {
       const int p = j * PJ + q;
       const float cv = resize_from_rows(rows + (b * P + p) * (61 * F_W), oy, ox);
-      e += logf((cv + spb[(size_t)p * FM_HW + pix]) + 1e-6f);
+      const float tv = (cv + spb[(size_t)p * FM_HW + pix]) + 1e-6f;
+      if (tsave) tsave[(b * P + p) * FM_HW + pix] = tv;      // training: the log's argument is the backward's denominator
+      e += logf(tv);
     }
     logits[(b * FM_HW + pix) * K + j] = e;
   }
 }
-hipError_t sm_finish_rows(const float* frame, const float* rows, const float* spbias, float* logits, int B, int K, int C, hipStream_t st) {
+hipError_t sm_finish_rows(const float* frame, const float* rows, const float* spbias, float* logits, float* tsave, int B, int K, int C,
+                          hipStream_t st) {
   const int64_t total = (int64_t)B * K * FM_HW;
   int64_t g = (total + 255) / 256;
-  hipLaunchKernelGGL(sm_finish_rows_kernel, dim3((int)(g > 16384 ? 16384 : g)), dim3(256), 0, st, frame, rows, spbias, logits, K, C, total);
+  hipLaunchKernelGGL(sm_finish_rows_kernel, dim3((int)(g > 16384 ? 16384 : g)), dim3(256), 0, st, frame, rows, spbias, logits, tsave, K, C, total);
   return hipGetLastError();
 }
 

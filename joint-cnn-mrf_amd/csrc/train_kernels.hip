@@ -1,0 +1,455 @@
+// Training-step kernels that are not convolutions: batch-statistics
+// BatchNorm forward/backward, ReLU / max-pool / bilinear-merge backward, the soft-label spatial
+// cross-entropy and its gradient, global-norm, Adam / momentum updates.  All tensors fp32 NHWC;
+// per-channel reductions accumulate per-thread partial sums in fp32 over short runs and combine
+// them in double, so a sum over 10^7 activations keeps fp32-exact inputs to the next stage.
+#include "kernels.h"
+
+namespace jcm {
+
+// ------------------------------------------------------------------------------------------------
+// Per-channel column reductions over a [N, C] row-major matrix.
+//   thread -> (row lane, channel), channel fastest so a wave reads contiguous memory;
+//   every block writes one double partial per (quantity, channel); a second kernel folds the blocks.
+// Op::Q quantities per element.
+// ------------------------------------------------------------------------------------------------
+constexpr int RED_THREADS = 256;
+constexpr int RED_MAX_BLOCKS = 1024;
+
+struct OpStats {              // sum x, sum x^2
+  static constexpr int Q = 2;
+  const float* x;
+  __device__ void operator()(size_t i, int, float* q) const {
+    const float v = x[i];
+    q[0] += v;
+    q[1] += v * v;
+  }
+};
+struct OpBnBwd {              // sum dy, sum dy * (r - mean)      (dy optionally pre-scaled)
+  static constexpr int Q = 2;
+  const float* dy;
+  const float* r;
+  const float* mean;
+  float dy_scale;
+  __device__ void operator()(size_t i, int c, float* q) const {
+    const float g = dy[i] * dy_scale;
+    q[0] += g;
+    q[1] += g * (r[i] - mean[c]);
+  }
+};
+struct OpSum {                // sum x   (bias gradient of a conv: sum of dz)
+  static constexpr int Q = 1;
+  const float* x;
+  __device__ void operator()(size_t i, int, float* q) const { q[0] += x[i]; }
+};
+
+template <class Op>
+__global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(Op op, size_t N, int C, double* __restrict__ partial) {
+  // partial: [gridDim.x][Q][C]
+  __shared__ float red[RED_THREADS * Op::Q];
+  const int lanes = RED_THREADS / C > 0 ? RED_THREADS / C : 1;   // row lanes per block when C <= 256
+  const int tid = threadIdx.x;
+  // channels are walked in groups of RED_THREADS when C > RED_THREADS
+  for (int c0 = 0; c0 < C; c0 += RED_THREADS) {
+    const int cw = C - c0 < RED_THREADS ? C - c0 : RED_THREADS;   // channels handled in this pass
+    const int nl = C <= RED_THREADS ? lanes : 1;
+    const int c = tid % cw, rl = tid / cw;
+    float q[Op::Q];
+#pragma unroll
+    for (int k = 0; k < Op::Q; ++k) q[k] = 0.f;
+    if (rl < nl) {
+      for (size_t row = (size_t)blockIdx.x * nl + rl; row < N; row += (size_t)gridDim.x * nl) op(row * C + c0 + c, c0 + c, q);
+    }
+#pragma unroll
+    for (int k = 0; k < Op::Q; ++k) red[k * RED_THREADS + tid] = q[k];
+    __syncthreads();
+    if (tid < cw) {
+#pragma unroll
+      for (int k = 0; k < Op::Q; ++k) {
+        double s = 0.0;
+        for (int l = 0; l < nl; ++l) s += (double)red[k * RED_THREADS + l * cw + tid];
+        partial[((size_t)blockIdx.x * Op::Q + k) * C + c0 + tid] = s;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <class Op>
+static hipError_t col_reduce(const Op& op, size_t N, int C, double* partial, int* blocks_out, hipStream_t st) {
+  const int nl = C <= RED_THREADS ? RED_THREADS / C : 1;
+  size_t want = (N + (size_t)nl * 64 - 1) / ((size_t)nl * 64);        // ~64 rows per thread
+  int blocks = (int)(want < 1 ? 1 : (want > RED_MAX_BLOCKS ? RED_MAX_BLOCKS : want));
+  hipLaunchKernelGGL(col_reduce_kernel<Op>, dim3(blocks), dim3(RED_THREADS), 0, st, op, N, C, partial);
+  *blocks_out = blocks;
+  return hipGetLastError();
+}
+
+size_t train_reduce_scratch_doubles(int C) { return (size_t)RED_MAX_BLOCKS * 2 * C; }
+
+// fold the block partials: batch mean / variance and the moving-average update of
+// tf.contrib.layers.batch_norm(decay=0.9, fused): moving_var gets the Bessel-corrected variance
+__global__ void bn_stats_finish_kernel(const double* __restrict__ partial, int blocks, int C, double N, float eps, float decay,
+                                       float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ mov_mean,
+                                       float* __restrict__ mov_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < blocks; ++b) {
+    s += partial[((size_t)b * 2 + 0) * C + c];
+    ss += partial[((size_t)b * 2 + 1) * C + c];
+  }
+  const double m = s / N;
+  double var = ss / N - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (mov_mean) {
+    const double unb = N > 1.0 ? var * (N / (N - 1.0)) : var;
+    mov_mean[c] = (float)((double)mov_mean[c] * decay + (1.0 - (double)decay) * m);
+    mov_var[c] = (float)((double)mov_var[c] * decay + (1.0 - (double)decay) * unb);
+  }
+}
+
+hipError_t bn_batch_stats(const float* x, size_t N, int C, float eps, float decay, float* mean, float* rstd, float* mov_mean,
+                          float* mov_var, double* scratch, hipStream_t st) {
+  int blocks = 0;
+  hipError_t e = col_reduce(OpStats{x}, N, C, scratch, &blocks, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, blocks, C, (double)N, eps, decay, mean,
+                     rstd, mov_mean, mov_var);
+  return hipGetLastError();
+}
+
+// y = (r - mean) * rstd * gamma + beta
+__global__ void bn_apply_kernel(const float* __restrict__ r, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y, size_t total, int C) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    y[i] = (r[i] - mean[c]) * (rstd[c] * gamma[c]) + beta[c];
+  }
+}
+hipError_t bn_apply(const float* r, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y, size_t N,
+                    int C, hipStream_t st) {
+  const size_t total = N * C;
+  size_t g = (total + 255) / 256;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((int)(g > 65536 ? 65536 : g)), dim3(256), 0, st, r, mean, rstd, gamma, beta, y, total, C);
+  return hipGetLastError();
+}
+
+// sums[0][c] = sum dy, sums[1][c] = sum dy*(r-mean)  ->  dgamma = sums[1]*rstd, dbeta = sums[0]
+__global__ void bn_bwd_finish_kernel(const double* __restrict__ partial, int blocks, int C, const float* __restrict__ rstd,
+                                     float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, sx = 0.0;
+  for (int b = 0; b < blocks; ++b) {
+    s += partial[((size_t)b * 2 + 0) * C + c];
+    sx += partial[((size_t)b * 2 + 1) * C + c];
+  }
+  sums[c] = (float)s;
+  sums[C + c] = (float)sx;
+  if (dgamma) dgamma[c] = (float)(sx * (double)rstd[c]);
+  if (dbeta) dbeta[c] = (float)s;
+}
+hipError_t bn_bwd_reduce(const float* dy, float dy_scale, const float* r, const float* mean, const float* rstd, size_t N, int C,
+                         float* sums, float* dgamma, float* dbeta, double* scratch, hipStream_t st) {
+  int blocks = 0;
+  hipError_t e = col_reduce(OpBnBwd{dy, r, mean, dy_scale}, N, C, scratch, &blocks, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, blocks, C, rstd, sums, dgamma, dbeta);
+  return hipGetLastError();
+}
+
+// dr = gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat)),  xhat = (r-mean)*rstd;  dz = relu ? dr*(r>0) : dr
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, float dy_scale, const float* __restrict__ r,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ sums, float invN, int relu, float* __restrict__ dz, size_t total, int C) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    const float rv = r[i];
+    const float rs = rstd[c];
+    const float xc = rv - mean[c];
+    const float g = dy[i] * dy_scale;
+    const float d = (gamma[c] * rs) * (g - sums[c] * invN - xc * (rs * rs) * (sums[C + c] * invN));
+    dz[i] = (relu && !(rv > 0.f)) ? 0.f : d;
+  }
+}
+hipError_t bn_bwd_apply(const float* dy, float dy_scale, const float* r, const float* mean, const float* rstd, const float* gamma,
+                        const float* sums, size_t N, int C, int relu, float* dz, hipStream_t st) {
+  const size_t total = N * C;
+  size_t g = (total + 255) / 256;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((int)(g > 65536 ? 65536 : g)), dim3(256), 0, st, dy, dy_scale, r, mean, rstd, gamma, sums,
+                     (float)(1.0 / (double)N), relu, dz, total, C);
+  return hipGetLastError();
+}
+
+__global__ void col_sum_finish_kernel(const double* __restrict__ partial, int blocks, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < blocks; ++b) s += partial[(size_t)b * C + c];
+  out[c] = (float)s;
+}
+hipError_t col_sum(const float* x, size_t N, int C, float* out, double* scratch, hipStream_t st) {
+  int blocks = 0;
+  hipError_t e = col_reduce(OpSum{x}, N, C, scratch, &blocks, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(col_sum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, blocks, C, out);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2x2 stride-2 SAME max-pool backward: the gradient of a window goes to its first maximum in
+// row-major window order (TF MaxPoolGrad).  x [B,H,W,C] is the pool input, dy [B,Ho,Wo,C].
+// ------------------------------------------------------------------------------------------------
+__global__ void max_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int H, int W,
+                                    int C, int Ho, int Wo, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    size_t r = i / C;
+    const int ix = r % W; r /= W;
+    const int iy = r % H;
+    const size_t b = r / H;
+    const int oy = iy >> 1, ox = ix >> 1;
+    const float* xb = x + b * (size_t)H * W * C;
+    int best = -1;
+    float bv = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = 2 * oy + (k >> 1), xx = 2 * ox + (k & 1);
+      if (yy < H && xx < W) {
+        const float v = xb[((size_t)yy * W + xx) * C + c];
+        if (best < 0 || v > bv) { best = k; bv = v; }
+      }
+    }
+    const int me = ((iy & 1) << 1) | (ix & 1);
+    dx[i] = me == best ? dy[((b * Ho + oy) * Wo + ox) * C + c] : 0.f;
+  }
+}
+hipError_t max_pool_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, hipStream_t st) {
+  const size_t total = (size_t)B * H * W * C;
+  size_t g = (total + 255) / 256;
+  hipLaunchKernelGGL(max_pool_bwd_kernel, dim3((int)(g > 65536 ? 65536 : g)), dim3(256), 0, st, x, dy, dx, H, W, C, (H + 1) / 2, (W + 1) / 2,
+                     total);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adjoint of the TF-1.x bilinear resize [B,h,w,C] -> [B,H,W,C] (main.py:58,67), scaled by `scale`
+// (the 1/3 of the branch merge): gathers, for every source pixel, the output pixels that read it.
+// The index / weight arithmetic is the forward's, in fp32, so both sides agree bit for bit.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bil_src(int o, float s, int n, int* lo, int* hi, float* t) {
+  const float f = __fmul_rn((float)o, s);
+  const int l = (int)floorf(f);
+  *lo = l;
+  *hi = min(l + 1, n - 1);
+  *t = f - (float)l;
+}
+__global__ void resize_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int h, int w, int H, int W, int C, float sy,
+                                  float sx, float scale, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    size_t r = i / C;
+    const int ix = r % w; r /= w;
+    const int iy = r % h;
+    const size_t b = r / h;
+    // outputs whose lo or hi index can equal iy: o*sy in [iy-1, iy+1)
+    int oy0 = (int)floorf((float)(iy - 1) / sy) - 1, oy1 = (int)ceilf((float)(iy + 1) / sy) + 1;
+    int ox0 = (int)floorf((float)(ix - 1) / sx) - 1, ox1 = (int)ceilf((float)(ix + 1) / sx) + 1;
+    oy0 = max(oy0, 0); oy1 = min(oy1, H - 1);
+    ox0 = max(ox0, 0); ox1 = min(ox1, W - 1);
+    float acc = 0.f;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+      int ylo, yhi; float ty;
+      bil_src(oy, sy, h, &ylo, &yhi, &ty);
+      float wy = 0.f;
+      if (ylo == iy) wy += 1.f - ty;
+      if (yhi == iy) wy += ty;
+      if (wy == 0.f) continue;
+      for (int ox = ox0; ox <= ox1; ++ox) {
+        int xlo, xhi; float tx;
+        bil_src(ox, sx, w, &xlo, &xhi, &tx);
+        float wx = 0.f;
+        if (xlo == ix) wx += 1.f - tx;
+        if (xhi == ix) wx += tx;
+        if (wx == 0.f) continue;
+        acc += wy * wx * dy[((b * H + oy) * W + ox) * C + c];
+      }
+    }
+    dx[i] = acc * scale;
+  }
+}
+hipError_t resize_bilinear_bwd(const float* dy, float* dx, int B, int h, int w, int H, int W, int C, float scale, hipStream_t st) {
+  const size_t total = (size_t)B * h * w * C;
+  size_t g = (total + 255) / 256;
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  hipLaunchKernelGGL(resize_bwd_kernel, dim3((int)(g > 65536 ? 65536 : g)), dim3(256), 0, st, dy, dx, h, w, H, W, C, sy, sx, scale, total);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// softmax_cross_entropy (main.py:220-240): one block per (image, joint) map of HW pixels.
+//   loss[b*K+k] = -sum_px t * log_softmax(z);  dz (+)= gscale * (softmax(z) * sum(t) - t)
+// logits [B,HW,K]; target [B,HW,Kt] (first K channels used); dz [B,HW,ldz] (channels >= K untouched).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max) {
+  const int tid = threadIdx.x;
+  sh[tid] = v;
+  __syncthreads();
+  for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+    if (tid < s) sh[tid] = is_max ? fmaxf(sh[tid], sh[tid + s]) : sh[tid] + sh[tid + s];
+    __syncthreads();
+  }
+  const float r = sh[0];
+  __syncthreads();
+  return r;
+}
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ z, const float* __restrict__ t, int HW, int K, int Kt,
+                                                         float gscale, float* __restrict__ loss, float* __restrict__ dz, int ldz,
+                                                         int accumulate) {
+  __shared__ float sh[256];
+  const int b = blockIdx.x / K, k = blockIdx.x % K;
+  const float* zb = z + (size_t)b * HW * K + k;
+  const float* tb = t + (size_t)b * HW * Kt + k;
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < HW; i += 256) m = fmaxf(m, zb[(size_t)i * K]);
+  m = block_reduce(m, sh, true);
+  float se = 0.f, st = 0.f, stz = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    const float zv = zb[(size_t)i * K] - m, tv = tb[(size_t)i * Kt];
+    se += expf(zv);
+    st += tv;
+    stz += tv * zv;
+  }
+  se = block_reduce(se, sh, false);
+  st = block_reduce(st, sh, false);
+  stz = block_reduce(stz, sh, false);
+  const float lse = logf(se);
+  if (threadIdx.x == 0) loss[blockIdx.x] = st * lse - stz;
+  if (dz) {
+    float* db = dz + (size_t)b * HW * ldz + k;
+    const float inv = 1.f / se;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+      const float p = expf(zb[(size_t)i * K] - m) * inv;
+      const float g = gscale * (p * st - tb[(size_t)i * Kt]);
+      db[(size_t)i * ldz] = accumulate ? db[(size_t)i * ldz] + g : g;
+    }
+  }
+}
+hipError_t softmax_ce(const float* logits, const float* target, int B, int HW, int K, int Kt, float gscale, float* loss, float* dz,
+                      int ldz, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(B * K), dim3(256), 0, st, logits, target, HW, K, Kt, gscale, loss, dz, ldz, accumulate);
+  return hipGetLastError();
+}
+
+// softmax backward over the pixels of each (image, joint) map: dz += p * (g - sum_px p*g)
+// p [B,HW,K] probabilities, g [B,HW,ldg] gradient w.r.t. p (first K channels), dz [B,HW,ldz].
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ g, int HW, int K, int ldg,
+                                                          float* __restrict__ dz, int ldz) {
+  __shared__ float sh[256];
+  const int b = blockIdx.x / K, k = blockIdx.x % K;
+  const float* pb = p + (size_t)b * HW * K + k;
+  const float* gb = g + (size_t)b * HW * ldg + k;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) s += pb[(size_t)i * K] * gb[(size_t)i * ldg];
+  s = block_reduce(s, sh, false);
+  float* db = dz + (size_t)b * HW * ldz + k;
+  for (int i = threadIdx.x; i < HW; i += 256) db[(size_t)i * ldz] += pb[(size_t)i * K] * (gb[(size_t)i * ldg] - s);
+}
+hipError_t softmax_bwd(const float* p, const float* g, int B, int HW, int K, int ldg, float* dz, int ldz, hipStream_t st) {
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(B * K), dim3(256), 0, st, p, g, HW, K, ldg, dz, ldz);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// optimizer side: sum of squares (double), scale, Adam / momentum (tf.train semantics)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n, double* __restrict__ partial) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const double v = x[i];
+    s += v * v;
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+__global__ void sum_partials_kernel(const double* __restrict__ partial, int n, double* __restrict__ out, int accumulate) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = accumulate ? *out : 0.0;
+    for (int i = 0; i < n; ++i) s += partial[i];
+    *out = s;
+  }
+}
+// *out (+)= sum x^2 ; scratch: 1024 doubles
+hipError_t sum_squares(const float* x, size_t n, double* out, int accumulate, double* scratch, hipStream_t st) {
+  size_t g = (n + 256 * 16 - 1) / (256 * 16);
+  const int blocks = (int)(g < 1 ? 1 : (g > 1024 ? 1024 : g));
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, x, n, scratch);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, st, scratch, blocks, out, accumulate);
+  return hipGetLastError();
+}
+
+// g *= clip / max(sqrt(*sumsq), clip)      (tf.clip_by_global_norm)
+// then Adam: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; w -= lr_t * m / (sqrt(v) + eps)
+__global__ void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                            const double* __restrict__ sumsq, float clip, float lr_t, float b1, float b2, float eps) {
+  float s = 1.f;
+  if (sumsq) {
+    const float norm = (float)sqrt(*sumsq);
+    s = clip / fmaxf(norm, clip);
+  }
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * s;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    w[i] = w[i] - lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+hipError_t adam_update(float* w, const float* g, float* m, float* v, size_t n, const double* sumsq, float clip, float lr_t, float b1,
+                       float b2, float eps, hipStream_t st) {
+  size_t gr = (n + 255) / 256;
+  hipLaunchKernelGGL(adam_kernel, dim3((int)(gr > 4096 ? 4096 : gr)), dim3(256), 0, st, w, g, m, v, n, sumsq, clip, lr_t, b1, b2, eps);
+  return hipGetLastError();
+}
+// tf.train.MomentumOptimizer: acc = mom*acc + g; w -= lr*acc
+__global__ void momentum_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ acc, size_t n,
+                                const double* __restrict__ sumsq, float clip, float lr, float mom) {
+  float s = 1.f;
+  if (sumsq) {
+    const float norm = (float)sqrt(*sumsq);
+    s = clip / fmaxf(norm, clip);
+  }
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float a = mom * acc[i] + g[i] * s;
+    acc[i] = a;
+    w[i] = w[i] - lr * a;
+  }
+}
+hipError_t momentum_update(float* w, const float* g, float* acc, size_t n, const double* sumsq, float clip, float lr, float mom,
+                           hipStream_t st) {
+  size_t gr = (n + 255) / 256;
+  hipLaunchKernelGGL(momentum_kernel, dim3((int)(gr > 4096 ? 4096 : gr)), dim3(256), 0, st, w, g, acc, n, sumsq, clip, lr, mom);
+  return hipGetLastError();
+}
+
+// out[i] = a[i] * s
+__global__ void scale_copy_kernel(const float* __restrict__ a, float s, float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = a[i] * s;
+}
+hipError_t scale_copy(const float* a, float s, float* out, size_t n, hipStream_t st) {
+  size_t g = (n + 255) / 256;
+  hipLaunchKernelGGL(scale_copy_kernel, dim3((int)(g > 65536 ? 65536 : g)), dim3(256), 0, st, a, s, out, n);
+  return hipGetLastError();
+}
+
+}  // namespace jcm

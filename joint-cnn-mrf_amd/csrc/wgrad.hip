@@ -1,0 +1,272 @@
+// Weight gradients of the SAME convolutions (training step).
+//
+//   dW[ky][kx][ci][co] = sum_{b,y,x} X[b, y+ky-PAD, x+kx-PAD, ci] * dZ[b, y, x, co]
+//
+// GEMM view: M = Cin, N = Cout, K = B*H*W pixels, one GEMM per tap.  A workgroup owns one tap
+// ROW (ky fixed, all KS values of kx) of a 64(ci) x 64(co) tile and walks K in strips of one
+// image row x 32 pixels: the strip's dZ [32 px][64 co] and the matching input-row segment
+// [32+KS-1 px][64 ci] are staged in LDS once, each wave lifts its 32 channels of both into
+// registers (KS+39 values), and the KS taps then run 16 v_mfma_f32_32x32x2_f32 each straight
+// from registers -- the kx shift is a register index.  K is split over `splits` workgroups that
+// write partial tiles; wgrad_reduce sums them in a fixed order (deterministic) and adds the
+// weight-decay term lmbd*W (main.py:540).
+#include "kernels.h"
+
+namespace jcm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WG_PW = 32;        // pixels per strip
+constexpr int WG_T = 64;         // channel tile (both ci and co)
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ partial,
+                                                        int B, int H, int W, int Cin, int Cout, int ldz, int n_ci, int n_co, int splits) {
+  constexpr int PAD = (KS - 1) / 2;
+  constexpr int XW = WG_PW + KS - 1;           // input pixels per strip
+  __shared__ float Xs[2][XW][WG_T];
+  __shared__ float Zs[2][WG_PW][WG_T];
+
+  int bid = blockIdx.x;
+  const int ky = bid % KS; bid /= KS;
+  const int cit = bid % n_ci; bid /= n_ci;
+  const int cot = bid % n_co; bid /= n_co;
+  const int split = bid;
+  const int ci0 = cit * WG_T, co0 = cot * WG_T;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wid >> 1, wo = wid & 1;
+  const int h = lane >> 5, l31 = lane & 31;
+
+  const int nseg = (W + WG_PW - 1) / WG_PW;
+  const long rows = (long)B * H;
+  const long r0 = rows * split / splits, r1 = rows * (split + 1) / splits;
+  const long nstrip = (r1 - r0) * nseg;
+
+  f32x16 acc[KS];
+#pragma unroll
+  for (int t = 0; t < KS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  // global -> register staging of one strip (zero outside the image / beyond the channel counts)
+  constexpr int XF4 = XW * WG_T / 4, ZF4 = WG_PW * WG_T / 4;
+  constexpr int XR = (XF4 + 255) / 256, ZR = (ZF4 + 255) / 256;
+  f32x4 xr[XR], zr[ZR];
+  auto gload = [&](long s) {
+    const long row = r0 + s / nseg;
+    const int seg = (int)(s % nseg);
+    const int b = (int)(row / H), y = (int)(row % H);
+    const int yi = y + ky - PAD;
+    const int px0 = seg * WG_PW;
+    const bool row_ok = (unsigned)yi < (unsigned)H;
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+      const int idx = tid + i * 256;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < XF4) {
+        const int c4 = idx % (WG_T / 4), p = idx / (WG_T / 4);
+        const int xi = px0 + p - PAD, ci = ci0 + c4 * 4;
+        if (row_ok && (unsigned)xi < (unsigned)W && ci < Cin)
+          v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + yi) * W + xi) * Cin + ci);
+      }
+      xr[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < ZR; ++i) {
+      const int idx = tid + i * 256;
+      const int c4 = idx % (WG_T / 4), p = idx / (WG_T / 4);
+      const int xo = px0 + p, co = co0 + c4 * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (xo < W && co < ldz) v = *reinterpret_cast<const f32x4*>(dz + (((size_t)b * H + y) * W + xo) * ldz + co);
+      zr[i] = v;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < XF4) *reinterpret_cast<f32x4*>(&Xs[buf][idx / (WG_T / 4)][(idx % (WG_T / 4)) * 4]) = xr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < ZR; ++i) {
+      const int idx = tid + i * 256;
+      *reinterpret_cast<f32x4*>(&Zs[buf][idx / (WG_T / 4)][(idx % (WG_T / 4)) * 4]) = zr[i];
+    }
+  };
+
+  if (nstrip > 0) gload(0);
+  int buf = 0;
+  for (long s = 0; s < nstrip; ++s) {
+    lstore(buf);
+    __syncthreads();                       // strip s visible.  One barrier per strip is enough with two buffers: a wave reaches
+                                           // this barrier only after its reads of strip s-1, and buffer `buf` is rewritten at s+2
+    if (s + 1 < nstrip) gload(s + 1);      // in flight behind this strip's MFMAs
+    // lift this wave's operands into registers: lane (l31, h) needs input pixels h + m, m = 0 .. 30+KS-1 (even steps use m = 2kk+kx)
+    constexpr int NA = WG_PW - 2 + KS;     // avv[2kk + kx] = input pixel 2kk + kx + h of the strip, 2kk + kx = 0 .. 30+KS-1
+    float avv[NA];
+    float bv[WG_PW / 2];
+#pragma unroll
+    for (int m = 0; m < NA; ++m) avv[m] = Xs[buf][m + h][wi * 32 + l31];
+#pragma unroll
+    for (int kk = 0; kk < WG_PW / 2; ++kk) bv[kk] = Zs[buf][2 * kk + h][wo * 32 + l31];
+#pragma unroll
+    for (int kk = 0; kk < WG_PW / 2; ++kk)
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(avv[2 * kk + kx], bv[kk], acc[kx], 0, 0, 0);
+    buf ^= 1;
+  }
+
+  // ---- partial tile store: D col = lane&31 -> co, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -> ci
+  float* out = partial + (size_t)split * KS * KS * Cin * Cout;
+  const int co = co0 + wo * 32 + l31;
+  if (co < Cout) {
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ci = ci0 + wi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (ci < Cin) out[(((size_t)ky * KS + kx) * Cin + ci) * Cout + co] = acc[kx][i];
+      }
+    }
+  }
+}
+
+int wgrad_splits(int ks, int Cin, int Cout, int B, int H) {
+  const int n_ci = (Cin + WG_T - 1) / WG_T, n_co = (Cout + WG_T - 1) / WG_T;
+  const int base = ks * n_ci * n_co;
+  int s = (2048 + base - 1) / base;            // ~8 workgroups per CU
+  const long rows = (long)B * H;
+  if (s > rows) s = (int)rows;
+  if (s > 256) s = 256;
+  return s < 1 ? 1 : s;
+}
+
+// x [B,H,W,Cin] (Cin % 4 == 0), dz [B,H,W,ldz] (ldz % 4 == 0, first Cout channels used), partial [splits][KS][KS][Cin][Cout]
+hipError_t wgrad_f32(const float* x, const float* dz, float* partial, int splits, int ks, int B, int H, int W, int Cin, int Cout, int ldz,
+                     hipStream_t st) {
+  if (Cin % 4 || ldz % 4) return hipErrorInvalidValue;
+  const int n_ci = (Cin + WG_T - 1) / WG_T, n_co = (Cout + WG_T - 1) / WG_T;
+  const int blocks = ks * n_ci * n_co * splits;
+  if (ks == 9)
+    hipLaunchKernelGGL(wgrad_kernel<9>, dim3(blocks), dim3(256), 0, st, x, dz, partial, B, H, W, Cin, Cout, ldz, n_ci, n_co, splits);
+  else if (ks == 5)
+    hipLaunchKernelGGL(wgrad_kernel<5>, dim3(blocks), dim3(256), 0, st, x, dz, partial, B, H, W, Cin, Cout, ldz, n_ci, n_co, splits);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// dw[i] = sum_s partial[s][i] + lmbd * w[i]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, size_t n, const float* __restrict__ w, float lmbd,
+                                    float* __restrict__ dw) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    double s = 0.0;                           // partial tiles cancel heavily (BN backward makes sum(dz) ~ 0)
+    for (int k = 0; k < splits; ++k) s += (double)partial[(size_t)k * n + i];
+    dw[i] = (float)s + lmbd * w[i];
+  }
+}
+hipError_t wgrad_reduce(const float* partial, int splits, size_t n, const float* w, float lmbd, float* dw, hipStream_t st) {
+  size_t g = (n + 255) / 256;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)(g > 16384 ? 16384 : g)), dim3(256), 0, st, partial, splits, n, w, lmbd, dw);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv1: 5x5 stride-2 SAME (pad 1 before, 2 after), Cin = 3, on the sub-sampled image
+// x[:, ::sub, ::sub].  75 x Cout outputs, K = B*Ho*Wo pixels: VALU, one workgroup per strip of
+// output rows; thread -> (co, tap group); partial sums per workgroup, reduced by wgrad_reduce.
+// ------------------------------------------------------------------------------------------------
+constexpr int W1_PX = 64;          // output pixels per LDS strip
+__global__ __launch_bounds__(256) void wgrad_conv1_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                          float* __restrict__ partial, int B, int H0, int W0, int sub, int Ho, int Wo,
+                                                          int Cout, int nblk) {
+  // LDS: input patch rows for one output row segment: 5 rows x (2*W1_PX + 3) px x 3 ch; dz [W1_PX][Cout<=64]
+  __shared__ float Xs[5][2 * W1_PX + 3][3];
+  __shared__ float Zs[W1_PX][64];
+  const int tid = threadIdx.x;
+  const int co = tid & 63, grp = tid >> 6;          // 4 groups share the 75 (tap, ci) rows: 19 each
+  constexpr int NJ = 19;
+  float acc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
+  const int Hs = H0 / sub, Ws = W0 / sub;           // sub-sampled image size
+  const int nseg = (Wo + W1_PX - 1) / W1_PX;
+  const long nstrip = (long)B * Ho * nseg;
+  for (long s = blockIdx.x; s < nstrip; s += nblk) {
+    const int seg = (int)(s % nseg);
+    const long row = s / nseg;
+    const int b = (int)(row / Ho), oy = (int)(row % Ho);
+    const int ox0 = seg * W1_PX;
+    __syncthreads();
+    for (int idx = tid; idx < 5 * (2 * W1_PX + 3) * 3; idx += 256) {
+      const int ch = idx % 3;
+      int r = idx / 3;
+      const int px = r % (2 * W1_PX + 3), ry = r / (2 * W1_PX + 3);
+      const int iy = 2 * oy + ry - 1, ix = 2 * ox0 + px - 1;
+      float v = 0.f;
+      if ((unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws) v = x[(((size_t)b * H0 + (size_t)iy * sub) * W0 + (size_t)ix * sub) * 3 + ch];
+      Xs[ry][px][ch] = v;
+    }
+    for (int idx = tid; idx < W1_PX * 64; idx += 256) {
+      const int c = idx & 63, p = idx >> 6;
+      const int ox = ox0 + p;
+      Zs[p][c] = (ox < Wo && c < Cout) ? dz[(((size_t)b * Ho + oy) * Wo + ox) * Cout + c] : 0.f;
+    }
+    __syncthreads();
+    for (int p = 0; p < W1_PX; ++p) {
+      const float g = Zs[p][co];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int rix = grp + 4 * j;              // (tap*3 + ci) index, < 75
+        if (rix < 75) {
+          const int tap = rix / 3, ch = rix - tap * 3;
+          const int ky = tap / 5, kx = tap - ky * 5;
+          acc[j] += Xs[ky][2 * p + kx][ch] * g;
+        }
+      }
+    }
+  }
+  if (co < Cout) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int rix = grp + 4 * j;
+      if (rix < 75) partial[((size_t)blockIdx.x * 75 + rix) * Cout + co] = acc[j];
+    }
+  }
+}
+int wgrad_conv1_blocks(void) { return 1024; }
+// partial: [wgrad_conv1_blocks()][5][5][3][Cout]
+hipError_t wgrad_conv1(const float* x, const float* dz, float* partial, int B, int H0, int W0, int sub, int Cout, hipStream_t st) {
+  if (Cout > 64) return hipErrorInvalidValue;
+  const int Hs = H0 / sub, Ws = W0 / sub;
+  const int Ho = (Hs + 1) / 2, Wo = (Ws + 1) / 2;
+  const int nblk = wgrad_conv1_blocks();
+  hipLaunchKernelGGL(wgrad_conv1_kernel, dim3(nblk), dim3(256), 0, st, x, dz, partial, B, H0, W0, sub, Ho, Wo, Cout, nblk);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Data-gradient weights: dX = conv_SAME(dZ, Wd) with Wd[ky][kx][co][ci] = W[KS-1-ky][KS-1-kx][ci][co]
+// (stride 1, odd KS).  `CoP` pads the (new) input-channel axis with zeros (dZ channel stride).
+// ------------------------------------------------------------------------------------------------
+__global__ void flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wd, int ks, int Cin, int Cout, int CoP) {
+  const size_t n = (size_t)ks * ks * CoP * Cin;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int ci = i % Cin;
+    size_t r = i / Cin;
+    const int co = r % CoP;
+    const int tap = r / CoP;
+    const int ky = tap / ks, kx = tap - ky * ks;
+    wd[i] = co < Cout ? w[((((size_t)(ks - 1 - ky) * ks) + (ks - 1 - kx)) * Cin + ci) * Cout + co] : 0.f;
+  }
+}
+hipError_t flip_transpose_weights(const float* w_hwio, float* wd, int ks, int Cin, int Cout, int CoP, hipStream_t st) {
+  hipLaunchKernelGGL(flip_transpose_kernel, dim3(2048), dim3(256), 0, st, w_hwio, wd, ks, Cin, Cout, CoP);
+  return hipGetLastError();
+}
+
+}  // namespace jcm

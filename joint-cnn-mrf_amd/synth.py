@@ -141,3 +141,18 @@ def make_torso(batch, seed=4321, hm_height=60, hm_width=90):
         r, c = rs.randint(1, hm_height - 1), rs.randint(1, hm_width - 1)
         t[b, r - 1:r + 2, c - 1:c + 2, 0] = kern
     return t
+
+
+def make_targets(batch, seed=4321, hm_height=60, hm_width=90, n_channels=10):
+    """[B,60,90,10] target heat maps y_in (main.py:488): one 3x3 binomial blob per joint and image
+    (data.py:112-114,180-186).  Channel 9 (torso) uses the same stream as `make_torso(batch, seed)`
+    so `make_targets(...)[..., 9:]` equals it."""
+    kern = np.outer([1, 2, 1], [1, 2, 1]).astype(np.float32) / 16
+    t = np.zeros((batch, hm_height, hm_width, n_channels), np.float32)
+    t[..., n_channels - 1:] = make_torso(batch, seed, hm_height, hm_width)
+    rs = np.random.RandomState(seed + 1)
+    for b in range(batch):
+        for k in range(n_channels - 1):
+            r, c = rs.randint(1, hm_height - 1), rs.randint(1, hm_width - 1)
+            t[b, r - 1:r + 2, c - 1:c + 2, k] = kern
+    return t

@@ -1,0 +1,114 @@
+"""Host side of the joint training step (reference: main.py:464-470,491-506,511-577,644).
+
+`Trainer` wraps an fp32 `Engine`: `loss_and_grads` is one tower's forward (training-mode BatchNorm)
++ `opt.compute_gradients`; `train_step` adds the tower average (an RCCL all-reduce of the flat
+gradient buffer when `torch.distributed` is initialised -- average_gradients, main.py:243-267),
+`grad_renorm(., 4.0)` and `opt.apply_gradients`.  The arithmetic is libjcm's HIP kernels; torch
+only owns the buffers and runs the collective.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+CLIP_NORM = 4.0      # main.py:576
+
+
+def piecewise_lr(n_iters, n_updates_total, lr):
+    """lr_tf of main.py:467-469,492: tf.train.piecewise_constant(n_iters, round([.7,.8,.9]*total),
+    [lr, lr/2, lr/5, lr/10]) -- the value used by update number n_iters+1."""
+    bounds = [round(0.7 * n_updates_total), round(0.8 * n_updates_total), round(0.9 * n_updates_total)]
+    vals = [lr, lr / 2, lr / 5, lr / 10]
+    for b, v in zip(bounds, vals):
+        if n_iters <= b:
+            return v
+    return vals[-1]
+
+
+class Trainer:
+    def __init__(self, engine, optimizer='adam', lr=0.001, lmbd=0.001, use_sm=True, n_updates_total=None):
+        if engine.precision not in ('fp32', 'f32'):
+            raise ValueError('the training step is fp32')
+        if optimizer not in ('adam', 'momentum'):
+            raise Exception('wrong optimizer')                      # main.py:506
+        self.eng = engine
+        self.optimizer, self.lr, self.lmbd, self.use_sm = optimizer, float(lr), float(lmbd), bool(use_sm)
+        self.n_updates_total = n_updates_total
+        self._lib = engine._lib
+        _lib.check(self._lib.jcm_train_begin(engine._h), 'jcm_train_begin')
+        nt, ne = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(self._lib.jcm_train_param_count(engine._h, ctypes.byref(nt), ctypes.byref(ne)), 'jcm_train_param_count')
+        self.n_elements = ne.value
+        self.layout = []                                            # (name, offset, count)
+        buf = ctypes.create_string_buffer(256)
+        for i in range(nt.value):
+            off, cnt = ctypes.c_int64(), ctypes.c_int64()
+            _lib.check(self._lib.jcm_train_param_info(engine._h, i, buf, 256, ctypes.byref(off), ctypes.byref(cnt)),
+                       'jcm_train_param_info')
+            self.layout.append((buf.value.decode(), off.value, cnt.value))
+        self.grads = torch.zeros(self.n_elements, dtype=torch.float32, device=engine.device)
+        self.losses = torch.zeros(4, dtype=torch.float32, device=engine.device)
+
+    @property
+    def n_iters(self):
+        n = ctypes.c_int64()
+        _lib.check(self._lib.jcm_train_steps(self.eng._h, ctypes.byref(n)), 'jcm_train_steps')
+        return n.value
+
+    def loss_and_grads(self, x, y):
+        """x [B,H,W,3], y [B,60,90,K+1] -> (losses[4] device tensor, flat grads device tensor).
+        losses = (loss_tower, loss_pd, loss_sm, weight_decay)."""
+        e = self.eng
+        e._chk(x, 4, 'x')
+        e._chk(y, 4, 'y')
+        B, H, W, C = x.shape
+        if C != 3 or y.shape[0] != B or y.shape[3] != e.n_joints + 1:
+            raise ValueError('x must be [B,H,W,3] and y [B,h,w,%d]; got %s, %s' % (e.n_joints + 1, tuple(x.shape), tuple(y.shape)))
+        _lib.check(self._lib.jcm_train_loss_grads(e._h, e._p(x), e._p(y), B, H, W, int(self.use_sm), self.lmbd,
+                                                  e._p(self.grads), e._p(self.losses)), 'jcm_train_loss_grads')
+        return self.losses, self.grads
+
+    def grads_dict(self):
+        """The flat gradient buffer as {TF variable name: numpy array} (reference shapes unknown here: flat)."""
+        g = self.grads.cpu().numpy()
+        return {n: g[o:o + c].copy() for n, o, c in self.layout}
+
+    def average_gradients(self):
+        """main.py:243-267 across ranks: mean of the per-tower gradients."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if dist.get_backend() == 'gloo':
+                g = self.grads.cpu()
+                dist.all_reduce(g)
+                self.grads.copy_(g)
+            else:
+                dist.all_reduce(self.grads)
+            self.grads.div_(dist.get_world_size())
+
+    def apply(self, lr=None, want_norm=False):
+        """grad_renorm + apply_gradients (main.py:576-577) on self.grads."""
+        if lr is None:
+            lr = self.lr if self.n_updates_total is None else piecewise_lr(self.n_iters, self.n_updates_total, self.lr)
+        norm = ctypes.c_float()
+        opt = _lib.JCM_OPT_ADAM if self.optimizer == 'adam' else _lib.JCM_OPT_MOMENTUM
+        _lib.check(self._lib.jcm_train_apply(self.eng._h, self.eng._p(self.grads), opt, float(lr), CLIP_NORM,
+                                             ctypes.byref(norm) if want_norm else None), 'jcm_train_apply')
+        return norm.value if want_norm else None
+
+    def train_step(self, x, y, want_norm=False):
+        """One sess.run(train_step) (main.py:644).  Returns (losses tensor, grad norm or None)."""
+        self.loss_and_grads(x, y)
+        self.average_gradients()
+        return self.losses, self.apply(want_norm=want_norm)
+
+    def get_tensor(self, name, shape):
+        out = np.empty(int(np.prod(shape)), np.float32)
+        _lib.check(self._lib.jcm_get_tensor(self.eng._h, name.encode(), ctypes.c_void_p(out.ctypes.data), out.size),
+                   'jcm_get_tensor(%s)' % name)
+        return out.reshape(shape)
+
+    def get_params(self, like):
+        """All stored parameters with the shapes of the dict `like` (what Saver.save would write)."""
+        return {k: self.get_tensor(k, np.asarray(v).shape) for k, v in like.items()}
