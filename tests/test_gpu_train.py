@@ -83,3 +83,65 @@ def test_joint_loss_and_grads(debug_case):
     eng.close()
     np.testing.assert_allclose(l, [ref['loss'], ref['loss_pd'], ref['loss_sm'], ref['l2']], rtol=2e-5)
     check_grads(got, ref['grads'], ref32['grads'], verbose=True)
+
+
+def test_moving_statistics_update(debug_case):
+    """UPDATE_OPS (main.py:557): moving = 0.9*moving + 0.1*batch, variance Bessel-corrected."""
+    p, x, y = debug_case
+    ref = T.loss_and_grads(x, y, p, use_sm=True)
+    want = T.update_moving(p, ref['bn_stats'])
+    eng, tr = make_trainer(p, use_sm=True)
+    tr.loss_and_grads(dev(x), dev(y))
+    got = {k: tr.get_tensor(k, np.asarray(p[k]).shape) for k in want}
+    eng.close()
+    for k in want:
+        np.testing.assert_allclose(got[k], want[k], rtol=2e-5, atol=1e-7, err_msg=k)
+
+
+@pytest.mark.parametrize('optimizer', ['adam', 'momentum'])
+def test_apply_gradients(debug_case, optimizer):
+    """grad_renorm(4.0) + apply_gradients (main.py:576-577) on the gradients the GPU produced: the
+    restated tf.train update applied to the same numbers must land on the same parameters, two updates
+    in a row (slots carried over).  Then every derived table must have followed: the inference tower
+    evaluated with the new parameters equals the oracle's."""
+    import oracle.jcm_oracle as O
+    p, x, y = debug_case
+    eng, tr = make_trainer(p, use_sm=True, optimizer=optimizer, lr=0.01)
+    cur = {k: np.asarray(v, np.float64) for k, v in p.items()}
+    slots = {}
+    shapes = {k: np.asarray(v).shape for k, v in p.items()}
+    for step in (1, 2):
+        tr.loss_and_grads(dev(x), dev(y))
+        g = {k: v.astype(np.float64).reshape(shapes[k]) for k, v in tr.grads_dict().items()}
+        for k in list(cur):                       # moving statistics were advanced by the forward
+            if k.endswith('moving_mean') or k.endswith('moving_variance'):
+                cur[k] = tr.get_tensor(k, shapes[k]).astype(np.float64)
+        clipped, norm = T.clip_by_global_norm(g)
+        upd = T.adam_apply(cur, clipped, slots, step, 0.01) if optimizer == 'adam' else T.momentum_apply(cur, clipped, slots, 0.01)
+        cur.update(upd)
+        got_norm = tr.apply(want_norm=True)
+        assert abs(got_norm - norm) <= 1e-5 * norm
+        assert tr.n_iters == step
+        got = tr.get_params(p)
+        for k in cur:
+            np.testing.assert_allclose(got[k], cur[k], rtol=2e-6, atol=2e-7, err_msg='%s after update %d' % (k, step))
+    xs, torso = x[:1], y[:1, :, :, 9:]
+    r = eng.forward(dev(xs), dev(torso), use_sm=True)
+    ref = O.forward(xs.astype(np.float64), torso.astype(np.float64), {k: v.astype(np.float64) for k, v in got.items()})
+    eng.close()
+    np.testing.assert_allclose(r['pd_prob'].cpu().numpy(), ref['pd_prob'], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(r['sm_prob'].cpu().numpy(), ref['sm_prob'], atol=1e-4, rtol=0)
+
+
+def test_loss_goes_down(debug_case):
+    p, x, y = debug_case
+    eng, tr = make_trainer(p, use_sm=True, optimizer='adam', lr=0.001)
+    xs, ys = dev(x), dev(y)
+    hist = []
+    for _ in range(6):
+        losses, _ = tr.train_step(xs, ys)
+        hist.append(losses.cpu().numpy().copy())
+    eng.close()
+    hist = np.array(hist)
+    assert np.isfinite(hist).all()
+    assert hist[-1, 0] < hist[0, 0], hist[:, 0]
