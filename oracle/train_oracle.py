@@ -145,7 +145,7 @@ def loss_and_grads(x_nhwc, y_nhwc, params, use_sm=True, lmbd=0.001, n_joints=N_J
     loss = loss_pd + loss_sm + lmbd * l2
     names = [k for k in sorted(p) if p[k].requires_grad]
     gs = torch.autograd.grad(loss, [p[k] for k in names], allow_unused=True)
-    r.update(loss=float(loss), loss_pd=float(loss_pd), loss_sm=float(loss_sm), l2=float(l2),
+    r.update(loss=float(loss.detach()), loss_pd=float(loss_pd.detach()), loss_sm=float(loss_sm.detach()), l2=float(l2.detach()),
              grads={k: (np.zeros(tuple(p[k].shape)) if g is None else g.numpy()) for k, g in zip(names, gs)},
              bn_stats={k: (m.numpy(), v.numpy()) for k, (m, v) in stats.items()})
     return r

@@ -106,7 +106,7 @@ def test_apply_gradients(debug_case, optimizer):
     evaluated with the new parameters equals the oracle's."""
     import oracle.jcm_oracle as O
     p, x, y = debug_case
-    eng, tr = make_trainer(p, use_sm=True, optimizer=optimizer, lr=0.01)
+    eng, tr = make_trainer(p, use_sm=True, optimizer=optimizer, lr=0.001)
     cur = {k: np.asarray(v, np.float64) for k, v in p.items()}
     slots = {}
     shapes = {k: np.asarray(v).shape for k, v in p.items()}
@@ -117,7 +117,7 @@ def test_apply_gradients(debug_case, optimizer):
             if k.endswith('moving_mean') or k.endswith('moving_variance'):
                 cur[k] = tr.get_tensor(k, shapes[k]).astype(np.float64)
         clipped, norm = T.clip_by_global_norm(g)
-        upd = T.adam_apply(cur, clipped, slots, step, 0.01) if optimizer == 'adam' else T.momentum_apply(cur, clipped, slots, 0.01)
+        upd = T.adam_apply(cur, clipped, slots, step, 0.001) if optimizer == 'adam' else T.momentum_apply(cur, clipped, slots, 0.001)
         cur.update(upd)
         got_norm = tr.apply(want_norm=True)
         assert abs(got_norm - norm) <= 1e-5 * norm
