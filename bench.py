@@ -131,6 +131,57 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm):
     return out
 
 
+# Training step (BASELINE.json configs[4]): algorithmic FLOPs per image = forward + data gradient + weight
+# gradient of every conv (no data gradient for the three conv1 layers) + 3x the pairwise term.
+FLOPS_CONV1 = 1_088_640_000 + 272_160_000 + 68_040_000          # conv1 full/half/quarter
+FLOPS_TRAIN = 3 * FLOPS_PD_SM - FLOPS_CONV1
+
+
+def run_train(args, B, params, world, rank, local_rank, dev, use_sm):
+    """`--train`: time the joint training step (loss + gradients, gradient all-reduce, clip + Adam, table
+    refresh) on B images per GPU; data-parallel, one RCCL all-reduce of the flat gradient buffer per step."""
+    from joint_cnn_mrf_amd.train import Trainer
+    eng = Engine(device=local_rank, precision='fp32').load_params(params)
+    tr = Trainer(eng, optimizer='adam', lr=0.001, lmbd=0.001, use_sm=use_sm)
+    x = torch.as_tensor(synth.make_images(B, seed=1234 + rank), device=dev)
+    y = torch.as_tensor(synth.make_targets(B, seed=4321 + rank), device=dev)
+    moving = Trainer.moving_statistics_of(params) if world > 1 else None
+    for _ in range(args.warmup):
+        tr.train_step(x, y, moving=moving)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses, _ = tr.train_step(x, y, moving=moving)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    out = None
+    if rank == 0:
+        value = world * B * args.steps / dt
+        scale = 16 if args.debug else 1
+        out = {'metric': 'images/sec joint training step (fwd+bwd+update), part detector + spatial model', 'value': value,
+               'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': 'configs[4]: joint training, batch=%d/GPU synthetic 480x720x3, fp32 MFMA, Adam, clip 4.0%s'
+                                      % (B, ', DEBUG filters/4' if args.debug else ''),
+                          'batch_per_gpu': B, 'global_batch': world * B, 'use_sm': use_sm,
+                          'collective': 'all_reduce of %d fp32 gradients' % tr.n_elements},
+               'train_tflops': value * FLOPS_TRAIN / scale / 1e12, 'mfma_peak_tflops': PEAK_TFLOPS['fp32'],
+               'frac_of_fp32_mfma_peak': value * FLOPS_TRAIN / scale / 1e12 / PEAK_TFLOPS['fp32'],
+               'loss': [float(v) for v in losses.cpu().numpy()], 'workspace_gb': eng.workspace_bytes() / 1e9}
+    eng.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -143,6 +194,8 @@ def main():
     ap.add_argument('--no-sm', action='store_true', help='part detector only')
     ap.add_argument('--debug', action='store_true', help='filters/4 (main.py:40-41); not the headline config, fp32 only')
     ap.add_argument('--cpu-images', type=int, default=4, help='size of the cpu_baseline sample (0 = skip)')
+    ap.add_argument('--train', action='store_true', help='time the joint training step (configs[4]) instead of the forward; fp32, '
+                                                         'default 16 images per GPU (batch 128 over 8 GPUs)')
     ap.add_argument('--layer-times', action='store_true', help='print the HIP-event time of every MFMA conv layer to stderr')
     args = ap.parse_args()
 
@@ -170,6 +223,14 @@ def main():
     params = synth.make_pd_params(debug=args.debug)                    # He init, BN identity (main.py:138-153)
     if use_sm:
         params.update(synth.make_sm_params(synth.synthetic_priors(), kind='init'))   # main.py:477-487
+
+    if args.train:
+        out = run_train(args, args.batch or 16, params, world, rank, local_rank, dev, use_sm)
+        if rank == 0:
+            print(json.dumps(out))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     head_dtype = args.dtype or 'fp32'
     head_batch = args.batch or (64 if head_dtype == 'fp32' else 256)

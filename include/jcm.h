@@ -149,6 +149,10 @@ int jcm_train_apply(jcm_handle h, const float* grads, int optimizer, float lr, f
 int jcm_train_steps(jcm_handle h, int64_t* n_iters);     /* n_iters_tf (main.py:491) */
 /* Saver.save side (main.py:666): copy a stored parameter out (host or device pointer). */
 int jcm_get_tensor(jcm_handle h, const char* name, float* out, int64_t count);
+/* Saver.restore on a live session (main.py:612): overwrite a stored parameter after jcm_finalize
+ * (same element count; host or device pointer).  refresh != 0 rebuilds the derived tables (packed
+ * weights, folded BN, prior spectra); pass 0 on all but the last tensor of a batch of updates. */
+int jcm_update_tensor(jcm_handle h, const char* name, const float* data, int64_t count, int refresh);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,7 @@ SIGNATURES = {
     'jcm_train_apply': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.POINTER(ctypes.c_float)]),
     'jcm_train_steps': (ctypes.c_int, [_handle, ctypes.POINTER(ctypes.c_int64)]),
     'jcm_get_tensor': (ctypes.c_int, [_handle, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64]),
+    'jcm_update_tensor': (ctypes.c_int, [_handle, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]),
 }
 
 _lib = None

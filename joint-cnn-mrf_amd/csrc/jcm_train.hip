@@ -564,6 +564,22 @@ int jcm_get_tensor(jcm_handle h, const char* name, float* out, int64_t count) {
   return JCM_OK;
 }
 
+int jcm_update_tensor(jcm_handle h, const char* name, const float* data, int64_t count, int refresh) {
+  JCM_TRY(check(h, true));
+  if (!name || !data) return fail(JCM_ERR_ARG, "bad update_tensor arguments");
+  auto it = h->params.find(name);
+  if (it == h->params.end()) return fail(JCM_ERR_STATE, std::string("no parameter '") + name + "'");
+  if ((int64_t)it->second.n != count) return fail(JCM_ERR_ARG, std::string("'") + name + "' has " + std::to_string(it->second.n) + " elements");
+  DeviceGuard g(h->device);
+  HIP_TRY(hipMemcpyAsync(it->second.d, data, it->second.n * sizeof(float), hipMemcpyDefault, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));   // the caller may free `data` on return
+  if (refresh) {
+    JCM_TRY(refresh_derived(h, false));
+    if (h->train) JCM_TRY(repack_dgrad(h));
+  }
+  return JCM_OK;
+}
+
 }  // extern "C"
 
 namespace jcm {

@@ -41,3 +41,21 @@ def allgather_coords(local_coords, group=None):
                       device=local_coords.device)
     dist.all_gather_into_tensor(out, local_coords, group=group)
     return out.to(dev)
+
+
+def average_gradients(flat_grads, group=None):
+    """average_gradients (main.py:243-267) across ranks: the mean of the per-tower gradients, in place
+    on the flat fp32 gradient buffer -- one all-reduce (RCCL over xGMI: 58.7 M fp32 = 235 MB) per step.
+    The training step is the one place on this path with a real exchange; BatchNorm statistics stay
+    per tower, as in the reference."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return flat_grads
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) != 'nccl' and flat_grads.device.type != 'cpu':
+        host = flat_grads.cpu()                       # gloo moves host memory (CPU tests / plumbing runs)
+        dist.all_reduce(host, group=group)
+        flat_grads.copy_(host)
+    else:
+        dist.all_reduce(flat_grads, group=group)
+    flat_grads.div_(world)
+    return flat_grads

@@ -11,8 +11,8 @@ this module keeps the same names; they are filled by `configure()` instead of at
 (the reference parses argv and loads `.npy` files at import time, main.py:440,459).
 
 CLI: `python -m joint_cnn_mrf_amd.main --gpus 0 --use_sm --batch_size 64 [--debug]` runs the
-inference tower on synthetic data; `--train` is the reference's training loop and is out of
-scope here.
+inference tower on synthetic data; `--train` runs the reference's epoch loop (main.py:620-667) on a
+synthetic data set through `train.Trainer`.
 """
 import argparse
 import json
@@ -201,11 +201,51 @@ def get_predictions(X_np, Y_np, sess=None):
     return multiscale.get_predictions(engine(), X_np, Y_np, use_sm=hps.use_sm)
 
 
+def train_main(args):
+    """`--train` (main.py:620-667): n_epochs over a synthetic data set of 4 batches; prints the reference's
+    per-epoch line.  Losses are the training-mode losses of the last batch of the epoch; detection rates
+    are evaluated in inference mode (flag_train=False) on the first batch."""
+    from . import evaluation
+    from .train import Trainer
+    dev_id = args.gpus[0]
+    torch.cuda.set_device(dev_id)
+    params = synth.make_pd_params(debug=args.debug)
+    if args.use_sm:
+        params.update(synth.make_sm_params(synth.synthetic_priors(), kind='init'))
+    eng = configure(params, device=dev_id, debug=args.debug)
+    B = args.batch_size
+    n_train = 4 * B
+    n_updates_total = args.n_epochs * n_train // B                      # main.py:466
+    tr = Trainer(eng, optimizer=args.optimizer, lr=args.lr, lmbd=args.lmbd, use_sm=args.use_sm, n_updates_total=n_updates_total)
+    X = [torch.as_tensor(synth.make_images(B, seed=100 + i), device=eng.device) for i in range(n_train // B)]
+    Y = [torch.as_tensor(synth.make_targets(B, seed=200 + i), device=eng.device) for i in range(n_train // B)]
+    joints_to_eval, det_radius = [2], 10                                # main.py:455-456
+    for epoch in range(1, args.n_epochs + 1):
+        t0 = time.time()
+        for xb, yb in zip(X, Y):
+            losses, _ = tr.train_step(xb, yb)
+        l = losses.cpu().numpy()
+        r = eng.forward(X[0], Y[0][..., n_joints:].contiguous(), use_sm=args.use_sm)
+        tgt = Y[0][..., :n_joints].contiguous()
+        dr_pd = evaluation.det_rate(r['pd_prob'], tgt, det_radius, joints_to_eval, engine=eng)
+        dr_sm = evaluation.det_rate(r['sm_prob'] if args.use_sm else r['pd_prob'], tgt, det_radius, joints_to_eval, engine=eng)
+        print('Epoch {:d}  train_dr {:.3f} {:.3f}  train_loss {:.5f} {:.5f}  total {:.5f}  lr {:g}  {:.1f} img/s'.format(
+            epoch, dr_pd, dr_sm, l[1], l[2], l[0], piecewise(tr), n_train / (time.time() - t0)))
+    return tr
+
+
+def piecewise(tr):
+    from .train import piecewise_lr
+    return piecewise_lr(tr.n_iters, tr.n_updates_total, tr.lr)
+
+
 def main(argv=None):
     global hps
     args = build_parser().parse_args(argv)
     if args.train:
-        raise SystemExit('--train: the joint training step is out of scope of this build (inference hot path only)')
+        hps = args
+        train_main(args)
+        return
     if args.restore:
         raise SystemExit('--restore: no TF checkpoint ships with the reference; parameters are synthetic here')
     hps = args

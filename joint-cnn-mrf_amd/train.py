@@ -49,6 +49,7 @@ class Trainer:
                        'jcm_train_param_info')
             self.layout.append((buf.value.decode(), off.value, cnt.value))
         self.grads = torch.zeros(self.n_elements, dtype=torch.float32, device=engine.device)
+        self._moving = None                                         # [(name, offset, count)] of the BN moving statistics
         self.losses = torch.zeros(4, dtype=torch.float32, device=engine.device)
 
     @property
@@ -76,16 +77,9 @@ class Trainer:
         return {n: g[o:o + c].copy() for n, o, c in self.layout}
 
     def average_gradients(self):
-        """main.py:243-267 across ranks: mean of the per-tower gradients."""
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            if dist.get_backend() == 'gloo':
-                g = self.grads.cpu()
-                dist.all_reduce(g)
-                self.grads.copy_(g)
-            else:
-                dist.all_reduce(self.grads)
-            self.grads.div_(dist.get_world_size())
+        """main.py:243-267 across ranks: mean of the per-tower gradients (dist.average_gradients)."""
+        from . import dist as jdist
+        jdist.average_gradients(self.grads)
 
     def apply(self, lr=None, want_norm=False):
         """grad_renorm + apply_gradients (main.py:576-577) on self.grads."""
@@ -97,11 +91,44 @@ class Trainer:
                                              ctypes.byref(norm) if want_norm else None), 'jcm_train_apply')
         return norm.value if want_norm else None
 
-    def train_step(self, x, y, want_norm=False):
-        """One sess.run(train_step) (main.py:644).  Returns (losses tensor, grad norm or None)."""
+    def sync_moving_statistics(self, names_and_counts):
+        """Keep the replicas identical under data parallelism: every rank advanced moving_mean /
+        moving_variance with its own tower's batch statistics (main.py:557 runs the towers' update ops on
+        the shared variables one after the other); here the replicas take the mean of the per-rank results,
+        i.e. one update with the tower-averaged statistics.  `names_and_counts`: [(name, count)]."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        from . import dist as jdist
+        if self._moving is None:
+            off, lay = 0, []
+            for n, c in names_and_counts:
+                lay.append((n, off, c))
+                off += c
+            self._moving = lay
+            self._moving_buf = torch.zeros(off, dtype=torch.float32, device=self.eng.device)
+        buf = self._moving_buf
+        for n, o, c in self._moving:
+            _lib.check(self._lib.jcm_get_tensor(self.eng._h, n.encode(), ctypes.c_void_p(buf.data_ptr() + 4 * o), c), 'jcm_get_tensor(%s)' % n)
+        jdist.average_gradients(buf)
+        for i, (n, o, c) in enumerate(self._moving):
+            _lib.check(self._lib.jcm_update_tensor(self.eng._h, n.encode(), ctypes.c_void_p(buf.data_ptr() + 4 * o), c,
+                                                   int(i == len(self._moving) - 1)), 'jcm_update_tensor(%s)' % n)
+
+    def train_step(self, x, y, want_norm=False, moving=None):
+        """One sess.run(train_step) (main.py:644).  Returns (losses tensor, grad norm or None).
+        `moving`: [(name, count)] of the BN moving statistics to keep in sync across ranks (N > 1)."""
         self.loss_and_grads(x, y)
         self.average_gradients()
-        return self.losses, self.apply(want_norm=want_norm)
+        norm = self.apply(want_norm=want_norm)
+        if moving:
+            self.sync_moving_statistics(moving)
+        return self.losses, norm
+
+    @staticmethod
+    def moving_statistics_of(params):
+        return [(k, int(np.asarray(v).size)) for k, v in sorted(params.items())
+                if k.endswith('moving_mean') or k.endswith('moving_variance')]
 
     def get_tensor(self, name, shape):
         out = np.empty(int(np.prod(shape)), np.float32)

@@ -239,3 +239,17 @@ def forward(x, torso, p, use_sm=True, dtype=np.float64):
         r['sm_prob'] = spatial_softmax(r['sm_logits'])                      # main.py:531
         r['sm_coords'] = argmax_coords(r['sm_prob'])
     return r
+
+
+def det_rate(hm_pred, hm_target, normalized_radius=10, joints='all'):
+    """evaluation.py:4-37: percentage of (image, joint) pairs whose arg-max is within
+    `normalized_radius` % of the torso length (target channels 0 and 7) of the target's arg-max.
+    A zero torso length divides by zero exactly as the reference does (inf / nan compare False)."""
+    pred = argmax_coords(hm_pred).astype(np.float32)
+    true = argmax_coords(hm_target).astype(np.float32)
+    torso = np.linalg.norm(true[:, :, 0] - true[:, :, 7], axis=1, keepdims=True)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        nd = np.linalg.norm(pred - true, axis=1) * 100 / torso
+    if joints != 'all':
+        nd = nd[:, list(joints)]
+    return float(100 * np.mean((nd <= normalized_radius).astype(np.float32)))

@@ -67,3 +67,62 @@ def test_shard_bounds_drop_remainder_like_reference():
 def test_allgather_is_identity_without_process_group():
     c = torch.zeros(3, 2, 9, dtype=torch.int32)
     assert jdist.allgather_coords(c) is c
+
+
+# ---------------------------------------------------------------- training: tower-averaged gradients
+def _train_case():
+    from joint_cnn_mrf_amd import synth
+    p = synth.make_pd_params(debug=True, bn='trained')
+    rs = np.random.RandomState(21)
+    x = rs.random_sample((4, 32, 48, 3)).astype(np.float32)
+    y = np.zeros((4, 4, 6, 10), np.float32)
+    for b in range(4):
+        for k in range(10):
+            y[b, rs.randint(4), rs.randint(6), k] = 1.0
+    return p, x, y
+
+
+def _flat(grads):
+    return np.concatenate([np.asarray(grads[k], np.float64).reshape(-1) for k in sorted(grads)])
+
+
+def _train_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle import train_oracle as T
+        p, x, y = _train_case()
+        lo, hi = jdist.shard_bounds(x.shape[0], world, rank)
+        r = T.loss_and_grads(x[lo:hi], y[lo:hi], p, use_sm=False)       # the tower's compute_gradients (stand-in for the GPU)
+        g = torch.as_tensor(_flat(r['grads']))
+        jdist.average_gradients(g)
+        q.put((rank, g.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_average_gradients_world2_equals_two_towers():
+    """One process per GPU + all-reduce/N is the reference's in-graph tower average (main.py:243-267)."""
+    from oracle import train_oracle as T
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    p, x, y = _train_case()
+    _, info = T.train_step(x, y, p, {}, 1, use_sm=False, towers=2)
+    want = _flat(info['grads'])
+    for r in range(world):
+        np.testing.assert_allclose(res[r], want, rtol=1e-12, atol=1e-15)
+
+
+def test_average_gradients_is_identity_without_process_group():
+    g = torch.arange(5, dtype=torch.float32)
+    assert jdist.average_gradients(g) is g

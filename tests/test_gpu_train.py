@@ -145,3 +145,32 @@ def test_loss_goes_down(debug_case):
     hist = np.array(hist)
     assert np.isfinite(hist).all()
     assert hist[-1, 0] < hist[0, 0], hist[:, 0]
+
+
+def test_det_rate_matches_restatement():
+    """evaluation.py:4-37 through the arg-max kernel."""
+    import oracle.jcm_oracle as O
+    from joint_cnn_mrf_amd import evaluation
+    from joint_cnn_mrf_amd.engine import Engine
+    rs = np.random.RandomState(8)
+    tgt = synth.make_targets(16)[..., :9].copy()
+    pred = tgt + 0.02 * rs.random_sample(tgt.shape).astype(np.float32)       # mostly right, some joints displaced
+    pred[::3] = rs.random_sample(pred[::3].shape).astype(np.float32)
+    eng = Engine(device=0)
+    eng.finalize()
+    for joints in ('all', [2], [2, 5, 8]):
+        for radius in (10, 30):
+            got = evaluation.det_rate(dev(pred), dev(tgt), radius, joints, engine=eng)
+            assert abs(got - O.det_rate(pred, tgt, radius, joints)) < 1e-4
+    eng.close()
+
+
+def test_train_cli_debug():
+    """`main.py --train` (main.py:620-667) end to end at --debug size."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-m', 'joint_cnn_mrf_amd.main', '--train', '--debug', '--use_sm', '--n_epochs', '2',
+                          '--batch_size', '2', '--gpus', '0'], cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('Epoch')]
+    assert len(lines) == 2 and 'train_loss' in lines[0], out.stdout
