@@ -87,18 +87,23 @@ static hipError_t col_reduce(const Op& op, size_t N, int C, double* partial, int
 
 size_t train_reduce_scratch_doubles(int C) { return (size_t)RED_MAX_BLOCKS * 2 * C; }
 
+// sum over the `blocks` partials of quantity k for channel c, by the 64 threads of one wave (fixed order: deterministic)
+__device__ __forceinline__ double fold_partials(const double* __restrict__ partial, int blocks, int Q, int C, int k, int c) {
+  double s = 0.0;
+  for (int b = threadIdx.x; b < blocks; b += 64) s += partial[((size_t)b * Q + k) * C + c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  return s;
+}
+
 // fold the block partials: batch mean / variance and the moving-average update of
 // tf.contrib.layers.batch_norm(decay=0.9, fused): moving_var gets the Bessel-corrected variance
 __global__ void bn_stats_finish_kernel(const double* __restrict__ partial, int blocks, int C, double N, float eps, float decay,
                                        float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ mov_mean,
                                        float* __restrict__ mov_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (int b = 0; b < blocks; ++b) {
-    s += partial[((size_t)b * 2 + 0) * C + c];
-    ss += partial[((size_t)b * 2 + 1) * C + c];
-  }
+  const int c = blockIdx.x;                  // one wave per channel
+  const double s = fold_partials(partial, blocks, 2, C, 0, c), ss = fold_partials(partial, blocks, 2, C, 1, c);
+  if (threadIdx.x != 0) return;
   const double m = s / N;
   double var = ss / N - m * m;
   if (var < 0.0) var = 0.0;
@@ -116,7 +121,7 @@ hipError_t bn_batch_stats(const float* x, size_t N, int C, float eps, float deca
   int blocks = 0;
   hipError_t e = col_reduce(OpStats{x}, N, C, scratch, &blocks, st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, blocks, C, (double)N, eps, decay, mean,
+  hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(C), dim3(64), 0, st, scratch, blocks, C, (double)N, eps, decay, mean,
                      rstd, mov_mean, mov_var);
   return hipGetLastError();
 }
@@ -140,13 +145,9 @@ hipError_t bn_apply(const float* r, const float* mean, const float* rstd, const 
 // sums[0][c] = sum dy, sums[1][c] = sum dy*(r-mean)  ->  dgamma = sums[1]*rstd, dbeta = sums[0]
 __global__ void bn_bwd_finish_kernel(const double* __restrict__ partial, int blocks, int C, const float* __restrict__ rstd,
                                      float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, sx = 0.0;
-  for (int b = 0; b < blocks; ++b) {
-    s += partial[((size_t)b * 2 + 0) * C + c];
-    sx += partial[((size_t)b * 2 + 1) * C + c];
-  }
+  const int c = blockIdx.x;                  // one wave per channel
+  const double s = fold_partials(partial, blocks, 2, C, 0, c), sx = fold_partials(partial, blocks, 2, C, 1, c);
+  if (threadIdx.x != 0) return;
   sums[c] = (float)s;
   sums[C + c] = (float)sx;
   if (dgamma) dgamma[c] = (float)(sx * (double)rstd[c]);
@@ -157,7 +158,7 @@ hipError_t bn_bwd_reduce(const float* dy, float dy_scale, const float* r, const 
   int blocks = 0;
   hipError_t e = col_reduce(OpBnBwd{dy, r, mean, dy_scale}, N, C, scratch, &blocks, st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, blocks, C, rstd, sums, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(C), dim3(64), 0, st, scratch, blocks, C, rstd, sums, dgamma, dbeta);
   return hipGetLastError();
 }
 
@@ -185,17 +186,15 @@ hipError_t bn_bwd_apply(const float* dy, float dy_scale, const float* r, const f
 }
 
 __global__ void col_sum_finish_kernel(const double* __restrict__ partial, int blocks, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0;
-  for (int b = 0; b < blocks; ++b) s += partial[(size_t)b * C + c];
-  out[c] = (float)s;
+  const int c = blockIdx.x;                  // one wave per channel
+  const double s = fold_partials(partial, blocks, 1, C, 0, c);
+  if (threadIdx.x == 0) out[c] = (float)s;
 }
 hipError_t col_sum(const float* x, size_t N, int C, float* out, double* scratch, hipStream_t st) {
   int blocks = 0;
   hipError_t e = col_reduce(OpSum{x}, N, C, scratch, &blocks, st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(col_sum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, blocks, C, out);
+  hipLaunchKernelGGL(col_sum_finish_kernel, dim3(C), dim3(64), 0, st, scratch, blocks, C, out);
   return hipGetLastError();
 }
 

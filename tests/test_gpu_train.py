@@ -174,3 +174,33 @@ def test_train_cli_debug():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('Epoch')]
     assert len(lines) == 2 and 'train_loss' in lines[0], out.stdout
+
+
+def test_full_size_step_vs_golden():
+    """The full-size network (filters 64..512), one 480x720 image: losses, sampled gradient entries, gradient
+    norms and the moving-statistics update against tests/golden/train_full.json (float64 restatement,
+    generated by tests/golden/make_train_golden.py)."""
+    import json, os
+    from golden.make_train_golden import case, LMBD
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'train_full.json')) as fh:
+        gold = json.load(fh)
+    p, x, y = case()
+    eng, tr = make_trainer(p, use_sm=True, lmbd=LMBD)
+    losses, _ = tr.loss_and_grads(dev(x), dev(y))
+    got = tr.grads_dict()
+    l = losses.cpu().numpy()
+    moving = {k: tr.get_tensor(k, np.asarray(p[k]).shape).reshape(-1) for k in gold['moving']}
+    eng.close()
+    np.testing.assert_allclose(l, gold['losses'], rtol=2e-5)
+    assert set(gold['tensors']) == set(got)
+    bad = []
+    for k, t in gold['tensors'].items():
+        g = got[k].astype(np.float64)
+        tol = GRAD_RTOL * t['max'] + 2 * t['slack'] + 1e-7
+        err = np.abs(g[t['idx']] - np.asarray(t['val'])).max()
+        nerr = abs(np.linalg.norm(g) - t['norm'])
+        if not (err <= tol and nerr <= tol * np.sqrt(g.size)):
+            bad.append('%s: entry err %.3e norm err %.3e (tol %.3e, max|g| %.3e)' % (k, err, nerr, tol, t['max']))
+    assert not bad, '\n'.join(bad)
+    for k, t in gold['moving'].items():
+        np.testing.assert_allclose(moving[k][t['idx']], t['val'], rtol=2e-5, atol=1e-7, err_msg=k)
