@@ -124,6 +124,14 @@ def main():
     print('y_train', y_train.shape, float(y_train.sum(axis=(1, 2)).mean()))
     cells = cells_from_heat_maps(y_train)
     np.save(os.path.join(HERE, 'flic_train_cells.npy'), cells)
+    # the annotations themselves (x, y of the nine joints, float64), input of joint_cnn_mrf_amd.data; the package's
+    # data preparation must rebuild y_train / y_test bit for bit from them
+    from joint_cnn_mrf_amd import data as jdata
+    xy, _names, is_train = jdata.load_flic(os.path.join(REF, 'data_FLIC.mat'))
+    np.save(os.path.join(HERE, 'flic_train_xy.npy'), xy[is_train])
+    assert np.array_equal(jdata.target_heat_maps(jdata.joint_cells(xy[is_train])), y_train)
+    assert np.array_equal(jdata.target_heat_maps(jdata.joint_cells(xy[~is_train])), flic_heat_maps('test'))
+    print('data.py: y_train / y_test identical to the line-by-line restatement of the reference script')
     pri = priors.build_pairwise_distributions(cells)
     if not skip_ref:
         ref = run_reference_prior_builder(y_train)

@@ -67,3 +67,41 @@ def test_pool_property(h, w, seed):
     b = T.max_pool_same(torch.as_tensor(x).permute(0, 3, 1, 2)).permute(0, 2, 3, 1).numpy()
     assert a.shape == (1, (h + 1) // 2, (w + 1) // 2, 3)
     np.testing.assert_array_equal(a, b)
+
+
+# ---------------------------------------------------------------- data preparation
+def test_flic_target_heat_maps_from_annotations():
+    """data.py:163-189 on the real FLIC annotations (tests/golden/flic_train_xy.npy): the arg-max cells of the
+    rebuilt y_train equal the committed cells the prior builder was pinned with; make_golden.py asserts the
+    full arrays (train and test) bit for bit against the reference script's logic."""
+    import os
+    from joint_cnn_mrf_amd import data
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    xy = np.load(os.path.join(here, 'flic_train_xy.npy'))
+    gold = np.load(os.path.join(here, 'flic_train_cells.npy'))
+    y = data.target_heat_maps(data.joint_cells(xy[:600]))
+    assert y.shape == (600, 60, 90, 10) and y.dtype == np.float32
+    flat = y.reshape(600, 5400, 10)
+    idx = flat.argmax(axis=1)
+    np.testing.assert_array_equal(np.stack([idx // 90, idx % 90], axis=2), gold[:600])
+    assert abs(float(flat.max()) - 0.25) < 1e-7                     # centre of the [1,2,1]x[1,2,1]/16 blob
+    s = flat.sum(axis=1)
+    assert (s <= 1 + 1e-6).all() and (s[:, 9] > 0.99).mean() > 0.95  # blobs cut only at the image border
+
+
+def test_flic_backward_pose_flip_and_border_clamp():
+    from joint_cnn_mrf_amd import data
+    xy = np.zeros((2, 2, 9))
+    xy[:, 0] = [100, 110, 120, 300, 310, 320, 150, 250, 200]         # x: lsho lelb lwri rsho relb rwri lhip rhip nose
+    xy[:, 1] = [80, 120, 160, 80, 120, 160, 240, 240, 40]
+    xy[1, 0, 6], xy[1, 0, 7] = 250, 150                              # image 1: frontal (left hip right of the right hip)
+    xy[1, :, 8] = [900, 600]                                         # nose annotated outside the image
+    c = data.joint_cells(xy)
+    # image 0 (lhip.x < rhip.x): the reference's view-based swap leaves left := right (data.py:35-49)
+    np.testing.assert_array_equal(c[0, 0], c[0, 3])
+    np.testing.assert_array_equal(c[0, 2], c[0, 5])
+    np.testing.assert_array_equal(c[0, 6], c[0, 7])
+    np.testing.assert_array_equal(c[1, 0], [10, 12])                 # untouched: (80/8, 100/8)
+    np.testing.assert_array_equal(c[1, 8], [60, 90])                 # clamped to (480, 720) / 8: blob cut by the border
+    y = data.target_heat_maps(c)
+    assert y[1, 59, 89, 8] == np.float32(1 / 16) and y[1, :, :, 8].sum() == np.float32(1 / 16)
