@@ -152,6 +152,7 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    eng.set_profile(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses, _ = tr.train_step(x, y, moving=moving)
@@ -164,10 +165,19 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm):
         t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    eng.set_profile(False)
     out = None
     if rank == 0:
         value = world * B * args.steps / dt
         scale = 16 if args.debug else 1
+        # dominant training kernels: the three conv5 passes, each 229.3 GFLOP per image (60x90 px, 81 taps, 512x512)
+        kern = {}
+        for key, what in (('conv5', 'forward conv_igemm_f32'), ('dgrad:conv5', 'data gradient, conv_igemm_f32 on flipped weights'),
+                          ('wgrad:conv5', 'weight gradient, wgrad_kernel<9>')):
+            ms, n = eng.profile_read(key)
+            if n:
+                tf = FLOPS_DOMINANT['conv5'] / scale * B / (ms / n * 1e-3) / 1e12
+                kern[key] = {'kernel': what, 'launch_ms': ms / n, 'launches': n, 'achieved': tf, 'frac': tf / PEAK_TFLOPS['fp32']}
         out = {'metric': 'images/sec joint training step (fwd+bwd+update), part detector + spatial model', 'value': value,
                'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
@@ -177,6 +187,11 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm):
                           'collective': 'all_reduce of %d fp32 gradients' % tr.n_elements},
                'train_tflops': value * FLOPS_TRAIN / scale / 1e12, 'mfma_peak_tflops': PEAK_TFLOPS['fp32'],
                'frac_of_fp32_mfma_peak': value * FLOPS_TRAIN / scale / 1e12 / PEAK_TFLOPS['fp32'],
+               'roofline': dict(bound='mfma', peak=PEAK_TFLOPS['fp32'], unit='TFLOP/s', traffic=None,
+                                **({'kernel': 'wgrad_kernel<9> on conv5 (fp32 MFMA 32x32x2, 64x64 channel tile x 9 taps)',
+                                    'achieved': kern['wgrad:conv5']['achieved'], 'frac': kern['wgrad:conv5']['frac'],
+                                    'launch_ms': kern['wgrad:conv5']['launch_ms']} if 'wgrad:conv5' in kern else {})),
+               'conv5_passes': kern,
                'loss': [float(v) for v in losses.cpu().numpy()], 'workspace_gb': eng.workspace_bytes() / 1e9}
     eng.close()
     return out

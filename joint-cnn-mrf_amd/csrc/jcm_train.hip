@@ -140,7 +140,17 @@ int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const float* dz, int ldz, int B, f
   const size_t mark = c->arena_off;
   float* partial = arena_alloc<float>(c, n * splits);
   if (!c->dry) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profile) {
+      HIP_TRY(hipEventCreate(&e0));
+      HIP_TRY(hipEventCreate(&e1));
+      HIP_TRY(hipEventRecord(e0, c->stream));
+    }
     HIP_TRY(wgrad_f32(f.in, dz, partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream));
+    if (c->profile) {
+      HIP_TRY(hipEventRecord(e1, c->stream));
+      c->prof["wgrad:" + f.scope].emplace_back(e0, e1);      // read with jcm_profile_read("wgrad:<scope>")
+    }
     HIP_TRY(wgrad_reduce(partial, splits, n, L->w_raw, lmbd, grad_of(t, grads, f.scope + "/weights"), c->stream));
   }
   c->arena_off = mark;
@@ -155,7 +165,17 @@ int conv_dgrad(jcm_ctx* c, const LayerFwd& f, const float* dz, int B, float* dx)
   ConvArgs a;
   a.x = dz; a.wp = d.wd; a.bias = t->zeros; a.scale = t->ones; a.shift = t->zeros; a.out = dx;
   a.B = B; a.H = f.H; a.W = f.W; a.Cin = d.cinp; a.Cout = f.L->cin; a.CoutP = d.coutp; a.relu_bn = 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c->profile) {
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, c->stream));
+  }
   HIP_TRY(conv_igemm_f32(a, f.L->ks, c->stream));
+  if (c->profile) {
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    c->prof["dgrad:" + f.scope].emplace_back(e0, e1);
+  }
   return JCM_OK;
 }
 

@@ -4,9 +4,9 @@
 //
 // GEMM view: M = Cin, N = Cout, K = B*H*W pixels, one GEMM per tap.  A workgroup owns one tap
 // ROW (ky fixed, all KS values of kx) of a 64(ci) x 64(co) tile and walks K in strips of one
-// image row x 32 pixels: the strip's dZ [32 px][64 co] and the matching input-row segment
-// [32+KS-1 px][64 ci] are staged in LDS once, each wave lifts its 32 channels of both into
-// registers (KS+39 values), and the KS taps then run 16 v_mfma_f32_32x32x2_f32 each straight
+// image row x 30 pixels: the strip's dZ [30 px][64 co] and the matching input-row segment
+// [30+KS-1 px][64 ci] are staged in LDS once, each wave lifts its 32 channels of both into
+// registers (KS+43 values), and the KS taps then run 15 v_mfma_f32_32x32x2_f32 each straight
 // from registers -- the kx shift is a register index.  K is split over `splits` workgroups that
 // write partial tiles; wgrad_reduce sums them in a fixed order (deterministic) and adds the
 // weight-decay term lmbd*W (main.py:540).
@@ -17,7 +17,7 @@ namespace jcm {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int WG_PW = 32;        // pixels per strip
+constexpr int WG_PW = 30;        // pixels per strip: 15 MFMA k-steps; divides the 90- and 180-wide maps of the model exactly
 constexpr int WG_T = 64;         // channel tile (both ci and co)
 
 template <int KS>
@@ -42,7 +42,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
   const int h = lane >> 5, l31 = lane & 31;
 
   const int nseg = (W + WG_PW - 1) / WG_PW;
-  const long rows = (long)B * H;
+  // output rows whose input row y + ky - PAD lies inside the image (the others contribute zeros: skipped)
+  const int ylo = ky < PAD ? PAD - ky : 0;
+  const int nvalid = H - (ky < PAD ? PAD - ky : ky - PAD);
+  const long rows = nvalid > 0 ? (long)B * nvalid : 0;
   const long r0 = rows * split / splits, r1 = rows * (split + 1) / splits;
   const long nstrip = (r1 - r0) * nseg;
 
@@ -59,10 +62,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
   auto gload = [&](long s) {
     const long row = r0 + s / nseg;
     const int seg = (int)(s % nseg);
-    const int b = (int)(row / H), y = (int)(row % H);
+    const int b = (int)(row / nvalid), y = ylo + (int)(row % nvalid);
     const int yi = y + ky - PAD;
     const int px0 = seg * WG_PW;
-    const bool row_ok = (unsigned)yi < (unsigned)H;
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
       const int idx = tid + i * 256;
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
       if (idx < XF4) {
         const int c4 = idx % (WG_T / 4), p = idx / (WG_T / 4);
         const int xi = px0 + p - PAD, ci = ci0 + c4 * 4;
-        if (row_ok && (unsigned)xi < (unsigned)W && ci < Cin)
+        if ((unsigned)xi < (unsigned)W && ci < Cin)
           v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + yi) * W + xi) * Cin + ci);
       }
       xr[i] = v;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
       const int c4 = idx % (WG_T / 4), p = idx / (WG_T / 4);
       const int xo = px0 + p, co = co0 + c4 * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (xo < W && co < ldz) v = *reinterpret_cast<const f32x4*>(dz + (((size_t)b * H + y) * W + xo) * ldz + co);
+      if (idx < ZF4 && xo < W && co < ldz) v = *reinterpret_cast<const f32x4*>(dz + (((size_t)b * H + y) * W + xo) * ldz + co);
       zr[i] = v;
     }
   };
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < ZR; ++i) {
       const int idx = tid + i * 256;
-      *reinterpret_cast<f32x4*>(&Zs[buf][idx / (WG_T / 4)][(idx % (WG_T / 4)) * 4]) = zr[i];
+      if (idx < ZF4) *reinterpret_cast<f32x4*>(&Zs[buf][idx / (WG_T / 4)][(idx % (WG_T / 4)) * 4]) = zr[i];
     }
   };
 

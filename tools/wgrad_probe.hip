@@ -38,5 +38,32 @@ int main() {
     for (int i = 0; i < 75 * C; ++i) { double e = fabs(got[i] - ref[i]); if (e > me) { me = e; worst = i; } if (fabs(ref[i]) > mx) mx = fabs(ref[i]); }
     printf("sub %d: max err %.3e (max |ref| %.3e) worst idx %d (tap %d ch %d co %d) got %.6f ref %.6f\n", sub, me, mx, worst, worst / C / 3, (worst / C) % 3, worst % C, got[worst], ref[worst]);
   }
+  for (int ks = 5; ks <= 9; ks += 4) {
+    const int B2 = 2, H = 7, W = 45, Cin = 16, Cout = 24, ldz = 24, pad = (ks - 1) / 2;
+    std::vector<float> x((size_t)B2 * H * W * Cin), dz((size_t)B2 * H * W * ldz);
+    for (auto& v : x) v = rand() / (float)RAND_MAX - 0.5f;
+    for (auto& v : dz) v = rand() / (float)RAND_MAX - 0.5f;
+    const size_t n = (size_t)ks * ks * Cin * Cout;
+    std::vector<double> ref(n, 0.0);
+    for (int b = 0; b < B2; ++b) for (int y = 0; y < H; ++y) for (int xx = 0; xx < W; ++xx)
+      for (int ky = 0; ky < ks; ++ky) for (int kx = 0; kx < ks; ++kx) {
+        const int yi = y + ky - pad, xi = xx + kx - pad;
+        if (yi < 0 || yi >= H || xi < 0 || xi >= W) continue;
+        for (int ci = 0; ci < Cin; ++ci) for (int co = 0; co < Cout; ++co)
+          ref[((size_t)(ky * ks + kx) * Cin + ci) * Cout + co] += (double)x[(((size_t)b * H + yi) * W + xi) * Cin + ci] * dz[(((size_t)b * H + y) * W + xx) * ldz + co];
+      }
+    const int splits = wgrad_splits(ks, Cin, Cout, B2, H);
+    float *dx, *dd, *dp, *dw, *w;
+    hipMalloc(&dx, x.size() * 4); hipMalloc(&dd, dz.size() * 4); hipMalloc(&dp, n * splits * 4); hipMalloc(&dw, n * 4); hipMalloc(&w, n * 4);
+    hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dd, dz.data(), dz.size() * 4, hipMemcpyHostToDevice);
+    hipMemset(w, 0, n * 4);
+    hipError_t e = wgrad_f32(dx, dd, dp, splits, ks, B2, H, W, Cin, Cout, ldz, 0);
+    wgrad_reduce(dp, splits, n, w, 0.f, dw, 0);
+    std::vector<float> got(n);
+    hipMemcpy(got.data(), dw, n * 4, hipMemcpyDeviceToHost);
+    double me = 0, mx = 0;
+    for (size_t i = 0; i < n; ++i) { me = fmax(me, fabs(got[i] - ref[i])); mx = fmax(mx, fabs(ref[i])); }
+    printf("wgrad ks %d splits %d (%s): max err %.3e (max |ref| %.3e)\n", ks, splits, hipGetErrorString(e), me, mx);
+  }
   return 0;
 }
