@@ -63,10 +63,11 @@ def cpu_baseline(n_images, params):
                       '(TensorFlow unavailable); host has %d logical CPUs' % (n_images, os.cpu_count())}
 
 
-def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm):
+def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32_conv=None):
     """Time `args.steps` steps of one (dtype, batch) configuration; returns the result dict on
-    rank 0 (None elsewhere).  Timed region: barrier + synchronize on both sides, max over ranks."""
-    eng = Engine(device=local_rank, precision=dtype).load_params(params)
+    rank 0 (None elsewhere).  Timed region: barrier + synchronize on both sides, max over ranks.
+    f32_conv='split': the fp32 path with its 60x90 9x9 layers on the bf16x6 split kernel (conv_split.hip)."""
+    eng = Engine(device=local_rank, precision=dtype, f32_conv=f32_conv).load_params(params)
     x = torch.as_tensor(synth.make_images(B, seed=1234 + rank), device=dev)          # resident in HBM
     torso = torch.as_tensor(synth.make_torso(B, seed=4321 + rank), device=dev)
 
@@ -115,12 +116,15 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm):
             'value': value, 'ms_per_step': dt / args.steps * 1e3, 'dtype': 'f32' if dtype == 'fp32' else 'bf16',
             'config': {'workload': '%s: batch=%d/GPU synthetic 480x720x3, part detector%s forward + argmax, %s%s'
                                    % ('configs[1]' if dtype == 'fp32' else 'configs[2]', B, ' + spatial model' if use_sm else '',
-                                      dtype, ', DEBUG filters/4' if args.debug else ''),
+                                      dtype + (' operands, 60x90 9x9 layers as bf16x6 split MFMA' if f32_conv == 'split' else ''),
+                                      ', DEBUG filters/4' if args.debug else ''),
                        'batch_per_gpu': B, 'global_batch': world * B, 'use_sm': use_sm,
                        'collective': 'all_gather coords int32 [B,2,9]'},
             'path_tflops': value * FLOPS_PD_SM / (16 if args.debug else 1) / 1e12,
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm 9x9, 60x90 maps (conv4_fullres + conv5 launches; %s)'
-                                   % ('fp32 MFMA 32x32x2, 4x32 patch x 128 ch' if dtype == 'fp32' else 'bf16 MFMA 32x32x16, 12x32 patch x 256 ch'),
+                                   % ('fp32 operands as 3 bf16 parts, 6 x bf16 MFMA 32x32x16 per k16 step, 12x32 patch x 256 ch; achieved = fp32-equivalent FLOPs'
+                                      if f32_conv == 'split' else
+                                      'fp32 MFMA 32x32x2, 4x32 patch x 128 ch' if dtype == 'fp32' else 'bf16 MFMA 32x32x16, 12x32 patch x 256 ch'),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None,
                          'traffic': pmc_traffic('%s_b%d' % (dtype, B)) if not args.debug else None,
                          'launch_ms': launch_ms, 'launches': tot_n, 'flops_per_launch': flops_launch},
@@ -207,6 +211,7 @@ def main():
                     help='default: the headline line is configs[1] (fp32, batch 64) and configs[2] (bf16, batch 256) '
                          'is measured too and reported under "bf16_config2"')
     ap.add_argument('--no-sm', action='store_true', help='part detector only')
+    ap.add_argument('--f32-conv', default=None, choices=['exact', 'split'], help='fp32 convolution algorithm of the headline run (default exact)')
     ap.add_argument('--debug', action='store_true', help='filters/4 (main.py:40-41); not the headline config, fp32 only')
     ap.add_argument('--cpu-images', type=int, default=4, help='size of the cpu_baseline sample (0 = skip)')
     ap.add_argument('--train', action='store_true', help='time the joint training step (configs[4]) instead of the forward; fp32, '
@@ -249,10 +254,16 @@ def main():
 
     head_dtype = args.dtype or 'fp32'
     head_batch = args.batch or (64 if head_dtype == 'fp32' else 256)
-    head = run_config(args, head_dtype, head_batch, params, world, rank, local_rank, dev, use_sm)
-    second = None
+    head = run_config(args, head_dtype, head_batch, params, world, rank, local_rank, dev, use_sm,
+                      f32_conv=args.f32_conv if head_dtype == 'fp32' else None)
+    second = split = None
     if args.dtype is None and not args.debug:
         second = run_config(args, 'bf16', args.batch or 256, params, world, rank, local_rank, dev, use_sm)
+        # the same fp32 configuration with the 60x90 9x9 layers on the bf16 matrix cores (three-way operand split, fp32-class
+        # error, same parity tests); reported beside the headline, which stays on the exact fp32 MFMA chain
+        split = run_config(args, 'fp32', head_batch, params, world, rank, local_rank, dev, use_sm, f32_conv='split')
+        if split is not None:
+            split['roofline']['mfma_bf16_frac'] = (6 * split['roofline']['achieved'] / PEAK_TFLOPS['bf16']) if split['roofline']['achieved'] else None
 
     if rank == 0:
         out = {'metric': 'images/sec (720x480, K=9 joints) part-detector+spatial-model fwd',
@@ -262,6 +273,8 @@ def main():
                'roofline': head['roofline']}
         if second is not None:
             out['bf16_config2'] = second
+        if split is not None:
+            out['f32_split_config1'] = split
         if args.cpu_images > 0:
             out['cpu_baseline'] = cpu_baseline(args.cpu_images, params)
         print(json.dumps(out))

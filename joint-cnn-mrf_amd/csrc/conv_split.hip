@@ -1,0 +1,310 @@
+// fp32 convolution on the bf16 matrix cores: 3-way operand split, 6 products ("bf16x6").
+//
+// Every fp32 value is the exact sum of three bf16 numbers (8 + 8 + 8 mantissa bits):
+//     a = a0 + a1 + a2,   a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1)
+// and a*b = sum_{p,q} a_p*b_q.  Each bf16 x bf16 product is exact in fp32; dropping the three terms
+// with p + q >= 3 (relative size <= 2^-24 each) leaves
+//     a*b ~ a0*b2 + a1*b1 + a2*b0 + a0*b1 + a1*b0 + a0*b0          (issued small to large)
+// with a per-product error below one fp32 ulp, accumulated in the MFMA's fp32 accumulators -- the
+// error class of an fp32 FMA chain (measured on a K = 41472 dot product: 1.5e-7 of max|result|
+// against 2.9e-7 for an fp32 GEMM).  Six v_mfma_f32_32x32x16_bf16 replace eight
+// v_mfma_f32_32x32x2_f32 per 16 k-values at 16x the rate: 2.7x the fp32 MFMA peak.
+//
+// Dataflow = conv_igemm_bf16.hip's big-tile kernel (12x32 pixels x 256 channels per workgroup, 8
+// waves of 3x4 fragments, rotating-B schedule, weights by LDS-DMA) with the K axis extended by the
+// six (p,q) sub-steps: activations stay fp32 in HBM and are split once per 16-channel chunk while the
+// halo is written to LDS (three bf16 planes); weights are split at pack time.
+#include "kernels.h"
+
+namespace jcm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+struct CfgS {
+  static constexpr int KS = 9, TH = 12, TW = 32, BN = 256, WM = 4, WN = 2;
+  static constexpr int NT = WM * WN * 64;
+  static constexpr int U = 2;                       // 16-B units per chunk = 16 channels = one k16 step
+  static constexpr int NSPLIT = 3, NSUB = 6;
+  static constexpr int PAD = (KS - 1) / 2;
+  static constexpr int HH = TH + KS - 1, WH = TW + KS - 1, WHP = WH;
+  static constexpr int PLANE = HH * WHP + 2;
+  static constexpr int BM = TH * TW, MR = BM / WM / 32, NR = BN / WN / 32;
+  static constexpr int HALO_F4 = NSPLIT * U * PLANE;            // [split][unit][slot]
+  static constexpr int WSTAGE_F4 = NSPLIT * U * BN;             // one tap: [split][unit][co]
+  static constexpr int NSTAGE = KS * KS;
+  static constexpr int LDS_BYTES = (HALO_F4 + 2 * WSTAGE_F4) * 16;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+using C = CfgS;
+
+// sub-step -> (activation part, weight part), smallest products first
+__host__ __device__ constexpr int sub_a(int s) { return s < 3 ? s : (s < 5 ? s - 3 : 0); }        // 0 1 2 0 1 0
+__host__ __device__ constexpr int sub_b(int s) { return s < 3 ? 2 - s : (s < 5 ? 4 - s : 0); }    // 2 1 0 1 0 0
+
+template <int STEP>
+__device__ __forceinline__ void a_load(f32x4 (&fa)[C::MR], const unsigned (&aaddr)[C::MR]) {
+  constexpr int aoff = sub_a(STEP) * C::U * C::PLANE * 16;
+  static_assert(aoff < 65536, "ds_read offset field is 16 bits");
+#pragma unroll
+  for (int f = 0; f < C::MR; ++f)
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[f]) : "v"(aaddr[f]), "i"(aoff) : "memory");
+}
+template <int STEP>
+__device__ __forceinline__ void b_load(f32x4& fb, unsigned baddr) {
+  constexpr int boff = sub_b(STEP) * C::U * C::BN * 16;
+  static_assert(boff < 65536, "ds_read offset field is 16 bits");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb) : "v"(baddr), "i"(boff) : "memory");
+}
+// rotating-B schedule (see conv_igemm_bf16.hip): lgkmcnt(MR+NR-1) at every (step, g), NR-1-g in the last step
+template <int STEP, int G>
+__device__ __forceinline__ void rot_g(f32x4 (&fa)[2][C::MR], f32x4 (&fb)[C::NR], const unsigned (&baddr)[C::NR], f32x16 (&acc)[C::MR][C::NR]) {
+  if constexpr (G < C::NR) {
+    constexpr bool more = STEP + 1 < C::NSUB;
+    constexpr int cur = STEP & 1;
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(more ? C::MR + C::NR - 1 : C::NR - 1 - G) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int f = 0; f < C::MR; ++f)
+      acc[f][G] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cur][f]), __builtin_bit_cast(bf16x8, fb[G]),
+                                                          acc[f][G], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (more) b_load<STEP + 1>(fb[G], baddr[G]);
+    rot_g<STEP, G + 1>(fa, fb, baddr, acc);
+  }
+}
+template <int STEP>
+__device__ __forceinline__ void stage_steps(f32x4 (&fa)[2][C::MR], f32x4 (&fb)[C::NR], const unsigned (&aaddr)[C::MR],
+                                            const unsigned (&baddr)[C::NR], f32x16 (&acc)[C::MR][C::NR]) {
+  if constexpr (STEP < C::NSUB) {
+    if constexpr (STEP + 1 < C::NSUB) a_load<STEP + 1>(fa[(STEP & 1) ^ 1], aaddr);
+    rot_g<STEP, 0>(fa, fb, baddr, acc);
+    stage_steps<STEP + 1>(fa, fb, aaddr, baddr, acc);
+  }
+}
+
+// exact three-way split of 8 fp32 values into bf16 planes (round to nearest even at each level)
+__device__ __forceinline__ void split8(const f32x4& lo, const f32x4& hi, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float v = i < 4 ? lo[i] : hi[i - 4];
+    const __bf16 b0 = static_cast<__bf16>(v);
+    const float r1 = v - static_cast<float>(b0);
+    const __bf16 b1 = static_cast<__bf16>(r1);
+    const float r2 = r1 - static_cast<float>(b1);
+    p0[i] = b0; p1[i] = b1; p2[i] = static_cast<__bf16>(r2);
+  }
+}
+
+__global__ __launch_bounds__(C::NT, 2) void conv_split_kernel(ConvArgs a, int tiles_x, int tiles_y, int mtiles, int nN) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* halo = reinterpret_cast<f32x4*>(smem);
+  f32x4* wbuf = halo + C::HALO_F4;
+
+  const int L = blockIdx.x;
+  int mt, nt;
+  if ((8 % nN) == 0) {   // an XCD (blocks b, b+8, ...) keeps one channel tile: its L2 streams 1/nN of the weights
+    const int xcd = L & 7, q = L >> 3, per = 8 / nN;
+    nt = xcd % nN;
+    mt = q * per + xcd / nN;
+  } else {
+    nt = L % nN;
+    mt = L / nN;
+  }
+  if (mt >= mtiles) return;
+  const int tx = mt % tiles_x, ty = (mt / tiles_x) % tiles_y, b = mt / (tiles_x * tiles_y);
+  const int y0 = ty * C::TH, x0 = tx * C::TW, n0 = nt * C::BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / C::WN, wn = wid % C::WN;
+  const int h = lane >> 5, l31 = lane & 31;
+
+  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, CoutP = a.CoutP;
+  const float* __restrict__ xb = static_cast<const float*>(a.x) + (size_t)b * H * W * Cin;
+  const __bf16* __restrict__ wp = static_cast<const __bf16*>(a.wp);
+
+  int aslot[C::MR], bcol[C::NR];
+#pragma unroll
+  for (int f = 0; f < C::MR; ++f) {
+    const int r = (wm * C::MR + f) * 32 + l31;
+    aslot[f] = (r / C::TW) * C::WHP + (r % C::TW);
+  }
+#pragma unroll
+  for (int g = 0; g < C::NR; ++g) bcol[g] = (wn * C::NR + g) * 32 + l31;
+
+  // half-wave h reads unit h of the chunk (channels 8h..8h+7): MFMA operand k = 8*(lane>>5) + i
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  unsigned abase[C::MR], bbase[C::NR];
+#pragma unroll
+  for (int f = 0; f < C::MR; ++f) abase[f] = lds0 + (unsigned)(h * C::PLANE + aslot[f]) * 16u;
+#pragma unroll
+  for (int g = 0; g < C::NR; ++g) bbase[g] = lds0 + (unsigned)(h * C::BN + bcol[g]) * 16u;
+
+  f32x16 acc[C::MR][C::NR];
+#pragma unroll
+  for (int f = 0; f < C::MR; ++f)
+#pragma unroll
+    for (int g = 0; g < C::NR; ++g)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[f][g][i] = 0.f;
+
+  const int cin8 = Cin >> 3;
+  // one stage = one tap of one 16-channel chunk: 3 parts x 2 units x 256 channels x 16 B = 24 KB, 24 LDS-DMA pieces of 1 KB
+  constexpr int NWAVE = C::NT / 64;
+  constexpr int NPIECE = C::WSTAGE_F4 / 64;
+  constexpr int QPU = C::BN / 64;
+  static_assert(NPIECE % NWAVE == 0, "pieces divide over the waves");
+  const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wp), 0,
+                                                       (int)((size_t)C::KS * C::KS * Cin * CoutP * 2 * C::NSPLIT), 0x00020000);
+  const unsigned wvoff = (unsigned)(n0 + lane) * 16u;
+  auto wdma = [&](int g, int bufsel) {
+    const int chunk = g / C::NSTAGE, tap = g - chunk * C::NSTAGE;
+#pragma unroll
+    for (int i = 0; i < NPIECE / NWAVE; ++i) {
+      const int piece = wid + i * NWAVE;              // wave-uniform; LDS image [part][unit][co]
+      f32x4* dst = wbuf + bufsel * C::WSTAGE_F4 + piece * 64;
+      const int q = piece % QPU, pu = piece / QPU;
+      const int u = pu % C::U, part = pu / C::U;
+      const unsigned soff = (unsigned)(((((tap * cin8 + chunk * C::U + u) * C::NSPLIT) + part) * CoutP + q * 64) * 16);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff, soff, 0, 0);
+    }
+  };
+
+  const int nchunk = Cin >> 4;
+  const int nstage_total = nchunk * C::NSTAGE;
+  int buf = 0;
+  wdma(0, 0);
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    __syncthreads();   // every wave is done reading the previous chunk's halo
+    for (int idx = tid; idx < C::U * C::HH * C::WH; idx += C::NT) {
+      const int u = idx & (C::U - 1);
+      const int pix = idx >> 1;
+      const int hy = pix / C::WH, hx = pix - hy * C::WH;
+      const int gy = y0 - C::PAD + hy, gx = x0 - C::PAD + hx;
+      f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+        const float* src = xb + ((size_t)gy * W + gx) * Cin + chunk * 16 + u * 8;
+        lo = *reinterpret_cast<const f32x4*>(src);
+        hi = *reinterpret_cast<const f32x4*>(src + 4);
+      }
+      bf16x8 p0, p1, p2;
+      split8(lo, hi, p0, p1, p2);
+      const int slot = hy * C::WHP + hx;
+      halo[(0 * C::U + u) * C::PLANE + slot] = __builtin_bit_cast(f32x4, p0);
+      halo[(1 * C::U + u) * C::PLANE + slot] = __builtin_bit_cast(f32x4, p1);
+      halo[(2 * C::U + u) * C::PLANE + slot] = __builtin_bit_cast(f32x4, p2);
+    }
+    __syncthreads();   // halo visible before any wave's (pre-barrier) step-0 A reads
+    for (int s = 0; s < C::NSTAGE; ++s) {
+      const int g = chunk * C::NSTAGE + s;
+      const int ky = s / C::KS, kx = s - ky * C::KS;
+      const unsigned tbytes = (unsigned)(ky * C::WHP + kx) * 16u;
+      const unsigned wbytes = (unsigned)(C::HALO_F4 + buf * C::WSTAGE_F4) * 16u;
+      unsigned aaddr[C::MR], baddr[C::NR];
+#pragma unroll
+      for (int f = 0; f < C::MR; ++f) aaddr[f] = abase[f] + tbytes;
+#pragma unroll
+      for (int gq = 0; gq < C::NR; ++gq) baddr[gq] = bbase[gq] + wbytes;
+      f32x4 fa[2][C::MR], fb[C::NR];
+      a_load<0>(fa[0], aaddr);                              // from the halo: stable for the whole chunk
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of stage g have landed
+      __builtin_amdgcn_s_barrier();                         // ... and everyone's; the other buffer (stage g-1) is free
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int gq = 0; gq < C::NR; ++gq) b_load<0>(fb[gq], baddr[gq]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 1 < nstage_total) wdma(g + 1, buf ^ 1);       // in flight behind this stage's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      stage_steps<0>(fa, fb, aaddr, baddr, acc);
+      buf ^= 1;
+    }
+  }
+
+  // epilogue: bias (+ ReLU + folded BatchNorm) -> fp32 NHWC
+  float* __restrict__ ob = static_cast<float*>(a.out) + (size_t)b * H * W * Cout;
+#pragma unroll
+  for (int g = 0; g < C::NR; ++g) {
+    const int co = n0 + bcol[g];
+    if (co >= Cout) continue;
+    const float bi = a.bias[co];
+    float sc = 1.f, sh = 0.f;
+    if (a.relu_bn) { sc = a.scale[co]; sh = a.shift[co]; }
+#pragma unroll
+    for (int f = 0; f < C::MR; ++f) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = (wm * C::MR + f) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int y = y0 + r / C::TW, x = x0 + r % C::TW;
+        if (y < H && x < W) {
+          float v = acc[f][g][i] + bi;
+          if (a.relu_bn) v = fmaxf(v, 0.f) * sc + sh;
+          ob[((size_t)y * W + x) * Cout + co] = v;
+        }
+      }
+    }
+  }
+}
+
+// fp32 HWIO [k,k,Cin,Cout] -> bf16 [tap][Cin/8][part][CoutP][8], part = 0 (high) .. 2 (low); zero-padded channels
+__global__ void pack_weights_split_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int taps, int Cin, int Cout, int CoutP) {
+  const size_t n = (size_t)taps * Cin * CoutP;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int k8 = i & 7;
+    size_t r = i >> 3;
+    const int co = r % CoutP; r /= CoutP;
+    const int c8 = r % (Cin >> 3);
+    const int tap = r / (Cin >> 3);
+    const float v = co < Cout ? w[((size_t)tap * Cin + c8 * 8 + k8) * Cout + co] : 0.f;
+    const __bf16 b0 = static_cast<__bf16>(v);
+    const float r1 = v - static_cast<float>(b0);
+    const __bf16 b1 = static_cast<__bf16>(r1);
+    const __bf16 b2 = static_cast<__bf16>(r1 - static_cast<float>(b1));
+    const size_t base = (((size_t)tap * (Cin >> 3) + c8) * 3) * CoutP * 8 + (size_t)co * 8 + k8;
+    wp[base] = b0;
+    wp[base + (size_t)CoutP * 8] = b1;
+    wp[base + (size_t)CoutP * 16] = b2;
+  }
+}
+
+}  // namespace
+
+bool conv_split_supported(int ks, int Cin, int CoutP, int H, int W) {
+  return ks == 9 && Cin % 16 == 0 && CoutP % C::BN == 0 && W >= 64 && H % C::TH == 0;
+}
+
+size_t conv_split_weight_bytes(int ks, int Cin, int CoutP) { return (size_t)ks * ks * Cin * CoutP * 2 * C::NSPLIT; }
+
+hipError_t pack_weights_split(const float* w_hwio, void* wp, int ks, int Cin, int Cout, int CoutP, hipStream_t st) {
+  hipLaunchKernelGGL(pack_weights_split_kernel, dim3(2048), dim3(256), 0, st, w_hwio, static_cast<__bf16*>(wp), ks * ks, Cin, Cout, CoutP);
+  return hipGetLastError();
+}
+
+// a.x fp32 NHWC, a.wp from pack_weights_split (CoutP a multiple of 256), a.out fp32
+hipError_t conv_split_f32(const ConvArgs& a, int ks, hipStream_t st) {
+  if (!conv_split_supported(ks, a.Cin, a.CoutP, a.H, a.W)) return hipErrorInvalidValue;
+  const int tiles_x = (a.W + C::TW - 1) / C::TW, tiles_y = a.H / C::TH;
+  const int mtiles = tiles_x * tiles_y * a.B;
+  const int nN = a.CoutP / C::BN;
+  int blocks;
+  if ((8 % nN) == 0) {
+    const int per = 8 / nN;
+    blocks = (mtiles + per - 1) / per * 8;
+  } else {
+    blocks = mtiles * nN;
+  }
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(conv_split_kernel, dim3(blocks), dim3(C::NT), C::LDS_BYTES, st, a, tiles_x, tiles_y, mtiles, nN);
+  return hipGetLastError();
+}
+
+}  // namespace jcm

@@ -51,6 +51,8 @@ struct ConvLayer {
   bool has_bn = false;
   const float* w_raw = nullptr;   // HWIO (conv1 kernel reads it directly)
   float* wp = nullptr;            // packed for conv_igemm_f32
+  void* wp_split = nullptr;       // three bf16 parts per weight for conv_split_f32 (fp32 handles, "f32_conv" = 1)
+  int coutp_split = 0;
   void* wp_bf16 = nullptr;        // packed for conv_igemm_bf16
   void* wq1_bf16 = nullptr;       // packed for conv1_mfma_pool (5x5, Cin=3, Cout=64)
   int coutp_bf16 = 0;
@@ -74,6 +76,7 @@ struct jcm_ctx {
   hipStream_t stream = nullptr;
   int precision = JCM_PRECISION_F32;
   int K = 9;
+  int f32_conv = 0;             // fp32 handles: 0 = exact fp32 MFMA everywhere, 1 = bf16x6 split kernel where it applies
   bool finalized = false;
   std::map<std::string, jcm::Tensor> params;
   std::map<std::string, jcm::ConvLayer> convs;

@@ -15,12 +15,15 @@ def dev(a):
     return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device='cuda:0')
 
 
+@pytest.mark.parametrize('f32_conv', ['exact', 'split'])
 @pytest.mark.parametrize('kind', ['init', 'trained'])
-def test_full_size_tower_vs_golden(kind):
+def test_full_size_tower_vs_golden(kind, f32_conv):
+    """Both fp32 convolution algorithms to the same bar: the exact fp32 MFMA chain and the bf16x6 split
+    (conv_split.hip: fp32 operands as three bf16 parts, six products on the bf16 matrix cores)."""
     from joint_cnn_mrf_amd.engine import Engine
     x, torso, p = full_inputs()
     p.update(synth.make_sm_params(flic_priors(), kind=kind, seed=seeds()['sm']))
-    eng = Engine(device=0).load_params(p)
+    eng = Engine(device=0, f32_conv=f32_conv).load_params(p)
     logits = eng.model(dev(x)).cpu().numpy()
     r = eng.forward(dev(x), dev(torso), use_sm=True)
     eng.close()
@@ -125,3 +128,23 @@ def test_repeatability_soak(precision, batch):
         assert torch.equal(r['pd_prob'], ref_pd), 'part-detector output changed on repeat %d' % it
         assert torch.equal(r['sm_prob'], ref_sm), 'spatial-model output changed on repeat %d' % it
     eng.close()
+
+
+def test_split_conv_layer_error_is_fp32_class():
+    """conv5 alone (K = 41472): the split kernel against the float64 oracle, next to the exact fp32 kernel."""
+    from joint_cnn_mrf_amd.engine import Engine
+    import oracle.jcm_oracle as O64
+    x, _torso, p = full_inputs()
+    rs = np.random.RandomState(3)
+    a = np.maximum(rs.standard_normal((1, 60, 90, 512)), 0).astype(np.float32)
+    ref = O64.conv_layer(a.astype(np.float64), p, 9, 1, 'conv5')
+    outs = {}
+    for algo in ('exact', 'split'):
+        eng = Engine(device=0, f32_conv=algo).load_params(p)
+        outs[algo] = eng.conv_layer(dev(a), 'conv5', 1, n_out=512).cpu().numpy().astype(np.float64)
+        eng.close()
+    scale = np.abs(ref).max()
+    e_exact, e_split = np.abs(outs['exact'] - ref).max() / scale, np.abs(outs['split'] - ref).max() / scale
+    r_exact, r_split = np.sqrt(np.mean((outs['exact'] - ref) ** 2)) / scale, np.sqrt(np.mean((outs['split'] - ref) ** 2)) / scale
+    print('conv5 error / max|out|: exact max %.2e rms %.2e, split max %.2e rms %.2e' % (e_exact, r_exact, e_split, r_split))
+    assert e_exact <= 1e-5 and e_split <= 2e-5 and r_split <= 3 * r_exact + 1e-7      # the same error class
