@@ -126,7 +126,7 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
                                       if f32_conv == 'split' else
                                       'fp32 MFMA 32x32x2, 4x32 patch x 128 ch' if dtype == 'fp32' else 'bf16 MFMA 32x32x16, 12x32 patch x 256 ch'),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None,
-                         'traffic': pmc_traffic('%s_b%d' % (dtype, B)) if not args.debug else None,
+                         'traffic': pmc_traffic('%s_b%d' % (dtype, B)) if not (args.debug or f32_conv == 'split') else None,
                          'launch_ms': launch_ms, 'launches': tot_n, 'flops_per_launch': flops_launch},
         }
     eng.close()
@@ -145,7 +145,7 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm):
     """`--train`: time the joint training step (loss + gradients, gradient all-reduce, clip + Adam, table
     refresh) on B images per GPU; data-parallel, one RCCL all-reduce of the flat gradient buffer per step."""
     from joint_cnn_mrf_amd.train import Trainer
-    eng = Engine(device=local_rank, precision='fp32').load_params(params)
+    eng = Engine(device=local_rank, precision='fp32', f32_conv=args.f32_conv).load_params(params)
     tr = Trainer(eng, optimizer='adam', lr=0.001, lmbd=0.001, use_sm=use_sm)
     x = torch.as_tensor(synth.make_images(B, seed=1234 + rank), device=dev)
     y = torch.as_tensor(synth.make_targets(B, seed=4321 + rank), device=dev)
@@ -185,8 +185,9 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm):
         out = {'metric': 'images/sec joint training step (fwd+bwd+update), part detector + spatial model', 'value': value,
                'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-               'config': {'workload': 'configs[4]: joint training, batch=%d/GPU synthetic 480x720x3, fp32 MFMA, Adam, clip 4.0%s'
-                                      % (B, ', DEBUG filters/4' if args.debug else ''),
+               'config': {'workload': 'configs[4]: joint training, batch=%d/GPU synthetic 480x720x3, fp32 MFMA%s, Adam, clip 4.0%s'
+                                      % (B, ' (forward + data gradient of the 60x90 9x9 layers as bf16x6 split MFMA)' if args.f32_conv == 'split' else '',
+                                         ', DEBUG filters/4' if args.debug else ''),
                           'batch_per_gpu': B, 'global_batch': world * B, 'use_sm': use_sm,
                           'collective': 'all_reduce of %d fp32 gradients' % tr.n_elements},
                'train_tflops': value * FLOPS_TRAIN / scale / 1e12, 'mfma_peak_tflops': PEAK_TFLOPS['fp32'],

@@ -19,6 +19,7 @@ struct BnSave {
 
 struct DgradW {
   float* wd = nullptr;     // packed flipped/transposed weights for conv_igemm_f32
+  void* wd_split = nullptr;  // the same in three bf16 parts for conv_split_f32 (handles with f32_conv = 1)
   int cinp = 0;            // dZ channel stride the kernel reads (= Cout rounded up to 16)
   int coutp = 0;           // packed N extent (= Cin rounded up to the kernel's N tile)
 };
@@ -69,6 +70,7 @@ int repack_dgrad(jcm_ctx* c) {
     DgradW& d = kv.second;
     HIP_TRY(flip_transpose_weights(L->w_raw, t->scratch_flip, L->ks, L->cin, L->cout, d.cinp, c->stream));
     HIP_TRY(pack_weights_f32(t->scratch_flip, d.wd, L->ks, d.cinp, L->cin, d.coutp, c->stream));
+    if (d.wd_split) HIP_TRY(pack_weights_split(t->scratch_flip, d.wd_split, L->ks, d.cinp, L->cin, L->cin, c->stream));
   }
   return JCM_OK;
 }
@@ -165,13 +167,16 @@ int conv_dgrad(jcm_ctx* c, const LayerFwd& f, const float* dz, int B, float* dx)
   ConvArgs a;
   a.x = dz; a.wp = d.wd; a.bias = t->zeros; a.scale = t->ones; a.shift = t->zeros; a.out = dx;
   a.B = B; a.H = f.H; a.W = f.W; a.Cin = d.cinp; a.Cout = f.L->cin; a.CoutP = d.coutp; a.relu_bn = 0;
+  const bool split = d.wd_split && conv_split_supported(f.L->ks, d.cinp, f.L->cin, f.H, f.W);
+  if (split) { a.wp = d.wd_split; a.CoutP = f.L->cin; }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->profile) {
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, c->stream));
   }
-  HIP_TRY(conv_igemm_f32(a, f.L->ks, c->stream));
+  if (split) HIP_TRY(conv_split_f32(a, f.L->ks, c->stream));
+  else HIP_TRY(conv_igemm_f32(a, f.L->ks, c->stream));
   if (c->profile) {
     HIP_TRY(hipEventRecord(e1, c->stream));
     c->prof["dgrad:" + f.scope].emplace_back(e0, e1);
@@ -442,6 +447,8 @@ int jcm_train_begin(jcm_handle h) {
     const int bn = conv_igemm_bn(L.cin);
     d.coutp = (L.cin + bn - 1) / bn * bn;
     JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&d.wd), (size_t)L.ks * L.ks * d.cinp * d.coutp * sizeof(float)));
+    if (c->f32_conv == 1 && L.ks == 9 && L.cin % 256 == 0)      // data gradient on the bf16x6 split kernel where its tile fits
+      JCM_TRY(dev_alloc(c, &d.wd_split, conv_split_weight_bytes(L.ks, d.cinp, L.cin)));
     const size_t nf = (size_t)L.ks * L.ks * d.cinp * L.cin;
     if (nf > max_w) max_w = nf;
     t->dgrad[kv.first] = d;

@@ -18,10 +18,10 @@ def dev(a):
     return torch.as_tensor(np.ascontiguousarray(a), device='cuda:0')
 
 
-def make_trainer(params, **kw):
+def make_trainer(params, f32_conv=None, **kw):
     from joint_cnn_mrf_amd.engine import Engine
     from joint_cnn_mrf_amd.train import Trainer
-    eng = Engine(device=0).load_params(params)
+    eng = Engine(device=0, f32_conv=f32_conv).load_params(params)
     return eng, Trainer(eng, **kw)
 
 
@@ -176,7 +176,8 @@ def test_train_cli_debug():
     assert len(lines) == 2 and 'train_loss' in lines[0], out.stdout
 
 
-def test_full_size_step_vs_golden():
+@pytest.mark.parametrize('f32_conv', ['exact', 'split'])
+def test_full_size_step_vs_golden(f32_conv):
     """The full-size network (filters 64..512), one 480x720 image: losses, sampled gradient entries, gradient
     norms and the moving-statistics update against tests/golden/train_full.json (float64 restatement,
     generated by tests/golden/make_train_golden.py)."""
@@ -185,7 +186,7 @@ def test_full_size_step_vs_golden():
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'train_full.json')) as fh:
         gold = json.load(fh)
     p, x, y = case()
-    eng, tr = make_trainer(p, use_sm=True, lmbd=LMBD)
+    eng, tr = make_trainer(p, f32_conv=f32_conv, use_sm=True, lmbd=LMBD)      # 'split': forward + data gradient of conv4_fullres / conv5 on conv_split.hip
     losses, _ = tr.loss_and_grads(dev(x), dev(y))
     got = tr.grads_dict()
     l = losses.cpu().numpy()
