@@ -126,7 +126,7 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
                                       if f32_conv == 'split' else
                                       'fp32 MFMA 32x32x2, 4x32 patch x 128 ch' if dtype == 'fp32' else 'bf16 MFMA 32x32x16, 12x32 patch x 256 ch'),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None,
-                         'traffic': pmc_traffic('%s_b%d' % (dtype, B)) if not (args.debug or f32_conv == 'split') else None,
+                         'traffic': pmc_traffic('%s%s_b%d' % (dtype, '_split' if f32_conv == 'split' else '', B)) if not args.debug else None,
                          'launch_ms': launch_ms, 'launches': tot_n, 'flops_per_launch': flops_launch},
         }
     eng.close()

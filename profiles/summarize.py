@@ -14,6 +14,7 @@ import sys
 
 
 def short(name):
+    name = name.replace('(anonymous namespace)::', '')
     name = re.sub(r'\(.*$', '', name)
     return name.replace('void ', '').replace('jcm::', '')
 
