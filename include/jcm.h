@@ -47,8 +47,8 @@ int jcm_abi_version(void);
  * "precision": JCM_PRECISION_*  (the reference is fp32 throughout)
  * "n_joints" : K, default 9      (main.py:458)
  * "f32_conv"  : fp32 handles only; 0 (default) = every convolution on the exact fp32 MFMA chain,
- *              1 = the 9x9 layers on 60x90 / 120x180 maps with Cout % 256 == 0 run as three-way
- *              bf16 operand splits with six products on the bf16 matrix cores (fp32-class error).
+ *              1 = the stride-1 layers with Cin % 16 == 0 and Cout % 128 == 0 run as three-way bf16
+ *              operand splits with six products on the bf16 matrix cores (fp32-class error).
  * All three must be set before jcm_finalize.
  * "profile"  : 0/1, any time: bracket every MFMA conv launch with HIP events on the launch
  *              stream; read the totals back with jcm_profile_read. */

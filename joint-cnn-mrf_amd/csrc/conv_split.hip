@@ -24,14 +24,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
+// KS x KS taps, TH x TW pixel patch (or, FLAT, TH*TW pixel slots filled with whole rows of a narrow map), BN channels
+template <int KS_, int BN_, bool FLAT_>
 struct CfgS {
-  static constexpr int KS = 9, TH = 12, TW = 32, BN = 256, WM = 4, WN = 2;
+  static constexpr int KS = KS_, TH = 12, TW = 32, BN = BN_, WM = 4, WN = 2;
+  static constexpr bool FLAT = FLAT_;
   static constexpr int NT = WM * WN * 64;
   static constexpr int U = 2;                       // 16-B units per chunk = 16 channels = one k16 step
   static constexpr int NSPLIT = 3, NSUB = 6;
   static constexpr int PAD = (KS - 1) / 2;
   static constexpr int HH = TH + KS - 1, WH = TW + KS - 1, WHP = WH;
-  static constexpr int PLANE = HH * WHP + 2;
+  // FLAT: (R + KS-1) x (W + KS-1) slots with R = floor(384 / W) rows: 16x53 (30x45 maps) / 23x31 (15x23) for KS = 9
+  static constexpr int PLANE = FLAT ? 850 : HH * WHP + 2;
   static constexpr int BM = TH * TW, MR = BM / WM / 32, NR = BN / WN / 32;
   static constexpr int HALO_F4 = NSPLIT * U * PLANE;            // [split][unit][slot]
   static constexpr int WSTAGE_F4 = NSPLIT * U * BN;             // one tap: [split][unit][co]
@@ -39,7 +43,7 @@ struct CfgS {
   static constexpr int LDS_BYTES = (HALO_F4 + 2 * WSTAGE_F4) * 16;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
-using C = CfgS;
+constexpr int kNSub = 6;
 
 // sub-step -> (activation part, weight part).  Weight parts are visited in runs (0 0 0 1 1 2) so that a B
 // fragment is re-read only when its part changes, and the last two steps share a0: 5*MR + 3*NR = 27 fragment reads per
@@ -47,15 +51,15 @@ using C = CfgS;
 // (All six products land in the same accumulator, whose magnitude is the running sum: their order is immaterial.)
 __host__ __device__ constexpr int sub_b(int s) { return s < 3 ? 0 : (s < 5 ? 1 : 2); }            // 0 0 0 1 1 2
 __host__ __device__ constexpr int sub_a(int s) { return s < 3 ? 2 - s : (s < 5 ? 4 - s : 0); }    // 2 1 0 1 0 0
-__host__ __device__ constexpr bool reload_b(int s) { return s == 0 || (s < 6 && sub_b(s) != sub_b(s - 1)); }
-__host__ __device__ constexpr bool load_a(int s) { return s == 0 || (s < 6 && sub_a(s) != sub_a(s - 1)); }   // steps 4, 5 share a0
+__host__ __device__ constexpr bool reload_b(int s) { return s == 0 || (s < kNSub && sub_b(s) != sub_b(s - 1)); }
+__host__ __device__ constexpr bool load_a(int s) { return s == 0 || (s < kNSub && sub_a(s) != sub_a(s - 1)); }   // steps 4, 5 share a0
 __host__ __device__ constexpr int a_buf(int s) {          // which of the two A register sets step s reads
   int n = 0;
   for (int k = 1; k <= s; ++k) n += load_a(k) ? 1 : 0;
   return n & 1;
 }
 
-template <int STEP>
+template <class C, int STEP>
 __device__ __forceinline__ void a_load(f32x4 (&fa)[C::MR], const unsigned (&aaddr)[C::MR]) {
   constexpr int aoff = sub_a(STEP) * C::U * C::PLANE * 16;
   static_assert(aoff < 65536, "ds_read offset field is 16 bits");
@@ -63,7 +67,7 @@ __device__ __forceinline__ void a_load(f32x4 (&fa)[C::MR], const unsigned (&aadd
   for (int f = 0; f < C::MR; ++f)
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[f]) : "v"(aaddr[f]), "i"(aoff) : "memory");
 }
-template <int STEP>
+template <class C, int STEP>
 __device__ __forceinline__ void b_load(f32x4& fb, unsigned baddr) {
   constexpr int boff = sub_b(STEP) * C::U * C::BN * 16;
   static_assert(boff < 65536, "ds_read offset field is 16 bits");
@@ -73,7 +77,7 @@ __device__ __forceinline__ void b_load(f32x4& fb, unsigned baddr) {
 // with the bracketed reloads present only where the weight part changes.  When the MFMAs of (step k, group g)
 // issue they need A(k) and the latest B[g]; younger reads still allowed in flight:
 //   the rest of this step's B reloads (NR-1-g, if B was reloaded for k) + A(k+1) (MR) + next step's reloads so far (g)
-template <int STEP, int G>
+template <class C, int STEP, int G>
 __device__ __forceinline__ void rot_g(f32x4 (&fa)[2][C::MR], f32x4 (&fb)[C::NR], const unsigned (&baddr)[C::NR], f32x16 (&acc)[C::MR][C::NR]) {
   if constexpr (G < C::NR) {
     constexpr bool more = STEP + 1 < C::NSUB;
@@ -86,17 +90,17 @@ __device__ __forceinline__ void rot_g(f32x4 (&fa)[2][C::MR], f32x4 (&fb)[C::NR],
       acc[f][G] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cur][f]), __builtin_bit_cast(bf16x8, fb[G]),
                                                           acc[f][G], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (more && reload_b(STEP + 1)) b_load<STEP + 1>(fb[G], baddr[G]);
-    rot_g<STEP, G + 1>(fa, fb, baddr, acc);
+    if constexpr (more && reload_b(STEP + 1)) b_load<C, STEP + 1>(fb[G], baddr[G]);
+    rot_g<C, STEP, G + 1>(fa, fb, baddr, acc);
   }
 }
-template <int STEP>
+template <class C, int STEP>
 __device__ __forceinline__ void stage_steps(f32x4 (&fa)[2][C::MR], f32x4 (&fb)[C::NR], const unsigned (&aaddr)[C::MR],
                                             const unsigned (&baddr)[C::NR], f32x16 (&acc)[C::MR][C::NR]) {
   if constexpr (STEP < C::NSUB) {
-    if constexpr (STEP + 1 < C::NSUB && load_a(STEP + 1)) a_load<STEP + 1>(fa[a_buf(STEP + 1)], aaddr);
-    rot_g<STEP, 0>(fa, fb, baddr, acc);
-    stage_steps<STEP + 1>(fa, fb, aaddr, baddr, acc);
+    if constexpr (STEP + 1 < C::NSUB && load_a(STEP + 1)) a_load<C, STEP + 1>(fa[a_buf(STEP + 1)], aaddr);
+    rot_g<C, STEP, 0>(fa, fb, baddr, acc);
+    stage_steps<C, STEP + 1>(fa, fb, aaddr, baddr, acc);
   }
 }
 
@@ -113,6 +117,7 @@ __device__ __forceinline__ void split8(const f32x4& lo, const f32x4& hi, bf16x8&
   }
 }
 
+template <class C>
 __global__ __launch_bounds__(C::NT, 2) void conv_split_kernel(ConvArgs a, int tiles_x, int tiles_y, int mtiles, int nN) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* halo = reinterpret_cast<f32x4*>(smem);
@@ -129,8 +134,12 @@ __global__ __launch_bounds__(C::NT, 2) void conv_split_kernel(ConvArgs a, int ti
     mt = L / nN;
   }
   if (mt >= mtiles) return;
-  const int tx = mt % tiles_x, ty = (mt / tiles_x) % tiles_y, b = mt / (tiles_x * tiles_y);
-  const int y0 = ty * C::TH, x0 = tx * C::TW, n0 = nt * C::BN;
+  // FLAT tiles: `tiles_x` carries R (rows per tile), there is one tile across
+  const int flat_r = C::FLAT ? tiles_x : 0;
+  const int tx = C::FLAT ? 0 : mt % tiles_x;
+  const int ty = C::FLAT ? mt % tiles_y : (mt / tiles_x) % tiles_y;
+  const int b = C::FLAT ? mt / tiles_y : mt / (tiles_x * tiles_y);
+  const int y0 = ty * (C::FLAT ? flat_r : C::TH), x0 = tx * C::TW, n0 = nt * C::BN;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -142,11 +151,21 @@ __global__ __launch_bounds__(C::NT, 2) void conv_split_kernel(ConvArgs a, int ti
   const float* __restrict__ xb = static_cast<const float*>(a.x) + (size_t)b * H * W * Cin;
   const __bf16* __restrict__ wp = static_cast<const __bf16*>(a.wp);
 
+  // halo geometry: compile-time for patches, per-launch for FLAT tiles
+  const int whp = C::FLAT ? W + C::KS - 1 : C::WHP;
+  const int wh = C::FLAT ? W + C::KS - 1 : C::WH;
+  const int hh = C::FLAT ? flat_r + C::KS - 1 : C::HH;
   int aslot[C::MR], bcol[C::NR];
 #pragma unroll
   for (int f = 0; f < C::MR; ++f) {
     const int r = (wm * C::MR + f) * 32 + l31;
-    aslot[f] = (r / C::TW) * C::WHP + (r % C::TW);
+    if constexpr (C::FLAT) {
+      const int rr = r < flat_r * W ? r : 0;          // padding slots compute on pixel 0 and are dropped
+      const int yy = rr / W;
+      aslot[f] = yy * whp + (rr - yy * W);
+    } else {
+      aslot[f] = (r / C::TW) * C::WHP + (r % C::TW);
+    }
   }
 #pragma unroll
   for (int g = 0; g < C::NR; ++g) bcol[g] = (wn * C::NR + g) * 32 + l31;
@@ -168,19 +187,20 @@ __global__ __launch_bounds__(C::NT, 2) void conv_split_kernel(ConvArgs a, int ti
       for (int i = 0; i < 16; ++i) acc[f][g][i] = 0.f;
 
   const int cin8 = Cin >> 3;
-  // one stage = one tap of one 16-channel chunk: 3 parts x 2 units x 256 channels x 16 B = 24 KB, 24 LDS-DMA pieces of 1 KB
+  // one stage = one tap of one 16-channel chunk: 3 parts x 2 units x BN channels x 16 B (24 KB at BN = 256) in 1-KB LDS-DMA pieces
   constexpr int NWAVE = C::NT / 64;
   constexpr int NPIECE = C::WSTAGE_F4 / 64;
   constexpr int QPU = C::BN / 64;
-  static_assert(NPIECE % NWAVE == 0, "pieces divide over the waves");
+  static_assert(C::BN % 64 == 0, "a (part, unit) row is a whole number of pieces");
   const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wp), 0,
                                                        (int)((size_t)C::KS * C::KS * Cin * CoutP * 2 * C::NSPLIT), 0x00020000);
   const unsigned wvoff = (unsigned)(n0 + lane) * 16u;
   auto wdma = [&](int g, int bufsel) {
     const int chunk = g / C::NSTAGE, tap = g - chunk * C::NSTAGE;
 #pragma unroll
-    for (int i = 0; i < NPIECE / NWAVE; ++i) {
+    for (int i = 0; i < (NPIECE + NWAVE - 1) / NWAVE; ++i) {
       const int piece = wid + i * NWAVE;              // wave-uniform; LDS image [part][unit][co]
+      if ((NPIECE % NWAVE != 0) && piece >= NPIECE) break;
       f32x4* dst = wbuf + bufsel * C::WSTAGE_F4 + piece * 64;
       const int q = piece % QPU, pu = piece / QPU;
       const int u = pu % C::U, part = pu / C::U;
@@ -195,10 +215,10 @@ __global__ __launch_bounds__(C::NT, 2) void conv_split_kernel(ConvArgs a, int ti
   wdma(0, 0);
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     __syncthreads();   // every wave is done reading the previous chunk's halo
-    for (int idx = tid; idx < C::U * C::HH * C::WH; idx += C::NT) {
+    for (int idx = tid; idx < C::U * hh * wh; idx += C::NT) {
       const int u = idx & (C::U - 1);
       const int pix = idx >> 1;
-      const int hy = pix / C::WH, hx = pix - hy * C::WH;
+      const int hy = pix / wh, hx = pix - hy * wh;
       const int gy = y0 - C::PAD + hy, gx = x0 - C::PAD + hx;
       f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
       if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
@@ -208,7 +228,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv_split_kernel(ConvArgs a, int ti
       }
       bf16x8 p0, p1, p2;
       split8(lo, hi, p0, p1, p2);
-      const int slot = hy * C::WHP + hx;
+      const int slot = hy * whp + hx;
       halo[(0 * C::U + u) * C::PLANE + slot] = __builtin_bit_cast(f32x4, p0);
       halo[(1 * C::U + u) * C::PLANE + slot] = __builtin_bit_cast(f32x4, p1);
       halo[(2 * C::U + u) * C::PLANE + slot] = __builtin_bit_cast(f32x4, p2);
@@ -217,7 +237,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv_split_kernel(ConvArgs a, int ti
     for (int s = 0; s < C::NSTAGE; ++s) {
       const int g = chunk * C::NSTAGE + s;
       const int ky = s / C::KS, kx = s - ky * C::KS;
-      const unsigned tbytes = (unsigned)(ky * C::WHP + kx) * 16u;
+      const unsigned tbytes = (unsigned)(ky * whp + kx) * 16u;
       const unsigned wbytes = (unsigned)(C::HALO_F4 + buf * C::WSTAGE_F4) * 16u;
       unsigned aaddr[C::MR], baddr[C::NR];
 #pragma unroll
@@ -225,16 +245,16 @@ __global__ __launch_bounds__(C::NT, 2) void conv_split_kernel(ConvArgs a, int ti
 #pragma unroll
       for (int gq = 0; gq < C::NR; ++gq) baddr[gq] = bbase[gq] + wbytes;
       f32x4 fa[2][C::MR], fb[C::NR];
-      a_load<0>(fa[0], aaddr);                              // from the halo: stable for the whole chunk
+      a_load<C, 0>(fa[0], aaddr);                              // from the halo: stable for the whole chunk
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of stage g have landed
       __builtin_amdgcn_s_barrier();                         // ... and everyone's; the other buffer (stage g-1) is free
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int gq = 0; gq < C::NR; ++gq) b_load<0>(fb[gq], baddr[gq]);
+      for (int gq = 0; gq < C::NR; ++gq) b_load<C, 0>(fb[gq], baddr[gq]);
       __builtin_amdgcn_sched_barrier(0);
       if (g + 1 < nstage_total) wdma(g + 1, buf ^ 1);       // in flight behind this stage's MFMAs
       __builtin_amdgcn_sched_barrier(0);
-      stage_steps<0>(fa, fb, aaddr, baddr, acc);
+      stage_steps<C, 0>(fa, fb, aaddr, baddr, acc);
       buf ^= 1;
     }
   }
@@ -253,8 +273,17 @@ __global__ __launch_bounds__(C::NT, 2) void conv_split_kernel(ConvArgs a, int ti
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int r = (wm * C::MR + f) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        const int y = y0 + r / C::TW, x = x0 + r % C::TW;
-        if (y < H && x < W) {
+        int y, x;
+        bool ok;
+        if constexpr (C::FLAT) {
+          const int yy = r / W;
+          y = y0 + yy; x = r - yy * W;
+          ok = r < flat_r * W && y < H;
+        } else {
+          y = y0 + r / C::TW; x = x0 + r % C::TW;
+          ok = y < H && x < W;
+        }
+        if (ok) {
           float v = acc[f][g][i] + bi;
           if (a.relu_bn) v = fmaxf(v, 0.f) * sc + sh;
           ob[((size_t)y * W + x) * Cout + co] = v;
@@ -287,22 +316,19 @@ __global__ void pack_weights_split_kernel(const float* __restrict__ w, __bf16* _
 
 }  // namespace
 
-bool conv_split_supported(int ks, int Cin, int CoutP, int H, int W) {
-  return ks == 9 && Cin % 16 == 0 && CoutP % C::BN == 0 && W >= 64 && H % C::TH == 0;
-}
-
-size_t conv_split_weight_bytes(int ks, int Cin, int CoutP) { return (size_t)ks * ks * Cin * CoutP * 2 * C::NSPLIT; }
-
-hipError_t pack_weights_split(const float* w_hwio, void* wp, int ks, int Cin, int Cout, int CoutP, hipStream_t st) {
-  hipLaunchKernelGGL(pack_weights_split_kernel, dim3(2048), dim3(256), 0, st, w_hwio, static_cast<__bf16*>(wp), ks * ks, Cin, Cout, CoutP);
-  return hipGetLastError();
-}
-
-// a.x fp32 NHWC, a.wp from pack_weights_split (CoutP a multiple of 256), a.out fp32
-hipError_t conv_split_f32(const ConvArgs& a, int ks, hipStream_t st) {
-  if (!conv_split_supported(ks, a.Cin, a.CoutP, a.H, a.W)) return hipErrorInvalidValue;
-  const int tiles_x = (a.W + C::TW - 1) / C::TW, tiles_y = a.H / C::TH;
-  const int mtiles = tiles_x * tiles_y * a.B;
+namespace {
+template <class C>
+hipError_t launch_s(const ConvArgs& a, hipStream_t st) {
+  int tiles_x = (a.W + C::TW - 1) / C::TW, tiles_y = (a.H + C::TH - 1) / C::TH;
+  int mtiles = tiles_x * tiles_y * a.B;
+  if constexpr (C::FLAT) {
+    int R = C::BM / a.W;
+    if (R > a.H) R = a.H;
+    if (R < 1 || (R + C::KS - 1) * (a.W + C::KS - 1) + 2 > C::PLANE) return hipErrorInvalidValue;
+    tiles_y = (a.H + R - 1) / R;
+    tiles_x = R;                      // the kernel reads R from this slot
+    mtiles = tiles_y * a.B;
+  }
   const int nN = a.CoutP / C::BN;
   int blocks;
   if ((8 % nN) == 0) {
@@ -313,12 +339,46 @@ hipError_t conv_split_f32(const ConvArgs& a, int ks, hipStream_t st) {
   }
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(conv_split_kernel, dim3(blocks), dim3(C::NT), C::LDS_BYTES, st, a, tiles_x, tiles_y, mtiles, nN);
+  hipLaunchKernelGGL(conv_split_kernel<C>, dim3(blocks), dim3(C::NT), C::LDS_BYTES, st, a, tiles_x, tiles_y, mtiles, nN);
   return hipGetLastError();
+}
+bool flat_fits(int ks, int H, int W) {
+  int R = 384 / W;
+  if (R > H) R = H;
+  return W <= 48 && R >= 1 && (R + ks - 1) * (W + ks - 1) + 2 <= 850;
+}
+}  // namespace
+
+// channel tile the kernel will use for a layer (its packed CoutP must be a multiple of it)
+int conv_split_bn(int Cout) { return Cout % 256 == 0 ? 256 : 128; }
+
+bool conv_split_supported(int ks, int Cin, int CoutP, int H, int W) {
+  if (!(ks == 9 || ks == 5) || Cin % 16 || CoutP % 128) return false;
+  return (W >= 64 && H % 12 == 0) || flat_fits(ks, H, W);
+}
+
+size_t conv_split_weight_bytes(int ks, int Cin, int CoutP) { return (size_t)ks * ks * Cin * CoutP * 2 * 3; }
+
+hipError_t pack_weights_split(const float* w_hwio, void* wp, int ks, int Cin, int Cout, int CoutP, hipStream_t st) {
+  hipLaunchKernelGGL(pack_weights_split_kernel, dim3(2048), dim3(256), 0, st, w_hwio, static_cast<__bf16*>(wp), ks * ks, Cin, Cout, CoutP);
+  return hipGetLastError();
+}
+
+// a.x fp32 NHWC, a.wp from pack_weights_split (CoutP a multiple of 128), a.out fp32
+hipError_t conv_split_f32(const ConvArgs& a, int ks, hipStream_t st) {
+  if (!conv_split_supported(ks, a.Cin, a.CoutP, a.H, a.W)) return hipErrorInvalidValue;
+  const bool wide = a.W >= 64 && a.H % 12 == 0;
+  const bool big = a.CoutP % 256 == 0;
+  if (ks == 9) {
+    if (big) return wide ? launch_s<CfgS<9, 256, false>>(a, st) : launch_s<CfgS<9, 256, true>>(a, st);
+    return wide ? launch_s<CfgS<9, 128, false>>(a, st) : launch_s<CfgS<9, 128, true>>(a, st);
+  }
+  if (big) return wide ? launch_s<CfgS<5, 256, false>>(a, st) : launch_s<CfgS<5, 256, true>>(a, st);
+  return wide ? launch_s<CfgS<5, 128, false>>(a, st) : launch_s<CfgS<5, 128, true>>(a, st);
 }
 
 }  // namespace jcm

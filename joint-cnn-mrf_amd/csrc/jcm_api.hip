@@ -153,7 +153,7 @@ int refresh_derived(jcm_ctx* c, bool first) {
       if (!L.wp) JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&L.wp), n * sizeof(float)));
       HIP_TRY(pack_weights_f32(w.d, L.wp, L.ks, L.cin, L.cout, L.coutp, c->stream));
     }
-    if (c->precision == JCM_PRECISION_F32 && c->f32_conv == 1 && L.ks == 9 && L.cin % 16 == 0 && L.cout % 256 == 0) {
+    if (c->precision == JCM_PRECISION_F32 && c->f32_conv == 1 && (L.ks == 9 || L.ks == 5) && L.cin % 16 == 0 && L.cout % 128 == 0) {
       L.coutp_split = L.cout;
       if (!L.wp_split) JCM_TRY(dev_alloc(c, &L.wp_split, conv_split_weight_bytes(L.ks, L.cin, L.coutp_split)));
       HIP_TRY(pack_weights_split(w.d, L.wp_split, L.ks, L.cin, L.cout, L.coutp_split, c->stream));

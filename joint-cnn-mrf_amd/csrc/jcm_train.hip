@@ -447,7 +447,7 @@ int jcm_train_begin(jcm_handle h) {
     const int bn = conv_igemm_bn(L.cin);
     d.coutp = (L.cin + bn - 1) / bn * bn;
     JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&d.wd), (size_t)L.ks * L.ks * d.cinp * d.coutp * sizeof(float)));
-    if (c->f32_conv == 1 && L.ks == 9 && L.cin % 256 == 0)      // data gradient on the bf16x6 split kernel where its tile fits
+    if (c->f32_conv == 1 && L.cin % 128 == 0)      // data gradient on the bf16x6 split kernel where its tile fits
       JCM_TRY(dev_alloc(c, &d.wd_split, conv_split_weight_bytes(L.ks, d.cinp, L.cin)));
     const size_t nf = (size_t)L.ks * L.ks * d.cinp * L.cin;
     if (nf > max_w) max_w = nf;
