@@ -141,14 +141,24 @@ int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const float* dz, int ldz, int B, f
   const int splits = wgrad_splits(L->ks, L->cin, L->cout, B, f.H);
   const size_t mark = c->arena_off;
   float* partial = arena_alloc<float>(c, n * splits);
+  // handles with f32_conv = 1: the bf16x6 split kernel on pre-split operands (wgrad_split.hip)
+  const bool split = c->f32_conv == 1 && wgrad_split_supported(L->ks, L->cin, ldz);
+  const size_t nx = (size_t)B * f.H * f.W * L->cin, nz = (size_t)B * f.H * f.W * ldz;
+  char* xparts = split ? arena_alloc<char>(c, nx * 6) : nullptr;
+  char* zparts = split ? arena_alloc<char>(c, nz * 6) : nullptr;
   if (!c->dry) {
+    if (split) {
+      HIP_TRY(split_parts(f.in, xparts, nx, c->stream));
+      HIP_TRY(split_parts(dz, zparts, nz, c->stream));
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profile) {
       HIP_TRY(hipEventCreate(&e0));
       HIP_TRY(hipEventCreate(&e1));
       HIP_TRY(hipEventRecord(e0, c->stream));
     }
-    HIP_TRY(wgrad_f32(f.in, dz, partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream));
+    if (split) HIP_TRY(wgrad_split(xparts, zparts, partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream));
+    else HIP_TRY(wgrad_f32(f.in, dz, partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream));
     if (c->profile) {
       HIP_TRY(hipEventRecord(e1, c->stream));
       c->prof["wgrad:" + f.scope].emplace_back(e0, e1);      // read with jcm_profile_read("wgrad:<scope>")

@@ -148,6 +148,11 @@ hipError_t wgrad_f32(const float* x, const float* dz, float* partial, int splits
 hipError_t wgrad_reduce(const float* partial, int splits, size_t n, const float* w, float lmbd, float* dw, hipStream_t st);
 int wgrad_conv1_blocks(void);
 hipError_t wgrad_conv1(const float* x, const float* dz, float* partial, int B, int H0, int W0, int sub, int Cout, hipStream_t st);
+// wgrad_split.hip: the same on the bf16 matrix cores (three-way operand split, six products, LDS transpose reads)
+hipError_t split_parts(const float* x, void* out_bf16_3n, size_t n, hipStream_t st);    // out[p*n + i] = part p of x[i]
+bool wgrad_split_supported(int ks, int Cin, int ldz);
+hipError_t wgrad_split(const void* xp, const void* zp, float* partial, int splits, int ks, int B, int H, int W, int Cin, int Cout, int ldz,
+                       hipStream_t st);
 hipError_t flip_transpose_weights(const float* w_hwio, float* wd, int ks, int Cin, int Cout, int CoP, hipStream_t st);
 
 // ---- sm_train.hip : backward of the spatial model (frequency-domain correlations) -----------------------

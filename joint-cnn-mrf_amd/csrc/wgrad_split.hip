@@ -1,0 +1,234 @@
+// Weight gradient on the bf16 matrix cores with fp32-class accuracy (the bf16x6 operand split of
+// conv_split.hip applied to wgrad.hip's dataflow).
+//
+//   dW[ky][kx][ci][co] = sum_{b,y,x} X[b, y+ky-PAD, x+kx-PAD, ci] * dZ[b, y, x, co]
+//
+// GEMM per tap: M = ci, N = co, K = pixels.  v_mfma_f32_32x32x16_bf16 wants, per lane, 8 consecutive
+// K values of one M (or N) index -- but NHWC keeps the *channels* of a pixel contiguous, not the
+// pixels of a channel.  gfx950's LDS transpose read closes the gap: the strip is staged exactly as it
+// lies in memory, [pixel][32 channels] (64-byte rows; LDS-DMA, no VGPR round trip), and
+// ds_read_b64_tr_b16 hands every lane the 4 consecutive pixels of its channel: in each 16-lane group,
+// lane t supplies the address of the 8-byte piece (row t/4, columns 4(t%4)..+3) of a 4 x 16 block
+// and receives column t of it.  The kx tap shift is a row offset of the read (an immediate).
+//
+// Both operands arrive pre-split into three bf16 parts (split_parts: a = a0 + a1 + a2 exactly); the
+// six products with part indices p + q <= 2 accumulate into the tap's fp32 accumulator.  A workgroup
+// owns one tap row (ky, all kx) of a 64(ci) x 64(co) tile like wgrad_kernel; K is split over
+// workgroups and the partial tiles are reduced by wgrad_reduce.
+#include "kernels.h"
+
+namespace jcm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int WS_PW = 32;          // output pixels per strip = two k16 steps
+constexpr int WS_XPX = 48;         // staged input pixels per strip (>= 32 + KS - 1, a multiple of the 16-pixel DMA piece)
+constexpr int WS_ROW = 64;         // bytes per staged row: 32 bf16 channels
+constexpr int WS_XBYTES = 3 * 2 * WS_XPX * WS_ROW;     // [part][half][pixel][32 ch]
+constexpr int WS_ZBYTES = 3 * 2 * WS_PW * WS_ROW;
+constexpr int WS_BUF = WS_XBYTES + WS_ZBYTES;
+
+template <int OFF>
+__device__ __forceinline__ u32x2 tr_read_imm(unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF) : "memory");
+  return v;
+}
+
+__device__ __forceinline__ bf16x8 pack_op(u32x2 lo, u32x2 hi) {
+  u32x4 r = {lo.x, lo.y, hi.x, hi.y};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+// the KS shifted activation operands of one (k16 step S, part PA): 2 transpose reads each
+template <int KS, int S, int PA, int KX>
+__device__ __forceinline__ void load_taps(unsigned abase, u32x2 (&lo)[KS], u32x2 (&hi)[KS]) {
+  if constexpr (KX < KS) {
+    constexpr int off = (PA * 2 * WS_XPX + 16 * S + KX) * WS_ROW;      // + 8*kh rows in the lane address
+    lo[KX] = tr_read_imm<off>(abase);
+    hi[KX] = tr_read_imm<off + 4 * WS_ROW>(abase);
+    load_taps<KS, S, PA, KX + 1>(abase, lo, hi);
+  }
+}
+// all MFMAs of one (S, PA): KS taps x the gradient parts q <= 2 - PA
+template <int KS, int S, int PA>
+__device__ __forceinline__ void taps(unsigned abase, const bf16x8 (&bz)[3], f32x16 (&acc)[KS]) {
+  u32x2 lo[KS], hi[KS];
+  load_taps<KS, S, PA, 0>(abase, lo, hi);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);       // the MFMAs below must not be hoisted above the wait (the compiler cannot see the reads)
+#pragma unroll
+  for (int kx = 0; kx < KS; ++kx) {
+    const bf16x8 a = pack_op(lo[kx], hi[kx]);
+#pragma unroll
+    for (int q = 0; q <= 2 - PA; ++q) acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bz[q], acc[kx], 0, 0, 0);
+  }
+}
+
+template <int KS, int S>
+__device__ __forceinline__ void k16_step(unsigned abase, unsigned zbase, f32x16 (&acc)[KS]) {
+  bf16x8 bz[3];
+  {
+    constexpr int o0 = (0 * 2 * WS_PW + 16 * S) * WS_ROW, o1 = (1 * 2 * WS_PW + 16 * S) * WS_ROW, o2 = (2 * 2 * WS_PW + 16 * S) * WS_ROW;
+    const u32x2 a0 = tr_read_imm<o0>(zbase), a1 = tr_read_imm<o0 + 4 * WS_ROW>(zbase);
+    const u32x2 b0 = tr_read_imm<o1>(zbase), b1 = tr_read_imm<o1 + 4 * WS_ROW>(zbase);
+    const u32x2 c0 = tr_read_imm<o2>(zbase), c1 = tr_read_imm<o2 + 4 * WS_ROW>(zbase);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    bz[0] = pack_op(a0, a1); bz[1] = pack_op(b0, b1); bz[2] = pack_op(c0, c1);
+  }
+  taps<KS, S, 2>(abase, bz, acc);      // smallest products first
+  taps<KS, S, 1>(abase, bz, acc);
+  taps<KS, S, 0>(abase, bz, acc);
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const __bf16* __restrict__ xp, const __bf16* __restrict__ zp,
+                                                              float* __restrict__ partial, int B, int H, int W, int Cin, int Cout, int ldz,
+                                                              int n_ci, int n_co, int splits, long xpart, long zpart) {
+  constexpr int PAD = (KS - 1) / 2;
+  static_assert(WS_PW + KS - 1 <= WS_XPX, "halo fits the staged rows");
+  extern __shared__ __attribute__((aligned(16))) char smem[];     // two strip buffers
+
+  int bid = blockIdx.x;
+  const int ky = bid % KS; bid /= KS;
+  const int cit = bid % n_ci; bid /= n_ci;
+  const int cot = bid % n_co; bid /= n_co;
+  const int split = bid;
+  const int ci0 = cit * 64, co0 = cot * 64;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wid >> 1, wo = wid & 1;
+
+  const int nseg = (W + WS_PW - 1) / WS_PW;
+  const int ylo = ky < PAD ? PAD - ky : 0;
+  const int nvalid = H - (ky < PAD ? PAD - ky : ky - PAD);
+  const long rows = nvalid > 0 ? (long)B * nvalid : 0;
+  const long r0 = rows * split / splits, r1 = rows * (split + 1) / splits;
+  const long nstrip = (r1 - r0) * nseg;
+
+  f32x16 acc[KS];
+#pragma unroll
+  for (int t = 0; t < KS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  // ---- staging: 30 LDS-DMA pieces of 1 KB per strip (16 pixels x 64 B), dealt round-robin to the 4 waves.
+  // A row of the image is one buffer descriptor, so pixels left / right of it read as zeros (SAME padding).
+  const int dpix = lane >> 2, dchunk = lane & 3;
+  auto stage = [&](long s, int bufsel) {
+    const long row = r0 + s / nseg;
+    const int seg = (int)(s % nseg);
+    const int b = (int)(row / nvalid), y = ylo + (int)(row % nvalid);
+    const int yi = y + ky - PAD;
+    const int px0 = seg * WS_PW;
+    char* base = smem + bufsel * WS_BUF;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int d = wid + 4 * i;                        // wave-uniform piece index
+      if (d < 18) {                                     // X: [part][half][3 groups of 16 pixels]
+        const int grp = d % 3, half = (d / 3) % 2, part = d / 6;
+        const __bf16* rowp = xp + part * xpart + ((size_t)b * H + yi) * W * Cin;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(rowp), 0, W * Cin * 2, 0x00020000);
+        const int pix = px0 - PAD + 16 * grp + dpix;
+        const unsigned voff = (unsigned)((pix * Cin + ci0 + 32 * half) * 2 + dchunk * 16);
+        char* dst = base + ((part * 2 + half) * WS_XPX + 16 * grp) * WS_ROW;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, 0);
+      } else if (d < 30) {                              // dZ: [part][half][2 groups of 16 pixels]
+        const int e = d - 18;
+        const int grp = e % 2, half = (e / 2) % 2, part = e / 4;
+        const __bf16* rowp = zp + part * zpart + ((size_t)b * H + y) * W * ldz;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(rowp), 0, W * ldz * 2, 0x00020000);
+        const int pix = px0 + 16 * grp + dpix;
+        const unsigned voff = (unsigned)((pix * ldz + co0 + 32 * half) * 2 + dchunk * 16);
+        char* dst = base + WS_XBYTES + ((part * 2 + half) * WS_PW + 16 * grp) * WS_ROW;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- per-lane read addresses: group g = lane>>4 -> (column block g&1, k half g>>1); lane t of the group supplies the
+  // piece (row t/4, columns 4(t%4)..+3) of the 4 x 16 block
+  const int g = lane >> 4, t = lane & 15;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned lane_off = (unsigned)((8 * (g >> 1) + (t >> 2)) * WS_ROW + (16 * (g & 1) + 4 * (t & 3)) * 2);
+  const unsigned a_lane = lds0 + (unsigned)(wi * WS_XPX * WS_ROW) + lane_off;
+  const unsigned z_lane = lds0 + (unsigned)(WS_XBYTES + wo * WS_PW * WS_ROW) + lane_off;
+
+  if (nstrip > 0) stage(0, 0);
+  int buf = 0;
+  for (long s = 0; s < nstrip; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of strip s have landed
+    __syncthreads();                                        // ... and everyone's; every wave is past its reads of the other buffer
+    if (s + 1 < nstrip) stage(s + 1, buf ^ 1);              // in flight behind this strip's MFMAs
+    const unsigned ab = a_lane + (unsigned)(buf * WS_BUF), zb = z_lane + (unsigned)(buf * WS_BUF);
+    k16_step<KS, 0>(ab, zb, acc);
+    k16_step<KS, 1>(ab, zb, acc);
+    buf ^= 1;
+  }
+
+  // ---- partial tile store: D col = lane&31 -> co, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -> ci
+  float* out = partial + (size_t)split * KS * KS * Cin * Cout;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int co = co0 + wo * 32 + l31;
+  if (co < Cout) {
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ci = ci0 + wi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (ci < Cin) out[(((size_t)ky * KS + kx) * Cin + ci) * Cout + co] = acc[kx][i];
+      }
+    }
+  }
+}
+
+// out[p][i] = part p of x[i]  (p = 0 high .. 2 low; x = out[0] + out[1] + out[2] exactly)
+__global__ void split_parts_kernel(const float* __restrict__ x, __bf16* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    const __bf16 b0 = static_cast<__bf16>(v);
+    const float r1 = v - static_cast<float>(b0);
+    const __bf16 b1 = static_cast<__bf16>(r1);
+    out[i] = b0;
+    out[n + i] = b1;
+    out[2 * n + i] = static_cast<__bf16>(r1 - static_cast<float>(b1));
+  }
+}
+
+}  // namespace
+
+hipError_t split_parts(const float* x, void* out, size_t n, hipStream_t st) {
+  size_t g = (n + 255) / 256;
+  hipLaunchKernelGGL(split_parts_kernel, dim3((int)(g > 65536 ? 65536 : g)), dim3(256), 0, st, x, static_cast<__bf16*>(out), n);
+  return hipGetLastError();
+}
+
+bool wgrad_split_supported(int ks, int Cin, int ldz) { return (ks == 9 || ks == 5) && Cin % 8 == 0 && ldz % 8 == 0; }
+
+// xp / zp: split_parts images of x [B,H,W,Cin] and dz [B,H,W,ldz]; partial as wgrad_f32
+hipError_t wgrad_split(const void* xp, const void* zp, float* partial, int splits, int ks, int B, int H, int W, int Cin, int Cout, int ldz,
+                       hipStream_t st) {
+  if (!wgrad_split_supported(ks, Cin, ldz)) return hipErrorInvalidValue;
+  const int n_ci = (Cin + 63) / 64, n_co = (Cout + 63) / 64;
+  const int blocks = ks * n_ci * n_co * splits;
+  const long xpart = (long)B * H * W * Cin, zpart = (long)B * H * W * ldz;
+  const int lds = 2 * WS_BUF;
+  if (ks == 9)
+    hipLaunchKernelGGL(wgrad_split_kernel<9>, dim3(blocks), dim3(256), lds, st, static_cast<const __bf16*>(xp), static_cast<const __bf16*>(zp),
+                       partial, B, H, W, Cin, Cout, ldz, n_ci, n_co, splits, xpart, zpart);
+  else
+    hipLaunchKernelGGL(wgrad_split_kernel<5>, dim3(blocks), dim3(256), lds, st, static_cast<const __bf16*>(xp), static_cast<const __bf16*>(zp),
+                       partial, B, H, W, Cin, Cout, ldz, n_ci, n_co, splits, xpart, zpart);
+  return hipGetLastError();
+}
+
+}  // namespace jcm

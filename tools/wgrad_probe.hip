@@ -1,5 +1,6 @@
 // Stand-alone check of wgrad_conv1 / wgrad_f32 against a CPU loop (debugging aid).
 #include "../joint-cnn-mrf_amd/csrc/wgrad.hip"
+#include "../joint-cnn-mrf_amd/csrc/wgrad_split.hip"
 #include <cstdio>
 #include <vector>
 #include <cstdlib>
@@ -64,6 +65,20 @@ int main() {
     double me = 0, mx = 0;
     for (size_t i = 0; i < n; ++i) { me = fmax(me, fabs(got[i] - ref[i])); mx = fmax(mx, fabs(ref[i])); }
     printf("wgrad ks %d splits %d (%s): max err %.3e (max |ref| %.3e)\n", ks, splits, hipGetErrorString(e), me, mx);
+    // the same through the bf16x6 split kernel
+    void *xp, *zp;
+    hipMalloc(&xp, x.size() * 6); hipMalloc(&zp, dz.size() * 6);
+    split_parts(dx, xp, x.size(), 0); split_parts(dd, zp, dz.size(), 0);
+    hipMemset(dp, 0xff, n * splits * 4);
+    e = wgrad_split(xp, zp, dp, splits, ks, B2, H, W, Cin, Cout, ldz, 0);
+    wgrad_reduce(dp, splits, n, w, 0.f, dw, 0);
+    hipError_t e2 = hipDeviceSynchronize();
+    hipMemcpy(got.data(), dw, n * 4, hipMemcpyDeviceToHost);
+    me = 0;
+    size_t worst = 0;
+    for (size_t i = 0; i < n; ++i) { double er = fabs(got[i] - ref[i]); if (!(er <= me)) { me = er; worst = i; } }
+    printf("wgrad_split ks %d (%s / %s): max err %.3e at tap %zu ci %zu co %zu (got %.5f ref %.5f)\n", ks, hipGetErrorString(e), hipGetErrorString(e2), me,
+           worst / (Cin * Cout), (worst / Cout) % Cin, worst % Cout, got[worst], ref[worst]);
   }
   return 0;
 }
