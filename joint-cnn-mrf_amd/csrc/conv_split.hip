@@ -356,9 +356,23 @@ bool flat_fits(int ks, int H, int W) {
 // channel tile the kernel will use for a layer (its packed CoutP must be a multiple of it)
 int conv_split_bn(int Cout) { return Cout % 256 == 0 ? 256 : 128; }
 
-bool conv_split_supported(int ks, int Cin, int CoutP, int H, int W) {
+namespace {
+// pixel tiles of one launch (12x32 patches, or whole-row tiles on the narrow maps)
+int split_tiles(int B, int H, int W) {
+  if (W >= 64 && H % 12 == 0) return B * (H / 12) * ((W + 31) / 32);
+  int R = 384 / W;
+  if (R > H) R = H;
+  return B * ((H + R - 1) / R);
+}
+// 256-channel tiles unless that leaves most of the 256 CUs without a workgroup (small maps at small batch)
+int split_bn(int CoutP, int tiles) { return (CoutP % 256 == 0 && tiles * (CoutP / 256) >= 256) ? 256 : 128; }
+}  // namespace
+
+bool conv_split_supported(int ks, int Cin, int CoutP, int B, int H, int W) {
   if (!(ks == 9 || ks == 5) || Cin % 16 || CoutP % 128) return false;
-  return (W >= 64 && H % 12 == 0) || flat_fits(ks, H, W);
+  if (!((W >= 64 && H % 12 == 0) || flat_fits(ks, H, W))) return false;
+  const int tiles = split_tiles(B, H, W);
+  return tiles * (CoutP / split_bn(CoutP, tiles)) >= 128;      // below half a chip of 384-pixel tiles the 128-pixel exact kernel wins
 }
 
 size_t conv_split_weight_bytes(int ks, int Cin, int CoutP) { return (size_t)ks * ks * Cin * CoutP * 2 * 3; }
@@ -370,9 +384,9 @@ hipError_t pack_weights_split(const float* w_hwio, void* wp, int ks, int Cin, in
 
 // a.x fp32 NHWC, a.wp from pack_weights_split (CoutP a multiple of 128), a.out fp32
 hipError_t conv_split_f32(const ConvArgs& a, int ks, hipStream_t st) {
-  if (!conv_split_supported(ks, a.Cin, a.CoutP, a.H, a.W)) return hipErrorInvalidValue;
+  if (!conv_split_supported(ks, a.Cin, a.CoutP, a.B, a.H, a.W)) return hipErrorInvalidValue;
   const bool wide = a.W >= 64 && a.H % 12 == 0;
-  const bool big = a.CoutP % 256 == 0;
+  const bool big = split_bn(a.CoutP, split_tiles(a.B, a.H, a.W)) == 256;
   if (ks == 9) {
     if (big) return wide ? launch_s<CfgS<9, 256, false>>(a, st) : launch_s<CfgS<9, 256, true>>(a, st);
     return wide ? launch_s<CfgS<9, 128, false>>(a, st) : launch_s<CfgS<9, 128, true>>(a, st);

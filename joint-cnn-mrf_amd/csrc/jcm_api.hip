@@ -104,7 +104,7 @@ int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int
     a.CoutP = L->coutp;
     if (L->thin) {
       HIP_TRY(conv_thin_f32(a, c->stream));
-    } else if (L->wp_split && conv_split_supported(L->ks, L->cin, L->coutp_split, H, W)) {
+    } else if (L->wp_split && conv_split_supported(L->ks, L->cin, L->coutp_split, B, H, W)) {
       a.wp = L->wp_split;
       a.CoutP = L->coutp_split;
       HIP_TRY(conv_split_f32(a, L->ks, c->stream));

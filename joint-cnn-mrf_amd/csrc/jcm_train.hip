@@ -177,7 +177,7 @@ int conv_dgrad(jcm_ctx* c, const LayerFwd& f, const float* dz, int B, float* dx)
   ConvArgs a;
   a.x = dz; a.wp = d.wd; a.bias = t->zeros; a.scale = t->ones; a.shift = t->zeros; a.out = dx;
   a.B = B; a.H = f.H; a.W = f.W; a.Cin = d.cinp; a.Cout = f.L->cin; a.CoutP = d.coutp; a.relu_bn = 0;
-  const bool split = d.wd_split && conv_split_supported(f.L->ks, d.cinp, f.L->cin, f.H, f.W);
+  const bool split = d.wd_split && conv_split_supported(f.L->ks, d.cinp, f.L->cin, B, f.H, f.W);
   if (split) { a.wp = d.wd_split; a.CoutP = f.L->cin; }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->profile) {
