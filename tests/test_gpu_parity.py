@@ -206,3 +206,27 @@ def test_missing_parameters_fail_loudly():
     del sm['energy_nose_torso']
     with pytest.raises(RuntimeError, match='energy_nose_torso'):
         Engine(device=0).load_params(sm)
+
+
+def test_split_convs_debug_width_and_odd_shapes():
+    """f32_conv='split' (conv_split.hip) on the shapes the other tests use: at --debug width the 128-channel
+    layers take the 128-channel tiles, 30x45 / 15x23 maps the whole-row tiles, small grids fall back to the exact
+    kernel -- same tolerances as the exact path, including a non-480x720 input and batch 1."""
+    from joint_cnn_mrf_amd.engine import Engine
+    p = synth.make_pd_params(debug=True, bn='trained', conv6_gain=8.0)
+    p.update(synth.make_sm_params(synth.synthetic_priors(), kind='trained'))
+    eng = Engine(device=0, f32_conv='split').load_params(p)
+    x, torso = synth.make_images(4, seed=31), synth.make_torso(4, seed=32)
+    ref = O.forward(x, torso, p)
+    r = eng.forward(dev(x), dev(torso), use_sm=True)
+    for k in ('pd_prob', 'sm_prob'):
+        np.testing.assert_allclose(r[k].cpu().numpy(), ref[k], atol=HM_TOL, rtol=0)
+    for k in ('pd_coords', 'sm_coords'):
+        np.testing.assert_array_equal(r[k].cpu().numpy(), ref[k])
+    x2 = synth.make_images(3, seed=41, height=240, width=368)
+    ref2 = O.model(x2, p)
+    got2 = eng.model(dev(x2)).cpu().numpy()
+    np.testing.assert_allclose(got2, ref2, atol=logit_tol(ref2), rtol=0)
+    one = eng.model(dev(x2[:1])).cpu().numpy()
+    np.testing.assert_allclose(one, got2[:1], atol=logit_tol(ref2), rtol=0)   # a different batch may pick a different kernel
+    eng.close()
