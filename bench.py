@@ -145,7 +145,8 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm):
     """`--train`: time the joint training step (loss + gradients, gradient all-reduce, clip + Adam, table
     refresh) on B images per GPU; data-parallel, one RCCL all-reduce of the flat gradient buffer per step."""
     from joint_cnn_mrf_amd.train import Trainer
-    eng = Engine(device=local_rank, precision='fp32', f32_conv=args.f32_conv).load_params(params)
+    prec = args.dtype or 'fp32'
+    eng = Engine(device=local_rank, precision=prec, f32_conv=args.f32_conv if prec == 'fp32' else None).load_params(params)
     tr = Trainer(eng, optimizer='adam', lr=0.001, lmbd=0.001, use_sm=use_sm)
     x = torch.as_tensor(synth.make_images(B, seed=1234 + rank), device=dev)
     y = torch.as_tensor(synth.make_targets(B, seed=4321 + rank), device=dev)
@@ -176,26 +177,28 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm):
         scale = 16 if args.debug else 1
         # dominant training kernels: the three conv5 passes, each 229.3 GFLOP per image (60x90 px, 81 taps, 512x512)
         kern = {}
-        sp = args.f32_conv == 'split'
+        sp = args.f32_conv == 'split' and prec == 'fp32'
         for key, what in (('conv5', 'forward, ' + ('conv_split_kernel' if sp else 'conv_igemm_f32')),
                           ('dgrad:conv5', 'data gradient, ' + ('conv_split_kernel' if sp else 'conv_igemm_f32') + ' on flipped weights'),
                           ('wgrad:conv5', 'weight gradient, ' + ('wgrad_split_kernel<9>' if sp else 'wgrad_kernel<9>'))):
             ms, n = eng.profile_read(key)
             if n:
                 tf = FLOPS_DOMINANT['conv5'] / scale * B / (ms / n * 1e-3) / 1e12
-                kern[key] = {'kernel': what, 'launch_ms': ms / n, 'launches': n, 'achieved': tf, 'frac': tf / PEAK_TFLOPS['fp32']}
+                kern[key] = {'kernel': what, 'launch_ms': ms / n, 'launches': n, 'achieved': tf, 'frac': tf / PEAK_TFLOPS[prec]}
         out = {'metric': 'images/sec joint training step (fwd+bwd+update), part detector + spatial model', 'value': value,
                'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-               'config': {'workload': 'configs[4]: joint training, batch=%d/GPU synthetic 480x720x3, fp32 MFMA%s, Adam, clip 4.0%s'
-                                      % (B, ' operands; forward, data and weight gradients of the stride-1 layers as bf16x6 split MFMA' if args.f32_conv == 'split' else '',
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if prec == 'fp32' else 'bf16', 'data': 'synthetic',
+               'config': {'workload': 'configs[4]: joint training, batch=%d/GPU synthetic 480x720x3, %s%s, Adam, clip 4.0%s'
+                                      % (B, 'fp32 MFMA' if prec == 'fp32' else 'mixed precision: bf16 activations/gradients + bf16 MFMA, fp32 master weights / statistics / losses / spatial model / optimizer',
+                                         ' operands; forward, data and weight gradients of the stride-1 layers as bf16x6 split MFMA' if args.f32_conv == 'split' else '',
                                          ', DEBUG filters/4' if args.debug else ''),
                           'batch_per_gpu': B, 'global_batch': world * B, 'use_sm': use_sm,
                           'collective': 'all_reduce of %d fp32 gradients' % tr.n_elements},
-               'train_tflops': value * FLOPS_TRAIN / scale / 1e12, 'mfma_peak_tflops': PEAK_TFLOPS['fp32'],
-               'frac_of_fp32_mfma_peak': value * FLOPS_TRAIN / scale / 1e12 / PEAK_TFLOPS['fp32'],
-               'roofline': dict(bound='mfma', peak=PEAK_TFLOPS['fp32'], unit='TFLOP/s', traffic=None,
-                                **({'kernel': ('wgrad_split_kernel<9> on conv5 (3 bf16 parts per operand, 6 x bf16 MFMA 32x32x16 per k16 step; achieved = fp32-equivalent FLOPs)'
+               'train_tflops': value * FLOPS_TRAIN / scale / 1e12, 'mfma_peak_tflops': PEAK_TFLOPS[prec],
+               'frac_of_mfma_peak': value * FLOPS_TRAIN / scale / 1e12 / PEAK_TFLOPS[prec],
+               'roofline': dict(bound='mfma', peak=PEAK_TFLOPS[prec], unit='TFLOP/s', traffic=None,
+                                **({'kernel': ('wgrad_split_kernel<9,1> on conv5 (bf16 operands, LDS transpose reads)' if prec == 'bf16' else
+                                               'wgrad_split_kernel<9> on conv5 (3 bf16 parts per operand, 6 x bf16 MFMA 32x32x16 per k16 step; achieved = fp32-equivalent FLOPs)'
                                                if args.f32_conv == 'split' else 'wgrad_kernel<9> on conv5 (fp32 MFMA 32x32x2, 64x64 channel tile x 9 taps)'),
                                     'achieved': kern['wgrad:conv5']['achieved'], 'frac': kern['wgrad:conv5']['frac'],
                                     'launch_ms': kern['wgrad:conv5']['launch_ms']} if 'wgrad:conv5' in kern else {})),

@@ -20,6 +20,8 @@ struct BnSave {
 struct DgradW {
   float* wd = nullptr;     // packed flipped/transposed weights for conv_igemm_f32
   void* wd_split = nullptr;  // the same in three bf16 parts for conv_split_f32 (handles with f32_conv = 1)
+  void* wd_bf16 = nullptr;   // bf16 handles: packed for conv_igemm_bf16
+  int cinp_bf16 = 0, coutp_bf16 = 0;
   int cinp = 0;            // dZ channel stride the kernel reads (= Cout rounded up to 16)
   int coutp = 0;           // packed N extent (= Cin rounded up to the kernel's N tile)
 };
@@ -68,6 +70,11 @@ int repack_dgrad(jcm_ctx* c) {
   for (auto& kv : t->dgrad) {
     const ConvLayer* L = conv_of(c, kv.first);
     DgradW& d = kv.second;
+    if (d.wd_bf16) {
+      HIP_TRY(flip_transpose_weights(L->w_raw, t->scratch_flip, L->ks, L->cin, L->cout, d.cinp_bf16, c->stream));
+      HIP_TRY(pack_weights_bf16(t->scratch_flip, d.wd_bf16, L->ks, d.cinp_bf16, L->cin, d.coutp_bf16, c->stream));
+      continue;
+    }
     HIP_TRY(flip_transpose_weights(L->w_raw, t->scratch_flip, L->ks, L->cin, L->cout, d.cinp, c->stream));
     HIP_TRY(pack_weights_f32(t->scratch_flip, d.wd, L->ks, d.cinp, L->cin, d.coutp, c->stream));
     if (d.wd_split) HIP_TRY(pack_weights_split(t->scratch_flip, d.wd_split, L->ks, d.cinp, L->cin, L->cin, c->stream));
@@ -80,17 +87,22 @@ float* grad_of(TrainState* t, float* grads, const std::string& name) {
   return it == t->index.end() ? nullptr : grads + t->slots[it->second].off;
 }
 
+// Activations and their gradients are fp32, or bf16 on a bf16 handle (mixed precision: fp32 master weights,
+// statistics, losses, spatial model and optimizer; bf16 tensors between the layers, bf16 MFMA with fp32 accumulate).
+inline bool bf(const jcm_ctx* c) { return c->precision == JCM_PRECISION_BF16; }
+inline void* act(jcm_ctx* c, size_t elems) { return arena_alloc<char>(c, elems * (bf(c) ? 2 : 4)); }
+
 // ---- one conv layer in training mode: r = relu(conv + b) [or conv + b], batch stats, y = BN(r)
 struct LayerFwd {
   std::string scope;
   const ConvLayer* L = nullptr;
-  const float* in = nullptr;   // input activation (stride-1 layers) or the image (conv1)
+  const void* in = nullptr;    // input activation (stride-1 layers) or the fp32 image (conv1)
   int H = 0, W = 0;            // output map
-  float* r = nullptr;
-  float* y = nullptr;
+  void* r = nullptr;
+  void* y = nullptr;
 };
 
-int conv_train_fwd(jcm_ctx* c, LayerFwd& f, int stride, const float* x, int B, int Hin, int Win, int sub) {
+int conv_train_fwd(jcm_ctx* c, LayerFwd& f, int stride, const void* x, int B, int Hin, int Win, int sub) {
   TrainState* t = c->train;
   f.L = conv_of(c, f.scope);
   if (!f.L) return fail(JCM_ERR_STATE, "no conv layer '" + f.scope + "'");
@@ -98,43 +110,43 @@ int conv_train_fwd(jcm_ctx* c, LayerFwd& f, int stride, const float* x, int B, i
   f.H = stride == 2 ? cdiv2(Hin / sub) : Hin;
   f.W = stride == 2 ? cdiv2(Win / sub) : Win;
   const size_t N = (size_t)B * f.H * f.W;
-  f.r = arena_alloc<float>(c, N * f.L->cout);
+  f.r = f.L->has_bn ? act(c, N * f.L->cout) : static_cast<void*>(arena_alloc<float>(c, N * f.L->cout));   // the logits stay fp32
   ConvLayer L = *f.L;
   L.scale = t->ones;       // epilogue = relu(z + b) * 1 + 0
   L.shift = t->zeros;
-  JCM_TRY(run_conv_layer(c, &L, f.scope, stride, x, B, Hin, Win, sub, f.r, false, false));
+  JCM_TRY(run_conv_layer(c, &L, f.scope, stride, x, B, Hin, Win, sub, f.r, bf(c), !f.L->has_bn));
   if (!f.L->has_bn) { f.y = f.r; return JCM_OK; }
-  f.y = arena_alloc<float>(c, N * f.L->cout);
+  f.y = act(c, N * f.L->cout);
   if (c->dry) return JCM_OK;
   BnSave& s = t->bn[f.scope];
   Tensor& mm = c->params[f.scope + "/BatchNorm/moving_mean"];
   Tensor& mv = c->params[f.scope + "/BatchNorm/moving_variance"];
-  HIP_TRY(bn_batch_stats(f.r, N, f.L->cout, kBnEps, 0.9f, s.mean, s.rstd, mm.d, mv.d, t->red, c->stream));   // main.py:129,557
-  HIP_TRY(bn_apply(f.r, s.mean, s.rstd, find(c, f.scope + "/BatchNorm/gamma")->d, find(c, f.scope + "/BatchNorm/beta")->d, f.y, N,
+  HIP_TRY(bn_batch_stats(f.r, bf(c), N, f.L->cout, kBnEps, 0.9f, s.mean, s.rstd, mm.d, mv.d, t->red, c->stream));   // main.py:129,557
+  HIP_TRY(bn_apply(f.r, s.mean, s.rstd, find(c, f.scope + "/BatchNorm/gamma")->d, find(c, f.scope + "/BatchNorm/beta")->d, f.y, bf(c), N,
                    f.L->cout, c->stream));
   return JCM_OK;
 }
 
 // ---- backward of one BN(relu(conv+b)) layer given dy (scaled by dy_scale): fills the parameter
 // gradients, returns dz (arena) for the caller to push through wgrad / dgrad
-int conv_train_bwd_pre(jcm_ctx* c, const LayerFwd& f, const float* dy, float dy_scale, int B, float* grads, float** dz_out) {
+int conv_train_bwd_pre(jcm_ctx* c, const LayerFwd& f, const void* dy, float dy_scale, int B, float* grads, void** dz_out) {
   TrainState* t = c->train;
   const size_t N = (size_t)B * f.H * f.W;
   const int C = f.L->cout;
-  float* dz = arena_alloc<float>(c, N * C);
+  void* dz = act(c, N * C);
   *dz_out = dz;
   if (c->dry) return JCM_OK;
   const BnSave& s = t->bn[f.scope];
   float* sums = t->small;   // [2C] <= 1024 floats
-  HIP_TRY(bn_bwd_reduce(dy, dy_scale, f.r, s.mean, s.rstd, N, C, sums, grad_of(t, grads, f.scope + "/BatchNorm/gamma"),
+  HIP_TRY(bn_bwd_reduce(dy, dy_scale, f.r, bf(c), s.mean, s.rstd, N, C, sums, grad_of(t, grads, f.scope + "/BatchNorm/gamma"),
                         grad_of(t, grads, f.scope + "/BatchNorm/beta"), t->red, c->stream));
-  HIP_TRY(bn_bwd_apply(dy, dy_scale, f.r, s.mean, s.rstd, find(c, f.scope + "/BatchNorm/gamma")->d, sums, N, C, 1, dz, c->stream));
-  HIP_TRY(col_sum(dz, N, C, grad_of(t, grads, f.scope + "/biases"), t->red, c->stream));
+  HIP_TRY(bn_bwd_apply(dy, dy_scale, f.r, bf(c), s.mean, s.rstd, find(c, f.scope + "/BatchNorm/gamma")->d, sums, N, C, 1, dz, c->stream));
+  HIP_TRY(col_sum(dz, bf(c), N, C, grad_of(t, grads, f.scope + "/biases"), t->red, c->stream));
   return JCM_OK;
 }
 
 // dW (+ lmbd*W) of a stride-1 layer: x = layer input [B,H,W,Cin], dz [B,H,W,ldz]
-int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const float* dz, int ldz, int B, float lmbd, float* grads) {
+int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int ldz, int B, float lmbd, float* grads) {
   TrainState* t = c->train;
   const ConvLayer* L = f.L;
   const size_t n = (size_t)L->ks * L->ks * L->cin * L->cout;
@@ -142,14 +154,15 @@ int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const float* dz, int ldz, int B, f
   const size_t mark = c->arena_off;
   float* partial = arena_alloc<float>(c, n * splits);
   // handles with f32_conv = 1: the bf16x6 split kernel on pre-split operands (wgrad_split.hip)
-  const bool split = c->f32_conv == 1 && wgrad_split_supported(L->ks, L->cin, ldz);
+  const bool split = !bf(c) && c->f32_conv == 1 && wgrad_split_supported(L->ks, L->cin, ldz);
+  if (bf(c) && !wgrad_split_supported(L->ks, L->cin, ldz)) return fail(JCM_ERR_ARG, "no bf16 weight-gradient kernel for layer '" + f.scope + "'");
   const size_t nx = (size_t)B * f.H * f.W * L->cin, nz = (size_t)B * f.H * f.W * ldz;
   char* xparts = split ? arena_alloc<char>(c, nx * 6) : nullptr;
   char* zparts = split ? arena_alloc<char>(c, nz * 6) : nullptr;
   if (!c->dry) {
     if (split) {
-      HIP_TRY(split_parts(f.in, xparts, nx, c->stream));
-      HIP_TRY(split_parts(dz, zparts, nz, c->stream));
+      HIP_TRY(split_parts(static_cast<const float*>(f.in), xparts, nx, c->stream));
+      HIP_TRY(split_parts(static_cast<const float*>(dz), zparts, nz, c->stream));
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profile) {
@@ -157,8 +170,9 @@ int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const float* dz, int ldz, int B, f
       HIP_TRY(hipEventCreate(&e1));
       HIP_TRY(hipEventRecord(e0, c->stream));
     }
-    if (split) HIP_TRY(wgrad_split(xparts, zparts, partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream));
-    else HIP_TRY(wgrad_f32(f.in, dz, partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream));
+    if (bf(c)) HIP_TRY(wgrad_bf16(f.in, dz, partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream));
+    else if (split) HIP_TRY(wgrad_split(xparts, zparts, partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream));
+    else HIP_TRY(wgrad_f32(static_cast<const float*>(f.in), static_cast<const float*>(dz), partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream));
     if (c->profile) {
       HIP_TRY(hipEventRecord(e1, c->stream));
       c->prof["wgrad:" + f.scope].emplace_back(e0, e1);      // read with jcm_profile_read("wgrad:<scope>")
@@ -170,11 +184,17 @@ int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const float* dz, int ldz, int B, f
 }
 
 // dX = conv_SAME(dZ, flipped weights): [B,H,W,ldz] -> [B,H,W,Cin]
-int conv_dgrad(jcm_ctx* c, const LayerFwd& f, const float* dz, int B, float* dx) {
+int conv_dgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int B, void* dx) {
   if (c->dry) return JCM_OK;
   TrainState* t = c->train;
   const DgradW& d = t->dgrad[f.scope];
   ConvArgs a;
+  if (bf(c)) {      // bf16 gradients through the bf16 forward kernels on flipped weights
+    a.x = dz; a.wp = d.wd_bf16; a.bias = t->zeros; a.scale = t->ones; a.shift = t->zeros; a.out = dx;
+    a.B = B; a.H = f.H; a.W = f.W; a.Cin = d.cinp_bf16; a.Cout = f.L->cin; a.CoutP = d.coutp_bf16; a.relu_bn = 0;
+    HIP_TRY(conv_igemm_bf16(a, f.L->ks, false, c->stream));
+    return JCM_OK;
+  }
   a.x = dz; a.wp = d.wd; a.bias = t->zeros; a.scale = t->ones; a.shift = t->zeros; a.out = dx;
   a.B = B; a.H = f.H; a.W = f.W; a.Cin = d.cinp; a.Cout = f.L->cin; a.CoutP = d.coutp; a.relu_bn = 0;
   const bool split = d.wd_split && conv_split_supported(f.L->ks, d.cinp, f.L->cin, B, f.H, f.W);
@@ -215,7 +235,8 @@ int loss_grads_impl(jcm_ctx* c, const float* x, const float* y, int B, int H, in
   static const char* const kRes[3] = {"fullres", "halfres", "quarterres"};
   const int K = c->K;
   LayerFwd l1[3], l2[3], l3[3], l4[3], l5, l6;
-  float *p1[3], *p2[3];
+  void *p1[3], *p2[3];
+  const bool b16 = bf(c);
   for (int r = 0; r < 3; ++r) {
     const int sub = 1 << r;
     if (H % sub || W % sub) return fail(JCM_ERR_ARG, "training needs image sizes divisible by 4");
@@ -224,26 +245,26 @@ int loss_grads_impl(jcm_ctx* c, const float* x, const float* y, int B, int H, in
     JCM_TRY(conv_train_fwd(c, l1[r], 2, x, B, H, W, sub));                                     // main.py:44,52,61
     const int C1 = l1[r].L->cout;
     const int h2 = cdiv2(l1[r].H), w2 = cdiv2(l1[r].W);
-    p1[r] = arena_alloc<float>(c, (size_t)B * h2 * w2 * C1);
-    if (!c->dry) HIP_TRY(max_pool_2x2(l1[r].y, p1[r], false, B, l1[r].H, l1[r].W, C1, c->stream));   // :45,53,62
+    p1[r] = act(c, (size_t)B * h2 * w2 * C1);
+    if (!c->dry) HIP_TRY(max_pool_2x2(l1[r].y, p1[r], b16, B, l1[r].H, l1[r].W, C1, c->stream));   // :45,53,62
     JCM_TRY(conv_train_fwd(c, l2[r], 1, p1[r], B, h2, w2, 1));                                  // :46,54,63
     const int C2 = l2[r].L->cout;
     const int h3 = cdiv2(h2), w3 = cdiv2(w2);
-    p2[r] = arena_alloc<float>(c, (size_t)B * h3 * w3 * C2);
-    if (!c->dry) HIP_TRY(max_pool_2x2(l2[r].y, p2[r], false, B, h2, w2, C2, c->stream));            // :47,55,64
+    p2[r] = act(c, (size_t)B * h3 * w3 * C2);
+    if (!c->dry) HIP_TRY(max_pool_2x2(l2[r].y, p2[r], b16, B, h2, w2, C2, c->stream));            // :47,55,64
     JCM_TRY(conv_train_fwd(c, l3[r], 1, p2[r], B, h3, w3, 1));                                  // :48,56,65
     JCM_TRY(conv_train_fwd(c, l4[r], 1, l3[r].y, B, h3, w3, 1));                                // :49,57,66
   }
   const int hh = l4[0].H, ww = l4[0].W, C4 = l4[0].L->cout;
   const size_t NP = (size_t)B * hh * ww;
-  float* merged = arena_alloc<float>(c, NP * C4);
+  void* merged = act(c, NP * C4);
   if (!c->dry)
-    HIP_TRY(upsample_merge3(l4[0].y, l4[1].y, l4[1].H, l4[1].W, l4[2].y, l4[2].H, l4[2].W, merged, false, B, hh, ww, C4, c->stream));  // :58,67,69-70
+    HIP_TRY(upsample_merge3(l4[0].y, l4[1].y, l4[1].H, l4[1].W, l4[2].y, l4[2].H, l4[2].W, merged, b16, B, hh, ww, C4, c->stream));  // :58,67,69-70
   l5.scope = "conv5"; l6.scope = "conv6";
   JCM_TRY(conv_train_fwd(c, l5, 1, merged, B, hh, ww, 1));                                      // :71
   JCM_TRY(conv_train_fwd(c, l6, 1, l5.y, B, hh, ww, 1));                                        // :72 (no ReLU / BN)
   if (l6.L && (l6.L->has_bn || l6.L->cout != K)) return fail(JCM_ERR_STATE, "conv6 must be the K-channel logits layer");
-  float* logits = l6.r;
+  float* logits = static_cast<float*>(l6.r);
 
   // ---- losses and the gradient w.r.t. the part-detector logits, kept with a 16-channel stride
   constexpr int LDZ = 16;
@@ -278,58 +299,62 @@ int loss_grads_impl(jcm_ctx* c, const float* x, const float* y, int B, int H, in
 
   // ---- backward of the part detector
   // conv6: z = conv(y5) + b
+  constexpr int LDZB = 32;                      // bf16 kernels read 32-channel chunks
+  void* dlogb = b16 ? act(c, NP * LDZB) : nullptr;
   if (!c->dry) {
-    HIP_TRY(col_sum(dlog, NP, LDZ, t->small, t->red, c->stream));
+    HIP_TRY(col_sum(dlog, false, NP, LDZ, t->small, t->red, c->stream));
     HIP_TRY(hipMemcpyAsync(grad_of(t, grads, "conv6/biases"), t->small, K * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    if (b16) HIP_TRY(cast_pad_bf16(dlog, LDZ, dlogb, LDZB, NP, c->stream));
   }
-  JCM_TRY(conv_wgrad(c, l6, dlog, LDZ, B, lmbd, grads));
-  float* dy5 = arena_alloc<float>(c, NP * l5.L->cout);
-  JCM_TRY(conv_dgrad(c, l6, dlog, B, dy5));
-  float* dz5;
+  const void* dl = b16 ? dlogb : static_cast<const void*>(dlog);
+  JCM_TRY(conv_wgrad(c, l6, dl, b16 ? LDZB : LDZ, B, lmbd, grads));
+  void* dy5 = act(c, NP * l5.L->cout);
+  JCM_TRY(conv_dgrad(c, l6, dl, B, dy5));
+  void* dz5;
   JCM_TRY(conv_train_bwd_pre(c, l5, dy5, 1.0f, B, grads, &dz5));
   JCM_TRY(conv_wgrad(c, l5, dz5, l5.L->cout, B, lmbd, grads));
-  float* dmerged = dy5;                         // dy5 is dead once dz5 exists; same size when C4 == C5
-  if (l5.L->cin != l5.L->cout) dmerged = arena_alloc<float>(c, NP * C4);
+  void* dmerged = dy5;                          // dy5 is dead once dz5 exists; same size when C4 == C5
+  if (l5.L->cin != l5.L->cout) dmerged = act(c, NP * C4);
   JCM_TRY(conv_dgrad(c, l5, dz5, B, dmerged));
   for (int r = 0; r < 3; ++r) {
     const size_t mark = c->arena_off;
     // merge: x = (x1 + up(x2) + up(x3)) / 3
-    const float* dy4 = dmerged;
+    const void* dy4 = dmerged;
     float sc = 1.0f / 3.0f;
     if (l4[r].H != hh || l4[r].W != ww) {
-      float* d = arena_alloc<float>(c, (size_t)B * l4[r].H * l4[r].W * C4);
-      if (!c->dry) HIP_TRY(resize_bilinear_bwd(dmerged, d, B, l4[r].H, l4[r].W, hh, ww, C4, 1.0f / 3.0f, c->stream));
+      void* d = act(c, (size_t)B * l4[r].H * l4[r].W * C4);
+      if (!c->dry) HIP_TRY(resize_bilinear_bwd(dmerged, d, b16, B, l4[r].H, l4[r].W, hh, ww, C4, 1.0f / 3.0f, c->stream));
       dy4 = d;
       sc = 1.0f;
     }
-    float *dz4, *dz3, *dz2, *dz1;
+    void *dz4, *dz3, *dz2, *dz1;
     JCM_TRY(conv_train_bwd_pre(c, l4[r], dy4, sc, B, grads, &dz4));
     JCM_TRY(conv_wgrad(c, l4[r], dz4, C4, B, lmbd, grads));
     const size_t n3 = (size_t)B * l3[r].H * l3[r].W;
-    float* dy3 = arena_alloc<float>(c, n3 * l3[r].L->cout);
+    void* dy3 = act(c, n3 * l3[r].L->cout);
     JCM_TRY(conv_dgrad(c, l4[r], dz4, B, dy3));
     JCM_TRY(conv_train_bwd_pre(c, l3[r], dy3, 1.0f, B, grads, &dz3));
     JCM_TRY(conv_wgrad(c, l3[r], dz3, l3[r].L->cout, B, lmbd, grads));
-    float* dp2 = arena_alloc<float>(c, n3 * l2[r].L->cout);
+    void* dp2 = act(c, n3 * l2[r].L->cout);
     JCM_TRY(conv_dgrad(c, l3[r], dz3, B, dp2));
     const size_t n2 = (size_t)B * l2[r].H * l2[r].W;
-    float* dy2 = arena_alloc<float>(c, n2 * l2[r].L->cout);
-    if (!c->dry) HIP_TRY(max_pool_bwd(l2[r].y, dp2, dy2, B, l2[r].H, l2[r].W, l2[r].L->cout, c->stream));
+    void* dy2 = act(c, n2 * l2[r].L->cout);
+    if (!c->dry) HIP_TRY(max_pool_bwd(l2[r].y, dp2, dy2, b16, B, l2[r].H, l2[r].W, l2[r].L->cout, c->stream));
     JCM_TRY(conv_train_bwd_pre(c, l2[r], dy2, 1.0f, B, grads, &dz2));
     JCM_TRY(conv_wgrad(c, l2[r], dz2, l2[r].L->cout, B, lmbd, grads));
-    float* dp1 = arena_alloc<float>(c, n2 * l1[r].L->cout);
+    void* dp1 = act(c, n2 * l1[r].L->cout);
     JCM_TRY(conv_dgrad(c, l2[r], dz2, B, dp1));
     const size_t n1 = (size_t)B * l1[r].H * l1[r].W;
     const int C1 = l1[r].L->cout;
-    float* dy1 = arena_alloc<float>(c, n1 * C1);
-    if (!c->dry) HIP_TRY(max_pool_bwd(l1[r].y, dp1, dy1, B, l1[r].H, l1[r].W, C1, c->stream));
+    void* dy1 = act(c, n1 * C1);
+    if (!c->dry) HIP_TRY(max_pool_bwd(l1[r].y, dp1, dy1, b16, B, l1[r].H, l1[r].W, C1, c->stream));
     JCM_TRY(conv_train_bwd_pre(c, l1[r], dy1, 1.0f, B, grads, &dz1));
     {
       const size_t n = (size_t)25 * 3 * C1;
       const int nb = wgrad_conv1_blocks();
       float* partial = arena_alloc<float>(c, n * nb);
       if (!c->dry) {
-        HIP_TRY(wgrad_conv1(x, dz1, partial, B, H, W, 1 << r, C1, c->stream));
+        HIP_TRY(wgrad_conv1(x, dz1, b16, partial, B, H, W, 1 << r, C1, c->stream));
         HIP_TRY(wgrad_reduce(partial, nb, n, l1[r].L->w_raw, lmbd, grad_of(t, grads, l1[r].scope + "/weights"), c->stream));
       }
     }
@@ -367,7 +392,7 @@ int sm_train_impl(jcm_ctx* c, const float* pd_prob, const float* y, int B, float
     float* rows_r = arena_alloc<float>(c, (size_t)Bc * P * kCH * kPrW);
     if (!c->dry) {
       HIP_TRY(sm_concat_target(pd_prob, y, hm10, N, K, kC, c->stream));                                        // main.py:528
-      HIP_TRY(bn_batch_stats(hm10, N, kC, kBnEps, 0.9f, bs->mean, bs->rstd, c->params["bn_sm/BatchNorm/moving_mean"].d,
+      HIP_TRY(bn_batch_stats(hm10, false, N, kC, kBnEps, 0.9f, bs->mean, bs->rstd, c->params["bn_sm/BatchNorm/moving_mean"].d,
                              c->params["bn_sm/BatchNorm/moving_variance"].d, t->red, c->stream));              // main.py:113
       HIP_TRY(bn_fold_stats(bs->mean, bs->rstd, find(c, "bn_sm/BatchNorm/gamma")->d, find(c, "bn_sm/BatchNorm/beta")->d, sc, sh, kC, c->stream));
       for (int b0 = 0; b0 < B; b0 += Bc) {
@@ -411,9 +436,9 @@ int sm_train_impl(jcm_ctx* c, const float* pd_prob, const float* y, int B, float
       FFT_TRY(sm_fft_c2r(c->fft, dA_hat, D, P));
       HIP_TRY(sm_bwd_params(D, dspb, t->e_ptr, t->b_ptr, t->e_off, t->b_off, grads, P, c->stream));
       float* sums = t->small;
-      HIP_TRY(bn_bwd_reduce(dh, 1.0f, hm10, bs->mean, bs->rstd, N, kC, sums, grad_of(t, grads, "bn_sm/BatchNorm/gamma"),
+      HIP_TRY(bn_bwd_reduce(dh, 1.0f, hm10, false, bs->mean, bs->rstd, N, kC, sums, grad_of(t, grads, "bn_sm/BatchNorm/gamma"),
                             grad_of(t, grads, "bn_sm/BatchNorm/beta"), t->red, c->stream));
-      HIP_TRY(bn_bwd_apply(dh, 1.0f, hm10, bs->mean, bs->rstd, find(c, "bn_sm/BatchNorm/gamma")->d, sums, N, kC, 0, dhm, c->stream));
+      HIP_TRY(bn_bwd_apply(dh, 1.0f, hm10, false, bs->mean, bs->rstd, find(c, "bn_sm/BatchNorm/gamma")->d, sums, N, kC, 0, dhm, c->stream));
       HIP_TRY(softmax_bwd(pd_prob, dhm, B, kHmHW, K, kC, dlog, 16, c->stream));                                // through main.py:523
     }
   }
@@ -434,7 +459,6 @@ extern "C" {
 int jcm_train_begin(jcm_handle h) {
   JCM_TRY(check(h, true));
   if (h->train) return fail(JCM_ERR_STATE, "jcm_train_begin was already called");
-  if (h->precision != JCM_PRECISION_F32) return fail(JCM_ERR_STATE, "the training step is fp32 (create the handle with precision f32)");
   DeviceGuard g(h->device);
   jcm_ctx* c = h;
   TrainState* t = new TrainState();
@@ -456,10 +480,18 @@ int jcm_train_begin(jcm_handle h) {
     d.cinp = (L.cout + 15) / 16 * 16;
     const int bn = conv_igemm_bn(L.cin);
     d.coutp = (L.cin + bn - 1) / bn * bn;
-    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&d.wd), (size_t)L.ks * L.ks * d.cinp * d.coutp * sizeof(float)));
-    if (c->f32_conv == 1 && L.cin % 128 == 0)      // data gradient on the bf16x6 split kernel where its tile fits
-      JCM_TRY(dev_alloc(c, &d.wd_split, conv_split_weight_bytes(L.ks, d.cinp, L.cin)));
-    const size_t nf = (size_t)L.ks * L.ks * d.cinp * L.cin;
+    if (c->precision == JCM_PRECISION_BF16) {
+      if (L.cin % 32) return fail(JCM_ERR_ARG, "bf16 training needs Cin % 32 == 0 ('" + kv.first + "')");
+      d.cinp_bf16 = (L.cout + 31) / 32 * 32;
+      const int bnb = conv_igemm_bf16_bn(L.cin, L.ks);
+      d.coutp_bf16 = (L.cin + bnb - 1) / bnb * bnb;
+      JCM_TRY(dev_alloc(c, &d.wd_bf16, (size_t)L.ks * L.ks * d.cinp_bf16 * d.coutp_bf16 * 2));
+    } else {
+      JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&d.wd), (size_t)L.ks * L.ks * d.cinp * d.coutp * sizeof(float)));
+      if (c->f32_conv == 1 && L.cin % 128 == 0)      // data gradient on the bf16x6 split kernel where its tile fits
+        JCM_TRY(dev_alloc(c, &d.wd_split, conv_split_weight_bytes(L.ks, d.cinp, L.cin)));
+    }
+    const size_t nf = (size_t)L.ks * L.ks * (d.cinp_bf16 > d.cinp ? d.cinp_bf16 : d.cinp) * L.cin;
     if (nf > max_w) max_w = nf;
     t->dgrad[kv.first] = d;
   }

@@ -118,19 +118,21 @@ hipError_t group_mean(const float* in, float* out, int n, int G, size_t M, hipSt
 // ---- train_kernels.hip : training-step kernels other than convolutions (fp32 NHWC) ------------------
 size_t train_reduce_scratch_doubles(int C);      // scratch the per-channel reductions below need
 // batch mean / 1/sqrt(biased var + eps) of x [N,C]; moving stats (may be null) updated with `decay`
-hipError_t bn_batch_stats(const float* x, size_t N, int C, float eps, float decay, float* mean, float* rstd, float* mov_mean,
+// `bf16`: the activation / gradient tensors are bf16 instead of fp32 (statistics and arithmetic stay fp32)
+hipError_t bn_batch_stats(const void* x, bool bf16, size_t N, int C, float eps, float decay, float* mean, float* rstd, float* mov_mean,
                           float* mov_var, double* scratch, hipStream_t st);
-hipError_t bn_apply(const float* r, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y, size_t N,
+hipError_t bn_apply(const void* r, const float* mean, const float* rstd, const float* gamma, const float* beta, void* y, bool bf16, size_t N,
                     int C, hipStream_t st);
 // sums [2][C] = (sum dy, sum dy*(r-mean)) with dy pre-scaled by dy_scale; dgamma / dbeta may be null
-hipError_t bn_bwd_reduce(const float* dy, float dy_scale, const float* r, const float* mean, const float* rstd, size_t N, int C,
+hipError_t bn_bwd_reduce(const void* dy, float dy_scale, const void* r, bool bf16, const float* mean, const float* rstd, size_t N, int C,
                          float* sums, float* dgamma, float* dbeta, double* scratch, hipStream_t st);
-hipError_t bn_bwd_apply(const float* dy, float dy_scale, const float* r, const float* mean, const float* rstd, const float* gamma,
-                        const float* sums, size_t N, int C, int relu, float* dz, hipStream_t st);
-hipError_t col_sum(const float* x, size_t N, int C, float* out, double* scratch, hipStream_t st);
-hipError_t max_pool_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, hipStream_t st);
+hipError_t bn_bwd_apply(const void* dy, float dy_scale, const void* r, bool bf16, const float* mean, const float* rstd, const float* gamma,
+                        const float* sums, size_t N, int C, int relu, void* dz, hipStream_t st);
+hipError_t col_sum(const void* x, bool bf16, size_t N, int C, float* out, double* scratch, hipStream_t st);
+hipError_t max_pool_bwd(const void* x, const void* dy, void* dx, bool bf16, int B, int H, int W, int C, hipStream_t st);
+hipError_t cast_pad_bf16(const float* in, int ldi, void* out, int ldo, size_t N, hipStream_t st);
 // dx [B,h,w,C] = scale * adjoint of the TF-1.x bilinear resize h x w -> H x W applied to dy [B,H,W,C]
-hipError_t resize_bilinear_bwd(const float* dy, float* dx, int B, int h, int w, int H, int W, int C, float scale, hipStream_t st);
+hipError_t resize_bilinear_bwd(const void* dy, void* dx, bool bf16, int B, int h, int w, int H, int W, int C, float scale, hipStream_t st);
 hipError_t softmax_ce(const float* logits, const float* target, int B, int HW, int K, int Kt, float gscale, float* loss, float* dz,
                       int ldz, int accumulate, hipStream_t st);
 hipError_t softmax_bwd(const float* p, const float* g, int B, int HW, int K, int ldg, float* dz, int ldz, hipStream_t st);
@@ -147,12 +149,15 @@ hipError_t wgrad_f32(const float* x, const float* dz, float* partial, int splits
                      hipStream_t st);
 hipError_t wgrad_reduce(const float* partial, int splits, size_t n, const float* w, float lmbd, float* dw, hipStream_t st);
 int wgrad_conv1_blocks(void);
-hipError_t wgrad_conv1(const float* x, const float* dz, float* partial, int B, int H0, int W0, int sub, int Cout, hipStream_t st);
+hipError_t wgrad_conv1(const float* x, const void* dz, bool dz_bf16, float* partial, int B, int H0, int W0, int sub, int Cout, hipStream_t st);
 // wgrad_split.hip: the same on the bf16 matrix cores (three-way operand split, six products, LDS transpose reads)
 hipError_t split_parts(const float* x, void* out_bf16_3n, size_t n, hipStream_t st);    // out[p*n + i] = part p of x[i]
 bool wgrad_split_supported(int ks, int Cin, int ldz);
 hipError_t wgrad_split(const void* xp, const void* zp, float* partial, int splits, int ks, int B, int H, int W, int Cin, int Cout, int ldz,
                        hipStream_t st);
+// bf16 activations / gradients as they are (bf16 training): same kernel with one operand part
+hipError_t wgrad_bf16(const void* x, const void* dz, float* partial, int splits, int ks, int B, int H, int W, int Cin, int Cout, int ldz,
+                      hipStream_t st);
 hipError_t flip_transpose_weights(const float* w_hwio, float* wd, int ks, int Cin, int Cout, int CoP, hipStream_t st);
 
 // ---- sm_train.hip : backward of the spatial model (frequency-domain correlations) -----------------------

@@ -16,31 +16,34 @@ namespace jcm {
 constexpr int RED_THREADS = 256;
 constexpr int RED_MAX_BLOCKS = 1024;
 
+template <class T>
 struct OpStats {              // sum x, sum x^2
   static constexpr int Q = 2;
-  const float* x;
+  const T* x;
   __device__ void operator()(size_t i, int, float* q) const {
-    const float v = x[i];
+    const float v = static_cast<float>(x[i]);
     q[0] += v;
     q[1] += v * v;
   }
 };
+template <class T>
 struct OpBnBwd {              // sum dy, sum dy * (r - mean)      (dy optionally pre-scaled)
   static constexpr int Q = 2;
-  const float* dy;
-  const float* r;
+  const T* dy;
+  const T* r;
   const float* mean;
   float dy_scale;
   __device__ void operator()(size_t i, int c, float* q) const {
-    const float g = dy[i] * dy_scale;
+    const float g = static_cast<float>(dy[i]) * dy_scale;
     q[0] += g;
-    q[1] += g * (r[i] - mean[c]);
+    q[1] += g * (static_cast<float>(r[i]) - mean[c]);
   }
 };
+template <class T>
 struct OpSum {                // sum x   (bias gradient of a conv: sum of dz)
   static constexpr int Q = 1;
-  const float* x;
-  __device__ void operator()(size_t i, int, float* q) const { q[0] += x[i]; }
+  const T* x;
+  __device__ void operator()(size_t i, int, float* q) const { q[0] += static_cast<float>(x[i]); }
 };
 
 template <class Op>
@@ -116,10 +119,11 @@ __global__ void bn_stats_finish_kernel(const double* __restrict__ partial, int b
   }
 }
 
-hipError_t bn_batch_stats(const float* x, size_t N, int C, float eps, float decay, float* mean, float* rstd, float* mov_mean,
+hipError_t bn_batch_stats(const void* x, bool bf16, size_t N, int C, float eps, float decay, float* mean, float* rstd, float* mov_mean,
                           float* mov_var, double* scratch, hipStream_t st) {
   int blocks = 0;
-  hipError_t e = col_reduce(OpStats{x}, N, C, scratch, &blocks, st);
+  hipError_t e = bf16 ? col_reduce(OpStats<__bf16>{static_cast<const __bf16*>(x)}, N, C, scratch, &blocks, st)
+                      : col_reduce(OpStats<float>{static_cast<const float*>(x)}, N, C, scratch, &blocks, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(C), dim3(64), 0, st, scratch, blocks, C, (double)N, eps, decay, mean,
                      rstd, mov_mean, mov_var);
@@ -127,18 +131,23 @@ hipError_t bn_batch_stats(const float* x, size_t N, int C, float eps, float deca
 }
 
 // y = (r - mean) * rstd * gamma + beta
-__global__ void bn_apply_kernel(const float* __restrict__ r, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y, size_t total, int C) {
+template <class T>
+__global__ void bn_apply_kernel(const T* __restrict__ r, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y, size_t total, int C) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = i % C;
-    y[i] = (r[i] - mean[c]) * (rstd[c] * gamma[c]) + beta[c];
+    y[i] = static_cast<T>((static_cast<float>(r[i]) - mean[c]) * (rstd[c] * gamma[c]) + beta[c]);
   }
 }
-hipError_t bn_apply(const float* r, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y, size_t N,
+hipError_t bn_apply(const void* r, const float* mean, const float* rstd, const float* gamma, const float* beta, void* y, bool bf16, size_t N,
                     int C, hipStream_t st) {
   const size_t total = N * C;
   size_t g = (total + 255) / 256;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3((int)(g > 65536 ? 65536 : g)), dim3(256), 0, st, r, mean, rstd, gamma, beta, y, total, C);
+  const dim3 grid((int)(g > 65536 ? 65536 : g));
+  if (bf16)
+    hipLaunchKernelGGL(bn_apply_kernel<__bf16>, grid, dim3(256), 0, st, static_cast<const __bf16*>(r), mean, rstd, gamma, beta, static_cast<__bf16*>(y), total, C);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, st, static_cast<const float*>(r), mean, rstd, gamma, beta, static_cast<float*>(y), total, C);
   return hipGetLastError();
 }
 
@@ -153,35 +162,43 @@ __global__ void bn_bwd_finish_kernel(const double* __restrict__ partial, int blo
   if (dgamma) dgamma[c] = (float)(sx * (double)rstd[c]);
   if (dbeta) dbeta[c] = (float)s;
 }
-hipError_t bn_bwd_reduce(const float* dy, float dy_scale, const float* r, const float* mean, const float* rstd, size_t N, int C,
+hipError_t bn_bwd_reduce(const void* dy, float dy_scale, const void* r, bool bf16, const float* mean, const float* rstd, size_t N, int C,
                          float* sums, float* dgamma, float* dbeta, double* scratch, hipStream_t st) {
   int blocks = 0;
-  hipError_t e = col_reduce(OpBnBwd{dy, r, mean, dy_scale}, N, C, scratch, &blocks, st);
+  hipError_t e = bf16 ? col_reduce(OpBnBwd<__bf16>{static_cast<const __bf16*>(dy), static_cast<const __bf16*>(r), mean, dy_scale}, N, C, scratch, &blocks, st)
+                      : col_reduce(OpBnBwd<float>{static_cast<const float*>(dy), static_cast<const float*>(r), mean, dy_scale}, N, C, scratch, &blocks, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(C), dim3(64), 0, st, scratch, blocks, C, rstd, sums, dgamma, dbeta);
   return hipGetLastError();
 }
 
 // dr = gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat)),  xhat = (r-mean)*rstd;  dz = relu ? dr*(r>0) : dr
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, float dy_scale, const float* __restrict__ r,
+template <class T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, float dy_scale, const T* __restrict__ r,
                                     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ sums, float invN, int relu, float* __restrict__ dz, size_t total, int C) {
+                                    const float* __restrict__ sums, float invN, int relu, T* __restrict__ dz, size_t total, int C) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = i % C;
-    const float rv = r[i];
+    const float rv = static_cast<float>(r[i]);
     const float rs = rstd[c];
     const float xc = rv - mean[c];
-    const float g = dy[i] * dy_scale;
+    const float g = static_cast<float>(dy[i]) * dy_scale;
     const float d = (gamma[c] * rs) * (g - sums[c] * invN - xc * (rs * rs) * (sums[C + c] * invN));
-    dz[i] = (relu && !(rv > 0.f)) ? 0.f : d;
+    dz[i] = static_cast<T>((relu && !(rv > 0.f)) ? 0.f : d);
   }
 }
-hipError_t bn_bwd_apply(const float* dy, float dy_scale, const float* r, const float* mean, const float* rstd, const float* gamma,
-                        const float* sums, size_t N, int C, int relu, float* dz, hipStream_t st) {
+hipError_t bn_bwd_apply(const void* dy, float dy_scale, const void* r, bool bf16, const float* mean, const float* rstd, const float* gamma,
+                        const float* sums, size_t N, int C, int relu, void* dz, hipStream_t st) {
   const size_t total = N * C;
   size_t g = (total + 255) / 256;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((int)(g > 65536 ? 65536 : g)), dim3(256), 0, st, dy, dy_scale, r, mean, rstd, gamma, sums,
-                     (float)(1.0 / (double)N), relu, dz, total, C);
+  const dim3 grid((int)(g > 65536 ? 65536 : g));
+  const float invN = (float)(1.0 / (double)N);
+  if (bf16)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, grid, dim3(256), 0, st, static_cast<const __bf16*>(dy), dy_scale, static_cast<const __bf16*>(r), mean,
+                       rstd, gamma, sums, invN, relu, static_cast<__bf16*>(dz), total, C);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, static_cast<const float*>(dy), dy_scale, static_cast<const float*>(r), mean,
+                       rstd, gamma, sums, invN, relu, static_cast<float*>(dz), total, C);
   return hipGetLastError();
 }
 
@@ -190,9 +207,10 @@ __global__ void col_sum_finish_kernel(const double* __restrict__ partial, int bl
   const double s = fold_partials(partial, blocks, 1, C, 0, c);
   if (threadIdx.x == 0) out[c] = (float)s;
 }
-hipError_t col_sum(const float* x, size_t N, int C, float* out, double* scratch, hipStream_t st) {
+hipError_t col_sum(const void* x, bool bf16, size_t N, int C, float* out, double* scratch, hipStream_t st) {
   int blocks = 0;
-  hipError_t e = col_reduce(OpSum{x}, N, C, scratch, &blocks, st);
+  hipError_t e = bf16 ? col_reduce(OpSum<__bf16>{static_cast<const __bf16*>(x)}, N, C, scratch, &blocks, st)
+                      : col_reduce(OpSum<float>{static_cast<const float*>(x)}, N, C, scratch, &blocks, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(col_sum_finish_kernel, dim3(C), dim3(64), 0, st, scratch, blocks, C, out);
   return hipGetLastError();
@@ -202,7 +220,8 @@ hipError_t col_sum(const float* x, size_t N, int C, float* out, double* scratch,
 // 2x2 stride-2 SAME max-pool backward: the gradient of a window goes to its first maximum in
 // row-major window order (TF MaxPoolGrad).  x [B,H,W,C] is the pool input, dy [B,Ho,Wo,C].
 // ------------------------------------------------------------------------------------------------
-__global__ void max_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int H, int W,
+template <class T>
+__global__ void max_pool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int H, int W,
                                     int C, int Ho, int Wo, size_t total) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = i % C;
@@ -211,26 +230,31 @@ __global__ void max_pool_bwd_kernel(const float* __restrict__ x, const float* __
     const int iy = r % H;
     const size_t b = r / H;
     const int oy = iy >> 1, ox = ix >> 1;
-    const float* xb = x + b * (size_t)H * W * C;
+    const T* xb = x + b * (size_t)H * W * C;
     int best = -1;
     float bv = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int yy = 2 * oy + (k >> 1), xx = 2 * ox + (k & 1);
       if (yy < H && xx < W) {
-        const float v = xb[((size_t)yy * W + xx) * C + c];
+        const float v = static_cast<float>(xb[((size_t)yy * W + xx) * C + c]);
         if (best < 0 || v > bv) { best = k; bv = v; }
       }
     }
     const int me = ((iy & 1) << 1) | (ix & 1);
-    dx[i] = me == best ? dy[((b * Ho + oy) * Wo + ox) * C + c] : 0.f;
+    dx[i] = me == best ? dy[((b * Ho + oy) * Wo + ox) * C + c] : static_cast<T>(0.f);
   }
 }
-hipError_t max_pool_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, hipStream_t st) {
+hipError_t max_pool_bwd(const void* x, const void* dy, void* dx, bool bf16, int B, int H, int W, int C, hipStream_t st) {
   const size_t total = (size_t)B * H * W * C;
   size_t g = (total + 255) / 256;
-  hipLaunchKernelGGL(max_pool_bwd_kernel, dim3((int)(g > 65536 ? 65536 : g)), dim3(256), 0, st, x, dy, dx, H, W, C, (H + 1) / 2, (W + 1) / 2,
-                     total);
+  const dim3 grid((int)(g > 65536 ? 65536 : g));
+  if (bf16)
+    hipLaunchKernelGGL(max_pool_bwd_kernel<__bf16>, grid, dim3(256), 0, st, static_cast<const __bf16*>(x), static_cast<const __bf16*>(dy),
+                       static_cast<__bf16*>(dx), H, W, C, (H + 1) / 2, (W + 1) / 2, total);
+  else
+    hipLaunchKernelGGL(max_pool_bwd_kernel<float>, grid, dim3(256), 0, st, static_cast<const float*>(x), static_cast<const float*>(dy),
+                       static_cast<float*>(dx), H, W, C, (H + 1) / 2, (W + 1) / 2, total);
   return hipGetLastError();
 }
 
@@ -246,7 +270,8 @@ __device__ __forceinline__ void bil_src(int o, float s, int n, int* lo, int* hi,
   *hi = min(l + 1, n - 1);
   *t = f - (float)l;
 }
-__global__ void resize_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int h, int w, int H, int W, int C, float sy,
+template <class T>
+__global__ void resize_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int h, int w, int H, int W, int C, float sy,
                                   float sx, float scale, size_t total) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = i % C;
@@ -274,17 +299,21 @@ __global__ void resize_bwd_kernel(const float* __restrict__ dy, float* __restric
         if (xlo == ix) wx += 1.f - tx;
         if (xhi == ix) wx += tx;
         if (wx == 0.f) continue;
-        acc += wy * wx * dy[((b * H + oy) * W + ox) * C + c];
+        acc += wy * wx * static_cast<float>(dy[((b * H + oy) * W + ox) * C + c]);
       }
     }
-    dx[i] = acc * scale;
+    dx[i] = static_cast<T>(acc * scale);
   }
 }
-hipError_t resize_bilinear_bwd(const float* dy, float* dx, int B, int h, int w, int H, int W, int C, float scale, hipStream_t st) {
+hipError_t resize_bilinear_bwd(const void* dy, void* dx, bool bf16, int B, int h, int w, int H, int W, int C, float scale, hipStream_t st) {
   const size_t total = (size_t)B * h * w * C;
   size_t g = (total + 255) / 256;
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;
-  hipLaunchKernelGGL(resize_bwd_kernel, dim3((int)(g > 65536 ? 65536 : g)), dim3(256), 0, st, dy, dx, h, w, H, W, C, sy, sx, scale, total);
+  const dim3 grid((int)(g > 65536 ? 65536 : g));
+  if (bf16)
+    hipLaunchKernelGGL(resize_bwd_kernel<__bf16>, grid, dim3(256), 0, st, static_cast<const __bf16*>(dy), static_cast<__bf16*>(dx), h, w, H, W, C, sy, sx, scale, total);
+  else
+    hipLaunchKernelGGL(resize_bwd_kernel<float>, grid, dim3(256), 0, st, static_cast<const float*>(dy), static_cast<float*>(dx), h, w, H, W, C, sy, sx, scale, total);
   return hipGetLastError();
 }
 
@@ -438,6 +467,21 @@ hipError_t momentum_update(float* w, const float* g, float* acc, size_t n, const
                            hipStream_t st) {
   size_t gr = (n + 255) / 256;
   hipLaunchKernelGGL(momentum_kernel, dim3((int)(gr > 4096 ? 4096 : gr)), dim3(256), 0, st, w, g, acc, n, sumsq, clip, lr, mom);
+  return hipGetLastError();
+}
+
+// out [N, ldo] bf16 = in [N, ldi] fp32 in the first ldi columns, zeros beyond (the logits gradient for the bf16 kernels)
+__global__ void cast_pad_bf16_kernel(const float* __restrict__ in, int ldi, __bf16* __restrict__ out, int ldo, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % ldo;
+    const size_t n = i / ldo;
+    out[i] = static_cast<__bf16>(c < ldi ? in[n * ldi + c] : 0.f);
+  }
+}
+hipError_t cast_pad_bf16(const float* in, int ldi, void* out, int ldo, size_t N, hipStream_t st) {
+  const size_t total = N * ldo;
+  size_t g = (total + 255) / 256;
+  hipLaunchKernelGGL(cast_pad_bf16_kernel, dim3((int)(g > 65536 ? 65536 : g)), dim3(256), 0, st, in, ldi, static_cast<__bf16*>(out), ldo, total);
   return hipGetLastError();
 }
 

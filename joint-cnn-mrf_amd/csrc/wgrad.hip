@@ -183,7 +183,8 @@ hipError_t wgrad_reduce(const float* partial, int splits, size_t n, const float*
 // output rows; thread -> (co, tap group); partial sums per workgroup, reduced by wgrad_reduce.
 // ------------------------------------------------------------------------------------------------
 constexpr int W1_PX = 64;          // output pixels per LDS strip
-__global__ __launch_bounds__(256) void wgrad_conv1_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+template <class TZ>
+__global__ __launch_bounds__(256) void wgrad_conv1_kernel(const float* __restrict__ x, const TZ* __restrict__ dz,
                                                           float* __restrict__ partial, int B, int H0, int W0, int sub, int Ho, int Wo,
                                                           int Cout, int nblk) {
   // LDS: input patch rows for one output row segment: 5 rows x (2*W1_PX + 3) px x 3 ch; dz [W1_PX][Cout<=64]
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256) void wgrad_conv1_kernel(const float* __restric
     for (int idx = tid; idx < W1_PX * 64; idx += 256) {
       const int c = idx & 63, p = idx >> 6;
       const int ox = ox0 + p;
-      Zs[p][c] = (ox < Wo && c < Cout) ? dz[(((size_t)b * Ho + oy) * Wo + ox) * Cout + c] : 0.f;
+      Zs[p][c] = (ox < Wo && c < Cout) ? static_cast<float>(dz[(((size_t)b * Ho + oy) * Wo + ox) * Cout + c]) : 0.f;
     }
     __syncthreads();
     for (int p = 0; p < W1_PX; ++p) {
@@ -242,12 +243,15 @@ __global__ __launch_bounds__(256) void wgrad_conv1_kernel(const float* __restric
 }
 int wgrad_conv1_blocks(void) { return 1024; }
 // partial: [wgrad_conv1_blocks()][5][5][3][Cout]
-hipError_t wgrad_conv1(const float* x, const float* dz, float* partial, int B, int H0, int W0, int sub, int Cout, hipStream_t st) {
+hipError_t wgrad_conv1(const float* x, const void* dz, bool dz_bf16, float* partial, int B, int H0, int W0, int sub, int Cout, hipStream_t st) {
   if (Cout > 64) return hipErrorInvalidValue;
   const int Hs = H0 / sub, Ws = W0 / sub;
   const int Ho = (Hs + 1) / 2, Wo = (Ws + 1) / 2;
   const int nblk = wgrad_conv1_blocks();
-  hipLaunchKernelGGL(wgrad_conv1_kernel, dim3(nblk), dim3(256), 0, st, x, dz, partial, B, H0, W0, sub, Ho, Wo, Cout, nblk);
+  if (dz_bf16)
+    hipLaunchKernelGGL(wgrad_conv1_kernel<__bf16>, dim3(nblk), dim3(256), 0, st, x, static_cast<const __bf16*>(dz), partial, B, H0, W0, sub, Ho, Wo, Cout, nblk);
+  else
+    hipLaunchKernelGGL(wgrad_conv1_kernel<float>, dim3(nblk), dim3(256), 0, st, x, static_cast<const float*>(dz), partial, B, H0, W0, sub, Ho, Wo, Cout, nblk);
   return hipGetLastError();
 }
 

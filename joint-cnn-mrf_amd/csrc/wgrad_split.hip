@@ -29,9 +29,10 @@ namespace {
 constexpr int WS_PW = 32;          // output pixels per strip = two k16 steps
 constexpr int WS_XPX = 48;         // staged input pixels per strip (>= 32 + KS - 1, a multiple of the 16-pixel DMA piece)
 constexpr int WS_ROW = 64;         // bytes per staged row: 32 bf16 channels
-constexpr int WS_XBYTES = 3 * 2 * WS_XPX * WS_ROW;     // [part][half][pixel][32 ch]
-constexpr int WS_ZBYTES = 3 * 2 * WS_PW * WS_ROW;
-constexpr int WS_BUF = WS_XBYTES + WS_ZBYTES;
+// NP = operand parts: 3 = fp32 operands split by split_parts (six products), 1 = plain bf16 operands (one product)
+__host__ __device__ constexpr int ws_xbytes(int np) { return np * 2 * WS_XPX * WS_ROW; }     // [part][half][pixel][32 ch]
+__host__ __device__ constexpr int ws_zbytes(int np) { return np * 2 * WS_PW * WS_ROW; }
+__host__ __device__ constexpr int ws_buf(int np) { return ws_xbytes(np) + ws_zbytes(np); }
 
 template <int OFF>
 __device__ __forceinline__ u32x2 tr_read_imm(unsigned addr) {
@@ -56,9 +57,9 @@ __device__ __forceinline__ void load_taps(unsigned abase, u32x2 (&lo)[KS], u32x2
     load_taps<KS, S, PA, KX + 1>(abase, lo, hi);
   }
 }
-// all MFMAs of one (S, PA): KS taps x the gradient parts q <= 2 - PA
-template <int KS, int S, int PA>
-__device__ __forceinline__ void taps(unsigned abase, const bf16x8 (&bz)[3], f32x16 (&acc)[KS]) {
+// all MFMAs of one (S, PA): KS taps x the gradient parts q <= NP - 1 - PA
+template <int KS, int NP, int S, int PA>
+__device__ __forceinline__ void taps(unsigned abase, const bf16x8 (&bz)[NP], f32x16 (&acc)[KS]) {
   u32x2 lo[KS], hi[KS];
   load_taps<KS, S, PA, 0>(abase, lo, hi);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -67,28 +68,41 @@ __device__ __forceinline__ void taps(unsigned abase, const bf16x8 (&bz)[3], f32x
   for (int kx = 0; kx < KS; ++kx) {
     const bf16x8 a = pack_op(lo[kx], hi[kx]);
 #pragma unroll
-    for (int q = 0; q <= 2 - PA; ++q) acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bz[q], acc[kx], 0, 0, 0);
+    for (int q = 0; q <= NP - 1 - PA; ++q) acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bz[q], acc[kx], 0, 0, 0);
   }
 }
 
-template <int KS, int S>
+template <int NP, int S, int Q>
+__device__ __forceinline__ void load_z(unsigned zbase, u32x2 (&lo)[NP], u32x2 (&hi)[NP]) {
+  if constexpr (Q < NP) {
+    constexpr int off = (Q * 2 * WS_PW + 16 * S) * WS_ROW;
+    lo[Q] = tr_read_imm<off>(zbase);
+    hi[Q] = tr_read_imm<off + 4 * WS_ROW>(zbase);
+    load_z<NP, S, Q + 1>(zbase, lo, hi);
+  }
+}
+template <int KS, int NP, int S, int PA>
+__device__ __forceinline__ void parts_desc(unsigned abase, const bf16x8 (&bz)[NP], f32x16 (&acc)[KS]) {   // smallest products first
+  if constexpr (PA >= 0) {
+    taps<KS, NP, S, PA>(abase, bz, acc);
+    parts_desc<KS, NP, S, PA - 1>(abase, bz, acc);
+  }
+}
+template <int KS, int NP, int S>
 __device__ __forceinline__ void k16_step(unsigned abase, unsigned zbase, f32x16 (&acc)[KS]) {
-  bf16x8 bz[3];
+  bf16x8 bz[NP];
   {
-    constexpr int o0 = (0 * 2 * WS_PW + 16 * S) * WS_ROW, o1 = (1 * 2 * WS_PW + 16 * S) * WS_ROW, o2 = (2 * 2 * WS_PW + 16 * S) * WS_ROW;
-    const u32x2 a0 = tr_read_imm<o0>(zbase), a1 = tr_read_imm<o0 + 4 * WS_ROW>(zbase);
-    const u32x2 b0 = tr_read_imm<o1>(zbase), b1 = tr_read_imm<o1 + 4 * WS_ROW>(zbase);
-    const u32x2 c0 = tr_read_imm<o2>(zbase), c1 = tr_read_imm<o2 + 4 * WS_ROW>(zbase);
+    u32x2 lo[NP], hi[NP];
+    load_z<NP, S, 0>(zbase, lo, hi);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    bz[0] = pack_op(a0, a1); bz[1] = pack_op(b0, b1); bz[2] = pack_op(c0, c1);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) bz[q] = pack_op(lo[q], hi[q]);
   }
-  taps<KS, S, 2>(abase, bz, acc);      // smallest products first
-  taps<KS, S, 1>(abase, bz, acc);
-  taps<KS, S, 0>(abase, bz, acc);
+  parts_desc<KS, NP, S, NP - 1>(abase, bz, acc);
 }
 
-template <int KS>
+template <int KS, int NP>
 __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const __bf16* __restrict__ xp, const __bf16* __restrict__ zp,
                                                               float* __restrict__ partial, int B, int H, int W, int Cin, int Cout, int ldz,
                                                               int n_ci, int n_co, int splits, long xpart, long zpart) {
@@ -121,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const __bf16* __res
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  // ---- staging: 30 LDS-DMA pieces of 1 KB per strip (16 pixels x 64 B), dealt round-robin to the 4 waves.
+  // ---- staging: 10 * NP LDS-DMA pieces of 1 KB per strip (16 pixels x 64 B), dealt round-robin to the 4 waves.
   // A row of the image is one buffer descriptor, so pixels left / right of it read as zeros (SAME padding).
   const int dpix = lane >> 2, dchunk = lane & 3;
   auto stage = [&](long s, int bufsel) {
@@ -130,11 +144,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const __bf16* __res
     const int b = (int)(row / nvalid), y = ylo + (int)(row % nvalid);
     const int yi = y + ky - PAD;
     const int px0 = seg * WS_PW;
-    char* base = smem + bufsel * WS_BUF;
+    char* base = smem + bufsel * ws_buf(NP);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < (10 * NP + 3) / 4; ++i) {
       const int d = wid + 4 * i;                        // wave-uniform piece index
-      if (d < 18) {                                     // X: [part][half][3 groups of 16 pixels]
+      if (d < 6 * NP) {                                     // X: [part][half][3 groups of 16 pixels]
         const int grp = d % 3, half = (d / 3) % 2, part = d / 6;
         const __bf16* rowp = xp + part * xpart + ((size_t)b * H + yi) * W * Cin;
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(rowp), 0, W * Cin * 2, 0x00020000);
@@ -142,14 +156,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const __bf16* __res
         const unsigned voff = (unsigned)((pix * Cin + ci0 + 32 * half) * 2 + dchunk * 16);
         char* dst = base + ((part * 2 + half) * WS_XPX + 16 * grp) * WS_ROW;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, 0);
-      } else if (d < 30) {                              // dZ: [part][half][2 groups of 16 pixels]
-        const int e = d - 18;
+      } else if (d < 10 * NP) {                         // dZ: [part][half][2 groups of 16 pixels]
+        const int e = d - 6 * NP;
         const int grp = e % 2, half = (e / 2) % 2, part = e / 4;
         const __bf16* rowp = zp + part * zpart + ((size_t)b * H + y) * W * ldz;
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(rowp), 0, W * ldz * 2, 0x00020000);
         const int pix = px0 + 16 * grp + dpix;
         const unsigned voff = (unsigned)((pix * ldz + co0 + 32 * half) * 2 + dchunk * 16);
-        char* dst = base + WS_XBYTES + ((part * 2 + half) * WS_PW + 16 * grp) * WS_ROW;
+        char* dst = base + ws_xbytes(NP) + ((part * 2 + half) * WS_PW + 16 * grp) * WS_ROW;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, 0);
       }
     }
@@ -161,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const __bf16* __res
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const unsigned lane_off = (unsigned)((8 * (g >> 1) + (t >> 2)) * WS_ROW + (16 * (g & 1) + 4 * (t & 3)) * 2);
   const unsigned a_lane = lds0 + (unsigned)(wi * WS_XPX * WS_ROW) + lane_off;
-  const unsigned z_lane = lds0 + (unsigned)(WS_XBYTES + wo * WS_PW * WS_ROW) + lane_off;
+  const unsigned z_lane = lds0 + (unsigned)(ws_xbytes(NP) + wo * WS_PW * WS_ROW) + lane_off;
 
   if (nstrip > 0) stage(0, 0);
   int buf = 0;
@@ -169,9 +183,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const __bf16* __res
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of strip s have landed
     __syncthreads();                                        // ... and everyone's; every wave is past its reads of the other buffer
     if (s + 1 < nstrip) stage(s + 1, buf ^ 1);              // in flight behind this strip's MFMAs
-    const unsigned ab = a_lane + (unsigned)(buf * WS_BUF), zb = z_lane + (unsigned)(buf * WS_BUF);
-    k16_step<KS, 0>(ab, zb, acc);
-    k16_step<KS, 1>(ab, zb, acc);
+    const unsigned ab = a_lane + (unsigned)(buf * ws_buf(NP)), zb = z_lane + (unsigned)(buf * ws_buf(NP));
+    k16_step<KS, NP, 0>(ab, zb, acc);
+    k16_step<KS, NP, 1>(ab, zb, acc);
     buf ^= 1;
   }
 
@@ -214,21 +228,30 @@ hipError_t split_parts(const float* x, void* out, size_t n, hipStream_t st) {
 
 bool wgrad_split_supported(int ks, int Cin, int ldz) { return (ks == 9 || ks == 5) && Cin % 8 == 0 && ldz % 8 == 0; }
 
+namespace {
+template <int KS, int NP>
+hipError_t launch_w(const void* xp, const void* zp, float* partial, int splits, int B, int H, int W, int Cin, int Cout, int ldz, hipStream_t st) {
+  const int n_ci = (Cin + 63) / 64, n_co = (Cout + 63) / 64;
+  const int blocks = KS * n_ci * n_co * splits;
+  const long xpart = (long)B * H * W * Cin, zpart = (long)B * H * W * ldz;
+  hipLaunchKernelGGL((wgrad_split_kernel<KS, NP>), dim3(blocks), dim3(256), 2 * ws_buf(NP), st, static_cast<const __bf16*>(xp),
+                     static_cast<const __bf16*>(zp), partial, B, H, W, Cin, Cout, ldz, n_ci, n_co, splits, xpart, zpart);
+  return hipGetLastError();
+}
+}  // namespace
+
 // xp / zp: split_parts images of x [B,H,W,Cin] and dz [B,H,W,ldz]; partial as wgrad_f32
 hipError_t wgrad_split(const void* xp, const void* zp, float* partial, int splits, int ks, int B, int H, int W, int Cin, int Cout, int ldz,
                        hipStream_t st) {
   if (!wgrad_split_supported(ks, Cin, ldz)) return hipErrorInvalidValue;
-  const int n_ci = (Cin + 63) / 64, n_co = (Cout + 63) / 64;
-  const int blocks = ks * n_ci * n_co * splits;
-  const long xpart = (long)B * H * W * Cin, zpart = (long)B * H * W * ldz;
-  const int lds = 2 * WS_BUF;
-  if (ks == 9)
-    hipLaunchKernelGGL(wgrad_split_kernel<9>, dim3(blocks), dim3(256), lds, st, static_cast<const __bf16*>(xp), static_cast<const __bf16*>(zp),
-                       partial, B, H, W, Cin, Cout, ldz, n_ci, n_co, splits, xpart, zpart);
-  else
-    hipLaunchKernelGGL(wgrad_split_kernel<5>, dim3(blocks), dim3(256), lds, st, static_cast<const __bf16*>(xp), static_cast<const __bf16*>(zp),
-                       partial, B, H, W, Cin, Cout, ldz, n_ci, n_co, splits, xpart, zpart);
-  return hipGetLastError();
+  return ks == 9 ? launch_w<9, 3>(xp, zp, partial, splits, B, H, W, Cin, Cout, ldz, st) : launch_w<5, 3>(xp, zp, partial, splits, B, H, W, Cin, Cout, ldz, st);
+}
+
+// x, dz bf16 NHWC themselves (bf16 training): one product per k16 step, fp32 accumulate
+hipError_t wgrad_bf16(const void* x, const void* dz, float* partial, int splits, int ks, int B, int H, int W, int Cin, int Cout, int ldz,
+                      hipStream_t st) {
+  if (!wgrad_split_supported(ks, Cin, ldz)) return hipErrorInvalidValue;
+  return ks == 9 ? launch_w<9, 1>(x, dz, partial, splits, B, H, W, Cin, Cout, ldz, st) : launch_w<5, 1>(x, dz, partial, splits, B, H, W, Cin, Cout, ldz, st);
 }
 
 }  // namespace jcm

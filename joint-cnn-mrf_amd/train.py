@@ -29,8 +29,8 @@ def piecewise_lr(n_iters, n_updates_total, lr):
 
 class Trainer:
     def __init__(self, engine, optimizer='adam', lr=0.001, lmbd=0.001, use_sm=True, n_updates_total=None):
-        if engine.precision not in ('fp32', 'f32'):
-            raise ValueError('the training step is fp32')
+        # fp32 handle: fp32 tensors (exact fp32 MFMA, or bf16x6 split with f32_conv='split'); bf16 handle: mixed precision
+        # (bf16 activations / gradients and bf16 MFMA, fp32 master weights, statistics, losses, spatial model, optimizer)
         if optimizer not in ('adam', 'momentum'):
             raise Exception('wrong optimizer')                      # main.py:506
         self.eng = engine

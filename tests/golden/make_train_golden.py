@@ -41,6 +41,15 @@ def main():
         idx = np.unique(np.concatenate([rs.randint(0, g.size, 20), np.argsort(-np.abs(g))[:4]]))
         out['tensors'][k] = {'max': float(np.abs(g).max()), 'norm': float(np.linalg.norm(g)), 'slack': float(np.abs(g32 - g).max()),
                              'idx': [int(i) for i in idx], 'val': [float(g[i]) for i in idx]}
+    # a denser sample for the mixed-precision test (cosine similarity per tensor): up to 512 seeded entries each
+    rs2 = np.random.RandomState(6)
+    dense = {}
+    for k in sorted(r64['grads']):
+        g = np.asarray(r64['grads'][k], np.float64).reshape(-1)
+        idx = np.arange(g.size) if g.size <= 512 else np.sort(rs2.choice(g.size, 512, replace=False))
+        dense[k + '|idx'] = idx.astype(np.int64)
+        dense[k + '|val'] = g[idx].astype(np.float32)
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'train_full_samples.npz'), **dense)
     mv = T.update_moving(p, r64['bn_stats'])
     out['moving'] = {k: {'idx': [0, int(v.size) - 1], 'val': [float(v.reshape(-1)[0]), float(v.reshape(-1)[-1])]} for k, v in mv.items()}
     with open(os.path.join(ROOT, 'tests', 'golden', 'train_full.json'), 'w') as fh:

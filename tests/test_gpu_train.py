@@ -18,10 +18,10 @@ def dev(a):
     return torch.as_tensor(np.ascontiguousarray(a), device='cuda:0')
 
 
-def make_trainer(params, f32_conv=None, **kw):
+def make_trainer(params, f32_conv=None, precision='fp32', **kw):
     from joint_cnn_mrf_amd.engine import Engine
     from joint_cnn_mrf_amd.train import Trainer
-    eng = Engine(device=0, f32_conv=f32_conv).load_params(params)
+    eng = Engine(device=0, precision=precision, f32_conv=f32_conv).load_params(params)
     return eng, Trainer(eng, **kw)
 
 
@@ -205,3 +205,42 @@ def test_full_size_step_vs_golden(f32_conv):
     assert not bad, '\n'.join(bad)
     for k, t in gold['moving'].items():
         np.testing.assert_allclose(moving[k][t['idx']], t['val'], rtol=2e-5, atol=1e-7, err_msg=k)
+
+
+def test_full_size_step_bf16_mixed_precision():
+    """bf16 handle: bf16 activations / gradients between the layers, bf16 MFMA with fp32 accumulate; fp32 master weights,
+    BatchNorm statistics, losses, spatial model and optimizer.  Against the float64 golden: losses to 1 %; per gradient
+    tensor the cosine similarity over up to 512 sampled entries and the norm.  Bias gradients of layers followed by
+    BatchNorm are pure cancellation noise (the batch mean removes the bias: their true gradient is ~0) and are only
+    required to stay small."""
+    import json, os
+    from golden.make_train_golden import case, LMBD
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    with open(os.path.join(here, 'train_full.json')) as fh:
+        gold = json.load(fh)
+    dense = np.load(os.path.join(here, 'train_full_samples.npz'))
+    p, x, y = case()
+    eng, tr = make_trainer(p, precision='bf16', use_sm=True, lmbd=LMBD)
+    losses, _ = tr.loss_and_grads(dev(x), dev(y))
+    got = tr.grads_dict()
+    l = losses.cpu().numpy()
+    eng.close()
+    np.testing.assert_allclose(l, gold['losses'], rtol=1e-2)
+    rows, bad = [], []
+    for k, t in gold['tensors'].items():
+        g = got[k].astype(np.float64)
+        a, b = g[dense[k + '|idx']], dense[k + '|val'].astype(np.float64)
+        cos = float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
+        nerr = abs(np.linalg.norm(g) - t['norm']) / max(t['norm'], 1e-30)
+        rows.append((cos, nerr, k))
+        if k.endswith('/biases') and k != 'conv6/biases':
+            ok = np.linalg.norm(g) <= 3 * t['norm'] + 1e-6
+        elif k == 'conv6/biases':
+            ok = np.abs(g).max() < 1e-5                      # exactly zero in exact arithmetic (softmax is shift invariant)
+        else:
+            ok = cos >= 0.97 and nerr <= 0.10
+        if not ok:
+            bad.append('%s: cosine %.4f, norm err %.3f (norm %.2e)' % (k, cos, nerr, t['norm']))
+    for r in sorted(rows)[:10]:
+        print('  cosine %.4f  norm err %.3f  %s' % r)
+    assert not bad, '\n'.join(bad)

@@ -31,7 +31,7 @@ int main() {
     hipMalloc(&dx, x.size() * 4); hipMalloc(&dd, dz.size() * 4); hipMalloc(&dp, (size_t)nb * 75 * C * 4); hipMalloc(&dw, 75 * C * 4); hipMalloc(&w, 75 * C * 4);
     hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dd, dz.data(), dz.size() * 4, hipMemcpyHostToDevice);
     hipMemset(w, 0, 75 * C * 4);
-    wgrad_conv1(dx, dd, dp, B, H0, W0, sub, C, 0);
+    wgrad_conv1(dx, dd, false, dp, B, H0, W0, sub, C, 0);
     wgrad_reduce(dp, nb, 75 * C, w, 0.f, dw, 0);
     std::vector<float> got(75 * C);
     hipMemcpy(got.data(), dw, 75 * C * 4, hipMemcpyDeviceToHost);
