@@ -13,7 +13,18 @@ import sqlite3
 import sys
 
 
+def demangle_light(name):
+    """rocprofv3 leaves some template instantiations mangled; keep the function name and mark bf16 (DF16b)."""
+    m = re.match(r'_ZN3jcm(?:12_GLOBAL__N_1)?(\d+)', name)
+    if not m:
+        return name
+    n = int(m.group(1))
+    base = name[m.end():m.end() + n]
+    return base + ('<bf16>' if 'DF16b' in name else '')
+
+
 def short(name):
+    name = demangle_light(name)
     name = name.replace('(anonymous namespace)::', '')
     name = re.sub(r'\(.*$', '', name)
     return name.replace('void ', '').replace('jcm::', '')
