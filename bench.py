@@ -141,12 +141,13 @@ FLOPS_CONV1 = 1_088_640_000 + 272_160_000 + 68_040_000          # conv1 full/hal
 FLOPS_TRAIN = 3 * FLOPS_PD_SM - FLOPS_CONV1
 
 
-def run_train(args, B, params, world, rank, local_rank, dev, use_sm):
+def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, f32_conv='args'):
     """`--train`: time the joint training step (loss + gradients, gradient all-reduce, clip + Adam, table
     refresh) on B images per GPU; data-parallel, one RCCL all-reduce of the flat gradient buffer per step."""
     from joint_cnn_mrf_amd.train import Trainer
-    prec = args.dtype or 'fp32'
-    eng = Engine(device=local_rank, precision=prec, f32_conv=args.f32_conv if prec == 'fp32' else None).load_params(params)
+    prec = prec or args.dtype or 'fp32'
+    f32_conv = args.f32_conv if f32_conv == 'args' else f32_conv
+    eng = Engine(device=local_rank, precision=prec, f32_conv=f32_conv if prec == 'fp32' else None).load_params(params)
     tr = Trainer(eng, optimizer='adam', lr=0.001, lmbd=0.001, use_sm=use_sm)
     x = torch.as_tensor(synth.make_images(B, seed=1234 + rank), device=dev)
     y = torch.as_tensor(synth.make_targets(B, seed=4321 + rank), device=dev)
@@ -177,7 +178,7 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm):
         scale = 16 if args.debug else 1
         # dominant training kernels: the three conv5 passes, each 229.3 GFLOP per image (60x90 px, 81 taps, 512x512)
         kern = {}
-        sp = args.f32_conv == 'split' and prec == 'fp32'
+        sp = f32_conv == 'split' and prec == 'fp32'
         for key, what in (('conv5', 'forward, ' + ('conv_split_kernel' if sp else 'conv_igemm_f32')),
                           ('dgrad:conv5', 'data gradient, ' + ('conv_split_kernel' if sp else 'conv_igemm_f32') + ' on flipped weights'),
                           ('wgrad:conv5', 'weight gradient, ' + ('wgrad_split_kernel<9>' if sp else 'wgrad_kernel<9>'))):
@@ -190,7 +191,7 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm):
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if prec == 'fp32' else 'bf16', 'data': 'synthetic',
                'config': {'workload': 'configs[4]: joint training, batch=%d/GPU synthetic 480x720x3, %s%s, Adam, clip 4.0%s'
                                       % (B, 'fp32 MFMA' if prec == 'fp32' else 'mixed precision: bf16 activations/gradients + bf16 MFMA, fp32 master weights / statistics / losses / spatial model / optimizer',
-                                         ' operands; forward, data and weight gradients of the stride-1 layers as bf16x6 split MFMA' if args.f32_conv == 'split' else '',
+                                         ' operands; forward, data and weight gradients of the stride-1 layers as bf16x6 split MFMA' if f32_conv == 'split' else '',
                                          ', DEBUG filters/4' if args.debug else ''),
                           'batch_per_gpu': B, 'global_batch': world * B, 'use_sm': use_sm,
                           'collective': 'all_reduce of %d fp32 gradients' % tr.n_elements},
@@ -199,7 +200,7 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm):
                'roofline': dict(bound='mfma', peak=PEAK_TFLOPS[prec], unit='TFLOP/s', traffic=None,
                                 **({'kernel': ('wgrad_split_kernel<9,1> on conv5 (bf16 operands, LDS transpose reads)' if prec == 'bf16' else
                                                'wgrad_split_kernel<9> on conv5 (3 bf16 parts per operand, 6 x bf16 MFMA 32x32x16 per k16 step; achieved = fp32-equivalent FLOPs)'
-                                               if args.f32_conv == 'split' else 'wgrad_kernel<9> on conv5 (fp32 MFMA 32x32x2, 64x64 channel tile x 9 taps)'),
+                                               if f32_conv == 'split' else 'wgrad_kernel<9> on conv5 (fp32 MFMA 32x32x2, 64x64 channel tile x 9 taps)'),
                                     'achieved': kern['wgrad:conv5']['achieved'], 'frac': kern['wgrad:conv5']['frac'],
                                     'launch_ms': kern['wgrad:conv5']['launch_ms']} if 'wgrad:conv5' in kern else {})),
                'conv5_passes': kern,
@@ -272,6 +273,14 @@ def main():
         if split is not None:
             split['roofline']['mfma_bf16_frac'] = (6 * split['roofline']['achieved'] / PEAK_TFLOPS['bf16']) if split['roofline']['achieved'] else None
 
+    # configs[4] (joint training step, 16 images per GPU) beside the inference lines; single-GPU runs only, the
+    # multi-GPU training flow has its own entry point (`--train`)
+    train = {}
+    if args.dtype is None and not args.debug and world == 1 and use_sm:
+        train['train_config4_f32'] = run_train(args, 16, params, world, rank, local_rank, dev, use_sm, prec='fp32', f32_conv=None)
+        train['train_config4_f32_split'] = run_train(args, 16, params, world, rank, local_rank, dev, use_sm, prec='fp32', f32_conv='split')
+        train['train_config4_bf16'] = run_train(args, 16, params, world, rank, local_rank, dev, use_sm, prec='bf16', f32_conv=None)
+
     if rank == 0:
         out = {'metric': 'images/sec (720x480, K=9 joints) part-detector+spatial-model fwd',
                'value': head['value'], 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -282,6 +291,9 @@ def main():
             out['bf16_config2'] = second
         if split is not None:
             out['f32_split_config1'] = split
+        for key, tr_out in train.items():
+            if tr_out is not None:
+                out[key] = {k: tr_out[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'train_tflops', 'frac_of_mfma_peak', 'roofline')}
         if args.cpu_images > 0:
             out['cpu_baseline'] = cpu_baseline(args.cpu_images, params)
         print(json.dumps(out))
