@@ -88,6 +88,8 @@ struct jcm_ctx {
   float* bn_sm_scale = nullptr; // [10]
   float* bn_sm_shift = nullptr;
   int* cond = nullptr;          // [P] conditioning channel of pair p
+  const float** energy_ptrs = nullptr;   // [P] device table of the energy_* / bias_* parameter tensors, graph order
+  const float** bias_ptrs = nullptr;
   int* cond0 = nullptr;         // single zero (jcm_conv_mrf)
   int sm_algo = 2;              // 0 = FFT (2-D rocFFT), 1 = direct sliding-window VALU kernel, 2 = FFT with split row-pruned inverse
   int sm_chunk = 16;            // images per FFT slice

@@ -184,25 +184,32 @@ int refresh_derived(jcm_ctx* c, bool first) {
       JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->prior_spec), (size_t)P * kSpec * sizeof(float2)));
       JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->prior_spec_t), (size_t)P * kSpec * sizeof(float2)));
     }
-    std::vector<int> cond(P);
-    int p = 0;
-    for (int j = 0; j < c->K; ++j) {
-      for (int cc = 0; cc < kC; ++cc) {
-        if (cc == j) continue;
-        const std::string key = std::string(kJointNames[j]) + "_" + kJointNames[cc];
-        const Tensor* e = find(c, "energy_" + key);
-        const Tensor* bi = find(c, "bias_" + key);
-        if (!e || e->n != (size_t)kPrH * kPrW) return fail(JCM_ERR_STATE, "missing or mis-sized 'energy_" + key + "' (want [1,120,180,1])");
-        if (!bi || bi->n != (size_t)kHmHW) return fail(JCM_ERR_STATE, "missing or mis-sized 'bias_" + key + "' (want [1,60,90,1])");
-        HIP_TRY(sm_softplus5(e->d, c->sp_energy + (size_t)p * kPrH * kPrW, (int64_t)kPrH * kPrW, c->stream));   // main.py:120
-        HIP_TRY(sm_softplus5(bi->d, c->sp_bias + (size_t)p * kHmHW, kHmHW, c->stream));                          // main.py:122
-        cond[p++] = cc;
-      }
-    }
     if (first) {
+      std::vector<int> cond(P);
+      std::vector<const float*> ep(P), bp(P);
+      int p = 0;
+      for (int j = 0; j < c->K; ++j) {
+        for (int cc = 0; cc < kC; ++cc) {
+          if (cc == j) continue;
+          const std::string key = std::string(kJointNames[j]) + "_" + kJointNames[cc];
+          const Tensor* e = find(c, "energy_" + key);
+          const Tensor* bi = find(c, "bias_" + key);
+          if (!e || e->n != (size_t)kPrH * kPrW) return fail(JCM_ERR_STATE, "missing or mis-sized 'energy_" + key + "' (want [1,120,180,1])");
+          if (!bi || bi->n != (size_t)kHmHW) return fail(JCM_ERR_STATE, "missing or mis-sized 'bias_" + key + "' (want [1,60,90,1])");
+          ep[p] = e->d;
+          bp[p] = bi->d;
+          cond[p++] = cc;
+        }
+      }
+      JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->energy_ptrs), P * sizeof(float*)));
+      JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->bias_ptrs), P * sizeof(float*)));
       HIP_TRY(hipMemcpyAsync(c->cond, cond.data(), P * sizeof(int), hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(hipStreamSynchronize(c->stream));   // cond is stack-local
+      HIP_TRY(hipMemcpyAsync(c->energy_ptrs, ep.data(), P * sizeof(float*), hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipMemcpyAsync(c->bias_ptrs, bp.data(), P * sizeof(float*), hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));   // the tables are stack-local
     }
+    HIP_TRY(sm_softplus5_multi(c->energy_ptrs, c->sp_energy, P, (int64_t)kPrH * kPrW, c->stream));   // main.py:120
+    HIP_TRY(sm_softplus5_multi(c->bias_ptrs, c->sp_bias, P, kHmHW, c->stream));                        // main.py:122
     FFT_TRY(sm_fft_r2c(c->fft, c->sp_energy, c->prior_spec, P));
     HIP_TRY(sm_transpose(c->prior_spec, c->prior_spec_t, P, kPrH, kPrW / 2 + 1, 0, kPrW / 2 + 1, c->stream));
     c->has_sm = true;

@@ -51,6 +51,12 @@ struct TrainState {
   const float** b_ptr = nullptr;
   int64_t* e_off = nullptr;
   int64_t* b_off = nullptr;
+  // optimizer chunk table (one launch updates every tensor)
+  float** ck_w = nullptr;
+  int64_t* ck_start = nullptr;
+  int64_t* ck_off = nullptr;
+  int* ck_len = nullptr;
+  int n_chunks = 0;
   int maxC = 0;
   long step = 0;                       // optimizer updates applied (n_iters, main.py:491)
 };
@@ -547,6 +553,27 @@ int jcm_train_begin(jcm_handle h) {
     HIP_TRY(hipMemcpyAsync(t->b_off, bo.data(), P * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
+  {
+    constexpr int64_t kChunk = 16384;
+    std::vector<float*> cw;
+    std::vector<int64_t> cs, co;
+    std::vector<int> cl;
+    for (const Slot& sl : t->slots)
+      for (int64_t st0 = 0; st0 < (int64_t)sl.n; st0 += kChunk) {
+        cw.push_back(sl.w); cs.push_back(st0); co.push_back((int64_t)sl.off);
+        cl.push_back((int)((int64_t)sl.n - st0 < kChunk ? (int64_t)sl.n - st0 : kChunk));
+      }
+    t->n_chunks = (int)cw.size();
+    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->ck_w), cw.size() * sizeof(float*)));
+    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->ck_start), cs.size() * sizeof(int64_t)));
+    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->ck_off), co.size() * sizeof(int64_t)));
+    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->ck_len), cl.size() * sizeof(int)));
+    HIP_TRY(hipMemcpyAsync(t->ck_w, cw.data(), cw.size() * sizeof(float*), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(t->ck_start, cs.data(), cs.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(t->ck_off, co.data(), co.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(t->ck_len, cl.data(), cl.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
   JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->red), train_reduce_scratch_doubles(t->maxC) * sizeof(double)));
   JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->sumsq), 2 * sizeof(double)));
   JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->small), (size_t)(2 * t->maxC + 64) * sizeof(float)));
@@ -597,13 +624,12 @@ int jcm_train_apply(jcm_handle h, const float* grads, int optimizer, float lr, f
   t->step += 1;
   const double b1 = 0.9, b2 = 0.999;
   const float lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow(b2, (double)t->step)) / (1.0 - std::pow(b1, (double)t->step)));
-  for (const Slot& s : t->slots) {
-    if (optimizer == JCM_OPT_ADAM)
-      HIP_TRY(adam_update(s.w, grads + s.off, t->opt_m + s.off, t->opt_v + s.off, s.n, clip ? t->sumsq : nullptr, clip_norm, lr_t, 0.9f,
-                          0.999f, 1e-8f, c->stream));
-    else
-      HIP_TRY(momentum_update(s.w, grads + s.off, t->opt_m + s.off, s.n, clip ? t->sumsq : nullptr, clip_norm, lr, 0.9f, c->stream));
-  }
+  if (optimizer == JCM_OPT_ADAM)
+    HIP_TRY(optimizer_chunks(t->ck_w, t->ck_start, t->ck_off, t->ck_len, t->n_chunks, grads, t->opt_m, t->opt_v, clip ? t->sumsq : nullptr,
+                             clip_norm, lr_t, 0.9f, 0.999f, 1e-8f, 0, c->stream));
+  else
+    HIP_TRY(optimizer_chunks(t->ck_w, t->ck_start, t->ck_off, t->ck_len, t->n_chunks, grads, t->opt_m, t->opt_v, clip ? t->sumsq : nullptr,
+                             clip_norm, lr, 0.9f, 0.f, 0.f, 1, c->stream));
   if (grad_norm_out) {
     double ss = 0.0;
     HIP_TRY(hipMemcpyAsync(&ss, t->sumsq, sizeof(double), hipMemcpyDeviceToHost, c->stream));

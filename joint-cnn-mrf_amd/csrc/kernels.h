@@ -74,6 +74,8 @@ hipError_t bn_fold(const float* gamma, const float* beta, const float* mean, con
 // ---- spatial_model.hip -----------------------------------------------------------------------------
 // softplus5 tables of the batch-independent operands (main.py:120,122)
 hipError_t sm_softplus5(const float* in, float* out, int64_t n, hipStream_t st);
+// out[p][i] = softplus5(in[p][i]) for P separately allocated tensors of n elements each (one launch for the 81 pairs)
+hipError_t sm_softplus5_multi(const float* const* in, float* out, int P, int64_t n, hipStream_t st);
 // hm [B,5400,C] NHWC -> lik [B][C][5400] planar = softplus5(bn(hm))
 hipError_t sm_likelihood(const float* hm, const float* bn_scale, const float* bn_shift, float* lik,
                          int B, int C, hipStream_t st);
@@ -142,6 +144,10 @@ hipError_t adam_update(float* w, const float* g, float* m, float* v, size_t n, c
 hipError_t momentum_update(float* w, const float* g, float* acc, size_t n, const double* sumsq, float clip, float lr, float mom,
                            hipStream_t st);
 hipError_t scale_copy(const float* a, float s, float* out, size_t n, hipStream_t st);
+// clip + Adam (or momentum: b1 = momentum, momentum_mode = 1) over a chunk table covering every trainable tensor, one launch
+hipError_t optimizer_chunks(float* const* wptr, const int64_t* cstart, const int64_t* coff, const int* clen, int nchunks, const float* g,
+                            float* m, float* v, const double* sumsq, float clip, float lr_t, float b1, float b2, float eps, int momentum_mode,
+                            hipStream_t st);
 
 // ---- wgrad.hip : weight gradients on MFMA, data-gradient weight transform ------------------------------
 int wgrad_splits(int ks, int Cin, int Cout, int B, int H);

@@ -45,6 +45,17 @@ hipError_t sm_softplus5(const float* in, float* out, int64_t n, hipStream_t st) 
   return hipGetLastError();
 }
 
+__global__ void sm_softplus5_multi_kernel(const float* const* __restrict__ in, float* __restrict__ out, int64_t n) {
+  const int p = blockIdx.y;
+  const float* src = in[p];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[(size_t)p * n + i] = softplus5(src[i]);
+}
+hipError_t sm_softplus5_multi(const float* const* in, float* out, int P, int64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(sm_softplus5_multi_kernel, dim3((int)((n + 255) / 256 > 64 ? 64 : (n + 255) / 256), P), dim3(256), 0, st, in, out, n);
+  return hipGetLastError();
+}
+
 // lik[b][c] : [60][96] rows reversed along x:  lik[u][t] = sp(bn(h[b,u,89-t,c])) for t<90, 0 beyond;
 // the unary term reads it back as lik[u][89-x].
 __global__ void sm_likelihood_kernel(const float* __restrict__ hm, const float* __restrict__ sc, const float* __restrict__ sh,

@@ -470,6 +470,43 @@ hipError_t momentum_update(float* w, const float* g, float* acc, size_t n, const
   return hipGetLastError();
 }
 
+// ---- the optimizer over every trainable tensor in ONE launch: a chunk table (tensor pointer, offset of the chunk in the
+// tensor, offset of the tensor in the flat gradient / slot buffers, length) replaces one launch per tensor (218 of them)
+__global__ void adam_chunks_kernel(float* const* __restrict__ wptr, const int64_t* __restrict__ cstart, const int64_t* __restrict__ coff,
+                                   const int* __restrict__ clen, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                   const double* __restrict__ sumsq, float clip, float lr_t, float b1, float b2, float eps, int momentum_mode) {
+  float s = 1.f;
+  if (sumsq) {
+    const float norm = (float)sqrt(*sumsq);
+    s = clip / fmaxf(norm, clip);
+  }
+  const int c = blockIdx.x;
+  float* w = wptr[c] + cstart[c];
+  const int64_t base = coff[c] + cstart[c];
+  const int n = clen[c];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float gi = g[base + i] * s;
+    if (momentum_mode) {                       // tf.train.MomentumOptimizer: acc = mom*acc + g; w -= lr*acc   (b1 = momentum)
+      const float a = b1 * m[base + i] + gi;
+      m[base + i] = a;
+      w[i] = w[i] - lr_t * a;
+    } else {
+      const float mi = b1 * m[base + i] + (1.f - b1) * gi;
+      const float vi = b2 * v[base + i] + (1.f - b2) * gi * gi;
+      m[base + i] = mi;
+      v[base + i] = vi;
+      w[i] = w[i] - lr_t * mi / (sqrtf(vi) + eps);
+    }
+  }
+}
+hipError_t optimizer_chunks(float* const* wptr, const int64_t* cstart, const int64_t* coff, const int* clen, int nchunks, const float* g,
+                            float* m, float* v, const double* sumsq, float clip, float lr_t, float b1, float b2, float eps, int momentum_mode,
+                            hipStream_t st) {
+  hipLaunchKernelGGL(adam_chunks_kernel, dim3(nchunks), dim3(256), 0, st, wptr, cstart, coff, clen, g, m, v, sumsq, clip, lr_t, b1, b2, eps,
+                     momentum_mode);
+  return hipGetLastError();
+}
+
 // out [N, ldo] bf16 = in [N, ldi] fp32 in the first ldi columns, zeros beyond (the logits gradient for the bf16 kernels)
 __global__ void cast_pad_bf16_kernel(const float* __restrict__ in, int ldi, __bf16* __restrict__ out, int ldo, size_t total) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {

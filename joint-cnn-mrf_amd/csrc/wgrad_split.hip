@@ -47,26 +47,26 @@ __device__ __forceinline__ bf16x8 pack_op(u32x2 lo, u32x2 hi) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
-// the KS shifted activation operands of one (k16 step S, part PA): 2 transpose reads each
-template <int KS, int S, int PA, int KX>
-__device__ __forceinline__ void load_taps(unsigned abase, u32x2 (&lo)[KS], u32x2 (&hi)[KS]) {
-  if constexpr (KX < KS) {
-    constexpr int off = (PA * 2 * WS_XPX + 16 * S + KX) * WS_ROW;      // + 8*kh rows in the lane address
-    lo[KX] = tr_read_imm<off>(abase);
-    hi[KX] = tr_read_imm<off + 4 * WS_ROW>(abase);
-    load_taps<KS, S, PA, KX + 1>(abase, lo, hi);
+// The KS shifted activation operands of one (k16 step S, part PA).  The operand of tap kx is rows kx..kx+3 and kx+4..kx+7
+// (plus 8*kh) of the strip, so the 4-row blocks at offsets 0 .. KS+3 serve all taps: KS + 4 transpose reads instead of 2*KS.
+template <int KS, int S, int PA, int O>
+__device__ __forceinline__ void load_blocks(unsigned abase, u32x2 (&blk)[KS + 4]) {
+  if constexpr (O < KS + 4) {
+    constexpr int off = (PA * 2 * WS_XPX + 16 * S + O) * WS_ROW;       // + 8*kh rows in the lane address
+    blk[O] = tr_read_imm<off>(abase);
+    load_blocks<KS, S, PA, O + 1>(abase, blk);
   }
 }
 // all MFMAs of one (S, PA): KS taps x the gradient parts q <= NP - 1 - PA
 template <int KS, int NP, int S, int PA>
 __device__ __forceinline__ void taps(unsigned abase, const bf16x8 (&bz)[NP], f32x16 (&acc)[KS]) {
-  u32x2 lo[KS], hi[KS];
-  load_taps<KS, S, PA, 0>(abase, lo, hi);
+  u32x2 blk[KS + 4];
+  load_blocks<KS, S, PA, 0>(abase, blk);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);       // the MFMAs below must not be hoisted above the wait (the compiler cannot see the reads)
 #pragma unroll
   for (int kx = 0; kx < KS; ++kx) {
-    const bf16x8 a = pack_op(lo[kx], hi[kx]);
+    const bf16x8 a = pack_op(blk[kx], blk[kx + 4]);
 #pragma unroll
     for (int q = 0; q <= NP - 1 - PA; ++q) acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bz[q], acc[kx], 0, 0, 0);
   }
@@ -102,13 +102,13 @@ __device__ __forceinline__ void k16_step(unsigned abase, unsigned zbase, f32x16 
   parts_desc<KS, NP, S, NP - 1>(abase, bz, acc);
 }
 
-template <int KS, int NP>
+template <int KS, int NP, int NBUF>
 __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const __bf16* __restrict__ xp, const __bf16* __restrict__ zp,
                                                               float* __restrict__ partial, int B, int H, int W, int Cin, int Cout, int ldz,
                                                               int n_ci, int n_co, int splits, long xpart, long zpart) {
   constexpr int PAD = (KS - 1) / 2;
   static_assert(WS_PW + KS - 1 <= WS_XPX, "halo fits the staged rows");
-  extern __shared__ __attribute__((aligned(16))) char smem[];     // two strip buffers
+  extern __shared__ __attribute__((aligned(16))) char smem[];     // NBUF strip buffers: NBUF - 1 strips of LDS-DMA in flight
 
   int bid = blockIdx.x;
   const int ky = bid % KS; bid /= KS;
@@ -145,9 +145,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const __bf16* __res
     const int yi = y + ky - PAD;
     const int px0 = seg * WS_PW;
     char* base = smem + bufsel * ws_buf(NP);
+    constexpr int PER_WAVE = (10 * NP + 3) / 4;         // every wave issues the same number of DMAs per strip (the wait counts
 #pragma unroll
-    for (int i = 0; i < (10 * NP + 3) / 4; ++i) {
-      const int d = wid + 4 * i;                        // wave-uniform piece index
+    for (int i = 0; i < PER_WAVE; ++i) {                //  below are immediates): surplus slots repeat a piece, which is harmless
+      const int d = (wid + 4 * i) % (10 * NP);          // wave-uniform piece index
       if (d < 6 * NP) {                                     // X: [part][half][3 groups of 16 pixels]
         const int grp = d % 3, half = (d / 3) % 2, part = d / 6;
         const __bf16* rowp = xp + part * xpart + ((size_t)b * H + yi) * W * Cin;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const __bf16* __res
         const unsigned voff = (unsigned)((pix * Cin + ci0 + 32 * half) * 2 + dchunk * 16);
         char* dst = base + ((part * 2 + half) * WS_XPX + 16 * grp) * WS_ROW;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, 0);
-      } else if (d < 10 * NP) {                         // dZ: [part][half][2 groups of 16 pixels]
+      } else {                                          // dZ: [part][half][2 groups of 16 pixels]
         const int e = d - 6 * NP;
         const int grp = e % 2, half = (e / 2) % 2, part = e / 4;
         const __bf16* rowp = zp + part * zpart + ((size_t)b * H + y) * W * ldz;
@@ -177,16 +178,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const __bf16* __res
   const unsigned a_lane = lds0 + (unsigned)(wi * WS_XPX * WS_ROW) + lane_off;
   const unsigned z_lane = lds0 + (unsigned)(ws_xbytes(NP) + wo * WS_PW * WS_ROW) + lane_off;
 
-  if (nstrip > 0) stage(0, 0);
+  constexpr int D = NBUF - 1;                               // prefetch distance in strips
+  constexpr int PER_WAVE_DMA = (10 * NP + 3) / 4;
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < nstrip) stage(d, d);
   int buf = 0;
   for (long s = 0; s < nstrip; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of strip s have landed
-    __syncthreads();                                        // ... and everyone's; every wave is past its reads of the other buffer
-    if (s + 1 < nstrip) stage(s + 1, buf ^ 1);              // in flight behind this strip's MFMAs
+    // this wave's pieces of strip s have landed: at most the D-1 younger strips may still be in flight (near the end fewer
+    // strips are outstanding than that, so drain completely there)
+    if (s + D <= nstrip) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((D - 1) * PER_WAVE_DMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                        // ... and everyone's; every wave is past its reads of strip s-1's buffer
+    if (s + D < nstrip) stage(s + D, (buf + D) % NBUF);     // = the buffer strip s-1 used
     const unsigned ab = a_lane + (unsigned)(buf * ws_buf(NP)), zb = z_lane + (unsigned)(buf * ws_buf(NP));
     k16_step<KS, NP, 0>(ab, zb, acc);
     k16_step<KS, NP, 1>(ab, zb, acc);
-    buf ^= 1;
+    buf = (buf + 1) % NBUF;
   }
 
   // ---- partial tile store: D col = lane&31 -> co, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -> ci
@@ -234,7 +242,8 @@ hipError_t launch_w(const void* xp, const void* zp, float* partial, int splits, 
   const int n_ci = (Cin + 63) / 64, n_co = (Cout + 63) / 64;
   const int blocks = KS * n_ci * n_co * splits;
   const long xpart = (long)B * H * W * Cin, zpart = (long)B * H * W * ldz;
-  hipLaunchKernelGGL((wgrad_split_kernel<KS, NP>), dim3(blocks), dim3(256), 2 * ws_buf(NP), st, static_cast<const __bf16*>(xp),
+  constexpr int NBUF = NP == 1 ? 4 : 2;      // a bf16 strip is 18 MFMAs per wave: three strips of DMA in flight cover the HBM/L2 latency
+  hipLaunchKernelGGL((wgrad_split_kernel<KS, NP, NBUF>), dim3(blocks), dim3(256), NBUF * ws_buf(NP), st, static_cast<const __bf16*>(xp),
                      static_cast<const __bf16*>(zp), partial, B, H, W, Cin, Cout, ldz, n_ci, n_co, splits, xpart, zpart);
   return hipGetLastError();
 }
