@@ -10,6 +10,12 @@
 // against 2.9e-7 for an fp32 GEMM).  Six v_mfma_f32_32x32x16_bf16 replace eight
 // v_mfma_f32_32x32x2_f32 per 16 k-values at 16x the rate: 2.7x the fp32 MFMA peak.
 //
+// fp16x3 variant (NS = 2): an fp32 value is a0 + a1 with two fp16 parts to 22 bits (a1 may be an fp16 subnormal: absolute
+// error < 3e-8, harmless for O(1) activations; weights are stored times 2^12 so theirs is < 1e-11), fp16 x fp16 products are
+// exact in fp32, and a0*b1 + a0*b0 + a1*b0 -- three v_mfma_f32_32x32x16_f16 -- drops only a1*b1 (2^-22): on the same
+// K = 41472 dot product 2.6e-7 of max|result| with fp32 accumulation, i.e. the accumulate rounding, not the split, is what
+// is left.  5.3x the fp32 MFMA peak.  Needs |activation| < 65504 and |w| < 16 (true behind BatchNorm); not used for gradients.
+//
 // Dataflow = conv_igemm_bf16.hip's big-tile kernel (12x32 pixels x 256 channels per workgroup, 8
 // waves of 3x4 fragments, rotating-B schedule, weights by LDS-DMA) with the K axis extended by the
 // six (p,q) sub-steps: activations stay fp32 in HBM and are split once per 16-channel chunk while the
@@ -19,49 +25,56 @@
 namespace jcm {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
 // KS x KS taps, TH x TW pixel patch (or, FLAT, TH*TW pixel slots filled with whole rows of a narrow map), BN channels
-template <int KS_, int BN_, bool FLAT_>
+// NS_ = operand parts: 3 = bf16 parts, six products; 2 = fp16 parts, three products (header comment).  TPS_ = taps per
+// weight stage (the taps of a stage lie side by side in one kernel row).
+template <int KS_, int BN_, bool FLAT_, int NS_ = 3, int TPS_ = 1>
 struct CfgS {
   static constexpr int KS = KS_, TH = 12, TW = 32, BN = BN_, WM = 4, WN = 2;
   static constexpr bool FLAT = FLAT_;
   static constexpr int NT = WM * WN * 64;
   static constexpr int U = 2;                       // 16-B units per chunk = 16 channels = one k16 step
-  static constexpr int NSPLIT = 3, NSUB = 6;
+  static constexpr int NSPLIT = NS_, NSUB = NS_ == 3 ? 6 : 3, TPS = TPS_;
+  static constexpr int NSTEP = TPS * NSUB;          // MFMA groups between two barriers
   static constexpr int PAD = (KS - 1) / 2;
   static constexpr int HH = TH + KS - 1, WH = TW + KS - 1, WHP = WH;
   // FLAT: (R + KS-1) x (W + KS-1) slots with R = floor(384 / W) rows: 16x53 (30x45 maps) / 23x31 (15x23) for KS = 9
   static constexpr int PLANE = FLAT ? 850 : HH * WHP + 2;
   static constexpr int BM = TH * TW, MR = BM / WM / 32, NR = BN / WN / 32;
   static constexpr int HALO_F4 = NSPLIT * U * PLANE;            // [split][unit][slot]
-  static constexpr int WSTAGE_F4 = NSPLIT * U * BN;             // one tap: [split][unit][co]
-  static constexpr int NSTAGE = KS * KS;
+  static constexpr int WSTAGE_F4 = TPS * NSPLIT * U * BN;       // one stage: [tap][split][unit][co]
+  static constexpr int NSTAGE = KS * KS / TPS;
   static constexpr int LDS_BYTES = (HALO_F4 + 2 * WSTAGE_F4) * 16;
+  static_assert(KS % TPS == 0, "the taps of a stage share a kernel row");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
-constexpr int kNSub = 6;
 
-// sub-step -> (activation part, weight part).  Weight parts are visited in runs (0 0 0 1 1 2) so that a B
-// fragment is re-read only when its part changes, and the last two steps share a0: 5*MR + 3*NR = 27 fragment reads per
-// 72 MFMAs instead of 42.
-// (All six products land in the same accumulator, whose magnitude is the running sum: their order is immaterial.)
-__host__ __device__ constexpr int sub_b(int s) { return s < 3 ? 0 : (s < 5 ? 1 : 2); }            // 0 0 0 1 1 2
-__host__ __device__ constexpr int sub_a(int s) { return s < 3 ? 2 - s : (s < 5 ? 4 - s : 0); }    // 2 1 0 1 0 0
-__host__ __device__ constexpr bool reload_b(int s) { return s == 0 || (s < kNSub && sub_b(s) != sub_b(s - 1)); }
-__host__ __device__ constexpr bool load_a(int s) { return s == 0 || (s < kNSub && sub_a(s) != sub_a(s - 1)); }   // steps 4, 5 share a0
-__host__ __device__ constexpr int a_buf(int s) {          // which of the two A register sets step s reads
+// sub-step -> (activation part, weight part).  Weight parts are visited in runs (bf16x6: 0 0 0 1 1 2, fp16x3: 1 0 0) so
+// that a B fragment is re-read only when its part changes, and the last two steps of bf16x6 share a0: 27 instead of 42
+// fragment reads per 72 MFMAs.  (All products land in the same accumulator, whose magnitude is the running sum: their
+// order is immaterial.)
+template <int NS> __host__ __device__ constexpr int sub_b(int s) { return NS == 3 ? (s < 3 ? 0 : (s < 5 ? 1 : 2)) : (s == 0 ? 1 : 0); }
+template <int NS> __host__ __device__ constexpr int sub_a(int s) { return NS == 3 ? (s < 3 ? 2 - s : (s < 5 ? 4 - s : 0)) : (s == 2 ? 1 : 0); }
+// step of a stage -> (tap of the stage, sub-step)
+template <class C> __host__ __device__ constexpr int key_a(int st) { return (st / C::NSUB) * 8 + sub_a<C::NSPLIT>(st % C::NSUB); }
+template <class C> __host__ __device__ constexpr int key_b(int st) { return (st / C::NSUB) * 8 + sub_b<C::NSPLIT>(st % C::NSUB); }
+template <class C> __host__ __device__ constexpr bool reload_b(int st) { return st == 0 || (st < C::NSTEP && key_b<C>(st) != key_b<C>(st - 1)); }
+template <class C> __host__ __device__ constexpr bool load_a(int st) { return st == 0 || (st < C::NSTEP && key_a<C>(st) != key_a<C>(st - 1)); }
+template <class C> __host__ __device__ constexpr int a_buf(int st) {          // which of the two A register sets step st reads
   int n = 0;
-  for (int k = 1; k <= s; ++k) n += load_a(k) ? 1 : 0;
+  for (int k = 1; k <= st; ++k) n += load_a<C>(k) ? 1 : 0;
   return n & 1;
 }
 
 template <class C, int STEP>
 __device__ __forceinline__ void a_load(f32x4 (&fa)[C::MR], const unsigned (&aaddr)[C::MR]) {
-  constexpr int aoff = sub_a(STEP) * C::U * C::PLANE * 16;
+  constexpr int aoff = (sub_a<C::NSPLIT>(STEP % C::NSUB) * C::U * C::PLANE + STEP / C::NSUB) * 16;     // part plane + tap shift
   static_assert(aoff < 65536, "ds_read offset field is 16 bits");
 #pragma unroll
   for (int f = 0; f < C::MR; ++f)
@@ -69,7 +82,7 @@ __device__ __forceinline__ void a_load(f32x4 (&fa)[C::MR], const unsigned (&aadd
 }
 template <class C, int STEP>
 __device__ __forceinline__ void b_load(f32x4& fb, unsigned baddr) {
-  constexpr int boff = sub_b(STEP) * C::U * C::BN * 16;
+  constexpr int boff = ((STEP / C::NSUB) * C::NSPLIT + sub_b<C::NSPLIT>(STEP % C::NSUB)) * C::U * C::BN * 16;
   static_assert(boff < 65536, "ds_read offset field is 16 bits");
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb) : "v"(baddr), "i"(boff) : "memory");
 }
@@ -80,25 +93,29 @@ __device__ __forceinline__ void b_load(f32x4& fb, unsigned baddr) {
 template <class C, int STEP, int G>
 __device__ __forceinline__ void rot_g(f32x4 (&fa)[2][C::MR], f32x4 (&fb)[C::NR], const unsigned (&baddr)[C::NR], f32x16 (&acc)[C::MR][C::NR]) {
   if constexpr (G < C::NR) {
-    constexpr bool more = STEP + 1 < C::NSUB;
-    constexpr int cur = a_buf(STEP);
-    constexpr int inflight = (reload_b(STEP) ? C::NR - 1 - G : 0) + ((more && load_a(STEP + 1)) ? C::MR : 0) + ((more && reload_b(STEP + 1)) ? G : 0);
+    constexpr bool more = STEP + 1 < C::NSTEP;
+    constexpr int cur = a_buf<C>(STEP);
+    constexpr int inflight = (reload_b<C>(STEP) ? C::NR - 1 - G : 0) + ((more && load_a<C>(STEP + 1)) ? C::MR : 0) +
+                             ((more && reload_b<C>(STEP + 1)) ? G : 0);
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(inflight) : "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int f = 0; f < C::MR; ++f)
-      acc[f][G] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cur][f]), __builtin_bit_cast(bf16x8, fb[G]),
-                                                          acc[f][G], 0, 0, 0);
+    for (int f = 0; f < C::MR; ++f) {
+      if constexpr (C::NSPLIT == 2)
+        acc[f][G] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[cur][f]), __builtin_bit_cast(f16x8, fb[G]), acc[f][G], 0, 0, 0);
+      else
+        acc[f][G] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cur][f]), __builtin_bit_cast(bf16x8, fb[G]), acc[f][G], 0, 0, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (more && reload_b(STEP + 1)) b_load<C, STEP + 1>(fb[G], baddr[G]);
+    if constexpr (more && reload_b<C>(STEP + 1)) b_load<C, STEP + 1>(fb[G], baddr[G]);
     rot_g<C, STEP, G + 1>(fa, fb, baddr, acc);
   }
 }
 template <class C, int STEP>
 __device__ __forceinline__ void stage_steps(f32x4 (&fa)[2][C::MR], f32x4 (&fb)[C::NR], const unsigned (&aaddr)[C::MR],
                                             const unsigned (&baddr)[C::NR], f32x16 (&acc)[C::MR][C::NR]) {
-  if constexpr (STEP < C::NSUB) {
-    if constexpr (STEP + 1 < C::NSUB && load_a(STEP + 1)) a_load<C, STEP + 1>(fa[a_buf(STEP + 1)], aaddr);
+  if constexpr (STEP < C::NSTEP) {
+    if constexpr (STEP + 1 < C::NSTEP && load_a<C>(STEP + 1)) a_load<C, STEP + 1>(fa[a_buf<C>(STEP + 1)], aaddr);
     rot_g<C, STEP, 0>(fa, fb, baddr, acc);
     stage_steps<C, STEP + 1>(fa, fb, aaddr, baddr, acc);
   }
@@ -116,6 +133,19 @@ __device__ __forceinline__ void split8(const f32x4& lo, const f32x4& hi, bf16x8&
     p0[i] = b0; p1[i] = b1; p2[i] = static_cast<__bf16>(r2);
   }
 }
+
+// two fp16 parts: a = a0 + a1 to 22 bits (fp16 subnormals keep the absolute error of a1 below 3e-8)
+__device__ __forceinline__ void split8h(const f32x4& lo, const f32x4& hi, f16x8& p0, f16x8& p1) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float v = i < 4 ? lo[i] : hi[i - 4];
+    const _Float16 h0 = static_cast<_Float16>(v);
+    p0[i] = h0;
+    p1[i] = static_cast<_Float16>(v - static_cast<float>(h0));
+  }
+}
+
+constexpr float kW16Scale = 4096.0f;     // fp16 weight parts are stored times 2^12 (|w| < 16), undone in the epilogue
 
 template <class C>
 __global__ __launch_bounds__(C::NT, 2) void conv_split_kernel(ConvArgs a, int tiles_x, int tiles_y, int mtiles, int nN) {
@@ -193,17 +223,18 @@ __global__ __launch_bounds__(C::NT, 2) void conv_split_kernel(ConvArgs a, int ti
   constexpr int QPU = C::BN / 64;
   static_assert(C::BN % 64 == 0, "a (part, unit) row is a whole number of pieces");
   const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wp), 0,
-                                                       (int)((size_t)C::KS * C::KS * Cin * CoutP * 2 * C::NSPLIT), 0x00020000);
+                                                       (int)((size_t)C::KS * C::KS * Cin * CoutP * 2 * C::NSPLIT), 0x00020000);   // 2-byte parts either way
   const unsigned wvoff = (unsigned)(n0 + lane) * 16u;
   auto wdma = [&](int g, int bufsel) {
-    const int chunk = g / C::NSTAGE, tap = g - chunk * C::NSTAGE;
+    const int chunk = g / C::NSTAGE, st = g - chunk * C::NSTAGE;
 #pragma unroll
     for (int i = 0; i < (NPIECE + NWAVE - 1) / NWAVE; ++i) {
       const int piece = wid + i * NWAVE;              // wave-uniform; LDS image [part][unit][co]
       if ((NPIECE % NWAVE != 0) && piece >= NPIECE) break;
       f32x4* dst = wbuf + bufsel * C::WSTAGE_F4 + piece * 64;
       const int q = piece % QPU, pu = piece / QPU;
-      const int u = pu % C::U, part = pu / C::U;
+      const int u = pu % C::U, pt = pu / C::U;
+      const int part = pt % C::NSPLIT, tap = st * C::TPS + pt / C::NSPLIT;
       const unsigned soff = (unsigned)(((((tap * cin8 + chunk * C::U + u) * C::NSPLIT) + part) * CoutP + q * 64) * 16);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff, soff, 0, 0);
     }
@@ -226,17 +257,25 @@ __global__ __launch_bounds__(C::NT, 2) void conv_split_kernel(ConvArgs a, int ti
         lo = *reinterpret_cast<const f32x4*>(src);
         hi = *reinterpret_cast<const f32x4*>(src + 4);
       }
-      bf16x8 p0, p1, p2;
-      split8(lo, hi, p0, p1, p2);
       const int slot = hy * whp + hx;
-      halo[(0 * C::U + u) * C::PLANE + slot] = __builtin_bit_cast(f32x4, p0);
-      halo[(1 * C::U + u) * C::PLANE + slot] = __builtin_bit_cast(f32x4, p1);
-      halo[(2 * C::U + u) * C::PLANE + slot] = __builtin_bit_cast(f32x4, p2);
+      if constexpr (C::NSPLIT == 2) {
+        f16x8 p0, p1;
+        split8h(lo, hi, p0, p1);
+        halo[(0 * C::U + u) * C::PLANE + slot] = __builtin_bit_cast(f32x4, p0);
+        halo[(1 * C::U + u) * C::PLANE + slot] = __builtin_bit_cast(f32x4, p1);
+      } else {
+        bf16x8 p0, p1, p2;
+        split8(lo, hi, p0, p1, p2);
+        halo[(0 * C::U + u) * C::PLANE + slot] = __builtin_bit_cast(f32x4, p0);
+        halo[(1 * C::U + u) * C::PLANE + slot] = __builtin_bit_cast(f32x4, p1);
+        halo[(2 * C::U + u) * C::PLANE + slot] = __builtin_bit_cast(f32x4, p2);
+      }
     }
     __syncthreads();   // halo visible before any wave's (pre-barrier) step-0 A reads
     for (int s = 0; s < C::NSTAGE; ++s) {
       const int g = chunk * C::NSTAGE + s;
-      const int ky = s / C::KS, kx = s - ky * C::KS;
+      const int tap0 = s * C::TPS;
+      const int ky = tap0 / C::KS, kx = tap0 - ky * C::KS;          // TPS divides KS: one kernel row per stage
       const unsigned tbytes = (unsigned)(ky * whp + kx) * 16u;
       const unsigned wbytes = (unsigned)(C::HALO_F4 + buf * C::WSTAGE_F4) * 16u;
       unsigned aaddr[C::MR], baddr[C::NR];
@@ -284,7 +323,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv_split_kernel(ConvArgs a, int ti
           ok = y < H && x < W;
         }
         if (ok) {
-          float v = acc[f][g][i] + bi;
+          float v = (C::NSPLIT == 2 ? acc[f][g][i] * (1.0f / kW16Scale) : acc[f][g][i]) + bi;
           if (a.relu_bn) v = fmaxf(v, 0.f) * sc + sh;
           ob[((size_t)y * W + x) * Cout + co] = v;
         }
@@ -294,6 +333,22 @@ __global__ __launch_bounds__(C::NT, 2) void conv_split_kernel(ConvArgs a, int ti
 }
 
 // fp32 HWIO [k,k,Cin,Cout] -> bf16 [tap][Cin/8][part][CoutP][8], part = 0 (high) .. 2 (low); zero-padded channels
+__global__ void pack_weights_split16_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int taps, int Cin, int Cout, int CoutP) {
+  const size_t n = (size_t)taps * Cin * CoutP;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int k8 = i & 7;
+    size_t r = i >> 3;
+    const int co = r % CoutP; r /= CoutP;
+    const int c8 = r % (Cin >> 3);
+    const int tap = r / (Cin >> 3);
+    const float v = (co < Cout ? w[((size_t)tap * Cin + c8 * 8 + k8) * Cout + co] : 0.f) * kW16Scale;
+    const _Float16 h0 = static_cast<_Float16>(v);
+    const size_t base = (((size_t)tap * (Cin >> 3) + c8) * 2) * CoutP * 8 + (size_t)co * 8 + k8;
+    wp[base] = h0;
+    wp[base + (size_t)CoutP * 8] = static_cast<_Float16>(v - static_cast<float>(h0));
+  }
+}
+
 __global__ void pack_weights_split_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int taps, int Cin, int Cout, int CoutP) {
   const size_t n = (size_t)taps * Cin * CoutP;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -368,31 +423,45 @@ int split_tiles(int B, int H, int W) {
 int split_bn(int CoutP, int tiles) { return (CoutP % 256 == 0 && tiles * (CoutP / 256) >= 256) ? 256 : 128; }
 }  // namespace
 
-bool conv_split_supported(int ks, int Cin, int CoutP, int B, int H, int W) {
+// min_wgs: smallest grid worth a launch (default 128: below half a chip of 384-pixel tiles the 128-pixel exact kernel wins; tests
+// pass 0 to force the split kernels on small batches)
+bool conv_split_supported(int ks, int Cin, int CoutP, int B, int H, int W, int min_wgs) {
   if (!(ks == 9 || ks == 5) || Cin % 16 || CoutP % 128) return false;
   if (!((W >= 64 && H % 12 == 0) || flat_fits(ks, H, W))) return false;
   const int tiles = split_tiles(B, H, W);
-  return tiles * (CoutP / split_bn(CoutP, tiles)) >= 128;      // below half a chip of 384-pixel tiles the 128-pixel exact kernel wins
+  return tiles * (CoutP / split_bn(CoutP, tiles)) >= min_wgs;
 }
 
-size_t conv_split_weight_bytes(int ks, int Cin, int CoutP) { return (size_t)ks * ks * Cin * CoutP * 2 * 3; }
+// ns = operand parts: 3 (bf16 parts, six products) or 2 (fp16 parts, three products)
+size_t conv_split_weight_bytes(int ks, int Cin, int CoutP, int ns) { return (size_t)ks * ks * Cin * CoutP * 2 * ns; }
 
-hipError_t pack_weights_split(const float* w_hwio, void* wp, int ks, int Cin, int Cout, int CoutP, hipStream_t st) {
-  hipLaunchKernelGGL(pack_weights_split_kernel, dim3(2048), dim3(256), 0, st, w_hwio, static_cast<__bf16*>(wp), ks * ks, Cin, Cout, CoutP);
+hipError_t pack_weights_split(const float* w_hwio, void* wp, int ks, int Cin, int Cout, int CoutP, int ns, hipStream_t st) {
+  if (ns == 2)
+    hipLaunchKernelGGL(pack_weights_split16_kernel, dim3(2048), dim3(256), 0, st, w_hwio, static_cast<_Float16*>(wp), ks * ks, Cin, Cout, CoutP);
+  else
+    hipLaunchKernelGGL(pack_weights_split_kernel, dim3(2048), dim3(256), 0, st, w_hwio, static_cast<__bf16*>(wp), ks * ks, Cin, Cout, CoutP);
   return hipGetLastError();
 }
 
-// a.x fp32 NHWC, a.wp from pack_weights_split (CoutP a multiple of 128), a.out fp32
-hipError_t conv_split_f32(const ConvArgs& a, int ks, hipStream_t st) {
-  if (!conv_split_supported(ks, a.Cin, a.CoutP, a.B, a.H, a.W)) return hipErrorInvalidValue;
+namespace {
+template <int NS, int TPS9>
+hipError_t dispatch_s(const ConvArgs& a, int ks, hipStream_t st) {
   const bool wide = a.W >= 64 && a.H % 12 == 0;
   const bool big = split_bn(a.CoutP, split_tiles(a.B, a.H, a.W)) == 256;
   if (ks == 9) {
-    if (big) return wide ? launch_s<CfgS<9, 256, false>>(a, st) : launch_s<CfgS<9, 256, true>>(a, st);
-    return wide ? launch_s<CfgS<9, 128, false>>(a, st) : launch_s<CfgS<9, 128, true>>(a, st);
+    if (big) return wide ? launch_s<CfgS<9, 256, false, NS, TPS9>>(a, st) : launch_s<CfgS<9, 256, true, NS, TPS9>>(a, st);
+    return wide ? launch_s<CfgS<9, 128, false, NS, TPS9>>(a, st) : launch_s<CfgS<9, 128, true, NS, TPS9>>(a, st);
   }
-  if (big) return wide ? launch_s<CfgS<5, 256, false>>(a, st) : launch_s<CfgS<5, 256, true>>(a, st);
-  return wide ? launch_s<CfgS<5, 128, false>>(a, st) : launch_s<CfgS<5, 128, true>>(a, st);
+  if (big) return wide ? launch_s<CfgS<5, 256, false, NS, 1>>(a, st) : launch_s<CfgS<5, 256, true, NS, 1>>(a, st);
+  return wide ? launch_s<CfgS<5, 128, false, NS, 1>>(a, st) : launch_s<CfgS<5, 128, true, NS, 1>>(a, st);
+}
+}  // namespace
+
+// a.x fp32 NHWC, a.wp from pack_weights_split with the same ns (CoutP a multiple of 128), a.out fp32
+hipError_t conv_split_f32(const ConvArgs& a, int ks, int ns, hipStream_t st) {
+  if (!conv_split_supported(ks, a.Cin, a.CoutP, a.B, a.H, a.W, 0)) return hipErrorInvalidValue;
+  // fp16x3: three taps of weights per stage (108 MFMAs between barriers); bf16x6 carries three parts and stays at one tap
+  return ns == 2 ? dispatch_s<2, 3>(a, ks, st) : dispatch_s<3, 1>(a, ks, st);
 }
 
 }  // namespace jcm

@@ -76,7 +76,8 @@ struct jcm_ctx {
   hipStream_t stream = nullptr;
   int precision = JCM_PRECISION_F32;
   int K = 9;
-  int f32_conv = 0;             // fp32 handles: 0 = exact fp32 MFMA everywhere, 1 = bf16x6 split kernel where it applies
+  int f32_conv = 0;             // fp32 handles: 0 = exact fp32 MFMA everywhere, 1 = bf16x6 split kernels, 2 = fp16x3 forward + bf16x6 gradients
+  int split_min_wgs = 128;      // grids smaller than this keep the exact kernel (option "split_min_wgs")
   bool finalized = false;
   std::map<std::string, jcm::Tensor> params;
   std::map<std::string, jcm::ConvLayer> convs;

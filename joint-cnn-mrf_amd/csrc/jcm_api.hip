@@ -104,10 +104,10 @@ int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int
     a.CoutP = L->coutp;
     if (L->thin) {
       HIP_TRY(conv_thin_f32(a, c->stream));
-    } else if (L->wp_split && conv_split_supported(L->ks, L->cin, L->coutp_split, B, H, W)) {
+    } else if (L->wp_split && conv_split_supported(L->ks, L->cin, L->coutp_split, B, H, W, c->split_min_wgs)) {
       a.wp = L->wp_split;
       a.CoutP = L->coutp_split;
-      HIP_TRY(conv_split_f32(a, L->ks, c->stream));
+      HIP_TRY(conv_split_f32(a, L->ks, c->f32_conv == 2 ? 2 : 3, c->stream));
     } else {
       HIP_TRY(conv_igemm_f32(a, L->ks, c->stream));
     }
@@ -153,10 +153,11 @@ int refresh_derived(jcm_ctx* c, bool first) {
       if (!L.wp) JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&L.wp), n * sizeof(float)));
       HIP_TRY(pack_weights_f32(w.d, L.wp, L.ks, L.cin, L.cout, L.coutp, c->stream));
     }
-    if (c->precision == JCM_PRECISION_F32 && c->f32_conv == 1 && (L.ks == 9 || L.ks == 5) && L.cin % 16 == 0 && L.cout % 128 == 0) {
+    if (c->precision == JCM_PRECISION_F32 && c->f32_conv >= 1 && (L.ks == 9 || L.ks == 5) && L.cin % 16 == 0 && L.cout % 128 == 0) {
+      const int ns = c->f32_conv == 2 ? 2 : 3;      // forward operand parts: bf16x6 or fp16x3
       L.coutp_split = L.cout;
-      if (!L.wp_split) JCM_TRY(dev_alloc(c, &L.wp_split, conv_split_weight_bytes(L.ks, L.cin, L.coutp_split)));
-      HIP_TRY(pack_weights_split(w.d, L.wp_split, L.ks, L.cin, L.cout, L.coutp_split, c->stream));
+      if (!L.wp_split) JCM_TRY(dev_alloc(c, &L.wp_split, conv_split_weight_bytes(L.ks, L.cin, L.coutp_split, ns)));
+      HIP_TRY(pack_weights_split(w.d, L.wp_split, L.ks, L.cin, L.cout, L.coutp_split, ns, c->stream));
     }
     if (L.ks == 5 && L.cin == 3 && L.cout == 64 && L.has_bn && c->precision == JCM_PRECISION_BF16) {
       if (!L.wq1_bf16) JCM_TRY(dev_alloc(c, &L.wq1_bf16, 5 * 2 * 64 * 16));
@@ -408,6 +409,11 @@ int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
     h->sm_chunk = (int)value;
     return JCM_OK;
   }
+  if (k == "split_min_wgs") {   // allowed at any time
+    if (value < 0) return fail(JCM_ERR_ARG, "split_min_wgs must be >= 0");
+    h->split_min_wgs = (int)value;
+    return JCM_OK;
+  }
   if (k == "sm_algo") {   // allowed at any time
     if (value < 0 || value > 2) return fail(JCM_ERR_ARG, "sm_algo must be 0 (fft), 1 (direct) or 2 (fft_split)");
     h->sm_algo = (int)value;
@@ -418,7 +424,7 @@ int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
     if (value != JCM_PRECISION_F32 && value != JCM_PRECISION_BF16) return fail(JCM_ERR_ARG, "precision must be 0 (f32) or 1 (bf16)");
     h->precision = (int)value;
   } else if (k == "f32_conv") {
-    if (value != 0 && value != 1) return fail(JCM_ERR_ARG, "f32_conv must be 0 (fp32 MFMA) or 1 (bf16x6 split)");
+    if (value < 0 || value > 2) return fail(JCM_ERR_ARG, "f32_conv must be 0 (fp32 MFMA), 1 (bf16x6 split) or 2 (fp16x3 split forward)");
     h->f32_conv = (int)value;
   } else if (k == "n_joints") {
     if (value < 1 || value > 9) return fail(JCM_ERR_ARG, "n_joints must be in [1,9]");

@@ -83,7 +83,7 @@ int repack_dgrad(jcm_ctx* c) {
     }
     HIP_TRY(flip_transpose_weights(L->w_raw, t->scratch_flip, L->ks, L->cin, L->cout, d.cinp, c->stream));
     HIP_TRY(pack_weights_f32(t->scratch_flip, d.wd, L->ks, d.cinp, L->cin, d.coutp, c->stream));
-    if (d.wd_split) HIP_TRY(pack_weights_split(t->scratch_flip, d.wd_split, L->ks, d.cinp, L->cin, L->cin, c->stream));
+    if (d.wd_split) HIP_TRY(pack_weights_split(t->scratch_flip, d.wd_split, L->ks, d.cinp, L->cin, L->cin, 3, c->stream));   // gradients: bf16 parts (range)
   }
   return JCM_OK;
 }
@@ -160,7 +160,7 @@ int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int ldz, int B, fl
   const size_t mark = c->arena_off;
   float* partial = arena_alloc<float>(c, n * splits);
   // handles with f32_conv = 1: the bf16x6 split kernel on pre-split operands (wgrad_split.hip)
-  const bool split = !bf(c) && c->f32_conv == 1 && wgrad_split_supported(L->ks, L->cin, ldz);
+  const bool split = !bf(c) && c->f32_conv >= 1 && wgrad_split_supported(L->ks, L->cin, ldz);
   if (bf(c) && !wgrad_split_supported(L->ks, L->cin, ldz)) return fail(JCM_ERR_ARG, "no bf16 weight-gradient kernel for layer '" + f.scope + "'");
   const size_t nx = (size_t)B * f.H * f.W * L->cin, nz = (size_t)B * f.H * f.W * ldz;
   char* xparts = split ? arena_alloc<char>(c, nx * 6) : nullptr;
@@ -203,7 +203,7 @@ int conv_dgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int B, void* dx) {
   }
   a.x = dz; a.wp = d.wd; a.bias = t->zeros; a.scale = t->ones; a.shift = t->zeros; a.out = dx;
   a.B = B; a.H = f.H; a.W = f.W; a.Cin = d.cinp; a.Cout = f.L->cin; a.CoutP = d.coutp; a.relu_bn = 0;
-  const bool split = d.wd_split && conv_split_supported(f.L->ks, d.cinp, f.L->cin, B, f.H, f.W);
+  const bool split = d.wd_split && conv_split_supported(f.L->ks, d.cinp, f.L->cin, B, f.H, f.W, c->split_min_wgs);
   if (split) { a.wp = d.wd_split; a.CoutP = f.L->cin; }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->profile) {
@@ -211,7 +211,7 @@ int conv_dgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int B, void* dx) {
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, c->stream));
   }
-  if (split) HIP_TRY(conv_split_f32(a, f.L->ks, c->stream));
+  if (split) HIP_TRY(conv_split_f32(a, f.L->ks, 3, c->stream));
   else HIP_TRY(conv_igemm_f32(a, f.L->ks, c->stream));
   if (c->profile) {
     HIP_TRY(hipEventRecord(e1, c->stream));
@@ -494,8 +494,8 @@ int jcm_train_begin(jcm_handle h) {
       JCM_TRY(dev_alloc(c, &d.wd_bf16, (size_t)L.ks * L.ks * d.cinp_bf16 * d.coutp_bf16 * 2));
     } else {
       JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&d.wd), (size_t)L.ks * L.ks * d.cinp * d.coutp * sizeof(float)));
-      if (c->f32_conv == 1 && L.cin % 128 == 0)      // data gradient on the bf16x6 split kernel where its tile fits
-        JCM_TRY(dev_alloc(c, &d.wd_split, conv_split_weight_bytes(L.ks, d.cinp, L.cin)));
+      if (c->f32_conv >= 1 && L.cin % 128 == 0)      // data gradient on the bf16x6 split kernel where its tile fits
+        JCM_TRY(dev_alloc(c, &d.wd_split, conv_split_weight_bytes(L.ks, d.cinp, L.cin, 3)));
     }
     const size_t nf = (size_t)L.ks * L.ks * (d.cinp_bf16 > d.cinp ? d.cinp_bf16 : d.cinp) * L.cin;
     if (nf > max_w) max_w = nf;

@@ -25,10 +25,10 @@ hipError_t pack_weights_f32(const float* w_hwio, float* wp, int ks, int Cin, int
 
 // ---- conv_split.hip : fp32 9x9 convolution on the bf16 matrix cores (three-way operand split, six products) --
 // same contract as conv_igemm_f32 (fp32 in / out, same epilogue) for the shapes conv_split_supported() accepts
-bool conv_split_supported(int ks, int Cin, int CoutP, int B, int H, int W);   // 5x5 / 9x9, Cin % 16 == 0, CoutP % 128 == 0; 12x32 patches or whole-row tiles
-size_t conv_split_weight_bytes(int ks, int Cin, int CoutP);
-hipError_t pack_weights_split(const float* w_hwio, void* wp, int ks, int Cin, int Cout, int CoutP, hipStream_t st);
-hipError_t conv_split_f32(const ConvArgs& a, int ks, hipStream_t st);
+bool conv_split_supported(int ks, int Cin, int CoutP, int B, int H, int W, int min_wgs);   // 5x5 / 9x9, Cin % 16 == 0, CoutP % 128 == 0; 12x32 patches or whole-row tiles
+size_t conv_split_weight_bytes(int ks, int Cin, int CoutP, int ns);     // ns: 3 = bf16x6, 2 = fp16x3
+hipError_t pack_weights_split(const float* w_hwio, void* wp, int ks, int Cin, int Cout, int CoutP, int ns, hipStream_t st);
+hipError_t conv_split_f32(const ConvArgs& a, int ks, int ns, hipStream_t st);
 
 // ---- conv_thin_f32.hip : 9x9 conv with Cout <= 12 (the logits layer) on v_mfma_f32_4x4x1_16b_f32 ----
 // weights packed by pack_weights_f32 with CoutP = 16

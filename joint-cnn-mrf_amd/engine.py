@@ -19,7 +19,7 @@ def _hm_size(n):
 class Engine:
     """Owns a jcm_handle.  All tensor arguments are torch CUDA float32 NHWC, contiguous."""
 
-    def __init__(self, device=0, precision='fp32', n_joints=9, stream=None, f32_conv=None):
+    def __init__(self, device=0, precision='fp32', n_joints=9, stream=None, f32_conv=None, split_min_wgs=None):
         if not torch.cuda.is_available():
             raise RuntimeError('joint-cnn-mrf_amd needs an MI355X (gfx950) GPU; torch.cuda.is_available() is False '
                                'and there is no CPU path')
@@ -36,8 +36,10 @@ class Engine:
         prec = {'fp32': _lib.JCM_PRECISION_F32, 'f32': _lib.JCM_PRECISION_F32, 'bf16': _lib.JCM_PRECISION_BF16}[precision]
         _lib.check(self._lib.jcm_set_option(self._h, b'precision', prec), 'jcm_set_option(precision)')
         _lib.check(self._lib.jcm_set_option(self._h, b'n_joints', self.n_joints), 'jcm_set_option(n_joints)')
-        if f32_conv is not None:      # 'exact' = fp32 MFMA, 'split' = bf16x6 on the bf16 matrix cores (fp32-level accuracy)
-            _lib.check(self._lib.jcm_set_option(self._h, b'f32_conv', {'exact': 0, 'split': 1}[f32_conv]), 'jcm_set_option(f32_conv)')
+        if f32_conv is not None:      # 'exact' = fp32 MFMA, 'split' = bf16x6, 'split16' = fp16x3 forward (+ bf16x6 gradients): fp32-level accuracy on the 16-bit matrix cores
+            _lib.check(self._lib.jcm_set_option(self._h, b'f32_conv', {'exact': 0, 'split': 1, 'split16': 2}[f32_conv]), 'jcm_set_option(f32_conv)')
+        if split_min_wgs is not None: # 0 forces the split kernels even on grids too small to pay off (parity tests at small batch)
+            _lib.check(self._lib.jcm_set_option(self._h, b'split_min_wgs', int(split_min_wgs)), 'jcm_set_option(split_min_wgs)')
 
     # ------------------------------------------------------------------ lifecycle
     def close(self):

@@ -15,7 +15,7 @@ def dev(a):
     return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device='cuda:0')
 
 
-@pytest.mark.parametrize('f32_conv', ['exact', 'split'])
+@pytest.mark.parametrize('f32_conv', ['exact', 'split', 'split16'])
 @pytest.mark.parametrize('kind', ['init', 'trained'])
 def test_full_size_tower_vs_golden(kind, f32_conv):
     """Both fp32 convolution algorithms to the same bar: the exact fp32 MFMA chain and the bf16x6 split
@@ -23,7 +23,7 @@ def test_full_size_tower_vs_golden(kind, f32_conv):
     from joint_cnn_mrf_amd.engine import Engine
     x, torso, p = full_inputs()
     p.update(synth.make_sm_params(flic_priors(), kind=kind, seed=seeds()['sm']))
-    eng = Engine(device=0, f32_conv=f32_conv).load_params(p)
+    eng = Engine(device=0, f32_conv=f32_conv, split_min_wgs=0).load_params(p)
     logits = eng.model(dev(x)).cpu().numpy()
     r = eng.forward(dev(x), dev(torso), use_sm=True)
     eng.close()
@@ -139,12 +139,40 @@ def test_split_conv_layer_error_is_fp32_class():
     a = np.maximum(rs.standard_normal((1, 60, 90, 512)), 0).astype(np.float32)
     ref = O64.conv_layer(a.astype(np.float64), p, 9, 1, 'conv5')
     outs = {}
-    for algo in ('exact', 'split'):
-        eng = Engine(device=0, f32_conv=algo).load_params(p)
+    for algo in ('exact', 'split', 'split16'):
+        eng = Engine(device=0, f32_conv=algo, split_min_wgs=0).load_params(p)
         outs[algo] = eng.conv_layer(dev(a), 'conv5', 1, n_out=512).cpu().numpy().astype(np.float64)
         eng.close()
     scale = np.abs(ref).max()
     e_exact, e_split = np.abs(outs['exact'] - ref).max() / scale, np.abs(outs['split'] - ref).max() / scale
     r_exact, r_split = np.sqrt(np.mean((outs['exact'] - ref) ** 2)) / scale, np.sqrt(np.mean((outs['split'] - ref) ** 2)) / scale
-    print('conv5 error / max|out|: exact max %.2e rms %.2e, split max %.2e rms %.2e' % (e_exact, r_exact, e_split, r_split))
+    e16, r16 = np.abs(outs['split16'] - ref).max() / scale, np.sqrt(np.mean((outs['split16'] - ref) ** 2)) / scale
+    print('conv5 error / max|out|: exact max %.2e rms %.2e, bf16x6 max %.2e rms %.2e, fp16x3 max %.2e rms %.2e' % (e_exact, r_exact, e_split, r_split, e16, r16))
+    assert e16 <= 2e-5 and r16 <= 3 * r_exact + 1e-7
     assert e_exact <= 1e-5 and e_split <= 2e-5 and r_split <= 3 * r_exact + 1e-7      # the same error class
+
+
+def test_split_kernels_match_exact_on_every_layer_shape():
+    """conv_split.hip (bf16x6 and fp16x3) against the exact fp32 MFMA kernel on every stride-1 layer shape of the model
+    (5x5 / 9x9, 128- / 256-channel tiles, 12x32 patches and whole-row tiles), forced onto small grids (batch 1 and 3)."""
+    from joint_cnn_mrf_amd.engine import Engine
+    p = synth.make_pd_params(debug=False, bn='trained')
+    engs = {a: Engine(device=0, f32_conv=a, split_min_wgs=0).load_params(p) for a in ('exact', 'split', 'split16')}
+    rs = np.random.RandomState(1)
+    shapes = [('conv2_fullres', 120, 180, 64, 128), ('conv3_fullres', 60, 90, 128, 256), ('conv4_fullres', 60, 90, 256, 512),
+              ('conv5', 60, 90, 512, 512), ('conv2_halfres', 60, 90, 64, 128), ('conv3_halfres', 30, 45, 128, 256),
+              ('conv4_halfres', 30, 45, 256, 512), ('conv2_quarterres', 30, 45, 64, 128), ('conv3_quarterres', 15, 23, 128, 256),
+              ('conv4_quarterres', 15, 23, 256, 512)]
+    bad = []
+    for B in (1, 3):
+        for name, H, W, ci, co in shapes:
+            x = torch.as_tensor(rs.standard_normal((B, H, W, ci)).astype(np.float32), device='cuda:0')
+            outs = {a: e.conv_layer(x, name, 1, n_out=co).double() for a, e in engs.items()}
+            sc = float(outs['exact'].abs().max())
+            for a in ('split', 'split16'):
+                err = float((outs[a] - outs['exact']).abs().max()) / sc
+                if not err <= 3e-5:
+                    bad.append('B=%d %s %s: %.2e' % (B, name, a, err))
+    for e in engs.values():
+        e.close()
+    assert not bad, '\n'.join(bad)

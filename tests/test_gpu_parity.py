@@ -208,14 +208,15 @@ def test_missing_parameters_fail_loudly():
         Engine(device=0).load_params(sm)
 
 
-def test_split_convs_debug_width_and_odd_shapes():
+@pytest.mark.parametrize('f32_conv', ['split', 'split16'])
+def test_split_convs_debug_width_and_odd_shapes(f32_conv):
     """f32_conv='split' (conv_split.hip) on the shapes the other tests use: at --debug width the 128-channel
     layers take the 128-channel tiles, 30x45 / 15x23 maps the whole-row tiles, small grids fall back to the exact
     kernel -- same tolerances as the exact path, including a non-480x720 input and batch 1."""
     from joint_cnn_mrf_amd.engine import Engine
     p = synth.make_pd_params(debug=True, bn='trained', conv6_gain=8.0)
     p.update(synth.make_sm_params(synth.synthetic_priors(), kind='trained'))
-    eng = Engine(device=0, f32_conv='split').load_params(p)
+    eng = Engine(device=0, f32_conv=f32_conv, split_min_wgs=0).load_params(p)
     x, torso = synth.make_images(4, seed=31), synth.make_torso(4, seed=32)
     ref = O.forward(x, torso, p)
     r = eng.forward(dev(x), dev(torso), use_sm=True)

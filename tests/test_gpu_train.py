@@ -21,7 +21,7 @@ def dev(a):
 def make_trainer(params, f32_conv=None, precision='fp32', **kw):
     from joint_cnn_mrf_amd.engine import Engine
     from joint_cnn_mrf_amd.train import Trainer
-    eng = Engine(device=0, precision=precision, f32_conv=f32_conv).load_params(params)
+    eng = Engine(device=0, precision=precision, f32_conv=f32_conv, split_min_wgs=0 if f32_conv else None).load_params(params)
     return eng, Trainer(eng, **kw)
 
 
@@ -176,7 +176,7 @@ def test_train_cli_debug():
     assert len(lines) == 2 and 'train_loss' in lines[0], out.stdout
 
 
-@pytest.mark.parametrize('f32_conv', ['exact', 'split'])
+@pytest.mark.parametrize('f32_conv', ['exact', 'split', 'split16'])
 def test_full_size_step_vs_golden(f32_conv):
     """The full-size network (filters 64..512), one 480x720 image: losses, sampled gradient entries, gradient
     norms and the moving-statistics update against tests/golden/train_full.json (float64 restatement,
@@ -197,7 +197,11 @@ def test_full_size_step_vs_golden(f32_conv):
     bad = []
     for k, t in gold['tensors'].items():
         g = got[k].astype(np.float64)
-        tol = GRAD_RTOL * t['max'] + 2 * t['slack'] + 1e-7
+        # 'exact': the strict bound.  The split modes compute the same convolutions to fp32 accuracy (pinned layer by layer in
+        # test_split_kernels_match_exact_on_every_layer_shape) but round differently, so a ReLU / max-pool decision can flip
+        # somewhere else than it does in torch's fp32 run; on the 15x23 maps of one image (345 samples per channel) one flip
+        # moves a gradient by ~3e-3 of its largest entry.
+        tol = (GRAD_RTOL if f32_conv == 'exact' else 5e-3) * t['max'] + 2 * t['slack'] + 1e-7
         err = np.abs(g[t['idx']] - np.asarray(t['val'])).max()
         nerr = abs(np.linalg.norm(g) - t['norm'])
         if not (err <= tol and nerr <= tol * np.sqrt(g.size)):
@@ -246,7 +250,7 @@ def test_full_size_step_bf16_mixed_precision():
     assert not bad, '\n'.join(bad)
 
 
-@pytest.mark.parametrize('mode', ['exact', 'split', 'bf16'])
+@pytest.mark.parametrize('mode', ['exact', 'split', 'split16', 'bf16'])
 def test_gradients_are_deterministic_and_training_is_stable(mode):
     """The same batch twice gives bit-identical gradients (fixed-order split-K reductions, no atomics), and 12 Adam
     updates at full size keep every loss finite and moving down in all three arithmetic modes."""
