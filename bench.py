@@ -219,7 +219,7 @@ def main():
                     help='default: the headline line is configs[1] (fp32, batch 64) and configs[2] (bf16, batch 256) '
                          'is measured too and reported under "bf16_config2"')
     ap.add_argument('--no-sm', action='store_true', help='part detector only')
-    ap.add_argument('--f32-conv', default=None, choices=['exact', 'split'], help='fp32 convolution algorithm of the headline run (default exact)')
+    ap.add_argument('--f32-conv', default=None, choices=['exact', 'split', 'split16'], help='fp32 convolution algorithm of the headline run (default exact)')
     ap.add_argument('--debug', action='store_true', help='filters/4 (main.py:40-41); not the headline config, fp32 only')
     ap.add_argument('--cpu-images', type=int, default=4, help='size of the cpu_baseline sample (0 = skip)')
     ap.add_argument('--train', action='store_true', help='time the joint training step (configs[4]) instead of the forward; fp32, '

@@ -200,8 +200,8 @@ def test_full_size_step_vs_golden(f32_conv):
         # 'exact': the strict bound.  The split modes compute the same convolutions to fp32 accuracy (pinned layer by layer in
         # test_split_kernels_match_exact_on_every_layer_shape) but round differently, so a ReLU / max-pool decision can flip
         # somewhere else than it does in torch's fp32 run; on the 15x23 maps of one image (345 samples per channel) one flip
-        # moves a gradient by ~3e-3 of its largest entry.
-        tol = (GRAD_RTOL if f32_conv == 'exact' else 5e-3) * t['max'] + 2 * t['slack'] + 1e-7
+        # moves a gradient by up to ~1e-2 of its largest entry (measured 8e-3).
+        tol = (GRAD_RTOL if f32_conv == 'exact' else 1e-2) * t['max'] + 2 * t['slack'] + 1e-7
         err = np.abs(g[t['idx']] - np.asarray(t['val'])).max()
         nerr = abs(np.linalg.norm(g) - t['norm'])
         if not (err <= tol and nerr <= tol * np.sqrt(g.size)):
