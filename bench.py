@@ -116,7 +116,8 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
             'value': value, 'ms_per_step': dt / args.steps * 1e3, 'dtype': 'f32' if dtype == 'fp32' else 'bf16',
             'config': {'workload': '%s: batch=%d/GPU synthetic 480x720x3, part detector%s forward + argmax, %s%s'
                                    % ('configs[1]' if dtype == 'fp32' else 'configs[2]', B, ' + spatial model' if use_sm else '',
-                                      dtype + (' operands, 60x90 9x9 layers as bf16x6 split MFMA' if f32_conv == 'split' else ''),
+                                      dtype + (' operands, stride-1 layers as bf16x6 split MFMA' if f32_conv == 'split' else
+                                               ' operands, stride-1 layers as fp16x3 split MFMA' if f32_conv == 'split16' else ''),
                                       ', DEBUG filters/4' if args.debug else ''),
                        'batch_per_gpu': B, 'global_batch': world * B, 'use_sm': use_sm,
                        'collective': 'all_gather coords int32 [B,2,9]'},
@@ -124,9 +125,11 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm 9x9, 60x90 maps (conv4_fullres + conv5 launches; %s)'
                                    % ('fp32 operands as 3 bf16 parts, 6 x bf16 MFMA 32x32x16 per k16 step, 12x32 patch x 256 ch; achieved = fp32-equivalent FLOPs'
                                       if f32_conv == 'split' else
+                                      'fp32 operands as 2 fp16 parts, 3 x fp16 MFMA 32x32x16 per k16 step, 12x32 patch x 256 ch; achieved = fp32-equivalent FLOPs'
+                                      if f32_conv == 'split16' else
                                       'fp32 MFMA 32x32x2, 4x32 patch x 128 ch' if dtype == 'fp32' else 'bf16 MFMA 32x32x16, 12x32 patch x 256 ch'),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None,
-                         'traffic': pmc_traffic('%s%s_b%d' % (dtype, '_split' if f32_conv == 'split' else '', B)) if not args.debug else None,
+                         'traffic': pmc_traffic('%s%s_b%d' % (dtype, '_' + f32_conv if f32_conv in ('split', 'split16') else '', B)) if not args.debug else None,
                          'launch_ms': launch_ms, 'launches': tot_n, 'flops_per_launch': flops_launch},
         }
     eng.close()
@@ -178,7 +181,7 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
         scale = 16 if args.debug else 1
         # dominant training kernels: the three conv5 passes, each 229.3 GFLOP per image (60x90 px, 81 taps, 512x512)
         kern = {}
-        sp = f32_conv == 'split' and prec == 'fp32'
+        sp = f32_conv in ('split', 'split16') and prec == 'fp32'
         for key, what in (('conv5', 'forward, ' + ('conv_split_kernel' if sp else 'conv_igemm_f32')),
                           ('dgrad:conv5', 'data gradient, ' + ('conv_split_kernel' if sp else 'conv_igemm_f32') + ' on flipped weights'),
                           ('wgrad:conv5', 'weight gradient, ' + ('wgrad_split_kernel<9>' if sp else 'wgrad_kernel<9>'))):
@@ -191,7 +194,8 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if prec == 'fp32' else 'bf16', 'data': 'synthetic',
                'config': {'workload': 'configs[4]: joint training, batch=%d/GPU synthetic 480x720x3, %s%s, Adam, clip 4.0%s'
                                       % (B, 'fp32 MFMA' if prec == 'fp32' else 'mixed precision: bf16 activations/gradients + bf16 MFMA, fp32 master weights / statistics / losses / spatial model / optimizer',
-                                         ' operands; forward, data and weight gradients of the stride-1 layers as bf16x6 split MFMA' if f32_conv == 'split' else '',
+                                         ' operands; forward, data and weight gradients of the stride-1 layers as bf16x6 split MFMA' if f32_conv == 'split' else
+                                         ' operands; forward as fp16x3, data and weight gradients as bf16x6 split MFMA' if f32_conv == 'split16' else '',
                                          ', DEBUG filters/4' if args.debug else ''),
                           'batch_per_gpu': B, 'global_batch': world * B, 'use_sm': use_sm,
                           'collective': 'all_reduce of %d fp32 gradients' % tr.n_elements},
@@ -200,7 +204,7 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
                'roofline': dict(bound='mfma', peak=PEAK_TFLOPS[prec], unit='TFLOP/s', traffic=None,
                                 **({'kernel': ('wgrad_split_kernel<9,1> on conv5 (bf16 operands, LDS transpose reads)' if prec == 'bf16' else
                                                'wgrad_split_kernel<9> on conv5 (3 bf16 parts per operand, 6 x bf16 MFMA 32x32x16 per k16 step; achieved = fp32-equivalent FLOPs)'
-                                               if f32_conv == 'split' else 'wgrad_kernel<9> on conv5 (fp32 MFMA 32x32x2, 64x64 channel tile x 9 taps)'),
+                                               if f32_conv in ('split', 'split16') else 'wgrad_kernel<9> on conv5 (fp32 MFMA 32x32x2, 64x64 channel tile x 9 taps)'),
                                     'achieved': kern['wgrad:conv5']['achieved'], 'frac': kern['wgrad:conv5']['frac'],
                                     'launch_ms': kern['wgrad:conv5']['launch_ms']} if 'wgrad:conv5' in kern else {})),
                'conv5_passes': kern,
@@ -264,7 +268,7 @@ def main():
     head_batch = args.batch or (64 if head_dtype == 'fp32' else 256)
     head = run_config(args, head_dtype, head_batch, params, world, rank, local_rank, dev, use_sm,
                       f32_conv=args.f32_conv if head_dtype == 'fp32' else None)
-    second = split = None
+    second = split = split16 = None
     if args.dtype is None and not args.debug:
         second = run_config(args, 'bf16', args.batch or 256, params, world, rank, local_rank, dev, use_sm)
         # the same fp32 configuration with the 60x90 9x9 layers on the bf16 matrix cores (three-way operand split, fp32-class
@@ -272,6 +276,9 @@ def main():
         split = run_config(args, 'fp32', head_batch, params, world, rank, local_rank, dev, use_sm, f32_conv='split')
         if split is not None:
             split['roofline']['mfma_bf16_frac'] = (6 * split['roofline']['achieved'] / PEAK_TFLOPS['bf16']) if split['roofline']['achieved'] else None
+        split16 = run_config(args, 'fp32', head_batch, params, world, rank, local_rank, dev, use_sm, f32_conv='split16')
+        if split16 is not None:
+            split16['roofline']['mfma_f16_frac'] = (3 * split16['roofline']['achieved'] / PEAK_TFLOPS['bf16']) if split16['roofline']['achieved'] else None
 
     # configs[4] (joint training step, 16 images per GPU) beside the inference lines; single-GPU runs only, the
     # multi-GPU training flow has its own entry point (`--train`)
@@ -279,6 +286,7 @@ def main():
     if args.dtype is None and not args.debug and world == 1 and use_sm:
         train['train_config4_f32'] = run_train(args, 16, params, world, rank, local_rank, dev, use_sm, prec='fp32', f32_conv=None)
         train['train_config4_f32_split'] = run_train(args, 16, params, world, rank, local_rank, dev, use_sm, prec='fp32', f32_conv='split')
+        train['train_config4_f32_split16'] = run_train(args, 16, params, world, rank, local_rank, dev, use_sm, prec='fp32', f32_conv='split16')
         train['train_config4_bf16'] = run_train(args, 16, params, world, rank, local_rank, dev, use_sm, prec='bf16', f32_conv=None)
 
     if rank == 0:
@@ -291,6 +299,8 @@ def main():
             out['bf16_config2'] = second
         if split is not None:
             out['f32_split_config1'] = split
+        if split16 is not None:
+            out['f32_split16_config1'] = split16
         for key, tr_out in train.items():
             if tr_out is not None:
                 out[key] = {k: tr_out[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'train_tflops', 'frac_of_mfma_peak', 'roofline')}

@@ -48,7 +48,10 @@ int jcm_abi_version(void);
  * "n_joints" : K, default 9      (main.py:458)
  * "f32_conv"  : fp32 handles only; 0 (default) = every convolution on the exact fp32 MFMA chain,
  *              1 = the stride-1 layers with Cin % 16 == 0 and Cout % 128 == 0 run as three-way bf16
- *              operand splits with six products on the bf16 matrix cores (fp32-class error).
+ *              operand splits with six products on the bf16 matrix cores (fp32-class error);
+ *              2 = forward as two-way fp16 splits with three products (needs |activation| < 65504,
+ *              |w| < 16), gradients as in 1.
+ * "split_min_wgs": any time; grids smaller than this keep the exact kernel (default 128, 0 = always split).
  * All three must be set before jcm_finalize.
  * "profile"  : 0/1, any time: bracket every MFMA conv launch with HIP events on the launch
  *              stream; read the totals back with jcm_profile_read. */
