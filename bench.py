@@ -304,7 +304,7 @@ def main():
         for key, tr_out in train.items():
             if tr_out is not None:
                 out[key] = {k: tr_out[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'train_tflops', 'frac_of_mfma_peak', 'roofline')}
-        if args.cpu_images > 0:
+        if args.cpu_images > 0 and world == 1:      # the CPU baseline is a single-GPU-run item (rank 0, N = 1)
             out['cpu_baseline'] = cpu_baseline(args.cpu_images, params)
         print(json.dumps(out))
     if world > 1:
