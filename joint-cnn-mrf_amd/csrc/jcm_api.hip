@@ -102,7 +102,11 @@ int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int
     else HIP_TRY(conv_igemm_bf16(a, L->ks, out_f32, c->stream));
   } else {
     a.CoutP = L->coutp;
-    if (L->thin) {
+    if (L->thin && L->wp_split && c->f32_conv == 2) {
+      a.wp = L->wp_split;
+      a.CoutP = 16;
+      HIP_TRY(conv_thin_split16(a, c->stream));
+    } else if (L->thin) {
       HIP_TRY(conv_thin_f32(a, c->stream));
     } else if (L->wp_split && conv_split_supported(L->ks, L->cin, L->coutp_split, B, H, W, c->split_min_wgs)) {
       a.wp = L->wp_split;
@@ -158,6 +162,11 @@ int refresh_derived(jcm_ctx* c, bool first) {
       L.coutp_split = L.cout;
       if (!L.wp_split) JCM_TRY(dev_alloc(c, &L.wp_split, conv_split_weight_bytes(L.ks, L.cin, L.coutp_split, ns)));
       HIP_TRY(pack_weights_split(w.d, L.wp_split, L.ks, L.cin, L.cout, L.coutp_split, ns, c->stream));
+    }
+    if (c->precision == JCM_PRECISION_F32 && c->f32_conv == 2 && L.ks == 9 && L.cout <= 16 && L.cin % 32 == 0) {   // logits layer, fp16x3
+      L.coutp_split = 16;
+      if (!L.wp_split) JCM_TRY(dev_alloc(c, &L.wp_split, conv_split_weight_bytes(L.ks, L.cin, 16, 2)));
+      HIP_TRY(pack_weights_split(w.d, L.wp_split, L.ks, L.cin, L.cout, 16, 2, c->stream));
     }
     if (L.ks == 5 && L.cin == 3 && L.cout == 64 && L.has_bn && c->precision == JCM_PRECISION_BF16) {
       if (!L.wq1_bf16) JCM_TRY(dev_alloc(c, &L.wq1_bf16, 5 * 2 * 64 * 16));

@@ -30,6 +30,9 @@ size_t conv_split_weight_bytes(int ks, int Cin, int CoutP, int ns);     // ns: 3
 hipError_t pack_weights_split(const float* w_hwio, void* wp, int ks, int Cin, int Cout, int CoutP, int ns, hipStream_t st);
 hipError_t conv_split_f32(const ConvArgs& a, int ks, int ns, hipStream_t st);
 
+// conv_thin_split.hip: the 9-channel logits layer as fp16x3 (weights from pack_weights_split(ns = 2) with CoutP = 16)
+hipError_t conv_thin_split16(const ConvArgs& a, hipStream_t st);
+
 // ---- conv_thin_f32.hip : 9x9 conv with Cout <= 12 (the logits layer) on v_mfma_f32_4x4x1_16b_f32 ----
 // weights packed by pack_weights_f32 with CoutP = 16
 hipError_t conv_thin_f32(const ConvArgs& a, hipStream_t st);
