@@ -195,7 +195,7 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
                'config': {'workload': 'configs[4]: joint training, batch=%d/GPU synthetic 480x720x3, %s%s, Adam, clip 4.0%s'
                                       % (B, 'fp32 MFMA' if prec == 'fp32' else 'mixed precision: bf16 activations/gradients + bf16 MFMA, fp32 master weights / statistics / losses / spatial model / optimizer',
                                          ' operands; forward, data and weight gradients of the stride-1 layers as bf16x6 split MFMA' if f32_conv == 'split' else
-                                         ' operands; forward as fp16x3, data and weight gradients as bf16x6 split MFMA' if f32_conv == 'split16' else '',
+                                         ' operands; forward, data and weight gradients as fp16x3 split MFMA (gradients scaled per tensor by a power of two)' if f32_conv == 'split16' else '',
                                          ', DEBUG filters/4' if args.debug else ''),
                           'batch_per_gpu': B, 'global_batch': world * B, 'use_sm': use_sm,
                           'collective': 'all_reduce of %d fp32 gradients' % tr.n_elements},
@@ -203,8 +203,10 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
                'frac_of_mfma_peak': value * FLOPS_TRAIN / scale / 1e12 / PEAK_TFLOPS[prec],
                'roofline': dict(bound='mfma', peak=PEAK_TFLOPS[prec], unit='TFLOP/s', traffic=None,
                                 **({'kernel': ('wgrad_split_kernel<9,1> on conv5 (bf16 operands, LDS transpose reads)' if prec == 'bf16' else
+                                               'wgrad_split_kernel<9,2> on conv5 (2 fp16 parts per operand, 3 x fp16 MFMA per k16 step; achieved = fp32-equivalent FLOPs)'
+                                               if f32_conv == 'split16' else
                                                'wgrad_split_kernel<9> on conv5 (3 bf16 parts per operand, 6 x bf16 MFMA 32x32x16 per k16 step; achieved = fp32-equivalent FLOPs)'
-                                               if f32_conv in ('split', 'split16') else 'wgrad_kernel<9> on conv5 (fp32 MFMA 32x32x2, 64x64 channel tile x 9 taps)'),
+                                               if f32_conv == 'split' else 'wgrad_kernel<9> on conv5 (fp32 MFMA 32x32x2, 64x64 channel tile x 9 taps)'),
                                     'achieved': kern['wgrad:conv5']['achieved'], 'frac': kern['wgrad:conv5']['frac'],
                                     'launch_ms': kern['wgrad:conv5']['launch_ms']} if 'wgrad:conv5' in kern else {})),
                'conv5_passes': kern,

@@ -259,6 +259,11 @@ __global__ __launch_bounds__(C::NT, 2) void conv_split_kernel(ConvArgs a, int ti
       }
       const int slot = hy * whp + hx;
       if constexpr (C::NSPLIT == 2) {
+        if (a.in_scale) {                 // gradients: lift into the fp16 range by the tensor's power-of-two scale
+          const float S = a.in_scale[0];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { lo[i] *= S; hi[i] *= S; }
+        }
         f16x8 p0, p1;
         split8h(lo, hi, p0, p1);
         halo[(0 * C::U + u) * C::PLANE + slot] = __builtin_bit_cast(f32x4, p0);
@@ -300,6 +305,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv_split_kernel(ConvArgs a, int ti
 
   // epilogue: bias (+ ReLU + folded BatchNorm) -> fp32 NHWC
   float* __restrict__ ob = static_cast<float*>(a.out) + (size_t)b * H * W * Cout;
+  const float unscale = (C::NSPLIT == 2 ? 1.0f / kW16Scale : 1.0f) * (a.in_scale ? a.in_scale[1] : 1.0f);
 #pragma unroll
   for (int g = 0; g < C::NR; ++g) {
     const int co = n0 + bcol[g];
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv_split_kernel(ConvArgs a, int ti
           ok = y < H && x < W;
         }
         if (ok) {
-          float v = (C::NSPLIT == 2 ? acc[f][g][i] * (1.0f / kW16Scale) : acc[f][g][i]) + bi;
+          float v = (C::NSPLIT == 2 ? acc[f][g][i] * unscale : acc[f][g][i]) + bi;
           if (a.relu_bn) v = fmaxf(v, 0.f) * sc + sh;
           ob[((size_t)y * W + x) * Cout + co] = v;
         }

@@ -52,6 +52,8 @@ struct TrainState {
   int64_t* e_off = nullptr;
   int64_t* b_off = nullptr;
   // optimizer chunk table (one launch updates every tensor)
+  float* gscale = nullptr;             // [2] {S, 1/S}: power-of-two scale of the current layer's gradient (f32_conv = 2)
+  float* gscratch = nullptr;           // [1024]
   float** ck_w = nullptr;
   int64_t* ck_start = nullptr;
   int64_t* ck_off = nullptr;
@@ -83,7 +85,8 @@ int repack_dgrad(jcm_ctx* c) {
     }
     HIP_TRY(flip_transpose_weights(L->w_raw, t->scratch_flip, L->ks, L->cin, L->cout, d.cinp, c->stream));
     HIP_TRY(pack_weights_f32(t->scratch_flip, d.wd, L->ks, d.cinp, L->cin, d.coutp, c->stream));
-    if (d.wd_split) HIP_TRY(pack_weights_split(t->scratch_flip, d.wd_split, L->ks, d.cinp, L->cin, L->cin, 3, c->stream));   // gradients: bf16 parts (range)
+    // gradients: bf16 parts (full fp32 range) in mode 1; fp16 parts + a per-tensor power-of-two scale in mode 2
+    if (d.wd_split) HIP_TRY(pack_weights_split(t->scratch_flip, d.wd_split, L->ks, d.cinp, L->cin, L->cin, c->f32_conv == 2 ? 2 : 3, c->stream));
   }
   return JCM_OK;
 }
@@ -161,12 +164,18 @@ int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int ldz, int B, fl
   float* partial = arena_alloc<float>(c, n * splits);
   // handles with f32_conv = 1: the bf16x6 split kernel on pre-split operands (wgrad_split.hip)
   const bool split = !bf(c) && c->f32_conv >= 1 && wgrad_split_supported(L->ks, L->cin, ldz);
+  const bool h16 = split && c->f32_conv == 2;     // fp16x3: dz is lifted into the fp16 range by its own power-of-two scale
   if (bf(c) && !wgrad_split_supported(L->ks, L->cin, ldz)) return fail(JCM_ERR_ARG, "no bf16 weight-gradient kernel for layer '" + f.scope + "'");
   const size_t nx = (size_t)B * f.H * f.W * L->cin, nz = (size_t)B * f.H * f.W * ldz;
-  char* xparts = split ? arena_alloc<char>(c, nx * 6) : nullptr;
-  char* zparts = split ? arena_alloc<char>(c, nz * 6) : nullptr;
+  char* xparts = split ? arena_alloc<char>(c, nx * (h16 ? 4 : 6)) : nullptr;
+  char* zparts = split ? arena_alloc<char>(c, nz * (h16 ? 4 : 6)) : nullptr;
   if (!c->dry) {
-    if (split) {
+    if (h16) {
+      // the scale computed here is reused by conv_dgrad of the same layer (every conv_dgrad follows its layer's conv_wgrad)
+      HIP_TRY(pow2_scale_of(static_cast<const float*>(dz), nz, t->gscale, t->gscratch, c->stream));
+      HIP_TRY(split_parts16(static_cast<const float*>(f.in), xparts, nx, nullptr, c->stream));
+      HIP_TRY(split_parts16(static_cast<const float*>(dz), zparts, nz, t->gscale, c->stream));
+    } else if (split) {
       HIP_TRY(split_parts(static_cast<const float*>(f.in), xparts, nx, c->stream));
       HIP_TRY(split_parts(static_cast<const float*>(dz), zparts, nz, c->stream));
     }
@@ -177,13 +186,14 @@ int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int ldz, int B, fl
       HIP_TRY(hipEventRecord(e0, c->stream));
     }
     if (bf(c)) HIP_TRY(wgrad_bf16(f.in, dz, partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream));
+    else if (h16) HIP_TRY(wgrad_split16(xparts, zparts, partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream));
     else if (split) HIP_TRY(wgrad_split(xparts, zparts, partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream));
     else HIP_TRY(wgrad_f32(static_cast<const float*>(f.in), static_cast<const float*>(dz), partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream));
     if (c->profile) {
       HIP_TRY(hipEventRecord(e1, c->stream));
       c->prof["wgrad:" + f.scope].emplace_back(e0, e1);      // read with jcm_profile_read("wgrad:<scope>")
     }
-    HIP_TRY(wgrad_reduce(partial, splits, n, L->w_raw, lmbd, grad_of(t, grads, f.scope + "/weights"), c->stream));
+    HIP_TRY(wgrad_reduce(partial, splits, n, L->w_raw, lmbd, grad_of(t, grads, f.scope + "/weights"), c->stream, h16 ? t->gscale + 1 : nullptr));
   }
   c->arena_off = mark;
   return JCM_OK;
@@ -204,14 +214,18 @@ int conv_dgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int B, void* dx) {
   a.x = dz; a.wp = d.wd; a.bias = t->zeros; a.scale = t->ones; a.shift = t->zeros; a.out = dx;
   a.B = B; a.H = f.H; a.W = f.W; a.Cin = d.cinp; a.Cout = f.L->cin; a.CoutP = d.coutp; a.relu_bn = 0;
   const bool split = d.wd_split && conv_split_supported(f.L->ks, d.cinp, f.L->cin, B, f.H, f.W, c->split_min_wgs);
-  if (split) { a.wp = d.wd_split; a.CoutP = f.L->cin; }
+  const int ns = c->f32_conv == 2 ? 2 : 3;
+  if (split) {
+    a.wp = d.wd_split; a.CoutP = f.L->cin;
+    if (ns == 2) a.in_scale = t->gscale;          // set by this layer's conv_wgrad just before
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->profile) {
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, c->stream));
   }
-  if (split) HIP_TRY(conv_split_f32(a, f.L->ks, 3, c->stream));
+  if (split) HIP_TRY(conv_split_f32(a, f.L->ks, ns, c->stream));
   else HIP_TRY(conv_igemm_f32(a, f.L->ks, c->stream));
   if (c->profile) {
     HIP_TRY(hipEventRecord(e1, c->stream));
@@ -495,7 +509,7 @@ int jcm_train_begin(jcm_handle h) {
     } else {
       JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&d.wd), (size_t)L.ks * L.ks * d.cinp * d.coutp * sizeof(float)));
       if (c->f32_conv >= 1 && L.cin % 128 == 0)      // data gradient on the bf16x6 split kernel where its tile fits
-        JCM_TRY(dev_alloc(c, &d.wd_split, conv_split_weight_bytes(L.ks, d.cinp, L.cin, 3)));
+        JCM_TRY(dev_alloc(c, &d.wd_split, conv_split_weight_bytes(L.ks, d.cinp, L.cin, 3)));   // sized for three parts, two used in mode 2
     }
     const size_t nf = (size_t)L.ks * L.ks * (d.cinp_bf16 > d.cinp ? d.cinp_bf16 : d.cinp) * L.cin;
     if (nf > max_w) max_w = nf;
@@ -574,6 +588,8 @@ int jcm_train_begin(jcm_handle h) {
     HIP_TRY(hipMemcpyAsync(t->ck_len, cl.data(), cl.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
+  JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->gscale), 2 * sizeof(float)));
+  JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->gscratch), 1024 * sizeof(float)));
   JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->red), train_reduce_scratch_doubles(t->maxC) * sizeof(double)));
   JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->sumsq), 2 * sizeof(double)));
   JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->small), (size_t)(2 * t->maxC + 64) * sizeof(float)));

@@ -18,6 +18,9 @@ struct ConvArgs {
   void* out;
   int B, H, W, Cin, Cout, CoutP;
   int relu_bn;
+  // conv_split fp16x3 on gradients: device pair {S, 1/S}; the input is multiplied by S (a power of two that lifts it
+  // into the fp16 range) before it is split and the result by 1/S.  Null = no scaling.
+  const float* in_scale = nullptr;
 };
 int conv_igemm_bn(int Cout);                     // N-tile the dispatcher will use for this Cout
 hipError_t conv_igemm_f32(const ConvArgs& a, int ks, hipStream_t st);
@@ -156,11 +159,19 @@ hipError_t optimizer_chunks(float* const* wptr, const int64_t* cstart, const int
 int wgrad_splits(int ks, int Cin, int Cout, int B, int H);
 hipError_t wgrad_f32(const float* x, const float* dz, float* partial, int splits, int ks, int B, int H, int W, int Cin, int Cout, int ldz,
                      hipStream_t st);
-hipError_t wgrad_reduce(const float* partial, int splits, size_t n, const float* w, float lmbd, float* dw, hipStream_t st);
+// dw = out_scale * sum(partials) + lmbd * w   (out_scale: device scalar, null = 1)
+hipError_t wgrad_reduce(const float* partial, int splits, size_t n, const float* w, float lmbd, float* dw, hipStream_t st, const float* out_scale = nullptr);
 int wgrad_conv1_blocks(void);
 hipError_t wgrad_conv1(const float* x, const void* dz, bool dz_bf16, float* partial, int B, int H0, int W0, int sub, int Cout, hipStream_t st);
 // wgrad_split.hip: the same on the bf16 matrix cores (three-way operand split, six products, LDS transpose reads)
 hipError_t split_parts(const float* x, void* out_bf16_3n, size_t n, hipStream_t st);    // out[p*n + i] = part p of x[i]
+// two fp16 parts of x * S (S = scale[0], a device scalar; null = 1)
+hipError_t split_parts16(const float* x, void* out_f16_2n, size_t n, const float* scale, hipStream_t st);
+// scale[0] = S = the power of two that brings max|x| just below 2^14, scale[1] = 1/S   (scratch: >= 1024 floats)
+hipError_t pow2_scale_of(const float* x, size_t n, float* scale, float* scratch, hipStream_t st);
+// fp16x3 weight gradient: x / dz as split_parts16 images
+hipError_t wgrad_split16(const void* xp, const void* zp, float* partial, int splits, int ks, int B, int H, int W, int Cin, int Cout, int ldz,
+                         hipStream_t st);
 bool wgrad_split_supported(int ks, int Cin, int ldz);
 hipError_t wgrad_split(const void* xp, const void* zp, float* partial, int splits, int ks, int B, int H, int W, int Cin, int Cout, int ldz,
                        hipStream_t st);

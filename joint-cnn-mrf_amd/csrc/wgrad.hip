@@ -164,16 +164,17 @@ hipError_t wgrad_f32(const float* x, const float* dz, float* partial, int splits
 
 // dw[i] = sum_s partial[s][i] + lmbd * w[i]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, size_t n, const float* __restrict__ w, float lmbd,
-                                    float* __restrict__ dw) {
+                                    float* __restrict__ dw, const float* __restrict__ out_scale) {
+  const float os = out_scale ? *out_scale : 1.0f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     double s = 0.0;                           // partial tiles cancel heavily (BN backward makes sum(dz) ~ 0)
     for (int k = 0; k < splits; ++k) s += (double)partial[(size_t)k * n + i];
-    dw[i] = (float)s + lmbd * w[i];
+    dw[i] = (float)s * os + lmbd * w[i];
   }
 }
-hipError_t wgrad_reduce(const float* partial, int splits, size_t n, const float* w, float lmbd, float* dw, hipStream_t st) {
+hipError_t wgrad_reduce(const float* partial, int splits, size_t n, const float* w, float lmbd, float* dw, hipStream_t st, const float* out_scale) {
   size_t g = (n + 255) / 256;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)(g > 16384 ? 16384 : g)), dim3(256), 0, st, partial, splits, n, w, lmbd, dw);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)(g > 16384 ? 16384 : g)), dim3(256), 0, st, partial, splits, n, w, lmbd, dw, out_scale);
   return hipGetLastError();
 }
 

@@ -20,6 +20,7 @@
 namespace jcm {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -58,7 +59,7 @@ __device__ __forceinline__ void load_blocks(unsigned abase, u32x2 (&blk)[KS + 4]
   }
 }
 // all MFMAs of one (S, PA): KS taps x the gradient parts q <= NP - 1 - PA
-template <int KS, int NP, int S, int PA>
+template <int KS, int NP, bool F16, int S, int PA>
 __device__ __forceinline__ void taps(unsigned abase, const bf16x8 (&bz)[NP], f32x16 (&acc)[KS]) {
   u32x2 blk[KS + 4];
   load_blocks<KS, S, PA, 0>(abase, blk);
@@ -68,7 +69,12 @@ __device__ __forceinline__ void taps(unsigned abase, const bf16x8 (&bz)[NP], f32
   for (int kx = 0; kx < KS; ++kx) {
     const bf16x8 a = pack_op(blk[kx], blk[kx + 4]);
 #pragma unroll
-    for (int q = 0; q <= NP - 1 - PA; ++q) acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bz[q], acc[kx], 0, 0, 0);
+    for (int q = 0; q <= NP - 1 - PA; ++q) {
+      if constexpr (F16)
+        acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bz[q]), acc[kx], 0, 0, 0);
+      else
+        acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bz[q], acc[kx], 0, 0, 0);
+    }
   }
 }
 
@@ -81,14 +87,14 @@ __device__ __forceinline__ void load_z(unsigned zbase, u32x2 (&lo)[NP], u32x2 (&
     load_z<NP, S, Q + 1>(zbase, lo, hi);
   }
 }
-template <int KS, int NP, int S, int PA>
+template <int KS, int NP, bool F16, int S, int PA>
 __device__ __forceinline__ void parts_desc(unsigned abase, const bf16x8 (&bz)[NP], f32x16 (&acc)[KS]) {   // smallest products first
   if constexpr (PA >= 0) {
-    taps<KS, NP, S, PA>(abase, bz, acc);
-    parts_desc<KS, NP, S, PA - 1>(abase, bz, acc);
+    taps<KS, NP, F16, S, PA>(abase, bz, acc);
+    parts_desc<KS, NP, F16, S, PA - 1>(abase, bz, acc);
   }
 }
-template <int KS, int NP, int S>
+template <int KS, int NP, bool F16, int S>
 __device__ __forceinline__ void k16_step(unsigned abase, unsigned zbase, f32x16 (&acc)[KS]) {
   bf16x8 bz[NP];
   {
@@ -99,10 +105,10 @@ __device__ __forceinline__ void k16_step(unsigned abase, unsigned zbase, f32x16 
 #pragma unroll
     for (int q = 0; q < NP; ++q) bz[q] = pack_op(lo[q], hi[q]);
   }
-  parts_desc<KS, NP, S, NP - 1>(abase, bz, acc);
+  parts_desc<KS, NP, F16, S, NP - 1>(abase, bz, acc);
 }
 
-template <int KS, int NP, int NBUF>
+template <int KS, int NP, int NBUF, bool F16>
 __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const __bf16* __restrict__ xp, const __bf16* __restrict__ zp,
                                                               float* __restrict__ partial, int B, int H, int W, int Cin, int Cout, int ldz,
                                                               int n_ci, int n_co, int splits, long xpart, long zpart) {
@@ -192,8 +198,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const __bf16* __res
     __syncthreads();                                        // ... and everyone's; every wave is past its reads of strip s-1's buffer
     if (s + D < nstrip) stage(s + D, (buf + D) % NBUF);     // = the buffer strip s-1 used
     const unsigned ab = a_lane + (unsigned)(buf * ws_buf(NP)), zb = z_lane + (unsigned)(buf * ws_buf(NP));
-    k16_step<KS, NP, 0>(ab, zb, acc);
-    k16_step<KS, NP, 1>(ab, zb, acc);
+    k16_step<KS, NP, F16, 0>(ab, zb, acc);
+    k16_step<KS, NP, F16, 1>(ab, zb, acc);
     buf = (buf + 1) % NBUF;
   }
 
@@ -213,6 +219,43 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const __bf16* __res
   }
 }
 
+// fp16 parts of x * S: out[0] = fp16(xS), out[1] = fp16(xS - out[0])   (conv_split.hip, fp16x3)
+__global__ void split_parts16_kernel(const float* __restrict__ x, _Float16* __restrict__ out, size_t n, const float* __restrict__ scale) {
+  const float S = scale ? scale[0] : 1.0f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = x[i] * S;
+    const _Float16 h0 = static_cast<_Float16>(v);
+    out[i] = h0;
+    out[n + i] = static_cast<_Float16>(v - static_cast<float>(h0));
+  }
+}
+
+// max |x| per block -> scratch; then S = 2^floor(log2(2^14 / max)) (clamped), scale = {S, 1/S}
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, size_t n, float* __restrict__ scratch) {
+  __shared__ float sh[256];
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+  sh[threadIdx.x] = m;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + k]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) scratch[blockIdx.x] = sh[0];
+}
+__global__ void pow2_scale_kernel(const float* __restrict__ scratch, int nb, float* __restrict__ scale) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float m = 0.f;
+  for (int i = 0; i < nb; ++i) m = fmaxf(m, scratch[i]);
+  int e = 0;                                   // m = f * 2^e, f in [0.5, 1)
+  if (m > 0.f && isfinite(m)) (void)frexpf(m, &e);
+  else e = 14;                                 // all zeros (or not finite): S = 1
+  int k = 14 - e;                              // m * 2^k in [2^13, 2^14)
+  k = k > 60 ? 60 : (k < -60 ? -60 : k);
+  scale[0] = ldexpf(1.0f, k);
+  scale[1] = ldexpf(1.0f, -k);
+}
+
 // out[p][i] = part p of x[i]  (p = 0 high .. 2 low; x = out[0] + out[1] + out[2] exactly)
 __global__ void split_parts_kernel(const float* __restrict__ x, __bf16* __restrict__ out, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -228,6 +271,20 @@ __global__ void split_parts_kernel(const float* __restrict__ x, __bf16* __restri
 
 }  // namespace
 
+hipError_t split_parts16(const float* x, void* out, size_t n, const float* scale, hipStream_t st) {
+  size_t g = (n + 255) / 256;
+  hipLaunchKernelGGL(split_parts16_kernel, dim3((int)(g > 65536 ? 65536 : g)), dim3(256), 0, st, x, static_cast<_Float16*>(out), n, scale);
+  return hipGetLastError();
+}
+
+hipError_t pow2_scale_of(const float* x, size_t n, float* scale, float* scratch, hipStream_t st) {
+  size_t g = (n + 256 * 16 - 1) / (256 * 16);
+  const int nb = (int)(g < 1 ? 1 : (g > 1024 ? 1024 : g));
+  hipLaunchKernelGGL(amax_kernel, dim3(nb), dim3(256), 0, st, x, n, scratch);
+  hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(64), 0, st, scratch, nb, scale);
+  return hipGetLastError();
+}
+
 hipError_t split_parts(const float* x, void* out, size_t n, hipStream_t st) {
   size_t g = (n + 255) / 256;
   hipLaunchKernelGGL(split_parts_kernel, dim3((int)(g > 65536 ? 65536 : g)), dim3(256), 0, st, x, static_cast<__bf16*>(out), n);
@@ -237,13 +294,13 @@ hipError_t split_parts(const float* x, void* out, size_t n, hipStream_t st) {
 bool wgrad_split_supported(int ks, int Cin, int ldz) { return (ks == 9 || ks == 5) && Cin % 8 == 0 && ldz % 8 == 0; }
 
 namespace {
-template <int KS, int NP>
+template <int KS, int NP, bool F16 = false>
 hipError_t launch_w(const void* xp, const void* zp, float* partial, int splits, int B, int H, int W, int Cin, int Cout, int ldz, hipStream_t st) {
   const int n_ci = (Cin + 63) / 64, n_co = (Cout + 63) / 64;
   const int blocks = KS * n_ci * n_co * splits;
   const long xpart = (long)B * H * W * Cin, zpart = (long)B * H * W * ldz;
   constexpr int NBUF = NP == 1 ? 4 : 2;      // a bf16 strip is 18 MFMAs per wave: three strips of DMA in flight cover the HBM/L2 latency
-  hipLaunchKernelGGL((wgrad_split_kernel<KS, NP, NBUF>), dim3(blocks), dim3(256), NBUF * ws_buf(NP), st, static_cast<const __bf16*>(xp),
+  hipLaunchKernelGGL((wgrad_split_kernel<KS, NP, NBUF, F16>), dim3(blocks), dim3(256), NBUF * ws_buf(NP), st, static_cast<const __bf16*>(xp),
                      static_cast<const __bf16*>(zp), partial, B, H, W, Cin, Cout, ldz, n_ci, n_co, splits, xpart, zpart);
   return hipGetLastError();
 }
@@ -254,6 +311,14 @@ hipError_t wgrad_split(const void* xp, const void* zp, float* partial, int split
                        hipStream_t st) {
   if (!wgrad_split_supported(ks, Cin, ldz)) return hipErrorInvalidValue;
   return ks == 9 ? launch_w<9, 3>(xp, zp, partial, splits, B, H, W, Cin, Cout, ldz, st) : launch_w<5, 3>(xp, zp, partial, splits, B, H, W, Cin, Cout, ldz, st);
+}
+
+// fp16x3: xp / zp are split_parts16 images (two fp16 parts each, dz pre-scaled by its power-of-two scale)
+hipError_t wgrad_split16(const void* xp, const void* zp, float* partial, int splits, int ks, int B, int H, int W, int Cin, int Cout, int ldz,
+                         hipStream_t st) {
+  if (!wgrad_split_supported(ks, Cin, ldz)) return hipErrorInvalidValue;
+  return ks == 9 ? launch_w<9, 2, true>(xp, zp, partial, splits, B, H, W, Cin, Cout, ldz, st)
+                 : launch_w<5, 2, true>(xp, zp, partial, splits, B, H, W, Cin, Cout, ldz, st);
 }
 
 // x, dz bf16 NHWC themselves (bf16 training): one product per k16 step, fp32 accumulate
