@@ -49,8 +49,8 @@ int jcm_abi_version(void);
  * "f32_conv"  : fp32 handles only; 0 (default) = every convolution on the exact fp32 MFMA chain,
  *              1 = the stride-1 layers with Cin % 16 == 0 and Cout % 128 == 0 run as three-way bf16
  *              operand splits with six products on the bf16 matrix cores (fp32-class error);
- *              2 = two-way fp16 splits with three products (needs |activation| < 65504, |w| < 16);
- *              in the training step gradients are scaled per tensor by a power of two first.
+ *              2 = two-way fp16 splits with three products; every operand tensor (weights, layer
+ *              inputs, gradients) is lifted into the fp16 range by its own power-of-two scale first.
  * "split_min_wgs": any time; grids smaller than this keep the exact kernel (default 128, 0 = always split).
  * All three must be set before jcm_finalize.
  * "profile"  : 0/1, any time: bracket every MFMA conv launch with HIP events on the launch

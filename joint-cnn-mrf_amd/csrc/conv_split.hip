@@ -14,7 +14,8 @@
 // error < 3e-8, harmless for O(1) activations; weights are stored times 2^12 so theirs is < 1e-11), fp16 x fp16 products are
 // exact in fp32, and a0*b1 + a0*b0 + a1*b0 -- three v_mfma_f32_32x32x16_f16 -- drops only a1*b1 (2^-22): on the same
 // K = 41472 dot product 2.6e-7 of max|result| with fp32 accumulation, i.e. the accumulate rounding, not the split, is what
-// is left.  5.3x the fp32 MFMA peak.  Needs |activation| < 65504 and |w| < 16 (true behind BatchNorm); not used for gradients.
+// is left.  5.3x the fp32 MFMA peak.  Range: callers pass power-of-two scales (ConvArgs::in_scale / w_scale, pow2_scale_of)
+// that lift each operand tensor's largest magnitude into [2^13, 2^14); the epilogue undoes them exactly.
 //
 // Dataflow = conv_igemm_bf16.hip's big-tile kernel (12x32 pixels x 256 channels per workgroup, 8
 // waves of 3x4 fragments, rotating-B schedule, weights by LDS-DMA) with the K axis extended by the
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv_split_kernel(ConvArgs a, int ti
 
   // epilogue: bias (+ ReLU + folded BatchNorm) -> fp32 NHWC
   float* __restrict__ ob = static_cast<float*>(a.out) + (size_t)b * H * W * Cout;
-  const float unscale = (C::NSPLIT == 2 ? 1.0f / kW16Scale : 1.0f) * (a.in_scale ? a.in_scale[1] : 1.0f);
+  const float unscale = (C::NSPLIT == 2 ? (a.w_scale ? a.w_scale[1] : 1.0f / kW16Scale) : 1.0f) * (a.in_scale ? a.in_scale[1] : 1.0f);
 #pragma unroll
   for (int g = 0; g < C::NR; ++g) {
     const int co = n0 + bcol[g];
@@ -339,7 +340,9 @@ __global__ __launch_bounds__(C::NT, 2) void conv_split_kernel(ConvArgs a, int ti
 }
 
 // fp32 HWIO [k,k,Cin,Cout] -> bf16 [tap][Cin/8][part][CoutP][8], part = 0 (high) .. 2 (low); zero-padded channels
-__global__ void pack_weights_split16_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int taps, int Cin, int Cout, int CoutP) {
+__global__ void pack_weights_split16_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int taps, int Cin, int Cout, int CoutP,
+                                            const float* __restrict__ w_scale) {
+  const float sw = w_scale ? w_scale[0] : kW16Scale;
   const size_t n = (size_t)taps * Cin * CoutP;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int k8 = i & 7;
@@ -347,7 +350,7 @@ __global__ void pack_weights_split16_kernel(const float* __restrict__ w, _Float1
     const int co = r % CoutP; r /= CoutP;
     const int c8 = r % (Cin >> 3);
     const int tap = r / (Cin >> 3);
-    const float v = (co < Cout ? w[((size_t)tap * Cin + c8 * 8 + k8) * Cout + co] : 0.f) * kW16Scale;
+    const float v = (co < Cout ? w[((size_t)tap * Cin + c8 * 8 + k8) * Cout + co] : 0.f) * sw;
     const _Float16 h0 = static_cast<_Float16>(v);
     const size_t base = (((size_t)tap * (Cin >> 3) + c8) * 2) * CoutP * 8 + (size_t)co * 8 + k8;
     wp[base] = h0;
@@ -441,9 +444,9 @@ bool conv_split_supported(int ks, int Cin, int CoutP, int B, int H, int W, int m
 // ns = operand parts: 3 (bf16 parts, six products) or 2 (fp16 parts, three products)
 size_t conv_split_weight_bytes(int ks, int Cin, int CoutP, int ns) { return (size_t)ks * ks * Cin * CoutP * 2 * ns; }
 
-hipError_t pack_weights_split(const float* w_hwio, void* wp, int ks, int Cin, int Cout, int CoutP, int ns, hipStream_t st) {
+hipError_t pack_weights_split(const float* w_hwio, void* wp, int ks, int Cin, int Cout, int CoutP, int ns, hipStream_t st, const float* w_scale) {
   if (ns == 2)
-    hipLaunchKernelGGL(pack_weights_split16_kernel, dim3(2048), dim3(256), 0, st, w_hwio, static_cast<_Float16*>(wp), ks * ks, Cin, Cout, CoutP);
+    hipLaunchKernelGGL(pack_weights_split16_kernel, dim3(2048), dim3(256), 0, st, w_hwio, static_cast<_Float16*>(wp), ks * ks, Cin, Cout, CoutP, w_scale);
   else
     hipLaunchKernelGGL(pack_weights_split_kernel, dim3(2048), dim3(256), 0, st, w_hwio, static_cast<__bf16*>(wp), ks * ks, Cin, Cout, CoutP);
   return hipGetLastError();

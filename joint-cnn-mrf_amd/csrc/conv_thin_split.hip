@@ -85,6 +85,11 @@ __global__ __launch_bounds__(thins::NT, 3) void conv_thin_split16_kernel(ConvArg
         const float* src = xb + ((size_t)gy * W + gx) * Cin + chunk * 32 + u * 8;
         lo = *reinterpret_cast<const f32x4*>(src);
         hi = *reinterpret_cast<const f32x4*>(src + 4);
+        if (a.in_scale) {
+          const float S = a.in_scale[0];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { lo[i] *= S; hi[i] *= S; }
+        }
       }
       f16x8 p0, p1;
 #pragma unroll
@@ -123,6 +128,7 @@ __global__ __launch_bounds__(thins::NT, 3) void conv_thin_split16_kernel(ConvArg
   // epilogue: lane (channel li, row group lq): reg r = pixel 4*lq + r of the 16-pixel fragment
   if (li < Cout) {
     const float bi = a.bias[li];
+    const float unscale = (a.w_scale ? a.w_scale[1] : kScaleInv) * (a.in_scale ? a.in_scale[1] : 1.0f);
 #pragma unroll
     for (int f = 0; f < MF; ++f) {
       const int y = y0 + wid;
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(thins::NT, 3) void conv_thin_split16_kernel(ConvArg
       for (int r = 0; r < 4; ++r) {
         const int x = x0 + f * 16 + 4 * lq + r;
         if (y < H && x < W) {
-          float v = acc[f][r] * kScaleInv + bi;
+          float v = acc[f][r] * unscale + bi;
           if (a.relu_bn) v = fmaxf(v, 0.f) * a.scale[li] + a.shift[li];
           static_cast<float*>(a.out)[(((size_t)b * H + y) * W + x) * Cout + li] = v;
         }

@@ -53,6 +53,7 @@ struct ConvLayer {
   float* wp = nullptr;            // packed for conv_igemm_f32
   void* wp_split = nullptr;       // three bf16 parts per weight for conv_split_f32 (fp32 handles, "f32_conv" = 1)
   int coutp_split = 0;
+  float* wscale = nullptr;        // fp16x3: device {Sw, 1/Sw}, the power-of-two scale the packed weights carry
   void* wp_bf16 = nullptr;        // packed for conv_igemm_bf16
   void* wq1_bf16 = nullptr;       // packed for conv1_mfma_pool (5x5, Cin=3, Cout=64)
   int coutp_bf16 = 0;
@@ -77,6 +78,8 @@ struct jcm_ctx {
   int precision = JCM_PRECISION_F32;
   int K = 9;
   int f32_conv = 0;             // fp32 handles: 0 = exact fp32 MFMA everywhere, 1 = bf16x6 split kernels, 2 = fp16x3 forward + bf16x6 gradients
+  float* act_scale = nullptr;   // fp16x3: device {S, 1/S} of the current layer input (computed before every launch), + scratch
+  float* scale_scratch = nullptr;
   int split_min_wgs = 128;      // grids smaller than this keep the exact kernel (option "split_min_wgs")
   bool finalized = false;
   std::map<std::string, jcm::Tensor> params;

@@ -102,13 +102,19 @@ int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int
     else HIP_TRY(conv_igemm_bf16(a, L->ks, out_f32, c->stream));
   } else {
     a.CoutP = L->coutp;
+    const bool use_split = L->wp_split && (L->thin ? c->f32_conv == 2 : conv_split_supported(L->ks, L->cin, L->coutp_split, B, H, W, c->split_min_wgs));
+    if (use_split && c->f32_conv == 2) {     // fp16x3: lift this input into the fp16 range by its own power-of-two scale
+      HIP_TRY(pow2_scale_of(static_cast<const float*>(x), (size_t)B * H * W * L->cin, c->act_scale, c->scale_scratch, c->stream));
+      a.in_scale = c->act_scale;
+      a.w_scale = L->wscale;
+    }
     if (L->thin && L->wp_split && c->f32_conv == 2) {
       a.wp = L->wp_split;
       a.CoutP = 16;
       HIP_TRY(conv_thin_split16(a, c->stream));
     } else if (L->thin) {
       HIP_TRY(conv_thin_f32(a, c->stream));
-    } else if (L->wp_split && conv_split_supported(L->ks, L->cin, L->coutp_split, B, H, W, c->split_min_wgs)) {
+    } else if (use_split) {
       a.wp = L->wp_split;
       a.CoutP = L->coutp_split;
       HIP_TRY(conv_split_f32(a, L->ks, c->f32_conv == 2 ? 2 : 3, c->stream));
@@ -126,6 +132,17 @@ int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int
 }  // namespace jcm
 
 namespace jcm {
+
+// fp16x3: {Sw, 1/Sw} with Sw the power of two that brings max|w| just below 2^14 (device scalars, recomputed at every refresh)
+static int weight_scale(jcm_ctx* c, const Tensor& w, float** wscale) {
+  if (!c->scale_scratch) {
+    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->scale_scratch), 1024 * sizeof(float)));
+    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->act_scale), 2 * sizeof(float)));
+  }
+  if (!*wscale) JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(wscale), 2 * sizeof(float)));
+  HIP_TRY(pow2_scale_of(w.d, w.n, *wscale, c->scale_scratch, c->stream));
+  return JCM_OK;
+}
 
 int refresh_derived(jcm_ctx* c, bool first) {
   // ---- conv layers: every "<scope>/weights" of rank 4
@@ -161,12 +178,14 @@ int refresh_derived(jcm_ctx* c, bool first) {
       const int ns = c->f32_conv == 2 ? 2 : 3;      // forward operand parts: bf16x6 or fp16x3
       L.coutp_split = L.cout;
       if (!L.wp_split) JCM_TRY(dev_alloc(c, &L.wp_split, conv_split_weight_bytes(L.ks, L.cin, L.coutp_split, ns)));
-      HIP_TRY(pack_weights_split(w.d, L.wp_split, L.ks, L.cin, L.cout, L.coutp_split, ns, c->stream));
+      if (ns == 2) JCM_TRY(weight_scale(c, w, &L.wscale));
+      HIP_TRY(pack_weights_split(w.d, L.wp_split, L.ks, L.cin, L.cout, L.coutp_split, ns, c->stream, L.wscale));
     }
     if (c->precision == JCM_PRECISION_F32 && c->f32_conv == 2 && L.ks == 9 && L.cout <= 16 && L.cin % 32 == 0) {   // logits layer, fp16x3
       L.coutp_split = 16;
       if (!L.wp_split) JCM_TRY(dev_alloc(c, &L.wp_split, conv_split_weight_bytes(L.ks, L.cin, 16, 2)));
-      HIP_TRY(pack_weights_split(w.d, L.wp_split, L.ks, L.cin, L.cout, 16, 2, c->stream));
+      JCM_TRY(weight_scale(c, w, &L.wscale));
+      HIP_TRY(pack_weights_split(w.d, L.wp_split, L.ks, L.cin, L.cout, 16, 2, c->stream, L.wscale));
     }
     if (L.ks == 5 && L.cin == 3 && L.cout == 64 && L.has_bn && c->precision == JCM_PRECISION_BF16) {
       if (!L.wq1_bf16) JCM_TRY(dev_alloc(c, &L.wq1_bf16, 5 * 2 * 64 * 16));

@@ -86,7 +86,7 @@ int repack_dgrad(jcm_ctx* c) {
     HIP_TRY(flip_transpose_weights(L->w_raw, t->scratch_flip, L->ks, L->cin, L->cout, d.cinp, c->stream));
     HIP_TRY(pack_weights_f32(t->scratch_flip, d.wd, L->ks, d.cinp, L->cin, d.coutp, c->stream));
     // gradients: bf16 parts (full fp32 range) in mode 1; fp16 parts + a per-tensor power-of-two scale in mode 2
-    if (d.wd_split) HIP_TRY(pack_weights_split(t->scratch_flip, d.wd_split, L->ks, d.cinp, L->cin, L->cin, c->f32_conv == 2 ? 2 : 3, c->stream));
+    if (d.wd_split) HIP_TRY(pack_weights_split(t->scratch_flip, d.wd_split, L->ks, d.cinp, L->cin, L->cin, c->f32_conv == 2 ? 2 : 3, c->stream, L->wscale));
   }
   return JCM_OK;
 }
@@ -217,7 +217,7 @@ int conv_dgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int B, void* dx) {
   const int ns = c->f32_conv == 2 ? 2 : 3;
   if (split) {
     a.wp = d.wd_split; a.CoutP = f.L->cin;
-    if (ns == 2) a.in_scale = t->gscale;          // set by this layer's conv_wgrad just before
+    if (ns == 2) { a.in_scale = t->gscale; a.w_scale = f.L->wscale; }   // gscale: set by this layer's conv_wgrad just before
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->profile) {

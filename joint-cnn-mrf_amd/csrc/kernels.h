@@ -21,6 +21,8 @@ struct ConvArgs {
   // conv_split fp16x3 on gradients: device pair {S, 1/S}; the input is multiplied by S (a power of two that lifts it
   // into the fp16 range) before it is split and the result by 1/S.  Null = no scaling.
   const float* in_scale = nullptr;
+  // fp16x3 weights: device pair {Sw, 1/Sw} the weights were multiplied by at pack time (pack_weights_split(ns = 2)); null = 2^12
+  const float* w_scale = nullptr;
 };
 int conv_igemm_bn(int Cout);                     // N-tile the dispatcher will use for this Cout
 hipError_t conv_igemm_f32(const ConvArgs& a, int ks, hipStream_t st);
@@ -30,7 +32,8 @@ hipError_t pack_weights_f32(const float* w_hwio, float* wp, int ks, int Cin, int
 // same contract as conv_igemm_f32 (fp32 in / out, same epilogue) for the shapes conv_split_supported() accepts
 bool conv_split_supported(int ks, int Cin, int CoutP, int B, int H, int W, int min_wgs);   // 5x5 / 9x9, Cin % 16 == 0, CoutP % 128 == 0; 12x32 patches or whole-row tiles
 size_t conv_split_weight_bytes(int ks, int Cin, int CoutP, int ns);     // ns: 3 = bf16x6, 2 = fp16x3
-hipError_t pack_weights_split(const float* w_hwio, void* wp, int ks, int Cin, int Cout, int CoutP, int ns, hipStream_t st);
+hipError_t pack_weights_split(const float* w_hwio, void* wp, int ks, int Cin, int Cout, int CoutP, int ns, hipStream_t st,
+                              const float* w_scale = nullptr);     // ns = 2: weights are stored times w_scale[0] (device; null = 2^12)
 hipError_t conv_split_f32(const ConvArgs& a, int ks, int ns, hipStream_t st);
 
 // conv_thin_split.hip: the 9-channel logits layer as fp16x3 (weights from pack_weights_split(ns = 2) with CoutP = 16)

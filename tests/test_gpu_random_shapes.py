@@ -71,3 +71,20 @@ def test_bf16_tower_other_resolutions_tracks_fp32(hw):
     scale = np.abs(outs['fp32']).max()
     assert np.abs(outs['bf16'] - outs['fp32']).max() <= 4e-2 * scale
     assert np.sqrt(np.mean((outs['bf16'] - outs['fp32']) ** 2)) <= 1e-2 * scale
+
+
+@pytest.mark.parametrize('gain', [1e-9, 1.0, 3e7])
+def test_split16_is_range_free(gain):
+    """fp16x3 on inputs and weights far outside the fp16 range: every operand tensor is lifted by its own power-of-two
+    scale (activations per launch, weights at pack time), so the kernel inherits fp32's range."""
+    from joint_cnn_mrf_amd.engine import Engine
+    rs = np.random.RandomState(77)
+    p = layer_params(rs, 64, 128, 9)
+    p['c/weights'] = (p['c/weights'] * np.float32(gain ** 0.5 if gain > 1 else 1.0)).astype(np.float32)
+    x = (rs.standard_normal((3, 24, 64, 64)) * gain).astype(np.float32)
+    ref = O.conv_layer(x.astype(np.float64), p, 9, 1, 'c')
+    eng = Engine(device=0, f32_conv='split16', split_min_wgs=0).load_params(p)
+    got = eng.conv_layer(torch.as_tensor(x, device='cuda:0'), 'c', 1, n_out=128).cpu().numpy()
+    eng.close()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
