@@ -429,7 +429,12 @@ int split_tiles(int B, int H, int W) {
   return B * ((H + R - 1) / R);
 }
 // 256-channel tiles unless that leaves most of the 256 CUs without a workgroup (small maps at small batch)
-int split_bn(int CoutP, int tiles) { return (CoutP % 256 == 0 && tiles * (CoutP / 256) >= 256) ? 256 : 128; }
+// ... and 64-channel tiles when even 128-channel ones leave more than half the chip idle (15x23 maps at 16 images)
+int split_bn(int CoutP, int tiles) {
+  if (CoutP % 256 == 0 && tiles * (CoutP / 256) >= 256) return 256;
+  if (tiles * (CoutP / 128) >= 128) return 128;
+  return 64;
+}
 }  // namespace
 
 // min_wgs: smallest grid worth a launch (default 128: below half a chip of 384-pixel tiles the 128-pixel exact kernel wins; tests
@@ -456,13 +461,15 @@ namespace {
 template <int NS, int TPS9>
 hipError_t dispatch_s(const ConvArgs& a, int ks, hipStream_t st) {
   const bool wide = a.W >= 64 && a.H % 12 == 0;
-  const bool big = split_bn(a.CoutP, split_tiles(a.B, a.H, a.W)) == 256;
+  const int bn = split_bn(a.CoutP, split_tiles(a.B, a.H, a.W));
   if (ks == 9) {
-    if (big) return wide ? launch_s<CfgS<9, 256, false, NS, TPS9>>(a, st) : launch_s<CfgS<9, 256, true, NS, TPS9>>(a, st);
-    return wide ? launch_s<CfgS<9, 128, false, NS, TPS9>>(a, st) : launch_s<CfgS<9, 128, true, NS, TPS9>>(a, st);
+    if (bn == 256) return wide ? launch_s<CfgS<9, 256, false, NS, TPS9>>(a, st) : launch_s<CfgS<9, 256, true, NS, TPS9>>(a, st);
+    if (bn == 128) return wide ? launch_s<CfgS<9, 128, false, NS, TPS9>>(a, st) : launch_s<CfgS<9, 128, true, NS, TPS9>>(a, st);
+    return wide ? launch_s<CfgS<9, 64, false, NS, TPS9>>(a, st) : launch_s<CfgS<9, 64, true, NS, TPS9>>(a, st);
   }
-  if (big) return wide ? launch_s<CfgS<5, 256, false, NS, 1>>(a, st) : launch_s<CfgS<5, 256, true, NS, 1>>(a, st);
-  return wide ? launch_s<CfgS<5, 128, false, NS, 1>>(a, st) : launch_s<CfgS<5, 128, true, NS, 1>>(a, st);
+  if (bn == 256) return wide ? launch_s<CfgS<5, 256, false, NS, 1>>(a, st) : launch_s<CfgS<5, 256, true, NS, 1>>(a, st);
+  if (bn == 128) return wide ? launch_s<CfgS<5, 128, false, NS, 1>>(a, st) : launch_s<CfgS<5, 128, true, NS, 1>>(a, st);
+  return wide ? launch_s<CfgS<5, 64, false, NS, 1>>(a, st) : launch_s<CfgS<5, 64, true, NS, 1>>(a, st);
 }
 }  // namespace
 
