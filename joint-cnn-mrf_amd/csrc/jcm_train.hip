@@ -54,6 +54,7 @@ struct TrainState {
   // optimizer chunk table (one launch updates every tensor)
   float* gscale = nullptr;             // [2] {S, 1/S}: power-of-two scale of the current layer's gradient (f32_conv = 2)
   float* gscratch = nullptr;           // [1024]
+  const void* gscale_of = nullptr;     // the tensor gscale currently describes
   float** ck_w = nullptr;
   int64_t* ck_start = nullptr;
   int64_t* ck_off = nullptr;
@@ -173,6 +174,7 @@ int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int ldz, int B, fl
     if (h16) {
       // the scale computed here is reused by conv_dgrad of the same layer (every conv_dgrad follows its layer's conv_wgrad)
       HIP_TRY(pow2_scale_of(static_cast<const float*>(dz), nz, t->gscale, t->gscratch, c->stream));
+      t->gscale_of = dz;
       HIP_TRY(split_parts16(static_cast<const float*>(f.in), xparts, nx, nullptr, c->stream));
       HIP_TRY(split_parts16(static_cast<const float*>(dz), zparts, nz, t->gscale, c->stream));
     } else if (split) {
@@ -217,7 +219,15 @@ int conv_dgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int B, void* dx) {
   const int ns = c->f32_conv == 2 ? 2 : 3;
   if (split) {
     a.wp = d.wd_split; a.CoutP = f.L->cin;
-    if (ns == 2) { a.in_scale = t->gscale; a.w_scale = f.L->wscale; }   // gscale: set by this layer's conv_wgrad just before
+    if (ns == 2) {
+      if (t->gscale_of != dz) {                   // normally set by this layer's conv_wgrad just before
+        HIP_TRY(pow2_scale_of(static_cast<const float*>(dz), (size_t)B * f.H * f.W * d.cinp, t->gscale, t->gscratch, c->stream));
+        t->gscale_of = dz;
+      }
+      a.in_scale = t->gscale;
+      a.w_scale = f.L->wscale;
+      t->gscale_of = nullptr;                     // consumed: arena addresses are reused by later tensors
+    }
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->profile) {
@@ -254,6 +264,7 @@ int loss_grads_impl(jcm_ctx* c, const float* x, const float* y, int B, int H, in
   TrainState* t = c->train;
   static const char* const kRes[3] = {"fullres", "halfres", "quarterres"};
   const int K = c->K;
+  t->gscale_of = nullptr;
   LayerFwd l1[3], l2[3], l3[3], l4[3], l5, l6;
   void *p1[3], *p2[3];
   const bool b16 = bf(c);
