@@ -243,10 +243,12 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
   }
   if (threadIdx.x == 0) scratch[blockIdx.x] = sh[0];
 }
-__global__ void pow2_scale_kernel(const float* __restrict__ scratch, int nb, float* __restrict__ scale) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void pow2_scale_kernel(const float* __restrict__ scratch, int nb, float* __restrict__ scale) {   // one wave
   float m = 0.f;
-  for (int i = 0; i < nb; ++i) m = fmaxf(m, scratch[i]);
+  for (int i = threadIdx.x; i < nb; i += 64) m = fmaxf(m, scratch[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (threadIdx.x != 0) return;
   int e = 0;                                   // m = f * 2^e, f in [0.5, 1)
   if (m > 0.f && isfinite(m)) (void)frexpf(m, &e);
   else e = 14;                                 // all zeros (or not finite): S = 1
