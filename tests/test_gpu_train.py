@@ -53,6 +53,13 @@ def debug_case():
     return p, synth.make_images(B), synth.make_targets(B)
 
 
+@pytest.fixture(scope='module')
+def joint_ref(debug_case):
+    """The float64 restatement of the joint step at --debug size (shared: it costs ~25 s of CPU)."""
+    p, x, y = debug_case
+    return T.loss_and_grads(x, y, p, use_sm=True, lmbd=0.001)
+
+
 def test_pd_only_loss_and_grads(debug_case):
     p, x, y = debug_case
     ref = T.loss_and_grads(x, y, p, use_sm=False, lmbd=0.001)
@@ -70,11 +77,11 @@ def test_pd_only_loss_and_grads(debug_case):
             assert not got[k].any(), k
 
 
-def test_joint_loss_and_grads(debug_case):
+def test_joint_loss_and_grads(debug_case, joint_ref):
     """use_sm: loss_sm flows through the spatial model into the 81 priors / biases, bn_sm and, through
     hm_pred_pd, back into the part detector (main.py:523-531,539)."""
     p, x, y = debug_case
-    ref = T.loss_and_grads(x, y, p, use_sm=True, lmbd=0.001)
+    ref = joint_ref
     ref32 = T.loss_and_grads(x, y, p, use_sm=True, lmbd=0.001, dtype=torch.float32)
     eng, tr = make_trainer(p, use_sm=True, lmbd=0.001)
     losses, _ = tr.loss_and_grads(dev(x), dev(y))
@@ -85,10 +92,10 @@ def test_joint_loss_and_grads(debug_case):
     check_grads(got, ref['grads'], ref32['grads'], verbose=True)
 
 
-def test_moving_statistics_update(debug_case):
+def test_moving_statistics_update(debug_case, joint_ref):
     """UPDATE_OPS (main.py:557): moving = 0.9*moving + 0.1*batch, variance Bessel-corrected."""
     p, x, y = debug_case
-    ref = T.loss_and_grads(x, y, p, use_sm=True)
+    ref = joint_ref
     want = T.update_moving(p, ref['bn_stats'])
     eng, tr = make_trainer(p, use_sm=True)
     tr.loss_and_grads(dev(x), dev(y))
