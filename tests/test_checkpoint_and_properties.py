@@ -105,3 +105,15 @@ def test_flic_backward_pose_flip_and_border_clamp():
     np.testing.assert_array_equal(c[1, 8], [60, 90])                 # clamped to (480, 720) / 8: blob cut by the border
     y = data.target_heat_maps(c)
     assert y[1, 59, 89, 8] == np.float32(1 / 16) and y[1, :, :, 8].sum() == np.float32(1 / 16)
+
+
+def test_piecewise_learning_rate_schedule():
+    """lr_tf (main.py:467-469,492): boundaries round(0.7/0.8/0.9 * total), values lr, lr/2, lr/5, lr/10; the host helper
+    agrees with the restatement on every update of a short and a long run, including the boundary updates."""
+    from joint_cnn_mrf_amd.train import piecewise_lr
+    from oracle.train_oracle import piecewise_lr as ref
+    for total, lr in ((10, 0.001), (8541, 0.01), (3, 1.0)):
+        for n in range(total + 2):
+            assert piecewise_lr(n, total, lr) == ref(n, total, lr)
+    assert piecewise_lr(0, 100, 1.0) == 1.0 and piecewise_lr(70, 100, 1.0) == 1.0 and piecewise_lr(71, 100, 1.0) == 0.5
+    assert piecewise_lr(81, 100, 1.0) == 0.2 and piecewise_lr(91, 100, 1.0) == 0.1 and piecewise_lr(1000, 100, 1.0) == 0.1
