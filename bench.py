@@ -151,7 +151,7 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
     prec = prec or args.dtype or 'fp32'
     f32_conv = args.f32_conv if f32_conv == 'args' else f32_conv
     eng = Engine(device=local_rank, precision=prec, f32_conv=f32_conv if prec == 'fp32' else None).load_params(params)
-    tr = Trainer(eng, optimizer='adam', lr=0.001, lmbd=0.001, use_sm=use_sm)
+    tr = Trainer(eng, optimizer='adam', lr=0.001, lmbd=0.001, use_sm=use_sm, overlap_allreduce=args.overlap)
     x = torch.as_tensor(synth.make_images(B, seed=1234 + rank), device=dev)
     y = torch.as_tensor(synth.make_targets(B, seed=4321 + rank), device=dev)
     moving = Trainer.moving_statistics_of(params) if world > 1 else None
@@ -230,6 +230,7 @@ def main():
     ap.add_argument('--cpu-images', type=int, default=4, help='size of the cpu_baseline sample (0 = skip)')
     ap.add_argument('--train', action='store_true', help='time the joint training step (configs[4]) instead of the forward; fp32, '
                                                          'default 16 images per GPU (batch 128 over 8 GPUs)')
+    ap.add_argument('--overlap', action='store_true', help='--train, N > 1, RCCL: start each layer\'s gradient all-reduce during the backward pass')
     ap.add_argument('--layer-times', action='store_true', help='print the HIP-event time of every MFMA conv layer to stderr')
     args = ap.parse_args()
 

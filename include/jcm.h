@@ -152,6 +152,13 @@ int jcm_train_loss_grads(jcm_handle h, const float* x, const float* y, int B, in
  * (main.py:492); clip_norm <= 0 disables the clip; grad_norm_out (host, may be NULL) receives the
  * global norm before clipping and makes the call synchronise. */
 int jcm_train_apply(jcm_handle h, const float* grads, int optimizer, float lr, float clip_norm, float* grad_norm_out);
+/* Overlapping the tower average with the backward pass: `fn(user, offset, count)` is called on the calling thread, from
+ * inside jcm_train_loss_grads, as soon as every kernel that writes grads[offset, offset+count) has been enqueued on
+ * the handle's stream (one call per layer, last layer first; the spatial-model blocks first of all).  The host
+ * records an event on that stream and starts the all-reduce of the range on another stream.  Every trainable
+ * element is reported exactly once per call.  NULL disables. */
+typedef void (*jcm_grad_ready_fn)(void* user, int64_t offset, int64_t count);
+int jcm_train_set_grad_callback(jcm_handle h, jcm_grad_ready_fn fn, void* user);
 int jcm_train_steps(jcm_handle h, int64_t* n_iters);     /* n_iters_tf (main.py:491) */
 /* Saver.save side (main.py:666): copy a stored parameter out (host or device pointer). */
 int jcm_get_tensor(jcm_handle h, const char* name, float* out, int64_t count);

@@ -14,6 +14,7 @@ JCM_OPT_MOMENTUM = 1
 _c_float_p = ctypes.c_void_p      # device pointers travel as integers
 _c_i32_p = ctypes.c_void_p
 _handle = ctypes.c_void_p
+GRAD_READY_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64)   # jcm_grad_ready_fn
 
 # name -> (restype, argtypes); exactly the declarations of include/jcm.h
 SIGNATURES = {
@@ -48,6 +49,7 @@ SIGNATURES = {
     'jcm_train_loss_grads': (ctypes.c_int, [_handle, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_float, _c_float_p, _c_float_p]),
     'jcm_train_apply': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.POINTER(ctypes.c_float)]),
+    'jcm_train_set_grad_callback': (ctypes.c_int, [_handle, ctypes.c_void_p, ctypes.c_void_p]),
     'jcm_train_steps': (ctypes.c_int, [_handle, ctypes.POINTER(ctypes.c_int64)]),
     'jcm_get_tensor': (ctypes.c_int, [_handle, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64]),
     'jcm_update_tensor': (ctypes.c_int, [_handle, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]),

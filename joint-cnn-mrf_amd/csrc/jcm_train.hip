@@ -55,6 +55,10 @@ struct TrainState {
   float* gscale = nullptr;             // [2] {S, 1/S}: power-of-two scale of the current layer's gradient (f32_conv = 2)
   float* gscratch = nullptr;           // [1024]
   const void* gscale_of = nullptr;     // the tensor gscale currently describes
+  // "these gradients are final" notifications (jcm_train_set_grad_callback): name prefix -> [offset, count) of the flat buffer
+  jcm_grad_ready_fn ready_fn = nullptr;
+  void* ready_user = nullptr;
+  std::map<std::string, std::pair<int64_t, int64_t>> ranges;
   float** ck_w = nullptr;
   int64_t* ck_start = nullptr;
   int64_t* ck_off = nullptr;
@@ -90,6 +94,15 @@ int repack_dgrad(jcm_ctx* c) {
     if (d.wd_split) HIP_TRY(pack_weights_split(t->scratch_flip, d.wd_split, L->ks, d.cinp, L->cin, L->cin, c->f32_conv == 2 ? 2 : 3, c->stream, L->wscale));
   }
   return JCM_OK;
+}
+
+// Every write of the gradients with this name prefix has been enqueued on the stream: tell the host, which can start
+// reducing that range on another stream (after an event recorded now) while the backward pass goes on.
+void notify_ready(jcm_ctx* c, const std::string& prefix) {
+  TrainState* t = c->train;
+  if (c->dry || !t->ready_fn) return;
+  auto it = t->ranges.find(prefix);
+  if (it != t->ranges.end() && it->second.second > 0) t->ready_fn(t->ready_user, it->second.first, it->second.second);
 }
 
 float* grad_of(TrainState* t, float* grads, const std::string& name) {
@@ -198,6 +211,7 @@ int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int ldz, int B, fl
     HIP_TRY(wgrad_reduce(partial, splits, n, L->w_raw, lmbd, grad_of(t, grads, f.scope + "/weights"), c->stream, h16 ? t->gscale + 1 : nullptr));
   }
   c->arena_off = mark;
+  notify_ready(c, f.scope + "/");      // weights were the layer's last gradient (BatchNorm and bias gradients precede them)
   return JCM_OK;
 }
 
@@ -313,6 +327,9 @@ int loss_grads_impl(jcm_ctx* c, const float* x, const float* y, int B, int H, in
     float* prob = arena_alloc<float>(c, NP * K);
     if (!c->dry) HIP_TRY(spatial_softmax(logits, prob, B, hh * ww, K, c->stream));             // main.py:523
     JCM_TRY(sm_train_impl(c, prob, y, B, gscale, ce_sm, dlog, grads));                          // main.py:528-531,539 + backward
+    notify_ready(c, "bias_");
+    notify_ready(c, "bn_sm/");
+    notify_ready(c, "energy_");
   } else if (!c->dry) {
     HIP_TRY(hipMemcpyAsync(ce_sm, ce_pd, (size_t)B * K * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
   }
@@ -388,6 +405,7 @@ int loss_grads_impl(jcm_ctx* c, const float* x, const float* y, int B, int H, in
         HIP_TRY(wgrad_conv1(x, dz1, b16, partial, B, H, W, 1 << r, C1, c->stream));
         HIP_TRY(wgrad_reduce(partial, nb, n, l1[r].L->w_raw, lmbd, grad_of(t, grads, l1[r].scope + "/weights"), c->stream));
       }
+      notify_ready(c, l1[r].scope + "/");
     }
     c->arena_off = mark;
   }
@@ -499,6 +517,16 @@ int jcm_train_begin(jcm_handle h) {
     t->index[kv.first] = t->slots.size();
     t->slots.push_back(Slot{kv.first, kv.second.d, kv.second.n, t->total});
     t->total += kv.second.n;
+  }
+  for (const Slot& sl : t->slots) {      // contiguous name-prefix ranges: "<scope>/" per layer, "bias_", "bn_sm/", "energy_"
+    std::string pre;
+    if (sl.name.compare(0, 5, "bias_") == 0) pre = "bias_";
+    else if (sl.name.compare(0, 7, "energy_") == 0) pre = "energy_";
+    else pre = sl.name.substr(0, sl.name.find('/') + 1);
+    auto it = t->ranges.find(pre);
+    if (it == t->ranges.end()) t->ranges[pre] = {(int64_t)sl.off, (int64_t)sl.n};
+    else if (it->second.first + it->second.second == (int64_t)sl.off) it->second.second += (int64_t)sl.n;
+    else return fail(JCM_ERR_STATE, "gradient range of '" + pre + "' is not contiguous");
   }
   size_t max_w = 0;
   for (auto& kv : c->convs) {
@@ -665,6 +693,13 @@ int jcm_train_apply(jcm_handle h, const float* grads, int optimizer, float lr, f
   }
   JCM_TRY(refresh_derived(c, false));   // packed weights, folded moving statistics, softplus'd priors + spectra
   JCM_TRY(repack_dgrad(c));
+  return JCM_OK;
+}
+
+int jcm_train_set_grad_callback(jcm_handle h, jcm_grad_ready_fn fn, void* user) {
+  JCM_TRY(need_train(h));
+  h->train->ready_fn = fn;
+  h->train->ready_user = user;
   return JCM_OK;
 }
 

@@ -28,7 +28,7 @@ def piecewise_lr(n_iters, n_updates_total, lr):
 
 
 class Trainer:
-    def __init__(self, engine, optimizer='adam', lr=0.001, lmbd=0.001, use_sm=True, n_updates_total=None):
+    def __init__(self, engine, optimizer='adam', lr=0.001, lmbd=0.001, use_sm=True, n_updates_total=None, overlap_allreduce=False):
         # fp32 handle: fp32 tensors (exact fp32 MFMA, or bf16x6 split with f32_conv='split'); bf16 handle: mixed precision
         # (bf16 activations / gradients and bf16 MFMA, fp32 master weights, statistics, losses, spatial model, optimizer)
         if optimizer not in ('adam', 'momentum'):
@@ -36,6 +36,9 @@ class Trainer:
         self.eng = engine
         self.optimizer, self.lr, self.lmbd, self.use_sm = optimizer, float(lr), float(lmbd), bool(use_sm)
         self.n_updates_total = n_updates_total
+        # start each layer's gradient all-reduce (RCCL) as soon as the backward pass has produced it; opt-in: this round's
+        # boxes have one GPU, so the asynchronous path is exercised only up to its notifications (tests) -- not end to end
+        self.overlap_allreduce = bool(overlap_allreduce)
         self._lib = engine._lib
         _lib.check(self._lib.jcm_train_begin(engine._h), 'jcm_train_begin')
         nt, ne = ctypes.c_int64(), ctypes.c_int64()
@@ -50,6 +53,11 @@ class Trainer:
             self.layout.append((buf.value.decode(), off.value, cnt.value))
         self.grads = torch.zeros(self.n_elements, dtype=torch.float32, device=engine.device)
         self._moving = None                                         # [(name, offset, count)] of the BN moving statistics
+        self._ready_hook = None                                     # user hook(offset, count) for the gradient-ready notifications
+        self._pending, self._covered, self._side = [], [], None
+        self._cb = _lib.GRAD_READY_FN(self._on_grads_ready)         # keep the ctypes thunk alive as long as the trainer
+        _lib.check(self._lib.jcm_train_set_grad_callback(engine._h, ctypes.cast(self._cb, ctypes.c_void_p), None),
+                   'jcm_train_set_grad_callback')
         self.losses = torch.zeros(4, dtype=torch.float32, device=engine.device)
 
     @property
@@ -76,10 +84,52 @@ class Trainer:
         g = self.grads.cpu().numpy()
         return {n: g[o:o + c].copy() for n, o, c in self.layout}
 
+    # ------------------------------------------------------------------ tower average overlapped with the backward pass
+    def set_ready_hook(self, fn):
+        """fn(offset, count) is called from inside loss_and_grads as each layer's gradients become final."""
+        self._ready_hook = fn
+
+    def _overlap_active(self):
+        import torch.distributed as dist
+        return (self.overlap_allreduce and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+                and dist.get_backend() == 'nccl')
+
+    def _on_grads_ready(self, _user, offset, count):
+        """jcm_grad_ready_fn: the kernels writing grads[offset:offset+count] are enqueued on the engine's stream.  With RCCL
+        the range's all-reduce starts now, on a side stream behind an event, while the backward pass keeps the compute
+        stream busy (xGMI links and MFMA pipes are independent resources); other back ends reduce after the pass."""
+        if self._ready_hook is not None:
+            self._ready_hook(int(offset), int(count))
+        if not self._overlap_active():
+            return
+        import torch.distributed as dist
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.eng.device)
+        ev = torch.cuda.Event()
+        ev.record(self.eng._stream)
+        self._side.wait_event(ev)
+        with torch.cuda.stream(self._side):
+            self._pending.append(dist.all_reduce(self.grads[offset:offset + count], async_op=True))
+        self._covered.append((int(offset), int(count)))
+
     def average_gradients(self):
-        """main.py:243-267 across ranks: mean of the per-tower gradients (dist.average_gradients)."""
+        """main.py:243-267 across ranks: mean of the per-tower gradients.  Ranges already in flight (see _on_grads_ready)
+        are waited for; whatever was not reported during the pass is reduced now."""
         from . import dist as jdist
-        jdist.average_gradients(self.grads)
+        if not self._pending:
+            jdist.average_gradients(self.grads)
+            return
+        import torch.distributed as dist
+        with torch.cuda.stream(self.eng._stream):
+            for w in self._pending:
+                w.wait()                                    # the compute stream waits for the collective
+            pos = 0
+            for off, cnt in sorted(self._covered) + [(self.n_elements, 0)]:
+                if off > pos:
+                    dist.all_reduce(self.grads[pos:off])    # e.g. the spatial-model blocks when use_sm is off (zeros)
+                pos = max(pos, off + cnt)
+            self.grads.div_(dist.get_world_size())
+        self._pending, self._covered = [], []
 
     def apply(self, lr=None, want_norm=False):
         """grad_renorm + apply_gradients (main.py:576-577) on self.grads."""

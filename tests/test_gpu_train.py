@@ -279,3 +279,39 @@ def test_gradients_are_deterministic_and_training_is_stable(mode):
     hist = np.array(hist)
     assert np.isfinite(hist).all()
     assert hist[-1, 1] < hist[0, 1] and hist[-1, 2] < hist[0, 2], hist[:, :3]
+
+
+@pytest.mark.parametrize('use_sm', [True, False])
+def test_gradient_ready_notifications_cover_every_tensor_once(debug_case, use_sm):
+    """jcm_train_set_grad_callback: the ranges reported during the backward pass (the hook the RCCL overlap hangs on) are
+    disjoint, aligned with whole tensors, reported last-layer-first, and together cover every trainable element that the
+    loss reaches -- and at the moment a range is reported its kernels are already enqueued (the value read after a
+    stream sync inside the hook equals the final gradient)."""
+    p, x, y = debug_case
+    eng, tr = make_trainer(p, use_sm=use_sm)
+    seen, snaps = [], []
+
+    def hook(off, cnt):
+        seen.append((off, cnt))
+        torch.cuda.synchronize()
+        snaps.append(tr.grads[off:off + cnt].clone())
+
+    tr.set_ready_hook(hook)
+    tr.loss_and_grads(dev(x), dev(y))
+    torch.cuda.synchronize()
+    final = tr.grads.clone()
+    eng.close()
+    starts = {o: (n, c) for n, o, c in tr.layout}
+    covered = np.zeros(tr.n_elements, bool)
+    for (off, cnt), snap in zip(seen, snaps):
+        assert off in starts and not covered[off:off + cnt].any()
+        covered[off:off + cnt] = True
+        assert torch.equal(snap, final[off:off + cnt])
+    names_left = [n for n, o, c in tr.layout if not covered[o]]
+    if use_sm:
+        assert not names_left
+        assert tr.layout[[o for _, o, _ in tr.layout].index(seen[0][0])][0].startswith('bias_')      # spatial model first
+    else:
+        assert names_left and all(n.startswith(('bias_', 'bn_sm', 'energy_')) for n in names_left)
+    order = [starts[o][0].split('/')[0] for o, _ in seen if not starts[o][0].startswith(('bias_', 'bn_sm', 'energy_'))]
+    assert order[0] == 'conv6' and order[1] == 'conv5' and order[-1] == 'conv1_quarterres'
