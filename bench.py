@@ -111,6 +111,11 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
         flops_launch = tot_flops / max(tot_n, 1)               # average algorithmic FLOPs per launch
         achieved = flops_launch / (launch_ms * 1e-3) / 1e12 if tot_n else None
         peak = PEAK_TFLOPS[dtype]
+        fp32_equiv = None
+        if f32_conv in ('split', 'split16') and achieved:      # the roofline of these kernels is the 16-bit matrix-core peak
+            fp32_equiv = achieved
+            achieved = achieved * (6 if f32_conv == 'split' else 3)
+            peak = PEAK_TFLOPS['bf16']
         value = world * B * args.steps / dt
         out = {
             'value': value, 'ms_per_step': dt / args.steps * 1e3, 'dtype': 'f32' if dtype == 'fp32' else 'bf16',
@@ -123,15 +128,18 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
                        'collective': 'all_gather coords int32 [B,2,9]'},
             'path_tflops': value * FLOPS_PD_SM / (16 if args.debug else 1) / 1e12,
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm 9x9, 60x90 maps (conv4_fullres + conv5 launches; %s)'
-                                   % ('fp32 operands as 3 bf16 parts, 6 x bf16 MFMA 32x32x16 per k16 step, 12x32 patch x 256 ch; achieved = fp32-equivalent FLOPs'
+                                   % ('fp32 operands as 3 bf16 parts, 6 x bf16 MFMA 32x32x16 per k16 step, 12x32 patch x 256 ch; achieved = executed bf16 MFMA FLOPs (6 x algorithmic) against the bf16 peak'
                                       if f32_conv == 'split' else
-                                      'fp32 operands as 2 fp16 parts, 3 x fp16 MFMA 32x32x16 per k16 step, 12x32 patch x 256 ch; achieved = fp32-equivalent FLOPs'
+                                      'fp32 operands as 2 fp16 parts, 3 x fp16 MFMA 32x32x16 per k16 step, 12x32 patch x 256 ch; achieved = executed fp16 MFMA FLOPs (3 x algorithmic) against the fp16 peak'
                                       if f32_conv == 'split16' else
                                       'fp32 MFMA 32x32x2, 4x32 patch x 128 ch' if dtype == 'fp32' else 'bf16 MFMA 32x32x16, 12x32 patch x 256 ch'),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None,
                          'traffic': pmc_traffic('%s%s_b%d' % (dtype, '_' + f32_conv if f32_conv in ('split', 'split16') else '', B)) if not args.debug else None,
                          'launch_ms': launch_ms, 'launches': tot_n, 'flops_per_launch': flops_launch},
         }
+        if fp32_equiv is not None:
+            out['roofline']['fp32_equivalent_tflops'] = fp32_equiv
+            out['roofline']['x_fp32_mfma_peak'] = fp32_equiv / PEAK_TFLOPS['fp32']
     eng.close()
     del x, torso
     torch.cuda.empty_cache()
@@ -182,13 +190,18 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
         # dominant training kernels: the three conv5 passes, each 229.3 GFLOP per image (60x90 px, 81 taps, 512x512)
         kern = {}
         sp = f32_conv in ('split', 'split16') and prec == 'fp32'
+        mult = 6 if f32_conv == 'split' else 3
         for key, what in (('conv5', 'forward, ' + ('conv_split_kernel' if sp else 'conv_igemm_f32')),
                           ('dgrad:conv5', 'data gradient, ' + ('conv_split_kernel' if sp else 'conv_igemm_f32') + ' on flipped weights'),
                           ('wgrad:conv5', 'weight gradient, ' + ('wgrad_split_kernel<9>' if sp else 'wgrad_kernel<9>'))):
             ms, n = eng.profile_read(key)
             if n:
-                tf = FLOPS_DOMINANT['conv5'] / scale * B / (ms / n * 1e-3) / 1e12
-                kern[key] = {'kernel': what, 'launch_ms': ms / n, 'launches': n, 'achieved': tf, 'frac': tf / PEAK_TFLOPS[prec]}
+                tf = FLOPS_DOMINANT['conv5'] / scale * B / (ms / n * 1e-3) / 1e12      # algorithmic (fp32-equivalent) FLOPs
+                if sp:       # split kernels execute `mult` 16-bit MFMA FLOPs per algorithmic one: their roofline is the 16-bit peak
+                    kern[key] = {'kernel': what, 'launch_ms': ms / n, 'launches': n, 'achieved': tf * mult, 'frac': tf * mult / PEAK_TFLOPS['bf16'],
+                                 'fp32_equivalent_tflops': tf}
+                else:
+                    kern[key] = {'kernel': what, 'launch_ms': ms / n, 'launches': n, 'achieved': tf, 'frac': tf / PEAK_TFLOPS[prec]}
         out = {'metric': 'images/sec joint training step (fwd+bwd+update), part detector + spatial model', 'value': value,
                'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if prec == 'fp32' else 'bf16', 'data': 'synthetic',
@@ -201,11 +214,11 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
                           'collective': 'all_reduce of %d fp32 gradients' % tr.n_elements},
                'train_tflops': value * FLOPS_TRAIN / scale / 1e12, 'mfma_peak_tflops': PEAK_TFLOPS[prec],
                'frac_of_mfma_peak': value * FLOPS_TRAIN / scale / 1e12 / PEAK_TFLOPS[prec],
-               'roofline': dict(bound='mfma', peak=PEAK_TFLOPS[prec], unit='TFLOP/s', traffic=None,
+               'roofline': dict(bound='mfma', peak=PEAK_TFLOPS['bf16'] if sp else PEAK_TFLOPS[prec], unit='TFLOP/s', traffic=None,
                                 **({'kernel': ('wgrad_split_kernel<9,1> on conv5 (bf16 operands, LDS transpose reads)' if prec == 'bf16' else
-                                               'wgrad_split_kernel<9,2> on conv5 (2 fp16 parts per operand, 3 x fp16 MFMA per k16 step; achieved = fp32-equivalent FLOPs)'
+                                               'wgrad_split_kernel<9,2> on conv5 (2 fp16 parts per operand, 3 x fp16 MFMA per k16 step; achieved = executed fp16 MFMA FLOPs)'
                                                if f32_conv == 'split16' else
-                                               'wgrad_split_kernel<9> on conv5 (3 bf16 parts per operand, 6 x bf16 MFMA 32x32x16 per k16 step; achieved = fp32-equivalent FLOPs)'
+                                               'wgrad_split_kernel<9> on conv5 (3 bf16 parts per operand, 6 x bf16 MFMA 32x32x16 per k16 step; achieved = executed bf16 MFMA FLOPs)'
                                                if f32_conv == 'split' else 'wgrad_kernel<9> on conv5 (fp32 MFMA 32x32x2, 64x64 channel tile x 9 taps)'),
                                     'achieved': kern['wgrad:conv5']['achieved'], 'frac': kern['wgrad:conv5']['frac'],
                                     'launch_ms': kern['wgrad:conv5']['launch_ms']} if 'wgrad:conv5' in kern else {})),
@@ -277,11 +290,7 @@ def main():
         # the same fp32 configuration with the 60x90 9x9 layers on the bf16 matrix cores (three-way operand split, fp32-class
         # error, same parity tests); reported beside the headline, which stays on the exact fp32 MFMA chain
         split = run_config(args, 'fp32', head_batch, params, world, rank, local_rank, dev, use_sm, f32_conv='split')
-        if split is not None:
-            split['roofline']['mfma_bf16_frac'] = (6 * split['roofline']['achieved'] / PEAK_TFLOPS['bf16']) if split['roofline']['achieved'] else None
         split16 = run_config(args, 'fp32', head_batch, params, world, rank, local_rank, dev, use_sm, f32_conv='split16')
-        if split16 is not None:
-            split16['roofline']['mfma_f16_frac'] = (3 * split16['roofline']['achieved'] / PEAK_TFLOPS['bf16']) if split16['roofline']['achieved'] else None
 
     # configs[4] (joint training step, 16 images per GPU) beside the inference lines; single-GPU runs only, the
     # multi-GPU training flow has its own entry point (`--train`)
