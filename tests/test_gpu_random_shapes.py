@@ -88,3 +88,29 @@ def test_split16_is_range_free(gain):
     eng.close()
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('seed', [101, 202, 303])
+def test_tower_more_seeds_debug_width(seed):
+    """The whole tower (part detector + spatial model + arg-max) on fresh seeded weights / images / priors at --debug width,
+    in the three fp32 convolution modes: heat maps within 1e-4, arg-max identical wherever the oracle's own top-2 margin
+    is not at rounding level."""
+    from joint_cnn_mrf_amd import synth
+    from joint_cnn_mrf_amd.engine import Engine
+    p = synth.make_pd_params(debug=True, seed=seed, bn='trained', conv6_gain=6.0)
+    p.update(synth.make_sm_params(synth.synthetic_priors(seed=seed + 1), kind='trained', seed=seed + 2))
+    x, torso = synth.make_images(2, seed=seed + 3), synth.make_torso(2, seed=seed + 4)
+    ref = O.forward(x.astype(np.float64), torso.astype(np.float64), p)
+    for mode in ('exact', 'split', 'split16'):
+        eng = Engine(device=0, f32_conv=mode, split_min_wgs=0).load_params(p)
+        r = eng.forward(torch.as_tensor(x, device='cuda:0'), torch.as_tensor(torso, device='cuda:0'), use_sm=True)
+        eng.close()
+        for k in ('pd_prob', 'sm_prob'):
+            got = r[k].cpu().numpy()
+            assert np.abs(got - ref[k]).max() <= 1e-4, (mode, k)
+            flat = ref[k].reshape(2, 5400, 9)
+            top2 = np.sort(flat, axis=1)[:, -2:, :]
+            safe = (top2[:, 1, :] - top2[:, 0, :]) > 1e-6 * top2[:, 1, :]
+            ck = 'pd_coords' if k == 'pd_prob' else 'sm_coords'
+            same = (r[ck].cpu().numpy() == ref[ck]).all(axis=1)
+            assert (same | ~safe).all(), (mode, ck)
