@@ -132,7 +132,7 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
                                       if f32_conv == 'split' else
                                       'fp32 operands as 2 fp16 parts, 3 x fp16 MFMA 32x32x16 per k16 step, 12x32 patch x 256 ch; achieved = executed fp16 MFMA FLOPs (3 x algorithmic) against the fp16 peak'
                                       if f32_conv == 'split16' else
-                                      'fp32 MFMA 32x32x2, 4x32 patch x 128 ch' if dtype == 'fp32' else 'bf16 MFMA 32x32x16, 12x32 patch x 256 ch'),
+                                      'fp32 MFMA 32x32x2, 128-pixel strip tiles x 128 ch' if dtype == 'fp32' else 'bf16 MFMA 32x32x16, 12x32 patch x 256 ch'),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None,
                          'traffic': pmc_traffic('%s%s_b%d' % (dtype, '_' + f32_conv if f32_conv in ('split', 'split16') else '', B)) if not args.debug else None,
                          'launch_ms': launch_ms, 'launches': tot_n, 'flops_per_launch': flops_launch},

@@ -21,18 +21,31 @@ namespace jcm {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int KS_, int TH_, int TW_, int BN_, int WM_, int WN_, int TPS_, bool FLAT_ = false>
+// STRIP tiling (host side: make_strips): the map is cut into column strips (32 wide, plus the remainder; a narrow map is one
+// strip) and every strip is walked in its own row-major pixel order, 128 pixels per tile regardless of row ends.  A 60x90
+// map costs 15 + 15 + 13 = 43 tiles instead of the 45 of 4x32 patches (the 26-wide remainder strip wastes 1.6 % instead of
+// 19 %), a 30x45 map 11 instead of the 15 of two-row tiles.
+struct Strips {
+  int n;                 // strips used
+  int x_off[8], ws[8];   // first column / width
+  int tile0[9];          // first tile of strip i within an image; tile0[n] = tiles per image
+};
+
+template <int KS_, int TH_, int TW_, int BN_, int WM_, int WN_, int TPS_, bool FLAT_ = false, bool STRIP_ = false>
 struct Cfg {
   static constexpr int KS = KS_, TH = TH_, TW = TW_, BN = BN_, WM = WM_, WN = WN_, TPS = TPS_;
   // FLAT: the 128 pixel slots are R whole rows of a narrow map (R = floor(128 / W), set at launch)
   // instead of a TH x TW patch: a 15x23 map costs 3 tiles x 128 slots instead of 4 x 128.
   static constexpr bool FLAT = FLAT_;
+  static constexpr bool STRIP = STRIP_;
   static constexpr int U = 4;                       // 16-B units per chunk = 16 fp32 channels
   static constexpr int PAD = (KS - 1) / 2;          // SAME, stride 1: symmetric
   static constexpr int HH = TH + KS - 1;
   static constexpr int WH = TW + KS - 1;
   static constexpr int WHP = (WH + 15) / 16 * 16;   // halo row pitch in slots (bank-conflict-free reads)
-  static constexpr int PLANE = HH * WHP + 2;        // +2 slots: spreads the 4 unit planes over banks on the write side
+  // +2 slots: spreads the 4 unit planes over banks on the write side.  STRIP keeps the patch tiling's LDS footprint (3 workgroups
+  // per CU): strips up to 32 wide need (5 + k-1) x (32 + k-1) slots at most
+  static constexpr int PLANE = HH * WHP + 2;
   static constexpr int BM = TH * TW;
   static constexpr int MR = BM / WM / 32;
   static constexpr int NR = BN / WN / 32;
@@ -46,7 +59,7 @@ struct Cfg {
 };
 
 template <class C>
-__global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs a, int tiles_x, int tiles_y, int mtiles, int nN) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs a, int tiles_x, int tiles_y, int mtiles, int nN, Strips sp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* halo = reinterpret_cast<f32x4*>(smem);
   f32x4* wbuf = halo + C::HALO_F4;
@@ -67,8 +80,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs a, int 
   const int flat_r = C::FLAT ? tiles_x : 0;        // FLAT: `tiles_x` carries R, one tile across
   const int tx = C::FLAT ? 0 : mt % tiles_x;
   const int ty = C::FLAT ? mt % tiles_y : (mt / tiles_x) % tiles_y;
-  const int b = C::FLAT ? mt / tiles_y : mt / (tiles_x * tiles_y);
-  const int y0 = ty * (C::FLAT ? flat_r : C::TH), x0 = tx * C::TW, n0 = nt * C::BN;
+  int b = C::FLAT ? mt / tiles_y : mt / (tiles_x * tiles_y);
+  int y0 = ty * (C::FLAT ? flat_r : C::TH), x0 = tx * C::TW;
+  const int n0 = nt * C::BN;
+  // STRIP: tile -> (image, strip, first pixel of the tile in the strip's row-major order)
+  int s_ws = 1, s_p0 = 0, s_rows = 0;
+  if constexpr (C::STRIP) {
+    const int tpi = sp.tile0[sp.n];
+    b = mt / tpi;
+    const int ti = mt - b * tpi;
+    int si = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+      if (k < sp.n && ti >= sp.tile0[k]) si = k;
+    s_ws = sp.ws[si];
+    s_p0 = (ti - sp.tile0[si]) * C::BM;
+    x0 = sp.x_off[si];
+    y0 = s_p0 / s_ws;                                       // first row the tile touches
+    const int ylast = min((s_p0 + C::BM - 1) / s_ws, a.H - 1);
+    s_rows = ylast - y0 + 1;
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -80,14 +111,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs a, int 
   const float* __restrict__ xb = static_cast<const float*>(a.x) + (size_t)b * H * W * Cin;
   const float* __restrict__ wp = static_cast<const float*>(a.wp);
 
-  const int whp = C::FLAT ? W + C::KS - 1 : C::WHP;
-  const int wh = C::FLAT ? W + C::KS - 1 : C::WH;
-  const int hh = C::FLAT ? flat_r + C::KS - 1 : C::HH;
+  const int whp = C::STRIP ? s_ws + C::KS - 1 : (C::FLAT ? W + C::KS - 1 : C::WHP);
+  const int wh = C::STRIP ? s_ws + C::KS - 1 : (C::FLAT ? W + C::KS - 1 : C::WH);
+  const int hh = C::STRIP ? s_rows + C::KS - 1 : (C::FLAT ? flat_r + C::KS - 1 : C::HH);
   int aslot[C::MR], bcol[C::NR];
 #pragma unroll
   for (int f = 0; f < C::MR; ++f) {
     const int r = (wm * C::MR + f) * 32 + l31;
-    if constexpr (C::FLAT) {
+    if constexpr (C::STRIP) {
+      const int p = s_p0 + r < H * s_ws ? s_p0 + r : s_p0;   // slots past the strip's end compute on its first pixel and are dropped
+      const int yy = p / s_ws;
+      aslot[f] = (yy - y0) * whp + (p - yy * s_ws);
+    } else if constexpr (C::FLAT) {
       const int rr = r < flat_r * W ? r : 0;          // padding slots compute on pixel 0 and are dropped
       const int yy = rr / W;
       aslot[f] = yy * whp + (rr - yy * W);
@@ -195,7 +230,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs a, int 
         const int r = (wm * C::MR + f) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
         int y, x;
         bool ok;
-        if constexpr (C::FLAT) {
+        if constexpr (C::STRIP) {
+          const int p = s_p0 + r;
+          y = p / s_ws; x = x0 + (p - y * s_ws);
+          ok = p < H * s_ws;
+        } else if constexpr (C::FLAT) {
           const int yy = r / W;
           y = y0 + yy; x = r - yy * W;
           ok = r < flat_r * W && y < H;
@@ -213,10 +252,45 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs a, int 
   }
 }
 
+// column strips of an H x W map for the STRIP tiling: the whole map if its halo fits, else 32-wide strips + the remainder
+// (a remainder thinner than 8 columns joins the last strip); returns tiles per image, 0 if the map cannot be cut
+static int make_strips(int H, int W, int ks, int plane, int bm, Strips* sp) {
+  auto fits = [&](int ws) {
+    const int rows = (ws - 1 + bm - 1) / ws + 1;               // most rows a run of bm pixels can touch
+    return (rows + ks - 1) * (ws + ks - 1) + 2 <= plane;
+  };
+  int n = 0;
+  if (fits(W)) {
+    sp->x_off[0] = 0; sp->ws[0] = W; n = 1;
+  } else {
+    int x = 0;
+    while (x < W && n < 8) {
+      int ws = W - x >= 32 ? 32 : W - x;
+      if (W - x - ws > 0 && W - x - ws < 8) ws = W - x;        // absorb a thin remainder
+      if (!fits(ws)) return 0;
+      sp->x_off[n] = x; sp->ws[n] = ws; ++n;
+      x += ws;
+    }
+    if (x < W) return 0;
+  }
+  sp->n = n;
+  int t = 0;
+  for (int i = 0; i < n; ++i) { sp->tile0[i] = t; t += (H * sp->ws[i] + bm - 1) / bm; }
+  sp->tile0[n] = t;
+  for (int i = n; i < 8; ++i) { sp->x_off[i] = 0; sp->ws[i] = 1; }
+  return t;
+}
+
 template <class C>
 static hipError_t launch(const ConvArgs& a, hipStream_t st) {
   int tiles_x = (a.W + C::TW - 1) / C::TW, tiles_y = (a.H + C::TH - 1) / C::TH;
   int mtiles = tiles_x * tiles_y * a.B;
+  Strips sp = {};
+  if constexpr (C::STRIP) {
+    const int tpi = make_strips(a.H, a.W, C::KS, C::PLANE, C::BM, &sp);
+    if (tpi == 0) return hipErrorInvalidValue;
+    mtiles = tpi * a.B;
+  }
   if constexpr (C::FLAT) {
     int R = C::BM / a.W;
     if (R > a.H) R = a.H;
@@ -240,7 +314,7 @@ static hipError_t launch(const ConvArgs& a, hipStream_t st) {
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(conv_igemm_f32_kernel<C>, dim3(blocks), dim3(256), C::LDS_BYTES, st, a, tiles_x, tiles_y, mtiles, nN);
+  hipLaunchKernelGGL(conv_igemm_f32_kernel<C>, dim3(blocks), dim3(256), C::LDS_BYTES, st, a, tiles_x, tiles_y, mtiles, nN, sp);
   return hipGetLastError();
 }
 
@@ -259,6 +333,14 @@ static inline int slots_flat(int H, int W, int ks) {
 hipError_t conv_igemm_f32(const ConvArgs& a, int ks, hipStream_t st) {
   const int bn = conv_igemm_bn(a.Cout);
   const bool wide = (a.W >= 64) && (a.H % 4 == 0);
+  if (bn == 128) {      // strip tiling whenever it needs fewer 128-pixel tiles than the patch / whole-row choices
+    Strips sp;
+    const int t_strip = make_strips(a.H, a.W, ks, (4 + ks - 1) * 48 + 2, 128, &sp);
+    const int t_patch = wide ? ((a.H + 3) / 4) * ((a.W + 31) / 32) : slots_patch(a.H, a.W) / 128;
+    const int t_flat = slots_flat(a.H, a.W, ks) / 128;
+    if (t_strip > 0 && t_strip < t_patch && t_strip < t_flat)
+      return ks == 9 ? launch<Cfg<9, 4, 32, 128, 2, 2, 1, false, true>>(a, st) : launch<Cfg<5, 4, 32, 128, 2, 2, 1, false, true>>(a, st);
+  }
   if (!wide && bn == 128 && slots_flat(a.H, a.W, ks) < slots_patch(a.H, a.W)) {   // e.g. 15x23: 3 tiles instead of 4
     if (ks == 9) return launch<Cfg<9, 8, 16, 128, 2, 2, 1, true>>(a, st);
     if (ks == 5) return launch<Cfg<5, 8, 16, 128, 2, 2, 1, true>>(a, st);
