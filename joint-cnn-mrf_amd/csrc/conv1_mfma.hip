@@ -111,6 +111,112 @@ __global__ __launch_bounds__(256) void conv1_mfma_pool_kernel(const float* __res
   }
 }
 
+// ---- the same fusion on the exact fp32 path: v_mfma_f32_32x32x2_f32 (an exact k-ordered fma chain), fp32 window in LDS.
+// K = 5 kernel rows x 16 (15 values + a zero pad) = 40 MFMA k-steps of 2; lane (pixel, h) supplies window element 2s+h of its
+// row, lane (channel, h) the matching filter value (one ds_read_b32 each).  Same accumulator layout, same register-local pool.
+constexpr int CF_ROW = 35 * 3 + 3;              // fp32 row pitch of the LDS window (105 values + 3 zeros: element 15 of the last pixel's row window)
+__global__ __launch_bounds__(256) void conv1_mfma_pool_f32_kernel(const float* __restrict__ x, const float* __restrict__ wq,
+                                                                  const float* __restrict__ bias, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, float* __restrict__ out,
+                                                                  int H0, int W0, int sub, int Hin, int Win, int Hp, int Wp,
+                                                                  int pad_t, int pad_l, int tiles_x) {
+  __shared__ float win[CM_IN * CF_ROW];
+  __shared__ float wl[5 * 16 * 64];            // [ky][k'][co]
+  const int b = blockIdx.y;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int oy0 = ty * CM_T, ox0 = tx * CM_T;
+  const int tid = threadIdx.x;
+  const float* xb = x + (size_t)b * H0 * W0 * 3;
+  for (int i = tid; i < CM_IN * CM_IN; i += 256) {
+    const int iy = i / CM_IN, ix = i - iy * CM_IN;
+    const int gy = oy0 * 2 - pad_t + iy, gx = ox0 * 2 - pad_l + ix;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+    if ((unsigned)gy < (unsigned)Hin && (unsigned)gx < (unsigned)Win) {
+      const float* px3 = xb + ((size_t)(gy * sub) * W0 + gx * sub) * 3;
+      v0 = px3[0]; v1 = px3[1]; v2 = px3[2];
+    }
+    float* w3 = win + iy * CF_ROW + ix * 3;
+    w3[0] = v0; w3[1] = v1; w3[2] = v2;
+  }
+  for (int i = tid; i < CM_IN * 3; i += 256) win[(i / 3) * CF_ROW + CM_IN * 3 + i % 3] = 0.f;
+  for (int i = tid; i < 5 * 16 * 64; i += 256) wl[i] = wq[i];
+  __syncthreads();
+
+  const int lane = tid & 63, wid = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int px = l31 & 15, pr = l31 >> 4;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[f][g][i] = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 5; ++ky) {
+    int arow[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) arow[f] = (2 * (2 * (2 * wid + f) + pr) + ky) * CF_ROW + 6 * px + h;    // + 2s: window element 2s+h
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      float af[2], bf[2];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) af[f] = win[arow[f] + 2 * s8];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) bf[g] = wl[(ky * 16 + 2 * s8 + h) * 64 + g * 32 + l31];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) acc[f][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[f], bf[g], acc[f][g], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int co = g * 32 + l31;
+    const float bi = bias[co], sc = scale[co], sh = shift[co];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int PY = (oy0 >> 1) + 2 * wid + f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {                 // one 2x2 pooling window: regs (i0, i0+1, i0+8, i0+9)
+        const int i0 = (j & 1) * 2 + (j >> 1) * 4;
+        const float v0 = fmaxf(acc[f][g][i0] + bi, 0.f) * sc + sh;
+        const float v1 = fmaxf(acc[f][g][i0 + 1] + bi, 0.f) * sc + sh;
+        const float v2 = fmaxf(acc[f][g][i0 + 8] + bi, 0.f) * sc + sh;
+        const float v3 = fmaxf(acc[f][g][i0 + 9] + bi, 0.f) * sc + sh;
+        const int r = (i0 & 3) + 8 * (i0 >> 2) + 4 * h;
+        const int PX = (ox0 >> 1) + ((r & 15) >> 1);
+        if (PY < Hp && PX < Wp) out[(((size_t)b * Hp + PY) * Wp + PX) * 64 + co] = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+      }
+    }
+  }
+}
+
+// HWIO [5,5,3,64] fp32 -> [ky][k' = 3*kx + c (15 = zero pad)][co] fp32
+__global__ void pack_conv1_f32_kernel(const float* __restrict__ w, float* __restrict__ wq) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 5 * 16 * 64) return;
+  const int co = i & 63, k = (i >> 6) & 15, ky = i >> 10;
+  wq[i] = k < 15 ? w[(((size_t)ky * 5 + k / 3) * 3 + k % 3) * 64 + co] : 0.f;
+}
+hipError_t pack_conv1_f32(const float* w_hwio, float* wq, hipStream_t st) {
+  hipLaunchKernelGGL(pack_conv1_f32_kernel, dim3((5 * 16 * 64 + 255) / 256), dim3(256), 0, st, w_hwio, wq);
+  return hipGetLastError();
+}
+// x [B,H0,W0,3] fp32 -> out [B,Hp,Wp,64] fp32 (conv s2 + bias/ReLU/BN + pool s2); H0/sub and W0/sub divisible by 4
+hipError_t conv1_mfma_pool_f32(const float* x, const float* wq, const float* bias, const float* scale, const float* shift, float* out,
+                               int B, int H0, int W0, int sub, hipStream_t st) {
+  if (H0 % (4 * sub) != 0 || W0 % (4 * sub) != 0) return hipErrorInvalidValue;
+  const int Hin = H0 / sub, Win = W0 / sub;
+  const int Ho = Hin / 2, Wo = Win / 2;
+  const int tot_h = (Ho - 1) * 2 + 5 - Hin, tot_w = (Wo - 1) * 2 + 5 - Win;
+  const int pad_t = tot_h / 2, pad_l = tot_w / 2;
+  const int tiles_x = (Wo + CM_T - 1) / CM_T, tiles_y = (Ho + CM_T - 1) / CM_T;
+  hipLaunchKernelGGL(conv1_mfma_pool_f32_kernel, dim3(tiles_x * tiles_y, B), dim3(256), 0, st, x, wq, bias, scale, shift, out, H0, W0, sub,
+                     Hin, Win, Ho / 2, Wo / 2, pad_t, pad_l, tiles_x);
+  return hipGetLastError();
+}
+
 // HWIO [5,5,3,64] fp32 -> [ky][h][co][8] bf16, k' = 8h+i = 3*kx + c, k' = 15 is the zero pad.
 __global__ void pack_conv1_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wq) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

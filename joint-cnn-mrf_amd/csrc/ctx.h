@@ -56,6 +56,7 @@ struct ConvLayer {
   float* wscale = nullptr;        // fp16x3: device {Sw, 1/Sw}, the power-of-two scale the packed weights carry
   void* wp_bf16 = nullptr;        // packed for conv_igemm_bf16
   void* wq1_bf16 = nullptr;       // packed for conv1_mfma_pool (5x5, Cin=3, Cout=64)
+  float* wq1_f32 = nullptr;       // packed for conv1_mfma_pool_f32 (fp32 handles)
   int coutp_bf16 = 0;
   bool thin = false;              // fp32: conv_thin_f32 instead of conv_igemm_f32
   bool thin_bf16 = false;         // bf16: conv_thin_bf16 (fp32 output) instead of conv_igemm_bf16

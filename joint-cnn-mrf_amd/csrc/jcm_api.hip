@@ -187,6 +187,10 @@ int refresh_derived(jcm_ctx* c, bool first) {
       JCM_TRY(weight_scale(c, w, &L.wscale));
       HIP_TRY(pack_weights_split(w.d, L.wp_split, L.ks, L.cin, L.cout, 16, 2, c->stream, L.wscale));
     }
+    if (L.ks == 5 && L.cin == 3 && L.cout == 64 && L.has_bn && c->precision == JCM_PRECISION_F32) {
+      if (!L.wq1_f32) JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&L.wq1_f32), 5 * 16 * 64 * sizeof(float)));
+      HIP_TRY(pack_conv1_f32(w.d, L.wq1_f32, c->stream));
+    }
     if (L.ks == 5 && L.cin == 3 && L.cout == 64 && L.has_bn && c->precision == JCM_PRECISION_BF16) {
       if (!L.wq1_bf16) JCM_TRY(dev_alloc(c, &L.wq1_bf16, 5 * 2 * 64 * 16));
       HIP_TRY(pack_conv1_bf16(w.d, L.wq1_bf16, c->stream));
@@ -300,7 +304,12 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
     const int h1 = cdiv2(hin), w1 = cdiv2(win);
     const int h2 = cdiv2(h1), w2 = cdiv2(w1);
     void* p1;
-    if (bf && L1->wq1_bf16 && xh % (4 * xsub) == 0 && xw % (4 * xsub) == 0) {
+    if (!bf && L1->wq1_f32 && xh % (4 * xsub) == 0 && xw % (4 * xsub) == 0) {
+      // fp32 path: conv1 + ReLU/BN + pool1 in one fp32-MFMA kernel (the unpooled 240x360x64 map never reaches HBM)
+      p1 = act((size_t)B * h2 * w2 * L1->cout);
+      if (!c->dry)
+        HIP_TRY(conv1_mfma_pool_f32(xin, L1->wq1_f32, L1->bias, L1->scale, L1->shift, static_cast<float*>(p1), B, xh, xw, xsub, c->stream));
+    } else if (bf && L1->wq1_bf16 && xh % (4 * xsub) == 0 && xw % (4 * xsub) == 0) {
       // bf16 path: conv1 + ReLU/BN + pool1 in one MFMA kernel; only the pooled map touches HBM
       p1 = act((size_t)B * h2 * w2 * L1->cout);
       if (!c->dry)

@@ -66,6 +66,11 @@ hipError_t pack_conv1_bf16(const float* w_hwio, void* wq, hipStream_t st);
 hipError_t conv1_mfma_pool(const float* x, const void* wq, const float* bias, const float* scale, const float* shift,
                            void* out, int B, int H0, int W0, int sub, hipStream_t st);
 
+// the same fusion on the exact fp32 path (v_mfma_f32_32x32x2_f32): wq [5][16][64] fp32 from pack_conv1_f32, out fp32
+hipError_t pack_conv1_f32(const float* w_hwio, float* wq, hipStream_t st);
+hipError_t conv1_mfma_pool_f32(const float* x, const float* wq, const float* bias, const float* scale, const float* shift, float* out,
+                               int B, int H0, int W0, int sub, hipStream_t st);
+
 // ---- glue.hip ----------------------------------------------------------------------------------
 // `bf16`: activations are bf16 instead of fp32 (arithmetic stays fp32).
 hipError_t max_pool_2x2(const void* x, void* out, bool bf16, int B, int H, int W, int C, hipStream_t st);
