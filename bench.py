@@ -63,25 +63,43 @@ def cpu_baseline(n_images, params):
                       '(TensorFlow unavailable); host has %d logical CPUs' % (n_images, os.cpu_count())}
 
 
-def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32_conv=None):
+def resident_inputs(B, rank, dev):
+    """B synthetic images + torso maps in HBM.  Large batches (a rank's share of configs[3]'s 2048) are generated in
+    slices of 256 so the host never holds more than 1 GB of them."""
+    x = torch.empty((B, 480, 720, 3), dtype=torch.float32, device=dev)
+    torso = torch.empty((B, 60, 90, 1), dtype=torch.float32, device=dev)
+    for b0 in range(0, B, 256):
+        n = min(256, B - b0)
+        x[b0:b0 + n] = torch.as_tensor(synth.make_images(n, seed=1234 + rank + 1000 * (b0 // 256)))
+        torso[b0:b0 + n] = torch.as_tensor(synth.make_torso(n, seed=4321 + rank + 1000 * (b0 // 256)))
+    return x, torso
+
+
+def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32_conv=None, config_name=None, micro_batch=None):
     """Time `args.steps` steps of one (dtype, batch) configuration; returns the result dict on
     rank 0 (None elsewhere).  Timed region: barrier + synchronize on both sides, max over ranks.
-    f32_conv='split': the fp32 path with its 60x90 9x9 layers on the bf16x6 split kernel (conv_split.hip)."""
-    eng = Engine(device=local_rank, precision=dtype, f32_conv=f32_conv).load_params(params)
-    x = torch.as_tensor(synth.make_images(B, seed=1234 + rank), device=dev)          # resident in HBM
-    torso = torch.as_tensor(synth.make_torso(B, seed=4321 + rank), device=dev)
+    f32_conv='split': the fp32 path with its 60x90 9x9 layers on the bf16x6 split kernel (conv_split.hip).
+    B is the rank's batch per step; jcm_forward walks it in micro-batches (256 bf16 / 64 fp32 unless `micro_batch`)."""
+    eng = Engine(device=local_rank, precision=dtype, f32_conv=f32_conv, micro_batch=micro_batch).load_params(params)
+    x, torso = resident_inputs(B, rank, dev)                                          # resident in HBM
 
     def step():
         r = eng.forward(x, torso if use_sm else None, use_sm=use_sm, want_prob=False)
         return jdist.allgather_coords(r['sm_coords' if use_sm else 'pd_coords'])
 
+    # The per-launch HIP events of the roofline object come from a pool inside the library: one profiled step
+    # before the warm-up creates them, so that the timed region below only records (2 hipEventRecord per conv
+    # launch, no event creation or destruction).
+    eng.set_profile(True)
+    step()
+    eng.set_profile(False)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    eng.set_profile(True)
+    eng.set_profile(True)          # recycles the warm-up record; nothing is allocated here
     t0 = time.perf_counter()
     for _ in range(args.steps):
         coords = step()
@@ -106,7 +124,8 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
         tot_ms, tot_n, tot_flops = 0.0, 0, 0.0
         for scope, fl in FLOPS_DOMINANT.items():
             ms, n = eng.profile_read(scope)
-            tot_ms, tot_n, tot_flops = tot_ms + ms, tot_n + n, tot_flops + n * fl / (16 if args.debug else 1) * B
+            tot_ms, tot_n = tot_ms + ms, tot_n + n
+            tot_flops += fl / (16 if args.debug else 1) * B * args.steps if n else 0.0     # n = steps x micro-batches launches cover steps x B images
         launch_ms = tot_ms / max(tot_n, 1)                     # average launch duration (HIP events, launch stream)
         flops_launch = tot_flops / max(tot_n, 1)               # average algorithmic FLOPs per launch
         achieved = flops_launch / (launch_ms * 1e-3) / 1e12 if tot_n else None
@@ -117,14 +136,18 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
             achieved = achieved * (6 if f32_conv == 'split' else 3)
             peak = PEAK_TFLOPS['bf16']
         value = world * B * args.steps / dt
+        mb = micro_batch or (256 if dtype == 'bf16' else 64)
         out = {
-            'value': value, 'ms_per_step': dt / args.steps * 1e3, 'dtype': 'f32' if dtype == 'fp32' else 'bf16',
-            'config': {'workload': '%s: batch=%d/GPU synthetic 480x720x3, part detector%s forward + argmax, %s%s'
-                                   % ('configs[1]' if dtype == 'fp32' else 'configs[2]', B, ' + spatial model' if use_sm else '',
+            'value': value, 'ms_per_step': dt / args.steps * 1e3,
+            # the arithmetic the path computes in: exact fp32 MFMA chain, or fp32 operands carried as 16-bit parts
+            'dtype': 'bf16' if dtype == 'bf16' else {'split': 'f32(bf16x6)', 'split16': 'f32(fp16x3)'}.get(f32_conv, 'f32'),
+            'config': {'workload': '%s: batch=%d/GPU synthetic 480x720x3, part detector%s forward + argmax, %s%s%s'
+                                   % (config_name or ('configs[1]' if dtype == 'fp32' else 'configs[2]'), B, ' + spatial model' if use_sm else '',
                                       dtype + (' operands, stride-1 layers as bf16x6 split MFMA' if f32_conv == 'split' else
                                                ' operands, stride-1 layers as fp16x3 split MFMA' if f32_conv == 'split16' else ''),
+                                      ', micro-batches of %d' % mb if B > mb else '',
                                       ', DEBUG filters/4' if args.debug else ''),
-                       'batch_per_gpu': B, 'global_batch': world * B, 'use_sm': use_sm,
+                       'batch_per_gpu': B, 'global_batch': world * B, 'micro_batch': min(mb, B), 'use_sm': use_sm,
                        'collective': 'all_gather coords int32 [B,2,9]'},
             'path_tflops': value * FLOPS_PD_SM / (16 if args.debug else 1) / 1e12,
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm 9x9, 60x90 maps (conv4_fullres + conv5 launches; %s)'
@@ -204,7 +227,8 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
                     kern[key] = {'kernel': what, 'launch_ms': ms / n, 'launches': n, 'achieved': tf, 'frac': tf / PEAK_TFLOPS[prec]}
         out = {'metric': 'images/sec joint training step (fwd+bwd+update), part detector + spatial model', 'value': value,
                'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if prec == 'fp32' else 'bf16', 'data': 'synthetic',
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': 'bf16' if prec == 'bf16' else {'split': 'f32(bf16x6)', 'split16': 'f32(fp16x3)'}.get(f32_conv, 'f32'), 'data': 'synthetic',
                'config': {'workload': 'configs[4]: joint training, batch=%d/GPU synthetic 480x720x3, %s%s, Adam, clip 4.0%s'
                                       % (B, 'fp32 MFMA' if prec == 'fp32' else 'mixed precision: bf16 activations/gradients + bf16 MFMA, fp32 master weights / statistics / losses / spatial model / optimizer',
                                          ' operands; forward, data and weight gradients of the stride-1 layers as bf16x6 split MFMA' if f32_conv == 'split' else
@@ -234,6 +258,10 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (default: 64 fp32 / 256 bf16)')
+    ap.add_argument('--global-batch', type=int, default=None,
+                    help='BASELINE configs[3]: a FIXED global batch (2048) sharded over the ranks, global_batch // N images per rank '
+                         '(main.py:511,516-517), walked in micro-batches inside one step; strong scaling.  bf16 unless --dtype fp32')
+    ap.add_argument('--micro-batch', type=int, default=None, help='images per internal slice of jcm_forward (default 256 bf16 / 64 fp32)')
     ap.add_argument('--dtype', default=None, choices=['fp32', 'bf16'],
                     help='default: the headline line is configs[1] (fp32, batch 64) and configs[2] (bf16, batch 256) '
                          'is measured too and reported under "bf16_config2"')
@@ -246,6 +274,18 @@ def main():
     ap.add_argument('--overlap', action='store_true', help='--train, N > 1, RCCL: start each layer\'s gradient all-reduce during the backward pass')
     ap.add_argument('--layer-times', action='store_true', help='print the HIP-event time of every MFMA conv layer to stderr')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the
+        # same command line the driver uses) and hand over.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -280,12 +320,25 @@ def main():
             dist.destroy_process_group()
         return
 
-    head_dtype = args.dtype or 'fp32'
-    head_batch = args.batch or (64 if head_dtype == 'fp32' else 256)
-    head = run_config(args, head_dtype, head_batch, params, world, rank, local_rank, dev, use_sm,
-                      f32_conv=args.f32_conv if head_dtype == 'fp32' else None)
+    scaling = 'weak'
+    if args.global_batch:
+        # configs[3]: the global batch is fixed, every rank takes global_batch // N contiguous images (the
+        # reference's tower slices, main.py:511,516-517) and one step is one pass over the rank's whole share
+        head_dtype = args.dtype or 'bf16'
+        head_batch = args.global_batch // world
+        if head_batch < 1:
+            raise SystemExit('--global-batch %d is smaller than the number of ranks %d' % (args.global_batch, world))
+        scaling = 'strong'
+        head = run_config(args, head_dtype, head_batch, params, world, rank, local_rank, dev, use_sm,
+                          f32_conv=args.f32_conv if head_dtype == 'fp32' else None, micro_batch=args.micro_batch,
+                          config_name='configs[3] (global batch %d sharded over %d rank%s)' % (args.global_batch, world, '' if world == 1 else 's'))
+    else:
+        head_dtype = args.dtype or 'fp32'
+        head_batch = args.batch or (64 if head_dtype == 'fp32' else 256)
+        head = run_config(args, head_dtype, head_batch, params, world, rank, local_rank, dev, use_sm,
+                          f32_conv=args.f32_conv if head_dtype == 'fp32' else None, micro_batch=args.micro_batch)
     second = split = split16 = None
-    if args.dtype is None and not args.debug:
+    if args.dtype is None and not args.debug and not args.global_batch:
         second = run_config(args, 'bf16', args.batch or 256, params, world, rank, local_rank, dev, use_sm)
         # the same fp32 configuration with the 60x90 9x9 layers on the bf16 matrix cores (three-way operand split, fp32-class
         # error, same parity tests); reported beside the headline, which stays on the exact fp32 MFMA chain
@@ -295,7 +348,7 @@ def main():
     # configs[4] (joint training step, 16 images per GPU) beside the inference lines; single-GPU runs only, the
     # multi-GPU training flow has its own entry point (`--train`)
     train = {}
-    if args.dtype is None and not args.debug and world == 1 and use_sm:
+    if args.dtype is None and not args.debug and world == 1 and use_sm and not args.global_batch:
         train['train_config4_f32'] = run_train(args, 16, params, world, rank, local_rank, dev, use_sm, prec='fp32', f32_conv=None)
         train['train_config4_f32_split'] = run_train(args, 16, params, world, rank, local_rank, dev, use_sm, prec='fp32', f32_conv='split')
         train['train_config4_f32_split16'] = run_train(args, 16, params, world, rank, local_rank, dev, use_sm, prec='fp32', f32_conv='split16')
@@ -304,7 +357,7 @@ def main():
     if rank == 0:
         out = {'metric': 'images/sec (720x480, K=9 joints) part-detector+spatial-model fwd',
                'value': head['value'], 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-               'ms_per_step': head['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'ms_per_step': head['ms_per_step'], 'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
                'dtype': head['dtype'], 'data': 'synthetic', 'config': head['config'], 'path_tflops': head['path_tflops'],
                'roofline': head['roofline']}
         if second is not None:

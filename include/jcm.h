@@ -54,7 +54,12 @@ int jcm_abi_version(void);
  * "split_min_wgs": any time; grids smaller than this keep the exact kernel (default 128, 0 = always split).
  * All three must be set before jcm_finalize.
  * "profile"  : 0/1, any time: bracket every MFMA conv launch with HIP events on the launch
- *              stream; read the totals back with jcm_profile_read. */
+ *              stream; read the totals back with jcm_profile_read.  Events come from a pool owned by the
+ *              handle (created on first use, recycled by jcm_profile_read and by switching the option on,
+ *              destroyed by jcm_destroy), so a profiled step only records.
+ * "micro_batch": any time; jcm_forward walks its batch in slices of this many images, so the workspace is
+ *              sized for one slice (a rank's share of BASELINE configs[3]'s 2048 images fits).  0 (default)
+ *              = 256 for bf16 handles, 64 for fp32 handles. */
 int jcm_set_option(jcm_handle h, const char* key, int64_t value);
 
 /* -- parameters -----------------------------------------------------------------------------
@@ -96,6 +101,11 @@ int jcm_sm_forward(jcm_handle h, const float* hm10, int B, float* logits_out);
 /* get_joints_coords / argmax_hm (evaluation.py:15-24, main.py:389-397): first-occurrence
  * flat argmax per (b,k); coords[b,0,k] = row, coords[b,1,k] = col.  hm [B,HH,WW,K]. */
 int jcm_argmax_coords(jcm_handle h, const float* hm, int B, int HH, int WW, int K, int32_t* coords);
+
+/* spatial_softmax (main.py:212-217) and the arg-max of its result (evaluation.py:15-24) in one pass over the
+ * logits -- the tail of the tower as jcm_forward runs it.  logits [B,HH,WW,K]; prob [B,HH,WW,K] and coords
+ * [B,2,K] may each be NULL (not both). */
+int jcm_softmax_argmax(jcm_handle h, const float* logits, int B, int HH, int WW, int K, float* prob, int32_t* coords);
 
 /* -- the whole tower ----------------------------------------------------------------------------
  * The graph of main.py:522-531: model -> spatial_softmax -> concat torso -> spatial_model ->

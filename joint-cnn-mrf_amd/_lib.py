@@ -35,6 +35,7 @@ SIGNATURES = {
     'jcm_conv_mrf': (ctypes.c_int, [_handle, _c_float_p, _c_float_p, ctypes.c_int, _c_float_p]),
     'jcm_sm_forward': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, _c_float_p]),
     'jcm_argmax_coords': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i32_p]),
+    'jcm_softmax_argmax': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p, _c_i32_p]),
     'jcm_forward': (ctypes.c_int, [_handle, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                    _c_float_p, _c_float_p, _c_i32_p, _c_i32_p]),
     'jcm_window_resize': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -307,13 +307,8 @@ static hipError_t launch(const ConvArgs& a, hipStream_t st) {
   } else {
     blocks = mtiles * nN;
   }
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_f32_kernel<C>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static LdsAttr attr;   // per device, not per process: a second Engine on another GPU needs its own call
+  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(conv_igemm_f32_kernel<C>), C::LDS_BYTES); e != hipSuccess) return e;
   hipLaunchKernelGGL(conv_igemm_f32_kernel<C>, dim3(blocks), dim3(256), C::LDS_BYTES, st, a, tiles_x, tiles_y, mtiles, nN, sp);
   return hipGetLastError();
 }

@@ -365,13 +365,8 @@ static hipError_t launch_b(const ConvArgs& a, hipStream_t st) {
   } else {
     blocks = mtiles * nN;
   }
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_bf16_kernel<C, OUT_F32>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static LdsAttr attr;   // per device, not per process: a second Engine on another GPU needs its own call
+  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(conv_igemm_bf16_kernel<C, OUT_F32>), C::LDS_BYTES); e != hipSuccess) return e;
   hipLaunchKernelGGL((conv_igemm_bf16_kernel<C, OUT_F32>), dim3(blocks), dim3(C::NT), C::LDS_BYTES, st, a, tiles_x, tiles_y, mtiles, nN);
   return hipGetLastError();
 }

@@ -134,12 +134,8 @@ hipError_t conv_thin_bf16(const ConvArgs& a, hipStream_t st) {
   using namespace thinb;
   if (a.Cout > CO || a.CoutP != CO || a.Cin % 32) return hipErrorInvalidValue;
   const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_thin_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static LdsAttr attr;   // per device, not per process: a second Engine on another GPU needs its own call
+  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(conv_thin_bf16_kernel), LDS_BYTES); e != hipSuccess) return e;
   hipLaunchKernelGGL(conv_thin_bf16_kernel, dim3(tiles_x * tiles_y * a.B), dim3(NT), LDS_BYTES, st, a, tiles_x, tiles_y);
   return hipGetLastError();
 }

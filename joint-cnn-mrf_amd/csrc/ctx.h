@@ -98,6 +98,7 @@ struct jcm_ctx {
   int* cond0 = nullptr;         // single zero (jcm_conv_mrf)
   int sm_algo = 2;              // 0 = FFT (2-D rocFFT), 1 = direct sliding-window VALU kernel, 2 = FFT with split row-pruned inverse
   int sm_chunk = 16;            // images per FFT slice
+  int micro_batch = 0;          // jcm_forward walks a batch in slices of this many images (0 = 256 bf16 / 64 fp32)
   jcm::SmFft* fft = nullptr;
   float2* prior_spec = nullptr; // [P][120*91] spectra of softplus5(energy)
   float2* prior_spec_t = nullptr; // the same, transposed [P][91][120] (split inverse)
@@ -109,6 +110,7 @@ struct jcm_ctx {
   // per-layer HIP-event timing on the launch stream (bench.py roofline object)
   bool profile = false;
   std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
+  std::vector<hipEvent_t> event_pool;   // recycled by jcm_profile_read / "profile"=0, destroyed by jcm_destroy
   jcm::TrainState* train = nullptr;   // created by jcm_train_begin
 };
 
@@ -144,6 +146,11 @@ int fold_bn(jcm_ctx* c, const std::string& scope, int n, float** scale, float** 
 // Rebuild every derived table (packed weights, folded BN, softplus'd priors and their spectra) from
 // the parameter store; called by jcm_finalize and after each optimizer update.
 int refresh_derived(jcm_ctx* c, bool first);
+// HIP-event pairs for the per-layer timing come from a pool: inside a timed region the only cost is two
+// hipEventRecord per launch (events are created on first use and recycled by jcm_profile_read).
+int prof_begin(jcm_ctx* c, hipEvent_t* e0, hipEvent_t* e1);
+void prof_end(jcm_ctx* c, const std::string& scope, hipEvent_t e0, hipEvent_t e1, bool ok);
+void prof_release_all(jcm_ctx* c, bool destroy);
 int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int stride, const void* x, int B, int H, int W, int sub,
                    void* out, bool act_bf16, bool out_f32);
 

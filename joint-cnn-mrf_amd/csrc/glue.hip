@@ -318,6 +318,143 @@ hipError_t argmax_coords(const float* hm, int32_t* coords, int B, int HW, int WW
   return hipGetLastError();
 }
 
+// ---- spatial_softmax + argmax of the probabilities in one pass (the tail of main.py:523,531 + evaluation.py:15-24) ----
+// One workgroup per image: its K maps (HW*K contiguous floats, 194 KB at 60x90x9) are read ONCE with 16-byte
+// loads into registers -- a thread owns QPT "quads" of 4 pixels x K channels = K float4 each, so every register's
+// channel is a compile-time constant -- then max, sum of exp, normalise, (optional) store and the first-occurrence
+// argmax of the probabilities all work on those registers.  The two-kernel form read each map three + one times
+// with a 4K-byte stride.
+constexpr int SA_NT = 704;      // 11 waves; 2 quads per thread cover HW <= 5632 pixels
+constexpr int SA_QPT = 2;
+template <int K>
+__global__ __launch_bounds__(SA_NT) void softmax_argmax_kernel(const float4* __restrict__ logits, float4* __restrict__ prob,
+                                                               int32_t* __restrict__ coords, int HW, int WW) {
+  constexpr int NW = SA_NT / 64;
+  __shared__ float redv[NW][K];
+  __shared__ int redi[NW][K];
+  const int b = blockIdx.x, tid = threadIdx.x, wv = tid >> 6;
+  const int nquad = HW >> 2;
+  const float4* src = logits + (size_t)b * nquad * K;
+  float v[SA_QPT][4 * K];
+  bool on[SA_QPT];
+#pragma unroll
+  for (int j = 0; j < SA_QPT; ++j) {
+    const int q = tid + j * SA_NT;
+    on[j] = q < nquad;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const float4 t = on[j] ? src[(size_t)q * K + i] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      v[j][4 * i] = t.x; v[j][4 * i + 1] = t.y; v[j][4 * i + 2] = t.z; v[j][4 * i + 3] = t.w;
+    }
+  }
+  // ---- per-channel max
+  float m[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float a = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < SA_QPT; ++j)
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) a = fmaxf(a, v[j][pp * K + k]);
+    a = wave_max(a);
+    if ((tid & 63) == 0) redv[wv][k] = a;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float a = redv[0][k];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) a = fmaxf(a, redv[w][k]);
+    m[k] = a;
+  }
+  __syncthreads();
+  // ---- exp(z - max) and its per-channel sum
+  float s[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < SA_QPT; ++j)
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) {
+        const float e = on[j] ? expf(v[j][pp * K + k] - m[k]) : 0.f;
+        v[j][pp * K + k] = e;
+        a += e;
+      }
+    a = wave_sum(a);
+    if ((tid & 63) == 0) redv[wv][k] = a;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float a = redv[0][k];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) a += redv[w][k];
+    s[k] = a;
+  }
+  __syncthreads();
+  // ---- normalise, store, argmax of the stored values (larger wins, ties go to the lower pixel index)
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < SA_QPT; ++j)
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) {
+        const float pv = v[j][pp * K + k] / s[k];
+        v[j][pp * K + k] = pv;
+        const int pix = 4 * (tid + j * SA_NT) + pp;
+        if (on[j] && (pv > bv || (pv == bv && pix < bi))) { bv = pv; bi = pix; }
+      }
+    if (coords) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      if ((tid & 63) == 0) { redv[wv][k] = bv; redi[wv][k] = bi; }
+    }
+  }
+  if (prob) {
+    float4* dst = prob + (size_t)b * nquad * K;
+#pragma unroll
+    for (int j = 0; j < SA_QPT; ++j)
+      if (on[j]) {
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+          dst[(size_t)(tid + j * SA_NT) * K + i] = make_float4(v[j][4 * i], v[j][4 * i + 1], v[j][4 * i + 2], v[j][4 * i + 3]);
+      }
+  }
+  if (coords) {
+    __syncthreads();
+    if (tid < K) {
+      float bv = redv[0][tid];
+      int bi = redi[0][tid];
+      for (int w = 1; w < NW; ++w)
+        if (redv[w][tid] > bv || (redv[w][tid] == bv && redi[w][tid] < bi)) { bv = redv[w][tid]; bi = redi[w][tid]; }
+      if (bi == 0x7fffffff) bi = 0;   // all-NaN map: np.argmax returns 0
+      const int row = bi / WW;
+      coords[((size_t)b * 2 + 0) * K + tid] = row;
+      coords[((size_t)b * 2 + 1) * K + tid] = bi - row * WW;
+    }
+  }
+}
+
+hipError_t softmax_argmax(const float* logits, float* prob, int32_t* coords, int B, int HW, int WW, int K, hipStream_t st) {
+  if (K == 9 && HW % 4 == 0 && HW / 4 <= SA_NT * SA_QPT) {
+    hipLaunchKernelGGL(softmax_argmax_kernel<9>, dim3(B), dim3(SA_NT), 0, st, reinterpret_cast<const float4*>(logits),
+                       reinterpret_cast<float4*>(prob), coords, HW, WW);
+    return hipGetLastError();
+  }
+  // other map sizes / joint counts: the two general kernels (prob is required there as the argmax input)
+  if (!prob) return hipErrorInvalidValue;
+  hipError_t e = spatial_softmax(logits, prob, B, HW, K, st);
+  if (e != hipSuccess || !coords) return e;
+  return argmax_coords(prob, coords, B, HW, WW, K, st);
+}
+
 // Inference BatchNorm folded to one multiply-add per channel (tf.contrib batch_norm with moving statistics).
 __global__ void bn_fold_kernel(const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ m,
                                const float* __restrict__ v, float eps, float* __restrict__ scale, float* __restrict__ shift, int n) {

@@ -73,26 +73,9 @@ const ConvLayer* conv_of(jcm_ctx* c, const std::string& scope) {
   return it == c->convs.end() ? nullptr : &it->second;
 }
 
-// One conv layer.  Activations are fp32, or bf16 when the handle runs the bf16 path (`act_bf16`);
-// `out_f32` forces an fp32 result (the logits layer).
-int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int stride, const void* x, int B, int H, int W, int sub,
-                   void* out, bool act_bf16, bool out_f32) {
-  if (c->dry) return JCM_OK;
-  if (stride == 2) {
-    if (!(L->ks == 5 && L->cin == 3 && L->has_bn))
-      return fail(JCM_ERR_ARG, "stride-2 kernel exists for 5x5, Cin=3, BN layers only (" + scope + ")");
-    HIP_TRY(conv1_5x5s2(static_cast<const float*>(x), L->w_raw, L->bias, L->scale, L->shift, out, act_bf16, B, H, W, sub,
-                        L->cout, c->stream));
-    return JCM_OK;
-  }
-  const void* wp = act_bf16 ? L->wp_bf16 : static_cast<const void*>(L->wp);
-  if (stride != 1 || !wp) return fail(JCM_ERR_ARG, "no kernel for layer '" + scope + "' with stride " + std::to_string(stride));
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (c->profile) {
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, c->stream));
-  }
+// The launch itself (kernel choice by precision / f32_conv); run_conv_layer brackets it with the timing events.
+static int launch_conv_layer(jcm_ctx* c, const ConvLayer* L, const void* wp, const void* x, int B, int H, int W, void* out, bool act_bf16,
+                             bool out_f32) {
   ConvArgs a;
   a.x = x; a.wp = wp; a.bias = L->bias; a.scale = L->scale; a.shift = L->shift; a.out = out;
   a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout; a.relu_bn = L->has_bn ? 1 : 0;
@@ -122,11 +105,70 @@ int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int
       HIP_TRY(conv_igemm_f32(a, L->ks, c->stream));
     }
   }
-  if (c->profile) {
-    HIP_TRY(hipEventRecord(e1, c->stream));
-    c->prof[scope].emplace_back(e0, e1);
+  return JCM_OK;
+}
+
+static int pool_get(jcm_ctx* c, hipEvent_t* e) {
+  if (!c->event_pool.empty()) {
+    *e = c->event_pool.back();
+    c->event_pool.pop_back();
+    return JCM_OK;
+  }
+  HIP_TRY(hipEventCreate(e));
+  return JCM_OK;
+}
+int prof_begin(jcm_ctx* c, hipEvent_t* e0, hipEvent_t* e1) {
+  *e0 = *e1 = nullptr;
+  if (!c->profile) return JCM_OK;
+  JCM_TRY(pool_get(c, e0));
+  if (int r = pool_get(c, e1); r != JCM_OK) { c->event_pool.push_back(*e0); *e0 = nullptr; return r; }
+  hipError_t e = hipEventRecord(*e0, c->stream);
+  if (e != hipSuccess) {
+    prof_end(c, "", *e0, *e1, false);
+    *e0 = *e1 = nullptr;
+    return fail(JCM_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e));
   }
   return JCM_OK;
+}
+// ok: the launch went out -> record the closing event and file the pair under `scope`; otherwise return both to the pool
+void prof_end(jcm_ctx* c, const std::string& scope, hipEvent_t e0, hipEvent_t e1, bool ok) {
+  if (!e0) return;
+  if (ok && hipEventRecord(e1, c->stream) == hipSuccess) {
+    c->prof[scope].emplace_back(e0, e1);
+  } else {
+    c->event_pool.push_back(e0);
+    c->event_pool.push_back(e1);
+  }
+}
+void prof_release_all(jcm_ctx* c, bool destroy) {
+  for (auto& kv : c->prof)
+    for (auto& ev : kv.second) { c->event_pool.push_back(ev.first); c->event_pool.push_back(ev.second); }
+  c->prof.clear();
+  if (destroy) {
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    c->event_pool.clear();
+  }
+}
+
+// One conv layer.  Activations are fp32, or bf16 when the handle runs the bf16 path (`act_bf16`);
+// `out_f32` forces an fp32 result (the logits layer).
+int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int stride, const void* x, int B, int H, int W, int sub,
+                   void* out, bool act_bf16, bool out_f32) {
+  if (c->dry) return JCM_OK;
+  if (stride == 2) {
+    if (!(L->ks == 5 && L->cin == 3 && L->has_bn))
+      return fail(JCM_ERR_ARG, "stride-2 kernel exists for 5x5, Cin=3, BN layers only (" + scope + ")");
+    HIP_TRY(conv1_5x5s2(static_cast<const float*>(x), L->w_raw, L->bias, L->scale, L->shift, out, act_bf16, B, H, W, sub,
+                        L->cout, c->stream));
+    return JCM_OK;
+  }
+  const void* wp = act_bf16 ? L->wp_bf16 : static_cast<const void*>(L->wp);
+  if (stride != 1 || !wp) return fail(JCM_ERR_ARG, "no kernel for layer '" + scope + "' with stride " + std::to_string(stride));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  JCM_TRY(prof_begin(c, &e0, &e1));
+  const int r = launch_conv_layer(c, L, wp, x, B, H, W, out, act_bf16, out_f32);
+  prof_end(c, scope, e0, e1, r == JCM_OK);
+  return r;
 }
 
 }  // namespace jcm
@@ -341,14 +383,16 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
 }
 
 // spatial_model(heat_map), main.py:94-125.
-int sm_forward_impl(jcm_ctx* c, const float* hm10, int B, float* logits) {
+// The 10-channel input is given as channels [0,Ca) of `hm` ([B,5400,Ca]) plus `extra` ([B,5400,10-Ca]): Ca = 10 for
+// jcm_sm_forward, Ca = 9 + the torso map inside the tower (the tf.concat of main.py:528 is never materialised).
+int sm_forward_impl(jcm_ctx* c, const float* hm, int Ca, const float* extra, int B, float* logits) {
   if (!c->has_sm) return fail(JCM_ERR_STATE, "spatial-model parameters (bn_sm, energy_*, bias_*) were not set");
   const int P = c->K * (kC - 1);
   if (c->sm_algo == 1) {   // direct convolution
     float* lik = arena_alloc<float>(c, (size_t)B * kC * kHmH * 96);
     float* cpre = arena_alloc<float>(c, (size_t)B * P * kCH * kCW);
     if (c->dry) return JCM_OK;
-    HIP_TRY(sm_likelihood(hm10, c->bn_sm_scale, c->bn_sm_shift, lik, B, kC, c->stream));
+    HIP_TRY(sm_likelihood(hm, Ca, extra, c->bn_sm_scale, c->bn_sm_shift, lik, B, kC, c->stream));
     HIP_TRY(sm_pair_conv(c->sp_energy, lik, c->cond, cpre, B, P, kC, c->stream));
     HIP_TRY(sm_finish(lik, cpre, c->sp_bias, logits, B, c->K, kC, c->stream));
     return JCM_OK;
@@ -365,7 +409,8 @@ int sm_forward_impl(jcm_ctx* c, const float* hm10, int B, float* logits) {
     if (c->dry) return JCM_OK;
     for (int b0 = 0; b0 < B; b0 += Bc) {
       const int nb = B - b0 < Bc ? B - b0 : Bc;
-      HIP_TRY(sm_pad_frame(hm10 + (size_t)b0 * kHmHW * kC, c->bn_sm_scale, c->bn_sm_shift, frame, nb, kC, c->stream));
+      HIP_TRY(sm_pad_frame(hm + (size_t)b0 * kHmHW * Ca, Ca, extra ? extra + (size_t)b0 * kHmHW * (kC - Ca) : nullptr, c->bn_sm_scale, c->bn_sm_shift,
+                           frame, nb, kC, c->stream));
       FFT_TRY(sm_fft_r2c(c->fft, frame, lhat, nb * kC));
       HIP_TRY(sm_transpose(lhat, lhat_t, nb * kC, kPrH, WC, 0, WC, c->stream));
       HIP_TRY(sm_spec_mul(lhat_t, c->prior_spec_t, c->cond, spec_t, nb, kC, P, c->stream));      // elementwise: layout-agnostic
@@ -387,7 +432,8 @@ int sm_forward_impl(jcm_ctx* c, const float* hm10, int B, float* logits) {
   if (c->dry) return JCM_OK;
   for (int b0 = 0; b0 < B; b0 += Bc) {
     const int nb = B - b0 < Bc ? B - b0 : Bc;
-    HIP_TRY(sm_pad_frame(hm10 + (size_t)b0 * kHmHW * kC, c->bn_sm_scale, c->bn_sm_shift, frame, nb, kC, c->stream));
+    HIP_TRY(sm_pad_frame(hm + (size_t)b0 * kHmHW * Ca, Ca, extra ? extra + (size_t)b0 * kHmHW * (kC - Ca) : nullptr, c->bn_sm_scale, c->bn_sm_shift,
+                           frame, nb, kC, c->stream));
     FFT_TRY(sm_fft_r2c(c->fft, frame, lhat, nb * kC));
     HIP_TRY(sm_spec_mul(lhat, c->prior_spec, c->cond, spec, nb, kC, P, c->stream));
     FFT_TRY(sm_fft_c2r(c->fft, spec, cfull, nb * P));
@@ -426,6 +472,7 @@ int jcm_destroy(jcm_handle h) {
   DeviceGuard g(h->device);
   (void)hipStreamSynchronize(h->stream);
   sm_fft_destroy(h->fft);
+  prof_release_all(h, true);
   if (h->train) train_destroy(h);
   for (auto& kv : h->params) (void)hipFree(kv.second.d);
   for (void* p : h->owned) (void)hipFree(p);
@@ -437,8 +484,18 @@ int jcm_destroy(jcm_handle h) {
 int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
   JCM_TRY(check(h, false));
   const std::string k = key ? key : "";
-  if (k == "profile") {   // allowed at any time
+  if (k == "profile") {   // allowed at any time; switching it on starts a fresh record (events go back to the pool)
+    if (value != 0 && !h->profile) {
+      DeviceGuard g(h->device);
+      (void)hipStreamSynchronize(h->stream);
+      prof_release_all(h, false);
+    }
     h->profile = value != 0;
+    return JCM_OK;
+  }
+  if (k == "micro_batch") {   // allowed at any time
+    if (value < 0) return fail(JCM_ERR_ARG, "micro_batch must be >= 0 (0 = default: 256 bf16 / 64 fp32)");
+    h->micro_batch = (int)value;
     return JCM_OK;
   }
   if (k == "sm_chunk") {  // allowed at any time
@@ -543,7 +600,7 @@ int jcm_spatial_softmax(jcm_handle h, const float* in, int B, int HW, int K, flo
   JCM_TRY(check(h, false));
   if (!in || !out || B < 1 || HW < 1 || K < 1) return fail(JCM_ERR_ARG, "bad spatial_softmax arguments");
   DeviceGuard g(h->device);
-  HIP_TRY(spatial_softmax(in, out, B, HW, K, h->stream));
+  HIP_TRY(softmax_argmax(in, out, nullptr, B, HW, 1, K, h->stream));   // one-pass kernel for K = 9 maps, general kernel otherwise
   return JCM_OK;
 }
 
@@ -557,7 +614,7 @@ int jcm_conv_mrf(jcm_handle h, const float* A, const float* Bmaps, int B, float*
       float* rev = arena_alloc<float>(c, (size_t)B * kHmH * 96);
       float* cpre = arena_alloc<float>(c, (size_t)B * kCH * kCW);
       if (c->dry) return (int)JCM_OK;
-      HIP_TRY(sm_likelihood(Bmaps, nullptr, nullptr, rev, B, 1, c->stream));     // reversed, padded copy
+      HIP_TRY(sm_likelihood(Bmaps, 1, nullptr, nullptr, nullptr, rev, B, 1, c->stream));     // reversed, padded copy
       HIP_TRY(sm_pair_conv(A, rev, c->cond0, cpre, B, 1, 1, c->stream));         // main.py:83-87
       HIP_TRY(sm_resize_only(cpre, out, B, c->stream));                          // main.py:89
       return (int)JCM_OK;
@@ -568,7 +625,7 @@ int jcm_conv_mrf(jcm_handle h, const float* A, const float* Bmaps, int B, float*
     float2* spec = arena_alloc<float2>(c, (size_t)B * kSpec);
     float* cfull = arena_alloc<float>(c, (size_t)B * kFrame);
     if (c->dry) return (int)JCM_OK;
-    HIP_TRY(sm_pad_frame(Bmaps, nullptr, nullptr, frame, B, 1, c->stream));
+    HIP_TRY(sm_pad_frame(Bmaps, 1, nullptr, nullptr, nullptr, frame, B, 1, c->stream));
     FFT_TRY(sm_fft_r2c(c->fft, frame, lhat, B));
     FFT_TRY(sm_fft_r2c(c->fft, A, ahat, 1));
     HIP_TRY(sm_spec_mul(lhat, ahat, c->cond0, spec, B, 1, 1, c->stream));        // main.py:83-87
@@ -582,7 +639,17 @@ int jcm_sm_forward(jcm_handle h, const float* hm10, int B, float* logits_out) {
   JCM_TRY(check(h, true));
   if (!hm10 || !logits_out || B < 1) return fail(JCM_ERR_ARG, "bad sm_forward arguments");
   DeviceGuard g(h->device);
-  return with_arena(h, [&] { return sm_forward_impl(h, hm10, B, logits_out); });
+  return with_arena(h, [&] { return sm_forward_impl(h, hm10, kC, nullptr, B, logits_out); });
+}
+
+int jcm_softmax_argmax(jcm_handle h, const float* logits, int B, int HH, int WW, int K, float* prob, int32_t* coords) {
+  JCM_TRY(check(h, false));
+  if (!logits || (!prob && !coords) || B < 1 || HH < 1 || WW < 1 || K < 1) return fail(JCM_ERR_ARG, "bad softmax_argmax arguments");
+  if (!prob && !(K == 9 && (HH * WW) % 4 == 0 && HH * WW <= 5632))
+    return fail(JCM_ERR_ARG, "softmax_argmax without a probability output exists for K = 9 and H*W % 4 == 0, H*W <= 5632 only");
+  DeviceGuard g(h->device);
+  HIP_TRY(softmax_argmax(logits, prob, coords, B, HH * WW, WW, K, h->stream));
+  return JCM_OK;
 }
 
 int jcm_argmax_coords(jcm_handle h, const float* hm, int B, int HH, int WW, int K, int32_t* coords) {
@@ -603,28 +670,46 @@ int jcm_forward(jcm_handle h, const float* x, const float* torso, int B, int H, 
   DeviceGuard g(h->device);
   jcm_ctx* c = h;
   const int K = c->K;
-  return with_arena(c, [&] {
-    const int hh = cdiv2(cdiv2(cdiv2(H))), ww = cdiv2(cdiv2(cdiv2(W)));
-    const size_t n = (size_t)B * hh * ww * K;
+  if (use_sm && K + 1 != kC) return fail(JCM_ERR_ARG, "use_sm requires n_joints == 9 (10-channel spatial model)");
+  const int hh = cdiv2(cdiv2(cdiv2(H))), ww = cdiv2(cdiv2(cdiv2(W)));
+  // Images are independent in inference (moving-statistics BatchNorm, main.py:406), so a large batch -- a rank's
+  // share of BASELINE configs[3]'s 2048 -- is walked in micro-batches: the arena is sized for one micro-batch,
+  // every launch sequence is the one a batch of that size gets, and the outputs land in the caller's tensors at
+  // the image offset.  The arena is sized once, for the largest micro-batch.
+  const int mb_opt = c->micro_batch > 0 ? c->micro_batch : (c->precision == JCM_PRECISION_BF16 ? 256 : 64);
+  const int mb = B < mb_opt ? B : mb_opt;
+  auto body = [&](int b0, int nb) {
+    const size_t n = (size_t)nb * hh * ww * K;
+    const size_t o = (size_t)b0 * hh * ww * K;
     float* logits = arena_alloc<float>(c, n);
-    float* prob = pd_prob ? pd_prob : arena_alloc<float>(c, n);
+    float* prob = pd_prob ? pd_prob + o : arena_alloc<float>(c, n);
     const size_t mark = c->arena_off;
-    JCM_TRY(pd_forward_impl(c, x, B, H, W, logits));                                      // main.py:522
+    JCM_TRY(pd_forward_impl(c, x + (size_t)b0 * H * W * 3, nb, H, W, logits));            // main.py:522
     c->arena_off = mark;
-    if (!c->dry) HIP_TRY(spatial_softmax(logits, prob, B, hh * ww, K, c->stream));           // main.py:523
-    if (pd_coords && !c->dry) HIP_TRY(argmax_coords(prob, pd_coords, B, hh * ww, ww, K, c->stream));
+    // spatial_softmax (main.py:523) and the argmax of evaluation.py:15-24 in one pass over the logits
+    if (!c->dry) HIP_TRY(softmax_argmax(logits, prob, pd_coords ? pd_coords + (size_t)b0 * 2 * K : nullptr, nb, hh * ww, ww, K, c->stream));
     if (use_sm) {
-      float* hm10 = arena_alloc<float>(c, (size_t)B * hh * ww * (K + 1));
       float* sml = arena_alloc<float>(c, n);
-      float* smp = sm_prob ? sm_prob : arena_alloc<float>(c, n);
-      if (K + 1 != kC) return fail(JCM_ERR_ARG, "use_sm requires n_joints == 9 (10-channel spatial model)");
-      if (!c->dry) HIP_TRY(concat_channels(prob, K, torso, 1, hm10, (size_t)B * hh * ww, c->stream));   // main.py:528
-      JCM_TRY(sm_forward_impl(c, hm10, B, sml));                                          // main.py:530
-      if (!c->dry) HIP_TRY(spatial_softmax(sml, smp, B, hh * ww, K, c->stream));           // main.py:531
-      if (sm_coords && !c->dry) HIP_TRY(argmax_coords(smp, sm_coords, B, hh * ww, ww, K, c->stream));
+      float* smp = sm_prob ? sm_prob + o : nullptr;
+      JCM_TRY(sm_forward_impl(c, prob, K, torso + (size_t)b0 * hh * ww, nb, sml));       // main.py:528,530
+      if (!c->dry && (smp || sm_coords))
+        HIP_TRY(softmax_argmax(sml, smp, sm_coords ? sm_coords + (size_t)b0 * 2 * K : nullptr, nb, hh * ww, ww, K, c->stream));   // main.py:531
     }
     return (int)JCM_OK;
-  });
+  };
+  // sizing pass on the largest micro-batch, then the real passes (the arena never reallocates mid-graph)
+  c->dry = true;
+  c->arena_off = 0;
+  c->arena_peak = 0;
+  int r = body(0, mb);
+  c->dry = false;
+  if (r != JCM_OK) return r;
+  JCM_TRY(arena_reserve(c, c->arena_peak));
+  for (int b0 = 0; b0 < B; b0 += mb) {
+    c->arena_off = 0;
+    JCM_TRY(body(b0, B - b0 < mb ? B - b0 : mb));
+  }
+  return JCM_OK;
 }
 
 int jcm_window_resize(jcm_handle h, const float* src, int nsrc, int H, int W, int C, const int32_t* windows, int NW,
@@ -671,8 +756,8 @@ int jcm_profile_read(jcm_handle h, const char* scope, double* total_ms, int* lau
       HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
       tot += ms;
       ++n;
-      (void)hipEventDestroy(ev.first);
-      (void)hipEventDestroy(ev.second);
+      h->event_pool.push_back(ev.first);
+      h->event_pool.push_back(ev.second);
     }
     h->prof.erase(it);
   }

@@ -195,19 +195,14 @@ int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int ldz, int B, fl
       HIP_TRY(split_parts(static_cast<const float*>(dz), zparts, nz, c->stream));
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->profile) {
-      HIP_TRY(hipEventCreate(&e0));
-      HIP_TRY(hipEventCreate(&e1));
-      HIP_TRY(hipEventRecord(e0, c->stream));
-    }
-    if (bf(c)) HIP_TRY(wgrad_bf16(f.in, dz, partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream));
-    else if (h16) HIP_TRY(wgrad_split16(xparts, zparts, partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream));
-    else if (split) HIP_TRY(wgrad_split(xparts, zparts, partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream));
-    else HIP_TRY(wgrad_f32(static_cast<const float*>(f.in), static_cast<const float*>(dz), partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream));
-    if (c->profile) {
-      HIP_TRY(hipEventRecord(e1, c->stream));
-      c->prof["wgrad:" + f.scope].emplace_back(e0, e1);      // read with jcm_profile_read("wgrad:<scope>")
-    }
+    JCM_TRY(prof_begin(c, &e0, &e1));
+    hipError_t le;
+    if (bf(c)) le = wgrad_bf16(f.in, dz, partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream);
+    else if (h16) le = wgrad_split16(xparts, zparts, partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream);
+    else if (split) le = wgrad_split(xparts, zparts, partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream);
+    else le = wgrad_f32(static_cast<const float*>(f.in), static_cast<const float*>(dz), partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream);
+    prof_end(c, "wgrad:" + f.scope, e0, e1, le == hipSuccess);      // read with jcm_profile_read("wgrad:<scope>")
+    if (le != hipSuccess) return fail(JCM_ERR_HIP, "weight-gradient launch of '" + f.scope + "': " + hipGetErrorString(le));
     HIP_TRY(wgrad_reduce(partial, splits, n, L->w_raw, lmbd, grad_of(t, grads, f.scope + "/weights"), c->stream, h16 ? t->gscale + 1 : nullptr));
   }
   c->arena_off = mark;
@@ -244,17 +239,10 @@ int conv_dgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int B, void* dx) {
     }
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (c->profile) {
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, c->stream));
-  }
-  if (split) HIP_TRY(conv_split_f32(a, f.L->ks, ns, c->stream));
-  else HIP_TRY(conv_igemm_f32(a, f.L->ks, c->stream));
-  if (c->profile) {
-    HIP_TRY(hipEventRecord(e1, c->stream));
-    c->prof["dgrad:" + f.scope].emplace_back(e0, e1);
-  }
+  JCM_TRY(prof_begin(c, &e0, &e1));
+  const hipError_t le = split ? conv_split_f32(a, f.L->ks, ns, c->stream) : conv_igemm_f32(a, f.L->ks, c->stream);
+  prof_end(c, "dgrad:" + f.scope, e0, e1, le == hipSuccess);
+  if (le != hipSuccess) return fail(JCM_ERR_HIP, "data-gradient launch of '" + f.scope + "': " + hipGetErrorString(le));
   return JCM_OK;
 }
 
@@ -448,7 +436,7 @@ int sm_train_impl(jcm_ctx* c, const float* pd_prob, const float* y, int B, float
         const int nb = B - b0 < Bc ? B - b0 : Bc;
         float* fr = frame + (size_t)b0 * kC * kFrame;
         float2* lh = lhat + (size_t)b0 * kC * kSpec;
-        HIP_TRY(sm_pad_frame(hm10 + (size_t)b0 * kHmHW * kC, sc, sh, fr, nb, kC, c->stream));
+        HIP_TRY(sm_pad_frame(hm10 + (size_t)b0 * kHmHW * kC, kC, nullptr, sc, sh, fr, nb, kC, c->stream));
         FFT_TRY(sm_fft_r2c(c->fft, fr, lh, nb * kC));
         HIP_TRY(sm_transpose(lh, lhat_t, nb * kC, kPrH, WC, 0, WC, c->stream));
         HIP_TRY(sm_spec_mul(lhat_t, c->prior_spec_t, c->cond, spec_t, nb, kC, P, c->stream));

@@ -4,7 +4,26 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace jcm {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: launchers that need more than
+// 64 KB of LDS call ensure() before every launch; the attribute is set once per (instantiation, current device).
+// Two threads racing on the same device both set the same value, which is harmless.
+struct LdsAttr {
+  std::atomic<uint64_t> done{0};
+  hipError_t ensure(const void* fn, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+  }
+};
 
 // ---- conv_igemm.hip : implicit-GEMM stride-1 SAME convolution on MFMA ----------------------
 // x NHWC [B,H,W,Cin] (Cin % 16 == 0), packed weights [k*k][Cin/4][CoutP][4] (fp32) or
@@ -81,6 +100,9 @@ hipError_t upsample_merge3(const void* x1, const void* x2, int H2, int W2, const
 hipError_t concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, size_t N, hipStream_t st);
 hipError_t spatial_softmax(const float* in, float* out, int B, int HW, int K, hipStream_t st);
 hipError_t argmax_coords(const float* hm, int32_t* coords, int B, int HW, int WW, int K, hipStream_t st);
+// spatial_softmax followed by the first-occurrence argmax of the probabilities, one pass over the logits, one
+// workgroup per image: prob (may be null) [B,HW,K], coords (may be null) [B,2,K].  HW % 4 == 0, K <= 9.
+hipError_t softmax_argmax(const float* logits, float* prob, int32_t* coords, int B, int HW, int WW, int K, hipStream_t st);
 // scale = gamma / sqrt(var + eps), shift = beta - mean * scale
 hipError_t bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale, float* shift,
                    int n, hipStream_t st);
@@ -91,7 +113,8 @@ hipError_t sm_softplus5(const float* in, float* out, int64_t n, hipStream_t st);
 // out[p][i] = softplus5(in[p][i]) for P separately allocated tensors of n elements each (one launch for the 81 pairs)
 hipError_t sm_softplus5_multi(const float* const* in, float* out, int P, int64_t n, hipStream_t st);
 // hm [B,5400,C] NHWC -> lik [B][C][5400] planar = softplus5(bn(hm))
-hipError_t sm_likelihood(const float* hm, const float* bn_scale, const float* bn_shift, float* lik,
+// (channels [0,Ca) from hm [B,5400,Ca], the rest from extra [B,5400,C-Ca]: main.py:528's concat read in place)
+hipError_t sm_likelihood(const float* hm, int Ca, const float* extra, const float* bn_scale, const float* bn_shift, float* lik,
                          int B, int C, hipStream_t st);
 // cpre[b][p][61*91] = valid true convolution of prior p (120x180, already softplus'd) with
 // maps[b][cond[p]] (60x90 planar)           (main.py:83-87)
@@ -111,7 +134,9 @@ void sm_fft_destroy(SmFft* f);
 const char* sm_fft_r2c(SmFft* f, const float* in, float2* out, int n);
 const char* sm_fft_c2r(SmFft* f, float2* in, float* out, int n);
 // frame[b][c] = softplus5(bn(hm[b,:,:,c])) in the top-left 60x90 of a zero 120x180 frame (sc null: raw)
-hipError_t sm_pad_frame(const float* hm, const float* sc, const float* sh, float* frame, int B, int C, hipStream_t st);
+// (channels [0,Ca) from hm [B,5400,Ca], the rest from extra [B,5400,C-Ca]: main.py:528's concat read in place)
+hipError_t sm_pad_frame(const float* hm, int Ca, const float* extra, const float* sc, const float* sh, float* frame, int B, int C,
+                        hipStream_t st);
 // spec[b][p] = lhat[b][cond[p]] * phat[p] / (120*180)
 hipError_t sm_spec_mul(const float2* lhat, const float2* phat, const int* cond, float2* spec, int B, int C, int P, hipStream_t st);
 hipError_t sm_finish_fft(const float* frame, const float* cfull, const float* spbias, float* logits, int B, int K, int C, hipStream_t st);

@@ -58,8 +58,9 @@ hipError_t sm_softplus5_multi(const float* const* in, float* out, int P, int64_t
 
 // lik[b][c] : [60][96] rows reversed along x:  lik[u][t] = sp(bn(h[b,u,89-t,c])) for t<90, 0 beyond;
 // the unary term reads it back as lik[u][89-x].
-__global__ void sm_likelihood_kernel(const float* __restrict__ hm, const float* __restrict__ sc, const float* __restrict__ sh,
-                                     float* __restrict__ lik, int C, int64_t total) {
+// channels [0,Ca) come from hm [B,5400,Ca], the rest from extra [B,5400,C-Ca] (the concat of main.py:528 read in place)
+__global__ void sm_likelihood_kernel(const float* __restrict__ hm, int Ca, const float* __restrict__ extra, const float* __restrict__ sc,
+                                     const float* __restrict__ sh, float* __restrict__ lik, int C, int64_t total) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int t = i % SM_LP;
     int64_t r = i / SM_LP;
@@ -68,16 +69,18 @@ __global__ void sm_likelihood_kernel(const float* __restrict__ hm, const float* 
     const int64_t b = r / C;
     float v = 0.f;
     if (t < SM_W) {
-      const float hv = hm[((b * SM_H + u) * SM_W + (SM_W - 1 - t)) * C + c];
+      const int64_t pix = (b * SM_H + u) * SM_W + (SM_W - 1 - t);
+      const float hv = c < Ca ? hm[pix * Ca + c] : extra[pix * (C - Ca) + (c - Ca)];
       v = sc ? softplus5(hv * sc[c] + sh[c]) : hv;   // sc == nullptr: raw reversed copy (jcm_conv_mrf)
     }
     lik[i] = v;
   }
 }
-hipError_t sm_likelihood(const float* hm, const float* bn_scale, const float* bn_shift, float* lik, int B, int C, hipStream_t st) {
+hipError_t sm_likelihood(const float* hm, int Ca, const float* extra, const float* bn_scale, const float* bn_shift, float* lik, int B, int C,
+                         hipStream_t st) {
   const int64_t total = (int64_t)B * C * SM_H * SM_LP;
   int64_t g = (total + 255) / 256;
-  hipLaunchKernelGGL(sm_likelihood_kernel, dim3((int)(g > 8192 ? 8192 : g)), dim3(256), 0, st, hm, bn_scale, bn_shift, lik, C, total);
+  hipLaunchKernelGGL(sm_likelihood_kernel, dim3((int)(g > 8192 ? 8192 : g)), dim3(256), 0, st, hm, Ca, extra, bn_scale, bn_shift, lik, C, total);
   return hipGetLastError();
 }
 
@@ -140,12 +143,8 @@ __global__ __launch_bounds__(PC_THREADS) void sm_pair_conv_kernel(const float* _
 
 hipError_t sm_pair_conv(const float* priors, const float* maps, const int* cond, float* cpre, int B, int P, int C, hipStream_t st) {
   const int lds = SM_PH * SM_PP * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sm_pair_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static LdsAttr attr;   // per device, not per process: a second Engine on another GPU needs its own call
+  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(sm_pair_conv_kernel), lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(sm_pair_conv_kernel, dim3(B * P), dim3(PC_THREADS), lds, st, priors, maps, cond, cpre, P, C);
   return hipGetLastError();
 }

@@ -19,7 +19,7 @@ def _hm_size(n):
 class Engine:
     """Owns a jcm_handle.  All tensor arguments are torch CUDA float32 NHWC, contiguous."""
 
-    def __init__(self, device=0, precision='fp32', n_joints=9, stream=None, f32_conv=None, split_min_wgs=None):
+    def __init__(self, device=0, precision='fp32', n_joints=9, stream=None, f32_conv=None, split_min_wgs=None, micro_batch=None):
         if not torch.cuda.is_available():
             raise RuntimeError('joint-cnn-mrf_amd needs an MI355X (gfx950) GPU; torch.cuda.is_available() is False '
                                'and there is no CPU path')
@@ -38,6 +38,8 @@ class Engine:
         _lib.check(self._lib.jcm_set_option(self._h, b'n_joints', self.n_joints), 'jcm_set_option(n_joints)')
         if f32_conv is not None:      # 'exact' = fp32 MFMA, 'split' = bf16x6, 'split16' = fp16x3 forward (+ bf16x6 gradients): fp32-level accuracy on the 16-bit matrix cores
             _lib.check(self._lib.jcm_set_option(self._h, b'f32_conv', {'exact': 0, 'split': 1, 'split16': 2}[f32_conv]), 'jcm_set_option(f32_conv)')
+        if micro_batch is not None:   # forward() walks a batch in slices of this many images (default 256 bf16 / 64 fp32)
+            self.set_micro_batch(micro_batch)
         if split_min_wgs is not None: # 0 forces the split kernels even on grids too small to pay off (parity tests at small batch)
             _lib.check(self._lib.jcm_set_option(self._h, b'split_min_wgs', int(split_min_wgs)), 'jcm_set_option(split_min_wgs)')
 
@@ -175,6 +177,16 @@ class Engine:
         _lib.check(self._lib.jcm_argmax_coords(self._h, self._p(hm), B, H, W, K, self._p(out)), 'jcm_argmax_coords')
         return out
 
+    def softmax_argmax(self, logits, want_prob=True):
+        """spatial_softmax + arg-max of the probabilities in one kernel (the tail of forward()):
+        [B,H,W,K] logits -> (prob [B,H,W,K] or None, coords int32 [B,2,K])."""
+        self._chk(logits, 4, 'logits')
+        B, H, W, K = logits.shape
+        prob = torch.empty_like(logits) if want_prob else None
+        coords = self._new(B, 2, K, dtype=torch.int32)
+        _lib.check(self._lib.jcm_softmax_argmax(self._h, self._p(logits), B, H, W, K, self._p(prob), self._p(coords)), 'jcm_softmax_argmax')
+        return prob, coords
+
     def forward(self, x, torso=None, use_sm=True, want_prob=True):
         """The tower of main.py:522-531 in one C call.  Returns a dict with 'pd_coords',
         'sm_coords' (int32 [B,2,K]) and, if want_prob, 'pd_prob' / 'sm_prob' [B,60,90,K]."""
@@ -230,6 +242,11 @@ class Engine:
         (rocFFT 1-D columns, then only the 61 rows the VALID window needs) or 'direct' (LDS sliding-window
         VALU kernel).  All are HIP paths; bench/profiles compare them."""
         _lib.check(self._lib.jcm_set_option(self._h, b'sm_algo', {'fft': 0, 'direct': 1, 'fft_split': 2}[algo]), 'jcm_set_option(sm_algo)')
+
+    def set_micro_batch(self, n):
+        """Images per internal slice of forward(): bounds the workspace when a rank holds a large share of a
+        global batch (BASELINE configs[3]: 2048 images over the ranks).  0 = default (256 bf16 / 64 fp32)."""
+        _lib.check(self._lib.jcm_set_option(self._h, b'micro_batch', int(n)), 'jcm_set_option(micro_batch)')
 
     def set_profile(self, on):
         _lib.check(self._lib.jcm_set_option(self._h, b'profile', int(bool(on))), 'jcm_set_option(profile)')

@@ -36,9 +36,10 @@ class Trainer:
         self.eng = engine
         self.optimizer, self.lr, self.lmbd, self.use_sm = optimizer, float(lr), float(lmbd), bool(use_sm)
         self.n_updates_total = n_updates_total
-        # start each layer's gradient all-reduce (RCCL) as soon as the backward pass has produced it; opt-in: this round's
-        # boxes have one GPU, so the asynchronous path is exercised only up to its notifications (tests) -- not end to end
+        # start each layer's gradient all-reduce (RCCL) as soon as the backward pass has produced it; opt-in.  The boxes
+        # of this build have one GPU: the path runs end to end on a one-rank RCCL group (tests/test_gpu_dist.py)
         self.overlap_allreduce = bool(overlap_allreduce)
+        self._cb_error = None
         self._lib = engine._lib
         _lib.check(self._lib.jcm_train_begin(engine._h), 'jcm_train_begin')
         nt, ne = ctypes.c_int64(), ctypes.c_int64()
@@ -75,8 +76,14 @@ class Trainer:
         B, H, W, C = x.shape
         if C != 3 or y.shape[0] != B or y.shape[3] != e.n_joints + 1:
             raise ValueError('x must be [B,H,W,3] and y [B,h,w,%d]; got %s, %s' % (e.n_joints + 1, tuple(x.shape), tuple(y.shape)))
-        _lib.check(self._lib.jcm_train_loss_grads(e._h, e._p(x), e._p(y), B, H, W, int(self.use_sm), self.lmbd,
-                                                  e._p(self.grads), e._p(self.losses)), 'jcm_train_loss_grads')
+        self._cb_error = None
+        status = self._lib.jcm_train_loss_grads(e._h, e._p(x), e._p(y), B, H, W, int(self.use_sm), self.lmbd,
+                                                e._p(self.grads), e._p(self.losses))
+        if self._cb_error is not None:      # ctypes swallows exceptions raised inside a callback: re-raise them here
+            err, self._cb_error = self._cb_error, None
+            self._pending, self._covered = [], []
+            raise err
+        _lib.check(status, 'jcm_train_loss_grads')
         return self.losses, self.grads
 
     def grads_dict(self):
@@ -91,33 +98,37 @@ class Trainer:
 
     def _overlap_active(self):
         import torch.distributed as dist
-        return (self.overlap_allreduce and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-                and dist.get_backend() == 'nccl')
+        return self.overlap_allreduce and dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl'
 
     def _on_grads_ready(self, _user, offset, count):
         """jcm_grad_ready_fn: the kernels writing grads[offset:offset+count] are enqueued on the engine's stream.  With RCCL
         the range's all-reduce starts now, on a side stream behind an event, while the backward pass keeps the compute
         stream busy (xGMI links and MFMA pipes are independent resources); other back ends reduce after the pass."""
-        if self._ready_hook is not None:
-            self._ready_hook(int(offset), int(count))
-        if not self._overlap_active():
-            return
-        import torch.distributed as dist
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.eng.device)
-        ev = torch.cuda.Event()
-        ev.record(self.eng._stream)
-        self._side.wait_event(ev)
-        with torch.cuda.stream(self._side):
-            self._pending.append(dist.all_reduce(self.grads[offset:offset + count], async_op=True))
-        self._covered.append((int(offset), int(count)))
+        if self._cb_error is not None:
+            return                                          # a previous notification failed: stop enqueueing, re-raise after the pass
+        try:
+            if self._ready_hook is not None:
+                self._ready_hook(int(offset), int(count))
+            if not self._overlap_active():
+                return
+            import torch.distributed as dist
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.eng.device)
+            ev = torch.cuda.Event()
+            ev.record(self.eng._stream)
+            self._side.wait_event(ev)
+            with torch.cuda.stream(self._side):
+                self._pending.append(dist.all_reduce(self.grads[offset:offset + count], async_op=True))
+            self._covered.append((int(offset), int(count)))
+        except BaseException as exc:                        # noqa: BLE001 -- must not propagate into the C caller
+            self._cb_error = exc
 
     def average_gradients(self):
         """main.py:243-267 across ranks: mean of the per-tower gradients.  Ranges already in flight (see _on_grads_ready)
         are waited for; whatever was not reported during the pass is reduced now."""
         from . import dist as jdist
         if not self._pending:
-            jdist.average_gradients(self.grads)
+            jdist.average_gradients(self.grads, stream=self.eng._stream)
             return
         import torch.distributed as dist
         with torch.cuda.stream(self.eng._stream):
@@ -128,7 +139,8 @@ class Trainer:
                 if off > pos:
                     dist.all_reduce(self.grads[pos:off])    # e.g. the spatial-model blocks when use_sm is off (zeros)
                 pos = max(pos, off + cnt)
-            self.grads.div_(dist.get_world_size())
+            if dist.get_world_size() > 1:
+                self.grads.div_(dist.get_world_size())
         self._pending, self._covered = [], []
 
     def apply(self, lr=None, want_norm=False):
@@ -147,7 +159,7 @@ class Trainer:
         the shared variables one after the other); here the replicas take the mean of the per-rank results,
         i.e. one update with the tower-averaged statistics.  `names_and_counts`: [(name, count)]."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        if not (dist.is_available() and dist.is_initialized()):
             return
         from . import dist as jdist
         if self._moving is None:
@@ -160,7 +172,7 @@ class Trainer:
         buf = self._moving_buf
         for n, o, c in self._moving:
             _lib.check(self._lib.jcm_get_tensor(self.eng._h, n.encode(), ctypes.c_void_p(buf.data_ptr() + 4 * o), c), 'jcm_get_tensor(%s)' % n)
-        jdist.average_gradients(buf)
+        jdist.average_gradients(buf, stream=self.eng._stream)
         for i, (n, o, c) in enumerate(self._moving):
             _lib.check(self._lib.jcm_update_tensor(self.eng._h, n.encode(), ctypes.c_void_p(buf.data_ptr() + 4 * o), c,
                                                    int(i == len(self._moving) - 1)), 'jcm_update_tensor(%s)' % n)

@@ -1,0 +1,110 @@
+"""BASELINE.json configs[2] / configs[3] at their real sizes on the GPU, through size-independent
+properties (the float64 oracle needs ~1 s per image, so 256 images are not compared value by value):
+every heat map is a distribution, the coordinates are the first-occurrence arg-max of the returned maps,
+an image's result does not depend on the batch it travels in (BatchNorm is in inference mode,
+main.py:406), and a batch walked in micro-batches equals the same batch in one piece."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import flic_priors, full_inputs, load, seeds
+from joint_cnn_mrf_amd import synth
+from oracle import jcm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device='cuda:0')
+
+
+def _full_params():
+    x2, torso2, p = full_inputs()
+    p.update(synth.make_sm_params(flic_priors(), kind='trained', seed=seeds()['sm']))
+    return x2, torso2, p
+
+
+def test_config3_batch256_bf16_properties():
+    """configs[2] (and a rank's share of configs[3]: 2048 / 8): batch 256, bf16, full-width network,
+    FLIC priors.  This is the size at which the arena holds 5 GB, the spatial model runs 16 FFT slices and
+    the 9x9 grids have thousands of tiles -- paths a 2-image test never takes."""
+    from joint_cnn_mrf_amd.engine import Engine
+    x2, torso2, p = _full_params()
+    B = 256
+    x = np.concatenate([x2, synth.make_images(B - 2, seed=177)], axis=0)
+    torso = np.concatenate([torso2, synth.make_torso(B - 2, seed=178)], axis=0)
+    eng = Engine(device=0, precision='bf16').load_params(p)
+    r = eng.forward(dev(x), dev(torso), use_sm=True)
+    pd, sm = r['pd_prob'].cpu().numpy(), r['sm_prob'].cpu().numpy()
+    pd_c, sm_c = r['pd_coords'].cpu().numpy(), r['sm_coords'].cpu().numpy()
+    assert pd.shape == sm.shape == (B, 60, 90, 9) and pd_c.shape == sm_c.shape == (B, 2, 9)
+    np.testing.assert_allclose(pd.sum(axis=(1, 2)), 1.0, rtol=2e-5)
+    np.testing.assert_allclose(sm.sum(axis=(1, 2)), 1.0, rtol=2e-5)
+    assert np.isfinite(pd).all() and np.isfinite(sm).all() and pd.min() >= 0 and sm.min() >= 0
+    np.testing.assert_array_equal(pd_c, O.argmax_coords(pd))
+    np.testing.assert_array_equal(sm_c, O.argmax_coords(sm))
+    # the first two images are the golden pair: the same engine on a batch of 2 must give the same bits
+    # (every output element is one fixed-order MFMA accumulation, whatever tile or workgroup computes it)
+    two = eng.forward(dev(x[:2]), dev(torso[:2]), use_sm=True)
+    assert np.array_equal(two['pd_prob'].cpu().numpy(), pd[:2])
+    np.testing.assert_allclose(two['sm_prob'].cpu().numpy(), sm[:2], atol=1e-6, rtol=0)
+    np.testing.assert_array_equal(two['pd_coords'].cpu().numpy(), pd_c[:2])
+    np.testing.assert_array_equal(two['sm_coords'].cpu().numpy(), sm_c[:2])
+    # an image deep in the batch against a single-image forward
+    one = eng.forward(dev(x[201:202]), dev(torso[201:202]), use_sm=True)
+    assert np.array_equal(one['pd_prob'].cpu().numpy(), pd[201:202])
+    np.testing.assert_allclose(one['sm_prob'].cpu().numpy(), sm[201:202], atol=1e-6, rtol=0)
+    np.testing.assert_array_equal(one['sm_coords'].cpu().numpy(), sm_c[201:202])
+    # and the golden pair stays within bf16 reach of the float64 oracle (argmax within one cell for most joints)
+    assert (np.abs(pd_c[:2] - load('full_pd_coords')).max(axis=1) <= 1).mean() >= 0.85
+    eng.close()
+
+
+@pytest.mark.parametrize('precision,debug,B,mb', [('fp32', True, 5, 2), ('bf16', False, 5, 2), ('fp32', False, 3, 2)])
+def test_micro_batched_forward_equals_one_piece(precision, debug, B, mb):
+    """jcm_forward walks a large batch in micro-batches (option "micro_batch": a rank's 2048 / N share of
+    configs[3]); ragged last slice included, every output lands at its image offset, results identical."""
+    from joint_cnn_mrf_amd.engine import Engine
+    p = synth.make_pd_params(debug=debug, bn='trained', conv6_gain=8.0)
+    p.update(synth.make_sm_params(synth.synthetic_priors(), kind='trained'))
+    x, torso = dev(synth.make_images(B, seed=5)), dev(synth.make_torso(B, seed=6))
+    eng = Engine(device=0, precision=precision, micro_batch=B).load_params(p)
+    whole = eng.forward(x, torso, use_sm=True)
+    whole = {k: v.clone() for k, v in whole.items()}
+    eng.set_micro_batch(mb)
+    parts = eng.forward(x, torso, use_sm=True)
+    for k in ('pd_prob', 'pd_coords', 'sm_coords'):
+        assert torch.equal(parts[k], whole[k]), k
+    assert float((parts['sm_prob'] - whole['sm_prob']).abs().max()) <= 1e-6
+    # coordinates only (the bench's call): no probability outputs requested
+    c = eng.forward(x, torso, use_sm=True, want_prob=False)
+    assert torch.equal(c['sm_coords'], whole['sm_coords']) and torch.equal(c['pd_coords'], whole['pd_coords'])
+    eng.close()
+
+
+def test_fused_softmax_argmax_matches_oracle_and_ties():
+    """The tail of the tower (spatial_softmax + arg-max in one kernel) against the float64 oracle, with
+    exact ties: the FIRST flat index wins (np.argmax / tf.argmax, KAT8)."""
+    from joint_cnn_mrf_amd.engine import Engine
+    eng = Engine(device=0)
+    eng.finalize()
+    rs = np.random.RandomState(4)
+    z = (3.0 * rs.standard_normal((5, 60, 90, 9))).astype(np.float32)
+    z[0, :, :, 0] = 0.25                       # a constant map: every pixel ties -> (0, 0)
+    z[1, 17, 40, 3] = z[1, 52, 7, 3] = 40.0    # two equal maxima: the earlier flat index (17, 40) wins
+    z[2, 59, 89, 8] = 50.0                     # the very last pixel
+    z[3, 0, 0, 5] = 50.0                       # the very first
+    prob, coords = eng.softmax_argmax(dev(z))
+    ref = O.spatial_softmax(z.astype(np.float64))
+    np.testing.assert_allclose(prob.cpu().numpy(), ref, rtol=2e-5, atol=1e-12)
+    c = coords.cpu().numpy()
+    np.testing.assert_array_equal(c, O.argmax_coords(prob.cpu().numpy()))
+    assert tuple(c[0, :, 0]) == (0, 0) and tuple(c[1, :, 3]) == (17, 40) and tuple(c[2, :, 8]) == (59, 89) and tuple(c[3, :, 5]) == (0, 0)
+    _none, coords_only = eng.softmax_argmax(dev(z), want_prob=False)
+    assert torch.equal(coords_only, coords)
+    # other joint counts / map sizes take the general two-kernel route behind the same entry point
+    z2 = rs.standard_normal((2, 15, 23, 4)).astype(np.float32)
+    p2, c2 = eng.softmax_argmax(dev(z2))
+    np.testing.assert_allclose(p2.cpu().numpy(), O.spatial_softmax(z2.astype(np.float64)), rtol=2e-5, atol=1e-12)
+    np.testing.assert_array_equal(c2.cpu().numpy(), O.argmax_coords(p2.cpu().numpy()))
+    eng.close()
