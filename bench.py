@@ -126,6 +126,7 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
             ms, n = eng.profile_read(scope)
             tot_ms, tot_n = tot_ms + ms, tot_n + n
             tot_flops += fl / (16 if args.debug else 1) * B * args.steps if n else 0.0     # n = steps x micro-batches launches cover steps x B images
+        kname = eng.conv_kernel_name('conv5', min(B, micro_batch or (256 if dtype == 'bf16' else 64)), 60, 90) if not args.debug else 'debug'
         launch_ms = tot_ms / max(tot_n, 1)                     # average launch duration (HIP events, launch stream)
         flops_launch = tot_flops / max(tot_n, 1)               # average algorithmic FLOPs per launch
         achieved = flops_launch / (launch_ms * 1e-3) / 1e12 if tot_n else None
@@ -155,7 +156,10 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
                                       if f32_conv == 'split' else
                                       'fp32 operands as 2 fp16 parts, 3 x fp16 MFMA 32x32x16 per k16 step, 12x32 patch x 256 ch; achieved = executed fp16 MFMA FLOPs (3 x algorithmic) against the fp16 peak'
                                       if f32_conv == 'split16' else
-                                      'fp32 MFMA 32x32x2, 128-pixel strip tiles x 128 ch' if dtype == 'fp32' else 'bf16 MFMA 32x32x16, 12x32 patch x 256 ch'),
+                                      'fp32 MFMA 32x32x2, 128-pixel strip tiles x 128 ch' if dtype == 'fp32' else
+                                      'bf16 MFMA 32x32x16, 384-pixel strips of the flattened batch x 256 ch, LDS-DMA halo + weight rings' if kname == 'conv_strip_bf16_kernel'
+                                      else 'bf16 MFMA 32x32x16, 12x32 patch x 256 ch'),
+                         'kernel_name': kname,
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None,
                          'traffic': pmc_traffic('%s%s_b%d' % (dtype, '_' + f32_conv if f32_conv in ('split', 'split16') else '', B)) if not args.debug else None,
                          'launch_ms': launch_ms, 'launches': tot_n, 'flops_per_launch': flops_launch},

@@ -130,6 +130,10 @@ int jcm_group_mean(jcm_handle h, const float* in, int n, int G, int64_t M, float
  * Sum of the HIP-event durations (ms) and the number of launches recorded for conv layer
  * `scope` since the last read; synchronises the stream and clears the record. */
 int jcm_profile_read(jcm_handle h, const char* scope, double* total_ms, int* launches);
+/* Name of the HIP kernel a launch of conv layer `scope` on a [B,H,W,Cin] input takes on this handle (the
+ * dispatch depends on precision, options and shape); bench.py labels its roofline object with it and the
+ * tests assert that the intended kernel is the one that runs. */
+int jcm_conv_kernel_name(jcm_handle h, const char* scope, int B, int H, int W, char* name, int cap);
 /* Bytes currently held by the workspace arena + packed parameters. */
 int64_t jcm_workspace_bytes(jcm_handle h);
 

@@ -42,6 +42,7 @@ SIGNATURES = {
                                          ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p]),
     'jcm_group_mean': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, _c_float_p]),
     'jcm_profile_read': (ctypes.c_int, [_handle, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
+    'jcm_conv_kernel_name': (ctypes.c_int, [_handle, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
     'jcm_workspace_bytes': (ctypes.c_int64, [_handle]),
     'jcm_train_begin': (ctypes.c_int, [_handle]),
     'jcm_train_param_count': (ctypes.c_int, [_handle, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),

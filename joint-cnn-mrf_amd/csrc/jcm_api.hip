@@ -766,6 +766,28 @@ int jcm_profile_read(jcm_handle h, const char* scope, double* total_ms, int* lau
   return JCM_OK;
 }
 
+int jcm_conv_kernel_name(jcm_handle h, const char* scope, int B, int H, int W, char* name, int cap) {
+  JCM_TRY(check(h, true));
+  if (!scope || !name || cap < 2 || B < 1 || H < 1 || W < 1) return fail(JCM_ERR_ARG, "bad conv_kernel_name arguments");
+  const ConvLayer* L = conv_of(h, scope);
+  if (!L) return fail(JCM_ERR_STATE, std::string("no conv layer '") + scope + "'");
+  ConvArgs a;
+  a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout;
+  const char* k;
+  if (L->cin == 3) {
+    k = h->precision == JCM_PRECISION_BF16 ? (L->wq1_bf16 ? "conv1_mfma_pool_kernel" : "conv1_5x5s2_kernel") : (L->wq1_f32 ? "conv1_mfma_pool_f32_kernel" : "conv1_5x5s2_kernel");
+  } else if (h->precision == JCM_PRECISION_BF16) {
+    a.CoutP = L->coutp_bf16;
+    k = L->thin_bf16 ? "conv_thin_bf16_kernel"
+        : (conv_igemm_bf16_bn(L->cout, L->ks) == 256 && conv_strip_bf16_supported(a, L->ks)) ? "conv_strip_bf16_kernel" : "conv_igemm_bf16_kernel";
+  } else {
+    const bool use_split = L->wp_split && (L->thin ? h->f32_conv == 2 : conv_split_supported(L->ks, L->cin, L->coutp_split, B, H, W, h->split_min_wgs));
+    k = L->thin ? (use_split ? "conv_thin_split16_kernel" : "conv_thin_f32_kernel") : use_split ? "conv_split_kernel" : "conv_igemm_f32_kernel";
+  }
+  std::snprintf(name, (size_t)cap, "%s", k);
+  return JCM_OK;
+}
+
 int64_t jcm_workspace_bytes(jcm_handle h) { return h ? (int64_t)(h->arena_cap + h->param_bytes) : 0; }
 
 }  // extern "C"

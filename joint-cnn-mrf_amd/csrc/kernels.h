@@ -73,6 +73,12 @@ int conv_igemm_bf16_bn(int Cout, int ks);
 hipError_t conv_igemm_bf16(const ConvArgs& a, int ks, bool out_f32, hipStream_t st);
 hipError_t pack_weights_bf16(const float* w_hwio, void* wp, int ks, int Cin, int Cout, int CoutP, hipStream_t st);
 
+// ---- conv_strip_bf16.hip : the 9x9 layers with M flattened over the batch (384-pixel strips, no padded slots),
+// halo and weights by LDS-DMA rings.  Same operands as conv_igemm_bf16 (bf16 NHWC in / out, packed weights
+// [81][Cin/8][CoutP][8]); CoutP % 256 == 0, Cin % 16 == 0, H*W >= 384.  conv_igemm_bf16 dispatches to it.
+bool conv_strip_bf16_supported(const ConvArgs& a, int ks);
+hipError_t conv_strip_bf16(const ConvArgs& a, hipStream_t st);
+
 // ---- conv1.hip : 5x5 stride-2 SAME convolution of the (sub-sampled) RGB image ---------------
 // x [B,H0,W0,3] fp32; the branch input is x[:, ::sub, ::sub] (TF-1.x bilinear with an integer
 // scale is pure sub-sampling, main.py:51,60); w HWIO [5,5,3,Cout]; out [B,Ho,Wo,Cout] fp32 or bf16.

@@ -257,5 +257,11 @@ class Engine:
         _lib.check(self._lib.jcm_profile_read(self._h, scope.encode(), ctypes.byref(ms), ctypes.byref(n)), 'jcm_profile_read')
         return ms.value, n.value
 
+    def conv_kernel_name(self, scope, B, H, W):
+        """The HIP kernel a [B,H,W,Cin] launch of conv layer `scope` takes on this engine."""
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(self._lib.jcm_conv_kernel_name(self._h, scope.encode(), int(B), int(H), int(W), buf, 128), 'jcm_conv_kernel_name')
+        return buf.value.decode()
+
     def workspace_bytes(self):
         return int(self._lib.jcm_workspace_bytes(self._h))

@@ -34,6 +34,8 @@ def test_config3_batch256_bf16_properties():
     x = np.concatenate([x2, synth.make_images(B - 2, seed=177)], axis=0)
     torso = np.concatenate([torso2, synth.make_torso(B - 2, seed=178)], axis=0)
     eng = Engine(device=0, precision='bf16').load_params(p)
+    # the kernel under test is the flattened-strip 9x9 kernel (a silent fallback to the patch kernel would pass too)
+    assert eng.conv_kernel_name('conv5', B, 60, 90) == eng.conv_kernel_name('conv4_fullres', B, 60, 90) == 'conv_strip_bf16_kernel'
     r = eng.forward(dev(x), dev(torso), use_sm=True)
     pd, sm = r['pd_prob'].cpu().numpy(), r['sm_prob'].cpu().numpy()
     pd_c, sm_c = r['pd_coords'].cpu().numpy(), r['sm_coords'].cpu().numpy()

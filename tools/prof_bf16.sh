@@ -1,0 +1,24 @@
+#!/bin/bash
+# rocprofv3 passes over the bf16 B=256 bench (run on the GPU box, from the repo root):
+#   bash tools/prof_bf16.sh NAME [extra bench args]
+# kernel-trace/stats in its own run; counters in separate --pmc runs (no tracing combined with --pmc);
+# FETCH_SIZE and WRITE_SIZE cannot share a pass (TCC slots).  Summaries -> gpurun_out/NAME_*.csv
+set -u
+NAME=$1; shift
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out
+mkdir -p $OUT
+CMD="python bench.py --dtype bf16 --steps 2 --warmup 1 --cpu-images 0 $*"
+rocprofv3 --kernel-trace --stats -d $OUT/prof_${NAME}_stats -o s -- $CMD > $OUT/${NAME}_stats.log 2>&1
+i=0
+for ctr in "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $ctr -d $OUT/prof_${NAME}_pmc$i -o p -- $CMD > $OUT/${NAME}_pmc$i.log 2>&1
+done
+DB=$(find $OUT/prof_${NAME}_stats -name "*.db" | head -1)
+python profiles/summarize.py stats $DB > $OUT/${NAME}_kernel_stats.csv
+python profiles/summarize.py pmc $(find $OUT/prof_${NAME}_pmc* -name "*.db" | sort) > $OUT/${NAME}_pmc.csv
+# the raw databases are large: keep only the summaries
+rm -rf $OUT/prof_${NAME}_stats $OUT/prof_${NAME}_pmc*
+head -12 $OUT/${NAME}_kernel_stats.csv | cut -c1-160
+grep -E "strip|CfgB<9, 12, 32, 256" $OUT/${NAME}_pmc.csv | cut -c1-200
