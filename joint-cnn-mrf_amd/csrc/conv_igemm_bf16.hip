@@ -336,7 +336,8 @@ __global__ __launch_bounds__(C::NT, (C::NT + 255) / 256) void conv_igemm_bf16_ke
         if (ok) {
           float v = acc[f][g][i] + bi;
           if (a.relu_bn) v = fmaxf(v, 0.f) * sc + sh;
-          const size_t o = (((size_t)b * H + y) * W + x) * Cout + co;
+          const size_t o = a.out_planar ? (((size_t)b * (Cout >> 3) + (co >> 3)) * H * W + (size_t)y * W + x) * 8 + (co & 7)
+                                        : (((size_t)b * H + y) * W + x) * Cout + co;
           if (OUT_F32) static_cast<float*>(a.out)[o] = v;
           else static_cast<__bf16*>(a.out)[o] = static_cast<__bf16>(v);
         }
@@ -383,6 +384,7 @@ hipError_t conv_igemm_bf16(const ConvArgs& a, int ks, bool out_f32, hipStream_t 
     return wide ? launch_b<CfgB<9, 6, 32, 32, 6, 1, 9>, true>(a, st) : launch_b<CfgB<9, 12, 16, 32, 6, 1, 9>, true>(a, st);
   }
   if (ks == 9 && bn == 256 && conv_strip_bf16_supported(a, ks)) return conv_strip_bf16(a, st);   // flattened strips: no padded slots
+  if (a.in_planar || (a.out_planar && (out_f32 || a.Cout % 8))) return hipErrorInvalidValue;       // the patch kernels read NHWC
   if (ks == 9) {
     // 60x90 / 120x180 maps: 12x32 patch x 256 channels, rotating-B schedule (half the weight stream
     // per FLOP of the 6x32 tile, 7 instead of 10 fragment reads per 12 MFMAs)

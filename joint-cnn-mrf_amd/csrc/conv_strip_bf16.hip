@@ -9,14 +9,18 @@
 //     A operand is read with per-lane LDS addresses), so a strip costs nothing over a patch in the MFMA loop.
 //   * halo = every image row the strip touches, +-4 rows, whole rows with a 4-slot zero gap between rows
 //     (pitch W+4: the gap is the right pad of one row and the left pad of the next) and 4 zero rows between
-//     the two images of a boundary tile.  It lives in LDS as two 16-byte-unit planes of a 16-CHANNEL chunk
-//     and is refilled by LDS-DMA in 1-KB pieces (64 consecutive slots; pad / out-of-image slots are
-//     out-of-range lanes of a buffer load and arrive as zeros).  A piece of the NEXT chunk is loaded as soon as
-//     the kernel rows of the current chunk that read it are done (schedule computed on the host: one piece
-//     per plane per stage, issued by waves 0 and 1), so the halo never stops the MFMA stream.
+//     the two images of a boundary tile.  It lives in LDS as two 16-byte-unit planes of a 16-CHANNEL chunk,
+//     zeroed once, and is (re)filled by LDS-DMA one row part at a time (64 pixels of one plane; the lanes past
+//     the row end are masked off, rows outside the image are never loaded).  Row j of the NEXT chunk is loaded
+//     while kernel row j+1 of the current chunk runs -- kernel row ky reads rows ky..ky+5, so row j is dead by
+//     then -- and the rows that stay live to the end (8..13) right after the chunk boundary, long before kernel
+//     row 3 first reads them: the halo never stops the MFMA stream.  All addressing is scalar.
 //   * weights: 3 taps x 16 channels x 256 output channels per stage (24.6 KB) in a 4-deep LDS-DMA ring;
 //     at the barrier that opens stage g the weights of stage g+1 have ALREADY landed, so the fragments of the
-//     next stage's first k-step are requested before the barrier and the barrier has no load behind it.
+//     next stage's first k-step are requested before the barrier and the barrier has no load behind it.  The
+//     two waves of a SIMD (w, w+4) issue their DMA in different k-steps: while one issues, the other computes.
+//   * the MFMA is issued as D^T = W^T X^T (operands swapped): a lane then owns one PIXEL and 4 consecutive output
+//     channels per accumulator quad, so the epilogue stores 8 bytes at a time instead of 2.
 //
 // Stage = 3 taps of one kernel row x one k16 step = 36 MFMAs per wave; 8 waves (4 x 2), 3 x 4 fragments of
 // 32x32 per wave, rotating-B fragment schedule as in conv_igemm_bf16.hip.
@@ -38,44 +42,52 @@ constexpr int TPS = 3, NSTAGE = 27, NB = 4;          // taps per stage, stages p
 constexpr int PLANE = 1728;                            // 16-B slots per halo plane (27 pieces of 64)
 constexpr int WST = TPS * 2 * BN;                      // slots per weight stage: [tap][unit][BN]
 constexpr int WB0 = 2 * PLANE;                         // first weight slot
-constexpr int DUMMY = WB0 + NB * WST;                  // 64 slots that absorb padding DMA (tail stages, unscheduled halo slots)
-constexpr int LDS_BYTES = (DUMMY + 64) * 16;
+constexpr int LDS_BYTES = (WB0 + NB * WST) * 16;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 struct Geom {
-  int H, W, HW, pitch, rows, npieces, magic;   // magic: s / pitch == (s * magic) >> 22 for s < PLANE
+  int H, W, HW, pitch, rows, nparts, Dn;       // rows: halo rows allocated; nparts: 64-pixel parts per row; Dn: rows a strip can touch
   int Mtotal, mtiles, nN, async_ok;
-  unsigned sched[7];                           // 27 bytes: bit 7 valid, bit 6 "next chunk", bits 0-4 piece
 };
 }  // namespace strip
 
 using namespace strip;
 
 // one k16 step = one tap: A at slot offset `tp`, B at [tp][unit h][BN]
+// EXP_* macros: timing experiments only (tools/exp_build.sh); they break the result on purpose.
 template <int TP>
 __device__ __forceinline__ void s_a_load(f32x4 (&fa)[MR], const unsigned (&aaddr)[MR]) {
+#ifdef EXP_NOLDS
+  return;
+#endif
 #pragma unroll
   for (int f = 0; f < MR; ++f) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[f]) : "v"(aaddr[f]), "i"(TP * 16) : "memory");
 }
-template <int TP>
+template <int TP, int G>      // column G of the wave's 4 B fragments: 32 channels = 512 bytes further on
 __device__ __forceinline__ void s_b_load(f32x4& fb, unsigned baddr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb) : "v"(baddr), "i"(TP * 2 * BN * 16) : "memory");
+#ifdef EXP_NOLDS
+  return;
+#endif
+  static_assert(TP * 2 * BN * 16 + G * 512 < 65536, "ds_read offset field is 16 bits");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb) : "v"(baddr), "i"(TP * 2 * BN * 16 + G * 512) : "memory");
 }
 
 // MFMAs of (step, column G) and the read of B[G] for the following step.  Queue invariant (see conv_igemm_bf16.hip):
 // exactly MR+NR-1 younger ds_reads are in flight when B[G] of the current step is needed.
 template <int PAR, int STEP, int G, class After>
-__device__ __forceinline__ void s_rot_g(f32x4 (&fa)[2][MR], f32x4 (&fb)[NR], const unsigned (&baddr)[NR], f32x16 (&acc)[MR][NR], After&& after) {
+__device__ __forceinline__ void s_rot_g(f32x4 (&fa)[2][MR], f32x4 (&fb)[NR], const unsigned baddr, f32x16 (&acc)[MR][NR], After&& after) {
   if constexpr (G < NR) {
     constexpr int cur = (STEP + PAR) & 1;          // a stage has 3 steps: the A double buffer flips parity every stage
+#ifndef EXP_NOLDS
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(MR + NR - 1) : "memory");
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int f = 0; f < MR; ++f)
-      acc[f][G] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cur][f]), __builtin_bit_cast(bf16x8, fb[G]), acc[f][G], 0, 0, 0);
+      acc[f][G] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[G]), __builtin_bit_cast(bf16x8, fa[cur][f]), acc[f][G], 0, 0, 0);   // D^T: rows = channels, columns = pixels
     __builtin_amdgcn_sched_barrier(0);
-    s_b_load<(STEP + 1) % TPS>(fb[G], baddr[G]);     // STEP == TPS-1: baddr already points at the next stage's buffer
-    after(G);
+    s_b_load<(STEP + 1) % TPS, G>(fb[G], baddr);     // STEP == TPS-1: baddr already points at the next stage's buffer
+    after(STEP * NR + G);
     __builtin_amdgcn_sched_barrier(0);
     s_rot_g<PAR, STEP, G + 1>(fa, fb, baddr, acc, after);
   }
@@ -114,7 +126,7 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
   const bool async_halo = gm.async_ok && !crossing;   // boundary tiles (1 in 15) reload their halo synchronously
 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-  unsigned aaddr[MR], baddr[NR];
+  unsigned aaddr[MR], baddr;
 #pragma unroll
   for (int f = 0; f < MR; ++f) {
     const int P = min(P0 + (wm * MR + f) * 32 + l31, gm.Mtotal - 1);      // slots past the end recompute the last pixel and are dropped
@@ -123,8 +135,7 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
     const int dv = (b - b0) * (H + 4) + y - y0;                             // halo row of the pixel at tap row 0 ... +ky
     aaddr[f] = lds0 + (unsigned)(h * PLANE + dv * pitch + x) * 16u;
   }
-#pragma unroll
-  for (int g = 0; g < NR; ++g) baddr[g] = lds0 + (unsigned)(WB0 + h * BN + (wn * NR + g) * 32 + l31) * 16u;
+  baddr = lds0 + (unsigned)(WB0 + h * BN + wn * NR * 32 + l31) * 16u;
 
   f32x16 acc[MR][NR];
 #pragma unroll
@@ -140,37 +151,48 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
   const int cin8 = Cin >> 3;
   const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(static_cast<const __bf16*>(a.wp)), 0,
                                                        (int)((size_t)KS * KS * Cin * CoutP * 2), 0x00020000);
-  const unsigned wvoff = (unsigned)(n0 + lane) * 16u;
+  const unsigned lane16 = (unsigned)lane * 16u;        // the only per-lane DMA offset: n0 goes into the scalar offsets
   const int wu = wid >> 2, wq = wid & 3;
   const unsigned wtap_stride = (unsigned)(cin8 * CoutP * 16);
-  auto w_piece = [&](int chunk, int s, int i, int buf, bool real) {      // tap i of the stage; !real: a padding DMA (zeros into the spare slots)
-    const unsigned soff = real ? (unsigned)(3 * s + i) * wtap_stride + (unsigned)(((chunk * 2 + wu) * CoutP + wq * 64) * 16) : 0u;
-    f32x4* dst = real ? lds + WB0 + buf * WST + (i * 2 + wu) * BN + wq * 64 : lds + DUMMY;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, real ? wvoff : 0x80000000u, soff, 0, 0);
+  auto w_piece = [&](int chunk, int s, int i, int buf) __attribute__((always_inline)) {      // tap i of stage (chunk, s) into ring slot buf (prologue; the loop advances scalars)
+    const unsigned soff = (unsigned)(3 * s + i) * wtap_stride + (unsigned)(((chunk * 2 + wu) * CoutP + n0 + wq * 64) * 16);
+    f32x4* dst = lds + WB0 + buf * WST + (i * 2 + wu) * BN + wq * 64;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, lane16, soff, 0, 0);
   };
 
-  // ---- halo: piece q = slots 64q..64q+63 of a plane; slot s -> (halo row j, position in row); position < 4 is the
-  // zero gap; halo row j is virtual row y0-4+j of the two-image column [image b0 | 4 zero rows | image b0+1].
+  // ---- halo: row j of a plane = slots j*pitch .. +pitch-1 = [4 zero slots | W pixels]; it holds virtual row y0-4+j of
+  // the two-image column [image b0 | 4 zero rows | image b0+1].  One DMA moves one 64-pixel part of one row of one plane;
+  // everything but the lane's pixel offset is wave-uniform.
   const int nimg = min(2, a.B - b0);
   const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(static_cast<const __bf16*>(a.x)) + (size_t)b0 * HW * Cin, 0,
                                                        (int)((size_t)nimg * HW * Cin * 2), 0x00020000);
-  auto halo_piece = [&](int q, int plane, int chunk, bool real) {
-    const int s = q * 64 + lane;
-    const int j = (int)(((unsigned)s * (unsigned)gm.magic) >> 22);
-    const int pos = s - j * pitch;
+  // per-lane source offset of a halo part: planar = 16 bytes per pixel (64 pixels of a unit plane are 1 KB contiguous);
+  // NHWC = Cin*2 bytes per pixel, computed where it is used (no register kept for it)
+  auto hvoff = [&]() __attribute__((always_inline)) { return a.in_planar ? lane16 : lane16 * (unsigned)(Cin >> 3); };
+  auto halo_part = [&](int j, int plane, int part, int chunk) __attribute__((always_inline)) -> bool {      // bulk (re)load of one row part; returns whether a DMA was issued
     int y = y0 - 4 + j, img = 0;
     if (y >= H + 4) { y -= H + 4; img = 1; }
-    const bool ok = real && pos >= 4 && j < gm.rows && y >= 0 && y < H && img < nimg;
-    const unsigned voff = ok ? (unsigned)(((img * H + y) * W + pos - 4) * Cin * 2) : 0x80000000u;
-    f32x4* dst = real ? lds + plane * PLANE + q * 64 : lds + DUMMY;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)dst, 16, voff, (unsigned)(chunk * 32 + plane * 16), 0, 0);
+    const bool ok = j < gm.rows && y >= 0 && y < H && img < nimg;
+    if (ok) {
+      const unsigned soff = a.in_planar ? (unsigned)((((img * cin8 + chunk * 2 + plane) * H + y) * W + 64 * part) * 16)
+                                        : (unsigned)(((img * H + y) * W + 64 * part) * Cin * 2 + chunk * 32 + plane * 16);
+      f32x4* dst = lds + plane * PLANE + j * pitch + 4 + 64 * part;
+      if (lane < W - 64 * part)      // lanes past the row end stay off: the next row's slots are not touched
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)dst, 16, hvoff(), soff, 0, 0);
+    }
+    return ok;
   };
-  auto bulk_halo = [&](int chunk) {
-    for (int q = wid; q < gm.npieces; q += NT / 64) {
-      halo_piece(q, 0, chunk, true);
-      halo_piece(q, 1, chunk, true);
+  const int upr = 2 * gm.nparts;                      // DMAs per halo row
+  auto bulk_halo = [&](int chunk) __attribute__((always_inline)) {
+    for (int u = wid; u < gm.rows * upr; u += NT / 64) {
+      const int j = u / upr, r = u - j * upr;
+      halo_part(j, r & 1, r >> 1, chunk);
     }
   };
+  // zero the two planes once: gaps, rows outside the image and the 4 rows between two images are never written again
+  for (int i = tid; i < 2 * PLANE; i += NT) lds[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
 
   const int nchunk = Cin >> 4;
   const int G = nchunk * NSTAGE;
@@ -179,79 +201,133 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
 #pragma unroll
   for (int s = 0; s < 3; ++s)
 #pragma unroll
-    for (int i = 0; i < TPS; ++i) w_piece(0, s, i, s, true);
+    for (int i = 0; i < TPS; ++i) w_piece(0, s, i, s);
   bulk_halo(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   f32x4 fa[2][MR], fb[NR];
   s_a_load<0>(fa[0], aaddr);
-#pragma unroll
-  for (int g = 0; g < NR; ++g) s_b_load<0>(fb[g], baddr[g]);
+  s_b_load<0, 0>(fb[0], baddr); s_b_load<0, 1>(fb[1], baddr); s_b_load<0, 2>(fb[2], baddr); s_b_load<0, 3>(fb[3], baddr);
+
+  // ---- per-stage control kept to a handful of scalar instructions (every SALU op sits between MFMAs of an in-order wave:
+  // 200 of them per stage cost 4 % of the kernel).
+  // Weights of stage g+3: source offset and LDS address advance by constants; past the last stage the offset runs out
+  // of the buffer and the DMA delivers zeros into a free ring slot -- no tail logic.
+  const unsigned TS = wtap_stride, CS = (unsigned)(2 * CoutP * 16);
+  unsigned wsoff = 9u * TS + (unsigned)((wu * CoutP + n0 + wq * 64) * 16);  // stage 3 = taps 9..11 of chunk 0
+  unsigned wm0 = lds0 + (unsigned)((WB0 + 3 * WST + wu * BN + wq * 64) * 16);
+  // Halo parts of an async tile: what THIS wave issues at stage st is fixed for the whole tile, so it is tabulated once,
+  // lane st of two VGPRs (read back with v_readlane): ha = source offset without the chunk term,
+  // hb = LDS slot | lanes << 12 | next-chunk << 19 | valid << 20.
+  //   kernel row ky = st/3 >= 1, its first stage: row ky-1 died with kernel row ky-1 -> its 2*nparts parts, for the NEXT
+  //   chunk, go to waves 0..2*nparts-1;  ky == 0: the rows that were live to the end of the previous chunk (8 .. Dn+7),
+  //   8 parts per stage, for THIS chunk.
+  unsigned htab = 0;                                    // lanes 0..26: hb, lanes 32..58: ha
+  if (async_halo && (lane & 31) < NSTAGE) {
+    const int stl = lane & 31;
+    unsigned ha = 0, hb = 0;
+    const int ky = stl / 3, si = stl - 3 * ky;
+    int hj = -1, hr = 0, nxt = 0;
+    if (ky == 0) {
+      const int u = stl * (NT / 64) + wid;
+      if (u < gm.Dn * upr) { hj = 8 + u / upr; hr = u % upr; }
+    } else if (si == 0 && wid < upr) {
+      hj = ky - 1; hr = wid; nxt = 1;
+    }
+    if (hj >= 0) {
+      const int plane = hr & 1, part = hr >> 1;
+      int y = y0 - 4 + hj, img = 0;
+      if (y >= H + 4) { y -= H + 4; img = 1; }
+      if (hj < gm.rows && y >= 0 && y < H && img < nimg) {
+        ha = a.in_planar ? (unsigned)((((img * cin8 + plane) * H + y) * W + 64 * part) * 16)
+                         : (unsigned)(((img * H + y) * W + 64 * part) * Cin * 2 + plane * 16);
+        hb = (unsigned)(plane * PLANE + hj * pitch + 4 + 64 * part) | ((unsigned)min(64, W - 64 * part) << 12) | ((unsigned)nxt << 19) | (1u << 20);
+      }
+    }
+    htab = lane < 32 ? hb : ha;
+  }
+  const unsigned hcs = a.in_planar ? (unsigned)(2 * HW * 16) : 32u;         // source step per 16-channel chunk
 
   // One stage; PAR = which A buffer holds its step 0.  A stage has 3 steps, so PAR flips every stage: the loop body is a
   // PAIR of stages in straight-line code (G is even: Cin % 32 == 0), never a branch on the parity.
-  int g = 0, buf = 0, chunk = 0, st = 0;
-  auto one_stage = [&](auto par) {
+  int buf = 0, chunk = 0, st = 0, si = 0;
+  bool prev_extra = false;
+  auto one_stage = [&](auto par) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par)::value;
     // ---- barrier that opens stage g: this wave's pieces of stage g+1 have landed (the newest batch stays in flight);
-    // afterwards everybody's have, and ring slot (g-1)%4 and the halo pieces that died with stage g-1 are free.
-    // Every wave issues the same number of DMAs at every stage (padding ones at the tail), so the count is static.
-    if (wid < 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // afterwards everybody's have, and ring slot (g-1)%4 and the halo rows that died with stage g-1 are free.
+    // Every wave issues 3 weight pieces per stage + at most one halo part.
+#ifndef EXP_NOVMW
+    if (prev_extra) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // the previous batch: 3 weight pieces (+ a halo part)
     else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#endif
+#ifndef EXP_NOBAR
     __builtin_amdgcn_s_barrier();
+#endif
     __builtin_amdgcn_sched_barrier(0);
 
-    // the DMA batch of this stage, spread behind the MFMA groups of step 0: weights of stage g+3, one halo piece
-    const bool wreal = g + 3 < G;
-    int c3 = chunk, s3 = st + 3;
-    if (s3 >= NSTAGE) { s3 -= NSTAGE; ++c3; }
-    const int buf3 = (buf + 3) & 3;
-    unsigned sw = 0;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) sw = (st >> 2) == i ? gm.sched[i] : sw;
-    const unsigned sb = (sw >> ((st & 3) * 8)) & 0xffu;
-    const int hchunk = chunk + ((sb >> 6) & 1);
-    const bool hreal = async_halo && (sb & 0x80u) && hchunk < nchunk && !(chunk == 0 && !(sb & 0x40u));
-    auto dma = [&](int Gc) {
-      if (Gc < TPS) w_piece(c3, s3, Gc, buf3, wreal);
-      else if (wid < 2) halo_piece((int)(sb & 31u), wid, hchunk, hreal);
+    const unsigned eb = __builtin_amdgcn_readlane(htab, st), ea = __builtin_amdgcn_readlane(htab, st + 32);
+    const int hchunk = chunk + (int)((eb >> 19) & 1u);
+    const bool extra = (eb >> 20) && hchunk < nchunk && (chunk | (int)((eb >> 19) & 1u)) != 0;   // this-chunk parts: chunk 0 came with the prologue
+    // idx = 4 * step + MFMA group: the three weight pieces behind groups 0..2 of step 0, the halo part behind group 3
+    auto dma = [&](int idx) __attribute__((always_inline)) {
+#ifdef EXP_NODMA
+      return;
+#endif
+      if (idx < TPS) {
+        auto dst = (__attribute__((address_space(3))) char*)(size_t)(wm0 + (unsigned)(idx * 2 * BN * 16));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, lane16, wsoff + (unsigned)idx * TS, 0, 0);
+      }
+#ifndef EXP_NOHALO
+      else if (idx == TPS && extra) {
+        auto dst = (__attribute__((address_space(3))) char*)(size_t)(lds0 + (eb & 0xfffu) * 16u);
+        if (lane16 < ((eb >> 8) & 0x7f0u))       // lanes past the row end stay off: the next row's slots are not touched
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)dst, 16, hvoff(), ea + (unsigned)hchunk * hcs, 0, 0);
+      }
+#endif
     };
-    auto nothing = [](int) {};
+    auto nodma = [](int) __attribute__((always_inline)) {};
 
     // step 0 (tap 3s): reads of step 1 go out, DMA issue interleaved
     s_a_load<1>(fa[PAR ^ 1], aaddr);
     s_rot_g<PAR, 0, 0>(fa, fb, baddr, acc, dma);
     // step 1
     s_a_load<2>(fa[PAR], aaddr);
-    s_rot_g<PAR, 1, 0>(fa, fb, baddr, acc, nothing);
-    // addresses of the next stage: 3 taps on, next kernel row, or back to tap 0 of the next chunk; next ring slot
+    s_rot_g<PAR, 1, 0>(fa, fb, baddr, acc, nodma);
+    // scalars and addresses of the next stage: 3 taps on, next kernel row, or back to tap 0 of the next chunk; next ring slots
+    const bool last = st == NSTAGE - 1;
     {
-      const int dslots = (st % 3 != 2) ? 3 : (st != NSTAGE - 1 ? pitch - 6 : -(8 * pitch + 6));
+      wsoff += st == NSTAGE - 4 ? 3u * TS + CS - 81u * TS : 3u * TS;      // stage g+4 opens a chunk when st == 23
+      wm0 = buf == 0 ? wm0 - (unsigned)(3 * WST * 16) : wm0 + (unsigned)(WST * 16);   // its ring slot (buf+3)%4 wraps when buf == 0
+      const int dslots = si != 2 ? 3 : (!last ? pitch - 6 : -(8 * pitch + 6));
       const unsigned da = (unsigned)(dslots * 16);
 #pragma unroll
       for (int f = 0; f < MR; ++f) aaddr[f] += da;
       const unsigned db = buf == 3 ? (unsigned)(-3 * WST * 16) : (unsigned)(WST * 16);
-#pragma unroll
-      for (int gq = 0; gq < NR; ++gq) baddr[gq] += db;
+      baddr += db;
       buf = (buf + 1) & 3;
+      si = si == 2 ? 0 : si + 1;
     }
     // step 2: its B reads and these A reads belong to step 0 of stage g+1 (landed at this stage's barrier)
     s_a_load<0>(fa[PAR ^ 1], aaddr);
-    s_rot_g<PAR, 2, 0>(fa, fb, baddr, acc, nothing);
+    s_rot_g<PAR, 2, 0>(fa, fb, baddr, acc, nodma);
 
-    if (!async_halo && st == NSTAGE - 1 && chunk + 1 < nchunk) {
-      // boundary tile / no schedule: reload the whole halo for the next chunk between two barriers
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      bulk_halo(chunk + 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      s_a_load<0>(fa[PAR ^ 1], aaddr);
-#pragma unroll
-      for (int gq = 0; gq < NR; ++gq) s_b_load<0>(fb[gq], baddr[gq]);
+    prev_extra = extra;
+    if (last) {
+      if (!async_halo && chunk + 1 < nchunk) {
+        // boundary tile / no schedule: reload the whole halo for the next chunk between two barriers
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        bulk_halo(chunk + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        prev_extra = false;
+        s_a_load<0>(fa[PAR ^ 1], aaddr);
+        s_b_load<0, 0>(fb[0], baddr); s_b_load<0, 1>(fb[1], baddr); s_b_load<0, 2>(fb[2], baddr); s_b_load<0, 3>(fb[3], baddr);
+      }
     }
-    ++g;
-    if (++st == NSTAGE) { st = 0; ++chunk; }
+    chunk += last ? 1 : 0;       // (not "if (last) ++chunk; else ++st;": LLVM turns that into an increment through a selected
+    st = last ? 0 : st + 1;      //  pointer, which keeps both counters in scratch memory and every use of them in VGPRs)
   };
   for (int gp = 0; gp < G; gp += 2) {
     one_stage(std::integral_constant<int, 0>{});
@@ -259,99 +335,70 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-  // ---- epilogue: bias, ReLU, folded BatchNorm -> bf16 NHWC at the flat pixel index
+  // ---- epilogue: bias, ReLU, folded BatchNorm -> bf16 NHWC at the flat pixel index.  acc[f][g][4q+k] = pixel
+  // (wm*3+f)*32 + l31, channel (wn*4+g)*32 + 8q + 4h + k: four consecutive channels -> one 8-byte store.
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int gq = 0; gq < NR; ++gq) {
-    const int co = n0 + (wn * NR + gq) * 32 + l31;
-    if (co >= Cout) continue;
-    const float bi = a.bias[co];
-    float sc = 1.f, sh = 0.f;
-    if (a.relu_bn) { sc = a.scale[co]; sh = a.shift[co]; }
 #pragma unroll
-    for (int f = 0; f < MR; ++f) {
+    for (int q = 0; q < 4; ++q) {
+      const int co = n0 + (wn * NR + gq) * 32 + 8 * q + 4 * h;
+      if (co >= Cout) continue;                        // Cout % 4 == 0 (checked on the host)
+      const float4 bi = *reinterpret_cast<const float4*>(a.bias + co);
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.relu_bn) { sc = *reinterpret_cast<const float4*>(a.scale + co); sh = *reinterpret_cast<const float4*>(a.shift + co); }
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int P = P0 + (wm * MR + f) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      for (int f = 0; f < MR; ++f) {
+        const int P = P0 + (wm * MR + f) * 32 + l31;
+        size_t o = (size_t)P * Cout + co;
+        if (a.out_planar) {                                // [B][Cout/8][H*W][8]: the 32 pixels of a fragment x 16 bytes are contiguous
+          const int b = P / HW;
+          o = (((size_t)b * (Cout >> 3) + (co >> 3)) * HW + (P - b * HW)) * 8 + (co & 7);
+        }
+        float v0 = acc[f][gq][4 * q] + bi.x, v1 = acc[f][gq][4 * q + 1] + bi.y, v2 = acc[f][gq][4 * q + 2] + bi.z, v3 = acc[f][gq][4 * q + 3] + bi.w;
+        if (a.relu_bn) {
+          v0 = fmaxf(v0, 0.f) * sc.x + sh.x; v1 = fmaxf(v1, 0.f) * sc.y + sh.y;
+          v2 = fmaxf(v2, 0.f) * sc.z + sh.z; v3 = fmaxf(v3, 0.f) * sc.w + sh.w;
+        }
+#ifdef EXP_NOEPI
+        if (P < gm.Mtotal && v0 == 12345.678f) {
+#else
         if (P < gm.Mtotal) {
-          float v = acc[f][gq][i] + bi;
-          if (a.relu_bn) v = fmaxf(v, 0.f) * sc + sh;
-          static_cast<__bf16*>(a.out)[(size_t)P * Cout + co] = static_cast<__bf16>(v);
+#endif
+          bf16x4 ov;
+          ov[0] = static_cast<__bf16>(v0); ov[1] = static_cast<__bf16>(v1); ov[2] = static_cast<__bf16>(v2); ov[3] = static_cast<__bf16>(v3);
+          *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(a.out) + o) = ov;
         }
       }
     }
   }
 }
 
-// ---- host side: geometry + the halo refill schedule -------------------------------------------------------------
+// ---- host side: geometry ---------------------------------------------------------------------------------------
 namespace {
 
-// Piece q of the next chunk may be issued once the last stage that reads it (in the current chunk) is over, and must
-// be issued 3 stages before the first stage that reads it (a batch issued behind barrier g is waited for at barrier
-// g+2, and the first fragments of a stage are requested one stage early).  Kernel row ky = stages 3ky..3ky+2 reads
-// halo rows ky .. ky+Dn-1 of a non-boundary tile.  Times are stages from the start of the current chunk; slot = time
-// mod 27; a slot holds one piece.  Returns false if no assignment exists.
-bool make_schedule(int pitch, int Dn, int npieces, unsigned (&sched)[7]) {
-  int lo[32], hi[32], ids[32], n = 0;
-  for (int q = 0; q < npieces; ++q) {
-    const int r1 = (64 * q) / pitch, r2 = (64 * q + 63) / pitch;
-    if (r1 > Dn + 7) continue;                         // rows no non-boundary tile reads
-    const int death = 3 * (r2 < 8 ? r2 : 8) + 2;
-    const int need = NSTAGE + 3 * (r1 - (Dn - 1) > 0 ? r1 - (Dn - 1) : 0);
-    lo[n] = death + 1;
-    hi[n] = need - 3;
-    ids[n] = q;
-    if (lo[n] > hi[n] || n >= NSTAGE) return false;
-    ++n;
-  }
-  // bipartite matching pieces -> slots (augmenting paths); a slot t in [lo,hi] maps to slot t % 27
-  int owner[NSTAGE], when[32];
-  for (int s = 0; s < NSTAGE; ++s) owner[s] = -1;
-  struct M {
-    static bool aug(int p, const int* lo, const int* hi, int* owner, int* when, bool* seen) {
-      for (int t = lo[p]; t <= hi[p] && t < lo[p] + NSTAGE; ++t) {
-        const int s = t % NSTAGE;
-        if (seen[s]) continue;
-        seen[s] = true;
-        if (owner[s] < 0 || aug(owner[s], lo, hi, owner, when, seen)) {
-          owner[s] = p;
-          when[p] = t;
-          return true;
-        }
-      }
-      return false;
-    }
-  };
-  for (int p = 0; p < n; ++p) {
-    bool seen[NSTAGE] = {};
-    if (!M::aug(p, lo, hi, owner, when, seen)) return false;
-  }
-  unsigned char bytes[28] = {};
-  for (int p = 0; p < n; ++p) {
-    const int t = when[p];
-    bytes[t % NSTAGE] = (unsigned char)(0x80 | (t < NSTAGE ? 0x40 : 0) | ids[p]);
-  }
-  for (int i = 0; i < 7; ++i) sched[i] = bytes[4 * i] | (bytes[4 * i + 1] << 8) | (bytes[4 * i + 2] << 16) | ((unsigned)bytes[4 * i + 3] << 24);
-  return true;
-}
-
 bool make_geom(const ConvArgs& a, Geom& gm) {
-  if (a.Cin % 32 || a.CoutP % BN || a.W < 8 || a.H < 1) return false;      // Cin % 32: stages are processed in pairs
+  if (a.Cin % 32 || a.CoutP % BN || a.Cout % 4 || a.W < 8 || a.H < 1 || (a.out_planar && a.Cout % 8)) return false;      // Cin % 32: stages are processed in pairs
   const long long HW = (long long)a.H * a.W, M = HW * a.B;
   if (HW < BM || M >= (1ll << 30) || 2 * HW * a.Cin * 2 >= (1ll << 31)) return false;   // a strip touches at most two images
   gm.H = a.H; gm.W = a.W; gm.HW = (int)HW; gm.pitch = a.W + 4;
-  const int Dn = (BM - 1 + a.W - 1) / a.W + 1;          // image rows a strip can touch
-  gm.rows = Dn + 12;                                     // + 4 above, 4 below, 4 zero rows between two images
-  const int slots = gm.rows * gm.pitch + 4;
-  if (slots > PLANE) return false;
-  gm.npieces = (slots + 63) / 64;
-  gm.magic = ((1 << 22) + gm.pitch - 1) / gm.pitch;
-  for (int s = 0; s < PLANE; ++s)
-    if ((int)(((unsigned)s * (unsigned)gm.magic) >> 22) != s / gm.pitch) return false;
+  gm.Dn = (BM - 1 + a.W - 1) / a.W + 1;               // image rows a strip can touch
+  gm.rows = gm.Dn + 12;                                // + 4 above, 4 below, 4 zero rows between two images
+  if (gm.rows * gm.pitch + 4 > PLANE) return false;
+  gm.nparts = (a.W + 63) / 64;
   gm.Mtotal = (int)M;
   gm.mtiles = (int)((M + BM - 1) / BM);
   gm.nN = a.CoutP / BN;
-  for (unsigned& w : gm.sched) w = 0;
-  gm.async_ok = make_schedule(gm.pitch, Dn, gm.npieces, gm.sched) ? 1 : 0;
+  // The in-loop halo refill (see the kernel): row j <= 7 is reloaded during kernel row j+1 by waves 0..2*nparts-1; rows
+  // 8..Dn+7 right after the chunk boundary, 8 parts per stage; a part issued behind barrier s is usable from stage s+3 on;
+  // kernel row ky (stages 3ky..) first reads row ky+Dn-1.  All of that must hold for the worst strip.
+  bool ok = 2 * gm.nparts <= NT / 64;
+  for (int j = 8; j < gm.Dn + 8 && ok; ++j) {
+    const int issued = ((j - 8) * 2 * gm.nparts) / (NT / 64);          // stage of the chunk in which row j is requested
+    const int need = 3 * (j - (gm.Dn - 1) > 0 ? j - (gm.Dn - 1) : 0);
+    ok = issued <= 2 && issued + 3 <= need;
+  }
+  gm.async_ok = ok ? 1 : 0;
   return true;
 }
 

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(thinb::NT, 3) void conv_thin_bf16_kernel(ConvArgs a
       const int gy = y0 - PAD + hy, gx = x0 - PAD + hx;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-        v = *reinterpret_cast<const f32x4*>(xb + ((size_t)gy * W + gx) * Cin + chunk * 32 + u * 8);
+        v = a.in_planar ? *reinterpret_cast<const f32x4*>(xb + (((size_t)(chunk * U + u) * H + gy) * W + gx) * 8)     // [C/8][H*W][8] of image b
+                        : *reinterpret_cast<const f32x4*>(xb + ((size_t)gy * W + gx) * Cin + chunk * 32 + u * 8);
       halo[u * PLANE + hy * WHP + hx] = v;
     }
     wload(chunk, 0);

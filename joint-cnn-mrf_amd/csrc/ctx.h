@@ -152,7 +152,7 @@ int prof_begin(jcm_ctx* c, hipEvent_t* e0, hipEvent_t* e1);
 void prof_end(jcm_ctx* c, const std::string& scope, hipEvent_t e0, hipEvent_t e1, bool ok);
 void prof_release_all(jcm_ctx* c, bool destroy);
 int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int stride, const void* x, int B, int H, int W, int sub,
-                   void* out, bool act_bf16, bool out_f32);
+                   void* out, bool act_bf16, bool out_f32, int in_planar = 0, int out_planar = 0);   // bf16 layouts: ConvArgs in kernels.h
 
 inline int cdiv2(int v) { return (v + 1) / 2; }
 

@@ -201,6 +201,34 @@ __global__ void upsample_merge3_bf16x8_kernel(const bf16x8v* __restrict__ x1, co
   }
 }
 
+// planar tensors: one thread = one pixel of one 8-channel plane; the taps of a plane are 16 bytes apart
+__global__ void upsample_merge3_planar_kernel(const bf16x8v* __restrict__ x1, const bf16x8v* __restrict__ x2, int H2, int W2,
+                                              const bf16x8v* __restrict__ x3, int H3, int W3, bf16x8v* __restrict__ out,
+                                              int H, int W, float sy2, float sx2, float sy3, float sx3, unsigned total) {
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned ox = i % (unsigned)W;
+    const unsigned r = i / (unsigned)W;
+    const unsigned oy = r % (unsigned)H;
+    const size_t plane = r / (unsigned)H;                  // b * C/8 + c8
+    const F8 a = ld8(x1 + i);
+    const F8 u2 = (H2 == H && W2 == W) ? ld8(x2 + i) : bilinear8(x2 + plane * H2 * W2, W2, 1, tf1_tap((int)oy, H2, sy2), tf1_tap((int)ox, W2, sx2));
+    const F8 u3 = (H3 == H && W3 == W) ? ld8(x3 + i) : bilinear8(x3 + plane * H3 * W3, W3, 1, tf1_tap((int)oy, H3, sy3), tf1_tap((int)ox, W3, sx3));
+    bf16x8v o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (__bf16)(((a.v[k] + u2.v[k]) + u3.v[k]) / 3.0f);
+    out[i] = o;
+  }
+}
+hipError_t upsample_merge3_planar(const void* x1, const void* x2, int H2, int W2, const void* x3, int H3, int W3,
+                                  void* out, int B, int H, int W, int C, hipStream_t st) {
+  const size_t total = (size_t)B * (C / 8) * H * W;
+  if (C % 8 || total >= (1ull << 32)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(upsample_merge3_planar_kernel, dim3(grid_for(total)), dim3(256), 0, st, static_cast<const bf16x8v*>(x1),
+                     static_cast<const bf16x8v*>(x2), H2, W2, static_cast<const bf16x8v*>(x3), H3, W3, static_cast<bf16x8v*>(out),
+                     H, W, (float)H2 / (float)H, (float)W2 / (float)W, (float)H3 / (float)H, (float)W3 / (float)W, (unsigned)total);
+  return hipGetLastError();
+}
+
 hipError_t upsample_merge3(const void* x1, const void* x2, int H2, int W2, const void* x3, int H3, int W3,
                            void* out, bool bf16, int B, int H, int W, int C, hipStream_t st) {
   if (C % 4) return hipErrorInvalidValue;

@@ -75,10 +75,12 @@ const ConvLayer* conv_of(jcm_ctx* c, const std::string& scope) {
 
 // The launch itself (kernel choice by precision / f32_conv); run_conv_layer brackets it with the timing events.
 static int launch_conv_layer(jcm_ctx* c, const ConvLayer* L, const void* wp, const void* x, int B, int H, int W, void* out, bool act_bf16,
-                             bool out_f32) {
+                             bool out_f32, int in_planar, int out_planar) {
   ConvArgs a;
   a.x = x; a.wp = wp; a.bias = L->bias; a.scale = L->scale; a.shift = L->shift; a.out = out;
   a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout; a.relu_bn = L->has_bn ? 1 : 0;
+  a.in_planar = in_planar; a.out_planar = out_planar;
+  if ((in_planar || out_planar) && !act_bf16) return fail(JCM_ERR_ARG, "planar activations exist on the bf16 path only");
   if (act_bf16) {
     a.CoutP = L->coutp_bf16;
     if (L->thin_bf16 && out_f32) HIP_TRY(conv_thin_bf16(a, c->stream));
@@ -153,7 +155,7 @@ void prof_release_all(jcm_ctx* c, bool destroy) {
 // One conv layer.  Activations are fp32, or bf16 when the handle runs the bf16 path (`act_bf16`);
 // `out_f32` forces an fp32 result (the logits layer).
 int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int stride, const void* x, int B, int H, int W, int sub,
-                   void* out, bool act_bf16, bool out_f32) {
+                   void* out, bool act_bf16, bool out_f32, int in_planar, int out_planar) {
   if (c->dry) return JCM_OK;
   if (stride == 2) {
     if (!(L->ks == 5 && L->cin == 3 && L->has_bn))
@@ -166,7 +168,7 @@ int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int
   if (stride != 1 || !wp) return fail(JCM_ERR_ARG, "no kernel for layer '" + scope + "' with stride " + std::to_string(stride));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   JCM_TRY(prof_begin(c, &e0, &e1));
-  const int r = launch_conv_layer(c, L, wp, x, B, H, W, out, act_bf16, out_f32);
+  const int r = launch_conv_layer(c, L, wp, x, B, H, W, out, act_bf16, out_f32, in_planar, out_planar);
   prof_end(c, scope, e0, e1, r == JCM_OK);
   return r;
 }
@@ -302,10 +304,20 @@ int refresh_derived(jcm_ctx* c, bool first) {
 namespace {
 
 int run_conv(jcm_ctx* c, const std::string& scope, int stride, const void* x, int B, int H, int W, int sub, void* out,
-             bool act_bf16, bool out_f32) {
+             bool act_bf16, bool out_f32, int in_planar = 0, int out_planar = 0) {
   const ConvLayer* L = conv_of(c, scope);
   if (!L) return fail(JCM_ERR_STATE, "no conv layer '" + scope + "' (set '" + scope + "/weights' and finalize)");
-  return run_conv_layer(c, L, scope, stride, x, B, H, W, sub, out, act_bf16, out_f32);
+  return run_conv_layer(c, L, scope, stride, x, B, H, W, sub, out, act_bf16, out_f32, in_planar, out_planar);
+}
+
+// bf16 handles: does a [B,H,W,Cin] launch of this 9x9 layer take the flattened-strip kernel (which reads / writes the
+// planar activation layout at full speed)?
+bool takes_strip(const ConvLayer* L, int B, int H, int W) {
+  if (!L->wp_bf16 || L->thin_bf16 || conv_igemm_bf16_bn(L->cout, L->ks) != 256) return false;
+  ConvArgs a;
+  a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout; a.CoutP = L->coutp_bf16;
+  a.out_planar = 1;
+  return conv_strip_bf16_supported(a, L->ks);
 }
 
 // model(x, n_joints), main.py:29-74.  x fp32 NHWC; intermediate activations fp32 or bf16.
@@ -327,6 +339,10 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
     w4[r] = cdiv2(cdiv2(cdiv2(win)));
     x4[r] = act((size_t)B * h4[r] * w4[r] * L4->cout);
   }
+  // bf16: the 9x9 chain (conv3 out -> conv4 -> merge -> conv5 -> conv6 in) runs on planar activations [B][C/8][H*W][8]
+  // when conv5 takes the strip kernel; every producer / consumer on that chain handles the layout.
+  const ConvLayer* L6 = conv_of(c, "conv6");
+  const int planar = bf && L6->thin_bf16 && L4->cout % 8 == 0 && L5->cout % 8 == 0 && takes_strip(L5, B, h4[0], w4[0]) ? 1 : 0;
   for (int r = 0; r < 3; ++r) {
     const size_t mark = c->arena_off;
     const std::string res = kRes[r];
@@ -368,17 +384,22 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
     void* p2 = act((size_t)B * h3 * w3 * L2->cout);
     if (!c->dry) HIP_TRY(max_pool_2x2(c2, p2, bf, B, h2, w2, L2->cout, c->stream));         // :47,55,64
     void* c3 = act((size_t)B * h3 * w3 * L3->cout);
-    JCM_TRY(run_conv(c, "conv3_" + res, 1, p2, B, h3, w3, 1, c3, bf, false));              // :48,56,65
-    JCM_TRY(run_conv(c, "conv4_" + res, 1, c3, B, h3, w3, 1, x4[r], bf, false));           // :49,57,66
+    const ConvLayer* L4r = conv_of(c, "conv4_" + res);
+    if (!L4r) return fail(JCM_ERR_STATE, "part-detector parameters incomplete (conv4_" + res + ")");
+    const int in4 = planar && L3->cout % 8 == 0 && takes_strip(L4r, B, h3, w3) ? 1 : 0;      // the patch kernels read NHWC
+    JCM_TRY(run_conv(c, "conv3_" + res, 1, p2, B, h3, w3, 1, c3, bf, false, 0, in4));      // :48,56,65
+    JCM_TRY(run_conv(c, "conv4_" + res, 1, c3, B, h3, w3, 1, x4[r], bf, false, in4, planar));   // :49,57,66
     c->arena_off = mark;
   }
   const int hh = h4[0], ww = w4[0];
   void* merged = act((size_t)B * hh * ww * L4->cout);
-  if (!c->dry)
-    HIP_TRY(upsample_merge3(x4[0], x4[1], h4[1], w4[1], x4[2], h4[2], w4[2], merged, bf, B, hh, ww, L4->cout, c->stream));  // :58,67,69-70
+  if (!c->dry) {                                                                           // :58,67,69-70
+    if (planar) HIP_TRY(upsample_merge3_planar(x4[0], x4[1], h4[1], w4[1], x4[2], h4[2], w4[2], merged, B, hh, ww, L4->cout, c->stream));
+    else HIP_TRY(upsample_merge3(x4[0], x4[1], h4[1], w4[1], x4[2], h4[2], w4[2], merged, bf, B, hh, ww, L4->cout, c->stream));
+  }
   void* c5 = act((size_t)B * hh * ww * L5->cout);
-  JCM_TRY(run_conv(c, "conv5", 1, merged, B, hh, ww, 1, c5, bf, false));                   // :71
-  JCM_TRY(run_conv(c, "conv6", 1, c5, B, hh, ww, 1, logits, bf, true));                    // :72
+  JCM_TRY(run_conv(c, "conv5", 1, merged, B, hh, ww, 1, c5, bf, false, planar, planar));   // :71
+  JCM_TRY(run_conv(c, "conv6", 1, c5, B, hh, ww, 1, logits, bf, true, planar, 0));         // :72
   return JCM_OK;
 }
 

@@ -42,6 +42,11 @@ struct ConvArgs {
   const float* in_scale = nullptr;
   // fp16x3 weights: device pair {Sw, 1/Sw} the weights were multiplied by at pack time (pack_weights_split(ns = 2)); null = 2^12
   const float* w_scale = nullptr;
+  // bf16 kernels: activation layout of the input / output tensor.  0 = NHWC (the boundary layout).  1 = "planar"
+  // [B][C/8][H*W][8]: the 8 channels of a 16-byte MFMA operand unit stay together and every unit is its own image plane,
+  // so a halo row of one unit is contiguous in HBM (a 64-pixel LDS-DMA reads 1 KB instead of 64 separate 128-byte
+  // lines).  The 9x9 chain conv3 -> conv4 -> merge -> conv5 -> conv6 of the bf16 path runs planar.
+  int in_planar = 0, out_planar = 0;
 };
 int conv_igemm_bn(int Cout);                     // N-tile the dispatcher will use for this Cout
 hipError_t conv_igemm_f32(const ConvArgs& a, int ks, hipStream_t st);
@@ -103,6 +108,9 @@ hipError_t resize_bilinear(const float* x, float* out, int B, int H, int W, int 
 // out = (x1 + resize(x2) + resize(x3)) / 3   (main.py:58,67,69-70); x1 [B,H,W,C]
 hipError_t upsample_merge3(const void* x1, const void* x2, int H2, int W2, const void* x3, int H3, int W3,
                            void* out, bool bf16, int B, int H, int W, int C, hipStream_t st);
+// the same on planar bf16 tensors ([B][C/8][H*W][8], all four); C % 8 == 0
+hipError_t upsample_merge3_planar(const void* x1, const void* x2, int H2, int W2, const void* x3, int H3, int W3,
+                                  void* out, int B, int H, int W, int C, hipStream_t st);
 hipError_t concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, size_t N, hipStream_t st);
 hipError_t spatial_softmax(const float* in, float* out, int B, int HW, int K, hipStream_t st);
 hipError_t argmax_coords(const float* hm, int32_t* coords, int B, int HW, int WW, int K, hipStream_t st);
