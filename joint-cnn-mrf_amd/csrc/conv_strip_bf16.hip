@@ -20,7 +20,8 @@
 //     next stage's first k-step are requested before the barrier and the barrier has no load behind it.  The
 //     two waves of a SIMD (w, w+4) issue their DMA in different k-steps: while one issues, the other computes.
 //   * the MFMA is issued as D^T = W^T X^T (operands swapped): a lane then owns one PIXEL and 4 consecutive output
-//     channels per accumulator quad, so the epilogue stores 8 bytes at a time instead of 2.
+//     channels per accumulator quad; the weight fragments are fed with their 32 channels permuted so that the 16
+//     accumulators of a lane are 16 consecutive channels: the epilogue stores 16 bytes at a time instead of 2.
 //
 // Stage = 3 taps of one kernel row x one k16 step = 36 MFMAs per wave; 8 waves (4 x 2), 3 x 4 fragments of
 // 32x32 per wave, rotating-B fragment schedule as in conv_igemm_bf16.hip.
@@ -135,7 +136,10 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
     const int dv = (b - b0) * (H + 4) + y - y0;                             // halo row of the pixel at tap row 0 ... +ky
     aaddr[f] = lds0 + (unsigned)(h * PLANE + dv * pitch + x) * 16u;
   }
-  baddr = lds0 + (unsigned)(WB0 + h * BN + wn * NR * 32 + l31) * 16u;
+  // Row m of a D^T fragment comes out in lane half h = (m>>2)&1, register 4*(m>>3) + (m&3).  Feeding channel
+  // 16h + 4(m>>3) + (m&3) as row m makes a lane's 16 registers 16 CONSECUTIVE channels: two 16-byte stores per fragment.
+  const int bperm = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
+  baddr = lds0 + (unsigned)(WB0 + h * BN + wn * NR * 32 + bperm) * 16u;
 
   f32x16 acc[MR][NR];
 #pragma unroll
@@ -248,6 +252,9 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
   }
   const unsigned hcs = a.in_planar ? (unsigned)(2 * HW * 16) : 32u;         // source step per 16-channel chunk
 
+#ifdef EXP_SETPRIO
+  if (wid >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   // One stage; PAR = which A buffer holds its step 0.  A stage has 3 steps, so PAR flips every stage: the loop body is a
   // PAIR of stages in straight-line code (G is even: Cin % 32 == 0), never a branch on the parity.
   int buf = 0, chunk = 0, st = 0, si = 0;
@@ -274,7 +281,10 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
 #ifdef EXP_NODMA
       return;
 #endif
-      if (idx < TPS) {
+#ifdef EXP_DMA_SHIFT
+      idx -= EXP_DMA_SHIFT;
+#endif
+      if (idx >= 0 && idx < TPS) {
         auto dst = (__attribute__((address_space(3))) char*)(size_t)(wm0 + (unsigned)(idx * 2 * BN * 16));
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, lane16, wsoff + (unsigned)idx * TS, 0, 0);
       }
@@ -293,7 +303,11 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
     s_rot_g<PAR, 0, 0>(fa, fb, baddr, acc, dma);
     // step 1
     s_a_load<2>(fa[PAR], aaddr);
+#ifdef EXP_DMA_SHIFT
+    s_rot_g<PAR, 1, 0>(fa, fb, baddr, acc, dma);
+#else
     s_rot_g<PAR, 1, 0>(fa, fb, baddr, acc, nodma);
+#endif
     // scalars and addresses of the next stage: 3 taps on, next kernel row, or back to tap 0 of the next chunk; next ring slots
     const bool last = st == NSTAGE - 1;
     {
@@ -335,39 +349,52 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-  // ---- epilogue: bias, ReLU, folded BatchNorm -> bf16 NHWC at the flat pixel index.  acc[f][g][4q+k] = pixel
-  // (wm*3+f)*32 + l31, channel (wn*4+g)*32 + 8q + 4h + k: four consecutive channels -> one 8-byte store.
-  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  // ---- epilogue: bias, ReLU, folded BatchNorm -> bf16.  acc[f][g][i] = pixel (wm*3+f)*32 + l31, channel
+  // (wn*4+g)*32 + 16h + i (see bperm): two 8-channel units, one 16-byte store each.
+  int pb[MR], pp[MR];
+#pragma unroll
+  for (int f = 0; f < MR; ++f) {
+    const int P = P0 + (wm * MR + f) * 32 + l31;
+    pb[f] = P / HW;
+    pp[f] = P < gm.Mtotal ? P - pb[f] * HW : -1;
+  }
 #pragma unroll
   for (int gq = 0; gq < NR; ++gq) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int co = n0 + (wn * NR + gq) * 32 + 8 * q + 4 * h;
-      if (co >= Cout) continue;                        // Cout % 4 == 0 (checked on the host)
-      const float4 bi = *reinterpret_cast<const float4*>(a.bias + co);
-      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a.relu_bn) { sc = *reinterpret_cast<const float4*>(a.scale + co); sh = *reinterpret_cast<const float4*>(a.shift + co); }
+    for (int u = 0; u < 2; ++u) {
+      const int co = n0 + (wn * NR + gq) * 32 + 16 * h + 8 * u;
+      if (co >= Cout) continue;                        // Cout % 8 == 0 (checked on the host)
+      float bi[8], sc[8], sh[8];
+      *reinterpret_cast<float4*>(bi) = *reinterpret_cast<const float4*>(a.bias + co);
+      *reinterpret_cast<float4*>(bi + 4) = *reinterpret_cast<const float4*>(a.bias + co + 4);
+      if (a.relu_bn) {
+        *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(a.scale + co);
+        *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(a.scale + co + 4);
+        *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(a.shift + co);
+        *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(a.shift + co + 4);
+      }
 #pragma unroll
       for (int f = 0; f < MR; ++f) {
-        const int P = P0 + (wm * MR + f) * 32 + l31;
-        size_t o = (size_t)P * Cout + co;
-        if (a.out_planar) {                                // [B][Cout/8][H*W][8]: the 32 pixels of a fragment x 16 bytes are contiguous
-          const int b = P / HW;
-          o = (((size_t)b * (Cout >> 3) + (co >> 3)) * HW + (P - b * HW)) * 8 + (co & 7);
-        }
-        float v0 = acc[f][gq][4 * q] + bi.x, v1 = acc[f][gq][4 * q + 1] + bi.y, v2 = acc[f][gq][4 * q + 2] + bi.z, v3 = acc[f][gq][4 * q + 3] + bi.w;
-        if (a.relu_bn) {
-          v0 = fmaxf(v0, 0.f) * sc.x + sh.x; v1 = fmaxf(v1, 0.f) * sc.y + sh.y;
-          v2 = fmaxf(v2, 0.f) * sc.z + sh.z; v3 = fmaxf(v3, 0.f) * sc.w + sh.w;
+        bf16x8 ov;
+        bool special = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float v = acc[f][gq][8 * u + k] + bi[k];
+          if (a.relu_bn) v = fmaxf(v, 0.f) * sc[k] + sh[k];
+#ifdef EXP_NOEPI
+          special = special || v == 12345.678f;
+#endif
+          ov[k] = static_cast<__bf16>(v);
         }
 #ifdef EXP_NOEPI
-        if (P < gm.Mtotal && v0 == 12345.678f) {
+        if (pp[f] >= 0 && special) {
 #else
-        if (P < gm.Mtotal) {
+        (void)special;
+        if (pp[f] >= 0) {
 #endif
-          bf16x4 ov;
-          ov[0] = static_cast<__bf16>(v0); ov[1] = static_cast<__bf16>(v1); ov[2] = static_cast<__bf16>(v2); ov[3] = static_cast<__bf16>(v3);
-          *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(a.out) + o) = ov;
+          const size_t o = a.out_planar ? (((size_t)pb[f] * (Cout >> 3) + (co >> 3)) * HW + pp[f]) * 8      // [B][Cout/8][H*W][8]: 32 pixels x 16 B contiguous
+                                        : ((size_t)pb[f] * HW + pp[f]) * Cout + co;
+          *reinterpret_cast<bf16x8*>(static_cast<__bf16*>(a.out) + o) = ov;
         }
       }
     }
@@ -378,7 +405,7 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
 namespace {
 
 bool make_geom(const ConvArgs& a, Geom& gm) {
-  if (a.Cin % 32 || a.CoutP % BN || a.Cout % 4 || a.W < 8 || a.H < 1 || (a.out_planar && a.Cout % 8)) return false;      // Cin % 32: stages are processed in pairs
+  if (a.Cin % 32 || a.CoutP % BN || a.Cout % 8 || a.W < 8 || a.H < 1) return false;      // Cin % 32: stages are processed in pairs
   const long long HW = (long long)a.H * a.W, M = HW * a.B;
   if (HW < BM || M >= (1ll << 30) || 2 * HW * a.Cin * 2 >= (1ll << 31)) return false;   // a strip touches at most two images
   gm.H = a.H; gm.W = a.W; gm.HW = (int)HW; gm.pitch = a.W + 4;
