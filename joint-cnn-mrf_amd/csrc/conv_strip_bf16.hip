@@ -49,6 +49,7 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 struct Geom {
   int H, W, HW, pitch, rows, nparts, Dn;       // rows: halo rows allocated; nparts: 64-pixel parts per row; Dn: rows a strip can touch
   int Mtotal, mtiles, nN, async_ok;
+  int nfull, nrem;                             // item list: nfull tile-units as full tiles, then nrem tile-units as 4 quarter tiles each
 };
 }  // namespace strip
 
@@ -75,12 +76,12 @@ __device__ __forceinline__ void s_b_load(f32x4& fb, unsigned baddr) {
 
 // MFMAs of (step, column G) and the read of B[G] for the following step.  Queue invariant (see conv_igemm_bf16.hip):
 // exactly MR+NR-1 younger ds_reads are in flight when B[G] of the current step is needed.
-template <int PAR, int STEP, int G, class After>
-__device__ __forceinline__ void s_rot_g(f32x4 (&fa)[2][MR], f32x4 (&fb)[NR], const unsigned baddr, f32x16 (&acc)[MR][NR], After&& after) {
-  if constexpr (G < NR) {
+template <int NC, int PAR, int STEP, int G, class After>      // NC: B fragments (32-channel columns) per wave
+__device__ __forceinline__ void s_rot_g(f32x4 (&fa)[2][MR], f32x4 (&fb)[NC], const unsigned baddr, f32x16 (&acc)[MR][NC], After&& after) {
+  if constexpr (G < NC) {
     constexpr int cur = (STEP + PAR) & 1;          // a stage has 3 steps: the A double buffer flips parity every stage
 #ifndef EXP_NOLDS
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(MR + NR - 1) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(MR + NC - 1) : "memory");
 #endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -88,28 +89,18 @@ __device__ __forceinline__ void s_rot_g(f32x4 (&fa)[2][MR], f32x4 (&fb)[NR], con
       acc[f][G] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[G]), __builtin_bit_cast(bf16x8, fa[cur][f]), acc[f][G], 0, 0, 0);   // D^T: rows = channels, columns = pixels
     __builtin_amdgcn_sched_barrier(0);
     s_b_load<(STEP + 1) % TPS, G>(fb[G], baddr);     // STEP == TPS-1: baddr already points at the next stage's buffer
-    after(STEP * NR + G);
+    after(STEP * NC + G);
     __builtin_amdgcn_sched_barrier(0);
-    s_rot_g<PAR, STEP, G + 1>(fa, fb, baddr, acc, after);
+    s_rot_g<NC, PAR, STEP, G + 1>(fa, fb, baddr, acc, after);
   }
 }
 
-__global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom gm) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// One work item: the 384-pixel strip `mt` x NC 32-channel columns per wave.  NC = 4: the full 256-channel tile `nt`.
+// NC = 1: a quarter of it (64 channels, `sub`), used for the last items of a launch so that the remainder of
+// tiles / CUs does not cost a whole extra round of full tiles.
+template <int NC>
+__device__ __forceinline__ void strip_tile(const ConvArgs& a, const Geom& gm, char* smem, int mt, int nt, int sub) {
   f32x4* lds = reinterpret_cast<f32x4*>(smem);
-
-  const int L = blockIdx.x, nN = gm.nN;
-  int mt, nt;
-  if ((8 % nN) == 0) {   // an XCD (blocks b, b+8, ...) keeps one channel tile: its L2 streams 1/nN of the weights
-    const int xcd = L & 7, q = L >> 3, per = 8 / nN;
-    nt = xcd % nN;
-    mt = q * per + xcd / nN;
-  } else {
-    nt = L % nN;
-    mt = L / nN;
-  }
-  if (mt >= gm.mtiles) return;
-
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
@@ -139,13 +130,14 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
   // Row m of a D^T fragment comes out in lane half h = (m>>2)&1, register 4*(m>>3) + (m&3).  Feeding channel
   // 16h + 4(m>>3) + (m&3) as row m makes a lane's 16 registers 16 CONSECUTIVE channels: two 16-byte stores per fragment.
   const int bperm = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
-  baddr = lds0 + (unsigned)(WB0 + h * BN + wn * NR * 32 + bperm) * 16u;
+  const int col0 = NC == NR ? wn * NR * 32 : sub * 64 + wn * 32;      // first channel of the wave inside the 256-channel tile
+  baddr = lds0 + (unsigned)(WB0 + h * BN + col0 + bperm) * 16u;
 
-  f32x16 acc[MR][NR];
+  f32x16 acc[MR][NC];
 #pragma unroll
   for (int f = 0; f < MR; ++f)
 #pragma unroll
-    for (int g = 0; g < NR; ++g)
+    for (int g = 0; g < NC; ++g)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[f][g][i] = 0.f;
 
@@ -156,7 +148,11 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
   const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(static_cast<const __bf16*>(a.wp)), 0,
                                                        (int)((size_t)KS * KS * Cin * CoutP * 2), 0x00020000);
   const unsigned lane16 = (unsigned)lane * 16u;        // the only per-lane DMA offset: n0 goes into the scalar offsets
-  const int wu = wid >> 2, wq = wid & 3;
+  // NC = 4: wave w moves unit w/4, quarter w%4 of each of the 3 taps.  NC = 1: only quarter `sub` is needed: 6 pieces,
+  // one for each of waves 0..5 (tap w/2, unit w%2).
+  const int wu = NC == NR ? wid >> 2 : wid & 1, wq = NC == NR ? wid & 3 : sub;
+  const int nw = NC == NR ? TPS : (wid < 6 ? 1 : 0);                 // weight pieces this wave issues per stage
+  const int wt0 = NC == NR ? 0 : wid >> 1;                            // its (first) tap inside the stage
   const unsigned wtap_stride = (unsigned)(cin8 * CoutP * 16);
   auto w_piece = [&](int chunk, int s, int i, int buf) __attribute__((always_inline)) {      // tap i of stage (chunk, s) into ring slot buf (prologue; the loop advances scalars)
     const unsigned soff = (unsigned)(3 * s + i) * wtap_stride + (unsigned)(((chunk * 2 + wu) * CoutP + n0 + wq * 64) * 16);
@@ -193,7 +189,9 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
       halo_part(j, r & 1, r >> 1, chunk);
     }
   };
-  // zero the two planes once: gaps, rows outside the image and the 4 rows between two images are never written again
+  // zero the two planes once per item: gaps, rows outside the image and the 4 rows between two images are never written
+  // again.  (The barrier in front: every wave has finished the LDS reads of the work group's previous item.)
+  __builtin_amdgcn_s_barrier();
   for (int i = tid; i < 2 * PLANE; i += NT) lds[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -203,23 +201,32 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
 
   // ---- prologue: three weight stages + the whole halo of chunk 0, everything landed before the first read
 #pragma unroll
-  for (int s = 0; s < 3; ++s)
+  for (int s = 0; s < 3; ++s) {
+    if constexpr (NC == NR) {
 #pragma unroll
-    for (int i = 0; i < TPS; ++i) w_piece(0, s, i, s);
+      for (int i = 0; i < TPS; ++i) w_piece(0, s, i, s);
+    } else if (nw) {
+      w_piece(0, s, wt0, s);
+    }
+  }
   bulk_halo(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  f32x4 fa[2][MR], fb[NR];
+  f32x4 fa[2][MR], fb[NC];
+  auto b_load0 = [&]() __attribute__((always_inline)) {      // the B fragments of a stage's step 0
+    s_b_load<0, 0>(fb[0], baddr);
+    if constexpr (NC == NR) { s_b_load<0, 1>(fb[1], baddr); s_b_load<0, 2>(fb[2], baddr); s_b_load<0, 3>(fb[3], baddr); }
+  };
   s_a_load<0>(fa[0], aaddr);
-  s_b_load<0, 0>(fb[0], baddr); s_b_load<0, 1>(fb[1], baddr); s_b_load<0, 2>(fb[2], baddr); s_b_load<0, 3>(fb[3], baddr);
+  b_load0();
 
   // ---- per-stage control kept to a handful of scalar instructions (every SALU op sits between MFMAs of an in-order wave:
   // 200 of them per stage cost 4 % of the kernel).
   // Weights of stage g+3: source offset and LDS address advance by constants; past the last stage the offset runs out
   // of the buffer and the DMA delivers zeros into a free ring slot -- no tail logic.
   const unsigned TS = wtap_stride, CS = (unsigned)(2 * CoutP * 16);
-  unsigned wsoff = 9u * TS + (unsigned)((wu * CoutP + n0 + wq * 64) * 16);  // stage 3 = taps 9..11 of chunk 0
-  unsigned wm0 = lds0 + (unsigned)((WB0 + 3 * WST + wu * BN + wq * 64) * 16);
+  unsigned wsoff = (unsigned)(9 + wt0) * TS + (unsigned)((wu * CoutP + n0 + wq * 64) * 16);  // stage 3 = taps 9..11 of chunk 0
+  unsigned wm0 = lds0 + (unsigned)((WB0 + 3 * WST + (wt0 * 2 + wu) * BN + wq * 64) * 16);
   // Halo parts of an async tile: what THIS wave issues at stage st is fixed for the whole tile, so it is tabulated once,
   // lane st of two VGPRs (read back with v_readlane): ha = source offset without the chunk term,
   // hb = LDS slot | lanes << 12 | next-chunk << 19 | valid << 20.
@@ -252,9 +259,6 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
   }
   const unsigned hcs = a.in_planar ? (unsigned)(2 * HW * 16) : 32u;         // source step per 16-channel chunk
 
-#ifdef EXP_SETPRIO
-  if (wid >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
   // One stage; PAR = which A buffer holds its step 0.  A stage has 3 steps, so PAR flips every stage: the loop body is a
   // PAIR of stages in straight-line code (G is even: Cin % 32 == 0), never a branch on the parity.
   int buf = 0, chunk = 0, st = 0, si = 0;
@@ -265,8 +269,14 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
     // afterwards everybody's have, and ring slot (g-1)%4 and the halo rows that died with stage g-1 are free.
     // Every wave issues 3 weight pieces per stage + at most one halo part.
 #ifndef EXP_NOVMW
-    if (prev_extra) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // the previous batch: 3 weight pieces (+ a halo part)
-    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    {   // the previous batch (nw weight pieces + maybe a halo part) may stay in flight
+      const int keep = nw + (prev_extra ? 1 : 0);
+      if (keep == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (keep == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (keep == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if (keep == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 #endif
 #ifndef EXP_NOBAR
     __builtin_amdgcn_s_barrier();
@@ -281,15 +291,12 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
 #ifdef EXP_NODMA
       return;
 #endif
-#ifdef EXP_DMA_SHIFT
-      idx -= EXP_DMA_SHIFT;
-#endif
-      if (idx >= 0 && idx < TPS) {
+      if (idx >= 0 && idx < nw) {
         auto dst = (__attribute__((address_space(3))) char*)(size_t)(wm0 + (unsigned)(idx * 2 * BN * 16));
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, lane16, wsoff + (unsigned)idx * TS, 0, 0);
       }
 #ifndef EXP_NOHALO
-      else if (idx == TPS && extra) {
+      else if (idx == (NC == NR ? TPS : 1) && extra) {
         auto dst = (__attribute__((address_space(3))) char*)(size_t)(lds0 + (eb & 0xfffu) * 16u);
         if (lane16 < ((eb >> 8) & 0x7f0u))       // lanes past the row end stay off: the next row's slots are not touched
           __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)dst, 16, hvoff(), ea + (unsigned)hchunk * hcs, 0, 0);
@@ -297,17 +304,14 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
 #endif
     };
     auto nodma = [](int) __attribute__((always_inline)) {};
+    auto dma1 = [&](int idx) __attribute__((always_inline)) { if constexpr (NC != NR) dma(idx); };   // NC = 1: one MFMA group per step, the DMA slots 1.. follow in step 1
 
     // step 0 (tap 3s): reads of step 1 go out, DMA issue interleaved
     s_a_load<1>(fa[PAR ^ 1], aaddr);
-    s_rot_g<PAR, 0, 0>(fa, fb, baddr, acc, dma);
+    s_rot_g<NC, PAR, 0, 0>(fa, fb, baddr, acc, dma);
     // step 1
     s_a_load<2>(fa[PAR], aaddr);
-#ifdef EXP_DMA_SHIFT
-    s_rot_g<PAR, 1, 0>(fa, fb, baddr, acc, dma);
-#else
-    s_rot_g<PAR, 1, 0>(fa, fb, baddr, acc, nodma);
-#endif
+    s_rot_g<NC, PAR, 1, 0>(fa, fb, baddr, acc, dma1);
     // scalars and addresses of the next stage: 3 taps on, next kernel row, or back to tap 0 of the next chunk; next ring slots
     const bool last = st == NSTAGE - 1;
     {
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
     }
     // step 2: its B reads and these A reads belong to step 0 of stage g+1 (landed at this stage's barrier)
     s_a_load<0>(fa[PAR ^ 1], aaddr);
-    s_rot_g<PAR, 2, 0>(fa, fb, baddr, acc, nodma);
+    s_rot_g<NC, PAR, 2, 0>(fa, fb, baddr, acc, nodma);
 
     prev_extra = extra;
     if (last) {
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
         __builtin_amdgcn_s_barrier();
         prev_extra = false;
         s_a_load<0>(fa[PAR ^ 1], aaddr);
-        s_b_load<0, 0>(fb[0], baddr); s_b_load<0, 1>(fb[1], baddr); s_b_load<0, 2>(fb[2], baddr); s_b_load<0, 3>(fb[3], baddr);
+        b_load0();
       }
     }
     chunk += last ? 1 : 0;       // (not "if (last) ++chunk; else ++st;": LLVM turns that into an increment through a selected
@@ -348,6 +352,7 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
     one_stage(std::integral_constant<int, 1>{});
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the look-ahead DMAs of the last stages (zeros into free ring slots)
 
   // ---- epilogue: bias, ReLU, folded BatchNorm -> bf16.  acc[f][g][i] = pixel (wm*3+f)*32 + l31, channel
   // (wn*4+g)*32 + 16h + i (see bperm): two 8-channel units, one 16-byte store each.
@@ -359,10 +364,10 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
     pp[f] = P < gm.Mtotal ? P - pb[f] * HW : -1;
   }
 #pragma unroll
-  for (int gq = 0; gq < NR; ++gq) {
+  for (int gq = 0; gq < NC; ++gq) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int co = n0 + (wn * NR + gq) * 32 + 16 * h + 8 * u;
+      const int co = n0 + col0 + gq * 32 + 16 * h + 8 * u;
       if (co >= Cout) continue;                        // Cout % 8 == 0 (checked on the host)
       float bi[8], sc[8], sh[8];
       *reinterpret_cast<float4*>(bi) = *reinterpret_cast<const float4*>(a.bias + co);
@@ -398,6 +403,34 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
         }
       }
     }
+  }
+}
+
+// Persistent launch: one work group per CU walks the item list.  Items 0 .. nfull-1 are full tiles in the XCD-aware order
+// (work group w takes w, w + grid, ...: grid is a multiple of 8, so a work group -- and with it an XCD's L2 -- keeps one
+// channel tile's weights); the remaining `nrem` tile-units follow as 4 quarter-tile items each, one per work group.
+__global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom gm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nN = gm.nN;
+  auto unit_of = [&](int L, int& mt, int& nt) __attribute__((always_inline)) {
+    if ((8 % nN) == 0) {   // an XCD (items b, b+8, ...) keeps one channel tile: its L2 streams 1/nN of the weights
+      const int xcd = L & 7, q = L >> 3, per = 8 / nN;
+      nt = xcd % nN;
+      mt = q * per + xcd / nN;
+    } else {
+      nt = L % nN;
+      mt = L / nN;
+    }
+  };
+  for (int L = blockIdx.x; L < gm.nfull; L += gridDim.x) {
+    int mt, nt;
+    unit_of(L, mt, nt);
+    if (mt < gm.mtiles) strip_tile<NR>(a, gm, smem, mt, nt, 0);
+  }
+  for (int q = blockIdx.x; q < 4 * gm.nrem; q += gridDim.x) {
+    int mt, nt;
+    unit_of(gm.nfull + (q >> 2), mt, nt);
+    if (mt < gm.mtiles) strip_tile<1>(a, gm, smem, mt, nt, q & 3);
   }
 }
 
@@ -440,13 +473,30 @@ bool conv_strip_bf16_supported(const ConvArgs& a, int ks) {
 hipError_t conv_strip_bf16(const ConvArgs& a, hipStream_t st) {
   Geom gm;
   if (!make_geom(a, gm)) return hipErrorInvalidValue;
-  int blocks;
+  int units;                                           // tile-units in the XCD-aware numbering (padded to whole groups of 8)
   if ((8 % gm.nN) == 0) {
     const int per = 8 / gm.nN;
-    blocks = (gm.mtiles + per - 1) / per * 8;
+    units = (gm.mtiles + per - 1) / per * 8;
   } else {
-    blocks = gm.mtiles * gm.nN;
+    units = gm.mtiles * gm.nN;
   }
+  // one work group per CU (153 KB of LDS each).  Whole rounds of full tiles; what is left over, if it fits the chip as
+  // quarter tiles, runs as quarter tiles: 7200 units on 256 CUs = 28 rounds + 128 quarter items instead of 29 rounds.
+  static std::atomic<int> ncu_cache[64];
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+  int ncu = ncu_cache[dev & 63].load();
+  if (!ncu) {
+    if (hipError_t e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess) return e;
+    ncu = ncu / 8 * 8;
+    if (ncu < 8) ncu = 8;
+    ncu_cache[dev & 63].store(ncu);
+  }
+  static const int tail_split = [] { const char* e = std::getenv("JCM_STRIP_TAIL"); return e ? std::atoi(e) : 1; }();   // 0: A/B without quarter tiles
+  gm.nfull = units / ncu * ncu;
+  gm.nrem = units - gm.nfull;
+  if (!tail_split || 4 * gm.nrem > ncu) { gm.nfull = units; gm.nrem = 0; }
+  const int blocks = units < ncu && gm.nrem == 0 ? units : ncu;
   static LdsAttr attr;
   if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(conv_strip_bf16_kernel), LDS_BYTES); e != hipSuccess) return e;
   hipLaunchKernelGGL(conv_strip_bf16_kernel, dim3(blocks), dim3(NT), LDS_BYTES, st, a, gm);
