@@ -81,7 +81,9 @@ int jcm_finalize(jcm_handle h);
  * BN(relu(conv_SAME(x,w)+b)), or conv+b for the last layer.  x [B,H,W,Cin] -> out
  * [B,ceil(H/s),ceil(W/s),Cout]; size and channel counts come from the stored "<scope>/weights".
  * Kernels exist for the shapes the model uses: (size 5, stride 2, Cin 3) and (size 5|9,
- * stride 1, Cin % 16 == 0); anything else returns JCM_ERR_ARG. */
+ * stride 1, Cin % 16 == 0); anything else returns JCM_ERR_ARG.  On a bf16 handle (stride-1 layers, Cin % 32 == 0)
+ * x and out are still fp32: the input is rounded to bf16, the layer runs on the bf16 MFMA kernel the tower uses and
+ * its bf16 result (fp32 for the last layer) is widened back. */
 int jcm_conv_layer(jcm_handle h, const char* scope, int stride, int last_layer, const float* x, int B, int H, int W,
                    float* out);
 /* max_pool_layer(x, 2, 2) (main.py:172-174): 2x2/2 SAME. [B,H,W,C] -> [B,ceil(H/2),ceil(W/2),C] */

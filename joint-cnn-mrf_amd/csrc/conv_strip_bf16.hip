@@ -399,7 +399,11 @@ __device__ __forceinline__ void strip_tile(const ConvArgs& a, const Geom& gm, ch
 #endif
           const size_t o = a.out_planar ? (((size_t)pb[f] * (Cout >> 3) + (co >> 3)) * HW + pp[f]) * 8      // [B][Cout/8][H*W][8]: 32 pixels x 16 B contiguous
                                         : ((size_t)pb[f] * HW + pp[f]) * Cout + co;
+#ifdef EXP_NTSTORE
+          __builtin_nontemporal_store(ov, reinterpret_cast<bf16x8*>(static_cast<__bf16*>(a.out) + o));
+#else
           *reinterpret_cast<bf16x8*>(static_cast<__bf16*>(a.out) + o) = ov;
+#endif
         }
       }
     }

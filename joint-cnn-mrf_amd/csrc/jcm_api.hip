@@ -589,9 +589,21 @@ int jcm_conv_layer(jcm_handle h, const char* scope, int stride, int last_layer, 
   if (!L) return fail(JCM_ERR_STATE, std::string("no conv layer '") + scope + "'");
   if ((last_layer != 0) == L->has_bn)
     return fail(JCM_ERR_ARG, std::string("last_layer flag disagrees with the BatchNorm parameters stored for '") + scope + "'");
-  if (h->precision != JCM_PRECISION_F32)
-    return fail(JCM_ERR_STATE, "per-layer entry points exchange fp32 activations; a bf16 handle runs jcm_pd_forward / jcm_forward");
-  return run_conv(h, scope, stride, x, B, H, W, 1, out, false, false);
+  if (h->precision == JCM_PRECISION_F32) return run_conv(h, scope, stride, x, B, H, W, 1, out, false, false);
+  // bf16 handle: the boundary stays fp32 NHWC; the layer runs exactly as inside the tower -- input rounded to bf16 (the
+  // activation type of that path), bf16 MFMA kernel, bf16 result (fp32 for the logits layer) -- and is widened back.
+  if (stride != 1) return fail(JCM_ERR_ARG, "bf16 handles run the stride-2 first layer fused with its pool inside jcm_pd_forward only");
+  jcm_ctx* c = h;
+  return with_arena(c, [&] {
+    const size_t nin = (size_t)B * H * W * L->cin, nout = (size_t)B * H * W * L->cout;
+    void* xb = arena_alloc<char>(c, nin * 2);
+    void* ob = last_layer ? nullptr : static_cast<void*>(arena_alloc<char>(c, nout * 2));
+    if (c->dry) return (int)JCM_OK;
+    HIP_TRY(cast_pad_bf16(x, L->cin, xb, L->cin, (size_t)B * H * W, c->stream));
+    JCM_TRY(run_conv(c, scope, 1, xb, B, H, W, 1, last_layer ? static_cast<void*>(out) : ob, true, last_layer != 0));
+    if (!last_layer) HIP_TRY(cast_bf16_f32(ob, out, nout, c->stream));
+    return (int)JCM_OK;
+  });
 }
 
 int jcm_max_pool(jcm_handle h, const float* x, int B, int H, int W, int C, float* out) {

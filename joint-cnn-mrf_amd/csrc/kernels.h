@@ -186,6 +186,7 @@ hipError_t bn_bwd_apply(const void* dy, float dy_scale, const void* r, bool bf16
 hipError_t col_sum(const void* x, bool bf16, size_t N, int C, float* out, double* scratch, hipStream_t st);
 hipError_t max_pool_bwd(const void* x, const void* dy, void* dx, bool bf16, int B, int H, int W, int C, hipStream_t st);
 hipError_t cast_pad_bf16(const float* in, int ldi, void* out, int ldo, size_t N, hipStream_t st);
+hipError_t cast_bf16_f32(const void* in, float* out, size_t n, hipStream_t st);
 // dx [B,h,w,C] = scale * adjoint of the TF-1.x bilinear resize h x w -> H x W applied to dy [B,H,W,C]
 hipError_t resize_bilinear_bwd(const void* dy, void* dx, bool bf16, int B, int h, int w, int H, int W, int C, float scale, hipStream_t st);
 hipError_t softmax_ce(const float* logits, const float* target, int B, int HW, int K, int Kt, float gscale, float* loss, float* dz,

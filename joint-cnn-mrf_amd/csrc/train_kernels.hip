@@ -522,6 +522,15 @@ hipError_t cast_pad_bf16(const float* in, int ldi, void* out, int ldo, size_t N,
   return hipGetLastError();
 }
 
+__global__ void cast_bf16_f32_kernel(const __bf16* __restrict__ in, float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = static_cast<float>(in[i]);
+}
+hipError_t cast_bf16_f32(const void* in, float* out, size_t n, hipStream_t st) {
+  size_t g = (n + 255) / 256;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((int)(g > 65536 ? 65536 : g)), dim3(256), 0, st, static_cast<const __bf16*>(in), out, n);
+  return hipGetLastError();
+}
+
 // out[i] = a[i] * s
 __global__ void scale_copy_kernel(const float* __restrict__ a, float s, float* __restrict__ out, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = a[i] * s;

@@ -126,20 +126,40 @@ def softplus5(x):
     return tf_softplus(SOFTPLUS_ALPHA * x) / SOFTPLUS_ALPHA
 
 
+def bf16_round(x):
+    """Round to the nearest bfloat16 (ties to even), returned in x's dtype.  Used by the `emulate='bf16'` mode below: the
+    MI355X bf16 path (BASELINE.json configs[2]) keeps weights and activations in bf16 and accumulates in fp32, which
+    the reference (fp32 throughout) does not do -- so the emulation is a statement about OUR kernels' arithmetic, used to
+    hold them to rounding-level error instead of the 1e-2 distance between bf16 and fp32 results."""
+    a = np.asarray(x)
+    b = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    b = ((b + 0x7FFF + ((b >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return b.view(np.float32).astype(a.dtype if a.dtype.kind == 'f' else np.float32).reshape(a.shape)
+
+
 # --------------------------------------------------------------------------- model graph
-def conv_layer(x, p, size, stride, name, last_layer=False, dtype=np.float64):
-    """main.py:156-169: conv SAME + bias -> ReLU -> BN (BN *after* ReLU); last layer linear."""
+def conv_layer(x, p, size, stride, name, last_layer=False, dtype=np.float64, emulate=None):
+    """main.py:156-169: conv SAME + bias -> ReLU -> BN (BN *after* ReLU); last layer linear.
+    emulate='bf16': input and weights rounded to bf16 before the (wide) accumulation, the result of a non-last layer
+    rounded to bf16 (it is stored as a bf16 activation); bias / ReLU / BatchNorm stay in `dtype`."""
     w = p[name + '/weights']
     assert w.shape[0] == size and w.shape[1] == size
+    if emulate == 'bf16':
+        x, w = bf16_round(np.asarray(x, dtype)), bf16_round(np.asarray(w, dtype))
+    elif emulate is not None:
+        raise ValueError('emulate must be None or "bf16"')
     pre = conv2d_same(x, w, stride, dtype) + np.asarray(p[name + '/biases'], dtype)
     if last_layer:
         return pre
-    return bn_infer(np.maximum(pre, 0), p, name, dtype)
+    out = bn_infer(np.maximum(pre, 0), p, name, dtype)
+    return bf16_round(out) if emulate == 'bf16' else out
 
 
-def model(x, p, n_joints=N_JOINTS, dtype=np.float64, taps=None):
+def model(x, p, n_joints=N_JOINTS, dtype=np.float64, taps=None, emulate=None):
     """main.py:29-74: 3-resolution part detector -> logits [B,60,90,n_joints].
-    `taps` (dict) optionally receives every intermediate activation by scope name."""
+    `taps` (dict) optionally receives every intermediate activation by scope name.
+    emulate='bf16': every conv layer as conv_layer(..., emulate='bf16'), the merged map rounded to bf16 (max-pool and
+    sub-sampling are exact on bf16 values) -- the arithmetic of Engine(precision='bf16')."""
     x = np.asarray(x, dtype)
     H, W = x.shape[1], x.shape[2]
 
@@ -149,12 +169,12 @@ def model(x, p, n_joints=N_JOINTS, dtype=np.float64, taps=None):
         return v
 
     def branch(xin, res):
-        h = keep('conv1_' + res, conv_layer(xin, p, 5, 2, 'conv1_' + res, dtype=dtype))
+        h = keep('conv1_' + res, conv_layer(xin, p, 5, 2, 'conv1_' + res, dtype=dtype, emulate=emulate))
         h = keep('pool1_' + res, max_pool_same(h))
-        h = keep('conv2_' + res, conv_layer(h, p, 5, 1, 'conv2_' + res, dtype=dtype))
+        h = keep('conv2_' + res, conv_layer(h, p, 5, 1, 'conv2_' + res, dtype=dtype, emulate=emulate))
         h = keep('pool2_' + res, max_pool_same(h))
-        h = keep('conv3_' + res, conv_layer(h, p, 5, 1, 'conv3_' + res, dtype=dtype))
-        h = keep('conv4_' + res, conv_layer(h, p, 9, 1, 'conv4_' + res, dtype=dtype))
+        h = keep('conv3_' + res, conv_layer(h, p, 5, 1, 'conv3_' + res, dtype=dtype, emulate=emulate))
+        h = keep('conv4_' + res, conv_layer(h, p, 9, 1, 'conv4_' + res, dtype=dtype, emulate=emulate))
         return h
 
     x1 = branch(x, 'fullres')                                               # main.py:43-49
@@ -162,9 +182,10 @@ def model(x, p, n_joints=N_JOINTS, dtype=np.float64, taps=None):
     x2 = resize_bilinear_tf1(x2, x1.shape[1], x1.shape[2])                  # main.py:58
     x3 = branch(resize_bilinear_tf1(x, H // 4, W // 4), 'quarterres')       # main.py:60-66
     x3 = resize_bilinear_tf1(x3, x1.shape[1], x1.shape[2])                  # main.py:67
-    h = keep('merge', (x1 + x2 + x3) / dtype(3))                            # main.py:69-70
-    h = keep('conv5', conv_layer(h, p, 9, 1, 'conv5', dtype=dtype))         # main.py:71
-    return keep('conv6', conv_layer(h, p, 9, 1, 'conv6', last_layer=True, dtype=dtype))  # :72
+    h = (x1 + x2 + x3) / dtype(3)                                           # main.py:69-70
+    h = keep('merge', bf16_round(h) if emulate == 'bf16' else h)
+    h = keep('conv5', conv_layer(h, p, 9, 1, 'conv5', dtype=dtype, emulate=emulate))     # main.py:71
+    return keep('conv6', conv_layer(h, p, 9, 1, 'conv6', last_layer=True, dtype=dtype, emulate=emulate))  # :72
 
 
 def spatial_softmax(hm):

@@ -44,14 +44,50 @@ def test_conv_layer_random_shape(case):
     scale = np.abs(ref).max()
     xd = torch.as_tensor(x, device='cuda:0')
     for mode, kw, tol in (('exact', dict(f32_conv='exact'), 2e-5), ('split', dict(f32_conv='split', split_min_wgs=0), 2e-5),
-                          ('split16', dict(f32_conv='split16', split_min_wgs=0), 2e-5), ('bf16', dict(precision='bf16'), None)):
-        if mode == 'bf16':
-            continue                      # per-layer entry points are fp32-only (jcm_conv_layer); the bf16 kernels are covered by the tower tests
+                          ('split16', dict(f32_conv='split16', split_min_wgs=0), 2e-5)):
         eng = Engine(device=0, **kw).load_params(p)
         got = eng.conv_layer(xd, 'c', 1, n_out=cout).cpu().numpy()
         eng.close()
         err = np.abs(got - ref).max() / scale
         assert err <= tol, '%s: %.2e' % (mode, err)
+    # bf16 path, per layer: against the oracle in ITS arithmetic (operands rounded to bf16, wide accumulation, result
+    # rounded to bf16).  The kernel accumulates in fp32, so a result that lands on a rounding boundary may come out one
+    # bf16 ulp away; everything else must be identical.
+    refb = O.conv_layer(x.astype(np.float64), p, ks, 1, 'c', emulate='bf16')
+    eng = Engine(device=0, precision='bf16').load_params(p)
+    gotb = eng.conv_layer(xd, 'c', 1, n_out=cout).cpu().numpy().astype(np.float64)
+    eng.close()
+    check_bf16_layer(gotb, refb)
+
+
+def check_bf16_layer(got, ref):
+    """got, ref: bf16-valued arrays.  At most one bf16 ulp apart (plus the fp32 accumulation error of the kernel, which
+    is relative to the layer's scale, not to a result that the bias / BatchNorm shift happens to bring near zero), and
+    apart in at most 2 % of the entries."""
+    ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref), 1e-30))) - 7)
+    diff = np.abs(got - ref)
+    slack = 1e-5 * np.abs(ref).max()
+    assert (diff <= 1.001 * ulp + slack).all(), 'more than one bf16 ulp: worst %.3g ulp' % float(((diff - slack) / ulp).max())
+    assert (diff > 0).mean() <= 0.02, 'rounded differently in %.2f %% of the entries' % (100 * (diff > 0).mean())
+    assert np.sqrt(np.mean(diff ** 2)) <= 1e-3 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('shape', [(2, 60, 90, 512, 9), (1, 30, 45, 64, 9), (3, 17, 29, 96, 7)], ids=lambda s: 'B%d_%dx%d_%d-%d' % s)
+def test_bf16_logits_layer_vs_bf16_oracle(shape):
+    """The last (linear) layer on the bf16 path keeps its fp32 result: no output rounding, so the kernel must agree with
+    the bf16-operand oracle to accumulation error (fp32 vs float64), orders of magnitude below the bf16-vs-fp32 gap."""
+    from joint_cnn_mrf_amd.engine import Engine
+    B, H, W, cin, cout = shape
+    rs = np.random.RandomState(B * 1000 + cin)
+    p = {'c/weights': (rs.standard_normal((9, 9, cin, cout)) * np.sqrt(2.0 / (81 * cin))).astype(np.float32),
+         'c/biases': (0.1 * rs.standard_normal(cout)).astype(np.float32)}
+    x = np.maximum(rs.standard_normal((B, H, W, cin)), 0).astype(np.float32)
+    ref = O.conv_layer(x.astype(np.float64), p, 9, 1, 'c', last_layer=True, emulate='bf16')
+    eng = Engine(device=0, precision='bf16').load_params(p)
+    got = eng.conv_layer(torch.as_tensor(x, device='cuda:0'), 'c', 1, last_layer=True, n_out=cout).cpu().numpy()
+    eng.close()
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+    assert np.abs(got - O.conv_layer(x.astype(np.float64), p, 9, 1, 'c', last_layer=True)).max() >= 1e-4 * np.abs(ref).max()   # ...which this test would not see
 
 
 @pytest.mark.parametrize('hw', [(240, 368), (480, 720), (328, 488)])

@@ -149,3 +149,24 @@ def test_two_formulations_agree_end_to_end(bn, kind):
     sb = T.spatial_model(hm10, p)
     np.testing.assert_allclose(sa, sb, rtol=1e-9, atol=1e-9)
     np.testing.assert_array_equal(O.argmax_coords(O.spatial_softmax(sa)), T.argmax_coords(T.spatial_softmax(sb)))
+
+
+def test_bf16_round_is_round_to_nearest_even():
+    """oracle.bf16_round (the emulate='bf16' mode that pins the bf16 kernels) against torch's float32 -> bfloat16 cast,
+    ties included."""
+    ties = np.array([1.00390625, 1.01171875, -1.00390625, 3.0e38, 1e-40], np.float64)      # exact halves round to even
+    rs = np.random.RandomState(5)
+    y = np.concatenate([ties, rs.standard_normal(20000) * 10.0 ** rs.uniform(-30, 30, 20000)])
+    want = torch.tensor(y, dtype=torch.float32).to(torch.bfloat16).to(torch.float64).numpy()
+    np.testing.assert_array_equal(O.bf16_round(y), want)
+    assert O.bf16_round(np.float64(1.00390625)) == 1.0 and O.bf16_round(np.float64(1.01171875)) == 1.015625
+
+
+def test_emulated_bf16_layer_differs_from_fp32_by_bf16_not_more():
+    rs = np.random.RandomState(6)
+    p = {'c/weights': (rs.standard_normal((5, 5, 32, 32)) * 0.05).astype(np.float32), 'c/biases': np.zeros(32, np.float32)}
+    x = rs.standard_normal((1, 9, 11, 32))
+    a = O.conv_layer(x, p, 5, 1, 'c', last_layer=True)
+    b = O.conv_layer(x, p, 5, 1, 'c', last_layer=True, emulate='bf16')
+    rel = np.abs(a - b).max() / np.abs(a).max()
+    assert 1e-4 < rel < 2e-2
