@@ -19,6 +19,7 @@
 #ifndef JCM_H
 #define JCM_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -117,6 +118,14 @@ int jcm_softmax_argmax(jcm_handle h, const float* logits, int B, int HH, int WW,
 int jcm_forward(jcm_handle h, const float* x, const float* torso, int B, int H, int W, int use_sm,
                 float* pd_prob, float* sm_prob, int32_t* pd_coords, int32_t* sm_coords);
 
+/* The same tower with the two losses of the graph in inference mode -- what eval_error runs per batch
+ * (main.py:275-283: sess.run([loss_pd, loss_sm, det_rate_pd, det_rate_sm], flag_train=False)).  y = y_in
+ * [B,60,90,K+1] (main.py:488): its first K channels are the targets of softmax_cross_entropy (main.py:220-240,
+ * 538-539), channel K the torso map.  losses: device fp32 [2] = loss_pd, loss_sm (loss_sm = loss_pd when use_sm == 0,
+ * main.py:535).  The detection rates are a few [B,2,K] operations on the returned coordinates (evaluation.py). */
+int jcm_eval_forward(jcm_handle h, const float* x, const float* y, int B, int H, int W, int use_sm,
+                     float* pd_prob, float* sm_prob, int32_t* pd_coords, int32_t* sm_coords, float* losses);
+
 /* -- multi-scale test-time evaluation (the caller of the tower, main.py:326-425) ---------------------
  * One pad-or-crop window per output, then skimage.transform.resize(window, [OH,OW]) with the
  * 0.13.x defaults the reference relies on (bilinear, half-pixel centres, zeros outside, clip to
@@ -127,6 +136,26 @@ int jcm_window_resize(jcm_handle h, const float* src, int nsrc, int H, int W, in
                       int OH, int OW, float* out);
 /* np.average over the G scale copies of each image (main.py:413-414): in [n*G, M] -> out [n, M]. */
 int jcm_group_mean(jcm_handle h, const float* in, int n, int G, int64_t M, float* out);
+
+/* -- tower concat across processes (main.py:573-574: tf.concat of the per-tower maps; here one process per GPU) --------
+ * The only collective of the inference path: every rank contributes its [B_local,2,K] int32 coordinates and receives
+ * all ranks' in rank order, moved by RCCL (the ROCm build of the NCCL API) over xGMI.  RCCL is resolved with dlopen on
+ * first use (inside a torch process that is the copy torch loaded).
+ *   jcm_comm_unique_id : rank 0 creates the 128-byte rendezvous id (ncclGetUniqueId); the host hands it to the other ranks
+ *                        by whatever channel it has (the Python host uses the torch.distributed store);
+ *   jcm_comm_create    : ncclCommInitRank on `device` (collective over all ranks);
+ *   jcm_allgather_coords: ncclAllGather on the handle's stream, then synchronises that stream -- the one entry point of
+ *                        the path that does; local [B_local,2,K], all_out [world*B_local,2,K], both device int32. */
+#define JCM_COMM_ID_BYTES 128
+typedef struct jcm_comm_s* jcm_comm;
+int jcm_comm_unique_id(unsigned char* id);
+int jcm_comm_create(const unsigned char* id, int world, int rank, int device, jcm_comm* out);
+int jcm_comm_destroy(jcm_comm c);
+int jcm_allgather_coords(jcm_handle h, jcm_comm c, const int32_t* local, int B_local, int32_t* all_out);
+
+/* CRC-32C (Castagnoli) of host memory, continuing from `crc` (0 to start): the checksum of tf.train.Saver checkpoint
+ * files (tf_checkpoint.py reads and writes them; main.py:604,612,666).  Host-only helper, no device work. */
+uint32_t jcm_crc32c(const void* data, size_t n, uint32_t crc);
 
 /* -- introspection (used by bench.py for the roofline object) ------------------------------------
  * Sum of the HIP-event durations (ms) and the number of launches recorded for conv layer
@@ -176,6 +205,12 @@ int jcm_train_apply(jcm_handle h, const float* grads, int optimizer, float lr, f
 typedef void (*jcm_grad_ready_fn)(void* user, int64_t offset, int64_t count);
 int jcm_train_set_grad_callback(jcm_handle h, jcm_grad_ready_fn fn, void* user);
 int jcm_train_steps(jcm_handle h, int64_t* n_iters);     /* n_iters_tf (main.py:491) */
+/* The optimizer side of Saver.save / Saver.restore (main.py:604,612,666 cover every global variable): slot 0 = the
+ * '<var>/Adam' first moments (or '<var>/Momentum' accumulators), slot 1 = the '<var>/Adam_1' second moments, flat in the
+ * layout of jcm_train_param_info (host or device pointer, may be NULL to move n_iters only); n_iters also fixes Adam's
+ * beta powers (beta^n_iters) and the position in the learning-rate schedule. */
+int jcm_train_get_state(jcm_handle h, int slot, float* out, int64_t count, int64_t* n_iters);
+int jcm_train_set_state(jcm_handle h, int slot, const float* data, int64_t count, int64_t n_iters);
 /* Saver.save side (main.py:666): copy a stored parameter out (host or device pointer). */
 int jcm_get_tensor(jcm_handle h, const char* name, float* out, int64_t count);
 /* Saver.restore on a live session (main.py:612): overwrite a stored parameter after jcm_finalize

@@ -38,10 +38,17 @@ SIGNATURES = {
     'jcm_softmax_argmax': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p, _c_i32_p]),
     'jcm_forward': (ctypes.c_int, [_handle, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                    _c_float_p, _c_float_p, _c_i32_p, _c_i32_p]),
+    'jcm_eval_forward': (ctypes.c_int, [_handle, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        _c_float_p, _c_float_p, _c_i32_p, _c_i32_p, _c_float_p]),
     'jcm_window_resize': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p]),
     'jcm_group_mean': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, _c_float_p]),
     'jcm_profile_read': (ctypes.c_int, [_handle, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
+    'jcm_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p]),
+    'jcm_comm_create': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    'jcm_comm_destroy': (ctypes.c_int, [ctypes.c_void_p]),
+    'jcm_allgather_coords': (ctypes.c_int, [_handle, ctypes.c_void_p, _c_i32_p, ctypes.c_int, _c_i32_p]),
+    'jcm_crc32c': (ctypes.c_uint32, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]),
     'jcm_conv_kernel_name': (ctypes.c_int, [_handle, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
     'jcm_workspace_bytes': (ctypes.c_int64, [_handle]),
     'jcm_train_begin': (ctypes.c_int, [_handle]),
@@ -53,6 +60,8 @@ SIGNATURES = {
     'jcm_train_apply': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.POINTER(ctypes.c_float)]),
     'jcm_train_set_grad_callback': (ctypes.c_int, [_handle, ctypes.c_void_p, ctypes.c_void_p]),
     'jcm_train_steps': (ctypes.c_int, [_handle, ctypes.POINTER(ctypes.c_int64)]),
+    'jcm_train_get_state': (ctypes.c_int, [_handle, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
+    'jcm_train_set_state': (ctypes.c_int, [_handle, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]),
     'jcm_get_tensor': (ctypes.c_int, [_handle, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64]),
     'jcm_update_tensor': (ctypes.c_int, [_handle, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]),
 }

@@ -10,7 +10,11 @@ whose keys are exactly the TF variable names:
 
 A TF-1.x user exports one with
     r = tf.train.load_checkpoint(path); np.savez(out, **{k: r.get_tensor(k) for k in r.get_variable_to_shape_map()})
-(optimizer slots such as '<var>/Adam' and 'n_iters' are ignored on load).
+`load_npz` keeps the variables the inference path reads; `session_state` / `restore_session_state` add what
+tf.train.Saver also saves and a resumed training run needs (main.py:604,612,666): the optimizer slots '<var>/Adam',
+'<var>/Adam_1' (or '<var>/Momentum'), Adam's 'beta1_power' / 'beta2_power' and the update counter 'n_iters'.
+The TensorFlow checkpoint-V2 files themselves (`<prefix>.index` + `<prefix>.data-00000-of-00001`) are read and written
+by `tf_checkpoint.py`.
 """
 import numpy as np
 
@@ -59,3 +63,60 @@ def load_npz(path, debug=False, use_sm=True):
     with np.load(path) as z:
         params = {k: np.asarray(z[k], np.float32) for k in z.files if k in want}
     return validate(params, debug, use_sm)
+
+
+# ---------------------------------------------------------------------------------------------------- training sessions
+ADAM_BETA1, ADAM_BETA2 = 0.9, 0.999          # tf.train.AdamOptimizer defaults (main.py:502)
+
+
+def session_state(trainer, like):
+    """Everything `saver.save(sess, ...)` writes for a training session (main.py:604,666), keyed by the TF variable names:
+    the model variables (shapes taken from the dict `like`), the optimizer slots of every trainable variable, Adam's beta
+    powers and n_iters."""
+    import ctypes
+    from . import _lib
+    out = dict(trainer.get_params(like))
+    n = ctypes.c_int64()
+    slots = []
+    for slot in (0, 1):
+        buf = np.empty(trainer.n_elements, np.float32)
+        _lib.check(trainer._lib.jcm_train_get_state(trainer.eng._h, slot, ctypes.c_void_p(buf.ctypes.data), buf.size, ctypes.byref(n)),
+                   'jcm_train_get_state')
+        slots.append(buf)
+    adam = trainer.optimizer == 'adam'
+    for name, off, cnt in trainer.layout:
+        shape = np.asarray(like[name]).shape
+        if adam:
+            out[name + '/Adam'] = slots[0][off:off + cnt].reshape(shape).copy()
+            out[name + '/Adam_1'] = slots[1][off:off + cnt].reshape(shape).copy()
+        else:
+            out[name + '/Momentum'] = slots[0][off:off + cnt].reshape(shape).copy()
+    if adam:
+        out['beta1_power'] = np.float32(ADAM_BETA1 ** n.value)
+        out['beta2_power'] = np.float32(ADAM_BETA2 ** n.value)
+    out['n_iters'] = np.int32(n.value)
+    return out
+
+
+def restore_session_state(trainer, state):
+    """`saver.restore` for the optimizer side: the model variables of `state` are loaded through Engine.load_params /
+    jcm_update_tensor by the caller; this puts the slots and n_iters back (missing slots restore as zeros, like a
+    checkpoint written before the optimizer existed)."""
+    import ctypes
+    from . import _lib
+    adam = trainer.optimizer == 'adam'
+    names = ('/Adam', '/Adam_1') if adam else ('/Momentum',)
+    n_iters = int(state.get('n_iters', 0))
+    for slot, suffix in enumerate(names):
+        buf = np.zeros(trainer.n_elements, np.float32)
+        for name, off, cnt in trainer.layout:
+            if name + suffix in state:
+                v = np.asarray(state[name + suffix], np.float32).reshape(-1)
+                if v.size != cnt:
+                    raise ValueError('%s has %d elements, expected %d' % (name + suffix, v.size, cnt))
+                buf[off:off + cnt] = v
+        _lib.check(trainer._lib.jcm_train_set_state(trainer.eng._h, slot, ctypes.c_void_p(buf.ctypes.data), buf.size, n_iters),
+                   'jcm_train_set_state')
+    if not adam:
+        _lib.check(trainer._lib.jcm_train_set_state(trainer.eng._h, 1, None, 0, n_iters), 'jcm_train_set_state')
+    return n_iters

@@ -406,14 +406,15 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
 // spatial_model(heat_map), main.py:94-125.
 // The 10-channel input is given as channels [0,Ca) of `hm` ([B,5400,Ca]) plus `extra` ([B,5400,10-Ca]): Ca = 10 for
 // jcm_sm_forward, Ca = 9 + the torso map inside the tower (the tf.concat of main.py:528 is never materialised).
-int sm_forward_impl(jcm_ctx* c, const float* hm, int Ca, const float* extra, int B, float* logits) {
+int sm_forward_impl(jcm_ctx* c, const float* hm, int Ca, const float* extra, int B, float* logits, int extra_ld = 0) {
+  if (extra_ld <= 0) extra_ld = kC - Ca;
   if (!c->has_sm) return fail(JCM_ERR_STATE, "spatial-model parameters (bn_sm, energy_*, bias_*) were not set");
   const int P = c->K * (kC - 1);
   if (c->sm_algo == 1) {   // direct convolution
     float* lik = arena_alloc<float>(c, (size_t)B * kC * kHmH * 96);
     float* cpre = arena_alloc<float>(c, (size_t)B * P * kCH * kCW);
     if (c->dry) return JCM_OK;
-    HIP_TRY(sm_likelihood(hm, Ca, extra, c->bn_sm_scale, c->bn_sm_shift, lik, B, kC, c->stream));
+    HIP_TRY(sm_likelihood(hm, Ca, extra, c->bn_sm_scale, c->bn_sm_shift, lik, B, kC, c->stream, extra_ld));
     HIP_TRY(sm_pair_conv(c->sp_energy, lik, c->cond, cpre, B, P, kC, c->stream));
     HIP_TRY(sm_finish(lik, cpre, c->sp_bias, logits, B, c->K, kC, c->stream));
     return JCM_OK;
@@ -430,8 +431,8 @@ int sm_forward_impl(jcm_ctx* c, const float* hm, int Ca, const float* extra, int
     if (c->dry) return JCM_OK;
     for (int b0 = 0; b0 < B; b0 += Bc) {
       const int nb = B - b0 < Bc ? B - b0 : Bc;
-      HIP_TRY(sm_pad_frame(hm + (size_t)b0 * kHmHW * Ca, Ca, extra ? extra + (size_t)b0 * kHmHW * (kC - Ca) : nullptr, c->bn_sm_scale, c->bn_sm_shift,
-                           frame, nb, kC, c->stream));
+      HIP_TRY(sm_pad_frame(hm + (size_t)b0 * kHmHW * Ca, Ca, extra ? extra + (size_t)b0 * kHmHW * extra_ld : nullptr, c->bn_sm_scale, c->bn_sm_shift,
+                           frame, nb, kC, c->stream, extra_ld));
       FFT_TRY(sm_fft_r2c(c->fft, frame, lhat, nb * kC));
       HIP_TRY(sm_transpose(lhat, lhat_t, nb * kC, kPrH, WC, 0, WC, c->stream));
       HIP_TRY(sm_spec_mul(lhat_t, c->prior_spec_t, c->cond, spec_t, nb, kC, P, c->stream));      // elementwise: layout-agnostic
@@ -453,8 +454,8 @@ int sm_forward_impl(jcm_ctx* c, const float* hm, int Ca, const float* extra, int
   if (c->dry) return JCM_OK;
   for (int b0 = 0; b0 < B; b0 += Bc) {
     const int nb = B - b0 < Bc ? B - b0 : Bc;
-    HIP_TRY(sm_pad_frame(hm + (size_t)b0 * kHmHW * Ca, Ca, extra ? extra + (size_t)b0 * kHmHW * (kC - Ca) : nullptr, c->bn_sm_scale, c->bn_sm_shift,
-                           frame, nb, kC, c->stream));
+    HIP_TRY(sm_pad_frame(hm + (size_t)b0 * kHmHW * Ca, Ca, extra ? extra + (size_t)b0 * kHmHW * extra_ld : nullptr, c->bn_sm_scale, c->bn_sm_shift,
+                           frame, nb, kC, c->stream, extra_ld));
     FFT_TRY(sm_fft_r2c(c->fft, frame, lhat, nb * kC));
     HIP_TRY(sm_spec_mul(lhat, c->prior_spec, c->cond, spec, nb, kC, P, c->stream));
     FFT_TRY(sm_fft_c2r(c->fft, spec, cfull, nb * P));
@@ -693,10 +694,14 @@ int jcm_argmax_coords(jcm_handle h, const float* hm, int B, int HH, int WW, int 
   return JCM_OK;
 }
 
-int jcm_forward(jcm_handle h, const float* x, const float* torso, int B, int H, int W, int use_sm,
-                float* pd_prob, float* sm_prob, int32_t* pd_coords, int32_t* sm_coords) {
+// The tower of main.py:522-531, optionally with the two cross-entropy terms of main.py:538-539 in inference mode (what
+// eval_error runs, main.py:275-283).  The torso channel is `torso` [B,HW,1], or channel K of y [B,HW,K+1] when y is given.
+static int forward_impl(jcm_handle h, const float* x, const float* torso, const float* y, int B, int H, int W, int use_sm,
+                        float* pd_prob, float* sm_prob, int32_t* pd_coords, int32_t* sm_coords, float* losses) {
   JCM_TRY(check(h, true));
   if (!x || B < 1 || H < 8 || W < 8) return fail(JCM_ERR_ARG, "bad forward arguments");
+  const int tld = y ? h->K + 1 : 1;                       // floats per pixel of the tensor the torso channel lives in
+  if (y) torso = y + h->K;
   if (use_sm && !torso) return fail(JCM_ERR_ARG, "use_sm needs the torso heat map (y_in[...,K:], main.py:528)");
   if (use_sm && (cdiv2(cdiv2(cdiv2(H))) != kHmH || cdiv2(cdiv2(cdiv2(W))) != kHmW))
     return fail(JCM_ERR_ARG, "the spatial model is defined for 60x90 heat maps (480x720 images) only");
@@ -721,13 +726,20 @@ int jcm_forward(jcm_handle h, const float* x, const float* torso, int B, int H, 
     c->arena_off = mark;
     // spatial_softmax (main.py:523) and the argmax of evaluation.py:15-24 in one pass over the logits
     if (!c->dry) HIP_TRY(softmax_argmax(logits, prob, pd_coords ? pd_coords + (size_t)b0 * 2 * K : nullptr, nb, hh * ww, ww, K, c->stream));
+    float* ce = losses ? arena_alloc<float>(c, 2 * (size_t)nb * K) : nullptr;            // per (image, joint) cross entropies
+    const float* yb = y ? y + (size_t)b0 * hh * ww * (K + 1) : nullptr;
+    if (losses && !c->dry) HIP_TRY(softmax_ce(logits, yb, nb, hh * ww, K, K + 1, 0.f, ce, nullptr, 0, 0, c->stream));     // main.py:538
     if (use_sm) {
       float* sml = arena_alloc<float>(c, n);
       float* smp = sm_prob ? sm_prob + o : nullptr;
-      JCM_TRY(sm_forward_impl(c, prob, K, torso + (size_t)b0 * hh * ww, nb, sml));       // main.py:528,530
+      JCM_TRY(sm_forward_impl(c, prob, K, torso + (size_t)b0 * hh * ww * tld, nb, sml, tld));       // main.py:528,530
       if (!c->dry && (smp || sm_coords))
         HIP_TRY(softmax_argmax(sml, smp, sm_coords ? sm_coords + (size_t)b0 * 2 * K : nullptr, nb, hh * ww, ww, K, c->stream));   // main.py:531
+      if (losses && !c->dry) HIP_TRY(softmax_ce(sml, yb, nb, hh * ww, K, K + 1, 0.f, ce + (size_t)nb * K, nullptr, 0, 0, c->stream));   // main.py:539
+    } else if (losses && !c->dry) {
+      HIP_TRY(hipMemcpyAsync(ce + (size_t)nb * K, ce, (size_t)nb * K * sizeof(float), hipMemcpyDeviceToDevice, c->stream));       // main.py:535
     }
+    if (losses && !c->dry) HIP_TRY(loss_means_accumulate(ce, nb * K, 1.0f / (float)(B * K), losses, b0 == 0, c->stream));      // reduce_mean, main.py:240
     return (int)JCM_OK;
   };
   // sizing pass on the largest micro-batch, then the real passes (the arena never reallocates mid-graph)
@@ -743,6 +755,17 @@ int jcm_forward(jcm_handle h, const float* x, const float* torso, int B, int H, 
     JCM_TRY(body(b0, B - b0 < mb ? B - b0 : mb));
   }
   return JCM_OK;
+}
+
+int jcm_forward(jcm_handle h, const float* x, const float* torso, int B, int H, int W, int use_sm,
+                float* pd_prob, float* sm_prob, int32_t* pd_coords, int32_t* sm_coords) {
+  return forward_impl(h, x, torso, nullptr, B, H, W, use_sm, pd_prob, sm_prob, pd_coords, sm_coords, nullptr);
+}
+
+int jcm_eval_forward(jcm_handle h, const float* x, const float* y, int B, int H, int W, int use_sm,
+                     float* pd_prob, float* sm_prob, int32_t* pd_coords, int32_t* sm_coords, float* losses) {
+  if (!y || !losses) return fail(JCM_ERR_ARG, "eval_forward needs the target heat maps y [B,60,90,K+1] and a 2-float loss buffer");
+  return forward_impl(h, x, nullptr, y, B, H, W, use_sm, pd_prob, sm_prob, pd_coords, sm_coords, losses);
 }
 
 int jcm_window_resize(jcm_handle h, const float* src, int nsrc, int H, int W, int C, const int32_t* windows, int NW,

@@ -664,15 +664,16 @@ int jcm_train_apply(jcm_handle h, const float* grads, int optimizer, float lr, f
   TrainState* t = c->train;
   const bool clip = clip_norm > 0.f;
   HIP_TRY(sum_squares(grads, t->total, t->sumsq, 0, t->red, c->stream));         // tf.clip_by_global_norm (main.py:302-309)
-  t->step += 1;
+  const long step = t->step + 1;          // n_iters advances only once the update has been enqueued (a failed launch must not move the LR schedule)
   const double b1 = 0.9, b2 = 0.999;
-  const float lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow(b2, (double)t->step)) / (1.0 - std::pow(b1, (double)t->step)));
+  const float lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow(b2, (double)step)) / (1.0 - std::pow(b1, (double)step)));
   if (optimizer == JCM_OPT_ADAM)
     HIP_TRY(optimizer_chunks(t->ck_w, t->ck_start, t->ck_off, t->ck_len, t->n_chunks, grads, t->opt_m, t->opt_v, clip ? t->sumsq : nullptr,
                              clip_norm, lr_t, 0.9f, 0.999f, 1e-8f, 0, c->stream));
   else
     HIP_TRY(optimizer_chunks(t->ck_w, t->ck_start, t->ck_off, t->ck_len, t->n_chunks, grads, t->opt_m, t->opt_v, clip ? t->sumsq : nullptr,
                              clip_norm, lr, 0.9f, 0.f, 0.f, 1, c->stream));
+  t->step = step;
   if (grad_norm_out) {
     double ss = 0.0;
     HIP_TRY(hipMemcpyAsync(&ss, t->sumsq, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -688,6 +689,35 @@ int jcm_train_set_grad_callback(jcm_handle h, jcm_grad_ready_fn fn, void* user) 
   JCM_TRY(need_train(h));
   h->train->ready_fn = fn;
   h->train->ready_user = user;
+  return JCM_OK;
+}
+
+// Saver.save / Saver.restore of the optimizer side of the session (main.py:604,612,666 save every global variable: the
+// '<var>/Adam', '<var>/Adam_1' -- or '<var>/Momentum' -- slots, beta1_power / beta2_power and n_iters).  slot 0 = first
+// moment / momentum accumulator, slot 1 = second moment; same flat layout as the gradient buffer.
+int jcm_train_get_state(jcm_handle h, int slot, float* out, int64_t count, int64_t* n_iters) {
+  JCM_TRY(need_train(h));
+  TrainState* t = h->train;
+  if (slot < 0 || slot > 1 || (out && count != (int64_t)t->total)) return fail(JCM_ERR_ARG, "bad train_get_state arguments");
+  DeviceGuard g(h->device);
+  if (out) {
+    HIP_TRY(hipMemcpyAsync(out, slot ? t->opt_v : t->opt_m, t->total * sizeof(float), hipMemcpyDefault, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  if (n_iters) *n_iters = t->step;
+  return JCM_OK;
+}
+
+int jcm_train_set_state(jcm_handle h, int slot, const float* data, int64_t count, int64_t n_iters) {
+  JCM_TRY(need_train(h));
+  TrainState* t = h->train;
+  if (slot < 0 || slot > 1 || (data && count != (int64_t)t->total) || n_iters < 0) return fail(JCM_ERR_ARG, "bad train_set_state arguments");
+  DeviceGuard g(h->device);
+  if (data) {
+    HIP_TRY(hipMemcpyAsync(slot ? t->opt_v : t->opt_m, data, t->total * sizeof(float), hipMemcpyDefault, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));   // the caller may free `data` on return
+  }
+  t->step = (long)n_iters;
   return JCM_OK;
 }
 

@@ -127,9 +127,10 @@ hipError_t sm_softplus5(const float* in, float* out, int64_t n, hipStream_t st);
 // out[p][i] = softplus5(in[p][i]) for P separately allocated tensors of n elements each (one launch for the 81 pairs)
 hipError_t sm_softplus5_multi(const float* const* in, float* out, int P, int64_t n, hipStream_t st);
 // hm [B,5400,C] NHWC -> lik [B][C][5400] planar = softplus5(bn(hm))
-// (channels [0,Ca) from hm [B,5400,Ca], the rest from extra [B,5400,C-Ca]: main.py:528's concat read in place)
+// (channels [0,Ca) from hm [B,5400,Ca], the rest from extra [B,5400,C-Ca]: main.py:528's concat read in place;
+//  extra_ld: floats per pixel of the tensor `extra` points into -- e.g. K+1 when it is channel K of y_in; 0 = C-Ca)
 hipError_t sm_likelihood(const float* hm, int Ca, const float* extra, const float* bn_scale, const float* bn_shift, float* lik,
-                         int B, int C, hipStream_t st);
+                         int B, int C, hipStream_t st, int extra_ld = 0);
 // cpre[b][p][61*91] = valid true convolution of prior p (120x180, already softplus'd) with
 // maps[b][cond[p]] (60x90 planar)           (main.py:83-87)
 hipError_t sm_pair_conv(const float* priors, const float* maps, const int* cond, float* cpre,
@@ -150,7 +151,7 @@ const char* sm_fft_c2r(SmFft* f, float2* in, float* out, int n);
 // frame[b][c] = softplus5(bn(hm[b,:,:,c])) in the top-left 60x90 of a zero 120x180 frame (sc null: raw)
 // (channels [0,Ca) from hm [B,5400,Ca], the rest from extra [B,5400,C-Ca]: main.py:528's concat read in place)
 hipError_t sm_pad_frame(const float* hm, int Ca, const float* extra, const float* sc, const float* sh, float* frame, int B, int C,
-                        hipStream_t st);
+                        hipStream_t st, int extra_ld = 0);
 // spec[b][p] = lhat[b][cond[p]] * phat[p] / (120*180)
 hipError_t sm_spec_mul(const float2* lhat, const float2* phat, const int* cond, float2* spec, int B, int C, int P, hipStream_t st);
 hipError_t sm_finish_fft(const float* frame, const float* cfull, const float* spbias, float* logits, int B, int K, int C, hipStream_t st);
@@ -192,6 +193,7 @@ hipError_t resize_bilinear_bwd(const void* dy, void* dx, bool bf16, int B, int h
 hipError_t softmax_ce(const float* logits, const float* target, int B, int HW, int K, int Kt, float gscale, float* loss, float* dz,
                       int ldz, int accumulate, hipStream_t st);
 hipError_t softmax_bwd(const float* p, const float* g, int B, int HW, int K, int ldg, float* dz, int ldz, hipStream_t st);
+hipError_t loss_means_accumulate(const float* ce, int n, float scale, float* out, bool first, hipStream_t st);
 hipError_t sum_squares(const float* x, size_t n, double* out, int accumulate, double* scratch, hipStream_t st);
 hipError_t adam_update(float* w, const float* g, float* m, float* v, size_t n, const double* sumsq, float clip, float lr_t, float b1,
                        float b2, float eps, hipStream_t st);

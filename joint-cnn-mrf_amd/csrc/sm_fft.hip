@@ -157,7 +157,7 @@ __device__ __forceinline__ float softplus5f(float x) {
 // frame[b][c][120][180]: sp(bn(h[b,y,x,c])) on the top-left 60x90, zero elsewhere (sc == nullptr: raw copy).
 // The C-channel map is read from two tensors -- channels [0,Ca) from hm [B,5400,Ca], the rest from extra
 // [B,5400,C-Ca] -- which is tf.concat([hm, torso], axis=3) of main.py:528 without materialising it.
-__global__ void sm_pad_frame_kernel(const float* __restrict__ hm, int Ca, const float* __restrict__ extra, const float* __restrict__ sc,
+__global__ void sm_pad_frame_kernel(const float* __restrict__ hm, int Ca, const float* __restrict__ extra, int extra_ld, const float* __restrict__ sc,
                                     const float* __restrict__ sh, float* __restrict__ frame, int C, int64_t total) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int x = i % F_W;
@@ -168,17 +168,18 @@ __global__ void sm_pad_frame_kernel(const float* __restrict__ hm, int Ca, const 
     float v = 0.f;
     if (y < FM_H && x < FM_W) {
       const int64_t pix = (b * FM_H + y) * FM_W + x;
-      const float hv = c < Ca ? hm[pix * Ca + c] : extra[pix * (C - Ca) + (c - Ca)];
+      const float hv = c < Ca ? hm[pix * Ca + c] : extra[pix * extra_ld + (c - Ca)];
       v = sc ? softplus5f(hv * sc[c] + sh[c]) : hv;
     }
     frame[i] = v;
   }
 }
 hipError_t sm_pad_frame(const float* hm, int Ca, const float* extra, const float* sc, const float* sh, float* frame, int B, int C,
-                        hipStream_t st) {
+                        hipStream_t st, int extra_ld) {
+  if (extra_ld <= 0) extra_ld = C - Ca;
   const int64_t total = (int64_t)B * C * F_HW;
   int64_t g = (total + 255) / 256;
-  hipLaunchKernelGGL(sm_pad_frame_kernel, dim3((int)(g > 16384 ? 16384 : g)), dim3(256), 0, st, hm, Ca, extra, sc, sh, frame, C, total);
+  hipLaunchKernelGGL(sm_pad_frame_kernel, dim3((int)(g > 16384 ? 16384 : g)), dim3(256), 0, st, hm, Ca, extra, extra_ld, sc, sh, frame, C, total);
   return hipGetLastError();
 }
 

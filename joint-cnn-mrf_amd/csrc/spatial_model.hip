@@ -59,7 +59,7 @@ hipError_t sm_softplus5_multi(const float* const* in, float* out, int P, int64_t
 // lik[b][c] : [60][96] rows reversed along x:  lik[u][t] = sp(bn(h[b,u,89-t,c])) for t<90, 0 beyond;
 // the unary term reads it back as lik[u][89-x].
 // channels [0,Ca) come from hm [B,5400,Ca], the rest from extra [B,5400,C-Ca] (the concat of main.py:528 read in place)
-__global__ void sm_likelihood_kernel(const float* __restrict__ hm, int Ca, const float* __restrict__ extra, const float* __restrict__ sc,
+__global__ void sm_likelihood_kernel(const float* __restrict__ hm, int Ca, const float* __restrict__ extra, int extra_ld, const float* __restrict__ sc,
                                      const float* __restrict__ sh, float* __restrict__ lik, int C, int64_t total) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int t = i % SM_LP;
@@ -70,17 +70,18 @@ __global__ void sm_likelihood_kernel(const float* __restrict__ hm, int Ca, const
     float v = 0.f;
     if (t < SM_W) {
       const int64_t pix = (b * SM_H + u) * SM_W + (SM_W - 1 - t);
-      const float hv = c < Ca ? hm[pix * Ca + c] : extra[pix * (C - Ca) + (c - Ca)];
+      const float hv = c < Ca ? hm[pix * Ca + c] : extra[pix * extra_ld + (c - Ca)];
       v = sc ? softplus5(hv * sc[c] + sh[c]) : hv;   // sc == nullptr: raw reversed copy (jcm_conv_mrf)
     }
     lik[i] = v;
   }
 }
 hipError_t sm_likelihood(const float* hm, int Ca, const float* extra, const float* bn_scale, const float* bn_shift, float* lik, int B, int C,
-                         hipStream_t st) {
+                         hipStream_t st, int extra_ld) {
+  if (extra_ld <= 0) extra_ld = C - Ca;
   const int64_t total = (int64_t)B * C * SM_H * SM_LP;
   int64_t g = (total + 255) / 256;
-  hipLaunchKernelGGL(sm_likelihood_kernel, dim3((int)(g > 8192 ? 8192 : g)), dim3(256), 0, st, hm, Ca, extra, bn_scale, bn_shift, lik, C, total);
+  hipLaunchKernelGGL(sm_likelihood_kernel, dim3((int)(g > 8192 ? 8192 : g)), dim3(256), 0, st, hm, Ca, extra, extra_ld, bn_scale, bn_shift, lik, C, total);
   return hipGetLastError();
 }
 

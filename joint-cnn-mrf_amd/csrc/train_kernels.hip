@@ -361,7 +361,10 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
     const float inv = 1.f / se;
     for (int i = threadIdx.x; i < HW; i += 256) {
       const float p = expf(zb[(size_t)i * K] - m) * inv;
-      const float g = gscale * (p * st - tb[(size_t)i * Kt]);
+      // TF-1.x's softmax_cross_entropy_with_logits kernel emits backprop = softmax - labels (the registered gradient
+      // multiplies it by the upstream gradient): NOT the exact derivative p * sum(t) - t when a target map does not sum to
+      // one (FLIC blobs clipped by the map border, data.py:171-183).  The reference trains with TF's, so does this.
+      const float g = gscale * (p - tb[(size_t)i * Kt]);
       db[(size_t)i * ldz] = accumulate ? db[(size_t)i * ldz] + g : g;
     }
   }
@@ -369,6 +372,18 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
 hipError_t softmax_ce(const float* logits, const float* target, int B, int HW, int K, int Kt, float gscale, float* loss, float* dz,
                       int ldz, int accumulate, hipStream_t st) {
   hipLaunchKernelGGL(softmax_ce_kernel, dim3(B * K), dim3(256), 0, st, logits, target, HW, K, Kt, gscale, loss, dz, ldz, accumulate);
+  return hipGetLastError();
+}
+
+// out[0] (+)= scale * sum(ce[0:n]), out[1] (+)= scale * sum(ce[n:2n])   (the two loss means of eval_error, main.py:275-283)
+__global__ void loss_means_kernel(const float* __restrict__ ce, int n, float scale, float* __restrict__ out, int first) {
+  if (threadIdx.x >= 2 || blockIdx.x) return;
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += ce[threadIdx.x * n + i];
+  out[threadIdx.x] = (first ? 0.f : out[threadIdx.x]) + (float)(s * scale);
+}
+hipError_t loss_means_accumulate(const float* ce, int n, float scale, float* out, bool first, hipStream_t st) {
+  hipLaunchKernelGGL(loss_means_kernel, dim3(1), dim3(64), 0, st, ce, n, scale, out, first ? 1 : 0);
   return hipGetLastError();
 }
 

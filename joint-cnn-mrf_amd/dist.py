@@ -74,3 +74,85 @@ def average_gradients(flat_grads, group=None, stream=None):
         if world > 1:
             flat_grads.div_(world)
     return flat_grads
+
+
+class RcclComm:
+    """A libjcm RCCL communicator (include/jcm.h: jcm_comm_*): the C-ABI route of the coordinate all-gather, for hosts that
+    do not want torch.distributed on the data path.  The 128-byte rendezvous id travels through the torch.distributed
+    store (any backend) once; afterwards `allgather_coords` is a single ncclAllGather on the engine's stream."""
+
+    def __init__(self, engine, group=None):
+        import ctypes
+        from . import _lib
+        self._lib, self._eng = _lib.load(), engine
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        ident = ctypes.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(self._lib.jcm_comm_unique_id(ident), 'jcm_comm_unique_id')
+        if world > 1:
+            box = [ident.raw]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = ctypes.create_string_buffer(box[0], 128)
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.jcm_comm_create(ident, world, rank, engine.device.index, ctypes.byref(h)), 'jcm_comm_create')
+        self._h, self.world, self.rank = h, world, rank
+
+    def allgather_coords(self, local_coords):
+        """[B_local,2,K] int32 on the engine's device -> [world*B_local,2,K], rank-major (main.py:573-574)."""
+        import ctypes
+        from . import _lib
+        if local_coords.dtype != torch.int32 or local_coords.device != self._eng.device or not local_coords.is_contiguous():
+            raise TypeError('coords must be a contiguous int32 tensor on %s' % self._eng.device)
+        out = torch.empty((self.world * local_coords.shape[0],) + tuple(local_coords.shape[1:]), dtype=torch.int32, device=local_coords.device)
+        _lib.check(self._lib.jcm_allgather_coords(self._eng._h, self._h, ctypes.c_void_p(local_coords.data_ptr()), local_coords.shape[0],
+                                                  ctypes.c_void_p(out.data_ptr())), 'jcm_allgather_coords')
+        return out
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            self._lib.jcm_comm_destroy(self._h)
+            self._h.value = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Towers:
+    """The reference's in-process towers (main.py:509-517,573-574): `--gpus i j k` builds one tower per listed device inside
+    ONE process, slices the batch into batch_size // n_gpus contiguous pieces and concatenates the per-tower results.
+    Here a tower is an Engine (its own replica of the parameters) on its device; the launches of all towers are enqueued
+    before any result is read, so the devices run concurrently.  (A device may be listed twice: two towers share it.)"""
+
+    def __init__(self, params, gpus, **engine_kw):
+        from .engine import Engine
+        if not gpus:
+            raise ValueError('--gpus needs at least one device index')
+        self.gpus = [int(g) for g in gpus]
+        self.engines = [Engine(device=g, **engine_kw).load_params(params) for g in self.gpus]
+
+    @property
+    def n(self):
+        return len(self.engines)
+
+    def slices(self, batch_size):
+        return [shard_bounds(batch_size, self.n, i) for i in range(self.n)]           # main.py:511,516-517
+
+    def forward(self, x, torso, use_sm=True, want_prob=False):
+        """x [B,480,720,3], torso [B,60,90,1] (host or any device) -> dict of tensors on the FIRST tower's device,
+        concatenated in tower order (= tf.concat axis 0); a remainder B % n_gpus is dropped as in the reference."""
+        outs = []
+        for eng, (lo, hi) in zip(self.engines, self.slices(x.shape[0])):
+            xs = torch.as_tensor(x[lo:hi]).to(eng.device, non_blocking=True).contiguous()
+            ts = torch.as_tensor(torso[lo:hi]).to(eng.device, non_blocking=True).contiguous() if use_sm else None
+            with torch.cuda.device(eng.device):
+                outs.append(eng.forward(xs, ts, use_sm=use_sm, want_prob=want_prob))
+        dev0 = self.engines[0].device
+        return {k: torch.cat([o[k].to(dev0) for o in outs], dim=0) for k in outs[0]}
+
+    def close(self):
+        for e in self.engines:
+            e.close()

@@ -78,6 +78,13 @@ class Engine:
             self.finalize()
         return self
 
+    def update_tensor(self, name, value, refresh=True):
+        """Overwrite a stored parameter after finalize (Saver.restore on a live session, main.py:612); refresh rebuilds
+        the derived tables (pass False on all but the last tensor of a batch of updates)."""
+        a = np.ascontiguousarray(value, dtype=np.float32)
+        _lib.check(self._lib.jcm_update_tensor(self._h, name.encode(), ctypes.c_void_p(a.ctypes.data), a.size, int(bool(refresh))),
+                   'jcm_update_tensor(%s)' % name)
+
     def finalize(self):
         _lib.check(self._lib.jcm_finalize(self._h), 'jcm_finalize')
         self._finalized = True
@@ -211,6 +218,28 @@ class Engine:
         _lib.check(self._lib.jcm_forward(self._h, self._p(x), self._p(torso if use_sm else None), B, H, W, int(bool(use_sm)),
                                          self._p(r.get('pd_prob')), self._p(r.get('sm_prob')),
                                          self._p(r['pd_coords']), self._p(r.get('sm_coords'))), 'jcm_forward')
+        return r
+
+    def eval_forward(self, x, y, use_sm=True, want_prob=True):
+        """The tower in inference mode plus the two cross-entropy losses of the graph (main.py:538-539), as eval_error
+        runs it per batch (main.py:275-283).  y = y_in [B,60,90,K+1]: targets + torso channel.  Returns the dict of
+        forward() plus 'losses' (device fp32 [2]: loss_pd, loss_sm)."""
+        self._chk(x, 4, 'x')
+        self._chk(y, 4, 'y')
+        B, H, W, C = x.shape
+        hh, ww, K = _hm_size(H), _hm_size(W), self.n_joints
+        if C != 3 or tuple(y.shape) != (B, hh, ww, K + 1):
+            raise ValueError('x must be [B,H,W,3] and y [B,%d,%d,%d]; got %s, %s' % (hh, ww, K + 1, tuple(x.shape), tuple(y.shape)))
+        r = {'pd_coords': self._new(B, 2, K, dtype=torch.int32), 'losses': self._new(2)}
+        if want_prob:
+            r['pd_prob'] = self._new(B, hh, ww, K)
+        if use_sm:
+            r['sm_coords'] = self._new(B, 2, K, dtype=torch.int32)
+            if want_prob:
+                r['sm_prob'] = self._new(B, hh, ww, K)
+        _lib.check(self._lib.jcm_eval_forward(self._h, self._p(x), self._p(y), B, H, W, int(bool(use_sm)),
+                                              self._p(r.get('pd_prob')), self._p(r.get('sm_prob')), self._p(r['pd_coords']),
+                                              self._p(r.get('sm_coords')), self._p(r['losses'])), 'jcm_eval_forward')
         return r
 
     def window_resize(self, src, windows, oh, ow):

@@ -10,12 +10,14 @@ Where the reference reads module globals (`hps`, `flag_train`, `pairwise_energie
 this module keeps the same names; they are filled by `configure()` instead of at import
 (the reference parses argv and loads `.npy` files at import time, main.py:440,459).
 
-CLI: `python -m joint_cnn_mrf_amd.main --gpus 0 --use_sm --batch_size 64 [--debug]` runs the
-inference tower on synthetic data; `--train` runs the reference's epoch loop (main.py:620-667) on a
-synthetic data set through `train.Trainer`.
+CLI (the reference's flags, main.py:428-439): `python -m joint_cnn_mrf_amd.main --gpus 0 1 --use_sm --batch_size 64`
+evaluates the test split (single scale sharded over the listed devices, or `--multiscale`); `--train` runs the
+reference's epoch loop (main.py:620-667) with one tower per device, eval_error after every epoch and tf.train.Saver
+checkpoints; `--restore --restore_path P` resumes from one.  Data: the .npy files data.py prepares, or `--synthetic`.
 """
 import argparse
 import json
+import os
 import time
 
 import numpy as np
@@ -42,7 +44,9 @@ _engine = None
 
 
 def build_parser():
-    """The reference's flags (main.py:428-439); training-only ones are accepted and ignored."""
+    """The reference's eleven flags (main.py:428-439), same names, types and defaults (but --gpus, whose reference default
+    [6] names a device of the authors' server), plus what the reference hard-codes in module globals: where the data and
+    the checkpoints live, and an explicit switch for generated data."""
     parser = argparse.ArgumentParser(description='Define hyperparameters.')
     parser.add_argument('--debug', action='store_true', help='True if we want to debug.')
     parser.add_argument('--train', action='store_true', help='True if we want to train the model.')
@@ -55,6 +59,16 @@ def build_parser():
     parser.add_argument('--optimizer', type=str, default='adam', help='momentum or adam')
     parser.add_argument('--lr', type=float, default=0.001, help='Learning rate.')
     parser.add_argument('--lmbd', type=float, default=0.001, help='Regularization coefficient.')
+    # not in the reference (module globals / hard-coded paths there)
+    parser.add_argument('--data_dir', default='.', help='directory of x_*_flic.npy, y_*_flic.npy, pairwise_distribution.pickle (main.py:290-298).')
+    parser.add_argument('--synthetic', action='store_true', help='generated images / targets / priors instead of the FLIC files.')
+    parser.add_argument('--synthetic_size', type=int, default=56, help='number of generated training examples with --synthetic.')
+    parser.add_argument('--model_path', default=model_path, help='checkpoint directory (main.py:444).')
+    parser.add_argument('--restore_path', default=None, help='checkpoint prefix (tf.train.Saver files) or .npz for --restore (main.py:443,612).')
+    parser.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'], help='arithmetic of the kernels.')
+    parser.add_argument('--multiscale', action='store_true', help='evaluation run: 8-scale test-time evaluation (get_predictions, main.py:382-425).')
+    parser.add_argument('--predictions', default=None, help='evaluation run: write flic_pred_pd / flic_pred_sm to this .mat file (main.py:675).')
+    parser.add_argument('--seed', type=int, default=0, help='shuffling seed.')
     return parser
 
 
@@ -201,72 +215,204 @@ def get_predictions(X_np, Y_np, sess=None):
     return multiscale.get_predictions(engine(), X_np, Y_np, use_sm=hps.use_sm)
 
 
-def train_main(args):
-    """`--train` (main.py:620-667): n_epochs over a synthetic data set of 4 batches; prints the reference's
-    per-epoch line.  Losses are the training-mode losses of the last batch of the epoch; detection rates
-    are evaluated in inference mode (flag_train=False) on the first batch."""
-    from . import evaluation
-    from .train import Trainer
-    dev_id = args.gpus[0]
-    torch.cuda.set_device(dev_id)
+# ------------------------------------------------------------------ data set, session files (main.py:286-299,604-612,666)
+DATASET_FILES = ('x_train_flic.npy', 'y_train_flic.npy', 'x_test_flic.npy', 'y_test_flic.npy')     # main.py:290-293, written by data.py
+model_path = 'models_ex'                                                                            # main.py:444
+
+
+def get_dataset(data_dir='.'):
+    """main.py:286-294: the four arrays data.py prepares (x [N,480,720,3] fp32 in [0,1], y [N,60,90,10])."""
+    missing = [f for f in DATASET_FILES if not os.path.exists(os.path.join(data_dir, f))]
+    if missing:
+        raise FileNotFoundError('%s not found in %r: run `python -m joint_cnn_mrf_amd.data` on the FLIC frames first (the reference\'s '
+                                'data.py step), or pass --synthetic for generated data' % (', '.join(missing), data_dir))
+    return tuple(np.load(os.path.join(data_dir, f), mmap_mode='r') for f in DATASET_FILES)
+
+
+def get_pairwise_distr(data_dir='.'):
+    """main.py:297-299: the pickle prepare_pairwise_distribution.py writes ({'<j>_<c>': [120,180] float64})."""
+    import pickle
+    with open(os.path.join(data_dir, 'pairwise_distribution.pickle'), 'rb') as handle:
+        return pickle.load(handle)
+
+
+def _synthetic_dataset(n_train, n_test):
+    return (synth.make_images(n_train, seed=100), synth.make_targets(n_train, seed=200),
+            synth.make_images(n_test, seed=300), synth.make_targets(n_test, seed=400))
+
+
+def initial_params(args, pairwise_distr):
+    """tf.global_variables_initializer on the graph of main.py:474-487: He-initialised convolutions, identity BatchNorm,
+    energies = the pairwise distributions, biases = 1e-5."""
     params = synth.make_pd_params(debug=args.debug)
     if args.use_sm:
-        params.update(synth.make_sm_params(synth.synthetic_priors(), kind='init'))
-    eng = configure(params, device=dev_id, debug=args.debug)
-    B = args.batch_size
-    n_train = 4 * B
-    n_updates_total = args.n_epochs * n_train // B                      # main.py:466
-    tr = Trainer(eng, optimizer=args.optimizer, lr=args.lr, lmbd=args.lmbd, use_sm=args.use_sm, n_updates_total=n_updates_total)
-    X = [torch.as_tensor(synth.make_images(B, seed=100 + i), device=eng.device) for i in range(n_train // B)]
-    Y = [torch.as_tensor(synth.make_targets(B, seed=200 + i), device=eng.device) for i in range(n_train // B)]
-    joints_to_eval, det_radius = [2], 10                                # main.py:455-456
+        params.update(synth.make_sm_params(pairwise_distr, kind='init'))
+    return params
+
+
+def restore_params(path, args):
+    """saver.restore (main.py:612): `path` is a tf.train.Saver checkpoint prefix (P.index + P.data-00000-of-00001, read by
+    tf_checkpoint.py) or an .npz keyed by the same variable names.  Returns every saved variable, optimizer slots included."""
+    from . import checkpoint, tf_checkpoint
+    if path.endswith('.npz'):
+        with np.load(path) as z:
+            state = {k: z[k] for k in z.files}
+    else:
+        state = tf_checkpoint.load_checkpoint(path)
+    checkpoint.validate({k: v for k, v in state.items() if k in checkpoint.expected_shapes(args.debug, args.use_sm)}, args.debug, args.use_sm)
+    return state
+
+
+class TowerTrainer:
+    """The training side of the in-process towers (main.py:509-577): every listed device runs compute_gradients on its
+    slice of the batch, the tower gradients are averaged (average_gradients, main.py:243-267: here a sum on the first
+    device divided by the tower count) and the same clipped update is applied to every replica.  The BatchNorm moving
+    statistics are shared variables in the reference and the towers' update ops (main.py:557) run on them one after the
+    other, tower 0 first: moving <- 0.9 * moving + 0.1 * stat_i for i = 0, 1, ...  Each replica here did that once from the
+    common start, so the composition is rebuilt from the per-replica results and written to every replica."""
+    BN_DECAY = 0.9          # decay=0.9 of the reference's tf.contrib.layers.batch_norm calls (main.py:113,129)
+
+    def __init__(self, towers, params, **trainer_kw):
+        from .train import Trainer
+        self.towers = towers
+        self.trainers = [Trainer(e, **trainer_kw) for e in towers.engines]
+        self.moving = {k: np.asarray(v, np.float32).reshape(-1).copy() for k, v in params.items()
+                       if k.endswith('moving_mean') or k.endswith('moving_variance')}
+
+    def train_step(self, x, y):
+        tw = self.towers
+        for tr, eng, (lo, hi) in zip(self.trainers, tw.engines, tw.slices(x.shape[0])):
+            xs = torch.as_tensor(x[lo:hi]).to(eng.device, non_blocking=True).contiguous()
+            ys = torch.as_tensor(y[lo:hi]).to(eng.device, non_blocking=True).contiguous()
+            with torch.cuda.device(eng.device):
+                tr.loss_and_grads(xs, ys)
+        dev0 = tw.engines[0].device
+        if tw.n > 1:
+            total = self.trainers[0].grads
+            for tr in self.trainers[1:]:
+                total += tr.grads.to(dev0)
+            total /= tw.n
+            for tr in self.trainers[1:]:
+                tr.grads.copy_(total)
+        for tr, eng in zip(self.trainers, tw.engines):
+            with torch.cuda.device(eng.device):
+                tr.apply()
+        names = sorted(self.moving)
+        for i, name in enumerate(names):
+            start = self.moving[name]
+            if tw.n == 1:
+                self.moving[name] = self.trainers[0].get_tensor(name, start.shape)
+                continue
+            cur = start.astype(np.float64)
+            for tr in self.trainers:                               # r_i = d * start + (1 - d) * stat_i  ->  cur = d * cur + (r_i - d * start)
+                cur = self.BN_DECAY * cur + (tr.get_tensor(name, start.shape).astype(np.float64) - self.BN_DECAY * start)
+            self.moving[name] = cur.astype(np.float32)
+            for eng in tw.engines:
+                eng.update_tensor(name, self.moving[name], refresh=i == len(names) - 1)
+        return self.trainers[0].losses
+
+
+def train_main(args):
+    """`--train` (main.py:620-667): the reference's epoch loop -- shuffled whole batches (get_next_batch), eval_error on
+    the first n_eval_ex train / test examples after every epoch, the reference's progress line, a checkpoint per epoch once
+    half of the epochs are done (tf.train.Saver format) -- on one tower per device of --gpus."""
+    from . import checkpoint, evaluation, tf_checkpoint
+    from .dist import Towers
+    from .train import Trainer
+    if args.data_augm:
+        raise NotImplementedError('--data_augm: the augmentation pipeline (augmentation.py: flips, rotations, crops on the TF input '
+                                  'queue) is outside the hot path this build covers; train without it')
+    t_start = time.time()
+    if args.synthetic:
+        x_train, y_train, x_test, y_test = _synthetic_dataset(args.synthetic_size, max(args.batch_size, args.synthetic_size // 2))
+        pairwise = synth.synthetic_priors()
+    else:
+        x_train, y_train, x_test, y_test = get_dataset(args.data_dir)
+        pairwise = get_pairwise_distr(args.data_dir)
+    n_train, n_test = x_train.shape[0], x_test.shape[0]
+    rng = np.random.RandomState(args.seed)
+    n_eval_ex = 512 if args.debug else 1100                              # main.py:453
+    if args.debug and not args.synthetic:                                # main.py:459-462
+        n_train, n_test = min(1024, n_train), min(512, n_test)
+        tr_idx, te_idx = np.sort(rng.permutation(x_train.shape[0])[:n_train]), np.sort(rng.permutation(x_test.shape[0])[:n_test])
+        x_train, y_train, x_test, y_test = x_train[tr_idx], y_train[tr_idx], x_test[te_idx], y_test[te_idx]
+    n_updates_total = args.n_epochs * n_train // args.batch_size        # main.py:466
+    state = restore_params(args.restore_path, args) if args.restore else None
+    params = {k: v for k, v in state.items() if k in checkpoint.expected_shapes(args.debug, args.use_sm)} if state else initial_params(args, pairwise)
+    towers = Towers(params, args.gpus, precision=args.precision)
+    tt = TowerTrainer(towers, params, optimizer=args.optimizer, lr=args.lr, lmbd=args.lmbd, use_sm=args.use_sm, n_updates_total=n_updates_total)
+    if state:
+        for tr in tt.trainers:
+            checkpoint.restore_session_state(tr, state)
+    eng = towers.engines[0]
+    model_name = '{}_lr={}_lambda={}_bs={}'.format(time.strftime('%Y-%m-%d %H:%M:%S'), args.lr, args.lmbd, args.batch_size)     # main.py:447
+    joints_to_eval, det_radius = [2], 10                                 # main.py:455-456
+
+    def report(epoch):
+        tr_e = evaluation.eval_error(x_train[:n_eval_ex], y_train[:n_eval_ex], eng, args.batch_size, args.use_sm, joints_to_eval, det_radius)
+        te_e = evaluation.eval_error(x_test[:n_eval_ex], y_test[:n_eval_ex], eng, args.batch_size, args.use_sm, joints_to_eval, det_radius)
+        print('Epoch {:d}  test_dr {:.3f} {:.3f}  train_dr {:.3f} {:.3f}  test_mse {:.5f} {:.5f}  train_mse {:.5f} {:.5f}'.format(
+            epoch, te_e[2], te_e[3], tr_e[2], tr_e[3], te_e[0], te_e[1], tr_e[0], tr_e[1]), flush=True)      # main.py:628-631,656-657
+
+    report(0)
     for epoch in range(1, args.n_epochs + 1):
-        t0 = time.time()
-        for xb, yb in zip(X, Y):
-            losses, _ = tr.train_step(xb, yb)
-        l = losses.cpu().numpy()
-        r = eng.forward(X[0], Y[0][..., n_joints:].contiguous(), use_sm=args.use_sm)
-        tgt = Y[0][..., :n_joints].contiguous()
-        dr_pd = evaluation.det_rate(r['pd_prob'], tgt, det_radius, joints_to_eval, engine=eng)
-        dr_sm = evaluation.det_rate(r['sm_prob'] if args.use_sm else r['pd_prob'], tgt, det_radius, joints_to_eval, engine=eng)
-        print('Epoch {:d}  train_dr {:.3f} {:.3f}  train_loss {:.5f} {:.5f}  total {:.5f}  lr {:g}  {:.1f} img/s'.format(
-            epoch, dr_pd, dr_sm, l[1], l[2], l[0], piecewise(tr), n_train / (time.time() - t0)))
-    return tr
-
-
-def piecewise(tr):
-    from .train import piecewise_lr
-    return piecewise_lr(tr.n_iters, tr.n_updates_total, tr.lr)
+        for bx, by in evaluation.get_next_batch(x_train, y_train, args.batch_size, shuffle=True, rng=rng):      # main.py:641
+            tt.train_step(np.ascontiguousarray(bx, np.float32), np.ascontiguousarray(by, np.float32))
+        report(epoch)
+        if epoch > args.n_epochs // 2:                                   # main.py:663-666
+            tf_checkpoint.save_checkpoint('{}/{}-{}'.format(args.model_path, model_name, epoch), checkpoint.session_state(tt.trainers[0], params))
+    print('Done in {:.2f} min\n\n'.format((time.time() - t_start) / 60))
+    return tt
 
 
 def main(argv=None):
     global hps
     args = build_parser().parse_args(argv)
+    hps = args
+    if args.restore and not args.restore_path:
+        raise SystemExit('--restore needs --restore_path <checkpoint prefix or .npz> (the reference hard-codes best_model_name, main.py:443)')
+    for g in args.gpus:
+        if g < 0 or g >= torch.cuda.device_count():
+            raise SystemExit('--gpus %s: device %d does not exist (%d visible)' % (args.gpus, g, torch.cuda.device_count()))
     if args.train:
-        hps = args
         train_main(args)
         return
-    if args.restore:
-        raise SystemExit('--restore: no TF checkpoint ships with the reference; parameters are synthetic here')
-    hps = args
-    dev = args.gpus[0]
-    torch.cuda.set_device(dev)
-    params = synth.make_pd_params(debug=args.debug)
-    if args.use_sm:
-        params.update(synth.make_sm_params(synth.synthetic_priors(), kind='init'))
-    eng = configure(params, device=dev, debug=args.debug)
-    B = args.batch_size
-    x = torch.as_tensor(synth.make_images(B), device=eng.device)
-    torso = torch.as_tensor(synth.make_torso(B), device=eng.device)
-    eng.forward(x, torso, use_sm=args.use_sm, want_prob=False)
-    torch.cuda.synchronize()
+    # evaluation run (main.py:668-675): multi-scale predictions of the test set -> matlab/predictions.mat
+    from . import checkpoint
+    from .dist import Towers
+    if args.synthetic:
+        _xt, _yt, x_test, y_test = _synthetic_dataset(args.batch_size, args.synthetic_size)
+        pairwise = synth.synthetic_priors()
+    else:
+        _xt, _yt, x_test, y_test = get_dataset(args.data_dir)
+        pairwise = get_pairwise_distr(args.data_dir)
+    state = restore_params(args.restore_path, args) if args.restore else None
+    params = {k: v for k, v in state.items() if k in checkpoint.expected_shapes(args.debug, args.use_sm)} if state else initial_params(args, pairwise)
+    towers = Towers(params, args.gpus, precision=args.precision)
+    configure(params, device=args.gpus[0], precision=args.precision, debug=args.debug)
     t0 = time.time()
-    r = eng.forward(x, torso, use_sm=args.use_sm, want_prob=False)
+    if args.multiscale:
+        pred_pd, pred_sm = get_predictions(np.asarray(x_test), np.asarray(y_test))                     # main.py:674
+    else:                                                                                              # single scale, sharded over the towers
+        B = args.batch_size
+        pd, sm = [], []
+        for lo in range(0, (x_test.shape[0] // B) * B, B):
+            r = towers.forward(np.ascontiguousarray(x_test[lo:lo + B], np.float32), np.ascontiguousarray(y_test[lo:lo + B, :, :, n_joints:], np.float32),
+                               use_sm=args.use_sm)
+            pd.append(r['pd_coords'])
+            sm.append(r['sm_coords'] if args.use_sm else r['pd_coords'])
+        to_ref = lambda c: torch.cat(c).permute(1, 2, 0).cpu().numpy()      # [2,K,N] (row, col) stacked on the last axis, main.py:425
+        pred_pd, pred_sm = to_ref(pd), to_ref(sm)
     torch.cuda.synchronize()
     dt = time.time() - t0
-    key = 'sm_coords' if args.use_sm else 'pd_coords'
-    print(json.dumps({'batch_size': B, 'use_sm': bool(args.use_sm), 'debug': bool(args.debug), 'seconds': dt,
-                      'images_per_sec': B / dt, 'coords_image0': r[key][0].cpu().numpy().tolist()}))
+    if args.predictions:
+        import scipy.io
+        os.makedirs(os.path.dirname(args.predictions) or '.', exist_ok=True)
+        scipy.io.savemat(args.predictions, {'flic_pred_pd': pred_pd, 'flic_pred_sm': pred_sm})         # main.py:675
+    print(json.dumps({'n_images': int(pred_pd.shape[2]), 'gpus': args.gpus, 'use_sm': bool(args.use_sm), 'debug': bool(args.debug),
+                      'multiscale': bool(args.multiscale), 'seconds': dt, 'images_per_sec': pred_pd.shape[2] / dt,
+                      'coords_image0_pd': pred_pd[:, :, 0].tolist()}))
+    towers.close()
 
 
 if __name__ == '__main__':

@@ -108,11 +108,29 @@ def spatial_model_train(hm10_nchw, p, stats, n_joints=N_JOINTS):
     return torch.stack(out, dim=1)
 
 
+class _TfSoftmaxCE(torch.autograd.Function):
+    """tf.nn.softmax_cross_entropy_with_logits as TF-1.x computes it: loss = -sum(labels * log_softmax(logits)); the
+    gradient w.r.t. the logits that the op's kernel emits ("backprop") is softmax - labels, multiplied by the upstream
+    gradient (tensorflow/python/ops/nn_grad.py: _SoftmaxCrossEntropyWithLogitsGrad).  That is the exact derivative only
+    when the labels of a row sum to one; FLIC target blobs clipped by the map border (data.py:171-183) do not, and the
+    reference trains with TF's gradient -- so the restatement must, too.  No gradient flows to the labels (constants)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):            # [..., n] over the last axis
+        ls = torch.log_softmax(logits, dim=-1)
+        ctx.save_for_backward(ls, labels)
+        return -(labels * ls).sum(dim=-1)
+
+    @staticmethod
+    def backward(ctx, g):
+        ls, labels = ctx.saved_tensors
+        return g.unsqueeze(-1) * (ls.exp() - labels), None
+
+
 def softmax_cross_entropy(logits_nchw, target_nchw):
-    """main.py:220-240: softmax over the pixels, soft labels, mean over (image, joint)."""
+    """main.py:220-240: softmax over the pixels, soft labels, mean over (image, joint); TF's gradient (see _TfSoftmaxCE)."""
     B, K = logits_nchw.shape[:2]
-    ls = torch.log_softmax(logits_nchw.reshape(B, K, -1), dim=2)
-    return -(target_nchw.reshape(B, K, -1) * ls).sum(dim=2).mean()
+    return _TfSoftmaxCE.apply(logits_nchw.reshape(B, K, -1), target_nchw.reshape(B, K, -1)).mean()
 
 
 def weight_decay(p):

@@ -1,5 +1,7 @@
 """Parameter-file format (TF variable naming) and Hypothesis property tests between the two
 oracle formulations on small random shapes."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -117,3 +119,76 @@ def test_piecewise_learning_rate_schedule():
             assert piecewise_lr(n, total, lr) == ref(n, total, lr)
     assert piecewise_lr(0, 100, 1.0) == 1.0 and piecewise_lr(70, 100, 1.0) == 1.0 and piecewise_lr(71, 100, 1.0) == 0.5
     assert piecewise_lr(81, 100, 1.0) == 0.2 and piecewise_lr(91, 100, 1.0) == 0.1 and piecewise_lr(1000, 100, 1.0) == 0.1
+
+
+# ---------------------------------------------------------------------------------------------------- tf.train.Saver files
+def test_crc32c_known_answers():
+    """RFC 3720 B.4 vectors + the leveldb mask (crc32c::Mask / Unmask)."""
+    from joint_cnn_mrf_amd import tf_checkpoint as C
+    assert C.crc32c(bytes(32)) == 0x8a9136aa
+    assert C.crc32c(b'\xff' * 32) == 0x62a8ab43
+    assert C.crc32c(bytes(range(32))) == 0x46dd794e
+    assert C.crc32c(b'123456789') == 0xe3069283
+    big = np.random.RandomState(0).bytes(70001)             # long enough for the libjcm (hardware) route
+    c = 0
+    for b in big:                                           # byte-at-a-time table reference
+        c = C.crc32c(bytes([b]), c)
+    assert C.crc32c(big) == c == C.crc32c(big[30000:], C.crc32c(big[:30000]))
+    assert C.unmask_crc(C.mask_crc(0xdeadbeef)) == 0xdeadbeef and C.mask_crc(0xdeadbeef) != 0xdeadbeef
+
+
+def test_tf_checkpoint_v2_round_trip(tmp_path):
+    """Writer and reader of the tf.train.Saver checkpoint-V2 files (main.py:604,612,666) against each other: model
+    variables under the reference's names, Adam slots, scalars (n_iters int32, beta powers), enough variables for several
+    restart groups, a block size small enough for several data blocks."""
+    from joint_cnn_mrf_amd import synth
+    from joint_cnn_mrf_amd import tf_checkpoint as C
+    p = synth.make_pd_params(debug=True, bn='trained')
+    p.update(synth.make_sm_params(synth.synthetic_priors(), kind='trained'))
+    state = dict(p)
+    state['conv5/weights/Adam'] = np.full_like(p['conv5/weights'], 0.25)
+    state['conv5/weights/Adam_1'] = np.full_like(p['conv5/weights'], 1e-9)
+    state['beta1_power'], state['beta2_power'], state['n_iters'] = np.float32(0.9 ** 5), np.float32(0.999 ** 5), np.int32(5)
+    prefix = str(tmp_path / 'models_ex' / 'run_lr=0.001-17')
+    C.save_checkpoint(prefix, state)
+    assert sorted(f.name for f in (tmp_path / 'models_ex').iterdir()) == ['run_lr=0.001-17.data-00000-of-00001', 'run_lr=0.001-17.index']
+    back = C.load_checkpoint(prefix)
+    assert set(back) == set(state)
+    for k, v in state.items():
+        assert back[k].shape == np.shape(v) and back[k].dtype == np.asarray(v).dtype, k
+        np.testing.assert_array_equal(back[k], v, err_msg=k)
+    assert back['n_iters'].dtype == np.int32 and back['n_iters'].shape == ()
+    listed = {n: (s, d) for n, s, d in C.list_variables(prefix)}
+    assert listed['conv6/weights'] == ((9, 9, 128, 9), np.dtype('float32')) and listed['energy_lsho_lelb'][0] == (1, 120, 180, 1)
+    # data file: tensors back to back in key order
+    assert os.path.getsize(prefix + '.data-00000-of-00001') == sum(np.asarray(v).nbytes for v in state.values())
+    # table structure: magic number at the end, header entry first, keys sorted, several data blocks with a tiny block size
+    small = str(tmp_path / 'small.index')
+    items = [(('k%04d' % i).encode(), bytes([i % 256]) * (i % 37)) for i in range(500)]
+    C.write_table(small, items, block_size=256)
+    assert C.read_table(small) == items
+    raw = open(small, 'rb').read()
+    assert raw[-8:] == bytes.fromhex('57fb808b247547db')            # kTableMagicNumber 0xdb4775248b80fb57, little endian
+    assert C.read_table(prefix + '.index')[0] == (b'', b'\x08\x01\x1a\x02\x08\x01')   # num_shards 1, version.producer 1
+    # corruption is detected: flip one byte of a tensor / of a table block
+    with open(prefix + '.data-00000-of-00001', 'r+b') as fh:
+        fh.seek(100)
+        b0 = fh.read(1)
+        fh.seek(100)
+        fh.write(bytes([b0[0] ^ 1]))
+    with pytest.raises(ValueError, match='CRC-32C'):
+        C.load_checkpoint(prefix)
+    bad = bytearray(raw)
+    bad[10] ^= 0x40
+    open(small, 'wb').write(bytes(bad))
+    with pytest.raises(ValueError, match='checksum'):
+        C.read_table(small)
+
+
+def test_snappy_blocks_are_readable():
+    """Tables written with the leveldb default (snappy, block type 1) must be readable too: hand-assembled stream with a
+    literal and the three copy forms."""
+    from joint_cnn_mrf_amd import tf_checkpoint as C
+    #  length 18 | literal "abcd" | copy1 off 4 len 4 | copy2 off 8 len 6 | literal "xyzw"
+    stream = bytes([18]) + bytes([(4 - 1) << 2]) + b'abcd' + bytes([((4 - 4) << 2) | 1 | (0 << 5), 4]) + bytes([((6 - 1) << 2) | 2, 8, 0]) + bytes([(4 - 1) << 2]) + b'xyzw'
+    assert C._snappy_uncompress(stream) == b'abcdabcdabcdabxyzw'

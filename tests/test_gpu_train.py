@@ -172,17 +172,6 @@ def test_det_rate_matches_restatement():
     eng.close()
 
 
-def test_train_cli_debug():
-    """`main.py --train` (main.py:620-667) end to end at --debug size."""
-    import subprocess, sys, os
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, '-m', 'joint_cnn_mrf_amd.main', '--train', '--debug', '--use_sm', '--n_epochs', '2',
-                          '--batch_size', '2', '--gpus', '0'], cwd=root, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith('Epoch')]
-    assert len(lines) == 2 and 'train_loss' in lines[0], out.stdout
-
-
 @pytest.mark.parametrize('f32_conv', ['exact', 'split', 'split16'])
 def test_full_size_step_vs_golden(f32_conv):
     """The full-size network (filters 64..512), one 480x720 image: losses, sampled gradient entries, gradient
@@ -315,3 +304,62 @@ def test_gradient_ready_notifications_cover_every_tensor_once(debug_case, use_sm
         assert names_left and all(n.startswith(('bias_', 'bn_sm', 'energy_')) for n in names_left)
     order = [starts[o][0].split('/')[0] for o, _ in seen if not starts[o][0].startswith(('bias_', 'bn_sm', 'energy_'))]
     assert order[0] == 'conv6' and order[1] == 'conv5' and order[-1] == 'conv1_quarterres'
+
+
+def test_border_clipped_targets_follow_tf_gradient(debug_case):
+    """Targets whose blob is cut by the map border do not sum to one (data.py:171-183).  TF-1.x's
+    softmax_cross_entropy_with_logits back-propagates softmax - labels there, NOT the exact derivative
+    softmax * sum(labels) - labels; the reference trains with TF's, and so must the kernels (the two differ by the
+    missing mass: 7/16 for a corner blob)."""
+    p, x, y = debug_case
+    y2 = y.copy()
+    kern = np.outer([1, 2, 1], [1, 2, 1]).astype(np.float32) / 16
+    y2[:, :, :, 0] = 0
+    y2[:, 0:2, 0:2, 0] = kern[1:, 1:]            # corner: 9/16 of the mass left
+    y2[:, :, :, 4] = 0
+    y2[:, 58:60, 40:43, 4] = kern[:2, :]         # bottom edge: 12/16
+    ref = T.loss_and_grads(x, y2, p, use_sm=True, lmbd=0.001)
+    ref32 = T.loss_and_grads(x, y2, p, use_sm=True, lmbd=0.001, dtype=torch.float32)
+    eng, tr = make_trainer(p, use_sm=True, lmbd=0.001)
+    losses, _ = tr.loss_and_grads(dev(x), dev(y2))
+    got = tr.grads_dict()
+    eng.close()
+    np.testing.assert_allclose(losses.cpu().numpy()[:3], [ref['loss'], ref['loss_pd'], ref['loss_sm']], rtol=2e-5)
+    check_grads(got, ref['grads'], ref32['grads'])
+    # part detector alone (loss = 2 * CE_pd, main.py:535): d loss / d conv6 bias_k = 2/(B*K) * sum_b (sum_px p - sum_px t)
+    # = 2/K * (1 - mass_k) with TF's gradient; the exact derivative p * sum(t) - t would give 0 for every joint.
+    eng, tr = make_trainer(p, use_sm=False, lmbd=0.0)
+    tr.loss_and_grads(dev(x), dev(y2))
+    gb = tr.grads_dict()['conv6/biases']
+    eng.close()
+    want = np.zeros(9)
+    want[0], want[4] = 2.0 / 9 * (1 - 9.0 / 16), 2.0 / 9 * (1 - 12.0 / 16)
+    np.testing.assert_allclose(gb, want, atol=2e-6)
+
+
+def test_optimizer_state_round_trip_resumes_training(debug_case):
+    """Saver.save / Saver.restore cover the Adam slots, the beta powers and n_iters (main.py:604,612,666): three
+    uninterrupted steps equal two steps, a save, a fresh session restored from it, and the third step -- bit for bit."""
+    from joint_cnn_mrf_amd import checkpoint
+    p, x, y = debug_case
+    xd, yd = dev(x), dev(y)
+    eng, tr = make_trainer(p, use_sm=True, lmbd=0.001, n_updates_total=3)       # 3 updates: the LR schedule moves at every one
+    for _ in range(3):
+        tr.train_step(xd, yd)
+    want = tr.get_params(p)
+    eng.close()
+    eng, tr = make_trainer(p, use_sm=True, lmbd=0.001, n_updates_total=3)
+    for _ in range(2):
+        tr.train_step(xd, yd)
+    saved = checkpoint.session_state(tr, p)
+    assert saved['n_iters'] == 2 and 'conv5/weights/Adam' in saved and 'conv5/weights/Adam_1' in saved and 'beta1_power' in saved
+    eng.close()
+    params2 = {k: v for k, v in saved.items() if k in p}
+    eng, tr = make_trainer(params2, use_sm=True, lmbd=0.001, n_updates_total=3)
+    checkpoint.restore_session_state(tr, saved)
+    assert tr.n_iters == 2
+    tr.train_step(xd, yd)
+    got = tr.get_params(p)
+    eng.close()
+    for k in want:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
