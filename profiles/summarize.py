@@ -4,6 +4,7 @@ are committed under profiles/.
 
   python profiles/summarize.py stats gpurun_out/prof_r1/r1_results.db  > profiles/rNN_kernel_stats.csv
   python profiles/summarize.py pmc   gpurun_out/pmc_x/x_results.db ... > profiles/rNN_pmc.csv
+  python profiles/summarize.py pmc_min 10000 db...   (only dispatches of >= 10 ms: the dominant 60x90 launches)
 
 `stats` = per-kernel calls / total / average / share (what `--kernel-trace --stats` tabulates);
 `pmc`   = per-kernel, per-counter mean value per dispatch (one --pmc pass per database).
@@ -40,12 +41,14 @@ def stats(db):
         print('"%s",%d,%.1f,%.1f,%.1f,%.1f,%.2f' % (short(n), c, s / 1e3, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * s / tot))
 
 
-def pmc(dbs):
+def pmc(dbs, min_us=0.0):
+    """min_us > 0: only dispatches at least that long (e.g. the two 60x90 launches of the strip kernel, which shares its
+    name with the shorter 30x45 launch)."""
     print('kernel,counter,dispatches,mean_value_per_dispatch,mean_duration_us')
     for db in dbs:
         con = sqlite3.connect(db)
         rows = con.execute('select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection '
-                           'group by kernel_name, counter_name order by avg(duration)*count(*) desc').fetchall()
+                           'where duration >= ? group by kernel_name, counter_name order by avg(duration)*count(*) desc', (min_us * 1e3,)).fetchall()
         for n, cn, c, v, d in rows:
             if d * c < 2e5:      # skip kernels below 0.2 ms total
                 continue
@@ -55,5 +58,7 @@ def pmc(dbs):
 if __name__ == '__main__':
     if sys.argv[1] == 'stats':
         stats(sys.argv[2])
+    elif sys.argv[1] == 'pmc_min':          # pmc_min MIN_US db...
+        pmc(sys.argv[3:], float(sys.argv[2]))
     else:
         pmc(sys.argv[2:])

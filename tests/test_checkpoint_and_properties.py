@@ -192,3 +192,46 @@ def test_snappy_blocks_are_readable():
     #  length 18 | literal "abcd" | copy1 off 4 len 4 | copy2 off 8 len 6 | literal "xyzw"
     stream = bytes([18]) + bytes([(4 - 1) << 2]) + b'abcd' + bytes([((4 - 4) << 2) | 1 | (0 << 5), 4]) + bytes([((6 - 1) << 2) | 2, 8, 0]) + bytes([(4 - 1) << 2]) + b'xyzw'
     assert C._snappy_uncompress(stream) == b'abcdabcdabcdabxyzw'
+
+
+def test_data_prepare_writes_the_four_arrays_from_frames(tmp_path):
+    """data.prepare end to end, image half included (data.py:120-196): an annotation file in data_FLIC.mat's structure
+    (examples[0][i][2] = [2,29] coordinates, [3] = file name, [7] = is-train flag) plus JPEG frames on disk ->
+    x_{train,test}_flic.npy (fp32 RGB / 255, [N,480,720,3]) and y_{train,test}_flic.npy ([N,60,90,10]), split and
+    ordered as the reference's loops."""
+    import scipy.io
+    from PIL import Image
+    from joint_cnn_mrf_amd import data
+    rs = np.random.RandomState(12)
+    frames = tmp_path / 'images_FLIC'
+    frames.mkdir()
+    n = 5
+    ex = np.zeros((1, n), dtype=[('poselet_hit_idx', 'O'), ('moviename', 'O'), ('coords', 'O'), ('filepath', 'O'), ('imgdims', 'O'),
+                                 ('currframe', 'O'), ('torsobox', 'O'), ('istrain', 'O'), ('istest', 'O'), ('isbad', 'O'), ('isunchecked', 'O')])
+    is_train = [1, 0, 1, 1, 0]
+    imgs = []
+    for i in range(n):
+        xy = np.full((2, 29), np.nan)
+        xy[0, :] = rs.uniform(40, 680, 29)
+        xy[1, :] = rs.uniform(40, 440, 29)
+        name = 'movie-%08d.jpg' % i
+        img = (rs.random_sample((480, 720, 3)) * 255).astype(np.uint8)
+        Image.fromarray(img).save(str(frames / name), quality=95)
+        imgs.append(np.asarray(Image.open(str(frames / name)).convert('RGB'), np.float32) / 255)
+        ex[0, i]['coords'], ex[0, i]['filepath'], ex[0, i]['istrain'] = xy, np.array([name]), np.array([[is_train[i]]])
+    mat = str(tmp_path / 'data_FLIC.mat')
+    scipy.io.savemat(mat, {'examples': ex})
+    out = data.prepare(mat, images_dir=str(frames), out_dir=str(tmp_path))
+    assert out == {'y_train': (3, 60, 90, 10), 'x_train': (3, 480, 720, 3), 'y_test': (2, 60, 90, 10), 'x_test': (2, 480, 720, 3)}
+    x_train, x_test = np.load(tmp_path / 'x_train_flic.npy'), np.load(tmp_path / 'x_test_flic.npy')
+    assert x_train.dtype == np.float32 and 0 <= x_train.min() and x_train.max() <= 1
+    np.testing.assert_array_equal(x_train, np.stack([imgs[0], imgs[2], imgs[3]]))
+    np.testing.assert_array_equal(x_test, np.stack([imgs[1], imgs[4]]))
+    y_train = np.load(tmp_path / 'y_train_flic.npy')
+    xy_all, _names, tr = data.load_flic(mat)
+    np.testing.assert_array_equal(y_train, data.target_heat_maps(data.joint_cells(xy_all[tr])))
+    np.testing.assert_allclose(y_train.sum(axis=(1, 2)), 1.0, rtol=1e-6)      # none of these blobs touches the border
+    # the files are exactly what main.get_dataset reads
+    from joint_cnn_mrf_amd import main as M
+    xs = M.get_dataset(str(tmp_path))
+    assert [a.shape[0] for a in xs] == [3, 3, 2, 2]

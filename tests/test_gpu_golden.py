@@ -208,3 +208,28 @@ def test_split_kernels_match_exact_on_every_layer_shape():
     for e in engs.values():
         e.close()
     assert not bad, '\n'.join(bad)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_checkpoint_file_to_engine_reproduces_golden_tower(tmp_path, precision):
+    """SURVEY 8f next-3 end to end: the full-size parameters written as a tf.train.Saver checkpoint (prefix.index +
+    prefix.data-00000-of-00001, 235 MB), read back from the files, loaded into an Engine under the reference's variable
+    names, and the tower reproduces the committed goldens (fp32: 1e-4 / arg-max identical; bf16: its own bar)."""
+    from joint_cnn_mrf_amd import checkpoint, tf_checkpoint
+    from joint_cnn_mrf_amd.engine import Engine
+    x, torso, p = full_inputs()
+    p.update(synth.make_sm_params(flic_priors(), kind='trained', seed=seeds()['sm']))
+    prefix = str(tmp_path / 'models_ex' / '2018-02-17 11:34:12_lr=0.001_lambda=0.001_bs=14-76')      # the reference's naming, main.py:443,447
+    tf_checkpoint.save_checkpoint(prefix, dict(p, n_iters=np.int32(76 * 284)))
+    state = tf_checkpoint.load_checkpoint(prefix)
+    params = checkpoint.validate({k: v for k, v in state.items() if k in checkpoint.expected_shapes()})
+    assert int(state['n_iters']) == 76 * 284 and set(params) == set(p)
+    eng = Engine(device=0, precision=precision).load_params(params)
+    r = eng.forward(dev(x), dev(torso), use_sm=True)
+    eng.close()
+    if precision == 'fp32':
+        np.testing.assert_allclose(r['sm_prob'].cpu().numpy(), O.spatial_softmax(load('full_sm_logits_trained').astype(np.float64)), atol=1e-4, rtol=0)
+        np.testing.assert_array_equal(r['pd_coords'].cpu().numpy(), load('full_pd_coords'))
+        np.testing.assert_array_equal(r['sm_coords'].cpu().numpy(), load('full_sm_coords_trained'))
+    else:
+        assert (np.abs(r['sm_coords'].cpu().numpy() - load('full_sm_coords_trained')).max(axis=1) <= 1).mean() >= 0.85

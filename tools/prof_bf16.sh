@@ -18,7 +18,8 @@ done
 DB=$(find $OUT/prof_${NAME}_stats -name "*.db" | head -1)
 python profiles/summarize.py stats $DB > $OUT/${NAME}_kernel_stats.csv
 python profiles/summarize.py pmc $(find $OUT/prof_${NAME}_pmc* -name "*.db" | sort) > $OUT/${NAME}_pmc.csv
+python profiles/summarize.py pmc_min 10000 $(find $OUT/prof_${NAME}_pmc* -name "*.db" | sort) > $OUT/${NAME}_pmc_dominant.csv
 # the raw databases are large: keep only the summaries
 rm -rf $OUT/prof_${NAME}_stats $OUT/prof_${NAME}_pmc*
 head -12 $OUT/${NAME}_kernel_stats.csv | cut -c1-160
-grep -E "strip|CfgB<9, 12, 32, 256" $OUT/${NAME}_pmc.csv | cut -c1-200
+cat $OUT/${NAME}_pmc_dominant.csv | cut -c1-200
