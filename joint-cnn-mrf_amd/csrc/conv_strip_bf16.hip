@@ -84,9 +84,15 @@ __device__ __forceinline__ void s_rot_g(f32x4 (&fa)[2][MR], f32x4 (&fb)[NC], con
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(MR + NC - 1) : "memory");
 #endif
     __builtin_amdgcn_sched_barrier(0);
+#ifdef EXP_PRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int f = 0; f < MR; ++f)
       acc[f][G] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[G]), __builtin_bit_cast(bf16x8, fa[cur][f]), acc[f][G], 0, 0, 0);   // D^T: rows = channels, columns = pixels
+#ifdef EXP_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     s_b_load<(STEP + 1) % TPS, G>(fb[G], baddr);     // STEP == TPS-1: baddr already points at the next stage's buffer
     after(STEP * NC + G);
@@ -283,7 +289,16 @@ __device__ __forceinline__ void strip_tile(const ConvArgs& a, const Geom& gm, ch
 #endif
     __builtin_amdgcn_sched_barrier(0);
 
-    const unsigned eb = __builtin_amdgcn_readlane(htab, st), ea = __builtin_amdgcn_readlane(htab, st + 32);
+    // halo parts exist only in the first stage of a kernel row and in the first three stages of a chunk: the table is not even
+    // looked at elsewhere (two thirds of the stages)
+    unsigned eb = 0, ea = 0;
+#ifndef EXP_NOGATE
+    if (si == 0 || st < 3)
+#endif
+    {
+      eb = __builtin_amdgcn_readlane(htab, st);
+      ea = __builtin_amdgcn_readlane(htab, st + 32);
+    }
     const int hchunk = chunk + (int)((eb >> 19) & 1u);
     const bool extra = (eb >> 20) && hchunk < nchunk && (chunk | (int)((eb >> 19) & 1u)) != 0;   // this-chunk parts: chunk 0 came with the prologue
     // idx = 4 * step + MFMA group: the three weight pieces behind groups 0..2 of step 0, the halo part behind group 3

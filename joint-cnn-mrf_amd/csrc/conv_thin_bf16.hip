@@ -81,8 +81,10 @@ __global__ __launch_bounds__(thinb::NT, 3) void conv_thin_bf16_kernel(ConvArgs a
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     __syncthreads();
     for (int idx = tid; idx < U * HH * WH; idx += NT) {
-      const int u = idx & (U - 1);
-      const int pix = idx >> 2;
+      // NHWC: the 4 units of a pixel are 64 contiguous bytes -> unit fastest.  Planar: a unit plane row is contiguous
+      // -> pixel fastest (consecutive lanes read consecutive 16-byte slots of one plane).
+      const int u = a.in_planar ? idx / (HH * WH) : idx & (U - 1);
+      const int pix = a.in_planar ? idx - u * (HH * WH) : idx >> 2;
       const int hy = pix / WH, hx = pix - hy * WH;
       const int gy = y0 - PAD + hy, gx = x0 - PAD + hx;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
