@@ -198,6 +198,9 @@ __device__ __forceinline__ void strip_tile(const ConvArgs& a, const Geom& gm, ch
   // zero the two planes once per item: gaps, rows outside the image and the 4 rows between two images are never written
   // again.  (The barrier in front: every wave has finished the LDS reads of the work group's previous item.)
   __builtin_amdgcn_s_barrier();
+#ifdef EXP_NOPROLOGUE
+  if (mt < 4)
+#endif
   for (int i = tid; i < 2 * PLANE; i += NT) lds[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -206,6 +209,9 @@ __device__ __forceinline__ void strip_tile(const ConvArgs& a, const Geom& gm, ch
   const int G = nchunk * NSTAGE;
 
   // ---- prologue: three weight stages + the whole halo of chunk 0, everything landed before the first read
+#ifdef EXP_NOPROLOGUE
+  if (mt < 4)
+#endif
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
     if constexpr (NC == NR) {
@@ -215,6 +221,9 @@ __device__ __forceinline__ void strip_tile(const ConvArgs& a, const Geom& gm, ch
       w_piece(0, s, wt0, s);
     }
   }
+#ifdef EXP_NOPROLOGUE
+  if (mt < 4)
+#endif
   bulk_halo(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -446,6 +455,7 @@ __global__ __launch_bounds__(NT, 2) void conv_strip_bf16_kernel(ConvArgs a, Geom
     unit_of(L, mt, nt);
     if (mt < gm.mtiles) strip_tile<NR>(a, gm, smem, mt, nt, 0);
   }
+  // (running the quarter items FIRST, to stagger the output bursts of the work groups, measured 0.5 % slower)
   for (int q = blockIdx.x; q < 4 * gm.nrem; q += gridDim.x) {
     int mt, nt;
     unit_of(gm.nfull + (q >> 2), mt, nt);
