@@ -253,21 +253,8 @@ hipError_t upsample_merge3(const void* x1, const void* x2, int H2, int W2, const
   return hipGetLastError();
 }
 
-// tf.concat([a, b], axis=3) on [N,Ca] / [N,Cb] rows (main.py:528: append the torso channel).
-__global__ void concat_channels_kernel(const float* __restrict__ a, int Ca, const float* __restrict__ b, int Cb,
-                                       float* __restrict__ out, size_t total) {
-  const int C = Ca + Cb;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = i % C;
-    const size_t n = i / C;
-    out[i] = c < Ca ? a[n * Ca + c] : b[n * Cb + (c - Ca)];
-  }
-}
-hipError_t concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, size_t N, hipStream_t st) {
-  const size_t total = N * (Ca + Cb);
-  hipLaunchKernelGGL(concat_channels_kernel, dim3(grid_for(total)), dim3(256), 0, st, a, Ca, b, Cb, out, total);
-  return hipGetLastError();
-}
+// (tf.concat([hm, torso], axis=3) of main.py:528 has no kernel: the spatial model reads its ten channels from the two
+// tensors in place -- sm_pad_frame / sm_likelihood.)
 
 // ------------------------------------------------------------------------------ softmax / argmax
 __device__ __forceinline__ float wave_max(float v) {

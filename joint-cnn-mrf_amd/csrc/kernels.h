@@ -111,7 +111,6 @@ hipError_t upsample_merge3(const void* x1, const void* x2, int H2, int W2, const
 // the same on planar bf16 tensors ([B][C/8][H*W][8], all four); C % 8 == 0
 hipError_t upsample_merge3_planar(const void* x1, const void* x2, int H2, int W2, const void* x3, int H3, int W3,
                                   void* out, int B, int H, int W, int C, hipStream_t st);
-hipError_t concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, size_t N, hipStream_t st);
 hipError_t spatial_softmax(const float* in, float* out, int B, int HW, int K, hipStream_t st);
 hipError_t argmax_coords(const float* hm, int32_t* coords, int B, int HW, int WW, int K, hipStream_t st);
 // spatial_softmax followed by the first-occurrence argmax of the probabilities, one pass over the logits, one
