@@ -408,6 +408,38 @@ __global__ __launch_bounds__(SA_NT) void softmax_argmax_kernel(const float4* __r
     s[k] = a;
   }
   __syncthreads();
+  if (!prob) {
+    // ---- coordinates only (the call of the benchmark and of a sharded forward): the arg-max of the probabilities without
+    // computing them.  exp(z - max) is exactly 1 at every maximum, so the largest probability is pmax = fl(1 / s); any
+    // other pixel can only TIE with it after the rounding of the division, and only if its exp is within a few ulp of 1:
+    // for those few the quotient is evaluated and compared, the rest is skipped.  First occurrence = smallest pixel index
+    // among the pixels whose probability equals pmax -- exactly what the general path below finds.
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float pmax = 1.0f / s[k];
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < SA_QPT; ++j)
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+          const float e = v[j][pp * K + k];
+          if (on[j] && e > 0.99999f && e / s[k] == pmax) bi = min(bi, 4 * (tid + j * SA_NT) + pp);
+        }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) bi = min(bi, __shfl_xor(bi, o));
+      if ((tid & 63) == 0) redi[wv][k] = bi;
+    }
+    __syncthreads();
+    if (tid < K) {
+      int bi = redi[0][tid];
+      for (int w = 1; w < NW; ++w) bi = min(bi, redi[w][tid]);
+      if (bi == 0x7fffffff) bi = 0;   // all-NaN map: np.argmax returns 0
+      const int row = bi / WW;
+      coords[((size_t)b * 2 + 0) * K + tid] = row;
+      coords[((size_t)b * 2 + 1) * K + tid] = bi - row * WW;
+    }
+    return;
+  }
   // ---- normalise, store, argmax of the stored values (larger wins, ties go to the lower pixel index)
 #pragma unroll
   for (int k = 0; k < K; ++k) {

@@ -110,3 +110,28 @@ def test_fused_softmax_argmax_matches_oracle_and_ties():
     np.testing.assert_allclose(p2.cpu().numpy(), O.spatial_softmax(z2.astype(np.float64)), rtol=2e-5, atol=1e-12)
     np.testing.assert_array_equal(c2.cpu().numpy(), O.argmax_coords(p2.cpu().numpy()))
     eng.close()
+
+
+def test_coords_only_argmax_equals_argmax_of_probabilities_under_near_ties():
+    """The coordinates-only route of the fused tail skips the division for every pixel whose exp is not within a few ulp of
+    1.  Maps whose two largest logits differ by 0, 1, 2 and 3 float32 ulps (the later pixel holding the larger one) are
+    where a rounded quotient can tie: both routes must return the same pixel as np.argmax of the returned probabilities."""
+    from joint_cnn_mrf_amd.engine import Engine
+    eng = Engine(device=0)
+    eng.finalize()
+    rs = np.random.RandomState(8)
+    z = (2.0 * rs.standard_normal((40, 60, 90, 9))).astype(np.float32)
+    top = np.float32(9.0)
+    for b in range(40):
+        for k in range(9):
+            lo, hi = sorted(rs.choice(5400, 2, replace=False))
+            later = top
+            for _ in range((b + k) % 4):
+                later = np.nextafter(later, np.float32(np.inf))
+            z[b].reshape(5400, 9)[lo, k] = top          # earlier pixel: the smaller (or equal) logit
+            z[b].reshape(5400, 9)[hi, k] = later
+    prob, coords = eng.softmax_argmax(dev(z))
+    _none, coords_only = eng.softmax_argmax(dev(z), want_prob=False)
+    eng.close()
+    np.testing.assert_array_equal(coords.cpu().numpy(), O.argmax_coords(prob.cpu().numpy()))
+    assert torch.equal(coords_only, coords)
