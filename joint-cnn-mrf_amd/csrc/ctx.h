@@ -55,6 +55,7 @@ struct ConvLayer {
   int coutp_split = 0;
   float* wscale = nullptr;        // fp16x3: device {Sw, 1/Sw}, the power-of-two scale the packed weights carry
   void* wp_bf16 = nullptr;        // packed for conv_igemm_bf16
+  void* wp_kxfold = nullptr;      // logits layer packed for conv_kxfold_bf16 (bf16 handles, Cout == 9)
   void* wq1_bf16 = nullptr;       // packed for conv1_mfma_pool (5x5, Cin=3, Cout=64)
   float* wq1_f32 = nullptr;       // packed for conv1_mfma_pool_f32 (fp32 handles)
   int coutp_bf16 = 0;

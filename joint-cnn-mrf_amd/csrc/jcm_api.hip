@@ -83,7 +83,12 @@ static int launch_conv_layer(jcm_ctx* c, const ConvLayer* L, const void* wp, con
   if ((in_planar || out_planar) && !act_bf16) return fail(JCM_ERR_ARG, "planar activations exist on the bf16 path only");
   if (act_bf16) {
     a.CoutP = L->coutp_bf16;
-    if (L->thin_bf16 && out_f32) HIP_TRY(conv_thin_bf16(a, c->stream));
+    if (L->thin_bf16 && out_f32 && L->wp_kxfold && conv_kxfold_bf16_supported(a, L->ks)) {
+      a.wp = L->wp_kxfold;
+      HIP_TRY(conv_kxfold_bf16(a, c->stream));
+    } else if (L->thin_bf16 && out_f32) {
+      HIP_TRY(conv_thin_bf16(a, c->stream));
+    }
     else HIP_TRY(conv_igemm_bf16(a, L->ks, out_f32, c->stream));
   } else {
     a.CoutP = L->coutp;
@@ -247,6 +252,10 @@ int refresh_derived(jcm_ctx* c, bool first) {
       const size_t n = (size_t)L.ks * L.ks * L.cin * L.coutp_bf16;
       if (!L.wp_bf16) JCM_TRY(dev_alloc(c, &L.wp_bf16, n * 2));
       HIP_TRY(pack_weights_bf16(w.d, L.wp_bf16, L.ks, L.cin, L.cout, L.coutp_bf16, c->stream));
+      if (L.thin_bf16 && L.cout == 9) {              // the logits layer's second packing: kernel columns folded into N
+        if (!L.wp_kxfold) JCM_TRY(dev_alloc(c, &L.wp_kxfold, conv_kxfold_weight_bytes(L.cin)));
+        HIP_TRY(pack_weights_kxfold(w.d, L.wp_kxfold, L.cin, c->stream));
+      }
     }
     c->convs[scope] = L;
   }
@@ -834,7 +843,8 @@ int jcm_conv_kernel_name(jcm_handle h, const char* scope, int B, int H, int W, c
     k = h->precision == JCM_PRECISION_BF16 ? (L->wq1_bf16 ? "conv1_mfma_pool_kernel" : "conv1_5x5s2_kernel") : (L->wq1_f32 ? "conv1_mfma_pool_f32_kernel" : "conv1_5x5s2_kernel");
   } else if (h->precision == JCM_PRECISION_BF16) {
     a.CoutP = L->coutp_bf16;
-    k = L->thin_bf16 ? "conv_thin_bf16_kernel"
+    a.in_planar = 0;
+    k = L->thin_bf16 ? (L->wp_kxfold && conv_kxfold_bf16_supported(a, L->ks) ? "conv_kxfold_bf16_kernel" : "conv_thin_bf16_kernel")
         : (conv_igemm_bf16_bn(L->cout, L->ks) == 256 && conv_strip_bf16_supported(a, L->ks)) ? "conv_strip_bf16_kernel" : "conv_igemm_bf16_kernel";
   } else {
     const bool use_split = L->wp_split && (L->thin ? h->f32_conv == 2 : conv_split_supported(L->ks, L->cin, L->coutp_split, B, H, W, h->split_min_wgs));

@@ -71,6 +71,14 @@ hipError_t conv_thin_f32(const ConvArgs& a, hipStream_t st);
 // weights packed by pack_weights_bf16 with CoutP = 16
 hipError_t conv_thin_bf16(const ConvArgs& a, hipStream_t st);
 
+// ---- conv_kxfold_bf16.hip : the 9-channel logits layer with the kernel columns folded into the MFMA's N axis (81 -> 96
+// columns, one 1x1-conv GEMM per kernel row, shifted sum over kx through LDS); bf16 in (NHWC or planar), fp32 NHWC out.
+// Weights packed by pack_weights_kxfold: [Cin/16][ky][unit][96][8].  Shapes: Cout == 9, Cin % 32 == 0, 82 <= W <= 90.
+bool conv_kxfold_bf16_supported(const ConvArgs& a, int ks);
+size_t conv_kxfold_weight_bytes(int Cin);
+hipError_t pack_weights_kxfold(const float* w_hwio, void* wp, int Cin, hipStream_t st);
+hipError_t conv_kxfold_bf16(const ConvArgs& a, hipStream_t st);
+
 // ---- conv_igemm_bf16.hip : the same dataflow on v_mfma_f32_32x32x16_bf16 ---------------------
 // x bf16 NHWC (Cin % 32 == 0), packed weights bf16 [k*k][Cin/8][CoutP][8], out bf16 (fp32 when
 // out_f32: the logits layer).

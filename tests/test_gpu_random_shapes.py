@@ -72,7 +72,10 @@ def check_bf16_layer(got, ref):
     assert np.sqrt(np.mean(diff ** 2)) <= 1e-3 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize('shape', [(2, 60, 90, 512, 9), (1, 30, 45, 64, 9), (3, 17, 29, 96, 7)], ids=lambda s: 'B%d_%dx%d_%d-%d' % s)
+# 82 <= W <= 90 with 9 joints: conv_kxfold_bf16_kernel (kernel columns folded into N); its last tile of an image runs 3, 2 or 1
+# fragments per wave: 60x90 -> 2, 9x82 -> 1, 23x86 -> 3; 61x88: odd height, rows that straddle every window edge
+@pytest.mark.parametrize('shape', [(2, 60, 90, 512, 9), (1, 30, 45, 64, 9), (3, 17, 29, 96, 7), (3, 9, 82, 64, 9), (2, 23, 86, 32, 9), (1, 61, 88, 96, 9),
+                                   (5, 60, 90, 64, 9)], ids=lambda s: 'B%d_%dx%d_%d-%d' % s)
 def test_bf16_logits_layer_vs_bf16_oracle(shape):
     """The last (linear) layer on the bf16 path keeps its fp32 result: no output rounding, so the kernel must agree with
     the bf16-operand oracle to accumulation error (fp32 vs float64), orders of magnitude below the bf16-vs-fp32 gap."""
@@ -84,6 +87,7 @@ def test_bf16_logits_layer_vs_bf16_oracle(shape):
     x = np.maximum(rs.standard_normal((B, H, W, cin)), 0).astype(np.float32)
     ref = O.conv_layer(x.astype(np.float64), p, 9, 1, 'c', last_layer=True, emulate='bf16')
     eng = Engine(device=0, precision='bf16').load_params(p)
+    assert eng.conv_kernel_name('c', B, H, W) == ('conv_kxfold_bf16_kernel' if cout == 9 and 82 <= W <= 90 else 'conv_thin_bf16_kernel')
     got = eng.conv_layer(torch.as_tensor(x, device='cuda:0'), 'c', 1, last_layer=True, n_out=cout).cpu().numpy()
     eng.close()
     assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
