@@ -21,7 +21,8 @@
 //     loaded and stay zero), 1-KB weight pieces.  What a wave issues is tabulated once per tile in two VGPRs (v_readlane).
 //   * D^T = W^T X^T as in conv_strip_bf16.hip: a lane owns a pixel, so Y goes to LDS column-major with conflict-free
 //     32-bit writes and comes back with conflict-free reads along s.
-// Reference semantics: conv2d SAME stride 1 + bias (main.py:133-135, 72); optional ReLU + folded BatchNorm epilogue.
+// Reference semantics: conv2d SAME stride 1 + bias, no activation (main.py:133-135, 72).
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -56,8 +57,18 @@ struct Geom {
 
 using namespace kxf;
 
+#ifdef KXEXP_TIMING
+__device__ unsigned long long kx_dbg[8];
+#define KX_T(i) do { if (blockIdx.x == 0 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&kx_dbg[i], t_ - t_prev); t_prev = t_; } } while (0)
+#else
+#define KX_T(i) do { } while (0)
+#endif
+
 template <int MR, int KY>
 __device__ __forceinline__ void kx_loads(f32x4 (&fa)[MRMAX], f32x4 (&fb)[NF], const unsigned (&aaddr)[MRMAX], unsigned aoff, unsigned baddr) {
+#ifdef KXEXP_NOLDS
+  return;
+#endif
 #pragma unroll
   for (int g = 0; g < NF; ++g) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[g]) : "v"(baddr), "i"(KY * 2 * NCOL * 16 + g * 512) : "memory");
 #pragma unroll
@@ -122,6 +133,12 @@ __device__ __forceinline__ void kx_tile(const ConvArgs& a, const Geom& gm, char*
     const unsigned eb = __builtin_amdgcn_readlane(tb, i), ea = __builtin_amdgcn_readlane(ta, i);
     if (!(eb >> 29)) return;
     const bool wts = (eb >> 28) & 1u;
+#ifdef KXEXP_NOWDMA
+    if (wts && chunk > 1) return;
+#endif
+#ifdef KXEXP_NOXDMA
+    if (!wts && chunk > 1) return;
+#endif
     const unsigned slot = (eb & 0x3fffu) + (unsigned)bufsel * (wts ? (unsigned)WCH : (unsigned)XBUF);
     auto dst = (__attribute__((address_space(3))) char*)(size_t)(lds0 + slot * 16u);
     const unsigned lo = (eb >> 14) & 0x7fu, hi = (eb >> 21) & 0x7fu;
@@ -131,6 +148,9 @@ __device__ __forceinline__ void kx_tile(const ConvArgs& a, const Geom& gm, char*
     }
   };
 
+#ifdef KXEXP_TIMING
+  unsigned long long t_prev = __builtin_readcyclecounter();
+#endif
   // ---- zero both X buffers (gaps, rows outside the image), then chunk 0 into buffer 0
   __builtin_amdgcn_s_barrier();                        // the previous item's epilogue reads are done
   for (int i = tid; i < 2 * XBUF; i += NT) lds[XB0 + i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -138,9 +158,14 @@ __device__ __forceinline__ void kx_tile(const ConvArgs& a, const Geom& gm, char*
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int i = 0; i < EPW; ++i) dma(i, 0, 0);
+#ifdef KXEXP_NODMA
+#pragma unroll
+  for (int i = 0; i < EPW; ++i) dma(i, 1, 1);
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+  KX_T(0);
   const int nchunk = Cin >> 4;
   const unsigned P16 = (unsigned)P * 16u;
   f32x4 fa[2][MRMAX], fb[2][NF];
@@ -148,91 +173,137 @@ __device__ __forceinline__ void kx_tile(const ConvArgs& a, const Geom& gm, char*
 
   // One chunk = 9 kernel rows; PAR = the fragment set that holds kernel row 0.  9 is odd, so PAR flips every chunk: the loop
   // body is a pair of chunks in straight-line code.
+  //
+  // Everything that is not an MFMA is issued BETWEEN the MFMAs of a kernel row, one piece per MFMA: the two waves of a SIMD
+  // are served alternately, so they reach the end of a row together and whatever is issued in one block there is exposed
+  // (measured: 6 ds_reads per row in a block cost 17 % of the kernel, the DMA entries 19 %).
+  //
+  // The chunk's one barrier sits between kernel rows 7 and 8.  In front of it a wave has completed every LDS read of this
+  // chunk's buffers (row 8's fragments were requested during row 7) and its share of the next chunk's DMA has landed; behind
+  // it, row 8 requests the first fragments of the next chunk from the other buffers, and the DMA of the chunk after that may
+  // overwrite this chunk's buffers from the next row on: no bubble at the chunk boundary.
   auto one_chunk = [&](auto par, int chunk) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par)::value;
     const int bufsel = chunk & 1;
-    const unsigned aoff = (unsigned)(bufsel * XBUF * 16);
-    const unsigned bcur = baddr + (unsigned)(bufsel * WCH * 16);
+    const unsigned aoff = (unsigned)(bufsel * XBUF * 16), aoffn = (unsigned)((bufsel ^ 1) * XBUF * 16);
+    const unsigned bcur = baddr + (unsigned)(bufsel * WCH * 16), bnxt = baddr + (unsigned)((bufsel ^ 1) * WCH * 16);
     const bool more = chunk + 1 < nchunk;
     auto step = [&](auto kyc) __attribute__((always_inline)) {
       constexpr int KY = decltype(kyc)::value;
-      constexpr int cur = (KY + PAR) & 1;
-      if constexpr (KY < KS - 1) {
-        kx_loads<MR, KY + 1>(fa[cur ^ 1], fb[cur ^ 1], aaddr, aoff + (unsigned)(KY + 1) * P16, bcur);
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(MR + NF) : "memory");
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      constexpr int cur = (KY + PAR) & 1, nxt = cur ^ 1;
+      constexpr int KN = KY < KS - 1 ? KY + 1 : 0;                 // the kernel row whose fragments this row requests
+      const unsigned ao = KY < KS - 1 ? aoff + (unsigned)KN * P16 : aoffn;
+      const unsigned bo = KY < KS - 1 ? bcur : bnxt;
+      // request j of the next row's fragments: A0 B0 A1 A2 B1 B2 (fragments beyond MR dropped)
+      auto req = [&](int j) __attribute__((always_inline)) {
+#ifdef KXEXP_NOLDS
+        return;
+#endif
+        if (KY == KS - 1 && !more) return;
+        if (j == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[nxt][0]) : "v"(aaddr[0] + ao) : "memory");
+        if (j == 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[nxt][0]) : "v"(bo), "i"(KN * 2 * NCOL * 16) : "memory");
+        if (j == 2 && MR > 1) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[nxt][1]) : "v"(aaddr[1] + ao) : "memory");
+        if (j == 3 && MR > 2) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[nxt][2]) : "v"(aaddr[2] + ao) : "memory");
+        if (j == 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[nxt][1]) : "v"(bo), "i"(KN * 2 * NCOL * 16 + 512) : "memory");
+        if (j == 5) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[nxt][2]) : "v"(bo), "i"(KN * 2 * NCOL * 16 + 1024) : "memory");
+      };
+#ifndef KXEXP_NOLDS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this row's fragments (requested one row ago)
+#endif
+      if constexpr (KY == KS - 1) {
+#ifndef KXEXP_NOBAR
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
+      constexpr int NM = MR * NF;
 #pragma unroll
-      for (int g = 0; g < NF; ++g)
-#pragma unroll
-        for (int f = 0; f < MR; ++f)
-          acc[f][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[cur][g]), __builtin_bit_cast(bf16x8, fa[cur][f]), acc[f][g], 0, 0, 0);   // D^T: rows = columns of Y, columns = pixels
-      __builtin_amdgcn_sched_barrier(0);
-      if (more) {                                        // the next chunk's window and weights, two entries per kernel row
-        if constexpr (2 * KY < EPW) dma(2 * KY, chunk + 1, bufsel ^ 1);
-        if constexpr (2 * KY + 1 < EPW) dma(2 * KY + 1, chunk + 1, bufsel ^ 1);
+      for (int m = 0; m < NM; ++m) {
+        const int g = m / MR, f = m % MR;
+        acc[f][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[cur][g]), __builtin_bit_cast(bf16x8, fa[cur][f]), acc[f][g], 0, 0, 0);   // D^T: rows = columns of Y, columns = pixels
+        __builtin_amdgcn_sched_barrier(0);
+        // behind MFMA m: request m (the last MFMA takes all that are left), then the DMA entries of this row behind the last two
+        if (m < NM - 1) req(m);
+        else
+          for (int j = NM - 1; j < 6; ++j) req(j);
+#ifndef KXEXP_NODMA
+        if (KY < KS - 2 && more) {                                  // rows 0..6 carry the 13 entries of the next chunk
+          if (m == (NM >= 3 ? NM - 3 : 0) && 2 * KY < EPW) dma(2 * KY, chunk + 1, bufsel ^ 1);
+          if (m == NM - 1 && 2 * KY + 1 < EPW) dma(2 * KY + 1, chunk + 1, bufsel ^ 1);
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
     };
     step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
     step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
     step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
-    // everybody's DMA of the next chunk has landed and everybody has left this chunk's buffers
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (more) kx_loads<MR, 0>(fa[PAR ^ 1], fb[PAR ^ 1], aaddr, (unsigned)((bufsel ^ 1) * XBUF * 16), baddr + (unsigned)((bufsel ^ 1) * WCH * 16));
   };
   for (int chunk = 0; chunk < nchunk; chunk += 2) {
     one_chunk(std::integral_constant<int, 0>{}, chunk);
     one_chunk(std::integral_constant<int, 1>{}, chunk + 1);
   }
+  // (every wave completed its last LDS read before the last chunk's barrier: the epilogue may reuse the LDS right away)
+  KX_T(1);
 
-  // ---- epilogue: the shifted sum over kx, one 32-column fragment at a time through Ybuf[column][s] (the barrier that closed the
-  // last chunk has freed the whole LDS).  acc[f][g][i]: pixel (wid*MR+f)*32 + l31, column 32 g + 8 (i>>2) + 4 h + (i&3).
+  // ---- epilogue: the shifted sum over kx, one 32-column fragment at a time through Ybuf[column][s] (the whole LDS
+  // is free).  acc[f][g][i]: pixel (wid*MR+f)*32 + l31, column 32 g + 8 (i>>2) + 4 h + (i&3).
   // Thread t sums outputs pq = t and t + 512 for all 9 joints.
   float sum[CO][2];
 #pragma unroll
   for (int k = 0; k < CO; ++k) sum[k][0] = sum[k][1] = 0.f;
-  const int pq1 = tid + NT;
+  constexpr bool TWO = OUTQ > NT;                        // MR = 3: 760 outputs per joint on 512 threads
+  // The thread index goes through an empty asm: every address below is then computed HERE.  (Otherwise LLVM hoists the
+  // tile-invariant epilogue addresses out of the persistent item loop, spills them around the MFMA loop and reloads
+  // them one by one with a full vmcnt(0) wait each: measured 23 000 cycles per tile.)
+  int te = tid;
+  asm volatile("" : "+v"(te));
+  const int eh = (te >> 5) & 1, el = te & 31, ew = te >> 6;
+  const int pq1 = te + NT;                               // (threads past the last output read along and drop their sums: no branch around a read)
+  // the 9 biases: scalar loads (load and wait in one statement: the compiler may copy the result registers right away)
+  typedef float f32x8s __attribute__((ext_vector_type(8)));
+  f32x8s bias8;
+  float bias9;
+  asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(bias8), "=&s"(bias9) : "s"(a.bias) : "memory");
 #pragma unroll
   for (int g = 0; g < NF; ++g) {
     if (g) __syncthreads();                             // the previous fragment's reads are done
 #pragma unroll
     for (int f = 0; f < MR; ++f)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) ldsf[(8 * (i >> 2) + 4 * h + (i & 3)) * YS + (wid * MR + f) * 32 + l31] = acc[f][g][i];
+      for (int i = 0; i < 16; ++i) ldsf[(8 * (i >> 2) + 4 * eh + (i & 3)) * YS + (ew * MR + f) * 32 + el] = acc[f][g][i];
     __syncthreads();
 #pragma unroll
     for (int n = 0; n < 32; ++n) {
       const int col = 32 * g + n;
       if (col < KS * CO) {
         const int kx = col / CO, k = col % CO;
-        sum[k][0] += ldsf[n * YS + tid + kx];
-        if (pq1 < OUTQ) sum[k][1] += ldsf[n * YS + pq1 + kx];
+        sum[k][0] += ldsf[n * YS + te + kx];
+        if constexpr (TWO) sum[k][1] += ldsf[n * YS + pq1 + kx];      // te + 512 + 8 < 1032: inside the LDS for every thread
       }
     }
   }
+  KX_T(2);
+  // bias, then through obuf[pq][k] (stride 9: conflict-free) to coalesced NHWC stores
 #pragma unroll
   for (int k = 0; k < CO; ++k) {
-    const float bi = a.bias[k];
-    float v0 = sum[k][0] + bi, v1 = sum[k][1] + bi;
-    if (a.relu_bn) {
-      const float sc = a.scale[k], sh = a.shift[k];
-      v0 = fmaxf(v0, 0.f) * sc + sh;
-      v1 = fmaxf(v1, 0.f) * sc + sh;
-    }
-    if (tid < OUTQ) ldsf[OB0 + tid * CO + k] = v0;
-    if (pq1 < OUTQ) ldsf[OB0 + pq1 * CO + k] = v1;
+    const float bi = k < 8 ? bias8[k < 8 ? k : 0] : bias9;
+    if (te < OUTQ) ldsf[OB0 + te * CO + k] = sum[k][0] + bi;
+    if (TWO && pq1 < OUTQ) ldsf[OB0 + pq1 * CO + k] = sum[k][1] + bi;
   }
   __syncthreads();
   float* __restrict__ out = static_cast<float*>(a.out) + (size_t)b * HW * CO;
-  for (int o = tid; o < OUTQ * CO; o += NT) {
+  const int r0 = s0 / P, c0 = s0 - r0 * P;               // scalar; below, (c0 + pq) / P through a float reciprocal (exact: the operand stays below 2^11)
+  const float rP = 1.0f / (float)P;
+#pragma unroll 2
+  for (int o = te; o < OUTQ * CO; o += NT) {
     const int pq = o / CO, k = o - pq * CO;
-    const int s = s0 + pq, r = s / P, cc = s - r * P;
+    const int sr = c0 + pq, dr = (int)(((float)sr + 0.5f) * rP);
+    const int r = r0 + dr, cc = sr - dr * P;
     if (cc >= 4 && r < H) out[(r * W + cc - 4) * CO + k] = ldsf[OB0 + o];
   }
+  KX_T(3);
 }
 
 __global__ __launch_bounds__(NT, 2) void conv_kxfold_bf16_kernel(ConvArgs a, Geom gm) {
@@ -269,7 +340,7 @@ __global__ void pack_weights_kxfold_kernel(const float* __restrict__ w, __bf16* 
 
 namespace {
 bool make_geom(const ConvArgs& a, Geom& gm) {
-  if (a.Cout != CO || a.Cin % 32 || a.W < 8 || a.W > 90 || a.H < 1 || a.B < 1) return false;
+  if (a.Cout != CO || a.relu_bn || a.Cin % 32 || a.W < 8 || a.W > 90 || a.H < 1 || a.B < 1) return false;
   const long long HW = (long long)a.H * a.W;
   if (HW * a.Cin * 2 >= (1ll << 31) || (long long)a.H * (a.W + 4) >= (1 << 24)) return false;
   gm.H = a.H; gm.W = a.W; gm.HW = (int)HW; gm.P = a.W + 4;
@@ -314,6 +385,16 @@ hipError_t conv_kxfold_bf16(const ConvArgs& a, hipStream_t st) {
   static LdsAttr attr;
   if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(conv_kxfold_bf16_kernel), LDS_BYTES); e != hipSuccess) return e;
   hipLaunchKernelGGL(conv_kxfold_bf16_kernel, dim3(blocks), dim3(NT), LDS_BYTES, st, a, gm);
+#ifdef KXEXP_TIMING
+  {
+    unsigned long long h[8] = {0};
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(kx_dbg), sizeof(h));
+    fprintf(stderr, "kx timing (block 0, s_memtime ticks): prologue %llu  loop %llu  gather %llu  store %llu\n", h[0], h[1], h[2], h[3]);
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(kx_dbg), z, sizeof(z));
+  }
+#endif
   return hipGetLastError();
 }
 

@@ -76,7 +76,7 @@ const ConvLayer* conv_of(jcm_ctx* c, const std::string& scope) {
 // The launch itself (kernel choice by precision / f32_conv); run_conv_layer brackets it with the timing events.
 static int launch_conv_layer(jcm_ctx* c, const ConvLayer* L, const void* wp, const void* x, int B, int H, int W, void* out, bool act_bf16,
                              bool out_f32, int in_planar, int out_planar) {
-  ConvArgs a;
+  ConvArgs a{};
   a.x = x; a.wp = wp; a.bias = L->bias; a.scale = L->scale; a.shift = L->shift; a.out = out;
   a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout; a.relu_bn = L->has_bn ? 1 : 0;
   a.in_planar = in_planar; a.out_planar = out_planar;
@@ -323,7 +323,7 @@ int run_conv(jcm_ctx* c, const std::string& scope, int stride, const void* x, in
 // planar activation layout at full speed)?
 bool takes_strip(const ConvLayer* L, int B, int H, int W) {
   if (!L->wp_bf16 || L->thin_bf16 || conv_igemm_bf16_bn(L->cout, L->ks) != 256) return false;
-  ConvArgs a;
+  ConvArgs a{};
   a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout; a.CoutP = L->coutp_bf16;
   a.out_planar = 1;
   return conv_strip_bf16_supported(a, L->ks);
@@ -836,8 +836,8 @@ int jcm_conv_kernel_name(jcm_handle h, const char* scope, int B, int H, int W, c
   if (!scope || !name || cap < 2 || B < 1 || H < 1 || W < 1) return fail(JCM_ERR_ARG, "bad conv_kernel_name arguments");
   const ConvLayer* L = conv_of(h, scope);
   if (!L) return fail(JCM_ERR_STATE, std::string("no conv layer '") + scope + "'");
-  ConvArgs a;
-  a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout;
+  ConvArgs a{};
+  a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout; a.relu_bn = L->has_bn ? 1 : 0;
   const char* k;
   if (L->cin == 3) {
     k = h->precision == JCM_PRECISION_BF16 ? (L->wq1_bf16 ? "conv1_mfma_pool_kernel" : "conv1_5x5s2_kernel") : (L->wq1_f32 ? "conv1_mfma_pool_f32_kernel" : "conv1_5x5s2_kernel");
