@@ -97,7 +97,7 @@ struct jcm_ctx {
   const float** energy_ptrs = nullptr;   // [P] device table of the energy_* / bias_* parameter tensors, graph order
   const float** bias_ptrs = nullptr;
   int* cond0 = nullptr;         // single zero (jcm_conv_mrf)
-  int sm_algo = 2;              // 0 = FFT (2-D rocFFT), 1 = direct sliding-window VALU kernel, 2 = FFT with split row-pruned inverse
+  int sm_algo = 3;              // 0 = FFT (2-D rocFFT), 1 = direct sliding-window VALU kernel, 2 = rocFFT with split row-pruned inverse, 3 = fused LDS FFTs (sm_fused.hip)
   int sm_chunk = 32;            // images per FFT slice (measured at B=256, split inverse: 64 -> 3.32 ms, 32 -> 3.10, 16 -> 3.26, 8 -> 3.83)
   int micro_batch = 0;          // jcm_forward walks a batch in slices of this many images (0 = 256 bf16 / 64 fp32)
   jcm::SmFft* fft = nullptr;

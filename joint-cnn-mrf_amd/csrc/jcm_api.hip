@@ -428,6 +428,13 @@ int sm_forward_impl(jcm_ctx* c, const float* hm, int Ca, const float* extra, int
     HIP_TRY(sm_finish(lik, cpre, c->sp_bias, logits, B, c->K, kC, c->stream));
     return JCM_OK;
   }
+  if (c->sm_algo == 3) {   // fused: all transforms in LDS, only the 10 likelihood spectra per image leave the CU
+    float2* lhat_t = arena_alloc<float2>(c, (size_t)B * kC * kSpec);
+    if (c->dry) return JCM_OK;
+    HIP_TRY(sm_fused_forward(hm, Ca, extra, extra_ld, c->bn_sm_scale, c->bn_sm_shift, c->prior_spec_t, c->cond, c->sp_bias, lhat_t, logits, B, c->K, kC,
+                             c->stream));
+    return JCM_OK;
+  }
   if (c->sm_algo == 2) {   // FFT with a split, row-pruned inverse
     const int Bc = B < c->sm_chunk ? B : c->sm_chunk;
     constexpr int WC = kPrW / 2 + 1;                      // 91
@@ -540,7 +547,7 @@ int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
     return JCM_OK;
   }
   if (k == "sm_algo") {   // allowed at any time
-    if (value < 0 || value > 2) return fail(JCM_ERR_ARG, "sm_algo must be 0 (fft), 1 (direct) or 2 (fft_split)");
+    if (value < 0 || value > 3) return fail(JCM_ERR_ARG, "sm_algo must be 0 (fft), 1 (direct), 2 (fft_split) or 3 (fft_fused)");
     h->sm_algo = (int)value;
     return JCM_OK;
   }

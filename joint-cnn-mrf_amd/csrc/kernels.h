@@ -163,6 +163,11 @@ hipError_t sm_pad_frame(const float* hm, int Ca, const float* extra, const float
 hipError_t sm_spec_mul(const float2* lhat, const float2* phat, const int* cond, float2* spec, int B, int C, int P, hipStream_t st);
 hipError_t sm_finish_fft(const float* frame, const float* cfull, const float* spbias, float* logits, int B, int K, int C, hipStream_t st);
 hipError_t sm_resize_frame(const float* cfull, float* out, int B, hipStream_t st);
+// ---- sm_fused.hip (sm_algo = 3, default): every transform of the pairwise convolutions in LDS -- forward spectra per (image,
+// channel) into lhat_t [B][C][91][120], then per (image, joint) product + inverse + window + resize + bias + log + sum
+hipError_t sm_fused_forward(const float* hm, int Ca, const float* extra, int extra_ld, const float* sc, const float* sh, const float2* phat_t,
+                            const int* cond, const float* spbias, float2* lhat_t, float* logits, int B, int K, int C, hipStream_t st);
+
 // split inverse (sm_algo = 2): spectra kept transposed [n][91][120]; columns by 1-D C2C, then only rows
 // 59..119 are transposed back ([n][61][91]) and go through a 1-D C2R
 const char* sm_fft_cols(SmFft* f, float2* data, int n);

@@ -270,7 +270,7 @@ class Engine:
         """Pairwise-convolution algorithm of the spatial model: 'fft' (rocFFT 2-D), 'fft_split'
         (rocFFT 1-D columns, then only the 61 rows the VALID window needs) or 'direct' (LDS sliding-window
         VALU kernel).  All are HIP paths; bench/profiles compare them."""
-        _lib.check(self._lib.jcm_set_option(self._h, b'sm_algo', {'fft': 0, 'direct': 1, 'fft_split': 2}[algo]), 'jcm_set_option(sm_algo)')
+        _lib.check(self._lib.jcm_set_option(self._h, b'sm_algo', {'fft': 0, 'direct': 1, 'fft_split': 2, 'fft_fused': 3}[algo]), 'jcm_set_option(sm_algo)')
 
     def set_micro_batch(self, n):
         """Images per internal slice of forward(): bounds the workspace when a rank holds a large share of a
