@@ -26,76 +26,84 @@
 namespace jcm {
 
 namespace smf {
+typedef float cf __attribute__((ext_vector_type(2)));      // complex: a 2-vector, so that add / sub / scale / fma are ONE packed VALU instruction
 constexpr int FH = 120, FW = 180, WC = 91;        // frame, half-spectrum columns
 constexpr int MH = 60, MW = 90, MHW = MH * MW;    // heat map
 constexpr int PU = 121, PX = 181;                 // LDS pitches (complex elements) of the column buffer [91][PU] and the row buffer [31][PX]
 constexpr int NROWP = 31;                         // row pairs of the inverse (61 rows); the forward has 30
-constexpr int NT = 512;
-constexpr int CB = 0, RB = WC * PU, TW120 = RB + NROWP * PX, TW180 = TW120 + FH, TY = TW180 + FW, TX = TY + MH, LDS_C = TX + MW;   // offsets in float2
+constexpr int NT = 768;                           // 12 waves: 91 x 8 radix-15 butterflies in one sweep; measured 1.21 ms per 256 images against 1.24 ms with 8 waves
+constexpr int CB = 0, RB = WC * PU, TW120 = RB + NROWP * PX, TW180 = TW120 + FH, TY = TW180 + FW, TX = TY + MH, LDS_C = TX + MW;   // offsets in complex elements
 constexpr int LDS_BYTES = LDS_C * 8;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-constexpr int NE = (WC * FH + NT - 1) / NT;       // spectrum elements per thread: 22
-constexpr int NPIX = (MHW + NT - 1) / NT;         // output pixels per thread: 11
+constexpr int NE = (WC * FH + NT - 1) / NT;       // spectrum elements per thread: 15
+constexpr int NPIX = (MHW + NT - 1) / NT;         // output pixels per thread: 8
 
 __device__ __forceinline__ int pos120(int y) { return (y & 7) * 15 + (y >> 3); }       // X[m + 8 k] sits at 15 m + k
 __device__ __forceinline__ int pos180(int x) { return (x % 12) * 15 + x / 12; }          // X[m + 12 k] sits at 15 m + k
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x)); }
-template <int S> __device__ __forceinline__ float2 muli(float2 a) { return S > 0 ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }   // a * (S i)
+__device__ __forceinline__ cf cfma(cf a, cf b, cf c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ cf sfma(float a, cf b, cf c) { return __builtin_elementwise_fma(cf{a, a}, b, c); }
+template <int S> __device__ __forceinline__ cf muli(cf a) { return S > 0 ? cf{-a.y, a.x} : cf{a.y, -a.x}; }   // a * (S i)
+__device__ __forceinline__ cf cmul(cf a, cf b) { return cfma(a.yy, cf{-b.y, b.x}, a.xx * b); }
+// a + (S i) b in ONE packed add: the 90-degree rotation is the instruction's operand select (low result: a.x -+ b.y, high: a.y +- b.x)
+template <int S> __device__ __forceinline__ cf add_i(cf a, cf b) {
+  cf r;
+  if (S > 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 
 // r-point DFTs, y_k = sum_m x_m e^{S 2 pi i m k / r} (S = +1 inverse, -1 forward), in place
 template <int R, int S> struct Dft;
 template <int S> struct Dft<3, S> {
-  static __device__ __forceinline__ void run(float2 (&x)[3]) {
-    const float2 t1 = cadd(x[1], x[2]);
-    const float2 t2 = make_float2(fmaf(-0.5f, t1.x, x[0].x), fmaf(-0.5f, t1.y, x[0].y));
-    const float2 d = csub(x[1], x[2]);
-    const float2 t3 = muli<S>(make_float2(0.86602540378443865f * d.x, 0.86602540378443865f * d.y));
-    x[0] = cadd(x[0], t1);
-    x[1] = cadd(t2, t3);
-    x[2] = csub(t2, t3);
+  static __device__ __forceinline__ void run(cf (&x)[3]) {
+    const cf t1 = x[1] + x[2];
+    const cf t2 = sfma(-0.5f, t1, x[0]);
+    const cf t3 = 0.86602540378443865f * (x[1] - x[2]);
+    x[0] = x[0] + t1;
+    x[1] = add_i<S>(t2, t3);
+    x[2] = add_i<-S>(t2, t3);
   }
 };
 template <int S> struct Dft<4, S> {
-  static __device__ __forceinline__ void run(float2 (&x)[4]) {
-    const float2 a = cadd(x[0], x[2]), b = csub(x[0], x[2]), c = cadd(x[1], x[3]), d = muli<S>(csub(x[1], x[3]));
-    x[0] = cadd(a, c); x[2] = csub(a, c); x[1] = cadd(b, d); x[3] = csub(b, d);
+  static __device__ __forceinline__ void run(cf (&x)[4]) {
+    const cf a = x[0] + x[2], b = x[0] - x[2], c = x[1] + x[3], d = x[1] - x[3];
+    x[0] = a + c; x[2] = a - c; x[1] = add_i<S>(b, d); x[3] = add_i<-S>(b, d);
   }
 };
 template <int S> struct Dft<5, S> {
-  static __device__ __forceinline__ void run(float2 (&x)[5]) {
+  static __device__ __forceinline__ void run(cf (&x)[5]) {
     constexpr float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f, s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
-    const float2 t1 = cadd(x[1], x[4]), t2 = cadd(x[2], x[3]), t3 = csub(x[1], x[4]), t4 = csub(x[2], x[3]);
-    const float2 a1 = make_float2(fmaf(c2, t2.x, fmaf(c1, t1.x, x[0].x)), fmaf(c2, t2.y, fmaf(c1, t1.y, x[0].y)));
-    const float2 a2 = make_float2(fmaf(c1, t2.x, fmaf(c2, t1.x, x[0].x)), fmaf(c1, t2.y, fmaf(c2, t1.y, x[0].y)));
-    const float2 b1 = muli<S>(make_float2(fmaf(s2, t4.x, s1 * t3.x), fmaf(s2, t4.y, s1 * t3.y)));
-    const float2 b2 = muli<S>(make_float2(fmaf(-s1, t4.x, s2 * t3.x), fmaf(-s1, t4.y, s2 * t3.y)));
-    x[0] = cadd(x[0], cadd(t1, t2));
-    x[1] = cadd(a1, b1); x[4] = csub(a1, b1);
-    x[2] = cadd(a2, b2); x[3] = csub(a2, b2);
+    const cf t1 = x[1] + x[4], t2 = x[2] + x[3], t3 = x[1] - x[4], t4 = x[2] - x[3];
+    const cf a1 = sfma(c2, t2, sfma(c1, t1, x[0]));
+    const cf a2 = sfma(c1, t2, sfma(c2, t1, x[0]));
+    const cf b1 = sfma(s2, t4, s1 * t3);
+    const cf b2 = sfma(-s1, t4, s2 * t3);
+    x[0] = x[0] + (t1 + t2);
+    x[1] = add_i<S>(a1, b1); x[4] = add_i<-S>(a1, b1);
+    x[2] = add_i<S>(a2, b2); x[3] = add_i<-S>(a2, b2);
   }
 };
 template <int S> struct Dft<8, S> {
-  static __device__ __forceinline__ void run(float2 (&x)[8]) {
-    float2 e[4] = {x[0], x[2], x[4], x[6]}, o[4] = {x[1], x[3], x[5], x[7]};
+  static __device__ __forceinline__ void run(cf (&x)[8]) {
+    cf e[4] = {x[0], x[2], x[4], x[6]}, o[4] = {x[1], x[3], x[5], x[7]};
     Dft<4, S>::run(e);
     Dft<4, S>::run(o);
-    constexpr float h = 0.70710678118654752f, sf = (float)S;
-    o[1] = make_float2(h * (o[1].x - sf * o[1].y), h * (o[1].y + sf * o[1].x));       // * (1 + S i) / sqrt 2
-    o[2] = muli<S>(o[2]);
-    o[3] = make_float2(h * (-o[3].x - sf * o[3].y), h * (-o[3].y + sf * o[3].x));     // * (-1 + S i) / sqrt 2
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { x[k] = cadd(e[k], o[k]); x[k + 4] = csub(e[k], o[k]); }
+    constexpr float h = 0.70710678118654752f;
+    o[1] = h * add_i<S>(o[1], o[1]);            // * (1 + S i) / sqrt 2
+    o[3] = h * add_i<S>(-o[3], o[3]);           // * (-1 + S i) / sqrt 2
+    x[0] = e[0] + o[0]; x[4] = e[0] - o[0];
+    x[1] = e[1] + o[1]; x[5] = e[1] - o[1];
+    x[2] = add_i<S>(e[2], o[2]); x[6] = add_i<-S>(e[2], o[2]);      // o[2] * (S i)
+    x[3] = e[3] + o[3]; x[7] = e[3] - o[3];
   }
 };
 // Prime-factor (Good-Thomas) compositions: n = (R2 n1 + R1 n2) mod R1 R2 in, k = (A k1 + B k2) mod R1 R2 out with k = k1 (mod R1),
 // k = k2 (mod R2); the exponent n k then splits into n1 k1 / R1 + n2 k2 / R2 exactly: no twiddles.
 template <int R1, int R2, int A, int B, int S>
-__device__ __forceinline__ void dft_pfa(float2 (&x)[R1 * R2]) {
+__device__ __forceinline__ void dft_pfa(cf (&x)[R1 * R2]) {
   constexpr int R = R1 * R2;
-  float2 b[R1][R2];
+  cf b[R1][R2];
 #pragma unroll
   for (int n1 = 0; n1 < R1; ++n1) {
 #pragma unroll
@@ -104,7 +112,7 @@ __device__ __forceinline__ void dft_pfa(float2 (&x)[R1 * R2]) {
   }
 #pragma unroll
   for (int k2 = 0; k2 < R2; ++k2) {
-    float2 c[R1];
+    cf c[R1];
 #pragma unroll
     for (int n1 = 0; n1 < R1; ++n1) c[n1] = b[n1][k2];
     Dft<R1, S>::run(c);
@@ -112,26 +120,27 @@ __device__ __forceinline__ void dft_pfa(float2 (&x)[R1 * R2]) {
     for (int k1 = 0; k1 < R1; ++k1) x[(A * k1 + B * k2) % R] = c[k1];
   }
 }
-template <int S> struct Dft<15, S> { static __device__ __forceinline__ void run(float2 (&x)[15]) { dft_pfa<3, 5, 10, 6, S>(x); } };
-template <int S> struct Dft<12, S> { static __device__ __forceinline__ void run(float2 (&x)[12]) { dft_pfa<3, 4, 4, 9, S>(x); } };
+template <int S> struct Dft<15, S> { static __device__ __forceinline__ void run(cf (&x)[15]) { dft_pfa<3, 5, 10, 6, S>(x); } };
+template <int S> struct Dft<12, S> { static __device__ __forceinline__ void run(cf (&x)[12]) { dft_pfa<3, 4, 4, 9, S>(x); } };
 
-// One decimation-in-frequency stage of nb transforms of length N (row pitch PITCH), radix R on blocks of length L.
-// tw[k] = e^{+2 pi i k / N}.
-template <int N, int R, int L, int PITCH, int S>
-__device__ __forceinline__ void fft_stage(float2* buf, const float2* tw, int nb, int tid) {
+// One decimation-in-frequency stage of NB transforms of length N (row pitch PITCH), radix R on blocks of length L.
+// tw[k] = e^{+2 pi i k / N}.  Consecutive threads take the same butterfly of consecutive transforms: the LDS stride is the
+// (odd) pitch, which is bank-conflict free, and a wave reads its twiddles as broadcasts.
+template <int N, int R, int L, int PITCH, int S, int NB>
+__device__ __forceinline__ void fft_stage(cf* buf, const cf* tw, int tid) {
   constexpr int M = L / R, BF = N / R;
-  for (int t = tid; t < BF * nb; t += NT) {
-    const int v = t / BF, bf = t - v * BF;
+  for (int t = tid; t < BF * NB; t += NT) {
+    const int bf = t / NB, v = t - bf * NB;
     const int blk = bf / M, k = bf - blk * M;
-    float2* p = buf + v * PITCH + blk * L + k;
-    float2 x[R];
+    cf* p = buf + v * PITCH + blk * L + k;
+    cf x[R];
 #pragma unroll
     for (int m = 0; m < R; ++m) x[m] = p[m * M];
     Dft<R, S>::run(x);
     if (M > 1) {
 #pragma unroll
       for (int m = 1; m < R; ++m) {
-        float2 w = tw[(N / L) * k * m];
+        cf w = tw[(N / L) * k * m];
         if (S < 0) w.y = -w.y;
         x[m] = cmul(x[m], w);
       }
@@ -140,24 +149,24 @@ __device__ __forceinline__ void fft_stage(float2* buf, const float2* tw, int nb,
     for (int m = 0; m < R; ++m) p[m * M] = x[m];
   }
 }
-template <int PITCH, int S>
-__device__ __forceinline__ void fft120(float2* buf, const float2* tw, int nb, int tid) {
-  fft_stage<120, 8, 120, PITCH, S>(buf, tw, nb, tid); __syncthreads();
-  fft_stage<120, 15, 15, PITCH, S>(buf, tw, nb, tid); __syncthreads();
+template <int PITCH, int S, int NB>
+__device__ __forceinline__ void fft120(cf* buf, const cf* tw, int tid) {
+  fft_stage<120, 8, 120, PITCH, S, NB>(buf, tw, tid); __syncthreads();
+  fft_stage<120, 15, 15, PITCH, S, NB>(buf, tw, tid); __syncthreads();
 }
-template <int PITCH, int S>
-__device__ __forceinline__ void fft180(float2* buf, const float2* tw, int nb, int tid) {
-  fft_stage<180, 12, 180, PITCH, S>(buf, tw, nb, tid); __syncthreads();
-  fft_stage<180, 15, 15, PITCH, S>(buf, tw, nb, tid); __syncthreads();
+template <int PITCH, int S, int NB>
+__device__ __forceinline__ void fft180(cf* buf, const cf* tw, int tid) {
+  fft_stage<180, 12, 180, PITCH, S, NB>(buf, tw, tid); __syncthreads();
+  fft_stage<180, 15, 15, PITCH, S, NB>(buf, tw, tid); __syncthreads();
 }
 
-__device__ __forceinline__ void make_twiddles(float2* lds, int tid) {
+__device__ __forceinline__ void make_twiddles(cf* lds, int tid) {
   for (int k = tid; k < FH + FW; k += NT) {
     const bool a = k < FH;
     const int kk = a ? k : k - FH;
     double sn, cs;
     sincospi(2.0 * (double)kk / (double)(a ? FH : FW), &sn, &cs);
-    lds[(a ? TW120 : TW180) + kk] = make_float2((float)cs, (float)sn);
+    lds[(a ? TW120 : TW180) + kk] = cf{(float)cs, (float)sn};
   }
 }
 
@@ -183,14 +192,14 @@ using namespace smf;
 __global__ __launch_bounds__(NT) void sm_fwd_spectra_kernel(const float* __restrict__ hm, int Ca, const float* __restrict__ extra, int extra_ld,
                                                               const float* __restrict__ sc, const float* __restrict__ sh, float2* __restrict__ lhat_t, int C) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float2* lds = reinterpret_cast<float2*>(smem);
-  float2* cb = lds + CB;
-  float2* rb = lds + RB;
+  cf* lds = reinterpret_cast<cf*>(smem);
+  cf* cb = lds + CB;
+  cf* rb = lds + RB;
   const int tid = threadIdx.x;
   const int b = blockIdx.x / C, c = blockIdx.x - b * C;
   make_twiddles(lds, tid);
-  for (int i = tid; i < NROWP * PX; i += NT) rb[i] = make_float2(0.f, 0.f);
-  for (int i = tid; i < WC * PU; i += NT) cb[i] = make_float2(0.f, 0.f);
+  for (int i = tid; i < NROWP * PX; i += NT) rb[i] = cf{0.f, 0.f};
+  for (int i = tid; i < WC * PU; i += NT) cb[i] = cf{0.f, 0.f};
   __syncthreads();
   float* rbf = reinterpret_cast<float*>(rb);
   for (int pix = tid; pix < MHW; pix += NT) {
@@ -198,17 +207,17 @@ __global__ __launch_bounds__(NT) void sm_fwd_spectra_kernel(const float* __restr
     rbf[((y >> 1) * PX + x) * 2 + (y & 1)] = lik_of(hm, Ca, extra, extra_ld, sc, sh, (int64_t)b * MHW + pix, c);
   }
   __syncthreads();
-  fft180<PX, -1>(rb, lds + TW180, MH / 2, tid);
+  fft180<PX, -1, MH / 2>(rb, lds + TW180, tid);
   // Z_i = FFT(row 2i + i row 2i+1):  X_a[k] = (Z[k] + conj Z[-k]) / 2,  X_b[k] = (Z[k] - conj Z[-k]) / (2i)  ->  cb[k][2i], cb[k][2i+1]
   for (int t = tid; t < (MH / 2) * WC; t += NT) {
     const int i = t / WC, k = t - i * WC;
-    const float2 zk = rb[i * PX + pos180(k)], zn = rb[i * PX + pos180(k == 0 ? 0 : FW - k)];
-    cb[k * PU + 2 * i] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-    cb[k * PU + 2 * i + 1] = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+    const cf zk = rb[i * PX + pos180(k)], zn = rb[i * PX + pos180(k == 0 ? 0 : FW - k)];
+    cb[k * PU + 2 * i] = cf{0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)};
+    cb[k * PU + 2 * i + 1] = cf{0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x)};
   }
   __syncthreads();
-  fft120<PU, -1>(cb, lds + TW120, WC, tid);
-  float2* __restrict__ out = lhat_t + (size_t)blockIdx.x * (WC * FH);
+  fft120<PU, -1, WC>(cb, lds + TW120, tid);
+  cf* __restrict__ out = reinterpret_cast<cf*>(lhat_t) + (size_t)blockIdx.x * (WC * FH);
   for (int e = tid; e < WC * FH; e += NT) {
     const int v = e / FH, u = e - v * FH;
     out[e] = cb[v * PU + pos120(u)];
@@ -223,13 +232,25 @@ __global__ __launch_bounds__(NT) void sm_inv_finish_kernel(const float* __restri
                                                              const int* __restrict__ cond, const float* __restrict__ spb, float* __restrict__ logits, int K,
                                                              int C) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float2* lds = reinterpret_cast<float2*>(smem);
-  float2* cb = lds + CB;
-  float2* rb = lds + RB;
+  cf* lds = reinterpret_cast<cf*>(smem);
+  cf* cb = lds + CB;
+  cf* rb = lds + RB;
   const int tid = threadIdx.x;
   const int b = blockIdx.x / K, j = blockIdx.x - b * K;
   const int PJ = C - 1;
   make_twiddles(lds, tid);
+  // TF-1.x bilinear 61x91 -> 60x90 (main.py:89), the arithmetic of sm_fft.hip, separable: per output row {offset of window rows ylo |
+  // yhi << 16 in the row buffer, weight ty}, per output column {offset of window columns xlo | xhi << 16, weight tx}.  Window row yy is
+  // frame row 59 + yy = row pair yy >> 1, real / imaginary part; window column xx is frame column 89 + xx.
+  for (int t = tid; t < MH + MW; t += NT) {
+    const bool isy = t < MH;
+    const int o = isy ? t : t - MH;
+    const float f = __fmul_rn((float)o, isy ? 61.0f / 60.0f : 91.0f / 90.0f);
+    const int lo = (int)floorf(f), hi = min(lo + 1, isy ? 60 : 90);
+    const int olo = isy ? ((lo >> 1) * PX) * 2 + (lo & 1) : 2 * pos180(89 + lo);
+    const int ohi = isy ? ((hi >> 1) * PX) * 2 + (hi & 1) : 2 * pos180(89 + hi);
+    lds[TY + t] = cf{__uint_as_float((unsigned)olo | ((unsigned)ohi << 16)), f - (float)lo};
+  }
 
   float e[NPIX];
 #pragma unroll
@@ -238,26 +259,13 @@ __global__ __launch_bounds__(NT) void sm_inv_finish_kernel(const float* __restri
     e[i] = pix < MHW ? logf(lik_of(hm, Ca, extra, extra_ld, sc, sh, (int64_t)b * MHW + pix, j) + 1e-6f) : 0.f;
   }
 
-  // TF-1.x bilinear 61x91 -> 60x90 (main.py:89), the arithmetic of sm_fft.hip, separable: per output row {offset of window rows ylo |
-  // yhi << 16 in the row buffer, weight ty}, per output column {offset of window columns xlo | xhi << 16, weight tx}.  Window row yy is
-  // frame row 59 + yy = row pair yy >> 1, real / imaginary part; window column xx is frame column 89 + xx.
-  {
-    float2* tyx = lds + TY;
-    for (int t = tid; t < MH + MW; t += NT) {
-      const bool isy = t < MH;
-      const int o = isy ? t : t - MH;
-      const float f = __fmul_rn((float)o, isy ? 61.0f / 60.0f : 91.0f / 90.0f);
-      const int lo = (int)floorf(f), hi = min(lo + 1, isy ? 60 : 90);
-      const int olo = isy ? ((lo >> 1) * PX) * 2 + (lo & 1) : 2 * pos180(89 + lo);
-      const int ohi = isy ? ((hi >> 1) * PX) * 2 + (hi & 1) : 2 * pos180(89 + hi);
-      tyx[t] = make_float2(__uint_as_float((unsigned)olo | ((unsigned)ohi << 16)), f - (float)lo);
-    }
-  }
+  constexpr int NG = NT / WC;                       // packing step: thread = (column pk, row-pair group pg)
+  const int pk = tid % WC, pg = tid / WC;
 
-  float2 l[NE], q[NE];
+  cf l[NE], q[NE];
   auto request = [&](int p) __attribute__((always_inline)) {
-    const float2* __restrict__ ls = lhat_t + ((size_t)b * C + cond[p]) * (WC * FH);
-    const float2* __restrict__ qs = phat_t + (size_t)p * (WC * FH);
+    const cf* __restrict__ ls = reinterpret_cast<const cf*>(lhat_t) + ((size_t)b * C + cond[p]) * (WC * FH);
+    const cf* __restrict__ qs = reinterpret_cast<const cf*>(phat_t) + (size_t)p * (WC * FH);
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
       const int idx = tid + i * NT;
@@ -272,28 +280,25 @@ __global__ __launch_bounds__(NT) void sm_inv_finish_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
       const int idx = tid + i * NT;
-      if (idx < WC * FH) {
-        const int v = idx / FH, u = idx - v * FH;
-        cb[v * PU + u] = make_float2((l[i].x * q[i].x - l[i].y * q[i].y) * scale, (l[i].x * q[i].y + l[i].y * q[i].x) * scale);
+      if (idx < WC * FH) cb[idx + idx / FH] = scale * cmul(l[i], q[i]);       // [v][u] with pitch 121 = 120 + 1
+    }
+    __syncthreads();
+    fft120<PU, 1, WC>(cb, lds + TW120, tid);
+    // rows 59 + 2i (real part) and 60 + 2i (imaginary part) of the frame as ONE complex inverse transform: Z = X_a + i X_b with the
+    // Hermitian extension X[180 - k] = conj X[k]: one read of X_a[k], X_b[k] gives Z[k] and Z[180 - k]
+    if (pg < NG) {
+      const bool edge = pk == 0 || pk == FW / 2;       // DC / Nyquist: real by symmetry; a C2R transform ignores their imaginary parts
+      for (int i = pg; i < NROWP; i += NG) {
+        cf xa = cb[pk * PU + pos120(59 + 2 * i)];
+        cf xb = i < 30 ? cb[pk * PU + pos120(60 + 2 * i)] : cf{0.f, 0.f};
+        if (edge) { xa.y = 0.f; xb.y = 0.f; }
+        rb[i * PX + pk] = cf{xa.x - xb.y, xa.y + xb.x};
+        if (!edge) rb[i * PX + FW - pk] = cf{xa.x + xb.y, xb.x - xa.y};
       }
     }
     __syncthreads();
-    fft120<PU, 1>(cb, lds + TW120, WC, tid);
-    // rows 59 + 2i (real part) and 60 + 2i (imaginary part) of the frame as ONE complex inverse transform: Z = X_a + i X_b with the
-    // Hermitian extension X[180 - k] = conj X[k]
-    for (int t = tid; t < NROWP * FW; t += NT) {
-      const int i = t / FW, k = t - i * FW;
-      const int kk = k <= FW / 2 ? k : FW - k;
-      const float cj = k <= FW / 2 ? 1.f : -1.f;
-      float2 xa = cb[kk * PU + pos120(59 + 2 * i)];
-      float2 xb = i < 30 ? cb[kk * PU + pos120(60 + 2 * i)] : make_float2(0.f, 0.f);
-      xa.y *= cj; xb.y *= cj;
-      if (kk == 0 || kk == FW / 2) { xa.y = 0.f; xb.y = 0.f; }
-      rb[i * PX + k] = make_float2(xa.x - xb.y, xa.y + xb.x);
-    }
-    __syncthreads();
     if (qq + 1 < PJ) request(p + 1);      // lands behind the row transforms and the epilogue (the registers are free of the column butterflies now)
-    fft180<PX, 1>(rb, lds + TW180, NROWP, tid);
+    fft180<PX, 1, NROWP>(rb, lds + TW180, tid);
     // VALID window Cpre[yy][xx] = frame[59 + yy][89 + xx] -> resize -> + bias, + 1e-6, log
     const float* rbf = reinterpret_cast<const float*>(rb);
     const float* __restrict__ bias = spb + (size_t)p * MHW;
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(NT) void sm_inv_finish_kernel(const float* __restri
       const int pix = tid + i * NT;
       if (pix < MHW) {
         const int oy = pix / MW, ox = pix - oy * MW;
-        const float2 cy = lds[TY + oy], cx = lds[TX + ox];
+        const cf cy = lds[TY + oy], cx = lds[TX + ox];
         const unsigned ry = __float_as_uint(cy.x), rx = __float_as_uint(cx.x);
         const unsigned rlo = ry & 0xffffu, rhi = ry >> 16, plo = rx & 0xffffu, phi = rx >> 16;
         const float tl = rbf[rlo + plo], tr = rbf[rlo + phi];
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(NT) void sm_inv_finish_kernel(const float* __restri
         const float top = tl + (tr - tl) * cx.y;
         const float bot = bl + (br - bl) * cx.y;
         const float cv = top + (bot - top) * cy.y;
-        e[i] += logf((cv + bias[pix]) + 1e-6f);
+        e[i] += __logf((cv + bias[pix]) + 1e-6f);      // v_log_f32 * ln 2: the argument is a normal number >= 1e-6
       }
     }
     __syncthreads();      // the row buffer is rewritten by the next pair's packing step (its column buffer is free already)

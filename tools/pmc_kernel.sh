@@ -1,13 +1,13 @@
 #!/bin/bash
 # Counters of one kernel (name pattern) in the bf16 batch-256 step, one --pmc pass per counter group:
 #   bash tools/pmc_kernel.sh kxfold "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"
-# (run on the GPU box; JCM_LIB selects an experiment build)
+# (run on the GPU box; JCM_LIB selects an experiment build; PMC_CMD replaces the profiled command, e.g. "python tools/sm_time.py")
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 PAT=$1; shift
 for grp in "$@"; do
   rm -rf $OUT/prof_x
-  rocprofv3 --pmc $grp -d $OUT/prof_x -o p -- python bench.py --dtype bf16 --steps 1 --warmup 0 --cpu-images 0 --no-sm > /dev/null 2>&1
+  rocprofv3 --pmc $grp -d $OUT/prof_x -o p -- ${PMC_CMD:-python bench.py --dtype bf16 --steps 1 --warmup 0 --cpu-images 0 --no-sm} > /dev/null 2>&1
   python - "$PAT" $(find $OUT/prof_x -name "*.db") <<'PY'
 import sqlite3, sys
 con = sqlite3.connect(sys.argv[2])
