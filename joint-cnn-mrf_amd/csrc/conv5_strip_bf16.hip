@@ -1,0 +1,443 @@
+// 5x5 SAME convolution with 128-channel output tiles (conv2_*: 64 -> 128, conv3_*: 128 -> 256 of the part detector, main.py:45-47)
+// on bf16 MFMA with 768-pixel strips.
+//
+// The patch kernel of conv_igemm_bf16.hip gives these layers a 6x32 pixel x 128 channel tile: every tile streams all
+// 25 x Cin x 128 weights (0.8 MB at Cin = 128) from L2 for 192 pixels -- 190 FLOP per byte, 6.3 GB per launch -- and a wave
+// owns 3 x 1 fragments (4 LDS reads per 3 MFMAs).  Measured 20-37 % of the MFMA peak.  Here:
+//
+//   * M tile = 768 consecutive positions of one image's padded-flattened pixel axis s = r*P + 2 + x (P = W + 2: the two
+//     zero slots in front of a row are also the right pad of the row above), so a tap is ONE uniform shift
+//     (ky-2)*P + (kx-2) of the A operand and a tile streams the weights once per 768 pixels (4x less L2 traffic);
+//     8 waves x (3 x 4 fragments): 96 pixels x all 128 channels per wave, 7 LDS reads per 12 MFMAs as in conv_strip_bf16.hip.
+//     The last tile of an image runs with 2 or 1 fragment rows per wave.
+//   * 16-channel chunks.  The window of the input the tile reads (768 + 4P + 4 slots x 2 unit planes) is double-buffered
+//     and filled by LDS-DMA one row part at a time while the previous chunk computes (table in two VGPRs, v_readlane);
+//     weights: one kernel row = 5 taps x 16 channels x 128 columns (20 KB) per stage in a 3-deep ring, requested two
+//     stages ahead.  One barrier per stage (60 MFMAs per wave).
+//   * D^T = W^T X^T with the channel permutation of conv_strip_bf16.hip: a lane owns a pixel and stores 8 channels at a time.
+//   * A tile is short (77-154 k MFMA cycles per SIMD), so what surrounds the MFMA loop counts: the work groups are persistent, and
+//     the NEXT item's table, first window and first weight stages are issued before the CURRENT item's epilogue (which
+//     works from registers); bias / scale / shift of the item's 128 channels wait in LDS.  Measured on conv2_fullres: prologue
+//     17 k + epilogue 26 k cycles per tile beside 94 k of loop before this overlap.
+// Reference semantics: conv2d SAME stride 1 + bias + ReLU + BatchNorm (main.py:133-135,156-169).
+#include <cstdlib>
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace jcm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace c5 {
+constexpr int KS = 5, BN = 128, NR = 4, NW = 8, NT = NW * 64, MRMAX = 3;
+constexpr int NB = 3;                                  // weight ring depth (stages)
+constexpr int WST = KS * 2 * BN;                       // slots per weight stage: [kx][unit][BN]
+constexpr int WB0 = 0, XB0 = NB * WST;                 // weights first (a masked-off low lane of a row part may point below its buffer)
+constexpr int WINMAX = 1544;                           // window slots per unit plane: 768 + 4P + 4, W <= 191
+constexpr int XBUF = 2 * WINMAX;
+constexpr int EC0 = XB0 + 2 * XBUF;                    // epilogue constants, staged once per work group: [bias, scale, shift][CMAX] floats
+constexpr int CMAX = 256;                              // output channels (CoutP) the staging area holds
+constexpr int LDS_BYTES = (EC0 + 3 * CMAX / 4) * 16;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+constexpr int EPS = 3, NXI = 4 * EPS;                  // window-part table: entries per wave and stage (stages 0..3 of a chunk), entries per wave
+
+struct Geom {
+  int H, W, HW, P, S, tpi, nN, items, nparts;         // S = H*P padded positions per image; tpi tiles per image; nN 128-channel tiles
+};
+struct Item { int b, s0, n0, mr; };                    // image, first position, first output channel, fragment rows per wave
+struct Tab { unsigned ta, tb, nxs; };                  // the wave's window-part table (lanes 0..NXI-1) and its per-stage counts
+constexpr unsigned kZeroSrc = 0x40000000u;             // a source offset beyond any tensor this kernel accepts (< 2^30 bytes per image): the DMA delivers zeros
+}  // namespace c5
+
+using namespace c5;
+
+#ifdef C5EXP_TIMING
+#include <cstdio>
+__device__ unsigned long long c5_dbg[8];
+#define C5_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&c5_dbg[i], t_ - t_prev); t_prev = t_; } } while (0)
+#else
+#define C5_T(i) do { } while (0)
+#endif
+
+template <int TP>
+__device__ __forceinline__ void c5_a_load(f32x4 (&fa)[MRMAX], const unsigned (&aaddr)[MRMAX], int mr) {
+#pragma unroll
+  for (int f = 0; f < MRMAX; ++f)
+    if (f < mr) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[f]) : "v"(aaddr[f]), "i"(TP * 16) : "memory");
+}
+template <int TP, int G>
+__device__ __forceinline__ void c5_b_load(f32x4& fb, unsigned baddr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb) : "v"(baddr), "i"(TP * 2 * BN * 16 + G * 512) : "memory");
+}
+
+__device__ __forceinline__ Item c5_item(const ConvArgs& a, const Geom& gm, int L) {
+  Item it;
+  it.b = L % a.B;
+  const int r = L / a.B;
+  const int nt = r % gm.nN, ti = r / gm.nN;             // the channel tiles of one strip follow each other on the same CU: its window is an L2 hit
+  it.n0 = nt * BN;
+  it.s0 = ti * (NW * MRMAX * 32);
+  const int left = gm.S - it.s0;
+  it.mr = left > NW * 2 * 32 ? 3 : left > NW * 32 ? 2 : 1;
+  return it;
+}
+__device__ __forceinline__ auto c5_xrsrc(const ConvArgs& a, const Geom& gm, int b) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(static_cast<const __bf16*>(a.x)) + (size_t)b * gm.HW * a.Cin, 0, (int)((size_t)gm.HW * a.Cin * 2), 0x00020000);
+}
+__device__ __forceinline__ auto c5_wrsrc(const ConvArgs& a) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(static_cast<const __bf16*>(a.wp)), 0, (int)((size_t)KS * KS * a.Cin * a.CoutP * 2), 0x00020000);
+}
+// window part i of this wave (table lane i) for `chunk` into window `bufsel`
+template <class R>
+__device__ __forceinline__ void c5_xdma(const ConvArgs& a, const Geom& gm, R xrsrc, unsigned lds0, const Tab& t, int i, int chunk, int bufsel, int lane) {
+  const unsigned eb = __builtin_amdgcn_readlane(t.tb, i), ea = __builtin_amdgcn_readlane(t.ta, i);
+  if (!((eb >> 29) & 1u)) return;
+  auto dst = (__attribute__((address_space(3))) char*)(size_t)(lds0 + ((eb & 0x3fffu) + (unsigned)(bufsel * XBUF)) * 16u);
+  const unsigned lo = (eb >> 14) & 0x7fu, hi = (eb >> 21) & 0x7fu;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const bool p0 = (eb >> 28) & 1u;
+  const unsigned l16 = p0 ? lane16 - 32u : lane16;                                    // part 0: lanes 0, 1 are the pad slots in front of the row
+  unsigned xvoff = a.in_planar ? l16 : l16 * (unsigned)(a.Cin >> 3);
+  if ((p0 && lane < 2) || ((eb >> 30) & 1u)) xvoff = kZeroSrc;                        // pad slots, rows above / below the image
+  const unsigned xcs = a.in_planar ? (unsigned)(2 * gm.HW * 16) : 32u;                // source step per 16-channel chunk
+  const unsigned soff = ea + (unsigned)chunk * xcs;
+  if ((unsigned)lane - lo < hi - lo)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)dst, 16, xvoff, soff, 0, 0);
+}
+// weights of stage (chunk, ky) into ring slot `slot`: 20 pieces of 1 KB = (kx, unit, 64-column half); wave w moves pieces w, w+8, w+16.
+// Past the last stage the source offset runs past the item's data (or out of the buffer: zeros) into a free slot: no tail logic.
+template <class R>
+__device__ __forceinline__ void c5_wdma(const ConvArgs& a, R wrsrc, f32x4* lds, int wid, int lane, int n0, int chunk, int ky, int slot) {
+  const unsigned wtap = (unsigned)((a.Cin >> 3) * a.CoutP * 16);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int piece = wid + NW * i;
+    if (piece < KS * 4) {
+      const int kx = piece >> 2, unit = (piece >> 1) & 1, q = piece & 1;
+      const unsigned soff = (unsigned)(ky * KS + kx) * wtap + (unsigned)(((chunk * 2 + unit) * a.CoutP + n0 + q * 64) * 16);
+      f32x4* dst = lds + WB0 + slot * WST + (kx * 2 + unit) * BN + q * 64;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, (unsigned)lane * 16u, soff, 0, 0);
+    }
+  }
+}
+
+// Everything of an item that does not need the accumulators: the window-part table, chunk 0 and the first two weight stages requested
+// (NOT waited for).
+// Caller: every wave has finished its LDS reads of the previous item and drained its own DMAs.
+__device__ __forceinline__ Tab c5_setup(const ConvArgs& a, const Geom& gm, char* smem, const Item& it) {
+  f32x4* lds = reinterpret_cast<f32x4*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = gm.H, W = gm.W, P = gm.P, Cin = a.Cin;
+  const int WIN = NW * it.mr * 32 + 4 * P + 4;          // window: s0 - 2P - 2 ... + WIN
+  const int sB = it.s0 - 2 * P - 2;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  // Entry u = wid + 8 i (i = EPS * stage + j, stages 0..3) lives in lane i: one 64-slot part of one window row of one unit plane.  A row
+  // is [2 pad slots | W pixels]; the parts tile it from the pad on, so EVERY slot of the window is written by the DMAs of a chunk --
+  // pixels from the image, the pad slots and the rows above / below the image as zeros (source offset out of the buffer's range):
+  // nothing is zero-filled by hand.  tb = LDS slot (window 0) | lo << 14 | hi << 21 | part 0 << 28 | valid << 29 | zero row << 30;
+  // ta = source offset of the part's first pixel without the chunk term.  Zeros come from the per-LANE offset kZeroSrc (the
+  // lane offset is what the buffer's range check sees).
+  Tab t{0u, 0u, 0u};
+  if (lane < NXI) {
+    const int u = wid + NW * lane;
+    const int upr = 2 * gm.nparts;
+    const int r_lo = (sB >= 0 ? sB / P : -((-sB + P - 1) / P));
+    const int jr = u / upr, rem = u - jr * upr;
+    const int r = r_lo + jr, plane = rem & 1, part = rem >> 1;
+    const int rowbase = r * P + 64 * part - sB;                                     // window slot of lane 0
+    const int lo = max(0, -rowbase), hi = min(min(64, P - 64 * part), WIN - rowbase);
+    if (lo < hi) {
+      const bool inside = r >= 0 && r < H;
+      const int px0 = part == 0 ? r * W : r * W + 64 * part - 2;                   // pixel of lane 0 (part 0: of lane 2, behind the two pad lanes)
+      t.ta = !inside ? 0u : a.in_planar ? (unsigned)((plane * H * W + px0) * 16) : (unsigned)(px0 * Cin * 2 + plane * 16);
+      t.tb = (unsigned)(XB0 + plane * WINMAX + rowbase) | ((unsigned)lo << 14) | ((unsigned)hi << 21) | ((unsigned)(part == 0) << 28) | (1u << 29) |
+             ((unsigned)!inside << 30);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NXI; ++i) t.nxs += ((__builtin_amdgcn_readlane(t.tb, i) >> 29) & 1u) << (4 * (i / EPS));   // parts per stage, 4 bits each
+  __builtin_amdgcn_s_barrier();                           // every wave has drained its DMAs: the ring and the windows are free
+  const auto xrsrc = c5_xrsrc(a, gm, it.b);
+  const auto wrsrc = c5_wrsrc(a);
+#pragma unroll
+  for (int i = 0; i < NXI; ++i) c5_xdma(a, gm, xrsrc, lds0, t, i, 0, 0, lane);
+  c5_wdma(a, wrsrc, lds, wid, lane, it.n0, 0, 0, 0);
+  c5_wdma(a, wrsrc, lds, wid, lane, it.n0, 0, 1, 1);
+  return t;
+}
+
+// One item: the MFMA loop, then the NEXT item's setup, then this item's epilogue.
+template <int MR>
+__device__ __forceinline__ void c5_tile(const ConvArgs& a, const Geom& gm, char* smem, const Item& it, const Tab& t, bool has_next, const Item& nxt, Tab& tn) {
+  f32x4* lds = reinterpret_cast<f32x4*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int H = gm.H, W = gm.W, HW = gm.HW, P = gm.P;
+  const int Cin = a.Cin, Cout = a.Cout;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+#ifdef C5EXP_TIMING
+  unsigned long long t_prev = __builtin_readcyclecounter();
+#endif
+
+  unsigned aaddr[MRMAX], baddr;
+#pragma unroll
+  for (int f = 0; f < MR; ++f) aaddr[f] = lds0 + (unsigned)(XB0 + h * WINMAX + (wid * MR + f) * 32 + l31) * 16u;
+  // row m of a D^T fragment comes out in lane half (m>>2)&1, register 4*(m>>3) + (m&3): feeding channel 16h' + 4(m>>3) + (m&3) as row m
+  // makes a lane's 16 registers 16 consecutive channels (conv_strip_bf16.hip)
+  const int bperm = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
+  baddr = lds0 + (unsigned)(WB0 + h * BN + bperm) * 16u;
+
+  f32x16 acc[MR][NR];
+#pragma unroll
+  for (int f = 0; f < MR; ++f)
+#pragma unroll
+    for (int g = 0; g < NR; ++g)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[f][g][i] = 0.f;
+
+  const auto wrsrc = c5_wrsrc(a);
+  const auto xrsrc = c5_xrsrc(a, gm, it.b);
+  const int nw = wid < KS * 4 - 2 * NW ? 3 : 2;        // weight pieces this wave issues per stage
+
+  // the setup's requests (chunk 0, two weight stages) and its LDS writes have landed
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  C5_T(0);
+
+  const int nchunk = Cin >> 4;
+  const int G = nchunk * KS;                            // stages
+  const unsigned P16 = (unsigned)P * 16u;
+  f32x4 fa[2][MRMAX], fb[NR];
+  int chunk = 0, ky = 0, slot = 0;
+  int wchunk = 0, wky = 2;                              // weights of stage g + 2
+
+  // One stage = kernel row ky of one 16-channel chunk = 5 taps.  PAR = the A buffer of its first tap; 5 is odd, so PAR flips every
+  // stage: the loop body is a pair of stages (G is even: Cin % 32 == 0).
+  auto one_stage = [&](auto parc) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(parc)::value;
+    const int bufsel = chunk & 1;
+    // aaddr / baddr are running addresses: this stage's kernel row of this chunk's window, this stage's ring slot
+    // fragments of tap 0 (the barrier in front of this stage made the window and this stage's weights visible)
+    c5_a_load<0>(fa[PAR], aaddr, MR);
+    c5_b_load<0, 0>(fb[0], baddr); c5_b_load<0, 1>(fb[1], baddr); c5_b_load<0, 2>(fb[2], baddr); c5_b_load<0, 3>(fb[3], baddr);
+    auto step = [&](auto tpc) __attribute__((always_inline)) {
+      constexpr int TP = decltype(tpc)::value;
+      constexpr int cur = (TP + PAR) & 1;
+      constexpr bool more = TP + 1 < KS;
+      if constexpr (more) c5_a_load<TP + 1>(fa[cur ^ 1], aaddr, MR);
+#pragma unroll
+      for (int g = 0; g < NR; ++g) {
+        // queue invariant (conv_igemm_bf16.hip): MR + NR - 1 younger reads in flight when B[g] of this tap is needed
+        if (more) asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(MR + NR - 1) : "memory");
+        else if (g == 0) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+        else if (g == 1) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else if (g == 2) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < MR; ++f)
+          acc[f][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[g]), __builtin_bit_cast(bf16x8, fa[cur][f]), acc[f][g], 0, 0, 0);   // D^T: rows = channels, columns = pixels
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (more) {
+          if (g == 0) c5_b_load<TP + 1, 0>(fb[0], baddr);
+          if (g == 1) c5_b_load<TP + 1, 1>(fb[1], baddr);
+          if (g == 2) c5_b_load<TP + 1, 2>(fb[2], baddr);
+          if (g == 3) c5_b_load<TP + 1, 3>(fb[3], baddr);
+        }
+        // DMA of this stage: the weights of stage g + 2 first, then (stages 0..3 of a chunk) two parts of the next chunk's window
+        if (TP == 0 && g == 1) c5_wdma(a, wrsrc, lds, wid, lane, it.n0, wchunk, wky, slot == 0 ? NB - 1 : slot - 1);
+        if (TP == 1 && g == 1 && ky < KS - 1 && chunk + 1 < nchunk) c5_xdma(a, gm, xrsrc, lds0, t, EPS * ky, chunk + 1, bufsel ^ 1, lane);
+        if (TP == 2 && g == 1 && ky < KS - 1 && chunk + 1 < nchunk) c5_xdma(a, gm, xrsrc, lds0, t, EPS * ky + 1, chunk + 1, bufsel ^ 1, lane);
+        if (TP == 3 && g == 1 && ky < KS - 1 && chunk + 1 < nchunk) c5_xdma(a, gm, xrsrc, lds0, t, EPS * ky + 2, chunk + 1, bufsel ^ 1, lane);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{});
+    // next stage: one kernel row down, or back to row 0 of the other window; next ring slot
+    const bool last = ky == KS - 1;
+    const int oky = ky, oc = chunk;
+    {
+      const unsigned da = !last ? P16 : (unsigned)(bufsel ? -XBUF * 16 : XBUF * 16) - (unsigned)(KS - 1) * P16;
+#pragma unroll
+      for (int f = 0; f < MR; ++f) aaddr[f] += da;
+      baddr += slot == NB - 1 ? (unsigned)(-(NB - 1) * WST * 16) : (unsigned)(WST * 16);
+    }
+    chunk += last ? 1 : 0;
+    ky = last ? 0 : ky + 1;
+    const bool wlast = wky == KS - 1;
+    wchunk += wlast ? 1 : 0;
+    wky = wlast ? 0 : wky + 1;
+    slot = slot == NB - 1 ? 0 : slot + 1;
+    // This wave's pieces of the next stage's weights (requested one stage ago) have landed; everything younger may stay in flight: the
+    // previous stage's window parts, this stage's weights and window parts.  The chunk's last stage waits for all window parts.
+    {
+      const bool more_x = oc + 1 < nchunk;
+      const int nx1 = (last || !more_x) ? 0 : (int)((t.nxs >> (4 * oky)) & 15u);
+      const int nx0 = (oky == 0 || last || !more_x) ? 0 : (int)((t.nxs >> (4 * (oky - 1))) & 15u);
+      const int keep = nw + nx0 + nx1;
+      if (keep >= 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else if (keep == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (keep == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else if (keep == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (keep == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else if (keep == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (keep == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int g = 0; g < G; g += 2) {
+    one_stage(std::integral_constant<int, 0>{});
+    one_stage(std::integral_constant<int, 1>{});
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the look-ahead weight DMAs of the last stages (into free ring slots)
+  C5_T(1);
+
+  // ---- the next item's setup goes out now: its first window and weights land while this item's results are written
+  if (has_next) tn = c5_setup(a, gm, smem, nxt);
+  C5_T(2);
+
+  // ---- epilogue: bias, ReLU, folded BatchNorm -> bf16.  acc[f][g][i] = position s0 + (wid*MR+f)*32 + l31, channel n0 + 32 g + 16 h + i
+  // (the lane index goes through an empty asm: the addresses below are then computed HERE instead of being hoisted out of the
+  // persistent item loop and spilled around the MFMA loop)
+  int le = lane;
+  asm volatile("" : "+v"(le));
+  const int eh = le >> 5, el = le & 31;
+  int pp[MRMAX];
+  {
+    const float rP = 1.0f / (float)P;
+#pragma unroll
+    for (int f = 0; f < MR; ++f) {
+      const int s = it.s0 + (wid * MR + f) * 32 + el;
+      const int r = (int)(((float)s + 0.5f) * rP), c = s - r * P;      // exact: s < 2^22
+      pp[f] = (c >= 2 && r < H) ? r * W + c - 2 : -1;
+    }
+  }
+  const float* ec = reinterpret_cast<const float*>(lds + EC0) + it.n0;
+#pragma unroll
+  for (int g = 0; g < NR; ++g) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int cl = g * 32 + 16 * eh + 8 * u, co = it.n0 + cl;
+      if (co >= Cout) continue;                        // Cout % 8 == 0 (checked on the host)
+      float bi[8], sc[8], sh[8];
+      *reinterpret_cast<f32x4*>(bi) = *reinterpret_cast<const f32x4*>(ec + cl);
+      *reinterpret_cast<f32x4*>(bi + 4) = *reinterpret_cast<const f32x4*>(ec + cl + 4);
+      *reinterpret_cast<f32x4*>(sc) = *reinterpret_cast<const f32x4*>(ec + CMAX + cl);
+      *reinterpret_cast<f32x4*>(sc + 4) = *reinterpret_cast<const f32x4*>(ec + CMAX + cl + 4);
+      *reinterpret_cast<f32x4*>(sh) = *reinterpret_cast<const f32x4*>(ec + 2 * CMAX + cl);
+      *reinterpret_cast<f32x4*>(sh + 4) = *reinterpret_cast<const f32x4*>(ec + 2 * CMAX + cl + 4);
+#pragma unroll
+      for (int f = 0; f < MR; ++f) {
+        bf16x8 ov;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float v = acc[f][g][8 * u + k] + bi[k];
+          if (a.relu_bn) v = fmaxf(v, 0.f) * sc[k] + sh[k];
+          ov[k] = static_cast<__bf16>(v);
+        }
+        if (pp[f] >= 0) {
+          const size_t o = a.out_planar ? (((size_t)it.b * (Cout >> 3) + (co >> 3)) * HW + pp[f]) * 8      // [B][Cout/8][H*W][8]
+                                        : ((size_t)it.b * HW + pp[f]) * Cout + co;
+          *reinterpret_cast<bf16x8*>(static_cast<__bf16*>(a.out) + o) = ov;
+        }
+      }
+    }
+  }
+  C5_T(3);
+}
+
+__global__ __launch_bounds__(NT, 2) void conv5_strip_bf16_kernel(ConvArgs a, Geom gm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int L = blockIdx.x;
+  if (L >= gm.items) return;
+  {   // bias / scale / shift of all output channels, once (channels past Cout: 0 / 1 / 0)
+    float* ec = reinterpret_cast<float*>(reinterpret_cast<f32x4*>(smem) + EC0);
+    for (int i = threadIdx.x; i < 3 * CMAX; i += NT) {
+      const int k = i / CMAX, co = i - k * CMAX;
+      float v = k == 1 ? 1.f : 0.f;
+      if (co < a.Cout) v = k == 0 ? a.bias[co] : !a.relu_bn ? v : k == 1 ? a.scale[co] : a.shift[co];
+      ec[i] = v;
+    }
+  }
+  Item it = c5_item(a, gm, L);
+  Tab t = c5_setup(a, gm, smem, it);
+  for (;;) {
+    const int Ln = L + gridDim.x;
+    const bool has_next = Ln < gm.items;
+    const Item nxt = c5_item(a, gm, has_next ? Ln : L);
+    Tab tn{0u, 0u, 0u};
+    if (it.mr == 3) c5_tile<3>(a, gm, smem, it, t, has_next, nxt, tn);
+    else if (it.mr == 2) c5_tile<2>(a, gm, smem, it, t, has_next, nxt, tn);
+    else c5_tile<1>(a, gm, smem, it, t, has_next, nxt, tn);
+    if (!has_next) break;
+    L = Ln; it = nxt; t = tn;
+  }
+}
+
+namespace {
+bool make_geom(const ConvArgs& a, Geom& gm) {
+  if (a.CoutP % BN || a.CoutP < BN || a.CoutP > CMAX || a.Cout % 8 || a.Cout > a.CoutP || a.Cin % 32 || a.W < 8 || a.H < 1 || a.B < 1) return false;
+  const long long HW = (long long)a.H * a.W;
+  if (HW * a.Cin * 2 >= (1ll << 30) || (long long)a.H * (a.W + 2) >= (1 << 22) || (long long)KS * KS * a.Cin * a.CoutP * 2 >= (1ll << 31)) return false;
+  gm.H = a.H; gm.W = a.W; gm.HW = (int)HW; gm.P = a.W + 2;
+  gm.S = a.H * gm.P;
+  const int bm = NW * MRMAX * 32;
+  if (bm + 4 * gm.P + 4 > WINMAX) return false;
+  gm.tpi = (gm.S + bm - 1) / bm;
+  gm.nN = a.CoutP / BN;
+  if ((long long)gm.tpi * gm.nN * a.B >= (1ll << 30)) return false;
+  gm.items = gm.tpi * gm.nN * a.B;
+  gm.nparts = (gm.P + 63) / 64;                          // 64-slot parts of a window row (2 pad slots + W pixels)
+  // every row a window can touch needs its 2 * nparts entries in the table
+  const int rows = (bm + 4 * gm.P + 4 + gm.P - 1) / gm.P + 1;
+  if (rows * 2 * gm.nparts > NW * NXI) return false;
+  return true;
+}
+}  // namespace
+
+bool conv5_strip_bf16_supported(const ConvArgs& a, int ks) {
+  static const bool enabled = [] { const char* e = std::getenv("JCM_C5STRIP"); return !(e && e[0] == '0'); }();   // JCM_C5STRIP=0: A/B against the patch kernel
+  Geom gm;
+  return enabled && ks == KS && make_geom(a, gm);
+}
+
+hipError_t conv5_strip_bf16(const ConvArgs& a, hipStream_t st) {
+  Geom gm;
+  if (!make_geom(a, gm)) return hipErrorInvalidValue;
+  static std::atomic<int> ncu_cache[64];
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+  int ncu = ncu_cache[dev & 63].load();
+  if (!ncu) {
+    if (hipError_t e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess) return e;
+    ncu = ncu / 8 * 8;
+    if (ncu < 8) ncu = 8;
+    ncu_cache[dev & 63].store(ncu);
+  }
+  const int blocks = gm.items < ncu ? gm.items : ncu;
+  static LdsAttr attr;
+  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(conv5_strip_bf16_kernel), LDS_BYTES); e != hipSuccess) return e;
+  hipLaunchKernelGGL(conv5_strip_bf16_kernel, dim3(blocks), dim3(NT), LDS_BYTES, st, a, gm);
+#ifdef C5EXP_TIMING
+  {
+    unsigned long long h[8] = {0};
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(c5_dbg), sizeof(h));
+    fprintf(stderr, "c5 timing %dx%d Cin %d Cout %d (block 0 ticks): wait %llu  loop %llu  next-setup %llu  epilogue %llu  items/block %d\n", a.H, a.W, a.Cin, a.Cout, h[0], h[1],
+            h[2], h[3], (gm.items + blocks - 1) / blocks);
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(c5_dbg), z, sizeof(z));
+  }
+#endif
+  return hipGetLastError();
+}
+
+}  // namespace jcm

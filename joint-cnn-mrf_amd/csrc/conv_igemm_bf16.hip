@@ -384,6 +384,7 @@ hipError_t conv_igemm_bf16(const ConvArgs& a, int ks, bool out_f32, hipStream_t 
     return wide ? launch_b<CfgB<9, 6, 32, 32, 6, 1, 9>, true>(a, st) : launch_b<CfgB<9, 12, 16, 32, 6, 1, 9>, true>(a, st);
   }
   if (ks == 9 && bn == 256 && conv_strip_bf16_supported(a, ks)) return conv_strip_bf16(a, st);   // flattened strips: no padded slots
+  if (ks == 5 && bn == 128 && conv5_strip_bf16_supported(a, ks)) return conv5_strip_bf16(a, st);  // 768-pixel strips for the 5x5 layers
   if (a.in_planar || (a.out_planar && (out_f32 || a.Cout % 8))) return hipErrorInvalidValue;       // the patch kernels read NHWC
   if (ks == 9) {
     // 60x90 / 120x180 maps: 12x32 patch x 256 channels, rotating-B schedule (half the weight stream

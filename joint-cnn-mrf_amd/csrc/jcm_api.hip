@@ -330,6 +330,14 @@ bool takes_strip(const ConvLayer* L, int B, int H, int W) {
 }
 
 // model(x, n_joints), main.py:29-74.  x fp32 NHWC; intermediate activations fp32 or bf16.
+// will this bf16 5x5 layer run on conv5_strip_bf16_kernel (which reads and writes either activation layout)?
+bool takes_c5strip(const ConvLayer* L, int B, int H, int W) {
+  if (!L->wp_bf16 || L->ks != 5 || conv_igemm_bf16_bn(L->cout, L->ks) != 128 || L->cout % 8) return false;
+  ConvArgs a{};
+  a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout; a.CoutP = L->coutp_bf16;
+  return conv5_strip_bf16_supported(a, L->ks);
+}
+
 int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logits) {
   static const char* const kRes[3] = {"fullres", "halfres", "quarterres"};
   const ConvLayer* L4 = conv_of(c, "conv4_fullres");
@@ -388,15 +396,22 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
       if (!c->dry) HIP_TRY(max_pool_2x2(c1, p1, bf, B, h1, w1, L1->cout, c->stream));       // :45,53,62
     }
     void* c2 = act((size_t)B * h2 * w2 * L2->cout);
-    JCM_TRY(run_conv(c, "conv2_" + res, 1, p1, B, h2, w2, 1, c2, bf, false));              // :46,54,63
     const int h3 = cdiv2(h2), w3 = cdiv2(w2);
+    // bf16: conv2 -> pool2 -> conv3 on planar activations when both 5x5 layers take the strip kernel (its window rows are then 1-KB
+    // contiguous LDS-DMA reads; from NHWC every 16-byte unit of a pixel is a separate cache line).  A planar [B][C/8][H][W][8] tensor IS an
+    // NHWC tensor of B*C/8 images with 8 channels: the pooling kernel runs on it unchanged.
+    const int pl23 = bf && takes_c5strip(L2, B, h2, w2) && takes_c5strip(L3, B, h3, w3) ? 1 : 0;
+    JCM_TRY(run_conv(c, "conv2_" + res, 1, p1, B, h2, w2, 1, c2, bf, false, 0, pl23));     // :46,54,63
     void* p2 = act((size_t)B * h3 * w3 * L2->cout);
-    if (!c->dry) HIP_TRY(max_pool_2x2(c2, p2, bf, B, h2, w2, L2->cout, c->stream));         // :47,55,64
+    if (!c->dry) {                                                                          // :47,55,64
+      if (pl23) HIP_TRY(max_pool_2x2(c2, p2, bf, B * (L2->cout / 8), h2, w2, 8, c->stream));
+      else HIP_TRY(max_pool_2x2(c2, p2, bf, B, h2, w2, L2->cout, c->stream));
+    }
     void* c3 = act((size_t)B * h3 * w3 * L3->cout);
     const ConvLayer* L4r = conv_of(c, "conv4_" + res);
     if (!L4r) return fail(JCM_ERR_STATE, "part-detector parameters incomplete (conv4_" + res + ")");
     const int in4 = planar && L3->cout % 8 == 0 && takes_strip(L4r, B, h3, w3) ? 1 : 0;      // the patch kernels read NHWC
-    JCM_TRY(run_conv(c, "conv3_" + res, 1, p2, B, h3, w3, 1, c3, bf, false, 0, in4));      // :48,56,65
+    JCM_TRY(run_conv(c, "conv3_" + res, 1, p2, B, h3, w3, 1, c3, bf, false, pl23, in4));   // :48,56,65
     JCM_TRY(run_conv(c, "conv4_" + res, 1, c3, B, h3, w3, 1, x4[r], bf, false, in4, planar));   // :49,57,66
     c->arena_off = mark;
   }
@@ -852,7 +867,8 @@ int jcm_conv_kernel_name(jcm_handle h, const char* scope, int B, int H, int W, c
     a.CoutP = L->coutp_bf16;
     a.in_planar = 0;
     k = L->thin_bf16 ? (L->wp_kxfold && conv_kxfold_bf16_supported(a, L->ks) ? "conv_kxfold_bf16_kernel" : "conv_thin_bf16_kernel")
-        : (conv_igemm_bf16_bn(L->cout, L->ks) == 256 && conv_strip_bf16_supported(a, L->ks)) ? "conv_strip_bf16_kernel" : "conv_igemm_bf16_kernel";
+        : (conv_igemm_bf16_bn(L->cout, L->ks) == 256 && conv_strip_bf16_supported(a, L->ks)) ? "conv_strip_bf16_kernel"
+        : (L->ks == 5 && conv_igemm_bf16_bn(L->cout, L->ks) == 128 && conv5_strip_bf16_supported(a, L->ks)) ? "conv5_strip_bf16_kernel" : "conv_igemm_bf16_kernel";
   } else {
     const bool use_split = L->wp_split && (L->thin ? h->f32_conv == 2 : conv_split_supported(L->ks, L->cin, L->coutp_split, B, H, W, h->split_min_wgs));
     k = L->thin ? (use_split ? "conv_thin_split16_kernel" : "conv_thin_f32_kernel") : use_split ? "conv_split_kernel" : "conv_igemm_f32_kernel";

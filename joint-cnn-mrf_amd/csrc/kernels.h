@@ -71,6 +71,11 @@ hipError_t conv_thin_f32(const ConvArgs& a, hipStream_t st);
 // weights packed by pack_weights_bf16 with CoutP = 16
 hipError_t conv_thin_bf16(const ConvArgs& a, hipStream_t st);
 
+// ---- conv5_strip_bf16.hip : 5x5 SAME convolution in 128-channel output tiles on 768-pixel strips (bf16 in NHWC or planar, bf16 out NHWC or planar;
+// weights as packed by pack_weights_bf16); shapes: CoutP % 128 == 0, Cin % 32 == 0, Cout % 8 == 0, 8 <= W <= 191 and a window of at most 64 row parts
+bool conv5_strip_bf16_supported(const ConvArgs& a, int ks);
+hipError_t conv5_strip_bf16(const ConvArgs& a, hipStream_t st);
+
 // ---- conv_kxfold_bf16.hip : the 9-channel logits layer with the kernel columns folded into the MFMA's N axis (81 -> 96
 // columns, one 1x1-conv GEMM per kernel row, shifted sum over kx through LDS); bf16 in (NHWC or planar), fp32 NHWC out.
 // Weights packed by pack_weights_kxfold: [Cin/16][ky][unit][96][8].  Shapes: Cout == 9, Cin % 32 == 0, 82 <= W <= 90.

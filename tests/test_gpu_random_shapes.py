@@ -22,6 +22,10 @@ def cases():
         out.append((i, int(rs.choice([1, 2, 5])), int(rs.randint(6, 70)), int(rs.randint(9, 130)), cin, cout, ks))
     out.append((14, 3, 24, 64, 64, 128, 9))      # 12x32-patch path of the split kernels (W >= 64, H % 12 == 0)
     out.append((15, 2, 36, 96, 32, 256, 5))
+    # conv5_strip_bf16_kernel (5x5, 128 output channels, 768-position strips): the model's own maps, a last tile of 1, 2 and 3 fragment
+    # rows per wave, three row parts (W > 128), one (W < 64); 15x23 is too narrow for its 64-entry window table -> patch kernel
+    out += [(16, 2, 60, 90, 128, 128, 5), (17, 1, 120, 180, 64, 128, 5), (18, 3, 30, 45, 64, 128, 5), (19, 2, 15, 23, 128, 128, 5),
+            (20, 5, 17, 29, 32, 128, 5), (21, 1, 9, 128, 96, 128, 5)]
     return out
 
 
@@ -55,6 +59,8 @@ def test_conv_layer_random_shape(case):
     # bf16 ulp away; everything else must be identical.
     refb = O.conv_layer(x.astype(np.float64), p, ks, 1, 'c', emulate='bf16')
     eng = Engine(device=0, precision='bf16').load_params(p)
+    if i >= 16:
+        assert eng.conv_kernel_name("c", B, H, W) == "conv5_strip_bf16_kernel"
     gotb = eng.conv_layer(xd, 'c', 1, n_out=cout).cpu().numpy().astype(np.float64)
     eng.close()
     check_bf16_layer(gotb, refb)

@@ -24,7 +24,7 @@ for _ in range(5):
 torch.cuda.synchronize()
 eng.set_profile(False)
 print('kernel', eng.conv_kernel_name('conv6', B, 60, 90))
-for scope in ('conv4_fullres', 'conv5', 'conv6', 'conv4_quarterres'):
+for scope in os.environ.get('SCOPES', 'conv4_fullres conv5 conv6 conv4_quarterres').split():
     ms, n = eng.profile_read(scope)
     print('%-18s %.3f ms x %d' % (scope, ms / max(n, 1), n))
 eng.close()
