@@ -58,6 +58,10 @@ int jcm_abi_version(void);
  *              stream; read the totals back with jcm_profile_read.  Events come from a pool owned by the
  *              handle (created on first use, recycled by jcm_profile_read and by switching the option on,
  *              destroyed by jcm_destroy), so a profiled step only records.
+ * "sm_algo"  : any time; the pairwise convolutions of the spatial model (main.py:83-87): 3 (default) = every FFT in LDS
+ *              (sm_fused.hip); 2 = rocFFT with a split, row-pruned inverse; 0 = rocFFT 2-D transforms; 1 = direct
+ *              sliding-window kernel.  All four are HIP paths that pass the same parity tests; the training step always
+ *              uses route 2.  "sm_chunk": images per slice of routes 0 and 2 (default 32).
  * "micro_batch": any time; jcm_forward walks its batch in slices of this many images, so the workspace is
  *              sized for one slice (a rank's share of BASELINE configs[3]'s 2048 images fits).  0 (default)
  *              = 256 for bf16 handles, 64 for fp32 handles. */

@@ -62,7 +62,7 @@ using namespace strip;
 // EXP_* macros: timing experiments only (tools/exp_build.sh); they break the result on purpose.
 template <int TP>
 __device__ __forceinline__ void s_a_load(f32x4 (&fa)[MR], const unsigned (&aaddr)[MR]) {
-#ifdef EXP_NOLDS
+#if defined(EXP_NOLDS) || defined(EXP_NOALDS)
   return;
 #endif
 #pragma unroll
@@ -72,6 +72,9 @@ template <int TP, int G>      // column G of the wave's 4 B fragments: 32 channe
 __device__ __forceinline__ void s_b_load(f32x4& fb, unsigned baddr) {
 #ifdef EXP_NOLDS
   return;
+#endif
+#ifdef EXP_NOB1
+  if (TP == 1) return;
 #endif
   static_assert(TP * 2 * BN * 16 + G * 512 < 65536, "ds_read offset field is 16 bits");
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb) : "v"(baddr), "i"(TP * 2 * BN * 16 + G * 512) : "memory");
