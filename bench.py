@@ -127,6 +127,16 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
             tot_ms, tot_n = tot_ms + ms, tot_n + n
             tot_flops += fl / (16 if args.debug else 1) * B * args.steps if n else 0.0     # n = steps x micro-batches launches cover steps x B images
         kname = eng.conv_kernel_name('conv5', min(B, micro_batch or (256 if dtype == 'bf16' else 64)), 60, 90) if not args.debug else 'debug'
+        layer_ms = tot_ms / max(tot_n, 1)                      # average duration of a whole conv4_fullres / conv5 layer
+        freq_domain = kname.startswith('conv_fft')
+        if freq_domain:
+            # wide 9x9 layers in the frequency domain: the dominant kernel is the channel GEMM (rocBLAS cgemm_strided_batched, one complex
+            # matrix product per frequency of the 72 x 100 transform); its own algorithmic FLOPs, its own HIP events
+            tot_ms, tot_n, tot_flops = 0.0, 0, 0.0
+            for scope, (cin, cout) in {'conv4_fullres': (256, 512), 'conv5': (512, 512)}.items():
+                ms, n = eng.profile_read(scope + '/gemm')
+                tot_ms, tot_n = tot_ms + ms, tot_n + n
+                tot_flops += 8.0 * cin * cout * 72 * 51 * B * args.steps if n else 0.0
         launch_ms = tot_ms / max(tot_n, 1)                     # average launch duration (HIP events, launch stream)
         flops_launch = tot_flops / max(tot_n, 1)               # average algorithmic FLOPs per launch
         achieved = flops_launch / (launch_ms * 1e-3) / 1e12 if tot_n else None
@@ -151,8 +161,11 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
                        'batch_per_gpu': B, 'global_batch': world * B, 'micro_batch': min(mb, B), 'use_sm': use_sm,
                        'collective': 'all_gather coords int32 [B,2,9]'},
             'path_tflops': value * FLOPS_PD_SM / (16 if args.debug else 1) / 1e12,
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm 9x9, 60x90 maps (conv4_fullres + conv5 launches; %s)'
-                                   % ('fp32 operands as 3 bf16 parts, 6 x bf16 MFMA 32x32x16 per k16 step, 12x32 patch x 256 ch; achieved = executed bf16 MFMA FLOPs (6 x algorithmic) against the bf16 peak'
+            'roofline': {'bound': 'mfma', 'kernel': ('channel GEMM of the frequency-domain 9x9 layers (conv4_fullres + conv5; %s)' if freq_domain else
+                                                     'conv_igemm 9x9, 60x90 maps (conv4_fullres + conv5 launches; %s)')
+                                   % ('complex fp32, one [B x Cin] x [Cin x Cout] product per frequency of the 72 x 100 transform = 3672 per launch; achieved = 8 B Cin Cout x 3672 FLOP / GEMM time'
+                                      if freq_domain else
+                                      'fp32 operands as 3 bf16 parts, 6 x bf16 MFMA 32x32x16 per k16 step, 12x32 patch x 256 ch; achieved = executed bf16 MFMA FLOPs (6 x algorithmic) against the bf16 peak'
                                       if f32_conv == 'split' else
                                       'fp32 operands as 2 fp16 parts, 3 x fp16 MFMA 32x32x16 per k16 step, 12x32 patch x 256 ch; achieved = executed fp16 MFMA FLOPs (3 x algorithmic) against the fp16 peak'
                                       if f32_conv == 'split16' else
@@ -164,6 +177,10 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
                          'traffic': pmc_traffic('%s%s_b%d' % (dtype, '_' + f32_conv if f32_conv in ('split', 'split16') else '', B)) if not args.debug else None,
                          'launch_ms': launch_ms, 'launches': tot_n, 'flops_per_launch': flops_launch},
         }
+        if freq_domain:
+            out['roofline']['traffic'] = None      # no counter pass of the library kernel yet
+            out['roofline']['layer_ms'] = layer_ms  # the whole layer: four transform kernels + the GEMM
+            out['path_tflops_note'] = 'images/s x direct-convolution FLOPs: the wide 9x9 layers run 30x fewer in the frequency domain'
         if fp32_equiv is not None:
             out['roofline']['fp32_equivalent_tflops'] = fp32_equiv
             out['roofline']['x_fp32_mfma_peak'] = fp32_equiv / PEAK_TFLOPS['fp32']

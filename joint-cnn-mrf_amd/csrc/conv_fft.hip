@@ -1,0 +1,355 @@
+// 9x9 SAME convolution of the wide layers (conv4_*, conv5: 256/512 -> 512 channels) in the FREQUENCY domain, fp32.
+//
+// A 9x9 layer with 512 x 512 channels is 229 GFLOP per image as a direct convolution.  With the maps transformed once
+// (NY x NX >= (H+8) x (W+8): a linear convolution, nothing wraps) the layer is, for every frequency, one complex matrix product
+// over the channels:  Y[f][b][co] = sum_ci X[f][b][ci] * Wf[f][ci][co]  -- 8*Cin*Cout*NY*(NX/2+1) = 7.7 GFLOP per image for conv5
+// (72 x 100 transform of the 60 x 90 maps), 30x fewer.  The transforms add 0.4 GFLOP.  In fp32 this route is MORE accurate than the
+// fp32 MFMA accumulation chain it replaces (4e-7 of the output scale against 1.3e-6 for a sequential fp32 sum of the 41 472
+// products: DESIGN.md 4.1c), so it runs behind the same parity tests.
+//
+//   rows_fwd   (image, row, 64 channels)  : NHWC fp32, two adjacent channels = one complex number z = x_c + i x_{c+1}; complex FFT
+//                                           along x in LDS; X_c, X_{c+1} recovered through the Hermitian symmetry -> T[b][kx][y][ci]
+//   cols_fwd   (image, kx, 64 channels)   : FFT along y -> Xf[ky][kx][b][ci]   (frequency-major: a GEMM operand per frequency)
+//   rocBLAS cgemm_strided_batched         : the plain library GEMM, batch = NY * (NX/2+1) frequencies
+//   cols_inv   (image, kx, 64 channels)   : inverse along ky, rows 4 .. H+3 kept -> T[b][y][kx][co]
+//   rows_inv   (image, row, 64 channels)  : Z = Y_c + i Y_{c+1} (Hermitian extension), inverse complex FFT along kx, columns 4 .. W+3,
+//                                           1/(NY NX), bias, ReLU, folded BatchNorm -> NHWC fp32
+// The filter spectra Wf[f][ci][co] (flipped kernel: TF's conv2d is a correlation) are computed once per (layer, map size) at
+// jcm_finalize / first use: 7.7 GB for conv5.  FFTs: the in-LDS decimation-in-frequency stages of sm_fused.hip, channel-vectorised
+// (consecutive lanes = consecutive channels: every LDS and HBM access of a wave is one contiguous 512-byte run).
+// Reference semantics: conv2d SAME stride 1 + bias + ReLU + BatchNorm (main.py:133-135,156-169).
+#include <rocblas/rocblas.h>
+
+#include <mutex>
+
+#include "fft_lds.h"
+#include "kernels.h"
+
+namespace jcm {
+
+namespace cfft {
+using namespace fftl;
+constexpr int KS = 9, PAD = 4, CB = 64, NT = 256;      // channels per work group
+
+// radix chains (decimation in frequency, in place): the output X[n] sits at pos(n)
+template <int N> struct Plan;
+template <> struct Plan<100> { static constexpr int R1 = 4, R2 = 5, R3 = 5; };
+template <> struct Plan<72> { static constexpr int R1 = 8, R2 = 3, R3 = 3; };
+template <> struct Plan<60> { static constexpr int R1 = 4, R2 = 15, R3 = 1; };
+template <> struct Plan<40> { static constexpr int R1 = 8, R2 = 5, R3 = 1; };
+template <> struct Plan<32> { static constexpr int R1 = 8, R2 = 4, R3 = 1; };
+template <> struct Plan<24> { static constexpr int R1 = 8, R2 = 3, R3 = 1; };
+template <int N> __device__ __forceinline__ int pos(int n) {
+  using P = Plan<N>;
+  if constexpr (P::R3 == 1) return (n % P::R1) * (N / P::R1) + n / P::R1;
+  else return (n % P::R1) * (N / P::R1) + ((n / P::R1) % P::R2) * (N / (P::R1 * P::R2)) + n / (P::R1 * P::R2);
+}
+
+// one stage over CH channel lanes: buf[position][channel], tw[k] = e^{+2 pi i k / N}
+template <int N, int R, int L, int S, int CH>
+__device__ __forceinline__ void stage(cf* buf, const cf* tw, int tid) {
+  constexpr int M = L / R, BF = N / R;
+  for (int t = tid; t < BF * CH; t += NT) {
+    const int bf = t / CH, v = t % CH;
+    const int blk = bf / M, k = bf - blk * M;
+    cf* p = buf + (blk * L + k) * CH + v;
+    cf x[R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) x[m] = p[m * M * CH];
+    Dft<R, S>::run(x);
+    if (M > 1) {
+#pragma unroll
+      for (int m = 1; m < R; ++m) {
+        cf w = tw[(N / L) * k * m];
+        if (S < 0) w.y = -w.y;
+        x[m] = cmul(x[m], w);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < R; ++m) p[m * M * CH] = x[m];
+  }
+}
+template <int N, int S, int CH>
+__device__ __forceinline__ void fft(cf* buf, const cf* tw, int tid) {
+  using P = Plan<N>;
+  stage<N, P::R1, N, S, CH>(buf, tw, tid);
+  __syncthreads();
+  stage<N, P::R2, N / P::R1, S, CH>(buf, tw, tid);
+  __syncthreads();
+  if constexpr (P::R3 > 1) {
+    stage<N, P::R3, N / (P::R1 * P::R2), S, CH>(buf, tw, tid);
+    __syncthreads();
+  }
+}
+template <int N>
+__device__ __forceinline__ void twiddles(cf* tw, int tid) {
+  for (int k = tid; k < N; k += NT) {
+    double sn, cs;
+    sincospi(2.0 * (double)k / (double)N, &sn, &cs);
+    tw[k] = cf{(float)cs, (float)sn};
+  }
+}
+
+// ---- rows, forward: in NHWC fp32 [B][H][W][C] -> T[b][kx][y][c] complex, kx < NX/2+1
+template <int NX>
+__global__ __launch_bounds__(NT) void rows_fwd_kernel(const float* __restrict__ in, cf* __restrict__ T, int H, int W, int C) {
+  constexpr int CH = CB / 2, NXH = NX / 2 + 1;
+  __shared__ cf buf[NX * CH];
+  __shared__ cf tw[NX];
+  const int tid = threadIdx.x;
+  const int cblk = blockIdx.x % (C / CB), by = blockIdx.x / (C / CB);
+  const int y = by % H, b = by / H;
+  twiddles<NX>(tw, tid);
+  const cf* src = reinterpret_cast<const cf*>(in + ((size_t)(b * H + y) * W) * C + cblk * CB);
+  for (int t = tid; t < NX * CH; t += NT) {
+    const int x = t / CH, v = t % CH;
+    buf[t] = x < W ? src[(size_t)x * (C / 2) + v] : cf{0.f, 0.f};
+  }
+  __syncthreads();
+  fft<NX, -1, CH>(buf, tw, tid);
+  // Z = FFT(x_c + i x_{c+1}):  X_c[k] = (Z[k] + conj Z[-k]) / 2,  X_{c+1}[k] = (Z[k] - conj Z[-k]) / (2i)
+  float4* dst = reinterpret_cast<float4*>(T);
+  for (int t = tid; t < NXH * CH; t += NT) {
+    const int k = t / CH, v = t % CH;
+    const cf zk = buf[pos<NX>(k) * CH + v], zn = buf[pos<NX>(k == 0 ? 0 : NX - k) * CH + v];
+    dst[(((size_t)(b * NXH + k) * H + y) * C + cblk * CB) / 2 + v] =
+        make_float4(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y), 0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+  }
+}
+
+// ---- columns, forward: T[b][kx][y][c] -> Xf[ky][kx][b][c]
+template <int NY>
+__global__ __launch_bounds__(NT) void cols_fwd_kernel(const cf* __restrict__ T, cf* __restrict__ Xf, int B, int H, int NXH, int C) {
+  constexpr int CH = CB;
+  __shared__ cf buf[NY * CH];
+  __shared__ cf tw[NY];
+  const int tid = threadIdx.x;
+  const int cblk = blockIdx.x % (C / CB), bk = blockIdx.x / (C / CB);
+  const int kx = bk % NXH, b = bk / NXH;
+  twiddles<NY>(tw, tid);
+  const cf* src = T + ((size_t)(b * NXH + kx) * H) * C + cblk * CB;
+  for (int t = tid; t < NY * CH; t += NT) {
+    const int y = t / CH, v = t % CH;
+    buf[t] = y < H ? src[(size_t)y * C + v] : cf{0.f, 0.f};
+  }
+  __syncthreads();
+  fft<NY, -1, CH>(buf, tw, tid);
+  for (int t = tid; t < NY * CH; t += NT) {
+    const int ky = t / CH, v = t % CH;
+    Xf[((size_t)(ky * NXH + kx) * B + b) * C + cblk * CB + v] = buf[pos<NY>(ky) * CH + v];
+  }
+}
+
+// ---- columns, inverse: Yf[ky][kx][b][c] -> T[b][y][kx][c], y < H (row y of the output is row y + 4 of the linear convolution)
+template <int NY>
+__global__ __launch_bounds__(NT) void cols_inv_kernel(const cf* __restrict__ Yf, cf* __restrict__ T, int B, int H, int NXH, int C) {
+  constexpr int CH = CB;
+  __shared__ cf buf[NY * CH];
+  __shared__ cf tw[NY];
+  const int tid = threadIdx.x;
+  const int cblk = blockIdx.x % (C / CB), bk = blockIdx.x / (C / CB);
+  const int kx = bk % NXH, b = bk / NXH;
+  twiddles<NY>(tw, tid);
+  for (int t = tid; t < NY * CH; t += NT) {
+    const int ky = t / CH, v = t % CH;
+    buf[t] = Yf[((size_t)(ky * NXH + kx) * B + b) * C + cblk * CB + v];
+  }
+  __syncthreads();
+  fft<NY, 1, CH>(buf, tw, tid);
+  for (int t = tid; t < H * CH; t += NT) {
+    const int y = t / CH, v = t % CH;
+    T[((size_t)(b * H + y) * NXH + kx) * C + cblk * CB + v] = buf[pos<NY>(y + PAD) * CH + v];
+  }
+}
+
+// ---- rows, inverse + epilogue: T[b][y][kx][c] -> out NHWC fp32
+template <int NX>
+__global__ __launch_bounds__(NT) void rows_inv_kernel(const cf* __restrict__ T, float* __restrict__ out, const float* __restrict__ bias,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift, int relu_bn, int H, int W, int C,
+                                                      float norm) {
+  constexpr int CH = CB / 2, NXH = NX / 2 + 1;
+  __shared__ cf buf[NX * CH];
+  __shared__ cf tw[NX];
+  const int tid = threadIdx.x;
+  const int cblk = blockIdx.x % (C / CB), by = blockIdx.x / (C / CB);
+  const int y = by % H, b = by / H;
+  twiddles<NX>(tw, tid);
+  const float4* src = reinterpret_cast<const float4*>(T + ((size_t)(b * H + y) * NXH) * C + cblk * CB);
+  // Z = Y_c + i Y_{c+1} with the Hermitian extension Y[NX - k] = conj Y[k]; DC and Nyquist are real by symmetry
+  for (int t = tid; t < NXH * CH; t += NT) {
+    const int k = t / CH, v = t % CH;
+    float4 q = src[(size_t)k * (C / 2) + v];            // (Ya.re, Ya.im, Yb.re, Yb.im)
+    const bool edge = k == 0 || k == NX / 2;
+    if (edge) { q.y = 0.f; q.w = 0.f; }
+    buf[k * CH + v] = cf{q.x - q.w, q.y + q.z};
+    if (!edge) buf[(NX - k) * CH + v] = cf{q.x + q.w, q.z - q.y};
+  }
+  __syncthreads();
+  fft<NX, 1, CH>(buf, tw, tid);
+  const int c0 = cblk * CB;
+  cf* dst = reinterpret_cast<cf*>(out + ((size_t)(b * H + y) * W) * C + c0);
+  for (int t = tid; t < W * CH; t += NT) {
+    const int x = t / CH, v = t % CH;
+    const cf z = buf[pos<NX>(x + PAD) * CH + v];
+    const int c = c0 + 2 * v;
+    float v0 = z.x * norm + bias[c], v1 = z.y * norm + bias[c + 1];
+    if (relu_bn) {
+      v0 = fmaxf(v0, 0.f) * scale[c] + shift[c];
+      v1 = fmaxf(v1, 0.f) * scale[c + 1] + shift[c + 1];
+    }
+    dst[(size_t)x * (C / 2) + v] = cf{v0, v1};
+  }
+}
+
+// ---- filter spectra: HWIO fp32 [9][9][Cin][Cout] -> Wf[ky][kx][ci][co] = sum_{a,b} w[8-a][8-b][ci][co] e^{-2 pi i (ky a / NY + kx b / NX)}
+__global__ __launch_bounds__(256) void weight_spectra_kernel(const float* __restrict__ w, cf* __restrict__ Wf, int Cin, int Cout, int NY, int NX) {
+  __shared__ cf twy[128], twx[128];
+  const int tid = threadIdx.x;
+  for (int k = tid; k < NY + NX; k += 256) {
+    const bool isy = k < NY;
+    const int kk = isy ? k : k - NY;
+    double sn, cs;
+    sincospi(-2.0 * (double)kk / (double)(isy ? NY : NX), &sn, &cs);
+    (isy ? twy : twx)[kk] = cf{(float)cs, (float)sn};
+  }
+  __syncthreads();
+  const size_t io = (size_t)blockIdx.x * 256 + tid;           // ci * Cout + co
+  if (io >= (size_t)Cin * Cout) return;
+  float g[KS][KS];                                            // flipped kernel
+#pragma unroll
+  for (int a = 0; a < KS; ++a)
+#pragma unroll
+    for (int b = 0; b < KS; ++b) g[a][b] = w[((size_t)((KS - 1 - a) * KS + (KS - 1 - b))) * Cin * Cout + io];
+  const int NXH = NX / 2 + 1;
+  for (int kx = blockIdx.y; kx < NXH; kx += gridDim.y) {
+    cf ra[KS];
+#pragma unroll
+    for (int a = 0; a < KS; ++a) {
+      cf s = {0.f, 0.f};
+#pragma unroll
+      for (int b = 0; b < KS; ++b) s = sfma(g[a][b], twx[(kx * b) % NX], s);
+      ra[a] = s;
+    }
+    for (int ky = 0; ky < NY; ++ky) {
+      cf s = ra[0];
+#pragma unroll
+      for (int a = 1; a < KS; ++a) s = s + cmul(ra[a], twy[(ky * a) % NY]);
+      Wf[(size_t)(ky * NXH + kx) * Cin * Cout + io] = s;
+    }
+  }
+}
+
+struct Sizes { int NY, NX; };
+static bool pick(int need, int* n) {
+  static const int ok[] = {24, 32, 40, 60, 72, 100};
+  for (int v : ok)
+    if (v >= need) { *n = v; return true; }
+  return false;
+}
+static bool sizes_of(int H, int W, Sizes* s) { return pick(H + KS - 1, &s->NY) && pick(W + KS - 1, &s->NX); }
+
+template <int NX> static void launch_rows_fwd(const ConvArgs& a, cf* T, hipStream_t st) {
+  hipLaunchKernelGGL(rows_fwd_kernel<NX>, dim3(a.B * a.H * (a.Cin / CB)), dim3(NT), 0, st, static_cast<const float*>(a.x), T, a.H, a.W, a.Cin);
+}
+template <int NY> static void launch_cols_fwd(const ConvArgs& a, const cf* T, cf* Xf, int NXH, hipStream_t st) {
+  hipLaunchKernelGGL(cols_fwd_kernel<NY>, dim3(a.B * NXH * (a.Cin / CB)), dim3(NT), 0, st, T, Xf, a.B, a.H, NXH, a.Cin);
+}
+template <int NY> static void launch_cols_inv(const ConvArgs& a, const cf* Yf, cf* T, int NXH, hipStream_t st) {
+  hipLaunchKernelGGL(cols_inv_kernel<NY>, dim3(a.B * NXH * (a.Cout / CB)), dim3(NT), 0, st, Yf, T, a.B, a.H, NXH, a.Cout);
+}
+template <int NX> static void launch_rows_inv(const ConvArgs& a, const cf* T, float norm, hipStream_t st) {
+  hipLaunchKernelGGL(rows_inv_kernel<NX>, dim3(a.B * a.H * (a.Cout / CB)), dim3(NT), 0, st, T, static_cast<float*>(a.out), a.bias, a.scale, a.shift, a.relu_bn, a.H,
+                     a.W, a.Cout, norm);
+}
+#define CFFT_BY_SIZE(N, CALL)                    \
+  switch (N) {                                   \
+    case 24: CALL(24); break;                    \
+    case 32: CALL(32); break;                    \
+    case 40: CALL(40); break;                    \
+    case 60: CALL(60); break;                    \
+    case 72: CALL(72); break;                    \
+    default: CALL(100); break;                   \
+  }
+
+// one rocBLAS handle per device, shared by the engines of the process (created on first use; the stream is set per call)
+static rocblas_handle blas_for_device(int dev) {
+  static std::mutex mu;
+  static rocblas_handle hs[64] = {};
+  std::lock_guard<std::mutex> lk(mu);
+  if (!hs[dev & 63] && rocblas_create_handle(&hs[dev & 63]) != rocblas_status_success) hs[dev & 63] = nullptr;
+  return hs[dev & 63];
+}
+}  // namespace cfft
+
+using namespace cfft;
+
+bool conv_fft_supported(const ConvArgs& a, int ks) {
+  Sizes s;
+  return ks == KS && a.Cin % CB == 0 && a.Cout % CB == 0 && a.Cin >= 128 && a.Cout >= 128 && a.B >= 1 && sizes_of(a.H, a.W, &s);
+}
+size_t conv_fft_weight_bytes(int H, int W, int Cin, int Cout) {
+  Sizes s;
+  if (!sizes_of(H, W, &s)) return 0;
+  return (size_t)s.NY * (s.NX / 2 + 1) * Cin * Cout * sizeof(cf);
+}
+hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int Cin, int Cout, hipStream_t st) {
+  Sizes s;
+  if (!sizes_of(H, W, &s)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(weight_spectra_kernel, dim3((unsigned)(((size_t)Cin * Cout + 255) / 256), 8), dim3(256), 0, st, w_hwio, static_cast<cf*>(wf), Cin, Cout, s.NY,
+                     s.NX);
+  return hipGetLastError();
+}
+// scratch: T (the larger of the two row-transformed tensors) + Xf + Yf
+size_t conv_fft_workspace_bytes(const ConvArgs& a) {
+  Sizes s;
+  if (!sizes_of(a.H, a.W, &s)) return 0;
+  const size_t NXH = s.NX / 2 + 1, cmax = a.Cin > a.Cout ? a.Cin : a.Cout;
+  return ((size_t)a.B * NXH * a.H * cmax + (size_t)s.NY * NXH * a.B * (a.Cin + a.Cout)) * sizeof(cf);
+}
+// a.wp = the filter spectra of THIS map size; `work` = conv_fft_workspace_bytes(a) bytes.  *gemm_ms_events: optional pair of events
+// recorded around the GEMM (the dominant kernel of the layer) for the roofline record.
+hipError_t conv_fft_f32(const ConvArgs& a, void* work, hipEvent_t g0, hipEvent_t g1, hipStream_t st) {
+  Sizes s;
+  if (!conv_fft_supported(a, KS) || !sizes_of(a.H, a.W, &s)) return hipErrorInvalidValue;
+  const int NXH = s.NX / 2 + 1, F = s.NY * NXH;
+  const size_t cmax = a.Cin > a.Cout ? a.Cin : a.Cout;
+  cf* T = static_cast<cf*>(work);
+  cf* Xf = T + (size_t)a.B * NXH * a.H * cmax;
+  cf* Yf = Xf + (size_t)F * a.B * a.Cin;
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+  rocblas_handle bh = blas_for_device(dev);
+  if (!bh) return hipErrorUnknown;
+#define CALL(N) launch_rows_fwd<N>(a, T, st)
+  CFFT_BY_SIZE(s.NX, CALL)
+#undef CALL
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+#define CALL(N) launch_cols_fwd<N>(a, T, Xf, NXH, st)
+  CFFT_BY_SIZE(s.NY, CALL)
+#undef CALL
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+  // row-major Y[b][co] = X[b][ci] Wf[ci][co]  ==  column-major (Cout x B) = (Cout x Cin) (Cin x B)
+  {
+    static std::mutex mu;                       // the handle's stream is per call
+    std::lock_guard<std::mutex> lk(mu);
+    if (rocblas_set_stream(bh, st) != rocblas_status_success) return hipErrorUnknown;
+    if (g0 && hipEventRecord(g0, st) != hipSuccess) return hipErrorUnknown;
+    const rocblas_float_complex one{1.f, 0.f}, zero{0.f, 0.f};
+    const rocblas_status rs = rocblas_cgemm_strided_batched(
+        bh, rocblas_operation_none, rocblas_operation_none, a.Cout, a.B, a.Cin, &one, static_cast<const rocblas_float_complex*>(a.wp), a.Cout,
+        (rocblas_stride)a.Cin * a.Cout, reinterpret_cast<const rocblas_float_complex*>(Xf), a.Cin, (rocblas_stride)a.B * a.Cin, &zero,
+        reinterpret_cast<rocblas_float_complex*>(Yf), a.Cout, (rocblas_stride)a.B * a.Cout, F);
+    if (rs != rocblas_status_success) return hipErrorUnknown;
+    if (g1 && hipEventRecord(g1, st) != hipSuccess) return hipErrorUnknown;
+  }
+#define CALL(N) launch_cols_inv<N>(a, Yf, T, NXH, st)
+  CFFT_BY_SIZE(s.NY, CALL)
+#undef CALL
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+#define CALL(N) launch_rows_inv<N>(a, T, 1.0f / (float)(s.NY * s.NX), st)
+  CFFT_BY_SIZE(s.NX, CALL)
+#undef CALL
+  return hipGetLastError();
+}
+
+}  // namespace jcm

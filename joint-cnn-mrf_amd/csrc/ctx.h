@@ -98,6 +98,9 @@ struct jcm_ctx {
   const float** bias_ptrs = nullptr;
   int* cond0 = nullptr;         // single zero (jcm_conv_mrf)
   int sm_algo = 3;              // 0 = FFT (2-D rocFFT), 1 = direct sliding-window VALU kernel, 2 = rocFFT with split row-pruned inverse, 3 = fused LDS FFTs (sm_fused.hip)
+  int conv9_fft = 1;            // fp32 handles: wide 9x9 layers in the frequency domain (conv_fft.hip) when the shape allows; 0 = fp32 MFMA chain
+  struct FftW { void* p = nullptr; size_t bytes = 0; bool valid = false; };
+  std::map<std::string, FftW> fft_w;   // filter spectra per "<scope>@HxW", computed on first use, invalidated by refresh_derived
   int sm_chunk = 32;            // images per FFT slice (measured at B=256, split inverse: 64 -> 3.32 ms, 32 -> 3.10, 16 -> 3.26, 8 -> 3.83)
   int micro_batch = 0;          // jcm_forward walks a batch in slices of this many images (0 = 256 bf16 / 64 fp32)
   jcm::SmFft* fft = nullptr;

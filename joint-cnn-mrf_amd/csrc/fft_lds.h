@@ -1,0 +1,94 @@
+// Complex butterflies shared by the in-LDS FFT kernels (sm_fused.hip, conv_fft.hip).  A complex number is a 2-vector, so
+// that add / sub / scale / fma are ONE packed VALU instruction and the +-90 degree rotation of a butterfly is the operand
+// select of v_pk_add_f32.  Dft<R, S>::run(x): y_k = sum_m x_m e^{S 2 pi i m k / R}, in place (S = +1 inverse, -1 forward).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace jcm {
+namespace fftl {
+typedef float cf __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ cf cfma(cf a, cf b, cf c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ cf sfma(float a, cf b, cf c) { return __builtin_elementwise_fma(cf{a, a}, b, c); }
+template <int S> __device__ __forceinline__ cf muli(cf a) { return S > 0 ? cf{-a.y, a.x} : cf{a.y, -a.x}; }   // a * (S i)
+__device__ __forceinline__ cf cmul(cf a, cf b) { return cfma(a.yy, cf{-b.y, b.x}, a.xx * b); }
+// a + (S i) b in ONE packed add: the 90-degree rotation is the instruction's operand select (low result: a.x -+ b.y, high: a.y +- b.x)
+template <int S> __device__ __forceinline__ cf add_i(cf a, cf b) {
+  cf r;
+  if (S > 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// r-point DFTs, y_k = sum_m x_m e^{S 2 pi i m k / r} (S = +1 inverse, -1 forward), in place
+template <int R, int S> struct Dft;
+template <int S> struct Dft<3, S> {
+  static __device__ __forceinline__ void run(cf (&x)[3]) {
+    const cf t1 = x[1] + x[2];
+    const cf t2 = sfma(-0.5f, t1, x[0]);
+    const cf t3 = 0.86602540378443865f * (x[1] - x[2]);
+    x[0] = x[0] + t1;
+    x[1] = add_i<S>(t2, t3);
+    x[2] = add_i<-S>(t2, t3);
+  }
+};
+template <int S> struct Dft<4, S> {
+  static __device__ __forceinline__ void run(cf (&x)[4]) {
+    const cf a = x[0] + x[2], b = x[0] - x[2], c = x[1] + x[3], d = x[1] - x[3];
+    x[0] = a + c; x[2] = a - c; x[1] = add_i<S>(b, d); x[3] = add_i<-S>(b, d);
+  }
+};
+template <int S> struct Dft<5, S> {
+  static __device__ __forceinline__ void run(cf (&x)[5]) {
+    constexpr float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f, s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
+    const cf t1 = x[1] + x[4], t2 = x[2] + x[3], t3 = x[1] - x[4], t4 = x[2] - x[3];
+    const cf a1 = sfma(c2, t2, sfma(c1, t1, x[0]));
+    const cf a2 = sfma(c1, t2, sfma(c2, t1, x[0]));
+    const cf b1 = sfma(s2, t4, s1 * t3);
+    const cf b2 = sfma(-s1, t4, s2 * t3);
+    x[0] = x[0] + (t1 + t2);
+    x[1] = add_i<S>(a1, b1); x[4] = add_i<-S>(a1, b1);
+    x[2] = add_i<S>(a2, b2); x[3] = add_i<-S>(a2, b2);
+  }
+};
+template <int S> struct Dft<8, S> {
+  static __device__ __forceinline__ void run(cf (&x)[8]) {
+    cf e[4] = {x[0], x[2], x[4], x[6]}, o[4] = {x[1], x[3], x[5], x[7]};
+    Dft<4, S>::run(e);
+    Dft<4, S>::run(o);
+    constexpr float h = 0.70710678118654752f;
+    o[1] = h * add_i<S>(o[1], o[1]);            // * (1 + S i) / sqrt 2
+    o[3] = h * add_i<S>(-o[3], o[3]);           // * (-1 + S i) / sqrt 2
+    x[0] = e[0] + o[0]; x[4] = e[0] - o[0];
+    x[1] = e[1] + o[1]; x[5] = e[1] - o[1];
+    x[2] = add_i<S>(e[2], o[2]); x[6] = add_i<-S>(e[2], o[2]);      // o[2] * (S i)
+    x[3] = e[3] + o[3]; x[7] = e[3] - o[3];
+  }
+};
+// Prime-factor (Good-Thomas) compositions: n = (R2 n1 + R1 n2) mod R1 R2 in, k = (A k1 + B k2) mod R1 R2 out with k = k1 (mod R1),
+// k = k2 (mod R2); the exponent n k then splits into n1 k1 / R1 + n2 k2 / R2 exactly: no twiddles.
+template <int R1, int R2, int A, int B, int S>
+__device__ __forceinline__ void dft_pfa(cf (&x)[R1 * R2]) {
+  constexpr int R = R1 * R2;
+  cf b[R1][R2];
+#pragma unroll
+  for (int n1 = 0; n1 < R1; ++n1) {
+#pragma unroll
+    for (int n2 = 0; n2 < R2; ++n2) b[n1][n2] = x[(R2 * n1 + R1 * n2) % R];
+    Dft<R2, S>::run(b[n1]);
+  }
+#pragma unroll
+  for (int k2 = 0; k2 < R2; ++k2) {
+    cf c[R1];
+#pragma unroll
+    for (int n1 = 0; n1 < R1; ++n1) c[n1] = b[n1][k2];
+    Dft<R1, S>::run(c);
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) x[(A * k1 + B * k2) % R] = c[k1];
+  }
+}
+template <int S> struct Dft<15, S> { static __device__ __forceinline__ void run(cf (&x)[15]) { dft_pfa<3, 5, 10, 6, S>(x); } };
+template <int S> struct Dft<12, S> { static __device__ __forceinline__ void run(cf (&x)[12]) { dft_pfa<3, 4, 4, 9, S>(x); } };
+
+}  // namespace fftl
+}  // namespace jcm

@@ -2,6 +2,7 @@
 // the forward graph of main.py:29-74,94-125,522-531 as a sequence of kernel launches on one
 // HIP stream.  No tensor library types cross this boundary -- plain pointers and sizes.
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 
@@ -157,18 +158,58 @@ void prof_release_all(jcm_ctx* c, bool destroy) {
   }
 }
 
+// fp32 handles: does this layer run in the frequency domain (conv_fft.hip)?  Not while a training state exists (the filter spectra
+// would have to follow every update) and not for the thin logits layer.
+bool takes_fft(jcm_ctx* c, const ConvLayer* L, int B, int H, int W) {
+  static const bool env_on = [] { const char* e = std::getenv("JCM_CONV_FFT"); return !(e && e[0] == '0'); }();   // A/B switch
+  if (!env_on || !c->conv9_fft || c->precision != JCM_PRECISION_F32 || c->f32_conv != 0 || c->train || L->ks != 9 || L->thin || !L->w_raw) return false;
+  ConvArgs a{};
+  a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout;
+  return conv_fft_supported(a, L->ks);
+}
+static int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const void* x, int B, int H, int W, void* out) {
+  ConvArgs a{};
+  a.x = x; a.bias = L->bias; a.scale = L->scale; a.shift = L->shift; a.out = out;
+  a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout; a.CoutP = L->cout; a.relu_bn = L->has_bn ? 1 : 0;
+  const size_t mark = c->arena_off;
+  void* work = arena_alloc<char>(c, conv_fft_workspace_bytes(a));
+  c->arena_off = mark;                                   // scratch of this layer only: later layers run behind it on the stream
+  if (c->dry) return JCM_OK;
+  jcm_ctx::FftW& fw = c->fft_w[scope + "@" + std::to_string(H) + "x" + std::to_string(W)];
+  if (!fw.p) {
+    fw.bytes = conv_fft_weight_bytes(H, W, L->cin, L->cout);
+    JCM_TRY(dev_alloc(c, &fw.p, fw.bytes));
+  }
+  if (!fw.valid) {
+    HIP_TRY(conv_fft_pack_weights(L->w_raw, fw.p, H, W, L->cin, L->cout, c->stream));
+    fw.valid = true;
+  }
+  a.wp = fw.p;
+  hipEvent_t e0 = nullptr, e1 = nullptr, g0 = nullptr, g1 = nullptr;
+  JCM_TRY(prof_begin(c, &e0, &e1));
+  if (c->profile && (pool_get(c, &g0) != JCM_OK || pool_get(c, &g1) != JCM_OK)) { g0 = g1 = nullptr; }
+  const hipError_t e = conv_fft_f32(a, work, g0, g1, c->stream);
+  if (g0 && g1 && e == hipSuccess) c->prof[scope + "/gemm"].emplace_back(g0, g1);
+  else { if (g0) c->event_pool.push_back(g0); if (g1) c->event_pool.push_back(g1); }
+  prof_end(c, scope, e0, e1, e == hipSuccess);
+  if (e != hipSuccess) return fail(JCM_ERR_HIP, std::string("conv_fft_f32: ") + hipGetErrorString(e));
+  return JCM_OK;
+}
+
 // One conv layer.  Activations are fp32, or bf16 when the handle runs the bf16 path (`act_bf16`);
 // `out_f32` forces an fp32 result (the logits layer).
 int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int stride, const void* x, int B, int H, int W, int sub,
                    void* out, bool act_bf16, bool out_f32, int in_planar, int out_planar) {
-  if (c->dry) return JCM_OK;
   if (stride == 2) {
+    if (c->dry) return JCM_OK;
     if (!(L->ks == 5 && L->cin == 3 && L->has_bn))
       return fail(JCM_ERR_ARG, "stride-2 kernel exists for 5x5, Cin=3, BN layers only (" + scope + ")");
     HIP_TRY(conv1_5x5s2(static_cast<const float*>(x), L->w_raw, L->bias, L->scale, L->shift, out, act_bf16, B, H, W, sub,
                         L->cout, c->stream));
     return JCM_OK;
   }
+  if (stride == 1 && !act_bf16 && !out_f32 && takes_fft(c, L, B, H, W)) return run_conv_fft(c, L, scope, x, B, H, W, out);
+  if (c->dry) return JCM_OK;
   const void* wp = act_bf16 ? L->wp_bf16 : static_cast<const void*>(L->wp);
   if (stride != 1 || !wp) return fail(JCM_ERR_ARG, "no kernel for layer '" + scope + "' with stride " + std::to_string(stride));
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -194,6 +235,7 @@ static int weight_scale(jcm_ctx* c, const Tensor& w, float** wscale) {
 }
 
 int refresh_derived(jcm_ctx* c, bool first) {
+  for (auto& kv : c->fft_w) kv.second.valid = false;     // filter spectra follow the weights: recomputed on next use
   // ---- conv layers: every "<scope>/weights" of rank 4
   for (auto& kv : c->params) {
     const std::string& name = kv.first;
@@ -551,6 +593,10 @@ int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
     h->micro_batch = (int)value;
     return JCM_OK;
   }
+  if (k == "conv9_fft") {  // allowed at any time
+    h->conv9_fft = value != 0;
+    return JCM_OK;
+  }
   if (k == "sm_chunk") {  // allowed at any time
     if (value < 1) return fail(JCM_ERR_ARG, "sm_chunk must be >= 1");
     h->sm_chunk = (int)value;
@@ -621,7 +667,8 @@ int jcm_conv_layer(jcm_handle h, const char* scope, int stride, int last_layer, 
   if (!L) return fail(JCM_ERR_STATE, std::string("no conv layer '") + scope + "'");
   if ((last_layer != 0) == L->has_bn)
     return fail(JCM_ERR_ARG, std::string("last_layer flag disagrees with the BatchNorm parameters stored for '") + scope + "'");
-  if (h->precision == JCM_PRECISION_F32) return run_conv(h, scope, stride, x, B, H, W, 1, out, false, false);
+  if (h->precision == JCM_PRECISION_F32)      // (the frequency-domain route of the wide 9x9 layers takes its scratch from the arena)
+    return with_arena(h, [&] { return run_conv(h, scope, stride, x, B, H, W, 1, out, false, false); });
   // bf16 handle: the boundary stays fp32 NHWC; the layer runs exactly as inside the tower -- input rounded to bf16 (the
   // activation type of that path), bf16 MFMA kernel, bf16 result (fp32 for the logits layer) -- and is widened back.
   if (stride != 1) return fail(JCM_ERR_ARG, "bf16 handles run the stride-2 first layer fused with its pool inside jcm_pd_forward only");
@@ -872,6 +919,7 @@ int jcm_conv_kernel_name(jcm_handle h, const char* scope, int B, int H, int W, c
   } else {
     const bool use_split = L->wp_split && (L->thin ? h->f32_conv == 2 : conv_split_supported(L->ks, L->cin, L->coutp_split, B, H, W, h->split_min_wgs));
     k = L->thin ? (use_split ? "conv_thin_split16_kernel" : "conv_thin_f32_kernel") : use_split ? "conv_split_kernel" : "conv_igemm_f32_kernel";
+    if (takes_fft(h, L, B, H, W)) k = "conv_fft(rocblas_cgemm_strided_batched)";
   }
   std::snprintf(name, (size_t)cap, "%s", k);
   return JCM_OK;

@@ -19,7 +19,7 @@ def _hm_size(n):
 class Engine:
     """Owns a jcm_handle.  All tensor arguments are torch CUDA float32 NHWC, contiguous."""
 
-    def __init__(self, device=0, precision='fp32', n_joints=9, stream=None, f32_conv=None, split_min_wgs=None, micro_batch=None):
+    def __init__(self, device=0, precision='fp32', n_joints=9, stream=None, f32_conv=None, split_min_wgs=None, micro_batch=None, conv9_fft=None):
         if not torch.cuda.is_available():
             raise RuntimeError('joint-cnn-mrf_amd needs an MI355X (gfx950) GPU; torch.cuda.is_available() is False '
                                'and there is no CPU path')
@@ -40,6 +40,8 @@ class Engine:
             _lib.check(self._lib.jcm_set_option(self._h, b'f32_conv', {'exact': 0, 'split': 1, 'split16': 2}[f32_conv]), 'jcm_set_option(f32_conv)')
         if micro_batch is not None:   # forward() walks a batch in slices of this many images (default 256 bf16 / 64 fp32)
             self.set_micro_batch(micro_batch)
+        if conv9_fft is not None:     # False: the wide 9x9 layers of an fp32 engine on the fp32 MFMA chain instead of the frequency domain
+            self.set_conv9_fft(conv9_fft)
         if split_min_wgs is not None: # 0 forces the split kernels even on grids too small to pay off (parity tests at small batch)
             _lib.check(self._lib.jcm_set_option(self._h, b'split_min_wgs', int(split_min_wgs)), 'jcm_set_option(split_min_wgs)')
 
@@ -271,6 +273,11 @@ class Engine:
         (rocFFT 1-D columns, then only the 61 rows the VALID window needs) or 'direct' (LDS sliding-window
         VALU kernel).  All are HIP paths; bench/profiles compare them."""
         _lib.check(self._lib.jcm_set_option(self._h, b'sm_algo', {'fft': 0, 'direct': 1, 'fft_split': 2, 'fft_fused': 3}[algo]), 'jcm_set_option(sm_algo)')
+
+    def set_conv9_fft(self, on):
+        """fp32 engines: run the wide 9x9 layers in the frequency domain (in-LDS FFTs + one complex channel GEMM per frequency;
+        default) or on the fp32 MFMA accumulation chain.  Both pass the same parity tests."""
+        _lib.check(self._lib.jcm_set_option(self._h, b'conv9_fft', int(bool(on))), 'jcm_set_option(conv9_fft)')
 
     def set_micro_batch(self, n):
         """Images per internal slice of forward(): bounds the workspace when a rank holds a large share of a

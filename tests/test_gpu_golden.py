@@ -15,15 +15,17 @@ def dev(a):
     return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device='cuda:0')
 
 
-@pytest.mark.parametrize('f32_conv', ['exact', 'split', 'split16'])
+@pytest.mark.parametrize('f32_conv', ['exact', 'chain', 'split', 'split16'])
 @pytest.mark.parametrize('kind', ['init', 'trained'])
 def test_full_size_tower_vs_golden(kind, f32_conv):
-    """Both fp32 convolution algorithms to the same bar: the exact fp32 MFMA chain and the bf16x6 split
-    (conv_split.hip: fp32 operands as three bf16 parts, six products on the bf16 matrix cores)."""
+    """Every fp32 convolution algorithm to the same bar: 'exact' = the default fp32 engine (wide 9x9 layers in the frequency domain,
+    conv_fft.hip; everything else on the fp32 MFMA chain), 'chain' = the fp32 MFMA accumulation chain everywhere, 'split' / 'split16' =
+    fp32 operands as bf16 / fp16 parts on the 16-bit matrix cores (conv_split.hip)."""
     from joint_cnn_mrf_amd.engine import Engine
     x, torso, p = full_inputs()
     p.update(synth.make_sm_params(flic_priors(), kind=kind, seed=seeds()['sm']))
-    eng = Engine(device=0, f32_conv=f32_conv, split_min_wgs=0).load_params(p)
+    eng = Engine(device=0, f32_conv='exact' if f32_conv == 'chain' else f32_conv, split_min_wgs=0, conv9_fft=f32_conv != 'chain').load_params(p)
+    assert eng.conv_kernel_name('conv5', 2, 60, 90).startswith('conv_fft') == (f32_conv == 'exact')
     logits = eng.model(dev(x)).cpu().numpy()
     r = eng.forward(dev(x), dev(torso), use_sm=True)
     eng.close()
@@ -163,7 +165,8 @@ def test_repeatability_soak(precision, batch):
 
 
 def test_split_conv_layer_error_is_fp32_class():
-    """conv5 alone (K = 41472): the split kernel against the float64 oracle, next to the exact fp32 kernel."""
+    """conv5 alone (K = 41472): the split kernels and the frequency-domain route against the float64 oracle, next to the fp32
+    MFMA accumulation chain."""
     from joint_cnn_mrf_amd.engine import Engine
     import oracle.jcm_oracle as O64
     x, _torso, p = full_inputs()
@@ -171,17 +174,22 @@ def test_split_conv_layer_error_is_fp32_class():
     a = np.maximum(rs.standard_normal((1, 60, 90, 512)), 0).astype(np.float32)
     ref = O64.conv_layer(a.astype(np.float64), p, 9, 1, 'conv5')
     outs = {}
-    for algo in ('exact', 'split', 'split16'):
-        eng = Engine(device=0, f32_conv=algo, split_min_wgs=0).load_params(p)
+    for algo in ('exact', 'split', 'split16', 'fft'):
+        eng = Engine(device=0, f32_conv='exact' if algo == 'fft' else algo, split_min_wgs=0, conv9_fft=algo == 'fft').load_params(p)
+        assert eng.conv_kernel_name('conv5', 1, 60, 90).startswith('conv_fft') == (algo == 'fft')
         outs[algo] = eng.conv_layer(dev(a), 'conv5', 1, n_out=512).cpu().numpy().astype(np.float64)
         eng.close()
     scale = np.abs(ref).max()
+    e_fft, r_fft = np.abs(outs['fft'] - ref).max() / scale, np.sqrt(np.mean((outs['fft'] - ref) ** 2)) / scale
+    print('conv5 error / max|out|, frequency domain: max %.2e rms %.2e' % (e_fft, r_fft))
+    assert e_fft <= 3e-6        # measured 4e-7: below the sequential fp32 chain
     e_exact, e_split = np.abs(outs['exact'] - ref).max() / scale, np.abs(outs['split'] - ref).max() / scale
     r_exact, r_split = np.sqrt(np.mean((outs['exact'] - ref) ** 2)) / scale, np.sqrt(np.mean((outs['split'] - ref) ** 2)) / scale
     e16, r16 = np.abs(outs['split16'] - ref).max() / scale, np.sqrt(np.mean((outs['split16'] - ref) ** 2)) / scale
     print('conv5 error / max|out|: exact max %.2e rms %.2e, bf16x6 max %.2e rms %.2e, fp16x3 max %.2e rms %.2e' % (e_exact, r_exact, e_split, r_split, e16, r16))
     assert e16 <= 2e-5 and r16 <= 3 * r_exact + 1e-7
     assert e_exact <= 1e-5 and e_split <= 2e-5 and r_split <= 3 * r_exact + 1e-7      # the same error class
+    assert r_fft <= r_exact + 1e-7
 
 
 def test_split_kernels_match_exact_on_every_layer_shape():
@@ -189,7 +197,7 @@ def test_split_kernels_match_exact_on_every_layer_shape():
     (5x5 / 9x9, 128- / 256-channel tiles, 12x32 patches and whole-row tiles), forced onto small grids (batch 1 and 3)."""
     from joint_cnn_mrf_amd.engine import Engine
     p = synth.make_pd_params(debug=False, bn='trained')
-    engs = {a: Engine(device=0, f32_conv=a, split_min_wgs=0).load_params(p) for a in ('exact', 'split', 'split16')}
+    engs = {a: Engine(device=0, f32_conv=a, split_min_wgs=0, conv9_fft=False).load_params(p) for a in ('exact', 'split', 'split16')}
     rs = np.random.RandomState(1)
     shapes = [('conv2_fullres', 120, 180, 64, 128), ('conv3_fullres', 60, 90, 128, 256), ('conv4_fullres', 60, 90, 256, 512),
               ('conv5', 60, 90, 512, 512), ('conv2_halfres', 60, 90, 64, 128), ('conv3_halfres', 30, 45, 128, 256),

@@ -26,6 +26,9 @@ def cases():
     # rows per wave, three row parts (W > 128), one (W < 64); 15x23 is too narrow for its 64-entry window table -> patch kernel
     out += [(16, 2, 60, 90, 128, 128, 5), (17, 1, 120, 180, 64, 128, 5), (18, 3, 30, 45, 64, 128, 5), (19, 2, 15, 23, 128, 128, 5),
             (20, 5, 17, 29, 32, 128, 5), (21, 1, 9, 128, 96, 128, 5)]
+    # conv_fft (fp32, wide 9x9 layers in the frequency domain): the model's three map sizes (72x100, 40x60, 24x32 transforms) and a map
+    # that fills its 72x100 transform to the last row and column
+    out += [(22, 2, 60, 90, 256, 512, 9), (23, 1, 30, 45, 128, 128, 9), (24, 3, 15, 23, 128, 256, 9), (25, 1, 64, 92, 128, 128, 9)]
     return out
 
 
@@ -50,6 +53,8 @@ def test_conv_layer_random_shape(case):
     for mode, kw, tol in (('exact', dict(f32_conv='exact'), 2e-5), ('split', dict(f32_conv='split', split_min_wgs=0), 2e-5),
                           ('split16', dict(f32_conv='split16', split_min_wgs=0), 2e-5)):
         eng = Engine(device=0, **kw).load_params(p)
+        if i >= 22 and mode == 'exact':
+            assert eng.conv_kernel_name('c', B, H, W).startswith('conv_fft')
         got = eng.conv_layer(xd, 'c', 1, n_out=cout).cpu().numpy()
         eng.close()
         err = np.abs(got - ref).max() / scale
@@ -59,7 +64,7 @@ def test_conv_layer_random_shape(case):
     # bf16 ulp away; everything else must be identical.
     refb = O.conv_layer(x.astype(np.float64), p, ks, 1, 'c', emulate='bf16')
     eng = Engine(device=0, precision='bf16').load_params(p)
-    if i >= 16:
+    if 16 <= i <= 21:
         assert eng.conv_kernel_name("c", B, H, W) == "conv5_strip_bf16_kernel"
     gotb = eng.conv_layer(xd, 'c', 1, n_out=cout).cpu().numpy().astype(np.float64)
     eng.close()
