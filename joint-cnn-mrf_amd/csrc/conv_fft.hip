@@ -29,7 +29,7 @@ namespace jcm {
 
 namespace cfft {
 using namespace fftl;
-constexpr int KS = 9, PAD = 4, CB = 64, NT = 256;      // channels per work group
+constexpr int CB = 64, NT = 256;      // channels per work group; kernel sizes 9 and 5 (pad = (ks - 1) / 2 passed at launch)
 
 // radix chains (decimation in frequency, in place): the output X[n] sits at pos(n)
 template <int N> struct Plan;
@@ -140,9 +140,9 @@ __global__ __launch_bounds__(NT) void cols_fwd_kernel(const cf* __restrict__ T, 
   }
 }
 
-// ---- columns, inverse: Yf[ky][kx][b][c] -> T[b][y][kx][c], y < H (row y of the output is row y + 4 of the linear convolution)
+// ---- columns, inverse: Yf[ky][kx][b][c] -> T[b][y][kx][c], y < H (row y of the output is row y + pad of the linear convolution)
 template <int NY>
-__global__ __launch_bounds__(NT) void cols_inv_kernel(const cf* __restrict__ Yf, cf* __restrict__ T, int B, int H, int NXH, int C) {
+__global__ __launch_bounds__(NT) void cols_inv_kernel(const cf* __restrict__ Yf, cf* __restrict__ T, int B, int H, int NXH, int C, int pad) {
   constexpr int CH = CB;
   __shared__ cf buf[NY * CH];
   __shared__ cf tw[NY];
@@ -158,15 +158,15 @@ __global__ __launch_bounds__(NT) void cols_inv_kernel(const cf* __restrict__ Yf,
   fft<NY, 1, CH>(buf, tw, tid);
   for (int t = tid; t < H * CH; t += NT) {
     const int y = t / CH, v = t % CH;
-    T[((size_t)(b * H + y) * NXH + kx) * C + cblk * CB + v] = buf[pos<NY>(y + PAD) * CH + v];
+    T[((size_t)(b * H + y) * NXH + kx) * C + cblk * CB + v] = buf[pos<NY>(y + pad) * CH + v];
   }
 }
 
-// ---- rows, inverse + epilogue: T[b][y][kx][c] -> out NHWC fp32
+// ---- rows, inverse + epilogue: T[b][y][kx][c] (C channels, padded to a multiple of 64) -> out NHWC fp32 with Cout channels
 template <int NX>
 __global__ __launch_bounds__(NT) void rows_inv_kernel(const cf* __restrict__ T, float* __restrict__ out, const float* __restrict__ bias,
                                                       const float* __restrict__ scale, const float* __restrict__ shift, int relu_bn, int H, int W, int C,
-                                                      float norm) {
+                                                      int Cout, int pad, float norm) {
   constexpr int CH = CB / 2, NXH = NX / 2 + 1;
   __shared__ cf buf[NX * CH];
   __shared__ cf tw[NX];
@@ -187,23 +187,30 @@ __global__ __launch_bounds__(NT) void rows_inv_kernel(const cf* __restrict__ T, 
   __syncthreads();
   fft<NX, 1, CH>(buf, tw, tid);
   const int c0 = cblk * CB;
-  cf* dst = reinterpret_cast<cf*>(out + ((size_t)(b * H + y) * W) * C + c0);
+  float* dst = out + ((size_t)(b * H + y) * W) * Cout;
+  const bool pairs = (Cout & 1) == 0;                   // two channels = one aligned 8-byte store
   for (int t = tid; t < W * CH; t += NT) {
     const int x = t / CH, v = t % CH;
-    const cf z = buf[pos<NX>(x + PAD) * CH + v];
     const int c = c0 + 2 * v;
-    float v0 = z.x * norm + bias[c], v1 = z.y * norm + bias[c + 1];
+    if (c >= Cout) continue;
+    const cf z = buf[pos<NX>(x + pad) * CH + v];
+    const bool two = c + 1 < Cout;
+    float v0 = z.x * norm + bias[c], v1 = two ? z.y * norm + bias[c + 1] : 0.f;
     if (relu_bn) {
       v0 = fmaxf(v0, 0.f) * scale[c] + shift[c];
-      v1 = fmaxf(v1, 0.f) * scale[c + 1] + shift[c + 1];
+      if (two) v1 = fmaxf(v1, 0.f) * scale[c + 1] + shift[c + 1];
     }
-    dst[(size_t)x * (C / 2) + v] = cf{v0, v1};
+    float* o = dst + (size_t)x * Cout + c;
+    if (pairs) *reinterpret_cast<cf*>(o) = cf{v0, v1};
+    else { o[0] = v0; if (two) o[1] = v1; }
   }
 }
 
-// ---- filter spectra: HWIO fp32 [9][9][Cin][Cout] -> Wf[ky][kx][ci][co] = sum_{a,b} w[8-a][8-b][ci][co] e^{-2 pi i (ky a / NY + kx b / NX)}
-__global__ __launch_bounds__(256) void weight_spectra_kernel(const float* __restrict__ w, cf* __restrict__ Wf, int Cin, int Cout, int NY, int NX) {
-  __shared__ cf twy[128], twx[128];
+// ---- filter spectra: HWIO fp32 [k][k][Cin][Cout] -> Wf[ky][kx][ci][co < CoutP] = sum_{a,b} w[k-1-a][k-1-b][ci][co] e^{-2 pi i (ky a / NY + kx b / NX)}
+// (the flipped kernel: TF's conv2d is a correlation; channels Cout .. CoutP-1 are zero)
+template <int KS>
+__global__ __launch_bounds__(256) void weight_spectra_kernel(const float* __restrict__ w, cf* __restrict__ Wf, int Cin, int Cout, int CoutP, int NY, int NX) {
+  __shared__ cf twy[256], twx[256];
   const int tid = threadIdx.x;
   for (int k = tid; k < NY + NX; k += 256) {
     const bool isy = k < NY;
@@ -213,13 +220,14 @@ __global__ __launch_bounds__(256) void weight_spectra_kernel(const float* __rest
     (isy ? twy : twx)[kk] = cf{(float)cs, (float)sn};
   }
   __syncthreads();
-  const size_t io = (size_t)blockIdx.x * 256 + tid;           // ci * Cout + co
-  if (io >= (size_t)Cin * Cout) return;
+  const size_t io = (size_t)blockIdx.x * 256 + tid;           // ci * CoutP + co
+  if (io >= (size_t)Cin * CoutP) return;
+  const int ci = (int)(io / CoutP), co = (int)(io - (size_t)ci * CoutP);
   float g[KS][KS];                                            // flipped kernel
 #pragma unroll
   for (int a = 0; a < KS; ++a)
 #pragma unroll
-    for (int b = 0; b < KS; ++b) g[a][b] = w[((size_t)((KS - 1 - a) * KS + (KS - 1 - b))) * Cin * Cout + io];
+    for (int b = 0; b < KS; ++b) g[a][b] = co < Cout ? w[(((size_t)((KS - 1 - a) * KS + (KS - 1 - b))) * Cin + ci) * Cout + co] : 0.f;
   const int NXH = NX / 2 + 1;
   for (int kx = blockIdx.y; kx < NXH; kx += gridDim.y) {
     cf ra[KS];
@@ -234,7 +242,7 @@ __global__ __launch_bounds__(256) void weight_spectra_kernel(const float* __rest
       cf s = ra[0];
 #pragma unroll
       for (int a = 1; a < KS; ++a) s = s + cmul(ra[a], twy[(ky * a) % NY]);
-      Wf[(size_t)(ky * NXH + kx) * Cin * Cout + io] = s;
+      Wf[(size_t)(ky * NXH + kx) * Cin * CoutP + io] = s;
     }
   }
 }
@@ -246,7 +254,8 @@ static bool pick(int need, int* n) {
     if (v >= need) { *n = v; return true; }
   return false;
 }
-static bool sizes_of(int H, int W, Sizes* s) { return pick(H + KS - 1, &s->NY) && pick(W + KS - 1, &s->NX); }
+static bool sizes_of(int H, int W, int ks, Sizes* s) { return (ks == 9 || ks == 5) && pick(H + ks - 1, &s->NY) && pick(W + ks - 1, &s->NX); }
+static int pad64(int c) { return (c + CB - 1) / CB * CB; }
 
 template <int NX> static void launch_rows_fwd(const ConvArgs& a, cf* T, hipStream_t st) {
   hipLaunchKernelGGL(rows_fwd_kernel<NX>, dim3(a.B * a.H * (a.Cin / CB)), dim3(NT), 0, st, static_cast<const float*>(a.x), T, a.H, a.W, a.Cin);
@@ -254,12 +263,12 @@ template <int NX> static void launch_rows_fwd(const ConvArgs& a, cf* T, hipStrea
 template <int NY> static void launch_cols_fwd(const ConvArgs& a, const cf* T, cf* Xf, int NXH, hipStream_t st) {
   hipLaunchKernelGGL(cols_fwd_kernel<NY>, dim3(a.B * NXH * (a.Cin / CB)), dim3(NT), 0, st, T, Xf, a.B, a.H, NXH, a.Cin);
 }
-template <int NY> static void launch_cols_inv(const ConvArgs& a, const cf* Yf, cf* T, int NXH, hipStream_t st) {
-  hipLaunchKernelGGL(cols_inv_kernel<NY>, dim3(a.B * NXH * (a.Cout / CB)), dim3(NT), 0, st, Yf, T, a.B, a.H, NXH, a.Cout);
+template <int NY> static void launch_cols_inv(const ConvArgs& a, const cf* Yf, cf* T, int NXH, int pad, hipStream_t st) {
+  hipLaunchKernelGGL(cols_inv_kernel<NY>, dim3(a.B * NXH * (a.CoutP / CB)), dim3(NT), 0, st, Yf, T, a.B, a.H, NXH, a.CoutP, pad);
 }
-template <int NX> static void launch_rows_inv(const ConvArgs& a, const cf* T, float norm, hipStream_t st) {
-  hipLaunchKernelGGL(rows_inv_kernel<NX>, dim3(a.B * a.H * (a.Cout / CB)), dim3(NT), 0, st, T, static_cast<float*>(a.out), a.bias, a.scale, a.shift, a.relu_bn, a.H,
-                     a.W, a.Cout, norm);
+template <int NX> static void launch_rows_inv(const ConvArgs& a, const cf* T, int pad, float norm, hipStream_t st) {
+  hipLaunchKernelGGL(rows_inv_kernel<NX>, dim3(a.B * a.H * (a.CoutP / CB)), dim3(NT), 0, st, T, static_cast<float*>(a.out), a.bias, a.scale, a.shift, a.relu_bn, a.H,
+                     a.W, a.CoutP, a.Cout, pad, norm);
 }
 #define CFFT_BY_SIZE(N, CALL)                    \
   switch (N) {                                   \
@@ -285,34 +294,39 @@ using namespace cfft;
 
 bool conv_fft_supported(const ConvArgs& a, int ks) {
   Sizes s;
-  return ks == KS && a.Cin % CB == 0 && a.Cout % CB == 0 && a.Cin >= 128 && a.Cout >= 128 && a.B >= 1 && sizes_of(a.H, a.W, &s);
+  return a.Cin % CB == 0 && a.Cin >= CB && a.Cout >= 1 && a.B >= 1 && sizes_of(a.H, a.W, ks, &s);
 }
-size_t conv_fft_weight_bytes(int H, int W, int Cin, int Cout) {
+size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout) {
   Sizes s;
-  if (!sizes_of(H, W, &s)) return 0;
-  return (size_t)s.NY * (s.NX / 2 + 1) * Cin * Cout * sizeof(cf);
+  if (!sizes_of(H, W, ks, &s)) return 0;
+  return (size_t)s.NY * (s.NX / 2 + 1) * Cin * pad64(Cout) * sizeof(cf);
 }
-hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int Cin, int Cout, hipStream_t st) {
+hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, hipStream_t st) {
   Sizes s;
-  if (!sizes_of(H, W, &s)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(weight_spectra_kernel, dim3((unsigned)(((size_t)Cin * Cout + 255) / 256), 8), dim3(256), 0, st, w_hwio, static_cast<cf*>(wf), Cin, Cout, s.NY,
-                     s.NX);
+  if (!sizes_of(H, W, ks, &s)) return hipErrorInvalidValue;
+  const int CoutP = pad64(Cout);
+  const dim3 grid((unsigned)(((size_t)Cin * CoutP + 255) / 256), 8);
+  if (ks == 9) hipLaunchKernelGGL(weight_spectra_kernel<9>, grid, dim3(256), 0, st, w_hwio, static_cast<cf*>(wf), Cin, Cout, CoutP, s.NY, s.NX);
+  else hipLaunchKernelGGL(weight_spectra_kernel<5>, grid, dim3(256), 0, st, w_hwio, static_cast<cf*>(wf), Cin, Cout, CoutP, s.NY, s.NX);
   return hipGetLastError();
 }
 // scratch: T (the larger of the two row-transformed tensors) + Xf + Yf
-size_t conv_fft_workspace_bytes(const ConvArgs& a) {
+size_t conv_fft_workspace_bytes(const ConvArgs& a, int ks) {
   Sizes s;
-  if (!sizes_of(a.H, a.W, &s)) return 0;
-  const size_t NXH = s.NX / 2 + 1, cmax = a.Cin > a.Cout ? a.Cin : a.Cout;
-  return ((size_t)a.B * NXH * a.H * cmax + (size_t)s.NY * NXH * a.B * (a.Cin + a.Cout)) * sizeof(cf);
+  if (!sizes_of(a.H, a.W, ks, &s)) return 0;
+  const size_t NXH = s.NX / 2 + 1, cop = pad64(a.Cout), cmax = (size_t)a.Cin > cop ? a.Cin : cop;
+  return ((size_t)a.B * NXH * a.H * cmax + (size_t)s.NY * NXH * a.B * (a.Cin + cop)) * sizeof(cf);
 }
-// a.wp = the filter spectra of THIS map size; `work` = conv_fft_workspace_bytes(a) bytes.  *gemm_ms_events: optional pair of events
+// a.wp = the filter spectra of THIS map size and kernel size; `work` = conv_fft_workspace_bytes(a, ks) bytes.  g0 / g1: optional events
 // recorded around the GEMM (the dominant kernel of the layer) for the roofline record.
-hipError_t conv_fft_f32(const ConvArgs& a, void* work, hipEvent_t g0, hipEvent_t g1, hipStream_t st) {
+hipError_t conv_fft_f32(const ConvArgs& a0, int ks, void* work, hipEvent_t g0, hipEvent_t g1, hipStream_t st) {
   Sizes s;
-  if (!conv_fft_supported(a, KS) || !sizes_of(a.H, a.W, &s)) return hipErrorInvalidValue;
+  if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s)) return hipErrorInvalidValue;
+  ConvArgs a = a0;
+  a.CoutP = pad64(a.Cout);
+  const int pad = (ks - 1) / 2;
   const int NXH = s.NX / 2 + 1, F = s.NY * NXH;
-  const size_t cmax = a.Cin > a.Cout ? a.Cin : a.Cout;
+  const size_t cmax = a.Cin > a.CoutP ? a.Cin : a.CoutP;
   cf* T = static_cast<cf*>(work);
   cf* Xf = T + (size_t)a.B * NXH * a.H * cmax;
   cf* Yf = Xf + (size_t)F * a.B * a.Cin;
@@ -328,7 +342,7 @@ hipError_t conv_fft_f32(const ConvArgs& a, void* work, hipEvent_t g0, hipEvent_t
   CFFT_BY_SIZE(s.NY, CALL)
 #undef CALL
   if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-  // row-major Y[b][co] = X[b][ci] Wf[ci][co]  ==  column-major (Cout x B) = (Cout x Cin) (Cin x B)
+  // row-major Y[b][co] = X[b][ci] Wf[ci][co]  ==  column-major (CoutP x B) = (CoutP x Cin) (Cin x B)
   {
     static std::mutex mu;                       // the handle's stream is per call
     std::lock_guard<std::mutex> lk(mu);
@@ -336,17 +350,17 @@ hipError_t conv_fft_f32(const ConvArgs& a, void* work, hipEvent_t g0, hipEvent_t
     if (g0 && hipEventRecord(g0, st) != hipSuccess) return hipErrorUnknown;
     const rocblas_float_complex one{1.f, 0.f}, zero{0.f, 0.f};
     const rocblas_status rs = rocblas_cgemm_strided_batched(
-        bh, rocblas_operation_none, rocblas_operation_none, a.Cout, a.B, a.Cin, &one, static_cast<const rocblas_float_complex*>(a.wp), a.Cout,
-        (rocblas_stride)a.Cin * a.Cout, reinterpret_cast<const rocblas_float_complex*>(Xf), a.Cin, (rocblas_stride)a.B * a.Cin, &zero,
-        reinterpret_cast<rocblas_float_complex*>(Yf), a.Cout, (rocblas_stride)a.B * a.Cout, F);
+        bh, rocblas_operation_none, rocblas_operation_none, a.CoutP, a.B, a.Cin, &one, static_cast<const rocblas_float_complex*>(a.wp), a.CoutP,
+        (rocblas_stride)a.Cin * a.CoutP, reinterpret_cast<const rocblas_float_complex*>(Xf), a.Cin, (rocblas_stride)a.B * a.Cin, &zero,
+        reinterpret_cast<rocblas_float_complex*>(Yf), a.CoutP, (rocblas_stride)a.B * a.CoutP, F);
     if (rs != rocblas_status_success) return hipErrorUnknown;
     if (g1 && hipEventRecord(g1, st) != hipSuccess) return hipErrorUnknown;
   }
-#define CALL(N) launch_cols_inv<N>(a, Yf, T, NXH, st)
+#define CALL(N) launch_cols_inv<N>(a, Yf, T, NXH, pad, st)
   CFFT_BY_SIZE(s.NY, CALL)
 #undef CALL
   if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-#define CALL(N) launch_rows_inv<N>(a, T, 1.0f / (float)(s.NY * s.NX), st)
+#define CALL(N) launch_rows_inv<N>(a, T, pad, 1.0f / (float)(s.NY * s.NX), st)
   CFFT_BY_SIZE(s.NX, CALL)
 #undef CALL
   return hipGetLastError();

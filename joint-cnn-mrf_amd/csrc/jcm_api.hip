@@ -158,11 +158,11 @@ void prof_release_all(jcm_ctx* c, bool destroy) {
   }
 }
 
-// fp32 handles: does this layer run in the frequency domain (conv_fft.hip)?  Not while a training state exists (the filter spectra
-// would have to follow every update) and not for the thin logits layer.
+// fp32 handles: does this stride-1 layer run in the frequency domain (conv_fft.hip)?  Not while a training state exists (the filter
+// spectra would have to follow every update).
 bool takes_fft(jcm_ctx* c, const ConvLayer* L, int B, int H, int W) {
   static const bool env_on = [] { const char* e = std::getenv("JCM_CONV_FFT"); return !(e && e[0] == '0'); }();   // A/B switch
-  if (!env_on || !c->conv9_fft || c->precision != JCM_PRECISION_F32 || c->f32_conv != 0 || c->train || L->ks != 9 || L->thin || !L->w_raw) return false;
+  if (!env_on || !c->conv9_fft || c->precision != JCM_PRECISION_F32 || c->f32_conv != 0 || c->train || (L->ks != 9 && L->ks != 5) || L->cin == 3 || !L->w_raw) return false;
   ConvArgs a{};
   a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout;
   return conv_fft_supported(a, L->ks);
@@ -172,23 +172,23 @@ static int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope
   a.x = x; a.bias = L->bias; a.scale = L->scale; a.shift = L->shift; a.out = out;
   a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout; a.CoutP = L->cout; a.relu_bn = L->has_bn ? 1 : 0;
   const size_t mark = c->arena_off;
-  void* work = arena_alloc<char>(c, conv_fft_workspace_bytes(a));
+  void* work = arena_alloc<char>(c, conv_fft_workspace_bytes(a, L->ks));
   c->arena_off = mark;                                   // scratch of this layer only: later layers run behind it on the stream
   if (c->dry) return JCM_OK;
   jcm_ctx::FftW& fw = c->fft_w[scope + "@" + std::to_string(H) + "x" + std::to_string(W)];
   if (!fw.p) {
-    fw.bytes = conv_fft_weight_bytes(H, W, L->cin, L->cout);
+    fw.bytes = conv_fft_weight_bytes(H, W, L->ks, L->cin, L->cout);
     JCM_TRY(dev_alloc(c, &fw.p, fw.bytes));
   }
   if (!fw.valid) {
-    HIP_TRY(conv_fft_pack_weights(L->w_raw, fw.p, H, W, L->cin, L->cout, c->stream));
+    HIP_TRY(conv_fft_pack_weights(L->w_raw, fw.p, H, W, L->ks, L->cin, L->cout, c->stream));
     fw.valid = true;
   }
   a.wp = fw.p;
   hipEvent_t e0 = nullptr, e1 = nullptr, g0 = nullptr, g1 = nullptr;
   JCM_TRY(prof_begin(c, &e0, &e1));
   if (c->profile && (pool_get(c, &g0) != JCM_OK || pool_get(c, &g1) != JCM_OK)) { g0 = g1 = nullptr; }
-  const hipError_t e = conv_fft_f32(a, work, g0, g1, c->stream);
+  const hipError_t e = conv_fft_f32(a, L->ks, work, g0, g1, c->stream);
   if (g0 && g1 && e == hipSuccess) c->prof[scope + "/gemm"].emplace_back(g0, g1);
   else { if (g0) c->event_pool.push_back(g0); if (g1) c->event_pool.push_back(g1); }
   prof_end(c, scope, e0, e1, e == hipSuccess);
@@ -208,7 +208,7 @@ int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int
                         L->cout, c->stream));
     return JCM_OK;
   }
-  if (stride == 1 && !act_bf16 && !out_f32 && takes_fft(c, L, B, H, W)) return run_conv_fft(c, L, scope, x, B, H, W, out);
+  if (stride == 1 && !act_bf16 && takes_fft(c, L, B, H, W)) return run_conv_fft(c, L, scope, x, B, H, W, out);
   if (c->dry) return JCM_OK;
   const void* wp = act_bf16 ? L->wp_bf16 : static_cast<const void*>(L->wp);
   if (stride != 1 || !wp) return fail(JCM_ERR_ARG, "no kernel for layer '" + scope + "' with stride " + std::to_string(stride));

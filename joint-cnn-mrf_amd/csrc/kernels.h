@@ -71,14 +71,14 @@ hipError_t conv_thin_f32(const ConvArgs& a, hipStream_t st);
 // weights packed by pack_weights_bf16 with CoutP = 16
 hipError_t conv_thin_bf16(const ConvArgs& a, hipStream_t st);
 
-// ---- conv_fft.hip : 9x9 SAME convolution of the wide fp32 layers in the frequency domain (in-LDS FFTs + rocBLAS cgemm over the channels,
-// one matrix product per frequency); NHWC fp32 in / out, a.wp = filter spectra of this map size (conv_fft_pack_weights).
-// Shapes: Cin, Cout multiples of 64 and >= 128, H + 8 <= 100, W + 8 <= 100.
+// ---- conv_fft.hip : stride-1 SAME convolution (9x9, 5x5) of the fp32 path in the frequency domain (in-LDS FFTs + rocBLAS cgemm over the
+// channels, one matrix product per frequency); NHWC fp32 in / out, a.wp = filter spectra of this map and kernel size
+// (conv_fft_pack_weights; output channels padded to a multiple of 64).  Shapes: Cin % 64 == 0, H + k - 1 <= 100, W + k - 1 <= 100.
 bool conv_fft_supported(const ConvArgs& a, int ks);
-size_t conv_fft_weight_bytes(int H, int W, int Cin, int Cout);
-hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int Cin, int Cout, hipStream_t st);
-size_t conv_fft_workspace_bytes(const ConvArgs& a);
-hipError_t conv_fft_f32(const ConvArgs& a, void* work, hipEvent_t g0, hipEvent_t g1, hipStream_t st);   // g0/g1: optional events around the GEMM
+size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout);
+hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, hipStream_t st);
+size_t conv_fft_workspace_bytes(const ConvArgs& a, int ks);
+hipError_t conv_fft_f32(const ConvArgs& a, int ks, void* work, hipEvent_t g0, hipEvent_t g1, hipStream_t st);   // g0/g1: optional events around the GEMM
 
 // ---- conv5_strip_bf16.hip : 5x5 SAME convolution in 128-channel output tiles on 768-pixel strips (bf16 in NHWC or planar, bf16 out NHWC or planar;
 // weights as packed by pack_weights_bf16); shapes: CoutP % 128 == 0, Cin % 32 == 0, Cout % 8 == 0, 8 <= W <= 191 and a window of at most 64 row parts

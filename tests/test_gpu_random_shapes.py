@@ -50,11 +50,12 @@ def test_conv_layer_random_shape(case):
     ref = O.conv_layer(x.astype(np.float64), p, ks, 1, 'c')
     scale = np.abs(ref).max()
     xd = torch.as_tensor(x, device='cuda:0')
-    for mode, kw, tol in (('exact', dict(f32_conv='exact'), 2e-5), ('split', dict(f32_conv='split', split_min_wgs=0), 2e-5),
+    for mode, kw, tol in (('exact', dict(f32_conv='exact'), 2e-5), ('chain', dict(f32_conv='exact', conv9_fft=False), 2e-5),
+                          ('split', dict(f32_conv='split', split_min_wgs=0), 2e-5),
                           ('split16', dict(f32_conv='split16', split_min_wgs=0), 2e-5)):
         eng = Engine(device=0, **kw).load_params(p)
-        if i >= 22 and mode == 'exact':
-            assert eng.conv_kernel_name('c', B, H, W).startswith('conv_fft')
+        if mode in ('exact', 'chain'):      # 'exact' = the default fp32 engine: frequency domain whenever the shape allows
+            assert eng.conv_kernel_name('c', B, H, W).startswith('conv_fft') == (mode == 'exact' and cin % 64 == 0 and H + ks <= 101 and W + ks <= 101)
         got = eng.conv_layer(xd, 'c', 1, n_out=cout).cpu().numpy()
         eng.close()
         err = np.abs(got - ref).max() / scale
