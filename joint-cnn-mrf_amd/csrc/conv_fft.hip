@@ -33,6 +33,8 @@ constexpr int CB = 64, NT = 256;      // channels per work group; kernel sizes 9
 
 // radix chains (decimation in frequency, in place): the output X[n] sits at pos(n)
 template <int N> struct Plan;
+template <> struct Plan<192> { static constexpr int R1 = 8, R2 = 8, R3 = 3; };
+template <> struct Plan<128> { static constexpr int R1 = 8, R2 = 4, R3 = 4; };
 template <> struct Plan<100> { static constexpr int R1 = 4, R2 = 5, R3 = 5; };
 template <> struct Plan<72> { static constexpr int R1 = 8, R2 = 3, R3 = 3; };
 template <> struct Plan<60> { static constexpr int R1 = 4, R2 = 15, R3 = 1; };
@@ -118,9 +120,10 @@ __global__ __launch_bounds__(NT) void rows_fwd_kernel(const float* __restrict__ 
 }
 
 // ---- columns, forward: T[b][kx][y][c] -> Xf[ky][kx][b][c]
+template <int NY> constexpr int colblk() { return NY > 100 ? 32 : 64; }      // channels per work group of the column kernels (<= 64 KB of LDS)
 template <int NY>
 __global__ __launch_bounds__(NT) void cols_fwd_kernel(const cf* __restrict__ T, cf* __restrict__ Xf, int B, int H, int NXH, int C) {
-  constexpr int CH = CB;
+  constexpr int CH = colblk<NY>(), CB = CH;
   __shared__ cf buf[NY * CH];
   __shared__ cf tw[NY];
   const int tid = threadIdx.x;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(NT) void cols_fwd_kernel(const cf* __restrict__ T, 
 // ---- columns, inverse: Yf[ky][kx][b][c] -> T[b][y][kx][c], y < H (row y of the output is row y + pad of the linear convolution)
 template <int NY>
 __global__ __launch_bounds__(NT) void cols_inv_kernel(const cf* __restrict__ Yf, cf* __restrict__ T, int B, int H, int NXH, int C, int pad) {
-  constexpr int CH = CB;
+  constexpr int CH = colblk<NY>(), CB = CH;
   __shared__ cf buf[NY * CH];
   __shared__ cf tw[NY];
   const int tid = threadIdx.x;
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(256) void weight_spectra_kernel(const float* __rest
 
 struct Sizes { int NY, NX; };
 static bool pick(int need, int* n) {
-  static const int ok[] = {24, 32, 40, 60, 72, 100};
+  static const int ok[] = {24, 32, 40, 60, 72, 100, 128, 192};
   for (int v : ok)
     if (v >= need) { *n = v; return true; }
   return false;
@@ -261,10 +264,10 @@ template <int NX> static void launch_rows_fwd(const ConvArgs& a, cf* T, hipStrea
   hipLaunchKernelGGL(rows_fwd_kernel<NX>, dim3(a.B * a.H * (a.Cin / CB)), dim3(NT), 0, st, static_cast<const float*>(a.x), T, a.H, a.W, a.Cin);
 }
 template <int NY> static void launch_cols_fwd(const ConvArgs& a, const cf* T, cf* Xf, int NXH, hipStream_t st) {
-  hipLaunchKernelGGL(cols_fwd_kernel<NY>, dim3(a.B * NXH * (a.Cin / CB)), dim3(NT), 0, st, T, Xf, a.B, a.H, NXH, a.Cin);
+  hipLaunchKernelGGL(cols_fwd_kernel<NY>, dim3(a.B * NXH * (a.Cin / colblk<NY>())), dim3(NT), 0, st, T, Xf, a.B, a.H, NXH, a.Cin);
 }
 template <int NY> static void launch_cols_inv(const ConvArgs& a, const cf* Yf, cf* T, int NXH, int pad, hipStream_t st) {
-  hipLaunchKernelGGL(cols_inv_kernel<NY>, dim3(a.B * NXH * (a.CoutP / CB)), dim3(NT), 0, st, Yf, T, a.B, a.H, NXH, a.CoutP, pad);
+  hipLaunchKernelGGL(cols_inv_kernel<NY>, dim3(a.B * NXH * (a.CoutP / colblk<NY>())), dim3(NT), 0, st, Yf, T, a.B, a.H, NXH, a.CoutP, pad);
 }
 template <int NX> static void launch_rows_inv(const ConvArgs& a, const cf* T, int pad, float norm, hipStream_t st) {
   hipLaunchKernelGGL(rows_inv_kernel<NX>, dim3(a.B * a.H * (a.CoutP / CB)), dim3(NT), 0, st, T, static_cast<float*>(a.out), a.bias, a.scale, a.shift, a.relu_bn, a.H,
@@ -277,7 +280,9 @@ template <int NX> static void launch_rows_inv(const ConvArgs& a, const cf* T, in
     case 40: CALL(40); break;                    \
     case 60: CALL(60); break;                    \
     case 72: CALL(72); break;                    \
-    default: CALL(100); break;                   \
+    case 100: CALL(100); break;                  \
+    case 128: CALL(128); break;                  \
+    default: CALL(192); break;                   \
   }
 
 // one rocBLAS handle per device, shared by the engines of the process (created on first use; the stream is set per call)

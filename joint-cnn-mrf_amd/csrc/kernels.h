@@ -73,7 +73,7 @@ hipError_t conv_thin_bf16(const ConvArgs& a, hipStream_t st);
 
 // ---- conv_fft.hip : stride-1 SAME convolution (9x9, 5x5) of the fp32 path in the frequency domain (in-LDS FFTs + rocBLAS cgemm over the
 // channels, one matrix product per frequency); NHWC fp32 in / out, a.wp = filter spectra of this map and kernel size
-// (conv_fft_pack_weights; output channels padded to a multiple of 64).  Shapes: Cin % 64 == 0, H + k - 1 <= 100, W + k - 1 <= 100.
+// (conv_fft_pack_weights; output channels padded to a multiple of 64).  Shapes: Cin % 64 == 0, H + k - 1 <= 192, W + k - 1 <= 192.
 bool conv_fft_supported(const ConvArgs& a, int ks);
 size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout);
 hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, hipStream_t st);

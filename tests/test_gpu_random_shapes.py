@@ -28,7 +28,8 @@ def cases():
             (20, 5, 17, 29, 32, 128, 5), (21, 1, 9, 128, 96, 128, 5)]
     # conv_fft (fp32, wide 9x9 layers in the frequency domain): the model's three map sizes (72x100, 40x60, 24x32 transforms) and a map
     # that fills its 72x100 transform to the last row and column
-    out += [(22, 2, 60, 90, 256, 512, 9), (23, 1, 30, 45, 128, 128, 9), (24, 3, 15, 23, 128, 256, 9), (25, 1, 64, 92, 128, 128, 9)]
+    out += [(22, 2, 60, 90, 256, 512, 9), (23, 1, 30, 45, 128, 128, 9), (24, 3, 15, 23, 128, 256, 9), (25, 1, 64, 92, 128, 128, 9),
+            (26, 1, 120, 180, 64, 128, 5), (27, 2, 97, 121, 64, 64, 9)]      # 128 x 192 transforms (32-channel column blocks)
     return out
 
 
@@ -55,7 +56,7 @@ def test_conv_layer_random_shape(case):
                           ('split16', dict(f32_conv='split16', split_min_wgs=0), 2e-5)):
         eng = Engine(device=0, **kw).load_params(p)
         if mode in ('exact', 'chain'):      # 'exact' = the default fp32 engine: frequency domain whenever the shape allows
-            assert eng.conv_kernel_name('c', B, H, W).startswith('conv_fft') == (mode == 'exact' and cin % 64 == 0 and H + ks <= 101 and W + ks <= 101)
+            assert eng.conv_kernel_name('c', B, H, W).startswith('conv_fft') == (mode == 'exact' and cin % 64 == 0 and H + ks <= 193 and W + ks <= 193)
         got = eng.conv_layer(xd, 'c', 1, n_out=cout).cpu().numpy()
         eng.close()
         err = np.abs(got - ref).max() / scale
