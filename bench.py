@@ -140,7 +140,7 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
         launch_ms = tot_ms / max(tot_n, 1)                     # average launch duration (HIP events, launch stream)
         flops_launch = tot_flops / max(tot_n, 1)               # average algorithmic FLOPs per launch
         achieved = flops_launch / (launch_ms * 1e-3) / 1e12 if tot_n else None
-        peak = PEAK_TFLOPS[dtype]
+        peak = PEAK_TFLOPS['fp32' if freq_domain else dtype]     # the channel GEMM of the frequency-domain route is complex fp32
         fp32_equiv = None
         if f32_conv in ('split', 'split16') and achieved:      # the roofline of these kernels is the 16-bit matrix-core peak
             fp32_equiv = achieved
@@ -151,7 +151,7 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
         out = {
             'value': value, 'ms_per_step': dt / args.steps * 1e3,
             # the arithmetic the path computes in: exact fp32 MFMA chain, or fp32 operands carried as 16-bit parts
-            'dtype': 'bf16' if dtype == 'bf16' else {'split': 'f32(bf16x6)', 'split16': 'f32(fp16x3)'}.get(f32_conv, 'f32'),
+            'dtype': ('bf16+f32' if freq_domain else 'bf16') if dtype == 'bf16' else {'split': 'f32(bf16x6)', 'split16': 'f32(fp16x3)'}.get(f32_conv, 'f32'),
             'config': {'workload': '%s: batch=%d/GPU synthetic 480x720x3, part detector%s forward + argmax, %s%s%s'
                                    % (config_name or ('configs[1]' if dtype == 'fp32' else 'configs[2]'), B, ' + spatial model' if use_sm else '',
                                       dtype + (' operands, stride-1 layers as bf16x6 split MFMA' if f32_conv == 'split' else

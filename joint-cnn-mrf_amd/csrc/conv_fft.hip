@@ -92,9 +92,11 @@ __device__ __forceinline__ void twiddles(cf* tw, int tid) {
   }
 }
 
-// ---- rows, forward: in NHWC fp32 [B][H][W][C] -> T[b][kx][y][c] complex, kx < NX/2+1
-template <int NX>
-__global__ __launch_bounds__(NT) void rows_fwd_kernel(const float* __restrict__ in, cf* __restrict__ T, int H, int W, int C) {
+// ---- rows, forward: NHWC fp32 / NHWC bf16 / planar bf16 [B][C/8][H*W][8] -> T[b][kx][y][c] complex, kx < NX/2+1
+// LAYOUT: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar.  Two adjacent channels are one complex number.
+__device__ __forceinline__ cf bf16pair(unsigned bits) { return cf{__uint_as_float(bits << 16), __uint_as_float(bits & 0xffff0000u)}; }
+template <int NX, int LAYOUT>
+__global__ __launch_bounds__(NT) void rows_fwd_kernel(const void* __restrict__ in, cf* __restrict__ T, int H, int W, int C) {
   constexpr int CH = CB / 2, NXH = NX / 2 + 1;
   __shared__ cf buf[NX * CH];
   __shared__ cf tw[NX];
@@ -102,10 +104,20 @@ __global__ __launch_bounds__(NT) void rows_fwd_kernel(const float* __restrict__ 
   const int cblk = blockIdx.x % (C / CB), by = blockIdx.x / (C / CB);
   const int y = by % H, b = by / H;
   twiddles<NX>(tw, tid);
-  const cf* src = reinterpret_cast<const cf*>(in + ((size_t)(b * H + y) * W) * C + cblk * CB);
   for (int t = tid; t < NX * CH; t += NT) {
     const int x = t / CH, v = t % CH;
-    buf[t] = x < W ? src[(size_t)x * (C / 2) + v] : cf{0.f, 0.f};
+    cf z = {0.f, 0.f};
+    if (x < W) {
+      if constexpr (LAYOUT == 0) {
+        z = reinterpret_cast<const cf*>(static_cast<const float*>(in) + ((size_t)(b * H + y) * W + x) * C + cblk * CB)[v];
+      } else if constexpr (LAYOUT == 1) {
+        z = bf16pair(reinterpret_cast<const unsigned*>(static_cast<const __bf16*>(in) + ((size_t)(b * H + y) * W + x) * C + cblk * CB)[v]);
+      } else {
+        const int c = cblk * CB + 2 * v;
+        z = bf16pair(*reinterpret_cast<const unsigned*>(static_cast<const __bf16*>(in) + (((size_t)b * (C >> 3) + (c >> 3)) * H * W + (size_t)y * W + x) * 8 + (c & 7)));
+      }
+    }
+    buf[t] = z;
   }
   __syncthreads();
   fft<NX, -1, CH>(buf, tw, tid);
@@ -165,9 +177,10 @@ __global__ __launch_bounds__(NT) void cols_inv_kernel(const cf* __restrict__ Yf,
   }
 }
 
-// ---- rows, inverse + epilogue: T[b][y][kx][c] (C channels, padded to a multiple of 64) -> out NHWC fp32 with Cout channels
-template <int NX>
-__global__ __launch_bounds__(NT) void rows_inv_kernel(const cf* __restrict__ T, float* __restrict__ out, const float* __restrict__ bias,
+// ---- rows, inverse + epilogue: T[b][y][kx][c] (C channels, padded to a multiple of 64) -> out with Cout channels
+// LAYOUT: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar (Cout % 8 == 0)
+template <int NX, int LAYOUT>
+__global__ __launch_bounds__(NT) void rows_inv_kernel(const cf* __restrict__ T, void* __restrict__ out, const float* __restrict__ bias,
                                                       const float* __restrict__ scale, const float* __restrict__ shift, int relu_bn, int H, int W, int C,
                                                       int Cout, int pad, float norm) {
   constexpr int CH = CB / 2, NXH = NX / 2 + 1;
@@ -190,8 +203,7 @@ __global__ __launch_bounds__(NT) void rows_inv_kernel(const cf* __restrict__ T, 
   __syncthreads();
   fft<NX, 1, CH>(buf, tw, tid);
   const int c0 = cblk * CB;
-  float* dst = out + ((size_t)(b * H + y) * W) * Cout;
-  const bool pairs = (Cout & 1) == 0;                   // two channels = one aligned 8-byte store
+  const bool pairs = (Cout & 1) == 0;                   // two channels = one aligned store
   for (int t = tid; t < W * CH; t += NT) {
     const int x = t / CH, v = t % CH;
     const int c = c0 + 2 * v;
@@ -203,16 +215,25 @@ __global__ __launch_bounds__(NT) void rows_inv_kernel(const cf* __restrict__ T, 
       v0 = fmaxf(v0, 0.f) * scale[c] + shift[c];
       if (two) v1 = fmaxf(v1, 0.f) * scale[c + 1] + shift[c + 1];
     }
-    float* o = dst + (size_t)x * Cout + c;
-    if (pairs) *reinterpret_cast<cf*>(o) = cf{v0, v1};
-    else { o[0] = v0; if (two) o[1] = v1; }
+    if constexpr (LAYOUT == 0) {
+      float* o = static_cast<float*>(out) + ((size_t)(b * H + y) * W + x) * Cout + c;
+      if (pairs) *reinterpret_cast<cf*>(o) = cf{v0, v1};
+      else { o[0] = v0; if (two) o[1] = v1; }
+    } else {
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      __bf16* o = static_cast<__bf16*>(out) + (LAYOUT == 1 ? ((size_t)(b * H + y) * W + x) * Cout + c
+                                                           : (((size_t)b * (Cout >> 3) + (c >> 3)) * H * W + (size_t)y * W + x) * 8 + (c & 7));
+      if (pairs) *reinterpret_cast<bf16x2*>(o) = bf16x2{static_cast<__bf16>(v0), static_cast<__bf16>(v1)};
+      else { o[0] = static_cast<__bf16>(v0); if (two) o[1] = static_cast<__bf16>(v1); }
+    }
   }
 }
 
 // ---- filter spectra: HWIO fp32 [k][k][Cin][Cout] -> Wf[ky][kx][ci][co < CoutP] = sum_{a,b} w[k-1-a][k-1-b][ci][co] e^{-2 pi i (ky a / NY + kx b / NX)}
 // (the flipped kernel: TF's conv2d is a correlation; channels Cout .. CoutP-1 are zero)
 template <int KS>
-__global__ __launch_bounds__(256) void weight_spectra_kernel(const float* __restrict__ w, cf* __restrict__ Wf, int Cin, int Cout, int CoutP, int NY, int NX) {
+__global__ __launch_bounds__(256) void weight_spectra_kernel(const float* __restrict__ w, cf* __restrict__ Wf, int Cin, int Cout, int CoutP, int NY, int NX,
+                                                             int round_bf16) {
   __shared__ cf twy[256], twx[256];
   const int tid = threadIdx.x;
   for (int k = tid; k < NY + NX; k += 256) {
@@ -230,7 +251,11 @@ __global__ __launch_bounds__(256) void weight_spectra_kernel(const float* __rest
 #pragma unroll
   for (int a = 0; a < KS; ++a)
 #pragma unroll
-    for (int b = 0; b < KS; ++b) g[a][b] = co < Cout ? w[(((size_t)((KS - 1 - a) * KS + (KS - 1 - b))) * Cin + ci) * Cout + co] : 0.f;
+    for (int b = 0; b < KS; ++b) {
+      float wv = co < Cout ? w[(((size_t)((KS - 1 - a) * KS + (KS - 1 - b))) * Cin + ci) * Cout + co] : 0.f;
+      if (round_bf16) wv = static_cast<float>(static_cast<__bf16>(wv));       // bf16 handles: the filter the bf16 MFMA kernels multiply with
+      g[a][b] = wv;
+    }
   const int NXH = NX / 2 + 1;
   for (int kx = blockIdx.y; kx < NXH; kx += gridDim.y) {
     cf ra[KS];
@@ -260,8 +285,11 @@ static bool pick(int need, int* n) {
 static bool sizes_of(int H, int W, int ks, Sizes* s) { return (ks == 9 || ks == 5) && pick(H + ks - 1, &s->NY) && pick(W + ks - 1, &s->NX); }
 static int pad64(int c) { return (c + CB - 1) / CB * CB; }
 
-template <int NX> static void launch_rows_fwd(const ConvArgs& a, cf* T, hipStream_t st) {
-  hipLaunchKernelGGL(rows_fwd_kernel<NX>, dim3(a.B * a.H * (a.Cin / CB)), dim3(NT), 0, st, static_cast<const float*>(a.x), T, a.H, a.W, a.Cin);
+template <int NX> static void launch_rows_fwd(const ConvArgs& a, int layout, cf* T, hipStream_t st) {
+  const dim3 grid(a.B * a.H * (a.Cin / CB));
+  if (layout == 0) hipLaunchKernelGGL((rows_fwd_kernel<NX, 0>), grid, dim3(NT), 0, st, a.x, T, a.H, a.W, a.Cin);
+  else if (layout == 1) hipLaunchKernelGGL((rows_fwd_kernel<NX, 1>), grid, dim3(NT), 0, st, a.x, T, a.H, a.W, a.Cin);
+  else hipLaunchKernelGGL((rows_fwd_kernel<NX, 2>), grid, dim3(NT), 0, st, a.x, T, a.H, a.W, a.Cin);
 }
 template <int NY> static void launch_cols_fwd(const ConvArgs& a, const cf* T, cf* Xf, int NXH, hipStream_t st) {
   hipLaunchKernelGGL(cols_fwd_kernel<NY>, dim3(a.B * NXH * (a.Cin / colblk<NY>())), dim3(NT), 0, st, T, Xf, a.B, a.H, NXH, a.Cin);
@@ -269,9 +297,14 @@ template <int NY> static void launch_cols_fwd(const ConvArgs& a, const cf* T, cf
 template <int NY> static void launch_cols_inv(const ConvArgs& a, const cf* Yf, cf* T, int NXH, int pad, hipStream_t st) {
   hipLaunchKernelGGL(cols_inv_kernel<NY>, dim3(a.B * NXH * (a.CoutP / colblk<NY>())), dim3(NT), 0, st, Yf, T, a.B, a.H, NXH, a.CoutP, pad);
 }
-template <int NX> static void launch_rows_inv(const ConvArgs& a, const cf* T, int pad, float norm, hipStream_t st) {
-  hipLaunchKernelGGL(rows_inv_kernel<NX>, dim3(a.B * a.H * (a.CoutP / CB)), dim3(NT), 0, st, T, static_cast<float*>(a.out), a.bias, a.scale, a.shift, a.relu_bn, a.H,
-                     a.W, a.CoutP, a.Cout, pad, norm);
+template <int NX> static void launch_rows_inv(const ConvArgs& a, int layout, const cf* T, int pad, float norm, hipStream_t st) {
+  const dim3 grid(a.B * a.H * (a.CoutP / CB));
+  if (layout == 0)
+    hipLaunchKernelGGL((rows_inv_kernel<NX, 0>), grid, dim3(NT), 0, st, T, a.out, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm);
+  else if (layout == 1)
+    hipLaunchKernelGGL((rows_inv_kernel<NX, 1>), grid, dim3(NT), 0, st, T, a.out, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm);
+  else
+    hipLaunchKernelGGL((rows_inv_kernel<NX, 2>), grid, dim3(NT), 0, st, T, a.out, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm);
 }
 #define CFFT_BY_SIZE(N, CALL)                    \
   switch (N) {                                   \
@@ -306,13 +339,13 @@ size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout) {
   if (!sizes_of(H, W, ks, &s)) return 0;
   return (size_t)s.NY * (s.NX / 2 + 1) * Cin * pad64(Cout) * sizeof(cf);
 }
-hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, hipStream_t st) {
+hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, bool round_bf16, hipStream_t st) {
   Sizes s;
   if (!sizes_of(H, W, ks, &s)) return hipErrorInvalidValue;
   const int CoutP = pad64(Cout);
   const dim3 grid((unsigned)(((size_t)Cin * CoutP + 255) / 256), 8);
-  if (ks == 9) hipLaunchKernelGGL(weight_spectra_kernel<9>, grid, dim3(256), 0, st, w_hwio, static_cast<cf*>(wf), Cin, Cout, CoutP, s.NY, s.NX);
-  else hipLaunchKernelGGL(weight_spectra_kernel<5>, grid, dim3(256), 0, st, w_hwio, static_cast<cf*>(wf), Cin, Cout, CoutP, s.NY, s.NX);
+  if (ks == 9) hipLaunchKernelGGL(weight_spectra_kernel<9>, grid, dim3(256), 0, st, w_hwio, static_cast<cf*>(wf), Cin, Cout, CoutP, s.NY, s.NX, round_bf16 ? 1 : 0);
+  else hipLaunchKernelGGL(weight_spectra_kernel<5>, grid, dim3(256), 0, st, w_hwio, static_cast<cf*>(wf), Cin, Cout, CoutP, s.NY, s.NX, round_bf16 ? 1 : 0);
   return hipGetLastError();
 }
 // scratch: T (the larger of the two row-transformed tensors) + Xf + Yf
@@ -324,9 +357,10 @@ size_t conv_fft_workspace_bytes(const ConvArgs& a, int ks) {
 }
 // a.wp = the filter spectra of THIS map size and kernel size; `work` = conv_fft_workspace_bytes(a, ks) bytes.  g0 / g1: optional events
 // recorded around the GEMM (the dominant kernel of the layer) for the roofline record.
-hipError_t conv_fft_f32(const ConvArgs& a0, int ks, void* work, hipEvent_t g0, hipEvent_t g1, hipStream_t st) {
+// in_layout / out_layout: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar
+hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int in_layout, int out_layout, void* work, hipEvent_t g0, hipEvent_t g1, hipStream_t st) {
   Sizes s;
-  if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s)) return hipErrorInvalidValue;
+  if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s) || (out_layout == 2 && a0.Cout % 8)) return hipErrorInvalidValue;
   ConvArgs a = a0;
   a.CoutP = pad64(a.Cout);
   const int pad = (ks - 1) / 2;
@@ -339,7 +373,7 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, void* work, hipEvent_t g0, h
   if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
   rocblas_handle bh = blas_for_device(dev);
   if (!bh) return hipErrorUnknown;
-#define CALL(N) launch_rows_fwd<N>(a, T, st)
+#define CALL(N) launch_rows_fwd<N>(a, in_layout, T, st)
   CFFT_BY_SIZE(s.NX, CALL)
 #undef CALL
   if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
@@ -365,7 +399,7 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, void* work, hipEvent_t g0, h
   CFFT_BY_SIZE(s.NY, CALL)
 #undef CALL
   if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-#define CALL(N) launch_rows_inv<N>(a, T, pad, 1.0f / (float)(s.NY * s.NX), st)
+#define CALL(N) launch_rows_inv<N>(a, out_layout, T, pad, 1.0f / (float)(s.NY * s.NX), st)
   CFFT_BY_SIZE(s.NX, CALL)
 #undef CALL
   return hipGetLastError();

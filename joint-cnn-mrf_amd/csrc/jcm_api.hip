@@ -162,12 +162,14 @@ void prof_release_all(jcm_ctx* c, bool destroy) {
 // spectra would have to follow every update).
 bool takes_fft(jcm_ctx* c, const ConvLayer* L, int B, int H, int W) {
   static const bool env_on = [] { const char* e = std::getenv("JCM_CONV_FFT"); return !(e && e[0] == '0'); }();   // A/B switch
-  if (!env_on || !c->conv9_fft || c->precision != JCM_PRECISION_F32 || c->f32_conv != 0 || c->train || (L->ks != 9 && L->ks != 5) || L->cin == 3 || !L->w_raw) return false;
+  if (!env_on || !c->conv9_fft || c->f32_conv != 0 || c->train || (L->ks != 9 && L->ks != 5) || L->cin == 3 || !L->w_raw) return false;
+  // bf16 handles: the wide 9x9 layers only (the 5x5 layers and the logits layer are faster on their bf16 MFMA strip kernels)
+  if (c->precision == JCM_PRECISION_BF16 && (L->ks != 9 || L->thin_bf16 || L->cout % 8)) return false;
   ConvArgs a{};
   a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout;
   return conv_fft_supported(a, L->ks);
 }
-static int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const void* x, int B, int H, int W, void* out) {
+static int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const void* x, int B, int H, int W, void* out, int in_layout, int out_layout) {
   ConvArgs a{};
   a.x = x; a.bias = L->bias; a.scale = L->scale; a.shift = L->shift; a.out = out;
   a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout; a.CoutP = L->cout; a.relu_bn = L->has_bn ? 1 : 0;
@@ -181,14 +183,14 @@ static int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope
     JCM_TRY(dev_alloc(c, &fw.p, fw.bytes));
   }
   if (!fw.valid) {
-    HIP_TRY(conv_fft_pack_weights(L->w_raw, fw.p, H, W, L->ks, L->cin, L->cout, c->stream));
+    HIP_TRY(conv_fft_pack_weights(L->w_raw, fw.p, H, W, L->ks, L->cin, L->cout, c->precision == JCM_PRECISION_BF16, c->stream));
     fw.valid = true;
   }
   a.wp = fw.p;
   hipEvent_t e0 = nullptr, e1 = nullptr, g0 = nullptr, g1 = nullptr;
   JCM_TRY(prof_begin(c, &e0, &e1));
   if (c->profile && (pool_get(c, &g0) != JCM_OK || pool_get(c, &g1) != JCM_OK)) { g0 = g1 = nullptr; }
-  const hipError_t e = conv_fft_f32(a, L->ks, work, g0, g1, c->stream);
+  const hipError_t e = conv_fft_f32(a, L->ks, in_layout, out_layout, work, g0, g1, c->stream);
   if (g0 && g1 && e == hipSuccess) c->prof[scope + "/gemm"].emplace_back(g0, g1);
   else { if (g0) c->event_pool.push_back(g0); if (g1) c->event_pool.push_back(g1); }
   prof_end(c, scope, e0, e1, e == hipSuccess);
@@ -208,7 +210,8 @@ int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int
                         L->cout, c->stream));
     return JCM_OK;
   }
-  if (stride == 1 && !act_bf16 && takes_fft(c, L, B, H, W)) return run_conv_fft(c, L, scope, x, B, H, W, out);
+  if (stride == 1 && takes_fft(c, L, B, H, W))
+    return run_conv_fft(c, L, scope, x, B, H, W, out, act_bf16 ? (in_planar ? 2 : 1) : 0, (act_bf16 && !out_f32) ? (out_planar ? 2 : 1) : 0);
   if (c->dry) return JCM_OK;
   const void* wp = act_bf16 ? L->wp_bf16 : static_cast<const void*>(L->wp);
   if (stride != 1 || !wp) return fail(JCM_ERR_ARG, "no kernel for layer '" + scope + "' with stride " + std::to_string(stride));
@@ -677,10 +680,9 @@ int jcm_conv_layer(jcm_handle h, const char* scope, int stride, int last_layer, 
     const size_t nin = (size_t)B * H * W * L->cin, nout = (size_t)B * H * W * L->cout;
     void* xb = arena_alloc<char>(c, nin * 2);
     void* ob = last_layer ? nullptr : static_cast<void*>(arena_alloc<char>(c, nout * 2));
-    if (c->dry) return (int)JCM_OK;
-    HIP_TRY(cast_pad_bf16(x, L->cin, xb, L->cin, (size_t)B * H * W, c->stream));
-    JCM_TRY(run_conv(c, scope, 1, xb, B, H, W, 1, last_layer ? static_cast<void*>(out) : ob, true, last_layer != 0));
-    if (!last_layer) HIP_TRY(cast_bf16_f32(ob, out, nout, c->stream));
+    if (!c->dry) HIP_TRY(cast_pad_bf16(x, L->cin, xb, L->cin, (size_t)B * H * W, c->stream));
+    JCM_TRY(run_conv(c, scope, 1, xb, B, H, W, 1, last_layer ? static_cast<void*>(out) : ob, true, last_layer != 0));   // (sizes its own scratch in the dry pass)
+    if (!c->dry && !last_layer) HIP_TRY(cast_bf16_f32(ob, out, nout, c->stream));
     return (int)JCM_OK;
   });
 }
@@ -916,6 +918,7 @@ int jcm_conv_kernel_name(jcm_handle h, const char* scope, int B, int H, int W, c
     k = L->thin_bf16 ? (L->wp_kxfold && conv_kxfold_bf16_supported(a, L->ks) ? "conv_kxfold_bf16_kernel" : "conv_thin_bf16_kernel")
         : (conv_igemm_bf16_bn(L->cout, L->ks) == 256 && conv_strip_bf16_supported(a, L->ks)) ? "conv_strip_bf16_kernel"
         : (L->ks == 5 && conv_igemm_bf16_bn(L->cout, L->ks) == 128 && conv5_strip_bf16_supported(a, L->ks)) ? "conv5_strip_bf16_kernel" : "conv_igemm_bf16_kernel";
+    if (takes_fft(h, L, B, H, W)) k = "conv_fft(rocblas_cgemm_strided_batched)";
   } else {
     const bool use_split = L->wp_split && (L->thin ? h->f32_conv == 2 : conv_split_supported(L->ks, L->cin, L->coutp_split, B, H, W, h->split_min_wgs));
     k = L->thin ? (use_split ? "conv_thin_split16_kernel" : "conv_thin_f32_kernel") : use_split ? "conv_split_kernel" : "conv_igemm_f32_kernel";

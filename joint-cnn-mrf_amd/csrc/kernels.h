@@ -76,9 +76,10 @@ hipError_t conv_thin_bf16(const ConvArgs& a, hipStream_t st);
 // (conv_fft_pack_weights; output channels padded to a multiple of 64).  Shapes: Cin % 64 == 0, H + k - 1 <= 192, W + k - 1 <= 192.
 bool conv_fft_supported(const ConvArgs& a, int ks);
 size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout);
-hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, hipStream_t st);
+hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, bool round_bf16, hipStream_t st);
 size_t conv_fft_workspace_bytes(const ConvArgs& a, int ks);
-hipError_t conv_fft_f32(const ConvArgs& a, int ks, void* work, hipEvent_t g0, hipEvent_t g1, hipStream_t st);   // g0/g1: optional events around the GEMM
+// in / out layout: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar (bf16 handles: operands are bf16 values, the arithmetic is fp32); g0/g1: optional events around the GEMM
+hipError_t conv_fft_f32(const ConvArgs& a, int ks, int in_layout, int out_layout, void* work, hipEvent_t g0, hipEvent_t g1, hipStream_t st);
 
 // ---- conv5_strip_bf16.hip : 5x5 SAME convolution in 128-channel output tiles on 768-pixel strips (bf16 in NHWC or planar, bf16 out NHWC or planar;
 // weights as packed by pack_weights_bf16); shapes: CoutP % 128 == 0, Cin % 32 == 0, Cout % 8 == 0, 8 <= W <= 191 and a window of at most 64 row parts

@@ -24,7 +24,8 @@ def _full_params():
     return x2, torso2, p
 
 
-def test_config3_batch256_bf16_properties():
+@pytest.mark.parametrize('fft', [True, False], ids=['fft', 'mfma'])
+def test_config3_batch256_bf16_properties(fft):
     """configs[2] (and a rank's share of configs[3]: 2048 / 8): batch 256, bf16, full-width network,
     FLIC priors.  This is the size at which the arena holds 5 GB, the spatial model runs 16 FFT slices and
     the 9x9 grids have thousands of tiles -- paths a 2-image test never takes."""
@@ -33,9 +34,11 @@ def test_config3_batch256_bf16_properties():
     B = 256
     x = np.concatenate([x2, synth.make_images(B - 2, seed=177)], axis=0)
     torso = np.concatenate([torso2, synth.make_torso(B - 2, seed=178)], axis=0)
-    eng = Engine(device=0, precision='bf16').load_params(p)
-    # the kernel under test is the flattened-strip 9x9 kernel (a silent fallback to the patch kernel would pass too)
-    assert eng.conv_kernel_name('conv5', B, 60, 90) == eng.conv_kernel_name('conv4_fullres', B, 60, 90) == 'conv_strip_bf16_kernel'
+    eng = Engine(device=0, precision='bf16', conv9_fft=fft).load_params(p)
+    # the kernels under test: the frequency-domain route of the wide 9x9 layers (default), or the flattened-strip bf16 MFMA kernel (a
+    # silent fallback to the patch kernel would pass too)
+    want = 'conv_fft(rocblas_cgemm_strided_batched)' if fft else 'conv_strip_bf16_kernel'
+    assert eng.conv_kernel_name('conv5', B, 60, 90) == eng.conv_kernel_name('conv4_fullres', B, 60, 90) == want
     r = eng.forward(dev(x), dev(torso), use_sm=True)
     pd, sm = r['pd_prob'].cpu().numpy(), r['sm_prob'].cpu().numpy()
     pd_c, sm_c = r['pd_coords'].cpu().numpy(), r['sm_coords'].cpu().numpy()
