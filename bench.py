@@ -178,7 +178,7 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
                          'launch_ms': launch_ms, 'launches': tot_n, 'flops_per_launch': flops_launch},
         }
         if freq_domain:
-            out['roofline']['traffic'] = None      # no counter pass of the library kernel yet
+            out['roofline']['traffic'] = pmc_traffic('%s_b%d_fft' % (dtype, B)) if not args.debug else None
             out['roofline']['layer_ms'] = layer_ms  # the whole layer: four transform kernels + the GEMM
             out['path_tflops_note'] = 'images/s x direct-convolution FLOPs: the wide 9x9 layers run 30x fewer in the frequency domain'
         if fp32_equiv is not None:
