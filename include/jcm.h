@@ -58,6 +58,10 @@ int jcm_abi_version(void);
  *              stream; read the totals back with jcm_profile_read.  Events come from a pool owned by the
  *              handle (created on first use, recycled by jcm_profile_read and by switching the option on,
  *              destroyed by jcm_destroy), so a profiled step only records.
+ * "conv9_fft": any time, default 1: stride-1 convolutions in the frequency domain (conv_fft.hip: in-LDS FFTs + one complex channel
+ *              GEMM per frequency through rocBLAS) -- every such layer of an fp32 handle, the wide 9x9 layers of a bf16 handle --
+ *              whenever the shape allows (Cin % 64 == 0, map + kernel - 1 <= 192) and no training state exists; 0 = the direct MFMA
+ *              kernels.  Filter spectra are built per (layer, map size) on first use (13 GB for the full-width model).
  * "sm_algo"  : any time; the pairwise convolutions of the spatial model (main.py:83-87): 3 (default) = every FFT in LDS
  *              (sm_fused.hip); 2 = rocFFT with a split, row-pruned inverse; 0 = rocFFT 2-D transforms; 1 = direct
  *              sliding-window kernel.  All four are HIP paths that pass the same parity tests; the training step always
