@@ -20,6 +20,7 @@
 // Reference semantics: conv2d SAME stride 1 + bias + ReLU + BatchNorm (main.py:133-135,156-169).
 #include <rocblas/rocblas.h>
 
+#include <cstdlib>
 #include <mutex>
 
 #include "fft_lds.h"
@@ -96,13 +97,13 @@ __device__ __forceinline__ void twiddles(cf* tw, int tid) {
 // LAYOUT: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar.  Two adjacent channels are one complex number.
 __device__ __forceinline__ cf bf16pair(unsigned bits) { return cf{__uint_as_float(bits << 16), __uint_as_float(bits & 0xffff0000u)}; }
 template <int NX, int LAYOUT>
-__global__ __launch_bounds__(NT) void rows_fwd_kernel(const void* __restrict__ in, cf* __restrict__ T, int H, int W, int C) {
+__global__ __launch_bounds__(NT) void rows_fwd_kernel(const void* __restrict__ in, cf* __restrict__ T, int H, int W, int C, int b0) {
   constexpr int CH = CB / 2, NXH = NX / 2 + 1;
   __shared__ cf buf[NX * CH];
   __shared__ cf tw[NX];
   const int tid = threadIdx.x;
   const int cblk = blockIdx.x % (C / CB), by = blockIdx.x / (C / CB);
-  const int y = by % H, b = by / H;
+  const int y = by % H, bl = by / H, b = b0 + bl;       // bl: image inside this slice of the batch (indexes T), b: image of the batch
   twiddles<NX>(tw, tid);
   for (int t = tid; t < NX * CH; t += NT) {
     const int x = t / CH, v = t % CH;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(NT) void rows_fwd_kernel(const void* __restrict__ i
   for (int t = tid; t < NXH * CH; t += NT) {
     const int k = t / CH, v = t % CH;
     const cf zk = buf[pos<NX>(k) * CH + v], zn = buf[pos<NX>(k == 0 ? 0 : NX - k) * CH + v];
-    dst[(((size_t)(b * NXH + k) * H + y) * C + cblk * CB) / 2 + v] =
+    dst[(((size_t)(bl * NXH + k) * H + y) * C + cblk * CB) / 2 + v] =
         make_float4(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y), 0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
   }
 }
@@ -134,15 +135,15 @@ __global__ __launch_bounds__(NT) void rows_fwd_kernel(const void* __restrict__ i
 // ---- columns, forward: T[b][kx][y][c] -> Xf[ky][kx][b][c]
 template <int NY> constexpr int colblk() { return NY > 100 ? 32 : 64; }      // channels per work group of the column kernels (<= 64 KB of LDS)
 template <int NY>
-__global__ __launch_bounds__(NT) void cols_fwd_kernel(const cf* __restrict__ T, cf* __restrict__ Xf, int B, int H, int NXH, int C) {
+__global__ __launch_bounds__(NT) void cols_fwd_kernel(const cf* __restrict__ T, cf* __restrict__ Xf, int B, int H, int NXH, int C, int b0) {
   constexpr int CH = colblk<NY>(), CB = CH;
   __shared__ cf buf[NY * CH];
   __shared__ cf tw[NY];
   const int tid = threadIdx.x;
   const int cblk = blockIdx.x % (C / CB), bk = blockIdx.x / (C / CB);
-  const int kx = bk % NXH, b = bk / NXH;
+  const int kx = bk % NXH, bl = bk / NXH, b = b0 + bl;
   twiddles<NY>(tw, tid);
-  const cf* src = T + ((size_t)(b * NXH + kx) * H) * C + cblk * CB;
+  const cf* src = T + ((size_t)(bl * NXH + kx) * H) * C + cblk * CB;
   for (int t = tid; t < NY * CH; t += NT) {
     const int y = t / CH, v = t % CH;
     buf[t] = y < H ? src[(size_t)y * C + v] : cf{0.f, 0.f};
@@ -157,13 +158,13 @@ __global__ __launch_bounds__(NT) void cols_fwd_kernel(const cf* __restrict__ T, 
 
 // ---- columns, inverse: Yf[ky][kx][b][c] -> T[b][y][kx][c], y < H (row y of the output is row y + pad of the linear convolution)
 template <int NY>
-__global__ __launch_bounds__(NT) void cols_inv_kernel(const cf* __restrict__ Yf, cf* __restrict__ T, int B, int H, int NXH, int C, int pad) {
+__global__ __launch_bounds__(NT) void cols_inv_kernel(const cf* __restrict__ Yf, cf* __restrict__ T, int B, int H, int NXH, int C, int pad, int b0) {
   constexpr int CH = colblk<NY>(), CB = CH;
   __shared__ cf buf[NY * CH];
   __shared__ cf tw[NY];
   const int tid = threadIdx.x;
   const int cblk = blockIdx.x % (C / CB), bk = blockIdx.x / (C / CB);
-  const int kx = bk % NXH, b = bk / NXH;
+  const int kx = bk % NXH, bl = bk / NXH, b = b0 + bl;
   twiddles<NY>(tw, tid);
   for (int t = tid; t < NY * CH; t += NT) {
     const int ky = t / CH, v = t % CH;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(NT) void cols_inv_kernel(const cf* __restrict__ Yf,
   fft<NY, 1, CH>(buf, tw, tid);
   for (int t = tid; t < H * CH; t += NT) {
     const int y = t / CH, v = t % CH;
-    T[((size_t)(b * H + y) * NXH + kx) * C + cblk * CB + v] = buf[pos<NY>(y + pad) * CH + v];
+    T[((size_t)(bl * H + y) * NXH + kx) * C + cblk * CB + v] = buf[pos<NY>(y + pad) * CH + v];
   }
 }
 
@@ -182,15 +183,15 @@ __global__ __launch_bounds__(NT) void cols_inv_kernel(const cf* __restrict__ Yf,
 template <int NX, int LAYOUT>
 __global__ __launch_bounds__(NT) void rows_inv_kernel(const cf* __restrict__ T, void* __restrict__ out, const float* __restrict__ bias,
                                                       const float* __restrict__ scale, const float* __restrict__ shift, int relu_bn, int H, int W, int C,
-                                                      int Cout, int pad, float norm) {
+                                                      int Cout, int pad, float norm, int b0) {
   constexpr int CH = CB / 2, NXH = NX / 2 + 1;
   __shared__ cf buf[NX * CH];
   __shared__ cf tw[NX];
   const int tid = threadIdx.x;
   const int cblk = blockIdx.x % (C / CB), by = blockIdx.x / (C / CB);
-  const int y = by % H, b = by / H;
+  const int y = by % H, bl = by / H, b = b0 + bl;
   twiddles<NX>(tw, tid);
-  const float4* src = reinterpret_cast<const float4*>(T + ((size_t)(b * H + y) * NXH) * C + cblk * CB);
+  const float4* src = reinterpret_cast<const float4*>(T + ((size_t)(bl * H + y) * NXH) * C + cblk * CB);
   // Z = Y_c + i Y_{c+1} with the Hermitian extension Y[NX - k] = conj Y[k]; DC and Nyquist are real by symmetry
   for (int t = tid; t < NXH * CH; t += NT) {
     const int k = t / CH, v = t % CH;
@@ -285,26 +286,38 @@ static bool pick(int need, int* n) {
 static bool sizes_of(int H, int W, int ks, Sizes* s) { return (ks == 9 || ks == 5) && pick(H + ks - 1, &s->NY) && pick(W + ks - 1, &s->NX); }
 static int pad64(int c) { return (c + CB - 1) / CB * CB; }
 
-template <int NX> static void launch_rows_fwd(const ConvArgs& a, int layout, cf* T, hipStream_t st) {
-  const dim3 grid(a.B * a.H * (a.Cin / CB));
-  if (layout == 0) hipLaunchKernelGGL((rows_fwd_kernel<NX, 0>), grid, dim3(NT), 0, st, a.x, T, a.H, a.W, a.Cin);
-  else if (layout == 1) hipLaunchKernelGGL((rows_fwd_kernel<NX, 1>), grid, dim3(NT), 0, st, a.x, T, a.H, a.W, a.Cin);
-  else hipLaunchKernelGGL((rows_fwd_kernel<NX, 2>), grid, dim3(NT), 0, st, a.x, T, a.H, a.W, a.Cin);
+// (b0, nb): the slice of the batch a launch covers; T is the slice's scratch
+template <int NX> static void launch_rows_fwd(const ConvArgs& a, int layout, cf* T, int b0, int nb, hipStream_t st) {
+  const dim3 grid(nb * a.H * (a.Cin / CB));
+  if (layout == 0) hipLaunchKernelGGL((rows_fwd_kernel<NX, 0>), grid, dim3(NT), 0, st, a.x, T, a.H, a.W, a.Cin, b0);
+  else if (layout == 1) hipLaunchKernelGGL((rows_fwd_kernel<NX, 1>), grid, dim3(NT), 0, st, a.x, T, a.H, a.W, a.Cin, b0);
+  else hipLaunchKernelGGL((rows_fwd_kernel<NX, 2>), grid, dim3(NT), 0, st, a.x, T, a.H, a.W, a.Cin, b0);
 }
-template <int NY> static void launch_cols_fwd(const ConvArgs& a, const cf* T, cf* Xf, int NXH, hipStream_t st) {
-  hipLaunchKernelGGL(cols_fwd_kernel<NY>, dim3(a.B * NXH * (a.Cin / colblk<NY>())), dim3(NT), 0, st, T, Xf, a.B, a.H, NXH, a.Cin);
+template <int NY> static void launch_cols_fwd(const ConvArgs& a, const cf* T, cf* Xf, int NXH, int b0, int nb, hipStream_t st) {
+  hipLaunchKernelGGL(cols_fwd_kernel<NY>, dim3(nb * NXH * (a.Cin / colblk<NY>())), dim3(NT), 0, st, T, Xf, a.B, a.H, NXH, a.Cin, b0);
 }
-template <int NY> static void launch_cols_inv(const ConvArgs& a, const cf* Yf, cf* T, int NXH, int pad, hipStream_t st) {
-  hipLaunchKernelGGL(cols_inv_kernel<NY>, dim3(a.B * NXH * (a.CoutP / colblk<NY>())), dim3(NT), 0, st, Yf, T, a.B, a.H, NXH, a.CoutP, pad);
+template <int NY> static void launch_cols_inv(const ConvArgs& a, const cf* Yf, cf* T, int NXH, int pad, int b0, int nb, hipStream_t st) {
+  hipLaunchKernelGGL(cols_inv_kernel<NY>, dim3(nb * NXH * (a.CoutP / colblk<NY>())), dim3(NT), 0, st, Yf, T, a.B, a.H, NXH, a.CoutP, pad, b0);
 }
-template <int NX> static void launch_rows_inv(const ConvArgs& a, int layout, const cf* T, int pad, float norm, hipStream_t st) {
-  const dim3 grid(a.B * a.H * (a.CoutP / CB));
+template <int NX> static void launch_rows_inv(const ConvArgs& a, int layout, const cf* T, int pad, float norm, int b0, int nb, hipStream_t st) {
+  const dim3 grid(nb * a.H * (a.CoutP / CB));
   if (layout == 0)
-    hipLaunchKernelGGL((rows_inv_kernel<NX, 0>), grid, dim3(NT), 0, st, T, a.out, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm);
+    hipLaunchKernelGGL((rows_inv_kernel<NX, 0>), grid, dim3(NT), 0, st, T, a.out, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm, b0);
   else if (layout == 1)
-    hipLaunchKernelGGL((rows_inv_kernel<NX, 1>), grid, dim3(NT), 0, st, T, a.out, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm);
+    hipLaunchKernelGGL((rows_inv_kernel<NX, 1>), grid, dim3(NT), 0, st, T, a.out, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm, b0);
   else
-    hipLaunchKernelGGL((rows_inv_kernel<NX, 2>), grid, dim3(NT), 0, st, T, a.out, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm);
+    hipLaunchKernelGGL((rows_inv_kernel<NX, 2>), grid, dim3(NT), 0, st, T, a.out, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm, b0);
+}
+// Images per slice of the transform passes.  JCM_FFT_SLICE_MB=n keeps the row-transformed tensor T of a slice below n MB (so that it
+// could stay in the 256 MB Infinity Cache between the row and the column kernel); measured at 160 / 96 / 48 MB: 2.6 / 2.1 / 9 % SLOWER
+// than the whole batch in one launch (fp32 B=64; bf16 B=256: 3.9 %), so the default is 0 = whole batch.
+static int slice_images(const ConvArgs& a, const Sizes& s) {
+  static const long long cap = [] { const char* e = std::getenv("JCM_FFT_SLICE_MB"); return (long long)(e ? std::atoi(e) : 0) << 20; }();
+  const size_t cmax = a.Cin > a.CoutP ? a.Cin : a.CoutP;
+  const long long per = (long long)(s.NX / 2 + 1) * a.H * cmax * sizeof(cf);
+  if (cap <= 0) return a.B;
+  const long long n = cap / per;
+  return n < 1 ? 1 : n > a.B ? a.B : (int)n;
 }
 #define CFFT_BY_SIZE(N, CALL)                    \
   switch (N) {                                   \
@@ -353,7 +366,9 @@ size_t conv_fft_workspace_bytes(const ConvArgs& a, int ks) {
   Sizes s;
   if (!sizes_of(a.H, a.W, ks, &s)) return 0;
   const size_t NXH = s.NX / 2 + 1, cop = pad64(a.Cout), cmax = (size_t)a.Cin > cop ? a.Cin : cop;
-  return ((size_t)a.B * NXH * a.H * cmax + (size_t)s.NY * NXH * a.B * (a.Cin + cop)) * sizeof(cf);
+  ConvArgs ap = a;
+  ap.CoutP = (int)cop;
+  return ((size_t)slice_images(ap, s) * NXH * a.H * cmax + (size_t)s.NY * NXH * a.B * (a.Cin + cop)) * sizeof(cf);
 }
 // a.wp = the filter spectra of THIS map size and kernel size; `work` = conv_fft_workspace_bytes(a, ks) bytes.  g0 / g1: optional events
 // recorded around the GEMM (the dominant kernel of the layer) for the roofline record.
@@ -366,21 +381,24 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int in_layout, int out_layou
   const int pad = (ks - 1) / 2;
   const int NXH = s.NX / 2 + 1, F = s.NY * NXH;
   const size_t cmax = a.Cin > a.CoutP ? a.Cin : a.CoutP;
+  const int SL = slice_images(a, s);
   cf* T = static_cast<cf*>(work);
-  cf* Xf = T + (size_t)a.B * NXH * a.H * cmax;
+  cf* Xf = T + (size_t)SL * NXH * a.H * cmax;
   cf* Yf = Xf + (size_t)F * a.B * a.Cin;
   int dev = 0;
   if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
   rocblas_handle bh = blas_for_device(dev);
   if (!bh) return hipErrorUnknown;
-#define CALL(N) launch_rows_fwd<N>(a, in_layout, T, st)
-  CFFT_BY_SIZE(s.NX, CALL)
+  for (int b0 = 0; b0 < a.B; b0 += SL) {
+    const int nb = a.B - b0 < SL ? a.B - b0 : SL;
+#define CALL(N) launch_rows_fwd<N>(a, in_layout, T, b0, nb, st)
+    CFFT_BY_SIZE(s.NX, CALL)
 #undef CALL
-  if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-#define CALL(N) launch_cols_fwd<N>(a, T, Xf, NXH, st)
-  CFFT_BY_SIZE(s.NY, CALL)
+#define CALL(N) launch_cols_fwd<N>(a, T, Xf, NXH, b0, nb, st)
+    CFFT_BY_SIZE(s.NY, CALL)
 #undef CALL
-  if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+  }
   // row-major Y[b][co] = X[b][ci] Wf[ci][co]  ==  column-major (CoutP x B) = (CoutP x Cin) (Cin x B)
   {
     static std::mutex mu;                       // the handle's stream is per call
@@ -395,14 +413,17 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int in_layout, int out_layou
     if (rs != rocblas_status_success) return hipErrorUnknown;
     if (g1 && hipEventRecord(g1, st) != hipSuccess) return hipErrorUnknown;
   }
-#define CALL(N) launch_cols_inv<N>(a, Yf, T, NXH, pad, st)
-  CFFT_BY_SIZE(s.NY, CALL)
+  for (int b0 = 0; b0 < a.B; b0 += SL) {
+    const int nb = a.B - b0 < SL ? a.B - b0 : SL;
+#define CALL(N) launch_cols_inv<N>(a, Yf, T, NXH, pad, b0, nb, st)
+    CFFT_BY_SIZE(s.NY, CALL)
 #undef CALL
-  if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-#define CALL(N) launch_rows_inv<N>(a, out_layout, T, pad, 1.0f / (float)(s.NY * s.NX), st)
-  CFFT_BY_SIZE(s.NX, CALL)
+#define CALL(N) launch_rows_inv<N>(a, out_layout, T, pad, 1.0f / (float)(s.NY * s.NX), b0, nb, st)
+    CFFT_BY_SIZE(s.NX, CALL)
 #undef CALL
-  return hipGetLastError();
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 }  // namespace jcm
