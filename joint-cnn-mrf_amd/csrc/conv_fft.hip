@@ -203,29 +203,28 @@ __global__ __launch_bounds__(NT) void rows_inv_kernel(const cf* __restrict__ T, 
   }
   __syncthreads();
   fft<NX, 1, CH>(buf, tw, tid);
-  const int c0 = cblk * CB;
-  const bool pairs = (Cout & 1) == 0;                   // two channels = one aligned store
-  for (int t = tid; t < W * CH; t += NT) {
-    const int x = t / CH, v = t % CH;
-    const int c = c0 + 2 * v;
-    if (c >= Cout) continue;
-    const cf z = buf[pos<NX>(x + pad) * CH + v];
-    const bool two = c + 1 < Cout;
-    float v0 = z.x * norm + bias[c], v1 = two ? z.y * norm + bias[c + 1] : 0.f;
-    if (relu_bn) {
-      v0 = fmaxf(v0, 0.f) * scale[c] + shift[c];
-      if (two) v1 = fmaxf(v1, 0.f) * scale[c + 1] + shift[c + 1];
-    }
-    if constexpr (LAYOUT == 0) {
-      float* o = static_cast<float*>(out) + ((size_t)(b * H + y) * W + x) * Cout + c;
-      if (pairs) *reinterpret_cast<cf*>(o) = cf{v0, v1};
-      else { o[0] = v0; if (two) o[1] = v1; }
-    } else {
-      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-      __bf16* o = static_cast<__bf16*>(out) + (LAYOUT == 1 ? ((size_t)(b * H + y) * W + x) * Cout + c
-                                                           : (((size_t)b * (Cout >> 3) + (c >> 3)) * H * W + (size_t)y * W + x) * 8 + (c & 7));
-      if (pairs) *reinterpret_cast<bf16x2*>(o) = bf16x2{static_cast<__bf16>(v0), static_cast<__bf16>(v1)};
-      else { o[0] = static_cast<__bf16>(v0); if (two) o[1] = static_cast<__bf16>(v1); }
+  // a thread keeps its channel pair for the whole row (NT is a multiple of CH): bias / scale / shift are loaded once
+  const int v = tid % CH, c = cblk * CB + 2 * v;
+  if (c < Cout) {
+    const bool two = c + 1 < Cout, pairs = (Cout & 1) == 0;      // two channels = one aligned store
+    const float b0v = bias[c], b1v = two ? bias[c + 1] : 0.f;
+    float s0 = 1.f, s1 = 1.f, h0 = 0.f, h1 = 0.f;
+    if (relu_bn) { s0 = scale[c]; h0 = shift[c]; if (two) { s1 = scale[c + 1]; h1 = shift[c + 1]; } }
+    for (int x = tid / CH; x < W; x += NT / CH) {
+      const cf z = buf[pos<NX>(x + pad) * CH + v];
+      float v0 = z.x * norm + b0v, v1 = z.y * norm + b1v;
+      if (relu_bn) { v0 = fmaxf(v0, 0.f) * s0 + h0; v1 = fmaxf(v1, 0.f) * s1 + h1; }
+      if constexpr (LAYOUT == 0) {
+        float* o = static_cast<float*>(out) + ((size_t)(b * H + y) * W + x) * Cout + c;
+        if (pairs) *reinterpret_cast<cf*>(o) = cf{v0, v1};
+        else { o[0] = v0; if (two) o[1] = v1; }
+      } else {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        __bf16* o = static_cast<__bf16*>(out) + (LAYOUT == 1 ? ((size_t)(b * H + y) * W + x) * Cout + c
+                                                             : (((size_t)b * (Cout >> 3) + (c >> 3)) * H * W + (size_t)y * W + x) * 8 + (c & 7));
+        if (pairs) *reinterpret_cast<bf16x2*>(o) = bf16x2{static_cast<__bf16>(v0), static_cast<__bf16>(v1)};
+        else { o[0] = static_cast<__bf16>(v0); if (two) o[1] = static_cast<__bf16>(v1); }
+      }
     }
   }
 }
