@@ -177,10 +177,28 @@ static int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope
   void* work = arena_alloc<char>(c, conv_fft_workspace_bytes(a, L->ks));
   c->arena_off = mark;                                   // scratch of this layer only: later layers run behind it on the stream
   if (c->dry) return JCM_OK;
-  jcm_ctx::FftW& fw = c->fft_w[scope + "@" + std::to_string(H) + "x" + std::to_string(W)];
+  // Filter spectra are cached per (layer, map size).  The cache is bounded (JCM_FFT_CACHE_GB, default 64): a caller that walks many
+  // image sizes (7.7 GB per size for conv5) makes it drop every spectrum that is not this layer's before it grows past the bound.
+  const std::string key = scope + "@" + std::to_string(H) + "x" + std::to_string(W);
+  if (!c->fft_w.count(key)) {
+    static const size_t cap = [] { const char* e = std::getenv("JCM_FFT_CACHE_GB"); return (size_t)(e ? std::atoi(e) : 64) << 30; }();
+    const size_t need = conv_fft_weight_bytes(H, W, L->ks, L->cin, L->cout);
+    size_t held = 0;
+    for (auto& kv : c->fft_w) held += kv.second.bytes;
+    if (held + need > cap && !c->fft_w.empty()) {
+      HIP_TRY(hipStreamSynchronize(c->stream));            // earlier layers of this forward may still read theirs
+      for (auto& kv : c->fft_w) (void)hipFree(kv.second.p);
+      c->fft_w.clear();
+    }
+  }
+  jcm_ctx::FftW& fw = c->fft_w[key];
   if (!fw.p) {
     fw.bytes = conv_fft_weight_bytes(H, W, L->ks, L->cin, L->cout);
-    JCM_TRY(dev_alloc(c, &fw.p, fw.bytes));
+    if (hipMalloc(&fw.p, fw.bytes) != hipSuccess) {
+      const size_t mb = fw.bytes >> 20;
+      c->fft_w.erase(key);
+      return fail(JCM_ERR_HIP, "out of device memory for the filter spectra of '" + scope + "' (" + std::to_string(mb) + " MB); jcm_set_option(\"conv9_fft\", 0) selects the direct kernels");
+    }
   }
   if (!fw.valid) {
     HIP_TRY(conv_fft_pack_weights(L->w_raw, fw.p, H, W, L->ks, L->cin, L->cout, c->precision == JCM_PRECISION_BF16, c->stream));
@@ -574,6 +592,7 @@ int jcm_destroy(jcm_handle h) {
   if (h->train) train_destroy(h);
   for (auto& kv : h->params) (void)hipFree(kv.second.d);
   for (void* p : h->owned) (void)hipFree(p);
+  for (auto& kv : h->fft_w) (void)hipFree(kv.second.p);
   if (h->arena) (void)hipFree(h->arena);
   delete h;
   return JCM_OK;

@@ -167,3 +167,34 @@ def test_tower_more_seeds_debug_width(seed):
             ck = 'pd_coords' if k == 'pd_prob' else 'sm_coords'
             same = (r[ck].cpu().numpy() == ref[ck]).all(axis=1)
             assert (same | ~safe).all(), (mode, ck)
+
+
+def test_filter_spectra_cache_is_bounded():
+    """conv_fft keeps the filter spectra per (layer, map size); with the bound at 0 GB every new (layer, size) evicts the others, and the
+    results stay those of the oracle (a process of its own: the bound is read once)."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np, torch
+import joint_cnn_mrf_amd
+from joint_cnn_mrf_amd.engine import Engine
+from oracle import jcm_oracle as O
+rs = np.random.RandomState(5)
+p = {}
+for s, (cin, cout) in {'a': (64, 64), 'b': (128, 64)}.items():
+    p[s + '/weights'] = (rs.standard_normal((9, 9, cin, cout)) * np.sqrt(2.0 / (81 * cin))).astype(np.float32)
+    p[s + '/biases'] = (0.1 * rs.standard_normal(cout)).astype(np.float32)
+eng = Engine(device=0).load_params(p)
+for rep in range(2):
+    for s, cin, (H, W) in (('a', 64, (20, 30)), ('b', 128, (12, 40)), ('a', 64, (33, 17)), ('b', 128, (12, 40))):
+        x = rs.standard_normal((2, H, W, cin)).astype(np.float32)
+        assert eng.conv_kernel_name(s, 2, H, W).startswith('conv_fft')
+        got = eng.conv_layer(torch.as_tensor(x, device='cuda:0'), s, 1, last_layer=True, n_out=64).cpu().numpy()
+        ref = O.conv_layer(x.astype(np.float64), p, 9, 1, s, last_layer=True)
+        assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+print('ok')
+"""
+    env = dict(os.environ, JCM_FFT_CACHE_GB='0', PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] + sys.path))
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
