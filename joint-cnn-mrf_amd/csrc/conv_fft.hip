@@ -21,7 +21,9 @@
 #include <rocblas/rocblas.h>
 
 #include <cstdlib>
+#include <map>
 #include <mutex>
+#include <utility>
 
 #include "fft_lds.h"
 #include "kernels.h"
@@ -330,13 +332,19 @@ static int slice_images(const ConvArgs& a, const Sizes& s) {
     default: CALL(192); break;                   \
   }
 
-// one rocBLAS handle per device, shared by the engines of the process (created on first use; the stream is set per call)
-static rocblas_handle blas_for_device(int dev) {
+// one rocBLAS handle per (device, stream), shared by the engines of the process and created on first use: a handle owns scratch
+// memory, so concurrent streams (the three resolution branches) each need their own
+static rocblas_handle blas_for(int dev, hipStream_t st) {
   static std::mutex mu;
-  static rocblas_handle hs[64] = {};
+  static std::map<std::pair<int, hipStream_t>, rocblas_handle> hs;
   std::lock_guard<std::mutex> lk(mu);
-  if (!hs[dev & 63] && rocblas_create_handle(&hs[dev & 63]) != rocblas_status_success) hs[dev & 63] = nullptr;
-  return hs[dev & 63];
+  auto it = hs.find({dev, st});
+  if (it != hs.end()) return it->second;
+  rocblas_handle h = nullptr;
+  if (rocblas_create_handle(&h) != rocblas_status_success) return nullptr;
+  if (rocblas_set_stream(h, st) != rocblas_status_success) { rocblas_destroy_handle(h); return nullptr; }
+  hs[{dev, st}] = h;
+  return h;
 }
 }  // namespace cfft
 
@@ -386,7 +394,7 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int in_layout, int out_layou
   cf* Yf = Xf + (size_t)F * a.B * a.Cin;
   int dev = 0;
   if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
-  rocblas_handle bh = blas_for_device(dev);
+  rocblas_handle bh = blas_for(dev, st);
   if (!bh) return hipErrorUnknown;
   for (int b0 = 0; b0 < a.B; b0 += SL) {
     const int nb = a.B - b0 < SL ? a.B - b0 : SL;
@@ -400,9 +408,6 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int in_layout, int out_layou
   }
   // row-major Y[b][co] = X[b][ci] Wf[ci][co]  ==  column-major (CoutP x B) = (CoutP x Cin) (Cin x B)
   {
-    static std::mutex mu;                       // the handle's stream is per call
-    std::lock_guard<std::mutex> lk(mu);
-    if (rocblas_set_stream(bh, st) != rocblas_status_success) return hipErrorUnknown;
     if (g0 && hipEventRecord(g0, st) != hipSuccess) return hipErrorUnknown;
     const rocblas_float_complex one{1.f, 0.f}, zero{0.f, 0.f};
     const rocblas_status rs = rocblas_cgemm_strided_batched(

@@ -98,6 +98,10 @@ struct jcm_ctx {
   const float** bias_ptrs = nullptr;
   int* cond0 = nullptr;         // single zero (jcm_conv_mrf)
   int sm_algo = 3;              // 0 = FFT (2-D rocFFT), 1 = direct sliding-window VALU kernel, 2 = rocFFT with split row-pruned inverse, 3 = fused LDS FFTs (sm_fused.hip)
+  int branch_streams = 0;       // EXPERIMENTAL, off: the three resolution branches of the part detector on three HIP streams (fork / join by events)
+  hipStream_t side[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  bool no_reuse = false;        // while branches run concurrently, arena scratch is not handed out twice
   int conv9_fft = 1;            // fp32 handles: wide 9x9 layers in the frequency domain (conv_fft.hip) when the shape allows; 0 = fp32 MFMA chain
   struct FftW { void* p = nullptr; size_t bytes = 0; bool valid = false; };
   std::map<std::string, FftW> fft_w;   // filter spectra per "<scope>@HxW", computed on first use, invalidated by refresh_derived
