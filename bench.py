@@ -131,12 +131,12 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
         freq_domain = kname.startswith('conv_fft')
         if freq_domain:
             # wide 9x9 layers in the frequency domain: the dominant kernel is the channel GEMM (rocBLAS cgemm_strided_batched, one complex
-            # matrix product per frequency of the 72 x 100 transform); its own algorithmic FLOPs, its own HIP events
+            # matrix product per frequency of the 70 x 98 transform); its own algorithmic FLOPs, its own HIP events
             tot_ms, tot_n, tot_flops = 0.0, 0, 0.0
             for scope, (cin, cout) in {'conv4_fullres': (256, 512), 'conv5': (512, 512)}.items():
                 ms, n = eng.profile_read(scope + '/gemm')
                 tot_ms, tot_n = tot_ms + ms, tot_n + n
-                tot_flops += 8.0 * cin * cout * 72 * 51 * B * args.steps if n else 0.0
+                tot_flops += 8.0 * cin * cout * 70 * 50 * B * args.steps if n else 0.0
         launch_ms = tot_ms / max(tot_n, 1)                     # average launch duration (HIP events, launch stream)
         flops_launch = tot_flops / max(tot_n, 1)               # average algorithmic FLOPs per launch
         achieved = flops_launch / (launch_ms * 1e-3) / 1e12 if tot_n else None
@@ -163,7 +163,7 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
             'path_tflops': value * FLOPS_PD_SM / (16 if args.debug else 1) / 1e12,
             'roofline': {'bound': 'mfma', 'kernel': ('channel GEMM of the frequency-domain 9x9 layers (conv4_fullres + conv5; %s)' if freq_domain else
                                                      'conv_igemm 9x9, 60x90 maps (conv4_fullres + conv5 launches; %s)')
-                                   % ('complex fp32, one [B x Cin] x [Cin x Cout] product per frequency of the 72 x 100 transform = 3672 per launch; achieved = 8 B Cin Cout x 3672 FLOP / GEMM time'
+                                   % ('complex fp32, one [B x Cin] x [Cin x Cout] product per frequency of the 70 x 98 transform = 3500 per launch; achieved = 8 B Cin Cout x 3500 FLOP / GEMM time'
                                       if freq_domain else
                                       'fp32 operands as 3 bf16 parts, 6 x bf16 MFMA 32x32x16 per k16 step, 12x32 patch x 256 ch; achieved = executed bf16 MFMA FLOPs (6 x algorithmic) against the bf16 peak'
                                       if f32_conv == 'split' else

@@ -39,6 +39,8 @@ template <int N> struct Plan;
 template <> struct Plan<192> { static constexpr int R1 = 8, R2 = 8, R3 = 3; };
 template <> struct Plan<128> { static constexpr int R1 = 8, R2 = 4, R3 = 4; };
 template <> struct Plan<100> { static constexpr int R1 = 4, R2 = 5, R3 = 5; };
+template <> struct Plan<98> { static constexpr int R1 = 7, R2 = 14, R3 = 1; };
+template <> struct Plan<70> { static constexpr int R1 = 7, R2 = 10, R3 = 1; };
 template <> struct Plan<72> { static constexpr int R1 = 8, R2 = 3, R3 = 3; };
 template <> struct Plan<60> { static constexpr int R1 = 4, R2 = 15, R3 = 1; };
 template <> struct Plan<40> { static constexpr int R1 = 8, R2 = 5, R3 = 1; };
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) void weight_spectra_kernel(const float* __rest
 
 struct Sizes { int NY, NX; };
 static bool pick(int need, int* n) {
-  static const int ok[] = {24, 32, 40, 60, 72, 100, 128, 192};
+  static const int ok[] = {24, 32, 40, 60, 70, 72, 98, 100, 128, 192};      // 70 x 98 is the exact linear-convolution size of a 9x9 kernel on the 60x90 maps
   for (int v : ok)
     if (v >= need) { *n = v; return true; }
   return false;
@@ -326,7 +328,9 @@ static int slice_images(const ConvArgs& a, const Sizes& s) {
     case 32: CALL(32); break;                    \
     case 40: CALL(40); break;                    \
     case 60: CALL(60); break;                    \
+    case 70: CALL(70); break;                    \
     case 72: CALL(72); break;                    \
+    case 98: CALL(98); break;                    \
     case 100: CALL(100); break;                  \
     case 128: CALL(128); break;                  \
     default: CALL(192); break;                   \

@@ -22,6 +22,12 @@ template <int S> __device__ __forceinline__ cf add_i(cf a, cf b) {
 
 // r-point DFTs, y_k = sum_m x_m e^{S 2 pi i m k / r} (S = +1 inverse, -1 forward), in place
 template <int R, int S> struct Dft;
+template <int S> struct Dft<2, S> {
+  static __device__ __forceinline__ void run(cf (&x)[2]) {
+    const cf a = x[0] + x[1], b = x[0] - x[1];
+    x[0] = a; x[1] = b;
+  }
+};
 template <int S> struct Dft<3, S> {
   static __device__ __forceinline__ void run(cf (&x)[3]) {
     const cf t1 = x[1] + x[2];
@@ -87,8 +93,30 @@ __device__ __forceinline__ void dft_pfa(cf (&x)[R1 * R2]) {
     for (int k1 = 0; k1 < R1; ++k1) x[(A * k1 + B * k2) % R] = c[k1];
   }
 }
+// 7 points: the three conjugate pairs (m, 7 - m) as sums and differences, 18 real-by-complex multiply-adds each way
+template <int S> struct Dft<7, S> {
+  static __device__ __forceinline__ void run(cf (&x)[7]) {
+    constexpr float c1 = 0.62348980185873353f, c2 = -0.22252093395631440f, c3 = -0.90096886790241913f;
+    constexpr float s1 = 0.78183148246802981f, s2 = 0.97492791218182361f, s3 = 0.43388373911755812f;
+    const cf p1 = x[1] + x[6], p2 = x[2] + x[5], p3 = x[3] + x[4];
+    const cf q1 = x[1] - x[6], q2 = x[2] - x[5], q3 = x[3] - x[4];
+    // y_k = x0 + sum_m cos(2 pi m k / 7) p_m  +-  S i sum_m sin(2 pi m k / 7) q_m
+    const cf a1 = sfma(c3, p3, sfma(c2, p2, sfma(c1, p1, x[0])));
+    const cf a2 = sfma(c1, p3, sfma(c3, p2, sfma(c2, p1, x[0])));
+    const cf a3 = sfma(c2, p3, sfma(c1, p2, sfma(c3, p1, x[0])));
+    const cf b1 = sfma(s3, q3, sfma(s2, q2, s1 * q1));
+    const cf b2 = sfma(-s1, q3, sfma(-s3, q2, s2 * q1));     // sin(2 pi 2 m / 7), m = 1, 2, 3: s2, -s3, -s1
+    const cf b3 = sfma(s2, q3, sfma(-s1, q2, s3 * q1));      // sin(2 pi 3 m / 7): s3, -s1, s2
+    x[0] = x[0] + (p1 + (p2 + p3));
+    x[1] = add_i<S>(a1, b1); x[6] = add_i<-S>(a1, b1);
+    x[2] = add_i<S>(a2, b2); x[5] = add_i<-S>(a2, b2);
+    x[3] = add_i<S>(a3, b3); x[4] = add_i<-S>(a3, b3);
+  }
+};
 template <int S> struct Dft<15, S> { static __device__ __forceinline__ void run(cf (&x)[15]) { dft_pfa<3, 5, 10, 6, S>(x); } };
 template <int S> struct Dft<12, S> { static __device__ __forceinline__ void run(cf (&x)[12]) { dft_pfa<3, 4, 4, 9, S>(x); } };
+template <int S> struct Dft<10, S> { static __device__ __forceinline__ void run(cf (&x)[10]) { dft_pfa<2, 5, 5, 6, S>(x); } };    // k = 5 k1 + 6 k2
+template <int S> struct Dft<14, S> { static __device__ __forceinline__ void run(cf (&x)[14]) { dft_pfa<2, 7, 7, 8, S>(x); } };    // k = 7 k1 + 8 k2
 
 }  // namespace fftl
 }  // namespace jcm
