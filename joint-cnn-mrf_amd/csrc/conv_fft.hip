@@ -1,9 +1,10 @@
-// 9x9 SAME convolution of the wide layers (conv4_*, conv5: 256/512 -> 512 channels) in the FREQUENCY domain, fp32.
+// Stride-1 SAME convolution (9x9, 5x5) in the FREQUENCY domain, fp32 arithmetic: every such layer of an fp32 handle, the wide 9x9
+// layers (conv4_*, conv5: 256/512 -> 512 channels) of a bf16 handle.
 //
 // A 9x9 layer with 512 x 512 channels is 229 GFLOP per image as a direct convolution.  With the maps transformed once
 // (NY x NX >= (H+8) x (W+8): a linear convolution, nothing wraps) the layer is, for every frequency, one complex matrix product
-// over the channels:  Y[f][b][co] = sum_ci X[f][b][ci] * Wf[f][ci][co]  -- 8*Cin*Cout*NY*(NX/2+1) = 7.7 GFLOP per image for conv5
-// (72 x 100 transform of the 60 x 90 maps), 30x fewer.  The transforms add 0.4 GFLOP.  In fp32 this route is MORE accurate than the
+// over the channels:  Y[f][b][co] = sum_ci X[f][b][ci] * Wf[f][ci][co]  -- 8*Cin*Cout*NY*(NX/2+1) = 7.3 GFLOP per image for conv5
+// (70 x 98 transform of the 60 x 90 maps), 31x fewer.  The transforms add 0.4 GFLOP.  In fp32 this route is MORE accurate than the
 // fp32 MFMA accumulation chain it replaces (4e-7 of the output scale against 1.3e-6 for a sequential fp32 sum of the 41 472
 // products: DESIGN.md 4.1c), so it runs behind the same parity tests.
 //
@@ -11,11 +12,11 @@
 //                                           along x in LDS; X_c, X_{c+1} recovered through the Hermitian symmetry -> T[b][kx][y][ci]
 //   cols_fwd   (image, kx, 64 channels)   : FFT along y -> Xf[ky][kx][b][ci]   (frequency-major: a GEMM operand per frequency)
 //   rocBLAS cgemm_strided_batched         : the plain library GEMM, batch = NY * (NX/2+1) frequencies
-//   cols_inv   (image, kx, 64 channels)   : inverse along ky, rows 4 .. H+3 kept -> T[b][y][kx][co]
+//   cols_inv   (image, kx, 64 channels)   : inverse along ky, rows pad .. pad+H-1 kept -> T[b][y][kx][co]
 //   rows_inv   (image, row, 64 channels)  : Z = Y_c + i Y_{c+1} (Hermitian extension), inverse complex FFT along kx, columns 4 .. W+3,
 //                                           1/(NY NX), bias, ReLU, folded BatchNorm -> NHWC fp32
 // The filter spectra Wf[f][ci][co] (flipped kernel: TF's conv2d is a correlation) are computed once per (layer, map size) at
-// jcm_finalize / first use: 7.7 GB for conv5.  FFTs: the in-LDS decimation-in-frequency stages of sm_fused.hip, channel-vectorised
+// first use: 7.3 GB for conv5.  FFTs: the in-LDS decimation-in-frequency stages of sm_fused.hip, channel-vectorised
 // (consecutive lanes = consecutive channels: every LDS and HBM access of a wave is one contiguous 512-byte run).
 // Reference semantics: conv2d SAME stride 1 + bias + ReLU + BatchNorm (main.py:133-135,156-169).
 #include <rocblas/rocblas.h>
