@@ -234,6 +234,59 @@ __global__ __launch_bounds__(NT) void rows_inv_kernel(const cf* __restrict__ T, 
   }
 }
 
+// ---- rows, inverse of layer L + epilogue + rows, forward of layer L+1 in one kernel (fp32 handles; same map, same NX, C % 64 == 0):
+// the activation between two frequency-domain layers never goes to HBM.  T_in[b][y][kx][c] -> T_out[b][kx][y][c].
+// The epilogue's result IS the next layer's packed input: channel pair (c, c+1) = one complex number.
+template <int NX>
+__global__ __launch_bounds__(NT) void rows_inv_fwd_kernel(const cf* __restrict__ T, cf* __restrict__ Tn, const float* __restrict__ bias,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift, int relu_bn, int H, int W, int C,
+                                                          int pad, float norm) {
+  constexpr int CH = CB / 2, NXH = NX / 2 + 1;
+  __shared__ cf buf[NX * CH];
+  __shared__ cf nxt[NX * CH];
+  __shared__ cf tw[NX];
+  const int tid = threadIdx.x;
+  const int cblk = blockIdx.x % (C / CB), by = blockIdx.x / (C / CB);
+  const int y = by % H, b = by / H;
+  twiddles<NX>(tw, tid);
+  const float4* src = reinterpret_cast<const float4*>(T + ((size_t)(b * H + y) * NXH) * C + cblk * CB);
+  for (int t = tid; t < NXH * CH; t += NT) {
+    const int k = t / CH, v = t % CH;
+    float4 q = src[(size_t)k * (C / 2) + v];
+    const bool edge = k == 0 || k == NX / 2;
+    if (edge) { q.y = 0.f; q.w = 0.f; }
+    buf[k * CH + v] = cf{q.x - q.w, q.y + q.z};
+    if (!edge) buf[(NX - k) * CH + v] = cf{q.x + q.w, q.z - q.y};
+  }
+  __syncthreads();
+  fft<NX, 1, CH>(buf, tw, tid);
+  {
+    const int v = tid % CH, c = cblk * CB + 2 * v;
+    const float b0v = bias[c], b1v = bias[c + 1];
+    float s0 = 1.f, s1 = 1.f, h0 = 0.f, h1 = 0.f;
+    if (relu_bn) { s0 = scale[c]; h0 = shift[c]; s1 = scale[c + 1]; h1 = shift[c + 1]; }
+    for (int x = tid / CH; x < NX; x += NT / CH) {
+      cf o = {0.f, 0.f};
+      if (x < W) {
+        const cf z = buf[pos<NX>(x + pad) * CH + v];
+        float v0 = z.x * norm + b0v, v1 = z.y * norm + b1v;
+        if (relu_bn) { v0 = fmaxf(v0, 0.f) * s0 + h0; v1 = fmaxf(v1, 0.f) * s1 + h1; }
+        o = cf{v0, v1};
+      }
+      nxt[x * CH + v] = o;
+    }
+  }
+  __syncthreads();
+  fft<NX, -1, CH>(nxt, tw, tid);
+  float4* dst = reinterpret_cast<float4*>(Tn);
+  for (int t = tid; t < NXH * CH; t += NT) {
+    const int k = t / CH, v = t % CH;
+    const cf zk = nxt[pos<NX>(k) * CH + v], zn = nxt[pos<NX>(k == 0 ? 0 : NX - k) * CH + v];
+    dst[(((size_t)(b * NXH + k) * H + y) * C + cblk * CB) / 2 + v] =
+        make_float4(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y), 0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+  }
+}
+
 // ---- filter spectra: HWIO fp32 [k][k][Cin][Cout] -> Wf[ky][kx][ci][co < CoutP] = sum_{a,b} w[k-1-a][k-1-b][ci][co] e^{-2 pi i (ky a / NY + kx b / NX)}
 // (the flipped kernel: TF's conv2d is a correlation; channels Cout .. CoutP-1 are zero)
 template <int KS>
@@ -312,6 +365,9 @@ template <int NX> static void launch_rows_inv(const ConvArgs& a, int layout, con
   else
     hipLaunchKernelGGL((rows_inv_kernel<NX, 2>), grid, dim3(NT), 0, st, T, a.out, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm, b0);
 }
+template <int NX> static void launch_rows_inv_fwd(const ConvArgs& a, const cf* T, cf* Tn, int pad, float norm, hipStream_t st) {
+  hipLaunchKernelGGL(rows_inv_fwd_kernel<NX>, dim3(a.B * a.H * (a.Cout / CB)), dim3(NT), 0, st, T, Tn, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.Cout, pad, norm);
+}
 // Images per slice of the transform passes.  JCM_FFT_SLICE_MB=n keeps the row-transformed tensor T of a slice below n MB (so that it
 // could stay in the 256 MB Infinity Cache between the row and the column kernel); measured at 160 / 96 / 48 MB: 2.6 / 2.1 / 9 % SLOWER
 // than the whole batch in one launch (fp32 B=64; bf16 B=256: 3.9 %), so the default is 0 = whole batch.
@@ -382,10 +438,27 @@ size_t conv_fft_workspace_bytes(const ConvArgs& a, int ks) {
   ap.CoutP = (int)cop;
   return ((size_t)slice_images(ap, s) * NXH * a.H * cmax + (size_t)s.NY * NXH * a.B * (a.Cin + cop)) * sizeof(cf);
 }
+// Can layer L (a, ks) hand its output to layer L+1 (kernel size ks_next, same map) in row-transformed form?  Same NX for both kernel
+// sizes, unpadded channel count, whole batch in one pass.
+bool conv_fft_fusable(const ConvArgs& a, int ks, int ks_next) {
+  Sizes s, n;
+  if (!sizes_of(a.H, a.W, ks, &s) || !sizes_of(a.H, a.W, ks_next, &n) || s.NX != n.NX || s.NX > 100 || a.Cout % CB) return false;   // (two row buffers in LDS)
+  ConvArgs ap = a;
+  ap.CoutP = a.Cout;
+  return slice_images(ap, s) == a.B;
+}
+size_t conv_fft_handover_bytes(const ConvArgs& a, int ks) {      // T[b][kx][y][Cout] of the next layer
+  Sizes s;
+  if (!sizes_of(a.H, a.W, ks, &s)) return 0;
+  return (size_t)a.B * (s.NX / 2 + 1) * a.H * a.Cout * sizeof(cf);
+}
 // a.wp = the filter spectra of THIS map size and kernel size; `work` = conv_fft_workspace_bytes(a, ks) bytes.  g0 / g1: optional events
 // recorded around the GEMM (the dominant kernel of the layer) for the roofline record.
 // in_layout / out_layout: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar
-hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int in_layout, int out_layout, void* work, hipEvent_t g0, hipEvent_t g1, hipStream_t st) {
+// t_in (fp32 handles): the row-transformed input T[b][kx][y][ci] left by the previous layer's fused kernel -- the forward row pass is skipped;
+// t_next: write the NEXT layer's row-transformed input there instead of the spatial output (conv_fft_fusable() says when that is legal).
+hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int in_layout, int out_layout, void* work, const void* t_in, void* t_next, hipEvent_t g0, hipEvent_t g1,
+                        hipStream_t st) {
   Sizes s;
   if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s) || (out_layout == 2 && a0.Cout % 8)) return hipErrorInvalidValue;
   ConvArgs a = a0;
@@ -393,7 +466,8 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int in_layout, int out_layou
   const int pad = (ks - 1) / 2;
   const int NXH = s.NX / 2 + 1, F = s.NY * NXH;
   const size_t cmax = a.Cin > a.CoutP ? a.Cin : a.CoutP;
-  const int SL = slice_images(a, s);
+  const int SL = (t_in || t_next) ? a.B : slice_images(a, s);      // the fused hand-over covers the whole batch
+  if ((t_in || t_next) && (in_layout != 0 || out_layout != 0 || (t_next && a.Cout % CB))) return hipErrorInvalidValue;
   cf* T = static_cast<cf*>(work);
   cf* Xf = T + (size_t)SL * NXH * a.H * cmax;
   cf* Yf = Xf + (size_t)F * a.B * a.Cin;
@@ -403,10 +477,12 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int in_layout, int out_layou
   if (!bh) return hipErrorUnknown;
   for (int b0 = 0; b0 < a.B; b0 += SL) {
     const int nb = a.B - b0 < SL ? a.B - b0 : SL;
+    if (!t_in) {
 #define CALL(N) launch_rows_fwd<N>(a, in_layout, T, b0, nb, st)
-    CFFT_BY_SIZE(s.NX, CALL)
+      CFFT_BY_SIZE(s.NX, CALL)
 #undef CALL
-#define CALL(N) launch_cols_fwd<N>(a, T, Xf, NXH, b0, nb, st)
+    }
+#define CALL(N) launch_cols_fwd<N>(a, t_in ? static_cast<const cf*>(t_in) : T, Xf, NXH, b0, nb, st)
     CFFT_BY_SIZE(s.NY, CALL)
 #undef CALL
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
@@ -427,9 +503,15 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int in_layout, int out_layou
 #define CALL(N) launch_cols_inv<N>(a, Yf, T, NXH, pad, b0, nb, st)
     CFFT_BY_SIZE(s.NY, CALL)
 #undef CALL
-#define CALL(N) launch_rows_inv<N>(a, out_layout, T, pad, 1.0f / (float)(s.NY * s.NX), b0, nb, st)
-    CFFT_BY_SIZE(s.NX, CALL)
+    if (t_next) {
+#define CALL(N) launch_rows_inv_fwd<N>(a, T, static_cast<cf*>(t_next), pad, 1.0f / (float)(s.NY * s.NX), st)
+      CFFT_BY_SIZE(s.NX, CALL)
 #undef CALL
+    } else {
+#define CALL(N) launch_rows_inv<N>(a, out_layout, T, pad, 1.0f / (float)(s.NY * s.NX), b0, nb, st)
+      CFFT_BY_SIZE(s.NX, CALL)
+#undef CALL
+    }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
   }
   return hipSuccess;

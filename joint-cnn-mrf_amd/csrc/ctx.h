@@ -102,6 +102,9 @@ struct jcm_ctx {
   hipStream_t side[2] = {nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   bool no_reuse = false;        // while branches run concurrently, arena scratch is not handed out twice
+  // transient, set by jcm_pd_forward around two consecutive frequency-domain layers: the first writes the second's row-transformed input
+  void* fft_t_next = nullptr;
+  const void* fft_t_in = nullptr;
   int conv9_fft = 1;            // fp32 handles: wide 9x9 layers in the frequency domain (conv_fft.hip) when the shape allows; 0 = fp32 MFMA chain
   struct FftW { void* p = nullptr; size_t bytes = 0; bool valid = false; };
   std::map<std::string, FftW> fft_w;   // filter spectra per "<scope>@HxW", computed on first use, invalidated by refresh_derived

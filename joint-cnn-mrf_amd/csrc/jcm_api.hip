@@ -176,7 +176,7 @@ static int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope
   const size_t mark = c->arena_off;
   void* work = arena_alloc<char>(c, conv_fft_workspace_bytes(a, L->ks));
   if (!c->no_reuse) c->arena_off = mark;                 // scratch of this layer only: later layers run behind it on the stream
-  if (c->dry) return JCM_OK;
+  if (c->dry) { c->fft_t_in = nullptr; c->fft_t_next = nullptr; return JCM_OK; }
   // Filter spectra are cached per (layer, map size).  The cache is bounded (JCM_FFT_CACHE_GB, default 64): a caller that walks many
   // image sizes (7.7 GB per size for conv5) makes it drop every spectrum that is not this layer's before it grows past the bound.
   const std::string key = scope + "@" + std::to_string(H) + "x" + std::to_string(W);
@@ -208,7 +208,10 @@ static int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope
   hipEvent_t e0 = nullptr, e1 = nullptr, g0 = nullptr, g1 = nullptr;
   JCM_TRY(prof_begin(c, &e0, &e1));
   if (c->profile && (pool_get(c, &g0) != JCM_OK || pool_get(c, &g1) != JCM_OK)) { g0 = g1 = nullptr; }
-  const hipError_t e = conv_fft_f32(a, L->ks, in_layout, out_layout, work, g0, g1, c->stream);
+  const void* t_in = c->fft_t_in;
+  void* t_next = c->fft_t_next;
+  c->fft_t_in = nullptr; c->fft_t_next = nullptr;
+  const hipError_t e = conv_fft_f32(a, L->ks, in_layout, out_layout, work, t_in, t_next, g0, g1, c->stream);
   if (g0 && g1 && e == hipSuccess) c->prof[scope + "/gemm"].emplace_back(g0, g1);
   else { if (g0) c->event_pool.push_back(g0); if (g1) c->event_pool.push_back(g1); }
   prof_end(c, scope, e0, e1, e == hipSuccess);
@@ -401,6 +404,19 @@ bool takes_c5strip(const ConvLayer* L, int B, int H, int W) {
   return conv5_strip_bf16_supported(a, L->ks);
 }
 
+// fp32 handles: two consecutive frequency-domain layers on the same map -- the first one's fused inverse/forward row kernel writes the
+// second one's row-transformed input (from the arena) and the activation between them never reaches HBM.  Call right before
+// run_conv(first); returns the buffer to pass to expect_handover() before run_conv(second), or null.
+static void* offer_handover(jcm_ctx* c, const ConvLayer* La, const ConvLayer* Lb, int B, int H, int W) {
+  if (c->precision != JCM_PRECISION_F32 || !takes_fft(c, La, B, H, W) || !takes_fft(c, Lb, B, H, W)) return nullptr;
+  ConvArgs a{};
+  a.B = B; a.H = H; a.W = W; a.Cin = La->cin; a.Cout = La->cout;
+  if (La->cout != Lb->cin || !conv_fft_fusable(a, La->ks, Lb->ks)) return nullptr;
+  void* t = arena_alloc<char>(c, conv_fft_handover_bytes(a, La->ks));
+  c->fft_t_next = t;
+  return t;
+}
+
 int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logits) {
   static const char* const kRes[3] = {"fullres", "halfres", "quarterres"};
   const ConvLayer* L4 = conv_of(c, "conv4_fullres");
@@ -499,7 +515,9 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
     const ConvLayer* L4r = conv_of(c, "conv4_" + res);
     if (!L4r) return fail(JCM_ERR_STATE, "part-detector parameters incomplete (conv4_" + res + ")");
     const int in4 = planar && L3->cout % 8 == 0 && takes_strip(L4r, B, h3, w3) ? 1 : 0;      // the patch kernels read NHWC
+    void* t34 = offer_handover(c, L3, L4r, B, h3, w3);
     JCM_TRY(run_conv(c, "conv3_" + res, 1, p2, B, h3, w3, 1, c3, bf, false, pl23, in4));   // :48,56,65
+    c->fft_t_in = t34;
     JCM_TRY(run_conv(c, "conv4_" + res, 1, c3, B, h3, w3, 1, x4[r], bf, false, in4, planar));   // :49,57,66
     if (!fork) c->arena_off = mark;
     if (fork && !c->dry && r > 0) HIP_TRY(hipEventRecord(c->ev_join[r - 1], c->stream));
@@ -515,7 +533,9 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
     else HIP_TRY(upsample_merge3(x4[0], x4[1], h4[1], w4[1], x4[2], h4[2], w4[2], merged, bf, B, hh, ww, L4->cout, c->stream));
   }
   void* c5 = act((size_t)B * hh * ww * L5->cout);
+  void* t56 = offer_handover(c, L5, conv_of(c, "conv6"), B, hh, ww);
   JCM_TRY(run_conv(c, "conv5", 1, merged, B, hh, ww, 1, c5, bf, false, planar, planar));   // :71
+  c->fft_t_in = t56;
   JCM_TRY(run_conv(c, "conv6", 1, c5, B, hh, ww, 1, logits, bf, true, planar, 0));         // :72
   return JCM_OK;
 }
