@@ -28,6 +28,7 @@
 
 #include "fft_lds.h"
 #include "kernels.h"
+#include "resize_tf1.h"
 
 namespace jcm {
 
@@ -133,6 +134,51 @@ __global__ __launch_bounds__(NT) void rows_fwd_kernel(const void* __restrict__ i
     const int k = t / CH, v = t % CH;
     const cf zk = buf[pos<NX>(k) * CH + v], zn = buf[pos<NX>(k == 0 ? 0 : NX - k) * CH + v];
     dst[(((size_t)(bl * NXH + k) * H + y) * C + cblk * CB) / 2 + v] =
+        make_float4(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y), 0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+  }
+}
+
+// ---- rows, forward, of the MERGED map (fp32 NHWC): x = ((x1 + up(x2)) + up(x3)) / 3 (main.py:58,67,69-70; the arithmetic and association
+// order of upsample_merge3_kernel) is formed while the row is loaded: the merged tensor never goes to HBM.
+template <int NX>
+__global__ __launch_bounds__(NT) void rows_fwd_merge_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int H2, int W2,
+                                                            const float* __restrict__ x3, int H3, int W3, cf* __restrict__ T, int H, int W, int C, float sy2,
+                                                            float sx2, float sy3, float sx3) {
+  constexpr int CH = CB / 2, NXH = NX / 2 + 1;
+  __shared__ cf buf[NX * CH];
+  __shared__ cf tw[NX];
+  const int tid = threadIdx.x;
+  const int cblk = blockIdx.x % (C / CB), by = blockIdx.x / (C / CB);
+  const int y = by % H, b = by / H;
+  twiddles<NX>(tw, tid);
+  const Tap ty2 = tf1_tap(y, H2, sy2), ty3 = tf1_tap(y, H3, sy3);
+  const int C2 = C / 2;
+  const cf* p1 = reinterpret_cast<const cf*>(x1 + ((size_t)(b * H + y) * W) * C + cblk * CB);
+  const cf* p2 = reinterpret_cast<const cf*>(x2 + (size_t)b * H2 * W2 * C + cblk * CB);
+  const cf* p3 = reinterpret_cast<const cf*>(x3 + (size_t)b * H3 * W3 * C + cblk * CB);
+  auto bil = [&](const cf* p, int Wl, Tap ty, Tap tx, int v) __attribute__((always_inline)) {
+    const cf tl = p[((size_t)ty.lo * Wl + tx.lo) * C2 + v], tr = p[((size_t)ty.lo * Wl + tx.hi) * C2 + v];
+    const cf bl = p[((size_t)ty.hi * Wl + tx.lo) * C2 + v], br = p[((size_t)ty.hi * Wl + tx.hi) * C2 + v];
+    return cf{lerp2(tl.x, tr.x, bl.x, br.x, tx.t, ty.t), lerp2(tl.y, tr.y, bl.y, br.y, tx.t, ty.t)};
+  };
+  for (int t = tid; t < NX * CH; t += NT) {
+    const int x = t / CH, v = t % CH;
+    cf z = {0.f, 0.f};
+    if (x < W) {
+      const cf a = p1[(size_t)x * C2 + v];
+      const cf u2 = (H2 == H && W2 == W) ? p2[((size_t)y * W + x) * C2 + v] : bil(p2, W2, ty2, tf1_tap(x, W2, sx2), v);
+      const cf u3 = (H3 == H && W3 == W) ? p3[((size_t)y * W + x) * C2 + v] : bil(p3, W3, ty3, tf1_tap(x, W3, sx3), v);
+      z = cf{((a.x + u2.x) + u3.x) / 3.0f, ((a.y + u2.y) + u3.y) / 3.0f};
+    }
+    buf[t] = z;
+  }
+  __syncthreads();
+  fft<NX, -1, CH>(buf, tw, tid);
+  float4* dst = reinterpret_cast<float4*>(T);
+  for (int t = tid; t < NXH * CH; t += NT) {
+    const int k = t / CH, v = t % CH;
+    const cf zk = buf[pos<NX>(k) * CH + v], zn = buf[pos<NX>(k == 0 ? 0 : NX - k) * CH + v];
+    dst[(((size_t)(b * NXH + k) * H + y) * C + cblk * CB) / 2 + v] =
         make_float4(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y), 0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
   }
 }
@@ -368,6 +414,10 @@ template <int NX> static void launch_rows_inv(const ConvArgs& a, int layout, con
 template <int NX> static void launch_rows_inv_fwd(const ConvArgs& a, const cf* T, cf* Tn, int pad, float norm, hipStream_t st) {
   hipLaunchKernelGGL(rows_inv_fwd_kernel<NX>, dim3(a.B * a.H * (a.Cout / CB)), dim3(NT), 0, st, T, Tn, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.Cout, pad, norm);
 }
+template <int NX> static void launch_rows_fwd_merge(const ConvArgs& a, const FftMerge& m, cf* T, hipStream_t st) {
+  hipLaunchKernelGGL(rows_fwd_merge_kernel<NX>, dim3(a.B * a.H * (a.Cin / CB)), dim3(NT), 0, st, static_cast<const float*>(a.x), m.x2, m.H2, m.W2, m.x3, m.H3, m.W3, T, a.H,
+                     a.W, a.Cin, (float)m.H2 / (float)a.H, (float)m.W2 / (float)a.W, (float)m.H3 / (float)a.H, (float)m.W3 / (float)a.W);
+}
 // Images per slice of the transform passes.  JCM_FFT_SLICE_MB=n keeps the row-transformed tensor T of a slice below n MB (so that it
 // could stay in the 256 MB Infinity Cache between the row and the column kernel); measured at 160 / 96 / 48 MB: 2.6 / 2.1 / 9 % SLOWER
 // than the whole batch in one launch (fp32 B=64; bf16 B=256: 3.9 %), so the default is 0 = whole batch.
@@ -457,8 +507,8 @@ size_t conv_fft_handover_bytes(const ConvArgs& a, int ks) {      // T[b][kx][y][
 // in_layout / out_layout: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar
 // t_in (fp32 handles): the row-transformed input T[b][kx][y][ci] left by the previous layer's fused kernel -- the forward row pass is skipped;
 // t_next: write the NEXT layer's row-transformed input there instead of the spatial output (conv_fft_fusable() says when that is legal).
-hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int in_layout, int out_layout, void* work, const void* t_in, void* t_next, hipEvent_t g0, hipEvent_t g1,
-                        hipStream_t st) {
+hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int in_layout, int out_layout, void* work, const void* t_in, void* t_next, const FftMerge* merge,
+                        hipEvent_t g0, hipEvent_t g1, hipStream_t st) {
   Sizes s;
   if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s) || (out_layout == 2 && a0.Cout % 8)) return hipErrorInvalidValue;
   ConvArgs a = a0;
@@ -466,8 +516,8 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int in_layout, int out_layou
   const int pad = (ks - 1) / 2;
   const int NXH = s.NX / 2 + 1, F = s.NY * NXH;
   const size_t cmax = a.Cin > a.CoutP ? a.Cin : a.CoutP;
-  const int SL = (t_in || t_next) ? a.B : slice_images(a, s);      // the fused hand-over covers the whole batch
-  if ((t_in || t_next) && (in_layout != 0 || out_layout != 0 || (t_next && a.Cout % CB))) return hipErrorInvalidValue;
+  const int SL = (t_in || t_next || merge) ? a.B : slice_images(a, s);      // the fused hand-over covers the whole batch
+  if ((t_in || t_next || merge) && (in_layout != 0 || out_layout != 0 || (t_next && a.Cout % CB))) return hipErrorInvalidValue;
   cf* T = static_cast<cf*>(work);
   cf* Xf = T + (size_t)SL * NXH * a.H * cmax;
   cf* Yf = Xf + (size_t)F * a.B * a.Cin;
@@ -477,7 +527,11 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int in_layout, int out_layou
   if (!bh) return hipErrorUnknown;
   for (int b0 = 0; b0 < a.B; b0 += SL) {
     const int nb = a.B - b0 < SL ? a.B - b0 : SL;
-    if (!t_in) {
+    if (merge && !t_in) {        // a.x = the full-resolution branch; the two upsampled branches are added while the row is loaded
+#define CALL(N) launch_rows_fwd_merge<N>(a, *merge, T, st)
+      CFFT_BY_SIZE(s.NX, CALL)
+#undef CALL
+    } else if (!t_in) {
 #define CALL(N) launch_rows_fwd<N>(a, in_layout, T, b0, nb, st)
       CFFT_BY_SIZE(s.NX, CALL)
 #undef CALL

@@ -4,6 +4,7 @@
 // (evaluation.py:15-24, main.py:389-397).  NHWC; activations are fp32 (parity path) or bf16
 // (roofline path); arithmetic is always fp32; accesses are 4-channel vectors (16 B / 8 B).
 #include "kernels.h"
+#include "resize_tf1.h"
 
 namespace jcm {
 
@@ -76,20 +77,6 @@ hipError_t max_pool_2x2(const void* x, void* out, bool bf16, int B, int H, int W
 // ------------------------------------------------------------------------------ bilinear
 // TF-1.x ResizeBilinear, align_corners=False: scale = in/float(out); src = i*scale (float32);
 // lo = floor(src); hi = min(lo+1, in-1); lerp = src-lo.  Lerp along x, then along y.
-struct Tap { int lo, hi; float t; };
-__device__ __forceinline__ Tap tf1_tap(int i, int in_size, float scale) {
-  const float src = __fmul_rn((float)i, scale);   // rounded product, as TF computes `in = i * scale`
-  Tap r;
-  r.lo = (int)floorf(src);
-  r.hi = min(r.lo + 1, in_size - 1);
-  r.t = src - (float)r.lo;
-  return r;
-}
-__device__ __forceinline__ float lerp2(float tl, float tr, float bl, float br, float tx, float ty) {
-  const float top = tl + (tr - tl) * tx;
-  const float bot = bl + (br - bl) * tx;
-  return top + (bot - top) * ty;
-}
 template <class T>
 __device__ __forceinline__ float4 bilinear4(const typename V4<T>::type* base, int W, int C4, Tap ty, Tap tx) {
   const float4 tl = V4<T>::ld(base + ((size_t)ty.lo * W + tx.lo) * C4), tr = V4<T>::ld(base + ((size_t)ty.lo * W + tx.hi) * C4);

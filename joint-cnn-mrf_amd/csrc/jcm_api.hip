@@ -176,7 +176,7 @@ static int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope
   const size_t mark = c->arena_off;
   void* work = arena_alloc<char>(c, conv_fft_workspace_bytes(a, L->ks));
   if (!c->no_reuse) c->arena_off = mark;                 // scratch of this layer only: later layers run behind it on the stream
-  if (c->dry) { c->fft_t_in = nullptr; c->fft_t_next = nullptr; return JCM_OK; }
+  if (c->dry) { c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; return JCM_OK; }
   // Filter spectra are cached per (layer, map size).  The cache is bounded (JCM_FFT_CACHE_GB, default 64): a caller that walks many
   // image sizes (7.7 GB per size for conv5) makes it drop every spectrum that is not this layer's before it grows past the bound.
   const std::string key = scope + "@" + std::to_string(H) + "x" + std::to_string(W);
@@ -210,8 +210,9 @@ static int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope
   if (c->profile && (pool_get(c, &g0) != JCM_OK || pool_get(c, &g1) != JCM_OK)) { g0 = g1 = nullptr; }
   const void* t_in = c->fft_t_in;
   void* t_next = c->fft_t_next;
-  c->fft_t_in = nullptr; c->fft_t_next = nullptr;
-  const hipError_t e = conv_fft_f32(a, L->ks, in_layout, out_layout, work, t_in, t_next, g0, g1, c->stream);
+  const FftMerge* mg = static_cast<const FftMerge*>(c->fft_merge);
+  c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr;
+  const hipError_t e = conv_fft_f32(a, L->ks, in_layout, out_layout, work, t_in, t_next, mg, g0, g1, c->stream);
   if (g0 && g1 && e == hipSuccess) c->prof[scope + "/gemm"].emplace_back(g0, g1);
   else { if (g0) c->event_pool.push_back(g0); if (g1) c->event_pool.push_back(g1); }
   prof_end(c, scope, e0, e1, e == hipSuccess);
@@ -527,13 +528,17 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
   if (fork && !c->dry)
     for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamWaitEvent(main_stream, c->ev_join[i], 0));
   const int hh = h4[0], ww = w4[0];
-  void* merged = act((size_t)B * hh * ww * L4->cout);
-  if (!c->dry) {                                                                           // :58,67,69-70
+  // fp32 handle with conv5 in the frequency domain: its forward row kernel forms ((x1 + up(x2)) + up(x3)) / 3 while it loads the rows
+  const bool fuse_merge = !bf && takes_fft(c, L5, B, hh, ww);
+  FftMerge mg{static_cast<const float*>(x4[1]), h4[1], w4[1], static_cast<const float*>(x4[2]), h4[2], w4[2]};
+  void* merged = fuse_merge ? x4[0] : act((size_t)B * hh * ww * L4->cout);
+  if (!c->dry && !fuse_merge) {                                                            // :58,67,69-70
     if (planar) HIP_TRY(upsample_merge3_planar(x4[0], x4[1], h4[1], w4[1], x4[2], h4[2], w4[2], merged, B, hh, ww, L4->cout, c->stream));
     else HIP_TRY(upsample_merge3(x4[0], x4[1], h4[1], w4[1], x4[2], h4[2], w4[2], merged, bf, B, hh, ww, L4->cout, c->stream));
   }
   void* c5 = act((size_t)B * hh * ww * L5->cout);
   void* t56 = offer_handover(c, L5, conv_of(c, "conv6"), B, hh, ww);
+  if (fuse_merge) c->fft_merge = &mg;
   JCM_TRY(run_conv(c, "conv5", 1, merged, B, hh, ww, 1, c5, bf, false, planar, planar));   // :71
   c->fft_t_in = t56;
   JCM_TRY(run_conv(c, "conv6", 1, c5, B, hh, ww, 1, logits, bf, true, planar, 0));         // :72

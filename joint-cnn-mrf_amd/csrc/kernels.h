@@ -79,9 +79,11 @@ size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout);
 hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, bool round_bf16, hipStream_t st);
 size_t conv_fft_workspace_bytes(const ConvArgs& a, int ks);
 // in / out layout: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar (bf16 handles: operands are bf16 values, the arithmetic is fp32); g0/g1: optional events around the GEMM
-// t_in / t_next: the row-transformed tensor handed from one frequency-domain layer to the next (fp32 NHWC handles; conv_fft_fusable)
-hipError_t conv_fft_f32(const ConvArgs& a, int ks, int in_layout, int out_layout, void* work, const void* t_in, void* t_next, hipEvent_t g0, hipEvent_t g1,
-                        hipStream_t st);
+// t_in / t_next: the row-transformed tensor handed from one frequency-domain layer to the next (fp32 NHWC handles; conv_fft_fusable).
+// merge: a.x is the full-resolution branch x1 and the layer's input is ((x1 + up(x2)) + up(x3)) / 3, formed while the rows are loaded.
+struct FftMerge { const float* x2; int H2, W2; const float* x3; int H3, W3; };
+hipError_t conv_fft_f32(const ConvArgs& a, int ks, int in_layout, int out_layout, void* work, const void* t_in, void* t_next, const FftMerge* merge,
+                        hipEvent_t g0, hipEvent_t g1, hipStream_t st);
 bool conv_fft_fusable(const ConvArgs& a, int ks, int ks_next);
 size_t conv_fft_handover_bytes(const ConvArgs& a, int ks);
 
