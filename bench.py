@@ -8,8 +8,10 @@ A step = one pass of the whole path over one batch per GPU (BASELINE.json config
 fp32) with inputs already resident in HBM.  Ranks shard by batch (images are independent);
 the only collective is the all-gather of [B,2,9] int32 coordinates (main.py:573-574 -> RCCL).
 Prints ONE JSON line on rank 0 with the driver's contract keys plus `roofline` (dominant
-kernel = the conv5 MFMA implicit-GEMM launch, timed live with HIP events on its stream) and
-`cpu_baseline` (the CPU restatement timed on the host cores; TensorFlow is unavailable).
+kernel = the channel GEMM of the frequency-domain conv4_fullres / conv5 layers -- or, with the
+direct kernels selected, their MFMA implicit-GEMM launch -- timed live with HIP events on its
+stream) and `cpu_baseline` (the CPU restatement timed on the host cores; TensorFlow is
+unavailable).
 """
 import argparse
 import json
