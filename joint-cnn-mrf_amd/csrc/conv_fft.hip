@@ -186,13 +186,13 @@ __global__ __launch_bounds__(NT) void rows_fwd_merge_kernel(const float* __restr
 // ---- columns, forward: T[b][kx][y][c] -> Xf[ky][kx][b][c]
 template <int NY> constexpr int colblk() { return NY > 100 ? 32 : 64; }      // channels per work group of the column kernels (<= 64 KB of LDS)
 template <int NY>
-__global__ __launch_bounds__(NT) void cols_fwd_kernel(const cf* __restrict__ T, cf* __restrict__ Xf, int B, int H, int NXH, int C, int b0) {
+__global__ __launch_bounds__(NT) void cols_fwd_kernel(const cf* __restrict__ T, cf* __restrict__ Xf, int B, int H, int NXH, int C, int b0, int kx0, int nkx) {
   constexpr int CH = colblk<NY>(), CB = CH;
   __shared__ cf buf[NY * CH];
   __shared__ cf tw[NY];
   const int tid = threadIdx.x;
   const int cblk = blockIdx.x % (C / CB), bk = blockIdx.x / (C / CB);
-  const int kx = bk % NXH, bl = bk / NXH, b = b0 + bl;
+  const int kx = kx0 + bk % nkx, bl = bk / nkx, b = b0 + bl;
   twiddles<NY>(tw, tid);
   const cf* src = T + ((size_t)(bl * NXH + kx) * H) * C + cblk * CB;
   for (int t = tid; t < NY * CH; t += NT) {
@@ -203,23 +203,24 @@ __global__ __launch_bounds__(NT) void cols_fwd_kernel(const cf* __restrict__ T, 
   fft<NY, -1, CH>(buf, tw, tid);
   for (int t = tid; t < NY * CH; t += NT) {
     const int ky = t / CH, v = t % CH;
-    Xf[((size_t)(ky * NXH + kx) * B + b) * C + cblk * CB + v] = buf[pos<NY>(ky) * CH + v];
+    Xf[((size_t)(kx * NY + ky) * B + b) * C + cblk * CB + v] = buf[pos<NY>(ky) * CH + v];
   }
 }
 
 // ---- columns, inverse: Yf[ky][kx][b][c] -> T[b][y][kx][c], y < H (row y of the output is row y + pad of the linear convolution)
 template <int NY>
-__global__ __launch_bounds__(NT) void cols_inv_kernel(const cf* __restrict__ Yf, cf* __restrict__ T, int B, int H, int NXH, int C, int pad, int b0) {
+__global__ __launch_bounds__(NT) void cols_inv_kernel(const cf* __restrict__ Yf, cf* __restrict__ T, int B, int H, int NXH, int C, int pad, int b0, int kx0,
+                                                      int nkx) {
   constexpr int CH = colblk<NY>(), CB = CH;
   __shared__ cf buf[NY * CH];
   __shared__ cf tw[NY];
   const int tid = threadIdx.x;
   const int cblk = blockIdx.x % (C / CB), bk = blockIdx.x / (C / CB);
-  const int kx = bk % NXH, bl = bk / NXH, b = b0 + bl;
+  const int kx = kx0 + bk % nkx, bl = bk / nkx, b = b0 + bl;
   twiddles<NY>(tw, tid);
   for (int t = tid; t < NY * CH; t += NT) {
     const int ky = t / CH, v = t % CH;
-    buf[t] = Yf[((size_t)(ky * NXH + kx) * B + b) * C + cblk * CB + v];
+    buf[t] = Yf[((size_t)(kx * NY + ky) * B + b) * C + cblk * CB + v];
   }
   __syncthreads();
   fft<NY, 1, CH>(buf, tw, tid);
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(256) void weight_spectra_kernel(const float* __rest
       cf s = ra[0];
 #pragma unroll
       for (int a = 1; a < KS; ++a) s = s + cmul(ra[a], twy[(ky * a) % NY]);
-      Wf[(size_t)(ky * NXH + kx) * Cin * CoutP + io] = s;
+      Wf[(size_t)(kx * NY + ky) * Cin * CoutP + io] = s;
     }
   }
 }
@@ -396,11 +397,12 @@ template <int NX> static void launch_rows_fwd(const ConvArgs& a, int layout, cf*
   else if (layout == 1) hipLaunchKernelGGL((rows_fwd_kernel<NX, 1>), grid, dim3(NT), 0, st, a.x, T, a.H, a.W, a.Cin, b0);
   else hipLaunchKernelGGL((rows_fwd_kernel<NX, 2>), grid, dim3(NT), 0, st, a.x, T, a.H, a.W, a.Cin, b0);
 }
-template <int NY> static void launch_cols_fwd(const ConvArgs& a, const cf* T, cf* Xf, int NXH, int b0, int nb, hipStream_t st) {
-  hipLaunchKernelGGL(cols_fwd_kernel<NY>, dim3(nb * NXH * (a.Cin / colblk<NY>())), dim3(NT), 0, st, T, Xf, a.B, a.H, NXH, a.Cin, b0);
+// (kx0, nkx): the range of frequency columns a launch covers
+template <int NY> static void launch_cols_fwd(const ConvArgs& a, const cf* T, cf* Xf, int NXH, int b0, int nb, int kx0, int nkx, hipStream_t st) {
+  hipLaunchKernelGGL(cols_fwd_kernel<NY>, dim3(nb * nkx * (a.Cin / colblk<NY>())), dim3(NT), 0, st, T, Xf, a.B, a.H, NXH, a.Cin, b0, kx0, nkx);
 }
-template <int NY> static void launch_cols_inv(const ConvArgs& a, const cf* Yf, cf* T, int NXH, int pad, int b0, int nb, hipStream_t st) {
-  hipLaunchKernelGGL(cols_inv_kernel<NY>, dim3(nb * NXH * (a.CoutP / colblk<NY>())), dim3(NT), 0, st, Yf, T, a.B, a.H, NXH, a.CoutP, pad, b0);
+template <int NY> static void launch_cols_inv(const ConvArgs& a, const cf* Yf, cf* T, int NXH, int pad, int b0, int nb, int kx0, int nkx, hipStream_t st) {
+  hipLaunchKernelGGL(cols_inv_kernel<NY>, dim3(nb * nkx * (a.CoutP / colblk<NY>())), dim3(NT), 0, st, Yf, T, a.B, a.H, NXH, a.CoutP, pad, b0, kx0, nkx);
 }
 template <int NX> static void launch_rows_inv(const ConvArgs& a, int layout, const cf* T, int pad, float norm, int b0, int nb, hipStream_t st) {
   const dim3 grid(nb * a.H * (a.CoutP / CB));
@@ -456,6 +458,25 @@ static rocblas_handle blas_for(int dev, hipStream_t st) {
   if (rocblas_set_stream(h, st) != rocblas_status_success) { rocblas_destroy_handle(h); return nullptr; }
   hs[{dev, st}] = h;
   return h;
+}
+// A side stream and four events per (device, main stream): the column passes of one half of the frequency columns beside the GEMM of the
+// other half (the GEMM is MFMA-bound, the column kernels HBM-bound).  EXPERIMENT, off unless JCM_FFT_OVERLAP=1: measured 16.94 against
+// 16.58 ms per fp32 step and 45.15 against 45.59 ms per bf16 step -- the GEMM fills every CU and the halves cost it more than the
+// overlap returns.
+struct Side { hipStream_t s = nullptr; hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr}; };
+static Side* side_for(int dev, hipStream_t st) {
+  static const bool on = [] { const char* e = std::getenv("JCM_FFT_OVERLAP"); return e && e[0] == '1'; }();
+  if (!on) return nullptr;
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, Side> sides;
+  std::lock_guard<std::mutex> lk(mu);
+  Side& sd = sides[{dev, st}];
+  if (!sd.s) {
+    if (hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) != hipSuccess) { sd.s = nullptr; return nullptr; }
+    for (auto& ev : sd.e)
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+  }
+  return &sd;
 }
 }  // namespace cfft
 
@@ -525,9 +546,71 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int in_layout, int out_layou
   if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
   rocblas_handle bh = blas_for(dev, st);
   if (!bh) return hipErrorUnknown;
+  const float norm = 1.0f / (float)(s.NY * s.NX);
+  const cf* Tin = t_in ? static_cast<const cf*>(t_in) : T;
+  auto gemm = [&](int kx0, int nkx) -> bool {      // the frequency columns kx0 .. kx0 + nkx - 1: nkx * NY matrix products
+    const rocblas_float_complex one{1.f, 0.f}, zero{0.f, 0.f};
+    const size_t f0 = (size_t)kx0 * s.NY;
+    return rocblas_cgemm_strided_batched(bh, rocblas_operation_none, rocblas_operation_none, a.CoutP, a.B, a.Cin, &one,
+                                         static_cast<const rocblas_float_complex*>(a.wp) + f0 * a.Cin * a.CoutP, a.CoutP, (rocblas_stride)a.Cin * a.CoutP,
+                                         reinterpret_cast<const rocblas_float_complex*>(Xf) + f0 * a.B * a.Cin, a.Cin, (rocblas_stride)a.B * a.Cin, &zero,
+                                         reinterpret_cast<rocblas_float_complex*>(Yf) + f0 * a.B * a.CoutP, a.CoutP, (rocblas_stride)a.B * a.CoutP,
+                                         nkx * s.NY) == rocblas_status_success;
+  };
+  Side* sd = SL == a.B && NXH >= 8 ? side_for(dev, st) : nullptr;
+  if (sd) {
+    // ---- two halves of the frequency columns, the column passes of one beside the GEMM of the other:
+    //   main: rows_fwd | cols_fwd(H0) GEMM(H0) ........ GEMM(H1) cols_inv(H1) | rows_inv
+    //   side:          | cols_fwd(H1) ......... cols_inv(H0)                  |
+    const int k1 = NXH / 2, n1 = NXH - k1;
+    if (merge && !t_in) {
+#define CALL(N) launch_rows_fwd_merge<N>(a, *merge, T, st)
+      CFFT_BY_SIZE(s.NX, CALL)
+#undef CALL
+    } else if (!t_in) {
+#define CALL(N) launch_rows_fwd<N>(a, in_layout, T, 0, a.B, st)
+      CFFT_BY_SIZE(s.NX, CALL)
+#undef CALL
+    }
+    if (hipEventRecord(sd->e[0], st) != hipSuccess || hipStreamWaitEvent(sd->s, sd->e[0], 0) != hipSuccess) return hipErrorUnknown;
+#define CALL(N) launch_cols_fwd<N>(a, Tin, Xf, NXH, 0, a.B, k1, n1, sd->s)
+    CFFT_BY_SIZE(s.NY, CALL)
+#undef CALL
+    if (hipEventRecord(sd->e[1], sd->s) != hipSuccess) return hipErrorUnknown;
+#define CALL(N) launch_cols_fwd<N>(a, Tin, Xf, NXH, 0, a.B, 0, k1, st)
+    CFFT_BY_SIZE(s.NY, CALL)
+#undef CALL
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    if (g0 && hipEventRecord(g0, st) != hipSuccess) return hipErrorUnknown;
+    if (!gemm(0, k1)) return hipErrorUnknown;
+    if (hipEventRecord(sd->e[2], st) != hipSuccess || hipStreamWaitEvent(sd->s, sd->e[2], 0) != hipSuccess) return hipErrorUnknown;
+    // the side stream has finished its cols_fwd (same stream) and the main stream's cols_fwd(H0) precedes e[2]: nobody reads T any more
+#define CALL(N) launch_cols_inv<N>(a, Yf, T, NXH, pad, 0, a.B, 0, k1, sd->s)
+    CFFT_BY_SIZE(s.NY, CALL)
+#undef CALL
+    if (hipEventRecord(sd->e[3], sd->s) != hipSuccess) return hipErrorUnknown;
+    if (hipStreamWaitEvent(st, sd->e[1], 0) != hipSuccess) return hipErrorUnknown;
+    if (!gemm(k1, n1)) return hipErrorUnknown;
+    if (g1 && hipEventRecord(g1, st) != hipSuccess) return hipErrorUnknown;
+#define CALL(N) launch_cols_inv<N>(a, Yf, T, NXH, pad, 0, a.B, k1, n1, st)
+    CFFT_BY_SIZE(s.NY, CALL)
+#undef CALL
+    if (hipStreamWaitEvent(st, sd->e[3], 0) != hipSuccess) return hipErrorUnknown;
+    if (t_next) {
+#define CALL(N) launch_rows_inv_fwd<N>(a, T, static_cast<cf*>(t_next), pad, norm, st)
+      CFFT_BY_SIZE(s.NX, CALL)
+#undef CALL
+    } else {
+#define CALL(N) launch_rows_inv<N>(a, out_layout, T, pad, norm, 0, a.B, st)
+      CFFT_BY_SIZE(s.NX, CALL)
+#undef CALL
+    }
+    return hipGetLastError();
+  }
+  // ---- one stream
   for (int b0 = 0; b0 < a.B; b0 += SL) {
     const int nb = a.B - b0 < SL ? a.B - b0 : SL;
-    if (merge && !t_in) {        // a.x = the full-resolution branch; the two upsampled branches are added while the row is loaded
+    if (merge && !t_in) {
 #define CALL(N) launch_rows_fwd_merge<N>(a, *merge, T, st)
       CFFT_BY_SIZE(s.NX, CALL)
 #undef CALL
@@ -536,33 +619,25 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int in_layout, int out_layou
       CFFT_BY_SIZE(s.NX, CALL)
 #undef CALL
     }
-#define CALL(N) launch_cols_fwd<N>(a, t_in ? static_cast<const cf*>(t_in) : T, Xf, NXH, b0, nb, st)
+#define CALL(N) launch_cols_fwd<N>(a, Tin, Xf, NXH, b0, nb, 0, NXH, st)
     CFFT_BY_SIZE(s.NY, CALL)
 #undef CALL
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
   }
-  // row-major Y[b][co] = X[b][ci] Wf[ci][co]  ==  column-major (CoutP x B) = (CoutP x Cin) (Cin x B)
-  {
-    if (g0 && hipEventRecord(g0, st) != hipSuccess) return hipErrorUnknown;
-    const rocblas_float_complex one{1.f, 0.f}, zero{0.f, 0.f};
-    const rocblas_status rs = rocblas_cgemm_strided_batched(
-        bh, rocblas_operation_none, rocblas_operation_none, a.CoutP, a.B, a.Cin, &one, static_cast<const rocblas_float_complex*>(a.wp), a.CoutP,
-        (rocblas_stride)a.Cin * a.CoutP, reinterpret_cast<const rocblas_float_complex*>(Xf), a.Cin, (rocblas_stride)a.B * a.Cin, &zero,
-        reinterpret_cast<rocblas_float_complex*>(Yf), a.CoutP, (rocblas_stride)a.B * a.CoutP, F);
-    if (rs != rocblas_status_success) return hipErrorUnknown;
-    if (g1 && hipEventRecord(g1, st) != hipSuccess) return hipErrorUnknown;
-  }
+  if (g0 && hipEventRecord(g0, st) != hipSuccess) return hipErrorUnknown;
+  if (!gemm(0, NXH)) return hipErrorUnknown;
+  if (g1 && hipEventRecord(g1, st) != hipSuccess) return hipErrorUnknown;
   for (int b0 = 0; b0 < a.B; b0 += SL) {
     const int nb = a.B - b0 < SL ? a.B - b0 : SL;
-#define CALL(N) launch_cols_inv<N>(a, Yf, T, NXH, pad, b0, nb, st)
+#define CALL(N) launch_cols_inv<N>(a, Yf, T, NXH, pad, b0, nb, 0, NXH, st)
     CFFT_BY_SIZE(s.NY, CALL)
 #undef CALL
     if (t_next) {
-#define CALL(N) launch_rows_inv_fwd<N>(a, T, static_cast<cf*>(t_next), pad, 1.0f / (float)(s.NY * s.NX), st)
+#define CALL(N) launch_rows_inv_fwd<N>(a, T, static_cast<cf*>(t_next), pad, norm, st)
       CFFT_BY_SIZE(s.NX, CALL)
 #undef CALL
     } else {
-#define CALL(N) launch_rows_inv<N>(a, out_layout, T, pad, 1.0f / (float)(s.NY * s.NX), b0, nb, st)
+#define CALL(N) launch_rows_inv<N>(a, out_layout, T, pad, norm, b0, nb, st)
       CFFT_BY_SIZE(s.NX, CALL)
 #undef CALL
     }
