@@ -1,0 +1,269 @@
+// The channel GEMM of the frequency-domain convolutions (conv_fft.hip) on the bf16 matrix cores.
+//
+// For every frequency f of the transformed maps a stride-1 SAME convolution (main.py:133-135; the 9x9 calls at :49,57,66,71,72) is one
+// complex matrix product over the channels,  Y[f][b][co] = sum_ci X[f][b][ci] * W[f][ci][co]  (M = images, K = Cin, N = Cout), and
+// there are NY * (NX/2+1) of them per layer (3136 for the 60x90 maps).  Round 2 ran them through a library fp32 GEMM on the fp32 matrix
+// pipe (1/16 of the bf16 rate).  This kernel runs them on v_mfma_f32_32x32x16_bf16 with SPLIT operands:
+//
+//   * an fp32 number is the exact sum of three bf16 numbers, x = x0 + x1 + x2 (8 significant bits each); every bf16 x bf16 product is
+//     exact in the fp32 accumulator.  fp32 handles (NP = 3) take the six products with p + q <= 2 -- what is dropped is below 2^-24 of
+//     x*w, the fp32 rounding itself -- bf16 handles (NP = 2, whose layer output is rounded to bf16 anyway) the three
+//     products x0w0 + x0w1 + x1w0 of two-part operands (16 significant bits).
+//   * the complex product is four real ones: Yr += Xr Wr - Xi Wi, Yi += Xr Wi + Xi Wr; the minus is a sign flip of the Xi fragment in
+//     registers (one v_xor per VGPR).  Both accumulators of an output element stay in the same lane.
+//   * both operands arrive ALREADY SPLIT in the exact image the LDS wants -- the activation spectra from the column pass of the forward
+//     transform (conv_fft.hip: cols_fwd_split_kernel), the filter spectra once per handle (weight_spectra_split_kernel) -- tile-major, so
+//     that a work group streams two contiguous arrays with LDS-DMA (buffer_load ... lds, 1 KB per wave instruction) and nothing else:
+//         Xs[f][m-tile][k16][re|im][part][k-half][MT rows][8 bf16]       Ws[f][n-tile][k16][re|im][part][k-half][128 cols][8 bf16]
+//     (an MFMA operand lane holds 8 consecutive k of one row / column = one 16-byte unit; units of consecutive rows are consecutive, so
+//     every ds_read_b128 of a fragment is bank-conflict free.)  With two parts the split spectra are exactly as large as fp32 complex
+//     ones: no extra HBM traffic on bf16 handles.
+//   * a stage = one k16 step of all parts; R-deep ring, counted vmcnt + raw s_barrier (the DMA of stage g+R-1 is issued right after
+//     the barrier that opens stage g, so R-1 stages are in flight while one computes); the fragments of a product are read while the
+//     MFMAs of the previous one run.
+//   * work groups b, b+8, ... share an XCD: they are given the tiles of the same frequencies, so the N-tiles that re-read an X slab
+//     (and the M-tiles that re-read a W slab) find it in that XCD's L2.
+//
+// Output: Y[f][b][co] complex fp32 (what the inverse column pass reads).  gfx950 only.
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace jcm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace cg {
+
+// NP parts per operand; WM x WN waves, FM x FN 32x32 fragments per wave; R stages in LDS
+template <int NP_, int WM_, int WN_, int FM_, int FN_, int R_>
+struct Cfg {
+  static constexpr int NP = NP_, WM = WM_, WN = WN_, FM = FM_, FN = FN_, R = R_;
+  static constexpr int NW = WM * WN, NT = 64 * NW;
+  static constexpr int MT = 32 * WM * FM, NTL = 32 * WN * FN;
+  static constexpr int XST = 4 * NP * MT, WST = 4 * NP * NTL;      // 16-byte units per stage: [re|im][part][k-half][rows]
+  static constexpr int STAGE = XST + WST;
+  static constexpr int XPW = XST / 64 / NW, WPW = WST / 64 / NW;    // 1-KB DMA pieces per wave per stage
+  static constexpr int PW = XPW + WPW;
+  static constexpr int LDS_BYTES = R * STAGE * 16;
+  static constexpr int NPROD = NP == 3 ? 6 : NP == 2 ? 3 : 1;
+  static_assert(NTL == kCgemmNT, "the filter spectra are laid out for 128-column tiles");
+  static_assert(XST % (64 * NW) == 0 && WST % (64 * NW) == 0, "whole DMA pieces per wave");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+  static_assert((R - 1) * PW < 64, "vmcnt is a 6-bit counter");
+};
+
+// (x part, w part) of product s.  Any order gives the same sum up to fp32 rounding of the accumulator, which carries the whole K sum.
+template <int NP> __device__ __forceinline__ constexpr int prod_x(int s) { return NP == 3 ? (s == 0 ? 0 : s == 1 ? 1 : s == 2 ? 2 : s == 3 ? 1 : s == 4 ? 0 : 0) : NP == 2 ? (s == 0 ? 0 : s == 1 ? 1 : 0) : 0; }
+template <int NP> __device__ __forceinline__ constexpr int prod_w(int s) { return NP == 3 ? (s == 0 ? 2 : s == 1 ? 1 : s == 2 ? 0 : s == 3 ? 0 : s == 4 ? 1 : 0) : NP == 2 ? (s == 0 ? 1 : s == 1 ? 0 : 0) : 0; }
+
+template <int OFF> __device__ __forceinline__ void lds_read(f32x4& v, unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF) : "memory");
+}
+
+// the fragments of one product: X part PX (re, im) for the wave's FM row blocks, W part PWT (re, im) for its FN column blocks.
+// Unit of (plane c, part p, k-half, row) inside a stage: ((c * NP + p) * 2 + k-half) * rows + row; the k-half and the row are in the lane address.
+template <class C, int PX, int PWT>
+__device__ __forceinline__ void frag_load(f32x4 (&xr)[C::FM], f32x4 (&xi)[C::FM], f32x4 (&wr)[C::FN], f32x4 (&wi)[C::FN], unsigned xaddr, unsigned waddr) {
+  constexpr int XR = (0 * C::NP + PX) * 2 * C::MT * 16, XI = (1 * C::NP + PX) * 2 * C::MT * 16;
+  constexpr int WR = (0 * C::NP + PWT) * 2 * C::NTL * 16, WI = (1 * C::NP + PWT) * 2 * C::NTL * 16;
+  lds_read<XR>(xr[0], xaddr);
+  lds_read<XI>(xi[0], xaddr);
+  if constexpr (C::FM > 1) {
+    lds_read<XR + 512>(xr[1], xaddr);
+    lds_read<XI + 512>(xi[1], xaddr);
+  }
+  lds_read<WR>(wr[0], waddr);
+  lds_read<WI>(wi[0], waddr);
+  if constexpr (C::FN > 1) {
+    lds_read<WR + 512>(wr[1], waddr);
+    lds_read<WI + 512>(wi[1], waddr);
+  }
+}
+
+struct Args {
+  const char* xs;       // split activation spectra
+  const char* ws;       // split filter spectra
+  float2* y;            // [F][B][CoutP]
+  int F, B, CoutP, KC;  // KC = Cin / 16
+  int mtiles, ntiles;
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
+  static_assert(C::FM <= 2 && C::FN <= 2, "frag_load covers 1 or 2 fragments per side");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NP = C::NP, FM = C::FM, FN = C::FN, MT = C::MT, NTL = C::NTL, R = C::R, NW = C::NW;
+  constexpr int XST = C::XST, WST = C::WST, STAGE = C::STAGE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / C::WN, wn = wid % C::WN;
+  const int h = lane >> 5, l31 = lane & 31;
+
+  // work groups b, b+8, ... run on one XCD: they walk the tiles of frequencies xcd, xcd + 8, ... one frequency after the other
+  const int T = a.mtiles * a.ntiles;
+  const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+  const int f = (j / T) * 8 + xcd, t = j % T;
+  if (f >= a.F) return;
+  const int mt = t / a.ntiles, nt = t % a.ntiles;
+  const int KC = a.KC;
+
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const char* xg = a.xs + ((size_t)(f * a.mtiles + mt) * KC) * (size_t)(XST * 16);
+  const char* wg = a.ws + ((size_t)(f * a.ntiles + nt) * KC) * (size_t)(WST * 16);
+  const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xg), 0, KC * XST * 16, 0x00020000);
+  const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wg), 0, KC * WST * 16, 0x00020000);
+  const unsigned lane16 = (unsigned)lane * 16u;
+
+  // stage g -> ring slot: the LDS image of a stage is its HBM image, X pieces first; wave w moves pieces w, w + NW, ...
+  // Past the last stage the offsets run out of the buffer descriptors and the DMA delivers zeros into a free slot: no tail logic.
+  auto issue = [&](int g, int slot) __attribute__((always_inline)) {
+    const unsigned sbase = (unsigned)(slot * STAGE * 16);
+#pragma unroll
+    for (int i = 0; i < C::XPW; ++i) {
+      const unsigned q = (unsigned)(wid + i * NW) * 1024u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(smem + sbase + q), 16, lane16, (unsigned)g * (unsigned)(XST * 16) + q, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < C::WPW; ++i) {
+      const unsigned q = (unsigned)(wid + i * NW) * 1024u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(smem + sbase + XST * 16 + q), 16, lane16, (unsigned)g * (unsigned)(WST * 16) + q, 0, 0);
+    }
+  };
+
+  f32x16 accr[FM][FN], acci[FM][FN];
+#pragma unroll
+  for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { accr[fm][fn][i] = 0.f; acci[fm][fn][i] = 0.f; }
+
+#pragma unroll
+  for (int s = 0; s < R - 1; ++s) issue(s, s);
+
+  // per-lane fragment addresses inside slot 0: unit (k-half h, row) of plane (re, part 0)
+  unsigned xaddr = lds0 + (unsigned)(h * MT + wm * FM * 32 + l31) * 16u;
+  unsigned waddr = lds0 + (unsigned)(XST + h * NTL + wn * FN * 32 + l31) * 16u;
+
+  int slot = 0;
+  for (int g = 0; g < KC; ++g) {
+    // this wave's pieces of stage g have landed (R-2 younger stages may stay in flight); after the barrier everybody's have, and
+    // every wave is done reading slot (g-1) % R, which the DMA of stage g+R-1 now refills
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"((R - 2) * C::PW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const int ns = slot == 0 ? R - 1 : slot - 1;
+      issue(g + R - 1, ns);
+    }
+    f32x4 xr[2][FM], xi[2][FM], wr[2][FN], wi[2][FN];
+    frag_load<C, prod_x<NP>(0), prod_w<NP>(0)>(xr[0], xi[0], wr[0], wi[0], xaddr, waddr);
+    auto product = [&](auto sc) __attribute__((always_inline)) {
+      constexpr int S = decltype(sc)::value, cur = S & 1;
+      if constexpr (S + 1 < C::NPROD) {
+        frag_load<C, prod_x<NP>(S + 1), prod_w<NP>(S + 1)>(xr[cur ^ 1], xi[cur ^ 1], wr[cur ^ 1], wi[cur ^ 1], xaddr, waddr);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(2 * FM + 2 * FN) : "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 nxi[FM];
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) {
+        const u32x4 v = __builtin_bit_cast(u32x4, xi[cur][fm]) ^ u32x4{0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
+        nxi[fm] = __builtin_bit_cast(f32x4, v);
+      }
+      // re += Xr Wr ; im += Xr Wi ; re += (-Xi) Wi ; im += Xi Wr  -- consecutive MFMAs never share an accumulator
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn)
+          accr[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xr[cur][fm]), __builtin_bit_cast(bf16x8, wr[cur][fn]), accr[fm][fn], 0, 0, 0);
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn)
+          acci[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xr[cur][fm]), __builtin_bit_cast(bf16x8, wi[cur][fn]), acci[fm][fn], 0, 0, 0);
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn)
+          accr[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, nxi[fm]), __builtin_bit_cast(bf16x8, wi[cur][fn]), accr[fm][fn], 0, 0, 0);
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn)
+          acci[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xi[cur][fm]), __builtin_bit_cast(bf16x8, wr[cur][fn]), acci[fm][fn], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    product(std::integral_constant<int, 0>{});
+    if constexpr (C::NPROD > 1) product(std::integral_constant<int, 1>{});
+    if constexpr (C::NPROD > 2) product(std::integral_constant<int, 2>{});
+    if constexpr (C::NPROD > 3) product(std::integral_constant<int, 3>{});
+    if constexpr (C::NPROD > 4) product(std::integral_constant<int, 4>{});
+    if constexpr (C::NPROD > 5) product(std::integral_constant<int, 5>{});
+    // next ring slot
+    const bool wrap = slot == R - 1;
+    const unsigned d = wrap ? (unsigned)(-(R - 1) * STAGE * 16) : (unsigned)(STAGE * 16);
+    xaddr += d;
+    waddr += d;
+    slot = wrap ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the look-ahead DMAs of the last stages (zeros into free slots)
+
+  // ---- Y[f][b][co]: accumulator register i of a fragment is row (i&3) + 8 (i>>2) + 4 h, column l31: a half wave stores 32 complex
+  // numbers = 256 contiguous bytes per instruction
+  const int n0 = nt * NTL + wn * FN * 32 + l31;
+  float2* yf = a.y + (size_t)f * a.B * a.CoutP;
+#pragma unroll
+  for (int fm = 0; fm < FM; ++fm) {
+    const int r0 = mt * MT + (wm * FM + fm) * 32 + 4 * h;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = r0 + (i & 3) + 8 * (i >> 2);
+      if (row < a.B) {
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) yf[(size_t)row * a.CoutP + n0 + fn * 32] = make_float2(accr[fm][fn][i], acci[fm][fn][i]);
+      }
+    }
+  }
+}
+
+// tile shapes.  NT = 128 columns everywhere (the layout of the filter spectra); what varies is the M tile and the ring depth.
+using CfgB256 = Cfg<2, 4, 2, 2, 2, 3>;      // bf16 handles, 129 .. 256 images: the whole micro-batch in one 256 x 128 tile, W read once
+using CfgB128 = Cfg<2, 2, 2, 2, 2, 2>;      // bf16 handles, 65 .. 128 images (two work groups per CU)
+using CfgB64 = Cfg<2, 1, 4, 2, 1, 2>;       // bf16 handles, <= 64 images
+using CfgF64 = Cfg<3, 1, 4, 2, 1, 2>;       // fp32 handles, <= 64 images per tile
+using CfgF128 = Cfg<3, 2, 2, 2, 2, 2>;      // fp32 handles, > 64 images: 128-row tiles
+
+template <class C> hipError_t launch(const Args& a, hipStream_t st) {
+  static LdsAttr attr;
+  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(cgemm_split_kernel<C>), C::LDS_BYTES); e != hipSuccess) return e;
+  const int T = a.mtiles * a.ntiles;
+  const int blocks = (a.F + 7) / 8 * 8 * T;
+  hipLaunchKernelGGL(cgemm_split_kernel<C>, dim3(blocks), dim3(C::NT), C::LDS_BYTES, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace cg
+
+int cgemm_split_mtile(int np, int B) {
+  if (np == 2) return B > 128 ? 256 : B > 64 ? 128 : 64;
+  return B > 64 ? 128 : 64;
+}
+
+hipError_t cgemm_split(const void* xs, const void* ws, void* y, int np, int F, int B, int Cin, int CoutP, hipStream_t st) {
+  if ((np != 2 && np != 3) || Cin % 16 || CoutP % kCgemmNT || F < 1 || B < 1) return hipErrorInvalidValue;
+  const int MT = cgemm_split_mtile(np, B);
+  cg::Args a{static_cast<const char*>(xs), static_cast<const char*>(ws), static_cast<float2*>(y), F, B, CoutP, Cin / 16, (B + MT - 1) / MT, CoutP / kCgemmNT};
+  if ((long long)a.KC * 4 * np * (MT > kCgemmNT ? MT : kCgemmNT) * 16 >= (1ll << 31)) return hipErrorInvalidValue;      // buffer descriptor range
+  if (np == 2) return MT == 256 ? cg::launch<cg::CfgB256>(a, st) : MT == 128 ? cg::launch<cg::CfgB128>(a, st) : cg::launch<cg::CfgB64>(a, st);
+  return MT == 128 ? cg::launch<cg::CfgF128>(a, st) : cg::launch<cg::CfgF64>(a, st);
+}
+
+}  // namespace jcm

@@ -1,30 +1,32 @@
-// Stride-1 SAME convolution (9x9, 5x5) in the FREQUENCY domain, fp32 arithmetic: every such layer of an fp32 handle, the wide 9x9
-// layers (conv4_*, conv5: 256/512 -> 512 channels) of a bf16 handle.
+// Stride-1 SAME convolution (9x9, 5x5) in the FREQUENCY domain: every such layer of an fp32 handle, the wide 9x9 layers (conv4_*, conv5:
+// 256/512 -> 512 channels) of a bf16 handle.
 //
-// A 9x9 layer with 512 x 512 channels is 229 GFLOP per image as a direct convolution.  With the maps transformed once
-// (NY x NX >= (H+8) x (W+8): a linear convolution, nothing wraps) the layer is, for every frequency, one complex matrix product
-// over the channels:  Y[f][b][co] = sum_ci X[f][b][ci] * Wf[f][ci][co]  -- 8*Cin*Cout*NY*(NX/2+1) = 7.3 GFLOP per image for conv5
-// (70 x 98 transform of the 60 x 90 maps), 31x fewer.  The transforms add 0.4 GFLOP.  In fp32 this route is MORE accurate than the
-// fp32 MFMA accumulation chain it replaces (4e-7 of the output scale against 1.3e-6 for a sequential fp32 sum of the 41 472
-// products: DESIGN.md 4.1c), so it runs behind the same parity tests.
+// A 9x9 layer with 512 x 512 channels is 229 GFLOP per image as a direct convolution.  With the maps transformed once the layer is, for
+// every frequency, one complex matrix product over the channels:  Y[f][b][co] = sum_ci X[f][b][ci] * Wf[f][ci][co].  The transform is a
+// CIRCULAR convolution of size NY x NX >= (H + pad) x (W + pad), pad = (k-1)/2: the SAME output y in [0, H) reads inputs y-pad .. y+pad,
+// so the wrap-around only has to land in the zero rows H .. NY-1 -- which H + pad rows guarantee (a full linear convolution would need
+// H + k - 1).  60x90 maps: 64 x 96 transforms, 64 * 49 = 3136 frequencies, 8*Cin*Cout*3136 = 6.6 GFLOP per image for conv5, 35x fewer
+// than the direct form.  In fp32 the route is MORE accurate than the fp32 MFMA accumulation chain it replaces.
 //
-//   rows_fwd   (image, row, 64 channels)  : NHWC fp32, two adjacent channels = one complex number z = x_c + i x_{c+1}; complex FFT
-//                                           along x in LDS; X_c, X_{c+1} recovered through the Hermitian symmetry -> T[b][kx][y][ci]
-//   cols_fwd   (image, kx, 64 channels)   : FFT along y -> Xf[ky][kx][b][ci]   (frequency-major: a GEMM operand per frequency)
-//   rocBLAS cgemm_strided_batched         : the plain library GEMM, batch = NY * (NX/2+1) frequencies
-//   cols_inv   (image, kx, 64 channels)   : inverse along ky, rows pad .. pad+H-1 kept -> T[b][y][kx][co]
-//   rows_inv   (image, row, 64 channels)  : Z = Y_c + i Y_{c+1} (Hermitian extension), inverse complex FFT along kx, columns 4 .. W+3,
-//                                           1/(NY NX), bias, ReLU, folded BatchNorm -> NHWC fp32
-// The filter spectra Wf[f][ci][co] (flipped kernel: TF's conv2d is a correlation) are computed once per (layer, map size) at
-// first use: 7.3 GB for conv5.  FFTs: the in-LDS decimation-in-frequency stages of sm_fused.hip, channel-vectorised
-// (consecutive lanes = consecutive channels: every LDS and HBM access of a wave is one contiguous 512-byte run).
+//   rows_fwd        (image, row, 64 channels)        : NHWC fp32 / bf16 (or planar bf16); two adjacent channels = one complex number
+//                                                      z = x_c + i x_{c+1}; complex FFT along x in LDS; X_c, X_{c+1} through the Hermitian
+//                                                      symmetry -> T[kx][c/16][b][y][16]   (a column work group's input is contiguous)
+//   cols_fwd_split  (8 images, kx, 16 channels)      : FFT along y, then the spectra are SPLIT into bf16 parts and written in the exact
+//                                                      LDS image of the channel GEMM: Xs[f][m-tile][c/16][re|im][part][k-half][row][8]
+//   cgemm_split     (cgemm_split.hip)                : the channel GEMM on the bf16 matrix cores, one complex product per frequency
+//   cols_inv        (image, kx, 64 channels)         : inverse along ky, rows pad .. pad+H-1 kept -> T[b][y][kx][co]
+//   rows_inv        (image, row, 64 channels)        : Z = Y_c + i Y_{c+1} (Hermitian extension), inverse complex FFT along kx, columns
+//                                                      pad .. pad+W-1, 1/(NY NX), bias, ReLU, folded BatchNorm -> NHWC fp32 / bf16 / planar
+// The filter spectra (flipped kernel: TF's conv2d is a correlation) are computed once per (layer, map size) at first use, split into the
+// same bf16 parts, in the GEMM's tile-major layout.  FFTs: the in-LDS decimation-in-frequency stages of sm_fused.hip, channel-vectorised
+// (consecutive lanes = consecutive channels).  Twiddles come from one table per device, built on the host in double precision.
 // Reference semantics: conv2d SAME stride 1 + bias + ReLU + BatchNorm (main.py:133-135,156-169).
-#include <rocblas/rocblas.h>
-
+#include <cmath>
 #include <cstdlib>
 #include <map>
 #include <mutex>
 #include <utility>
+#include <vector>
 
 #include "fft_lds.h"
 #include "kernels.h"
@@ -41,13 +43,17 @@ template <int N> struct Plan;
 template <> struct Plan<192> { static constexpr int R1 = 8, R2 = 8, R3 = 3; };
 template <> struct Plan<128> { static constexpr int R1 = 8, R2 = 4, R3 = 4; };
 template <> struct Plan<100> { static constexpr int R1 = 4, R2 = 5, R3 = 5; };
-template <> struct Plan<98> { static constexpr int R1 = 7, R2 = 14, R3 = 1; };
-template <> struct Plan<70> { static constexpr int R1 = 7, R2 = 10, R3 = 1; };
+template <> struct Plan<96> { static constexpr int R1 = 8, R2 = 12, R3 = 1; };
 template <> struct Plan<72> { static constexpr int R1 = 8, R2 = 3, R3 = 3; };
+template <> struct Plan<64> { static constexpr int R1 = 8, R2 = 8, R3 = 1; };
 template <> struct Plan<60> { static constexpr int R1 = 4, R2 = 15, R3 = 1; };
+template <> struct Plan<50> { static constexpr int R1 = 5, R2 = 10, R3 = 1; };
 template <> struct Plan<40> { static constexpr int R1 = 8, R2 = 5, R3 = 1; };
+template <> struct Plan<36> { static constexpr int R1 = 4, R2 = 3, R3 = 3; };
 template <> struct Plan<32> { static constexpr int R1 = 8, R2 = 4, R3 = 1; };
+template <> struct Plan<28> { static constexpr int R1 = 4, R2 = 7, R3 = 1; };
 template <> struct Plan<24> { static constexpr int R1 = 8, R2 = 3, R3 = 1; };
+template <> struct Plan<20> { static constexpr int R1 = 4, R2 = 5, R3 = 1; };
 template <int N> __device__ __forceinline__ int pos(int n) {
   using P = Plan<N>;
   if constexpr (P::R3 == 1) return (n % P::R1) * (N / P::R1) + n / P::R1;
@@ -90,27 +96,41 @@ __device__ __forceinline__ void fft(cf* buf, const cf* tw, int tid) {
     __syncthreads();
   }
 }
+// tw[k] = e^{+2 pi i k / N} from the per-device table (host-built in double precision; tw_offset(N) entries in)
 template <int N>
-__device__ __forceinline__ void twiddles(cf* tw, int tid) {
-  for (int k = tid; k < N; k += NT) {
-    double sn, cs;
-    sincospi(2.0 * (double)k / (double)N, &sn, &cs);
-    tw[k] = cf{(float)cs, (float)sn};
-  }
+__device__ __forceinline__ void twiddles(cf* tw, const cf* __restrict__ twg, int tid) {
+  for (int k = tid; k < N; k += NT) tw[k] = twg[k];
 }
 
-// ---- rows, forward: NHWC fp32 / NHWC bf16 / planar bf16 [B][C/8][H*W][8] -> T[b][kx][y][c] complex, kx < NX/2+1
+// ---- rows, forward: NHWC fp32 / NHWC bf16 / planar bf16 [B][C/8][H*W][8] -> T[kx][c/16][b][y][16] complex, kx < NX/2+1
 // LAYOUT: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar.  Two adjacent channels are one complex number.
+// T is chunk-major: the (8 images x H rows x 16 channels) block a column work group transforms is one contiguous run, and this kernel
+// writes it in whole 128-byte lines (8 lanes x float4 = the 16 channels of one (kx, chunk, image, row)).
 __device__ __forceinline__ cf bf16pair(unsigned bits) { return cf{__uint_as_float(bits << 16), __uint_as_float(bits & 0xffff0000u)}; }
-template <int NX, int LAYOUT>
-__global__ __launch_bounds__(NT) void rows_fwd_kernel(const void* __restrict__ in, cf* __restrict__ T, int H, int W, int C, int b0) {
+// index, in float4 = two channels, of channel pair v (0..31) of 64-channel block cblk
+__device__ __forceinline__ size_t t_fwd_index(int k, int cblk, int v, int b, int y, int B, int H, int C) {
+  return ((((size_t)k * (C >> 4) + cblk * 4 + (v >> 3)) * B + b) * H + y) * 8 + (v & 7);
+}
+// Z = FFT(x_c + i x_{c+1}):  X_c[k] = (Z[k] + conj Z[-k]) / 2,  X_{c+1}[k] = (Z[k] - conj Z[-k]) / (2i)
+template <int NX>
+__device__ __forceinline__ void rows_fwd_store(const cf* buf, cf* __restrict__ T, int tid, int cblk, int b, int y, int B, int H, int C) {
   constexpr int CH = CB / 2, NXH = NX / 2 + 1;
+  float4* dst = reinterpret_cast<float4*>(T);
+  for (int t = tid; t < NXH * CH; t += NT) {
+    const int k = t / CH, v = t % CH;
+    const cf zk = buf[pos<NX>(k) * CH + v], zn = buf[pos<NX>(k == 0 ? 0 : NX - k) * CH + v];
+    dst[t_fwd_index(k, cblk, v, b, y, B, H, C)] = make_float4(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y), 0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+  }
+}
+template <int NX, int LAYOUT>
+__global__ __launch_bounds__(NT) void rows_fwd_kernel(const void* __restrict__ in, cf* __restrict__ T, const cf* __restrict__ twg, int B, int H, int W, int C) {
+  constexpr int CH = CB / 2;
   __shared__ cf buf[NX * CH];
   __shared__ cf tw[NX];
   const int tid = threadIdx.x;
   const int cblk = blockIdx.x % (C / CB), by = blockIdx.x / (C / CB);
-  const int y = by % H, bl = by / H, b = b0 + bl;       // bl: image inside this slice of the batch (indexes T), b: image of the batch
-  twiddles<NX>(tw, tid);
+  const int y = by % H, b = by / H;
+  twiddles<NX>(tw, twg, tid);
   for (int t = tid; t < NX * CH; t += NT) {
     const int x = t / CH, v = t % CH;
     cf z = {0.f, 0.f};
@@ -128,29 +148,22 @@ __global__ __launch_bounds__(NT) void rows_fwd_kernel(const void* __restrict__ i
   }
   __syncthreads();
   fft<NX, -1, CH>(buf, tw, tid);
-  // Z = FFT(x_c + i x_{c+1}):  X_c[k] = (Z[k] + conj Z[-k]) / 2,  X_{c+1}[k] = (Z[k] - conj Z[-k]) / (2i)
-  float4* dst = reinterpret_cast<float4*>(T);
-  for (int t = tid; t < NXH * CH; t += NT) {
-    const int k = t / CH, v = t % CH;
-    const cf zk = buf[pos<NX>(k) * CH + v], zn = buf[pos<NX>(k == 0 ? 0 : NX - k) * CH + v];
-    dst[(((size_t)(bl * NXH + k) * H + y) * C + cblk * CB) / 2 + v] =
-        make_float4(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y), 0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
-  }
+  rows_fwd_store<NX>(buf, T, tid, cblk, b, y, B, H, C);
 }
 
 // ---- rows, forward, of the MERGED map (fp32 NHWC): x = ((x1 + up(x2)) + up(x3)) / 3 (main.py:58,67,69-70; the arithmetic and association
 // order of upsample_merge3_kernel) is formed while the row is loaded: the merged tensor never goes to HBM.
 template <int NX>
 __global__ __launch_bounds__(NT) void rows_fwd_merge_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int H2, int W2,
-                                                            const float* __restrict__ x3, int H3, int W3, cf* __restrict__ T, int H, int W, int C, float sy2,
-                                                            float sx2, float sy3, float sx3) {
-  constexpr int CH = CB / 2, NXH = NX / 2 + 1;
+                                                            const float* __restrict__ x3, int H3, int W3, cf* __restrict__ T, const cf* __restrict__ twg, int B, int H,
+                                                            int W, int C, float sy2, float sx2, float sy3, float sx3) {
+  constexpr int CH = CB / 2;
   __shared__ cf buf[NX * CH];
   __shared__ cf tw[NX];
   const int tid = threadIdx.x;
   const int cblk = blockIdx.x % (C / CB), by = blockIdx.x / (C / CB);
   const int y = by % H, b = by / H;
-  twiddles<NX>(tw, tid);
+  twiddles<NX>(tw, twg, tid);
   const Tap ty2 = tf1_tap(y, H2, sy2), ty3 = tf1_tap(y, H3, sy3);
   const int C2 = C / 2;
   const cf* p1 = reinterpret_cast<const cf*>(x1 + ((size_t)(b * H + y) * W) * C + cblk * CB);
@@ -174,76 +187,112 @@ __global__ __launch_bounds__(NT) void rows_fwd_merge_kernel(const float* __restr
   }
   __syncthreads();
   fft<NX, -1, CH>(buf, tw, tid);
-  float4* dst = reinterpret_cast<float4*>(T);
-  for (int t = tid; t < NXH * CH; t += NT) {
-    const int k = t / CH, v = t % CH;
-    const cf zk = buf[pos<NX>(k) * CH + v], zn = buf[pos<NX>(k == 0 ? 0 : NX - k) * CH + v];
-    dst[(((size_t)(b * NXH + k) * H + y) * C + cblk * CB) / 2 + v] =
-        make_float4(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y), 0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
-  }
+  rows_fwd_store<NX>(buf, T, tid, cblk, b, y, B, H, C);
 }
 
-// ---- columns, forward: T[b][kx][y][c] -> Xf[ky][kx][b][c]
-template <int NY> constexpr int colblk() { return NY > 100 ? 32 : 64; }      // channels per work group of the column kernels (<= 64 KB of LDS)
-template <int NY>
-__global__ __launch_bounds__(NT) void cols_fwd_kernel(const cf* __restrict__ T, cf* __restrict__ Xf, int B, int H, int NXH, int C, int b0, int kx0, int nkx) {
-  constexpr int CH = colblk<NY>(), CB = CH;
-  __shared__ cf buf[NY * CH];
-  __shared__ cf tw[NY];
+// ---- columns, forward + operand split: T[kx][c/16][b][y][16] -> Xs[f = kx NY + ky][m-tile][c/16][re|im][part][k-half][row][8] bf16
+// One work group = (IMG images, kx, one 16-channel chunk): its input is one contiguous run of T; after the FFT along y every spectrum is
+// split into NP bf16 parts (x = x0 + x1 (+ x2), each rounded to nearest: exact for NP = 3, 16 significant bits for NP = 2) and stored as
+// 16-byte MFMA operand units -- 8 consecutive channels of one image -- with the units of the work group's IMG images consecutive: 128-byte
+// lines for IMG = 8.  The result is the channel GEMM's LDS image (cgemm_split.hip), which that kernel fetches by LDS-DMA.
+template <int NY> constexpr int colimg() { return NY > 96 ? 4 : 8; }         // images per work group (LDS: NY * IMG * 16 complex numbers)
+template <int NY> constexpr int colblk() { return NY > 100 ? 32 : 64; }      // channels per work group of the inverse column kernel (<= 64 KB of LDS)
+template <int NP>
+__device__ __forceinline__ void split8(const float (&x)[8], uint4 (&out)[NP]) {
+  unsigned short h[NP][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = x[e];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const __bf16 q = static_cast<__bf16>(v);           // round to nearest even
+      h[p][e] = __builtin_bit_cast(unsigned short, q);
+      v = v - static_cast<float>(q);                      // exact
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+    out[p] = make_uint4((unsigned)h[p][0] | ((unsigned)h[p][1] << 16), (unsigned)h[p][2] | ((unsigned)h[p][3] << 16), (unsigned)h[p][4] | ((unsigned)h[p][5] << 16),
+                        (unsigned)h[p][6] | ((unsigned)h[p][7] << 16));
+}
+template <int NY, int NP>
+__global__ __launch_bounds__(NT) void cols_fwd_split_kernel(const cf* __restrict__ T, uint4* __restrict__ Xs, const cf* __restrict__ twg, int B, int H, int KC, int MT,
+                                                            int mtiles) {
+  constexpr int IMG = colimg<NY>(), CH = IMG * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem_cf[];
+  cf* buf = reinterpret_cast<cf*>(smem_cf);
+  cf* tw = buf + NY * CH;
   const int tid = threadIdx.x;
-  const int cblk = blockIdx.x % (C / CB), bk = blockIdx.x / (C / CB);
-  const int kx = kx0 + bk % nkx, bl = bk / nkx, b = b0 + bl;
-  twiddles<NY>(tw, tid);
-  const cf* src = T + ((size_t)(bl * NXH + kx) * H) * C + cblk * CB;
+  const int NG = (B + IMG - 1) / IMG;
+  const int g = blockIdx.x % NG, kk = blockIdx.x / NG;
+  const int kc = kk % KC, kx = kk / KC;
+  const int b0 = g * IMG, nimg = min(IMG, B - b0);
+  twiddles<NY>(tw, twg, tid);
+  const cf* src = T + (((size_t)kx * KC + kc) * B + b0) * H * 16;
   for (int t = tid; t < NY * CH; t += NT) {
-    const int y = t / CH, v = t % CH;
-    buf[t] = y < H ? src[(size_t)y * C + v] : cf{0.f, 0.f};
+    const int y = t / CH, v = t % CH, img = v >> 4, c = v & 15;
+    buf[t] = (y < H && img < nimg) ? src[((size_t)img * H + y) * 16 + c] : cf{0.f, 0.f};
   }
   __syncthreads();
   fft<NY, -1, CH>(buf, tw, tid);
-  for (int t = tid; t < NY * CH; t += NT) {
-    const int ky = t / CH, v = t % CH;
-    Xf[((size_t)(kx * NY + ky) * B + b) * C + cblk * CB + v] = buf[pos<NY>(ky) * CH + v];
+  // item = (ky, k-half, image): 8 complex numbers -> NP units of the real parts + NP units of the imaginary parts
+  const int mt = b0 / MT, r0 = b0 - mt * MT;
+  for (int it = tid; it < NY * 2 * IMG; it += NT) {
+    const int img = it % IMG, kg = (it / IMG) & 1, ky = it / (2 * IMG);
+    const cf* z = buf + pos<NY>(ky) * CH + img * 16 + kg * 8;
+    float re[8], im[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { re[e] = z[e].x; im[e] = z[e].y; }
+    uint4 ur[NP], ui[NP];
+    split8<NP>(re, ur);
+    split8<NP>(im, ui);
+    const size_t f = (size_t)kx * NY + ky;
+    uint4* dst = Xs + (((f * mtiles + mt) * KC + kc) * (4 * NP) + kg) * MT + r0 + img;      // unit ((c * NP + p) * 2 + kg) * MT + row
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      dst[(size_t)(0 * NP + p) * 2 * MT] = ur[p];
+      dst[(size_t)(1 * NP + p) * 2 * MT] = ui[p];
+    }
   }
 }
 
-// ---- columns, inverse: Yf[ky][kx][b][c] -> T[b][y][kx][c], y < H (row y of the output is row y + pad of the linear convolution)
+// ---- columns, inverse: Yf[ky][kx][b][ldy channels] -> T[b][y][kx][c < C], y < H (row y of the output is row y + pad of the circular convolution)
 template <int NY>
-__global__ __launch_bounds__(NT) void cols_inv_kernel(const cf* __restrict__ Yf, cf* __restrict__ T, int B, int H, int NXH, int C, int pad, int b0, int kx0,
-                                                      int nkx) {
+__global__ __launch_bounds__(NT) void cols_inv_kernel(const cf* __restrict__ Yf, cf* __restrict__ T, const cf* __restrict__ twg, int B, int H, int NXH, int C, int ldy,
+                                                      int pad) {
   constexpr int CH = colblk<NY>(), CB = CH;
   __shared__ cf buf[NY * CH];
   __shared__ cf tw[NY];
   const int tid = threadIdx.x;
   const int cblk = blockIdx.x % (C / CB), bk = blockIdx.x / (C / CB);
-  const int kx = kx0 + bk % nkx, bl = bk / nkx, b = b0 + bl;
-  twiddles<NY>(tw, tid);
+  const int kx = bk % NXH, b = bk / NXH;
+  twiddles<NY>(tw, twg, tid);
   for (int t = tid; t < NY * CH; t += NT) {
     const int ky = t / CH, v = t % CH;
-    buf[t] = Yf[((size_t)(kx * NY + ky) * B + b) * C + cblk * CB + v];
+    buf[t] = Yf[((size_t)(kx * NY + ky) * B + b) * ldy + cblk * CB + v];
   }
   __syncthreads();
   fft<NY, 1, CH>(buf, tw, tid);
   for (int t = tid; t < H * CH; t += NT) {
     const int y = t / CH, v = t % CH;
-    T[((size_t)(bl * H + y) * NXH + kx) * C + cblk * CB + v] = buf[pos<NY>(y + pad) * CH + v];
+    T[((size_t)(b * H + y) * NXH + kx) * C + cblk * CB + v] = buf[pos<NY>(y + pad) * CH + v];
   }
 }
 
 // ---- rows, inverse + epilogue: T[b][y][kx][c] (C channels, padded to a multiple of 64) -> out with Cout channels
 // LAYOUT: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar (Cout % 8 == 0)
 template <int NX, int LAYOUT>
-__global__ __launch_bounds__(NT) void rows_inv_kernel(const cf* __restrict__ T, void* __restrict__ out, const float* __restrict__ bias,
+__global__ __launch_bounds__(NT) void rows_inv_kernel(const cf* __restrict__ T, void* __restrict__ out, const cf* __restrict__ twg, const float* __restrict__ bias,
                                                       const float* __restrict__ scale, const float* __restrict__ shift, int relu_bn, int H, int W, int C,
-                                                      int Cout, int pad, float norm, int b0) {
+                                                      int Cout, int pad, float norm) {
   constexpr int CH = CB / 2, NXH = NX / 2 + 1;
   __shared__ cf buf[NX * CH];
   __shared__ cf tw[NX];
   const int tid = threadIdx.x;
   const int cblk = blockIdx.x % (C / CB), by = blockIdx.x / (C / CB);
-  const int y = by % H, bl = by / H, b = b0 + bl;
-  twiddles<NX>(tw, tid);
-  const float4* src = reinterpret_cast<const float4*>(T + ((size_t)(bl * H + y) * NXH) * C + cblk * CB);
+  const int y = by % H, b = by / H;
+  twiddles<NX>(tw, twg, tid);
+  const float4* src = reinterpret_cast<const float4*>(T + ((size_t)(b * H + y) * NXH) * C + cblk * CB);
   // Z = Y_c + i Y_{c+1} with the Hermitian extension Y[NX - k] = conj Y[k]; DC and Nyquist are real by symmetry
   for (int t = tid; t < NXH * CH; t += NT) {
     const int k = t / CH, v = t % CH;
@@ -285,8 +334,8 @@ __global__ __launch_bounds__(NT) void rows_inv_kernel(const cf* __restrict__ T, 
 // the activation between two frequency-domain layers never goes to HBM.  T_in[b][y][kx][c] -> T_out[b][kx][y][c].
 // The epilogue's result IS the next layer's packed input: channel pair (c, c+1) = one complex number.
 template <int NX>
-__global__ __launch_bounds__(NT) void rows_inv_fwd_kernel(const cf* __restrict__ T, cf* __restrict__ Tn, const float* __restrict__ bias,
-                                                          const float* __restrict__ scale, const float* __restrict__ shift, int relu_bn, int H, int W, int C,
+__global__ __launch_bounds__(NT) void rows_inv_fwd_kernel(const cf* __restrict__ T, cf* __restrict__ Tn, const cf* __restrict__ twg, const float* __restrict__ bias,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift, int relu_bn, int B, int H, int W, int C,
                                                           int pad, float norm) {
   constexpr int CH = CB / 2, NXH = NX / 2 + 1;
   __shared__ cf buf[NX * CH];
@@ -295,7 +344,7 @@ __global__ __launch_bounds__(NT) void rows_inv_fwd_kernel(const cf* __restrict__
   const int tid = threadIdx.x;
   const int cblk = blockIdx.x % (C / CB), by = blockIdx.x / (C / CB);
   const int y = by % H, b = by / H;
-  twiddles<NX>(tw, tid);
+  twiddles<NX>(tw, twg, tid);
   const float4* src = reinterpret_cast<const float4*>(T + ((size_t)(b * H + y) * NXH) * C + cblk * CB);
   for (int t = tid; t < NXH * CH; t += NT) {
     const int k = t / CH, v = t % CH;
@@ -325,21 +374,19 @@ __global__ __launch_bounds__(NT) void rows_inv_fwd_kernel(const cf* __restrict__
   }
   __syncthreads();
   fft<NX, -1, CH>(nxt, tw, tid);
-  float4* dst = reinterpret_cast<float4*>(Tn);
-  for (int t = tid; t < NXH * CH; t += NT) {
-    const int k = t / CH, v = t % CH;
-    const cf zk = nxt[pos<NX>(k) * CH + v], zn = nxt[pos<NX>(k == 0 ? 0 : NX - k) * CH + v];
-    dst[(((size_t)(b * NXH + k) * H + y) * C + cblk * CB) / 2 + v] =
-        make_float4(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y), 0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
-  }
+  rows_fwd_store<NX>(nxt, Tn, tid, cblk, b, y, B, H, C);
 }
 
-// ---- filter spectra: HWIO fp32 [k][k][Cin][Cout] -> Wf[ky][kx][ci][co < CoutP] = sum_{a,b} w[k-1-a][k-1-b][ci][co] e^{-2 pi i (ky a / NY + kx b / NX)}
-// (the flipped kernel: TF's conv2d is a correlation; channels Cout .. CoutP-1 are zero)
-template <int KS>
-__global__ __launch_bounds__(256) void weight_spectra_kernel(const float* __restrict__ w, cf* __restrict__ Wf, int Cin, int Cout, int CoutP, int NY, int NX,
-                                                             int round_bf16) {
+// ---- filter spectra, split: HWIO fp32 [k][k][Cin][Cout] -> Wf[f][ci][co] = sum_{a,b} w[k-1-a][k-1-b][ci][co] e^{-2 pi i (ky a / NY + kx b / NX)}
+// (the flipped kernel: TF's conv2d is a correlation; output channels Cout .. CoutP-1 are zero), written as the channel GEMM's operand
+// image Ws[f][co/128][ci/16][re|im][part][k-half][128 columns][8 bf16] (cgemm_split.hip).  A work group owns 8 input channels (one
+// k-half) x 32 output channels: thread (ci, co) evaluates the separable 81- (25-) term DFT of its filter for one frequency after the
+// other, the 8 x 32 spectra meet in LDS, and 64 threads split them and store 16-byte units (32 columns = 512 contiguous bytes).
+template <int KS, int NP>
+__global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* __restrict__ w, uint4* __restrict__ Ws, int Cin, int Cout, int CoutP, int NY, int NX,
+                                                                   int round_bf16) {
   __shared__ cf twy[256], twx[256];
+  __shared__ cf sp[32][9];
   const int tid = threadIdx.x;
   for (int k = tid; k < NY + NX; k += 256) {
     const bool isy = k < NY;
@@ -349,9 +396,10 @@ __global__ __launch_bounds__(256) void weight_spectra_kernel(const float* __rest
     (isy ? twy : twx)[kk] = cf{(float)cs, (float)sn};
   }
   __syncthreads();
-  const size_t io = (size_t)blockIdx.x * 256 + tid;           // ci * CoutP + co
-  if (io >= (size_t)Cin * CoutP) return;
-  const int ci = (int)(io / CoutP), co = (int)(io - (size_t)ci * CoutP);
+  const int nco = CoutP / 32;
+  const int ci8 = blockIdx.x / nco, co32 = blockIdx.x % nco;
+  const int cil = tid & 7, col = tid >> 3;
+  const int ci = ci8 * 8 + cil, co = co32 * 32 + col;
   float g[KS][KS];                                            // flipped kernel
 #pragma unroll
   for (int a = 0; a < KS; ++a)
@@ -361,7 +409,11 @@ __global__ __launch_bounds__(256) void weight_spectra_kernel(const float* __rest
       if (round_bf16) wv = static_cast<float>(static_cast<__bf16>(wv));       // bf16 handles: the filter the bf16 MFMA kernels multiply with
       g[a][b] = wv;
     }
-  const int NXH = NX / 2 + 1;
+  const int NXH = NX / 2 + 1, KC = Cin / 16, ntiles = CoutP / kCgemmNT;
+  const int kc = ci8 >> 1, kg = ci8 & 1;
+  // the 64 storing threads: (column, re|im)
+  const int scol = tid & 31, sc = (tid >> 5) & 1;
+  const int sco = co32 * 32 + scol, snt = sco / kCgemmNT, sn = sco % kCgemmNT;
   for (int kx = blockIdx.y; kx < NXH; kx += gridDim.y) {
     cf ra[KS];
 #pragma unroll
@@ -375,109 +427,127 @@ __global__ __launch_bounds__(256) void weight_spectra_kernel(const float* __rest
       cf s = ra[0];
 #pragma unroll
       for (int a = 1; a < KS; ++a) s = s + cmul(ra[a], twy[(ky * a) % NY]);
-      Wf[(size_t)(kx * NY + ky) * Cin * CoutP + io] = s;
+      sp[col][cil] = s;
+      __syncthreads();
+      if (tid < 64) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = sc ? sp[scol][e].y : sp[scol][e].x;
+        uint4 u[NP];
+        split8<NP>(x, u);
+        const size_t f = (size_t)kx * NY + ky;
+        uint4* dst = Ws + (((f * ntiles + snt) * KC + kc) * (4 * NP) + (sc * NP) * 2 + kg) * kCgemmNT + sn;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) dst[(size_t)p * 2 * kCgemmNT] = u[p];
+      }
+      __syncthreads();
     }
   }
 }
 
 struct Sizes { int NY, NX; };
+// transform lengths with a radix plan (all even: the row pass packs two real rows into one complex transform and needs a Nyquist bin)
+static const int kLens[] = {20, 24, 28, 32, 36, 40, 50, 60, 64, 72, 96, 100, 128, 192};
 static bool pick(int need, int* n) {
-  static const int ok[] = {24, 32, 40, 60, 70, 72, 98, 100, 128, 192};      // 70 x 98 is the exact linear-convolution size of a 9x9 kernel on the 60x90 maps
-  for (int v : ok)
+  for (int v : kLens)
     if (v >= need) { *n = v; return true; }
   return false;
 }
-static bool sizes_of(int H, int W, int ks, Sizes* s) { return (ks == 9 || ks == 5) && pick(H + ks - 1, &s->NY) && pick(W + ks - 1, &s->NX); }
+static int tw_offset(int n) {
+  int off = 0;
+  for (int v : kLens) {
+    if (v == n) return off;
+    off += v;
+  }
+  return -1;
+}
+// circular convolution of size >= (H + pad) x (W + pad); one size per map for every kernel size (pad of the 9x9 layers), so that two
+// consecutive layers can hand the row-transformed tensor over.  The old limit H + k - 1 <= 192 is kept.
+static bool sizes_of(int H, int W, int ks, Sizes* s) {
+  return (ks == 9 || ks == 5) && H + ks - 1 <= 192 && W + ks - 1 <= 192 && pick(H + 4, &s->NY) && pick(W + 4, &s->NX);
+}
 static int pad64(int c) { return (c + CB - 1) / CB * CB; }
+static int pad128(int c) { return (c + kCgemmNT - 1) / kCgemmNT * kCgemmNT; }
 
-// (b0, nb): the slice of the batch a launch covers; T is the slice's scratch
-template <int NX> static void launch_rows_fwd(const ConvArgs& a, int layout, cf* T, int b0, int nb, hipStream_t st) {
-  const dim3 grid(nb * a.H * (a.Cin / CB));
-  if (layout == 0) hipLaunchKernelGGL((rows_fwd_kernel<NX, 0>), grid, dim3(NT), 0, st, a.x, T, a.H, a.W, a.Cin, b0);
-  else if (layout == 1) hipLaunchKernelGGL((rows_fwd_kernel<NX, 1>), grid, dim3(NT), 0, st, a.x, T, a.H, a.W, a.Cin, b0);
-  else hipLaunchKernelGGL((rows_fwd_kernel<NX, 2>), grid, dim3(NT), 0, st, a.x, T, a.H, a.W, a.Cin, b0);
+// e^{+2 pi i k / n} for every supported length, one table per device (built on the host in double precision, uploaded at first use)
+static const cf* twiddle_table(int dev) {
+  static std::mutex mu;
+  static std::map<int, cf*> tabs;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = tabs.find(dev);
+  if (it != tabs.end()) return it->second;
+  std::vector<float> h;
+  for (int n : kLens)
+    for (int k = 0; k < n; ++k) {
+      const double ang = 2.0 * 3.14159265358979323846 * (double)k / (double)n;
+      h.push_back((float)std::cos(ang));
+      h.push_back((float)std::sin(ang));
+    }
+  cf* d = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&d), h.size() * sizeof(float)) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+  tabs[dev] = d;
+  return d;
 }
-// (kx0, nkx): the range of frequency columns a launch covers
-template <int NY> static void launch_cols_fwd(const ConvArgs& a, const cf* T, cf* Xf, int NXH, int b0, int nb, int kx0, int nkx, hipStream_t st) {
-  hipLaunchKernelGGL(cols_fwd_kernel<NY>, dim3(nb * nkx * (a.Cin / colblk<NY>())), dim3(NT), 0, st, T, Xf, a.B, a.H, NXH, a.Cin, b0, kx0, nkx);
+
+template <int NX> static void launch_rows_fwd(const ConvArgs& a, int layout, cf* T, const cf* tw, hipStream_t st) {
+  const dim3 grid(a.B * a.H * (a.Cin / CB));
+  if (layout == 0) hipLaunchKernelGGL((rows_fwd_kernel<NX, 0>), grid, dim3(NT), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin);
+  else if (layout == 1) hipLaunchKernelGGL((rows_fwd_kernel<NX, 1>), grid, dim3(NT), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin);
+  else hipLaunchKernelGGL((rows_fwd_kernel<NX, 2>), grid, dim3(NT), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin);
 }
-template <int NY> static void launch_cols_inv(const ConvArgs& a, const cf* Yf, cf* T, int NXH, int pad, int b0, int nb, int kx0, int nkx, hipStream_t st) {
-  hipLaunchKernelGGL(cols_inv_kernel<NY>, dim3(nb * nkx * (a.CoutP / colblk<NY>())), dim3(NT), 0, st, Yf, T, a.B, a.H, NXH, a.CoutP, pad, b0, kx0, nkx);
+template <int NY> static hipError_t launch_cols_fwd(const ConvArgs& a, int np, const cf* T, void* Xs, const cf* tw, int NXH, int MT, hipStream_t st) {
+  constexpr int IMG = colimg<NY>();
+  constexpr int lds = (NY * IMG * 16 + NY) * (int)sizeof(cf);
+  const int KC = a.Cin / 16, mtiles = (a.B + MT - 1) / MT;
+  const dim3 grid((unsigned)(NXH * KC * ((a.B + IMG - 1) / IMG)));
+  static LdsAttr attr2, attr3;
+  if (np == 2) {
+    if (hipError_t e = attr2.ensure(reinterpret_cast<const void*>(cols_fwd_split_kernel<NY, 2>), lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 2>), grid, dim3(NT), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles);
+  } else {
+    if (hipError_t e = attr3.ensure(reinterpret_cast<const void*>(cols_fwd_split_kernel<NY, 3>), lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 3>), grid, dim3(NT), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles);
+  }
+  return hipSuccess;
 }
-template <int NX> static void launch_rows_inv(const ConvArgs& a, int layout, const cf* T, int pad, float norm, int b0, int nb, hipStream_t st) {
-  const dim3 grid(nb * a.H * (a.CoutP / CB));
+// a.CoutP = output channels the inverse passes transform (Cout padded to 64); ldy = channel stride of Yf (Cout padded to the GEMM's N tile)
+template <int NY> static void launch_cols_inv(const ConvArgs& a, const cf* Yf, cf* T, const cf* tw, int NXH, int ldy, int pad, hipStream_t st) {
+  hipLaunchKernelGGL(cols_inv_kernel<NY>, dim3(a.B * NXH * (a.CoutP / colblk<NY>())), dim3(NT), 0, st, Yf, T, tw, a.B, a.H, NXH, a.CoutP, ldy, pad);
+}
+template <int NX> static void launch_rows_inv(const ConvArgs& a, int layout, const cf* T, const cf* tw, int pad, float norm, hipStream_t st) {
+  const dim3 grid(a.B * a.H * (a.CoutP / CB));
   if (layout == 0)
-    hipLaunchKernelGGL((rows_inv_kernel<NX, 0>), grid, dim3(NT), 0, st, T, a.out, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm, b0);
+    hipLaunchKernelGGL((rows_inv_kernel<NX, 0>), grid, dim3(NT), 0, st, T, a.out, tw, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm);
   else if (layout == 1)
-    hipLaunchKernelGGL((rows_inv_kernel<NX, 1>), grid, dim3(NT), 0, st, T, a.out, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm, b0);
+    hipLaunchKernelGGL((rows_inv_kernel<NX, 1>), grid, dim3(NT), 0, st, T, a.out, tw, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm);
   else
-    hipLaunchKernelGGL((rows_inv_kernel<NX, 2>), grid, dim3(NT), 0, st, T, a.out, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm, b0);
+    hipLaunchKernelGGL((rows_inv_kernel<NX, 2>), grid, dim3(NT), 0, st, T, a.out, tw, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm);
 }
-template <int NX> static void launch_rows_inv_fwd(const ConvArgs& a, const cf* T, cf* Tn, int pad, float norm, hipStream_t st) {
-  hipLaunchKernelGGL(rows_inv_fwd_kernel<NX>, dim3(a.B * a.H * (a.Cout / CB)), dim3(NT), 0, st, T, Tn, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.Cout, pad, norm);
+template <int NX> static void launch_rows_inv_fwd(const ConvArgs& a, const cf* T, cf* Tn, const cf* tw, int pad, float norm, hipStream_t st) {
+  hipLaunchKernelGGL(rows_inv_fwd_kernel<NX>, dim3(a.B * a.H * (a.Cout / CB)), dim3(NT), 0, st, T, Tn, tw, a.bias, a.scale, a.shift, a.relu_bn, a.B, a.H, a.W, a.Cout, pad, norm);
 }
-template <int NX> static void launch_rows_fwd_merge(const ConvArgs& a, const FftMerge& m, cf* T, hipStream_t st) {
-  hipLaunchKernelGGL(rows_fwd_merge_kernel<NX>, dim3(a.B * a.H * (a.Cin / CB)), dim3(NT), 0, st, static_cast<const float*>(a.x), m.x2, m.H2, m.W2, m.x3, m.H3, m.W3, T, a.H,
-                     a.W, a.Cin, (float)m.H2 / (float)a.H, (float)m.W2 / (float)a.W, (float)m.H3 / (float)a.H, (float)m.W3 / (float)a.W);
-}
-// Images per slice of the transform passes.  JCM_FFT_SLICE_MB=n keeps the row-transformed tensor T of a slice below n MB (so that it
-// could stay in the 256 MB Infinity Cache between the row and the column kernel); measured at 160 / 96 / 48 MB: 2.6 / 2.1 / 9 % SLOWER
-// than the whole batch in one launch (fp32 B=64; bf16 B=256: 3.9 %), so the default is 0 = whole batch.
-static int slice_images(const ConvArgs& a, const Sizes& s) {
-  static const long long cap = [] { const char* e = std::getenv("JCM_FFT_SLICE_MB"); return (long long)(e ? std::atoi(e) : 0) << 20; }();
-  const size_t cmax = a.Cin > a.CoutP ? a.Cin : a.CoutP;
-  const long long per = (long long)(s.NX / 2 + 1) * a.H * cmax * sizeof(cf);
-  if (cap <= 0) return a.B;
-  const long long n = cap / per;
-  return n < 1 ? 1 : n > a.B ? a.B : (int)n;
+template <int NX> static void launch_rows_fwd_merge(const ConvArgs& a, const FftMerge& m, cf* T, const cf* tw, hipStream_t st) {
+  hipLaunchKernelGGL(rows_fwd_merge_kernel<NX>, dim3(a.B * a.H * (a.Cin / CB)), dim3(NT), 0, st, static_cast<const float*>(a.x), m.x2, m.H2, m.W2, m.x3, m.H3, m.W3, T, tw,
+                     a.B, a.H, a.W, a.Cin, (float)m.H2 / (float)a.H, (float)m.W2 / (float)a.W, (float)m.H3 / (float)a.H, (float)m.W3 / (float)a.W);
 }
 #define CFFT_BY_SIZE(N, CALL)                    \
   switch (N) {                                   \
+    case 20: CALL(20); break;                    \
     case 24: CALL(24); break;                    \
+    case 28: CALL(28); break;                    \
     case 32: CALL(32); break;                    \
+    case 36: CALL(36); break;                    \
     case 40: CALL(40); break;                    \
+    case 50: CALL(50); break;                    \
     case 60: CALL(60); break;                    \
-    case 70: CALL(70); break;                    \
+    case 64: CALL(64); break;                    \
     case 72: CALL(72); break;                    \
-    case 98: CALL(98); break;                    \
+    case 96: CALL(96); break;                    \
     case 100: CALL(100); break;                  \
     case 128: CALL(128); break;                  \
     default: CALL(192); break;                   \
   }
-
-// one rocBLAS handle per (device, stream), shared by the engines of the process and created on first use: a handle owns scratch
-// memory, so concurrent streams (the three resolution branches) each need their own
-static rocblas_handle blas_for(int dev, hipStream_t st) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, rocblas_handle> hs;
-  std::lock_guard<std::mutex> lk(mu);
-  auto it = hs.find({dev, st});
-  if (it != hs.end()) return it->second;
-  rocblas_handle h = nullptr;
-  if (rocblas_create_handle(&h) != rocblas_status_success) return nullptr;
-  if (rocblas_set_stream(h, st) != rocblas_status_success) { rocblas_destroy_handle(h); return nullptr; }
-  hs[{dev, st}] = h;
-  return h;
-}
-// A side stream and four events per (device, main stream): the column passes of one half of the frequency columns beside the GEMM of the
-// other half (the GEMM is MFMA-bound, the column kernels HBM-bound).  EXPERIMENT, off unless JCM_FFT_OVERLAP=1: measured 16.94 against
-// 16.58 ms per fp32 step and 45.15 against 45.59 ms per bf16 step -- the GEMM fills every CU and the halves cost it more than the
-// overlap returns.
-struct Side { hipStream_t s = nullptr; hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr}; };
-static Side* side_for(int dev, hipStream_t st) {
-  static const bool on = [] { const char* e = std::getenv("JCM_FFT_OVERLAP"); return e && e[0] == '1'; }();
-  if (!on) return nullptr;
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, Side> sides;
-  std::lock_guard<std::mutex> lk(mu);
-  Side& sd = sides[{dev, st}];
-  if (!sd.s) {
-    if (hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) != hipSuccess) { sd.s = nullptr; return nullptr; }
-    for (auto& ev : sd.e)
-      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
-  }
-  return &sd;
-}
 }  // namespace cfft
 
 using namespace cfft;
@@ -486,164 +556,117 @@ bool conv_fft_supported(const ConvArgs& a, int ks) {
   Sizes s;
   return a.Cin % CB == 0 && a.Cin >= CB && a.Cout >= 1 && a.B >= 1 && sizes_of(a.H, a.W, ks, &s);
 }
-size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout) {
+// np: bf16 parts per operand (3 = fp32 handles, 2 = bf16 handles)
+size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout, int np) {
   Sizes s;
   if (!sizes_of(H, W, ks, &s)) return 0;
-  return (size_t)s.NY * (s.NX / 2 + 1) * Cin * pad64(Cout) * sizeof(cf);
+  return (size_t)s.NY * (s.NX / 2 + 1) * Cin * pad128(Cout) * 4 * np;      // 2 (re, im) x np parts x 2 bytes per element
 }
-hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, bool round_bf16, hipStream_t st) {
+hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, int np, bool round_bf16, hipStream_t st) {
   Sizes s;
-  if (!sizes_of(H, W, ks, &s)) return hipErrorInvalidValue;
-  const int CoutP = pad64(Cout);
-  const dim3 grid((unsigned)(((size_t)Cin * CoutP + 255) / 256), 8);
-  if (ks == 9) hipLaunchKernelGGL(weight_spectra_kernel<9>, grid, dim3(256), 0, st, w_hwio, static_cast<cf*>(wf), Cin, Cout, CoutP, s.NY, s.NX, round_bf16 ? 1 : 0);
-  else hipLaunchKernelGGL(weight_spectra_kernel<5>, grid, dim3(256), 0, st, w_hwio, static_cast<cf*>(wf), Cin, Cout, CoutP, s.NY, s.NX, round_bf16 ? 1 : 0);
+  if (!sizes_of(H, W, ks, &s) || Cin % 16 || (np != 2 && np != 3)) return hipErrorInvalidValue;
+  const int CoutP = pad128(Cout);
+  const dim3 grid((unsigned)((Cin / 8) * (CoutP / 32)), 8);
+  uint4* dst = static_cast<uint4*>(wf);
+  const int rb = round_bf16 ? 1 : 0;
+  if (ks == 9 && np == 2) hipLaunchKernelGGL((weight_spectra_split_kernel<9, 2>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, s.NY, s.NX, rb);
+  else if (ks == 9) hipLaunchKernelGGL((weight_spectra_split_kernel<9, 3>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, s.NY, s.NX, rb);
+  else if (np == 2) hipLaunchKernelGGL((weight_spectra_split_kernel<5, 2>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, s.NY, s.NX, rb);
+  else hipLaunchKernelGGL((weight_spectra_split_kernel<5, 3>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, s.NY, s.NX, rb);
   return hipGetLastError();
 }
-// scratch: T (the larger of the two row-transformed tensors) + Xf + Yf
-size_t conv_fft_workspace_bytes(const ConvArgs& a, int ks) {
+// scratch: T (the larger of the two row-transformed tensors) + the split activation spectra Xs + the product spectra Yf
+namespace {
+struct Plan3 { size_t t_bytes, xs_bytes, yf_bytes; int MT, NXH, F, ldy; };
+Plan3 plan_of(const ConvArgs& a, const Sizes& s, int np) {
+  Plan3 p;
+  p.NXH = s.NX / 2 + 1;
+  p.F = s.NY * p.NXH;
+  p.ldy = pad128(a.Cout);
+  p.MT = cgemm_split_mtile(np, a.B);
+  const size_t cop = pad64(a.Cout), cmax = (size_t)a.Cin > cop ? a.Cin : cop;
+  const size_t bp = (size_t)(a.B + p.MT - 1) / p.MT * p.MT;
+  p.t_bytes = (size_t)a.B * p.NXH * a.H * cmax * sizeof(cf);
+  p.xs_bytes = (size_t)p.F * bp * a.Cin * 4 * np;
+  p.yf_bytes = (size_t)p.F * a.B * p.ldy * sizeof(cf);
+  return p;
+}
+size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+}  // namespace
+size_t conv_fft_workspace_bytes(const ConvArgs& a, int ks, int np) {
   Sizes s;
   if (!sizes_of(a.H, a.W, ks, &s)) return 0;
-  const size_t NXH = s.NX / 2 + 1, cop = pad64(a.Cout), cmax = (size_t)a.Cin > cop ? a.Cin : cop;
-  ConvArgs ap = a;
-  ap.CoutP = (int)cop;
-  return ((size_t)slice_images(ap, s) * NXH * a.H * cmax + (size_t)s.NY * NXH * a.B * (a.Cin + cop)) * sizeof(cf);
+  const Plan3 p = plan_of(a, s, np);
+  return align256(p.t_bytes) + align256(p.xs_bytes) + align256(p.yf_bytes);
 }
 // Can layer L (a, ks) hand its output to layer L+1 (kernel size ks_next, same map) in row-transformed form?  Same NX for both kernel
-// sizes, unpadded channel count, whole batch in one pass.
+// sizes (always: the size depends on the map only), unpadded channel count, two row buffers in LDS.
 bool conv_fft_fusable(const ConvArgs& a, int ks, int ks_next) {
   Sizes s, n;
-  if (!sizes_of(a.H, a.W, ks, &s) || !sizes_of(a.H, a.W, ks_next, &n) || s.NX != n.NX || s.NX > 100 || a.Cout % CB) return false;   // (two row buffers in LDS)
-  ConvArgs ap = a;
-  ap.CoutP = a.Cout;
-  return slice_images(ap, s) == a.B;
+  return sizes_of(a.H, a.W, ks, &s) && sizes_of(a.H, a.W, ks_next, &n) && s.NX == n.NX && s.NX <= 100 && a.Cout % CB == 0;
 }
-size_t conv_fft_handover_bytes(const ConvArgs& a, int ks) {      // T[b][kx][y][Cout] of the next layer
+size_t conv_fft_handover_bytes(const ConvArgs& a, int ks) {      // T[kx][c/16][b][y][16] of the next layer
   Sizes s;
   if (!sizes_of(a.H, a.W, ks, &s)) return 0;
   return (size_t)a.B * (s.NX / 2 + 1) * a.H * a.Cout * sizeof(cf);
 }
-// a.wp = the filter spectra of THIS map size and kernel size; `work` = conv_fft_workspace_bytes(a, ks) bytes.  g0 / g1: optional events
-// recorded around the GEMM (the dominant kernel of the layer) for the roofline record.
+// a.wp = the split filter spectra of THIS map size and kernel size; `work` = conv_fft_workspace_bytes(a, ks, np) bytes.  g0 / g1: optional
+// events recorded around the GEMM (the dominant kernel of the layer) for the roofline record.
 // in_layout / out_layout: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar
-// t_in (fp32 handles): the row-transformed input T[b][kx][y][ci] left by the previous layer's fused kernel -- the forward row pass is skipped;
+// t_in (fp32 handles): the row-transformed input left by the previous layer's fused kernel -- the forward row pass is skipped;
 // t_next: write the NEXT layer's row-transformed input there instead of the spatial output (conv_fft_fusable() says when that is legal).
-hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int in_layout, int out_layout, void* work, const void* t_in, void* t_next, const FftMerge* merge,
+hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int out_layout, void* work, const void* t_in, void* t_next, const FftMerge* merge,
                         hipEvent_t g0, hipEvent_t g1, hipStream_t st) {
   Sizes s;
-  if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s) || (out_layout == 2 && a0.Cout % 8)) return hipErrorInvalidValue;
+  if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s) || (out_layout == 2 && a0.Cout % 8) || (np != 2 && np != 3)) return hipErrorInvalidValue;
+  if ((t_in || t_next || merge) && (in_layout != 0 || out_layout != 0 || (t_next && a0.Cout % CB))) return hipErrorInvalidValue;
   ConvArgs a = a0;
   a.CoutP = pad64(a.Cout);
-  const int pad = (ks - 1) / 2;
-  const int NXH = s.NX / 2 + 1, F = s.NY * NXH;
-  const size_t cmax = a.Cin > a.CoutP ? a.Cin : a.CoutP;
-  const int SL = (t_in || t_next || merge) ? a.B : slice_images(a, s);      // the fused hand-over covers the whole batch
-  if ((t_in || t_next || merge) && (in_layout != 0 || out_layout != 0 || (t_next && a.Cout % CB))) return hipErrorInvalidValue;
-  cf* T = static_cast<cf*>(work);
-  cf* Xf = T + (size_t)SL * NXH * a.H * cmax;
-  cf* Yf = Xf + (size_t)F * a.B * a.Cin;
+  const int opad = (ks - 1) / 2;                         // output row y = row y + pad of the circular convolution (whose size is H + 4 for both kernel sizes)
+  const Plan3 p = plan_of(a, s, np);
+  char* wk = static_cast<char*>(work);
+  cf* T = reinterpret_cast<cf*>(wk);
+  void* Xs = wk + align256(p.t_bytes);
+  cf* Yf = reinterpret_cast<cf*>(wk + align256(p.t_bytes) + align256(p.xs_bytes));
   int dev = 0;
   if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
-  rocblas_handle bh = blas_for(dev, st);
-  if (!bh) return hipErrorUnknown;
+  const cf* twb = twiddle_table(dev);
+  if (!twb) return hipErrorOutOfMemory;
+  const cf* twx = twb + tw_offset(s.NX);
+  const cf* twy = twb + tw_offset(s.NY);
   const float norm = 1.0f / (float)(s.NY * s.NX);
   const cf* Tin = t_in ? static_cast<const cf*>(t_in) : T;
-  auto gemm = [&](int kx0, int nkx) -> bool {      // the frequency columns kx0 .. kx0 + nkx - 1: nkx * NY matrix products
-    const rocblas_float_complex one{1.f, 0.f}, zero{0.f, 0.f};
-    const size_t f0 = (size_t)kx0 * s.NY;
-    return rocblas_cgemm_strided_batched(bh, rocblas_operation_none, rocblas_operation_none, a.CoutP, a.B, a.Cin, &one,
-                                         static_cast<const rocblas_float_complex*>(a.wp) + f0 * a.Cin * a.CoutP, a.CoutP, (rocblas_stride)a.Cin * a.CoutP,
-                                         reinterpret_cast<const rocblas_float_complex*>(Xf) + f0 * a.B * a.Cin, a.Cin, (rocblas_stride)a.B * a.Cin, &zero,
-                                         reinterpret_cast<rocblas_float_complex*>(Yf) + f0 * a.B * a.CoutP, a.CoutP, (rocblas_stride)a.B * a.CoutP,
-                                         nkx * s.NY) == rocblas_status_success;
-  };
-  Side* sd = SL == a.B && NXH >= 8 ? side_for(dev, st) : nullptr;
-  if (sd) {
-    // ---- two halves of the frequency columns, the column passes of one beside the GEMM of the other:
-    //   main: rows_fwd | cols_fwd(H0) GEMM(H0) ........ GEMM(H1) cols_inv(H1) | rows_inv
-    //   side:          | cols_fwd(H1) ......... cols_inv(H0)                  |
-    const int k1 = NXH / 2, n1 = NXH - k1;
-    if (merge && !t_in) {
-#define CALL(N) launch_rows_fwd_merge<N>(a, *merge, T, st)
-      CFFT_BY_SIZE(s.NX, CALL)
+  if (merge && !t_in) {
+#define CALL(N) launch_rows_fwd_merge<N>(a, *merge, T, twx, st)
+    CFFT_BY_SIZE(s.NX, CALL)
 #undef CALL
-    } else if (!t_in) {
-#define CALL(N) launch_rows_fwd<N>(a, in_layout, T, 0, a.B, st)
-      CFFT_BY_SIZE(s.NX, CALL)
+  } else if (!t_in) {
+#define CALL(N) launch_rows_fwd<N>(a, in_layout, T, twx, st)
+    CFFT_BY_SIZE(s.NX, CALL)
 #undef CALL
-    }
-    if (hipEventRecord(sd->e[0], st) != hipSuccess || hipStreamWaitEvent(sd->s, sd->e[0], 0) != hipSuccess) return hipErrorUnknown;
-#define CALL(N) launch_cols_fwd<N>(a, Tin, Xf, NXH, 0, a.B, k1, n1, sd->s)
-    CFFT_BY_SIZE(s.NY, CALL)
-#undef CALL
-    if (hipEventRecord(sd->e[1], sd->s) != hipSuccess) return hipErrorUnknown;
-#define CALL(N) launch_cols_fwd<N>(a, Tin, Xf, NXH, 0, a.B, 0, k1, st)
-    CFFT_BY_SIZE(s.NY, CALL)
-#undef CALL
-    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-    if (g0 && hipEventRecord(g0, st) != hipSuccess) return hipErrorUnknown;
-    if (!gemm(0, k1)) return hipErrorUnknown;
-    if (hipEventRecord(sd->e[2], st) != hipSuccess || hipStreamWaitEvent(sd->s, sd->e[2], 0) != hipSuccess) return hipErrorUnknown;
-    // the side stream has finished its cols_fwd (same stream) and the main stream's cols_fwd(H0) precedes e[2]: nobody reads T any more
-#define CALL(N) launch_cols_inv<N>(a, Yf, T, NXH, pad, 0, a.B, 0, k1, sd->s)
-    CFFT_BY_SIZE(s.NY, CALL)
-#undef CALL
-    if (hipEventRecord(sd->e[3], sd->s) != hipSuccess) return hipErrorUnknown;
-    if (hipStreamWaitEvent(st, sd->e[1], 0) != hipSuccess) return hipErrorUnknown;
-    if (!gemm(k1, n1)) return hipErrorUnknown;
-    if (g1 && hipEventRecord(g1, st) != hipSuccess) return hipErrorUnknown;
-#define CALL(N) launch_cols_inv<N>(a, Yf, T, NXH, pad, 0, a.B, k1, n1, st)
-    CFFT_BY_SIZE(s.NY, CALL)
-#undef CALL
-    if (hipStreamWaitEvent(st, sd->e[3], 0) != hipSuccess) return hipErrorUnknown;
-    if (t_next) {
-#define CALL(N) launch_rows_inv_fwd<N>(a, T, static_cast<cf*>(t_next), pad, norm, st)
-      CFFT_BY_SIZE(s.NX, CALL)
-#undef CALL
-    } else {
-#define CALL(N) launch_rows_inv<N>(a, out_layout, T, pad, norm, 0, a.B, st)
-      CFFT_BY_SIZE(s.NX, CALL)
-#undef CALL
-    }
-    return hipGetLastError();
   }
-  // ---- one stream
-  for (int b0 = 0; b0 < a.B; b0 += SL) {
-    const int nb = a.B - b0 < SL ? a.B - b0 : SL;
-    if (merge && !t_in) {
-#define CALL(N) launch_rows_fwd_merge<N>(a, *merge, T, st)
-      CFFT_BY_SIZE(s.NX, CALL)
+  hipError_t ce = hipSuccess;
+#define CALL(N) ce = launch_cols_fwd<N>(a, np, Tin, Xs, twy, p.NXH, p.MT, st)
+  CFFT_BY_SIZE(s.NY, CALL)
 #undef CALL
-    } else if (!t_in) {
-#define CALL(N) launch_rows_fwd<N>(a, in_layout, T, b0, nb, st)
-      CFFT_BY_SIZE(s.NX, CALL)
-#undef CALL
-    }
-#define CALL(N) launch_cols_fwd<N>(a, Tin, Xf, NXH, b0, nb, 0, NXH, st)
-    CFFT_BY_SIZE(s.NY, CALL)
-#undef CALL
-    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-  }
+  if (ce != hipSuccess) return ce;
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
   if (g0 && hipEventRecord(g0, st) != hipSuccess) return hipErrorUnknown;
-  if (!gemm(0, NXH)) return hipErrorUnknown;
+  if (hipError_t e = cgemm_split(Xs, a.wp, Yf, np, p.F, a.B, a.Cin, p.ldy, st); e != hipSuccess) return e;
   if (g1 && hipEventRecord(g1, st) != hipSuccess) return hipErrorUnknown;
-  for (int b0 = 0; b0 < a.B; b0 += SL) {
-    const int nb = a.B - b0 < SL ? a.B - b0 : SL;
-#define CALL(N) launch_cols_inv<N>(a, Yf, T, NXH, pad, b0, nb, 0, NXH, st)
-    CFFT_BY_SIZE(s.NY, CALL)
+#define CALL(N) launch_cols_inv<N>(a, Yf, T, twy, p.NXH, p.ldy, opad, st)
+  CFFT_BY_SIZE(s.NY, CALL)
 #undef CALL
-    if (t_next) {
-#define CALL(N) launch_rows_inv_fwd<N>(a, T, static_cast<cf*>(t_next), pad, norm, st)
-      CFFT_BY_SIZE(s.NX, CALL)
+  if (t_next) {
+#define CALL(N) launch_rows_inv_fwd<N>(a, T, static_cast<cf*>(t_next), twx, opad, norm, st)
+    CFFT_BY_SIZE(s.NX, CALL)
 #undef CALL
-    } else {
-#define CALL(N) launch_rows_inv<N>(a, out_layout, T, pad, norm, b0, nb, st)
-      CFFT_BY_SIZE(s.NX, CALL)
+  } else {
+#define CALL(N) launch_rows_inv<N>(a, out_layout, T, twx, opad, norm, st)
+    CFFT_BY_SIZE(s.NX, CALL)
 #undef CALL
-    }
-    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
   }
-  return hipSuccess;
+  return hipGetLastError();
 }
 
 }  // namespace jcm

@@ -174,7 +174,8 @@ static int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope
   a.x = x; a.bias = L->bias; a.scale = L->scale; a.shift = L->shift; a.out = out;
   a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout; a.CoutP = L->cout; a.relu_bn = L->has_bn ? 1 : 0;
   const size_t mark = c->arena_off;
-  void* work = arena_alloc<char>(c, conv_fft_workspace_bytes(a, L->ks));
+  const int np = c->precision == JCM_PRECISION_BF16 ? 2 : 3;      // bf16 parts per operand of the channel GEMM (cgemm_split.hip)
+  void* work = arena_alloc<char>(c, conv_fft_workspace_bytes(a, L->ks, np));
   if (!c->no_reuse) c->arena_off = mark;                 // scratch of this layer only: later layers run behind it on the stream
   if (c->dry) { c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; return JCM_OK; }
   // Filter spectra are cached per (layer, map size).  The cache is bounded (JCM_FFT_CACHE_GB, default 64): a caller that walks many
@@ -182,7 +183,7 @@ static int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope
   const std::string key = scope + "@" + std::to_string(H) + "x" + std::to_string(W);
   if (!c->fft_w.count(key)) {
     static const size_t cap = [] { const char* e = std::getenv("JCM_FFT_CACHE_GB"); return (size_t)(e ? std::atoi(e) : 64) << 30; }();
-    const size_t need = conv_fft_weight_bytes(H, W, L->ks, L->cin, L->cout);
+    const size_t need = conv_fft_weight_bytes(H, W, L->ks, L->cin, L->cout, np);
     size_t held = 0;
     for (auto& kv : c->fft_w) held += kv.second.bytes;
     if (held + need > cap && !c->fft_w.empty()) {
@@ -193,7 +194,7 @@ static int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope
   }
   jcm_ctx::FftW& fw = c->fft_w[key];
   if (!fw.p) {
-    fw.bytes = conv_fft_weight_bytes(H, W, L->ks, L->cin, L->cout);
+    fw.bytes = conv_fft_weight_bytes(H, W, L->ks, L->cin, L->cout, np);
     if (hipMalloc(&fw.p, fw.bytes) != hipSuccess) {
       const size_t mb = fw.bytes >> 20;
       c->fft_w.erase(key);
@@ -201,7 +202,7 @@ static int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope
     }
   }
   if (!fw.valid) {
-    HIP_TRY(conv_fft_pack_weights(L->w_raw, fw.p, H, W, L->ks, L->cin, L->cout, c->precision == JCM_PRECISION_BF16, c->stream));
+    HIP_TRY(conv_fft_pack_weights(L->w_raw, fw.p, H, W, L->ks, L->cin, L->cout, np, c->precision == JCM_PRECISION_BF16, c->stream));
     fw.valid = true;
   }
   a.wp = fw.p;
@@ -212,7 +213,7 @@ static int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope
   void* t_next = c->fft_t_next;
   const FftMerge* mg = static_cast<const FftMerge*>(c->fft_merge);
   c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr;
-  const hipError_t e = conv_fft_f32(a, L->ks, in_layout, out_layout, work, t_in, t_next, mg, g0, g1, c->stream);
+  const hipError_t e = conv_fft_f32(a, L->ks, np, in_layout, out_layout, work, t_in, t_next, mg, g0, g1, c->stream);
   if (g0 && g1 && e == hipSuccess) c->prof[scope + "/gemm"].emplace_back(g0, g1);
   else { if (g0) c->event_pool.push_back(g0); if (g1) c->event_pool.push_back(g1); }
   prof_end(c, scope, e0, e1, e == hipSuccess);
@@ -1001,11 +1002,11 @@ int jcm_conv_kernel_name(jcm_handle h, const char* scope, int B, int H, int W, c
     k = L->thin_bf16 ? (L->wp_kxfold && conv_kxfold_bf16_supported(a, L->ks) ? "conv_kxfold_bf16_kernel" : "conv_thin_bf16_kernel")
         : (conv_igemm_bf16_bn(L->cout, L->ks) == 256 && conv_strip_bf16_supported(a, L->ks)) ? "conv_strip_bf16_kernel"
         : (L->ks == 5 && conv_igemm_bf16_bn(L->cout, L->ks) == 128 && conv5_strip_bf16_supported(a, L->ks)) ? "conv5_strip_bf16_kernel" : "conv_igemm_bf16_kernel";
-    if (takes_fft(h, L, B, H, W)) k = "conv_fft(rocblas_cgemm_strided_batched)";
+    if (takes_fft(h, L, B, H, W)) k = "conv_fft(cgemm_split_kernel)";
   } else {
     const bool use_split = L->wp_split && (L->thin ? h->f32_conv == 2 : conv_split_supported(L->ks, L->cin, L->coutp_split, B, H, W, h->split_min_wgs));
     k = L->thin ? (use_split ? "conv_thin_split16_kernel" : "conv_thin_f32_kernel") : use_split ? "conv_split_kernel" : "conv_igemm_f32_kernel";
-    if (takes_fft(h, L, B, H, W)) k = "conv_fft(rocblas_cgemm_strided_batched)";
+    if (takes_fft(h, L, B, H, W)) k = "conv_fft(cgemm_split_kernel)";
   }
   std::snprintf(name, (size_t)cap, "%s", k);
   return JCM_OK;

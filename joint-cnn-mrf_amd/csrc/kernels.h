@@ -71,21 +71,31 @@ hipError_t conv_thin_f32(const ConvArgs& a, hipStream_t st);
 // weights packed by pack_weights_bf16 with CoutP = 16
 hipError_t conv_thin_bf16(const ConvArgs& a, hipStream_t st);
 
-// ---- conv_fft.hip : stride-1 SAME convolution (9x9, 5x5) of the fp32 path in the frequency domain (in-LDS FFTs + rocBLAS cgemm over the
-// channels, one matrix product per frequency); NHWC fp32 in / out, a.wp = filter spectra of this map and kernel size
-// (conv_fft_pack_weights; output channels padded to a multiple of 64).  Shapes: Cin % 64 == 0, H + k - 1 <= 192, W + k - 1 <= 192.
+// ---- conv_fft.hip : stride-1 SAME convolution (9x9, 5x5) in the frequency domain: in-LDS FFTs (rows, then columns with the operand split
+// fused in) around the channel GEMM of cgemm_split.hip, one complex matrix product per frequency.  a.wp = split filter spectra of this map
+// and kernel size (conv_fft_pack_weights).  np = bf16 parts per operand: 3 on fp32 handles (six products, fp32-class), 2 on bf16 handles.
+// Shapes: Cin % 64 == 0, H + k - 1 <= 192, W + k - 1 <= 192.
 bool conv_fft_supported(const ConvArgs& a, int ks);
-size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout);
-hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, bool round_bf16, hipStream_t st);
-size_t conv_fft_workspace_bytes(const ConvArgs& a, int ks);
-// in / out layout: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar (bf16 handles: operands are bf16 values, the arithmetic is fp32); g0/g1: optional events around the GEMM
+size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout, int np);
+hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, int np, bool round_bf16, hipStream_t st);
+size_t conv_fft_workspace_bytes(const ConvArgs& a, int ks, int np);
+// in / out layout: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar (bf16 handles: operands are bf16 values, the arithmetic is fp32-class); g0/g1: optional events around the GEMM
 // t_in / t_next: the row-transformed tensor handed from one frequency-domain layer to the next (fp32 NHWC handles; conv_fft_fusable).
 // merge: a.x is the full-resolution branch x1 and the layer's input is ((x1 + up(x2)) + up(x3)) / 3, formed while the rows are loaded.
 struct FftMerge { const float* x2; int H2, W2; const float* x3; int H3, W3; };
-hipError_t conv_fft_f32(const ConvArgs& a, int ks, int in_layout, int out_layout, void* work, const void* t_in, void* t_next, const FftMerge* merge,
+hipError_t conv_fft_f32(const ConvArgs& a, int ks, int np, int in_layout, int out_layout, void* work, const void* t_in, void* t_next, const FftMerge* merge,
                         hipEvent_t g0, hipEvent_t g1, hipStream_t st);
 bool conv_fft_fusable(const ConvArgs& a, int ks, int ks_next);
 size_t conv_fft_handover_bytes(const ConvArgs& a, int ks);
+
+// ---- cgemm_split.hip : Y[f][b][co] = sum_ci X[f][b][ci] W[f][ci][co] (complex) for F frequencies on v_mfma_f32_32x32x16_bf16, operands
+// pre-split into np bf16 parts in tile-major LDS-image layout:
+//   xs[f][m-tile][Cin/16][re|im][part][k-half][MT rows][8]   (MT = cgemm_split_mtile(np, B); rows >= B are never stored)
+//   ws[f][n-tile][Cin/16][re|im][part][k-half][128 cols][8]  (CoutP % 128 == 0)
+//   y [f][B][CoutP] complex fp32
+constexpr int kCgemmNT = 128;
+int cgemm_split_mtile(int np, int B);
+hipError_t cgemm_split(const void* xs, const void* ws, void* y, int np, int F, int B, int Cin, int CoutP, hipStream_t st);
 
 // ---- conv5_strip_bf16.hip : 5x5 SAME convolution in 128-channel output tiles on 768-pixel strips (bf16 in NHWC or planar, bf16 out NHWC or planar;
 // weights as packed by pack_weights_bf16); shapes: CoutP % 128 == 0, Cin % 32 == 0, Cout % 8 == 0, 8 <= W <= 191 and a window of at most 64 row parts

@@ -37,7 +37,7 @@ def test_config3_batch256_bf16_properties(fft):
     eng = Engine(device=0, precision='bf16', conv9_fft=fft).load_params(p)
     # the kernels under test: the frequency-domain route of the wide 9x9 layers (default), or the flattened-strip bf16 MFMA kernel (a
     # silent fallback to the patch kernel would pass too)
-    want = 'conv_fft(rocblas_cgemm_strided_batched)' if fft else 'conv_strip_bf16_kernel'
+    want = 'conv_fft(cgemm_split_kernel)' if fft else 'conv_strip_bf16_kernel'
     assert eng.conv_kernel_name('conv5', B, 60, 90) == eng.conv_kernel_name('conv4_fullres', B, 60, 90) == want
     r = eng.forward(dev(x), dev(torso), use_sm=True)
     pd, sm = r['pd_prob'].cpu().numpy(), r['sm_prob'].cpu().numpy()

@@ -1,0 +1,118 @@
+// Stand-alone check + timing of the channel GEMM (joint-cnn-mrf_amd/csrc/cgemm_split.hip) outside the library:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I joint-cnn-mrf_amd/csrc tools/cgemm_probe.hip -o tools/cgemm_probe
+//   tools/cgemm_probe <np> <F> <B> <Cin> <Cout> [iters]
+// Operands are a hash of their index (the same on host and device), split on the device into the kernel's tile-major layouts by
+// two naive packing kernels; sampled outputs are compared with a float64 host sum of the SAME fp32 values.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../joint-cnn-mrf_amd/csrc/cgemm_split.hip"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+__host__ __device__ inline float hval(unsigned long long i, unsigned salt) {
+  unsigned long long z = i * 0x9E3779B97F4A7C15ull + salt * 0xD1B54A32D192ED03ull;
+  z ^= z >> 31; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 29; z *= 0x94D049BB133111EBull; z ^= z >> 32;
+  return (float)((double)(z & 0xffffff) / 8388608.0 - 1.0);      // [-1, 1), 24 random bits: a full fp32 mantissa
+}
+__host__ __device__ inline float xval(size_t f, int b, int ci, int c, int B, int Cin) { return hval(((f * B + b) * Cin + ci) * 2 + c, 1); }
+__host__ __device__ inline float wval(size_t f, int ci, int co, int c, int Cin, int Cout) { return hval(((f * Cin + ci) * Cout + co) * 2 + c, 2) * 0.05f; }
+
+__device__ inline void split_store(float v, int np, __bf16* dst, size_t pstride) {
+  for (int p = 0; p < np; ++p) {
+    const __bf16 q = static_cast<__bf16>(v);
+    dst[p * pstride] = q;
+    v = v - static_cast<float>(q);
+  }
+}
+// one thread per (f, row, ci)
+__global__ void pack_x(__bf16* xs, int np, int F, int B, int Cin, int MT, int mtiles) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)F * mtiles * MT * Cin;
+  if (i >= n) return;
+  const int ci = (int)(i % Cin);
+  const int row = (int)((i / Cin) % (mtiles * MT));
+  const size_t f = i / ((size_t)Cin * mtiles * MT);
+  const int mt = row / MT, r = row % MT, kc = ci / 16, kg = (ci % 16) / 8, e = ci % 8, KC = Cin / 16;
+  for (int c = 0; c < 2; ++c) {
+    const float v = row < B ? xval(f, row, ci, c, B, Cin) : 0.f;
+    __bf16* dst = xs + (((((f * mtiles + mt) * KC + kc) * (4 * np) + (size_t)(c * np) * 2 + kg) * MT + r) * 8 + e);
+    split_store(v, np, dst, (size_t)2 * MT * 8);
+  }
+}
+__global__ void pack_w(__bf16* ws, int np, int F, int Cin, int Cout, int CoutP) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)F * Cin * CoutP;
+  if (i >= n) return;
+  const int co = (int)(i % CoutP);
+  const int ci = (int)((i / CoutP) % Cin);
+  const size_t f = i / ((size_t)CoutP * Cin);
+  const int nt = co / 128, cn = co % 128, kc = ci / 16, kg = (ci % 16) / 8, e = ci % 8, KC = Cin / 16, ntiles = CoutP / 128;
+  for (int c = 0; c < 2; ++c) {
+    const float v = co < Cout ? wval(f, ci, co, c, Cin, Cout) : 0.f;
+    __bf16* dst = ws + (((((f * ntiles + nt) * KC + kc) * (4 * np) + (size_t)(c * np) * 2 + kg) * 128 + cn) * 8 + e);
+    split_store(v, np, dst, (size_t)2 * 128 * 8);
+  }
+}
+
+int main(int argc, char** argv) {
+  const int np = argc > 1 ? atoi(argv[1]) : 2, F = argc > 2 ? atoi(argv[2]) : 64, B = argc > 3 ? atoi(argv[3]) : 256;
+  const int Cin = argc > 4 ? atoi(argv[4]) : 512, Cout = argc > 5 ? atoi(argv[5]) : 512, iters = argc > 6 ? atoi(argv[6]) : 5;
+  const int CoutP = (Cout + 127) / 128 * 128;
+  const int MT = jcm::cgemm_split_mtile(np, B), mtiles = (B + MT - 1) / MT;
+  const size_t xbytes = (size_t)F * mtiles * MT * Cin * 4 * np, wbytes = (size_t)F * Cin * CoutP * 4 * np, ybytes = (size_t)F * B * CoutP * 8;
+  void *xs, *ws, *y;
+  CK(hipMalloc(&xs, xbytes)); CK(hipMalloc(&ws, wbytes)); CK(hipMalloc(&y, ybytes));
+  CK(hipMemset(y, 0xff, ybytes));
+  {
+    const size_t nx = (size_t)F * mtiles * MT * Cin, nw = (size_t)F * Cin * CoutP;
+    hipLaunchKernelGGL(pack_x, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, 0, (__bf16*)xs, np, F, B, Cin, MT, mtiles);
+    hipLaunchKernelGGL(pack_w, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, 0, (__bf16*)ws, np, F, Cin, Cout, CoutP);
+    CK(hipDeviceSynchronize());
+  }
+  CK(jcm::cgemm_split(xs, ws, y, np, F, B, Cin, CoutP, 0));
+  CK(hipDeviceSynchronize());
+  // ---- check sampled outputs
+  double worst = 0, scale = 0;
+  int bad = 0;
+  for (int s = 0; s < 400; ++s) {
+    const size_t f = (size_t)((s * 7919u) % F);
+    const int b = s < 8 ? (s & 1 ? B - 1 : 0) : (int)((s * 104729u) % B);
+    const int co = s < 8 ? (s & 2 ? Cout - 1 : 0) : (int)((s * 1299709u) % Cout);
+    double yr = 0, yi = 0, mag = 0;
+    for (int ci = 0; ci < Cin; ++ci) {
+      const double xr = xval(f, b, ci, 0, B, Cin), xi = xval(f, b, ci, 1, B, Cin), wr = wval(f, ci, co, 0, Cin, Cout), wi = wval(f, ci, co, 1, Cin, Cout);
+      yr += xr * wr - xi * wi;
+      yi += xr * wi + xi * wr;
+      mag += fabs(xr * wr) + fabs(xi * wi);
+    }
+    float2 got;
+    CK(hipMemcpy(&got, (char*)y + ((f * B + b) * CoutP + co) * 8, 8, hipMemcpyDeviceToHost));
+    const double err = fmax(fabs(got.x - yr), fabs(got.y - yi));
+    const double rms = sqrt((double)Cin) * 0.05 * 0.577 * 0.577 * 1.414;      // typical |y|
+    if (!(err <= (np == 3 ? 6e-6 : 1e-4) * rms)) { if (bad < 5) printf("MISMATCH f=%zu b=%d co=%d got (%g,%g) want (%g,%g)\n", f, b, co, got.x, got.y, yr, yi); ++bad; }
+    worst = fmax(worst, err / rms);
+    scale = rms;
+  }
+  printf("np=%d F=%d B=%d Cin=%d Cout=%d MT=%d: worst error / typical |y| = %.3g (%d bad of 400; |y| ~ %.3g)\n", np, F, B, Cin, Cout, MT, worst, bad, scale);
+  // ---- timing
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i) CK(jcm::cgemm_split(xs, ws, y, np, F, B, Cin, CoutP, 0));
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i) CK(jcm::cgemm_split(xs, ws, y, np, F, B, Cin, CoutP, 0));
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= iters;
+  const double nprod = np == 3 ? 6 : 3;
+  const double flop32 = 8.0 * B * Cin * (double)CoutP * F, bytes = (double)xbytes * B / (mtiles * MT) + wbytes + ybytes;
+  printf("  %.3f ms  | %.1f TF fp32-equivalent, %.1f TF executed bf16 (%.1f %% of 2.5 PF) | %.2f GB algorithmic -> %.2f TB/s\n", ms, flop32 / ms / 1e9,
+         flop32 * nprod / ms / 1e9, flop32 * nprod / ms / 1e9 / 25.0, bytes / 1e9, bytes / ms / 1e9);
+  return bad ? 2 : 0;
+}
