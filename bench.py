@@ -8,10 +8,13 @@ A step = one pass of the whole path over one batch per GPU (BASELINE.json config
 fp32) with inputs already resident in HBM.  Ranks shard by batch (images are independent);
 the only collective is the all-gather of [B,2,9] int32 coordinates (main.py:573-574 -> RCCL).
 Prints ONE JSON line on rank 0 with the driver's contract keys plus `roofline` (dominant
-kernel = the channel GEMM of the frequency-domain conv4_fullres / conv5 layers -- or, with the
-direct kernels selected, their MFMA implicit-GEMM launch -- timed live with HIP events on its
-stream) and `cpu_baseline` (the CPU restatement timed on the host cores; TensorFlow is
-unavailable).
+kernel = the hand-written channel GEMM `cgemm_split_kernel` of the frequency-domain conv4_fullres /
+conv5 layers -- or, with the direct kernels selected, their MFMA implicit-GEMM launch -- timed live
+with HIP events on its stream) and `cpu_baseline` (the CPU restatement timed on the host cores;
+TensorFlow is unavailable).  Beside the headline (configs[1], fp32, batch 64) the line carries
+`bf16_config2` (configs[2], default route), `bf16_config2_mfma` (configs[2] on the direct bf16 MFMA
+kernels only, `conv9_fft=0`) and `config3_gb2048` (configs[3]: a fixed global batch of 2048 images
+sharded over the ranks, strong scaling).
 """
 import argparse
 import json
@@ -37,6 +40,19 @@ FLOPS_PD_SM = 413_188_758_480
 # 60x90 maps.  Algorithmic FLOPs per image of each launch = 60*90 * Cout * 81*Cin * 2:
 FLOPS_DOMINANT = {'conv4_fullres': 114_661_785_600, 'conv5': 229_323_571_200}
 PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0                            # HBM3E spec (6.3 TB/s is what a streaming copy achieves)
+# Frequency-domain route (conv_fft.hip): 60x90 maps -> 64 x 96 circular transforms, 64 * 49 frequencies; the channel GEMM
+# (cgemm_split.hip) is one complex [B x Cin] x [Cin x Cout] product per frequency on bf16 MFMA with operands split into
+# NP bf16 parts (3 on fp32 handles: six real products per real multiply; 2 on bf16 handles: three).
+FFT_FREQS = 64 * 49
+GEMM_LAYERS = {'conv4_fullres': (256, 512), 'conv5': (512, 512)}
+
+
+def gemm_mtile(np_parts, b):
+    """cgemm_split_mtile() of cgemm_split.hip: rows of the M tile the activation spectra are laid out for."""
+    if np_parts == 2:
+        return 256 if b > 128 else 128 if b > 64 else 64
+    return 128 if b > 64 else 64
 
 
 def pmc_traffic(key):
@@ -46,9 +62,10 @@ def pmc_traffic(key):
     value is the last profiled one for this (dtype, batch), else null."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
-            return json.load(fh).get(key, {}).get('traffic_bytes_per_launch')
+            rec = json.load(fh).get(key, {})
+            return rec.get('traffic_bytes_per_launch'), rec.get('source')
     except OSError:
-        return None
+        return None, None
 
 
 def cpu_baseline(n_images, params):
@@ -77,12 +94,12 @@ def resident_inputs(B, rank, dev):
     return x, torso
 
 
-def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32_conv=None, config_name=None, micro_batch=None):
+def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32_conv=None, config_name=None, micro_batch=None, conv9_fft=None):
     """Time `args.steps` steps of one (dtype, batch) configuration; returns the result dict on
     rank 0 (None elsewhere).  Timed region: barrier + synchronize on both sides, max over ranks.
     f32_conv='split': the fp32 path with its 60x90 9x9 layers on the bf16x6 split kernel (conv_split.hip).
     B is the rank's batch per step; jcm_forward walks it in micro-batches (256 bf16 / 64 fp32 unless `micro_batch`)."""
-    eng = Engine(device=local_rank, precision=dtype, f32_conv=f32_conv, micro_batch=micro_batch).load_params(params)
+    eng = Engine(device=local_rank, precision=dtype, f32_conv=f32_conv, micro_batch=micro_batch, conv9_fft=conv9_fft).load_params(params)
     x, torso = resident_inputs(B, rank, dev)                                          # resident in HBM
 
     def step():
@@ -131,25 +148,34 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
         kname = eng.conv_kernel_name('conv5', min(B, micro_batch or (256 if dtype == 'bf16' else 64)), 60, 90) if not args.debug else 'debug'
         layer_ms = tot_ms / max(tot_n, 1)                      # average duration of a whole conv4_fullres / conv5 layer
         freq_domain = kname.startswith('conv_fft')
+        mb = micro_batch or (256 if dtype == 'bf16' else 64)
+        gemm = None
         if freq_domain:
-            # wide 9x9 layers in the frequency domain: the dominant kernel is the channel GEMM (rocBLAS cgemm_strided_batched, one complex
-            # matrix product per frequency of the 70 x 98 transform); its own algorithmic FLOPs, its own HIP events
-            tot_ms, tot_n, tot_flops = 0.0, 0, 0.0
-            for scope, (cin, cout) in {'conv4_fullres': (256, 512), 'conv5': (512, 512)}.items():
+            # wide 9x9 layers in the frequency domain: the dominant kernel is the channel GEMM cgemm_split_kernel (one complex matrix
+            # product per frequency); its own executed bf16-MFMA FLOPs and algorithmic HBM bytes, its own HIP events
+            np_parts = 2 if dtype == 'bf16' else 3
+            nprod = 3 if np_parts == 2 else 6
+            mrows = min(B, mb)
+            mt = gemm_mtile(np_parts, mrows)
+            rows_p = -(-mrows // mt) * mt
+            tot_ms, tot_n, tot_flops, tot_bytes, tot_flops32 = 0.0, 0, 0.0, 0.0, 0.0
+            for scope, (cin, cout) in GEMM_LAYERS.items():
                 ms, n = eng.profile_read(scope + '/gemm')
                 tot_ms, tot_n = tot_ms + ms, tot_n + n
-                tot_flops += 8.0 * cin * cout * 70 * 50 * B * args.steps if n else 0.0
+                tot_flops32 += 8.0 * cin * cout * FFT_FREQS * mrows * n              # complex multiply-adds as real FLOPs
+                tot_flops += nprod * 8.0 * cin * cout * FFT_FREQS * mrows * n        # executed on the bf16 matrix cores
+                tot_bytes += FFT_FREQS * (rows_p * cin * 4 * np_parts + cin * cout * 4 * np_parts + mrows * cout * 8) * n
+            gemm = {'np_parts': np_parts, 'products': nprod, 'flops32_per_launch': tot_flops32 / max(tot_n, 1), 'bytes_per_launch': tot_bytes / max(tot_n, 1)}
         launch_ms = tot_ms / max(tot_n, 1)                     # average launch duration (HIP events, launch stream)
-        flops_launch = tot_flops / max(tot_n, 1)               # average algorithmic FLOPs per launch
+        flops_launch = tot_flops / max(tot_n, 1)               # average algorithmic (direct kernels) / executed (split GEMM) FLOPs per launch
         achieved = flops_launch / (launch_ms * 1e-3) / 1e12 if tot_n else None
-        peak = PEAK_TFLOPS['fp32' if freq_domain else dtype]     # the channel GEMM of the frequency-domain route is complex fp32
+        peak = PEAK_TFLOPS['bf16' if freq_domain else dtype]     # the channel GEMM runs on the bf16 matrix cores for both handle types
         fp32_equiv = None
         if f32_conv in ('split', 'split16') and achieved:      # the roofline of these kernels is the 16-bit matrix-core peak
             fp32_equiv = achieved
             achieved = achieved * (6 if f32_conv == 'split' else 3)
             peak = PEAK_TFLOPS['bf16']
         value = world * B * args.steps / dt
-        mb = micro_batch or (256 if dtype == 'bf16' else 64)
         out = {
             'value': value, 'ms_per_step': dt / args.steps * 1e3,
             # the arithmetic the path computes in: exact fp32 MFMA chain, or fp32 operands carried as 16-bit parts
@@ -163,9 +189,12 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
                        'batch_per_gpu': B, 'global_batch': world * B, 'micro_batch': min(mb, B), 'use_sm': use_sm,
                        'collective': 'all_gather coords int32 [B,2,9]'},
             'path_tflops': value * FLOPS_PD_SM / (16 if args.debug else 1) / 1e12,
-            'roofline': {'bound': 'mfma', 'kernel': ('channel GEMM of the frequency-domain 9x9 layers (conv4_fullres + conv5; %s)' if freq_domain else
+            'scaling': 'weak',
+            'roofline': {'bound': 'mfma', 'kernel': ('cgemm_split_kernel: channel GEMM of the frequency-domain 9x9 layers (conv4_fullres + conv5; %s)' if freq_domain else
                                                      'conv_igemm 9x9, 60x90 maps (conv4_fullres + conv5 launches; %s)')
-                                   % ('complex fp32, one [B x Cin] x [Cin x Cout] product per frequency of the 70 x 98 transform = 3500 per launch; achieved = 8 B Cin Cout x 3500 FLOP / GEMM time'
+                                   % ('hand-written, v_mfma_f32_32x32x16_bf16, operands split into %d bf16 parts (%d real products per multiply), one complex [B x Cin] x [Cin x Cout] '
+                                      'product per frequency of the 64 x 96 transform = 3136 per launch, LDS-DMA operand rings; achieved = executed bf16 MFMA FLOPs / GEMM time'
+                                      % (gemm['np_parts'], gemm['products'])
                                       if freq_domain else
                                       'fp32 operands as 3 bf16 parts, 6 x bf16 MFMA 32x32x16 per k16 step, 12x32 patch x 256 ch; achieved = executed bf16 MFMA FLOPs (6 x algorithmic) against the bf16 peak'
                                       if f32_conv == 'split' else
@@ -176,13 +205,24 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
                                       else 'bf16 MFMA 32x32x16, 12x32 patch x 256 ch'),
                          'kernel_name': kname,
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None,
-                         'traffic': pmc_traffic('%s%s_b%d' % (dtype, '_' + f32_conv if f32_conv in ('split', 'split16') else '', B)) if not args.debug else None,
                          'launch_ms': launch_ms, 'launches': tot_n, 'flops_per_launch': flops_launch},
         }
+        rf = out['roofline']
+        tkey = '%s_b%d_fft' % (dtype, min(B, mb)) if freq_domain else '%s%s_b%d' % (dtype, '_' + f32_conv if f32_conv in ('split', 'split16') else '', min(B, mb))
+        rf['traffic'], rf['traffic_source'] = pmc_traffic(tkey) if not args.debug else (None, None)
+        # SURVEY 8d's yardstick beside the executed-work one: images/s x 413.19 GFLOP (the direct-convolution FLOPs of the path) / MFMA peak of the handle's type
+        rf['algorithmic_frac'] = out['path_tflops'] / PEAK_TFLOPS[dtype]
         if freq_domain:
-            out['roofline']['traffic'] = pmc_traffic('%s_b%d_fft' % (dtype, B)) if not args.debug else None
-            out['roofline']['layer_ms'] = layer_ms  # the whole layer: four transform kernels + the GEMM
-            out['path_tflops_note'] = 'images/s x direct-convolution FLOPs: the wide 9x9 layers run 30x fewer in the frequency domain'
+            # the GEMM against both ceilings; `bound` names the one it sits closer to
+            gbs = gemm['bytes_per_launch'] / (launch_ms * 1e-3) / 1e9 if tot_n else None
+            rf['mfma'] = {'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None,
+                          'fp32_equivalent_tflops': gemm['flops32_per_launch'] / (launch_ms * 1e-3) / 1e12 if tot_n else None}
+            rf['hbm'] = {'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': (gbs / PEAK_HBM_GBS) if gbs else None,
+                         'algorithmic_bytes_per_launch': gemm['bytes_per_launch']}
+            if gbs and achieved and gbs / PEAK_HBM_GBS > achieved / peak:
+                rf.update({'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS})
+            rf['layer_ms'] = layer_ms  # the whole layer: four transform kernels + the GEMM
+            out['path_tflops_note'] = 'images/s x direct-convolution FLOPs: the wide 9x9 layers execute 35x fewer in the frequency domain'
         if fp32_equiv is not None:
             out['roofline']['fp32_equivalent_tflops'] = fp32_equiv
             out['roofline']['x_fp32_mfma_peak'] = fp32_equiv / PEAK_TFLOPS['fp32']
@@ -360,11 +400,24 @@ def main():
         head_batch = args.batch or (64 if head_dtype == 'fp32' else 256)
         head = run_config(args, head_dtype, head_batch, params, world, rank, local_rank, dev, use_sm,
                           f32_conv=args.f32_conv if head_dtype == 'fp32' else None, micro_batch=args.micro_batch)
-    second = split = split16 = None
+    second = second_mfma = split = split16 = config3 = None
     if args.dtype is None and not args.debug and not args.global_batch:
         second = run_config(args, 'bf16', args.batch or 256, params, world, rank, local_rank, dev, use_sm)
-        # the same fp32 configuration with the 60x90 9x9 layers on the bf16 matrix cores (three-way operand split, fp32-class
-        # error, same parity tests); reported beside the headline, which stays on the exact fp32 MFMA chain
+        # configs[2] on the direct bf16 MFMA kernels only (conv_strip_bf16_kernel for the 9x9 layers): the north star's
+        # "9x9 + pairwise pass on the bf16 matrix cores" with its own driver-timed roofline
+        second_mfma = run_config(args, 'bf16', args.batch or 256, params, world, rank, local_rank, dev, use_sm, conv9_fft=False,
+                                 config_name='configs[2], direct bf16 MFMA kernels only (conv9_fft=0)')
+        # configs[3]: a FIXED global batch of 2048 images sharded over the ranks (main.py:511,516-517), bf16, micro-batches of 256;
+        # present in every line so that the driver's N = 1/2/4/8 runs trace the strong-scaling curve
+        gb = 2048
+        if gb // world >= 1:
+            config3 = run_config(args, 'bf16', gb // world, params, world, rank, local_rank, dev, use_sm,
+                                 config_name='configs[3] (global batch %d sharded over %d rank%s)' % (gb, world, '' if world == 1 else 's'))
+            if config3 is not None:
+                config3['scaling'] = 'strong'
+    if args.dtype is None and not args.debug and not args.global_batch and world == 1:
+        # the same fp32 configuration with the 60x90 9x9 layers on the direct split kernels (three-way operand split, fp32-class
+        # error, same parity tests); reported beside the headline
         split = run_config(args, 'fp32', head_batch, params, world, rank, local_rank, dev, use_sm, f32_conv='split')
         split16 = run_config(args, 'fp32', head_batch, params, world, rank, local_rank, dev, use_sm, f32_conv='split16')
 
@@ -385,6 +438,10 @@ def main():
                'roofline': head['roofline']}
         if second is not None:
             out['bf16_config2'] = second
+        if second_mfma is not None:
+            out['bf16_config2_mfma'] = second_mfma
+        if config3 is not None:
+            out['config3_gb2048'] = config3
         if split is not None:
             out['f32_split_config1'] = split
         if split16 is not None:

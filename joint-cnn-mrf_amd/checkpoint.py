@@ -92,8 +92,10 @@ def session_state(trainer, like):
         else:
             out[name + '/Momentum'] = slots[0][off:off + cnt].reshape(shape).copy()
     if adam:
-        out['beta1_power'] = np.float32(ADAM_BETA1 ** n.value)
-        out['beta2_power'] = np.float32(ADAM_BETA2 ** n.value)
+        # tf.train.AdamOptimizer creates the accumulators AT beta (not 1) and multiplies them by beta in _finish after every
+        # update: after n updates a Saver checkpoint holds beta ** (n + 1)
+        out['beta1_power'] = np.float32(ADAM_BETA1 ** (n.value + 1))
+        out['beta2_power'] = np.float32(ADAM_BETA2 ** (n.value + 1))
     out['n_iters'] = np.int32(n.value)
     return out
 

@@ -404,9 +404,8 @@ bool make_geom(const ConvArgs& a, Geom& gm) {
 }  // namespace
 
 bool conv5_strip_bf16_supported(const ConvArgs& a, int ks) {
-  static const bool enabled = [] { const char* e = std::getenv("JCM_C5STRIP"); return !(e && e[0] == '0'); }();   // JCM_C5STRIP=0: A/B against the patch kernel
   Geom gm;
-  return enabled && ks == KS && make_geom(a, gm);
+  return ks == KS && make_geom(a, gm);
 }
 
 hipError_t conv5_strip_bf16(const ConvArgs& a, hipStream_t st) {

@@ -1,0 +1,110 @@
+// Column passes of the frequency-domain convolution: forward with the bf16 operand split fused in, inverse (see conv_fft.hip).
+#include "conv_fft_common.h"
+
+namespace jcm {
+namespace cfft {
+
+// ---- columns, forward + operand split: T[kx][c/16][b][y][16] -> Xs[f = kx NY + ky][m-tile][c/16][re|im][part][k-half][row][8] bf16
+// One work group = (IMG images, kx, one 16-channel chunk): its input is one contiguous run of T; after the FFT along y every spectrum is
+// split into NP bf16 parts (x = x0 + x1 (+ x2), each rounded to nearest: exact for NP = 3, 16 significant bits for NP = 2) and stored as
+// 16-byte MFMA operand units -- 8 consecutive channels of one image -- with the units of the work group's IMG images consecutive: 128-byte
+// lines for IMG = 8.  The result is the channel GEMM's LDS image (cgemm_split.hip), which that kernel fetches by LDS-DMA.
+template <int NY, int NP>
+__global__ __launch_bounds__(colfwd_threads<NY>()) void cols_fwd_split_kernel(const cf* __restrict__ T, uint4* __restrict__ Xs, const cf* __restrict__ twg, int B, int H, int KC, int MT,
+                                                            int mtiles) {
+  constexpr int IMG = colimg<NY>(), CH = IMG * 16, NTC = colfwd_threads<NY>();
+  extern __shared__ __attribute__((aligned(16))) char smem_cf[];
+  cf* buf = reinterpret_cast<cf*>(smem_cf);
+  cf* tw = buf + NY * CH;
+  const int tid = threadIdx.x;
+  const int NG = (B + IMG - 1) / IMG;
+  const int g = blockIdx.x % NG, kk = blockIdx.x / NG;
+  const int kc = kk % KC, kx = kk / KC;
+  const int b0 = g * IMG, nimg = min(IMG, B - b0);
+  twiddles<NY, NTC>(tw, twg, tid);
+  const cf* src = T + (((size_t)kx * KC + kc) * B + b0) * H * 16;
+  for (int t = tid; t < NY * CH; t += NTC) {
+    const int y = t / CH, v = t % CH, img = v >> 4, c = v & 15;
+    buf[t] = (y < H && img < nimg) ? src[((size_t)img * H + y) * 16 + c] : cf{0.f, 0.f};
+  }
+  __syncthreads();
+  fft<NY, -1, CH, NTC>(buf, tw, tid);
+  // item = (ky, k-half, image): 8 complex numbers -> NP units of the real parts + NP units of the imaginary parts
+  const int mt = b0 / MT, r0 = b0 - mt * MT;
+  for (int it = tid; it < NY * 2 * IMG; it += NTC) {
+    const int img = it % IMG, kg = (it / IMG) & 1, ky = it / (2 * IMG);
+    const cf* z = buf + pos<NY>(ky) * CH + img * 16 + kg * 8;
+    float re[8], im[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { re[e] = z[e].x; im[e] = z[e].y; }
+    uint4 ur[NP], ui[NP];
+    split8<NP>(re, ur);
+    split8<NP>(im, ui);
+    const size_t f = (size_t)kx * NY + ky;
+    uint4* dst = Xs + (((f * mtiles + mt) * KC + kc) * (4 * NP) + kg) * MT + r0 + img;      // unit ((c * NP + p) * 2 + kg) * MT + row
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      dst[(size_t)(0 * NP + p) * 2 * MT] = ur[p];
+      dst[(size_t)(1 * NP + p) * 2 * MT] = ui[p];
+    }
+  }
+}
+
+// ---- columns, inverse: Yf[ky][kx][b][ldy channels] -> T[b][y][kx][c < C], y < H (row y of the output is row y + pad of the circular convolution)
+template <int NY>
+__global__ __launch_bounds__(colinv_threads<NY>()) void cols_inv_kernel(const cf* __restrict__ Yf, cf* __restrict__ T, const cf* __restrict__ twg, int B, int H, int NXH, int C, int ldy,
+                                                      int pad) {
+  constexpr int CH = colblk<NY>(), CB = CH, NTC = colinv_threads<NY>();
+  __shared__ cf buf[NY * CH];
+  __shared__ cf tw[NY];
+  const int tid = threadIdx.x;
+  const int cblk = blockIdx.x % (C / CB), bk = blockIdx.x / (C / CB);
+  const int kx = bk % NXH, b = bk / NXH;
+  twiddles<NY, NTC>(tw, twg, tid);
+  for (int t = tid; t < NY * CH; t += NTC) {
+    const int ky = t / CH, v = t % CH;
+    buf[t] = Yf[((size_t)(kx * NY + ky) * B + b) * ldy + cblk * CB + v];
+  }
+  __syncthreads();
+  fft<NY, 1, CH, NTC>(buf, tw, tid);
+  for (int t = tid; t < H * CH; t += NTC) {
+    const int y = t / CH, v = t % CH;
+    T[((size_t)(b * H + y) * NXH + kx) * C + cblk * CB + v] = buf[pos<NY>(y + pad) * CH + v];
+  }
+}
+
+
+template <int NY> static hipError_t launch_cols_fwd(const ConvArgs& a, int np, const cf* T, void* Xs, const cf* tw, int NXH, int MT, hipStream_t st) {
+  constexpr int IMG = colimg<NY>();
+  constexpr int lds = (NY * IMG * 16 + NY) * (int)sizeof(cf);
+  const int KC = a.Cin / 16, mtiles = (a.B + MT - 1) / MT;
+  const dim3 grid((unsigned)(NXH * KC * ((a.B + IMG - 1) / IMG)));
+  static LdsAttr attr2, attr3;
+  if (np == 2) {
+    if (hipError_t e = attr2.ensure(reinterpret_cast<const void*>(cols_fwd_split_kernel<NY, 2>), lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 2>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles);
+  } else {
+    if (hipError_t e = attr3.ensure(reinterpret_cast<const void*>(cols_fwd_split_kernel<NY, 3>), lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 3>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles);
+  }
+  return hipSuccess;
+}
+// a.CoutP = output channels the inverse passes transform (Cout padded to 64); ldy = channel stride of Yf (Cout padded to the GEMM's N tile)
+template <int NY> static void launch_cols_inv(const ConvArgs& a, const cf* Yf, cf* T, const cf* tw, int NXH, int ldy, int pad, hipStream_t st) {
+  hipLaunchKernelGGL(cols_inv_kernel<NY>, dim3(a.B * NXH * (a.CoutP / colblk<NY>())), dim3(colinv_threads<NY>()), 0, st, Yf, T, tw, a.B, a.H, NXH, a.CoutP, ldy, pad);
+}
+hipError_t cfft_cols_fwd(int NY, const ConvArgs& a, int np, const cf* T, void* Xs, const cf* tw, int NXH, int MT, hipStream_t st) {
+  hipError_t e = hipSuccess;
+#define CALL(N) e = launch_cols_fwd<N>(a, np, T, Xs, tw, NXH, MT, st)
+  CFFT_BY_SIZE(NY, CALL)
+#undef CALL
+  return e;
+}
+void cfft_cols_inv(int NY, const ConvArgs& a, const cf* Yf, cf* T, const cf* tw, int NXH, int ldy, int pad, hipStream_t st) {
+#define CALL(N) launch_cols_inv<N>(a, Yf, T, tw, NXH, ldy, pad, st)
+  CFFT_BY_SIZE(NY, CALL)
+#undef CALL
+}
+
+}  // namespace cfft
+}  // namespace jcm

@@ -1,0 +1,147 @@
+// Shared by the translation units of the frequency-domain convolution (conv_fft.hip: host side + filter spectra; conv_fft_rows_fwd.hip,
+// conv_fft_rows_inv.hip, conv_fft_cols.hip: the transform kernels, one file per pass so that they compile in parallel): radix plans,
+// the channel-vectorised in-LDS FFT stages, the bf16 operand split, and the size-dispatching launchers each file exports.
+#pragma once
+#include "fft_lds.h"
+#include "kernels.h"
+
+namespace jcm {
+namespace cfft {
+using namespace fftl;
+constexpr int CB = 64, NT = 256;      // channels per work group; kernel sizes 9 and 5 (pad = (ks - 1) / 2 passed at launch)
+
+// radix chains (decimation in frequency, in place): the output X[n] sits at pos(n)
+template <int N> struct Plan;
+template <> struct Plan<192> { static constexpr int R1 = 8, R2 = 8, R3 = 3; };
+template <> struct Plan<128> { static constexpr int R1 = 8, R2 = 4, R3 = 4; };
+template <> struct Plan<100> { static constexpr int R1 = 4, R2 = 5, R3 = 5; };
+template <> struct Plan<96> { static constexpr int R1 = 8, R2 = 12, R3 = 1; };
+template <> struct Plan<72> { static constexpr int R1 = 8, R2 = 3, R3 = 3; };
+template <> struct Plan<64> { static constexpr int R1 = 8, R2 = 8, R3 = 1; };
+template <> struct Plan<60> { static constexpr int R1 = 4, R2 = 15, R3 = 1; };
+template <> struct Plan<50> { static constexpr int R1 = 5, R2 = 10, R3 = 1; };
+template <> struct Plan<40> { static constexpr int R1 = 8, R2 = 5, R3 = 1; };
+template <> struct Plan<36> { static constexpr int R1 = 4, R2 = 3, R3 = 3; };
+template <> struct Plan<32> { static constexpr int R1 = 8, R2 = 4, R3 = 1; };
+template <> struct Plan<28> { static constexpr int R1 = 4, R2 = 7, R3 = 1; };
+template <> struct Plan<24> { static constexpr int R1 = 8, R2 = 3, R3 = 1; };
+template <> struct Plan<20> { static constexpr int R1 = 4, R2 = 5, R3 = 1; };
+template <int N> __device__ __forceinline__ int pos(int n) {
+  using P = Plan<N>;
+  if constexpr (P::R3 == 1) return (n % P::R1) * (N / P::R1) + n / P::R1;
+  else return (n % P::R1) * (N / P::R1) + ((n / P::R1) % P::R2) * (N / (P::R1 * P::R2)) + n / (P::R1 * P::R2);
+}
+
+// one stage over CH channel lanes: buf[position][channel], tw[k] = e^{+2 pi i k / N}
+template <int N, int R, int L, int S, int CH, int NTH = NT>
+__device__ __forceinline__ void stage(cf* buf, const cf* tw, int tid) {
+  constexpr int M = L / R, BF = N / R;
+  for (int t = tid; t < BF * CH; t += NTH) {
+    const int bf = t / CH, v = t % CH;
+    const int blk = bf / M, k = bf - blk * M;
+    cf* p = buf + (blk * L + k) * CH + v;
+    cf x[R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) x[m] = p[m * M * CH];
+    Dft<R, S>::run(x);
+    if (M > 1) {
+#pragma unroll
+      for (int m = 1; m < R; ++m) {
+        cf w = tw[(N / L) * k * m];
+        if (S < 0) w.y = -w.y;
+        x[m] = cmul(x[m], w);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < R; ++m) p[m * M * CH] = x[m];
+  }
+}
+template <int N, int S, int CH, int NTH = NT>
+__device__ __forceinline__ void fft(cf* buf, const cf* tw, int tid) {
+  using P = Plan<N>;
+  stage<N, P::R1, N, S, CH, NTH>(buf, tw, tid);
+  __syncthreads();
+  stage<N, P::R2, N / P::R1, S, CH, NTH>(buf, tw, tid);
+  __syncthreads();
+  if constexpr (P::R3 > 1) {
+    stage<N, P::R3, N / (P::R1 * P::R2), S, CH, NTH>(buf, tw, tid);
+    __syncthreads();
+  }
+}
+// tw[k] = e^{+2 pi i k / N} from the per-device table (host-built in double precision; tw_offset(N) entries in)
+template <int N, int NTH = NT>
+__device__ __forceinline__ void twiddles(cf* tw, const cf* __restrict__ twg, int tid) {
+  for (int k = tid; k < N; k += NTH) tw[k] = twg[k];
+}
+
+
+__device__ __forceinline__ cf bf16pair(unsigned bits) { return cf{__uint_as_float(bits << 16), __uint_as_float(bits & 0xffff0000u)}; }
+// index, in float4 = two channels, of channel pair v (0..31) of 64-channel block cblk in T[kx][c/16][b][y][16]
+__device__ __forceinline__ size_t t_fwd_index(int k, int cblk, int v, int b, int y, int B, int H, int C) {
+  return ((((size_t)k * (C >> 4) + cblk * 4 + (v >> 3)) * B + b) * H + y) * 8 + (v & 7);
+}
+// Z = FFT(x_c + i x_{c+1}):  X_c[k] = (Z[k] + conj Z[-k]) / 2,  X_{c+1}[k] = (Z[k] - conj Z[-k]) / (2i)
+template <int NX, int NTH = NT>
+__device__ __forceinline__ void rows_fwd_store(const cf* buf, cf* __restrict__ T, int tid, int cblk, int b, int y, int B, int H, int C) {
+  constexpr int CH = CB / 2, NXH = NX / 2 + 1;
+  float4* dst = reinterpret_cast<float4*>(T);
+  for (int t = tid; t < NXH * CH; t += NTH) {
+    const int k = t / CH, v = t % CH;
+    const cf zk = buf[pos<NX>(k) * CH + v], zn = buf[pos<NX>(k == 0 ? 0 : NX - k) * CH + v];
+    dst[t_fwd_index(k, cblk, v, b, y, B, H, C)] = make_float4(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y), 0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+  }
+}
+// The row kernels keep NX x 32 complex numbers in LDS: threads per work group chosen so that the work groups the LDS admits fill the CU's 32 waves
+template <int NX> constexpr int rows_threads() { return NX >= 128 ? 512 : NX >= 72 ? 384 : 256; }
+template <int NY> constexpr int colblk() { return NY > 100 ? 32 : 64; }      // channels per work group of the inverse column kernel (<= 64 KB of LDS)
+template <int NY> constexpr int colimg() { return NY > 96 ? 4 : 8; }         // images per work group (LDS: NY * IMG * 16 complex numbers)
+// The column kernels hold big LDS tiles (two work groups per CU for the forward pass): they are latency-bound -- load, three barriers, store --
+// unless the tile is worked on by many waves.  Threads per work group, so that a CU runs its full 32 waves:
+template <int NY> constexpr int colfwd_threads() { return NY * colimg<NY>() * 16 >= 8192 ? 1024 : NY * colimg<NY>() * 16 >= 4096 ? 512 : 256; }
+template <int NY> constexpr int colinv_threads() { return NY * colblk<NY>() >= 4096 ? 512 : 256; }
+template <int NP>
+__device__ __forceinline__ void split8(const float (&x)[8], uint4 (&out)[NP]) {
+  unsigned short h[NP][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = x[e];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const __bf16 q = static_cast<__bf16>(v);           // round to nearest even
+      h[p][e] = __builtin_bit_cast(unsigned short, q);
+      v = v - static_cast<float>(q);                      // exact
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+    out[p] = make_uint4((unsigned)h[p][0] | ((unsigned)h[p][1] << 16), (unsigned)h[p][2] | ((unsigned)h[p][3] << 16), (unsigned)h[p][4] | ((unsigned)h[p][5] << 16),
+                        (unsigned)h[p][6] | ((unsigned)h[p][7] << 16));
+}
+#define CFFT_BY_SIZE(N, CALL)                    \
+  switch (N) {                                   \
+    case 20: CALL(20); break;                    \
+    case 24: CALL(24); break;                    \
+    case 28: CALL(28); break;                    \
+    case 32: CALL(32); break;                    \
+    case 36: CALL(36); break;                    \
+    case 40: CALL(40); break;                    \
+    case 50: CALL(50); break;                    \
+    case 60: CALL(60); break;                    \
+    case 64: CALL(64); break;                    \
+    case 72: CALL(72); break;                    \
+    case 96: CALL(96); break;                    \
+    case 100: CALL(100); break;                  \
+    case 128: CALL(128); break;                  \
+    default: CALL(192); break;                   \
+  }
+
+// ---- launchers (N = transform length, one of the lengths with a Plan); a.CoutP = output channels the inverse passes transform (Cout
+// padded to 64), ldy = channel stride of the product spectra (Cout padded to the GEMM's N tile)
+void cfft_rows_fwd(int NX, const ConvArgs& a, int layout, cf* T, const cf* tw, hipStream_t st);
+void cfft_rows_fwd_merge(int NX, const ConvArgs& a, const FftMerge& m, cf* T, const cf* tw, hipStream_t st);
+hipError_t cfft_cols_fwd(int NY, const ConvArgs& a, int np, const cf* T, void* Xs, const cf* tw, int NXH, int MT, hipStream_t st);
+void cfft_cols_inv(int NY, const ConvArgs& a, const cf* Yf, cf* T, const cf* tw, int NXH, int ldy, int pad, hipStream_t st);
+void cfft_rows_inv(int NX, const ConvArgs& a, int layout, const cf* T, const cf* tw, int pad, float norm, hipStream_t st);
+void cfft_rows_inv_fwd(int NX, const ConvArgs& a, const cf* T, cf* Tn, const cf* tw, int pad, float norm, hipStream_t st);
+}  // namespace cfft
+}  // namespace jcm

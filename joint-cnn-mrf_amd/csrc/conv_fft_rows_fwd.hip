@@ -1,0 +1,103 @@
+// Forward row pass of the frequency-domain convolution (see conv_fft.hip for the whole route).
+#include "conv_fft_common.h"
+#include "resize_tf1.h"
+
+namespace jcm {
+namespace cfft {
+
+// ---- rows, forward: NHWC fp32 / NHWC bf16 / planar bf16 [B][C/8][H*W][8] -> T[kx][c/16][b][y][16] complex, kx < NX/2+1
+// LAYOUT: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar.  Two adjacent channels are one complex number.
+// T is chunk-major: the (8 images x H rows x 16 channels) block a column work group transforms is one contiguous run, and this kernel
+// writes it in whole 128-byte lines (8 lanes x float4 = the 16 channels of one (kx, chunk, image, row)).
+template <int NX, int LAYOUT>
+__global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_kernel(const void* __restrict__ in, cf* __restrict__ T, const cf* __restrict__ twg, int B, int H, int W, int C) {
+  constexpr int CH = CB / 2, NTR = rows_threads<NX>();
+  __shared__ cf buf[NX * CH];
+  __shared__ cf tw[NX];
+  const int tid = threadIdx.x;
+  const int cblk = blockIdx.x % (C / CB), by = blockIdx.x / (C / CB);
+  const int y = by % H, b = by / H;
+  twiddles<NX, NTR>(tw, twg, tid);
+  for (int t = tid; t < NX * CH; t += NTR) {
+    const int x = t / CH, v = t % CH;
+    cf z = {0.f, 0.f};
+    if (x < W) {
+      if constexpr (LAYOUT == 0) {
+        z = reinterpret_cast<const cf*>(static_cast<const float*>(in) + ((size_t)(b * H + y) * W + x) * C + cblk * CB)[v];
+      } else if constexpr (LAYOUT == 1) {
+        z = bf16pair(reinterpret_cast<const unsigned*>(static_cast<const __bf16*>(in) + ((size_t)(b * H + y) * W + x) * C + cblk * CB)[v]);
+      } else {
+        const int c = cblk * CB + 2 * v;
+        z = bf16pair(*reinterpret_cast<const unsigned*>(static_cast<const __bf16*>(in) + (((size_t)b * (C >> 3) + (c >> 3)) * H * W + (size_t)y * W + x) * 8 + (c & 7)));
+      }
+    }
+    buf[t] = z;
+  }
+  __syncthreads();
+  fft<NX, -1, CH, NTR>(buf, tw, tid);
+  rows_fwd_store<NX, NTR>(buf, T, tid, cblk, b, y, B, H, C);
+}
+
+// ---- rows, forward, of the MERGED map (fp32 NHWC): x = ((x1 + up(x2)) + up(x3)) / 3 (main.py:58,67,69-70; the arithmetic and association
+// order of upsample_merge3_kernel) is formed while the row is loaded: the merged tensor never goes to HBM.
+template <int NX>
+__global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_merge_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int H2, int W2,
+                                                            const float* __restrict__ x3, int H3, int W3, cf* __restrict__ T, const cf* __restrict__ twg, int B, int H,
+                                                            int W, int C, float sy2, float sx2, float sy3, float sx3) {
+  constexpr int CH = CB / 2, NTR = rows_threads<NX>();
+  __shared__ cf buf[NX * CH];
+  __shared__ cf tw[NX];
+  const int tid = threadIdx.x;
+  const int cblk = blockIdx.x % (C / CB), by = blockIdx.x / (C / CB);
+  const int y = by % H, b = by / H;
+  twiddles<NX, NTR>(tw, twg, tid);
+  const Tap ty2 = tf1_tap(y, H2, sy2), ty3 = tf1_tap(y, H3, sy3);
+  const int C2 = C / 2;
+  const cf* p1 = reinterpret_cast<const cf*>(x1 + ((size_t)(b * H + y) * W) * C + cblk * CB);
+  const cf* p2 = reinterpret_cast<const cf*>(x2 + (size_t)b * H2 * W2 * C + cblk * CB);
+  const cf* p3 = reinterpret_cast<const cf*>(x3 + (size_t)b * H3 * W3 * C + cblk * CB);
+  auto bil = [&](const cf* p, int Wl, Tap ty, Tap tx, int v) __attribute__((always_inline)) {
+    const cf tl = p[((size_t)ty.lo * Wl + tx.lo) * C2 + v], tr = p[((size_t)ty.lo * Wl + tx.hi) * C2 + v];
+    const cf bl = p[((size_t)ty.hi * Wl + tx.lo) * C2 + v], br = p[((size_t)ty.hi * Wl + tx.hi) * C2 + v];
+    return cf{lerp2(tl.x, tr.x, bl.x, br.x, tx.t, ty.t), lerp2(tl.y, tr.y, bl.y, br.y, tx.t, ty.t)};
+  };
+  for (int t = tid; t < NX * CH; t += NTR) {
+    const int x = t / CH, v = t % CH;
+    cf z = {0.f, 0.f};
+    if (x < W) {
+      const cf a = p1[(size_t)x * C2 + v];
+      const cf u2 = (H2 == H && W2 == W) ? p2[((size_t)y * W + x) * C2 + v] : bil(p2, W2, ty2, tf1_tap(x, W2, sx2), v);
+      const cf u3 = (H3 == H && W3 == W) ? p3[((size_t)y * W + x) * C2 + v] : bil(p3, W3, ty3, tf1_tap(x, W3, sx3), v);
+      z = cf{((a.x + u2.x) + u3.x) / 3.0f, ((a.y + u2.y) + u3.y) / 3.0f};
+    }
+    buf[t] = z;
+  }
+  __syncthreads();
+  fft<NX, -1, CH, NTR>(buf, tw, tid);
+  rows_fwd_store<NX, NTR>(buf, T, tid, cblk, b, y, B, H, C);
+}
+
+
+template <int NX> static void launch_rows_fwd(const ConvArgs& a, int layout, cf* T, const cf* tw, hipStream_t st) {
+  const dim3 grid(a.B * a.H * (a.Cin / CB));
+  if (layout == 0) hipLaunchKernelGGL((rows_fwd_kernel<NX, 0>), grid, dim3(rows_threads<NX>()), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin);
+  else if (layout == 1) hipLaunchKernelGGL((rows_fwd_kernel<NX, 1>), grid, dim3(rows_threads<NX>()), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin);
+  else hipLaunchKernelGGL((rows_fwd_kernel<NX, 2>), grid, dim3(rows_threads<NX>()), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin);
+}
+template <int NX> static void launch_rows_fwd_merge(const ConvArgs& a, const FftMerge& m, cf* T, const cf* tw, hipStream_t st) {
+  hipLaunchKernelGGL(rows_fwd_merge_kernel<NX>, dim3(a.B * a.H * (a.Cin / CB)), dim3(rows_threads<NX>()), 0, st, static_cast<const float*>(a.x), m.x2, m.H2, m.W2, m.x3, m.H3, m.W3, T, tw,
+                     a.B, a.H, a.W, a.Cin, (float)m.H2 / (float)a.H, (float)m.W2 / (float)a.W, (float)m.H3 / (float)a.H, (float)m.W3 / (float)a.W);
+}
+void cfft_rows_fwd(int NX, const ConvArgs& a, int layout, cf* T, const cf* tw, hipStream_t st) {
+#define CALL(N) launch_rows_fwd<N>(a, layout, T, tw, st)
+  CFFT_BY_SIZE(NX, CALL)
+#undef CALL
+}
+void cfft_rows_fwd_merge(int NX, const ConvArgs& a, const FftMerge& m, cf* T, const cf* tw, hipStream_t st) {
+#define CALL(N) launch_rows_fwd_merge<N>(a, m, T, tw, st)
+  CFFT_BY_SIZE(NX, CALL)
+#undef CALL
+}
+
+}  // namespace cfft
+}  // namespace jcm

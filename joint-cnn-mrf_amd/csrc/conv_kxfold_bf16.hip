@@ -363,9 +363,8 @@ hipError_t pack_weights_kxfold(const float* w_hwio, void* wp, int Cin, hipStream
 }
 
 bool conv_kxfold_bf16_supported(const ConvArgs& a, int ks) {
-  static const bool enabled = [] { const char* e = std::getenv("JCM_KXFOLD"); return !(e && e[0] == '0'); }();   // JCM_KXFOLD=0: A/B against conv_thin_bf16
   Geom gm;
-  return enabled && ks == KS && make_geom(a, gm);
+  return ks == KS && make_geom(a, gm);
 }
 
 hipError_t conv_kxfold_bf16(const ConvArgs& a, hipStream_t st) {

@@ -500,9 +500,8 @@ bool make_geom(const ConvArgs& a, Geom& gm) {
 }  // namespace
 
 bool conv_strip_bf16_supported(const ConvArgs& a, int ks) {
-  static const bool enabled = [] { const char* e = std::getenv("JCM_STRIP"); return !(e && e[0] == '0'); }();   // JCM_STRIP=0: A/B against the patch kernel
   Geom gm;
-  return enabled && ks == KS && make_geom(a, gm);
+  return ks == KS && make_geom(a, gm);
 }
 
 hipError_t conv_strip_bf16(const ConvArgs& a, hipStream_t st) {
@@ -527,10 +526,9 @@ hipError_t conv_strip_bf16(const ConvArgs& a, hipStream_t st) {
     if (ncu < 8) ncu = 8;
     ncu_cache[dev & 63].store(ncu);
   }
-  static const int tail_split = [] { const char* e = std::getenv("JCM_STRIP_TAIL"); return e ? std::atoi(e) : 1; }();   // 0: A/B without quarter tiles
   gm.nfull = units / ncu * ncu;
   gm.nrem = units - gm.nfull;
-  if (!tail_split || 4 * gm.nrem > ncu) { gm.nfull = units; gm.nrem = 0; }
+  if (4 * gm.nrem > ncu) { gm.nfull = units; gm.nrem = 0; }
   const int blocks = units < ncu && gm.nrem == 0 ? units : ncu;
   static LdsAttr attr;
   if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(conv_strip_bf16_kernel), LDS_BYTES); e != hipSuccess) return e;

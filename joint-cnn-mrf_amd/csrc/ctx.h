@@ -98,10 +98,6 @@ struct jcm_ctx {
   const float** bias_ptrs = nullptr;
   int* cond0 = nullptr;         // single zero (jcm_conv_mrf)
   int sm_algo = 3;              // 0 = FFT (2-D rocFFT), 1 = direct sliding-window VALU kernel, 2 = rocFFT with split row-pruned inverse, 3 = fused LDS FFTs (sm_fused.hip)
-  int branch_streams = 0;       // EXPERIMENTAL, off: the three resolution branches of the part detector on three HIP streams (fork / join by events)
-  hipStream_t side[2] = {nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
-  bool no_reuse = false;        // while branches run concurrently, arena scratch is not handed out twice
   // transient, set by jcm_pd_forward around two consecutive frequency-domain layers: the first writes the second's row-transformed input
   void* fft_t_next = nullptr;
   const void* fft_t_in = nullptr;

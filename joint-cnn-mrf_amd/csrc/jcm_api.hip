@@ -161,8 +161,7 @@ void prof_release_all(jcm_ctx* c, bool destroy) {
 // fp32 handles: does this stride-1 layer run in the frequency domain (conv_fft.hip)?  Not while a training state exists (the filter
 // spectra would have to follow every update).
 bool takes_fft(jcm_ctx* c, const ConvLayer* L, int B, int H, int W) {
-  static const bool env_on = [] { const char* e = std::getenv("JCM_CONV_FFT"); return !(e && e[0] == '0'); }();   // A/B switch
-  if (!env_on || !c->conv9_fft || c->f32_conv != 0 || c->train || (L->ks != 9 && L->ks != 5) || L->cin == 3 || !L->w_raw) return false;
+  if (!c->conv9_fft || c->f32_conv != 0 || c->train || (L->ks != 9 && L->ks != 5) || L->cin == 3 || !L->w_raw) return false;
   // bf16 handles: the wide 9x9 layers only (the 5x5 layers and the logits layer are faster on their bf16 MFMA strip kernels)
   if (c->precision == JCM_PRECISION_BF16 && (L->ks != 9 || L->thin_bf16 || L->cout % 8)) return false;
   ConvArgs a{};
@@ -176,7 +175,7 @@ static int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope
   const size_t mark = c->arena_off;
   const int np = c->precision == JCM_PRECISION_BF16 ? 2 : 3;      // bf16 parts per operand of the channel GEMM (cgemm_split.hip)
   void* work = arena_alloc<char>(c, conv_fft_workspace_bytes(a, L->ks, np));
-  if (!c->no_reuse) c->arena_off = mark;                 // scratch of this layer only: later layers run behind it on the stream
+  c->arena_off = mark;                                   // scratch of this layer only: later layers run behind it on the stream
   if (c->dry) { c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; return JCM_OK; }
   // Filter spectra are cached per (layer, map size).  The cache is bounded (JCM_FFT_CACHE_GB, default 64): a caller that walks many
   // image sizes (7.7 GB per size for conv5) makes it drop every spectrum that is not this layer's before it grows past the bound.
@@ -441,33 +440,8 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
   // when conv5 takes the strip kernel; every producer / consumer on that chain handles the layout.
   const ConvLayer* L6 = conv_of(c, "conv6");
   const int planar = bf && L6->thin_bf16 && L4->cout % 8 == 0 && L5->cout % 8 == 0 && takes_strip(L5, B, h4[0], w4[0]) ? 1 : 0;
-  // EXPERIMENTAL (option "branch_streams" / JCM_STREAMS=1, off by default): the three branches are independent until the merge, so the
-  // half- and quarter-resolution ones (1/4 and 1/16 of the work, small grids) can run on two side streams beside the full-resolution
-  // branch; while they overlap nothing of the arena is handed out twice.  Measured +3 % on the fp32 config and nothing on the bf16
-  // config -- and one full-size golden run in a dozen came back wrong (an ordering the events do not cover, not found), so it stays
-  // off; fp16x3 handles never fork (their per-launch operand scale is one shared device scalar).
-  static const bool env_streams = [] { const char* e = std::getenv("JCM_STREAMS"); return e && e[0] == '1'; }();
-  const bool fork = (env_streams || c->branch_streams) && !c->train && c->f32_conv != 2;
-  hipStream_t main_stream = c->stream;
-  if (fork && !c->dry) {
-    if (!c->side[0]) {
-      for (int i = 0; i < 2; ++i) {
-        HIP_TRY(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
-      }
-      HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    }
-    HIP_TRY(hipEventRecord(c->ev_fork, main_stream));      // the input (and whatever the caller queued before) is ready
-    for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
-  }
-  c->no_reuse = fork;
-  struct Restore {        // whatever path leaves this function: one stream again
-    jcm_ctx* c; hipStream_t s;
-    ~Restore() { c->stream = s; c->no_reuse = false; }
-  } restore{c, main_stream};
   for (int r = 0; r < 3; ++r) {
     const size_t mark = c->arena_off;
-    if (fork && !c->dry) c->stream = r == 0 ? main_stream : c->side[r - 1];
     const std::string res = kRes[r];
     const int sub = 1 << r;
     const int hin = H / sub, win = W / sub;
@@ -521,13 +495,8 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
     JCM_TRY(run_conv(c, "conv3_" + res, 1, p2, B, h3, w3, 1, c3, bf, false, pl23, in4));   // :48,56,65
     c->fft_t_in = t34;
     JCM_TRY(run_conv(c, "conv4_" + res, 1, c3, B, h3, w3, 1, x4[r], bf, false, in4, planar));   // :49,57,66
-    if (!fork) c->arena_off = mark;
-    if (fork && !c->dry && r > 0) HIP_TRY(hipEventRecord(c->ev_join[r - 1], c->stream));
+    c->arena_off = mark;
   }
-  c->stream = main_stream;
-  c->no_reuse = false;
-  if (fork && !c->dry)
-    for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamWaitEvent(main_stream, c->ev_join[i], 0));
   const int hh = h4[0], ww = w4[0];
   // fp32 handle with conv5 in the frequency domain: its forward row kernel forms ((x1 + up(x2)) + up(x3)) / 3 while it loads the rows
   const bool fuse_merge = !bf && takes_fft(c, L5, B, hh, ww);
@@ -649,11 +618,6 @@ int jcm_destroy(jcm_handle h) {
   for (auto& kv : h->params) (void)hipFree(kv.second.d);
   for (void* p : h->owned) (void)hipFree(p);
   for (auto& kv : h->fft_w) (void)hipFree(kv.second.p);
-  for (int i = 0; i < 2; ++i) {
-    if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
-    if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
-  }
-  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->arena) (void)hipFree(h->arena);
   delete h;
   return JCM_OK;
@@ -674,10 +638,6 @@ int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
   if (k == "micro_batch") {   // allowed at any time
     if (value < 0) return fail(JCM_ERR_ARG, "micro_batch must be >= 0 (0 = default: 256 bf16 / 64 fp32)");
     h->micro_batch = (int)value;
-    return JCM_OK;
-  }
-  if (k == "branch_streams") {  // allowed at any time
-    h->branch_streams = value != 0;
     return JCM_OK;
   }
   if (k == "conv9_fft") {  // allowed at any time

@@ -1,0 +1,11 @@
+#!/bin/bash
+# rocprofv3 kernel stats of a bench config: bash tools/prof_stats.sh NAME <bench args>
+set -u
+NAME=$1; shift
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out
+mkdir -p $OUT
+rocprofv3 --kernel-trace --stats -d $OUT/prof_${NAME}_stats -o s -- python bench.py --steps 2 --warmup 1 --cpu-images 0 $* > $OUT/${NAME}_stats.log 2>&1
+python profiles/summarize.py stats $(find $OUT/prof_${NAME}_stats -name "*.db" | head -1) > $OUT/${NAME}_kernel_stats.csv
+rm -rf $OUT/prof_${NAME}_stats
+head -30 $OUT/${NAME}_kernel_stats.csv | cut -c1-150
