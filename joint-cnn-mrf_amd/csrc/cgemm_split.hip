@@ -18,6 +18,11 @@
 //     (an MFMA operand lane holds 8 consecutive k of one row / column = one 16-byte unit; units of consecutive rows are consecutive, so
 //     every ds_read_b128 of a fragment is bank-conflict free.)  With two parts the split spectra are exactly as large as fp32 complex
 //     ones: no extra HBM traffic on bf16 handles.
+//   * fp32 handles: three bf16 parts are 1.5x the bytes of the fp32 number, and at 64 images per launch the filter spectra ARE the traffic
+//     (2 MB per frequency against 0.4 MB of activations), so there the filter spectra stay fp32 in HBM
+//         Wf[f][n-tile][k16][re|im][k-half][4-channel half][cols][4 fp32]
+//     and are split on the way: 16-byte global loads into registers one stage ahead (issued behind the MFMAs of the previous stage),
+//     v_cvt / v_sub, ds_write_b128 into the same LDS image.  The 9-channel logits layer gets a 32-column tile instead of 128.
 //   * a stage = one k16 step of all parts; R-deep ring, counted vmcnt + raw s_barrier (the DMA of stage g+R-1 is issued right after
 //     the barrier that opens stage g, so R-1 stages are in flight while one computes); the fragments of a product are read while the
 //     MFMAs of the previous one run.
@@ -38,22 +43,27 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace cg {
 
-// NP parts per operand; WM x WN waves, FM x FN 32x32 fragments per wave; R stages in LDS
-template <int NP_, int WM_, int WN_, int FM_, int FN_, int R_>
+// NP parts per operand; WM x WN waves, FM x FN 32x32 fragments per wave; R stages in LDS; WF32: the W operand arrives as fp32 and is split here
+template <int NP_, int WM_, int WN_, int FM_, int FN_, int R_, bool WF32_ = false>
 struct Cfg {
   static constexpr int NP = NP_, WM = WM_, WN = WN_, FM = FM_, FN = FN_, R = R_;
+  static constexpr bool WF32 = WF32_;
   static constexpr int NW = WM * WN, NT = 64 * NW;
   static constexpr int MT = 32 * WM * FM, NTL = 32 * WN * FN;
   static constexpr int XST = 4 * NP * MT, WST = 4 * NP * NTL;      // 16-byte units per stage: [re|im][part][k-half][rows]
   static constexpr int STAGE = XST + WST;
-  static constexpr int XPW = XST / 64 / NW, WPW = WST / 64 / NW;    // 1-KB DMA pieces per wave per stage
+  static constexpr int XPW = XST / 64 / NW, WPW = WF32 ? 0 : WST / 64 / NW;    // 1-KB DMA pieces per wave per stage
   static constexpr int PW = XPW + WPW;
+  static constexpr int UPT = 4 * NTL / NT;                          // WF32: (re|im, k-half, column) source units of 8 fp32 per thread per stage
+  static constexpr int WL = WF32 ? 2 * UPT : 0;                     // ... = 16-byte global loads per thread per stage
+  static constexpr int WSRC = 4 * NTL * 32;                         // WF32: bytes of a stage of fp32 filter spectra
   static constexpr int LDS_BYTES = R * STAGE * 16;
   static constexpr int NPROD = NP == 3 ? 6 : NP == 2 ? 3 : 1;
-  static_assert(NTL == kCgemmNT, "the filter spectra are laid out for 128-column tiles");
-  static_assert(XST % (64 * NW) == 0 && WST % (64 * NW) == 0, "whole DMA pieces per wave");
+  static_assert(NTL == 128 || NTL == 32, "column tiles the filter spectra are laid out for");
+  static_assert(XST % (64 * NW) == 0 && (WF32 || WST % (64 * NW) == 0), "whole DMA pieces per wave");
+  static_assert(!WF32 || (R == 2 && (UPT == 1 || UPT == 2) && 4 * NTL % NT == 0), "in-kernel split: double buffer, one or two units per thread");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-  static_assert((R - 1) * PW < 64, "vmcnt is a 6-bit counter");
+  static_assert((R - 1) * PW + WL < 64, "vmcnt is a 6-bit counter");
 };
 
 // (x part, w part) of product s.  Any order gives the same sum up to fp32 rounding of the accumulator, which carries the whole K sum.
@@ -87,11 +97,30 @@ __device__ __forceinline__ void frag_load(f32x4 (&xr)[C::FM], f32x4 (&xi)[C::FM]
 
 struct Args {
   const char* xs;       // split activation spectra
-  const char* ws;       // split filter spectra
-  float2* y;            // [F][B][CoutP]
-  int F, B, CoutP, KC;  // KC = Cin / 16
+  const char* ws;       // filter spectra: split (bf16 parts) or fp32 (Cfg::WF32)
+  float2* y;            // [F][B][ldy]
+  int F, B, ldy, KC;    // ldy: complex numbers per row of y; KC = Cin / 16
   int mtiles, ntiles;
 };
+
+// 8 fp32 -> NP 16-byte units of bf16 parts (x = x0 + x1 (+ x2), each part rounded to nearest even; exact for NP = 3)
+template <int NP>
+__device__ __forceinline__ void split_unit(const u32x4& lo, const u32x4& hi, u32x4 (&out)[NP]) {
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(lo[e]); v[4 + e] = __uint_as_float(hi[e]); }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    unsigned short q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const __bf16 r = static_cast<__bf16>(v[e]);
+      q[e] = __builtin_bit_cast(unsigned short, r);
+      v[e] = v[e] - static_cast<float>(r);
+    }
+    out[p] = u32x4{(unsigned)q[0] | ((unsigned)q[1] << 16), (unsigned)q[2] | ((unsigned)q[3] << 16), (unsigned)q[4] | ((unsigned)q[5] << 16), (unsigned)q[6] | ((unsigned)q[7] << 16)};
+  }
+}
 
 template <class C>
 __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
@@ -99,6 +128,8 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NP = C::NP, FM = C::FM, FN = C::FN, MT = C::MT, NTL = C::NTL, R = C::R, NW = C::NW;
   constexpr int XST = C::XST, WST = C::WST, STAGE = C::STAGE;
+  constexpr bool WF32 = C::WF32;
+  constexpr int UPT = C::UPT, WL = C::WL;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / C::WN, wn = wid % C::WN;
@@ -113,10 +144,11 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
   const int KC = a.KC;
 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  constexpr int WBYTES = WF32 ? C::WSRC : WST * 16;      // bytes of one stage of the W stream in HBM
   const char* xg = a.xs + ((size_t)(f * a.mtiles + mt) * KC) * (size_t)(XST * 16);
-  const char* wg = a.ws + ((size_t)(f * a.ntiles + nt) * KC) * (size_t)(WST * 16);
+  const char* wg = a.ws + ((size_t)(f * a.ntiles + nt) * KC) * (size_t)WBYTES;
   const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xg), 0, KC * XST * 16, 0x00020000);
-  const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wg), 0, KC * WST * 16, 0x00020000);
+  const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wg), 0, KC * WBYTES, 0x00020000);
   const unsigned lane16 = (unsigned)lane * 16u;
 
   // stage g -> ring slot: the LDS image of a stage is its HBM image, X pieces first; wave w moves pieces w, w + NW, ...
@@ -135,6 +167,55 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
     }
   };
 
+  // ---- WF32: fp32 filter spectra through registers.  A source unit = the 8 input channels (one k-half) of one (re|im, column): two
+  // 16-byte loads (the stream is [re|im][k-half][4-channel half][column][4 fp32], so each load instruction of a wave is 1 KB contiguous).
+  // UPT = 2: thread (column, k-half) owns the re and the im unit; UPT = 1 (32-column tile): thread (column, re|im, k-half).
+  // The loads are inline asm: the compiler would otherwise drain the LDS-DMA queue (vmcnt(0)) in front of their first use.
+  const int wcol = tid % NTL, wsel = tid / NTL;
+  u32x4 wreg[UPT > 0 ? UPT : 1][2];
+  u32x4 wdesc;      // the W buffer descriptor as four dwords for the asm loads
+  if constexpr (WF32) {      // raw buffer, stride 0: base, base high bits, bytes, flags (the same descriptor make_buffer_rsrc builds)
+    const unsigned long long wa = (unsigned long long)(size_t)wg;
+    wdesc = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wa), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wa >> 32)) & 0xffffu,
+                  (unsigned)(KC * WBYTES), 0x00020000u};
+  }
+  auto unit_of = [&](int u, int& c, int& kg) __attribute__((always_inline)) {
+    if constexpr (UPT == 2) { c = u; kg = wsel; } else { c = wsel >> 1; kg = wsel & 1; }
+  };
+  auto load_w = [&](int g) __attribute__((always_inline)) {
+    if constexpr (WF32) {
+      const unsigned soff = (unsigned)g * (unsigned)C::WSRC;
+#pragma unroll
+      for (int u = 0; u < UPT; ++u) {
+        int c, kg;
+        unit_of(u, c, kg);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const unsigned voff = (unsigned)((((c * 2 + kg) * 2 + hh) * NTL + wcol) * 16);
+          asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(wreg[u][hh]) : "v"(voff), "s"(wdesc), "s"(soff) : "memory");
+        }
+      }
+    }
+  };
+  auto split_w = [&](int slot, int u) __attribute__((always_inline)) {      // unit u of the registers -> NP units of the LDS image
+    if constexpr (WF32) {
+      int c, kg;
+      unit_of(u, c, kg);
+      u32x4 parts[NP];
+      split_unit<NP>(wreg[u][0], wreg[u][1], parts);
+      u32x4* dst = reinterpret_cast<u32x4*>(smem + (size_t)slot * STAGE * 16 + XST * 16) + ((c * NP) * 2 + kg) * NTL + wcol;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) dst[p * 2 * NTL] = parts[p];
+    }
+  };
+  auto wait_w = [&](auto keep) __attribute__((always_inline)) {      // the W loads have landed (`keep` younger VMEM operations may stay in flight)
+    if constexpr (WF32) {
+      if constexpr (UPT == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(wreg[0][0]), "+v"(wreg[0][1]), "+v"(wreg[1][0]), "+v"(wreg[1][1]) : "i"(decltype(keep)::value) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wreg[0][0]), "+v"(wreg[0][1]) : "i"(decltype(keep)::value) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
   f32x16 accr[FM][FN], acci[FM][FN];
 #pragma unroll
   for (int fm = 0; fm < FM; ++fm)
@@ -143,8 +224,18 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) { accr[fm][fn][i] = 0.f; acci[fm][fn][i] = 0.f; }
 
+  if constexpr (WF32) {
+    // stage 0: X by DMA, W through the registers; then the loads of stage 1 go out
+    load_w(0);
+    issue(0, 0);
+    wait_w(std::integral_constant<int, C::XPW>{});
 #pragma unroll
-  for (int s = 0; s < R - 1; ++s) issue(s, s);
+    for (int u = 0; u < UPT; ++u) split_w(0, u);
+    load_w(1);
+  } else {
+#pragma unroll
+    for (int s = 0; s < R - 1; ++s) issue(s, s);
+  }
 
   // per-lane fragment addresses inside slot 0: unit (k-half h, row) of plane (re, part 0)
   unsigned xaddr = lds0 + (unsigned)(h * MT + wm * FM * 32 + l31) * 16u;
@@ -152,15 +243,15 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
 
   int slot = 0;
   for (int g = 0; g < KC; ++g) {
-    // this wave's pieces of stage g have landed (R-2 younger stages may stay in flight); after the barrier everybody's have, and
-    // every wave is done reading slot (g-1) % R, which the DMA of stage g+R-1 now refills
-    asm volatile("s_waitcnt vmcnt(%0)" ::"i"((R - 2) * C::PW) : "memory");
+    // this wave's DMA pieces of stage g have landed (R-2 younger stages -- WF32: the register loads of stage g+1 -- may stay in flight);
+    // after the barrier everybody's have (WF32: and everybody's split units of stage g are written), and every wave is done reading
+    // slot (g-1) % R, which the DMA of stage g+R-1 (WF32: and the split of stage g+1) now refills
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"((R - 2) * C::PW + WL) : "memory");
+    if constexpr (WF32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    {
-      const int ns = slot == 0 ? R - 1 : slot - 1;
-      issue(g + R - 1, ns);
-    }
+    const int ns = slot == 0 ? R - 1 : slot - 1;
+    issue(g + R - 1, ns);
     f32x4 xr[2][FM], xi[2][FM], wr[2][FN], wi[2][FN];
     frag_load<C, prod_x<NP>(0), prod_w<NP>(0)>(xr[0], xi[0], wr[0], wi[0], xaddr, waddr);
     auto product = [&](auto sc) __attribute__((always_inline)) {
@@ -203,7 +294,18 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
     };
     product(std::integral_constant<int, 0>{});
     if constexpr (C::NPROD > 1) product(std::integral_constant<int, 1>{});
+    if constexpr (WF32) {
+      // the filter spectra of stage g+1 (requested a stage ago; the DMA pieces just issued stay in flight) -> bf16 parts -> the other slot,
+      // one unit behind each of the next products; then the loads of stage g+2 go out
+      wait_w(std::integral_constant<int, C::XPW>{});
+      split_w(ns, 0);
+    }
     if constexpr (C::NPROD > 2) product(std::integral_constant<int, 2>{});
+    if constexpr (WF32) {
+      if constexpr (UPT == 2) split_w(ns, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      load_w(g + 2);
+    }
     if constexpr (C::NPROD > 3) product(std::integral_constant<int, 3>{});
     if constexpr (C::NPROD > 4) product(std::integral_constant<int, 4>{});
     if constexpr (C::NPROD > 5) product(std::integral_constant<int, 5>{});
@@ -214,12 +316,12 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
     waddr += d;
     slot = wrap ? 0 : slot + 1;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the look-ahead DMAs of the last stages (zeros into free slots)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the look-ahead loads of the last stages (zeros)
 
   // ---- Y[f][b][co]: accumulator register i of a fragment is row (i&3) + 8 (i>>2) + 4 h, column l31: a half wave stores 32 complex
   // numbers = 256 contiguous bytes per instruction
   const int n0 = nt * NTL + wn * FN * 32 + l31;
-  float2* yf = a.y + (size_t)f * a.B * a.CoutP;
+  float2* yf = a.y + (size_t)f * a.B * a.ldy;
 #pragma unroll
   for (int fm = 0; fm < FM; ++fm) {
     const int r0 = mt * MT + (wm * FM + fm) * 32 + 4 * h;
@@ -228,18 +330,19 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
       const int row = r0 + (i & 3) + 8 * (i >> 2);
       if (row < a.B) {
 #pragma unroll
-        for (int fn = 0; fn < FN; ++fn) yf[(size_t)row * a.CoutP + n0 + fn * 32] = make_float2(accr[fm][fn][i], acci[fm][fn][i]);
+        for (int fn = 0; fn < FN; ++fn) yf[(size_t)row * a.ldy + n0 + fn * 32] = make_float2(accr[fm][fn][i], acci[fm][fn][i]);
       }
     }
   }
 }
 
-// tile shapes.  NT = 128 columns everywhere (the layout of the filter spectra); what varies is the M tile and the ring depth.
-using CfgB256 = Cfg<2, 4, 2, 2, 2, 3>;      // bf16 handles, 129 .. 256 images: the whole micro-batch in one 256 x 128 tile, W read once
-using CfgB128 = Cfg<2, 2, 2, 2, 2, 2>;      // bf16 handles, 65 .. 128 images (two work groups per CU)
-using CfgB64 = Cfg<2, 1, 4, 2, 1, 2>;       // bf16 handles, <= 64 images
-using CfgF64 = Cfg<3, 1, 4, 2, 1, 2>;       // fp32 handles, <= 64 images per tile
-using CfgF128 = Cfg<3, 2, 2, 2, 2, 2>;      // fp32 handles, > 64 images: 128-row tiles
+// tile shapes.  128 columns (32 for the thin logits layer); what varies is the M tile, the ring depth and where the W operand is split.
+using CfgB256 = Cfg<2, 4, 2, 2, 2, 3>;            // bf16 handles, 129 .. 256 images: the whole micro-batch in one 256 x 128 tile, W read once
+using CfgB128 = Cfg<2, 2, 2, 2, 2, 2>;            // bf16 handles, 65 .. 128 images (two work groups per CU)
+using CfgB64 = Cfg<2, 1, 4, 2, 1, 2>;             // bf16 handles, <= 64 images
+using CfgF64 = Cfg<3, 1, 4, 2, 1, 2, true>;       // fp32 handles, <= 64 images per tile; fp32 filter spectra split in the kernel
+using CfgF128 = Cfg<3, 2, 2, 2, 2, 2, true>;      // fp32 handles, > 64 images: 128-row tiles
+using CfgF64T = Cfg<3, 2, 1, 1, 1, 2, true>;      // fp32 handles, Cout <= 32 (the logits layer): 64 x 32 tile, two waves
 
 template <class C> hipError_t launch(const Args& a, hipStream_t st) {
   static LdsAttr attr;
@@ -252,17 +355,28 @@ template <class C> hipError_t launch(const Args& a, hipStream_t st) {
 
 }  // namespace cg
 
-int cgemm_split_mtile(int np, int B) {
+int cgemm_split_ntile(int np, int Cout) { return np == 3 && Cout <= 32 ? 32 : 128; }
+int cgemm_split_mtile(int np, int B, int Cout) {
+  if (cgemm_split_ntile(np, Cout) == 32) return 64;
   if (np == 2) return B > 128 ? 256 : B > 64 ? 128 : 64;
   return B > 64 ? 128 : 64;
 }
+bool cgemm_split_w_fp32(int np) { return np == 3; }
+size_t cgemm_split_w_bytes(int np, int F, int Cin, int Cout) {
+  const int ntl = cgemm_split_ntile(np, Cout);
+  const size_t coutp = (size_t)(Cout + ntl - 1) / ntl * ntl;
+  return (size_t)F * Cin * coutp * (cgemm_split_w_fp32(np) ? 8 : 4 * np);
+}
 
-hipError_t cgemm_split(const void* xs, const void* ws, void* y, int np, int F, int B, int Cin, int CoutP, hipStream_t st) {
-  if ((np != 2 && np != 3) || Cin % 16 || CoutP % kCgemmNT || F < 1 || B < 1) return hipErrorInvalidValue;
-  const int MT = cgemm_split_mtile(np, B);
-  cg::Args a{static_cast<const char*>(xs), static_cast<const char*>(ws), static_cast<float2*>(y), F, B, CoutP, Cin / 16, (B + MT - 1) / MT, CoutP / kCgemmNT};
-  if ((long long)a.KC * 4 * np * (MT > kCgemmNT ? MT : kCgemmNT) * 16 >= (1ll << 31)) return hipErrorInvalidValue;      // buffer descriptor range
+hipError_t cgemm_split(const void* xs, const void* ws, void* y, int np, int F, int B, int Cin, int Cout, int ldy, hipStream_t st) {
+  const int ntl = cgemm_split_ntile(np, Cout);
+  const int ntiles = (Cout + ntl - 1) / ntl;
+  if ((np != 2 && np != 3) || Cin % 16 || ldy < ntiles * ntl || F < 1 || B < 1) return hipErrorInvalidValue;
+  const int MT = cgemm_split_mtile(np, B, Cout);
+  cg::Args a{static_cast<const char*>(xs), static_cast<const char*>(ws), static_cast<float2*>(y), F, B, ldy, Cin / 16, (B + MT - 1) / MT, ntiles};
+  if ((long long)a.KC * 4 * np * (MT > ntl ? MT : ntl) * 16 >= (1ll << 31)) return hipErrorInvalidValue;      // buffer descriptor range
   if (np == 2) return MT == 256 ? cg::launch<cg::CfgB256>(a, st) : MT == 128 ? cg::launch<cg::CfgB128>(a, st) : cg::launch<cg::CfgB64>(a, st);
+  if (ntl == 32) return cg::launch<cg::CfgF64T>(a, st);
   return MT == 128 ? cg::launch<cg::CfgF128>(a, st) : cg::launch<cg::CfgF64>(a, st);
 }
 

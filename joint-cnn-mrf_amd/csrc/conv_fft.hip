@@ -38,8 +38,10 @@ namespace cfft {
 // image Ws[f][co/128][ci/16][re|im][part][k-half][128 columns][8 bf16] (cgemm_split.hip).  A work group owns 8 input channels (one
 // k-half) x 32 output channels: thread (ci, co) evaluates the separable 81- (25-) term DFT of its filter for one frequency after the
 // other, the 8 x 32 spectra meet in LDS, and 64 threads split them and store 16-byte units (32 columns = 512 contiguous bytes).
+// NP = 0: fp32 handles -- the spectra stay fp32 (the GEMM splits them on the way, cgemm_split.hip): Wf[f][co/ntl][ci/16][re|im][k-half][4-channel
+// half][ntl columns][4 fp32].
 template <int KS, int NP>
-__global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* __restrict__ w, uint4* __restrict__ Ws, int Cin, int Cout, int CoutP, int NY, int NX,
+__global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* __restrict__ w, uint4* __restrict__ Ws, int Cin, int Cout, int CoutP, int ntl, int NY, int NX,
                                                                    int round_bf16) {
   __shared__ cf twy[256], twx[256];
   __shared__ cf sp[32][9];
@@ -65,11 +67,11 @@ __global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* 
       if (round_bf16) wv = static_cast<float>(static_cast<__bf16>(wv));       // bf16 handles: the filter the bf16 MFMA kernels multiply with
       g[a][b] = wv;
     }
-  const int NXH = NX / 2 + 1, KC = Cin / 16, ntiles = CoutP / kCgemmNT;
+  const int NXH = NX / 2 + 1, KC = Cin / 16, ntiles = CoutP / ntl;
   const int kc = ci8 >> 1, kg = ci8 & 1;
   // the 64 storing threads: (column, re|im)
   const int scol = tid & 31, sc = (tid >> 5) & 1;
-  const int sco = co32 * 32 + scol, snt = sco / kCgemmNT, sn = sco % kCgemmNT;
+  const int sco = co32 * 32 + scol, snt = sco / ntl, sn = sco % ntl;
   for (int kx = blockIdx.y; kx < NXH; kx += gridDim.y) {
     cf ra[KS];
 #pragma unroll
@@ -89,12 +91,18 @@ __global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* 
         float x[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = sc ? sp[scol][e].y : sp[scol][e].x;
-        uint4 u[NP];
-        split8<NP>(x, u);
         const size_t f = (size_t)kx * NY + ky;
-        uint4* dst = Ws + (((f * ntiles + snt) * KC + kc) * (4 * NP) + (sc * NP) * 2 + kg) * kCgemmNT + sn;
+        if constexpr (NP == 0) {
+          uint4* dst = Ws + ((((f * ntiles + snt) * KC + kc) * 2 + sc) * 2 + kg) * 2 * ntl + sn;
+          dst[0] = make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
+          dst[ntl] = make_uint4(__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7]));
+        } else {
+          uint4 u[NP > 0 ? NP : 1];
+          split8<(NP > 0 ? NP : 1)>(x, u);
+          uint4* dst = Ws + (((f * ntiles + snt) * KC + kc) * (4 * NP) + (sc * NP) * 2 + kg) * ntl + sn;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) dst[(size_t)p * 2 * kCgemmNT] = u[p];
+          for (int p = 0; p < NP; ++p) dst[(size_t)p * 2 * ntl] = u[p];
+        }
       }
       __syncthreads();
     }
@@ -123,7 +131,29 @@ static bool sizes_of(int H, int W, int ks, Sizes* s) {
   return (ks == 9 || ks == 5) && H + ks - 1 <= 192 && W + ks - 1 <= 192 && pick(H + 4, &s->NY) && pick(W + 4, &s->NX);
 }
 static int pad64(int c) { return (c + CB - 1) / CB * CB; }
-static int pad128(int c) { return (c + kCgemmNT - 1) / kCgemmNT * kCgemmNT; }
+static int padn(int c, int n) { return (c + n - 1) / n * n; }
+
+int persistent_grid(const void* kernel, int ntiles, int threads) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, int> cache;      // (kernel, device) -> resident work groups
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int resident = 0;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find({kernel, dev});
+    if (it != cache.end()) resident = it->second;
+  }
+  if (!resident) {
+    int ncu = 256, per_cu = 0;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    resident = ncu * per_cu;
+    std::lock_guard<std::mutex> lk(mu);
+    cache[{kernel, dev}] = resident;
+  }
+  return resident < ntiles ? resident : ntiles;
+}
 
 // e^{+2 pi i k / n} for every supported length, one table per device (built on the host in double precision, uploaded at first use)
 static const cf* twiddle_table(int dev) {
@@ -158,19 +188,22 @@ bool conv_fft_supported(const ConvArgs& a, int ks) {
 size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout, int np) {
   Sizes s;
   if (!sizes_of(H, W, ks, &s)) return 0;
-  return (size_t)s.NY * (s.NX / 2 + 1) * Cin * pad128(Cout) * 4 * np;      // 2 (re, im) x np parts x 2 bytes per element
+  return cgemm_split_w_bytes(np, s.NY * (s.NX / 2 + 1), Cin, Cout);
 }
 hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, int np, bool round_bf16, hipStream_t st) {
   Sizes s;
   if (!sizes_of(H, W, ks, &s) || Cin % 16 || (np != 2 && np != 3)) return hipErrorInvalidValue;
-  const int CoutP = pad128(Cout);
+  const int ntl = cgemm_split_ntile(np, Cout), CoutP = padn(Cout, ntl);
   const dim3 grid((unsigned)((Cin / 8) * (CoutP / 32)), 8);
   uint4* dst = static_cast<uint4*>(wf);
   const int rb = round_bf16 ? 1 : 0;
-  if (ks == 9 && np == 2) hipLaunchKernelGGL((weight_spectra_split_kernel<9, 2>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, s.NY, s.NX, rb);
-  else if (ks == 9) hipLaunchKernelGGL((weight_spectra_split_kernel<9, 3>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, s.NY, s.NX, rb);
-  else if (np == 2) hipLaunchKernelGGL((weight_spectra_split_kernel<5, 2>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, s.NY, s.NX, rb);
-  else hipLaunchKernelGGL((weight_spectra_split_kernel<5, 3>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, s.NY, s.NX, rb);
+  const bool f32 = cgemm_split_w_fp32(np);      // fp32 handles: unsplit spectra, the GEMM splits them
+  if (ks == 9 && f32) hipLaunchKernelGGL((weight_spectra_split_kernel<9, 0>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, ntl, s.NY, s.NX, rb);
+  else if (ks == 9 && np == 2) hipLaunchKernelGGL((weight_spectra_split_kernel<9, 2>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, ntl, s.NY, s.NX, rb);
+  else if (ks == 9) hipLaunchKernelGGL((weight_spectra_split_kernel<9, 3>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, ntl, s.NY, s.NX, rb);
+  else if (f32) hipLaunchKernelGGL((weight_spectra_split_kernel<5, 0>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, ntl, s.NY, s.NX, rb);
+  else if (np == 2) hipLaunchKernelGGL((weight_spectra_split_kernel<5, 2>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, ntl, s.NY, s.NX, rb);
+  else hipLaunchKernelGGL((weight_spectra_split_kernel<5, 3>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, ntl, s.NY, s.NX, rb);
   return hipGetLastError();
 }
 // scratch: T (the larger of the two row-transformed tensors) + the split activation spectra Xs + the product spectra Yf
@@ -180,8 +213,9 @@ Plan3 plan_of(const ConvArgs& a, const Sizes& s, int np) {
   Plan3 p;
   p.NXH = s.NX / 2 + 1;
   p.F = s.NY * p.NXH;
-  p.ldy = pad128(a.Cout);
-  p.MT = cgemm_split_mtile(np, a.B);
+  p.ldy = padn(a.Cout, cgemm_split_ntile(np, a.Cout));      // complex numbers per row of the product spectra: whole N tiles, and whole
+  if (p.ldy < pad64(a.Cout)) p.ldy = pad64(a.Cout);          // 64-channel blocks of the inverse passes (columns no tile writes are never stored)
+  p.MT = cgemm_split_mtile(np, a.B, a.Cout);
   const size_t cop = pad64(a.Cout), cmax = (size_t)a.Cin > cop ? a.Cin : cop;
   const size_t bp = (size_t)(a.B + p.MT - 1) / p.MT * p.MT;
   p.t_bytes = (size_t)a.B * p.NXH * a.H * cmax * sizeof(cf);
@@ -242,7 +276,7 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
   if (hipError_t ce = cfft_cols_fwd(s.NY, a, np, Tin, Xs, twy, p.NXH, p.MT, st); ce != hipSuccess) return ce;
   if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
   if (g0 && hipEventRecord(g0, st) != hipSuccess) return hipErrorUnknown;
-  if (hipError_t e = cgemm_split(Xs, a.wp, Yf, np, p.F, a.B, a.Cin, p.ldy, st); e != hipSuccess) return e;
+  if (hipError_t e = cgemm_split(Xs, a.wp, Yf, np, p.F, a.B, a.Cin, a.Cout, p.ldy, st); e != hipSuccess) return e;
   if (g1 && hipEventRecord(g1, st) != hipSuccess) return hipErrorUnknown;
   cfft_cols_inv(s.NY, a, Yf, T, twy, p.NXH, p.ldy, opad, st);
   if (t_next) {

@@ -1,4 +1,6 @@
 // Forward row pass of the frequency-domain convolution (see conv_fft.hip for the whole route).
+#include <type_traits>
+
 #include "conv_fft_common.h"
 #include "resize_tf1.h"
 
@@ -9,33 +11,58 @@ namespace cfft {
 // LAYOUT: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar.  Two adjacent channels are one complex number.
 // T is chunk-major: the (8 images x H rows x 16 channels) block a column work group transforms is one contiguous run, and this kernel
 // writes it in whole 128-byte lines (8 lanes x float4 = the 16 channels of one (kx, chunk, image, row)).
+// Persistent work groups with register prefetch: the kernel is latency-bound (a tile is 12-23 KB in, 25 KB out, three barriers), so the
+// loads of a work group's NEXT (image, row, channel block) are issued before the FFT of the current one and land while it computes and stores.
 template <int NX, int LAYOUT>
-__global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_kernel(const void* __restrict__ in, cf* __restrict__ T, const cf* __restrict__ twg, int B, int H, int W, int C) {
-  constexpr int CH = CB / 2, NTR = rows_threads<NX>();
+__global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_kernel(const void* __restrict__ in, cf* __restrict__ T, const cf* __restrict__ twg, int B, int H, int W, int C,
+                                                                      int ntiles) {
+  constexpr int CH = CB / 2, NTR = rows_threads<NX>(), K = (NX * CH + NTR - 1) / NTR;
+  using Raw = std::conditional_t<LAYOUT == 0, cf, unsigned>;      // what a thread keeps per element: an fp32 channel pair, or two bf16 in one register
   __shared__ cf buf[NX * CH];
   __shared__ cf tw[NX];
-  const int tid = threadIdx.x;
-  const int cblk = blockIdx.x % (C / CB), by = blockIdx.x / (C / CB);
-  const int y = by % H, b = by / H;
+  const int tid = threadIdx.x, ncb = C / CB;
   twiddles<NX, NTR>(tw, twg, tid);
-  for (int t = tid; t < NX * CH; t += NTR) {
-    const int x = t / CH, v = t % CH;
-    cf z = {0.f, 0.f};
-    if (x < W) {
-      if constexpr (LAYOUT == 0) {
-        z = reinterpret_cast<const cf*>(static_cast<const float*>(in) + ((size_t)(b * H + y) * W + x) * C + cblk * CB)[v];
-      } else if constexpr (LAYOUT == 1) {
-        z = bf16pair(reinterpret_cast<const unsigned*>(static_cast<const __bf16*>(in) + ((size_t)(b * H + y) * W + x) * C + cblk * CB)[v]);
-      } else {
-        const int c = cblk * CB + 2 * v;
-        z = bf16pair(*reinterpret_cast<const unsigned*>(static_cast<const __bf16*>(in) + (((size_t)b * (C >> 3) + (c >> 3)) * H * W + (size_t)y * W + x) * 8 + (c & 7)));
+  Raw pre[K];
+  auto fetch = [&](int tile) __attribute__((always_inline)) {
+    const int cblk = tile % ncb, by = tile / ncb;
+    const int y = by % H, b = by / H;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int t = tid + i * NTR, x = t / CH, v = t % CH;
+      Raw r{};
+      if (x < W) {      // (x < W implies t < NX * CH)
+        if constexpr (LAYOUT == 0) {
+          r = reinterpret_cast<const cf*>(static_cast<const float*>(in) + ((size_t)(b * H + y) * W + x) * C + cblk * CB)[v];
+        } else if constexpr (LAYOUT == 1) {
+          r = reinterpret_cast<const unsigned*>(static_cast<const __bf16*>(in) + ((size_t)(b * H + y) * W + x) * C + cblk * CB)[v];
+        } else {
+          const int c = cblk * CB + 2 * v;
+          r = *reinterpret_cast<const unsigned*>(static_cast<const __bf16*>(in) + (((size_t)b * (C >> 3) + (c >> 3)) * H * W + (size_t)y * W + x) * 8 + (c & 7));
+        }
+      }
+      pre[i] = r;
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  while (tile < ntiles) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int t = tid + i * NTR;
+      if (t < NX * CH) {
+        if constexpr (LAYOUT == 0) buf[t] = pre[i];
+        else buf[t] = bf16pair(pre[i]);
       }
     }
-    buf[t] = z;
+    const int next = tile + gridDim.x;
+    if (next < ntiles) fetch(next);
+    __syncthreads();
+    fft<NX, -1, CH, NTR>(buf, tw, tid);
+    const int cblk = tile % ncb, by = tile / ncb;
+    rows_fwd_store<NX, NTR>(buf, T, tid, cblk, by / H, by % H, B, H, C);
+    __syncthreads();      // every wave is done reading buf
+    tile = next;
   }
-  __syncthreads();
-  fft<NX, -1, CH, NTR>(buf, tw, tid);
-  rows_fwd_store<NX, NTR>(buf, T, tid, cblk, b, y, B, H, C);
 }
 
 // ---- rows, forward, of the MERGED map (fp32 NHWC): x = ((x1 + up(x2)) + up(x3)) / 3 (main.py:58,67,69-70; the arithmetic and association
@@ -79,10 +106,13 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_merge_kernel(cons
 
 
 template <int NX> static void launch_rows_fwd(const ConvArgs& a, int layout, cf* T, const cf* tw, hipStream_t st) {
-  const dim3 grid(a.B * a.H * (a.Cin / CB));
-  if (layout == 0) hipLaunchKernelGGL((rows_fwd_kernel<NX, 0>), grid, dim3(rows_threads<NX>()), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin);
-  else if (layout == 1) hipLaunchKernelGGL((rows_fwd_kernel<NX, 1>), grid, dim3(rows_threads<NX>()), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin);
-  else hipLaunchKernelGGL((rows_fwd_kernel<NX, 2>), grid, dim3(rows_threads<NX>()), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin);
+  const int ntiles = a.B * a.H * (a.Cin / CB);
+  const void* fn = layout == 0 ? reinterpret_cast<const void*>(rows_fwd_kernel<NX, 0>) : layout == 1 ? reinterpret_cast<const void*>(rows_fwd_kernel<NX, 1>)
+                                                                                                  : reinterpret_cast<const void*>(rows_fwd_kernel<NX, 2>);
+  const dim3 grid(persistent_grid(fn, ntiles, rows_threads<NX>()));
+  if (layout == 0) hipLaunchKernelGGL((rows_fwd_kernel<NX, 0>), grid, dim3(rows_threads<NX>()), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin, ntiles);
+  else if (layout == 1) hipLaunchKernelGGL((rows_fwd_kernel<NX, 1>), grid, dim3(rows_threads<NX>()), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin, ntiles);
+  else hipLaunchKernelGGL((rows_fwd_kernel<NX, 2>), grid, dim3(rows_threads<NX>()), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin, ntiles);
 }
 template <int NX> static void launch_rows_fwd_merge(const ConvArgs& a, const FftMerge& m, cf* T, const cf* tw, hipStream_t st) {
   hipLaunchKernelGGL(rows_fwd_merge_kernel<NX>, dim3(a.B * a.H * (a.Cin / CB)), dim3(rows_threads<NX>()), 0, st, static_cast<const float*>(a.x), m.x2, m.H2, m.W2, m.x3, m.H3, m.W3, T, tw,

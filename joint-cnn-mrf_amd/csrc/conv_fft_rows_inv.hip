@@ -6,52 +6,73 @@ namespace cfft {
 
 // ---- rows, inverse + epilogue: T[b][y][kx][c] (C channels, padded to a multiple of 64) -> out with Cout channels
 // LAYOUT: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar (Cout % 8 == 0)
+// Persistent work groups with register prefetch, as rows_fwd_kernel: the next tile's half spectrum is in flight during the FFT and the stores.
 template <int NX, int LAYOUT>
 __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_kernel(const cf* __restrict__ T, void* __restrict__ out, const cf* __restrict__ twg, const float* __restrict__ bias,
                                                       const float* __restrict__ scale, const float* __restrict__ shift, int relu_bn, int H, int W, int C,
-                                                      int Cout, int pad, float norm) {
-  constexpr int CH = CB / 2, NXH = NX / 2 + 1, NTR = rows_threads<NX>();
+                                                      int Cout, int pad, float norm, int ntiles) {
+  constexpr int CH = CB / 2, NXH = NX / 2 + 1, NTR = rows_threads<NX>(), K = (NXH * CH + NTR - 1) / NTR;
   __shared__ cf buf[NX * CH];
   __shared__ cf tw[NX];
-  const int tid = threadIdx.x;
-  const int cblk = blockIdx.x % (C / CB), by = blockIdx.x / (C / CB);
-  const int y = by % H, b = by / H;
+  const int tid = threadIdx.x, ncb = C / CB;
   twiddles<NX, NTR>(tw, twg, tid);
-  const float4* src = reinterpret_cast<const float4*>(T + ((size_t)(b * H + y) * NXH) * C + cblk * CB);
-  // Z = Y_c + i Y_{c+1} with the Hermitian extension Y[NX - k] = conj Y[k]; DC and Nyquist are real by symmetry
-  for (int t = tid; t < NXH * CH; t += NTR) {
-    const int k = t / CH, v = t % CH;
-    float4 q = src[(size_t)k * (C / 2) + v];            // (Ya.re, Ya.im, Yb.re, Yb.im)
-    const bool edge = k == 0 || k == NX / 2;
-    if (edge) { q.y = 0.f; q.w = 0.f; }
-    buf[k * CH + v] = cf{q.x - q.w, q.y + q.z};
-    if (!edge) buf[(NX - k) * CH + v] = cf{q.x + q.w, q.z - q.y};
-  }
-  __syncthreads();
-  fft<NX, 1, CH, NTR>(buf, tw, tid);
-  // a thread keeps its channel pair for the whole row (NT is a multiple of CH): bias / scale / shift are loaded once
-  const int v = tid % CH, c = cblk * CB + 2 * v;
-  if (c < Cout) {
-    const bool two = c + 1 < Cout, pairs = (Cout & 1) == 0;      // two channels = one aligned store
-    const float b0v = bias[c], b1v = two ? bias[c + 1] : 0.f;
-    float s0 = 1.f, s1 = 1.f, h0 = 0.f, h1 = 0.f;
-    if (relu_bn) { s0 = scale[c]; h0 = shift[c]; if (two) { s1 = scale[c + 1]; h1 = shift[c + 1]; } }
-    for (int x = tid / CH; x < W; x += NTR / CH) {
-      const cf z = buf[pos<NX>(x + pad) * CH + v];
-      float v0 = z.x * norm + b0v, v1 = z.y * norm + b1v;
-      if (relu_bn) { v0 = fmaxf(v0, 0.f) * s0 + h0; v1 = fmaxf(v1, 0.f) * s1 + h1; }
-      if constexpr (LAYOUT == 0) {
-        float* o = static_cast<float*>(out) + ((size_t)(b * H + y) * W + x) * Cout + c;
-        if (pairs) *reinterpret_cast<cf*>(o) = cf{v0, v1};
-        else { o[0] = v0; if (two) o[1] = v1; }
-      } else {
-        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-        __bf16* o = static_cast<__bf16*>(out) + (LAYOUT == 1 ? ((size_t)(b * H + y) * W + x) * Cout + c
-                                                             : (((size_t)b * (Cout >> 3) + (c >> 3)) * H * W + (size_t)y * W + x) * 8 + (c & 7));
-        if (pairs) *reinterpret_cast<bf16x2*>(o) = bf16x2{static_cast<__bf16>(v0), static_cast<__bf16>(v1)};
-        else { o[0] = static_cast<__bf16>(v0); if (two) o[1] = static_cast<__bf16>(v1); }
+  float4 pre[K];
+  auto fetch = [&](int tile) __attribute__((always_inline)) {
+    const int cblk = tile % ncb, by = tile / ncb;      // by = b * H + y
+    const float4* src = reinterpret_cast<const float4*>(T + ((size_t)by * NXH) * C + cblk * CB);
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int t = tid + i * NTR, k = t / CH, v = t % CH;
+      pre[i] = t < NXH * CH ? src[(size_t)k * (C / 2) + v] : make_float4(0.f, 0.f, 0.f, 0.f);      // (Ya.re, Ya.im, Yb.re, Yb.im)
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  while (tile < ntiles) {
+    // Z = Y_c + i Y_{c+1} with the Hermitian extension Y[NX - k] = conj Y[k]; DC and Nyquist are real by symmetry
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int t = tid + i * NTR, k = t / CH, v = t % CH;
+      if (t < NXH * CH) {
+        float4 q = pre[i];
+        const bool edge = k == 0 || k == NX / 2;
+        if (edge) { q.y = 0.f; q.w = 0.f; }
+        buf[k * CH + v] = cf{q.x - q.w, q.y + q.z};
+        if (!edge) buf[(NX - k) * CH + v] = cf{q.x + q.w, q.z - q.y};
       }
     }
+    const int next = tile + gridDim.x;
+    if (next < ntiles) fetch(next);
+    __syncthreads();
+    fft<NX, 1, CH, NTR>(buf, tw, tid);
+    const int cblk = tile % ncb, by = tile / ncb;
+    const int y = by % H, b = by / H;
+    // a thread keeps its channel pair for the whole row (the thread count is a multiple of CH): bias / scale / shift are loaded once per tile
+    const int v = tid % CH, c = cblk * CB + 2 * v;
+    if (c < Cout) {
+      const bool two = c + 1 < Cout, pairs = (Cout & 1) == 0;      // two channels = one aligned store
+      const float b0v = bias[c], b1v = two ? bias[c + 1] : 0.f;
+      float s0 = 1.f, s1 = 1.f, h0 = 0.f, h1 = 0.f;
+      if (relu_bn) { s0 = scale[c]; h0 = shift[c]; if (two) { s1 = scale[c + 1]; h1 = shift[c + 1]; } }
+      for (int x = tid / CH; x < W; x += NTR / CH) {
+        const cf z = buf[pos<NX>(x + pad) * CH + v];
+        float v0 = z.x * norm + b0v, v1 = z.y * norm + b1v;
+        if (relu_bn) { v0 = fmaxf(v0, 0.f) * s0 + h0; v1 = fmaxf(v1, 0.f) * s1 + h1; }
+        if constexpr (LAYOUT == 0) {
+          float* o = static_cast<float*>(out) + ((size_t)(b * H + y) * W + x) * Cout + c;
+          if (pairs) *reinterpret_cast<cf*>(o) = cf{v0, v1};
+          else { o[0] = v0; if (two) o[1] = v1; }
+        } else {
+          typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+          __bf16* o = static_cast<__bf16*>(out) + (LAYOUT == 1 ? ((size_t)(b * H + y) * W + x) * Cout + c
+                                                               : (((size_t)b * (Cout >> 3) + (c >> 3)) * H * W + (size_t)y * W + x) * 8 + (c & 7));
+          if (pairs) *reinterpret_cast<bf16x2*>(o) = bf16x2{static_cast<__bf16>(v0), static_cast<__bf16>(v1)};
+          else { o[0] = static_cast<__bf16>(v0); if (two) o[1] = static_cast<__bf16>(v1); }
+        }
+      }
+    }
+    __syncthreads();      // every wave is done reading buf
+    tile = next;
   }
 }
 
@@ -104,13 +125,16 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_fwd_kernel(const 
 
 
 template <int NX> static void launch_rows_inv(const ConvArgs& a, int layout, const cf* T, const cf* tw, int pad, float norm, hipStream_t st) {
-  const dim3 grid(a.B * a.H * (a.CoutP / CB));
+  const int ntiles = a.B * a.H * (a.CoutP / CB);
+  const void* fn = layout == 0 ? reinterpret_cast<const void*>(rows_inv_kernel<NX, 0>) : layout == 1 ? reinterpret_cast<const void*>(rows_inv_kernel<NX, 1>)
+                                                                                                  : reinterpret_cast<const void*>(rows_inv_kernel<NX, 2>);
+  const dim3 grid(persistent_grid(fn, ntiles, rows_threads<NX>()));
   if (layout == 0)
-    hipLaunchKernelGGL((rows_inv_kernel<NX, 0>), grid, dim3(rows_threads<NX>()), 0, st, T, a.out, tw, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm);
+    hipLaunchKernelGGL((rows_inv_kernel<NX, 0>), grid, dim3(rows_threads<NX>()), 0, st, T, a.out, tw, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm, ntiles);
   else if (layout == 1)
-    hipLaunchKernelGGL((rows_inv_kernel<NX, 1>), grid, dim3(rows_threads<NX>()), 0, st, T, a.out, tw, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm);
+    hipLaunchKernelGGL((rows_inv_kernel<NX, 1>), grid, dim3(rows_threads<NX>()), 0, st, T, a.out, tw, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm, ntiles);
   else
-    hipLaunchKernelGGL((rows_inv_kernel<NX, 2>), grid, dim3(rows_threads<NX>()), 0, st, T, a.out, tw, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm);
+    hipLaunchKernelGGL((rows_inv_kernel<NX, 2>), grid, dim3(rows_threads<NX>()), 0, st, T, a.out, tw, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm, ntiles);
 }
 template <int NX> static void launch_rows_inv_fwd(const ConvArgs& a, const cf* T, cf* Tn, const cf* tw, int pad, float norm, hipStream_t st) {
   hipLaunchKernelGGL(rows_inv_fwd_kernel<NX>, dim3(a.B * a.H * (a.Cout / CB)), dim3(rows_threads<NX>()), 0, st, T, Tn, tw, a.bias, a.scale, a.shift, a.relu_bn, a.B, a.H, a.W, a.Cout, pad, norm);

@@ -440,6 +440,10 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
   // when conv5 takes the strip kernel; every producer / consumer on that chain handles the layout.
   const ConvLayer* L6 = conv_of(c, "conv6");
   const int planar = bf && L6->thin_bf16 && L4->cout % 8 == 0 && L5->cout % 8 == 0 && takes_strip(L5, B, h4[0], w4[0]) ? 1 : 0;
+  // ... except between two frequency-domain layers: their row passes read and write NHWC in whole 128-byte lines per pixel, while a planar
+  // tensor gives a lane only the 4 bytes of its channel pair inside a 16-byte unit (3.3 against 4.8 TB/s measured for the inverse row pass).
+  // So with conv5 in the frequency domain the chain conv4 -> merge -> conv5 is NHWC; conv5's OUTPUT stays planar for the logits kernel.
+  const int planar45 = planar && !takes_fft(c, L5, B, h4[0], w4[0]) ? 1 : 0;
   for (int r = 0; r < 3; ++r) {
     const size_t mark = c->arena_off;
     const std::string res = kRes[r];
@@ -490,26 +494,28 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
     void* c3 = act((size_t)B * h3 * w3 * L3->cout);
     const ConvLayer* L4r = conv_of(c, "conv4_" + res);
     if (!L4r) return fail(JCM_ERR_STATE, "part-detector parameters incomplete (conv4_" + res + ")");
-    const int in4 = planar && L3->cout % 8 == 0 && takes_strip(L4r, B, h3, w3) ? 1 : 0;      // the patch kernels read NHWC
+    const int in4 = planar && L3->cout % 8 == 0 && takes_strip(L4r, B, h3, w3) && !takes_fft(c, L4r, B, h3, w3) ? 1 : 0;      // the patch kernels and the row pass read NHWC
     void* t34 = offer_handover(c, L3, L4r, B, h3, w3);
     JCM_TRY(run_conv(c, "conv3_" + res, 1, p2, B, h3, w3, 1, c3, bf, false, pl23, in4));   // :48,56,65
     c->fft_t_in = t34;
-    JCM_TRY(run_conv(c, "conv4_" + res, 1, c3, B, h3, w3, 1, x4[r], bf, false, in4, planar));   // :49,57,66
+    JCM_TRY(run_conv(c, "conv4_" + res, 1, c3, B, h3, w3, 1, x4[r], bf, false, in4, planar45));   // :49,57,66
     c->arena_off = mark;
   }
   const int hh = h4[0], ww = w4[0];
   // fp32 handle with conv5 in the frequency domain: its forward row kernel forms ((x1 + up(x2)) + up(x3)) / 3 while it loads the rows
+  // (tried on bf16 handles too, and with the x1 row prefetched by persistent work groups: the 8 tap gathers per element then sit on the
+  // tile's critical path -- 4.5 ms against 1.1 + 1.1 ms for the separate merge kernel + plain row pass at B = 256)
   const bool fuse_merge = !bf && takes_fft(c, L5, B, hh, ww);
   FftMerge mg{static_cast<const float*>(x4[1]), h4[1], w4[1], static_cast<const float*>(x4[2]), h4[2], w4[2]};
   void* merged = fuse_merge ? x4[0] : act((size_t)B * hh * ww * L4->cout);
   if (!c->dry && !fuse_merge) {                                                            // :58,67,69-70
-    if (planar) HIP_TRY(upsample_merge3_planar(x4[0], x4[1], h4[1], w4[1], x4[2], h4[2], w4[2], merged, B, hh, ww, L4->cout, c->stream));
+    if (planar45) HIP_TRY(upsample_merge3_planar(x4[0], x4[1], h4[1], w4[1], x4[2], h4[2], w4[2], merged, B, hh, ww, L4->cout, c->stream));
     else HIP_TRY(upsample_merge3(x4[0], x4[1], h4[1], w4[1], x4[2], h4[2], w4[2], merged, bf, B, hh, ww, L4->cout, c->stream));
   }
   void* c5 = act((size_t)B * hh * ww * L5->cout);
   void* t56 = offer_handover(c, L5, conv_of(c, "conv6"), B, hh, ww);
   if (fuse_merge) c->fft_merge = &mg;
-  JCM_TRY(run_conv(c, "conv5", 1, merged, B, hh, ww, 1, c5, bf, false, planar, planar));   // :71
+  JCM_TRY(run_conv(c, "conv5", 1, merged, B, hh, ww, 1, c5, bf, false, planar45, planar));   // :71
   c->fft_t_in = t56;
   JCM_TRY(run_conv(c, "conv6", 1, c5, B, hh, ww, 1, logits, bf, true, planar, 0));         // :72
   return JCM_OK;

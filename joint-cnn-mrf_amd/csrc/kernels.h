@@ -89,13 +89,16 @@ bool conv_fft_fusable(const ConvArgs& a, int ks, int ks_next);
 size_t conv_fft_handover_bytes(const ConvArgs& a, int ks);
 
 // ---- cgemm_split.hip : Y[f][b][co] = sum_ci X[f][b][ci] W[f][ci][co] (complex) for F frequencies on v_mfma_f32_32x32x16_bf16, operands
-// pre-split into np bf16 parts in tile-major LDS-image layout:
-//   xs[f][m-tile][Cin/16][re|im][part][k-half][MT rows][8]   (MT = cgemm_split_mtile(np, B); rows >= B are never stored)
-//   ws[f][n-tile][Cin/16][re|im][part][k-half][128 cols][8]  (CoutP % 128 == 0)
-//   y [f][B][CoutP] complex fp32
-constexpr int kCgemmNT = 128;
-int cgemm_split_mtile(int np, int B);
-hipError_t cgemm_split(const void* xs, const void* ws, void* y, int np, int F, int B, int Cin, int CoutP, hipStream_t st);
+// as np bf16 parts in tile-major LDS-image layout:
+//   xs[f][m-tile][Cin/16][re|im][part][k-half][MT rows][8 bf16]   (MT = cgemm_split_mtile(np, B, Cout); rows >= B are never stored)
+//   ws[f][n-tile][Cin/16][re|im][part][k-half][ntl cols][8 bf16]  (np = 2), or fp32, split by the kernel (np = 3: cgemm_split_w_fp32):
+//   ws[f][n-tile][Cin/16][re|im][k-half][4-channel half][ntl cols][4 fp32];   ntl = cgemm_split_ntile(np, Cout): 128, or 32 for Cout <= 32 on fp32 handles
+//   y [f][B][ldy] complex fp32, ldy >= Cout rounded up to whole N tiles
+int cgemm_split_mtile(int np, int B, int Cout);
+int cgemm_split_ntile(int np, int Cout);
+bool cgemm_split_w_fp32(int np);
+size_t cgemm_split_w_bytes(int np, int F, int Cin, int Cout);
+hipError_t cgemm_split(const void* xs, const void* ws, void* y, int np, int F, int B, int Cin, int Cout, int ldy, hipStream_t st);
 
 // ---- conv5_strip_bf16.hip : 5x5 SAME convolution in 128-channel output tiles on 768-pixel strips (bf16 in NHWC or planar, bf16 out NHWC or planar;
 // weights as packed by pack_weights_bf16); shapes: CoutP % 128 == 0, Cin % 32 == 0, Cout % 8 == 0, 8 <= W <= 191 and a window of at most 64 row parts

@@ -55,8 +55,22 @@ def pmc(dbs, min_us=0.0):
             print('"%s",%s,%d,%.6g,%.1f' % (short(n), cn, c, v, d / 1e3))
 
 
+def trace(db, pattern, last=0):
+    """Dispatches of the kernels whose name contains `pattern`, in time order (the last `last` of them if > 0): which layer costs what."""
+    con = sqlite3.connect(db)
+    rows = con.execute('select name, start, duration from kernels where name like ? order by start', ('%' + pattern + '%',)).fetchall()
+    if last:
+        rows = rows[-last:]
+    print('kernel,start_us,duration_us')
+    t0 = rows[0][1] if rows else 0
+    for n, st, d in rows:
+        print('"%s",%.1f,%.1f' % (short(n), (st - t0) / 1e3, d / 1e3))
+
+
 if __name__ == '__main__':
-    if sys.argv[1] == 'stats':
+    if sys.argv[1] == 'trace':            # trace db pattern [last]
+        trace(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 0)
+    elif sys.argv[1] == 'stats':
         stats(sys.argv[2])
     elif sys.argv[1] == 'pmc_min':          # pmc_min MIN_US db...
         pmc(sys.argv[3:], float(sys.argv[2]))

@@ -44,37 +44,43 @@ __global__ void pack_x(__bf16* xs, int np, int F, int B, int Cin, int MT, int mt
     split_store(v, np, dst, (size_t)2 * MT * 8);
   }
 }
-__global__ void pack_w(__bf16* ws, int np, int F, int Cin, int Cout, int CoutP) {
+// ntl-column tiles; f32: unsplit fp32 layout [f][nt][kc][c][kg][4-channel half][col][4]
+__global__ void pack_w(void* ws, int np, int f32, int ntl, int F, int Cin, int Cout, int CoutP) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t n = (size_t)F * Cin * CoutP;
   if (i >= n) return;
   const int co = (int)(i % CoutP);
   const int ci = (int)((i / CoutP) % Cin);
   const size_t f = i / ((size_t)CoutP * Cin);
-  const int nt = co / 128, cn = co % 128, kc = ci / 16, kg = (ci % 16) / 8, e = ci % 8, KC = Cin / 16, ntiles = CoutP / 128;
+  const int nt = co / ntl, cn = co % ntl, kc = ci / 16, kg = (ci % 16) / 8, e = ci % 8, KC = Cin / 16, ntiles = CoutP / ntl;
   for (int c = 0; c < 2; ++c) {
     const float v = co < Cout ? wval(f, ci, co, c, Cin, Cout) : 0.f;
-    __bf16* dst = ws + (((((f * ntiles + nt) * KC + kc) * (4 * np) + (size_t)(c * np) * 2 + kg) * 128 + cn) * 8 + e);
-    split_store(v, np, dst, (size_t)2 * 128 * 8);
+    if (f32) {
+      static_cast<float*>(ws)[((((((f * ntiles + nt) * KC + kc) * 2 + c) * 2 + kg) * 2 + e / 4) * ntl + cn) * 4 + e % 4] = v;
+    } else {
+      __bf16* dst = static_cast<__bf16*>(ws) + (((((f * ntiles + nt) * KC + kc) * (4 * np) + (size_t)(c * np) * 2 + kg) * ntl + cn) * 8 + e);
+      split_store(v, np, dst, (size_t)2 * ntl * 8);
+    }
   }
 }
 
 int main(int argc, char** argv) {
   const int np = argc > 1 ? atoi(argv[1]) : 2, F = argc > 2 ? atoi(argv[2]) : 64, B = argc > 3 ? atoi(argv[3]) : 256;
   const int Cin = argc > 4 ? atoi(argv[4]) : 512, Cout = argc > 5 ? atoi(argv[5]) : 512, iters = argc > 6 ? atoi(argv[6]) : 5;
-  const int CoutP = (Cout + 127) / 128 * 128;
-  const int MT = jcm::cgemm_split_mtile(np, B), mtiles = (B + MT - 1) / MT;
-  const size_t xbytes = (size_t)F * mtiles * MT * Cin * 4 * np, wbytes = (size_t)F * Cin * CoutP * 4 * np, ybytes = (size_t)F * B * CoutP * 8;
+  const int ntl = jcm::cgemm_split_ntile(np, Cout), f32 = jcm::cgemm_split_w_fp32(np) ? 1 : 0;
+  const int CoutP = (Cout + ntl - 1) / ntl * ntl;
+  const int MT = jcm::cgemm_split_mtile(np, B, Cout), mtiles = (B + MT - 1) / MT;
+  const size_t xbytes = (size_t)F * mtiles * MT * Cin * 4 * np, wbytes = jcm::cgemm_split_w_bytes(np, F, Cin, Cout), ybytes = (size_t)F * B * CoutP * 8;
   void *xs, *ws, *y;
   CK(hipMalloc(&xs, xbytes)); CK(hipMalloc(&ws, wbytes)); CK(hipMalloc(&y, ybytes));
   CK(hipMemset(y, 0xff, ybytes));
   {
     const size_t nx = (size_t)F * mtiles * MT * Cin, nw = (size_t)F * Cin * CoutP;
     hipLaunchKernelGGL(pack_x, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, 0, (__bf16*)xs, np, F, B, Cin, MT, mtiles);
-    hipLaunchKernelGGL(pack_w, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, 0, (__bf16*)ws, np, F, Cin, Cout, CoutP);
+    hipLaunchKernelGGL(pack_w, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, 0, ws, np, f32, ntl, F, Cin, Cout, CoutP);
     CK(hipDeviceSynchronize());
   }
-  CK(jcm::cgemm_split(xs, ws, y, np, F, B, Cin, CoutP, 0));
+  CK(jcm::cgemm_split(xs, ws, y, np, F, B, Cin, Cout, CoutP, 0));
   CK(hipDeviceSynchronize());
   // ---- check sampled outputs
   double worst = 0, scale = 0;
@@ -102,9 +108,9 @@ int main(int argc, char** argv) {
   // ---- timing
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 2; ++i) CK(jcm::cgemm_split(xs, ws, y, np, F, B, Cin, CoutP, 0));
+  for (int i = 0; i < 2; ++i) CK(jcm::cgemm_split(xs, ws, y, np, F, B, Cin, Cout, CoutP, 0));
   CK(hipEventRecord(e0, 0));
-  for (int i = 0; i < iters; ++i) CK(jcm::cgemm_split(xs, ws, y, np, F, B, Cin, CoutP, 0));
+  for (int i = 0; i < iters; ++i) CK(jcm::cgemm_split(xs, ws, y, np, F, B, Cin, Cout, CoutP, 0));
   CK(hipEventRecord(e1, 0));
   CK(hipEventSynchronize(e1));
   float ms = 0;
