@@ -5,9 +5,9 @@
   python tests/golden/make_golden.py [--skip-reference-check]
 
 1. flic_train_cells.npy  [3987,10,2] uint8 -- heat-map cell (row, col) of the 9 joints + torso
-   for every FLIC training example, obtained by building the 60x90 heat maps exactly as
-   data.py:88-189 does from data_FLIC.mat (no JPEGs needed) and taking the arg-max cell the
-   way prepare_pairwise_distribution.py:39-42 reads it back.
+   for every FLIC training example, obtained by EXECUTING the reference's own data.py (runpy;
+   the JPEG reads are stood in for, the heat-map half only needs data_FLIC.mat) and taking the
+   arg-max cell of its y_train_flic.npy the way prepare_pairwise_distribution.py:39-42 reads it back.
    The reference's own prepare_pairwise_distribution.py is then executed (runpy, in a temp
    dir holding the generated y_train_flic.npy) and its pickle must equal
    joint_cnn_mrf_amd.priors.build_pairwise_distributions(cells) bit for bit.
@@ -40,50 +40,45 @@ from oracle import jcm_oracle as O  # noqa: E402
 GOLDEN_SEEDS = dict(weights=7, images=2024, torso=2025, sm=11, conv6_gain=24.0)
 
 
-def flic_heat_maps(split='train'):
-    """data.py:88-189 restricted to the heat-map half (the image half needs the JPEGs)."""
-    data_FLIC = loadmat(os.path.join(REF, 'data_FLIC.mat'))['examples'][0]
-    joint_ids = ['lsho', 'lelb', 'lwri', 'rsho', 'relb', 'rwri', 'lhip', 'rhip', 'nose']            # data.py:95
-    dict_ = {'lsho': 0, 'lelb': 1, 'lwri': 2, 'rsho': 3, 'relb': 4, 'rwri': 5, 'lhip': 6, 'lkne': 7, 'lank': 8,
-             'rhip': 9, 'rkne': 10, 'rank': 11, 'leye': 12, 'reye': 13, 'lear': 14, 'rear': 15, 'nose': 16,
-             'msho': 17, 'mhip': 18, 'mear': 19, 'mtorso': 20, 'mluarm': 21, 'mruarm': 22, 'mllarm': 23,
-             'mrlarm': 24, 'mluleg': 25, 'mruleg': 26, 'mllleg': 27, 'torso': 28}                    # data.py:96-100
-    is_train = np.array([data_FLIC[i][7][0, 0] for i in range(len(data_FLIC))])                      # data.py:101-102
-    index = np.where(is_train == (1 if split == 'train' else 0))[0]
-    coefs = np.array([[1, 2, 1]], dtype=np.float32) / 4                                              # data.py:112
-    kernel = coefs.T @ coefs
-    temp = round((len(kernel) - 1) / 2)
-    pad = 5
-    orig_h, orig_w = 480, 720
-    hmaps = []
-    for i in index:
-        flic_coords = data_FLIC[i][2]
-        # flip_backward_poses, data.py:35-49, with the reference's view (not copy) semantics
-        hip_left, hip_right = dict_['lhip'], dict_['rhip']
-        if flic_coords[:, hip_left][0] < flic_coords[:, hip_right][0]:
-            for jl, jr in zip(['lwri', 'lelb', 'lhip', 'lsho'], ['rwri', 'relb', 'rhip', 'rsho']):
-                jl, jr = dict_[jl], dict_[jr]
-                coords_left_joint = flic_coords[:, jl]
-                coords_right_joint = flic_coords[:, jr]
-                flic_coords[:, jl] = coords_right_joint
-                flic_coords[:, jr] = coords_left_joint
-        torso = (flic_coords[:, dict_['lsho']] + flic_coords[:, dict_['rhip']] + flic_coords[:, dict_['rsho']] +
-                 flic_coords[:, dict_['lhip']]) / 4                                                  # data.py:165-167
-        flic_coords[:, dict_['torso']] = torso
-        hmap = []
-        for joint in joint_ids + ['torso']:
-            coords = np.copy(flic_coords[:, dict_[joint]])
-            coords[0], coords[1] = max(min(coords[1], orig_h), 0), max(min(coords[0], orig_w), 0)    # data.py:171
-            coords /= 8
-            heat_map = np.zeros([60, 90], dtype=np.float32)
-            heat_map = np.pad(heat_map, ((pad, pad), (pad, pad)), "constant", constant_values=0)   # np.lib.pad in data.py:177
-            coords = coords + pad
-            h1_k, h2_k = int(coords[0] - temp), int(coords[0] + temp + 1)
-            w1_k, w2_k = int(coords[1] - temp), int(coords[1] + temp + 1)
-            heat_map[h1_k:h2_k, w1_k:w2_k] = kernel
-            hmap.append(heat_map[pad:pad + 60, pad:pad + 90])
-        hmaps.append(np.stack(hmap, axis=2))
-    return np.array(hmaps, dtype=np.float32)
+def run_reference_data_script():
+    """Execute /root/reference/data.py's own __main__ block (runpy) on data_FLIC.mat and return (y_train, y_test) as IT builds them.
+    The script also reads 5003 JPEG frames that are not in the repository and imports plotting / image libraries that are not
+    installed; only those are stood in for (every frame reads as one black pixel -- the heat-map half never looks at the pixels --
+    and the x_*_flic.npy arrays it writes are discarded).  Nothing of the script's text is kept here."""
+    import types
+    stubs = {}
+    imageio = types.ModuleType('imageio')
+    imageio.imread = lambda path: np.zeros((1, 1, 3), np.uint8)
+    stubs['imageio'] = imageio
+    skimage = types.ModuleType('skimage')
+    skimage.transform = types.ModuleType('skimage.transform')
+    stubs['skimage'], stubs['skimage.transform'] = skimage, skimage.transform
+    mpl = types.ModuleType('matplotlib')
+    mpl.pyplot = types.ModuleType('matplotlib.pyplot')
+    stubs['matplotlib'], stubs['matplotlib.pyplot'] = mpl, mpl.pyplot
+    saved = {k: sys.modules.get(k) for k in stubs}
+    cwd = os.getcwd()
+    had_lib_pad = hasattr(np.lib, 'pad')
+    with tempfile.TemporaryDirectory() as td:
+        os.symlink(os.path.join(REF, 'data_FLIC.mat'), os.path.join(td, 'data_FLIC.mat'))
+        os.chdir(td)
+        try:
+            sys.modules.update(stubs)
+            if not had_lib_pad:
+                np.lib.pad = np.pad          # the alias the 2018 script uses; NumPy 2 dropped it
+            runpy.run_path(os.path.join(REF, 'data.py'), run_name='__main__')
+            y_train = np.load(os.path.join(td, 'y_train_flic.npy'))
+            y_test = np.load(os.path.join(td, 'y_test_flic.npy'))
+        finally:
+            os.chdir(cwd)
+            if not had_lib_pad:
+                del np.lib.pad
+            for k, v in saved.items():
+                if v is None:
+                    sys.modules.pop(k, None)
+                else:
+                    sys.modules[k] = v
+    return y_train, y_test
 
 
 def cells_from_heat_maps(y):
@@ -120,8 +115,8 @@ def top2_margin(logits):
 
 def main():
     skip_ref = '--skip-reference-check' in sys.argv
-    y_train = flic_heat_maps('train')
-    print('y_train', y_train.shape, float(y_train.sum(axis=(1, 2)).mean()))
+    y_train, y_test = run_reference_data_script()
+    print('y_train', y_train.shape, float(y_train.sum(axis=(1, 2)).mean()), 'y_test', y_test.shape)
     cells = cells_from_heat_maps(y_train)
     np.save(os.path.join(HERE, 'flic_train_cells.npy'), cells)
     # the annotations themselves (x, y of the nine joints, float64), input of joint_cnn_mrf_amd.data; the package's
@@ -130,8 +125,8 @@ def main():
     xy, _names, is_train = jdata.load_flic(os.path.join(REF, 'data_FLIC.mat'))
     np.save(os.path.join(HERE, 'flic_train_xy.npy'), xy[is_train])
     assert np.array_equal(jdata.target_heat_maps(jdata.joint_cells(xy[is_train])), y_train)
-    assert np.array_equal(jdata.target_heat_maps(jdata.joint_cells(xy[~is_train])), flic_heat_maps('test'))
-    print('data.py: y_train / y_test identical to the line-by-line restatement of the reference script')
+    assert np.array_equal(jdata.target_heat_maps(jdata.joint_cells(xy[~is_train])), y_test)
+    print('joint_cnn_mrf_amd.data: y_train / y_test identical to the arrays the reference data.py writes')
     pri = priors.build_pairwise_distributions(cells)
     if not skip_ref:
         ref = run_reference_prior_builder(y_train)

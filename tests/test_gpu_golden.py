@@ -241,3 +241,38 @@ def test_checkpoint_file_to_engine_reproduces_golden_tower(tmp_path, precision):
         np.testing.assert_array_equal(r['sm_coords'].cpu().numpy(), load('full_sm_coords_trained'))
     else:
         assert (np.abs(r['sm_coords'].cpu().numpy() - load('full_sm_coords_trained')).max(axis=1) <= 1).mean() >= 0.85
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_two_engines_two_streams_soak(precision):
+    """Two engines on two HIP streams of one device run the full-size tower concurrently, 100 forwards each, nothing synchronised in
+    between (their kernels interleave on the GPU; twiddle tables, occupancy caches and per-kernel attributes are shared process state).
+    Every single result must be the golden one: fp32 to the golden bar, bf16 bit-identical to its own first result."""
+    from joint_cnn_mrf_amd.engine import Engine
+    x, torso, p = full_inputs()
+    p.update(synth.make_sm_params(flic_priors(), kind='trained', seed=seeds()['sm']))
+    streams = [torch.cuda.Stream(device='cuda:0') for _ in range(2)]
+    engs = [Engine(device=0, precision=precision, stream=s).load_params(p) for s in streams]
+    xd, td = dev(x), dev(torso)
+    torch.cuda.synchronize()
+    n_iter = 100
+    outs = [[], []]
+    for _ in range(n_iter):
+        for e, (eng, s) in enumerate(zip(engs, streams)):
+            with torch.cuda.stream(s):
+                r = eng.forward(xd, td, use_sm=True)
+                outs[e].append((r['sm_prob'], r['sm_coords'], r['pd_coords']))
+    torch.cuda.synchronize()
+    for eng in engs:
+        eng.close()
+    ref_sm_prob = O.spatial_softmax(load('full_sm_logits_trained').astype(np.float64))
+    first = [o.cpu().numpy() for o in outs[0][0]]
+    if precision == 'fp32':
+        np.testing.assert_allclose(first[0], ref_sm_prob, atol=1e-4, rtol=0)
+        np.testing.assert_array_equal(first[1], load('full_sm_coords_trained'))
+        np.testing.assert_array_equal(first[2], load('full_pd_coords'))
+    for e in range(2):
+        for i in range(n_iter):
+            got = [o.cpu().numpy() for o in outs[e][i]]
+            for g, f in zip(got, first):
+                assert np.array_equal(g, f), 'engine %d, forward %d differs from the first result' % (e, i)
