@@ -152,18 +152,21 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
   const unsigned lane16 = (unsigned)lane * 16u;
 
   // stage g -> ring slot: the LDS image of a stage is its HBM image, X pieces first; wave w moves pieces w, w + NW, ...
-  // Past the last stage the offsets run out of the buffer descriptors and the DMA delivers zeros into a free slot: no tail logic.
+  // Past the last stage the look-ahead requests run out of the buffer descriptor and deliver zeros into a free slot: no tail logic.  The
+  // stage offset therefore rides in the VECTOR offset: only that one is bounds-checked (a scalar offset past the end reads whatever
+  // lies behind the buffer -- harmless for this kernel, but those stray reads leave stale copies of OTHER streams' buffers in the
+  // per-XCD L2s at arbitrary times, and a kernel of that other stream then consumes them: found by the two-stream soak test).
   auto issue = [&](int g, int slot) __attribute__((always_inline)) {
     const unsigned sbase = (unsigned)(slot * STAGE * 16);
 #pragma unroll
     for (int i = 0; i < C::XPW; ++i) {
       const unsigned q = (unsigned)(wid + i * NW) * 1024u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(smem + sbase + q), 16, lane16, (unsigned)g * (unsigned)(XST * 16) + q, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(smem + sbase + q), 16, lane16 + (unsigned)g * (unsigned)(XST * 16) + q, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < C::WPW; ++i) {
       const unsigned q = (unsigned)(wid + i * NW) * 1024u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(smem + sbase + XST * 16 + q), 16, lane16, (unsigned)g * (unsigned)(WST * 16) + q, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(smem + sbase + XST * 16 + q), 16, lane16 + (unsigned)g * (unsigned)(WST * 16) + q, 0, 0, 0);
     }
   };
 
@@ -184,15 +187,15 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
   };
   auto load_w = [&](int g) __attribute__((always_inline)) {
     if constexpr (WF32) {
-      const unsigned soff = (unsigned)g * (unsigned)C::WSRC;
+      const unsigned goff = (unsigned)g * (unsigned)C::WSRC;      // in the vector offset: bounds-checked (see issue())
 #pragma unroll
       for (int u = 0; u < UPT; ++u) {
         int c, kg;
         unit_of(u, c, kg);
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-          const unsigned voff = (unsigned)((((c * 2 + kg) * 2 + hh) * NTL + wcol) * 16);
-          asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(wreg[u][hh]) : "v"(voff), "s"(wdesc), "s"(soff) : "memory");
+          const unsigned voff = (unsigned)((((c * 2 + kg) * 2 + hh) * NTL + wcol) * 16) + goff;
+          asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(wreg[u][hh]) : "v"(voff), "s"(wdesc) : "memory");
         }
       }
     }

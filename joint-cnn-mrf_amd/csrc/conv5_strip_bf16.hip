@@ -119,7 +119,7 @@ __device__ __forceinline__ void c5_wdma(const ConvArgs& a, R wrsrc, f32x4* lds, 
       const int kx = piece >> 2, unit = (piece >> 1) & 1, q = piece & 1;
       const unsigned soff = (unsigned)(ky * KS + kx) * wtap + (unsigned)(((chunk * 2 + unit) * a.CoutP + n0 + q * 64) * 16);
       f32x4* dst = lds + WB0 + slot * WST + (kx * 2 + unit) * BN + q * 64;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, (unsigned)lane * 16u, soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, (unsigned)lane * 16u + soff, 0, 0, 0);
     }
   }
 }

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(C::NT, (C::NT + 255) / 256) void conv_igemm_bf16_ke
           const int q = piece % QPU, tu = piece / QPU;
           const int u = tu % C::U, tap = s * C::TPS + tu / C::U;
           const unsigned soff = (unsigned)(((tap * cin8 + chunk * C::U + u) * CoutP + q * 64) * 16);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff, soff, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff + soff, 0, 0, 0);
         } else {
           const int idx = piece * 64 + lane;          // f32x4 index inside the stage image
           const int co = idx % C::BN;

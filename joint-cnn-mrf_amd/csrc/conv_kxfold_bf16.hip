@@ -143,7 +143,7 @@ __device__ __forceinline__ void kx_tile(const ConvArgs& a, const Geom& gm, char*
     auto dst = (__attribute__((address_space(3))) char*)(size_t)(lds0 + slot * 16u);
     const unsigned lo = (eb >> 14) & 0x7fu, hi = (eb >> 21) & 0x7fu;
     if ((unsigned)lane - lo < hi - lo) {
-      if (wts) __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, lane16, ea + (unsigned)chunk * wcs, 0, 0);
+      if (wts) __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, lane16 + ea + (unsigned)chunk * wcs, 0, 0, 0);
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)dst, 16, xvoff, ea + (unsigned)chunk * xcs, 0, 0);
     }
   };

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv_split_kernel(ConvArgs a, int ti
       const int u = pu % C::U, pt = pu / C::U;
       const int part = pt % C::NSPLIT, tap = st * C::TPS + pt / C::NSPLIT;
       const unsigned soff = (unsigned)(((((tap * cin8 + chunk * C::U + u) * C::NSPLIT) + part) * CoutP + q * 64) * 16);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff, soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff + soff, 0, 0, 0);
     }
   };
 

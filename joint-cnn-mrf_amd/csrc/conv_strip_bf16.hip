@@ -169,7 +169,7 @@ __device__ __forceinline__ void strip_tile(const ConvArgs& a, const Geom& gm, ch
   auto w_piece = [&](int chunk, int s, int i, int buf) __attribute__((always_inline)) {      // tap i of stage (chunk, s) into ring slot buf (prologue; the loop advances scalars)
     const unsigned soff = (unsigned)(3 * s + i) * wtap_stride + (unsigned)(((chunk * 2 + wu) * CoutP + n0 + wq * 64) * 16);
     f32x4* dst = lds + WB0 + buf * WST + (i * 2 + wu) * BN + wq * 64;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, lane16, soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, lane16 + soff, 0, 0, 0);
   };
 
   // ---- halo: row j of a plane = slots j*pitch .. +pitch-1 = [4 zero slots | W pixels]; it holds virtual row y0-4+j of
@@ -244,7 +244,8 @@ __device__ __forceinline__ void strip_tile(const ConvArgs& a, const Geom& gm, ch
   // ---- per-stage control kept to a handful of scalar instructions (every SALU op sits between MFMAs of an in-order wave:
   // 200 of them per stage cost 4 % of the kernel).
   // Weights of stage g+3: source offset and LDS address advance by constants; past the last stage the offset runs out
-  // of the buffer and the DMA delivers zeros into a free ring slot -- no tail logic.
+  // of the buffer and the DMA delivers zeros into a free ring slot -- no tail logic.  (The offset rides in the VECTOR operand:
+  // a scalar offset is not bounds-checked, and reads behind the buffer leave stale lines of other streams' data in the L2s.)
   const unsigned TS = wtap_stride, CS = (unsigned)(2 * CoutP * 16);
   unsigned wsoff = (unsigned)(9 + wt0) * TS + (unsigned)((wu * CoutP + n0 + wq * 64) * 16);  // stage 3 = taps 9..11 of chunk 0
   unsigned wm0 = lds0 + (unsigned)((WB0 + 3 * WST + (wt0 * 2 + wu) * BN + wq * 64) * 16);
@@ -323,7 +324,7 @@ __device__ __forceinline__ void strip_tile(const ConvArgs& a, const Geom& gm, ch
 #endif
       if (idx >= 0 && idx < nw) {
         auto dst = (__attribute__((address_space(3))) char*)(size_t)(wm0 + (unsigned)(idx * 2 * BN * 16));
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, lane16, wsoff + (unsigned)idx * TS, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, lane16 + wsoff + (unsigned)idx * TS, 0, 0, 0);
       }
 #ifndef EXP_NOHALO
       else if (idx == (NC == NR ? TPS : 1) && extra) {

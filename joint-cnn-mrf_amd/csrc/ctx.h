@@ -136,6 +136,19 @@ struct DeviceGuard {
   }
 };
 
+// Calls of DIFFERENT handles on one device are ordered on the GPU: every entry point that enqueues work waits (hipStreamWaitEvent, the
+// host does not block) for the previous call of another stream and records an event when it has queued its own kernels.  Each call
+// fills the chip on its own, so nothing is lost; what is gained is that no kernel of this library ever runs beside a kernel of another
+// handle.  The per-XCD L2s are not coherent with each other: a kernel that touches memory another stream is producing (the look-ahead
+// reads past the end of a buffer that cgemm_split.hip used to make were such touches) leaves stale lines that the other stream's next
+// kernel then consumes -- found by tests/test_gpu_golden.py::test_two_engines_two_streams_soak.  The known over-reads are fixed at the
+// source; this ordering is the guarantee that does not depend on having found them all.
+struct CallOrder {
+  jcm_ctx* c;
+  explicit CallOrder(jcm_ctx* ctx);
+  ~CallOrder();
+};
+
 template <class T>
 T* arena_alloc(jcm_ctx* c, size_t count) {
   const size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);

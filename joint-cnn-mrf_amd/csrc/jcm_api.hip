@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstring>
 
+#include <mutex>
+
 #include "ctx.h"
 
 using namespace jcm;
@@ -21,6 +23,25 @@ const char* const kJointNames[10] = {"lsho", "lelb", "lwri", "rsho", "relb", "rw
 int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
+}
+
+namespace {
+struct Chain { std::mutex mu; hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool armed = false; };
+Chain g_chain[64];
+}  // namespace
+CallOrder::CallOrder(jcm_ctx* ctx) : c(ctx) {
+  if (!c) return;
+  Chain& ch = g_chain[c->device & 63];
+  std::lock_guard<std::mutex> lk(ch.mu);
+  if (!ch.ev && hipEventCreateWithFlags(&ch.ev, hipEventDisableTiming) != hipSuccess) { ch.ev = nullptr; return; }
+  if (ch.armed && ch.last != c->stream) (void)hipStreamWaitEvent(c->stream, ch.ev, 0);
+}
+CallOrder::~CallOrder() {
+  if (!c) return;
+  Chain& ch = g_chain[c->device & 63];
+  std::lock_guard<std::mutex> lk(ch.mu);
+  if (!ch.ev) return;
+  if (hipEventRecord(ch.ev, c->stream) == hipSuccess) { ch.armed = true; ch.last = c->stream; }
 }
 
 int arena_reserve(jcm_ctx* c, size_t bytes) {
@@ -686,6 +707,7 @@ int jcm_set_tensor(jcm_handle h, const char* name, const float* data, const int6
   if (h->finalized) return fail(JCM_ERR_STATE, "parameters must be set before jcm_finalize");
   if (!name || !data || !shape || ndim < 1 || ndim > 4) return fail(JCM_ERR_ARG, "bad set_tensor arguments");
   DeviceGuard g(h->device);
+  CallOrder order(h);
   size_t n = 1;
   for (int i = 0; i < ndim; ++i) {
     if (shape[i] <= 0) return fail(JCM_ERR_ARG, std::string("non-positive dimension in '") + name + "'");
@@ -707,6 +729,7 @@ int jcm_finalize(jcm_handle h) {
   JCM_TRY(check(h, false));
   if (h->finalized) return fail(JCM_ERR_STATE, "already finalized");
   DeviceGuard g(h->device);
+  CallOrder order(h);
   JCM_TRY(refresh_derived(h, true));
   h->finalized = true;
   return JCM_OK;
@@ -716,6 +739,7 @@ int jcm_conv_layer(jcm_handle h, const char* scope, int stride, int last_layer, 
   JCM_TRY(check(h, true));
   if (!scope || !x || !out || B < 1 || H < 1 || W < 1) return fail(JCM_ERR_ARG, "bad conv_layer arguments");
   DeviceGuard g(h->device);
+  CallOrder order(h);
   const ConvLayer* L = conv_of(h, scope);
   if (!L) return fail(JCM_ERR_STATE, std::string("no conv layer '") + scope + "'");
   if ((last_layer != 0) == L->has_bn)
@@ -741,6 +765,7 @@ int jcm_max_pool(jcm_handle h, const float* x, int B, int H, int W, int C, float
   JCM_TRY(check(h, false));
   if (!x || !out || B < 1 || H < 1 || W < 1 || C < 1 || C % 4) return fail(JCM_ERR_ARG, "bad max_pool arguments (C must be a multiple of 4)");
   DeviceGuard g(h->device);
+  CallOrder order(h);
   HIP_TRY(max_pool_2x2(x, out, false, B, H, W, C, h->stream));
   return JCM_OK;
 }
@@ -749,6 +774,7 @@ int jcm_resize_bilinear(jcm_handle h, const float* x, int B, int H, int W, int C
   JCM_TRY(check(h, false));
   if (!x || !out || B < 1 || H < 1 || W < 1 || C < 1 || OH < 1 || OW < 1) return fail(JCM_ERR_ARG, "bad resize arguments");
   DeviceGuard g(h->device);
+  CallOrder order(h);
   HIP_TRY(resize_bilinear(x, out, B, H, W, C, OH, OW, h->stream));
   return JCM_OK;
 }
@@ -757,6 +783,7 @@ int jcm_pd_forward(jcm_handle h, const float* x, int B, int H, int W, float* log
   JCM_TRY(check(h, true));
   if (!x || !logits_out || B < 1 || H < 8 || W < 8) return fail(JCM_ERR_ARG, "bad pd_forward arguments");
   DeviceGuard g(h->device);
+  CallOrder order(h);
   return with_arena(h, [&] { return pd_forward_impl(h, x, B, H, W, logits_out); });
 }
 
@@ -764,6 +791,7 @@ int jcm_spatial_softmax(jcm_handle h, const float* in, int B, int HW, int K, flo
   JCM_TRY(check(h, false));
   if (!in || !out || B < 1 || HW < 1 || K < 1) return fail(JCM_ERR_ARG, "bad spatial_softmax arguments");
   DeviceGuard g(h->device);
+  CallOrder order(h);
   HIP_TRY(softmax_argmax(in, out, nullptr, B, HW, 1, K, h->stream));   // one-pass kernel for K = 9 maps, general kernel otherwise
   return JCM_OK;
 }
@@ -772,6 +800,7 @@ int jcm_conv_mrf(jcm_handle h, const float* A, const float* Bmaps, int B, float*
   JCM_TRY(check(h, true));
   if (!A || !Bmaps || !out || B < 1) return fail(JCM_ERR_ARG, "bad conv_mrf arguments");
   DeviceGuard g(h->device);
+  CallOrder order(h);
   jcm_ctx* c = h;
   return with_arena(c, [&] {
     if (c->sm_algo == 1) {
@@ -803,6 +832,7 @@ int jcm_sm_forward(jcm_handle h, const float* hm10, int B, float* logits_out) {
   JCM_TRY(check(h, true));
   if (!hm10 || !logits_out || B < 1) return fail(JCM_ERR_ARG, "bad sm_forward arguments");
   DeviceGuard g(h->device);
+  CallOrder order(h);
   return with_arena(h, [&] { return sm_forward_impl(h, hm10, kC, nullptr, B, logits_out); });
 }
 
@@ -812,6 +842,7 @@ int jcm_softmax_argmax(jcm_handle h, const float* logits, int B, int HH, int WW,
   if (!prob && !(K == 9 && (HH * WW) % 4 == 0 && HH * WW <= 5632))
     return fail(JCM_ERR_ARG, "softmax_argmax without a probability output exists for K = 9 and H*W % 4 == 0, H*W <= 5632 only");
   DeviceGuard g(h->device);
+  CallOrder order(h);
   HIP_TRY(softmax_argmax(logits, prob, coords, B, HH * WW, WW, K, h->stream));
   return JCM_OK;
 }
@@ -820,6 +851,7 @@ int jcm_argmax_coords(jcm_handle h, const float* hm, int B, int HH, int WW, int 
   JCM_TRY(check(h, false));
   if (!hm || !coords || B < 1 || HH < 1 || WW < 1 || K < 1) return fail(JCM_ERR_ARG, "bad argmax arguments");
   DeviceGuard g(h->device);
+  CallOrder order(h);
   HIP_TRY(argmax_coords(hm, coords, B, HH * WW, WW, K, h->stream));
   return JCM_OK;
 }
@@ -836,6 +868,7 @@ static int forward_impl(jcm_handle h, const float* x, const float* torso, const 
   if (use_sm && (cdiv2(cdiv2(cdiv2(H))) != kHmH || cdiv2(cdiv2(cdiv2(W))) != kHmW))
     return fail(JCM_ERR_ARG, "the spatial model is defined for 60x90 heat maps (480x720 images) only");
   DeviceGuard g(h->device);
+  CallOrder order(h);
   jcm_ctx* c = h;
   const int K = c->K;
   if (use_sm && K + 1 != kC) return fail(JCM_ERR_ARG, "use_sm requires n_joints == 9 (10-channel spatial model)");
@@ -908,6 +941,7 @@ int jcm_window_resize(jcm_handle h, const float* src, int nsrc, int H, int W, in
     if (w[0] < 0 || w[0] >= nsrc || w[3] < 1 || w[4] < 1) return fail(JCM_ERR_ARG, "bad window " + std::to_string(i));
   }
   DeviceGuard g(h->device);
+  CallOrder order(h);
   jcm_ctx* c = h;
   return with_arena(c, [&] {
     int* wdev = arena_alloc<int>(c, (size_t)NW * 5);
@@ -924,6 +958,7 @@ int jcm_group_mean(jcm_handle h, const float* in, int n, int G, int64_t M, float
   JCM_TRY(check(h, false));
   if (!in || !out || n < 1 || G < 1 || M < 1) return fail(JCM_ERR_ARG, "bad group_mean arguments");
   DeviceGuard g(h->device);
+  CallOrder order(h);
   HIP_TRY(group_mean(in, out, n, G, (size_t)M, h->stream));
   return JCM_OK;
 }

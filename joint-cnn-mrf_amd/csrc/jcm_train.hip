@@ -497,6 +497,7 @@ int jcm_train_begin(jcm_handle h) {
   JCM_TRY(check(h, true));
   if (h->train) return fail(JCM_ERR_STATE, "jcm_train_begin was already called");
   DeviceGuard g(h->device);
+  CallOrder order(h);
   jcm_ctx* c = h;
   TrainState* t = new TrainState();
   c->train = t;
@@ -650,6 +651,7 @@ int jcm_train_loss_grads(jcm_handle h, const float* x, const float* y, int B, in
   if (!x || !y || !grads || !losses || B < 1 || H < 8 || W < 8) return fail(JCM_ERR_ARG, "bad train_loss_grads arguments");
   if (use_sm && !h->has_sm) return fail(JCM_ERR_STATE, "use_sm needs the spatial-model parameters");
   DeviceGuard g(h->device);
+  CallOrder order(h);
   jcm_ctx* c = h;
   HIP_TRY(hipMemsetAsync(grads, 0, c->train->total * sizeof(float), c->stream));   // tensors the loss does not reach keep a zero gradient
   return with_arena(c, [&] { return loss_grads_impl(c, x, y, B, H, W, use_sm, lmbd, grads, losses); });
@@ -660,6 +662,7 @@ int jcm_train_apply(jcm_handle h, const float* grads, int optimizer, float lr, f
   if (!grads || !(lr >= 0.f)) return fail(JCM_ERR_ARG, "bad train_apply arguments");
   if (optimizer != JCM_OPT_ADAM && optimizer != JCM_OPT_MOMENTUM) return fail(JCM_ERR_ARG, "wrong optimizer");   // main.py:506
   DeviceGuard g(h->device);
+  CallOrder order(h);
   jcm_ctx* c = h;
   TrainState* t = c->train;
   const bool clip = clip_norm > 0.f;
@@ -700,6 +703,7 @@ int jcm_train_get_state(jcm_handle h, int slot, float* out, int64_t count, int64
   TrainState* t = h->train;
   if (slot < 0 || slot > 1 || (out && count != (int64_t)t->total)) return fail(JCM_ERR_ARG, "bad train_get_state arguments");
   DeviceGuard g(h->device);
+  CallOrder order(h);
   if (out) {
     HIP_TRY(hipMemcpyAsync(out, slot ? t->opt_v : t->opt_m, t->total * sizeof(float), hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -713,6 +717,7 @@ int jcm_train_set_state(jcm_handle h, int slot, const float* data, int64_t count
   TrainState* t = h->train;
   if (slot < 0 || slot > 1 || (data && count != (int64_t)t->total) || n_iters < 0) return fail(JCM_ERR_ARG, "bad train_set_state arguments");
   DeviceGuard g(h->device);
+  CallOrder order(h);
   if (data) {
     HIP_TRY(hipMemcpyAsync(slot ? t->opt_v : t->opt_m, data, t->total * sizeof(float), hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));   // the caller may free `data` on return
@@ -734,6 +739,7 @@ int jcm_get_tensor(jcm_handle h, const char* name, float* out, int64_t count) {
   if (!t) return fail(JCM_ERR_STATE, std::string("no parameter '") + name + "'");
   if ((int64_t)t->n != count) return fail(JCM_ERR_ARG, std::string("'") + name + "' has " + std::to_string(t->n) + " elements");
   DeviceGuard g(h->device);
+  CallOrder order(h);
   HIP_TRY(hipMemcpyAsync(out, t->d, t->n * sizeof(float), hipMemcpyDefault, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return JCM_OK;
@@ -746,6 +752,7 @@ int jcm_update_tensor(jcm_handle h, const char* name, const float* data, int64_t
   if (it == h->params.end()) return fail(JCM_ERR_STATE, std::string("no parameter '") + name + "'");
   if ((int64_t)it->second.n != count) return fail(JCM_ERR_ARG, std::string("'") + name + "' has " + std::to_string(it->second.n) + " elements");
   DeviceGuard g(h->device);
+  CallOrder order(h);
   HIP_TRY(hipMemcpyAsync(it->second.d, data, it->second.n * sizeof(float), hipMemcpyDefault, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));   // the caller may free `data` on return
   if (refresh) {

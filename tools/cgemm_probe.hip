@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../joint-cnn-mrf_amd/csrc/cgemm_split.hip"
@@ -64,6 +65,57 @@ __global__ void pack_w(void* ws, int np, int f32, int ntl, int F, int Cin, int C
   }
 }
 
+// leaves NaN patterns in LDS and in the vector registers of every CU it visits (a wave that reads LDS or registers it never
+// wrote sees what the previous occupant left: its own kind when the kernel runs alone, this when it shares the chip)
+__global__ __launch_bounds__(256) void noise_kernel(float* sink, int rounds) {
+  extern __shared__ unsigned nlds[];
+  for (int i = threadIdx.x; i < 16 * 1024; i += 256) nlds[i] = 0x7fc00000u + i;
+  float v[96];
+#pragma unroll
+  for (int i = 0; i < 96; ++i) v[i] = __uint_as_float(0x7fc00000u + i + threadIdx.x);
+  float acc = 0.f;
+  for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+    for (int i = 0; i < 96; ++i) { v[i] = v[i] * 1.0001f + (float)r; acc += v[i]; }
+    __syncthreads();
+    acc += __uint_as_float(nlds[(threadIdx.x * 17 + r) & 16383]);
+  }
+  if (acc == 12345.f) sink[0] = acc;
+}
+
+// a victim: keeps a known pattern in 33 KB of LDS for a while and counts words that changed under it (somebody else's out-of-bounds LDS write)
+__global__ __launch_bounds__(512) void lds_guard_kernel(unsigned long long* bad, int rounds) {
+  __shared__ unsigned g[33 * 256];
+  for (int i = threadIdx.x; i < 33 * 256; i += 512) g[i] = 0xabc00000u ^ (i * 2654435761u);
+  __syncthreads();
+  unsigned long long n = 0;
+  for (int r = 0; r < rounds; ++r) {
+    for (int i = threadIdx.x; i < 33 * 256; i += 512) n += g[i] != (0xabc00000u ^ (i * 2654435761u));
+    __builtin_amdgcn_s_sleep(20);
+  }
+  if (n) atomicAdd(bad, n);
+}
+
+// producer -> consumer over a kernel boundary on one stream: the producer overwrites a buffer with a pattern that depends on the round,
+// the consumer (another kernel, same stream) counts words that are not the pattern.  Same access shapes as the column / row passes:
+// 8-byte stores of a wave = 512 contiguous bytes, 16-byte loads.
+__global__ __launch_bounds__(512) void chain_write(float2* buf, size_t n, unsigned round) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    buf[i] = make_float2(__uint_as_float((unsigned)i * 2654435761u + round), __uint_as_float((unsigned)i ^ round));
+}
+__global__ __launch_bounds__(384) void chain_check(const float4* buf, size_t n2, unsigned round, unsigned long long* bad) {
+  unsigned long long nb = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = buf[i];
+    const unsigned i0 = (unsigned)(2 * i), i1 = i0 + 1;
+    nb += __float_as_uint(v.x) != i0 * 2654435761u + round;
+    nb += __float_as_uint(v.y) != (i0 ^ round);
+    nb += __float_as_uint(v.z) != i1 * 2654435761u + round;
+    nb += __float_as_uint(v.w) != (i1 ^ round);
+  }
+  if (nb) atomicAdd(bad, nb);
+}
+
 int main(int argc, char** argv) {
   const int np = argc > 1 ? atoi(argv[1]) : 2, F = argc > 2 ? atoi(argv[2]) : 64, B = argc > 3 ? atoi(argv[3]) : 256;
   const int Cin = argc > 4 ? atoi(argv[4]) : 512, Cout = argc > 5 ? atoi(argv[5]) : 512, iters = argc > 6 ? atoi(argv[6]) : 5;
@@ -105,6 +157,42 @@ int main(int argc, char** argv) {
     scale = rms;
   }
   printf("np=%d F=%d B=%d Cin=%d Cout=%d MT=%d: worst error / typical |y| = %.3g (%d bad of 400; |y| ~ %.3g)\n", np, F, B, Cin, Cout, MT, worst, bad, scale);
+  // ---- two streams at once: the same product into two buffers, repeatedly; every result must equal the one computed alone
+  if (argc > 7) {
+    void* y2;
+    CK(hipMalloc(&y2, ybytes));
+    std::vector<char> ref(ybytes), got(ybytes);
+    CK(hipMemcpy(ref.data(), y, ybytes, hipMemcpyDeviceToHost));
+    hipStream_t s1, s2;
+    CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    int wrong = 0;
+    for (int it = 0; it < 10; ++it) {
+      CK(hipMemsetAsync(y, 0xff, ybytes, s1)); CK(hipMemsetAsync(y2, (argv[7][0] == 'g' || argv[7][0] == 'p') ? 0 : 0xff, argv[7][0] == 'p' ? 4096 : ybytes, s2));
+      for (int k = 0; k < 3; ++k) {
+        CK(jcm::cgemm_split(xs, ws, y, np, F, B, Cin, Cout, CoutP, s1));
+        if (argv[7][0] == 'n') hipLaunchKernelGGL(noise_kernel, dim3(4096), dim3(256), 64 * 1024, s2, (float*)y2, 40);
+        else if (argv[7][0] == 'g') hipLaunchKernelGGL(lds_guard_kernel, dim3(8192), dim3(512), 0, s2, (unsigned long long*)y2, 300);
+        else if (argv[7][0] == 'p') {      // a chain of 6 producer / consumer pairs beside the GEMM; the first 8 bytes of y2 count bad words
+          const size_t n = (ybytes - 4096) / 8;
+          for (int r = 0; r < 6; ++r) {
+            hipLaunchKernelGGL(chain_write, dim3(2048), dim3(512), 0, s2, (float2*)((char*)y2 + 4096), n, (unsigned)(it * 100 + k * 10 + r));
+            hipLaunchKernelGGL(chain_check, dim3(1024), dim3(384), 0, s2, (const float4*)((char*)y2 + 4096), n / 2, (unsigned)(it * 100 + k * 10 + r), (unsigned long long*)y2);
+          }
+        }
+        else CK(jcm::cgemm_split(xs, ws, y2, np, F, B, Cin, Cout, CoutP, s2));
+      }
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(got.data(), y, ybytes, hipMemcpyDeviceToHost));
+      size_t d1 = 0, d2 = 0;
+      for (size_t i = 0; i < ybytes / 8; ++i) d1 += memcmp(&got[i * 8], &ref[i * 8], 8) != 0;
+      CK(hipMemcpy(got.data(), y2, ybytes, hipMemcpyDeviceToHost));
+      if (argv[7][0] == 'g' || argv[7][0] == 'p') d2 = *reinterpret_cast<unsigned long long*>(got.data());      // LDS words the guard kernel saw change
+      else if (argv[7][0] != 'n') for (size_t i = 0; i < ybytes / 8; ++i) d2 += memcmp(&got[i * 8], &ref[i * 8], 8) != 0;
+      printf("  concurrent run %d: %zu / %zu outputs differ on stream 1, %zu on stream 2\n", it, d1, ybytes / 8, d2);
+      wrong += d1 + d2 != 0;
+    }
+    return wrong ? 3 : 0;
+  }
   // ---- timing
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
