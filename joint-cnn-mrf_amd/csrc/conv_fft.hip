@@ -235,7 +235,7 @@ size_t conv_fft_workspace_bytes(const ConvArgs& a, int ks, int np) {
 // sizes (always: the size depends on the map only), unpadded channel count, two row buffers in LDS.
 bool conv_fft_fusable(const ConvArgs& a, int ks, int ks_next) {
   Sizes s, n;
-  return sizes_of(a.H, a.W, ks, &s) && sizes_of(a.H, a.W, ks_next, &n) && s.NX == n.NX && s.NX <= 100 && a.Cout % CB == 0;
+  return sizes_of(a.H, a.W, ks, &s) && sizes_of(a.H, a.W, ks_next, &n) && s.NX == n.NX && a.Cout % CB == 0;
 }
 size_t conv_fft_handover_bytes(const ConvArgs& a, int ks) {      // T[kx][c/16][b][y][16] of the next layer
   Sizes s;

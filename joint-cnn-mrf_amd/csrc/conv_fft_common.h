@@ -8,7 +8,8 @@
 namespace jcm {
 namespace cfft {
 using namespace fftl;
-constexpr int CB = 64, NT = 256;      // channels per work group; kernel sizes 9 and 5 (pad = (ks - 1) / 2 passed at launch)
+constexpr int CB = 64, NT = 256;
+constexpr int kParMax = 512;      // channels whose epilogue parameters the inverse row kernels keep in LDS
 
 // radix chains (decimation in frequency, in place): the output X[n] sits at pos(n)
 template <int N> struct Plan;

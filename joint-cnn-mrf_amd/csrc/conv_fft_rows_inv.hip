@@ -14,8 +14,16 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_kernel(const cf* 
   constexpr int CH = CB / 2, NXH = NX / 2 + 1, NTR = rows_threads<NX>(), K = (NXH * CH + NTR - 1) / NTR;
   __shared__ cf buf[NX * CH];
   __shared__ cf tw[NX];
+  __shared__ float par[3 * kParMax];      // bias | scale | shift of every channel: the epilogue issues no global load, so nothing drains the prefetch
   const int tid = threadIdx.x, ncb = C / CB;
   twiddles<NX, NTR>(tw, twg, tid);
+  const bool par_lds = C <= kParMax;
+  if (par_lds)
+    for (int i = tid; i < C; i += NTR) {
+      par[i] = i < Cout ? bias[i] : 0.f;
+      par[kParMax + i] = relu_bn && i < Cout ? scale[i] : 1.f;
+      par[2 * kParMax + i] = relu_bn && i < Cout ? shift[i] : 0.f;
+    }
   float4 pre[K];
   auto fetch = [&](int tile) __attribute__((always_inline)) {
     const int cblk = tile % ncb, by = tile / ncb;      // by = b * H + y
@@ -51,9 +59,13 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_kernel(const cf* 
     const int v = tid % CH, c = cblk * CB + 2 * v;
     if (c < Cout) {
       const bool two = c + 1 < Cout, pairs = (Cout & 1) == 0;      // two channels = one aligned store
-      const float b0v = bias[c], b1v = two ? bias[c + 1] : 0.f;
-      float s0 = 1.f, s1 = 1.f, h0 = 0.f, h1 = 0.f;
-      if (relu_bn) { s0 = scale[c]; h0 = shift[c]; if (two) { s1 = scale[c + 1]; h1 = shift[c + 1]; } }
+      float b0v, b1v, s0 = 1.f, s1 = 1.f, h0 = 0.f, h1 = 0.f;
+      if (par_lds) {
+        b0v = par[c]; b1v = par[c + 1]; s0 = par[kParMax + c]; s1 = par[kParMax + c + 1]; h0 = par[2 * kParMax + c]; h1 = par[2 * kParMax + c + 1];
+      } else {
+        b0v = bias[c]; b1v = two ? bias[c + 1] : 0.f;
+        if (relu_bn) { s0 = scale[c]; h0 = shift[c]; if (two) { s1 = scale[c + 1]; h1 = shift[c + 1]; } }
+      }
       for (int x = tid / CH; x < W; x += NTR / CH) {
         const cf z = buf[pos<NX>(x + pad) * CH + v];
         float v0 = z.x * norm + b0v, v1 = z.y * norm + b1v;
@@ -77,52 +89,91 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_kernel(const cf* 
 }
 
 // ---- rows, inverse of layer L + epilogue + rows, forward of layer L+1 in one kernel (fp32 handles; same map, same NX, C % 64 == 0):
-// the activation between two frequency-domain layers never goes to HBM.  T_in[b][y][kx][c] -> T_out[b][kx][y][c].
-// The epilogue's result IS the next layer's packed input: channel pair (c, c+1) = one complex number.
+// the activation between two frequency-domain layers never goes to HBM.  T_in[b][y][kx][c] -> T_out[kx][c/16][b][y][16].
+// The epilogue's result IS the next layer's packed input: channel pair (c, c+1) = one complex number.  Persistent work groups with
+// register prefetch as rows_inv_kernel; the epilogue takes the row out of LDS into registers and writes the activated row back into the
+// SAME buffer (one row buffer instead of two: twice the work groups per CU).
 template <int NX>
 __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_fwd_kernel(const cf* __restrict__ T, cf* __restrict__ Tn, const cf* __restrict__ twg, const float* __restrict__ bias,
                                                           const float* __restrict__ scale, const float* __restrict__ shift, int relu_bn, int B, int H, int W, int C,
-                                                          int pad, float norm) {
-  constexpr int CH = CB / 2, NXH = NX / 2 + 1, NTR = rows_threads<NX>();
+                                                          int pad, float norm, int ntiles) {
+  constexpr int CH = CB / 2, NXH = NX / 2 + 1, NTR = rows_threads<NX>(), K = (NXH * CH + NTR - 1) / NTR, XP = NTR / CH, KX = (NX + XP - 1) / XP;
   __shared__ cf buf[NX * CH];
-  __shared__ cf nxt[NX * CH];
   __shared__ cf tw[NX];
-  const int tid = threadIdx.x;
-  const int cblk = blockIdx.x % (C / CB), by = blockIdx.x / (C / CB);
-  const int y = by % H, b = by / H;
+  __shared__ float par[3 * kParMax];
+  const int tid = threadIdx.x, ncb = C / CB;
   twiddles<NX, NTR>(tw, twg, tid);
-  const float4* src = reinterpret_cast<const float4*>(T + ((size_t)(b * H + y) * NXH) * C + cblk * CB);
-  for (int t = tid; t < NXH * CH; t += NTR) {
-    const int k = t / CH, v = t % CH;
-    float4 q = src[(size_t)k * (C / 2) + v];
-    const bool edge = k == 0 || k == NX / 2;
-    if (edge) { q.y = 0.f; q.w = 0.f; }
-    buf[k * CH + v] = cf{q.x - q.w, q.y + q.z};
-    if (!edge) buf[(NX - k) * CH + v] = cf{q.x + q.w, q.z - q.y};
-  }
-  __syncthreads();
-  fft<NX, 1, CH, NTR>(buf, tw, tid);
-  {
-    const int v = tid % CH, c = cblk * CB + 2 * v;
-    const float b0v = bias[c], b1v = bias[c + 1];
-    float s0 = 1.f, s1 = 1.f, h0 = 0.f, h1 = 0.f;
-    if (relu_bn) { s0 = scale[c]; h0 = shift[c]; s1 = scale[c + 1]; h1 = shift[c + 1]; }
-    for (int x = tid / CH; x < NX; x += NTR / CH) {
-      cf o = {0.f, 0.f};
-      if (x < W) {
-        const cf z = buf[pos<NX>(x + pad) * CH + v];
-        float v0 = z.x * norm + b0v, v1 = z.y * norm + b1v;
-        if (relu_bn) { v0 = fmaxf(v0, 0.f) * s0 + h0; v1 = fmaxf(v1, 0.f) * s1 + h1; }
-        o = cf{v0, v1};
-      }
-      nxt[x * CH + v] = o;
+  const bool par_lds = C <= kParMax;
+  if (par_lds)
+    for (int i = tid; i < C; i += NTR) {
+      par[i] = bias[i];
+      par[kParMax + i] = relu_bn ? scale[i] : 1.f;
+      par[2 * kParMax + i] = relu_bn ? shift[i] : 0.f;
     }
+  float4 pre[K];
+  auto fetch = [&](int tile) __attribute__((always_inline)) {
+    const int cblk = tile % ncb, by = tile / ncb;
+    const float4* src = reinterpret_cast<const float4*>(T + ((size_t)by * NXH) * C + cblk * CB);
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int t = tid + i * NTR, k = t / CH, v = t % CH;
+      pre[i] = t < NXH * CH ? src[(size_t)k * (C / 2) + v] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  while (tile < ntiles) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int t = tid + i * NTR, k = t / CH, v = t % CH;
+      if (t < NXH * CH) {
+        float4 q = pre[i];
+        const bool edge = k == 0 || k == NX / 2;
+        if (edge) { q.y = 0.f; q.w = 0.f; }
+        buf[k * CH + v] = cf{q.x - q.w, q.y + q.z};
+        if (!edge) buf[(NX - k) * CH + v] = cf{q.x + q.w, q.z - q.y};
+      }
+    }
+    const int next = tile + gridDim.x;
+    if (next < ntiles) fetch(next);
+    __syncthreads();
+    fft<NX, 1, CH, NTR>(buf, tw, tid);
+    const int cblk = tile % ncb, by = tile / ncb;
+    {
+      const int v = tid % CH, c = cblk * CB + 2 * v;
+      float b0v, b1v, s0 = 1.f, s1 = 1.f, h0 = 0.f, h1 = 0.f;
+      if (par_lds) {
+        b0v = par[c]; b1v = par[c + 1]; s0 = par[kParMax + c]; s1 = par[kParMax + c + 1]; h0 = par[2 * kParMax + c]; h1 = par[2 * kParMax + c + 1];
+      } else {
+        b0v = bias[c]; b1v = bias[c + 1];
+        if (relu_bn) { s0 = scale[c]; h0 = shift[c]; s1 = scale[c + 1]; h1 = shift[c + 1]; }
+      }
+      cf o[KX];
+#pragma unroll
+      for (int i = 0; i < KX; ++i) {
+        const int x = tid / CH + i * XP;
+        o[i] = cf{0.f, 0.f};
+        if (x < W) {
+          const cf z = buf[pos<NX>(x + pad) * CH + v];
+          float v0 = z.x * norm + b0v, v1 = z.y * norm + b1v;
+          if (relu_bn) { v0 = fmaxf(v0, 0.f) * s0 + h0; v1 = fmaxf(v1, 0.f) * s1 + h1; }
+          o[i] = cf{v0, v1};
+        }
+      }
+      __syncthreads();      // every wave has taken its part of the inverse row out of buf
+#pragma unroll
+      for (int i = 0; i < KX; ++i) {
+        const int x = tid / CH + i * XP;
+        if (x < NX) buf[x * CH + v] = o[i];
+      }
+    }
+    __syncthreads();
+    fft<NX, -1, CH, NTR>(buf, tw, tid);
+    rows_fwd_store<NX, NTR>(buf, Tn, tid, cblk, by / H, by % H, B, H, C);
+    __syncthreads();      // every wave is done reading buf
+    tile = next;
   }
-  __syncthreads();
-  fft<NX, -1, CH, NTR>(nxt, tw, tid);
-  rows_fwd_store<NX, NTR>(nxt, Tn, tid, cblk, b, y, B, H, C);
 }
-
 
 template <int NX> static void launch_rows_inv(const ConvArgs& a, int layout, const cf* T, const cf* tw, int pad, float norm, hipStream_t st) {
   const int ntiles = a.B * a.H * (a.CoutP / CB);
@@ -137,7 +188,9 @@ template <int NX> static void launch_rows_inv(const ConvArgs& a, int layout, con
     hipLaunchKernelGGL((rows_inv_kernel<NX, 2>), grid, dim3(rows_threads<NX>()), 0, st, T, a.out, tw, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm, ntiles);
 }
 template <int NX> static void launch_rows_inv_fwd(const ConvArgs& a, const cf* T, cf* Tn, const cf* tw, int pad, float norm, hipStream_t st) {
-  hipLaunchKernelGGL(rows_inv_fwd_kernel<NX>, dim3(a.B * a.H * (a.Cout / CB)), dim3(rows_threads<NX>()), 0, st, T, Tn, tw, a.bias, a.scale, a.shift, a.relu_bn, a.B, a.H, a.W, a.Cout, pad, norm);
+  const int ntiles = a.B * a.H * (a.Cout / CB);
+  const dim3 grid(persistent_grid(reinterpret_cast<const void*>(rows_inv_fwd_kernel<NX>), ntiles, rows_threads<NX>()));
+  hipLaunchKernelGGL(rows_inv_fwd_kernel<NX>, grid, dim3(rows_threads<NX>()), 0, st, T, Tn, tw, a.bias, a.scale, a.shift, a.relu_bn, a.B, a.H, a.W, a.Cout, pad, norm, ntiles);
 }
 void cfft_rows_inv(int NX, const ConvArgs& a, int layout, const cf* T, const cf* tw, int pad, float norm, hipStream_t st) {
 #define CALL(N) launch_rows_inv<N>(a, layout, T, tw, pad, norm, st)
