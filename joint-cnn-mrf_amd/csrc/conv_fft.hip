@@ -43,8 +43,9 @@ namespace cfft {
 template <int KS, int NP>
 __global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* __restrict__ w, uint4* __restrict__ Ws, int Cin, int Cout, int CoutP, int ntl, int NY, int NX,
                                                                    int round_bf16) {
+  constexpr int JQ = 8;      // frequencies (ky) per exchange through LDS: every thread stores, two barriers per 8 frequencies
   __shared__ cf twy[256], twx[256];
-  __shared__ cf sp[32][9];
+  __shared__ cf sp[JQ][32][9];
   const int tid = threadIdx.x;
   for (int k = tid; k < NY + NX; k += 256) {
     const bool isy = k < NY;
@@ -69,8 +70,8 @@ __global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* 
     }
   const int NXH = NX / 2 + 1, KC = Cin / 16, ntiles = CoutP / ntl;
   const int kc = ci8 >> 1, kg = ci8 & 1;
-  // the 64 storing threads: (column, re|im)
-  const int scol = tid & 31, sc = (tid >> 5) & 1;
+  // storing role of a thread: frequency j of the group, column scol; it writes the re and the im units of (column, this block's 8 channels)
+  const int sj = tid >> 5, scol = tid & 31;
   const int sco = co32 * 32 + scol, snt = sco / ntl, sn = sco % ntl;
   for (int kx = blockIdx.y; kx < NXH; kx += gridDim.y) {
     cf ra[KS];
@@ -81,27 +82,36 @@ __global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* 
       for (int b = 0; b < KS; ++b) s = sfma(g[a][b], twx[(kx * b) % NX], s);
       ra[a] = s;
     }
-    for (int ky = 0; ky < NY; ++ky) {
-      cf s = ra[0];
+    for (int ky0 = 0; ky0 < NY; ky0 += JQ) {
 #pragma unroll
-      for (int a = 1; a < KS; ++a) s = s + cmul(ra[a], twy[(ky * a) % NY]);
-      sp[col][cil] = s;
+      for (int j = 0; j < JQ; ++j) {
+        const int ky = ky0 + j;
+        if (ky < NY) {
+          cf s = ra[0];
+#pragma unroll
+          for (int a = 1; a < KS; ++a) s = s + cmul(ra[a], twy[(ky * a) % NY]);
+          sp[j][col][cil] = s;
+        }
+      }
       __syncthreads();
-      if (tid < 64) {
-        float x[8];
+      if (ky0 + sj < NY) {
+        const size_t f = (size_t)kx * NY + ky0 + sj;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = sc ? sp[scol][e].y : sp[scol][e].x;
-        const size_t f = (size_t)kx * NY + ky;
-        if constexpr (NP == 0) {
-          uint4* dst = Ws + ((((f * ntiles + snt) * KC + kc) * 2 + sc) * 2 + kg) * 2 * ntl + sn;
-          dst[0] = make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
-          dst[ntl] = make_uint4(__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7]));
-        } else {
-          uint4 u[NP > 0 ? NP : 1];
-          split8<(NP > 0 ? NP : 1)>(x, u);
-          uint4* dst = Ws + (((f * ntiles + snt) * KC + kc) * (4 * NP) + (sc * NP) * 2 + kg) * ntl + sn;
+        for (int sc = 0; sc < 2; ++sc) {
+          float x[8];
 #pragma unroll
-          for (int p = 0; p < NP; ++p) dst[(size_t)p * 2 * ntl] = u[p];
+          for (int e = 0; e < 8; ++e) x[e] = sc ? sp[sj][scol][e].y : sp[sj][scol][e].x;
+          if constexpr (NP == 0) {
+            uint4* dst = Ws + ((((f * ntiles + snt) * KC + kc) * 2 + sc) * 2 + kg) * 2 * ntl + sn;
+            dst[0] = make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
+            dst[ntl] = make_uint4(__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7]));
+          } else {
+            uint4 u[NP > 0 ? NP : 1];
+            split8<(NP > 0 ? NP : 1)>(x, u);
+            uint4* dst = Ws + (((f * ntiles + snt) * KC + kc) * (4 * NP) + (sc * NP) * 2 + kg) * ntl + sn;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) dst[(size_t)p * 2 * ntl] = u[p];
+          }
         }
       }
       __syncthreads();

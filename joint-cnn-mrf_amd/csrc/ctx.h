@@ -172,6 +172,11 @@ int refresh_derived(jcm_ctx* c, bool first);
 int prof_begin(jcm_ctx* c, hipEvent_t* e0, hipEvent_t* e1);
 void prof_end(jcm_ctx* c, const std::string& scope, hipEvent_t e0, hipEvent_t e1, bool ok);
 void prof_release_all(jcm_ctx* c, bool destroy);
+// frequency-domain route (jcm_api.hip): takes_fft() says whether a layer / shape goes there; run_conv_fft() runs it (filter spectra cached in
+// c->fft_w under "<scope>@HxW", packed from L->w_raw when missing or invalidated); the training step uses both for its data gradient.
+bool takes_fft(jcm_ctx* c, const ConvLayer* L, int B, int H, int W);
+bool fft_spectra_valid(jcm_ctx* c, const std::string& scope, int H, int W);
+int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const void* x, int B, int H, int W, void* out, int in_layout, int out_layout);
 int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int stride, const void* x, int B, int H, int W, int sub,
                    void* out, bool act_bf16, bool out_f32, int in_planar = 0, int out_planar = 0);   // bf16 layouts: ConvArgs in kernels.h
 

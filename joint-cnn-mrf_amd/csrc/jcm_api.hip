@@ -179,17 +179,21 @@ void prof_release_all(jcm_ctx* c, bool destroy) {
   }
 }
 
-// fp32 handles: does this stride-1 layer run in the frequency domain (conv_fft.hip)?  Not while a training state exists (the filter
-// spectra would have to follow every update).
+// Does this stride-1 layer run in the frequency domain (conv_fft.hip)?  fp32 handles: inference and the training step (forward and data
+// gradient; the filter spectra are recomputed after every update -- refresh_derived invalidates them); bf16 handles: inference only.
 bool takes_fft(jcm_ctx* c, const ConvLayer* L, int B, int H, int W) {
-  if (!c->conv9_fft || c->f32_conv != 0 || c->train || (L->ks != 9 && L->ks != 5) || L->cin == 3 || !L->w_raw) return false;
+  if (!c->conv9_fft || c->f32_conv != 0 || (c->train && c->precision != JCM_PRECISION_F32) || (L->ks != 9 && L->ks != 5) || L->cin == 3 || !L->w_raw) return false;
   // bf16 handles: the wide 9x9 layers only (the 5x5 layers and the logits layer are faster on their bf16 MFMA strip kernels)
   if (c->precision == JCM_PRECISION_BF16 && (L->ks != 9 || L->thin_bf16 || L->cout % 8)) return false;
   ConvArgs a{};
   a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout;
   return conv_fft_supported(a, L->ks);
 }
-static int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const void* x, int B, int H, int W, void* out, int in_layout, int out_layout) {
+bool fft_spectra_valid(jcm_ctx* c, const std::string& scope, int H, int W) {
+  auto it = c->fft_w.find(scope + "@" + std::to_string(H) + "x" + std::to_string(W));
+  return it != c->fft_w.end() && it->second.valid;
+}
+int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const void* x, int B, int H, int W, void* out, int in_layout, int out_layout) {
   ConvArgs a{};
   a.x = x; a.bias = L->bias; a.scale = L->scale; a.shift = L->shift; a.out = out;
   a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout; a.CoutP = L->cout; a.relu_bn = L->has_bn ? 1 : 0;

@@ -212,9 +212,22 @@ int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int ldz, int B, fl
 
 // dX = conv_SAME(dZ, flipped weights): [B,H,W,ldz] -> [B,H,W,Cin]
 int conv_dgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int B, void* dx) {
-  if (c->dry) return JCM_OK;
   TrainState* t = c->train;
   const DgradW& d = t->dgrad[f.scope];
+  if (!bf(c)) {
+    // fp32 handles: the data gradient is a SAME correlation with the flipped, transposed filter -- in the frequency domain like the forward
+    // pass (conv_fft.hip); its filter spectra ("dgrad:<scope>") are packed from the flipped weights after every update, on first use.
+    ConvLayer Ld;
+    Ld.ks = f.L->ks; Ld.cin = d.cinp; Ld.cout = f.L->cin; Ld.has_bn = false;
+    Ld.w_raw = t->scratch_flip; Ld.bias = t->zeros; Ld.scale = t->ones; Ld.shift = t->zeros;
+    if (takes_fft(c, &Ld, B, f.H, f.W)) {
+      const std::string key = "dgrad:" + f.scope;
+      if (!c->dry && !fft_spectra_valid(c, key, f.H, f.W))
+        HIP_TRY(flip_transpose_weights(f.L->w_raw, t->scratch_flip, f.L->ks, f.L->cin, f.L->cout, d.cinp, c->stream));
+      return run_conv_fft(c, &Ld, key, dz, B, f.H, f.W, dx, 0, 0);
+    }
+  }
+  if (c->dry) return JCM_OK;
   ConvArgs a;
   if (bf(c)) {      // bf16 gradients through the bf16 forward kernels on flipped weights
     a.x = dz; a.wp = d.wd_bf16; a.bias = t->zeros; a.scale = t->ones; a.shift = t->zeros; a.out = dx;
