@@ -257,8 +257,11 @@ size_t conv_fft_handover_bytes(const ConvArgs& a, int ks) {      // T[kx][c/16][
 // in_layout / out_layout: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar
 // t_in (fp32 handles): the row-transformed input left by the previous layer's fused kernel -- the forward row pass is skipped;
 // t_next: write the NEXT layer's row-transformed input there instead of the spatial output (conv_fft_fusable() says when that is legal).
+// xs (optional): where the split activation spectra of the layer's input live instead of the scratch -- the training step keeps them for the
+// weight gradient (wgrad_fft.hip); xs_ready: they are there already (the data gradient after the weight gradient of the same layer): the
+// forward transforms are skipped.
 hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int out_layout, void* work, const void* t_in, void* t_next, const FftMerge* merge,
-                        hipEvent_t g0, hipEvent_t g1, hipStream_t st) {
+                        hipEvent_t g0, hipEvent_t g1, hipStream_t st, void* xs, bool xs_ready) {
   Sizes s;
   if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s) || (out_layout == 2 && a0.Cout % 8) || (np != 2 && np != 3)) return hipErrorInvalidValue;
   if ((t_in || t_next || merge) && (in_layout != 0 || out_layout != 0 || (t_next && a0.Cout % CB))) return hipErrorInvalidValue;
@@ -268,8 +271,9 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
   const Plan3 p = plan_of(a, s, np);
   char* wk = static_cast<char*>(work);
   cf* T = reinterpret_cast<cf*>(wk);
-  void* Xs = wk + align256(p.t_bytes);
+  void* Xs = xs ? xs : wk + align256(p.t_bytes);
   cf* Yf = reinterpret_cast<cf*>(wk + align256(p.t_bytes) + align256(p.xs_bytes));
+  if (xs_ready && !xs) return hipErrorInvalidValue;
   int dev = 0;
   if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
   const cf* twb = twiddle_table(dev);
@@ -278,12 +282,14 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
   const cf* twy = twb + tw_offset(s.NY);
   const float norm = 1.0f / (float)(s.NY * s.NX);
   const cf* Tin = t_in ? static_cast<const cf*>(t_in) : T;
-  if (merge && !t_in) {
-    cfft_rows_fwd_merge(s.NX, a, *merge, T, twx, st);
-  } else if (!t_in) {
-    cfft_rows_fwd(s.NX, a, in_layout, T, twx, st);
+  if (!xs_ready) {
+    if (merge && !t_in) {
+      cfft_rows_fwd_merge(s.NX, a, *merge, T, twx, st);
+    } else if (!t_in) {
+      cfft_rows_fwd(s.NX, a, in_layout, T, twx, st);
+    }
+    if (hipError_t ce = cfft_cols_fwd(s.NY, a, np, Tin, Xs, twy, p.NXH, p.MT, st); ce != hipSuccess) return ce;
   }
-  if (hipError_t ce = cfft_cols_fwd(s.NY, a, np, Tin, Xs, twy, p.NXH, p.MT, st); ce != hipSuccess) return ce;
   if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
   if (g0 && hipEventRecord(g0, st) != hipSuccess) return hipErrorUnknown;
   if (hipError_t e = cgemm_split(Xs, a.wp, Yf, np, p.F, a.B, a.Cin, a.Cout, p.ldy, st); e != hipSuccess) return e;
@@ -295,6 +301,35 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
     cfft_rows_inv(s.NX, a, out_layout, T, twx, opad, norm, st);
   }
   return hipGetLastError();
+}
+
+// the split spectra of an NHWC fp32 tensor alone (rows + columns forward): xs = conv_fft_xs_bytes() bytes, work = conv_fft_workspace_bytes()
+size_t conv_fft_xs_bytes(const ConvArgs& a, int ks, int np) {
+  Sizes s;
+  if (!sizes_of(a.H, a.W, ks, &s)) return 0;
+  return align256(plan_of(a, s, np).xs_bytes);
+}
+hipError_t conv_fft_spectra(const ConvArgs& a0, int ks, int np, void* work, void* xs, hipStream_t st) {
+  Sizes s;
+  if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s) || !xs) return hipErrorInvalidValue;
+  ConvArgs a = a0;
+  a.CoutP = pad64(a.Cout);
+  const Plan3 p = plan_of(a, s, np);
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+  const cf* twb = twiddle_table(dev);
+  if (!twb) return hipErrorOutOfMemory;
+  cf* T = static_cast<cf*>(work);
+  cfft_rows_fwd(s.NX, a, 0, T, twb + tw_offset(s.NX), st);
+  if (hipError_t ce = cfft_cols_fwd(s.NY, a, np, T, xs, twb + tw_offset(s.NY), p.NXH, p.MT, st); ce != hipSuccess) return ce;
+  return hipGetLastError();
+}
+// geometry of the spectra for the weight-gradient kernels
+bool conv_fft_geometry(int H, int W, int ks, int B, int Cout, int np, int* NY, int* NX, int* MT) {
+  Sizes s;
+  if (!sizes_of(H, W, ks, &s)) return false;
+  *NY = s.NY; *NX = s.NX; *MT = cgemm_split_mtile(np, B, Cout);
+  return true;
 }
 
 }  // namespace jcm

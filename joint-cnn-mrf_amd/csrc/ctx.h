@@ -101,6 +101,8 @@ struct jcm_ctx {
   // transient, set by jcm_pd_forward around two consecutive frequency-domain layers: the first writes the second's row-transformed input
   void* fft_t_next = nullptr;
   const void* fft_t_in = nullptr;
+  void* fft_xs = nullptr;            // transient: the next frequency-domain layer keeps its split input spectra here (training step: the weight gradient reads them)
+  bool fft_xs_ready = false;         // ... they are there already (data gradient after the weight gradient of the same layer): skip the forward transforms
   const void* fft_merge = nullptr;   // const jcm::FftMerge*: the next frequency-domain layer forms the merged map itself (jcm_pd_forward, conv5)
   int conv9_fft = 1;            // fp32 handles: wide 9x9 layers in the frequency domain (conv_fft.hip) when the shape allows; 0 = fp32 MFMA chain
   struct FftW { void* p = nullptr; size_t bytes = 0; bool valid = false; };

@@ -201,7 +201,7 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
   const int np = c->precision == JCM_PRECISION_BF16 ? 2 : 3;      // bf16 parts per operand of the channel GEMM (cgemm_split.hip)
   void* work = arena_alloc<char>(c, conv_fft_workspace_bytes(a, L->ks, np));
   c->arena_off = mark;                                   // scratch of this layer only: later layers run behind it on the stream
-  if (c->dry) { c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; return JCM_OK; }
+  if (c->dry) { c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; c->fft_xs = nullptr; c->fft_xs_ready = false; return JCM_OK; }
   // Filter spectra are cached per (layer, map size).  The cache is bounded (JCM_FFT_CACHE_GB, default 64): a caller that walks many
   // image sizes (7.7 GB per size for conv5) makes it drop every spectrum that is not this layer's before it grows past the bound.
   const std::string key = scope + "@" + std::to_string(H) + "x" + std::to_string(W);
@@ -236,8 +236,10 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
   const void* t_in = c->fft_t_in;
   void* t_next = c->fft_t_next;
   const FftMerge* mg = static_cast<const FftMerge*>(c->fft_merge);
-  c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr;
-  const hipError_t e = conv_fft_f32(a, L->ks, np, in_layout, out_layout, work, t_in, t_next, mg, g0, g1, c->stream);
+  void* xs = c->fft_xs;
+  const bool xs_ready = c->fft_xs_ready;
+  c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; c->fft_xs = nullptr; c->fft_xs_ready = false;
+  const hipError_t e = conv_fft_f32(a, L->ks, np, in_layout, out_layout, work, t_in, t_next, mg, g0, g1, c->stream, xs, xs_ready);
   if (g0 && g1 && e == hipSuccess) c->prof[scope + "/gemm"].emplace_back(g0, g1);
   else { if (g0) c->event_pool.push_back(g0); if (g1) c->event_pool.push_back(g1); }
   prof_end(c, scope, e0, e1, e == hipSuccess);

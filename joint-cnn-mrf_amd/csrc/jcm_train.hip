@@ -43,6 +43,8 @@ struct TrainState {
   std::map<std::string, DgradW> dgrad;
   std::map<std::string, BnSave> bn;
   float* scratch_flip = nullptr;       // largest flipped HWIO weight
+  void* zs = nullptr;                  // split spectra of the dz the last conv_wgrad saw (frequency-domain route), for the conv_dgrad that follows
+  const void* zs_of = nullptr;
   double* red = nullptr;               // per-channel reduction scratch
   double* sumsq = nullptr;             // [2]: grad sum of squares, weight sum of squares (l2)
   float* small = nullptr;              // [2*maxC + 64] misc
@@ -123,6 +125,7 @@ struct LayerFwd {
   int H = 0, W = 0;            // output map
   void* r = nullptr;
   void* y = nullptr;
+  void* xs = nullptr;          // fp32 handles, frequency-domain layers: the split spectra of the input, kept for the weight gradient (wgrad_fft.hip)
 };
 
 int conv_train_fwd(jcm_ctx* c, LayerFwd& f, int stride, const void* x, int B, int Hin, int Win, int sub) {
@@ -137,6 +140,12 @@ int conv_train_fwd(jcm_ctx* c, LayerFwd& f, int stride, const void* x, int B, in
   ConvLayer L = *f.L;
   L.scale = t->ones;       // epilogue = relu(z + b) * 1 + 0
   L.shift = t->zeros;
+  if (stride == 1 && !bf(c) && takes_fft(c, &L, B, Hin, Win)) {      // keep the input spectra: the weight gradient is taken in the frequency domain too
+    ConvArgs ax{};
+    ax.B = B; ax.H = Hin; ax.W = Win; ax.Cin = L.cin; ax.Cout = L.cout;
+    f.xs = arena_alloc<char>(c, conv_fft_xs_bytes(ax, L.ks, 3));
+    c->fft_xs = f.xs;
+  }
   JCM_TRY(run_conv_layer(c, &L, f.scope, stride, x, B, Hin, Win, sub, f.r, bf(c), !f.L->has_bn));
   if (!f.L->has_bn) { f.y = f.r; return JCM_OK; }
   f.y = act(c, N * f.L->cout);
@@ -172,6 +181,37 @@ int conv_train_bwd_pre(jcm_ctx* c, const LayerFwd& f, const void* dy, float dy_s
 int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int ldz, int B, float lmbd, float* grads) {
   TrainState* t = c->train;
   const ConvLayer* L = f.L;
+  t->zs = nullptr;
+  const auto dg = t->dgrad.find(f.scope);
+  if (f.xs && !bf(c) && ldz == L->cout && (dg == t->dgrad.end() || dg->second.cinp == ldz)) {
+    // frequency domain (wgrad_fft.hip): spectra of dz (kept in t->zs for the data gradient that follows), P[f] = conj(X)^T dZ per frequency, k x k taps
+    ConvLayer Lz;      // dz as the input of a frequency-domain layer: the same pseudo-layer conv_dgrad runs
+    Lz.ks = L->ks; Lz.cin = ldz; Lz.cout = L->cin; Lz.has_bn = false; Lz.w_raw = t->scratch_flip;
+    int NY = 0, NX = 0, MTx = 0, MTz = 0, ny2 = 0, nx2 = 0;
+    if (takes_fft(c, &Lz, B, f.H, f.W) && conv_fft_geometry(f.H, f.W, L->ks, B, L->cout, 3, &NY, &NX, &MTx) &&
+        conv_fft_geometry(f.H, f.W, L->ks, B, L->cin, 3, &ny2, &nx2, &MTz)) {
+      ConvArgs az{};
+      az.x = dz; az.B = B; az.H = f.H; az.W = f.W; az.Cin = ldz; az.Cout = L->cin;
+      char* zs = arena_alloc<char>(c, conv_fft_xs_bytes(az, L->ks, 3));      // stays allocated: conv_dgrad of this layer reads it
+      const size_t mark = c->arena_off;
+      char* work = arena_alloc<char>(c, conv_fft_workspace_bytes(az, L->ks, 3));
+      char* P = arena_alloc<char>(c, wgrad_fft_scratch_bytes(NY, NX, L->cin, L->cout));
+      if (!c->dry) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        JCM_TRY(prof_begin(c, &e0, &e1));
+        hipError_t le = conv_fft_spectra(az, L->ks, 3, work, zs, c->stream);
+        if (le == hipSuccess)
+          le = wgrad_fft(f.xs, zs, P, L->w_raw, lmbd, grad_of(t, grads, f.scope + "/weights"), L->ks, NY, NX, B, MTx, MTz, L->cin, L->cout, c->stream);
+        prof_end(c, "wgrad:" + f.scope, e0, e1, le == hipSuccess);
+        if (le != hipSuccess) return fail(JCM_ERR_HIP, "frequency-domain weight gradient of '" + f.scope + "': " + hipGetErrorString(le));
+        t->zs = zs;
+        t->zs_of = dz;
+      }
+      c->arena_off = mark;
+      notify_ready(c, f.scope + "/");
+      return JCM_OK;
+    }
+  }
   const size_t n = (size_t)L->ks * L->ks * L->cin * L->cout;
   const int splits = wgrad_splits(L->ks, L->cin, L->cout, B, f.H);
   const size_t mark = c->arena_off;
@@ -224,6 +264,8 @@ int conv_dgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int B, void* dx) {
       const std::string key = "dgrad:" + f.scope;
       if (!c->dry && !fft_spectra_valid(c, key, f.H, f.W))
         HIP_TRY(flip_transpose_weights(f.L->w_raw, t->scratch_flip, f.L->ks, f.L->cin, f.L->cout, d.cinp, c->stream));
+      if (!c->dry && t->zs && t->zs_of == dz) { c->fft_xs = t->zs; c->fft_xs_ready = true; }      // the spectra of dz are there (conv_wgrad just made them)
+      t->zs = nullptr;
       return run_conv_fft(c, &Ld, key, dz, B, f.H, f.W, dx, 0, 0);
     }
   }

@@ -83,8 +83,19 @@ size_t conv_fft_workspace_bytes(const ConvArgs& a, int ks, int np);
 // t_in / t_next: the row-transformed tensor handed from one frequency-domain layer to the next (fp32 NHWC handles; conv_fft_fusable).
 // merge: a.x is the full-resolution branch x1 and the layer's input is ((x1 + up(x2)) + up(x3)) / 3, formed while the rows are loaded.
 struct FftMerge { const float* x2; int H2, W2; const float* x3; int H3, W3; };
+// xs / xs_ready: keep the split activation spectra in a caller buffer (conv_fft_xs_bytes) / they are there already (skip the forward transforms)
 hipError_t conv_fft_f32(const ConvArgs& a, int ks, int np, int in_layout, int out_layout, void* work, const void* t_in, void* t_next, const FftMerge* merge,
-                        hipEvent_t g0, hipEvent_t g1, hipStream_t st);
+                        hipEvent_t g0, hipEvent_t g1, hipStream_t st, void* xs = nullptr, bool xs_ready = false);
+size_t conv_fft_xs_bytes(const ConvArgs& a, int ks, int np);
+hipError_t conv_fft_spectra(const ConvArgs& a, int ks, int np, void* work, void* xs, hipStream_t st);      // NHWC fp32 -> split spectra (the two forward passes)
+bool conv_fft_geometry(int H, int W, int ks, int B, int Cout, int np, int* NY, int* NX, int* MT);
+
+// ---- wgrad_fft.hip : weight gradient of a stride-1 layer in the frequency domain (fp32 handles, training step): per frequency
+// P[f][ci][co] = sum_b conj(X[f][b][ci]) dZ[f][b][co] on v_mfma_f32_32x32x16_bf16 from the split spectra of the layer input (kept by the forward pass)
+// and of dZ, then the k x k taps are read off the inverse transform:  dw = taps(P) / (NY NX) + lmbd * w.   xs / zs: np = 3 layouts of cgemm_split.hip
+size_t wgrad_fft_scratch_bytes(int NY, int NX, int Cin, int Cout);
+hipError_t wgrad_fft(const void* xs, const void* zs, void* scratch, const float* w, float lmbd, float* dw, int ks, int NY, int NX, int B, int MTx, int MTz, int Cin,
+                     int Cout, hipStream_t st);
 bool conv_fft_fusable(const ConvArgs& a, int ks, int ks_next);
 size_t conv_fft_handover_bytes(const ConvArgs& a, int ks);
 

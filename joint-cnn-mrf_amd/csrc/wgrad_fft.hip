@@ -1,0 +1,239 @@
+// Weight gradient of a stride-1 SAME convolution in the FREQUENCY domain (fp32 handles, training step; reference: the gradient of
+// conv2d in main.py:133-135 that tf.gradients builds at main.py:557-560).
+//
+// With X = transform of the layer input and dZ = transform of the gradient of the layer output (both zero-padded to the circular size
+// NY x NX of conv_fft.hip, both at the origin), the cross-correlation theorem gives, for every lag (ly, lx),
+//     C[ly][lx] = sum_{b,y,x} dz[b][y][x] x[b][y - ly][x - lx] = 1/(NY NX) sum_f P[f] e^{+2 pi i (ky ly / NY + kx lx / NX)},
+//     P[f][ci][co] = sum_b conj(X[f][b][ci]) dZ[f][b][co],
+// alias-free for |l| <= pad because NY >= H + pad (the same argument as the forward pass), and dw[j][i] = C[pad - j][pad - i].
+//
+//   wgrad_spec_kernel : P for every frequency = one complex [Cin x B] x [B x Cout] product -- K is the BATCH (16 images per GPU:
+//                       one k16 step), so the kernel is bound by writing P (8 bytes per (f, ci, co)).  Operands are the split spectra the
+//                       forward transforms already produced for the channel GEMM (cgemm_split.hip: units of 8 CHANNELS of one image);
+//                       the MFMA wants 8 IMAGES of one channel per lane, which is what gfx950's transposing LDS read delivers
+//                       (ds_read_b64_tr_b16, as in wgrad_split.hip): the units are staged as they lie, [image][channel], and read transposed.
+//                       Three bf16 parts per operand, six products: fp32-class, like the forward pass.
+//   wgrad_taps_kernel : one thread per (ci, co): the k x k taps of the inverse transform, separable -- k row sums over ky in double for
+//                       each kx, folded into k x k column sums with the Hermitian weights of the half spectrum -- + lmbd * w.
+#include "kernels.h"
+
+namespace jcm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace wf {
+constexpr int TM = 128, TN = 128, NT = 256, NP = 3;
+constexpr int PITCH = 2 * TM + 16;                 // bytes per image row of an LDS plane: 128 channels + one 16-byte pad (rows 4 apart hit different banks)
+constexpr int PLANE = 16 * PITCH;                  // one (re|im, part) plane: 16 images
+constexpr int OPER = 2 * NP * PLANE;               // one operand
+constexpr int LDS_BYTES = 2 * OPER;
+
+struct Args {
+  const uint4* xs;      // [f][mtile][Cin/16][re|im][part][k-half][MT][8]
+  const uint4* zs;      // [f][mtile][Cout/16][...]
+  float2* P;            // [f][Cin][Cout]
+  int F, B, MTx, MTz, Cin, Cout;      // MTx / MTz: rows per M tile of the two spectra (cgemm_split_mtile of the GEMM each was laid out for)
+};
+
+__device__ __forceinline__ u32x2 tr_read(unsigned addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+// the 8 images (k) x 32 channels fragment of plane `pl` whose first channel is ch0: two transposing reads (images 0..3, 4..7 of the lane's
+// k half); the caller waits once for all the fragments of a product
+struct Frag { u32x2 lo, hi; };
+__device__ __forceinline__ Frag frag_read(unsigned base, int pl, int ch0, unsigned lane_off) {
+  const unsigned a = base + (unsigned)(pl * PLANE + ch0 * 2) + lane_off;
+  Frag f;
+  f.lo = tr_read(a);
+  f.hi = tr_read(a + 4 * PITCH);
+  return f;
+}
+__device__ __forceinline__ bf16x8 frag_pack(const Frag& f) {
+  const u32x4 r = {f.lo.x, f.lo.y, f.hi.x, f.hi.y};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+__global__ __launch_bounds__(NT) void wgrad_spec_kernel(Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tiles_n = (a.Cout + TN - 1) / TN, tiles_m = (a.Cin + TM - 1) / TM;
+  const int tile = blockIdx.x % (tiles_m * tiles_n), f = blockIdx.x / (tiles_m * tiles_n);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int KCi = a.Cin / 16, KCo = a.Cout / 16;
+  const int rows_valid = (a.B + 3) / 4 * 4;      // the forward column pass writes whole groups of 4 or 8 images (zeros behind the last one): rows it surely wrote
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  // transposing read: in each 16-lane group g, lane t supplies the 8-byte piece (image t/4, channels 4(t%4)..+3) of a 4 x 16 block and
+  // receives channel t of it; group g -> channel block g&1, k half g>>1 (the MFMA operand lane l holds row/column l&31, k half l>>5)
+  const int g = lane >> 4, t = lane & 15;
+  const unsigned lane_off = (unsigned)((8 * (g >> 1) + (t >> 2)) * PITCH + (16 * (g & 1) + 4 * (t & 3)) * 2);
+
+  f32x16 pr[2][2], pi[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { pr[i][j][e] = 0.f; pi[i][j][e] = 0.f; }
+
+  for (int r0 = 0; r0 < rows_valid; r0 += 16) {      // (16 divides both tile heights: a step never straddles two M tiles)
+    __syncthreads();      // the previous step's fragments have been read
+    // stage both operands: (8 chunks x re|im x part x k-half) segments of 16 images x 16 bytes, as they lie in HBM
+    for (int idx = tid; idx < 2 * 96 * 16; idx += NT) {
+      const int op = idx / (96 * 16), r = idx - op * 96 * 16;
+      const int seg = r >> 4, j = r & 15;
+      const int kg = seg & 1, cp = (seg >> 1) % 6, kcl = seg / 12;      // cp = re|im * 3 + part
+      const int KC = op ? KCo : KCi, kc = (op ? tn : tm) * 8 + kcl;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (kc < KC && r0 + j < rows_valid) {
+        const uint4* src = op ? a.zs : a.xs;
+        const int MT = op ? a.MTz : a.MTx, mtiles = (a.B + MT - 1) / MT, mt = r0 / MT, rl = r0 - mt * MT;
+        v = src[((((size_t)f * mtiles + mt) * KC + kc) * (4 * NP) + cp * 2 + kg) * MT + rl + j];
+      }
+      *reinterpret_cast<uint4*>(smem + op * OPER + (cp * 16 + j) * PITCH + (kcl * 16 + kg * 8) * 2) = v;
+    }
+    __syncthreads();
+    // six products: (x part, z part) with px + pz <= 2, small terms first
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      const int px = s == 0 ? 0 : s == 1 ? 1 : s == 2 ? 2 : s == 3 ? 1 : 0, pz = s == 0 ? 2 : s == 1 ? 1 : s == 2 ? 0 : s == 3 ? 0 : s == 4 ? 1 : 0;
+      Frag fxr[2], fxi[2], fzr[2], fzi[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fxr[i] = frag_read(lds0, 0 * NP + px, (wm * 2 + i) * 32, lane_off);
+        fxi[i] = frag_read(lds0, 1 * NP + px, (wm * 2 + i) * 32, lane_off);
+        fzr[i] = frag_read(lds0 + OPER, 0 * NP + pz, (wn * 2 + i) * 32, lane_off);
+        fzi[i] = frag_read(lds0 + OPER, 1 * NP + pz, (wn * 2 + i) * 32, lane_off);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 xr[2], xi[2], nxi[2], zr[2], zi[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        xr[i] = frag_pack(fxr[i]); xi[i] = frag_pack(fxi[i]); zr[i] = frag_pack(fzr[i]); zi[i] = frag_pack(fzi[i]);
+        const u32x4 n = __builtin_bit_cast(u32x4, xi[i]) ^ u32x4{0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
+        nxi[i] = __builtin_bit_cast(bf16x8, n);
+      }
+      // P = conj(X)^T dZ:  Pr += Xr Zr + Xi Zi,  Pi += Xr Zi - Xi Zr
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          pr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xr[i], zr[j], pr[i][j], 0, 0, 0);
+          pi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xr[i], zi[j], pi[i][j], 0, 0, 0);
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          pr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xi[i], zi[j], pr[i][j], 0, 0, 0);
+          pi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nxi[i], zr[j], pi[i][j], 0, 0, 0);
+        }
+    }
+  }
+  // ---- P[f][ci][co]: accumulator register e is row (ci) (e&3) + 8 (e>>2) + 4 (lane>>5), column (co) lane&31
+  const int h = lane >> 5, l31 = lane & 31;
+  float2* pf = a.P + (size_t)f * a.Cin * a.Cout;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ci = tm * TM + (wm * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (ci < a.Cin) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int co = tn * TN + (wn * 2 + j) * 32 + l31;
+          if (co < a.Cout) pf[(size_t)ci * a.Cout + co] = make_float2(pr[i][j][e], pi[i][j][e]);
+        }
+      }
+    }
+}
+
+// ---- taps: dw[j][i][ci][co] = 1/(NY NX) sum_{ky, kx <= NX/2} wgt(kx) Re(P[ky][kx] e^{+2 pi i (ky (pad - j) / NY + kx (pad - i) / NX)}) + lmbd w
+template <int KS>
+__global__ __launch_bounds__(256) void wgrad_taps_kernel(const float2* __restrict__ P, const float* __restrict__ w, float* __restrict__ dw, int Cin, int Cout, int NY, int NX,
+                                                         float lmbd) {
+  constexpr int PAD = (KS - 1) / 2;
+  __shared__ double2 twy[192 * KS];       // e^{+2 pi i ky l / NY}, l = PAD - j
+  __shared__ double2 twx[97 * KS];        // wgt(kx) e^{+2 pi i kx l / NX} / (NY NX)
+  const int NXH = NX / 2 + 1;
+  for (int i = threadIdx.x; i < NY * KS; i += 256) {
+    const int ky = i / KS, l = PAD - i % KS;
+    double sn, cs;
+    sincospi(2.0 * (double)(((long long)ky * l) % NY) / (double)NY, &sn, &cs);
+    twy[i] = double2{cs, sn};
+  }
+  for (int i = threadIdx.x; i < NXH * KS; i += 256) {
+    const int kx = i / KS, l = PAD - i % KS;
+    double sn, cs;
+    sincospi(2.0 * (double)(((long long)kx * l) % NX) / (double)NX, &sn, &cs);
+    const double wgt = ((kx == 0 || 2 * kx == NX) ? 1.0 : 2.0) / ((double)NY * (double)NX);
+    twx[i] = double2{cs * wgt, sn * wgt};
+  }
+  __syncthreads();
+  const size_t n = (size_t)Cin * Cout, e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  float acc[KS][KS];
+#pragma unroll
+  for (int j = 0; j < KS; ++j)
+#pragma unroll
+    for (int i = 0; i < KS; ++i) acc[j][i] = 0.f;
+  for (int kx = 0; kx < NXH; ++kx) {
+    double2 R[KS];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) R[j] = double2{0.0, 0.0};
+    const float2* col = P + ((size_t)kx * NY) * n + e;
+#pragma unroll 4
+    for (int ky = 0; ky < NY; ++ky) {
+      const float2 p = col[(size_t)ky * n];
+      const double prr = p.x, pii = p.y;
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        const double2 t = twy[ky * KS + j];
+        R[j].x += prr * t.x - pii * t.y;
+        R[j].y += prr * t.y + pii * t.x;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+#pragma unroll
+      for (int i = 0; i < KS; ++i) {
+        const double2 t = twx[kx * KS + i];
+        acc[j][i] += (float)(R[j].x * t.x - R[j].y * t.y);
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < KS; ++j)
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const size_t o = ((size_t)(j * KS + i)) * n + e;
+      dw[o] = acc[j][i] + lmbd * w[o];
+    }
+}
+
+}  // namespace wf
+
+size_t wgrad_fft_scratch_bytes(int NY, int NX, int Cin, int Cout) { return (size_t)NY * (NX / 2 + 1) * Cin * Cout * sizeof(float2); }
+
+hipError_t wgrad_fft(const void* xs, const void* zs, void* scratch, const float* w, float lmbd, float* dw, int ks, int NY, int NX, int B, int MTx, int MTz, int Cin,
+                     int Cout, hipStream_t st) {
+  if ((ks != 9 && ks != 5) || Cin % 16 || Cout % 16 || NY > 192 || NX > 192 || B < 1) return hipErrorInvalidValue;
+  const int F = NY * (NX / 2 + 1);
+  if (MTx % 16 || MTz % 16) return hipErrorInvalidValue;
+  wf::Args a{static_cast<const uint4*>(xs), static_cast<const uint4*>(zs), static_cast<float2*>(scratch), F, B, MTx, MTz, Cin, Cout};
+  static LdsAttr attr;
+  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(wf::wgrad_spec_kernel), wf::LDS_BYTES); e != hipSuccess) return e;
+  const int tiles = ((Cin + wf::TM - 1) / wf::TM) * ((Cout + wf::TN - 1) / wf::TN);
+  hipLaunchKernelGGL(wf::wgrad_spec_kernel, dim3((unsigned)(F * tiles)), dim3(wf::NT), wf::LDS_BYTES, st, a);
+  const unsigned blocks = (unsigned)(((size_t)Cin * Cout + 255) / 256);
+  if (ks == 9) hipLaunchKernelGGL(wf::wgrad_taps_kernel<9>, dim3(blocks), dim3(256), 0, st, a.P, w, dw, Cin, Cout, NY, NX, lmbd);
+  else hipLaunchKernelGGL(wf::wgrad_taps_kernel<5>, dim3(blocks), dim3(256), 0, st, a.P, w, dw, Cin, Cout, NY, NX, lmbd);
+  return hipGetLastError();
+}
+
+}  // namespace jcm
