@@ -44,15 +44,18 @@ template <int KS, int NP>
 __global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* __restrict__ w, uint4* __restrict__ Ws, int Cin, int Cout, int CoutP, int ntl, int NY, int NX,
                                                                    int round_bf16) {
   constexpr int JQ = 8;      // frequencies (ky) per exchange through LDS: every thread stores, two barriers per 8 frequencies
-  __shared__ cf twy[256], twx[256];
+  __shared__ cf twy[192][KS - 1], twx[KS];      // e^{-2 pi i ky a / NY} (a = 1..KS-1), e^{-2 pi i kx b / NX} of this block's kx
   __shared__ cf sp[JQ][32][9];
   const int tid = threadIdx.x;
-  for (int k = tid; k < NY + NX; k += 256) {
-    const bool isy = k < NY;
-    const int kk = isy ? k : k - NY;
+  const int kx = blockIdx.y;
+  for (int k = tid; k < NY * (KS - 1) + KS; k += 256) {
+    const bool isy = k < NY * (KS - 1);
+    const int ky = k / (KS - 1), a = isy ? k % (KS - 1) + 1 : k - NY * (KS - 1);
     double sn, cs;
-    sincospi(-2.0 * (double)kk / (double)(isy ? NY : NX), &sn, &cs);
-    (isy ? twy : twx)[kk] = cf{(float)cs, (float)sn};
+    if (isy) sincospi(-2.0 * (double)((ky * a) % NY) / (double)NY, &sn, &cs);
+    else sincospi(-2.0 * (double)((kx * a) % NX) / (double)NX, &sn, &cs);
+    if (isy) twy[ky][a - 1] = cf{(float)cs, (float)sn};
+    else twx[a] = cf{(float)cs, (float)sn};
   }
   __syncthreads();
   const int nco = CoutP / 32;
@@ -68,18 +71,18 @@ __global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* 
       if (round_bf16) wv = static_cast<float>(static_cast<__bf16>(wv));       // bf16 handles: the filter the bf16 MFMA kernels multiply with
       g[a][b] = wv;
     }
-  const int NXH = NX / 2 + 1, KC = Cin / 16, ntiles = CoutP / ntl;
+  const int KC = Cin / 16, ntiles = CoutP / ntl;
   const int kc = ci8 >> 1, kg = ci8 & 1;
   // storing role of a thread: frequency j of the group, column scol; it writes the re and the im units of (column, this block's 8 channels)
   const int sj = tid >> 5, scol = tid & 31;
   const int sco = co32 * 32 + scol, snt = sco / ntl, sn = sco % ntl;
-  for (int kx = blockIdx.y; kx < NXH; kx += gridDim.y) {
+  {
     cf ra[KS];
 #pragma unroll
     for (int a = 0; a < KS; ++a) {
       cf s = {0.f, 0.f};
 #pragma unroll
-      for (int b = 0; b < KS; ++b) s = sfma(g[a][b], twx[(kx * b) % NX], s);
+      for (int b = 0; b < KS; ++b) s = sfma(g[a][b], twx[b], s);
       ra[a] = s;
     }
     for (int ky0 = 0; ky0 < NY; ky0 += JQ) {
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* 
         if (ky < NY) {
           cf s = ra[0];
 #pragma unroll
-          for (int a = 1; a < KS; ++a) s = s + cmul(ra[a], twy[(ky * a) % NY]);
+          for (int a = 1; a < KS; ++a) s = s + cmul(ra[a], twy[ky][a - 1]);
           sp[j][col][cil] = s;
         }
       }
@@ -204,7 +207,7 @@ hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, in
   Sizes s;
   if (!sizes_of(H, W, ks, &s) || Cin % 16 || (np != 2 && np != 3)) return hipErrorInvalidValue;
   const int ntl = cgemm_split_ntile(np, Cout), CoutP = padn(Cout, ntl);
-  const dim3 grid((unsigned)((Cin / 8) * (CoutP / 32)), 8);
+  const dim3 grid((unsigned)((Cin / 8) * (CoutP / 32)), (unsigned)(s.NX / 2 + 1));      // one kx per block
   uint4* dst = static_cast<uint4*>(wf);
   const int rb = round_bf16 ? 1 : 0;
   const bool f32 = cgemm_split_w_fp32(np);      // fp32 handles: unsplit spectra, the GEMM splits them

@@ -13,8 +13,8 @@
 //                       the MFMA wants 8 IMAGES of one channel per lane, which is what gfx950's transposing LDS read delivers
 //                       (ds_read_b64_tr_b16, as in wgrad_split.hip): the units are staged as they lie, [image][channel], and read transposed.
 //                       Three bf16 parts per operand, six products: fp32-class, like the forward pass.
-//   wgrad_taps_kernel : one thread per (ci, co): the k x k taps of the inverse transform, separable -- k row sums over ky in double for
-//                       each kx, folded into k x k column sums with the Hermitian weights of the half spectrum -- + lmbd * w.
+//   wgrad_taps_*      : the k x k taps of the inverse transform, separable: k column sums over ky for every kx (streams P once), then k x k
+//                       row sums over kx with the Hermitian weights of the half spectrum (double), + lmbd * w.
 #include "kernels.h"
 
 namespace jcm {
@@ -22,6 +22,7 @@ namespace jcm {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace wf {
@@ -90,6 +91,9 @@ __global__ __launch_bounds__(NT) void wgrad_spec_kernel(Args a) {
       const int kg = seg & 1, cp = (seg >> 1) % 6, kcl = seg / 12;      // cp = re|im * 3 + part
       const int KC = op ? KCo : KCi, kc = (op ? tn : tm) * 8 + kcl;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
+#ifdef WF_MODE
+      if (WF_MODE != 2)
+#endif
       if (kc < KC && r0 + j < rows_valid) {
         const uint4* src = op ? a.zs : a.xs;
         const int MT = op ? a.MTz : a.MTx, mtiles = (a.B + MT - 1) / MT, mt = r0 / MT, rl = r0 - mt * MT;
@@ -148,6 +152,9 @@ __global__ __launch_bounds__(NT) void wgrad_spec_kernel(Args a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int co = tn * TN + (wn * 2 + j) * 32 + l31;
+#ifdef WF_MODE
+          if (WF_MODE != 1 || pr[i][j][e] == 12345.f)
+#endif
           if (co < a.Cout) pf[(size_t)ci * a.Cout + co] = make_float2(pr[i][j][e], pi[i][j][e]);
         }
       }
@@ -155,84 +162,115 @@ __global__ __launch_bounds__(NT) void wgrad_spec_kernel(Args a) {
 }
 
 // ---- taps: dw[j][i][ci][co] = 1/(NY NX) sum_{ky, kx <= NX/2} wgt(kx) Re(P[ky][kx] e^{+2 pi i (ky (pad - j) / NY + kx (pad - i) / NX)}) + lmbd w
+// Separable, in two launches that both fill the chip (one thread per (ci, co) alone would be Cin Cout / 64 waves):
+//   cols : thread (pair, kx): R[kx][j][pair] = sum_ky P[kx][ky][pair] e^{+2 pi i ky (pad - j) / NY}     -- streams P once, coalesced over pairs
+//   rows : thread (pair, j):  dw[j][i][pair] = sum_kx Re(R[kx][j][pair] wgt(kx) e^{+2 pi i kx (pad - i) / NX}) / (NY NX) + lmbd w (double sums)
 template <int KS>
-__global__ __launch_bounds__(256) void wgrad_taps_kernel(const float2* __restrict__ P, const float* __restrict__ w, float* __restrict__ dw, int Cin, int Cout, int NY, int NX,
-                                                         float lmbd) {
+__global__ __launch_bounds__(256) void wgrad_taps_cols_kernel(const float2* __restrict__ P, float2* __restrict__ R, size_t n, int NY) {
   constexpr int PAD = (KS - 1) / 2;
-  __shared__ double2 twy[192 * KS];       // e^{+2 pi i ky l / NY}, l = PAD - j
-  __shared__ double2 twx[97 * KS];        // wgt(kx) e^{+2 pi i kx l / NX} / (NY NX)
-  const int NXH = NX / 2 + 1;
+  __shared__ float2 twy[192 * KS];       // e^{+2 pi i ky l / NY}, l = PAD - j
   for (int i = threadIdx.x; i < NY * KS; i += 256) {
     const int ky = i / KS, l = PAD - i % KS;
     double sn, cs;
-    sincospi(2.0 * (double)(((long long)ky * l) % NY) / (double)NY, &sn, &cs);
-    twy[i] = double2{cs, sn};
+    sincospi(2.0 * (double)(((ky * l) % NY + NY) % NY) / (double)NY, &sn, &cs);
+    twy[i] = float2{(float)cs, (float)sn};
   }
+  __syncthreads();
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int kx = blockIdx.y;
+  float2 acc[KS];
+#pragma unroll
+  for (int j = 0; j < KS; ++j) acc[j] = float2{0.f, 0.f};
+  const float2* col = P + ((size_t)kx * NY) * n + e;
+  constexpr int U = 8;                   // loads in flight per thread (NY is a multiple of 4; the tail is guarded)
+  for (int ky0 = 0; ky0 < NY; ky0 += U) {
+    float2 p[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (ky0 + u < NY) {
+        const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(col + (size_t)(ky0 + u) * n));
+        p[u] = float2{v.x, v.y};
+      } else {
+        p[u] = float2{0.f, 0.f};
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ky = ky0 + u < NY ? ky0 + u : 0;
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        const float2 t = twy[ky * KS + j];
+        acc[j].x += p[u].x * t.x - p[u].y * t.y;
+        acc[j].y += p[u].x * t.y + p[u].y * t.x;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < KS; ++j) R[((size_t)kx * KS + j) * n + e] = acc[j];
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void wgrad_taps_rows_kernel(const float2* __restrict__ R, const float* __restrict__ w, float* __restrict__ dw, size_t n, int NY, int NX,
+                                                              float lmbd) {
+  constexpr int PAD = (KS - 1) / 2;
+  __shared__ double2 twx[97 * KS];        // wgt(kx) e^{+2 pi i kx l / NX} / (NY NX), l = PAD - i
+  const int NXH = NX / 2 + 1;
   for (int i = threadIdx.x; i < NXH * KS; i += 256) {
     const int kx = i / KS, l = PAD - i % KS;
     double sn, cs;
-    sincospi(2.0 * (double)(((long long)kx * l) % NX) / (double)NX, &sn, &cs);
+    sincospi(2.0 * (double)(((kx * l) % NX + NX) % NX) / (double)NX, &sn, &cs);
     const double wgt = ((kx == 0 || 2 * kx == NX) ? 1.0 : 2.0) / ((double)NY * (double)NX);
     twx[i] = double2{cs * wgt, sn * wgt};
   }
   __syncthreads();
-  const size_t n = (size_t)Cin * Cout, e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
-  float acc[KS][KS];
+  const int j = blockIdx.y;
+  double acc[KS];
 #pragma unroll
-  for (int j = 0; j < KS; ++j)
-#pragma unroll
-    for (int i = 0; i < KS; ++i) acc[j][i] = 0.f;
-  for (int kx = 0; kx < NXH; ++kx) {
-    double2 R[KS];
-#pragma unroll
-    for (int j = 0; j < KS; ++j) R[j] = double2{0.0, 0.0};
-    const float2* col = P + ((size_t)kx * NY) * n + e;
+  for (int i = 0; i < KS; ++i) acc[i] = 0.0;
 #pragma unroll 4
-    for (int ky = 0; ky < NY; ++ky) {
-      const float2 p = col[(size_t)ky * n];
-      const double prr = p.x, pii = p.y;
-#pragma unroll
-      for (int j = 0; j < KS; ++j) {
-        const double2 t = twy[ky * KS + j];
-        R[j].x += prr * t.x - pii * t.y;
-        R[j].y += prr * t.y + pii * t.x;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < KS; ++j)
-#pragma unroll
-      for (int i = 0; i < KS; ++i) {
-        const double2 t = twx[kx * KS + i];
-        acc[j][i] += (float)(R[j].x * t.x - R[j].y * t.y);
-      }
-  }
-#pragma unroll
-  for (int j = 0; j < KS; ++j)
+  for (int kx = 0; kx < NXH; ++kx) {
+    const float2 r = R[((size_t)kx * KS + j) * n + e];
+    const double rr = r.x, ri = r.y;
 #pragma unroll
     for (int i = 0; i < KS; ++i) {
-      const size_t o = ((size_t)(j * KS + i)) * n + e;
-      dw[o] = acc[j][i] + lmbd * w[o];
+      const double2 t = twx[kx * KS + i];
+      acc[i] += rr * t.x - ri * t.y;
     }
+  }
+#pragma unroll
+  for (int i = 0; i < KS; ++i) {
+    const size_t o = ((size_t)(j * KS + i)) * n + e;
+    dw[o] = (float)acc[i] + lmbd * w[o];
+  }
 }
 
 }  // namespace wf
 
-size_t wgrad_fft_scratch_bytes(int NY, int NX, int Cin, int Cout) { return (size_t)NY * (NX / 2 + 1) * Cin * Cout * sizeof(float2); }
+static size_t p_bytes(int NY, int NX, int Cin, int Cout) { return ((size_t)NY * (NX / 2 + 1) * Cin * Cout * sizeof(float2) + 255) & ~size_t(255); }
+// P[f][ci][co] + R[kx][j][ci][co] (j < 9)
+size_t wgrad_fft_scratch_bytes(int NY, int NX, int Cin, int Cout) { return p_bytes(NY, NX, Cin, Cout) + (size_t)(NX / 2 + 1) * 9 * Cin * Cout * sizeof(float2); }
 
 hipError_t wgrad_fft(const void* xs, const void* zs, void* scratch, const float* w, float lmbd, float* dw, int ks, int NY, int NX, int B, int MTx, int MTz, int Cin,
                      int Cout, hipStream_t st) {
   if ((ks != 9 && ks != 5) || Cin % 16 || Cout % 16 || NY > 192 || NX > 192 || B < 1) return hipErrorInvalidValue;
-  const int F = NY * (NX / 2 + 1);
+  const int NXH = NX / 2 + 1, F = NY * NXH;
   if (MTx % 16 || MTz % 16) return hipErrorInvalidValue;
   wf::Args a{static_cast<const uint4*>(xs), static_cast<const uint4*>(zs), static_cast<float2*>(scratch), F, B, MTx, MTz, Cin, Cout};
+  float2* R = reinterpret_cast<float2*>(static_cast<char*>(scratch) + p_bytes(NY, NX, Cin, Cout));
   static LdsAttr attr;
   if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(wf::wgrad_spec_kernel), wf::LDS_BYTES); e != hipSuccess) return e;
   const int tiles = ((Cin + wf::TM - 1) / wf::TM) * ((Cout + wf::TN - 1) / wf::TN);
   hipLaunchKernelGGL(wf::wgrad_spec_kernel, dim3((unsigned)(F * tiles)), dim3(wf::NT), wf::LDS_BYTES, st, a);
-  const unsigned blocks = (unsigned)(((size_t)Cin * Cout + 255) / 256);
-  if (ks == 9) hipLaunchKernelGGL(wf::wgrad_taps_kernel<9>, dim3(blocks), dim3(256), 0, st, a.P, w, dw, Cin, Cout, NY, NX, lmbd);
-  else hipLaunchKernelGGL(wf::wgrad_taps_kernel<5>, dim3(blocks), dim3(256), 0, st, a.P, w, dw, Cin, Cout, NY, NX, lmbd);
+  const size_t n = (size_t)Cin * Cout;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  if (ks == 9) {
+    hipLaunchKernelGGL(wf::wgrad_taps_cols_kernel<9>, dim3(blocks, NXH), dim3(256), 0, st, a.P, R, n, NY);
+    hipLaunchKernelGGL(wf::wgrad_taps_rows_kernel<9>, dim3(blocks, 9), dim3(256), 0, st, R, w, dw, n, NY, NX, lmbd);
+  } else {
+    hipLaunchKernelGGL(wf::wgrad_taps_cols_kernel<5>, dim3(blocks, NXH), dim3(256), 0, st, a.P, R, n, NY);
+    hipLaunchKernelGGL(wf::wgrad_taps_rows_kernel<5>, dim3(blocks, 5), dim3(256), 0, st, R, w, dw, n, NY, NX, lmbd);
+  }
   return hipGetLastError();
 }
 
