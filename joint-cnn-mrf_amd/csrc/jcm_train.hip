@@ -22,6 +22,7 @@ struct DgradW {
   void* wd_split = nullptr;  // the same in three bf16 parts for conv_split_f32 (handles with f32_conv = 1)
   void* wd_bf16 = nullptr;   // bf16 handles: packed for conv_igemm_bf16
   int cinp_bf16 = 0, coutp_bf16 = 0;
+  bool stale = true;       // packed before the last weight update
   int cinp = 0;            // dZ channel stride the kernel reads (= Cout rounded up to 16)
   int coutp = 0;           // packed N extent (= Cin rounded up to the kernel's N tile)
 };
@@ -45,6 +46,7 @@ struct TrainState {
   float* scratch_flip = nullptr;       // largest flipped HWIO weight
   void* zs = nullptr;                  // split spectra of the dz the last conv_wgrad saw (frequency-domain route), for the conv_dgrad that follows
   const void* zs_of = nullptr;
+  int zs_cin = 0;
   double* red = nullptr;               // per-channel reduction scratch
   double* sumsq = nullptr;             // [2]: grad sum of squares, weight sum of squares (l2)
   float* small = nullptr;              // [2*maxC + 64] misc
@@ -80,15 +82,23 @@ bool ends_with(const std::string& s, const char* suf) {
 }
 bool trainable(const std::string& name) { return !ends_with(name, "moving_mean") && !ends_with(name, "moving_variance"); }
 
+// The weights changed: the packed data-gradient filters are stale.  They are repacked where a layer's data gradient next runs on the direct
+// kernels (conv_dgrad) -- layers on the frequency-domain route never read them.
 int repack_dgrad(jcm_ctx* c) {
+  for (auto& kv : c->train->dgrad) kv.second.stale = true;
+  return JCM_OK;
+}
+int ensure_dgrad_packed(jcm_ctx* c, const std::string& scope) {
   TrainState* t = c->train;
-  for (auto& kv : t->dgrad) {
-    const ConvLayer* L = conv_of(c, kv.first);
-    DgradW& d = kv.second;
+  {
+    const ConvLayer* L = conv_of(c, scope);
+    DgradW& d = t->dgrad[scope];
+    if (!d.stale) return JCM_OK;
+    d.stale = false;
     if (d.wd_bf16) {
       HIP_TRY(flip_transpose_weights(L->w_raw, t->scratch_flip, L->ks, L->cin, L->cout, d.cinp_bf16, c->stream));
       HIP_TRY(pack_weights_bf16(t->scratch_flip, d.wd_bf16, L->ks, d.cinp_bf16, L->cin, d.coutp_bf16, c->stream));
-      continue;
+      return JCM_OK;
     }
     HIP_TRY(flip_transpose_weights(L->w_raw, t->scratch_flip, L->ks, L->cin, L->cout, d.cinp, c->stream));
     HIP_TRY(pack_weights_f32(t->scratch_flip, d.wd, L->ks, d.cinp, L->cin, d.coutp, c->stream));
@@ -182,8 +192,7 @@ int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int ldz, int B, fl
   TrainState* t = c->train;
   const ConvLayer* L = f.L;
   t->zs = nullptr;
-  const auto dg = t->dgrad.find(f.scope);
-  if (f.xs && !bf(c) && ldz == L->cout && (dg == t->dgrad.end() || dg->second.cinp == ldz)) {
+  if (f.xs && !bf(c) && ldz >= L->cout && ldz % 64 == 0) {
     // frequency domain (wgrad_fft.hip): spectra of dz (kept in t->zs for the data gradient that follows), P[f] = conj(X)^T dZ per frequency, k x k taps
     ConvLayer Lz;      // dz as the input of a frequency-domain layer: the same pseudo-layer conv_dgrad runs
     Lz.ks = L->ks; Lz.cin = ldz; Lz.cout = L->cin; Lz.has_bn = false; Lz.w_raw = t->scratch_flip;
@@ -195,17 +204,18 @@ int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int ldz, int B, fl
       char* zs = arena_alloc<char>(c, conv_fft_xs_bytes(az, L->ks, 3));      // stays allocated: conv_dgrad of this layer reads it
       const size_t mark = c->arena_off;
       char* work = arena_alloc<char>(c, conv_fft_workspace_bytes(az, L->ks, 3));
-      char* P = arena_alloc<char>(c, wgrad_fft_scratch_bytes(NY, NX, L->cin, L->cout));
+      char* P = arena_alloc<char>(c, wgrad_fft_scratch_bytes(NY, NX, L->cin, ldz));
       if (!c->dry) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         JCM_TRY(prof_begin(c, &e0, &e1));
         hipError_t le = conv_fft_spectra(az, L->ks, 3, work, zs, c->stream);
         if (le == hipSuccess)
-          le = wgrad_fft(f.xs, zs, P, L->w_raw, lmbd, grad_of(t, grads, f.scope + "/weights"), L->ks, NY, NX, B, MTx, MTz, L->cin, L->cout, c->stream);
+          le = wgrad_fft(f.xs, zs, P, L->w_raw, lmbd, grad_of(t, grads, f.scope + "/weights"), L->ks, NY, NX, B, MTx, MTz, L->cin, ldz, L->cout, c->stream);
         prof_end(c, "wgrad:" + f.scope, e0, e1, le == hipSuccess);
         if (le != hipSuccess) return fail(JCM_ERR_HIP, "frequency-domain weight gradient of '" + f.scope + "': " + hipGetErrorString(le));
         t->zs = zs;
         t->zs_of = dz;
+        t->zs_cin = ldz;
       }
       c->arena_off = mark;
       notify_ready(c, f.scope + "/");
@@ -251,25 +261,30 @@ int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int ldz, int B, fl
 }
 
 // dX = conv_SAME(dZ, flipped weights): [B,H,W,ldz] -> [B,H,W,Cin]
-int conv_dgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int B, void* dx) {
+// ldz_fft: dz's channel stride when it differs from the packed data-gradient weights' (the logits gradient widened to 64 channels for the
+// frequency-domain route; 0 = d.cinp)
+int conv_dgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int B, void* dx, int ldz_fft = 0) {
   TrainState* t = c->train;
   const DgradW& d = t->dgrad[f.scope];
   if (!bf(c)) {
+    const int cin_fft = ldz_fft ? ldz_fft : d.cinp;
     // fp32 handles: the data gradient is a SAME correlation with the flipped, transposed filter -- in the frequency domain like the forward
     // pass (conv_fft.hip); its filter spectra ("dgrad:<scope>") are packed from the flipped weights after every update, on first use.
     ConvLayer Ld;
-    Ld.ks = f.L->ks; Ld.cin = d.cinp; Ld.cout = f.L->cin; Ld.has_bn = false;
+    Ld.ks = f.L->ks; Ld.cin = cin_fft; Ld.cout = f.L->cin; Ld.has_bn = false;
     Ld.w_raw = t->scratch_flip; Ld.bias = t->zeros; Ld.scale = t->ones; Ld.shift = t->zeros;
     if (takes_fft(c, &Ld, B, f.H, f.W)) {
       const std::string key = "dgrad:" + f.scope;
       if (!c->dry && !fft_spectra_valid(c, key, f.H, f.W))
-        HIP_TRY(flip_transpose_weights(f.L->w_raw, t->scratch_flip, f.L->ks, f.L->cin, f.L->cout, d.cinp, c->stream));
-      if (!c->dry && t->zs && t->zs_of == dz) { c->fft_xs = t->zs; c->fft_xs_ready = true; }      // the spectra of dz are there (conv_wgrad just made them)
+        HIP_TRY(flip_transpose_weights(f.L->w_raw, t->scratch_flip, f.L->ks, f.L->cin, f.L->cout, cin_fft, c->stream));
+      if (!c->dry && t->zs && t->zs_of == dz && t->zs_cin == cin_fft) { c->fft_xs = t->zs; c->fft_xs_ready = true; }      // the spectra of dz are there (conv_wgrad just made them)
       t->zs = nullptr;
       return run_conv_fft(c, &Ld, key, dz, B, f.H, f.W, dx, 0, 0);
     }
+    if (ldz_fft) return fail(JCM_ERR_STATE, "data gradient of '" + f.scope + "': widened dz without the frequency-domain route");
   }
   if (c->dry) return JCM_OK;
+  JCM_TRY(ensure_dgrad_packed(c, f.scope));
   ConvArgs a;
   if (bf(c)) {      // bf16 gradients through the bf16 forward kernels on flipped weights
     a.x = dz; a.wp = d.wd_bf16; a.bias = t->zeros; a.scale = t->ones; a.shift = t->zeros; a.out = dx;
@@ -398,9 +413,16 @@ int loss_grads_impl(jcm_ctx* c, const float* x, const float* y, int B, int H, in
     if (b16) HIP_TRY(cast_pad_bf16(dlog, LDZ, dlogb, LDZB, NP, c->stream));
   }
   const void* dl = b16 ? dlogb : static_cast<const void*>(dlog);
-  JCM_TRY(conv_wgrad(c, l6, dl, b16 ? LDZB : LDZ, B, lmbd, grads));
+  int ldl = b16 ? LDZB : LDZ, ldl_fft = 0;
+  if (l6.xs) {      // frequency-domain route (fp32 handles): its forward transforms take 64-channel blocks
+    constexpr int LDZF = 64;
+    float* dlogf = arena_alloc<float>(c, NP * LDZF);
+    if (!c->dry) HIP_TRY(pad_channels_f32(dlog, LDZ, dlogf, LDZF, NP, c->stream));
+    dl = dlogf; ldl = LDZF; ldl_fft = LDZF;
+  }
+  JCM_TRY(conv_wgrad(c, l6, dl, ldl, B, lmbd, grads));
   void* dy5 = act(c, NP * l5.L->cout);
-  JCM_TRY(conv_dgrad(c, l6, dl, B, dy5));
+  JCM_TRY(conv_dgrad(c, l6, dl, B, dy5, ldl_fft));
   void* dz5;
   JCM_TRY(conv_train_bwd_pre(c, l5, dy5, 1.0f, B, grads, &dz5));
   JCM_TRY(conv_wgrad(c, l5, dz5, l5.L->cout, B, lmbd, grads));

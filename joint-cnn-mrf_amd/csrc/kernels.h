@@ -94,8 +94,10 @@ bool conv_fft_geometry(int H, int W, int ks, int B, int Cout, int np, int* NY, i
 // P[f][ci][co] = sum_b conj(X[f][b][ci]) dZ[f][b][co] on v_mfma_f32_32x32x16_bf16 from the split spectra of the layer input (kept by the forward pass)
 // and of dZ, then the k x k taps are read off the inverse transform:  dw = taps(P) / (NY NX) + lmbd * w.   xs / zs: np = 3 layouts of cgemm_split.hip
 size_t wgrad_fft_scratch_bytes(int NY, int NX, int Cin, int Cout);
+// ldz: channels of the dZ spectra (P's columns, scratch sized with it) >= Cout, the filter's
 hipError_t wgrad_fft(const void* xs, const void* zs, void* scratch, const float* w, float lmbd, float* dw, int ks, int NY, int NX, int B, int MTx, int MTz, int Cin,
-                     int Cout, hipStream_t st);
+                     int ldz, int Cout, hipStream_t st);
+hipError_t pad_channels_f32(const float* in, int ldi, float* out, int ldo, size_t N, hipStream_t st);      // train_kernels.hip
 bool conv_fft_fusable(const ConvArgs& a, int ks, int ks_next);
 size_t conv_fft_handover_bytes(const ConvArgs& a, int ks);
 

@@ -537,6 +537,21 @@ hipError_t cast_pad_bf16(const float* in, int ldi, void* out, int ldo, size_t N,
   return hipGetLastError();
 }
 
+// the same in fp32 (the logits gradient widened to the 64-channel blocks of the forward transforms)
+__global__ void pad_channels_f32_kernel(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % ldo;
+    const size_t n = i / ldo;
+    out[i] = c < ldi ? in[n * ldi + c] : 0.f;
+  }
+}
+hipError_t pad_channels_f32(const float* in, int ldi, float* out, int ldo, size_t N, hipStream_t st) {
+  const size_t total = N * ldo;
+  size_t g = (total + 255) / 256;
+  hipLaunchKernelGGL(pad_channels_f32_kernel, dim3((int)(g > 65536 ? 65536 : g)), dim3(256), 0, st, in, ldi, out, ldo, total);
+  return hipGetLastError();
+}
+
 __global__ void cast_bf16_f32_kernel(const __bf16* __restrict__ in, float* __restrict__ out, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = static_cast<float>(in[i]);
 }

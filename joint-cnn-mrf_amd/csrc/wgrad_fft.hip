@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void wgrad_taps_cols_kernel(const float2* __re
 
 template <int KS>
 __global__ __launch_bounds__(256) void wgrad_taps_rows_kernel(const float2* __restrict__ R, const float* __restrict__ w, float* __restrict__ dw, size_t n, int NY, int NX,
-                                                              float lmbd) {
+                                                              float lmbd, int ldp, int Cout) {
   constexpr int PAD = (KS - 1) / 2;
   __shared__ double2 twx[97 * KS];        // wgt(kx) e^{+2 pi i kx l / NX} / (NY NX), l = PAD - i
   const int NXH = NX / 2 + 1;
@@ -224,6 +224,10 @@ __global__ __launch_bounds__(256) void wgrad_taps_rows_kernel(const float2* __re
   __syncthreads();
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
+  const size_t ci = e / (size_t)ldp;
+  const int co = (int)(e - ci * ldp);      // P has ldp >= Cout columns (dZ's channel stride); the filter has Cout
+  if (co >= Cout) return;
+  const size_t nw = n / (size_t)ldp * Cout, ew = ci * Cout + co;
   const int j = blockIdx.y;
   double acc[KS];
 #pragma unroll
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256) void wgrad_taps_rows_kernel(const float2* __re
   }
 #pragma unroll
   for (int i = 0; i < KS; ++i) {
-    const size_t o = ((size_t)(j * KS + i)) * n + e;
+    const size_t o = ((size_t)(j * KS + i)) * nw + ew;
     dw[o] = (float)acc[i] + lmbd * w[o];
   }
 }
@@ -248,28 +252,28 @@ __global__ __launch_bounds__(256) void wgrad_taps_rows_kernel(const float2* __re
 }  // namespace wf
 
 static size_t p_bytes(int NY, int NX, int Cin, int Cout) { return ((size_t)NY * (NX / 2 + 1) * Cin * Cout * sizeof(float2) + 255) & ~size_t(255); }
-// P[f][ci][co] + R[kx][j][ci][co] (j < 9)
+// P[f][ci][co] + R[kx][j][ci][co] (j < 9); Cout = dZ's channel stride
 size_t wgrad_fft_scratch_bytes(int NY, int NX, int Cin, int Cout) { return p_bytes(NY, NX, Cin, Cout) + (size_t)(NX / 2 + 1) * 9 * Cin * Cout * sizeof(float2); }
 
 hipError_t wgrad_fft(const void* xs, const void* zs, void* scratch, const float* w, float lmbd, float* dw, int ks, int NY, int NX, int B, int MTx, int MTz, int Cin,
-                     int Cout, hipStream_t st) {
-  if ((ks != 9 && ks != 5) || Cin % 16 || Cout % 16 || NY > 192 || NX > 192 || B < 1) return hipErrorInvalidValue;
+                     int ldz, int Cout, hipStream_t st) {
+  if ((ks != 9 && ks != 5) || Cin % 16 || ldz % 16 || Cout > ldz || Cout < 1 || NY > 192 || NX > 192 || B < 1) return hipErrorInvalidValue;
   const int NXH = NX / 2 + 1, F = NY * NXH;
   if (MTx % 16 || MTz % 16) return hipErrorInvalidValue;
-  wf::Args a{static_cast<const uint4*>(xs), static_cast<const uint4*>(zs), static_cast<float2*>(scratch), F, B, MTx, MTz, Cin, Cout};
-  float2* R = reinterpret_cast<float2*>(static_cast<char*>(scratch) + p_bytes(NY, NX, Cin, Cout));
+  wf::Args a{static_cast<const uint4*>(xs), static_cast<const uint4*>(zs), static_cast<float2*>(scratch), F, B, MTx, MTz, Cin, ldz};
+  float2* R = reinterpret_cast<float2*>(static_cast<char*>(scratch) + p_bytes(NY, NX, Cin, ldz));
   static LdsAttr attr;
   if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(wf::wgrad_spec_kernel), wf::LDS_BYTES); e != hipSuccess) return e;
-  const int tiles = ((Cin + wf::TM - 1) / wf::TM) * ((Cout + wf::TN - 1) / wf::TN);
+  const int tiles = ((Cin + wf::TM - 1) / wf::TM) * ((ldz + wf::TN - 1) / wf::TN);
   hipLaunchKernelGGL(wf::wgrad_spec_kernel, dim3((unsigned)(F * tiles)), dim3(wf::NT), wf::LDS_BYTES, st, a);
-  const size_t n = (size_t)Cin * Cout;
+  const size_t n = (size_t)Cin * ldz;
   const unsigned blocks = (unsigned)((n + 255) / 256);
   if (ks == 9) {
     hipLaunchKernelGGL(wf::wgrad_taps_cols_kernel<9>, dim3(blocks, NXH), dim3(256), 0, st, a.P, R, n, NY);
-    hipLaunchKernelGGL(wf::wgrad_taps_rows_kernel<9>, dim3(blocks, 9), dim3(256), 0, st, R, w, dw, n, NY, NX, lmbd);
+    hipLaunchKernelGGL(wf::wgrad_taps_rows_kernel<9>, dim3(blocks, 9), dim3(256), 0, st, R, w, dw, n, NY, NX, lmbd, ldz, Cout);
   } else {
     hipLaunchKernelGGL(wf::wgrad_taps_cols_kernel<5>, dim3(blocks, NXH), dim3(256), 0, st, a.P, R, n, NY);
-    hipLaunchKernelGGL(wf::wgrad_taps_rows_kernel<5>, dim3(blocks, 5), dim3(256), 0, st, R, w, dw, n, NY, NX, lmbd);
+    hipLaunchKernelGGL(wf::wgrad_taps_rows_kernel<5>, dim3(blocks, 5), dim3(256), 0, st, R, w, dw, n, NY, NX, lmbd, ldz, Cout);
   }
   return hipGetLastError();
 }

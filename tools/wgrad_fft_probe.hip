@@ -23,7 +23,7 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int it = 0; it < iters + 1; ++it) {
     if (it == 1) CK(hipEventRecord(e0, 0));
-    CK(jcm::wgrad_fft(xs, zs, sc, w, 0.f, dw, ks, NY, NX, B, MT, MT, Cin, Cout, 0));
+    CK(jcm::wgrad_fft(xs, zs, sc, w, 0.f, dw, ks, NY, NX, B, MT, MT, Cin, Cout, Cout, 0));
   }
   CK(hipEventRecord(e1, 0));
   CK(hipDeviceSynchronize());
