@@ -273,19 +273,33 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
     if rank == 0:
         value = world * B * args.steps / dt
         scale = 16 if args.debug else 1
-        # dominant training kernels: the three conv5 passes, each 229.3 GFLOP per image (60x90 px, 81 taps, 512x512)
+        # dominant training kernels: the three conv5 passes, each 229.3 GFLOP per image as a direct convolution (60x90 px, 81 taps, 512x512)
         kern = {}
         sp = f32_conv in ('split', 'split16') and prec == 'fp32'
+        fd = prec == 'fp32' and not sp        # fp32 handles: all three passes in the frequency domain (conv_fft.hip, wgrad_fft.hip)
         mult = 6 if f32_conv == 'split' else 3
-        for key, what in (('conv5', 'forward, ' + ('conv_split_kernel' if sp else 'conv_igemm_f32')),
-                          ('dgrad:conv5', 'data gradient, ' + ('conv_split_kernel' if sp else 'conv_igemm_f32') + ' on flipped weights'),
-                          ('wgrad:conv5', 'weight gradient, ' + ('wgrad_split_kernel<9>' if sp else 'wgrad_kernel<9>'))):
+        # frequency-domain passes are bound by the filter-sized spectra (F x Cin x Cout complex fp32: 6.58 GB for conv5 at 64x96), not by MFMA:
+        # bytes each pass must move: W or P spectra once per producer/consumer + split activation spectra + product spectra + maps
+        C5 = 512 // (4 if args.debug else 1)
+        wspec = FFT_FREQS * C5 * C5 * 8
+        xspec, yspec, amap = FFT_FREQS * B * C5 * 12, FFT_FREQS * B * C5 * 8, B * 60 * 90 * C5 * 4
+        fd_bytes = {'conv5': wspec + 2 * xspec + 2 * yspec + 2 * amap,             # read W; X spectra and product spectra written + read; map in / out
+                    'dgrad:conv5': wspec + xspec + 2 * yspec + amap,               # dz spectra are the weight gradient's
+                    'wgrad:conv5': 2 * wspec + amap + 3 * xspec}                   # P written (spec) + read (taps); dz spectra written, x and dz spectra read
+        for key, what in (('conv5', 'forward, ' + ('conv_split_kernel' if sp else 'conv_fft (cgemm_split_kernel)' if fd else 'conv_igemm_f32')),
+                          ('dgrad:conv5', 'data gradient, ' + ('conv_split_kernel on flipped weights' if sp else 'conv_fft on the flipped filter spectra, dz spectra shared with the weight gradient'
+                                                               if fd else 'conv_igemm_f32 on flipped weights')),
+                          ('wgrad:conv5', 'weight gradient, ' + ('wgrad_split_kernel<9>' if sp else 'wgrad_fft (dz transforms + wgrad_spec_kernel + wgrad_taps_*)' if fd else 'wgrad_kernel<9>'))):
             ms, n = eng.profile_read(key)
             if n:
                 tf = FLOPS_DOMINANT['conv5'] / scale * B / (ms / n * 1e-3) / 1e12      # algorithmic (fp32-equivalent) FLOPs
                 if sp:       # split kernels execute `mult` 16-bit MFMA FLOPs per algorithmic one: their roofline is the 16-bit peak
                     kern[key] = {'kernel': what, 'launch_ms': ms / n, 'launches': n, 'achieved': tf * mult, 'frac': tf * mult / PEAK_TFLOPS['bf16'],
                                  'fp32_equivalent_tflops': tf}
+                elif fd:
+                    gbs = fd_bytes[key] / (ms / n * 1e-3) / 1e9
+                    kern[key] = {'kernel': what, 'launch_ms': ms / n, 'launches': n, 'bound': 'hbm', 'bytes': fd_bytes[key], 'achieved': gbs, 'unit': 'GB/s',
+                                 'frac': gbs / PEAK_HBM_GBS, 'direct_equivalent_tflops': tf}
                 else:
                     kern[key] = {'kernel': what, 'launch_ms': ms / n, 'launches': n, 'achieved': tf, 'frac': tf / PEAK_TFLOPS[prec]}
         out = {'metric': 'images/sec joint training step (fwd+bwd+update), part detector + spatial model', 'value': value,
@@ -293,22 +307,26 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': 'bf16' if prec == 'bf16' else {'split': 'f32(bf16x6)', 'split16': 'f32(fp16x3)'}.get(f32_conv, 'f32'), 'data': 'synthetic',
                'config': {'workload': 'configs[4]: joint training, batch=%d/GPU synthetic 480x720x3, %s%s, Adam, clip 4.0%s'
-                                      % (B, 'fp32 MFMA' if prec == 'fp32' else 'mixed precision: bf16 activations/gradients + bf16 MFMA, fp32 master weights / statistics / losses / spatial model / optimizer',
+                                      % (B, ('fp32 (stride-1 layers in the frequency domain, channel products as bf16x6 split MFMA; conv1 on fp32 MFMA)' if fd else 'fp32 MFMA') if prec == 'fp32' else 'mixed precision: bf16 activations/gradients + bf16 MFMA, fp32 master weights / statistics / losses / spatial model / optimizer',
                                          ' operands; forward, data and weight gradients of the stride-1 layers as bf16x6 split MFMA' if f32_conv == 'split' else
                                          ' operands; forward, data and weight gradients as fp16x3 split MFMA (gradients scaled per tensor by a power of two)' if f32_conv == 'split16' else '',
                                          ', DEBUG filters/4' if args.debug else ''),
                           'batch_per_gpu': B, 'global_batch': world * B, 'use_sm': use_sm,
                           'collective': 'all_reduce of %d fp32 gradients' % tr.n_elements},
-               'train_tflops': value * FLOPS_TRAIN / scale / 1e12, 'mfma_peak_tflops': PEAK_TFLOPS[prec],
-               'frac_of_mfma_peak': value * FLOPS_TRAIN / scale / 1e12 / PEAK_TFLOPS[prec],
-               'roofline': dict(bound='mfma', peak=PEAK_TFLOPS['bf16'] if sp else PEAK_TFLOPS[prec], unit='TFLOP/s', traffic=None,
-                                **({'kernel': ('wgrad_split_kernel<9,1> on conv5 (bf16 operands, LDS transpose reads)' if prec == 'bf16' else
-                                               'wgrad_split_kernel<9,2> on conv5 (2 fp16 parts per operand, 3 x fp16 MFMA per k16 step; achieved = executed fp16 MFMA FLOPs)'
-                                               if f32_conv == 'split16' else
-                                               'wgrad_split_kernel<9> on conv5 (3 bf16 parts per operand, 6 x bf16 MFMA 32x32x16 per k16 step; achieved = executed bf16 MFMA FLOPs)'
-                                               if f32_conv == 'split' else 'wgrad_kernel<9> on conv5 (fp32 MFMA 32x32x2, 64x64 channel tile x 9 taps)'),
-                                    'achieved': kern['wgrad:conv5']['achieved'], 'frac': kern['wgrad:conv5']['frac'],
-                                    'launch_ms': kern['wgrad:conv5']['launch_ms']} if 'wgrad:conv5' in kern else {})),
+               'train_tflops': value * FLOPS_TRAIN / scale / 1e12,      # images/s x direct-convolution FLOPs (the frequency-domain passes execute far fewer)
+               **({} if fd else {'mfma_peak_tflops': PEAK_TFLOPS[prec], 'frac_of_mfma_peak': value * FLOPS_TRAIN / scale / 1e12 / PEAK_TFLOPS[prec]}),
+               'roofline': (dict(bound='hbm', peak=PEAK_HBM_GBS, unit='GB/s', traffic=None,
+                                 kernel='weight gradient of conv5 in the frequency domain: dz transforms, wgrad_spec_kernel (writes P[f][ci][co], 6.58 GB), '
+                                        'wgrad_taps_cols/rows (read it); achieved = bytes the pass must move / its time',
+                                 **({'achieved': kern['wgrad:conv5']['achieved'], 'frac': kern['wgrad:conv5']['frac'],
+                                     'launch_ms': kern['wgrad:conv5']['launch_ms']} if 'wgrad:conv5' in kern else {})) if fd else
+                            dict(bound='mfma', peak=PEAK_TFLOPS['bf16'] if sp else PEAK_TFLOPS[prec], unit='TFLOP/s', traffic=None,
+                                 **({'kernel': ('wgrad_split_kernel<9,1> on conv5 (bf16 operands, LDS transpose reads)' if prec == 'bf16' else
+                                                'wgrad_split_kernel<9,2> on conv5 (2 fp16 parts per operand, 3 x fp16 MFMA per k16 step; achieved = executed fp16 MFMA FLOPs)'
+                                                if f32_conv == 'split16' else
+                                                'wgrad_split_kernel<9> on conv5 (3 bf16 parts per operand, 6 x bf16 MFMA 32x32x16 per k16 step; achieved = executed bf16 MFMA FLOPs)'),
+                                     'achieved': kern['wgrad:conv5']['achieved'], 'frac': kern['wgrad:conv5']['frac'],
+                                     'launch_ms': kern['wgrad:conv5']['launch_ms']} if 'wgrad:conv5' in kern else {}))),
                'conv5_passes': kern,
                'loss': [float(v) for v in losses.cpu().numpy()], 'workspace_gb': eng.workspace_bytes() / 1e9}
     eng.close()
