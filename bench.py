@@ -466,7 +466,7 @@ def main():
             out['f32_split16_config1'] = split16
         for key, tr_out in train.items():
             if tr_out is not None:
-                out[key] = {k: tr_out[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'train_tflops', 'frac_of_mfma_peak', 'roofline')}
+                out[key] = {k: tr_out[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'train_tflops', 'frac_of_mfma_peak', 'roofline') if k in tr_out}
         if args.cpu_images > 0 and world == 1:      # the CPU baseline is a single-GPU-run item (rank 0, N = 1)
             out['cpu_baseline'] = cpu_baseline(args.cpu_images, params)
         print(json.dumps(out))

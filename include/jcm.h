@@ -58,10 +58,14 @@ int jcm_abi_version(void);
  *              stream; read the totals back with jcm_profile_read.  Events come from a pool owned by the
  *              handle (created on first use, recycled by jcm_profile_read and by switching the option on,
  *              destroyed by jcm_destroy), so a profiled step only records.
- * "conv9_fft": any time, default 1: stride-1 convolutions in the frequency domain (conv_fft.hip: in-LDS FFTs + one complex channel
- *              GEMM per frequency through rocBLAS) -- every such layer of an fp32 handle, the wide 9x9 layers of a bf16 handle --
- *              whenever the shape allows (Cin % 64 == 0, map + kernel - 1 <= 192) and no training state exists; 0 = the direct MFMA
- *              kernels.  Filter spectra are built per (layer, map size) on first use (13 GB for the full-width model).
+ * "conv9_fft": any time, default 1: stride-1 convolutions in the frequency domain (conv_fft*.hip: in-LDS FFTs around one complex channel
+ *              product per frequency on the bf16 matrix cores with split operands, cgemm_split.hip) -- every such layer of an fp32
+ *              handle, the wide 9x9 layers of a bf16 handle -- whenever the shape allows (Cin % 64 == 0, map + kernel - 1 <= 192);
+ *              0 = the direct MFMA kernels.  The training step of an fp32 handle takes the same route (forward, data and weight
+ *              gradients); a bf16 handle trains on the direct bf16 kernels.  Filter spectra are built per (layer, map size) on
+ *              first use (11.4 GB for the full-width model on 60x90 maps; cache bound: environment JCM_FFT_CACHE_GB, default 64).
+ *              Calls of different handles on one device are ordered one after the other (they may come from different threads
+ *              and streams; results do not depend on the interleaving).
  * "sm_algo"  : any time; the pairwise convolutions of the spatial model (main.py:83-87): 3 (default) = every FFT in LDS
  *              (sm_fused.hip); 2 = rocFFT with a split, row-pruned inverse; 0 = rocFFT 2-D transforms; 1 = direct
  *              sliding-window kernel.  All four are HIP paths that pass the same parity tests; the training step always

@@ -192,6 +192,138 @@ __global__ __launch_bounds__(256) void conv1_mfma_pool_f32_kernel(const float* _
   }
 }
 
+// ---- fp32 handles on the default route: the bf16 kernel above with SPLIT operands -- every fp32 value as three bf16 parts, the six products
+// with p + q <= 2 (what is dropped is below 2^-24 of x*w; cgemm_split.hip's arithmetic, which the stride-1 layers of such a handle run on
+// anyway).  120 MFMAs 32x32x16 per wave instead of 160 of the 32x32x2 fp32 ones at a quarter of their cost each.  fp32 in, fp32 out.
+constexpr int CS_NP = 3;
+__global__ __launch_bounds__(256) void conv1_mfma_pool_split_kernel(const float* __restrict__ x, const f32x4* __restrict__ wq,
+                                                                    const float* __restrict__ bias, const float* __restrict__ scale,
+                                                                    const float* __restrict__ shift, float* __restrict__ out,
+                                                                    int H0, int W0, int sub, int Hin, int Win, int Hp, int Wp,
+                                                                    int pad_t, int pad_l, int tiles_x) {
+  __shared__ __attribute__((aligned(16))) __bf16 win[CS_NP][CM_IN * CM_ROW];
+  __shared__ __attribute__((aligned(16))) f32x4 wl[CS_NP][CM_WQ_F4];
+  const int b = blockIdx.y;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int oy0 = ty * CM_T, ox0 = tx * CM_T;
+  const int tid = threadIdx.x;
+  const float* xb = x + (size_t)b * H0 * W0 * 3;
+  for (int i = tid; i < CM_IN * CM_IN; i += 256) {
+    const int iy = i / CM_IN, ix = i - iy * CM_IN;
+    const int gy = oy0 * 2 - pad_t + iy, gx = ox0 * 2 - pad_l + ix;
+    float v[3] = {0.f, 0.f, 0.f};
+    if ((unsigned)gy < (unsigned)Hin && (unsigned)gx < (unsigned)Win) {
+      const float* px3 = xb + ((size_t)(gy * sub) * W0 + gx * sub) * 3;
+      v[0] = px3[0]; v[1] = px3[1]; v[2] = px3[2];
+    }
+#pragma unroll
+    for (int p = 0; p < CS_NP; ++p)
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const __bf16 q = (__bf16)v[e];                 // round to nearest even; the remainder is exact
+        win[p][iy * CM_ROW + ix * 3 + e] = q;
+        v[e] -= (float)q;
+      }
+  }
+  for (int i = tid; i < CS_NP * CM_IN * (CM_ROW - CM_IN * 3); i += 256) {
+    const int p = i / (CM_IN * (CM_ROW - CM_IN * 3)), r = i - p * (CM_IN * (CM_ROW - CM_IN * 3));
+    const int iy = r / (CM_ROW - CM_IN * 3), e = r - iy * (CM_ROW - CM_IN * 3);
+    win[p][iy * CM_ROW + CM_IN * 3 + e] = (__bf16)0.f;
+  }
+  for (int i = tid; i < CS_NP * CM_WQ_F4; i += 256) (&wl[0][0])[i] = wq[i];
+  __syncthreads();
+
+  const int lane = tid & 63, wid = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int px = l31 & 15, pr = l31 >> 4;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[f][g][i] = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 5; ++ky) {
+    bf16x8 af[CS_NP][2], bf[CS_NP][2];
+#pragma unroll
+    for (int p = 0; p < CS_NP; ++p) {
+      const unsigned* win32 = reinterpret_cast<const unsigned*>(win[p]);
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const int py = 2 * (2 * wid + f) + pr;
+        const int e0 = ((2 * py + ky) * CM_ROW + 6 * px + 8 * h) >> 1;
+        u32x4 v;
+        v[0] = win32[e0]; v[1] = win32[e0 + 1]; v[2] = win32[e0 + 2]; v[3] = win32[e0 + 3];
+        af[p][f] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int g = 0; g < 2; ++g) bf[p][g] = __builtin_bit_cast(bf16x8, wl[p][(ky * 2 + h) * 64 + g * 32 + l31]);
+    }
+    // small terms first: (x part, w part) = (0,2) (1,1) (2,0) (1,0) (0,1) (0,0)
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      const int pxp = s == 0 ? 0 : s == 1 ? 1 : s == 2 ? 2 : s == 3 ? 1 : 0, pwp = s == 0 ? 2 : s == 1 ? 1 : s == 2 ? 0 : s == 3 ? 0 : s == 4 ? 1 : 0;
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) acc[f][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pxp][f], bf[pwp][g], acc[f][g], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int co = g * 32 + l31;
+    const float bi = bias[co], sc = scale[co], sh = shift[co];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int PY = (oy0 >> 1) + 2 * wid + f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {                 // one 2x2 pooling window: regs (i0, i0+1, i0+8, i0+9)
+        const int i0 = (j & 1) * 2 + (j >> 1) * 4;
+        const float v0 = fmaxf(acc[f][g][i0] + bi, 0.f) * sc + sh;
+        const float v1 = fmaxf(acc[f][g][i0 + 1] + bi, 0.f) * sc + sh;
+        const float v2 = fmaxf(acc[f][g][i0 + 8] + bi, 0.f) * sc + sh;
+        const float v3 = fmaxf(acc[f][g][i0 + 9] + bi, 0.f) * sc + sh;
+        const int r = (i0 & 3) + 8 * (i0 >> 2) + 4 * h;
+        const int PX = (ox0 >> 1) + ((r & 15) >> 1);
+        if (PY < Hp && PX < Wp) out[(((size_t)b * Hp + PY) * Wp + PX) * 64 + co] = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+      }
+    }
+  }
+}
+
+// HWIO [5,5,3,64] fp32 -> [part][ky][h][co][8] bf16 (three parts of every weight), k' = 8h+i = 3*kx + c, k' = 15 is the zero pad.
+__global__ void pack_conv1_split_kernel(const float* __restrict__ w, __bf16* __restrict__ wq) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= CM_WQ_F4 * 8) return;
+  const int e = i & 7, co = (i >> 3) & 63, h = (i >> 9) & 1, ky = i >> 10;
+  const int k = 8 * h + e;
+  float v = 0.f;
+  if (k < 15) v = w[(((size_t)ky * 5 + k / 3) * 3 + k % 3) * 64 + co];
+  for (int p = 0; p < CS_NP; ++p) {
+    const __bf16 q = (__bf16)v;
+    wq[(size_t)p * CM_WQ_F4 * 8 + i] = q;
+    v -= (float)q;
+  }
+}
+size_t conv1_split_weight_bytes() { return (size_t)CS_NP * CM_WQ_F4 * 16; }
+hipError_t pack_conv1_split(const float* w_hwio, void* wq, hipStream_t st) {
+  hipLaunchKernelGGL(pack_conv1_split_kernel, dim3((CM_WQ_F4 * 8 + 255) / 256), dim3(256), 0, st, w_hwio, static_cast<__bf16*>(wq));
+  return hipGetLastError();
+}
+hipError_t conv1_mfma_pool_split(const float* x, const void* wq, const float* bias, const float* scale, const float* shift, float* out,
+                                 int B, int H0, int W0, int sub, hipStream_t st) {
+  if (H0 % (4 * sub) != 0 || W0 % (4 * sub) != 0) return hipErrorInvalidValue;
+  const int Hin = H0 / sub, Win = W0 / sub;
+  const int Ho = Hin / 2, Wo = Win / 2;
+  const int tot_h = (Ho - 1) * 2 + 5 - Hin, tot_w = (Wo - 1) * 2 + 5 - Win;
+  const int pad_t = tot_h / 2, pad_l = tot_w / 2;
+  const int tiles_x = (Wo + CM_T - 1) / CM_T, tiles_y = (Ho + CM_T - 1) / CM_T;
+  hipLaunchKernelGGL(conv1_mfma_pool_split_kernel, dim3(tiles_x * tiles_y, B), dim3(256), 0, st, x, static_cast<const f32x4*>(wq), bias, scale, shift, out,
+                     H0, W0, sub, Hin, Win, Ho / 2, Wo / 2, pad_t, pad_l, tiles_x);
+  return hipGetLastError();
+}
+
 // HWIO [5,5,3,64] fp32 -> [ky][k' = 3*kx + c (15 = zero pad)][co] fp32
 __global__ void pack_conv1_f32_kernel(const float* __restrict__ w, float* __restrict__ wq) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

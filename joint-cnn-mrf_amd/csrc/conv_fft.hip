@@ -35,89 +35,100 @@ namespace cfft {
 
 // ---- filter spectra, split: HWIO fp32 [k][k][Cin][Cout] -> Wf[f][ci][co] = sum_{a,b} w[k-1-a][k-1-b][ci][co] e^{-2 pi i (ky a / NY + kx b / NX)}
 // (the flipped kernel: TF's conv2d is a correlation; output channels Cout .. CoutP-1 are zero), written as the channel GEMM's operand
-// image Ws[f][co/128][ci/16][re|im][part][k-half][128 columns][8 bf16] (cgemm_split.hip).  A work group owns 8 input channels (one
-// k-half) x 32 output channels: thread (ci, co) evaluates the separable 81- (25-) term DFT of its filter for one frequency after the
-// other, the 8 x 32 spectra meet in LDS, and 64 threads split them and store 16-byte units (32 columns = 512 contiguous bytes).
-// NP = 0: fp32 handles -- the spectra stay fp32 (the GEMM splits them on the way, cgemm_split.hip): Wf[f][co/ntl][ci/16][re|im][k-half][4-channel
-// half][ntl columns][4 fp32].
+// image Ws[f][co/ntl][ci/16][re|im][part][k-half][ntl columns][8 bf16] (cgemm_split.hip), or, NP = 0 (fp32 handles: the spectra stay fp32,
+// the GEMM splits them on the way): Wf[f][co/ntl][ci/16][re|im][k-half][4-channel half][ntl columns][4 fp32].
+// A thread owns the consecutive input channels of one 16-byte unit (8 bf16, or 4 fp32) of one output channel and one kx:
+// the k row sums of its filters stay in registers, then for one ky after the other the k-term column sum gives their spectra,
+// which are split and stored straight from registers -- consecutive threads are consecutive output channels, so a wave's store instruction is
+// one contiguous 1-KB run.  No exchange through LDS, no barrier in the loop (round 3: the packer runs once per weight update in the training
+// step, where it is 20 % of the step).
 template <int KS, int NP>
 __global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* __restrict__ w, uint4* __restrict__ Ws, int Cin, int Cout, int CoutP, int ntl, int NY, int NX,
                                                                    int round_bf16) {
-  constexpr int JQ = 8;      // frequencies (ky) per exchange through LDS: every thread stores, two barriers per 8 frequencies
   __shared__ cf twy[192][KS - 1], twx[KS];      // e^{-2 pi i ky a / NY} (a = 1..KS-1), e^{-2 pi i kx b / NX} of this block's kx
-  __shared__ cf sp[JQ][32][9];
   const int tid = threadIdx.x;
   const int kx = blockIdx.y;
+#pragma unroll 1
   for (int k = tid; k < NY * (KS - 1) + KS; k += 256) {
     const bool isy = k < NY * (KS - 1);
     const int ky = k / (KS - 1), a = isy ? k % (KS - 1) + 1 : k - NY * (KS - 1);
+    const int num = isy ? (ky * a) % NY : (kx * a) % NX, den = isy ? NY : NX;
     double sn, cs;
-    if (isy) sincospi(-2.0 * (double)((ky * a) % NY) / (double)NY, &sn, &cs);
-    else sincospi(-2.0 * (double)((kx * a) % NX) / (double)NX, &sn, &cs);
-    if (isy) twy[ky][a - 1] = cf{(float)cs, (float)sn};
-    else twx[a] = cf{(float)cs, (float)sn};
+    sincospi(-2.0 * (double)num / (double)den, &sn, &cs);
+    cf* dstw = isy ? &twy[ky][a - 1] : &twx[a];
+    *dstw = cf{(float)cs, (float)sn};
   }
   __syncthreads();
-  const int nco = CoutP / 32;
-  const int ci8 = blockIdx.x / nco, co32 = blockIdx.x % nco;
-  const int cil = tid & 7, col = tid >> 3;
-  const int ci = ci8 * 8 + cil, co = co32 * 32 + col;
-  float g[KS][KS];                                            // flipped kernel
+  constexpr int CPT = NP == 0 ? 4 : 8;                        // input channels per thread = one 16-byte unit of the layout
+  const size_t e = (size_t)blockIdx.x * 256 + tid;
+  if (e >= (size_t)(Cin / CPT) * CoutP) return;
+  const int co = (int)(e % CoutP), cig = (int)(e / CoutP);
+  cf ra[CPT][KS];                                             // row sums of the flipped kernels of input channels CPT cig .. +CPT-1
+  const unsigned toff = (unsigned)(cig * CPT * Cout + (co < Cout ? co : Cout - 1));
 #pragma unroll
-  for (int a = 0; a < KS; ++a)
+  for (int c = 0; c < CPT; ++c)
+#pragma unroll
+    for (int a = 0; a < KS; ++a) ra[c][a] = cf{0.f, 0.f};
+#pragma unroll 1
+  for (int a = 0; a < KS; ++a) {               // a real loop (k x CPT loads in flight, not k x k x CPT and their addresses) ...
+    cf sum[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) sum[c] = cf{0.f, 0.f};
 #pragma unroll
     for (int b = 0; b < KS; ++b) {
-      float wv = co < Cout ? w[(((size_t)((KS - 1 - a) * KS + (KS - 1 - b))) * Cin + ci) * Cout + co] : 0.f;
-      if (round_bf16) wv = static_cast<float>(static_cast<__bf16>(wv));       // bf16 handles: the filter the bf16 MFMA kernels multiply with
-      g[a][b] = wv;
+      // uniform tap base + 32-bit lane offset (always in bounds: no branch per load); tap-major so that one address serves the CPT channels
+      const float* tap = w + (size_t)((KS - 1 - a) * KS + (KS - 1 - b)) * Cin * Cout;
+      const cf tw = twx[b];
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) {
+        float wv = tap[toff + (unsigned)(c * Cout)];
+        wv = co < Cout ? wv : 0.f;
+        if (round_bf16) wv = static_cast<float>(static_cast<__bf16>(wv));       // bf16 handles: the filter the bf16 MFMA kernels multiply with
+        sum[c] = sfma(wv, tw, sum[c]);
+      }
     }
+#pragma unroll
+    for (int c = 0; c < CPT; ++c)
+#pragma unroll
+      for (int aa = 0; aa < KS; ++aa) ra[c][aa] = aa == a ? sum[c] : ra[c][aa];      // ... with the register array written by selects, not by index
+  }
   const int KC = Cin / 16, ntiles = CoutP / ntl;
-  const int kc = ci8 >> 1, kg = ci8 & 1;
-  // storing role of a thread: frequency j of the group, column scol; it writes the re and the im units of (column, this block's 8 channels)
-  const int sj = tid >> 5, scol = tid & 31;
-  const int sco = co32 * 32 + scol, snt = sco / ntl, sn = sco % ntl;
-  {
-    cf ra[KS];
+  const int ci0 = cig * CPT, kc = ci0 >> 4, kg = (ci0 >> 3) & 1, q4 = (ci0 >> 2) & 1, nt = co / ntl, sn = co % ntl;      // q4: 4-channel half (NP = 0)
+  // 16-byte units: stride between frequencies, and this thread's units inside one frequency
+  const size_t fstride = (size_t)ntiles * KC * (NP == 0 ? 8 : 4 * NP) * ntl;
+  uint4* dst = Ws + (size_t)kx * NY * fstride +
+               (NP == 0 ? (((((size_t)nt * KC + kc) * 2 + 0) * 2 + kg) * 2 + q4) * ntl + sn : ((size_t)nt * KC + kc) * (4 * NP) * ntl + (size_t)kg * ntl + sn);
+  for (int ky = 0; ky < NY; ++ky, dst += fstride) {
+    float xr[CPT], xi[CPT];
+    cf t[KS - 1];
 #pragma unroll
-    for (int a = 0; a < KS; ++a) {
-      cf s = {0.f, 0.f};
+    for (int a = 1; a < KS; ++a) t[a - 1] = twy[ky][a - 1];
 #pragma unroll
-      for (int b = 0; b < KS; ++b) s = sfma(g[a][b], twx[b], s);
-      ra[a] = s;
+    for (int c = 0; c < CPT; ++c) {
+      cf v = ra[c][0];
+#pragma unroll
+      for (int a = 1; a < KS; ++a) v = cmac(v, ra[c][a], t[a - 1]);
+      xr[c] = v.x;
+      xi[c] = v.y;
     }
-    for (int ky0 = 0; ky0 < NY; ky0 += JQ) {
+    if constexpr (NP == 0) {
+      // [re|im][k-half][4-channel half][ntl][4 fp32]: the im unit lies 4 ntl units behind the re unit
+      dst[0] = make_uint4(__float_as_uint(xr[0]), __float_as_uint(xr[1]), __float_as_uint(xr[2]), __float_as_uint(xr[3]));
+      dst[4 * ntl] = make_uint4(__float_as_uint(xi[0]), __float_as_uint(xi[1]), __float_as_uint(xi[2]), __float_as_uint(xi[3]));
+    } else {
+      // [re|im][part][k-half][ntl][8 bf16]
+      uint4 u[NP > 0 ? NP : 1];
+      float x8[8];
 #pragma unroll
-      for (int j = 0; j < JQ; ++j) {
-        const int ky = ky0 + j;
-        if (ky < NY) {
-          cf s = ra[0];
+      for (int c = 0; c < 8; ++c) x8[c] = xr[c % CPT];
+      split8<(NP > 0 ? NP : 1)>(x8, u);
 #pragma unroll
-          for (int a = 1; a < KS; ++a) s = s + cmul(ra[a], twy[ky][a - 1]);
-          sp[j][col][cil] = s;
-        }
-      }
-      __syncthreads();
-      if (ky0 + sj < NY) {
-        const size_t f = (size_t)kx * NY + ky0 + sj;
+      for (int p = 0; p < NP; ++p) dst[(size_t)p * 2 * ntl] = u[p];
 #pragma unroll
-        for (int sc = 0; sc < 2; ++sc) {
-          float x[8];
+      for (int c = 0; c < 8; ++c) x8[c] = xi[c % CPT];
+      split8<(NP > 0 ? NP : 1)>(x8, u);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) x[e] = sc ? sp[sj][scol][e].y : sp[sj][scol][e].x;
-          if constexpr (NP == 0) {
-            uint4* dst = Ws + ((((f * ntiles + snt) * KC + kc) * 2 + sc) * 2 + kg) * 2 * ntl + sn;
-            dst[0] = make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
-            dst[ntl] = make_uint4(__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7]));
-          } else {
-            uint4 u[NP > 0 ? NP : 1];
-            split8<(NP > 0 ? NP : 1)>(x, u);
-            uint4* dst = Ws + (((f * ntiles + snt) * KC + kc) * (4 * NP) + (sc * NP) * 2 + kg) * ntl + sn;
-#pragma unroll
-            for (int p = 0; p < NP; ++p) dst[(size_t)p * 2 * ntl] = u[p];
-          }
-        }
-      }
-      __syncthreads();
+      for (int p = 0; p < NP; ++p) dst[(size_t)(NP + p) * 2 * ntl] = u[p];
     }
   }
 }
@@ -207,7 +218,8 @@ hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, in
   Sizes s;
   if (!sizes_of(H, W, ks, &s) || Cin % 16 || (np != 2 && np != 3)) return hipErrorInvalidValue;
   const int ntl = cgemm_split_ntile(np, Cout), CoutP = padn(Cout, ntl);
-  const dim3 grid((unsigned)((Cin / 8) * (CoutP / 32)), (unsigned)(s.NX / 2 + 1));      // one kx per block
+  const size_t cpt = cgemm_split_w_fp32(np) ? 4 : 8;      // thread = (4 or 8 input channels: one 16-byte unit, output channel); one kx per block
+  const dim3 grid((unsigned)(((size_t)Cin / cpt * CoutP + 255) / 256), (unsigned)(s.NX / 2 + 1));
   uint4* dst = static_cast<uint4*>(wf);
   const int rb = round_bf16 ? 1 : 0;
   const bool f32 = cgemm_split_w_fp32(np);      // fp32 handles: unsplit spectra, the GEMM splits them

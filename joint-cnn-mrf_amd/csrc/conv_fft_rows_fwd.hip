@@ -79,25 +79,28 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_merge_kernel(cons
   const int y = by % H, b = by / H;
   twiddles<NX, NTR>(tw, twg, tid);
   const Tap ty2 = tf1_tap(y, H2, sy2), ty3 = tf1_tap(y, H3, sy3);
-  const int C2 = C / 2;
-  const cf* p1 = reinterpret_cast<const cf*>(x1 + ((size_t)(b * H + y) * W) * C + cblk * CB);
-  const cf* p2 = reinterpret_cast<const cf*>(x2 + (size_t)b * H2 * W2 * C + cblk * CB);
-  const cf* p3 = reinterpret_cast<const cf*>(x3 + (size_t)b * H3 * W3 * C + cblk * CB);
-  auto bil = [&](const cf* p, int Wl, Tap ty, Tap tx, int v) __attribute__((always_inline)) {
-    const cf tl = p[((size_t)ty.lo * Wl + tx.lo) * C2 + v], tr = p[((size_t)ty.lo * Wl + tx.hi) * C2 + v];
-    const cf bl = p[((size_t)ty.hi * Wl + tx.lo) * C2 + v], br = p[((size_t)ty.hi * Wl + tx.hi) * C2 + v];
-    return cf{lerp2(tl.x, tr.x, bl.x, br.x, tx.t, ty.t), lerp2(tl.y, tr.y, bl.y, br.y, tx.t, ty.t)};
+  // 16-byte loads: a thread-iteration forms two complex inputs (4 consecutive channels) of one pixel
+  const int C4 = C / 4;
+  const float4* p1 = reinterpret_cast<const float4*>(x1 + ((size_t)(b * H + y) * W) * C + cblk * CB);
+  const float4* p2 = reinterpret_cast<const float4*>(x2 + (size_t)b * H2 * W2 * C + cblk * CB);
+  const float4* p3 = reinterpret_cast<const float4*>(x3 + (size_t)b * H3 * W3 * C + cblk * CB);
+  auto bil = [&](const float4* p, int Wl, Tap ty, Tap tx, int v) __attribute__((always_inline)) {
+    const float4 tl = p[((size_t)ty.lo * Wl + tx.lo) * C4 + v], tr = p[((size_t)ty.lo * Wl + tx.hi) * C4 + v];
+    const float4 bl = p[((size_t)ty.hi * Wl + tx.lo) * C4 + v], br = p[((size_t)ty.hi * Wl + tx.hi) * C4 + v];
+    return make_float4(lerp2(tl.x, tr.x, bl.x, br.x, tx.t, ty.t), lerp2(tl.y, tr.y, bl.y, br.y, tx.t, ty.t), lerp2(tl.z, tr.z, bl.z, br.z, tx.t, ty.t),
+                       lerp2(tl.w, tr.w, bl.w, br.w, tx.t, ty.t));
   };
-  for (int t = tid; t < NX * CH; t += NTR) {
-    const int x = t / CH, v = t % CH;
-    cf z = {0.f, 0.f};
+  constexpr int CQ = CH / 2;
+  for (int t = tid; t < NX * CQ; t += NTR) {
+    const int x = t / CQ, v = t % CQ;
+    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     if (x < W) {
-      const cf a = p1[(size_t)x * C2 + v];
-      const cf u2 = (H2 == H && W2 == W) ? p2[((size_t)y * W + x) * C2 + v] : bil(p2, W2, ty2, tf1_tap(x, W2, sx2), v);
-      const cf u3 = (H3 == H && W3 == W) ? p3[((size_t)y * W + x) * C2 + v] : bil(p3, W3, ty3, tf1_tap(x, W3, sx3), v);
-      z = cf{((a.x + u2.x) + u3.x) / 3.0f, ((a.y + u2.y) + u3.y) / 3.0f};
+      const float4 a = p1[(size_t)x * C4 + v];
+      const float4 u2 = (H2 == H && W2 == W) ? p2[((size_t)y * W + x) * C4 + v] : bil(p2, W2, ty2, tf1_tap(x, W2, sx2), v);
+      const float4 u3 = (H3 == H && W3 == W) ? p3[((size_t)y * W + x) * C4 + v] : bil(p3, W3, ty3, tf1_tap(x, W3, sx3), v);
+      z = make_float4(((a.x + u2.x) + u3.x) / 3.0f, ((a.y + u2.y) + u3.y) / 3.0f, ((a.z + u2.z) + u3.z) / 3.0f, ((a.w + u2.w) + u3.w) / 3.0f);
     }
-    buf[t] = z;
+    *reinterpret_cast<float4*>(&buf[x * CH + 2 * v]) = z;
   }
   __syncthreads();
   fft<NX, -1, CH, NTR>(buf, tw, tid);

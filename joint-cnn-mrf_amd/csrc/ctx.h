@@ -58,6 +58,7 @@ struct ConvLayer {
   void* wp_kxfold = nullptr;      // logits layer packed for conv_kxfold_bf16 (bf16 handles, Cout == 9)
   void* wq1_bf16 = nullptr;       // packed for conv1_mfma_pool (5x5, Cin=3, Cout=64)
   float* wq1_f32 = nullptr;       // packed for conv1_mfma_pool_f32 (fp32 handles)
+  void* wq1_split = nullptr;      // packed for conv1_mfma_pool_split (fp32 handles, default route)
   int coutp_bf16 = 0;
   bool thin = false;              // fp32: conv_thin_f32 instead of conv_igemm_f32
   bool thin_bf16 = false;         // bf16: conv_thin_bf16 (fp32 output) instead of conv_igemm_bf16

@@ -12,6 +12,13 @@ __device__ __forceinline__ cf cfma(cf a, cf b, cf c) { return __builtin_elementw
 __device__ __forceinline__ cf sfma(float a, cf b, cf c) { return __builtin_elementwise_fma(cf{a, a}, b, c); }
 template <int S> __device__ __forceinline__ cf muli(cf a) { return S > 0 ? cf{-a.y, a.x} : cf{a.y, -a.x}; }   // a * (S i)
 __device__ __forceinline__ cf cmul(cf a, cf b) { return cfma(a.yy, cf{-b.y, b.x}, a.xx * b); }
+// acc + a * b (complex) in TWO packed FMAs whose operand selects broadcast a.x / a.y and rotate b: no broadcast or rotated copy of either
+// operand lives in registers (a loop-invariant `a` would otherwise be hoisted as a.xx AND a.yy)
+__device__ __forceinline__ cf cmac(cf acc, cf a, cf b) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(a), "v"(b));                     // (a.x b.x, a.x b.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(acc) : "v"(a), "v"(b));      // (-a.y b.y, a.y b.x)
+  return acc;
+}
 // a + (S i) b in ONE packed add: the 90-degree rotation is the instruction's operand select (low result: a.x -+ b.y, high: a.y +- b.x)
 template <int S> __device__ __forceinline__ cf add_i(cf a, cf b) {
   cf r;

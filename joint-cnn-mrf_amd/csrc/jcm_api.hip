@@ -333,6 +333,8 @@ int refresh_derived(jcm_ctx* c, bool first) {
     if (L.ks == 5 && L.cin == 3 && L.cout == 64 && L.has_bn && c->precision == JCM_PRECISION_F32) {
       if (!L.wq1_f32) JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&L.wq1_f32), 5 * 16 * 64 * sizeof(float)));
       HIP_TRY(pack_conv1_f32(w.d, L.wq1_f32, c->stream));
+      if (!L.wq1_split) JCM_TRY(dev_alloc(c, &L.wq1_split, conv1_split_weight_bytes()));
+      HIP_TRY(pack_conv1_split(w.d, L.wq1_split, c->stream));
     }
     if (L.ks == 5 && L.cin == 3 && L.cout == 64 && L.has_bn && c->precision == JCM_PRECISION_BF16) {
       if (!L.wq1_bf16) JCM_TRY(dev_alloc(c, &L.wq1_bf16, 5 * 2 * 64 * 16));
@@ -493,8 +495,11 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
     if (!bf && L1->wq1_f32 && xh % (4 * xsub) == 0 && xw % (4 * xsub) == 0) {
       // fp32 path: conv1 + ReLU/BN + pool1 in one fp32-MFMA kernel (the unpooled 240x360x64 map never reaches HBM)
       p1 = act((size_t)B * h2 * w2 * L1->cout);
+      // default route (the stride-1 layers run on split operands on the bf16 matrix cores): conv1 too; the exact fp32 MFMA chain otherwise
+      const bool split1 = c->conv9_fft && c->f32_conv == 0 && L1->wq1_split;
       if (!c->dry)
-        HIP_TRY(conv1_mfma_pool_f32(xin, L1->wq1_f32, L1->bias, L1->scale, L1->shift, static_cast<float*>(p1), B, xh, xw, xsub, c->stream));
+        HIP_TRY(split1 ? conv1_mfma_pool_split(xin, L1->wq1_split, L1->bias, L1->scale, L1->shift, static_cast<float*>(p1), B, xh, xw, xsub, c->stream)
+                       : conv1_mfma_pool_f32(xin, L1->wq1_f32, L1->bias, L1->scale, L1->shift, static_cast<float*>(p1), B, xh, xw, xsub, c->stream));
     } else if (bf && L1->wq1_bf16 && xh % (4 * xsub) == 0 && xw % (4 * xsub) == 0) {
       // bf16 path: conv1 + ReLU/BN + pool1 in one MFMA kernel; only the pooled map touches HBM
       p1 = act((size_t)B * h2 * w2 * L1->cout);
@@ -1002,7 +1007,7 @@ int jcm_conv_kernel_name(jcm_handle h, const char* scope, int B, int H, int W, c
   a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout; a.relu_bn = L->has_bn ? 1 : 0;
   const char* k;
   if (L->cin == 3) {
-    k = h->precision == JCM_PRECISION_BF16 ? (L->wq1_bf16 ? "conv1_mfma_pool_kernel" : "conv1_5x5s2_kernel") : (L->wq1_f32 ? "conv1_mfma_pool_f32_kernel" : "conv1_5x5s2_kernel");
+    k = h->precision == JCM_PRECISION_BF16 ? (L->wq1_bf16 ? "conv1_mfma_pool_kernel" : "conv1_5x5s2_kernel") : (L->wq1_f32 ? (h->conv9_fft && h->f32_conv == 0 && L->wq1_split ? "conv1_mfma_pool_split_kernel" : "conv1_mfma_pool_f32_kernel") : "conv1_5x5s2_kernel");
   } else if (h->precision == JCM_PRECISION_BF16) {
     a.CoutP = L->coutp_bf16;
     a.in_planar = 0;

@@ -153,6 +153,11 @@ hipError_t conv1_mfma_pool(const float* x, const void* wq, const float* bias, co
 
 // the same fusion on the exact fp32 path (v_mfma_f32_32x32x2_f32): wq [5][16][64] fp32 from pack_conv1_f32, out fp32
 hipError_t pack_conv1_f32(const float* w_hwio, float* wq, hipStream_t st);
+// the same with fp32 operands as three bf16 parts on the bf16 matrix cores (fp32 handles on the default frequency-domain route)
+size_t conv1_split_weight_bytes();
+hipError_t pack_conv1_split(const float* w_hwio, void* wq, hipStream_t st);
+hipError_t conv1_mfma_pool_split(const float* x, const void* wq, const float* bias, const float* scale, const float* shift, float* out,
+                                 int B, int H0, int W0, int sub, hipStream_t st);
 hipError_t conv1_mfma_pool_f32(const float* x, const float* wq, const float* bias, const float* scale, const float* shift, float* out,
                                int B, int H0, int W0, int sub, hipStream_t st);
 

@@ -91,9 +91,6 @@ __global__ __launch_bounds__(NT) void wgrad_spec_kernel(Args a) {
       const int kg = seg & 1, cp = (seg >> 1) % 6, kcl = seg / 12;      // cp = re|im * 3 + part
       const int KC = op ? KCo : KCi, kc = (op ? tn : tm) * 8 + kcl;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-#ifdef WF_MODE
-      if (WF_MODE != 2)
-#endif
       if (kc < KC && r0 + j < rows_valid) {
         const uint4* src = op ? a.zs : a.xs;
         const int MT = op ? a.MTz : a.MTx, mtiles = (a.B + MT - 1) / MT, mt = r0 / MT, rl = r0 - mt * MT;
@@ -152,9 +149,6 @@ __global__ __launch_bounds__(NT) void wgrad_spec_kernel(Args a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int co = tn * TN + (wn * 2 + j) * 32 + l31;
-#ifdef WF_MODE
-          if (WF_MODE != 1 || pr[i][j][e] == 12345.f)
-#endif
           if (co < a.Cout) pf[(size_t)ci * a.Cout + co] = make_float2(pr[i][j][e], pi[i][j][e]);
         }
       }

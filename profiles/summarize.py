@@ -5,6 +5,7 @@ are committed under profiles/.
   python profiles/summarize.py stats gpurun_out/prof_r1/r1_results.db  > profiles/rNN_kernel_stats.csv
   python profiles/summarize.py pmc   gpurun_out/pmc_x/x_results.db ... > profiles/rNN_pmc.csv
   python profiles/summarize.py pmc_min 10000 db...   (only dispatches of >= 10 ms: the dominant 60x90 launches)
+  python profiles/summarize.py table profiles/rNN_pmc.csv [profiles/rNN_kernel_stats.csv]   (markdown: bytes, us, TB/s per kernel)
 
 `stats` = per-kernel calls / total / average / share (what `--kernel-trace --stats` tabulates);
 `pmc`   = per-kernel, per-counter mean value per dispatch (one --pmc pass per database).
@@ -67,8 +68,40 @@ def trace(db, pattern, last=0):
         print('"%s",%.1f,%.1f' % (short(n), (st - t0) / 1e3, d / 1e3))
 
 
+def table(pmc_csv, stats_csv=None):
+    """Markdown table of the HBM-side figures per kernel from a committed pmc CSV: bytes per dispatch = 2 x FETCH_SIZE + WRITE_SIZE
+    (both in KB; FETCH_SIZE doubled: gfx950 tallies 128-byte requests at 64 bytes), mean dispatch time of the kernel-trace run if
+    `stats_csv` is given (counter passes run slower), achieved TB/s, clock (GRBM_GUI_ACTIVE is summed over the 8 XCDs) and MFMA-busy share."""
+    import csv
+    ctr = {}
+    for r in csv.DictReader(open(pmc_csv)):
+        ctr.setdefault(r['kernel'], {})[r['counter']] = (float(r['mean_value_per_dispatch']), float(r['mean_duration_us']), int(r['dispatches']))
+    avg = {}
+    if stats_csv:
+        for r in csv.DictReader(open(stats_csv)):
+            avg[r['kernel']] = (float(r['avg_us']), int(r['calls']))
+    rows = []
+    for k, c in ctr.items():
+        if 'FETCH_SIZE' not in c or 'WRITE_SIZE' not in c:
+            continue
+        rd, wr = 2 * c['FETCH_SIZE'][0] * 1024, c['WRITE_SIZE'][0] * 1024
+        us = avg.get(k, (c['GRBM_GUI_ACTIVE'][1] if 'GRBM_GUI_ACTIVE' in c else c['FETCH_SIZE'][1], 0))[0]
+        n = c['FETCH_SIZE'][2]
+        ghz = c['GRBM_GUI_ACTIVE'][0] / 8.0 / (c['GRBM_GUI_ACTIVE'][1] * 1e3) if 'GRBM_GUI_ACTIVE' in c else float('nan')
+        busy = ''
+        if c.get('SQ_VALU_MFMA_BUSY_CYCLES', (0,))[0] > 0 and 'SQ_BUSY_CU_CYCLES' in c:
+            busy = '%.0f %%' % (100.0 * c['SQ_VALU_MFMA_BUSY_CYCLES'][0] / (4.0 * c['SQ_BUSY_CU_CYCLES'][0]))
+        rows.append((us * n, k, n, us, rd, wr, (rd + wr) / (us * 1e-6) / 1e12, ghz, busy))
+    print('| kernel | dispatches | mean us | read MB | written MB | TB/s | GHz | MFMA busy |')
+    print('|---|---|---|---|---|---|---|---|')
+    for _, k, n, us, rd, wr, tbs, ghz, busy in sorted(rows, reverse=True):
+        print('| `%s` | %d | %.1f | %.0f | %.0f | %.2f | %.2f | %s |' % (k, n, us, rd / 1e6, wr / 1e6, tbs, ghz, busy))
+
+
 if __name__ == '__main__':
-    if sys.argv[1] == 'trace':            # trace db pattern [last]
+    if sys.argv[1] == 'table':            # table pmc.csv [kernel_stats.csv]
+        table(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
+    elif sys.argv[1] == 'trace':            # trace db pattern [last]
         trace(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 0)
     elif sys.argv[1] == 'stats':
         stats(sys.argv[2])

@@ -1,5 +1,5 @@
 // Timing of the frequency-domain weight gradient kernels (joint-cnn-mrf_amd/csrc/wgrad_fft.hip) outside the library:
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I joint-cnn-mrf_amd/csrc [-DWF_MODE=1|2] tools/wgrad_fft_probe.hip -o tools/wgrad_fft_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I joint-cnn-mrf_amd/csrc tools/wgrad_fft_probe.hip -o tools/wgrad_fft_probe
 //   tools/wgrad_fft_probe <NY> <NX> <Cin> <Cout> <ks> [B MT iters]
 #include <hip/hip_runtime.h>
 
