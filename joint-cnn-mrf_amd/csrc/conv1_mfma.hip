@@ -1,4 +1,4 @@
-// conv1 on the bf16 path: 5x5 stride-2 SAME convolution 3 -> 64 of the (sub-sampled) RGB image
+// conv1 on the bf16 matrix cores: 5x5 stride-2 SAME convolution 3 -> 64 of the (sub-sampled) RGB image
 // fused with bias + ReLU + inference BatchNorm AND the 2x2/2 max-pool that follows it
 // (main.py:44-45, 52-53, 61-62), on v_mfma_f32_32x32x16_bf16.
 //
@@ -23,92 +23,155 @@ constexpr int CM_T = 16;                        // conv-output patch edge
 constexpr int CM_IN = 2 * (CM_T - 1) + 5;       // 35 input rows / cols
 constexpr int CM_ROW = 112;                     // bf16 row pitch of the LDS window (35*3 = 105 -> 112)
 constexpr int CM_WQ_F4 = 5 * 2 * 64;            // packed filter: [ky][h][co] x 16 B
+namespace cfft { int persistent_grid(const void* kernel, int ntiles, int threads); }      // conv_fft.hip: work groups the chip holds at once
+
+// Persistent work groups (round 3): a group stages the packed filter once and walks tiles t, t + grid, ...; the window of the NEXT tile is
+// loaded into registers (5 pixels per thread) before the MFMAs of the current one, so the global-load latency -- which bounded the
+// one-tile-per-group version at 2 groups per CU -- hides behind them.
+// NP = 1: bf16 operands (bf16 handles), bf16 output.  NP = 3: every fp32 value as three bf16 parts, the six products with p + q <= 2
+// (what is dropped is below 2^-24 of x*w; cgemm_split.hip's arithmetic, which the stride-1 layers of an fp32 handle on the default route run
+// on anyway): 120 MFMAs 32x32x16 per wave instead of 160 of the 32x32x2 fp32 ones at a quarter of their cost each; fp32 output.
+template <int NP, typename OutT>
+__device__ __forceinline__ void conv1_mfma_pool_body(const float* __restrict__ x, const f32x4* __restrict__ wq, const float* __restrict__ bias,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift, OutT* __restrict__ out, int H0, int W0,
+                                                     int sub, int Hin, int Win, int Hp, int Wp, int pad_t, int pad_l, int tiles_x, int tiles_img, int ntiles) {
+  __shared__ __attribute__((aligned(16))) __bf16 win[NP][CM_IN * CM_ROW];
+  __shared__ __attribute__((aligned(16))) f32x4 wl[NP][CM_WQ_F4];
+  constexpr int PPT = (CM_IN * CM_IN + 255) / 256;      // window pixels per thread
+  const int tid = threadIdx.x;
+  // the 7-element tail of every 112-element row is zeroed once (it only ever meets zero weights; the pixel stores never touch it)
+  for (int i = tid; i < NP * CM_IN * (CM_ROW - CM_IN * 3); i += 256) {
+    const int p = i / (CM_IN * (CM_ROW - CM_IN * 3)), r = i - p * (CM_IN * (CM_ROW - CM_IN * 3));
+    const int iy = r / (CM_ROW - CM_IN * 3), e = r - iy * (CM_ROW - CM_IN * 3);
+    win[p][iy * CM_ROW + CM_IN * 3 + e] = (__bf16)0.f;
+  }
+  for (int i = tid; i < NP * CM_WQ_F4; i += 256) (&wl[0][0])[i] = wq[i];
+
+  const int lane = tid & 63, wid = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int px = l31 & 15, pr = l31 >> 4;
+  float bi[2], sc[2], sh[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) { bi[g] = bias[g * 32 + l31]; sc[g] = scale[g * 32 + l31]; sh[g] = shift[g * 32 + l31]; }
+
+  float v[PPT][3];
+  auto load_tile = [&](int t) __attribute__((always_inline)) {
+    const int b = t / tiles_img, r = t - b * tiles_img;
+    const int ty = r / tiles_x, tx = r - ty * tiles_x;
+    const float* xb = x + (size_t)b * H0 * W0 * 3;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const int i = tid + 256 * k;
+      const int iy = i / CM_IN, ix = i - iy * CM_IN;
+      const int gy = ty * CM_T * 2 - pad_t + iy, gx = tx * CM_T * 2 - pad_l + ix;
+      v[k][0] = v[k][1] = v[k][2] = 0.f;
+      if (i < CM_IN * CM_IN && (unsigned)gy < (unsigned)Hin && (unsigned)gx < (unsigned)Win) {
+        const float* px3 = xb + ((size_t)(gy * sub) * W0 + gx * sub) * 3;
+        v[k][0] = px3[0]; v[k][1] = px3[1]; v[k][2] = px3[2];
+      }
+    }
+  };
+  int t = blockIdx.x;
+  if (t < ntiles) load_tile(t);
+  for (; t < ntiles; t += gridDim.x) {
+    // window -> LDS as bf16 parts (round to nearest even; the remainders are exact)
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const int i = tid + 256 * k;
+      if (i < CM_IN * CM_IN) {
+        const int iy = i / CM_IN, ix = i - iy * CM_IN;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int e = 0; e < 3; ++e) {
+            const __bf16 q = (__bf16)v[k][e];
+            win[p][iy * CM_ROW + ix * 3 + e] = q;
+            v[k][e] -= (float)q;
+          }
+      }
+    }
+    __syncthreads();
+    if (t + (int)gridDim.x < ntiles) load_tile(t + gridDim.x);      // in flight behind the MFMAs below
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[f][g][i] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+      bf16x8 af[NP][2], bf[NP][2];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const unsigned* win32 = reinterpret_cast<const unsigned*>(win[p]);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          const int py = 2 * (2 * wid + f) + pr;                                  // conv row inside the patch
+          const int e0 = ((2 * py + ky) * CM_ROW + 6 * px + 8 * h) >> 1;          // dword index (4-byte aligned)
+          u32x4 u;
+          u[0] = win32[e0]; u[1] = win32[e0 + 1]; u[2] = win32[e0 + 2]; u[3] = win32[e0 + 3];
+          af[p][f] = __builtin_bit_cast(bf16x8, u);
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) bf[p][g] = __builtin_bit_cast(bf16x8, wl[p][(ky * 2 + h) * 64 + g * 32 + l31]);
+      }
+      // NP = 3, small terms first: (x part, w part) = (0,2) (1,1) (2,0) (1,0) (0,1) (0,0)
+      constexpr int NPROD = NP == 3 ? 6 : 1;
+#pragma unroll
+      for (int s = 0; s < NPROD; ++s) {
+        const int pxp = NP == 1 ? 0 : (s == 0 ? 0 : s == 1 ? 1 : s == 2 ? 2 : s == 3 ? 1 : 0);
+        const int pwp = NP == 1 ? 0 : (s == 0 ? 2 : s == 1 ? 1 : s == 2 ? 0 : s == 3 ? 0 : s == 4 ? 1 : 0);
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int g = 0; g < 2; ++g) acc[f][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pxp][f], bf[pwp][g], acc[f][g], 0, 0, 0);
+      }
+    }
+    // epilogue.  Accumulator reg i of lane (h, co) is fragment pixel r = (i&3) + 8*(i>>2) + 4*h, i.e.
+    // patch row (r>>4), column (r&15): regs {i, i+1} are horizontal neighbours (i even) and
+    // {i, i+8} vertical ones, so one lane holds whole 2x2 windows: pooled column q = (r&15)>>1.
+    const int b = t / tiles_img, rt = t - b * tiles_img;
+    const int ty = rt / tiles_x, tx = rt - ty * tiles_x;
+    const int oy0 = ty * CM_T, ox0 = tx * CM_T;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int co = g * 32 + l31;
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const int PY = (oy0 >> 1) + 2 * wid + f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                 // j -> regs (i0, i0+1, i0+8, i0+9), i0 = (j&1)*2 + (j>>1)*4
+          const int i0 = (j & 1) * 2 + (j >> 1) * 4;
+          const float v0 = fmaxf(acc[f][g][i0] + bi[g], 0.f) * sc[g] + sh[g];
+          const float v1 = fmaxf(acc[f][g][i0 + 1] + bi[g], 0.f) * sc[g] + sh[g];
+          const float v2 = fmaxf(acc[f][g][i0 + 8] + bi[g], 0.f) * sc[g] + sh[g];
+          const float v3 = fmaxf(acc[f][g][i0 + 9] + bi[g], 0.f) * sc[g] + sh[g];
+          const int r = (i0 & 3) + 8 * (i0 >> 2) + 4 * h;     // fragment pixel of reg i0 (row 0 of the pair)
+          const int PX = (ox0 >> 1) + ((r & 15) >> 1);
+          if (PY < Hp && PX < Wp) out[(((size_t)b * Hp + PY) * Wp + PX) * 64 + co] = (OutT)fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+        }
+      }
+    }
+    __syncthreads();      // the window is overwritten by the next tile
+  }
+}
 
 __global__ __launch_bounds__(256) void conv1_mfma_pool_kernel(const float* __restrict__ x, const f32x4* __restrict__ wq,
                                                               const float* __restrict__ bias, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, __bf16* __restrict__ out,
                                                               int H0, int W0, int sub, int Hin, int Win, int Hp, int Wp,
-                                                              int pad_t, int pad_l, int tiles_x) {
-  __shared__ __attribute__((aligned(16))) __bf16 win[CM_IN * CM_ROW];
-  __shared__ __attribute__((aligned(16))) f32x4 wl[CM_WQ_F4];
-  const int b = blockIdx.y;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int oy0 = ty * CM_T, ox0 = tx * CM_T;
-  const int tid = threadIdx.x;
-  const float* xb = x + (size_t)b * H0 * W0 * 3;
-  // window -> LDS as bf16, one pixel (3 contiguous floats = one dwordx3 load) per thread-iteration;
-  // the 7-element tail of every 112-element row is zeroed once (it only ever meets zero weights)
-  for (int i = tid; i < CM_IN * CM_IN; i += 256) {
-    const int iy = i / CM_IN, ix = i - iy * CM_IN;
-    const int gy = oy0 * 2 - pad_t + iy, gx = ox0 * 2 - pad_l + ix;
-    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-    if ((unsigned)gy < (unsigned)Hin && (unsigned)gx < (unsigned)Win) {
-      const float* px3 = xb + ((size_t)(gy * sub) * W0 + gx * sub) * 3;
-      v0 = px3[0]; v1 = px3[1]; v2 = px3[2];
-    }
-    __bf16* w3 = win + iy * CM_ROW + ix * 3;
-    w3[0] = (__bf16)v0; w3[1] = (__bf16)v1; w3[2] = (__bf16)v2;
-  }
-  for (int i = tid; i < CM_IN * (CM_ROW - CM_IN * 3); i += 256) {
-    const int iy = i / (CM_ROW - CM_IN * 3), e = i - iy * (CM_ROW - CM_IN * 3);
-    win[iy * CM_ROW + CM_IN * 3 + e] = (__bf16)0.f;
-  }
-  for (int i = tid; i < CM_WQ_F4; i += 256) wl[i] = wq[i];
-  __syncthreads();
-
-  const int lane = tid & 63, wid = tid >> 6;
-  const int h = lane >> 5, l31 = lane & 31;
-  const int px = l31 & 15, pr = l31 >> 4;
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int f = 0; f < 2; ++f)
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[f][g][i] = 0.f;
-  const unsigned* win32 = reinterpret_cast<const unsigned*>(win);
-#pragma unroll
-  for (int ky = 0; ky < 5; ++ky) {
-    bf16x8 af[2], bf[2];
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      const int py = 2 * (2 * wid + f) + pr;                                  // conv row inside the patch
-      const int e0 = ((2 * py + ky) * CM_ROW + 6 * px + 8 * h) >> 1;          // dword index (4-byte aligned)
-      u32x4 v;
-      v[0] = win32[e0]; v[1] = win32[e0 + 1]; v[2] = win32[e0 + 2]; v[3] = win32[e0 + 3];
-      af[f] = __builtin_bit_cast(bf16x8, v);
-    }
-#pragma unroll
-    for (int g = 0; g < 2; ++g) bf[g] = __builtin_bit_cast(bf16x8, wl[(ky * 2 + h) * 64 + g * 32 + l31]);
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-      for (int g = 0; g < 2; ++g) acc[f][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[f], bf[g], acc[f][g], 0, 0, 0);
-  }
-  // epilogue.  Accumulator reg i of lane (h, co) is fragment pixel r = (i&3) + 8*(i>>2) + 4*h, i.e.
-  // patch row (r>>4), column (r&15): regs {i, i+1} are horizontal neighbours (i even) and
-  // {i, i+8} vertical ones, so one lane holds whole 2x2 windows: pooled column q = (r&15)>>1.
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    const int co = g * 32 + l31;
-    const float bi = bias[co], sc = scale[co], sh = shift[co];
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      const int PY = (oy0 >> 1) + 2 * wid + f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {                 // j -> regs (i0, i0+1, i0+8, i0+9), i0 = (j&1)*2 + (j>>1)*4
-        const int i0 = (j & 1) * 2 + (j >> 1) * 4;
-        const float v0 = fmaxf(acc[f][g][i0] + bi, 0.f) * sc + sh;
-        const float v1 = fmaxf(acc[f][g][i0 + 1] + bi, 0.f) * sc + sh;
-        const float v2 = fmaxf(acc[f][g][i0 + 8] + bi, 0.f) * sc + sh;
-        const float v3 = fmaxf(acc[f][g][i0 + 9] + bi, 0.f) * sc + sh;
-        const int r = (i0 & 3) + 8 * (i0 >> 2) + 4 * h;     // fragment pixel of reg i0 (row 0 of the pair)
-        const int PX = (ox0 >> 1) + ((r & 15) >> 1);
-        if (PY < Hp && PX < Wp)
-          out[(((size_t)b * Hp + PY) * Wp + PX) * 64 + co] = (__bf16)fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
-      }
-    }
-  }
+                                                              int pad_t, int pad_l, int tiles_x, int tiles_img, int ntiles) {
+  conv1_mfma_pool_body<1, __bf16>(x, wq, bias, scale, shift, out, H0, W0, sub, Hin, Win, Hp, Wp, pad_t, pad_l, tiles_x, tiles_img, ntiles);
+}
+// fp32 handles on the default route: split operands (NP = 3), fp32 in, fp32 out
+__global__ __launch_bounds__(256) void conv1_mfma_pool_split_kernel(const float* __restrict__ x, const f32x4* __restrict__ wq,
+                                                                    const float* __restrict__ bias, const float* __restrict__ scale,
+                                                                    const float* __restrict__ shift, float* __restrict__ out,
+                                                                    int H0, int W0, int sub, int Hin, int Win, int Hp, int Wp,
+                                                                    int pad_t, int pad_l, int tiles_x, int tiles_img, int ntiles) {
+  conv1_mfma_pool_body<3, float>(x, wq, bias, scale, shift, out, H0, W0, sub, Hin, Win, Hp, Wp, pad_t, pad_l, tiles_x, tiles_img, ntiles);
 }
 
 // ---- the same fusion on the exact fp32 path: v_mfma_f32_32x32x2_f32 (an exact k-ordered fma chain), fp32 window in LDS.
@@ -192,106 +255,7 @@ __global__ __launch_bounds__(256) void conv1_mfma_pool_f32_kernel(const float* _
   }
 }
 
-// ---- fp32 handles on the default route: the bf16 kernel above with SPLIT operands -- every fp32 value as three bf16 parts, the six products
-// with p + q <= 2 (what is dropped is below 2^-24 of x*w; cgemm_split.hip's arithmetic, which the stride-1 layers of such a handle run on
-// anyway).  120 MFMAs 32x32x16 per wave instead of 160 of the 32x32x2 fp32 ones at a quarter of their cost each.  fp32 in, fp32 out.
 constexpr int CS_NP = 3;
-__global__ __launch_bounds__(256) void conv1_mfma_pool_split_kernel(const float* __restrict__ x, const f32x4* __restrict__ wq,
-                                                                    const float* __restrict__ bias, const float* __restrict__ scale,
-                                                                    const float* __restrict__ shift, float* __restrict__ out,
-                                                                    int H0, int W0, int sub, int Hin, int Win, int Hp, int Wp,
-                                                                    int pad_t, int pad_l, int tiles_x) {
-  __shared__ __attribute__((aligned(16))) __bf16 win[CS_NP][CM_IN * CM_ROW];
-  __shared__ __attribute__((aligned(16))) f32x4 wl[CS_NP][CM_WQ_F4];
-  const int b = blockIdx.y;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int oy0 = ty * CM_T, ox0 = tx * CM_T;
-  const int tid = threadIdx.x;
-  const float* xb = x + (size_t)b * H0 * W0 * 3;
-  for (int i = tid; i < CM_IN * CM_IN; i += 256) {
-    const int iy = i / CM_IN, ix = i - iy * CM_IN;
-    const int gy = oy0 * 2 - pad_t + iy, gx = ox0 * 2 - pad_l + ix;
-    float v[3] = {0.f, 0.f, 0.f};
-    if ((unsigned)gy < (unsigned)Hin && (unsigned)gx < (unsigned)Win) {
-      const float* px3 = xb + ((size_t)(gy * sub) * W0 + gx * sub) * 3;
-      v[0] = px3[0]; v[1] = px3[1]; v[2] = px3[2];
-    }
-#pragma unroll
-    for (int p = 0; p < CS_NP; ++p)
-#pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        const __bf16 q = (__bf16)v[e];                 // round to nearest even; the remainder is exact
-        win[p][iy * CM_ROW + ix * 3 + e] = q;
-        v[e] -= (float)q;
-      }
-  }
-  for (int i = tid; i < CS_NP * CM_IN * (CM_ROW - CM_IN * 3); i += 256) {
-    const int p = i / (CM_IN * (CM_ROW - CM_IN * 3)), r = i - p * (CM_IN * (CM_ROW - CM_IN * 3));
-    const int iy = r / (CM_ROW - CM_IN * 3), e = r - iy * (CM_ROW - CM_IN * 3);
-    win[p][iy * CM_ROW + CM_IN * 3 + e] = (__bf16)0.f;
-  }
-  for (int i = tid; i < CS_NP * CM_WQ_F4; i += 256) (&wl[0][0])[i] = wq[i];
-  __syncthreads();
-
-  const int lane = tid & 63, wid = tid >> 6;
-  const int h = lane >> 5, l31 = lane & 31;
-  const int px = l31 & 15, pr = l31 >> 4;
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int f = 0; f < 2; ++f)
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[f][g][i] = 0.f;
-#pragma unroll
-  for (int ky = 0; ky < 5; ++ky) {
-    bf16x8 af[CS_NP][2], bf[CS_NP][2];
-#pragma unroll
-    for (int p = 0; p < CS_NP; ++p) {
-      const unsigned* win32 = reinterpret_cast<const unsigned*>(win[p]);
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        const int py = 2 * (2 * wid + f) + pr;
-        const int e0 = ((2 * py + ky) * CM_ROW + 6 * px + 8 * h) >> 1;
-        u32x4 v;
-        v[0] = win32[e0]; v[1] = win32[e0 + 1]; v[2] = win32[e0 + 2]; v[3] = win32[e0 + 3];
-        af[p][f] = __builtin_bit_cast(bf16x8, v);
-      }
-#pragma unroll
-      for (int g = 0; g < 2; ++g) bf[p][g] = __builtin_bit_cast(bf16x8, wl[p][(ky * 2 + h) * 64 + g * 32 + l31]);
-    }
-    // small terms first: (x part, w part) = (0,2) (1,1) (2,0) (1,0) (0,1) (0,0)
-#pragma unroll
-    for (int s = 0; s < 6; ++s) {
-      const int pxp = s == 0 ? 0 : s == 1 ? 1 : s == 2 ? 2 : s == 3 ? 1 : 0, pwp = s == 0 ? 2 : s == 1 ? 1 : s == 2 ? 0 : s == 3 ? 0 : s == 4 ? 1 : 0;
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int g = 0; g < 2; ++g) acc[f][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pxp][f], bf[pwp][g], acc[f][g], 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    const int co = g * 32 + l31;
-    const float bi = bias[co], sc = scale[co], sh = shift[co];
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      const int PY = (oy0 >> 1) + 2 * wid + f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {                 // one 2x2 pooling window: regs (i0, i0+1, i0+8, i0+9)
-        const int i0 = (j & 1) * 2 + (j >> 1) * 4;
-        const float v0 = fmaxf(acc[f][g][i0] + bi, 0.f) * sc + sh;
-        const float v1 = fmaxf(acc[f][g][i0 + 1] + bi, 0.f) * sc + sh;
-        const float v2 = fmaxf(acc[f][g][i0 + 8] + bi, 0.f) * sc + sh;
-        const float v3 = fmaxf(acc[f][g][i0 + 9] + bi, 0.f) * sc + sh;
-        const int r = (i0 & 3) + 8 * (i0 >> 2) + 4 * h;
-        const int PX = (ox0 >> 1) + ((r & 15) >> 1);
-        if (PY < Hp && PX < Wp) out[(((size_t)b * Hp + PY) * Wp + PX) * 64 + co] = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
-      }
-    }
-  }
-}
-
 // HWIO [5,5,3,64] fp32 -> [part][ky][h][co][8] bf16 (three parts of every weight), k' = 8h+i = 3*kx + c, k' = 15 is the zero pad.
 __global__ void pack_conv1_split_kernel(const float* __restrict__ w, __bf16* __restrict__ wq) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -319,8 +283,10 @@ hipError_t conv1_mfma_pool_split(const float* x, const void* wq, const float* bi
   const int tot_h = (Ho - 1) * 2 + 5 - Hin, tot_w = (Wo - 1) * 2 + 5 - Win;
   const int pad_t = tot_h / 2, pad_l = tot_w / 2;
   const int tiles_x = (Wo + CM_T - 1) / CM_T, tiles_y = (Ho + CM_T - 1) / CM_T;
-  hipLaunchKernelGGL(conv1_mfma_pool_split_kernel, dim3(tiles_x * tiles_y, B), dim3(256), 0, st, x, static_cast<const f32x4*>(wq), bias, scale, shift, out,
-                     H0, W0, sub, Hin, Win, Ho / 2, Wo / 2, pad_t, pad_l, tiles_x);
+  const int ntiles = tiles_x * tiles_y * B;
+  const int grid = cfft::persistent_grid(reinterpret_cast<const void*>(conv1_mfma_pool_split_kernel), ntiles, 256);
+  hipLaunchKernelGGL(conv1_mfma_pool_split_kernel, dim3(grid), dim3(256), 0, st, x, static_cast<const f32x4*>(wq), bias, scale, shift, out,
+                     H0, W0, sub, Hin, Win, Ho / 2, Wo / 2, pad_t, pad_l, tiles_x, tiles_x * tiles_y, ntiles);
   return hipGetLastError();
 }
 
@@ -375,8 +341,10 @@ hipError_t conv1_mfma_pool(const float* x, const void* wq, const float* bias, co
   const int tot_h = (Ho - 1) * 2 + 5 - Hin, tot_w = (Wo - 1) * 2 + 5 - Win;     // SAME: 3 -> (1 before, 2 after)
   const int pad_t = tot_h / 2, pad_l = tot_w / 2;
   const int tiles_x = (Wo + CM_T - 1) / CM_T, tiles_y = (Ho + CM_T - 1) / CM_T;
-  hipLaunchKernelGGL(conv1_mfma_pool_kernel, dim3(tiles_x * tiles_y, B), dim3(256), 0, st, x, static_cast<const f32x4*>(wq), bias,
-                     scale, shift, static_cast<__bf16*>(out), H0, W0, sub, Hin, Win, Ho / 2, Wo / 2, pad_t, pad_l, tiles_x);
+  const int ntiles = tiles_x * tiles_y * B;
+  const int grid = cfft::persistent_grid(reinterpret_cast<const void*>(conv1_mfma_pool_kernel), ntiles, 256);
+  hipLaunchKernelGGL(conv1_mfma_pool_kernel, dim3(grid), dim3(256), 0, st, x, static_cast<const f32x4*>(wq), bias,
+                     scale, shift, static_cast<__bf16*>(out), H0, W0, sub, Hin, Win, Ho / 2, Wo / 2, pad_t, pad_l, tiles_x, tiles_x * tiles_y, ntiles);
   return hipGetLastError();
 }
 

@@ -170,7 +170,11 @@ __device__ __forceinline__ F8 bilinear8(const bf16x8v* base, int W, int C8, Tap 
 __global__ void upsample_merge3_bf16x8_kernel(const bf16x8v* __restrict__ x1, const bf16x8v* __restrict__ x2, int H2, int W2,
                                               const bf16x8v* __restrict__ x3, int H3, int W3, bf16x8v* __restrict__ out,
                                               int H, int W, int C8, float sy2, float sx2, float sy3, float sx3, size_t total) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  // work groups b, b + 8, ... share an XCD (and its L2): give each XCD a CONTIGUOUS eighth of every grid-sized span of pixels, so that the
+  // bilinear taps -- every coarse pixel is read by the 2x2 / 4x4 fine pixels around it -- are served by that L2 instead of being fetched
+  // from HBM once per XCD (measured: 5.3 GB read for 1.9 GB of distinct input)
+  const unsigned nb = gridDim.x, bid = nb % 8 == 0 ? (blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8 : blockIdx.x;
+  for (size_t i = (size_t)bid * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = i % C8;
     size_t r = i / C8;
     const int ox = r % W; r /= W;
