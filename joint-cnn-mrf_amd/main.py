@@ -18,6 +18,7 @@ checkpoints; `--restore --restore_path P` resumes from one.  Data: the .npy file
 import argparse
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -297,12 +298,11 @@ class TowerTrainer:
         for tr, eng in zip(self.trainers, tw.engines):
             with torch.cuda.device(eng.device):
                 tr.apply()
+        if tw.n == 1:                                              # one tower: its own moving statistics are the result, nothing to compose or read back
+            return self.trainers[0].losses
         names = sorted(self.moving)
         for i, name in enumerate(names):
             start = self.moving[name]
-            if tw.n == 1:
-                self.moving[name] = self.trainers[0].get_tensor(name, start.shape)
-                continue
             cur = start.astype(np.float64)
             for tr in self.trainers:                               # r_i = d * start + (1 - d) * stat_i  ->  cur = d * cur + (r_i - d * start)
                 cur = self.BN_DECAY * cur + (tr.get_tensor(name, start.shape).astype(np.float64) - self.BN_DECAY * start)
@@ -388,12 +388,18 @@ def main(argv=None):
         pairwise = get_pairwise_distr(args.data_dir)
     state = restore_params(args.restore_path, args) if args.restore else None
     params = {k: v for k, v in state.items() if k in checkpoint.expected_shapes(args.debug, args.use_sm)} if state else initial_params(args, pairwise)
-    towers = Towers(params, args.gpus, precision=args.precision)
-    configure(params, device=args.gpus[0], precision=args.precision, debug=args.debug)
+    # one set of engines only (each fp32 engine caches multi-GB filter spectra): the module engine for the multi-scale wrapper, which runs
+    # on one device, or one tower per listed device for the single-scale run
+    towers = None
     t0 = time.time()
     if args.multiscale:
+        if len(args.gpus) > 1:
+            print('--multiscale evaluates on device %d only; the other --gpus entries are not used' % args.gpus[0], file=sys.stderr)
+        configure(params, device=args.gpus[0], precision=args.precision, debug=args.debug)
         pred_pd, pred_sm = get_predictions(np.asarray(x_test), np.asarray(y_test))                     # main.py:674
     else:                                                                                              # single scale, sharded over the towers
+        hps.debug = bool(args.debug)
+        towers = Towers(params, args.gpus, precision=args.precision)
         B = args.batch_size
         pd, sm = [], []
         for lo in range(0, (x_test.shape[0] // B) * B, B):
@@ -412,7 +418,8 @@ def main(argv=None):
     print(json.dumps({'n_images': int(pred_pd.shape[2]), 'gpus': args.gpus, 'use_sm': bool(args.use_sm), 'debug': bool(args.debug),
                       'multiscale': bool(args.multiscale), 'seconds': dt, 'images_per_sec': pred_pd.shape[2] / dt,
                       'coords_image0_pd': pred_pd[:, :, 0].tolist()}))
-    towers.close()
+    if towers is not None:
+        towers.close()
 
 
 if __name__ == '__main__':
