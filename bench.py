@@ -42,15 +42,16 @@ FLOPS_DOMINANT = {'conv4_fullres': 114_661_785_600, 'conv5': 229_323_571_200}
 PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0                            # HBM3E spec (6.3 TB/s is what a streaming copy achieves)
 # Frequency-domain route (conv_fft.hip): 60x90 maps -> 64 x 96 circular transforms, 64 * 49 frequencies; the channel GEMM
-# (cgemm_split.hip) is one complex [B x Cin] x [Cin x Cout] product per frequency on bf16 MFMA with operands split into
-# NP bf16 parts (3 on fp32 handles: six real products per real multiply; 2 on bf16 handles: three).
+# (cgemm_split.hip) is one complex [B x Cin] x [Cin x Cout] product per frequency on the 16-bit matrix cores with operands split into
+# two 16-bit parts, three real products per real multiply: bf16 parts on bf16 handles, FP16 parts of spectra scaled by powers of two on
+# fp32 handles (22 significant bits: fp32-class).
 FFT_FREQS = 64 * 49
 GEMM_LAYERS = {'conv4_fullres': (256, 512), 'conv5': (512, 512)}
 
 
-def gemm_mtile(np_parts, b):
+def gemm_mtile(dtype, b):
     """cgemm_split_mtile() of cgemm_split.hip: rows of the M tile the activation spectra are laid out for."""
-    if np_parts == 2:
+    if dtype == 'bf16':
         return 256 if b > 128 else 128 if b > 64 else 64
     return 128 if b > 64 else 64
 
@@ -153,10 +154,10 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
         if freq_domain:
             # wide 9x9 layers in the frequency domain: the dominant kernel is the channel GEMM cgemm_split_kernel (one complex matrix
             # product per frequency); its own executed bf16-MFMA FLOPs and algorithmic HBM bytes, its own HIP events
-            np_parts = 2 if dtype == 'bf16' else 3
-            nprod = 3 if np_parts == 2 else 6
+            np_parts = 2                      # 16-bit parts per operand: two bf16 (bf16 handles) or two scaled fp16 (fp32 handles), three products either way
+            nprod = 3
             mrows = min(B, mb)
-            mt = gemm_mtile(np_parts, mrows)
+            mt = gemm_mtile(dtype, mrows)
             rows_p = -(-mrows // mt) * mt
             tot_ms, tot_n, tot_flops, tot_bytes, tot_flops32 = 0.0, 0, 0.0, 0.0, 0.0
             for scope, (cin, cout) in GEMM_LAYERS.items():
@@ -194,9 +195,9 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
             'scaling': 'weak',
             'roofline': {'bound': 'mfma', 'kernel': ('cgemm_split_kernel: channel GEMM of the frequency-domain 9x9 layers (conv4_fullres + conv5; %s)' if freq_domain else
                                                      'conv_igemm 9x9, 60x90 maps (conv4_fullres + conv5 launches; %s)')
-                                   % ('hand-written, v_mfma_f32_32x32x16_bf16, operands split into %d bf16 parts (%d real products per multiply), one complex [B x Cin] x [Cin x Cout] '
+                                   % ('hand-written, v_mfma_f32_32x32x16_%s, operands split into %d %s parts (%d real products per multiply), one complex [B x Cin] x [Cin x Cout] '
                                       'product per frequency of the 64 x 96 transform = 3136 per launch, LDS-DMA operand rings; achieved = executed bf16 MFMA FLOPs / GEMM time'
-                                      % (gemm['np_parts'], gemm['products'])
+                                      % ('bf16' if dtype == 'bf16' else 'f16', gemm['np_parts'], 'bf16' if dtype == 'bf16' else 'fp16 (scaled spectra)', gemm['products'])
                                       if freq_domain else
                                       'fp32 operands as 3 bf16 parts, 6 x bf16 MFMA 32x32x16 per k16 step, 12x32 patch x 256 ch; achieved = executed bf16 MFMA FLOPs (6 x algorithmic) against the bf16 peak'
                                       if f32_conv == 'split' else

@@ -37,6 +37,7 @@
 namespace jcm {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -44,10 +45,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 namespace cg {
 
 // NP parts per operand; WM x WN waves, FM x FN 32x32 fragments per wave; R stages in LDS; WF32: the W operand arrives as fp32 and is split here
-template <int NP_, int WM_, int WN_, int FM_, int FN_, int R_, bool WF32_ = false>
+// HALF: the parts are fp16 (11 significant bits each; operands scaled into the fp16 range by the producers) instead of bf16
+template <int NP_, int WM_, int WN_, int FM_, int FN_, int R_, bool WF32_ = false, bool HALF_ = false>
 struct Cfg {
   static constexpr int NP = NP_, WM = WM_, WN = WN_, FM = FM_, FN = FN_, R = R_;
-  static constexpr bool WF32 = WF32_;
+  static constexpr bool WF32 = WF32_, HALF = HALF_;
   static constexpr int NW = WM * WN, NT = 64 * NW;
   static constexpr int MT = 32 * WM * FM, NTL = 32 * WN * FN;
   static constexpr int XST = 4 * NP * MT, WST = 4 * NP * NTL;      // 16-byte units per stage: [re|im][part][k-half][rows]
@@ -95,6 +97,12 @@ __device__ __forceinline__ void frag_load(f32x4 (&xr)[C::FM], f32x4 (&xi)[C::FM]
   }
 }
 
+template <bool HALF>
+__device__ __forceinline__ f32x16 mfma16(const f32x4& a, const f32x4& b, const f32x16& c) {
+  if constexpr (HALF) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 struct Args {
   const char* xs;       // split activation spectra
   const char* ws;       // filter spectra: split (bf16 parts) or fp32 (Cfg::WF32)
@@ -104,7 +112,7 @@ struct Args {
 };
 
 // 8 fp32 -> NP 16-byte units of bf16 parts (x = x0 + x1 (+ x2), each part rounded to nearest even; exact for NP = 3)
-template <int NP>
+template <int NP, bool HALF = false>
 __device__ __forceinline__ void split_unit(const u32x4& lo, const u32x4& hi, u32x4 (&out)[NP]) {
   float v[8];
 #pragma unroll
@@ -114,9 +122,15 @@ __device__ __forceinline__ void split_unit(const u32x4& lo, const u32x4& hi, u32
     unsigned short q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const __bf16 r = static_cast<__bf16>(v[e]);
-      q[e] = __builtin_bit_cast(unsigned short, r);
-      v[e] = v[e] - static_cast<float>(r);
+      if constexpr (HALF) {
+        const _Float16 r = static_cast<_Float16>(v[e]);      // round to nearest even
+        q[e] = __builtin_bit_cast(unsigned short, r);
+        v[e] = v[e] - static_cast<float>(r);
+      } else {
+        const __bf16 r = static_cast<__bf16>(v[e]);
+        q[e] = __builtin_bit_cast(unsigned short, r);
+        v[e] = v[e] - static_cast<float>(r);
+      }
     }
     out[p] = u32x4{(unsigned)q[0] | ((unsigned)q[1] << 16), (unsigned)q[2] | ((unsigned)q[3] << 16), (unsigned)q[4] | ((unsigned)q[5] << 16), (unsigned)q[6] | ((unsigned)q[7] << 16)};
   }
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
       int c, kg;
       unit_of(u, c, kg);
       u32x4 parts[NP];
-      split_unit<NP>(wreg[u][0], wreg[u][1], parts);
+      split_unit<NP, C::HALF>(wreg[u][0], wreg[u][1], parts);
       u32x4* dst = reinterpret_cast<u32x4*>(smem + (size_t)slot * STAGE * 16 + XST * 16) + ((c * NP) * 2 + kg) * NTL + wcol;
 #pragma unroll
       for (int p = 0; p < NP; ++p) dst[p * 2 * NTL] = parts[p];
@@ -277,22 +291,22 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
       for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn)
-          accr[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xr[cur][fm]), __builtin_bit_cast(bf16x8, wr[cur][fn]), accr[fm][fn], 0, 0, 0);
+          accr[fm][fn] = mfma16<C::HALF>(xr[cur][fm], wr[cur][fn], accr[fm][fn]);
 #pragma unroll
       for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn)
-          acci[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xr[cur][fm]), __builtin_bit_cast(bf16x8, wi[cur][fn]), acci[fm][fn], 0, 0, 0);
+          acci[fm][fn] = mfma16<C::HALF>(xr[cur][fm], wi[cur][fn], acci[fm][fn]);
 #pragma unroll
       for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn)
-          accr[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, nxi[fm]), __builtin_bit_cast(bf16x8, wi[cur][fn]), accr[fm][fn], 0, 0, 0);
+          accr[fm][fn] = mfma16<C::HALF>(nxi[fm], wi[cur][fn], accr[fm][fn]);
 #pragma unroll
       for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn)
-          acci[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xi[cur][fm]), __builtin_bit_cast(bf16x8, wr[cur][fn]), acci[fm][fn], 0, 0, 0);
+          acci[fm][fn] = mfma16<C::HALF>(xi[cur][fm], wr[cur][fn], acci[fm][fn]);
       __builtin_amdgcn_sched_barrier(0);
     };
     product(std::integral_constant<int, 0>{});
@@ -346,6 +360,15 @@ using CfgB64 = Cfg<2, 1, 4, 2, 1, 2>;             // bf16 handles, <= 64 images
 using CfgF64 = Cfg<3, 1, 4, 2, 1, 2, true>;       // fp32 handles, <= 64 images per tile; fp32 filter spectra split in the kernel
 using CfgF128 = Cfg<3, 2, 2, 2, 2, 2, true>;      // fp32 handles, > 64 images: 128-row tiles
 using CfgF64T = Cfg<3, 2, 1, 1, 1, 2, true>;      // fp32 handles, Cout <= 32 (the logits layer): 64 x 32 tile, two waves
+// fp32 handles, np = 4: TWO FP16 parts per operand, three products (22 significant bits; the producers scale the spectra by powers of two so that
+// they fit fp16's range, conv_fft.hip) -- half the matrix-core work of the six-product bf16 form, a third less activation-spectra traffic.
+// Two fp16 parts are exactly as large as the fp32 number, so the filter spectra are stored split and both operands arrive by LDS-DMA.
+#ifndef CGEMM_H64_R
+#define CGEMM_H64_R 2
+#endif
+using CfgH64 = Cfg<2, 1, 4, 2, 1, CGEMM_H64_R, false, true>;      // <= 64 images
+using CfgH128 = Cfg<2, 2, 2, 2, 2, 2, false, true>;               // 65 .. 128 images per tile
+using CfgH64T = Cfg<2, 2, 1, 1, 1, 3, false, true>;               // Cout <= 32 (the logits layer): 64 x 32 tile, two waves
 
 template <class C> hipError_t launch(const Args& a, hipStream_t st) {
   static LdsAttr attr;
@@ -358,7 +381,9 @@ template <class C> hipError_t launch(const Args& a, hipStream_t st) {
 
 }  // namespace cg
 
-int cgemm_split_ntile(int np, int Cout) { return np == 3 && Cout <= 32 ? 32 : 128; }
+// np: 2 = bf16 handles (two bf16 parts, filter spectra pre-split); 3 = fp32 handles, three bf16 parts; 4 = fp32 handles, two fp16 parts (scaled)
+int cgemm_split_ntile(int np, int Cout) { return np >= 3 && Cout <= 32 ? 32 : 128; }
+int cgemm_split_parts(int np) { return np == 4 ? 2 : np; }
 int cgemm_split_mtile(int np, int B, int Cout) {
   if (cgemm_split_ntile(np, Cout) == 32) return 64;
   if (np == 2) return B > 128 ? 256 : B > 64 ? 128 : 64;
@@ -368,17 +393,18 @@ bool cgemm_split_w_fp32(int np) { return np == 3; }
 size_t cgemm_split_w_bytes(int np, int F, int Cin, int Cout) {
   const int ntl = cgemm_split_ntile(np, Cout);
   const size_t coutp = (size_t)(Cout + ntl - 1) / ntl * ntl;
-  return (size_t)F * Cin * coutp * (cgemm_split_w_fp32(np) ? 8 : 4 * np);
+  return (size_t)F * Cin * coutp * (cgemm_split_w_fp32(np) ? 8 : 4 * cgemm_split_parts(np));
 }
 
 hipError_t cgemm_split(const void* xs, const void* ws, void* y, int np, int F, int B, int Cin, int Cout, int ldy, hipStream_t st) {
   const int ntl = cgemm_split_ntile(np, Cout);
   const int ntiles = (Cout + ntl - 1) / ntl;
-  if ((np != 2 && np != 3) || Cin % 16 || ldy < ntiles * ntl || F < 1 || B < 1) return hipErrorInvalidValue;
+  if ((np != 2 && np != 3 && np != 4) || Cin % 16 || ldy < ntiles * ntl || F < 1 || B < 1) return hipErrorInvalidValue;
   const int MT = cgemm_split_mtile(np, B, Cout);
   cg::Args a{static_cast<const char*>(xs), static_cast<const char*>(ws), static_cast<float2*>(y), F, B, ldy, Cin / 16, (B + MT - 1) / MT, ntiles};
-  if ((long long)a.KC * 4 * np * (MT > ntl ? MT : ntl) * 16 >= (1ll << 31)) return hipErrorInvalidValue;      // buffer descriptor range
+  if ((long long)a.KC * 4 * cgemm_split_parts(np) * (MT > ntl ? MT : ntl) * 16 >= (1ll << 31)) return hipErrorInvalidValue;      // buffer descriptor range
   if (np == 2) return MT == 256 ? cg::launch<cg::CfgB256>(a, st) : MT == 128 ? cg::launch<cg::CfgB128>(a, st) : cg::launch<cg::CfgB64>(a, st);
+  if (np == 4) return ntl == 32 ? cg::launch<cg::CfgH64T>(a, st) : MT == 128 ? cg::launch<cg::CfgH128>(a, st) : cg::launch<cg::CfgH64>(a, st);
   if (ntl == 32) return cg::launch<cg::CfgF64T>(a, st);
   return MT == 128 ? cg::launch<cg::CfgF128>(a, st) : cg::launch<cg::CfgF64>(a, st);
 }

@@ -42,9 +42,11 @@ namespace cfft {
 // which are split and stored straight from registers -- consecutive threads are consecutive output channels, so a wave's store instruction is
 // one contiguous 1-KB run.  No exchange through LDS, no barrier in the loop (round 3: the packer runs once per weight update in the training
 // step, where it is 20 % of the step).
+// NP = 4: two FP16 parts of the spectrum times 2^k, k from wscale[0] = max over filters of sum |taps| >= |W[f]| (weight_bound_kernel); layout as
+// NP = 2; wscale[1] = 2^-k for the inverse row pass.
 template <int KS, int NP>
 __global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* __restrict__ w, uint4* __restrict__ Ws, int Cin, int Cout, int CoutP, int ntl, int NY, int NX,
-                                                                   int round_bf16) {
+                                                                   int round_bf16, float* __restrict__ wscale) {
   __shared__ cf twy[192][KS - 1], twx[KS];      // e^{-2 pi i ky a / NY} (a = 1..KS-1), e^{-2 pi i kx b / NX} of this block's kx
   const int tid = threadIdx.x;
   const int kx = blockIdx.y;
@@ -60,6 +62,15 @@ __global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* 
   }
   __syncthreads();
   constexpr int CPT = NP == 0 ? 4 : 8;                        // input channels per thread = one 16-byte unit of the layout
+  constexpr int NPP = NP == 4 ? 2 : NP;                       // 16-byte units per plane
+  float wmul = 1.f;
+  if constexpr (NP == 4) {
+    int ex = 0;
+    const float bound = wscale[0];
+    if (bound > 0.f && bound < 3.0e38f) (void)frexpf(bound, &ex);      // bound < 2^ex
+    wmul = ldexpf(1.f, 14 - ex);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) wscale[1] = ldexpf(1.f, ex - 14);
+  }
   const size_t e = (size_t)blockIdx.x * 256 + tid;
   if (e >= (size_t)(Cin / CPT) * CoutP) return;
   const int co = (int)(e % CoutP), cig = (int)(e / CoutP);
@@ -95,9 +106,9 @@ __global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* 
   const int KC = Cin / 16, ntiles = CoutP / ntl;
   const int ci0 = cig * CPT, kc = ci0 >> 4, kg = (ci0 >> 3) & 1, q4 = (ci0 >> 2) & 1, nt = co / ntl, sn = co % ntl;      // q4: 4-channel half (NP = 0)
   // 16-byte units: stride between frequencies, and this thread's units inside one frequency
-  const size_t fstride = (size_t)ntiles * KC * (NP == 0 ? 8 : 4 * NP) * ntl;
+  const size_t fstride = (size_t)ntiles * KC * (NP == 0 ? 8 : 4 * NPP) * ntl;
   uint4* dst = Ws + (size_t)kx * NY * fstride +
-               (NP == 0 ? (((((size_t)nt * KC + kc) * 2 + 0) * 2 + kg) * 2 + q4) * ntl + sn : ((size_t)nt * KC + kc) * (4 * NP) * ntl + (size_t)kg * ntl + sn);
+               (NP == 0 ? (((((size_t)nt * KC + kc) * 2 + 0) * 2 + kg) * 2 + q4) * ntl + sn : ((size_t)nt * KC + kc) * (4 * NPP) * ntl + (size_t)kg * ntl + sn);
   for (int ky = 0; ky < NY; ++ky, dst += fstride) {
     float xr[CPT], xi[CPT];
     cf t[KS - 1];
@@ -117,20 +128,38 @@ __global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* 
       dst[4 * ntl] = make_uint4(__float_as_uint(xi[0]), __float_as_uint(xi[1]), __float_as_uint(xi[2]), __float_as_uint(xi[3]));
     } else {
       // [re|im][part][k-half][ntl][8 bf16]
-      uint4 u[NP > 0 ? NP : 1];
+      uint4 u[NPP > 0 ? NPP : 1];
       float x8[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) x8[c] = xr[c % CPT];
-      split8<(NP > 0 ? NP : 1)>(x8, u);
+      if constexpr (NP == 4) split8h(x8, wmul, u);
+      else split8<(NPP > 0 ? NPP : 1)>(x8, u);
 #pragma unroll
-      for (int p = 0; p < NP; ++p) dst[(size_t)p * 2 * ntl] = u[p];
+      for (int p = 0; p < NPP; ++p) dst[(size_t)p * 2 * ntl] = u[p];
 #pragma unroll
       for (int c = 0; c < 8; ++c) x8[c] = xi[c % CPT];
-      split8<(NP > 0 ? NP : 1)>(x8, u);
+      if constexpr (NP == 4) split8h(x8, wmul, u);
+      else split8<(NPP > 0 ? NPP : 1)>(x8, u);
 #pragma unroll
-      for (int p = 0; p < NP; ++p) dst[(size_t)(NP + p) * 2 * ntl] = u[p];
+      for (int p = 0; p < NPP; ++p) dst[(size_t)(NPP + p) * 2 * ntl] = u[p];
     }
   }
+}
+
+// max over (ci, co) of sum_taps |w|: a bound of |W[f][ci][co]| for every frequency (np = 4)
+__global__ __launch_bounds__(256) void weight_bound_kernel(const float* __restrict__ w, int taps, size_t pairs, int round_bf16, float* __restrict__ wmax) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < pairs; e += (size_t)gridDim.x * 256) {
+    float sum = 0.f;
+    for (int t = 0; t < taps; ++t) {
+      float v = w[(size_t)t * pairs + e];
+      if (round_bf16) v = static_cast<float>(static_cast<__bf16>(v));
+      sum += fabsf(v);
+    }
+    m = fmaxf(m, sum);
+  }
+  block_max_to<256>(m * 1.0001f, wmax, red, threadIdx.x);      // (a hair of slack for the rounding of this sum)
 }
 
 struct Sizes { int NY, NX; };
@@ -214,21 +243,27 @@ size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout, int np) {
   if (!sizes_of(H, W, ks, &s)) return 0;
   return cgemm_split_w_bytes(np, s.NY * (s.NX / 2 + 1), Cin, Cout);
 }
-hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, int np, bool round_bf16, hipStream_t st) {
+hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, int np, bool round_bf16, hipStream_t st, float* wscale) {
   Sizes s;
-  if (!sizes_of(H, W, ks, &s) || Cin % 16 || (np != 2 && np != 3)) return hipErrorInvalidValue;
+  if (!sizes_of(H, W, ks, &s) || Cin % 16 || (np != 2 && np != 3 && np != 4) || (np == 4 && !wscale)) return hipErrorInvalidValue;
   const int ntl = cgemm_split_ntile(np, Cout), CoutP = padn(Cout, ntl);
   const size_t cpt = cgemm_split_w_fp32(np) ? 4 : 8;      // thread = (4 or 8 input channels: one 16-byte unit, output channel); one kx per block
   const dim3 grid((unsigned)(((size_t)Cin / cpt * CoutP + 255) / 256), (unsigned)(s.NX / 2 + 1));
   uint4* dst = static_cast<uint4*>(wf);
   const int rb = round_bf16 ? 1 : 0;
-  const bool f32 = cgemm_split_w_fp32(np);      // fp32 handles: unsplit spectra, the GEMM splits them
-  if (ks == 9 && f32) hipLaunchKernelGGL((weight_spectra_split_kernel<9, 0>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, ntl, s.NY, s.NX, rb);
-  else if (ks == 9 && np == 2) hipLaunchKernelGGL((weight_spectra_split_kernel<9, 2>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, ntl, s.NY, s.NX, rb);
-  else if (ks == 9) hipLaunchKernelGGL((weight_spectra_split_kernel<9, 3>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, ntl, s.NY, s.NX, rb);
-  else if (f32) hipLaunchKernelGGL((weight_spectra_split_kernel<5, 0>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, ntl, s.NY, s.NX, rb);
-  else if (np == 2) hipLaunchKernelGGL((weight_spectra_split_kernel<5, 2>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, ntl, s.NY, s.NX, rb);
-  else hipLaunchKernelGGL((weight_spectra_split_kernel<5, 3>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, ntl, s.NY, s.NX, rb);
+  const bool f32 = cgemm_split_w_fp32(np);      // np = 3: unsplit fp32 spectra, the GEMM splits them
+  if (np == 4) {
+    if (hipError_t e = hipMemsetAsync(wscale, 0, 2 * sizeof(float), st); e != hipSuccess) return e;
+    const size_t pairs = (size_t)Cin * Cout;
+    hipLaunchKernelGGL(weight_bound_kernel, dim3((unsigned)((pairs + 255) / 256 > 1024 ? 1024 : (pairs + 255) / 256)), dim3(256), 0, st, w_hwio, ks * ks, pairs, rb, wscale);
+  }
+#define WS_LAUNCH(KS, NPV) hipLaunchKernelGGL((weight_spectra_split_kernel<KS, NPV>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, ntl, s.NY, s.NX, rb, wscale)
+  if (ks == 9) {
+    if (f32) WS_LAUNCH(9, 0); else if (np == 2) WS_LAUNCH(9, 2); else if (np == 4) WS_LAUNCH(9, 4); else WS_LAUNCH(9, 3);
+  } else {
+    if (f32) WS_LAUNCH(5, 0); else if (np == 2) WS_LAUNCH(5, 2); else if (np == 4) WS_LAUNCH(5, 4); else WS_LAUNCH(5, 3);
+  }
+#undef WS_LAUNCH
   return hipGetLastError();
 }
 // scratch: T (the larger of the two row-transformed tensors) + the split activation spectra Xs + the product spectra Yf
@@ -244,7 +279,7 @@ Plan3 plan_of(const ConvArgs& a, const Sizes& s, int np) {
   const size_t cop = pad64(a.Cout), cmax = (size_t)a.Cin > cop ? a.Cin : cop;
   const size_t bp = (size_t)(a.B + p.MT - 1) / p.MT * p.MT;
   p.t_bytes = (size_t)a.B * p.NXH * a.H * cmax * sizeof(cf);
-  p.xs_bytes = (size_t)p.F * bp * a.Cin * 4 * np;
+  p.xs_bytes = (size_t)p.F * bp * a.Cin * 4 * cgemm_split_parts(np);
   p.yf_bytes = (size_t)p.F * a.B * p.ldy * sizeof(cf);
   return p;
 }
@@ -276,9 +311,15 @@ size_t conv_fft_handover_bytes(const ConvArgs& a, int ks) {      // T[kx][c/16][
 // weight gradient (wgrad_fft.hip); xs_ready: they are there already (the data gradient after the weight gradient of the same layer): the
 // forward transforms are skipped.
 hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int out_layout, void* work, const void* t_in, void* t_next, const FftMerge* merge,
-                        hipEvent_t g0, hipEvent_t g1, hipStream_t st, void* xs, bool xs_ready) {
+                        hipEvent_t g0, hipEvent_t g1, hipStream_t st, void* xs, bool xs_ready, const Fp16Scale* scp) {
   Sizes s;
-  if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s) || (out_layout == 2 && a0.Cout % 8) || (np != 2 && np != 3)) return hipErrorInvalidValue;
+  if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s) || (out_layout == 2 && a0.Cout % 8) || (np != 2 && np != 3 && np != 4)) return hipErrorInvalidValue;
+  Fp16Scale sc;
+  if (np == 4) {
+    if (!scp || !scp->tmax || !scp->winv || (t_next && !scp->tmax_next)) return hipErrorInvalidValue;
+    sc = *scp;
+    sc.hf = (float)a0.H;
+  }
   if ((t_in || t_next || merge) && (in_layout != 0 || out_layout != 0 || (t_next && a0.Cout % CB))) return hipErrorInvalidValue;
   ConvArgs a = a0;
   a.CoutP = pad64(a.Cout);
@@ -299,11 +340,11 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
   const cf* Tin = t_in ? static_cast<const cf*>(t_in) : T;
   if (!xs_ready) {
     if (merge && !t_in) {
-      cfft_rows_fwd_merge(s.NX, a, *merge, T, twx, st);
+      cfft_rows_fwd_merge(s.NX, a, *merge, T, twx, sc.tmax, st);
     } else if (!t_in) {
-      cfft_rows_fwd(s.NX, a, in_layout, T, twx, st);
+      cfft_rows_fwd(s.NX, a, in_layout, T, twx, sc.tmax, st);
     }
-    if (hipError_t ce = cfft_cols_fwd(s.NY, a, np, Tin, Xs, twy, p.NXH, p.MT, st); ce != hipSuccess) return ce;
+    if (hipError_t ce = cfft_cols_fwd(s.NY, a, np, Tin, Xs, twy, p.NXH, p.MT, sc, st); ce != hipSuccess) return ce;
   }
   if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
   if (g0 && hipEventRecord(g0, st) != hipSuccess) return hipErrorUnknown;
@@ -311,9 +352,9 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
   if (g1 && hipEventRecord(g1, st) != hipSuccess) return hipErrorUnknown;
   cfft_cols_inv(s.NY, a, Yf, T, twy, p.NXH, p.ldy, opad, st);
   if (t_next) {
-    cfft_rows_inv_fwd(s.NX, a, T, static_cast<cf*>(t_next), twx, opad, norm, st);
+    cfft_rows_inv_fwd(s.NX, a, T, static_cast<cf*>(t_next), twx, opad, norm, sc, st);
   } else {
-    cfft_rows_inv(s.NX, a, out_layout, T, twx, opad, norm, st);
+    cfft_rows_inv(s.NX, a, out_layout, T, twx, opad, norm, sc, st);
   }
   return hipGetLastError();
 }
@@ -324,9 +365,11 @@ size_t conv_fft_xs_bytes(const ConvArgs& a, int ks, int np) {
   if (!sizes_of(a.H, a.W, ks, &s)) return 0;
   return align256(plan_of(a, s, np).xs_bytes);
 }
-hipError_t conv_fft_spectra(const ConvArgs& a0, int ks, int np, void* work, void* xs, hipStream_t st) {
+hipError_t conv_fft_spectra(const ConvArgs& a0, int ks, int np, void* work, void* xs, hipStream_t st, float* tmax) {
   Sizes s;
-  if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s) || !xs) return hipErrorInvalidValue;
+  if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s) || !xs || (np == 4 && !tmax)) return hipErrorInvalidValue;
+  Fp16Scale sc;
+  if (np == 4) { sc.tmax = tmax; sc.hf = (float)a0.H; }
   ConvArgs a = a0;
   a.CoutP = pad64(a.Cout);
   const Plan3 p = plan_of(a, s, np);
@@ -335,8 +378,8 @@ hipError_t conv_fft_spectra(const ConvArgs& a0, int ks, int np, void* work, void
   const cf* twb = twiddle_table(dev);
   if (!twb) return hipErrorOutOfMemory;
   cf* T = static_cast<cf*>(work);
-  cfft_rows_fwd(s.NX, a, 0, T, twb + tw_offset(s.NX), st);
-  if (hipError_t ce = cfft_cols_fwd(s.NY, a, np, T, xs, twb + tw_offset(s.NY), p.NXH, p.MT, st); ce != hipSuccess) return ce;
+  cfft_rows_fwd(s.NX, a, 0, T, twb + tw_offset(s.NX), sc.tmax, st);
+  if (hipError_t ce = cfft_cols_fwd(s.NY, a, np, T, xs, twb + tw_offset(s.NY), p.NXH, p.MT, sc, st); ce != hipSuccess) return ce;
   return hipGetLastError();
 }
 // geometry of the spectra for the weight-gradient kernels

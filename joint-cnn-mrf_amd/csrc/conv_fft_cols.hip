@@ -9,10 +9,13 @@ namespace cfft {
 // split into NP bf16 parts (x = x0 + x1 (+ x2), each rounded to nearest: exact for NP = 3, 16 significant bits for NP = 2) and stored as
 // 16-byte MFMA operand units -- 8 consecutive channels of one image -- with the units of the work group's IMG images consecutive: 128-byte
 // lines for IMG = 8.  The result is the channel GEMM's LDS image (cgemm_split.hip), which that kernel fetches by LDS-DMA.
+// NP = 4: two FP16 parts of the spectrum times the power-of-two scale derived from max|T| (Fp16Scale, conv_fft_common.h); layout as NP = 2.
 template <int NY, int NP>
 __global__ __launch_bounds__(colfwd_threads<NY>()) void cols_fwd_split_kernel(const cf* __restrict__ T, uint4* __restrict__ Xs, const cf* __restrict__ twg, int B, int H, int KC, int MT,
-                                                            int mtiles) {
-  constexpr int IMG = colimg<NY>(), CH = IMG * 16, NTC = colfwd_threads<NY>();
+                                                            int mtiles, const float* __restrict__ tmax) {
+  constexpr int IMG = colimg<NY>(), CH = IMG * 16, NTC = colfwd_threads<NY>(), NPP = NP == 4 ? 2 : NP;      // NPP: 16-byte units per plane
+  float xscale = 1.f;
+  if constexpr (NP == 4) xscale = fp16_scale(tmax[0], (float)H);
   extern __shared__ __attribute__((aligned(16))) char smem_cf[];
   cf* buf = reinterpret_cast<cf*>(smem_cf);
   cf* tw = buf + NY * CH;
@@ -37,15 +40,20 @@ __global__ __launch_bounds__(colfwd_threads<NY>()) void cols_fwd_split_kernel(co
     float re[8], im[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { re[e] = z[e].x; im[e] = z[e].y; }
-    uint4 ur[NP], ui[NP];
-    split8<NP>(re, ur);
-    split8<NP>(im, ui);
+    uint4 ur[NPP], ui[NPP];
+    if constexpr (NP == 4) {
+      split8h(re, xscale, ur);
+      split8h(im, xscale, ui);
+    } else {
+      split8<NPP>(re, ur);
+      split8<NPP>(im, ui);
+    }
     const size_t f = (size_t)kx * NY + ky;
-    uint4* dst = Xs + (((f * mtiles + mt) * KC + kc) * (4 * NP) + kg) * MT + r0 + img;      // unit ((c * NP + p) * 2 + kg) * MT + row
+    uint4* dst = Xs + (((f * mtiles + mt) * KC + kc) * (4 * NPP) + kg) * MT + r0 + img;      // unit ((c * NPP + p) * 2 + kg) * MT + row
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      dst[(size_t)(0 * NP + p) * 2 * MT] = ur[p];
-      dst[(size_t)(1 * NP + p) * 2 * MT] = ui[p];
+    for (int p = 0; p < NPP; ++p) {
+      dst[(size_t)(0 * NPP + p) * 2 * MT] = ur[p];
+      dst[(size_t)(1 * NPP + p) * 2 * MT] = ui[p];
     }
   }
 }
@@ -74,18 +82,22 @@ __global__ __launch_bounds__(colinv_threads<NY>()) void cols_inv_kernel(const cf
 }
 
 
-template <int NY> static hipError_t launch_cols_fwd(const ConvArgs& a, int np, const cf* T, void* Xs, const cf* tw, int NXH, int MT, hipStream_t st) {
+template <int NY> static hipError_t launch_cols_fwd(const ConvArgs& a, int np, const cf* T, void* Xs, const cf* tw, int NXH, int MT, const Fp16Scale& sc, hipStream_t st) {
   constexpr int IMG = colimg<NY>();
   constexpr int lds = (NY * IMG * 16 + NY) * (int)sizeof(cf);
   const int KC = a.Cin / 16, mtiles = (a.B + MT - 1) / MT;
   const dim3 grid((unsigned)(NXH * KC * ((a.B + IMG - 1) / IMG)));
-  static LdsAttr attr2, attr3;
+  static LdsAttr attr2, attr3, attr4;
   if (np == 2) {
     if (hipError_t e = attr2.ensure(reinterpret_cast<const void*>(cols_fwd_split_kernel<NY, 2>), lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 2>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles);
+    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 2>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles, nullptr);
+  } else if (np == 4) {
+    if (!sc.tmax) return hipErrorInvalidValue;
+    if (hipError_t e = attr4.ensure(reinterpret_cast<const void*>(cols_fwd_split_kernel<NY, 4>), lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 4>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles, sc.tmax);
   } else {
     if (hipError_t e = attr3.ensure(reinterpret_cast<const void*>(cols_fwd_split_kernel<NY, 3>), lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 3>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles);
+    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 3>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles, nullptr);
   }
   return hipSuccess;
 }
@@ -93,9 +105,9 @@ template <int NY> static hipError_t launch_cols_fwd(const ConvArgs& a, int np, c
 template <int NY> static void launch_cols_inv(const ConvArgs& a, const cf* Yf, cf* T, const cf* tw, int NXH, int ldy, int pad, hipStream_t st) {
   hipLaunchKernelGGL(cols_inv_kernel<NY>, dim3(a.B * NXH * (a.CoutP / colblk<NY>())), dim3(colinv_threads<NY>()), 0, st, Yf, T, tw, a.B, a.H, NXH, a.CoutP, ldy, pad);
 }
-hipError_t cfft_cols_fwd(int NY, const ConvArgs& a, int np, const cf* T, void* Xs, const cf* tw, int NXH, int MT, hipStream_t st) {
+hipError_t cfft_cols_fwd(int NY, const ConvArgs& a, int np, const cf* T, void* Xs, const cf* tw, int NXH, int MT, const Fp16Scale& sc, hipStream_t st) {
   hipError_t e = hipSuccess;
-#define CALL(N) e = launch_cols_fwd<N>(a, np, T, Xs, tw, NXH, MT, st)
+#define CALL(N) e = launch_cols_fwd<N>(a, np, T, Xs, tw, NXH, MT, sc, st)
   CFFT_BY_SIZE(NY, CALL)
 #undef CALL
   return e;

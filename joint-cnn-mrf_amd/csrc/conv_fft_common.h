@@ -82,14 +82,45 @@ __device__ __forceinline__ size_t t_fwd_index(int k, int cblk, int v, int b, int
   return ((((size_t)k * (C >> 4) + cblk * 4 + (v >> 3)) * B + b) * H + y) * 8 + (v & 7);
 }
 // Z = FFT(x_c + i x_{c+1}):  X_c[k] = (Z[k] + conj Z[-k]) / 2,  X_{c+1}[k] = (Z[k] - conj Z[-k]) / (2i)
+// Returns the largest |component| this thread stored (the fp16-part GEMM of fp32 handles scales the spectra by it, see Fp16Scale).
 template <int NX, int NTH = NT>
-__device__ __forceinline__ void rows_fwd_store(const cf* buf, cf* __restrict__ T, int tid, int cblk, int b, int y, int B, int H, int C) {
+__device__ __forceinline__ float rows_fwd_store(const cf* buf, cf* __restrict__ T, int tid, int cblk, int b, int y, int B, int H, int C) {
   constexpr int CH = CB / 2, NXH = NX / 2 + 1;
   float4* dst = reinterpret_cast<float4*>(T);
+  float m = 0.f;
   for (int t = tid; t < NXH * CH; t += NTH) {
     const int k = t / CH, v = t % CH;
     const cf zk = buf[pos<NX>(k) * CH + v], zn = buf[pos<NX>(k == 0 ? 0 : NX - k) * CH + v];
-    dst[t_fwd_index(k, cblk, v, b, y, B, H, C)] = make_float4(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y), 0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+    const float4 o = make_float4(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y), 0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+    dst[t_fwd_index(k, cblk, v, b, y, B, H, C)] = o;
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+  }
+  return m;
+}
+
+// ---- fp32 handles, np = 4 (two FP16 parts per GEMM operand, cgemm_split.hip): fp16 carries 11 significant bits over 2^-24 .. 2^16, so the
+// spectra are scaled by a power of two that is exact to apply and to undo.  The bound is rigorous: a column transform sums H entries of the
+// row-transformed tensor T, so |X[f]| <= H * max|T|; max|T| is found by the row pass that writes T (one atomic max per work group on a device
+// word, order independent: deterministic), the column pass scales by 2^k with H * max|T| * 2^k < 2^15, and the inverse row pass multiplies its
+// 1 / (NY NX) by 2^-k and by the inverse of the filter spectra's own scale.  (struct Fp16Scale: kernels.h)
+__device__ __forceinline__ int fp16_exp(float tmax, float hf) {      // e with H * tmax < 2^e (0 for an all-zero tensor)
+  const float bound = tmax * hf;
+  int e = 0;
+  if (bound > 0.f && bound < 3.0e38f) (void)frexpf(bound, &e);
+  return e;
+}
+__device__ __forceinline__ float fp16_scale(float tmax, float hf) { return ldexpf(1.f, 15 - fp16_exp(tmax, hf)); }
+__device__ __forceinline__ float fp16_unscale(float tmax, float hf) { return ldexpf(1.f, fp16_exp(tmax, hf) - 15); }
+// the work group's maximum -> the device word (values are >= 0: their bit patterns order like unsigned integers)
+template <int NTH>
+__device__ __forceinline__ void block_max_to(float m, float* dst, float* red, int tid) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < NTH / 64; ++w) m = fmaxf(m, red[w]);
+    if (m > __builtin_nontemporal_load(dst)) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(m));
   }
 }
 // The row kernels keep NX x 32 complex numbers in LDS: threads per work group chosen so that the work groups the LDS admits fill the CU's 32 waves
@@ -100,6 +131,24 @@ template <int NY> constexpr int colimg() { return NY > 96 ? 4 : 8; }         // 
 // unless the tile is worked on by many waves.  Threads per work group, so that a CU runs its full 32 waves:
 template <int NY> constexpr int colfwd_threads() { return NY * colimg<NY>() * 16 >= 8192 ? 1024 : NY * colimg<NY>() * 16 >= 4096 ? 512 : 256; }
 template <int NY> constexpr int colinv_threads() { return NY * colblk<NY>() >= 4096 ? 512 : 256; }
+// two FP16 parts of x * scale (round to nearest even; 22 significant bits where the low part is a normal fp16 number)
+__device__ __forceinline__ void split8h(const float (&x)[8], float scale, uint4 (&out)[2]) {
+  unsigned short h[2][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = x[e] * scale;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const _Float16 q = static_cast<_Float16>(v);
+      h[p][e] = __builtin_bit_cast(unsigned short, q);
+      v = v - static_cast<float>(q);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+    out[p] = make_uint4((unsigned)h[p][0] | ((unsigned)h[p][1] << 16), (unsigned)h[p][2] | ((unsigned)h[p][3] << 16), (unsigned)h[p][4] | ((unsigned)h[p][5] << 16),
+                        (unsigned)h[p][6] | ((unsigned)h[p][7] << 16));
+}
 template <int NP>
 __device__ __forceinline__ void split8(const float (&x)[8], uint4 (&out)[NP]) {
   unsigned short h[NP][8];
@@ -142,11 +191,12 @@ int persistent_grid(const void* kernel, int ntiles, int threads);
 
 // ---- launchers (N = transform length, one of the lengths with a Plan); a.CoutP = output channels the inverse passes transform (Cout
 // padded to 64), ldy = channel stride of the product spectra (Cout padded to the GEMM's N tile)
-void cfft_rows_fwd(int NX, const ConvArgs& a, int layout, cf* T, const cf* tw, hipStream_t st);
-void cfft_rows_fwd_merge(int NX, const ConvArgs& a, const FftMerge& m, cf* T, const cf* tw, hipStream_t st);
-hipError_t cfft_cols_fwd(int NY, const ConvArgs& a, int np, const cf* T, void* Xs, const cf* tw, int NXH, int MT, hipStream_t st);
+// sc: the fp16 scaling of np = 4 (tmax written by the forward row passes, read by the column pass and the inverse row passes); all null otherwise
+void cfft_rows_fwd(int NX, const ConvArgs& a, int layout, cf* T, const cf* tw, float* tmax, hipStream_t st);
+void cfft_rows_fwd_merge(int NX, const ConvArgs& a, const FftMerge& m, cf* T, const cf* tw, float* tmax, hipStream_t st);
+hipError_t cfft_cols_fwd(int NY, const ConvArgs& a, int np, const cf* T, void* Xs, const cf* tw, int NXH, int MT, const Fp16Scale& sc, hipStream_t st);
 void cfft_cols_inv(int NY, const ConvArgs& a, const cf* Yf, cf* T, const cf* tw, int NXH, int ldy, int pad, hipStream_t st);
-void cfft_rows_inv(int NX, const ConvArgs& a, int layout, const cf* T, const cf* tw, int pad, float norm, hipStream_t st);
-void cfft_rows_inv_fwd(int NX, const ConvArgs& a, const cf* T, cf* Tn, const cf* tw, int pad, float norm, hipStream_t st);
+void cfft_rows_inv(int NX, const ConvArgs& a, int layout, const cf* T, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
+void cfft_rows_inv_fwd(int NX, const ConvArgs& a, const cf* T, cf* Tn, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
 }  // namespace cfft
 }  // namespace jcm

@@ -15,13 +15,15 @@ namespace cfft {
 // loads of a work group's NEXT (image, row, channel block) are issued before the FFT of the current one and land while it computes and stores.
 template <int NX, int LAYOUT>
 __global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_kernel(const void* __restrict__ in, cf* __restrict__ T, const cf* __restrict__ twg, int B, int H, int W, int C,
-                                                                      int ntiles) {
+                                                                      int ntiles, float* __restrict__ tmax) {
   constexpr int CH = CB / 2, NTR = rows_threads<NX>(), K = (NX * CH + NTR - 1) / NTR;
   using Raw = std::conditional_t<LAYOUT == 0, cf, unsigned>;      // what a thread keeps per element: an fp32 channel pair, or two bf16 in one register
   __shared__ cf buf[NX * CH];
   __shared__ cf tw[NX];
+  __shared__ float red[NTR / 64];
   const int tid = threadIdx.x, ncb = C / CB;
   twiddles<NX, NTR>(tw, twg, tid);
+  float tm = 0.f;
   Raw pre[K];
   auto fetch = [&](int tile) __attribute__((always_inline)) {
     const int cblk = tile % ncb, by = tile / ncb;
@@ -59,10 +61,11 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_kernel(const void
     __syncthreads();
     fft<NX, -1, CH, NTR>(buf, tw, tid);
     const int cblk = tile % ncb, by = tile / ncb;
-    rows_fwd_store<NX, NTR>(buf, T, tid, cblk, by / H, by % H, B, H, C);
+    tm = fmaxf(tm, rows_fwd_store<NX, NTR>(buf, T, tid, cblk, by / H, by % H, B, H, C));
     __syncthreads();      // every wave is done reading buf
     tile = next;
   }
+  if (tmax) block_max_to<NTR>(tm, tmax, red, tid);
 }
 
 // ---- rows, forward, of the MERGED map (fp32 NHWC): x = ((x1 + up(x2)) + up(x3)) / 3 (main.py:58,67,69-70; the arithmetic and association
@@ -70,10 +73,11 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_kernel(const void
 template <int NX>
 __global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_merge_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int H2, int W2,
                                                             const float* __restrict__ x3, int H3, int W3, cf* __restrict__ T, const cf* __restrict__ twg, int B, int H,
-                                                            int W, int C, float sy2, float sx2, float sy3, float sx3) {
+                                                            int W, int C, float sy2, float sx2, float sy3, float sx3, float* __restrict__ tmax) {
   constexpr int CH = CB / 2, NTR = rows_threads<NX>();
   __shared__ cf buf[NX * CH];
   __shared__ cf tw[NX];
+  __shared__ float red[NTR / 64];
   const int tid = threadIdx.x;
   const int cblk = blockIdx.x % (C / CB), by = blockIdx.x / (C / CB);
   const int y = by % H, b = by / H;
@@ -104,30 +108,31 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_merge_kernel(cons
   }
   __syncthreads();
   fft<NX, -1, CH, NTR>(buf, tw, tid);
-  rows_fwd_store<NX, NTR>(buf, T, tid, cblk, b, y, B, H, C);
+  const float tm = rows_fwd_store<NX, NTR>(buf, T, tid, cblk, b, y, B, H, C);
+  if (tmax) block_max_to<NTR>(tm, tmax, red, tid);      // (one atomic per work group at most: skipped once the word holds a larger value)
 }
 
 
-template <int NX> static void launch_rows_fwd(const ConvArgs& a, int layout, cf* T, const cf* tw, hipStream_t st) {
+template <int NX> static void launch_rows_fwd(const ConvArgs& a, int layout, cf* T, const cf* tw, float* tmax, hipStream_t st) {
   const int ntiles = a.B * a.H * (a.Cin / CB);
   const void* fn = layout == 0 ? reinterpret_cast<const void*>(rows_fwd_kernel<NX, 0>) : layout == 1 ? reinterpret_cast<const void*>(rows_fwd_kernel<NX, 1>)
                                                                                                   : reinterpret_cast<const void*>(rows_fwd_kernel<NX, 2>);
   const dim3 grid(persistent_grid(fn, ntiles, rows_threads<NX>()));
-  if (layout == 0) hipLaunchKernelGGL((rows_fwd_kernel<NX, 0>), grid, dim3(rows_threads<NX>()), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin, ntiles);
-  else if (layout == 1) hipLaunchKernelGGL((rows_fwd_kernel<NX, 1>), grid, dim3(rows_threads<NX>()), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin, ntiles);
-  else hipLaunchKernelGGL((rows_fwd_kernel<NX, 2>), grid, dim3(rows_threads<NX>()), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin, ntiles);
+  if (layout == 0) hipLaunchKernelGGL((rows_fwd_kernel<NX, 0>), grid, dim3(rows_threads<NX>()), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin, ntiles, tmax);
+  else if (layout == 1) hipLaunchKernelGGL((rows_fwd_kernel<NX, 1>), grid, dim3(rows_threads<NX>()), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin, ntiles, tmax);
+  else hipLaunchKernelGGL((rows_fwd_kernel<NX, 2>), grid, dim3(rows_threads<NX>()), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin, ntiles, tmax);
 }
-template <int NX> static void launch_rows_fwd_merge(const ConvArgs& a, const FftMerge& m, cf* T, const cf* tw, hipStream_t st) {
+template <int NX> static void launch_rows_fwd_merge(const ConvArgs& a, const FftMerge& m, cf* T, const cf* tw, float* tmax, hipStream_t st) {
   hipLaunchKernelGGL(rows_fwd_merge_kernel<NX>, dim3(a.B * a.H * (a.Cin / CB)), dim3(rows_threads<NX>()), 0, st, static_cast<const float*>(a.x), m.x2, m.H2, m.W2, m.x3, m.H3, m.W3, T, tw,
-                     a.B, a.H, a.W, a.Cin, (float)m.H2 / (float)a.H, (float)m.W2 / (float)a.W, (float)m.H3 / (float)a.H, (float)m.W3 / (float)a.W);
+                     a.B, a.H, a.W, a.Cin, (float)m.H2 / (float)a.H, (float)m.W2 / (float)a.W, (float)m.H3 / (float)a.H, (float)m.W3 / (float)a.W, tmax);
 }
-void cfft_rows_fwd(int NX, const ConvArgs& a, int layout, cf* T, const cf* tw, hipStream_t st) {
-#define CALL(N) launch_rows_fwd<N>(a, layout, T, tw, st)
+void cfft_rows_fwd(int NX, const ConvArgs& a, int layout, cf* T, const cf* tw, float* tmax, hipStream_t st) {
+#define CALL(N) launch_rows_fwd<N>(a, layout, T, tw, tmax, st)
   CFFT_BY_SIZE(NX, CALL)
 #undef CALL
 }
-void cfft_rows_fwd_merge(int NX, const ConvArgs& a, const FftMerge& m, cf* T, const cf* tw, hipStream_t st) {
-#define CALL(N) launch_rows_fwd_merge<N>(a, m, T, tw, st)
+void cfft_rows_fwd_merge(int NX, const ConvArgs& a, const FftMerge& m, cf* T, const cf* tw, float* tmax, hipStream_t st) {
+#define CALL(N) launch_rows_fwd_merge<N>(a, m, T, tw, tmax, st)
   CFFT_BY_SIZE(NX, CALL)
 #undef CALL
 }

@@ -10,8 +10,9 @@ namespace cfft {
 template <int NX, int LAYOUT>
 __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_kernel(const cf* __restrict__ T, void* __restrict__ out, const cf* __restrict__ twg, const float* __restrict__ bias,
                                                       const float* __restrict__ scale, const float* __restrict__ shift, int relu_bn, int H, int W, int C,
-                                                      int Cout, int pad, float norm, int ntiles) {
+                                                      int Cout, int pad, float norm0, int ntiles, Fp16Scale sc) {
   constexpr int CH = CB / 2, NXH = NX / 2 + 1, NTR = rows_threads<NX>(), K = (NXH * CH + NTR - 1) / NTR;
+  const float norm = sc.tmax ? norm0 * fp16_unscale(sc.tmax[0], sc.hf) * sc.winv[0] : norm0;      // powers of two: exact
   __shared__ cf buf[NX * CH];
   __shared__ cf tw[NX];
   __shared__ float par[3 * kParMax];      // bias | scale | shift of every channel: the epilogue issues no global load, so nothing drains the prefetch
@@ -96,11 +97,14 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_kernel(const cf* 
 template <int NX>
 __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_fwd_kernel(const cf* __restrict__ T, cf* __restrict__ Tn, const cf* __restrict__ twg, const float* __restrict__ bias,
                                                           const float* __restrict__ scale, const float* __restrict__ shift, int relu_bn, int B, int H, int W, int C,
-                                                          int pad, float norm, int ntiles) {
+                                                          int pad, float norm0, int ntiles, Fp16Scale sc) {
   constexpr int CH = CB / 2, NXH = NX / 2 + 1, NTR = rows_threads<NX>(), K = (NXH * CH + NTR - 1) / NTR, XP = NTR / CH, KX = (NX + XP - 1) / XP;
   __shared__ cf buf[NX * CH];
   __shared__ cf tw[NX];
   __shared__ float par[3 * kParMax];
+  __shared__ float red[NTR / 64];
+  const float norm = sc.tmax ? norm0 * fp16_unscale(sc.tmax[0], sc.hf) * sc.winv[0] : norm0;
+  float tm = 0.f;
   const int tid = threadIdx.x, ncb = C / CB;
   twiddles<NX, NTR>(tw, twg, tid);
   const bool par_lds = C <= kParMax;
@@ -169,36 +173,37 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_fwd_kernel(const 
     }
     __syncthreads();
     fft<NX, -1, CH, NTR>(buf, tw, tid);
-    rows_fwd_store<NX, NTR>(buf, Tn, tid, cblk, by / H, by % H, B, H, C);
+    tm = fmaxf(tm, rows_fwd_store<NX, NTR>(buf, Tn, tid, cblk, by / H, by % H, B, H, C));
     __syncthreads();      // every wave is done reading buf
     tile = next;
   }
+  if (sc.tmax_next) block_max_to<NTR>(tm, sc.tmax_next, red, tid);
 }
 
-template <int NX> static void launch_rows_inv(const ConvArgs& a, int layout, const cf* T, const cf* tw, int pad, float norm, hipStream_t st) {
+template <int NX> static void launch_rows_inv(const ConvArgs& a, int layout, const cf* T, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st) {
   const int ntiles = a.B * a.H * (a.CoutP / CB);
   const void* fn = layout == 0 ? reinterpret_cast<const void*>(rows_inv_kernel<NX, 0>) : layout == 1 ? reinterpret_cast<const void*>(rows_inv_kernel<NX, 1>)
                                                                                                   : reinterpret_cast<const void*>(rows_inv_kernel<NX, 2>);
   const dim3 grid(persistent_grid(fn, ntiles, rows_threads<NX>()));
   if (layout == 0)
-    hipLaunchKernelGGL((rows_inv_kernel<NX, 0>), grid, dim3(rows_threads<NX>()), 0, st, T, a.out, tw, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm, ntiles);
+    hipLaunchKernelGGL((rows_inv_kernel<NX, 0>), grid, dim3(rows_threads<NX>()), 0, st, T, a.out, tw, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm, ntiles, sc);
   else if (layout == 1)
-    hipLaunchKernelGGL((rows_inv_kernel<NX, 1>), grid, dim3(rows_threads<NX>()), 0, st, T, a.out, tw, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm, ntiles);
+    hipLaunchKernelGGL((rows_inv_kernel<NX, 1>), grid, dim3(rows_threads<NX>()), 0, st, T, a.out, tw, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm, ntiles, sc);
   else
-    hipLaunchKernelGGL((rows_inv_kernel<NX, 2>), grid, dim3(rows_threads<NX>()), 0, st, T, a.out, tw, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm, ntiles);
+    hipLaunchKernelGGL((rows_inv_kernel<NX, 2>), grid, dim3(rows_threads<NX>()), 0, st, T, a.out, tw, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm, ntiles, sc);
 }
-template <int NX> static void launch_rows_inv_fwd(const ConvArgs& a, const cf* T, cf* Tn, const cf* tw, int pad, float norm, hipStream_t st) {
+template <int NX> static void launch_rows_inv_fwd(const ConvArgs& a, const cf* T, cf* Tn, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st) {
   const int ntiles = a.B * a.H * (a.Cout / CB);
   const dim3 grid(persistent_grid(reinterpret_cast<const void*>(rows_inv_fwd_kernel<NX>), ntiles, rows_threads<NX>()));
-  hipLaunchKernelGGL(rows_inv_fwd_kernel<NX>, grid, dim3(rows_threads<NX>()), 0, st, T, Tn, tw, a.bias, a.scale, a.shift, a.relu_bn, a.B, a.H, a.W, a.Cout, pad, norm, ntiles);
+  hipLaunchKernelGGL(rows_inv_fwd_kernel<NX>, grid, dim3(rows_threads<NX>()), 0, st, T, Tn, tw, a.bias, a.scale, a.shift, a.relu_bn, a.B, a.H, a.W, a.Cout, pad, norm, ntiles, sc);
 }
-void cfft_rows_inv(int NX, const ConvArgs& a, int layout, const cf* T, const cf* tw, int pad, float norm, hipStream_t st) {
-#define CALL(N) launch_rows_inv<N>(a, layout, T, tw, pad, norm, st)
+void cfft_rows_inv(int NX, const ConvArgs& a, int layout, const cf* T, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st) {
+#define CALL(N) launch_rows_inv<N>(a, layout, T, tw, pad, norm, sc, st)
   CFFT_BY_SIZE(NX, CALL)
 #undef CALL
 }
-void cfft_rows_inv_fwd(int NX, const ConvArgs& a, const cf* T, cf* Tn, const cf* tw, int pad, float norm, hipStream_t st) {
-#define CALL(N) launch_rows_inv_fwd<N>(a, T, Tn, tw, pad, norm, st)
+void cfft_rows_inv_fwd(int NX, const ConvArgs& a, const cf* T, cf* Tn, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st) {
+#define CALL(N) launch_rows_inv_fwd<N>(a, T, Tn, tw, pad, norm, sc, st)
   CFFT_BY_SIZE(NX, CALL)
 #undef CALL
 }

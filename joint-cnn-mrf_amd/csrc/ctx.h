@@ -106,7 +106,14 @@ struct jcm_ctx {
   bool fft_xs_ready = false;         // ... they are there already (data gradient after the weight gradient of the same layer): skip the forward transforms
   const void* fft_merge = nullptr;   // const jcm::FftMerge*: the next frequency-domain layer forms the merged map itself (jcm_pd_forward, conv5)
   int conv9_fft = 1;            // fp32 handles: wide 9x9 layers in the frequency domain (conv_fft.hip) when the shape allows; 0 = fp32 MFMA chain
-  struct FftW { void* p = nullptr; size_t bytes = 0; bool valid = false; };
+  int fft_fp16 = 1;             // fp32 handles: the channel GEMM on two FP16 parts per operand (three products, scaled spectra); 0 = three bf16 parts (six products)
+  // device words of the fp16 scaling (kernels.h: Fp16Scale): a ring of zeroed floats, one per row-transformed tensor
+  static constexpr int kFftWords = 8192, kFftWordsPerCall = 2048;      // (a 2048-image forward in micro-batches of 64: 32 slices x 11 layers)
+  float* fft_words = nullptr;
+  int fft_word_i = 0;
+  float* fft_tmax_in = nullptr;     // transient: the word of the next frequency-domain layer's input (set with fft_t_in / fft_xs_ready by whoever produced that tensor)
+  float* fft_last_tmax = nullptr;   // the word the last frequency-domain layer's input used (the training step keeps it with the kept spectra)
+  struct FftW { void* p = nullptr; size_t bytes = 0; bool valid = false; float* wscale = nullptr; };      // wscale: two device floats behind the spectra (np = 4)
   std::map<std::string, FftW> fft_w;   // filter spectra per "<scope>@HxW", computed on first use, invalidated by refresh_derived
   int sm_chunk = 32;            // images per FFT slice (measured at B=256, split inverse: 64 -> 3.32 ms, 32 -> 3.10, 16 -> 3.26, 8 -> 3.83)
   int micro_batch = 0;          // jcm_forward walks a batch in slices of this many images (0 = 256 bf16 / 64 fp32)
@@ -179,6 +186,9 @@ void prof_release_all(jcm_ctx* c, bool destroy);
 // c->fft_w under "<scope>@HxW", packed from L->w_raw when missing or invalidated); the training step uses both for its data gradient.
 bool takes_fft(jcm_ctx* c, const ConvLayer* L, int B, int H, int W);
 bool fft_spectra_valid(jcm_ctx* c, const std::string& scope, int H, int W);
+// operand form of the channel GEMM on this handle (kernels.h): 2 = bf16 handles; fp32 handles: 4 (two fp16 parts, default) or 3 (three bf16 parts)
+inline int fft_np(const jcm_ctx* c) { return c->precision == JCM_PRECISION_BF16 ? 2 : (c->fft_fp16 ? 4 : 3); }
+int fft_new_word(jcm_ctx* c, float** w);      // a zeroed device word of the scaling ring
 int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const void* x, int B, int H, int W, void* out, int in_layout, int out_layout);
 int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int stride, const void* x, int B, int H, int W, int sub,
                    void* out, bool act_bf16, bool out_f32, int in_planar = 0, int out_planar = 0);   // bf16 layouts: ConvArgs in kernels.h

@@ -35,6 +35,11 @@ CallOrder::CallOrder(jcm_ctx* ctx) : c(ctx) {
   std::lock_guard<std::mutex> lk(ch.mu);
   if (!ch.ev && hipEventCreateWithFlags(&ch.ev, hipEventDisableTiming) != hipSuccess) { ch.ev = nullptr; return; }
   if (ch.armed && ch.last != c->stream) (void)hipStreamWaitEvent(c->stream, ch.ev, 0);
+  // the ring of fp16-scale words laps only BETWEEN calls (a call keeps words of its early layers until its last ones: the training step)
+  if (c->fft_words && c->fft_word_i > jcm_ctx::kFftWords - jcm_ctx::kFftWordsPerCall) {
+    (void)hipMemsetAsync(c->fft_words, 0, jcm_ctx::kFftWords * sizeof(float), c->stream);
+    c->fft_word_i = 0;
+  }
 }
 CallOrder::~CallOrder() {
   if (!c) return;
@@ -193,15 +198,27 @@ bool fft_spectra_valid(jcm_ctx* c, const std::string& scope, int H, int W) {
   auto it = c->fft_w.find(scope + "@" + std::to_string(H) + "x" + std::to_string(W));
   return it != c->fft_w.end() && it->second.valid;
 }
+// The ring is zeroed when it is created and every time it laps (CallOrder: between calls, in stream order, behind every kernel that read the
+// old words); a word is handed out once per lap.
+int fft_new_word(jcm_ctx* c, float** w) {
+  if (!c->fft_words) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->fft_words), jcm_ctx::kFftWords * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(c->fft_words, 0, jcm_ctx::kFftWords * sizeof(float), c->stream));
+    c->fft_word_i = 0;
+  }
+  if (c->fft_word_i >= jcm_ctx::kFftWords) return fail(JCM_ERR_STATE, "more frequency-domain layers in one call than scale words (kFftWordsPerCall)");
+  *w = c->fft_words + c->fft_word_i++;
+  return JCM_OK;
+}
 int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const void* x, int B, int H, int W, void* out, int in_layout, int out_layout) {
   ConvArgs a{};
   a.x = x; a.bias = L->bias; a.scale = L->scale; a.shift = L->shift; a.out = out;
   a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout; a.CoutP = L->cout; a.relu_bn = L->has_bn ? 1 : 0;
   const size_t mark = c->arena_off;
-  const int np = c->precision == JCM_PRECISION_BF16 ? 2 : 3;      // bf16 parts per operand of the channel GEMM (cgemm_split.hip)
+  const int np = fft_np(c);      // operand form of the channel GEMM (cgemm_split.hip)
   void* work = arena_alloc<char>(c, conv_fft_workspace_bytes(a, L->ks, np));
   c->arena_off = mark;                                   // scratch of this layer only: later layers run behind it on the stream
-  if (c->dry) { c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; c->fft_xs = nullptr; c->fft_xs_ready = false; return JCM_OK; }
+  if (c->dry) { c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; c->fft_xs = nullptr; c->fft_xs_ready = false; c->fft_tmax_in = nullptr; return JCM_OK; }
   // Filter spectra are cached per (layer, map size).  The cache is bounded (JCM_FFT_CACHE_GB, default 64): a caller that walks many
   // image sizes (7.7 GB per size for conv5) makes it drop every spectrum that is not this layer's before it grows past the bound.
   const std::string key = scope + "@" + std::to_string(H) + "x" + std::to_string(W);
@@ -218,15 +235,18 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
   }
   jcm_ctx::FftW& fw = c->fft_w[key];
   if (!fw.p) {
-    fw.bytes = conv_fft_weight_bytes(H, W, L->ks, L->cin, L->cout, np);
-    if (hipMalloc(&fw.p, fw.bytes) != hipSuccess) {
+    const size_t wb = (conv_fft_weight_bytes(H, W, L->ks, L->cin, L->cout, np) + 255) & ~size_t(255);
+    fw.bytes = wb + 256;      // + the two words of the filter spectra's scale (np = 4)
+    if (hipMalloc(&fw.p, fw.bytes) == hipSuccess) {
+      fw.wscale = reinterpret_cast<float*>(static_cast<char*>(fw.p) + wb);
+    } else {
       const size_t mb = fw.bytes >> 20;
       c->fft_w.erase(key);
       return fail(JCM_ERR_HIP, "out of device memory for the filter spectra of '" + scope + "' (" + std::to_string(mb) + " MB); jcm_set_option(\"conv9_fft\", 0) selects the direct kernels");
     }
   }
   if (!fw.valid) {
-    HIP_TRY(conv_fft_pack_weights(L->w_raw, fw.p, H, W, L->ks, L->cin, L->cout, np, c->precision == JCM_PRECISION_BF16, c->stream));
+    HIP_TRY(conv_fft_pack_weights(L->w_raw, fw.p, H, W, L->ks, L->cin, L->cout, np, c->precision == JCM_PRECISION_BF16, c->stream, fw.wscale));
     fw.valid = true;
   }
   a.wp = fw.p;
@@ -238,8 +258,19 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
   const FftMerge* mg = static_cast<const FftMerge*>(c->fft_merge);
   void* xs = c->fft_xs;
   const bool xs_ready = c->fft_xs_ready;
+  Fp16Scale sc;
+  if (np == 4) {
+    // the word of this layer's input: handed over with t_in / ready spectra, or a fresh one for this layer's own row pass
+    sc.tmax = c->fft_tmax_in;
+    if ((t_in || xs_ready) && !sc.tmax) return fail(JCM_ERR_STATE, "conv_fft '" + scope + "': a handed-over tensor without its scale word");
+    if (!sc.tmax) JCM_TRY(fft_new_word(c, &sc.tmax));
+    if (t_next) JCM_TRY(fft_new_word(c, &sc.tmax_next));
+    sc.winv = fw.wscale + 1;
+  }
   c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; c->fft_xs = nullptr; c->fft_xs_ready = false;
-  const hipError_t e = conv_fft_f32(a, L->ks, np, in_layout, out_layout, work, t_in, t_next, mg, g0, g1, c->stream, xs, xs_ready);
+  c->fft_tmax_in = sc.tmax_next;      // the next frequency-domain layer takes t_next (and its word)
+  c->fft_last_tmax = sc.tmax;
+  const hipError_t e = conv_fft_f32(a, L->ks, np, in_layout, out_layout, work, t_in, t_next, mg, g0, g1, c->stream, xs, xs_ready, np == 4 ? &sc : nullptr);
   if (g0 && g1 && e == hipSuccess) c->prof[scope + "/gemm"].emplace_back(g0, g1);
   else { if (g0) c->event_pool.push_back(g0); if (g1) c->event_pool.push_back(g1); }
   prof_end(c, scope, e0, e1, e == hipSuccess);
@@ -656,6 +687,7 @@ int jcm_destroy(jcm_handle h) {
   for (auto& kv : h->params) (void)hipFree(kv.second.d);
   for (void* p : h->owned) (void)hipFree(p);
   for (auto& kv : h->fft_w) (void)hipFree(kv.second.p);
+  if (h->fft_words) (void)hipFree(h->fft_words);
   if (h->arena) (void)hipFree(h->arena);
   delete h;
   return JCM_OK;
@@ -680,6 +712,15 @@ int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
   }
   if (k == "conv9_fft") {  // allowed at any time
     h->conv9_fft = value != 0;
+    return JCM_OK;
+  }
+  if (k == "fft_fp16") {   // allowed at any time; the filter spectra have another form: the cache is dropped
+    if ((value != 0) != (h->fft_fp16 != 0)) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      for (auto& kv : h->fft_w) (void)hipFree(kv.second.p);
+      h->fft_w.clear();
+    }
+    h->fft_fp16 = value != 0;
     return JCM_OK;
   }
   if (k == "sm_chunk") {  // allowed at any time

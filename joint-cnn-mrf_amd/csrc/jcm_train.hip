@@ -47,6 +47,7 @@ struct TrainState {
   void* zs = nullptr;                  // split spectra of the dz the last conv_wgrad saw (frequency-domain route), for the conv_dgrad that follows
   const void* zs_of = nullptr;
   int zs_cin = 0;
+  float* zs_tmax = nullptr;            // ... and the word of their fp16 scaling
   double* red = nullptr;               // per-channel reduction scratch
   double* sumsq = nullptr;             // [2]: grad sum of squares, weight sum of squares (l2)
   float* small = nullptr;              // [2*maxC + 64] misc
@@ -136,6 +137,7 @@ struct LayerFwd {
   void* r = nullptr;
   void* y = nullptr;
   void* xs = nullptr;          // fp32 handles, frequency-domain layers: the split spectra of the input, kept for the weight gradient (wgrad_fft.hip)
+  float* xs_tmax = nullptr;    // ... and the device word of their fp16 scaling (np = 4)
 };
 
 int conv_train_fwd(jcm_ctx* c, LayerFwd& f, int stride, const void* x, int B, int Hin, int Win, int sub) {
@@ -153,10 +155,11 @@ int conv_train_fwd(jcm_ctx* c, LayerFwd& f, int stride, const void* x, int B, in
   if (stride == 1 && !bf(c) && takes_fft(c, &L, B, Hin, Win)) {      // keep the input spectra: the weight gradient is taken in the frequency domain too
     ConvArgs ax{};
     ax.B = B; ax.H = Hin; ax.W = Win; ax.Cin = L.cin; ax.Cout = L.cout;
-    f.xs = arena_alloc<char>(c, conv_fft_xs_bytes(ax, L.ks, 3));
+    f.xs = arena_alloc<char>(c, conv_fft_xs_bytes(ax, L.ks, fft_np(c)));
     c->fft_xs = f.xs;
   }
   JCM_TRY(run_conv_layer(c, &L, f.scope, stride, x, B, Hin, Win, sub, f.r, bf(c), !f.L->has_bn));
+  if (f.xs && !c->dry) f.xs_tmax = c->fft_last_tmax;
   if (!f.L->has_bn) { f.y = f.r; return JCM_OK; }
   f.y = act(c, N * f.L->cout);
   if (c->dry) return JCM_OK;
@@ -197,20 +200,25 @@ int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int ldz, int B, fl
     ConvLayer Lz;      // dz as the input of a frequency-domain layer: the same pseudo-layer conv_dgrad runs
     Lz.ks = L->ks; Lz.cin = ldz; Lz.cout = L->cin; Lz.has_bn = false; Lz.w_raw = t->scratch_flip;
     int NY = 0, NX = 0, MTx = 0, MTz = 0, ny2 = 0, nx2 = 0;
-    if (takes_fft(c, &Lz, B, f.H, f.W) && conv_fft_geometry(f.H, f.W, L->ks, B, L->cout, 3, &NY, &NX, &MTx) &&
-        conv_fft_geometry(f.H, f.W, L->ks, B, L->cin, 3, &ny2, &nx2, &MTz)) {
+    const int np = fft_np(c);
+    if (takes_fft(c, &Lz, B, f.H, f.W) && conv_fft_geometry(f.H, f.W, L->ks, B, L->cout, np, &NY, &NX, &MTx) &&
+        conv_fft_geometry(f.H, f.W, L->ks, B, L->cin, np, &ny2, &nx2, &MTz)) {
       ConvArgs az{};
       az.x = dz; az.B = B; az.H = f.H; az.W = f.W; az.Cin = ldz; az.Cout = L->cin;
-      char* zs = arena_alloc<char>(c, conv_fft_xs_bytes(az, L->ks, 3));      // stays allocated: conv_dgrad of this layer reads it
+      char* zs = arena_alloc<char>(c, conv_fft_xs_bytes(az, L->ks, np));      // stays allocated: conv_dgrad of this layer reads it
       const size_t mark = c->arena_off;
-      char* work = arena_alloc<char>(c, conv_fft_workspace_bytes(az, L->ks, 3));
+      char* work = arena_alloc<char>(c, conv_fft_workspace_bytes(az, L->ks, np));
       char* P = arena_alloc<char>(c, wgrad_fft_scratch_bytes(NY, NX, L->cin, ldz));
       if (!c->dry) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         JCM_TRY(prof_begin(c, &e0, &e1));
-        hipError_t le = conv_fft_spectra(az, L->ks, 3, work, zs, c->stream);
+        float* ztmax = nullptr;
+        if (np == 4) JCM_TRY(fft_new_word(c, &ztmax));
+        hipError_t le = conv_fft_spectra(az, L->ks, np, work, zs, c->stream, ztmax);
         if (le == hipSuccess)
-          le = wgrad_fft(f.xs, zs, P, L->w_raw, lmbd, grad_of(t, grads, f.scope + "/weights"), L->ks, NY, NX, B, MTx, MTz, L->cin, ldz, L->cout, c->stream);
+          le = wgrad_fft(f.xs, zs, P, L->w_raw, lmbd, grad_of(t, grads, f.scope + "/weights"), L->ks, NY, NX, B, MTx, MTz, L->cin, ldz, L->cout, c->stream,
+                         np, f.xs_tmax, ztmax, f.H);
+        t->zs_tmax = ztmax;
         prof_end(c, "wgrad:" + f.scope, e0, e1, le == hipSuccess);
         if (le != hipSuccess) return fail(JCM_ERR_HIP, "frequency-domain weight gradient of '" + f.scope + "': " + hipGetErrorString(le));
         t->zs = zs;
@@ -277,7 +285,7 @@ int conv_dgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int B, void* dx, i
       const std::string key = "dgrad:" + f.scope;
       if (!c->dry && !fft_spectra_valid(c, key, f.H, f.W))
         HIP_TRY(flip_transpose_weights(f.L->w_raw, t->scratch_flip, f.L->ks, f.L->cin, f.L->cout, cin_fft, c->stream));
-      if (!c->dry && t->zs && t->zs_of == dz && t->zs_cin == cin_fft) { c->fft_xs = t->zs; c->fft_xs_ready = true; }      // the spectra of dz are there (conv_wgrad just made them)
+      if (!c->dry && t->zs && t->zs_of == dz && t->zs_cin == cin_fft) { c->fft_xs = t->zs; c->fft_xs_ready = true; c->fft_tmax_in = t->zs_tmax; }      // the spectra of dz are there (conv_wgrad just made them)
       t->zs = nullptr;
       return run_conv_fft(c, &Ld, key, dz, B, f.H, f.W, dx, 0, 0);
     }

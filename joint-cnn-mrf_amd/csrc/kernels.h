@@ -73,11 +73,25 @@ hipError_t conv_thin_bf16(const ConvArgs& a, hipStream_t st);
 
 // ---- conv_fft.hip : stride-1 SAME convolution (9x9, 5x5) in the frequency domain: in-LDS FFTs (rows, then columns with the operand split
 // fused in) around the channel GEMM of cgemm_split.hip, one complex matrix product per frequency.  a.wp = split filter spectra of this map
-// and kernel size (conv_fft_pack_weights).  np = bf16 parts per operand: 3 on fp32 handles (six products, fp32-class), 2 on bf16 handles.
+// and kernel size (conv_fft_pack_weights).  np = operand form of the channel GEMM: 2 = two bf16 parts (bf16 handles), 3 = three bf16 parts / six
+// products, 4 = two FP16 parts / three products of spectra scaled by powers of two (fp32 handles; both fp32-class, 4 is the default).
 // Shapes: Cin % 64 == 0, H + k - 1 <= 192, W + k - 1 <= 192.
+//
+// np = 4 scaling (fp16 carries 11 bits over 2^-24 .. 2^16): device words, all written and read on the stream --
+//   tmax      : max |T| of the layer's row-transformed input (atomic max by the row pass, or by the previous layer's fused kernel: ZERO it
+//               before the producer runs); the column pass scales by 2^k with H * tmax * 2^k < 2^15, the inverse row pass undoes it;
+//   tmax_next : the word of the NEXT layer when t_next is given;
+//   winv      : 1 / (scale of the filter spectra), written by conv_fft_pack_weights into wscale[1] (wscale[0] is its scratch).
+struct Fp16Scale {
+  float* tmax = nullptr;
+  float* tmax_next = nullptr;
+  const float* winv = nullptr;
+  float hf = 0.f;      // H (set by conv_fft_f32)
+};
 bool conv_fft_supported(const ConvArgs& a, int ks);
 size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout, int np);
-hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, int np, bool round_bf16, hipStream_t st);
+hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, int np, bool round_bf16, hipStream_t st,
+                                 float* wscale = nullptr);
 size_t conv_fft_workspace_bytes(const ConvArgs& a, int ks, int np);
 // in / out layout: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar (bf16 handles: operands are bf16 values, the arithmetic is fp32-class); g0/g1: optional events around the GEMM
 // t_in / t_next: the row-transformed tensor handed from one frequency-domain layer to the next (fp32 NHWC handles; conv_fft_fusable).
@@ -85,9 +99,10 @@ size_t conv_fft_workspace_bytes(const ConvArgs& a, int ks, int np);
 struct FftMerge { const float* x2; int H2, W2; const float* x3; int H3, W3; };
 // xs / xs_ready: keep the split activation spectra in a caller buffer (conv_fft_xs_bytes) / they are there already (skip the forward transforms)
 hipError_t conv_fft_f32(const ConvArgs& a, int ks, int np, int in_layout, int out_layout, void* work, const void* t_in, void* t_next, const FftMerge* merge,
-                        hipEvent_t g0, hipEvent_t g1, hipStream_t st, void* xs = nullptr, bool xs_ready = false);
+                        hipEvent_t g0, hipEvent_t g1, hipStream_t st, void* xs = nullptr, bool xs_ready = false, const Fp16Scale* sc = nullptr);
 size_t conv_fft_xs_bytes(const ConvArgs& a, int ks, int np);
-hipError_t conv_fft_spectra(const ConvArgs& a, int ks, int np, void* work, void* xs, hipStream_t st);      // NHWC fp32 -> split spectra (the two forward passes)
+// NHWC fp32 -> split spectra (the two forward passes); np = 4: tmax = the (zeroed) device word of this tensor
+hipError_t conv_fft_spectra(const ConvArgs& a, int ks, int np, void* work, void* xs, hipStream_t st, float* tmax = nullptr);
 bool conv_fft_geometry(int H, int W, int ks, int B, int Cout, int np, int* NY, int* NX, int* MT);
 
 // ---- wgrad_fft.hip : weight gradient of a stride-1 layer in the frequency domain (fp32 handles, training step): per frequency
@@ -95,8 +110,9 @@ bool conv_fft_geometry(int H, int W, int ks, int B, int Cout, int np, int* NY, i
 // and of dZ, then the k x k taps are read off the inverse transform:  dw = taps(P) / (NY NX) + lmbd * w.   xs / zs: np = 3 layouts of cgemm_split.hip
 size_t wgrad_fft_scratch_bytes(int NY, int NX, int Cin, int Cout);
 // ldz: channels of the dZ spectra (P's columns, scratch sized with it) >= Cout, the filter's
+// np = 3: three bf16 parts per operand; np = 4: two fp16 parts, scaled -- tmax_x / tmax_z = the device words of the two spectra, H = map height
 hipError_t wgrad_fft(const void* xs, const void* zs, void* scratch, const float* w, float lmbd, float* dw, int ks, int NY, int NX, int B, int MTx, int MTz, int Cin,
-                     int ldz, int Cout, hipStream_t st);
+                     int ldz, int Cout, hipStream_t st, int np = 3, const float* tmax_x = nullptr, const float* tmax_z = nullptr, int H = 0);
 hipError_t pad_channels_f32(const float* in, int ldi, float* out, int ldo, size_t N, hipStream_t st);      // train_kernels.hip
 bool conv_fft_fusable(const ConvArgs& a, int ks, int ks_next);
 size_t conv_fft_handover_bytes(const ConvArgs& a, int ks);
@@ -109,6 +125,7 @@ size_t conv_fft_handover_bytes(const ConvArgs& a, int ks);
 //   y [f][B][ldy] complex fp32, ldy >= Cout rounded up to whole N tiles
 int cgemm_split_mtile(int np, int B, int Cout);
 int cgemm_split_ntile(int np, int Cout);
+int cgemm_split_parts(int np);      // 16-bit parts per operand: np, or 2 for np = 4 (two fp16 parts)
 bool cgemm_split_w_fp32(int np);
 size_t cgemm_split_w_bytes(int np, int F, int Cin, int Cout);
 hipError_t cgemm_split(const void* xs, const void* ws, void* y, int np, int F, int B, int Cin, int Cout, int ldy, hipStream_t st);

@@ -15,22 +15,22 @@
 //                       Three bf16 parts per operand, six products: fp32-class, like the forward pass.
 //   wgrad_taps_*      : the k x k taps of the inverse transform, separable: k column sums over ky for every kx (streams P once), then k x k
 //                       row sums over kx with the Hermitian weights of the half spectrum (double), + lmbd * w.
-#include "kernels.h"
+#include "conv_fft_common.h"
 
 namespace jcm {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace wf {
-constexpr int TM = 128, TN = 128, NT = 256, NP = 3;
+constexpr int TM = 128, TN = 128, NT = 256;
 constexpr int PITCH = 2 * TM + 16;                 // bytes per image row of an LDS plane: 128 channels + one 16-byte pad (rows 4 apart hit different banks)
 constexpr int PLANE = 16 * PITCH;                  // one (re|im, part) plane: 16 images
-constexpr int OPER = 2 * NP * PLANE;               // one operand
-constexpr int LDS_BYTES = 2 * OPER;
+constexpr int lds_bytes(int np) { return 2 * 2 * np * PLANE; }      // two operands of (re|im) x np planes
 
 struct Args {
   const uint4* xs;      // [f][mtile][Cin/16][re|im][part][k-half][MT][8]
@@ -54,12 +54,21 @@ __device__ __forceinline__ Frag frag_read(unsigned base, int pl, int ch0, unsign
   f.hi = tr_read(a + 4 * PITCH);
   return f;
 }
+template <bool HALF>
+__device__ __forceinline__ f32x16 mma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  if constexpr (HALF) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 __device__ __forceinline__ bf16x8 frag_pack(const Frag& f) {
   const u32x4 r = {f.lo.x, f.lo.y, f.hi.x, f.hi.y};
   return __builtin_bit_cast(bf16x8, r);
 }
 
+// NP = 3, HALF = false: three bf16 parts, six products.  NP = 2, HALF = true: two FP16 parts of the scaled spectra (conv_fft's np = 4), three
+// products; P comes out scaled by both operands' powers of two, which the taps kernel undoes.
+template <int NP, bool HALF>
 __global__ __launch_bounds__(NT) void wgrad_spec_kernel(Args a) {
+  constexpr int OPER = 2 * NP * PLANE, SEGS = 8 * 2 * NP * 2;      // one operand in LDS; (chunk, re|im, part, k-half) segments of 16 images x 16 bytes
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -85,10 +94,10 @@ __global__ __launch_bounds__(NT) void wgrad_spec_kernel(Args a) {
   for (int r0 = 0; r0 < rows_valid; r0 += 16) {      // (16 divides both tile heights: a step never straddles two M tiles)
     __syncthreads();      // the previous step's fragments have been read
     // stage both operands: (8 chunks x re|im x part x k-half) segments of 16 images x 16 bytes, as they lie in HBM
-    for (int idx = tid; idx < 2 * 96 * 16; idx += NT) {
-      const int op = idx / (96 * 16), r = idx - op * 96 * 16;
+    for (int idx = tid; idx < 2 * SEGS * 16; idx += NT) {
+      const int op = idx / (SEGS * 16), r = idx - op * SEGS * 16;
       const int seg = r >> 4, j = r & 15;
-      const int kg = seg & 1, cp = (seg >> 1) % 6, kcl = seg / 12;      // cp = re|im * 3 + part
+      const int kg = seg & 1, cp = (seg >> 1) % (2 * NP), kcl = seg / (4 * NP);      // cp = re|im * NP + part
       const int KC = op ? KCo : KCi, kc = (op ? tn : tm) * 8 + kcl;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
       if (kc < KC && r0 + j < rows_valid) {
@@ -99,10 +108,12 @@ __global__ __launch_bounds__(NT) void wgrad_spec_kernel(Args a) {
       *reinterpret_cast<uint4*>(smem + op * OPER + (cp * 16 + j) * PITCH + (kcl * 16 + kg * 8) * 2) = v;
     }
     __syncthreads();
-    // six products: (x part, z part) with px + pz <= 2, small terms first
+    // products (x part, z part) with px + pz <= NP - 1, small terms first
+    constexpr int NPROD = NP == 3 ? 6 : 3;
 #pragma unroll
-    for (int s = 0; s < 6; ++s) {
-      const int px = s == 0 ? 0 : s == 1 ? 1 : s == 2 ? 2 : s == 3 ? 1 : 0, pz = s == 0 ? 2 : s == 1 ? 1 : s == 2 ? 0 : s == 3 ? 0 : s == 4 ? 1 : 0;
+    for (int s = 0; s < NPROD; ++s) {
+      const int px = NP == 3 ? (s == 0 ? 0 : s == 1 ? 1 : s == 2 ? 2 : s == 3 ? 1 : 0) : (s == 0 ? 0 : s == 1 ? 1 : 0);
+      const int pz = NP == 3 ? (s == 0 ? 2 : s == 1 ? 1 : s == 2 ? 0 : s == 3 ? 0 : s == 4 ? 1 : 0) : (s == 0 ? 1 : 0);
       Frag fxr[2], fxi[2], fzr[2], fzi[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -125,15 +136,15 @@ __global__ __launch_bounds__(NT) void wgrad_spec_kernel(Args a) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          pr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xr[i], zr[j], pr[i][j], 0, 0, 0);
-          pi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xr[i], zi[j], pi[i][j], 0, 0, 0);
+          pr[i][j] = mma<HALF>(xr[i], zr[j], pr[i][j]);
+          pi[i][j] = mma<HALF>(xr[i], zi[j], pi[i][j]);
         }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          pr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xi[i], zi[j], pr[i][j], 0, 0, 0);
-          pi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nxi[i], zr[j], pi[i][j], 0, 0, 0);
+          pr[i][j] = mma<HALF>(xi[i], zi[j], pr[i][j]);
+          pi[i][j] = mma<HALF>(nxi[i], zr[j], pi[i][j]);
         }
     }
   }
@@ -204,7 +215,7 @@ __global__ __launch_bounds__(256) void wgrad_taps_cols_kernel(const float2* __re
 
 template <int KS>
 __global__ __launch_bounds__(256) void wgrad_taps_rows_kernel(const float2* __restrict__ R, const float* __restrict__ w, float* __restrict__ dw, size_t n, int NY, int NX,
-                                                              float lmbd, int ldp, int Cout) {
+                                                              float lmbd, int ldp, int Cout, const float* __restrict__ tmax_x, const float* __restrict__ tmax_z, float hf) {
   constexpr int PAD = (KS - 1) / 2;
   __shared__ double2 twx[97 * KS];        // wgt(kx) e^{+2 pi i kx l / NX} / (NY NX), l = PAD - i
   const int NXH = NX / 2 + 1;
@@ -212,7 +223,8 @@ __global__ __launch_bounds__(256) void wgrad_taps_rows_kernel(const float2* __re
     const int kx = i / KS, l = PAD - i % KS;
     double sn, cs;
     sincospi(2.0 * (double)(((kx * l) % NX + NX) % NX) / (double)NX, &sn, &cs);
-    const double wgt = ((kx == 0 || 2 * kx == NX) ? 1.0 : 2.0) / ((double)NY * (double)NX);
+    double wgt = ((kx == 0 || 2 * kx == NX) ? 1.0 : 2.0) / ((double)NY * (double)NX);
+    if (tmax_x) wgt *= (double)cfft::fp16_unscale(tmax_x[0], hf) * (double)cfft::fp16_unscale(tmax_z[0], hf);      // the scaled fp16 operands (np = 4): powers of two
     twx[i] = double2{cs * wgt, sn * wgt};
   }
   __syncthreads();
@@ -250,24 +262,31 @@ static size_t p_bytes(int NY, int NX, int Cin, int Cout) { return ((size_t)NY * 
 size_t wgrad_fft_scratch_bytes(int NY, int NX, int Cin, int Cout) { return p_bytes(NY, NX, Cin, Cout) + (size_t)(NX / 2 + 1) * 9 * Cin * Cout * sizeof(float2); }
 
 hipError_t wgrad_fft(const void* xs, const void* zs, void* scratch, const float* w, float lmbd, float* dw, int ks, int NY, int NX, int B, int MTx, int MTz, int Cin,
-                     int ldz, int Cout, hipStream_t st) {
-  if ((ks != 9 && ks != 5) || Cin % 16 || ldz % 16 || Cout > ldz || Cout < 1 || NY > 192 || NX > 192 || B < 1) return hipErrorInvalidValue;
+                     int ldz, int Cout, hipStream_t st, int np, const float* tmax_x, const float* tmax_z, int H) {
+  if ((ks != 9 && ks != 5) || Cin % 16 || ldz % 16 || Cout > ldz || Cout < 1 || NY > 192 || NX > 192 || B < 1 || (np != 3 && np != 4)) return hipErrorInvalidValue;
+  if (np == 4 && (!tmax_x || !tmax_z || H < 1)) return hipErrorInvalidValue;
   const int NXH = NX / 2 + 1, F = NY * NXH;
   if (MTx % 16 || MTz % 16) return hipErrorInvalidValue;
   wf::Args a{static_cast<const uint4*>(xs), static_cast<const uint4*>(zs), static_cast<float2*>(scratch), F, B, MTx, MTz, Cin, ldz};
   float2* R = reinterpret_cast<float2*>(static_cast<char*>(scratch) + p_bytes(NY, NX, Cin, ldz));
-  static LdsAttr attr;
-  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(wf::wgrad_spec_kernel), wf::LDS_BYTES); e != hipSuccess) return e;
+  static LdsAttr attr3, attr4;
   const int tiles = ((Cin + wf::TM - 1) / wf::TM) * ((ldz + wf::TN - 1) / wf::TN);
-  hipLaunchKernelGGL(wf::wgrad_spec_kernel, dim3((unsigned)(F * tiles)), dim3(wf::NT), wf::LDS_BYTES, st, a);
+  if (np == 4) {
+    if (hipError_t e = attr4.ensure(reinterpret_cast<const void*>(wf::wgrad_spec_kernel<2, true>), wf::lds_bytes(2)); e != hipSuccess) return e;
+    hipLaunchKernelGGL((wf::wgrad_spec_kernel<2, true>), dim3((unsigned)(F * tiles)), dim3(wf::NT), wf::lds_bytes(2), st, a);
+  } else {
+    if (hipError_t e = attr3.ensure(reinterpret_cast<const void*>(wf::wgrad_spec_kernel<3, false>), wf::lds_bytes(3)); e != hipSuccess) return e;
+    hipLaunchKernelGGL((wf::wgrad_spec_kernel<3, false>), dim3((unsigned)(F * tiles)), dim3(wf::NT), wf::lds_bytes(3), st, a);
+    tmax_x = tmax_z = nullptr;
+  }
   const size_t n = (size_t)Cin * ldz;
   const unsigned blocks = (unsigned)((n + 255) / 256);
   if (ks == 9) {
     hipLaunchKernelGGL(wf::wgrad_taps_cols_kernel<9>, dim3(blocks, NXH), dim3(256), 0, st, a.P, R, n, NY);
-    hipLaunchKernelGGL(wf::wgrad_taps_rows_kernel<9>, dim3(blocks, 9), dim3(256), 0, st, R, w, dw, n, NY, NX, lmbd, ldz, Cout);
+    hipLaunchKernelGGL(wf::wgrad_taps_rows_kernel<9>, dim3(blocks, 9), dim3(256), 0, st, R, w, dw, n, NY, NX, lmbd, ldz, Cout, tmax_x, tmax_z, (float)H);
   } else {
     hipLaunchKernelGGL(wf::wgrad_taps_cols_kernel<5>, dim3(blocks, NXH), dim3(256), 0, st, a.P, R, n, NY);
-    hipLaunchKernelGGL(wf::wgrad_taps_rows_kernel<5>, dim3(blocks, 5), dim3(256), 0, st, R, w, dw, n, NY, NX, lmbd, ldz, Cout);
+    hipLaunchKernelGGL(wf::wgrad_taps_rows_kernel<5>, dim3(blocks, 5), dim3(256), 0, st, R, w, dw, n, NY, NX, lmbd, ldz, Cout, tmax_x, tmax_z, (float)H);
   }
   return hipGetLastError();
 }

@@ -19,7 +19,7 @@ def _hm_size(n):
 class Engine:
     """Owns a jcm_handle.  All tensor arguments are torch CUDA float32 NHWC, contiguous."""
 
-    def __init__(self, device=0, precision='fp32', n_joints=9, stream=None, f32_conv=None, split_min_wgs=None, micro_batch=None, conv9_fft=None):
+    def __init__(self, device=0, precision='fp32', n_joints=9, stream=None, f32_conv=None, split_min_wgs=None, micro_batch=None, conv9_fft=None, fft_fp16=None):
         if not torch.cuda.is_available():
             raise RuntimeError('joint-cnn-mrf_amd needs an MI355X (gfx950) GPU; torch.cuda.is_available() is False '
                                'and there is no CPU path')
@@ -42,6 +42,8 @@ class Engine:
             self.set_micro_batch(micro_batch)
         if conv9_fft is not None:     # False: the wide 9x9 layers of an fp32 engine on the fp32 MFMA chain instead of the frequency domain
             self.set_conv9_fft(conv9_fft)
+        if fft_fp16 is not None:      # False: fp32 engines run the channel GEMM on three bf16 parts (six products) instead of two scaled fp16 parts (three)
+            self.set_fft_fp16(fft_fp16)
         if split_min_wgs is not None: # 0 forces the split kernels even on grids too small to pay off (parity tests at small batch)
             _lib.check(self._lib.jcm_set_option(self._h, b'split_min_wgs', int(split_min_wgs)), 'jcm_set_option(split_min_wgs)')
 
@@ -278,6 +280,11 @@ class Engine:
         """fp32 engines: run the wide 9x9 layers in the frequency domain (in-LDS FFTs + one complex channel GEMM per frequency;
         default) or on the fp32 MFMA accumulation chain.  Both pass the same parity tests."""
         _lib.check(self._lib.jcm_set_option(self._h, b'conv9_fft', int(bool(on))), 'jcm_set_option(conv9_fft)')
+
+    def set_fft_fp16(self, on):
+        """fp32 engines, frequency-domain route: operands of the channel GEMM as two FP16 parts of spectra scaled by powers of two
+        (three products; default) or as three bf16 parts (six products).  Both are fp32-class and pass the same parity tests."""
+        _lib.check(self._lib.jcm_set_option(self._h, b'fft_fp16', int(bool(on))), 'jcm_set_option(fft_fp16)')
 
     def set_micro_batch(self, n):
         """Images per internal slice of forward(): bounds the workspace when a rank holds a large share of a

@@ -15,17 +15,19 @@ def dev(a):
     return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device='cuda:0')
 
 
-@pytest.mark.parametrize('f32_conv', ['exact', 'chain', 'split', 'split16'])
+@pytest.mark.parametrize('f32_conv', ['exact', 'exact_bf16x3', 'chain', 'split', 'split16'])
 @pytest.mark.parametrize('kind', ['init', 'trained'])
 def test_full_size_tower_vs_golden(kind, f32_conv):
-    """Every fp32 convolution algorithm to the same bar: 'exact' = the default fp32 engine (wide 9x9 layers in the frequency domain,
-    conv_fft.hip; everything else on the fp32 MFMA chain), 'chain' = the fp32 MFMA accumulation chain everywhere, 'split' / 'split16' =
-    fp32 operands as bf16 / fp16 parts on the 16-bit matrix cores (conv_split.hip)."""
+    """Every fp32 convolution algorithm to the same bar: 'exact' = the default fp32 engine (stride-1 layers in the frequency domain,
+    conv_fft.hip, channel GEMM on two scaled fp16 parts per operand), 'exact_bf16x3' = the same route with three bf16 parts / six products,
+    'chain' = the fp32 MFMA accumulation chain everywhere, 'split' / 'split16' = fp32 operands as bf16 / fp16 parts on the direct kernels
+    (conv_split.hip)."""
     from joint_cnn_mrf_amd.engine import Engine
     x, torso, p = full_inputs()
     p.update(synth.make_sm_params(flic_priors(), kind=kind, seed=seeds()['sm']))
-    eng = Engine(device=0, f32_conv='exact' if f32_conv == 'chain' else f32_conv, split_min_wgs=0, conv9_fft=f32_conv != 'chain').load_params(p)
-    assert eng.conv_kernel_name('conv5', 2, 60, 90).startswith('conv_fft') == (f32_conv == 'exact')
+    eng = Engine(device=0, f32_conv='exact' if f32_conv in ('chain', 'exact_bf16x3') else f32_conv, split_min_wgs=0, conv9_fft=f32_conv != 'chain',
+                 fft_fp16=f32_conv != 'exact_bf16x3').load_params(p)
+    assert eng.conv_kernel_name('conv5', 2, 60, 90).startswith('conv_fft') == (f32_conv in ('exact', 'exact_bf16x3'))
     logits = eng.model(dev(x)).cpu().numpy()
     r = eng.forward(dev(x), dev(torso), use_sm=True)
     eng.close()

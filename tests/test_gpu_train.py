@@ -18,10 +18,10 @@ def dev(a):
     return torch.as_tensor(np.ascontiguousarray(a), device='cuda:0')
 
 
-def make_trainer(params, f32_conv=None, precision='fp32', conv9_fft=None, **kw):
+def make_trainer(params, f32_conv=None, precision='fp32', conv9_fft=None, fft_fp16=None, **kw):
     from joint_cnn_mrf_amd.engine import Engine
     from joint_cnn_mrf_amd.train import Trainer
-    eng = Engine(device=0, precision=precision, f32_conv=f32_conv, split_min_wgs=0 if f32_conv else None, conv9_fft=conv9_fft).load_params(params)
+    eng = Engine(device=0, precision=precision, f32_conv=f32_conv, split_min_wgs=0 if f32_conv else None, conv9_fft=conv9_fft, fft_fp16=fft_fp16).load_params(params)
     return eng, Trainer(eng, **kw)
 
 
@@ -172,7 +172,7 @@ def test_det_rate_matches_restatement():
     eng.close()
 
 
-@pytest.mark.parametrize('f32_conv', ['exact', 'chain', 'split', 'split16'])
+@pytest.mark.parametrize('f32_conv', ['exact', 'exact_bf16x3', 'chain', 'split', 'split16'])
 def test_full_size_step_vs_golden(f32_conv):
     """The full-size network (filters 64..512), one 480x720 image: losses, sampled gradient entries, gradient
     norms and the moving-statistics update against tests/golden/train_full.json (float64 restatement,
@@ -184,9 +184,10 @@ def test_full_size_step_vs_golden(f32_conv):
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'train_full.json')) as fh:
         gold = json.load(fh)
     p, x, y = case()
-    eng, tr = make_trainer(p, f32_conv='exact' if f32_conv == 'chain' else f32_conv, conv9_fft=False if f32_conv == 'chain' else None, use_sm=True,
-                           lmbd=LMBD)      # 'split': forward + data gradient of conv4_fullres / conv5 on conv_split.hip
-    assert eng.conv_kernel_name('conv5', 1, 60, 90).startswith('conv_fft') == (f32_conv == 'exact')
+    eng, tr = make_trainer(p, f32_conv='exact' if f32_conv in ('chain', 'exact_bf16x3') else f32_conv, conv9_fft=False if f32_conv == 'chain' else None,
+                           fft_fp16=False if f32_conv == 'exact_bf16x3' else None, use_sm=True,
+                           lmbd=LMBD)      # 'split': forward + data gradient of conv4_fullres / conv5 on conv_split.hip; 'exact_bf16x3': the frequency-domain route on three bf16 parts
+    assert eng.conv_kernel_name('conv5', 1, 60, 90).startswith('conv_fft') == (f32_conv in ('exact', 'exact_bf16x3'))
     losses, _ = tr.loss_and_grads(dev(x), dev(y))
     got = tr.grads_dict()
     l = losses.cpu().numpy()
