@@ -319,6 +319,7 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
     if (!scp || !scp->tmax || !scp->winv || (t_next && !scp->tmax_next)) return hipErrorInvalidValue;
     sc = *scp;
     sc.hf = (float)a0.H;
+    sc.nb = a0.B;
   }
   if ((t_in || t_next || merge) && (in_layout != 0 || out_layout != 0 || (t_next && a0.Cout % CB))) return hipErrorInvalidValue;
   ConvArgs a = a0;
@@ -365,11 +366,11 @@ size_t conv_fft_xs_bytes(const ConvArgs& a, int ks, int np) {
   if (!sizes_of(a.H, a.W, ks, &s)) return 0;
   return align256(plan_of(a, s, np).xs_bytes);
 }
-hipError_t conv_fft_spectra(const ConvArgs& a0, int ks, int np, void* work, void* xs, hipStream_t st, float* tmax) {
+hipError_t conv_fft_spectra(const ConvArgs& a0, int ks, int np, void* work, void* xs, hipStream_t st, float* tmax, int common) {
   Sizes s;
   if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s) || !xs || (np == 4 && !tmax)) return hipErrorInvalidValue;
   Fp16Scale sc;
-  if (np == 4) { sc.tmax = tmax; sc.hf = (float)a0.H; }
+  if (np == 4) { sc.tmax = tmax; sc.hf = (float)a0.H; sc.nb = a0.B; sc.common = common; }
   ConvArgs a = a0;
   a.CoutP = pad64(a.Cout);
   const Plan3 p = plan_of(a, s, np);

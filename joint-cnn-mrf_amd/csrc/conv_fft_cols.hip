@@ -12,10 +12,8 @@ namespace cfft {
 // NP = 4: two FP16 parts of the spectrum times the power-of-two scale derived from max|T| (Fp16Scale, conv_fft_common.h); layout as NP = 2.
 template <int NY, int NP>
 __global__ __launch_bounds__(colfwd_threads<NY>()) void cols_fwd_split_kernel(const cf* __restrict__ T, uint4* __restrict__ Xs, const cf* __restrict__ twg, int B, int H, int KC, int MT,
-                                                            int mtiles, const float* __restrict__ tmax) {
+                                                            int mtiles, const float* __restrict__ tmax, int common) {
   constexpr int IMG = colimg<NY>(), CH = IMG * 16, NTC = colfwd_threads<NY>(), NPP = NP == 4 ? 2 : NP;      // NPP: 16-byte units per plane
-  float xscale = 1.f;
-  if constexpr (NP == 4) xscale = fp16_scale(tmax[0], (float)H);
   extern __shared__ __attribute__((aligned(16))) char smem_cf[];
   cf* buf = reinterpret_cast<cf*>(smem_cf);
   cf* tw = buf + NY * CH;
@@ -25,6 +23,9 @@ __global__ __launch_bounds__(colfwd_threads<NY>()) void cols_fwd_split_kernel(co
   const int kc = kk % KC, kx = kk / KC;
   const int b0 = g * IMG, nimg = min(IMG, B - b0);
   twiddles<NY, NTC>(tw, twg, tid);
+  __shared__ float xsc[IMG];      // NP = 4: the power of two of each of the work group's images (visible after the barrier below)
+  if constexpr (NP == 4)
+    if (tid < IMG) xsc[tid] = tid < nimg ? fp16_scale(tmax_of(tmax, b0 + tid, B, common), (float)H) : 1.f;
   const cf* src = T + (((size_t)kx * KC + kc) * B + b0) * H * 16;
   for (int t = tid; t < NY * CH; t += NTC) {
     const int y = t / CH, v = t % CH, img = v >> 4, c = v & 15;
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(colfwd_threads<NY>()) void cols_fwd_split_kernel(co
     for (int e = 0; e < 8; ++e) { re[e] = z[e].x; im[e] = z[e].y; }
     uint4 ur[NPP], ui[NPP];
     if constexpr (NP == 4) {
+      const float xscale = xsc[img];      // this image's power of two
       split8h(re, xscale, ur);
       split8h(im, xscale, ui);
     } else {
@@ -90,14 +92,14 @@ template <int NY> static hipError_t launch_cols_fwd(const ConvArgs& a, int np, c
   static LdsAttr attr2, attr3, attr4;
   if (np == 2) {
     if (hipError_t e = attr2.ensure(reinterpret_cast<const void*>(cols_fwd_split_kernel<NY, 2>), lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 2>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles, nullptr);
+    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 2>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles, nullptr, 0);
   } else if (np == 4) {
     if (!sc.tmax) return hipErrorInvalidValue;
     if (hipError_t e = attr4.ensure(reinterpret_cast<const void*>(cols_fwd_split_kernel<NY, 4>), lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 4>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles, sc.tmax);
+    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 4>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles, sc.tmax, sc.common);
   } else {
     if (hipError_t e = attr3.ensure(reinterpret_cast<const void*>(cols_fwd_split_kernel<NY, 3>), lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 3>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles, nullptr);
+    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 3>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles, nullptr, 0);
   }
   return hipSuccess;
 }

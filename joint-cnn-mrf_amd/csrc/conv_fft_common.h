@@ -100,8 +100,8 @@ __device__ __forceinline__ float rows_fwd_store(const cf* buf, cf* __restrict__ 
 
 // ---- fp32 handles, np = 4 (two FP16 parts per GEMM operand, cgemm_split.hip): fp16 carries 11 significant bits over 2^-24 .. 2^16, so the
 // spectra are scaled by a power of two that is exact to apply and to undo.  The bound is rigorous: a column transform sums H entries of the
-// row-transformed tensor T, so |X[f]| <= H * max|T|; max|T| is found by the row pass that writes T (one atomic max per work group on a device
-// word, order independent: deterministic), the column pass scales by 2^k with H * max|T| * 2^k < 2^15, and the inverse row pass multiplies its
+// row-transformed tensor T, so |X[f]| <= H * max|T|; max|T| of every image is found by the row pass that writes T (an atomic max per wave and
+// tile on the image's device word, order independent: deterministic), the column pass scales by 2^k with H * max|T| * 2^k < 2^15, and the inverse row pass multiplies its
 // 1 / (NY NX) by 2^-k and by the inverse of the filter spectra's own scale.  (struct Fp16Scale: kernels.h)
 __device__ __forceinline__ int fp16_exp(float tmax, float hf) {      // e with H * tmax < 2^e (0 for an all-zero tensor)
   const float bound = tmax * hf;
@@ -111,7 +111,21 @@ __device__ __forceinline__ int fp16_exp(float tmax, float hf) {      // e with H
 }
 __device__ __forceinline__ float fp16_scale(float tmax, float hf) { return ldexpf(1.f, 15 - fp16_exp(tmax, hf)); }
 __device__ __forceinline__ float fp16_unscale(float tmax, float hf) { return ldexpf(1.f, fp16_exp(tmax, hf) - 15); }
-// the work group's maximum -> the device word (values are >= 0: their bit patterns order like unsigned integers)
+// max |T| the scale of image b derives from: its own word, or (common) the largest of the tensor's nb words
+__device__ __forceinline__ float tmax_of(const float* __restrict__ tmax, int b, int nb, int common) {
+  if (!common) return tmax[b];
+  float m = 0.f;
+  for (int i = 0; i < nb; ++i) m = fmaxf(m, tmax[i]);
+  return m;
+}
+// a wave's maximum -> the device word (values are >= 0: their bit patterns order like unsigned integers).  No read of the word first: the
+// atomic returns nothing, so the wave does not wait for it.
+__device__ __forceinline__ void wave_max_to(float m, float* dst) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(m));
+}
+// the work group's maximum -> the device word
 template <int NTH>
 __device__ __forceinline__ void block_max_to(float m, float* dst, float* red, int tid) {
 #pragma unroll

@@ -20,10 +20,8 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_kernel(const void
   using Raw = std::conditional_t<LAYOUT == 0, cf, unsigned>;      // what a thread keeps per element: an fp32 channel pair, or two bf16 in one register
   __shared__ cf buf[NX * CH];
   __shared__ cf tw[NX];
-  __shared__ float red[NTR / 64];
   const int tid = threadIdx.x, ncb = C / CB;
   twiddles<NX, NTR>(tw, twg, tid);
-  float tm = 0.f;
   Raw pre[K];
   auto fetch = [&](int tile) __attribute__((always_inline)) {
     const int cblk = tile % ncb, by = tile / ncb;
@@ -45,9 +43,15 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_kernel(const void
       pre[i] = r;
     }
   };
-  int tile = blockIdx.x;
-  if (tile < ntiles) fetch(tile);
-  while (tile < ntiles) {
+  // A work group walks a CONTIGUOUS run of tiles (image-major order): its tiles belong to one or two images, so the running max|T| is
+  // flushed to an image's word when the image changes -- a handful of atomics per wave and launch.
+  const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+  int tile = blockIdx.x * per;
+  const int tend = min(ntiles, tile + per);
+  if (tile < tend) fetch(tile);
+  float tm = 0.f;
+  int tb = tile < tend ? tile / ncb / H : 0;
+  while (tile < tend) {
 #pragma unroll
     for (int i = 0; i < K; ++i) {
       const int t = tid + i * NTR;
@@ -56,16 +60,17 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_kernel(const void
         else buf[t] = bf16pair(pre[i]);
       }
     }
-    const int next = tile + gridDim.x;
-    if (next < ntiles) fetch(next);
+    const int next = tile + 1;
+    if (next < tend) fetch(next);
     __syncthreads();
     fft<NX, -1, CH, NTR>(buf, tw, tid);
-    const int cblk = tile % ncb, by = tile / ncb;
-    tm = fmaxf(tm, rows_fwd_store<NX, NTR>(buf, T, tid, cblk, by / H, by % H, B, H, C));
+    const int cblk = tile % ncb, by = tile / ncb, b = by / H;
+    if (tmax && b != tb) { wave_max_to(tm, tmax + tb); tm = 0.f; tb = b; }
+    tm = fmaxf(tm, rows_fwd_store<NX, NTR>(buf, T, tid, cblk, b, by % H, B, H, C));
     __syncthreads();      // every wave is done reading buf
     tile = next;
   }
-  if (tmax) block_max_to<NTR>(tm, tmax, red, tid);
+  if (tmax) wave_max_to(tm, tmax + tb);
 }
 
 // ---- rows, forward, of the MERGED map (fp32 NHWC): x = ((x1 + up(x2)) + up(x3)) / 3 (main.py:58,67,69-70; the arithmetic and association
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_merge_kernel(cons
   __syncthreads();
   fft<NX, -1, CH, NTR>(buf, tw, tid);
   const float tm = rows_fwd_store<NX, NTR>(buf, T, tid, cblk, b, y, B, H, C);
-  if (tmax) block_max_to<NTR>(tm, tmax, red, tid);      // (one atomic per work group at most: skipped once the word holds a larger value)
+  if (tmax) block_max_to<NTR>(tm, tmax + b, red, tid);      // one atomic per work group at most (skipped when the word already holds more)
 }
 
 

@@ -12,7 +12,7 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_kernel(const cf* 
                                                       const float* __restrict__ scale, const float* __restrict__ shift, int relu_bn, int H, int W, int C,
                                                       int Cout, int pad, float norm0, int ntiles, Fp16Scale sc) {
   constexpr int CH = CB / 2, NXH = NX / 2 + 1, NTR = rows_threads<NX>(), K = (NXH * CH + NTR - 1) / NTR;
-  const float norm = sc.tmax ? norm0 * fp16_unscale(sc.tmax[0], sc.hf) * sc.winv[0] : norm0;      // powers of two: exact
+  const float ncommon = sc.tmax ? norm0 * sc.winv[0] * (sc.common ? fp16_unscale(tmax_of(sc.tmax, 0, sc.nb, 1), sc.hf) : 1.f) : norm0;      // powers of two: exact
   __shared__ cf buf[NX * CH];
   __shared__ cf tw[NX];
   __shared__ float par[3 * kParMax];      // bias | scale | shift of every channel: the epilogue issues no global load, so nothing drains the prefetch
@@ -26,8 +26,11 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_kernel(const cf* 
       par[2 * kParMax + i] = relu_bn && i < Cout ? shift[i] : 0.f;
     }
   float4 pre[K];
+  float pre_t = 0.f;      // max|T| word of the prefetched tile's image
+  const bool per_image = sc.tmax && !sc.common;
   auto fetch = [&](int tile) __attribute__((always_inline)) {
     const int cblk = tile % ncb, by = tile / ncb;      // by = b * H + y
+    if (per_image) pre_t = sc.tmax[by / H];
     const float4* src = reinterpret_cast<const float4*>(T + ((size_t)by * NXH) * C + cblk * CB);
 #pragma unroll
     for (int i = 0; i < K; ++i) {
@@ -38,6 +41,7 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_kernel(const cf* 
   int tile = blockIdx.x;
   if (tile < ntiles) fetch(tile);
   while (tile < ntiles) {
+    const float norm = per_image ? ncommon * fp16_unscale(pre_t, sc.hf) : ncommon;      // this image's scale (taken before the next tile's prefetch overwrites it)
     // Z = Y_c + i Y_{c+1} with the Hermitian extension Y[NX - k] = conj Y[k]; DC and Nyquist are real by symmetry
 #pragma unroll
     for (int i = 0; i < K; ++i) {
@@ -102,9 +106,7 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_fwd_kernel(const 
   __shared__ cf buf[NX * CH];
   __shared__ cf tw[NX];
   __shared__ float par[3 * kParMax];
-  __shared__ float red[NTR / 64];
-  const float norm = sc.tmax ? norm0 * fp16_unscale(sc.tmax[0], sc.hf) * sc.winv[0] : norm0;
-  float tm = 0.f;
+  const float ncommon = sc.tmax ? norm0 * sc.winv[0] * (sc.common ? fp16_unscale(tmax_of(sc.tmax, 0, sc.nb, 1), sc.hf) : 1.f) : norm0;
   const int tid = threadIdx.x, ncb = C / CB;
   twiddles<NX, NTR>(tw, twg, tid);
   const bool par_lds = C <= kParMax;
@@ -115,8 +117,11 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_fwd_kernel(const 
       par[2 * kParMax + i] = relu_bn ? shift[i] : 0.f;
     }
   float4 pre[K];
+  float pre_t = 0.f;
+  const bool per_image = sc.tmax && !sc.common;
   auto fetch = [&](int tile) __attribute__((always_inline)) {
     const int cblk = tile % ncb, by = tile / ncb;
+    if (per_image) pre_t = sc.tmax[by / H];
     const float4* src = reinterpret_cast<const float4*>(T + ((size_t)by * NXH) * C + cblk * CB);
 #pragma unroll
     for (int i = 0; i < K; ++i) {
@@ -124,9 +129,15 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_fwd_kernel(const 
       pre[i] = t < NXH * CH ? src[(size_t)k * (C / 2) + v] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  int tile = blockIdx.x;
-  if (tile < ntiles) fetch(tile);
-  while (tile < ntiles) {
+  // contiguous runs of tiles per work group (image-major): the next layer's max|T| is flushed when the image changes (rows_fwd_kernel)
+  const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+  int tile = blockIdx.x * per;
+  const int tend = min(ntiles, tile + per);
+  if (tile < tend) fetch(tile);
+  float tm = 0.f;
+  int tb = tile < tend ? tile / ncb / H : 0;
+  while (tile < tend) {
+    const float norm = per_image ? ncommon * fp16_unscale(pre_t, sc.hf) : ncommon;
 #pragma unroll
     for (int i = 0; i < K; ++i) {
       const int t = tid + i * NTR, k = t / CH, v = t % CH;
@@ -138,8 +149,8 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_fwd_kernel(const 
         if (!edge) buf[(NX - k) * CH + v] = cf{q.x + q.w, q.z - q.y};
       }
     }
-    const int next = tile + gridDim.x;
-    if (next < ntiles) fetch(next);
+    const int next = tile + 1;
+    if (next < tend) fetch(next);
     __syncthreads();
     fft<NX, 1, CH, NTR>(buf, tw, tid);
     const int cblk = tile % ncb, by = tile / ncb;
@@ -173,11 +184,12 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_fwd_kernel(const 
     }
     __syncthreads();
     fft<NX, -1, CH, NTR>(buf, tw, tid);
+    if (sc.tmax_next && by / H != tb) { wave_max_to(tm, sc.tmax_next + tb); tm = 0.f; tb = by / H; }
     tm = fmaxf(tm, rows_fwd_store<NX, NTR>(buf, Tn, tid, cblk, by / H, by % H, B, H, C));
     __syncthreads();      // every wave is done reading buf
     tile = next;
   }
-  if (sc.tmax_next) block_max_to<NTR>(tm, sc.tmax_next, red, tid);
+  if (sc.tmax_next) wave_max_to(tm, sc.tmax_next + tb);
 }
 
 template <int NX> static void launch_rows_inv(const ConvArgs& a, int layout, const cf* T, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st) {

@@ -108,7 +108,7 @@ struct jcm_ctx {
   int conv9_fft = 1;            // fp32 handles: wide 9x9 layers in the frequency domain (conv_fft.hip) when the shape allows; 0 = fp32 MFMA chain
   int fft_fp16 = 1;             // fp32 handles: the channel GEMM on two FP16 parts per operand (three products, scaled spectra); 0 = three bf16 parts (six products)
   // device words of the fp16 scaling (kernels.h: Fp16Scale): a ring of zeroed floats, one per row-transformed tensor
-  static constexpr int kFftWords = 8192, kFftWordsPerCall = 2048;      // (a 2048-image forward in micro-batches of 64: 32 slices x 11 layers)
+  static constexpr int kFftWords = 1 << 18, kFftWordsPerCall = 1 << 16;      // (one word per image and layer: a 2048-image forward = 11 layers x 2048 + hand-overs)
   float* fft_words = nullptr;
   int fft_word_i = 0;
   float* fft_tmax_in = nullptr;     // transient: the word of the next frequency-domain layer's input (set with fft_t_in / fft_xs_ready by whoever produced that tensor)
@@ -188,7 +188,7 @@ bool takes_fft(jcm_ctx* c, const ConvLayer* L, int B, int H, int W);
 bool fft_spectra_valid(jcm_ctx* c, const std::string& scope, int H, int W);
 // operand form of the channel GEMM on this handle (kernels.h): 2 = bf16 handles; fp32 handles: 4 (two fp16 parts, default) or 3 (three bf16 parts)
 inline int fft_np(const jcm_ctx* c) { return c->precision == JCM_PRECISION_BF16 ? 2 : (c->fft_fp16 ? 4 : 3); }
-int fft_new_word(jcm_ctx* c, float** w);      // a zeroed device word of the scaling ring
+int fft_new_words(jcm_ctx* c, int n, float** w);      // n zeroed device words of the scaling ring (one per image)
 int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const void* x, int B, int H, int W, void* out, int in_layout, int out_layout);
 int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int stride, const void* x, int B, int H, int W, int sub,
                    void* out, bool act_bf16, bool out_f32, int in_planar = 0, int out_planar = 0);   // bf16 layouts: ConvArgs in kernels.h

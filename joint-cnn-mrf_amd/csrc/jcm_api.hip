@@ -200,14 +200,15 @@ bool fft_spectra_valid(jcm_ctx* c, const std::string& scope, int H, int W) {
 }
 // The ring is zeroed when it is created and every time it laps (CallOrder: between calls, in stream order, behind every kernel that read the
 // old words); a word is handed out once per lap.
-int fft_new_word(jcm_ctx* c, float** w) {
+int fft_new_words(jcm_ctx* c, int n, float** w) {
   if (!c->fft_words) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->fft_words), jcm_ctx::kFftWords * sizeof(float)));
     HIP_TRY(hipMemsetAsync(c->fft_words, 0, jcm_ctx::kFftWords * sizeof(float), c->stream));
     c->fft_word_i = 0;
   }
-  if (c->fft_word_i >= jcm_ctx::kFftWords) return fail(JCM_ERR_STATE, "more frequency-domain layers in one call than scale words (kFftWordsPerCall)");
-  *w = c->fft_words + c->fft_word_i++;
+  if (c->fft_word_i + n > jcm_ctx::kFftWords) return fail(JCM_ERR_STATE, "more frequency-domain layers x images in one call than scale words (kFftWordsPerCall)");
+  *w = c->fft_words + c->fft_word_i;
+  c->fft_word_i += n;
   return JCM_OK;
 }
 int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const void* x, int B, int H, int W, void* out, int in_layout, int out_layout) {
@@ -263,9 +264,10 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
     // the word of this layer's input: handed over with t_in / ready spectra, or a fresh one for this layer's own row pass
     sc.tmax = c->fft_tmax_in;
     if ((t_in || xs_ready) && !sc.tmax) return fail(JCM_ERR_STATE, "conv_fft '" + scope + "': a handed-over tensor without its scale word");
-    if (!sc.tmax) JCM_TRY(fft_new_word(c, &sc.tmax));
-    if (t_next) JCM_TRY(fft_new_word(c, &sc.tmax_next));
+    if (!sc.tmax) JCM_TRY(fft_new_words(c, B, &sc.tmax));
+    if (t_next) JCM_TRY(fft_new_words(c, B, &sc.tmax_next));
     sc.winv = fw.wscale + 1;
+    sc.common = c->train ? 1 : 0;      // a handle with training state: one scale per tensor (the weight gradient sums over the images)
   }
   c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; c->fft_xs = nullptr; c->fft_xs_ready = false;
   c->fft_tmax_in = sc.tmax_next;      // the next frequency-domain layer takes t_next (and its word)

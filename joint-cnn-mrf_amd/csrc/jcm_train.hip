@@ -213,8 +213,8 @@ int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int ldz, int B, fl
         hipEvent_t e0 = nullptr, e1 = nullptr;
         JCM_TRY(prof_begin(c, &e0, &e1));
         float* ztmax = nullptr;
-        if (np == 4) JCM_TRY(fft_new_word(c, &ztmax));
-        hipError_t le = conv_fft_spectra(az, L->ks, np, work, zs, c->stream, ztmax);
+        if (np == 4) JCM_TRY(fft_new_words(c, B, &ztmax));
+        hipError_t le = conv_fft_spectra(az, L->ks, np, work, zs, c->stream, ztmax, 1);
         if (le == hipSuccess)
           le = wgrad_fft(f.xs, zs, P, L->w_raw, lmbd, grad_of(t, grads, f.scope + "/weights"), L->ks, NY, NX, B, MTx, MTz, L->cin, ldz, L->cout, c->stream,
                          np, f.xs_tmax, ztmax, f.H);

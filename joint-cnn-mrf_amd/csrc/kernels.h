@@ -78,15 +78,20 @@ hipError_t conv_thin_bf16(const ConvArgs& a, hipStream_t st);
 // Shapes: Cin % 64 == 0, H + k - 1 <= 192, W + k - 1 <= 192.
 //
 // np = 4 scaling (fp16 carries 11 bits over 2^-24 .. 2^16): device words, all written and read on the stream --
-//   tmax      : max |T| of the layer's row-transformed input (atomic max by the row pass, or by the previous layer's fused kernel: ZERO it
-//               before the producer runs); the column pass scales by 2^k with H * tmax * 2^k < 2^15, the inverse row pass undoes it;
-//   tmax_next : the word of the NEXT layer when t_next is given;
-//   winv      : 1 / (scale of the filter spectra), written by conv_fft_pack_weights into wscale[1] (wscale[0] is its scratch).
+//   tmax[b]      : max |T| of image b of the layer's row-transformed input (atomic max by the row pass, or by the previous layer's fused kernel:
+//                  ZERO them before the producer runs); the column pass scales image b by 2^k with H * tmax[b] * 2^k < 2^15, the inverse row
+//                  pass undoes it.  One word per IMAGE: a row of the channel GEMM is one image, so an image's result does not depend on the
+//                  batch it is in.  common = 1: one scale for the tensor, from the max over the B words (the training step: the weight gradient
+//                  sums over the images and needs one scale);
+//   tmax_next[b] : the words of the NEXT layer when t_next is given;
+//   winv         : 1 / (scale of the filter spectra), written by conv_fft_pack_weights into wscale[1] (wscale[0] is its scratch).
 struct Fp16Scale {
   float* tmax = nullptr;
   float* tmax_next = nullptr;
   const float* winv = nullptr;
   float hf = 0.f;      // H (set by conv_fft_f32)
+  int nb = 0;          // B (set by conv_fft_f32)
+  int common = 0;
 };
 bool conv_fft_supported(const ConvArgs& a, int ks);
 size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout, int np);
@@ -102,7 +107,7 @@ hipError_t conv_fft_f32(const ConvArgs& a, int ks, int np, int in_layout, int ou
                         hipEvent_t g0, hipEvent_t g1, hipStream_t st, void* xs = nullptr, bool xs_ready = false, const Fp16Scale* sc = nullptr);
 size_t conv_fft_xs_bytes(const ConvArgs& a, int ks, int np);
 // NHWC fp32 -> split spectra (the two forward passes); np = 4: tmax = the (zeroed) device word of this tensor
-hipError_t conv_fft_spectra(const ConvArgs& a, int ks, int np, void* work, void* xs, hipStream_t st, float* tmax = nullptr);
+hipError_t conv_fft_spectra(const ConvArgs& a, int ks, int np, void* work, void* xs, hipStream_t st, float* tmax = nullptr, int common = 0);
 bool conv_fft_geometry(int H, int W, int ks, int B, int Cout, int np, int* NY, int* NX, int* MT);
 
 // ---- wgrad_fft.hip : weight gradient of a stride-1 layer in the frequency domain (fp32 handles, training step): per frequency
@@ -110,7 +115,7 @@ bool conv_fft_geometry(int H, int W, int ks, int B, int Cout, int np, int* NY, i
 // and of dZ, then the k x k taps are read off the inverse transform:  dw = taps(P) / (NY NX) + lmbd * w.   xs / zs: np = 3 layouts of cgemm_split.hip
 size_t wgrad_fft_scratch_bytes(int NY, int NX, int Cin, int Cout);
 // ldz: channels of the dZ spectra (P's columns, scratch sized with it) >= Cout, the filter's
-// np = 3: three bf16 parts per operand; np = 4: two fp16 parts, scaled -- tmax_x / tmax_z = the device words of the two spectra, H = map height
+// np = 3: three bf16 parts per operand; np = 4: two fp16 parts, scaled (common = 1) -- tmax_x / tmax_z = the B device words of the two spectra, H = map height
 hipError_t wgrad_fft(const void* xs, const void* zs, void* scratch, const float* w, float lmbd, float* dw, int ks, int NY, int NX, int B, int MTx, int MTz, int Cin,
                      int ldz, int Cout, hipStream_t st, int np = 3, const float* tmax_x = nullptr, const float* tmax_z = nullptr, int H = 0);
 hipError_t pad_channels_f32(const float* in, int ldi, float* out, int ldo, size_t N, hipStream_t st);      // train_kernels.hip

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void wgrad_taps_cols_kernel(const float2* __re
 
 template <int KS>
 __global__ __launch_bounds__(256) void wgrad_taps_rows_kernel(const float2* __restrict__ R, const float* __restrict__ w, float* __restrict__ dw, size_t n, int NY, int NX,
-                                                              float lmbd, int ldp, int Cout, const float* __restrict__ tmax_x, const float* __restrict__ tmax_z, float hf) {
+                                                              float lmbd, int ldp, int Cout, const float* __restrict__ tmax_x, const float* __restrict__ tmax_z, float hf, int nb) {
   constexpr int PAD = (KS - 1) / 2;
   __shared__ double2 twx[97 * KS];        // wgt(kx) e^{+2 pi i kx l / NX} / (NY NX), l = PAD - i
   const int NXH = NX / 2 + 1;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void wgrad_taps_rows_kernel(const float2* __re
     double sn, cs;
     sincospi(2.0 * (double)(((kx * l) % NX + NX) % NX) / (double)NX, &sn, &cs);
     double wgt = ((kx == 0 || 2 * kx == NX) ? 1.0 : 2.0) / ((double)NY * (double)NX);
-    if (tmax_x) wgt *= (double)cfft::fp16_unscale(tmax_x[0], hf) * (double)cfft::fp16_unscale(tmax_z[0], hf);      // the scaled fp16 operands (np = 4): powers of two
+    if (tmax_x) wgt *= (double)cfft::fp16_unscale(cfft::tmax_of(tmax_x, 0, nb, 1), hf) * (double)cfft::fp16_unscale(cfft::tmax_of(tmax_z, 0, nb, 1), hf);      // the scaled fp16 operands (np = 4): powers of two
     twx[i] = double2{cs * wgt, sn * wgt};
   }
   __syncthreads();
@@ -283,10 +283,10 @@ hipError_t wgrad_fft(const void* xs, const void* zs, void* scratch, const float*
   const unsigned blocks = (unsigned)((n + 255) / 256);
   if (ks == 9) {
     hipLaunchKernelGGL(wf::wgrad_taps_cols_kernel<9>, dim3(blocks, NXH), dim3(256), 0, st, a.P, R, n, NY);
-    hipLaunchKernelGGL(wf::wgrad_taps_rows_kernel<9>, dim3(blocks, 9), dim3(256), 0, st, R, w, dw, n, NY, NX, lmbd, ldz, Cout, tmax_x, tmax_z, (float)H);
+    hipLaunchKernelGGL(wf::wgrad_taps_rows_kernel<9>, dim3(blocks, 9), dim3(256), 0, st, R, w, dw, n, NY, NX, lmbd, ldz, Cout, tmax_x, tmax_z, (float)H, B);
   } else {
     hipLaunchKernelGGL(wf::wgrad_taps_cols_kernel<5>, dim3(blocks, NXH), dim3(256), 0, st, a.P, R, n, NY);
-    hipLaunchKernelGGL(wf::wgrad_taps_rows_kernel<5>, dim3(blocks, 5), dim3(256), 0, st, R, w, dw, n, NY, NX, lmbd, ldz, Cout, tmax_x, tmax_z, (float)H);
+    hipLaunchKernelGGL(wf::wgrad_taps_rows_kernel<5>, dim3(blocks, 5), dim3(256), 0, st, R, w, dw, n, NY, NX, lmbd, ldz, Cout, tmax_x, tmax_z, (float)H, B);
   }
   return hipGetLastError();
 }
