@@ -285,7 +285,7 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
         # bytes each pass must move: W or P spectra once per producer/consumer + split activation spectra + product spectra + maps
         C5 = 512 // (4 if args.debug else 1)
         wspec = FFT_FREQS * C5 * C5 * 8
-        xspec, yspec, amap = FFT_FREQS * B * C5 * 12, FFT_FREQS * B * C5 * 8, B * 60 * 90 * C5 * 4
+        xspec, yspec, amap = FFT_FREQS * B * C5 * 8, FFT_FREQS * B * C5 * 8, B * 60 * 90 * C5 * 4      # activation spectra: two fp16 parts
         fd_bytes = {'conv5': wspec + 2 * xspec + 2 * yspec + 2 * amap,             # read W; X spectra and product spectra written + read; map in / out
                     'dgrad:conv5': wspec + xspec + 2 * yspec + amap,               # dz spectra are the weight gradient's
                     'wgrad:conv5': 2 * wspec + amap + 3 * xspec}                   # P written (spec) + read (taps); dz spectra written, x and dz spectra read
@@ -310,7 +310,7 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': 'bf16' if prec == 'bf16' else {'split': 'f32(bf16x6)', 'split16': 'f32(fp16x3)'}.get(f32_conv, 'f32'), 'data': 'synthetic',
                'config': {'workload': 'configs[4]: joint training, batch=%d/GPU synthetic 480x720x3, %s%s, Adam, clip 4.0%s'
-                                      % (B, ('fp32 (stride-1 layers in the frequency domain, channel products as bf16x6 split MFMA; conv1 on fp32 MFMA)' if fd else 'fp32 MFMA') if prec == 'fp32' else 'mixed precision: bf16 activations/gradients + bf16 MFMA, fp32 master weights / statistics / losses / spatial model / optimizer',
+                                      % (B, ('fp32 (stride-1 layers in the frequency domain, channel products on two scaled fp16 parts per operand; conv1 on fp32 MFMA)' if fd else 'fp32 MFMA') if prec == 'fp32' else 'mixed precision: bf16 activations/gradients + bf16 MFMA, fp32 master weights / statistics / losses / spatial model / optimizer',
                                          ' operands; forward, data and weight gradients of the stride-1 layers as bf16x6 split MFMA' if f32_conv == 'split' else
                                          ' operands; forward, data and weight gradients as fp16x3 split MFMA (gradients scaled per tensor by a power of two)' if f32_conv == 'split16' else '',
                                          ', DEBUG filters/4' if args.debug else ''),

@@ -118,12 +118,22 @@ __device__ __forceinline__ float tmax_of(const float* __restrict__ tmax, int b, 
   for (int i = 0; i < nb; ++i) m = fmaxf(m, tmax[i]);
   return m;
 }
-// a wave's maximum -> the device word (values are >= 0: their bit patterns order like unsigned integers).  No read of the word first: the
-// atomic returns nothing, so the wave does not wait for it.
-__device__ __forceinline__ void wave_max_to(float m, float* dst) {
+// Per tile of a persistent row kernel: every wave leaves its maximum in LDS in front of the barrier that ends the tile anyway; behind it one
+// thread folds them and issues ONE atomic max on the image's device word (values are >= 0: their bit patterns order like unsigned integers).
+// The atomic returns nothing, so nobody waits for it; red[] is next written a whole tile (several barriers) later.
+__device__ __forceinline__ void wave_max_stash(float m, float* red) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+}
+template <int NTH>
+__device__ __forceinline__ void stash_to_word(const float* red, float* dst) {
+  if (threadIdx.x == 0) {
+    float m = red[0];
+#pragma unroll
+    for (int w = 1; w < NTH / 64; ++w) m = fmaxf(m, red[w]);
+    if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(m));
+  }
 }
 // the work group's maximum -> the device word
 template <int NTH>

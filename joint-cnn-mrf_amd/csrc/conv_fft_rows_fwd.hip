@@ -20,6 +20,7 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_kernel(const void
   using Raw = std::conditional_t<LAYOUT == 0, cf, unsigned>;      // what a thread keeps per element: an fp32 channel pair, or two bf16 in one register
   __shared__ cf buf[NX * CH];
   __shared__ cf tw[NX];
+  __shared__ float red[NTR / 64];
   const int tid = threadIdx.x, ncb = C / CB;
   twiddles<NX, NTR>(tw, twg, tid);
   Raw pre[K];
@@ -43,15 +44,9 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_kernel(const void
       pre[i] = r;
     }
   };
-  // A work group walks a CONTIGUOUS run of tiles (image-major order): its tiles belong to one or two images, so the running max|T| is
-  // flushed to an image's word when the image changes -- a handful of atomics per wave and launch.
-  const int per = (ntiles + gridDim.x - 1) / gridDim.x;
-  int tile = blockIdx.x * per;
-  const int tend = min(ntiles, tile + per);
-  if (tile < tend) fetch(tile);
-  float tm = 0.f;
-  int tb = tile < tend ? tile / ncb / H : 0;
-  while (tile < tend) {
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  while (tile < ntiles) {
 #pragma unroll
     for (int i = 0; i < K; ++i) {
       const int t = tid + i * NTR;
@@ -60,17 +55,17 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_kernel(const void
         else buf[t] = bf16pair(pre[i]);
       }
     }
-    const int next = tile + 1;
-    if (next < tend) fetch(next);
+    const int next = tile + gridDim.x;
+    if (next < ntiles) fetch(next);
     __syncthreads();
     fft<NX, -1, CH, NTR>(buf, tw, tid);
-    const int cblk = tile % ncb, by = tile / ncb, b = by / H;
-    if (tmax && b != tb) { wave_max_to(tm, tmax + tb); tm = 0.f; tb = b; }
-    tm = fmaxf(tm, rows_fwd_store<NX, NTR>(buf, T, tid, cblk, b, by % H, B, H, C));
+    const int cblk = tile % ncb, by = tile / ncb;
+    const float tm = rows_fwd_store<NX, NTR>(buf, T, tid, cblk, by / H, by % H, B, H, C);
+    if (tmax) wave_max_stash(tm, red);
     __syncthreads();      // every wave is done reading buf
+    if (tmax) stash_to_word<NTR>(red, tmax + by / H);      // the word of this tile's image
     tile = next;
   }
-  if (tmax) wave_max_to(tm, tmax + tb);
 }
 
 // ---- rows, forward, of the MERGED map (fp32 NHWC): x = ((x1 + up(x2)) + up(x3)) / 3 (main.py:58,67,69-70; the arithmetic and association

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_fwd_kernel(const 
   __shared__ cf buf[NX * CH];
   __shared__ cf tw[NX];
   __shared__ float par[3 * kParMax];
+  __shared__ float red[NTR / 64];
   const float ncommon = sc.tmax ? norm0 * sc.winv[0] * (sc.common ? fp16_unscale(tmax_of(sc.tmax, 0, sc.nb, 1), sc.hf) : 1.f) : norm0;
   const int tid = threadIdx.x, ncb = C / CB;
   twiddles<NX, NTR>(tw, twg, tid);
@@ -129,14 +130,9 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_fwd_kernel(const 
       pre[i] = t < NXH * CH ? src[(size_t)k * (C / 2) + v] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  // contiguous runs of tiles per work group (image-major): the next layer's max|T| is flushed when the image changes (rows_fwd_kernel)
-  const int per = (ntiles + gridDim.x - 1) / gridDim.x;
-  int tile = blockIdx.x * per;
-  const int tend = min(ntiles, tile + per);
-  if (tile < tend) fetch(tile);
-  float tm = 0.f;
-  int tb = tile < tend ? tile / ncb / H : 0;
-  while (tile < tend) {
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  while (tile < ntiles) {
     const float norm = per_image ? ncommon * fp16_unscale(pre_t, sc.hf) : ncommon;
 #pragma unroll
     for (int i = 0; i < K; ++i) {
@@ -149,8 +145,8 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_fwd_kernel(const 
         if (!edge) buf[(NX - k) * CH + v] = cf{q.x + q.w, q.z - q.y};
       }
     }
-    const int next = tile + 1;
-    if (next < tend) fetch(next);
+    const int next = tile + gridDim.x;
+    if (next < ntiles) fetch(next);
     __syncthreads();
     fft<NX, 1, CH, NTR>(buf, tw, tid);
     const int cblk = tile % ncb, by = tile / ncb;
@@ -184,12 +180,12 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_fwd_kernel(const 
     }
     __syncthreads();
     fft<NX, -1, CH, NTR>(buf, tw, tid);
-    if (sc.tmax_next && by / H != tb) { wave_max_to(tm, sc.tmax_next + tb); tm = 0.f; tb = by / H; }
-    tm = fmaxf(tm, rows_fwd_store<NX, NTR>(buf, Tn, tid, cblk, by / H, by % H, B, H, C));
+    const float tm = rows_fwd_store<NX, NTR>(buf, Tn, tid, cblk, by / H, by % H, B, H, C);
+    if (sc.tmax_next) wave_max_stash(tm, red);
     __syncthreads();      // every wave is done reading buf
+    if (sc.tmax_next) stash_to_word<NTR>(red, sc.tmax_next + by / H);
     tile = next;
   }
-  if (sc.tmax_next) wave_max_to(tm, sc.tmax_next + tb);
 }
 
 template <int NX> static void launch_rows_inv(const ConvArgs& a, int layout, const cf* T, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st) {
