@@ -66,6 +66,10 @@ int jcm_abi_version(void);
  *              first use (11.4 GB for the full-width model on 60x90 maps; cache bound: environment JCM_FFT_CACHE_GB, default 64).
  *              Calls of different handles on one device are ordered one after the other (they may come from different threads
  *              and streams; results do not depend on the interleaving).
+ * "fft_fp16" : any time, default 1 (fp32 handles): the channel product of the frequency-domain route on two FP16 parts per operand (three
+ *              products, 22 significant bits) of spectra scaled by powers of two -- one scale per image, derived from a rigorous bound, so an
+ *              image's result does not depend on its batch; a handle with training state uses one scale per tensor.  0 = three bf16 parts,
+ *              six products, no scaling (the same accuracy class at 1.3x the GEMM time).  Changing it drops the cached filter spectra.
  * "sm_algo"  : any time; the pairwise convolutions of the spatial model (main.py:83-87): 3 (default) = every FFT in LDS
  *              (sm_fused.hip); 2 = rocFFT with a split, row-pruned inverse; 0 = rocFFT 2-D transforms; 1 = direct
  *              sliding-window kernel.  All four are HIP paths that pass the same parity tests; the training step always
