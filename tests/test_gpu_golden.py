@@ -194,6 +194,39 @@ def test_split_conv_layer_error_is_fp32_class():
     assert r_fft <= r_exact + 1e-7
 
 
+def test_fft_fp16_scaling_is_robust_and_batch_independent():
+    """The default frequency-domain route of fp32 engines feeds its channel GEMM two FP16 parts of spectra scaled by one power of two per
+    image.  Inputs that stress the scaling -- magnitudes of 1e-6 and 1e+4, a single outlier 10^4 times the typical
+    value, an all-zero image -- in ONE batch: every image must come out as it does alone (bit for bit: an image's scale depends on that
+    image only), within fp32-class error of the float64 oracle relative to ITS OWN output scale, and like the six-product bf16 route."""
+    from joint_cnn_mrf_amd.engine import Engine
+    import oracle.jcm_oracle as O64
+    _x, _torso, p = full_inputs()
+    rs = np.random.RandomState(11)
+    base = np.maximum(rs.standard_normal((5, 60, 90, 256)), 0).astype(np.float32)
+    a = base.copy()
+    a[1] *= 1e-6
+    a[2] *= 1e4
+    a[3, 17, 23, 5] = 1e4                      # one outlier: the bound that sets the scale is 10^4 x looser for this image
+    a[4] = 0.0
+    ref = O64.conv_layer(a.astype(np.float64), p, 9, 1, 'conv4_fullres')
+    eng = Engine(device=0).load_params(p)
+    eng3 = Engine(device=0, fft_fp16=False).load_params(p)
+    assert eng.conv_kernel_name('conv4_fullres', 5, 60, 90).startswith('conv_fft')
+    got = eng.conv_layer(dev(a), 'conv4_fullres', 1, n_out=512).cpu().numpy()
+    got3 = eng3.conv_layer(dev(a), 'conv4_fullres', 1, n_out=512).cpu().numpy()
+    for b in range(5):
+        alone = eng.conv_layer(dev(a[b:b + 1]), 'conv4_fullres', 1, n_out=512).cpu().numpy()
+        np.testing.assert_array_equal(alone[0], got[b])
+        scale = np.abs(ref[b]).max()
+        e4, e3 = np.abs(got[b] - ref[b]).max() / scale, np.abs(got3[b] - ref[b]).max() / scale
+        print('image %d: output scale %.3g, error / scale: fp16x2 %.2e, bf16x3 %.2e' % (b, scale, e4, e3))
+        assert e4 <= 3e-6, (b, e4)      # measured 1e-7 .. 3e-7, the outlier image (whose scale bound is 10^4 x looser) included
+        assert e3 <= 3e-6, (b, e3)
+    eng.close()
+    eng3.close()
+
+
 def test_split_kernels_match_exact_on_every_layer_shape():
     """conv_split.hip (bf16x6 and fp16x3) against the exact fp32 MFMA kernel on every stride-1 layer shape of the model
     (5x5 / 9x9, 128- / 256-channel tiles, 12x32 patches and whole-row tiles), forced onto small grids (batch 1 and 3)."""
