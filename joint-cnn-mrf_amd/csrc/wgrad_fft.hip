@@ -24,6 +24,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace wf {
@@ -181,36 +182,38 @@ __global__ __launch_bounds__(256) void wgrad_taps_cols_kernel(const float2* __re
     twy[i] = float2{(float)cs, (float)sn};
   }
   __syncthreads();
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  // a thread owns TWO consecutive (ci, co) pairs: 16-byte loads (n = Cin * ldz is even), a wave instruction reads 1 KB contiguous
+  const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
   if (e >= n) return;
   const int kx = blockIdx.y;
-  float2 acc[KS];
+  float2 acc[KS][2];
 #pragma unroll
-  for (int j = 0; j < KS; ++j) acc[j] = float2{0.f, 0.f};
+  for (int j = 0; j < KS; ++j) acc[j][0] = acc[j][1] = float2{0.f, 0.f};
   const float2* col = P + ((size_t)kx * NY) * n + e;
-  constexpr int U = 8;                   // loads in flight per thread (NY is a multiple of 4; the tail is guarded)
+  constexpr int U = 8;                   // loads in flight per thread (the tail is guarded)
   for (int ky0 = 0; ky0 < NY; ky0 += U) {
-    float2 p[U];
+    f32x4 p[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) if (ky0 + u < NY) {
-        const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(col + (size_t)(ky0 + u) * n));
-        p[u] = float2{v.x, v.y};
-      } else {
-        p[u] = float2{0.f, 0.f};
-      }
+    for (int u = 0; u < U; ++u) {
+      if (ky0 + u < NY) p[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(col + (size_t)(ky0 + u) * n));
+      else p[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int ky = ky0 + u < NY ? ky0 + u : 0;
 #pragma unroll
       for (int j = 0; j < KS; ++j) {
         const float2 t = twy[ky * KS + j];
-        acc[j].x += p[u].x * t.x - p[u].y * t.y;
-        acc[j].y += p[u].x * t.y + p[u].y * t.x;
+        acc[j][0].x += p[u].x * t.x - p[u].y * t.y;
+        acc[j][0].y += p[u].x * t.y + p[u].y * t.x;
+        acc[j][1].x += p[u].z * t.x - p[u].w * t.y;
+        acc[j][1].y += p[u].z * t.y + p[u].w * t.x;
       }
     }
   }
 #pragma unroll
-  for (int j = 0; j < KS; ++j) R[((size_t)kx * KS + j) * n + e] = acc[j];
+  for (int j = 0; j < KS; ++j)
+    *reinterpret_cast<f32x4*>(R + ((size_t)kx * KS + j) * n + e) = f32x4{acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y};
 }
 
 template <int KS>
@@ -282,10 +285,10 @@ hipError_t wgrad_fft(const void* xs, const void* zs, void* scratch, const float*
   const size_t n = (size_t)Cin * ldz;
   const unsigned blocks = (unsigned)((n + 255) / 256);
   if (ks == 9) {
-    hipLaunchKernelGGL(wf::wgrad_taps_cols_kernel<9>, dim3(blocks, NXH), dim3(256), 0, st, a.P, R, n, NY);
+    hipLaunchKernelGGL(wf::wgrad_taps_cols_kernel<9>, dim3((blocks + 1) / 2, NXH), dim3(256), 0, st, a.P, R, n, NY);
     hipLaunchKernelGGL(wf::wgrad_taps_rows_kernel<9>, dim3(blocks, 9), dim3(256), 0, st, R, w, dw, n, NY, NX, lmbd, ldz, Cout, tmax_x, tmax_z, (float)H, B);
   } else {
-    hipLaunchKernelGGL(wf::wgrad_taps_cols_kernel<5>, dim3(blocks, NXH), dim3(256), 0, st, a.P, R, n, NY);
+    hipLaunchKernelGGL(wf::wgrad_taps_cols_kernel<5>, dim3((blocks + 1) / 2, NXH), dim3(256), 0, st, a.P, R, n, NY);
     hipLaunchKernelGGL(wf::wgrad_taps_rows_kernel<5>, dim3(blocks, 5), dim3(256), 0, st, R, w, dw, n, NY, NX, lmbd, ldz, Cout, tmax_x, tmax_z, (float)H, B);
   }
   return hipGetLastError();
