@@ -60,6 +60,34 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_kernel(const cf* 
     fft<NX, 1, CH, NTR>(buf, tw, tid);
     const int cblk = tile % ncb, by = tile / ncb;
     const int y = by % H, b = by / H;
+    if constexpr (LAYOUT == 2) {
+      // planar bf16 [B][C/8][H*W][8]: an item = (pixel, 8-channel plane) = one 16-byte store; 8 consecutive lanes = 8 consecutive pixels of
+      // one plane = a whole 128-byte line (the channel-pair mapping below would write 16-byte pieces of 16 different planes per instruction)
+      if (par_lds) {
+        typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+        const int nitems = ((W + 7) / 8) * 64;
+        for (int i = tid; i < nitems; i += NTR) {
+          const int xl = i & 7, g = (i >> 3) & 7, x = (i >> 6) * 8 + xl, c0 = cblk * CB + 8 * g;
+          if (x < W && c0 < Cout) {
+            const cf* zp = buf + pos<NX>(x + pad) * CH + 4 * g;
+            bf16x8v o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const cf z = zp[j];
+              const int c = c0 + 2 * j;
+              float v0 = z.x * norm + par[c], v1 = z.y * norm + par[c + 1];
+              if (relu_bn) { v0 = fmaxf(v0, 0.f) * par[kParMax + c] + par[2 * kParMax + c]; v1 = fmaxf(v1, 0.f) * par[kParMax + c + 1] + par[2 * kParMax + c + 1]; }
+              o[2 * j] = static_cast<__bf16>(v0);
+              o[2 * j + 1] = static_cast<__bf16>(v1);
+            }
+            *reinterpret_cast<bf16x8v*>(static_cast<__bf16*>(out) + (((size_t)b * (Cout >> 3) + (c0 >> 3)) * H * W + (size_t)y * W + x) * 8) = o;
+          }
+        }
+        __syncthreads();      // every wave is done reading buf
+        tile = next;
+        continue;
+      }
+    }
     // a thread keeps its channel pair for the whole row (the thread count is a multiple of CH): bias / scale / shift are loaded once per tile
     const int v = tid % CH, c = cblk * CB + 2 * v;
     if (c < Cout) {

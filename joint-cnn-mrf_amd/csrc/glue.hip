@@ -175,11 +175,13 @@ __global__ void upsample_merge3_bf16x8_kernel(const bf16x8v* __restrict__ x1, co
   // from HBM once per XCD (measured: 5.3 GB read for 1.9 GB of distinct input)
   const unsigned nb = gridDim.x, bid = nb % 8 == 0 ? (blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8 : blockIdx.x;
   for (size_t i = (size_t)bid * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = i % C8;
-    size_t r = i / C8;
-    const int ox = r % W; r /= W;
-    const int oy = r % H;
-    const size_t b = r / H;
+    // (32-bit index arithmetic: the launcher rejects tensors of 2^32 units or more; 64-bit divisions by run-time values cost more than the loads)
+    const unsigned iu = (unsigned)i;
+    const int c = (int)(iu % (unsigned)C8);
+    unsigned r = iu / (unsigned)C8;
+    const int ox = (int)(r % (unsigned)W); r /= (unsigned)W;
+    const int oy = (int)(r % (unsigned)H);
+    const size_t b = r / (unsigned)H;
     const F8 a = ld8(x1 + i);
     const F8 u2 = (H2 == H && W2 == W) ? ld8(x2 + i)
                                        : bilinear8(x2 + b * H2 * W2 * C8 + c, W2, C8, tf1_tap(oy, H2, sy2), tf1_tap(ox, W2, sx2));
@@ -225,6 +227,7 @@ hipError_t upsample_merge3(const void* x1, const void* x2, int H2, int W2, const
   if (C % 4) return hipErrorInvalidValue;
   if (bf16 && C % 8 == 0) {
     const size_t total8 = (size_t)B * H * W * (C / 8);
+    if (total8 >= (1ull << 32)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(upsample_merge3_bf16x8_kernel, dim3(grid_for(total8)), dim3(256), 0, st, static_cast<const bf16x8v*>(x1),
                        static_cast<const bf16x8v*>(x2), H2, W2, static_cast<const bf16x8v*>(x3), H3, W3,
                        static_cast<bf16x8v*>(out), H, W, C / 8, (float)H2 / (float)H, (float)W2 / (float)W,
