@@ -65,6 +65,42 @@ def test_config3_batch256_bf16_properties(fft):
     eng.close()
 
 
+def test_config1_batch64_fp32_properties():
+    """configs[1], the bench headline: batch 64, fp32, full-width network, FLIC priors, default route (stride-1 layers in the frequency
+    domain, channel GEMM on two scaled fp16 parts).  At this size a layer's 64 images share the launches and the GEMM tile: the first two
+    images are the golden pair and must come out bit for bit as on a batch of 2 (one power-of-two scale per image, every output element one
+    fixed-order accumulation), their arg-max coordinates must be the float64 goldens', and the probabilities must be probabilities."""
+    from joint_cnn_mrf_amd.engine import Engine
+    x2, torso2, p = _full_params()
+    B = 64
+    x = np.concatenate([x2, synth.make_images(B - 2, seed=277)], axis=0)
+    x[7] *= 0.01                                   # one dim and one bright image in the batch: their scales differ from their neighbours'
+    x[8] = np.minimum(x[8] * 3.0, 1.0)
+    torso = np.concatenate([torso2, synth.make_torso(B - 2, seed=278)], axis=0)
+    eng = Engine(device=0).load_params(p)
+    assert eng.conv_kernel_name('conv5', B, 60, 90) == eng.conv_kernel_name('conv2_fullres', B, 120, 180) == 'conv_fft(cgemm_split_kernel)'
+    r = eng.forward(dev(x), dev(torso), use_sm=True)
+    pd, sm = r['pd_prob'].cpu().numpy(), r['sm_prob'].cpu().numpy()
+    pd_c, sm_c = r['pd_coords'].cpu().numpy(), r['sm_coords'].cpu().numpy()
+    assert pd.shape == sm.shape == (B, 60, 90, 9) and pd_c.shape == sm_c.shape == (B, 2, 9)
+    np.testing.assert_allclose(pd.sum(axis=(1, 2)), 1.0, rtol=2e-5)
+    np.testing.assert_allclose(sm.sum(axis=(1, 2)), 1.0, rtol=2e-5)
+    assert np.isfinite(pd).all() and np.isfinite(sm).all() and pd.min() >= 0 and sm.min() >= 0
+    np.testing.assert_array_equal(pd_c, O.argmax_coords(pd))
+    np.testing.assert_array_equal(sm_c, O.argmax_coords(sm))
+    np.testing.assert_array_equal(pd_c[:2], load('full_pd_coords'))
+    np.testing.assert_array_equal(sm_c[:2], load('full_sm_coords_trained'))
+    np.testing.assert_allclose(pd[:2], O.spatial_softmax(load('full_pd_logits').astype(np.float64)), atol=1e-4, rtol=0)
+    two = eng.forward(dev(x[:2]), dev(torso[:2]), use_sm=True)
+    assert np.array_equal(two['pd_prob'].cpu().numpy(), pd[:2])
+    np.testing.assert_allclose(two['sm_prob'].cpu().numpy(), sm[:2], atol=1e-6, rtol=0)
+    for i in (7, 8, 41):                           # the dim image, the bright one, one deep in the batch: alone = in the batch
+        one = eng.forward(dev(x[i:i + 1]), dev(torso[i:i + 1]), use_sm=True)
+        assert np.array_equal(one['pd_prob'].cpu().numpy(), pd[i:i + 1]), i
+        np.testing.assert_array_equal(one['sm_coords'].cpu().numpy(), sm_c[i:i + 1])
+    eng.close()
+
+
 @pytest.mark.parametrize('precision,debug,B,mb', [('fp32', True, 5, 2), ('bf16', False, 5, 2), ('fp32', False, 3, 2)])
 def test_micro_batched_forward_equals_one_piece(precision, debug, B, mb):
     """jcm_forward walks a large batch in micro-batches (option "micro_batch": a rank's 2048 / N share of
