@@ -321,7 +321,8 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
     sc.hf = (float)a0.H;
     sc.nb = a0.B;
   }
-  if ((t_in || t_next || merge) && (in_layout != 0 || out_layout != 0 || (t_next && a0.Cout % CB))) return hipErrorInvalidValue;
+  if ((t_in || t_next) && (in_layout != 0 || out_layout != 0 || (t_next && a0.Cout % CB))) return hipErrorInvalidValue;
+  if (merge && in_layout == 2) return hipErrorInvalidValue;      // the merge reads NHWC (fp32 or bf16)
   ConvArgs a = a0;
   a.CoutP = pad64(a.Cout);
   const int opad = (ks - 1) / 2;                         // output row y = row y + pad of the circular convolution (whose size is H + 4 for both kernel sizes)
@@ -341,7 +342,7 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
   const cf* Tin = t_in ? static_cast<const cf*>(t_in) : T;
   if (!xs_ready) {
     if (merge && !t_in) {
-      cfft_rows_fwd_merge(s.NX, a, *merge, T, twx, sc.tmax, st);
+      cfft_rows_fwd_merge(s.NX, a, *merge, in_layout, T, twx, sc.tmax, st);
     } else if (!t_in) {
       cfft_rows_fwd(s.NX, a, in_layout, T, twx, sc.tmax, st);
     }

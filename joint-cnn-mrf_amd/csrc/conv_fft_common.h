@@ -217,7 +217,7 @@ int persistent_grid(const void* kernel, int ntiles, int threads);
 // padded to 64), ldy = channel stride of the product spectra (Cout padded to the GEMM's N tile)
 // sc: the fp16 scaling of np = 4 (tmax written by the forward row passes, read by the column pass and the inverse row passes); all null otherwise
 void cfft_rows_fwd(int NX, const ConvArgs& a, int layout, cf* T, const cf* tw, float* tmax, hipStream_t st);
-void cfft_rows_fwd_merge(int NX, const ConvArgs& a, const FftMerge& m, cf* T, const cf* tw, float* tmax, hipStream_t st);
+void cfft_rows_fwd_merge(int NX, const ConvArgs& a, const FftMerge& m, int in_layout, cf* T, const cf* tw, float* tmax, hipStream_t st);      // in_layout 0 / 1: NHWC fp32 / bf16
 hipError_t cfft_cols_fwd(int NY, const ConvArgs& a, int np, const cf* T, void* Xs, const cf* tw, int NXH, int MT, const Fp16Scale& sc, hipStream_t st);
 void cfft_cols_inv(int NY, const ConvArgs& a, const cf* Yf, cf* T, const cf* tw, int NXH, int ldy, int pad, hipStream_t st);
 void cfft_rows_inv(int NX, const ConvArgs& a, int layout, const cf* T, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st);

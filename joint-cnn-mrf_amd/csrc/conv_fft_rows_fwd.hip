@@ -68,13 +68,31 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_kernel(const void
   }
 }
 
-// ---- rows, forward, of the MERGED map (fp32 NHWC): x = ((x1 + up(x2)) + up(x3)) / 3 (main.py:58,67,69-70; the arithmetic and association
-// order of upsample_merge3_kernel) is formed while the row is loaded: the merged tensor never goes to HBM.
-template <int NX>
-__global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_merge_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int H2, int W2,
-                                                            const float* __restrict__ x3, int H3, int W3, cf* __restrict__ T, const cf* __restrict__ twg, int B, int H,
+// ---- rows, forward, of the MERGED map (NHWC fp32, or NHWC bf16 on bf16 handles): x = ((x1 + up(x2)) + up(x3)) / 3 (main.py:58,67,69-70; the
+// arithmetic and association order of upsample_merge3_kernel, rounded to bf16 on a bf16 handle exactly as that kernel's output is) is
+// formed while the row is loaded: the merged tensor never goes to HBM.  16-byte loads: 4 fp32 or 8 bf16 channels per thread-iteration.
+template <bool BF> struct MergeVec;
+template <> struct MergeVec<false> {
+  static constexpr int N = 4;
+  typedef float4 Raw;
+  __device__ static void unpack(const Raw& r, float (&f)[4]) { f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w; }
+};
+template <> struct MergeVec<true> {
+  static constexpr int N = 8;
+  typedef uint4 Raw;
+  __device__ static void unpack(const Raw& r, float (&f)[8]) {
+    const unsigned u[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(u[i] << 16); f[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u); }
+  }
+};
+template <int NX, bool BF>
+__global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_merge_kernel(const void* __restrict__ x1, const void* __restrict__ x2, int H2, int W2,
+                                                            const void* __restrict__ x3, int H3, int W3, cf* __restrict__ T, const cf* __restrict__ twg, int B, int H,
                                                             int W, int C, float sy2, float sx2, float sy3, float sx3, float* __restrict__ tmax) {
-  constexpr int CH = CB / 2, NTR = rows_threads<NX>();
+  using V = MergeVec<BF>;
+  using Raw = typename V::Raw;
+  constexpr int CH = CB / 2, NTR = rows_threads<NX>(), VN = V::N, CQ = CB / VN;      // CQ items per pixel of the 64-channel block
   __shared__ cf buf[NX * CH];
   __shared__ cf tw[NX];
   __shared__ float red[NTR / 64];
@@ -83,28 +101,40 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_merge_kernel(cons
   const int y = by % H, b = by / H;
   twiddles<NX, NTR>(tw, twg, tid);
   const Tap ty2 = tf1_tap(y, H2, sy2), ty3 = tf1_tap(y, H3, sy3);
-  // 16-byte loads: a thread-iteration forms two complex inputs (4 consecutive channels) of one pixel
-  const int C4 = C / 4;
-  const float4* p1 = reinterpret_cast<const float4*>(x1 + ((size_t)(b * H + y) * W) * C + cblk * CB);
-  const float4* p2 = reinterpret_cast<const float4*>(x2 + (size_t)b * H2 * W2 * C + cblk * CB);
-  const float4* p3 = reinterpret_cast<const float4*>(x3 + (size_t)b * H3 * W3 * C + cblk * CB);
-  auto bil = [&](const float4* p, int Wl, Tap ty, Tap tx, int v) __attribute__((always_inline)) {
-    const float4 tl = p[((size_t)ty.lo * Wl + tx.lo) * C4 + v], tr = p[((size_t)ty.lo * Wl + tx.hi) * C4 + v];
-    const float4 bl = p[((size_t)ty.hi * Wl + tx.lo) * C4 + v], br = p[((size_t)ty.hi * Wl + tx.hi) * C4 + v];
-    return make_float4(lerp2(tl.x, tr.x, bl.x, br.x, tx.t, ty.t), lerp2(tl.y, tr.y, bl.y, br.y, tx.t, ty.t), lerp2(tl.z, tr.z, bl.z, br.z, tx.t, ty.t),
-                       lerp2(tl.w, tr.w, bl.w, br.w, tx.t, ty.t));
+  const int CV = C / VN;
+  const Raw* p1 = static_cast<const Raw*>(x1) + ((size_t)(b * H + y) * W) * CV + cblk * CQ;
+  const Raw* p2 = static_cast<const Raw*>(x2) + (size_t)b * H2 * W2 * CV + cblk * CQ;
+  const Raw* p3 = static_cast<const Raw*>(x3) + (size_t)b * H3 * W3 * CV + cblk * CQ;
+  auto bil = [&](const Raw* p, int Wl, Tap ty, Tap tx, int v, float (&o)[VN]) __attribute__((always_inline)) {
+    float tl[VN], tr[VN], bl[VN], br[VN];
+    V::unpack(p[((size_t)ty.lo * Wl + tx.lo) * CV + v], tl);
+    V::unpack(p[((size_t)ty.lo * Wl + tx.hi) * CV + v], tr);
+    V::unpack(p[((size_t)ty.hi * Wl + tx.lo) * CV + v], bl);
+    V::unpack(p[((size_t)ty.hi * Wl + tx.hi) * CV + v], br);
+#pragma unroll
+    for (int i = 0; i < VN; ++i) o[i] = lerp2(tl[i], tr[i], bl[i], br[i], tx.t, ty.t);
   };
-  constexpr int CQ = CH / 2;
   for (int t = tid; t < NX * CQ; t += NTR) {
     const int x = t / CQ, v = t % CQ;
-    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float z[VN];
+#pragma unroll
+    for (int i = 0; i < VN; ++i) z[i] = 0.f;
     if (x < W) {
-      const float4 a = p1[(size_t)x * C4 + v];
-      const float4 u2 = (H2 == H && W2 == W) ? p2[((size_t)y * W + x) * C4 + v] : bil(p2, W2, ty2, tf1_tap(x, W2, sx2), v);
-      const float4 u3 = (H3 == H && W3 == W) ? p3[((size_t)y * W + x) * C4 + v] : bil(p3, W3, ty3, tf1_tap(x, W3, sx3), v);
-      z = make_float4(((a.x + u2.x) + u3.x) / 3.0f, ((a.y + u2.y) + u3.y) / 3.0f, ((a.z + u2.z) + u3.z) / 3.0f, ((a.w + u2.w) + u3.w) / 3.0f);
+      float a[VN], u2[VN], u3[VN];
+      V::unpack(p1[(size_t)x * CV + v], a);
+      if (H2 == H && W2 == W) V::unpack(p2[((size_t)y * W + x) * CV + v], u2);
+      else bil(p2, W2, ty2, tf1_tap(x, W2, sx2), v, u2);
+      if (H3 == H && W3 == W) V::unpack(p3[((size_t)y * W + x) * CV + v], u3);
+      else bil(p3, W3, ty3, tf1_tap(x, W3, sx3), v, u3);
+#pragma unroll
+      for (int i = 0; i < VN; ++i) {
+        z[i] = ((a[i] + u2[i]) + u3[i]) / 3.0f;
+        if constexpr (BF) z[i] = static_cast<float>(static_cast<__bf16>(z[i]));      // the merged map of a bf16 handle is a bf16 tensor
+      }
     }
-    *reinterpret_cast<float4*>(&buf[x * CH + 2 * v]) = z;
+    float4* dst = reinterpret_cast<float4*>(&buf[x * CH + (VN / 2) * v]);
+#pragma unroll
+    for (int i = 0; i < VN / 4; ++i) dst[i] = make_float4(z[4 * i], z[4 * i + 1], z[4 * i + 2], z[4 * i + 3]);
   }
   __syncthreads();
   fft<NX, -1, CH, NTR>(buf, tw, tid);
@@ -122,17 +152,21 @@ template <int NX> static void launch_rows_fwd(const ConvArgs& a, int layout, cf*
   else if (layout == 1) hipLaunchKernelGGL((rows_fwd_kernel<NX, 1>), grid, dim3(rows_threads<NX>()), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin, ntiles, tmax);
   else hipLaunchKernelGGL((rows_fwd_kernel<NX, 2>), grid, dim3(rows_threads<NX>()), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin, ntiles, tmax);
 }
-template <int NX> static void launch_rows_fwd_merge(const ConvArgs& a, const FftMerge& m, cf* T, const cf* tw, float* tmax, hipStream_t st) {
-  hipLaunchKernelGGL(rows_fwd_merge_kernel<NX>, dim3(a.B * a.H * (a.Cin / CB)), dim3(rows_threads<NX>()), 0, st, static_cast<const float*>(a.x), m.x2, m.H2, m.W2, m.x3, m.H3, m.W3, T, tw,
-                     a.B, a.H, a.W, a.Cin, (float)m.H2 / (float)a.H, (float)m.W2 / (float)a.W, (float)m.H3 / (float)a.H, (float)m.W3 / (float)a.W, tmax);
+template <int NX> static void launch_rows_fwd_merge(const ConvArgs& a, const FftMerge& m, int in_layout, cf* T, const cf* tw, float* tmax, hipStream_t st) {
+  const dim3 grid(a.B * a.H * (a.Cin / CB)), blk(rows_threads<NX>());
+  const float sy2 = (float)m.H2 / (float)a.H, sx2 = (float)m.W2 / (float)a.W, sy3 = (float)m.H3 / (float)a.H, sx3 = (float)m.W3 / (float)a.W;
+  if (in_layout == 1)
+    hipLaunchKernelGGL((rows_fwd_merge_kernel<NX, true>), grid, blk, 0, st, a.x, m.x2, m.H2, m.W2, m.x3, m.H3, m.W3, T, tw, a.B, a.H, a.W, a.Cin, sy2, sx2, sy3, sx3, tmax);
+  else
+    hipLaunchKernelGGL((rows_fwd_merge_kernel<NX, false>), grid, blk, 0, st, a.x, m.x2, m.H2, m.W2, m.x3, m.H3, m.W3, T, tw, a.B, a.H, a.W, a.Cin, sy2, sx2, sy3, sx3, tmax);
 }
 void cfft_rows_fwd(int NX, const ConvArgs& a, int layout, cf* T, const cf* tw, float* tmax, hipStream_t st) {
 #define CALL(N) launch_rows_fwd<N>(a, layout, T, tw, tmax, st)
   CFFT_BY_SIZE(NX, CALL)
 #undef CALL
 }
-void cfft_rows_fwd_merge(int NX, const ConvArgs& a, const FftMerge& m, cf* T, const cf* tw, float* tmax, hipStream_t st) {
-#define CALL(N) launch_rows_fwd_merge<N>(a, m, T, tw, tmax, st)
+void cfft_rows_fwd_merge(int NX, const ConvArgs& a, const FftMerge& m, int in_layout, cf* T, const cf* tw, float* tmax, hipStream_t st) {
+#define CALL(N) launch_rows_fwd_merge<N>(a, m, in_layout, T, tw, tmax, st)
   CFFT_BY_SIZE(NX, CALL)
 #undef CALL
 }

@@ -567,11 +567,12 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
     c->arena_off = mark;
   }
   const int hh = h4[0], ww = w4[0];
-  // fp32 handle with conv5 in the frequency domain: its forward row kernel forms ((x1 + up(x2)) + up(x3)) / 3 while it loads the rows
-  // (tried on bf16 handles too, and with the x1 row prefetched by persistent work groups: the 8 tap gathers per element then sit on the
-  // tile's critical path -- 4.5 ms against 1.1 + 1.1 ms for the separate merge kernel + plain row pass at B = 256)
-  const bool fuse_merge = !bf && takes_fft(c, L5, B, hh, ww);
-  FftMerge mg{static_cast<const float*>(x4[1]), h4[1], w4[1], static_cast<const float*>(x4[2]), h4[2], w4[2]};
+  // conv5 in the frequency domain: its forward row kernel forms ((x1 + up(x2)) + up(x3)) / 3 while it loads the rows (NHWC inputs: fp32, or
+  // bf16 on a bf16 handle, where the merged value is rounded to bf16 as the separate merge kernel's output would be).  (A variant with the
+  // x1 row prefetched by persistent work groups put the 8 tap gathers per element on the tile's critical path: 4.5 ms against 1.1 + 1.1 ms
+  // for the separate merge kernel + plain row pass at B = 256.)
+  const bool fuse_merge = takes_fft(c, L5, B, hh, ww) && !planar45;
+  FftMerge mg{x4[1], h4[1], w4[1], x4[2], h4[2], w4[2]};
   void* merged = fuse_merge ? x4[0] : act((size_t)B * hh * ww * L4->cout);
   if (!c->dry && !fuse_merge) {                                                            // :58,67,69-70
     if (planar45) HIP_TRY(upsample_merge3_planar(x4[0], x4[1], h4[1], w4[1], x4[2], h4[2], w4[2], merged, B, hh, ww, L4->cout, c->stream));

@@ -101,7 +101,7 @@ size_t conv_fft_workspace_bytes(const ConvArgs& a, int ks, int np);
 // in / out layout: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar (bf16 handles: operands are bf16 values, the arithmetic is fp32-class); g0/g1: optional events around the GEMM
 // t_in / t_next: the row-transformed tensor handed from one frequency-domain layer to the next (fp32 NHWC handles; conv_fft_fusable).
 // merge: a.x is the full-resolution branch x1 and the layer's input is ((x1 + up(x2)) + up(x3)) / 3, formed while the rows are loaded.
-struct FftMerge { const float* x2; int H2, W2; const float* x3; int H3, W3; };
+struct FftMerge { const void* x2; int H2, W2; const void* x3; int H3, W3; };      // x1 (a.x), x2, x3: NHWC in the layer's input type
 // xs / xs_ready: keep the split activation spectra in a caller buffer (conv_fft_xs_bytes) / they are there already (skip the forward transforms)
 hipError_t conv_fft_f32(const ConvArgs& a, int ks, int np, int in_layout, int out_layout, void* work, const void* t_in, void* t_next, const FftMerge* merge,
                         hipEvent_t g0, hipEvent_t g1, hipStream_t st, void* xs = nullptr, bool xs_ready = false, const Fp16Scale* sc = nullptr);
