@@ -33,8 +33,10 @@ typedef struct jcm_ctx* jcm_handle;
 #define JCM_ERR_STATE 2    /* parameter missing, handle not finalised, ...          */
 #define JCM_ERR_HIP 3      /* a HIP runtime call or kernel launch failed            */
 
-#define JCM_PRECISION_F32 0   /* fp32 MFMA (v_mfma_f32_32x32x2_f32): the parity path */
-#define JCM_PRECISION_BF16 1  /* bf16 operands, fp32 accumulate: the roofline path   */
+#define JCM_PRECISION_F32 0   /* fp32 tensors; fp32-class arithmetic: by default the stride-1 layers run in the frequency domain with every fp32
+                                 spectrum fed to the 16-bit matrix cores as two scaled fp16 parts (22 significant bits, "fft_fp16");
+                                 "conv9_fft" = 0 selects the exact fp32 MFMA accumulation chain (v_mfma_f32_32x32x2_f32) -- the parity path */
+#define JCM_PRECISION_BF16 1  /* bf16 tensors between the layers, fp32 accumulate -- the roofline path */
 
 /* -- lifecycle --------------------------------------------------------------------------
  * Replaces tf.Session(config, graph) / sess.close (main.py:606-608,677-680). `stream` is a
@@ -47,7 +49,9 @@ int jcm_abi_version(void);
 /* -- options ------------------------------------------------------------------------------
  * "precision": JCM_PRECISION_*  (the reference is fp32 throughout)
  * "n_joints" : K, default 9      (main.py:458)
- * "f32_conv"  : fp32 handles only; 0 (default) = every convolution on the exact fp32 MFMA chain,
+ * "f32_conv"  : fp32 handles only; arithmetic of the DIRECT (not frequency-domain) convolution kernels, i.e. of every layer when
+ *              "conv9_fft" = 0 and of the shapes the frequency-domain route does not take otherwise: 0 (default) = the exact fp32 MFMA
+ *              chain; a non-zero value also switches the frequency-domain route off;
  *              1 = the stride-1 layers with Cin % 16 == 0 and Cout % 128 == 0 run as three-way bf16
  *              operand splits with six products on the bf16 matrix cores (fp32-class error);
  *              2 = two-way fp16 splits with three products; every operand tensor (weights, layer
@@ -64,8 +68,13 @@ int jcm_abi_version(void);
  *              0 = the direct MFMA kernels.  The training step of an fp32 handle takes the same route (forward, data and weight
  *              gradients); a bf16 handle trains on the direct bf16 kernels.  Filter spectra are built per (layer, map size) on
  *              first use (11.4 GB for the full-width model on 60x90 maps; cache bound: environment JCM_FFT_CACHE_GB, default 64).
- *              Calls of different handles on one device are ordered one after the other (they may come from different threads
- *              and streams; results do not depend on the interleaving).
+ *              An fp32 handle WITH TRAINING STATE holds more: a second 11.4 GB set of spectra of the flipped, transposed filters for
+ *              the data gradient (both sets are repacked after every update) and up to 7.5 GB of weight-gradient scratch (the per-frequency
+ *              products P and the column sums R of conv5) in the workspace arena -- about 31 GB beside the 6 GB of activations.
+ * "call_order": any time, default 1: calls of different handles on one device are ordered one after the other on the GPU -- an entry
+ *              point holds a per-device lock while it enqueues, makes its stream wait for the previous call of another stream and records
+ *              an event behind its last kernel -- so they may come from different host threads and streams and results do not depend on
+ *              the interleaving.  0 takes the handle out of that chain (debugging: tools/determinism.py).
  * "fft_fp16" : any time, default 1 (fp32 handles): the channel product of the frequency-domain route on two FP16 parts per operand (three
  *              products, 22 significant bits) of spectra scaled by powers of two -- one scale per image, derived from a rigorous bound, so an
  *              image's result does not depend on its batch; a handle with training state uses one scale per tensor.  0 = three bf16 parts,
@@ -199,7 +208,9 @@ int64_t jcm_workspace_bytes(jcm_handle h);
  *       prior spectra) is rebuilt, so inference entry points see the new parameters.
  *
  * Trainable tensors are all parameters except the BatchNorm moving statistics, in ascending name
- * order.  fp32 handles only. */
+ * order.  fp32 handles take the default route of "conv9_fft" (forward, data and weight gradients in the frequency domain, two scaled
+ * fp16 parts per operand) or, with "conv9_fft" = 0 / "f32_conv", the direct kernels; bf16 handles train in mixed precision (bf16 tensors
+ * and MFMA operands, fp32 master weights, statistics, losses, spatial model and optimizer). */
 #define JCM_OPT_ADAM 0
 #define JCM_OPT_MOMENTUM 1
 int jcm_train_begin(jcm_handle h);                       /* after jcm_finalize: allocates optimizer slots, n_iters = 0 */
@@ -209,6 +220,13 @@ int jcm_train_param_info(jcm_handle h, int64_t index, char* name, int name_cap, 
  * losses: device fp32 [4] = loss_tower, loss_pd, loss_sm, weight_decay('weights'). */
 int jcm_train_loss_grads(jcm_handle h, const float* x, const float* y, int B, int H, int W, int use_sm, float lmbd,
                          float* grads, float* losses);
+/* The gradient kernels of one stride-1 conv layer on caller tensors, on the route the training step takes on this handle (what
+ * opt.compute_gradients, main.py:560, evaluates for tf.nn.conv2d, main.py:135): x [B,H,W,Cin] the layer input, dz [B,H,W,Cout] the gradient
+ * w.r.t. the convolution output;  grads[<scope>/weights] = sum over (b,y,x) of x (*) dz + lmbd * w  (flat buffer in the layout of
+ * jcm_train_param_info, only this slice is written) and dx_out [B,H,W,Cin] (may be NULL) = conv_SAME(dz, flipped transposed w).  Used by the
+ * tests to hold the gradient kernels to fp32-class error at full-size layer shapes; fp32 handles, after jcm_train_begin. */
+int jcm_train_layer_grads(jcm_handle h, const char* scope, const float* x, const float* dz, int B, int H, int W, float lmbd,
+                          float* grads, float* dx_out);
 /* grads: the (tower-averaged) gradients, same layout; lr: the value of lr_tf for this update
  * (main.py:492); clip_norm <= 0 disables the clip; grad_norm_out (host, may be NULL) receives the
  * global norm before clipping and makes the call synchronise. */

@@ -57,6 +57,8 @@ SIGNATURES = {
                                             ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     'jcm_train_loss_grads': (ctypes.c_int, [_handle, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_float, _c_float_p, _c_float_p]),
+    'jcm_train_layer_grads': (ctypes.c_int, [_handle, ctypes.c_char_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                             _c_float_p, _c_float_p]),
     'jcm_train_apply': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.POINTER(ctypes.c_float)]),
     'jcm_train_set_grad_callback': (ctypes.c_int, [_handle, ctypes.c_void_p, ctypes.c_void_p]),
     'jcm_train_steps': (ctypes.c_int, [_handle, ctypes.POINTER(ctypes.c_int64)]),

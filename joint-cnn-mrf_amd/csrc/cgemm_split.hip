@@ -158,6 +158,11 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
   const int KC = a.KC;
 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  // Keep the first LDS-DMA away from the start of the work group (round 4): with the burst of the first stages issued right
+  // behind the wave's set-up code, work groups of OTHER kernels on the CU (another stream's) saw 128-byte pieces of their LDS overwritten --
+  // 242 of 300 runs of a layer differed beside this kernel's 64 x 32 instantiation (3136 two-wave work groups, i.e. a work-group
+  // boundary every microsecond per CU), 0 of 300 with this pause (4 x 64 cycles) or with the requests spaced out.
+  __builtin_amdgcn_s_sleep(4);
   constexpr int WBYTES = WF32 ? C::WSRC : WST * 16;      // bytes of one stage of the W stream in HBM
   const char* xg = a.xs + ((size_t)(f * a.mtiles + mt) * KC) * (size_t)(XST * 16);
   const char* wg = a.ws + ((size_t)(f * a.ntiles + nt) * KC) * (size_t)WBYTES;
@@ -166,10 +171,13 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
   const unsigned lane16 = (unsigned)lane * 16u;
 
   // stage g -> ring slot: the LDS image of a stage is its HBM image, X pieces first; wave w moves pieces w, w + NW, ...
-  // Past the last stage the look-ahead requests run out of the buffer descriptor and deliver zeros into a free slot: no tail logic.  The
-  // stage offset therefore rides in the VECTOR offset: only that one is bounds-checked (a scalar offset past the end reads whatever
-  // lies behind the buffer -- harmless for this kernel, but those stray reads leave stale copies of OTHER streams' buffers in the
-  // per-XCD L2s at arbitrary times, and a kernel of that other stream then consumes them: found by the two-stream soak test).
+  // A DMA is issued for EXISTING stages only (g < KC; the callers guard).  Rounds 2-3 let the look-ahead run past the last stage -- first
+  // with the stage offset in the scalar operand (not bounds-checked: stray reads behind the buffer), then in the bounds-checked vector
+  // operand so that the request "delivers zeros into a free slot".  Round 4 found what that costs when kernels of ANOTHER stream share
+  // the CU: with such out-of-range LDS-DMAs in the last stages of a work group, 128-byte pieces of zeros appear in the LDS of a work
+  // group of a different kernel that was started on the CU afterwards (seen as three zeroed 128-byte lines, 1 KB apart, in the row
+  // transform's tile: tools/determinism.py).  A/B on one box: 266 of 300 runs of a layer differ beside this kernel
+  // with the out-of-range look-ahead, 0 of 300 without.  The stage offset still rides in the (bounds-checked) vector offset.
   auto issue = [&](int g, int slot) __attribute__((always_inline)) {
     const unsigned sbase = (unsigned)(slot * STAGE * 16);
 #pragma unroll
@@ -248,10 +256,11 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
     wait_w(std::integral_constant<int, C::XPW>{});
 #pragma unroll
     for (int u = 0; u < UPT; ++u) split_w(0, u);
-    load_w(1);
+    if (1 < KC) load_w(1);
   } else {
 #pragma unroll
-    for (int s = 0; s < R - 1; ++s) issue(s, s);
+    for (int s = 0; s < R - 1; ++s)
+      if (s < KC) issue(s, s);
   }
 
   // per-lane fragment addresses inside slot 0: unit (k-half h, row) of plane (re, part 0)
@@ -263,12 +272,16 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
     // this wave's DMA pieces of stage g have landed (R-2 younger stages -- WF32: the register loads of stage g+1 -- may stay in flight);
     // after the barrier everybody's have (WF32: and everybody's split units of stage g are written), and every wave is done reading
     // slot (g-1) % R, which the DMA of stage g+R-1 (WF32: and the split of stage g+1) now refills
-    asm volatile("s_waitcnt vmcnt(%0)" ::"i"((R - 2) * C::PW + WL) : "memory");
+    // Nothing is ever requested for a stage past the last one (see issue()): behind the last stage nothing younger is in flight.
+    static_assert(R == 2 || R == 3, "the wait below counts at most one younger stage");
+    const bool last = g + 1 >= KC;
+    if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"i"((R - 2) * C::PW + WL) : "memory");
     if constexpr (WF32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     const int ns = slot == 0 ? R - 1 : slot - 1;
-    issue(g + R - 1, ns);
+    if (g + R - 1 < KC) issue(g + R - 1, ns);
     f32x4 xr[2][FM], xi[2][FM], wr[2][FN], wi[2][FN];
     frag_load<C, prod_x<NP>(0), prod_w<NP>(0)>(xr[0], xi[0], wr[0], wi[0], xaddr, waddr);
     auto product = [&](auto sc) __attribute__((always_inline)) {
@@ -314,14 +327,16 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
     if constexpr (WF32) {
       // the filter spectra of stage g+1 (requested a stage ago; the DMA pieces just issued stay in flight) -> bf16 parts -> the other slot,
       // one unit behind each of the next products; then the loads of stage g+2 go out
-      wait_w(std::integral_constant<int, C::XPW>{});
-      split_w(ns, 0);
+      if (!last) {
+        wait_w(std::integral_constant<int, C::XPW>{});
+        split_w(ns, 0);
+      }
     }
     if constexpr (C::NPROD > 2) product(std::integral_constant<int, 2>{});
     if constexpr (WF32) {
-      if constexpr (UPT == 2) split_w(ns, 1);
+      if constexpr (UPT == 2) { if (!last) split_w(ns, 1); }
       __builtin_amdgcn_sched_barrier(0);
-      load_w(g + 2);
+      if (g + 2 < KC) load_w(g + 2);
     }
     if constexpr (C::NPROD > 3) product(std::integral_constant<int, 3>{});
     if constexpr (C::NPROD > 4) product(std::integral_constant<int, 4>{});
@@ -333,7 +348,7 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
     waddr += d;
     slot = wrap ? 0 : slot + 1;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the look-ahead loads of the last stages (zeros)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (nothing is in flight here any more; kept as the guard of the LDS hand-back)
 
   // ---- Y[f][b][co]: accumulator register i of a fragment is row (i&3) + 8 (i>>2) + 4 h, column l31: a half wave stores 32 complex
   // numbers = 256 contiguous bytes per instruction

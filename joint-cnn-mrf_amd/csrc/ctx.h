@@ -4,6 +4,7 @@
 #include "../../include/jcm.h"
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -107,10 +108,14 @@ struct jcm_ctx {
   const void* fft_merge = nullptr;   // const jcm::FftMerge*: the next frequency-domain layer forms the merged map itself (jcm_pd_forward, conv5)
   int conv9_fft = 1;            // fp32 handles: wide 9x9 layers in the frequency domain (conv_fft.hip) when the shape allows; 0 = fp32 MFMA chain
   int fft_fp16 = 1;             // fp32 handles: the channel GEMM on two FP16 parts per operand (three products, scaled spectra); 0 = three bf16 parts (six products)
-  // device words of the fp16 scaling (kernels.h: Fp16Scale): a ring of zeroed floats, one per row-transformed tensor
-  static constexpr int kFftWords = 1 << 18, kFftWordsPerCall = 1 << 16;      // (one word per image and layer: a 2048-image forward = 11 layers x 2048 + hand-overs)
-  float* fft_words = nullptr;
-  int fft_word_i = 0;
+  // device words of the fp16 scaling (kernels.h: Fp16Scale): zeroed floats, one per image of every row-transformed tensor of a call.  They come from
+  // blocks of kFftWords floats; a call that needs more than a block holds (a forward of > 20 000 images in one piece) gets further blocks on demand,
+  // and the blocks are re-zeroed and reused from the start BETWEEN calls (CallOrder), in stream order behind every kernel that read the old words.
+  static constexpr int kFftWords = 1 << 18, kFftWordsPerCall = 1 << 16;
+  struct WordBlock { float* p = nullptr; int cap = 0; };
+  std::vector<WordBlock> fft_blocks;
+  int fft_block_i = 0, fft_word_i = 0;      // next free word: fft_blocks[fft_block_i].p + fft_word_i
+  int call_order = 1;               // 0: this handle's calls are not ordered against other handles' (debugging only)
   float* fft_tmax_in = nullptr;     // transient: the word of the next frequency-domain layer's input (set with fft_t_in / fft_xs_ready by whoever produced that tensor)
   float* fft_last_tmax = nullptr;   // the word the last frequency-domain layer's input used (the training step keeps it with the kept spectra)
   struct FftW { void* p = nullptr; size_t bytes = 0; bool valid = false; float* wscale = nullptr; };      // wscale: two device floats behind the spectra (np = 4)
@@ -146,17 +151,23 @@ struct DeviceGuard {
   }
 };
 
-// Calls of DIFFERENT handles on one device are ordered on the GPU: every entry point that enqueues work waits (hipStreamWaitEvent, the
-// host does not block) for the previous call of another stream and records an event when it has queued its own kernels.  Each call
-// fills the chip on its own, so nothing is lost; what is gained is that no kernel of this library ever runs beside a kernel of another
+// Calls of DIFFERENT handles on one device are ordered on the GPU: an entry point that enqueues work holds the device's lock for as long
+// as it is enqueuing (so two host threads never interleave their launches), first makes its stream wait (hipStreamWaitEvent, the host does
+// not block) for the event the previous call of another stream recorded, and records the event again behind its own last kernel.  Each
+// call fills the chip on its own, so nothing is lost; what is gained is that no kernel of this library ever runs beside a kernel of another
 // handle.  The per-XCD L2s are not coherent with each other: a kernel that touches memory another stream is producing (the look-ahead
 // reads past the end of a buffer that cgemm_split.hip used to make were such touches) leaves stale lines that the other stream's next
 // kernel then consumes -- found by tests/test_gpu_golden.py::test_two_engines_two_streams_soak.  The known over-reads are fixed at the
-// source; this ordering is the guarantee that does not depend on having found them all.
+// source; this ordering is the guarantee that does not depend on having found them all.  jcm_set_option("call_order", 0) takes a handle
+// out of the chain (it neither waits nor records; tools/determinism.py and the soak tests use it to look for what the chain would hide).
+// The constructor also clears the transient hand-over fields an aborted call may have left behind and laps the fp16 scale-word ring.
 struct CallOrder {
   jcm_ctx* c;
+  std::unique_lock<std::mutex> lk;
   explicit CallOrder(jcm_ctx* ctx);
   ~CallOrder();
+  CallOrder(const CallOrder&) = delete;
+  CallOrder& operator=(const CallOrder&) = delete;
 };
 
 template <class T>

@@ -32,19 +32,24 @@ Chain g_chain[64];
 CallOrder::CallOrder(jcm_ctx* ctx) : c(ctx) {
   if (!c) return;
   Chain& ch = g_chain[c->device & 63];
-  std::lock_guard<std::mutex> lk(ch.mu);
-  if (!ch.ev && hipEventCreateWithFlags(&ch.ev, hipEventDisableTiming) != hipSuccess) { ch.ev = nullptr; return; }
-  if (ch.armed && ch.last != c->stream) (void)hipStreamWaitEvent(c->stream, ch.ev, 0);
-  // the ring of fp16-scale words laps only BETWEEN calls (a call keeps words of its early layers until its last ones: the training step)
-  if (c->fft_words && c->fft_word_i > jcm_ctx::kFftWords - jcm_ctx::kFftWordsPerCall) {
-    (void)hipMemsetAsync(c->fft_words, 0, jcm_ctx::kFftWords * sizeof(float), c->stream);
+  lk = std::unique_lock<std::mutex>(ch.mu);      // held until the call has queued its last kernel: two host threads never interleave their launches
+  if (c->call_order) {
+    if (!ch.ev && hipEventCreateWithFlags(&ch.ev, hipEventDisableTiming) != hipSuccess) ch.ev = nullptr;
+    if (ch.ev && ch.armed && ch.last != c->stream) (void)hipStreamWaitEvent(c->stream, ch.ev, 0);
+  }
+  // what an aborted call may have left behind
+  c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; c->fft_xs = nullptr; c->fft_xs_ready = false; c->fft_tmax_in = nullptr;
+  // the fp16-scale words are reused from the start only BETWEEN calls (a call keeps words of its early layers until its last ones: the training step)
+  if (c->fft_block_i > 0 || c->fft_word_i > jcm_ctx::kFftWords - jcm_ctx::kFftWordsPerCall) {
+    for (int i = 0; i <= c->fft_block_i && i < (int)c->fft_blocks.size(); ++i)
+      (void)hipMemsetAsync(c->fft_blocks[i].p, 0, (size_t)c->fft_blocks[i].cap * sizeof(float), c->stream);
+    c->fft_block_i = 0;
     c->fft_word_i = 0;
   }
 }
 CallOrder::~CallOrder() {
-  if (!c) return;
+  if (!c || !c->call_order) return;
   Chain& ch = g_chain[c->device & 63];
-  std::lock_guard<std::mutex> lk(ch.mu);
   if (!ch.ev) return;
   if (hipEventRecord(ch.ev, c->stream) == hipSuccess) { ch.armed = true; ch.last = c->stream; }
 }
@@ -198,18 +203,31 @@ bool fft_spectra_valid(jcm_ctx* c, const std::string& scope, int H, int W) {
   auto it = c->fft_w.find(scope + "@" + std::to_string(H) + "x" + std::to_string(W));
   return it != c->fft_w.end() && it->second.valid;
 }
-// The ring is zeroed when it is created and every time it laps (CallOrder: between calls, in stream order, behind every kernel that read the
-// old words); a word is handed out once per lap.
+// n zeroed device words (one per image of a row-transformed tensor).  Blocks are zeroed when they are created and every time the handle starts
+// over at the first one (CallOrder: between calls, in stream order, behind every kernel that read the old words); a word is handed out once per lap.
 int fft_new_words(jcm_ctx* c, int n, float** w) {
-  if (!c->fft_words) {
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->fft_words), jcm_ctx::kFftWords * sizeof(float)));
-    HIP_TRY(hipMemsetAsync(c->fft_words, 0, jcm_ctx::kFftWords * sizeof(float), c->stream));
-    c->fft_word_i = 0;
+  if (n < 1) return fail(JCM_ERR_ARG, "fft_new_words: n < 1");
+  for (;;) {
+    if (c->fft_block_i < (int)c->fft_blocks.size()) {
+      jcm_ctx::WordBlock& b = c->fft_blocks[c->fft_block_i];
+      if (c->fft_word_i + n <= b.cap) {
+        *w = b.p + c->fft_word_i;
+        c->fft_word_i += n;
+        return JCM_OK;
+      }
+      ++c->fft_block_i;      // the rest of this block stays unused until the next lap
+      c->fft_word_i = 0;
+      continue;
+    }
+    jcm_ctx::WordBlock b;
+    b.cap = n > jcm_ctx::kFftWords ? n : jcm_ctx::kFftWords;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b.p), (size_t)b.cap * sizeof(float)));
+    if (hipError_t e = hipMemsetAsync(b.p, 0, (size_t)b.cap * sizeof(float), c->stream); e != hipSuccess) {
+      (void)hipFree(b.p);
+      return fail(JCM_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+    }
+    c->fft_blocks.push_back(b);
   }
-  if (c->fft_word_i + n > jcm_ctx::kFftWords) return fail(JCM_ERR_STATE, "more frequency-domain layers x images in one call than scale words (kFftWordsPerCall)");
-  *w = c->fft_words + c->fft_word_i;
-  c->fft_word_i += n;
-  return JCM_OK;
 }
 int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const void* x, int B, int H, int W, void* out, int in_layout, int out_layout) {
   ConvArgs a{};
@@ -690,7 +708,7 @@ int jcm_destroy(jcm_handle h) {
   for (auto& kv : h->params) (void)hipFree(kv.second.d);
   for (void* p : h->owned) (void)hipFree(p);
   for (auto& kv : h->fft_w) (void)hipFree(kv.second.p);
-  if (h->fft_words) (void)hipFree(h->fft_words);
+  for (auto& b : h->fft_blocks) (void)hipFree(b.p);
   if (h->arena) (void)hipFree(h->arena);
   delete h;
   return JCM_OK;
@@ -711,6 +729,10 @@ int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
   if (k == "micro_batch") {   // allowed at any time
     if (value < 0) return fail(JCM_ERR_ARG, "micro_batch must be >= 0 (0 = default: 256 bf16 / 64 fp32)");
     h->micro_batch = (int)value;
+    return JCM_OK;
+  }
+  if (k == "call_order") {   // allowed at any time; 0 = debugging: this handle's calls are not ordered against other handles' on the device
+    h->call_order = value != 0;
     return JCM_OK;
   }
   if (k == "conv9_fft") {  // allowed at any time

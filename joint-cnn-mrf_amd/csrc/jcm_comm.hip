@@ -141,7 +141,10 @@ int jcm_allgather_coords(jcm_handle h, jcm_comm c, const int32_t* local, int B_l
   Rccl& r = rccl();
   jcm::DeviceGuard g(h->device);
   const size_t count = (size_t)B_local * 2 * h->K;
-  if (int e = r.all_gather(local, all_out, count, kNcclInt32, c->comm, h->stream)) return nccl_fail("ncclAllGather", e);
+  {
+    jcm::CallOrder order(h);      // the enqueue joins the device's call chain; the lock is released before the host waits for the peers
+    if (int e = r.all_gather(local, all_out, count, kNcclInt32, c->comm, h->stream)) return nccl_fail("ncclAllGather", e);
+  }
   HIP_TRY(hipStreamSynchronize(h->stream));       // the one call of the path that synchronises: the caller reads the result next
   return JCM_OK;
 }

@@ -140,7 +140,8 @@ struct LayerFwd {
   float* xs_tmax = nullptr;    // ... and the device word of their fp16 scaling (np = 4)
 };
 
-int conv_train_fwd(jcm_ctx* c, LayerFwd& f, int stride, const void* x, int B, int Hin, int Win, int sub) {
+// the convolution half: r = relu(conv + b) (or conv + b), the input spectra kept for the weight gradient where the layer runs in the frequency domain
+int conv_train_fwd_conv(jcm_ctx* c, LayerFwd& f, int stride, const void* x, int B, int Hin, int Win, int sub) {
   TrainState* t = c->train;
   f.L = conv_of(c, f.scope);
   if (!f.L) return fail(JCM_ERR_STATE, "no conv layer '" + f.scope + "'");
@@ -160,6 +161,13 @@ int conv_train_fwd(jcm_ctx* c, LayerFwd& f, int stride, const void* x, int B, in
   }
   JCM_TRY(run_conv_layer(c, &L, f.scope, stride, x, B, Hin, Win, sub, f.r, bf(c), !f.L->has_bn));
   if (f.xs && !c->dry) f.xs_tmax = c->fft_last_tmax;
+  return JCM_OK;
+}
+
+int conv_train_fwd(jcm_ctx* c, LayerFwd& f, int stride, const void* x, int B, int Hin, int Win, int sub) {
+  TrainState* t = c->train;
+  JCM_TRY(conv_train_fwd_conv(c, f, stride, x, B, Hin, Win, sub));
+  const size_t N = (size_t)B * f.H * f.W;
   if (!f.L->has_bn) { f.y = f.r; return JCM_OK; }
   f.y = act(c, N * f.L->cout);
   if (c->dry) return JCM_OK;
@@ -740,6 +748,44 @@ int jcm_train_loss_grads(jcm_handle h, const float* x, const float* y, int B, in
   jcm_ctx* c = h;
   HIP_TRY(hipMemsetAsync(grads, 0, c->train->total * sizeof(float), c->stream));   // tensors the loss does not reach keep a zero gradient
   return with_arena(c, [&] { return loss_grads_impl(c, x, y, B, H, W, use_sm, lmbd, grads, losses); });
+}
+
+// The two gradient kernels of ONE stride-1 layer on caller-supplied tensors -- the route the training step takes on this handle (frequency
+// domain, direct fp32 MFMA chain, split operands), isolated from the rest of the step so that tests can hold the kernels themselves to a tight
+// bound (inside a full step a ReLU / max-pool decision that rounds the other way upstream moves a gradient by far more than kernel error).
+int jcm_train_layer_grads(jcm_handle h, const char* scope, const float* x, const float* dz, int B, int H, int W, float lmbd, float* grads, float* dx_out) {
+  JCM_TRY(need_train(h));
+  if (!scope || !x || !dz || !grads || B < 1 || H < 1 || W < 1) return fail(JCM_ERR_ARG, "bad train_layer_grads arguments");
+  if (h->precision != JCM_PRECISION_F32) return fail(JCM_ERR_ARG, "train_layer_grads: fp32 handles only (bf16 handles keep bf16 tensors between the layers)");
+  DeviceGuard g(h->device);
+  CallOrder order(h);
+  jcm_ctx* c = h;
+  TrainState* t = c->train;
+  const ConvLayer* L = conv_of(c, scope);
+  if (!L || L->cin == 3 || !grad_of(t, grads, std::string(scope) + "/weights")) return fail(JCM_ERR_ARG, std::string("train_layer_grads: '") + scope + "' is not a stride-1 conv layer");
+  t->gscale_of = nullptr;
+  return with_arena(c, [&] {
+    LayerFwd f;
+    f.scope = scope;
+    JCM_TRY(conv_train_fwd_conv(c, f, 1, x, B, H, W, 1));      // (the frequency-domain weight gradient reads the input spectra the forward pass keeps)
+    const size_t NPX = (size_t)B * H * W;
+    const void* dl = dz;
+    int ldl = L->cout, ldl_fft = 0;
+    if (L->cout % 16) {      // the logits layer: its gradient travels with a 16-channel stride, widened to 64 for the frequency-domain route (loss_grads_impl)
+      constexpr int LDZ = 16, LDZF = 64;
+      float* d16 = arena_alloc<float>(c, NPX * LDZ);
+      if (!c->dry) HIP_TRY(pad_channels_f32(dz, L->cout, d16, LDZ, NPX, c->stream));
+      dl = d16; ldl = LDZ;
+      if (f.xs) {
+        float* d64 = arena_alloc<float>(c, NPX * LDZF);
+        if (!c->dry) HIP_TRY(pad_channels_f32(d16, LDZ, d64, LDZF, NPX, c->stream));
+        dl = d64; ldl = LDZF; ldl_fft = LDZF;
+      }
+    }
+    JCM_TRY(conv_wgrad(c, f, dl, ldl, B, lmbd, grads));
+    if (dx_out) JCM_TRY(conv_dgrad(c, f, dl, B, dx_out, ldl_fft));
+    return (int)JCM_OK;
+  });
 }
 
 int jcm_train_apply(jcm_handle h, const float* grads, int optimizer, float lr, float clip_norm, float* grad_norm_out) {

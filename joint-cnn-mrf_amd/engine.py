@@ -19,7 +19,7 @@ def _hm_size(n):
 class Engine:
     """Owns a jcm_handle.  All tensor arguments are torch CUDA float32 NHWC, contiguous."""
 
-    def __init__(self, device=0, precision='fp32', n_joints=9, stream=None, f32_conv=None, split_min_wgs=None, micro_batch=None, conv9_fft=None, fft_fp16=None):
+    def __init__(self, device=0, precision='fp32', n_joints=9, stream=None, f32_conv=None, split_min_wgs=None, micro_batch=None, conv9_fft=None, fft_fp16=None, call_order=None):
         if not torch.cuda.is_available():
             raise RuntimeError('joint-cnn-mrf_amd needs an MI355X (gfx950) GPU; torch.cuda.is_available() is False '
                                'and there is no CPU path')
@@ -44,6 +44,8 @@ class Engine:
             self.set_conv9_fft(conv9_fft)
         if fft_fp16 is not None:      # False: fp32 engines run the channel GEMM on three bf16 parts (six products) instead of two scaled fp16 parts (three)
             self.set_fft_fp16(fft_fp16)
+        if call_order is not None:    # False (debugging): this engine's calls are not ordered against other engines' on the device
+            self.set_option('call_order', int(bool(call_order)))
         if split_min_wgs is not None: # 0 forces the split kernels even on grids too small to pay off (parity tests at small batch)
             _lib.check(self._lib.jcm_set_option(self._h, b'split_min_wgs', int(split_min_wgs)), 'jcm_set_option(split_min_wgs)')
 
@@ -269,6 +271,10 @@ class Engine:
             m *= int(d)
         _lib.check(self._lib.jcm_group_mean(self._h, self._p(x.contiguous()), n, group, m, self._p(out)), 'jcm_group_mean')
         return out
+
+    def set_option(self, key, value):
+        """jcm_set_option(key, value) -- include/jcm.h lists the keys."""
+        _lib.check(self._lib.jcm_set_option(self._h, key.encode(), int(value)), 'jcm_set_option(%s)' % key)
 
     def set_sm_algo(self, algo):
         """Pairwise-convolution algorithm of the spatial model: 'fft' (rocFFT 2-D), 'fft_split'

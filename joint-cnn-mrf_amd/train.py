@@ -86,6 +86,19 @@ class Trainer:
         _lib.check(status, 'jcm_train_loss_grads')
         return self.losses, self.grads
 
+    def layer_grads(self, scope, x, dz, want_dx=True):
+        """The weight gradient (+ lmbd * w) and the data gradient of ONE stride-1 conv layer on given tensors, through the kernels the training
+        step uses on this engine: x [B,H,W,Cin], dz [B,H,W,Cout] -> (dw flat numpy [k*k*Cin*Cout] in HWIO order, dx [B,H,W,Cin] device or None)."""
+        e = self.eng
+        e._chk(x, 4, 'x')
+        e._chk(dz, 4, 'dz')
+        B, H, W, _ = x.shape
+        dx = torch.empty_like(x) if want_dx else None
+        _lib.check(self._lib.jcm_train_layer_grads(e._h, scope.encode(), e._p(x), e._p(dz), B, H, W, self.lmbd, e._p(self.grads), e._p(dx)),
+                   'jcm_train_layer_grads(%s)' % scope)
+        off, cnt = next((o, c) for n, o, c in self.layout if n == scope + '/weights')
+        return self.grads[off:off + cnt].cpu().numpy(), dx
+
     def grads_dict(self):
         """The flat gradient buffer as {TF variable name: numpy array} (reference shapes unknown here: flat)."""
         g = self.grads.cpu().numpy()

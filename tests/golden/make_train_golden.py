@@ -21,16 +21,21 @@ from joint_cnn_mrf_amd import synth  # noqa: E402
 from oracle import train_oracle as T  # noqa: E402
 
 SEED_X, SEED_Y, B, LMBD = 77, 78, 1, 0.001
+B_TOWER = 16      # BASELINE configs[4]: batch 128 over 8 GPUs = 16 images per tower (main.py:538-541,557-560)
 
 
-def case():
+def case(batch=B):
     p = synth.make_pd_params(debug=False, bn='trained')
     p.update(synth.make_sm_params(synth.synthetic_priors(), kind='trained'))
-    return p, synth.make_images(B, seed=SEED_X), synth.make_targets(B, seed=SEED_Y)
+    return p, synth.make_images(batch, seed=SEED_X), synth.make_targets(batch, seed=SEED_Y)
 
 
-def main():
-    p, x, y = case()
+def main(batch=B):
+    """batch = 1 -> train_full.json / train_full_samples.npz; batch = 16 (python make_train_golden.py 16; about two hours on 8 cores:
+    training-mode BatchNorm couples the images of a tower, so the 16-image golden cannot be assembled from smaller runs) ->
+    train_full_b16.json / train_full_b16_samples.npz."""
+    tag = '' if batch == B else '_b%d' % batch
+    p, x, y = case(batch)
     r64 = T.loss_and_grads(x, y, p, use_sm=True, lmbd=LMBD)
     r32 = T.loss_and_grads(x, y, p, use_sm=True, lmbd=LMBD, dtype=torch.float32)
     rs = np.random.RandomState(5)
@@ -49,13 +54,13 @@ def main():
         idx = np.arange(g.size) if g.size <= 512 else np.sort(rs2.choice(g.size, 512, replace=False))
         dense[k + '|idx'] = idx.astype(np.int64)
         dense[k + '|val'] = g[idx].astype(np.float32)
-    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'train_full_samples.npz'), **dense)
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'train_full%s_samples.npz' % tag), **dense)
     mv = T.update_moving(p, r64['bn_stats'])
     out['moving'] = {k: {'idx': [0, int(v.size) - 1], 'val': [float(v.reshape(-1)[0]), float(v.reshape(-1)[-1])]} for k, v in mv.items()}
-    with open(os.path.join(ROOT, 'tests', 'golden', 'train_full.json'), 'w') as fh:
+    with open(os.path.join(ROOT, 'tests', 'golden', 'train_full%s.json' % tag), 'w') as fh:
         json.dump(out, fh)
-    print('wrote train_full.json: loss', out['losses'])
+    print('wrote train_full%s.json: loss' % tag, out['losses'])
 
 
 if __name__ == '__main__':
-    main()
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else B)

@@ -31,3 +31,36 @@ def full_inputs():
     g = seeds()
     p = synth.make_pd_params(debug=False, seed=g['weights'], bn='trained', conv6_gain=g['conv6_gain'])
     return synth.make_images(2, seed=g['images']), synth.make_torso(2, seed=g['torso']), p
+
+
+def sampled_conv_grads(x, dz, w, lmbd, rs, n=40):
+    """float64 values of the two gradients of z = conv2d_SAME(x, w) (stride 1, HWIO) at sampled entries, straight from the definition:
+    dW[a,b,ci,co] = sum_{n,y,x} x[n,y+a-p,x+b-p,ci] dz[n,y,x,co] + lmbd w[a,b,ci,co];  dX[n,y,x,ci] = sum_{a,b,co} dz[n,y-a+p,x-b+p,co] w[a,b,ci,co]
+    (pinned against autograd on the float64 restatement: tests/test_oracle_kat.py::test_sampled_conv_grads_match_autograd).  Returns (flat HWIO indices, values), (NHWC indices, values)."""
+    k, _, cin, cout = w.shape
+    p = (k - 1) // 2
+    B, H, W, _ = x.shape
+    x64, z64, w64 = x.astype(np.float64), dz.astype(np.float64), w.astype(np.float64)
+    taps = [(0, 0), (0, k - 1), (k - 1, 0), (k - 1, k - 1), (p, p)] + [(int(rs.randint(k)), int(rs.randint(k))) for _ in range(n - 5)]
+    wi, wv = [], []
+    for a, b in taps:
+        ci, co = int(rs.randint(cin)), int(rs.randint(cout))
+        ys, ye = max(0, p - a), min(H, H + p - a)          # output rows whose input row y + a - p is inside the image
+        xs, xe = max(0, p - b), min(W, W + p - b)
+        v = np.sum(x64[:, ys + a - p:ye + a - p, xs + b - p:xe + b - p, ci] * z64[:, ys:ye, xs:xe, co]) + lmbd * w64[a, b, ci, co]
+        wi.append(((a * k + b) * cin + ci) * cout + co)
+        wv.append(v)
+    xi, xv = [], []
+    pts = [(0, 0), (0, W - 1), (H - 1, 0), (H - 1, W - 1)] + [(int(rs.randint(H)), int(rs.randint(W))) for _ in range(n - 4)]
+    for y0, x0 in pts:
+        nb, ci = int(rs.randint(B)), int(rs.randint(cin))
+        v = 0.0
+        for a in range(k):
+            y = y0 - a + p
+            if not 0 <= y < H:
+                continue
+            bs = [b for b in range(k) if 0 <= x0 - b + p < W]
+            v += np.sum(z64[nb, y, [x0 - b + p for b in bs], :] * w64[a, bs, ci, :])
+        xi.append((nb, y0, x0, ci))
+        xv.append(v)
+    return (np.array(wi), np.array(wv)), (xi, np.array(xv))

@@ -101,6 +101,63 @@ def test_config1_batch64_fp32_properties():
     eng.close()
 
 
+def test_config3_global_batch_2048_bf16_micro_batched():
+    """configs[3] at its single-GPU size: 2048 images in ONE jcm_forward, walked in 8 micro-batches of 256 (what `bench.py --global-batch 2048`
+    times on one rank, main.py:511-517).  2048 x 11 frequency-domain layers would lap a fixed ring of fp16 scale words on an fp32 handle; on
+    this bf16 handle the call exercises the arena reuse across micro-batches and the output offsets.  Properties: every map a distribution,
+    coordinates = first-occurrence arg-max of the returned maps, the golden pair (images 0, 1) bit-identical to a batch of 2, image 1500 (row
+    220 of micro-batch 5) alone = in the batch, the last image (the end of the last micro-batch) alone = in the batch."""
+    from joint_cnn_mrf_amd.engine import Engine
+    x2, torso2, p = _full_params()
+    B = 2048
+    g = torch.Generator(device='cuda:0')
+    g.manual_seed(2048)
+    x = torch.rand((B, 480, 720, 3), device='cuda:0', generator=g)        # 8.5 GB: generated on the device (U[0,1) like data.py:129-130)
+    x[:2] = dev(x2)
+    torso = dev(np.concatenate([torso2, synth.make_torso(B - 2, seed=2049)], axis=0))
+    eng = Engine(device=0, precision='bf16').load_params(p)
+    assert eng.conv_kernel_name('conv5', 256, 60, 90) == 'conv_fft(cgemm_split_kernel)'
+    r = eng.forward(x, torso, use_sm=True)
+    pd, sm, pd_c, sm_c = r['pd_prob'], r['sm_prob'], r['pd_coords'], r['sm_coords']
+    assert tuple(pd.shape) == tuple(sm.shape) == (B, 60, 90, 9) and tuple(sm_c.shape) == (B, 2, 9)
+    for t in (pd, sm):
+        s = t.sum(dim=(1, 2))
+        assert bool(torch.isfinite(t).all()) and float(t.min()) >= 0 and float((s - 1).abs().max()) <= 2e-5
+    for t, cc in ((pd, pd_c), (sm, sm_c)):                       # first-occurrence arg-max of the returned maps (evaluation.py:15-24), sampled
+        for i in (0, 255, 256, 1023, 1500, 2047):
+            np.testing.assert_array_equal(cc[i:i + 1].cpu().numpy(), O.argmax_coords(t[i:i + 1].cpu().numpy()))
+    for sl in (slice(0, 2), slice(1500, 1501), slice(2047, 2048)):
+        one = eng.forward(x[sl].contiguous(), torso[sl].contiguous(), use_sm=True)
+        assert torch.equal(one['pd_prob'], pd[sl]), sl
+        assert float((one['sm_prob'] - sm[sl]).abs().max()) <= 1e-6
+        assert torch.equal(one['pd_coords'], pd_c[sl]) and torch.equal(one['sm_coords'], sm_c[sl]), sl
+    assert (np.abs(pd_c[:2].cpu().numpy() - load('full_pd_coords')).max(axis=1) <= 1).mean() >= 0.85
+    eng.close()
+
+
+def test_fp32_forward_beyond_one_block_of_scale_words():
+    """An fp32 handle takes one fp16 scale word per image and frequency-domain layer (csrc/ctx.h: kFftWords = 2^18 per block).  A single
+    jcm_pd_forward of more images than one block serves must get further blocks instead of failing mid-call (round 3 returned JCM_ERR_STATE
+    above ~5900 images) -- checked at --debug width on 32x48 images so that it runs in seconds: the five frequency-domain layers of that network (conv4_*, conv5 and
+    its hand-over to conv6) take 5 words per image, 56000 images 280000 > 2^18 -- every
+    image's logits equal to the same image's in a batch of 3, and the next call starts over at the first block."""
+    from joint_cnn_mrf_amd.engine import Engine
+    p = synth.make_pd_params(debug=True, bn='trained', conv6_gain=8.0)
+    eng = Engine(device=0).load_params(p)
+    B = 56000
+    g = torch.Generator(device='cuda:0')
+    g.manual_seed(7)
+    x = torch.rand((B, 32, 48, 3), device='cuda:0', generator=g)
+    assert eng.conv_kernel_name('conv5', B, 4, 6).startswith('conv_fft')
+    big = eng.model(x)
+    for i in (0, 12345, 52500, B - 1):
+        small = eng.model(x[i:i + 1].contiguous())
+        assert torch.equal(small[0], big[i]), i
+    again = eng.model(x)
+    assert torch.equal(again, big)
+    eng.close()
+
+
 @pytest.mark.parametrize('precision,debug,B,mb', [('fp32', True, 5, 2), ('bf16', False, 5, 2), ('fp32', False, 3, 2)])
 def test_micro_batched_forward_equals_one_piece(precision, debug, B, mb):
     """jcm_forward walks a large batch in micro-batches (option "micro_batch": a rank's 2048 / N share of

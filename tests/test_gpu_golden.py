@@ -311,3 +311,95 @@ def test_two_engines_two_streams_soak(precision):
             got = [o.cpu().numpy() for o in outs[e][i]]
             for g, f in zip(got, first):
                 assert np.array_equal(g, f), 'engine %d, forward %d differs from the first result' % (e, i)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_two_engines_two_threads_soak(precision):
+    """Two HOST THREADS, each driving its own engine on its own stream of one device, 60 full-size forwards each with nothing synchronised in
+    between.  The entry points hold the per-device lock of the call chain while they enqueue (csrc/ctx.h: CallOrder), so the launches of the two
+    threads never interleave and every result must be bit-identical to the engine's first one (and, fp32, the golden one)."""
+    import threading
+    from joint_cnn_mrf_amd.engine import Engine
+    x, torso, p = full_inputs()
+    p.update(synth.make_sm_params(flic_priors(), kind='trained', seed=seeds()['sm']))
+    streams = [torch.cuda.Stream(device='cuda:0') for _ in range(2)]
+    engs = [Engine(device=0, precision=precision, stream=s).load_params(p) for s in streams]
+    xd, td = dev(x), dev(torso)
+    torch.cuda.synchronize()
+    n_iter = 60
+    outs, errs = [[], []], []
+
+    def drive(e):
+        try:
+            with torch.cuda.stream(streams[e]):
+                for _ in range(n_iter):
+                    r = engs[e].forward(xd, td, use_sm=True)
+                    outs[e].append((r['sm_prob'], r['sm_coords'], r['pd_coords']))
+        except Exception as ex:      # pragma: no cover
+            errs.append(ex)
+
+    ts = [threading.Thread(target=drive, args=(e,)) for e in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize()
+    for eng in engs:
+        eng.close()
+    assert not errs, errs
+    if precision == 'fp32':
+        np.testing.assert_allclose(outs[0][0][0].cpu().numpy(), O.spatial_softmax(load('full_sm_logits_trained').astype(np.float64)), atol=1e-4, rtol=0)
+        np.testing.assert_array_equal(outs[0][0][1].cpu().numpy(), load('full_sm_coords_trained'))
+    for e in range(2):
+        assert len(outs[e]) == n_iter
+        for i in range(n_iter):
+            for g, f in zip(outs[e][i], outs[0][0]):
+                assert torch.equal(g, f), 'thread %d, forward %d differs from the first result' % (e, i)
+
+
+def _soak_process(rank, barrier, q, precision, n_iter):
+    import joint_cnn_mrf_amd  # noqa: F401
+    from joint_cnn_mrf_amd.engine import Engine
+    x, torso, p = full_inputs()
+    p.update(synth.make_sm_params(flic_priors(), kind='trained', seed=seeds()['sm']))
+    eng = Engine(device=0, precision=precision).load_params(p)
+    xd, td = torch.as_tensor(x, device='cuda:0'), torch.as_tensor(torso, device='cuda:0')
+    first = eng.forward(xd, td, use_sm=True)
+    torch.cuda.synchronize()
+    barrier.wait(timeout=600)      # both processes hold a warm engine: from here on their kernels share the GPU
+    bad = 0
+    for i in range(n_iter):
+        r = eng.forward(xd, td, use_sm=True)
+        bad += int(not (torch.equal(r['sm_prob'], first['sm_prob']) and torch.equal(r['pd_prob'], first['pd_prob']) and torch.equal(r['sm_coords'], first['sm_coords'])))
+    torch.cuda.synchronize()
+    q.put((rank, bad, first['sm_prob'].cpu().numpy(), first['sm_coords'].cpu().numpy()))
+    eng.close()
+
+
+@pytest.mark.xfail(strict=False, reason='round 4 (DESIGN.md 4.1e): kernels of two handles that are co-resident on a CU are not yet isolated from each other -- the LDS-DMA '
+                   'ring of the channel GEMM was found to overwrite 128-byte pieces of another work group\'s LDS (tools/coresidency_probe.hip reproduces it against a '
+                   'plain kernel; fixed for every single layer), and the whole tower still shows a residual (fp32: a third of the forwards). Inside one process '
+                   'the per-device call chain keeps handles apart; across processes nothing does.')
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_two_processes_one_gpu_soak(precision):
+    """Two PROCESSES share the GPU (two ranks on one device, or a second job): no event chain reaches across them, so this is the test of the
+    kernels themselves -- no read outside a buffer, no LDS word used before it is written.  80 full-size forwards per process while the other
+    process runs the same loop; every result bit-identical to the process's first one, both processes bit-identical to each other.
+    EXPECTED TO FAIL for now (see the marker): kept so that the day the residual is found the test flips to XPASS."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q, barrier = ctx.Queue(), ctx.Barrier(2)
+    n_iter = 80
+    procs = [ctx.Process(target=_soak_process, args=(r, barrier, q, precision, n_iter)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = dict((r[0], r[1:]) for r in (q.get(timeout=900) for _ in range(2)))
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    assert res[0][0] == 0 and res[1][0] == 0, 'forwards that differ from the first result: process 0 %d, process 1 %d of %d' % (res[0][0], res[1][0], n_iter)
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    if precision == 'fp32':
+        np.testing.assert_allclose(res[0][1], O.spatial_softmax(load('full_sm_logits_trained').astype(np.float64)), atol=1e-4, rtol=0)
+        np.testing.assert_array_equal(res[0][2], load('full_sm_coords_trained'))

@@ -6,6 +6,7 @@ import pytest
 import torch
 
 import joint_cnn_mrf_amd  # noqa: F401
+from golden_util import sampled_conv_grads
 from joint_cnn_mrf_amd import synth
 from oracle import train_oracle as T
 
@@ -370,3 +371,86 @@ def test_optimizer_state_round_trip_resumes_training(debug_case):
     eng.close()
     for k in want:
         np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+
+
+# ---- the gradient KERNELS alone, at full-size layer shapes and the per-GPU batch of configs[4] (16 images)
+LAYER_SHAPES = [('conv5', 60, 90), ('conv4_fullres', 60, 90), ('conv6', 60, 90), ('conv3_fullres', 60, 90), ('conv2_fullres', 120, 180),
+                ('conv4_halfres', 30, 45), ('conv2_halfres', 60, 90), ('conv4_quarterres', 15, 23), ('conv3_quarterres', 15, 23)]
+
+
+@pytest.mark.parametrize('mode', ['exact', 'exact_bf16x3', 'chain', 'split16'])
+def test_gradient_kernels_at_full_size_layer_shapes(mode):
+    """jcm_train_layer_grads: the weight-gradient and data-gradient kernels of every stride-1 layer shape of the full-width network on the SAME
+    x and dz, 16 images (a tower's share of configs[4]: the batch is the K axis of the frequency-domain weight gradient's per-frequency product,
+    and a training handle scales all 16 images of a tensor by one power of two) -- compared at sampled entries with float64 sums taken straight
+    from the definition.  No ReLU or pooling is involved, so there is no rounding-decision noise: every route is held to GRAD_RTOL = 1e-4 of the
+    tensor's largest entry and must come within 3x of the fp32 MFMA chain's own error (+2e-6).  'exact' = the default fp32 engine (frequency
+    domain: wgrad_fft.hip and the data gradient through conv_fft on flipped filters, two scaled fp16 parts), 'exact_bf16x3' = the same on three
+    bf16 parts, 'chain' = wgrad.hip / conv_igemm on the fp32 MFMA accumulation chain, 'split16' = the direct kernels on fp16 parts."""
+    p = synth.make_pd_params(debug=False, bn='trained')
+    p.update(synth.make_sm_params(synth.synthetic_priors(), kind='init'))
+    lmbd = 0.001
+    kw = dict(f32_conv='exact' if mode in ('exact', 'exact_bf16x3', 'chain') else mode, conv9_fft=False if mode == 'chain' else None,
+              fft_fp16=False if mode == 'exact_bf16x3' else None)
+    eng, tr = make_trainer(p, use_sm=True, lmbd=lmbd, **kw)
+    B = 16
+    g = torch.Generator(device='cuda:0')
+    rows = []
+    for li, (scope, H, W) in enumerate(LAYER_SHAPES):
+        w = np.asarray(p[scope + '/weights'])
+        k, _, cin, cout = w.shape
+        assert eng.conv_kernel_name(scope, B, H, W).startswith('conv_fft') == (mode in ('exact', 'exact_bf16x3')), scope
+        g.manual_seed(100 + li)
+        x = torch.relu(torch.randn((B, H, W, cin), device='cuda:0', generator=g))
+        # dz as BatchNorm's backward leaves it: zero mean per channel (the weight gradient is then a sum with heavy cancellation), scale ~1e-3
+        dz = torch.randn((B, H, W, cout), device='cuda:0', generator=g) * 1e-3
+        dz = (dz - dz.mean(dim=(0, 1, 2), keepdim=True)).contiguous()
+        dw, dx = tr.layer_grads(scope, x, dz)
+        dx = dx.cpu().numpy()
+        (wi, wv), (xi, xv) = sampled_conv_grads(x.cpu().numpy(), dz.cpu().numpy(), w, lmbd, np.random.RandomState(li))
+        ew = np.abs(dw[wi].astype(np.float64) - wv).max() / np.abs(dw).max()
+        ex = np.abs(np.array([dx[i] for i in xi], np.float64) - xv).max() / np.abs(dx).max()
+        rows.append((scope, ew, ex))
+        print('  %-7s %-18s dW err / max|dW| %.2e   dX err / max|dX| %.2e' % (mode, scope, ew, ex))
+    eng.close()
+    bad = [r for r in rows if not (r[1] <= GRAD_RTOL and r[2] <= GRAD_RTOL)]
+    assert not bad, bad
+    # the frequency-domain kernels are no worse than the sequential fp32 chain (measured: chain dW <= 4e-6, dX <= 2e-6)
+    if mode != 'chain':
+        assert max(r[1] for r in rows) <= 2e-5 and max(r[2] for r in rows) <= 2e-5, rows
+
+
+def test_full_size_step_16_images_vs_golden():
+    """configs[4] at its real per-GPU workload (main.py:538-541,557-560: batch 128 over 8 towers): the full-width network, 16 images, training
+    handle, default route -- losses, moving statistics, gradient norms and sampled gradient entries against tests/golden/train_full_b16.json
+    (float64 restatement of the 16-image tower; training-mode BatchNorm couples the images, so this golden is its own two-hour CPU run).
+    End-to-end bound: 16 x 5400 samples per channel average the rounding-decision flips of a single image down, so the frequency-domain route is
+    held to 2e-3 of the tensor's largest entry (+ twice the float32 restatement's own distance from float64) and 'chain' to GRAD_RTOL."""
+    import json, os
+    from golden.make_train_golden import case, LMBD, B_TOWER
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'train_full_b16.json')
+    with open(path) as fh:
+        gold = json.load(fh)
+    p, x, y = case(B_TOWER)
+    for mode in ('exact', 'chain'):
+        eng, tr = make_trainer(p, conv9_fft=False if mode == 'chain' else None, use_sm=True, lmbd=LMBD)
+        losses, _ = tr.loss_and_grads(dev(x), dev(y))
+        got = tr.grads_dict()
+        l = losses.cpu().numpy()
+        moving = {k: tr.get_tensor(k, np.asarray(p[k]).shape).reshape(-1) for k in gold['moving']}
+        eng.close()
+        np.testing.assert_allclose(l, gold['losses'], rtol=2e-5)
+        bad, rows = [], []
+        for k, t in gold['tensors'].items():
+            g = got[k].astype(np.float64)
+            tol = (GRAD_RTOL if mode == 'chain' else 2e-3) * t['max'] + 2 * t['slack'] + 1e-7
+            err = np.abs(g[t['idx']] - np.asarray(t['val'])).max()
+            nerr = abs(np.linalg.norm(g) - t['norm'])
+            rows.append((err / max(t['max'], 1e-30), k, t['slack'] / max(t['max'], 1e-30)))
+            if not (err <= tol and nerr <= tol * np.sqrt(g.size)):
+                bad.append('%s %s: entry err %.3e norm err %.3e (tol %.3e, max|g| %.3e)' % (mode, k, err, nerr, tol, t['max']))
+        for r in sorted(rows, reverse=True)[:6]:
+            print('  %s rel %.2e  %-40s f32-slack %.2e' % ((mode,) + r))
+        assert not bad, '\n'.join(bad)
+        for k, t in gold['moving'].items():
+            np.testing.assert_allclose(moving[k][t['idx']], t['val'], rtol=2e-5, atol=1e-7, err_msg=k)

@@ -170,3 +170,24 @@ def test_emulated_bf16_layer_differs_from_fp32_by_bf16_not_more():
     b = O.conv_layer(x, p, 5, 1, 'c', last_layer=True, emulate='bf16')
     rel = np.abs(a - b).max() / np.abs(a).max()
     assert 1e-4 < rel < 2e-2
+
+
+@pytest.mark.parametrize('k', [5, 9])
+def test_sampled_conv_grads_match_autograd(k):
+    """tests/golden_util.sampled_conv_grads (the float64 sums the GPU test of the gradient kernels compares with) against autograd through the
+    restated tf.nn.conv2d SAME (oracle/jcm_oracle_torch.conv2d_same): every sampled weight-gradient and data-gradient entry, borders included."""
+    from golden_util import sampled_conv_grads
+    rs = np.random.RandomState(k)
+    B, H, W, cin, cout, lmbd = 2, 7, 10, 3, 4, 0.01
+    x = rs.standard_normal((B, H, W, cin)).astype(np.float32)
+    dz = rs.standard_normal((B, H, W, cout)).astype(np.float32)
+    w = rs.standard_normal((k, k, cin, cout)).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64).permute(0, 3, 1, 2).requires_grad_(True)
+    wt = torch.tensor(w, dtype=torch.float64).requires_grad_(True)
+    z = T.conv2d_same(xt, wt, 1)
+    loss = (z * torch.tensor(dz, dtype=torch.float64).permute(0, 3, 1, 2)).sum() + lmbd * (wt ** 2).sum() / 2
+    gx, gw = torch.autograd.grad(loss, [xt, wt])
+    gx, gw = gx.permute(0, 2, 3, 1).numpy(), gw.numpy().reshape(-1)
+    (wi, wv), (xi, xv) = sampled_conv_grads(x, dz, w, lmbd, np.random.RandomState(1), n=60)
+    np.testing.assert_allclose(wv, gw[wi], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(xv, [gx[i] for i in xi], rtol=1e-12, atol=1e-12)

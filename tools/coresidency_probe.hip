@@ -1,0 +1,185 @@
+// Is a plain, race-free kernel bit-reproducible while ANOTHER stream's kernels share the GPU?  (round 4)
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I joint-cnn-mrf_amd/csrc tools/coresidency_probe.hip -o tools/coresidency_probe
+//   tools/coresidency_probe [iters] [victim: 0 = generic adds, 1 = the library's 96-point row FFT] [aggressor: 0 none, 1 GEMM, 2 HBM copy, 3 both] [small: 0/1] [GEMM Cout (512; 9 = 64 x 32 tile)] [GEMM Cin]
+//
+// Stream 1 runs, per iteration:  [small kernel]  victim -> out1  [small kernel]  victim -> out2   and a compare kernel counts the 16-byte
+// pieces in which out1 and out2 differ.  The victim works on data it generates itself from a hash of (work group, position): no input
+// buffer, no atomics, every LDS hand-over behind __syncthreads().  Stream 2 runs the aggressor the whole time: the library's channel GEMM
+// (MFMA + LDS-DMA + HBM streaming) and / or a device copy.  A count above zero with victim 0 cannot be this library's code.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#ifndef CGEMM_SRC
+#define CGEMM_SRC "../joint-cnn-mrf_amd/csrc/cgemm_split.hip"
+#endif
+#include CGEMM_SRC
+#include "../joint-cnn-mrf_amd/csrc/conv_fft_common.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ inline float hashf(unsigned a, unsigned b) {
+  unsigned long long z = (unsigned long long)a * 0x9E3779B97F4A7C15ull + (unsigned long long)b * 0xD1B54A32D192ED03ull;
+  z ^= z >> 31; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 29;
+  return (float)((double)(z & 0xffffff) / 8388608.0 - 1.0);
+}
+
+// victim 0: 384 threads, 96 x 32 complex numbers in LDS; 6 rounds of { every thread takes 8 entries 12 rows apart, runs a fixed network of
+// packed adds / subs on them (the shape of a radix-8 butterfly, written with plain vector arithmetic), writes them back } with a barrier
+// between rounds; persistent over `tiles` tiles like the library's row passes.
+__global__ __launch_bounds__(384) void victim_generic(f2* out, int tiles) {
+  __shared__ f2 buf[96 * 32];
+  const int tid = threadIdx.x;
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    for (int t = tid; t < 96 * 32; t += 384) buf[t] = f2{hashf(tile, 2 * t), hashf(tile, 2 * t + 1)};
+    __syncthreads();
+    for (int r = 0; r < 6; ++r) {
+      const int k = tid / 32, v = tid % 32;      // 12 groups x 32 lanes
+      f2 x[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) x[m] = buf[((k + 12 * m + r) % 96) * 32 + v];
+      const f2 a0 = x[0] + x[4], a1 = x[0] - x[4], a2 = x[2] + x[6], a3 = x[2] - x[6];
+      const f2 b0 = x[1] + x[5], b1 = x[1] - x[5], b2 = x[3] + x[7], b3 = x[3] - x[7];
+      const f2 c0 = a0 + a2, c1 = a0 - a2, c2 = f2{a1.x - a3.y, a1.y + a3.x}, c3 = f2{a1.x + a3.y, a1.y - a3.x};
+      const f2 d0 = b0 + b2, d1 = b0 - b2, d2 = f2{b1.x - b3.y, b1.y + b3.x}, d3 = f2{b1.x + b3.y, b1.y - b3.x};
+      x[0] = (c0 + d0) * 0.35f; x[4] = (c0 - d0) * 0.35f; x[1] = (c2 + d2 * 0.70710678f) * 0.35f; x[5] = (c2 - d2 * 0.70710678f) * 0.35f;
+      x[2] = f2{c1.x - d1.y, c1.y + d1.x} * 0.35f; x[6] = f2{c1.x + d1.y, c1.y - d1.x} * 0.35f; x[3] = (c3 + d3 * 0.70710678f) * 0.35f; x[7] = (c3 - d3 * 0.70710678f) * 0.35f;
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < 8; ++m) buf[((k + 12 * m + r) % 96) * 32 + v] = x[m];
+      __syncthreads();
+    }
+    for (int t = tid; t < 96 * 32; t += 384) out[(size_t)tile * 96 * 32 + t] = buf[t];
+    __syncthreads();
+  }
+}
+
+// victim 1: the library's in-LDS 96-point FFT over 32 channel lanes (conv_fft_common.h), on hash data
+__global__ __launch_bounds__(384) void victim_fft(f2* out, const jcm::cfft::cf* twg, int tiles) {
+  using namespace jcm::cfft;
+  __shared__ cf buf[96 * 32];
+  __shared__ cf tw[96];
+  const int tid = threadIdx.x;
+  twiddles<96, 384>(tw, twg, tid);
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    for (int t = tid; t < 96 * 32; t += 384) buf[t] = cf{hashf(tile, 2 * t), hashf(tile, 2 * t + 1)};
+    __syncthreads();
+    fft<96, -1, 32, 384>(buf, tw, tid);
+    for (int t = tid; t < 96 * 32; t += 384) out[(size_t)tile * 96 * 32 + t] = buf[t];
+    __syncthreads();
+  }
+}
+
+// synthetic aggressors: nothing but LDS-DMA.  128 threads (2 waves), 36 KB of LDS, a short life -- the shape of the 64 x 32 GEMM tile's work
+// groups.  mode bit 0: `inr` in-range 1-KB pieces per wave right at the start; bit 1: `oob` pieces whose source offset is past the end of
+// the buffer descriptor ("return zero") after them; bit 2: pause (s_sleep) before the first request; bit 3: wait vmcnt(0), then pause
+// again before the end.  Every request is waited for (vmcnt(0)) before the wave ends, and every LDS address is inside the allocation.
+__global__ __launch_bounds__(128) void dma_aggressor(const uint4* src, unsigned src_bytes, int mode, int inr, int oob, float* sink) {
+  extern __shared__ __attribute__((aligned(16))) char alds[];
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(src), 0, src_bytes, 0x00020000);
+  if (mode & 4) __builtin_amdgcn_s_sleep(8);
+  const unsigned base = ((unsigned)blockIdx.x * 36864u) % (src_bytes - 65536u);
+  if (mode & 1)
+    for (int i = 0; i < inr; ++i) {
+      const unsigned q = (unsigned)(wid + 2 * i) * 1024u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(alds + q), 16, (unsigned)lane * 16u + base + q, 0, 0, 0);
+    }
+  if (mode & 2)
+    for (int i = 0; i < oob; ++i) {
+      const unsigned q = (unsigned)(wid + 2 * (i % 18)) * 1024u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(alds + q), 16, (unsigned)lane * 16u + src_bytes + 4096u + q, 0, 0, 0);
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (mode & 8) __builtin_amdgcn_s_sleep(8);
+  __builtin_amdgcn_s_barrier();
+  if (sink && reinterpret_cast<float*>(alds)[threadIdx.x] == 12345.f) sink[0] = 1.f;
+}
+
+__global__ void small_kernel(float* p) {
+  float v = p[blockIdx.x * 64 + (threadIdx.x & 63)];
+  for (int i = 0; i < 2000; ++i) v = v * 1.0001f + 0.5f;
+  if (v == 12345.f) p[0] = v;
+}
+
+__global__ void compare_kernel(const uint4* a, const uint4* b, size_t n, unsigned long long* cnt) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const uint4 x = a[i], y = b[i];
+    if (x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w) {
+      const unsigned long long k = atomicAdd(cnt, 1ull);
+      if (k < 8) cnt[1 + k] = i;
+    }
+  }
+}
+
+__global__ void copy_kernel(const uint4* a, uint4* b, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
+}
+
+int main(int argc, char** argv) {
+  const int iters = argc > 1 ? atoi(argv[1]) : 200, victim = argc > 2 ? atoi(argv[2]) : 0, aggr = argc > 3 ? atoi(argv[3]) : 1, small = argc > 4 ? atoi(argv[4]) : 1;
+  const int tiles = 960, grid = 768;
+  const size_t n = (size_t)tiles * 96 * 32;
+  f2 *o1, *o2;
+  unsigned long long* cnt;
+  float* sp;
+  CK(hipMalloc(&o1, n * 8)); CK(hipMalloc(&o2, n * 8)); CK(hipMalloc(&cnt, 16 * 8)); CK(hipMalloc(&sp, 1 << 20));
+  CK(hipMemset(sp, 0, 1 << 20));
+  // twiddles e^{+2 pi i k / 96}
+  std::vector<float> htw(192);
+  for (int k = 0; k < 96; ++k) { htw[2 * k] = (float)cos(2 * 3.14159265358979323846 * k / 96); htw[2 * k + 1] = (float)sin(2 * 3.14159265358979323846 * k / 96); }
+  jcm::cfft::cf* tw;
+  CK(hipMalloc(&tw, 192 * 4)); CK(hipMemcpy(tw, htw.data(), 192 * 4, hipMemcpyHostToDevice));
+  // aggressor operands: the conv4_fullres-sized channel GEMM of an fp32 handle (np = 4), 2 images
+  const int np = 4, F = 3136, B = 2;
+  int Cin = argc > 6 ? atoi(argv[6]) : 256, Cout = argc > 5 ? atoi(argv[5]) : 512;      // Cout = 9: the 64 x 32 tile of the logits layer
+  const int Cin_g = aggr >= 16 ? 256 : Cin, Cout_g = aggr >= 16 ? 512 : Cout;      // (the GEMM operands are allocated either way)
+  const int MT = jcm::cgemm_split_mtile(np, B, Cout_g), mtiles = (B + MT - 1) / MT;
+  const int ldy = (Cout_g + 127) / 128 * 128;
+  const size_t xbytes = (size_t)F * mtiles * MT * Cin_g * 8, wbytes = jcm::cgemm_split_w_bytes(np, F, Cin_g, Cout_g), ybytes = (size_t)F * B * ldy * 8;
+  void *xs, *ws, *y, *cpa, *cpb;
+  CK(hipMalloc(&xs, xbytes)); CK(hipMalloc(&ws, wbytes)); CK(hipMalloc(&y, ybytes));
+  CK(hipMemset(xs, 0x11, xbytes)); CK(hipMemset(ws, 0x22, wbytes));
+  const size_t cpn = (size_t)256 << 20;
+  CK(hipMalloc(&cpa, cpn)); CK(hipMalloc(&cpb, cpn)); CK(hipMemset(cpa, 1, cpn));
+  hipStream_t s1, s2;
+  CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+  auto run_victim = [&](f2* o) {
+    if (victim == 0) hipLaunchKernelGGL(victim_generic, dim3(grid), dim3(384), 0, s1, o, tiles);
+    else hipLaunchKernelGGL(victim_fft, dim3(grid), dim3(384), 0, s1, o, tw, tiles);
+  };
+  unsigned long long total = 0, bad_iters = 0, h[16];
+  for (int it = 0; it < iters; ++it) {
+    CK(hipMemsetAsync(cnt, 0, 16 * 8, s1));
+    for (int rep = 0; rep < 2; ++rep) {
+      if (small) { hipLaunchKernelGGL(small_kernel, dim3(98), dim3(512), 0, s1, sp); hipLaunchKernelGGL(small_kernel, dim3(120), dim3(384), 0, s1, sp); }
+      run_victim(rep ? o2 : o1);
+    }
+    hipLaunchKernelGGL(compare_kernel, dim3(1024), dim3(256), 0, s1, (const uint4*)o1, (const uint4*)o2, n / 2, cnt);
+    if (aggr >= 16) {      // synthetic LDS-DMA aggressor: aggr = 16 + mode, argv[5] = in-range pieces per wave, argv[6] = out-of-range pieces per wave
+      for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(dma_aggressor, dim3(3136), dim3(128), 36864, s2, (const uint4*)cpa, (unsigned)cpn, aggr - 16, Cout, Cin, sp);
+    } else
+    if (aggr & 1) for (int k = 0; k < (Cout <= 32 ? 4 : 1); ++k) CK(jcm::cgemm_split(xs, ws, y, np, F, B, Cin, Cout, ldy, s2));
+    if (aggr & 2) hipLaunchKernelGGL(copy_kernel, dim3(4096), dim3(256), 0, s2, (const uint4*)cpa, (uint4*)cpb, cpn / 16);
+    if (it % 8 == 7) CK(hipStreamSynchronize(s2));      // keep the two streams roughly in step
+    CK(hipMemcpyAsync(h, cnt, 16 * 8, hipMemcpyDeviceToHost, s1));
+    CK(hipStreamSynchronize(s1));
+    if (h[0]) {
+      ++bad_iters;
+      total += h[0];
+      if (bad_iters <= 5) {
+        printf("  iteration %d: %llu 16-byte pieces differ; first at element", it, h[0]);
+        for (unsigned long long k = 0; k < h[0] && k < 8; ++k) printf(" (tile %llu pos %llu lanes %llu..)", h[1 + k] * 2 / (96 * 32), h[1 + k] * 2 % (96 * 32) / 32, h[1 + k] * 2 % 32);
+        printf("\n");
+      }
+    }
+  }
+  CK(hipDeviceSynchronize());
+  printf("victim %s, aggressor %d, small kernels %d: %llu of %d iterations differ (%llu pieces)\n", victim ? "fft96" : "generic", aggr, small, bad_iters, iters, total);
+  return bad_iters ? 3 : 0;
+}
