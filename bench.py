@@ -69,6 +69,62 @@ def pmc_traffic(key):
         return None, None
 
 
+def step_traffic(key):
+    """HBM bytes of ONE step (every kernel) of a configuration, from the committed counter passes (profiles/pmc_traffic.json: step_bytes)."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
+            rec = json.load(fh).get(key, {})
+            return rec.get('step_bytes'), rec.get('step_source')
+    except OSError:
+        return None, None
+
+
+def smi_sample():
+    """Power / clock of GPU 0 from rocm-smi (best effort: None when the tool is missing or prints something unexpected)."""
+    import subprocess
+    try:
+        txt = subprocess.run(['rocm-smi', '-d', '0', '--showpower', '--showclocks', '--json'], capture_output=True, text=True, timeout=20).stdout
+        rec = json.loads(txt[txt.index('{'):])
+        card = rec[sorted(rec)[0]]
+        out = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if 'power' in kl and 'w' in kl:
+                out['power_w'] = float(str(v).split()[0])
+            elif kl.startswith('sclk clock'):
+                out['sclk_mhz'] = float(str(v).strip('()').lower().replace('mhz', ''))
+        return out or None
+    except Exception:
+        return None
+
+
+def sustained(args, dtype, B, params, local_rank, dev, use_sm, seconds=10.0):
+    """>= `seconds` of back-to-back steps (no host sync inside batches of 10 steps): shows whether the short timed region of the headline rides a
+    boost clock.  rocm-smi power / clock samples are taken while the loop runs (after a third and at the end)."""
+    eng = Engine(device=local_rank, precision=dtype).load_params(params)
+    x, torso = resident_inputs(B, 0, dev)
+    for _ in range(3):
+        eng.forward(x, torso if use_sm else None, use_sm=use_sm, want_prob=False)
+    torch.cuda.synchronize()
+    samples, n, t0 = [], 0, time.perf_counter()
+    while True:
+        for _ in range(10):
+            r = eng.forward(x, torso if use_sm else None, use_sm=use_sm, want_prob=False)
+        n += 10
+        el = time.perf_counter() - t0
+        if (len(samples) == 0 and el > seconds / 3) or (len(samples) == 1 and el > seconds * 0.9):
+            samples.append(smi_sample())          # (the GPU keeps working on the queued steps while rocm-smi runs)
+        if el >= seconds:
+            break
+        if n % 50 == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del r
+    eng.close()
+    return {'seconds': dt, 'steps': n, 'value': n * B / dt, 'unit': 'images/sec', 'ms_per_step': dt / n * 1e3, 'dtype': dtype, 'batch': B, 'smi': samples}
+
+
 def cpu_baseline(n_images, params):
     """The oracle's torch-CPU formulation (fp32) on the host cores: the stand-in for the
     reference's TF-CPU path, which cannot run here (no TensorFlow).  Bounded sample."""
@@ -182,7 +238,9 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
         out = {
             'value': value, 'ms_per_step': dt / args.steps * 1e3,
             # the arithmetic the path computes in: exact fp32 MFMA chain, or fp32 operands carried as 16-bit parts
-            'dtype': ('bf16+f32' if freq_domain else 'bf16') if dtype == 'bf16' else {'split': 'f32(bf16x6)', 'split16': 'f32(fp16x3)'}.get(f32_conv, 'f32'),
+            # 'f32' alone = the exact fp32 MFMA accumulation chain; the default fp32 route carries every fp32 spectrum as two scaled fp16 parts (22 bits)
+            'dtype': (('bf16(bf16x2 spectra, fft)' if freq_domain else 'bf16') if dtype == 'bf16' else
+                      {'split': 'f32(bf16x6)', 'split16': 'f32(fp16x3)'}.get(f32_conv, 'f32(fp16x2 spectra, fft)' if freq_domain else 'f32')),
             'config': {'workload': '%s: batch=%d/GPU synthetic 480x720x3, part detector%s forward + argmax, %s%s%s'
                                    % (config_name or ('configs[1]' if dtype == 'fp32' else 'configs[2]'), B, ' + spatial model' if use_sm else '',
                                       dtype + (' operands, stride-1 layers as bf16x6 split MFMA' if f32_conv == 'split' else
@@ -218,13 +276,24 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
         if freq_domain:
             # the GEMM against both ceilings; `bound` names the one it sits closer to
             gbs = gemm['bytes_per_launch'] / (launch_ms * 1e-3) / 1e9 if tot_n else None
+            useful = gemm['flops32_per_launch'] / (launch_ms * 1e-3) / 1e12 if tot_n else None      # complex-GEMM FLOPs without the split multiplier
             rf['mfma'] = {'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None,
-                          'fp32_equivalent_tflops': gemm['flops32_per_launch'] / (launch_ms * 1e-3) / 1e12 if tot_n else None}
+                          'fp32_equivalent_tflops': useful, 'useful_frac': (useful / peak) if useful else None,
+                          'note': 'achieved counts the %d real products per multiply of the split operands as executed FLOPs; useful_frac does not' % gemm['products']}
             rf['hbm'] = {'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': (gbs / PEAK_HBM_GBS) if gbs else None,
                          'algorithmic_bytes_per_launch': gemm['bytes_per_launch']}
             if gbs and achieved and gbs / PEAK_HBM_GBS > achieved / peak:
                 rf.update({'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS})
             rf['layer_ms'] = layer_ms  # the whole layer: four transform kernels + the GEMM
+            # the whole step against the HBM roof: bytes of every kernel of one step (2 x FETCH_SIZE + WRITE_SIZE summed over the committed counter pass of
+            # this configuration) / measured step time
+            sb, ssrc = step_traffic(tkey) if not args.debug else (None, None)
+            if sb:
+                imgs = min(B, mb)
+                gbs_step = sb * (B / imgs) / (dt / args.steps) / 1e9
+                rf['step'] = {'bytes_per_step': sb * (B / imgs), 'bytes_per_image': sb / imgs, 'achieved': gbs_step, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                              'frac': gbs_step / PEAK_HBM_GBS, 'traffic_source': ssrc,
+                              'note': 'SURVEY 8d prices the direct formulation at ~77 MB of activations per image; the five-pass frequency-domain route moves several times that'}
             out['path_tflops_note'] = 'images/s x direct-convolution FLOPs: the wide 9x9 layers execute 35x fewer in the frequency domain'
         if fp32_equiv is not None:
             out['roofline']['fp32_equivalent_tflops'] = fp32_equiv
@@ -350,7 +419,7 @@ def main():
                     help='default: the headline line is configs[1] (fp32, batch 64) and configs[2] (bf16, batch 256) '
                          'is measured too and reported under "bf16_config2"')
     ap.add_argument('--no-sm', action='store_true', help='part detector only')
-    ap.add_argument('--f32-conv', default=None, choices=['exact', 'split', 'split16'], help='fp32 convolution algorithm of the headline run (default exact)')
+    ap.add_argument('--f32-conv', default=None, choices=['exact', 'split', 'split16'], help='arithmetic of the DIRECT fp32 kernels of the headline run; anything but the default also leaves the frequency-domain route')
     ap.add_argument('--debug', action='store_true', help='filters/4 (main.py:40-41); not the headline config, fp32 only')
     ap.add_argument('--cpu-images', type=int, default=4, help='size of the cpu_baseline sample (0 = skip)')
     ap.add_argument('--train', action='store_true', help='time the joint training step (configs[4]) instead of the forward; fp32, '
@@ -421,7 +490,7 @@ def main():
         head_batch = args.batch or (64 if head_dtype == 'fp32' else 256)
         head = run_config(args, head_dtype, head_batch, params, world, rank, local_rank, dev, use_sm,
                           f32_conv=args.f32_conv if head_dtype == 'fp32' else None, micro_batch=args.micro_batch)
-    second = second_mfma = split = split16 = config3 = None
+    second = second_mfma = split = split16 = config3 = chain = sus = None
     if args.dtype is None and not args.debug and not args.global_batch:
         second = run_config(args, 'bf16', args.batch or 256, params, world, rank, local_rank, dev, use_sm)
         # configs[2] on the direct bf16 MFMA kernels only (conv_strip_bf16_kernel for the 9x9 layers): the north star's
@@ -439,6 +508,13 @@ def main():
     if args.dtype is None and not args.debug and not args.global_batch and world == 1:
         # the same fp32 configuration with the 60x90 9x9 layers on the direct split kernels (three-way operand split, fp32-class
         # error, same parity tests); reported beside the headline
+        # ... and on the exact fp32 MFMA accumulation chain (conv9_fft = 0: no reduced-precision operand anywhere); few steps, it is 18x slower
+        saved = args.steps, args.warmup
+        args.steps, args.warmup = min(args.steps, 5), min(args.warmup, 1)
+        chain = run_config(args, 'fp32', head_batch, params, world, rank, local_rank, dev, use_sm, conv9_fft=False,
+                           config_name='configs[1], exact fp32 MFMA chain (conv9_fft=0)')
+        args.steps, args.warmup = saved
+        sus = sustained(args, head_dtype, head_batch, params, local_rank, dev, use_sm)
         split = run_config(args, 'fp32', head_batch, params, world, rank, local_rank, dev, use_sm, f32_conv='split')
         split16 = run_config(args, 'fp32', head_batch, params, world, rank, local_rank, dev, use_sm, f32_conv='split16')
 
@@ -463,6 +539,11 @@ def main():
             out['bf16_config2_mfma'] = second_mfma
         if config3 is not None:
             out['config3_gb2048'] = config3
+        if chain is not None:
+            out['f32_chain_config1'] = chain
+        if sus is not None:
+            sus['vs_value'] = sus['value'] / head['value']
+            out['sustained'] = sus
         if split is not None:
             out['f32_split_config1'] = split
         if split16 is not None:
