@@ -177,9 +177,12 @@ def test_det_rate_matches_restatement():
 def test_full_size_step_vs_golden(f32_conv):
     """The full-size network (filters 64..512), one 480x720 image: losses, sampled gradient entries, gradient
     norms and the moving-statistics update against tests/golden/train_full.json (float64 restatement,
-    generated by tests/golden/make_train_golden.py).  'exact' = the default fp32 engine: forward and data gradient of the stride-1
-    layers in the frequency domain (conv_fft.hip), weight gradient on the fp32 MFMA chain; 'chain' = everything on the fp32 MFMA chain
-    (conv9_fft off), whose rounding the golden's float32 slack was measured with and which is therefore held to the strict bound."""
+    generated by tests/golden/make_train_golden.py).  'exact' = the default fp32 engine: forward, data gradient AND weight gradient of the
+    stride-1 layers in the frequency domain (conv_fft.hip, wgrad_fft.hip; two scaled fp16 parts per operand); 'exact_bf16x3' = the same on three
+    bf16 parts; 'chain' = everything on the fp32 MFMA chain (conv9_fft off), whose rounding the golden's float32 slack was measured with and
+    which is therefore held to the strict bound.  The other routes get 1e-2 HERE ONLY, for the end-to-end comparison of ONE image, where a
+    single ReLU / max-pool decision that rounds the other way moves a gradient of the 15x23 maps; the gradient KERNELS themselves are held to
+    1e-6 in test_gradient_kernels_at_full_size_layer_shapes and the 16-image step to the strict bound in test_full_size_step_16_images_vs_golden."""
     import json, os
     from golden.make_train_golden import case, LMBD
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'train_full.json')) as fh:
@@ -383,8 +386,8 @@ def test_gradient_kernels_at_full_size_layer_shapes(mode):
     """jcm_train_layer_grads: the weight-gradient and data-gradient kernels of every stride-1 layer shape of the full-width network on the SAME
     x and dz, 16 images (a tower's share of configs[4]: the batch is the K axis of the frequency-domain weight gradient's per-frequency product,
     and a training handle scales all 16 images of a tensor by one power of two) -- compared at sampled entries with float64 sums taken straight
-    from the definition.  No ReLU or pooling is involved, so there is no rounding-decision noise: every route is held to GRAD_RTOL = 1e-4 of the
-    tensor's largest entry and must come within 3x of the fp32 MFMA chain's own error (+2e-6).  'exact' = the default fp32 engine (frequency
+    from the definition.  No ReLU or pooling is involved, so there is no rounding-decision noise: the frequency-domain kernels are held to 1e-6 of
+    the tensor's largest entry, the direct kernels to 8e-6 (100x / 12x below GRAD_RTOL).  'exact' = the default fp32 engine (frequency
     domain: wgrad_fft.hip and the data gradient through conv_fft on flipped filters, two scaled fp16 parts), 'exact_bf16x3' = the same on three
     bf16 parts, 'chain' = wgrad.hip / conv_igemm on the fp32 MFMA accumulation chain, 'split16' = the direct kernels on fp16 parts."""
     p = synth.make_pd_params(debug=False, bn='trained')
@@ -413,19 +416,20 @@ def test_gradient_kernels_at_full_size_layer_shapes(mode):
         rows.append((scope, ew, ex))
         print('  %-7s %-18s dW err / max|dW| %.2e   dX err / max|dX| %.2e' % (mode, scope, ew, ex))
     eng.close()
-    bad = [r for r in rows if not (r[1] <= GRAD_RTOL and r[2] <= GRAD_RTOL)]
-    assert not bad, bad
-    # the frequency-domain kernels are no worse than the sequential fp32 chain (measured: chain dW <= 4e-6, dX <= 2e-6)
-    if mode != 'chain':
-        assert max(r[1] for r in rows) <= 2e-5 and max(r[2] for r in rows) <= 2e-5, rows
+    # measured (round 4, 16 images): frequency domain dW <= 2.6e-7, dX <= 2.6e-7 (both operand forms); fp32 MFMA chain dW <= 9.3e-7, dX <= 2.1e-6;
+    # direct fp16x3 kernels dW <= 1.0e-6, dX <= 2.3e-6 -- the bound is ~4x the measured value of each route, far below GRAD_RTOL
+    bound = 1e-6 if mode in ('exact', 'exact_bf16x3') else 8e-6
+    bad = [r for r in rows if not (r[1] <= bound and r[2] <= bound)]
+    assert not bad, (bound, bad)
 
 
 def test_full_size_step_16_images_vs_golden():
     """configs[4] at its real per-GPU workload (main.py:538-541,557-560: batch 128 over 8 towers): the full-width network, 16 images, training
     handle, default route -- losses, moving statistics, gradient norms and sampled gradient entries against tests/golden/train_full_b16.json
     (float64 restatement of the 16-image tower; training-mode BatchNorm couples the images, so this golden is its own two-hour CPU run).
-    End-to-end bound: 16 x 5400 samples per channel average the rounding-decision flips of a single image down, so the frequency-domain route is
-    held to 2e-3 of the tensor's largest entry (+ twice the float32 restatement's own distance from float64) and 'chain' to GRAD_RTOL."""
+    End-to-end bound, BOTH routes: GRAD_RTOL = 1e-4 of the tensor's largest entry + twice the float32 restatement's own distance from float64 (at 16
+    images x 5400 samples per channel a single rounding-decision flip no longer moves a gradient the way it does in the one-image golden; measured
+    worst entry: frequency domain 5.4e-4 of max|g| with a float32 slack of 2.6e-3, fp32 MFMA chain 3.8e-3 with a slack of 3.0e-3)."""
     import json, os
     from golden.make_train_golden import case, LMBD, B_TOWER
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'train_full_b16.json')
@@ -443,7 +447,7 @@ def test_full_size_step_16_images_vs_golden():
         bad, rows = [], []
         for k, t in gold['tensors'].items():
             g = got[k].astype(np.float64)
-            tol = (GRAD_RTOL if mode == 'chain' else 2e-3) * t['max'] + 2 * t['slack'] + 1e-7
+            tol = GRAD_RTOL * t['max'] + 2 * t['slack'] + 1e-7
             err = np.abs(g[t['idx']] - np.asarray(t['val'])).max()
             nerr = abs(np.linalg.norm(g) - t['norm'])
             rows.append((err / max(t['max'], 1e-30), k, t['slack'] / max(t['max'], 1e-30)))
