@@ -158,11 +158,6 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
   const int KC = a.KC;
 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-  // Keep the first LDS-DMA away from the start of the work group (round 4): with the burst of the first stages issued right
-  // behind the wave's set-up code, work groups of OTHER kernels on the CU (another stream's) saw 128-byte pieces of their LDS overwritten --
-  // 242 of 300 runs of a layer differed beside this kernel's 64 x 32 instantiation (3136 two-wave work groups, i.e. a work-group
-  // boundary every microsecond per CU), 0 of 300 with this pause (4 x 64 cycles) or with the requests spaced out.
-  __builtin_amdgcn_s_sleep(4);
   constexpr int WBYTES = WF32 ? C::WSRC : WST * 16;      // bytes of one stage of the W stream in HBM
   const char* xg = a.xs + ((size_t)(f * a.mtiles + mt) * KC) * (size_t)(XST * 16);
   const char* wg = a.ws + ((size_t)(f * a.ntiles + nt) * KC) * (size_t)WBYTES;
@@ -171,13 +166,9 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
   const unsigned lane16 = (unsigned)lane * 16u;
 
   // stage g -> ring slot: the LDS image of a stage is its HBM image, X pieces first; wave w moves pieces w, w + NW, ...
-  // A DMA is issued for EXISTING stages only (g < KC; the callers guard).  Rounds 2-3 let the look-ahead run past the last stage -- first
-  // with the stage offset in the scalar operand (not bounds-checked: stray reads behind the buffer), then in the bounds-checked vector
-  // operand so that the request "delivers zeros into a free slot".  Round 4 found what that costs when kernels of ANOTHER stream share
-  // the CU: with such out-of-range LDS-DMAs in the last stages of a work group, 128-byte pieces of zeros appear in the LDS of a work
-  // group of a different kernel that was started on the CU afterwards (seen as three zeroed 128-byte lines, 1 KB apart, in the row
-  // transform's tile: tools/determinism.py).  A/B on one box: 266 of 300 runs of a layer differ beside this kernel
-  // with the out-of-range look-ahead, 0 of 300 without.  The stage offset still rides in the (bounds-checked) vector offset.
+  // A DMA is issued for EXISTING stages only (g < KC; the callers guard): rounds 2-3 let the look-ahead run past the last stage and relied on
+  // the bounds check of the buffer descriptor ("delivers zeros into a free slot"); nothing is requested that is not used any more.  The stage
+  // offset rides in the (bounds-checked) vector offset.
   auto issue = [&](int g, int slot) __attribute__((always_inline)) {
     const unsigned sbase = (unsigned)(slot * STAGE * 16);
 #pragma unroll

@@ -99,18 +99,22 @@ __device__ __forceinline__ float rows_fwd_store(const cf* buf, cf* __restrict__ 
 }
 
 // ---- fp32 handles, np = 4 (two FP16 parts per GEMM operand, cgemm_split.hip): fp16 carries 11 significant bits over 2^-24 .. 2^16, so the
-// spectra are scaled by a power of two that is exact to apply and to undo.  The bound is rigorous: a column transform sums H entries of the
-// row-transformed tensor T, so |X[f]| <= H * max|T|; max|T| of every image is found by the row pass that writes T (an atomic max per wave and
-// tile on the image's device word, order independent: deterministic), the column pass scales by 2^k with H * max|T| * 2^k < 2^15, and the inverse row pass multiplies its
-// 1 / (NY NX) by 2^-k and by the inverse of the filter spectra's own scale.  (struct Fp16Scale: kernels.h)
+// spectra are scaled by a power of two that is exact to apply and to undo.  tmax = the largest |re| or |im| of the row-transformed tensor T of an
+// image (found by the row pass that writes T: an atomic max per tile on the image's device word, order independent: deterministic).  A column
+// transform is X[ky] = sum over the H rows of T[y] e^{-i phi}: a COMPONENT of X is sum (re cos + im sin), bounded by H * tmax * (|cos| + |sin|)
+// <= sqrt(2) * H * tmax.  The column pass scales by 2^k with H * tmax * 2^k < 2^15, so every scaled component is below sqrt(2) * 2^15 = 46341 --
+// inside fp16's 65504 by the remaining factor sqrt(2) only: THE TARGET EXPONENT 15 IS THE LARGEST THAT IS SAFE (16 would overflow to inf).
+// The inverse row pass multiplies its 1 / (NY NX) by 2^-k and by the inverse of the filter spectra's own scale.  (struct Fp16Scale: kernels.h)
+constexpr int kFp16TargetExp = 15;
+static_assert(kFp16TargetExp <= 15, "sqrt(2) * 2^kFp16TargetExp must stay below fp16's largest number 65504");
 __device__ __forceinline__ int fp16_exp(float tmax, float hf) {      // e with H * tmax < 2^e (0 for an all-zero tensor)
   const float bound = tmax * hf;
   int e = 0;
   if (bound > 0.f && bound < 3.0e38f) (void)frexpf(bound, &e);
   return e;
 }
-__device__ __forceinline__ float fp16_scale(float tmax, float hf) { return ldexpf(1.f, 15 - fp16_exp(tmax, hf)); }
-__device__ __forceinline__ float fp16_unscale(float tmax, float hf) { return ldexpf(1.f, fp16_exp(tmax, hf) - 15); }
+__device__ __forceinline__ float fp16_scale(float tmax, float hf) { return ldexpf(1.f, kFp16TargetExp - fp16_exp(tmax, hf)); }
+__device__ __forceinline__ float fp16_unscale(float tmax, float hf) { return ldexpf(1.f, fp16_exp(tmax, hf) - kFp16TargetExp); }
 // max |T| the scale of image b derives from: its own word, or (common) the largest of the tensor's nb words
 __device__ __forceinline__ float tmax_of(const float* __restrict__ tmax, int b, int nb, int common) {
   if (!common) return tmax[b];
@@ -144,7 +148,7 @@ __device__ __forceinline__ void block_max_to(float m, float* dst, float* red, in
   __syncthreads();
   if (tid == 0) {
     for (int w = 1; w < NTH / 64; ++w) m = fmaxf(m, red[w]);
-    if (m > __builtin_nontemporal_load(dst)) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(m));
+    if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(m));      // always the atomic: a plain pre-read of the word could be a stale cache line
   }
 }
 // The row kernels keep NX x 32 complex numbers in LDS: threads per work group chosen so that the work groups the LDS admits fill the CU's 32 waves

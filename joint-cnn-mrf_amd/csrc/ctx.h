@@ -116,6 +116,7 @@ struct jcm_ctx {
   std::vector<WordBlock> fft_blocks;
   int fft_block_i = 0, fft_word_i = 0;      // next free word: fft_blocks[fft_block_i].p + fft_word_i
   int call_order = 1;               // 0: this handle's calls are not ordered against other handles' (debugging only)
+  int debug_skip = 0;               // bisecting aid (jcm_pd_forward): bit 0 conv1(+pool1), 1 pool2, 2 conv2, 3 conv3, 4 conv4, 5 merge + conv5, 6 conv6 are NOT launched
   float* fft_tmax_in = nullptr;     // transient: the word of the next frequency-domain layer's input (set with fft_t_in / fft_xs_ready by whoever produced that tensor)
   float* fft_last_tmax = nullptr;   // the word the last frequency-domain layer's input used (the training step keeps it with the kept spectra)
   struct FftW { void* p = nullptr; size_t bytes = 0; bool valid = false; float* wscale = nullptr; };      // wscale: two device floats behind the spectra (np = 4)

@@ -1,6 +1,6 @@
-// Complex butterflies shared by the in-LDS FFT kernels (sm_fused.hip, conv_fft.hip).  A complex number is a 2-vector, so
-// that add / sub / scale / fma are ONE packed VALU instruction and the +-90 degree rotation of a butterfly is the operand
-// select of v_pk_add_f32.  Dft<R, S>::run(x): y_k = sum_m x_m e^{S 2 pi i m k / R}, in place (S = +1 inverse, -1 forward).
+// Complex butterflies shared by the in-LDS FFT kernels (sm_fused.hip, conv_fft.hip).  A complex number is a 2-vector (the compiler
+// keeps it in a register pair; the arithmetic is scalar fp32 instructions, see cmac below).  Dft<R, S>::run(x): y_k = sum_m x_m e^{S 2 pi i m k / R},
+// in place (S = +1 inverse, -1 forward).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -12,20 +12,16 @@ __device__ __forceinline__ cf cfma(cf a, cf b, cf c) { return __builtin_elementw
 __device__ __forceinline__ cf sfma(float a, cf b, cf c) { return __builtin_elementwise_fma(cf{a, a}, b, c); }
 template <int S> __device__ __forceinline__ cf muli(cf a) { return S > 0 ? cf{-a.y, a.x} : cf{a.y, -a.x}; }   // a * (S i)
 __device__ __forceinline__ cf cmul(cf a, cf b) { return cfma(a.yy, cf{-b.y, b.x}, a.xx * b); }
-// acc + a * b (complex) in TWO packed FMAs whose operand selects broadcast a.x / a.y and rotate b: no broadcast or rotated copy of either
-// operand lives in registers (a loop-invariant `a` would otherwise be hoisted as a.xx AND a.yy)
-__device__ __forceinline__ cf cmac(cf acc, cf a, cf b) {
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(a), "v"(b));                     // (a.x b.x, a.x b.y)
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(acc) : "v"(a), "v"(b));      // (-a.y b.y, a.y b.x)
-  return acc;
-}
-// a + (S i) b in ONE packed add: the 90-degree rotation is the instruction's operand select (low result: a.x -+ b.y, high: a.y +- b.x)
-template <int S> __device__ __forceinline__ cf add_i(cf a, cf b) {
-  cf r;
-  if (S > 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
+// acc + a * b (complex), and a + (S i) b.  Written per component: this library is compiled WITHOUT packed-fp32 instructions (Makefile:
+// -target-feature -packed-fp32-ops).  Rounds 1-3 had these two as hand-written v_pk_fma_f32 / v_pk_add_f32 with operand selects; round 4 found
+// that the RESULT OF A PACKED-FP32 INSTRUCTION (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32, compiler-generated or hand-written) can come out
+// wrong in lanes 48-63 of a wave while a wave of one of this library's MFMA kernels (LDS fragment reads feeding v_mfma) is resident on the
+// same CU -- which only happens when kernels of two streams / processes share the GPU.  tools/coresidency_probe.hip reproduces it against a
+// plain kernel (packed arithmetic: 210-283 of 300 runs differ beside the channel GEMM; the same arithmetic on scalar instructions: 0 of
+// 300); with the whole library on scalar fp32 instructions the two-engine soak without the call chain is clean (0 of 400 forwards, fp32 and
+// bf16; before: 250-505 of 600 and 14 of 600) at unchanged speed (the transform kernels are bound by HBM and LDS, not by VALU issue).
+__device__ __forceinline__ cf cmac(cf acc, cf a, cf b) { return cfma(a.yy, cf{-b.y, b.x}, cfma(a.xx, b, acc)); }
+template <int S> __device__ __forceinline__ cf add_i(cf a, cf b) { return S > 0 ? cf{a.x - b.y, a.y + b.x} : cf{a.x + b.y, a.y - b.x}; }
 
 // r-point DFTs, y_k = sum_m x_m e^{S 2 pi i m k / r} (S = +1 inverse, -1 forward), in place
 template <int R, int S> struct Dft;

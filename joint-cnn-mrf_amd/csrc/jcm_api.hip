@@ -543,7 +543,9 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
     const int h1 = cdiv2(hin), w1 = cdiv2(win);
     const int h2 = cdiv2(h1), w2 = cdiv2(w1);
     void* p1;
-    if (!bf && L1->wq1_f32 && xh % (4 * xsub) == 0 && xw % (4 * xsub) == 0) {
+    const int sk = c->debug_skip;
+    if (sk & 1) { p1 = act((size_t)B * h2 * w2 * L1->cout); }
+    else if (!bf && L1->wq1_f32 && xh % (4 * xsub) == 0 && xw % (4 * xsub) == 0) {
       // fp32 path: conv1 + ReLU/BN + pool1 in one fp32-MFMA kernel (the unpooled 240x360x64 map never reaches HBM)
       p1 = act((size_t)B * h2 * w2 * L1->cout);
       // default route (the stride-1 layers run on split operands on the bf16 matrix cores): conv1 too; the exact fp32 MFMA chain otherwise
@@ -568,9 +570,9 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
     // contiguous LDS-DMA reads; from NHWC every 16-byte unit of a pixel is a separate cache line).  A planar [B][C/8][H][W][8] tensor IS an
     // NHWC tensor of B*C/8 images with 8 channels: the pooling kernel runs on it unchanged.
     const int pl23 = bf && takes_c5strip(L2, B, h2, w2) && takes_c5strip(L3, B, h3, w3) ? 1 : 0;
-    JCM_TRY(run_conv(c, "conv2_" + res, 1, p1, B, h2, w2, 1, c2, bf, false, 0, pl23));     // :46,54,63
+    if (!(sk & 4)) JCM_TRY(run_conv(c, "conv2_" + res, 1, p1, B, h2, w2, 1, c2, bf, false, 0, pl23));     // :46,54,63
     void* p2 = act((size_t)B * h3 * w3 * L2->cout);
-    if (!c->dry) {                                                                          // :47,55,64
+    if (!c->dry && !(sk & 2)) {                                                             // :47,55,64
       if (pl23) HIP_TRY(max_pool_2x2(c2, p2, bf, B * (L2->cout / 8), h2, w2, 8, c->stream));
       else HIP_TRY(max_pool_2x2(c2, p2, bf, B, h2, w2, L2->cout, c->stream));
     }
@@ -578,10 +580,10 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
     const ConvLayer* L4r = conv_of(c, "conv4_" + res);
     if (!L4r) return fail(JCM_ERR_STATE, "part-detector parameters incomplete (conv4_" + res + ")");
     const int in4 = planar && L3->cout % 8 == 0 && takes_strip(L4r, B, h3, w3) && !takes_fft(c, L4r, B, h3, w3) ? 1 : 0;      // the patch kernels and the row pass read NHWC
-    void* t34 = offer_handover(c, L3, L4r, B, h3, w3);
-    JCM_TRY(run_conv(c, "conv3_" + res, 1, p2, B, h3, w3, 1, c3, bf, false, pl23, in4));   // :48,56,65
+    void* t34 = (sk & 24) ? nullptr : offer_handover(c, L3, L4r, B, h3, w3);      // (no hand-over when either side is left out)
+    if (!(sk & 8)) JCM_TRY(run_conv(c, "conv3_" + res, 1, p2, B, h3, w3, 1, c3, bf, false, pl23, in4));   // :48,56,65
     c->fft_t_in = t34;
-    JCM_TRY(run_conv(c, "conv4_" + res, 1, c3, B, h3, w3, 1, x4[r], bf, false, in4, planar45));   // :49,57,66
+    if (!(sk & 16)) JCM_TRY(run_conv(c, "conv4_" + res, 1, c3, B, h3, w3, 1, x4[r], bf, false, in4, planar45));   // :49,57,66
     c->arena_off = mark;
   }
   const int hh = h4[0], ww = w4[0];
@@ -592,16 +594,17 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
   const bool fuse_merge = takes_fft(c, L5, B, hh, ww) && !planar45;
   FftMerge mg{x4[1], h4[1], w4[1], x4[2], h4[2], w4[2]};
   void* merged = fuse_merge ? x4[0] : act((size_t)B * hh * ww * L4->cout);
-  if (!c->dry && !fuse_merge) {                                                            // :58,67,69-70
+  if (!c->dry && !fuse_merge && !(c->debug_skip & 32)) {                                   // :58,67,69-70
     if (planar45) HIP_TRY(upsample_merge3_planar(x4[0], x4[1], h4[1], w4[1], x4[2], h4[2], w4[2], merged, B, hh, ww, L4->cout, c->stream));
     else HIP_TRY(upsample_merge3(x4[0], x4[1], h4[1], w4[1], x4[2], h4[2], w4[2], merged, bf, B, hh, ww, L4->cout, c->stream));
   }
   void* c5 = act((size_t)B * hh * ww * L5->cout);
-  void* t56 = offer_handover(c, L5, conv_of(c, "conv6"), B, hh, ww);
-  if (fuse_merge) c->fft_merge = &mg;
-  JCM_TRY(run_conv(c, "conv5", 1, merged, B, hh, ww, 1, c5, bf, false, planar45, planar));   // :71
+  const int sk = c->debug_skip;
+  void* t56 = (sk & 96) ? nullptr : offer_handover(c, L5, conv_of(c, "conv6"), B, hh, ww);
+  if (fuse_merge && !(sk & 32)) c->fft_merge = &mg;
+  if (!(sk & 32)) JCM_TRY(run_conv(c, "conv5", 1, merged, B, hh, ww, 1, c5, bf, false, planar45, planar));   // :71
   c->fft_t_in = t56;
-  JCM_TRY(run_conv(c, "conv6", 1, c5, B, hh, ww, 1, logits, bf, true, planar, 0));         // :72
+  if (!(sk & 64)) JCM_TRY(run_conv(c, "conv6", 1, c5, B, hh, ww, 1, logits, bf, true, planar, 0));         // :72
   return JCM_OK;
 }
 
@@ -729,6 +732,10 @@ int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
   if (k == "micro_batch") {   // allowed at any time
     if (value < 0) return fail(JCM_ERR_ARG, "micro_batch must be >= 0 (0 = default: 256 bf16 / 64 fp32)");
     h->micro_batch = (int)value;
+    return JCM_OK;
+  }
+  if (k == "debug_skip") {   // allowed at any time; bisecting aid: groups of launches of jcm_pd_forward that are left out (results are then garbage)
+    h->debug_skip = (int)value;
     return JCM_OK;
   }
   if (k == "call_order") {   // allowed at any time; 0 = debugging: this handle's calls are not ordered against other handles' on the device

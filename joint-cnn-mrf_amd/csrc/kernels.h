@@ -79,7 +79,7 @@ hipError_t conv_thin_bf16(const ConvArgs& a, hipStream_t st);
 //
 // np = 4 scaling (fp16 carries 11 bits over 2^-24 .. 2^16): device words, all written and read on the stream --
 //   tmax[b]      : max |T| of image b of the layer's row-transformed input (atomic max by the row pass, or by the previous layer's fused kernel:
-//                  ZERO them before the producer runs); the column pass scales image b by 2^k with H * tmax[b] * 2^k < 2^15, the inverse row
+//                  ZERO them before the producer runs); the column pass scales image b by 2^k with H * tmax[b] * 2^k < 2^15 (components of the scaled spectra then stay below sqrt(2) * 2^15 < 65504: conv_fft_common.h), the inverse row
 //                  pass undoes it.  One word per IMAGE: a row of the channel GEMM is one image, so an image's result does not depend on the
 //                  batch it is in.  common = 1: one scale for the tensor, from the max over the B words (the training step: the weight gradient
 //                  sums over the images and needs one scale);

@@ -2,15 +2,16 @@
 """Generates the committed golden vectors.  Runs ONLY in the build container (it reads
 /root/reference); the tests read the small .npy/.json files it writes next to itself.
 
-  python tests/golden/make_golden.py [--skip-reference-check]
+  python tests/golden/make_golden.py [--exec-reference]
 
 1. flic_train_cells.npy  [3987,10,2] uint8 -- heat-map cell (row, col) of the 9 joints + torso
-   for every FLIC training example, obtained by EXECUTING the reference's own data.py (runpy;
-   the JPEG reads are stood in for, the heat-map half only needs data_FLIC.mat) and taking the
-   arg-max cell of its y_train_flic.npy the way prepare_pairwise_distribution.py:39-42 reads it back.
-   The reference's own prepare_pairwise_distribution.py is then executed (runpy, in a temp
-   dir holding the generated y_train_flic.npy) and its pickle must equal
-   joint_cnn_mrf_amd.priors.build_pairwise_distributions(cells) bit for bit.
+   for every FLIC training example: the arg-max cell of the y_train heat maps, read back the way
+   prepare_pairwise_distribution.py:39-42 reads it.  By default the maps come from this package's
+   restatement (joint_cnn_mrf_amd.data) of data_FLIC.mat; with --exec-reference the reference's own
+   data.py and prepare_pairwise_distribution.py are EXECUTED as well -- each in a child process inside a
+   temp dir (they are untrusted upstream code; the JPEG reads of data.py are stood in for, its heat-map half only
+   needs data_FLIC.mat) -- and their y_train / y_test arrays and the 90-pair pickle must equal the
+   restatement's outputs bit for bit.
 2. full_*.npy -- float64-oracle outputs of the FULL-SIZE network on 2 seeded images
    (inputs/weights are regenerated from seeds by the tests, only outputs are stored):
    pd_logits, sm_logits for FLIC priors with init / trained-like SM parameters, coords.
@@ -21,7 +22,6 @@
 import json
 import os
 import pickle
-import runpy
 import sys
 import tempfile
 
@@ -40,45 +40,38 @@ from oracle import jcm_oracle as O  # noqa: E402
 GOLDEN_SEEDS = dict(weights=7, images=2024, torso=2025, sm=11, conv6_gain=24.0)
 
 
+_CHILD = r"""
+import os, runpy, sys, types
+import numpy as np
+ref, script = sys.argv[1], sys.argv[2]
+if script == 'data.py':
+    # the script also reads 5003 JPEG frames that are not in the repository and imports plotting / image libraries that are not installed; only
+    # those are stood in for (every frame reads as one black pixel -- the heat-map half never looks at the pixels)
+    imageio = types.ModuleType('imageio'); imageio.imread = lambda path: np.zeros((1, 1, 3), np.uint8)
+    skimage = types.ModuleType('skimage'); skimage.transform = types.ModuleType('skimage.transform')
+    mpl = types.ModuleType('matplotlib'); mpl.pyplot = types.ModuleType('matplotlib.pyplot')
+    sys.modules.update({'imageio': imageio, 'skimage': skimage, 'skimage.transform': skimage.transform, 'matplotlib': mpl, 'matplotlib.pyplot': mpl.pyplot})
+    if not hasattr(np.lib, 'pad'):
+        np.lib.pad = np.pad          # the alias the 2018 script uses; NumPy 2 dropped it
+runpy.run_path(os.path.join(ref, script), run_name='__main__')
+"""
+
+
+def _run_reference_script(script, td):
+    """Execute one of the reference's own scripts (untrusted upstream code) in a CHILD process whose working directory is the temp dir `td`:
+    the stand-in modules, the NumPy alias and whatever the script writes stay in that process and that directory."""
+    import subprocess
+    subprocess.run([sys.executable, '-c', _CHILD, REF, script], cwd=td, check=True, stdout=subprocess.DEVNULL,
+                   env={'PATH': os.environ.get('PATH', ''), 'HOME': td, 'PYTHONDONTWRITEBYTECODE': '1'})
+
+
 def run_reference_data_script():
-    """Execute /root/reference/data.py's own __main__ block (runpy) on data_FLIC.mat and return (y_train, y_test) as IT builds them.
-    The script also reads 5003 JPEG frames that are not in the repository and imports plotting / image libraries that are not
-    installed; only those are stood in for (every frame reads as one black pixel -- the heat-map half never looks at the pixels --
-    and the x_*_flic.npy arrays it writes are discarded).  Nothing of the script's text is kept here."""
-    import types
-    stubs = {}
-    imageio = types.ModuleType('imageio')
-    imageio.imread = lambda path: np.zeros((1, 1, 3), np.uint8)
-    stubs['imageio'] = imageio
-    skimage = types.ModuleType('skimage')
-    skimage.transform = types.ModuleType('skimage.transform')
-    stubs['skimage'], stubs['skimage.transform'] = skimage, skimage.transform
-    mpl = types.ModuleType('matplotlib')
-    mpl.pyplot = types.ModuleType('matplotlib.pyplot')
-    stubs['matplotlib'], stubs['matplotlib.pyplot'] = mpl, mpl.pyplot
-    saved = {k: sys.modules.get(k) for k in stubs}
-    cwd = os.getcwd()
-    had_lib_pad = hasattr(np.lib, 'pad')
+    """--exec-reference: /root/reference/data.py's own __main__ block on data_FLIC.mat -> (y_train, y_test) as IT builds them (the x_*_flic.npy arrays
+    it writes are discarded).  Nothing of the script's text is kept here."""
     with tempfile.TemporaryDirectory() as td:
         os.symlink(os.path.join(REF, 'data_FLIC.mat'), os.path.join(td, 'data_FLIC.mat'))
-        os.chdir(td)
-        try:
-            sys.modules.update(stubs)
-            if not had_lib_pad:
-                np.lib.pad = np.pad          # the alias the 2018 script uses; NumPy 2 dropped it
-            runpy.run_path(os.path.join(REF, 'data.py'), run_name='__main__')
-            y_train = np.load(os.path.join(td, 'y_train_flic.npy'))
-            y_test = np.load(os.path.join(td, 'y_test_flic.npy'))
-        finally:
-            os.chdir(cwd)
-            if not had_lib_pad:
-                del np.lib.pad
-            for k, v in saved.items():
-                if v is None:
-                    sys.modules.pop(k, None)
-                else:
-                    sys.modules[k] = v
-    return y_train, y_test
+        _run_reference_script('data.py', td)
+        return np.load(os.path.join(td, 'y_train_flic.npy')), np.load(os.path.join(td, 'y_test_flic.npy'))
 
 
 def cells_from_heat_maps(y):
@@ -95,15 +88,10 @@ def cells_from_heat_maps(y):
 
 
 def run_reference_prior_builder(y_train):
-    """Execute /root/reference/prepare_pairwise_distribution.py itself on y_train."""
-    cwd = os.getcwd()
+    """--exec-reference: /root/reference/prepare_pairwise_distribution.py itself on y_train (child process, temp dir)."""
     with tempfile.TemporaryDirectory() as td:
         np.save(os.path.join(td, 'y_train_flic.npy'), y_train)
-        os.chdir(td)
-        try:
-            runpy.run_path(os.path.join(REF, 'prepare_pairwise_distribution.py'), run_name='__main__')
-        finally:
-            os.chdir(cwd)
+        _run_reference_script('prepare_pairwise_distribution.py', td)
         with open(os.path.join(td, 'pairwise_distribution.pickle'), 'rb') as fh:
             return pickle.load(fh)
 
@@ -114,21 +102,25 @@ def top2_margin(logits):
 
 
 def main():
-    skip_ref = '--skip-reference-check' in sys.argv
-    y_train, y_test = run_reference_data_script()
+    # Default: the heat maps and priors are built by this package's own restatement (joint_cnn_mrf_amd.data / .priors) from data_FLIC.mat.
+    # --exec-reference additionally EXECUTES the reference's data.py and prepare_pairwise_distribution.py (child processes, temp dirs) and asserts
+    # that their outputs equal the restatement's bit for bit -- the check that pins rows a10 / next-4 of SURVEY 8; the committed fixtures were
+    # generated with it (round 3) and re-checked with it in round 4.
+    exec_ref = '--exec-reference' in sys.argv
+    from joint_cnn_mrf_amd import data as jdata
+    xy, _names, is_train = jdata.load_flic(os.path.join(REF, 'data_FLIC.mat'))
+    y_train = jdata.target_heat_maps(jdata.joint_cells(xy[is_train]))
+    y_test = jdata.target_heat_maps(jdata.joint_cells(xy[~is_train]))
+    if exec_ref:
+        ry_train, ry_test = run_reference_data_script()
+        assert np.array_equal(ry_train, y_train) and np.array_equal(ry_test, y_test)
+        print('joint_cnn_mrf_amd.data: y_train / y_test identical to the arrays the reference data.py writes')
     print('y_train', y_train.shape, float(y_train.sum(axis=(1, 2)).mean()), 'y_test', y_test.shape)
     cells = cells_from_heat_maps(y_train)
     np.save(os.path.join(HERE, 'flic_train_cells.npy'), cells)
-    # the annotations themselves (x, y of the nine joints, float64), input of joint_cnn_mrf_amd.data; the package's
-    # data preparation must rebuild y_train / y_test bit for bit from them
-    from joint_cnn_mrf_amd import data as jdata
-    xy, _names, is_train = jdata.load_flic(os.path.join(REF, 'data_FLIC.mat'))
-    np.save(os.path.join(HERE, 'flic_train_xy.npy'), xy[is_train])
-    assert np.array_equal(jdata.target_heat_maps(jdata.joint_cells(xy[is_train])), y_train)
-    assert np.array_equal(jdata.target_heat_maps(jdata.joint_cells(xy[~is_train])), y_test)
-    print('joint_cnn_mrf_amd.data: y_train / y_test identical to the arrays the reference data.py writes')
+    np.save(os.path.join(HERE, 'flic_train_xy.npy'), xy[is_train])      # the annotations themselves (x, y of the nine joints, float64), input of joint_cnn_mrf_amd.data
     pri = priors.build_pairwise_distributions(cells)
-    if not skip_ref:
+    if exec_ref:
         ref = run_reference_prior_builder(y_train)
         assert sorted(ref) == sorted(pri) and len(ref) == 90
         for k in ref:

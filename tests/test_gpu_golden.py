@@ -278,16 +278,19 @@ def test_checkpoint_file_to_engine_reproduces_golden_tower(tmp_path, precision):
         assert (np.abs(r['sm_coords'].cpu().numpy() - load('full_sm_coords_trained')).max(axis=1) <= 1).mean() >= 0.85
 
 
+@pytest.mark.parametrize('call_order', [True, False], ids=['chain', 'nochain'])
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
-def test_two_engines_two_streams_soak(precision):
+def test_two_engines_two_streams_soak(precision, call_order):
     """Two engines on two HIP streams of one device run the full-size tower concurrently, 100 forwards each, nothing synchronised in
-    between (their kernels interleave on the GPU; twiddle tables, occupancy caches and per-kernel attributes are shared process state).
-    Every single result must be the golden one: fp32 to the golden bar, bf16 bit-identical to its own first result."""
+    between (twiddle tables, occupancy caches and per-kernel attributes are shared process state).  'chain': the default, calls of the two
+    handles are ordered one after the other on the GPU; 'nochain' (jcm_set_option "call_order" 0): their kernels really interleave on the
+    CUs -- the configuration that exposed the packed-fp32 / MFMA co-residency problem of rounds 2-3 (250-505 of 600 fp32
+    forwards differed before the fix).  Every single result must be the golden one: fp32 to the golden bar, bit-identical to the first result."""
     from joint_cnn_mrf_amd.engine import Engine
     x, torso, p = full_inputs()
     p.update(synth.make_sm_params(flic_priors(), kind='trained', seed=seeds()['sm']))
     streams = [torch.cuda.Stream(device='cuda:0') for _ in range(2)]
-    engs = [Engine(device=0, precision=precision, stream=s).load_params(p) for s in streams]
+    engs = [Engine(device=0, precision=precision, stream=s, call_order=call_order).load_params(p) for s in streams]
     xd, td = dev(x), dev(torso)
     torch.cuda.synchronize()
     n_iter = 100
@@ -376,16 +379,13 @@ def _soak_process(rank, barrier, q, precision, n_iter):
     eng.close()
 
 
-@pytest.mark.xfail(strict=False, reason='round 4 (DESIGN.md 4.1e): kernels of two handles that are co-resident on a CU are not yet isolated from each other -- the LDS-DMA '
-                   'ring of the channel GEMM was found to overwrite 128-byte pieces of another work group\'s LDS (tools/coresidency_probe.hip reproduces it against a '
-                   'plain kernel; fixed for every single layer), and the whole tower still shows a residual (fp32: a third of the forwards). Inside one process '
-                   'the per-device call chain keeps handles apart; across processes nothing does.')
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
 def test_two_processes_one_gpu_soak(precision):
     """Two PROCESSES share the GPU (two ranks on one device, or a second job): no event chain reaches across them, so this is the test of the
     kernels themselves -- no read outside a buffer, no LDS word used before it is written.  80 full-size forwards per process while the other
     process runs the same loop; every result bit-identical to the process's first one, both processes bit-identical to each other.
-    EXPECTED TO FAIL for now (see the marker): kept so that the day the residual is found the test flips to XPASS."""
+    (Failed before round 4's fix: packed-fp32 results of the transform kernels came out wrong beside another process's MFMA kernels,
+    DESIGN.md 4.1e.)"""
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     q, barrier = ctx.Queue(), ctx.Barrier(2)

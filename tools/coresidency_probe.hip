@@ -59,6 +59,145 @@ __global__ __launch_bounds__(384) void victim_generic(f2* out, int tiles) {
   }
 }
 
+// victim 2: the same network as victim 0 on separate real / imaginary floats (no packed-fp32 instruction: compiled with -fno-slp-vectorize and
+// checked in the ISA): does the corruption need v_pk_*_f32 in the victim?
+__global__ __launch_bounds__(384) void victim_scalar(f2* out, int tiles) {
+  __shared__ float br[96 * 32], bi[96 * 32];
+  const int tid = threadIdx.x;
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    for (int t = tid; t < 96 * 32; t += 384) { br[t] = hashf(tile, 2 * t); bi[t] = hashf(tile, 2 * t + 1); }
+    __syncthreads();
+    for (int r = 0; r < 6; ++r) {
+      const int k = tid / 32, v = tid % 32;
+      float xr[8], xi[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) { xr[m] = br[((k + 12 * m + r) % 96) * 32 + v]; xi[m] = bi[((k + 12 * m + r) % 96) * 32 + v]; }
+      const float a0r = xr[0] + xr[4], a0i = xi[0] + xi[4], a1r = xr[0] - xr[4], a1i = xi[0] - xi[4], a2r = xr[2] + xr[6], a2i = xi[2] + xi[6], a3r = xr[2] - xr[6], a3i = xi[2] - xi[6];
+      const float b0r = xr[1] + xr[5], b0i = xi[1] + xi[5], b1r = xr[1] - xr[5], b1i = xi[1] - xi[5], b2r = xr[3] + xr[7], b2i = xi[3] + xi[7], b3r = xr[3] - xr[7], b3i = xi[3] - xi[7];
+      const float c0r = a0r + a2r, c0i = a0i + a2i, c1r = a0r - a2r, c1i = a0i - a2i, c2r = a1r - a3i, c2i = a1i + a3r, c3r = a1r + a3i, c3i = a1i - a3r;
+      const float d0r = b0r + b2r, d0i = b0i + b2i, d1r = b0r - b2r, d1i = b0i - b2i, d2r = b1r - b3i, d2i = b1i + b3r, d3r = b1r + b3i, d3i = b1i - b3r;
+      const float h = 0.70710678f, g = 0.35f;
+      xr[0] = (c0r + d0r) * g; xi[0] = (c0i + d0i) * g; xr[4] = (c0r - d0r) * g; xi[4] = (c0i - d0i) * g;
+      xr[1] = (c2r + d2r * h) * g; xi[1] = (c2i + d2i * h) * g; xr[5] = (c2r - d2r * h) * g; xi[5] = (c2i - d2i * h) * g;
+      xr[2] = (c1r - d1i) * g; xi[2] = (c1i + d1r) * g; xr[6] = (c1r + d1i) * g; xi[6] = (c1i - d1r) * g;
+      xr[3] = (c3r + d3r * h) * g; xi[3] = (c3i + d3i * h) * g; xr[7] = (c3r - d3r * h) * g; xi[7] = (c3i - d3i * h) * g;
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < 8; ++m) { br[((k + 12 * m + r) % 96) * 32 + v] = xr[m]; bi[((k + 12 * m + r) % 96) * 32 + v] = xi[m]; }
+      __syncthreads();
+    }
+    for (int t = tid; t < 96 * 32; t += 384) out[(size_t)tile * 96 * 32 + t] = f2{br[t], bi[t]};
+    __syncthreads();
+  }
+}
+
+// victim 3: PACKED fp32 arithmetic on 4-byte LDS words (re and im planes as in victim 2, combined into 2-vectors in registers);
+// victim 4: SCALAR arithmetic on 8-byte LDS words (the buffer of victim 0, split into floats in registers) -- which half of victim 0 matters?
+__global__ __launch_bounds__(384) void victim_packed_b32(f2* out, int tiles) {
+  __shared__ float br[96 * 32], bi[96 * 32];
+  const int tid = threadIdx.x;
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    for (int t = tid; t < 96 * 32; t += 384) { br[t] = hashf(tile, 2 * t); bi[t] = hashf(tile, 2 * t + 1); }
+    __syncthreads();
+    for (int r = 0; r < 6; ++r) {
+      const int k = tid / 32, v = tid % 32;
+      f2 x[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) x[m] = f2{br[((k + 12 * m + r) % 96) * 32 + v], bi[((k + 12 * m + r) % 96) * 32 + v]};
+      const f2 a0 = x[0] + x[4], a1 = x[0] - x[4], a2 = x[2] + x[6], a3 = x[2] - x[6];
+      const f2 b0 = x[1] + x[5], b1 = x[1] - x[5], b2 = x[3] + x[7], b3 = x[3] - x[7];
+      const f2 c0 = a0 + a2, c1 = a0 - a2, c2 = f2{a1.x - a3.y, a1.y + a3.x}, c3 = f2{a1.x + a3.y, a1.y - a3.x};
+      const f2 d0 = b0 + b2, d1 = b0 - b2, d2 = f2{b1.x - b3.y, b1.y + b3.x}, d3 = f2{b1.x + b3.y, b1.y - b3.x};
+      x[0] = (c0 + d0) * 0.35f; x[4] = (c0 - d0) * 0.35f; x[1] = (c2 + d2 * 0.70710678f) * 0.35f; x[5] = (c2 - d2 * 0.70710678f) * 0.35f;
+      x[2] = f2{c1.x - d1.y, c1.y + d1.x} * 0.35f; x[6] = f2{c1.x + d1.y, c1.y - d1.x} * 0.35f; x[3] = (c3 + d3 * 0.70710678f) * 0.35f; x[7] = (c3 - d3 * 0.70710678f) * 0.35f;
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < 8; ++m) { br[((k + 12 * m + r) % 96) * 32 + v] = x[m].x; bi[((k + 12 * m + r) % 96) * 32 + v] = x[m].y; }
+      __syncthreads();
+    }
+    for (int t = tid; t < 96 * 32; t += 384) out[(size_t)tile * 96 * 32 + t] = f2{br[t], bi[t]};
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(384) void victim_scalar_b64(f2* out, int tiles) {
+  __shared__ f2 buf[96 * 32];
+  const int tid = threadIdx.x;
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    for (int t = tid; t < 96 * 32; t += 384) buf[t] = f2{hashf(tile, 2 * t), hashf(tile, 2 * t + 1)};
+    __syncthreads();
+    for (int r = 0; r < 6; ++r) {
+      const int k = tid / 32, v = tid % 32;
+      float xr[8], xi[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) { const f2 q = buf[((k + 12 * m + r) % 96) * 32 + v]; xr[m] = q.x; xi[m] = q.y; }
+      const float a0r = xr[0] + xr[4], a0i = xi[0] + xi[4], a1r = xr[0] - xr[4], a1i = xi[0] - xi[4], a2r = xr[2] + xr[6], a2i = xi[2] + xi[6], a3r = xr[2] - xr[6], a3i = xi[2] - xi[6];
+      const float b0r = xr[1] + xr[5], b0i = xi[1] + xi[5], b1r = xr[1] - xr[5], b1i = xi[1] - xi[5], b2r = xr[3] + xr[7], b2i = xi[3] + xi[7], b3r = xr[3] - xr[7], b3i = xi[3] - xi[7];
+      const float c0r = a0r + a2r, c0i = a0i + a2i, c1r = a0r - a2r, c1i = a0i - a2i, c2r = a1r - a3i, c2i = a1i + a3r, c3r = a1r + a3i, c3i = a1i - a3r;
+      const float d0r = b0r + b2r, d0i = b0i + b2i, d1r = b0r - b2r, d1i = b0i - b2i, d2r = b1r - b3i, d2i = b1i + b3r, d3r = b1r + b3i, d3i = b1i - b3r;
+      const float h = 0.70710678f, g = 0.35f;
+      xr[0] = (c0r + d0r) * g; xi[0] = (c0i + d0i) * g; xr[4] = (c0r - d0r) * g; xi[4] = (c0i - d0i) * g;
+      xr[1] = (c2r + d2r * h) * g; xi[1] = (c2i + d2i * h) * g; xr[5] = (c2r - d2r * h) * g; xi[5] = (c2i - d2i * h) * g;
+      xr[2] = (c1r - d1i) * g; xi[2] = (c1i + d1r) * g; xr[6] = (c1r + d1i) * g; xi[6] = (c1i - d1r) * g;
+      xr[3] = (c3r + d3r * h) * g; xi[3] = (c3i + d3i * h) * g; xr[7] = (c3r - d3r * h) * g; xi[7] = (c3i - d3i * h) * g;
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < 8; ++m) buf[((k + 12 * m + r) % 96) * 32 + v] = f2{xr[m], xi[m]};
+      __syncthreads();
+    }
+    for (int t = tid; t < 96 * 32; t += 384) out[(size_t)tile * 96 * 32 + t] = buf[t];
+    __syncthreads();
+  }
+}
+
+// synthetic aggressor 2: nothing but MFMA on registers (accumulators may live in AGPRs); no LDS, no memory traffic.  Short work groups of 2 waves.
+typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+typedef float pf32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(128) void mfma_aggressor(float* sink, int reps, int lds_touch) {
+  extern __shared__ __attribute__((aligned(16))) char mlds[];
+  pbf16x8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (threadIdx.x + i)); b[i] = (__bf16)(0.002f * (threadIdx.x ^ i)); }
+  pf32x16 acc0 = {}, acc1 = {};
+  for (int r = 0; r < reps; ++r) {
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc1, 0, 0, 0);
+  }
+  float sfin = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sfin += acc0[i] + acc1[i];
+  if (lds_touch) { reinterpret_cast<float*>(mlds)[threadIdx.x] = sfin; __syncthreads(); sfin += reinterpret_cast<float*>(mlds)[threadIdx.x ^ 1]; }
+  if (sfin == 12345.f) sink[0] = sfin;
+}
+
+// synthetic aggressor 3: MFMA operands fetched from LDS right in front of the MFMAs (what every tiled GEMM does): per step four 16-byte
+// fragment reads, a wait, four MFMAs.  No LDS-DMA, no global traffic inside the loop.
+typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
+typedef float pf32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(128) void lds_mfma_aggressor(float* sink, int reps) {
+  __shared__ __attribute__((aligned(16))) pf32x4 frag[2304];      // 36 KB
+  for (int i = threadIdx.x; i < 2304; i += 128) frag[i] = pf32x4{0.001f * i, 0.002f, 0.003f * (i & 7), 1.f};
+  __syncthreads();
+  pf32x16 acc0 = {}, acc1 = {};
+  const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) pf32x4*)frag + (threadIdx.x & 63) * 16u;
+  for (int r = 0; r < reps; ++r) {
+    pf32x4 a0, a1, b0, b1;
+    const unsigned ad = base + (unsigned)((r * 4096) % 28672);
+    asm volatile("ds_read_b128 %0, %1" : "=v"(a0) : "v"(ad) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(a1) : "v"(ad) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(b0) : "v"(ad) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(b1) : "v"(ad) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)::"memory");
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pf16x8, a0), __builtin_bit_cast(pf16x8, b0), acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pf16x8, a0), __builtin_bit_cast(pf16x8, b1), acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pf16x8, a1), __builtin_bit_cast(pf16x8, b1), acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pf16x8, a1), __builtin_bit_cast(pf16x8, b0), acc1, 0, 0, 0);
+  }
+  float sfin = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sfin += acc0[i] + acc1[i];
+  if (sfin == 12345.f) sink[0] = sfin;
+}
+
 // victim 1: the library's in-LDS 96-point FFT over 32 channel lanes (conv_fft_common.h), on hash data
 __global__ __launch_bounds__(384) void victim_fft(f2* out, const jcm::cfft::cf* twg, int tiles) {
   using namespace jcm::cfft;
@@ -150,7 +289,10 @@ int main(int argc, char** argv) {
   hipStream_t s1, s2;
   CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
   auto run_victim = [&](f2* o) {
-    if (victim == 0) hipLaunchKernelGGL(victim_generic, dim3(grid), dim3(384), 0, s1, o, tiles);
+    if (victim == 3) hipLaunchKernelGGL(victim_packed_b32, dim3(grid), dim3(384), 0, s1, o, tiles);
+    else if (victim == 4) hipLaunchKernelGGL(victim_scalar_b64, dim3(grid), dim3(384), 0, s1, o, tiles);
+    else if (victim == 2) hipLaunchKernelGGL(victim_scalar, dim3(grid), dim3(384), 0, s1, o, tiles);
+    else if (victim == 0) hipLaunchKernelGGL(victim_generic, dim3(grid), dim3(384), 0, s1, o, tiles);
     else hipLaunchKernelGGL(victim_fft, dim3(grid), dim3(384), 0, s1, o, tw, tiles);
   };
   unsigned long long total = 0, bad_iters = 0, h[16];
@@ -161,6 +303,12 @@ int main(int argc, char** argv) {
       run_victim(rep ? o2 : o1);
     }
     hipLaunchKernelGGL(compare_kernel, dim3(1024), dim3(256), 0, s1, (const uint4*)o1, (const uint4*)o2, n / 2, cnt);
+    if (aggr == 66) {      // synthetic [ds_read_b128 -> MFMA] aggressor; argv[5] = steps per wave
+      for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(lds_mfma_aggressor, dim3(3136), dim3(128), 0, s2, sp, Cout);
+    } else
+    if (aggr >= 64) {      // synthetic MFMA aggressor: aggr = 64 (+1: with 36 KB of LDS allocated and touched); argv[5] = MFMA pairs per wave
+      for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(mfma_aggressor, dim3(3136), dim3(128), (aggr & 1) ? 36864 : 0, s2, sp, Cout, aggr & 1);
+    } else
     if (aggr >= 16) {      // synthetic LDS-DMA aggressor: aggr = 16 + mode, argv[5] = in-range pieces per wave, argv[6] = out-of-range pieces per wave
       for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(dma_aggressor, dim3(3136), dim3(128), 36864, s2, (const uint4*)cpa, (unsigned)cpn, aggr - 16, Cout, Cin, sp);
     } else
@@ -180,6 +328,6 @@ int main(int argc, char** argv) {
     }
   }
   CK(hipDeviceSynchronize());
-  printf("victim %s, aggressor %d, small kernels %d: %llu of %d iterations differ (%llu pieces)\n", victim ? "fft96" : "generic", aggr, small, bad_iters, iters, total);
+  printf("victim %s, aggressor %d, small kernels %d: %llu of %d iterations differ (%llu pieces)\n", victim == 4 ? "scalar+b64" : victim == 3 ? "packed+b32" : victim == 2 ? "scalar" : victim ? "fft96" : "generic", aggr, small, bad_iters, iters, total);
   return bad_iters ? 3 : 0;
 }

@@ -178,6 +178,16 @@ if AGGR and 'conv6' in refs:
         torch.cuda.synchronize()
         print('  conv6 on engine 0 beside torch aggressor %-5s: mismatching runs %d of %d' % (kind, len(count_bad(res, refs['conv6'])), LITERS), flush=True)
         del res
+SKIPS = os.environ.get('DET_SKIPS')      # comma-separated debug_skip masks: engine 1 repeats model() with those launch groups left out, engine 0 the victim layer
+if SKIPS:
+    vict = os.environ.get('DET_SKIP_VICTIM', 'conv5')
+    VIT = int(os.environ.get('DET_VICTIM_ITERS', '300'))
+    for mask in SKIPS.split(','):
+        engs[1].set_option('debug_skip', int(mask))
+        res = run_both(lambda e: layer_call(e, vict if e == 0 else 'model'), VIT)
+        print('  victim %s beside model(debug_skip=%s): mismatching runs %d of %d' % (vict, mask, len(count_bad(res[0], refs[vict])), VIT), flush=True)
+        del res
+    engs[1].set_option('debug_skip', 0)
 VICTIM = os.environ.get('DET_VICTIM')      # 'victim:aggressor' scopes: engine 0 repeats the first while engine 1 repeats the second; only engine 0 is checked
 if VICTIM:
     va, vb = VICTIM.split(':')

@@ -8,6 +8,6 @@ SRC=${3:-conv_strip_bf16.hip}
 BASE=${SRC%.hip}
 make -s
 mkdir -p ../exp build_exp
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $2 -c $SRC -o build_exp/${BASE}_$1.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Xclang -target-feature -Xclang -packed-fp32-ops $2 -c $SRC -o build_exp/${BASE}_$1.o
 OBJS=$(ls build/*.o | grep -v "build/${BASE}.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../exp/libjcm_$1.so $OBJS build_exp/${BASE}_$1.o -L/opt/rocm/lib -lhipfft -ldl

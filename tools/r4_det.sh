@@ -1,10 +1,11 @@
 #!/bin/bash
-P=tools/coresidency_probe
-echo "mode 1: 6 in-range pieces per wave at the start";            timeout 300 $P 300 0 17 0 6 0 | tail -1
-echo "mode 3: 6 in-range + 6 out-of-range";                        timeout 300 $P 300 0 19 0 6 6 | tail -1
-echo "mode 2: 6 out-of-range only";                                timeout 300 $P 300 0 18 0 0 6 | tail -1
-echo "mode 5: pause, then 6 in-range";                             timeout 300 $P 300 0 21 0 6 0 | tail -1
-echo "mode 7: pause, 6 in-range + 6 out-of-range";                 timeout 300 $P 300 0 23 0 6 6 | tail -1
-echo "mode 11: 6 in-range + 6 out-of-range, pause before the end"; timeout 300 $P 300 0 27 0 6 6 | tail -1
-echo "mode 1: 18 in-range pieces per wave";                        timeout 300 $P 300 0 17 0 18 0 | tail -1
-echo "mode 0: no DMA at all (LDS allocated)";                      timeout 300 $P 300 0 16 0 0 0 | tail -1
+export JCM_LIB=$GRAFT_REPO_ROOT/joint-cnn-mrf_amd/exp/libjcm_nopk.so
+for prec in fp32 bf16; do
+  DET_CHAIN=0 DET_ITERS=400 DET_LAYER_ITERS=100 DET_ONLY=model,conv5,conv6 timeout 900 python tools/determinism.py $prec 2>&1 | grep "two engines: engine . pd\|layer "
+done
+for v in base nopk; do
+  if [ $v = base ]; then unset JCM_LIB; else export JCM_LIB=$GRAFT_REPO_ROOT/joint-cnn-mrf_amd/exp/libjcm_nopk.so; fi
+  for dt in fp32 bf16; do
+    python bench.py --dtype $dt --steps 20 --warmup 5 --cpu-images 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v $dt img/s %.0f ms/step %.2f gemm launch_ms %.3f' % (d['value'], d['ms_per_step'], d['roofline']['launch_ms']))"
+  done
+done
