@@ -151,12 +151,12 @@ def resident_inputs(B, rank, dev):
     return x, torso
 
 
-def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32_conv=None, config_name=None, micro_batch=None, conv9_fft=None):
+def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32_conv=None, config_name=None, micro_batch=None, conv9_fft=None, fft_single=None):
     """Time `args.steps` steps of one (dtype, batch) configuration; returns the result dict on
     rank 0 (None elsewhere).  Timed region: barrier + synchronize on both sides, max over ranks.
     f32_conv='split': the fp32 path with its 60x90 9x9 layers on the bf16x6 split kernel (conv_split.hip).
     B is the rank's batch per step; jcm_forward walks it in micro-batches (256 bf16 / 64 fp32 unless `micro_batch`)."""
-    eng = Engine(device=local_rank, precision=dtype, f32_conv=f32_conv, micro_batch=micro_batch, conv9_fft=conv9_fft).load_params(params)
+    eng = Engine(device=local_rank, precision=dtype, f32_conv=f32_conv, micro_batch=micro_batch, conv9_fft=conv9_fft, fft_single=fft_single).load_params(params)
     x, torso = resident_inputs(B, rank, dev)                                          # resident in HBM
 
     def step():
@@ -210,8 +210,10 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
         if freq_domain:
             # wide 9x9 layers in the frequency domain: the dominant kernel is the channel GEMM cgemm_split_kernel (one complex matrix
             # product per frequency); its own executed bf16-MFMA FLOPs and algorithmic HBM bytes, its own HIP events
-            np_parts = 2                      # 16-bit parts per operand: two bf16 (bf16 handles) or two scaled fp16 (fp32 handles), three products either way
-            nprod = 3
+            # 16-bit parts per operand and real products per multiply: fp32 handles two scaled fp16 parts / three products; bf16 handles ONE scaled fp16
+            # part / one product (default, "fft_single") or two bf16 parts / three products
+            single = dtype == 'bf16' and fft_single is not False
+            np_parts, nprod = (1, 1) if single else (2, 3)
             mrows = min(B, mb)
             mt = gemm_mtile(dtype, mrows)
             rows_p = -(-mrows // mt) * mt
@@ -221,9 +223,8 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
                 tot_ms, tot_n = tot_ms + ms, tot_n + n
                 tot_flops32 += 8.0 * cin * cout * FFT_FREQS * mrows * n              # complex multiply-adds as real FLOPs
                 tot_flops += nprod * 8.0 * cin * cout * FFT_FREQS * mrows * n        # executed on the bf16 matrix cores
-                # split activation spectra (2 B x np parts x re|im per channel), filter spectra (8 B per complex either way: two bf16 parts on bf16
-                # handles, fp32 split inside the kernel on fp32 handles), product spectra (complex fp32)
-                tot_bytes += FFT_FREQS * (rows_p * cin * 4 * np_parts + cin * cout * 8 + mrows * cout * 8) * n
+                # activation spectra and filter spectra (2 B x np parts x re|im per complex number), product spectra (complex fp32)
+                tot_bytes += FFT_FREQS * (rows_p * cin * 4 * np_parts + cin * cout * 4 * np_parts + mrows * cout * 8) * n
             gemm = {'np_parts': np_parts, 'products': nprod, 'flops32_per_launch': tot_flops32 / max(tot_n, 1), 'bytes_per_launch': tot_bytes / max(tot_n, 1)}
         launch_ms = tot_ms / max(tot_n, 1)                     # average launch duration (HIP events, launch stream)
         flops_launch = tot_flops / max(tot_n, 1)               # average algorithmic (direct kernels) / executed (split GEMM) FLOPs per launch
@@ -239,7 +240,7 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
             'value': value, 'ms_per_step': dt / args.steps * 1e3,
             # the arithmetic the path computes in: exact fp32 MFMA chain, or fp32 operands carried as 16-bit parts
             # 'f32' alone = the exact fp32 MFMA accumulation chain; the default fp32 route carries every fp32 spectrum as two scaled fp16 parts (22 bits)
-            'dtype': (('bf16(bf16x2 spectra, fft)' if freq_domain else 'bf16') if dtype == 'bf16' else
+            'dtype': ((('bf16(fp16 spectra, fft)' if fft_single is not False else 'bf16(bf16x2 spectra, fft)') if freq_domain else 'bf16') if dtype == 'bf16' else
                       {'split': 'f32(bf16x6)', 'split16': 'f32(fp16x3)'}.get(f32_conv, 'f32(fp16x2 spectra, fft)' if freq_domain else 'f32')),
             'config': {'workload': '%s: batch=%d/GPU synthetic 480x720x3, part detector%s forward + argmax, %s%s%s'
                                    % (config_name or ('configs[1]' if dtype == 'fp32' else 'configs[2]'), B, ' + spatial model' if use_sm else '',
@@ -255,7 +256,7 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
                                                      'conv_igemm 9x9, 60x90 maps (conv4_fullres + conv5 launches; %s)')
                                    % ('hand-written, v_mfma_f32_32x32x16_%s, operands split into %d %s parts (%d real products per multiply), one complex [B x Cin] x [Cin x Cout] '
                                       'product per frequency of the 64 x 96 transform = 3136 per launch, LDS-DMA operand rings; achieved = executed bf16 MFMA FLOPs / GEMM time'
-                                      % ('bf16' if dtype == 'bf16' else 'f16', gemm['np_parts'], 'bf16' if dtype == 'bf16' else 'fp16 (scaled spectra)', gemm['products'])
+                                      % ('bf16' if dtype == 'bf16' and gemm['np_parts'] == 2 else 'f16', gemm['np_parts'], 'bf16' if dtype == 'bf16' and gemm['np_parts'] == 2 else 'fp16 (scaled spectra)', gemm['products'])
                                       if freq_domain else
                                       'fp32 operands as 3 bf16 parts, 6 x bf16 MFMA 32x32x16 per k16 step, 12x32 patch x 256 ch; achieved = executed bf16 MFMA FLOPs (6 x algorithmic) against the bf16 peak'
                                       if f32_conv == 'split' else
@@ -269,7 +270,7 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
                          'launch_ms': launch_ms, 'launches': tot_n, 'flops_per_launch': flops_launch},
         }
         rf = out['roofline']
-        tkey = '%s_b%d_fft' % (dtype, min(B, mb)) if freq_domain else '%s%s_b%d' % (dtype, '_' + f32_conv if f32_conv in ('split', 'split16') else '', min(B, mb))
+        tkey = '%s_b%d_fft%s' % (dtype, min(B, mb), '_bf16x2' if dtype == 'bf16' and fft_single is False else '') if freq_domain else '%s%s_b%d' % (dtype, '_' + f32_conv if f32_conv in ('split', 'split16') else '', min(B, mb))
         rf['traffic'], rf['traffic_source'] = pmc_traffic(tkey) if not args.debug else (None, None)
         # SURVEY 8d's yardstick beside the executed-work one: images/s x 413.19 GFLOP (the direct-convolution FLOPs of the path) / MFMA peak of the handle's type
         rf['algorithmic_frac'] = out['path_tflops'] / PEAK_TFLOPS[dtype]
@@ -490,11 +491,14 @@ def main():
         head_batch = args.batch or (64 if head_dtype == 'fp32' else 256)
         head = run_config(args, head_dtype, head_batch, params, world, rank, local_rank, dev, use_sm,
                           f32_conv=args.f32_conv if head_dtype == 'fp32' else None, micro_batch=args.micro_batch)
-    second = second_mfma = split = split16 = config3 = chain = sus = None
+    second = second_x2 = second_mfma = split = split16 = config3 = chain = sus = None
     if args.dtype is None and not args.debug and not args.global_batch:
         second = run_config(args, 'bf16', args.batch or 256, params, world, rank, local_rank, dev, use_sm)
         # configs[2] on the direct bf16 MFMA kernels only (conv_strip_bf16_kernel for the 9x9 layers): the north star's
         # "9x9 + pairwise pass on the bf16 matrix cores" with its own driver-timed roofline
+        if world == 1:      # the round-3 operand form of the channel GEMM (two bf16 parts, three products) beside the default
+            second_x2 = run_config(args, 'bf16', args.batch or 256, params, world, rank, local_rank, dev, use_sm, fft_single=False,
+                                   config_name='configs[2], channel GEMM on two bf16 parts (fft_single=0)')
         second_mfma = run_config(args, 'bf16', args.batch or 256, params, world, rank, local_rank, dev, use_sm, conv9_fft=False,
                                  config_name='configs[2], direct bf16 MFMA kernels only (conv9_fft=0)')
         # configs[3]: a FIXED global batch of 2048 images sharded over the ranks (main.py:511,516-517), bf16, micro-batches of 256;
@@ -535,6 +539,8 @@ def main():
                'roofline': head['roofline']}
         if second is not None:
             out['bf16_config2'] = second
+        if second_x2 is not None:
+            out['bf16_config2_bf16x2'] = second_x2
         if second_mfma is not None:
             out['bf16_config2_mfma'] = second_mfma
         if config3 is not None:

@@ -79,6 +79,10 @@ int jcm_abi_version(void);
  *              products, 22 significant bits) of spectra scaled by powers of two -- one scale per image, derived from a rigorous bound, so an
  *              image's result does not depend on its batch; a handle with training state uses one scale per tensor.  0 = three bf16 parts,
  *              six products, no scaling (the same accuracy class at 1.3x the GEMM time).  Changing it drops the cached filter spectra.
+ * "fft_single": any time, default 1 (bf16 handles): the channel product of the frequency-domain route on ONE fp16 part per operand -- spectra scaled
+ *              by one power of two per image (the bound of "fft_fp16"), rounded once to fp16's 11 significant bits, one real product per multiply,
+ *              32 channels per GEMM stage.  The layer's input and output tensors are bf16 (8 bits): the spectra are eight times finer.
+ *              0 = two bf16 parts per operand, three products (rounds 2-3).  Changing it drops the cached filter spectra.
  * "sm_algo"  : any time; the pairwise convolutions of the spatial model (main.py:83-87): 3 (default) = every FFT in LDS
  *              (sm_fused.hip); 2 = rocFFT with a split, row-pruned inverse; 0 = rocFFT 2-D transforms; 1 = direct
  *              sliding-window kernel.  All four are HIP paths that pass the same parity tests; the training step always

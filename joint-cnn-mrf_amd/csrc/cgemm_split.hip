@@ -46,10 +46,12 @@ namespace cg {
 
 // NP parts per operand; WM x WN waves, FM x FN 32x32 fragments per wave; R stages in LDS; WF32: the W operand arrives as fp32 and is split here
 // HALF: the parts are fp16 (11 significant bits each; operands scaled into the fp16 range by the producers) instead of bf16
-template <int NP_, int WM_, int WN_, int FM_, int FN_, int R_, bool WF32_ = false, bool HALF_ = false>
+// K32: ONE 16-bit part per operand; the two "part" planes of the NP = 2 layout hold the two 16-channel halves of a 32-channel stage instead
+// (product s = half s of X times half s of W): the same LDS image, the same DMA pieces, two products per stage that both advance K.
+template <int NP_, int WM_, int WN_, int FM_, int FN_, int R_, bool WF32_ = false, bool HALF_ = false, bool K32_ = false>
 struct Cfg {
   static constexpr int NP = NP_, WM = WM_, WN = WN_, FM = FM_, FN = FN_, R = R_;
-  static constexpr bool WF32 = WF32_, HALF = HALF_;
+  static constexpr bool WF32 = WF32_, HALF = HALF_, K32 = K32_;
   static constexpr int NW = WM * WN, NT = 64 * NW;
   static constexpr int MT = 32 * WM * FM, NTL = 32 * WN * FN;
   static constexpr int XST = 4 * NP * MT, WST = 4 * NP * NTL;      // 16-byte units per stage: [re|im][part][k-half][rows]
@@ -60,7 +62,8 @@ struct Cfg {
   static constexpr int WL = WF32 ? 2 * UPT : 0;                     // ... = 16-byte global loads per thread per stage
   static constexpr int WSRC = 4 * NTL * 32;                         // WF32: bytes of a stage of fp32 filter spectra
   static constexpr int LDS_BYTES = R * STAGE * 16;
-  static constexpr int NPROD = NP == 3 ? 6 : NP == 2 ? 3 : 1;
+  static constexpr int NPROD = K32 ? 2 : NP == 3 ? 6 : NP == 2 ? 3 : 1;
+  static_assert(!K32 || (NP == 2 && !WF32), "K32 reuses the two-plane layout");
   static_assert(NTL == 128 || NTL == 32, "column tiles the filter spectra are laid out for");
   static_assert(XST % (64 * NW) == 0 && (WF32 || WST % (64 * NW) == 0), "whole DMA pieces per wave");
   static_assert(!WF32 || (R == 2 && (UPT == 1 || UPT == 2) && 4 * NTL % NT == 0), "in-kernel split: double buffer, one or two units per thread");
@@ -69,8 +72,13 @@ struct Cfg {
 };
 
 // (x part, w part) of product s.  Any order gives the same sum up to fp32 rounding of the accumulator, which carries the whole K sum.
+template <class C> __device__ __forceinline__ constexpr int cprod_x(int s);
+template <class C> __device__ __forceinline__ constexpr int cprod_w(int s);
 template <int NP> __device__ __forceinline__ constexpr int prod_x(int s) { return NP == 3 ? (s == 0 ? 0 : s == 1 ? 1 : s == 2 ? 2 : s == 3 ? 1 : s == 4 ? 0 : 0) : NP == 2 ? (s == 0 ? 0 : s == 1 ? 1 : 0) : 0; }
 template <int NP> __device__ __forceinline__ constexpr int prod_w(int s) { return NP == 3 ? (s == 0 ? 2 : s == 1 ? 1 : s == 2 ? 0 : s == 3 ? 0 : s == 4 ? 1 : 0) : NP == 2 ? (s == 0 ? 1 : s == 1 ? 0 : 0) : 0; }
+
+template <class C> __device__ __forceinline__ constexpr int cprod_x(int s) { return C::K32 ? s : prod_x<C::NP>(s); }
+template <class C> __device__ __forceinline__ constexpr int cprod_w(int s) { return C::K32 ? s : prod_w<C::NP>(s); }
 
 template <int OFF> __device__ __forceinline__ void lds_read(f32x4& v, unsigned addr) {
   static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
@@ -274,11 +282,11 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
     const int ns = slot == 0 ? R - 1 : slot - 1;
     if (g + R - 1 < KC) issue(g + R - 1, ns);
     f32x4 xr[2][FM], xi[2][FM], wr[2][FN], wi[2][FN];
-    frag_load<C, prod_x<NP>(0), prod_w<NP>(0)>(xr[0], xi[0], wr[0], wi[0], xaddr, waddr);
+    frag_load<C, cprod_x<C>(0), cprod_w<C>(0)>(xr[0], xi[0], wr[0], wi[0], xaddr, waddr);
     auto product = [&](auto sc) __attribute__((always_inline)) {
       constexpr int S = decltype(sc)::value, cur = S & 1;
       if constexpr (S + 1 < C::NPROD) {
-        frag_load<C, prod_x<NP>(S + 1), prod_w<NP>(S + 1)>(xr[cur ^ 1], xi[cur ^ 1], wr[cur ^ 1], wi[cur ^ 1], xaddr, waddr);
+        frag_load<C, cprod_x<C>(S + 1), cprod_w<C>(S + 1)>(xr[cur ^ 1], xi[cur ^ 1], wr[cur ^ 1], wi[cur ^ 1], xaddr, waddr);
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(2 * FM + 2 * FN) : "memory");
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -376,6 +384,12 @@ using CfgH64 = Cfg<2, 1, 4, 2, 1, CGEMM_H64_R, false, true>;      // <= 64 image
 using CfgH128 = Cfg<2, 2, 2, 2, 2, 2, false, true>;               // 65 .. 128 images per tile
 using CfgH64T = Cfg<2, 2, 1, 1, 1, 3, false, true>;               // Cout <= 32 (the logits layer): 64 x 32 tile, two waves
 
+// bf16 handles, np = 5: ONE scaled fp16 part per operand (11 significant bits -- eight times finer than the bf16 tensors the layer reads and
+// writes), 32 channels per stage: a third of the matrix-core work of the two-part form and half of its operand bytes.
+using CfgS256 = Cfg<2, 4, 2, 2, 2, 3, false, true, true>;
+using CfgS128 = Cfg<2, 2, 2, 2, 2, 2, false, true, true>;
+using CfgS64 = Cfg<2, 1, 4, 2, 1, 2, false, true, true>;
+
 template <class C> hipError_t launch(const Args& a, hipStream_t st) {
   static LdsAttr attr;
   if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(cgemm_split_kernel<C>), C::LDS_BYTES); e != hipSuccess) return e;
@@ -387,12 +401,13 @@ template <class C> hipError_t launch(const Args& a, hipStream_t st) {
 
 }  // namespace cg
 
-// np: 2 = bf16 handles (two bf16 parts, filter spectra pre-split); 3 = fp32 handles, three bf16 parts; 4 = fp32 handles, two fp16 parts (scaled)
-int cgemm_split_ntile(int np, int Cout) { return np >= 3 && Cout <= 32 ? 32 : 128; }
-int cgemm_split_parts(int np) { return np == 4 ? 2 : np; }
+// np: 2 = bf16 handles, two bf16 parts (filter spectra pre-split); 5 = bf16 handles, ONE scaled fp16 part, 32 channels per stage; 3 = fp32 handles,
+// three bf16 parts; 4 = fp32 handles, two fp16 parts (scaled)
+int cgemm_split_ntile(int np, int Cout) { return (np == 3 || np == 4) && Cout <= 32 ? 32 : 128; }
+int cgemm_split_parts(int np) { return np == 4 ? 2 : np == 5 ? 1 : np; }
 int cgemm_split_mtile(int np, int B, int Cout) {
   if (cgemm_split_ntile(np, Cout) == 32) return 64;
-  if (np == 2) return B > 128 ? 256 : B > 64 ? 128 : 64;
+  if (np == 2 || np == 5) return B > 128 ? 256 : B > 64 ? 128 : 64;
   return B > 64 ? 128 : 64;
 }
 bool cgemm_split_w_fp32(int np) { return np == 3; }
@@ -405,11 +420,13 @@ size_t cgemm_split_w_bytes(int np, int F, int Cin, int Cout) {
 hipError_t cgemm_split(const void* xs, const void* ws, void* y, int np, int F, int B, int Cin, int Cout, int ldy, hipStream_t st) {
   const int ntl = cgemm_split_ntile(np, Cout);
   const int ntiles = (Cout + ntl - 1) / ntl;
-  if ((np != 2 && np != 3 && np != 4) || Cin % 16 || ldy < ntiles * ntl || F < 1 || B < 1) return hipErrorInvalidValue;
+  const int kstep = np == 5 ? 32 : 16;      // channels per stage
+  if ((np < 2 || np > 5) || Cin % kstep || ldy < ntiles * ntl || F < 1 || B < 1) return hipErrorInvalidValue;
   const int MT = cgemm_split_mtile(np, B, Cout);
-  cg::Args a{static_cast<const char*>(xs), static_cast<const char*>(ws), static_cast<float2*>(y), F, B, ldy, Cin / 16, (B + MT - 1) / MT, ntiles};
-  if ((long long)a.KC * 4 * cgemm_split_parts(np) * (MT > ntl ? MT : ntl) * 16 >= (1ll << 31)) return hipErrorInvalidValue;      // buffer descriptor range
+  cg::Args a{static_cast<const char*>(xs), static_cast<const char*>(ws), static_cast<float2*>(y), F, B, ldy, Cin / kstep, (B + MT - 1) / MT, ntiles};
+  if ((long long)a.KC * 8 * (MT > ntl ? MT : ntl) * 16 >= (1ll << 31)) return hipErrorInvalidValue;      // buffer descriptor range (at most 8 units per row and stage)
   if (np == 2) return MT == 256 ? cg::launch<cg::CfgB256>(a, st) : MT == 128 ? cg::launch<cg::CfgB128>(a, st) : cg::launch<cg::CfgB64>(a, st);
+  if (np == 5) return MT == 256 ? cg::launch<cg::CfgS256>(a, st) : MT == 128 ? cg::launch<cg::CfgS128>(a, st) : cg::launch<cg::CfgS64>(a, st);
   if (np == 4) return ntl == 32 ? cg::launch<cg::CfgH64T>(a, st) : MT == 128 ? cg::launch<cg::CfgH128>(a, st) : cg::launch<cg::CfgH64>(a, st);
   if (ntl == 32) return cg::launch<cg::CfgF64T>(a, st);
   return MT == 128 ? cg::launch<cg::CfgF128>(a, st) : cg::launch<cg::CfgF64>(a, st);

@@ -62,9 +62,9 @@ __global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* 
   }
   __syncthreads();
   constexpr int CPT = NP == 0 ? 4 : 8;                        // input channels per thread = one 16-byte unit of the layout
-  constexpr int NPP = NP == 4 ? 2 : NP;                       // 16-byte units per plane
+  constexpr int NPP = NP == 4 ? 2 : NP == 5 ? 1 : NP;         // 16-byte units this thread writes per plane
   float wmul = 1.f;
-  if constexpr (NP == 4) {
+  if constexpr (NP >= 4) {
     int ex = 0;
     const float bound = wscale[0];
     if (bound > 0.f && bound < 3.0e38f) (void)frexpf(bound, &ex);      // bound < 2^ex
@@ -106,9 +106,11 @@ __global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* 
   const int KC = Cin / 16, ntiles = CoutP / ntl;
   const int ci0 = cig * CPT, kc = ci0 >> 4, kg = (ci0 >> 3) & 1, q4 = (ci0 >> 2) & 1, nt = co / ntl, sn = co % ntl;      // q4: 4-channel half (NP = 0)
   // 16-byte units: stride between frequencies, and this thread's units inside one frequency
-  const size_t fstride = (size_t)ntiles * KC * (NP == 0 ? 8 : 4 * NPP) * ntl;
+  // NP = 5: stages of 32 channels, the two planes of the NP = 2 layout = the stage's two 16-channel halves: unit ((c * 2 + half) * 2 + kg) * ntl + column
+  const size_t fstride = NP == 5 ? (size_t)ntiles * (KC >> 1) * 8 * ntl : (size_t)ntiles * KC * (NP == 0 ? 8 : 4 * NPP) * ntl;
   uint4* dst = Ws + (size_t)kx * NY * fstride +
-               (NP == 0 ? (((((size_t)nt * KC + kc) * 2 + 0) * 2 + kg) * 2 + q4) * ntl + sn : ((size_t)nt * KC + kc) * (4 * NPP) * ntl + (size_t)kg * ntl + sn);
+               (NP == 5 ? ((size_t)nt * (KC >> 1) + (kc >> 1)) * 8 * ntl + ((size_t)(kc & 1) * 2 + kg) * ntl + sn :
+                NP == 0 ? (((((size_t)nt * KC + kc) * 2 + 0) * 2 + kg) * 2 + q4) * ntl + sn : ((size_t)nt * KC + kc) * (4 * NPP) * ntl + (size_t)kg * ntl + sn);
   for (int ky = 0; ky < NY; ++ky, dst += fstride) {
     float xr[CPT], xi[CPT];
     cf t[KS - 1];
@@ -126,6 +128,14 @@ __global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* 
       // [re|im][k-half][4-channel half][ntl][4 fp32]: the im unit lies 4 ntl units behind the re unit
       dst[0] = make_uint4(__float_as_uint(xr[0]), __float_as_uint(xr[1]), __float_as_uint(xr[2]), __float_as_uint(xr[3]));
       dst[4 * ntl] = make_uint4(__float_as_uint(xi[0]), __float_as_uint(xi[1]), __float_as_uint(xi[2]), __float_as_uint(xi[3]));
+    } else if constexpr (NP == 5) {
+      float x8[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) x8[c] = xr[c % CPT];
+      dst[0] = round8h(x8, wmul);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) x8[c] = xi[c % CPT];
+      dst[(size_t)4 * ntl] = round8h(x8, wmul);
     } else {
       // [re|im][part][k-half][ntl][8 bf16]
       uint4 u[NPP > 0 ? NPP : 1];
@@ -245,23 +255,23 @@ size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout, int np) {
 }
 hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, int np, bool round_bf16, hipStream_t st, float* wscale) {
   Sizes s;
-  if (!sizes_of(H, W, ks, &s) || Cin % 16 || (np != 2 && np != 3 && np != 4) || (np == 4 && !wscale)) return hipErrorInvalidValue;
+  if (!sizes_of(H, W, ks, &s) || Cin % 16 || np < 2 || np > 5 || (np >= 4 && !wscale) || (np == 5 && Cin % 32)) return hipErrorInvalidValue;
   const int ntl = cgemm_split_ntile(np, Cout), CoutP = padn(Cout, ntl);
   const size_t cpt = cgemm_split_w_fp32(np) ? 4 : 8;      // thread = (4 or 8 input channels: one 16-byte unit, output channel); one kx per block
   const dim3 grid((unsigned)(((size_t)Cin / cpt * CoutP + 255) / 256), (unsigned)(s.NX / 2 + 1));
   uint4* dst = static_cast<uint4*>(wf);
   const int rb = round_bf16 ? 1 : 0;
   const bool f32 = cgemm_split_w_fp32(np);      // np = 3: unsplit fp32 spectra, the GEMM splits them
-  if (np == 4) {
+  if (np >= 4) {
     if (hipError_t e = hipMemsetAsync(wscale, 0, 2 * sizeof(float), st); e != hipSuccess) return e;
     const size_t pairs = (size_t)Cin * Cout;
     hipLaunchKernelGGL(weight_bound_kernel, dim3((unsigned)((pairs + 255) / 256 > 1024 ? 1024 : (pairs + 255) / 256)), dim3(256), 0, st, w_hwio, ks * ks, pairs, rb, wscale);
   }
 #define WS_LAUNCH(KS, NPV) hipLaunchKernelGGL((weight_spectra_split_kernel<KS, NPV>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, ntl, s.NY, s.NX, rb, wscale)
   if (ks == 9) {
-    if (f32) WS_LAUNCH(9, 0); else if (np == 2) WS_LAUNCH(9, 2); else if (np == 4) WS_LAUNCH(9, 4); else WS_LAUNCH(9, 3);
+    if (f32) WS_LAUNCH(9, 0); else if (np == 2) WS_LAUNCH(9, 2); else if (np == 4) WS_LAUNCH(9, 4); else if (np == 5) WS_LAUNCH(9, 5); else WS_LAUNCH(9, 3);
   } else {
-    if (f32) WS_LAUNCH(5, 0); else if (np == 2) WS_LAUNCH(5, 2); else if (np == 4) WS_LAUNCH(5, 4); else WS_LAUNCH(5, 3);
+    if (f32) WS_LAUNCH(5, 0); else if (np == 2) WS_LAUNCH(5, 2); else if (np == 4) WS_LAUNCH(5, 4); else if (np == 5) WS_LAUNCH(5, 5); else WS_LAUNCH(5, 3);
   }
 #undef WS_LAUNCH
   return hipGetLastError();
@@ -313,9 +323,9 @@ size_t conv_fft_handover_bytes(const ConvArgs& a, int ks) {      // T[kx][c/16][
 hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int out_layout, void* work, const void* t_in, void* t_next, const FftMerge* merge,
                         hipEvent_t g0, hipEvent_t g1, hipStream_t st, void* xs, bool xs_ready, const Fp16Scale* scp) {
   Sizes s;
-  if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s) || (out_layout == 2 && a0.Cout % 8) || (np != 2 && np != 3 && np != 4)) return hipErrorInvalidValue;
+  if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s) || (out_layout == 2 && a0.Cout % 8) || np < 2 || np > 5 || (np == 5 && a0.Cin % 32)) return hipErrorInvalidValue;
   Fp16Scale sc;
-  if (np == 4) {
+  if (np >= 4) {
     if (!scp || !scp->tmax || !scp->winv || (t_next && !scp->tmax_next)) return hipErrorInvalidValue;
     sc = *scp;
     sc.hf = (float)a0.H;
@@ -369,9 +379,9 @@ size_t conv_fft_xs_bytes(const ConvArgs& a, int ks, int np) {
 }
 hipError_t conv_fft_spectra(const ConvArgs& a0, int ks, int np, void* work, void* xs, hipStream_t st, float* tmax, int common) {
   Sizes s;
-  if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s) || !xs || (np == 4 && !tmax)) return hipErrorInvalidValue;
+  if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s) || !xs || (np >= 4 && !tmax)) return hipErrorInvalidValue;
   Fp16Scale sc;
-  if (np == 4) { sc.tmax = tmax; sc.hf = (float)a0.H; sc.nb = a0.B; sc.common = common; }
+  if (np >= 4) { sc.tmax = tmax; sc.hf = (float)a0.H; sc.nb = a0.B; sc.common = common; }
   ConvArgs a = a0;
   a.CoutP = pad64(a.Cout);
   const Plan3 p = plan_of(a, s, np);

@@ -10,10 +10,12 @@ namespace cfft {
 // 16-byte MFMA operand units -- 8 consecutive channels of one image -- with the units of the work group's IMG images consecutive: 128-byte
 // lines for IMG = 8.  The result is the channel GEMM's LDS image (cgemm_split.hip), which that kernel fetches by LDS-DMA.
 // NP = 4: two FP16 parts of the spectrum times the power-of-two scale derived from max|T| (Fp16Scale, conv_fft_common.h); layout as NP = 2.
+// NP = 5 (bf16 handles): ONE fp16 part of the scaled spectrum; the GEMM's stage is 32 channels and the two "part" planes of the NP = 2 layout hold
+// its two 16-channel halves: this work group's chunk kc is half (kc & 1) of stage kc / 2.
 template <int NY, int NP>
 __global__ __launch_bounds__(colfwd_threads<NY>()) void cols_fwd_split_kernel(const cf* __restrict__ T, uint4* __restrict__ Xs, const cf* __restrict__ twg, int B, int H, int KC, int MT,
                                                             int mtiles, const float* __restrict__ tmax, int common) {
-  constexpr int IMG = colimg<NY>(), CH = IMG * 16, NTC = colfwd_threads<NY>(), NPP = NP == 4 ? 2 : NP;      // NPP: 16-byte units per plane
+  constexpr int IMG = colimg<NY>(), CH = IMG * 16, NTC = colfwd_threads<NY>(), NPP = NP == 4 ? 2 : NP == 5 ? 1 : NP;      // NPP: 16-byte units this work group writes per plane
   extern __shared__ __attribute__((aligned(16))) char smem_cf[];
   cf* buf = reinterpret_cast<cf*>(smem_cf);
   cf* tw = buf + NY * CH;
@@ -24,7 +26,7 @@ __global__ __launch_bounds__(colfwd_threads<NY>()) void cols_fwd_split_kernel(co
   const int b0 = g * IMG, nimg = min(IMG, B - b0);
   twiddles<NY, NTC>(tw, twg, tid);
   __shared__ float xsc[IMG];      // NP = 4: the power of two of each of the work group's images (visible after the barrier below)
-  if constexpr (NP == 4)
+  if constexpr (NP >= 4)
     if (tid < IMG) xsc[tid] = tid < nimg ? fp16_scale(tmax_of(tmax, b0 + tid, B, common), (float)H) : 1.f;
   const cf* src = T + (((size_t)kx * KC + kc) * B + b0) * H * 16;
   for (int t = tid; t < NY * CH; t += NTC) {
@@ -42,7 +44,11 @@ __global__ __launch_bounds__(colfwd_threads<NY>()) void cols_fwd_split_kernel(co
 #pragma unroll
     for (int e = 0; e < 8; ++e) { re[e] = z[e].x; im[e] = z[e].y; }
     uint4 ur[NPP], ui[NPP];
-    if constexpr (NP == 4) {
+    if constexpr (NP == 5) {
+      const float xscale = xsc[img];
+      ur[0] = round8h(re, xscale);
+      ui[0] = round8h(im, xscale);
+    } else if constexpr (NP == 4) {
       const float xscale = xsc[img];      // this image's power of two
       split8h(re, xscale, ur);
       split8h(im, xscale, ui);
@@ -51,11 +57,18 @@ __global__ __launch_bounds__(colfwd_threads<NY>()) void cols_fwd_split_kernel(co
       split8<NPP>(im, ui);
     }
     const size_t f = (size_t)kx * NY + ky;
-    uint4* dst = Xs + (((f * mtiles + mt) * KC + kc) * (4 * NPP) + kg) * MT + r0 + img;      // unit ((c * NPP + p) * 2 + kg) * MT + row
+    if constexpr (NP == 5) {
+      // stage kc / 2 of KC / 2, unit ((c * 2 + half) * 2 + kg) * MT + row with half = kc & 1
+      uint4* dst = Xs + (((f * mtiles + mt) * (KC >> 1) + (kc >> 1)) * 8 + (size_t)(kc & 1) * 2 + kg) * MT + r0 + img;
+      dst[0] = ur[0];
+      dst[(size_t)4 * MT] = ui[0];
+    } else {
+      uint4* dst = Xs + (((f * mtiles + mt) * KC + kc) * (4 * NPP) + kg) * MT + r0 + img;      // unit ((c * NPP + p) * 2 + kg) * MT + row
 #pragma unroll
-    for (int p = 0; p < NPP; ++p) {
-      dst[(size_t)(0 * NPP + p) * 2 * MT] = ur[p];
-      dst[(size_t)(1 * NPP + p) * 2 * MT] = ui[p];
+      for (int p = 0; p < NPP; ++p) {
+        dst[(size_t)(0 * NPP + p) * 2 * MT] = ur[p];
+        dst[(size_t)(1 * NPP + p) * 2 * MT] = ui[p];
+      }
     }
   }
 }
@@ -89,8 +102,12 @@ template <int NY> static hipError_t launch_cols_fwd(const ConvArgs& a, int np, c
   constexpr int lds = (NY * IMG * 16 + NY) * (int)sizeof(cf);
   const int KC = a.Cin / 16, mtiles = (a.B + MT - 1) / MT;
   const dim3 grid((unsigned)(NXH * KC * ((a.B + IMG - 1) / IMG)));
-  static LdsAttr attr2, attr3, attr4;
-  if (np == 2) {
+  static LdsAttr attr2, attr3, attr4, attr5;
+  if (np == 5) {
+    if (!sc.tmax || (KC & 1)) return hipErrorInvalidValue;
+    if (hipError_t e = attr5.ensure(reinterpret_cast<const void*>(cols_fwd_split_kernel<NY, 5>), lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 5>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles, sc.tmax, sc.common);
+  } else if (np == 2) {
     if (hipError_t e = attr2.ensure(reinterpret_cast<const void*>(cols_fwd_split_kernel<NY, 2>), lds); e != hipSuccess) return e;
     hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 2>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles, nullptr, 0);
   } else if (np == 4) {

@@ -177,6 +177,13 @@ __device__ __forceinline__ void split8h(const float (&x)[8], float scale, uint4 
     out[p] = make_uint4((unsigned)h[p][0] | ((unsigned)h[p][1] << 16), (unsigned)h[p][2] | ((unsigned)h[p][3] << 16), (unsigned)h[p][4] | ((unsigned)h[p][5] << 16),
                         (unsigned)h[p][6] | ((unsigned)h[p][7] << 16));
 }
+// ONE fp16 part of x * scale (round to nearest even; 11 significant bits): np = 5, bf16 handles
+__device__ __forceinline__ uint4 round8h(const float (&x)[8], float scale) {
+  unsigned short h[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) h[e] = __builtin_bit_cast(unsigned short, static_cast<_Float16>(x[e] * scale));
+  return make_uint4((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16), (unsigned)h[4] | ((unsigned)h[5] << 16), (unsigned)h[6] | ((unsigned)h[7] << 16));
+}
 template <int NP>
 __device__ __forceinline__ void split8(const float (&x)[8], uint4 (&out)[NP]) {
   unsigned short h[NP][8];

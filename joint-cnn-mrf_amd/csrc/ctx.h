@@ -107,6 +107,7 @@ struct jcm_ctx {
   bool fft_xs_ready = false;         // ... they are there already (data gradient after the weight gradient of the same layer): skip the forward transforms
   const void* fft_merge = nullptr;   // const jcm::FftMerge*: the next frequency-domain layer forms the merged map itself (jcm_pd_forward, conv5)
   int conv9_fft = 1;            // fp32 handles: wide 9x9 layers in the frequency domain (conv_fft.hip) when the shape allows; 0 = fp32 MFMA chain
+  int fft_single = 1;           // bf16 handles: the channel GEMM on ONE scaled fp16 part per operand (np = 5; 0 = two bf16 parts, three products)
   int fft_fp16 = 1;             // fp32 handles: the channel GEMM on two FP16 parts per operand (three products, scaled spectra); 0 = three bf16 parts (six products)
   // device words of the fp16 scaling (kernels.h: Fp16Scale): zeroed floats, one per image of every row-transformed tensor of a call.  They come from
   // blocks of kFftWords floats; a call that needs more than a block holds (a forward of > 20 000 images in one piece) gets further blocks on demand,
@@ -198,8 +199,8 @@ void prof_release_all(jcm_ctx* c, bool destroy);
 // c->fft_w under "<scope>@HxW", packed from L->w_raw when missing or invalidated); the training step uses both for its data gradient.
 bool takes_fft(jcm_ctx* c, const ConvLayer* L, int B, int H, int W);
 bool fft_spectra_valid(jcm_ctx* c, const std::string& scope, int H, int W);
-// operand form of the channel GEMM on this handle (kernels.h): 2 = bf16 handles; fp32 handles: 4 (two fp16 parts, default) or 3 (three bf16 parts)
-inline int fft_np(const jcm_ctx* c) { return c->precision == JCM_PRECISION_BF16 ? 2 : (c->fft_fp16 ? 4 : 3); }
+// operand form of the channel GEMM on this handle (kernels.h): bf16 handles: 5 (one scaled fp16 part, default) or 2 (two bf16 parts); fp32 handles: 4 (two fp16 parts, default) or 3 (three bf16 parts)
+inline int fft_np(const jcm_ctx* c) { return c->precision == JCM_PRECISION_BF16 ? (c->fft_single ? 5 : 2) : (c->fft_fp16 ? 4 : 3); }
 int fft_new_words(jcm_ctx* c, int n, float** w);      // n zeroed device words of the scaling ring (one per image)
 int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const void* x, int B, int H, int W, void* out, int in_layout, int out_layout);
 int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int stride, const void* x, int B, int H, int W, int sub,

@@ -278,7 +278,7 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
   void* xs = c->fft_xs;
   const bool xs_ready = c->fft_xs_ready;
   Fp16Scale sc;
-  if (np == 4) {
+  if (np >= 4) {
     // the word of this layer's input: handed over with t_in / ready spectra, or a fresh one for this layer's own row pass
     sc.tmax = c->fft_tmax_in;
     if ((t_in || xs_ready) && !sc.tmax) return fail(JCM_ERR_STATE, "conv_fft '" + scope + "': a handed-over tensor without its scale word");
@@ -290,7 +290,7 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
   c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; c->fft_xs = nullptr; c->fft_xs_ready = false;
   c->fft_tmax_in = sc.tmax_next;      // the next frequency-domain layer takes t_next (and its word)
   c->fft_last_tmax = sc.tmax;
-  const hipError_t e = conv_fft_f32(a, L->ks, np, in_layout, out_layout, work, t_in, t_next, mg, g0, g1, c->stream, xs, xs_ready, np == 4 ? &sc : nullptr);
+  const hipError_t e = conv_fft_f32(a, L->ks, np, in_layout, out_layout, work, t_in, t_next, mg, g0, g1, c->stream, xs, xs_ready, np >= 4 ? &sc : nullptr);
   if (g0 && g1 && e == hipSuccess) c->prof[scope + "/gemm"].emplace_back(g0, g1);
   else { if (g0) c->event_pool.push_back(g0); if (g1) c->event_pool.push_back(g1); }
   prof_end(c, scope, e0, e1, e == hipSuccess);
@@ -744,6 +744,15 @@ int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
   }
   if (k == "conv9_fft") {  // allowed at any time
     h->conv9_fft = value != 0;
+    return JCM_OK;
+  }
+  if (k == "fft_single") {   // allowed at any time (bf16 handles); the filter spectra have another form: the cache is dropped
+    if ((value != 0) != (h->fft_single != 0)) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      for (auto& kv : h->fft_w) (void)hipFree(kv.second.p);
+      h->fft_w.clear();
+    }
+    h->fft_single = value != 0;
     return JCM_OK;
   }
   if (k == "fft_fp16") {   // allowed at any time; the filter spectra have another form: the cache is dropped

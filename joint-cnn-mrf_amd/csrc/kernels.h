@@ -73,11 +73,12 @@ hipError_t conv_thin_bf16(const ConvArgs& a, hipStream_t st);
 
 // ---- conv_fft.hip : stride-1 SAME convolution (9x9, 5x5) in the frequency domain: in-LDS FFTs (rows, then columns with the operand split
 // fused in) around the channel GEMM of cgemm_split.hip, one complex matrix product per frequency.  a.wp = split filter spectra of this map
-// and kernel size (conv_fft_pack_weights).  np = operand form of the channel GEMM: 2 = two bf16 parts (bf16 handles), 3 = three bf16 parts / six
+// and kernel size (conv_fft_pack_weights).  np = operand form of the channel GEMM: 5 = ONE fp16 part of spectra scaled by powers of two, one product, 32 channels per
+// stage (bf16 handles, default: the tensors on either side of the layer are bf16, an 11-bit spectrum is 8x finer); 2 = two bf16 parts (bf16 handles), 3 = three bf16 parts / six
 // products, 4 = two FP16 parts / three products of spectra scaled by powers of two (fp32 handles; both fp32-class, 4 is the default).
 // Shapes: Cin % 64 == 0, H + k - 1 <= 192, W + k - 1 <= 192.
 //
-// np = 4 scaling (fp16 carries 11 bits over 2^-24 .. 2^16): device words, all written and read on the stream --
+// np = 4 / 5 scaling (fp16 carries 11 bits over 2^-24 .. 2^16): device words, all written and read on the stream --
 //   tmax[b]      : max |T| of image b of the layer's row-transformed input (atomic max by the row pass, or by the previous layer's fused kernel:
 //                  ZERO them before the producer runs); the column pass scales image b by 2^k with H * tmax[b] * 2^k < 2^15 (components of the scaled spectra then stay below sqrt(2) * 2^15 < 65504: conv_fft_common.h), the inverse row
 //                  pass undoes it.  One word per IMAGE: a row of the channel GEMM is one image, so an image's result does not depend on the

@@ -73,16 +73,16 @@ def test_conv_layer_random_shape(case):
     check_bf16_layer(gotb, refb)
 
 
-def check_bf16_layer(got, ref):
-    """got, ref: bf16-valued arrays.  At most one bf16 ulp apart (plus the fp32 accumulation error of the kernel, which
+def check_bf16_layer(got, ref, slack_rel=1e-5, flips=0.02, rms_rel=1e-3):
+    """got, ref: bf16-valued arrays.  At most one bf16 ulp apart (plus the accumulation error of the kernel, which
     is relative to the layer's scale, not to a result that the bias / BatchNorm shift happens to bring near zero), and
-    apart in at most 2 % of the entries."""
+    apart in at most 2 % of the entries.  (The looser arguments are for the frequency-domain route with 11-bit spectra, test_gpu_golden.py.)"""
     ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref), 1e-30))) - 7)
     diff = np.abs(got - ref)
-    slack = 1e-5 * np.abs(ref).max()
+    slack = slack_rel * np.abs(ref).max()
     assert (diff <= 1.001 * ulp + slack).all(), 'more than one bf16 ulp: worst %.3g ulp' % float(((diff - slack) / ulp).max())
-    assert (diff > 0).mean() <= 0.02, 'rounded differently in %.2f %% of the entries' % (100 * (diff > 0).mean())
-    assert np.sqrt(np.mean(diff ** 2)) <= 1e-3 * np.abs(ref).max()
+    assert (diff > 0).mean() <= flips, 'rounded differently in %.2f %% of the entries' % (100 * (diff > 0).mean())
+    assert np.sqrt(np.mean(diff ** 2)) <= rms_rel * np.abs(ref).max()
 
 
 # 82 <= W <= 90 with 9 joints: conv_kxfold_bf16_kernel (kernel columns folded into N); its last tile of an image runs 3, 2 or 1

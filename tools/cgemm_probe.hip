@@ -24,12 +24,12 @@ __host__ __device__ inline float xval(size_t f, int b, int ci, int c, int B, int
 __host__ __device__ inline float wval(size_t f, int ci, int co, int c, int Cin, int Cout) { return hval(((f * Cin + ci) * Cout + co) * 2 + c, 2) * 0.05f; }
 
 // np = 4: two FP16 parts of the value scaled into fp16's range (what the transform passes do, conv_fft.hip)
-#define PARTS(np) ((np) == 4 ? 2 : (np))
-#define SX(np) ((np) == 4 ? 1024.f : 1.f)
-#define SW(np) ((np) == 4 ? 16384.f : 1.f)
+#define PARTS(np) ((np) == 4 ? 2 : (np) == 5 ? 1 : (np))
+#define SX(np) ((np) >= 4 ? 1024.f : 1.f)
+#define SW(np) ((np) >= 4 ? 16384.f : 1.f)
 __device__ inline void split_store(float v, int np, __bf16* dst, size_t pstride) {
   for (int p = 0; p < PARTS(np); ++p) {
-    if (np == 4) {
+    if (np >= 4) {
       const _Float16 q = static_cast<_Float16>(v);
       reinterpret_cast<_Float16*>(dst)[p * pstride] = q;
       v = v - static_cast<float>(q);
@@ -52,7 +52,8 @@ __global__ void pack_x(__bf16* xs, int np, int F, int B, int Cin, int MT, int mt
   for (int c = 0; c < 2; ++c) {
     const float v = row < B ? xval(f, row, ci, c, B, Cin) * SX(np) : 0.f;
     const int npp = PARTS(np);
-    __bf16* dst = xs + (((((f * mtiles + mt) * KC + kc) * (4 * npp) + (size_t)(c * npp) * 2 + kg) * MT + r) * 8 + e);
+    __bf16* dst = np == 5 ? xs + (((((f * mtiles + mt) * (KC / 2) + kc / 2) * 8 + (size_t)(c * 2 + (kc & 1)) * 2 + kg) * MT + r) * 8 + e)
+                          : xs + (((((f * mtiles + mt) * KC + kc) * (4 * npp) + (size_t)(c * npp) * 2 + kg) * MT + r) * 8 + e);
     split_store(v, np, dst, (size_t)2 * MT * 8);
   }
 }
@@ -71,7 +72,8 @@ __global__ void pack_w(void* ws, int np, int f32, int ntl, int F, int Cin, int C
       static_cast<float*>(ws)[((((((f * ntiles + nt) * KC + kc) * 2 + c) * 2 + kg) * 2 + e / 4) * ntl + cn) * 4 + e % 4] = v;
     } else {
       const int npp = PARTS(np);
-      __bf16* dst = static_cast<__bf16*>(ws) + (((((f * ntiles + nt) * KC + kc) * (4 * npp) + (size_t)(c * npp) * 2 + kg) * ntl + cn) * 8 + e);
+      __bf16* dst = np == 5 ? static_cast<__bf16*>(ws) + (((((f * ntiles + nt) * (KC / 2) + kc / 2) * 8 + (size_t)(c * 2 + (kc & 1)) * 2 + kg) * ntl + cn) * 8 + e)
+                            : static_cast<__bf16*>(ws) + (((((f * ntiles + nt) * KC + kc) * (4 * npp) + (size_t)(c * npp) * 2 + kg) * ntl + cn) * 8 + e);
       split_store(v, np, dst, (size_t)2 * ntl * 8);
     }
   }
@@ -165,7 +167,7 @@ int main(int argc, char** argv) {
     got.x /= SX(np) * SW(np); got.y /= SX(np) * SW(np);
     const double err = fmax(fabs(got.x - yr), fabs(got.y - yi));
     const double rms = sqrt((double)Cin) * 0.05 * 0.577 * 0.577 * 1.414;      // typical |y|
-    if (!(err <= (np >= 3 ? 6e-6 : 1e-4) * rms)) { if (bad < 5) printf("MISMATCH f=%zu b=%d co=%d got (%g,%g) want (%g,%g)\n", f, b, co, got.x, got.y, yr, yi); ++bad; }
+    if (!(err <= (np == 5 ? 2e-3 : np >= 3 ? 6e-6 : 1e-4) * rms)) { if (bad < 5) printf("MISMATCH f=%zu b=%d co=%d got (%g,%g) want (%g,%g)\n", f, b, co, got.x, got.y, yr, yi); ++bad; }
     worst = fmax(worst, err / rms);
     scale = rms;
   }
@@ -217,7 +219,7 @@ int main(int argc, char** argv) {
   float ms = 0;
   CK(hipEventElapsedTime(&ms, e0, e1));
   ms /= iters;
-  const double nprod = np == 3 ? 6 : 3;
+  const double nprod = np == 3 ? 6 : np == 5 ? 1 : 3;
   const double flop32 = 8.0 * B * Cin * (double)CoutP * F, bytes = (double)xbytes * B / (mtiles * MT) + wbytes + ybytes;
   printf("  %.3f ms  | %.1f TF fp32-equivalent, %.1f TF executed bf16 (%.1f %% of 2.5 PF) | %.2f GB algorithmic -> %.2f TB/s\n", ms, flop32 / ms / 1e9,
          flop32 * nprod / ms / 1e9, flop32 * nprod / ms / 1e9 / 25.0, bytes / 1e9, bytes / ms / 1e9);
