@@ -5,7 +5,7 @@ are committed under profiles/.
   python profiles/summarize.py stats gpurun_out/prof_r1/r1_results.db  > profiles/rNN_kernel_stats.csv
   python profiles/summarize.py pmc   gpurun_out/pmc_x/x_results.db ... > profiles/rNN_pmc.csv
   python profiles/summarize.py pmc_min 10000 db...   (only dispatches of >= 10 ms: the dominant 60x90 launches)
-  python profiles/summarize.py table profiles/rNN_pmc.csv [profiles/rNN_kernel_stats.csv]   (markdown: bytes, us, TB/s per kernel)
+  python profiles/summarize.py table profiles/rNN_pmc.csv [profiles/rNN_kernel_stats.csv [forwards images]]   (markdown: bytes, us, TB/s per kernel; per-step totals)
 
 `stats` = per-kernel calls / total / average / share (what `--kernel-trace --stats` tabulates);
 `pmc`   = per-kernel, per-counter mean value per dispatch (one --pmc pass per database).
@@ -68,7 +68,7 @@ def trace(db, pattern, last=0):
         print('"%s",%.1f,%.1f' % (short(n), (st - t0) / 1e3, d / 1e3))
 
 
-def table(pmc_csv, stats_csv=None):
+def table(pmc_csv, stats_csv=None, forwards=0, images=1):
     """Markdown table of the HBM-side figures per kernel from a committed pmc CSV: bytes per dispatch = 2 x FETCH_SIZE + WRITE_SIZE
     (both in KB; FETCH_SIZE doubled: gfx950 tallies 128-byte requests at 64 bytes), mean dispatch time of the kernel-trace run if
     `stats_csv` is given (counter passes run slower), achieved TB/s, clock (GRBM_GUI_ACTIVE is summed over the 8 XCDs) and MFMA-busy share."""
@@ -96,11 +96,20 @@ def table(pmc_csv, stats_csv=None):
     print('|---|---|---|---|---|---|---|---|')
     for _, k, n, us, rd, wr, tbs, ghz, busy in sorted(rows, reverse=True):
         print('| `%s` | %d | %.1f | %.0f | %.0f | %.2f | %.2f | %s |' % (k, n, us, rd / 1e6, wr / 1e6, tbs, ghz, busy))
+    if forwards:
+        # per step: everything except the once-per-engine filter-spectra kernels
+        step = [r for r in rows if 'weight_spectra' not in r[1] and 'weight_bound' not in r[1]]
+        b = sum(r[2] * (r[4] + r[5]) for r in step) / forwards
+        t = sum(r[2] * r[3] for r in step) / forwards
+        print()
+        print('**Per step** (%d forwards in the run, %d images per step; filter-spectra kernels excluded): **%.2f GB = %.0f MB per image**, %.2f ms of kernel time '
+              '-> %.2f TB/s = %.0f %% of the 8 TB/s HBM peak.' % (forwards, images, b / 1e9, b / images / 1e6, t / 1e3, b / (t * 1e-6) / 1e12, b / (t * 1e-6) / 8e12 * 100))
+    return rows
 
 
 if __name__ == '__main__':
     if sys.argv[1] == 'table':            # table pmc.csv [kernel_stats.csv]
-        table(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
+        table(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None, int(sys.argv[4]) if len(sys.argv) > 4 else 0, int(sys.argv[5]) if len(sys.argv) > 5 else 1)
     elif sys.argv[1] == 'trace':            # trace db pattern [last]
         trace(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 0)
     elif sys.argv[1] == 'stats':
