@@ -83,6 +83,10 @@ int jcm_abi_version(void);
  *              by one power of two per image (the bound of "fft_fp16"), rounded once to fp16's 11 significant bits, one real product per multiply,
  *              32 channels per GEMM stage.  The layer's input and output tensors are bf16 (8 bits): the spectra are eight times finer.
  *              0 = two bf16 parts per operand, three products (rounds 2-3).  Changing it drops the cached filter spectra.
+ * "fft_t16"  : any time, default 1 (bf16 handles with "fft_single" = 1): the row-transformed tensors between the row and the column passes of
+ *              the frequency-domain route (half of the transform passes' HBM traffic) as complex fp16 in block floating point -- one power-of-two
+ *              scale per (image, row, 64 channels) tile forward and per (image, kx, 64 channels) tile inverse, 11 significant bits like the
+ *              spectra.  0 = complex fp32 (round 3).
  * "sm_algo"  : any time; the pairwise convolutions of the spatial model (main.py:83-87): 3 (default) = every FFT in LDS
  *              (sm_fused.hip); 2 = rocFFT with a split, row-pruned inverse; 0 = rocFFT 2-D transforms; 1 = direct
  *              sliding-window kernel.  All four are HIP paths that pass the same parity tests; the training step always

@@ -278,7 +278,7 @@ hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, in
 }
 // scratch: T (the larger of the two row-transformed tensors) + the split activation spectra Xs + the product spectra Yf
 namespace {
-struct Plan3 { size_t t_bytes, xs_bytes, yf_bytes; int MT, NXH, F, ldy; };
+struct Plan3 { size_t t_bytes, xs_bytes, yf_bytes, sc_fwd_bytes, sc_inv_bytes; int MT, NXH, F, ldy, inv_cb; };
 Plan3 plan_of(const ConvArgs& a, const Sizes& s, int np) {
   Plan3 p;
   p.NXH = s.NX / 2 + 1;
@@ -291,6 +291,10 @@ Plan3 plan_of(const ConvArgs& a, const Sizes& s, int np) {
   p.t_bytes = (size_t)a.B * p.NXH * a.H * cmax * sizeof(cf);
   p.xs_bytes = (size_t)p.F * bp * a.Cin * 4 * cgemm_split_parts(np);
   p.yf_bytes = (size_t)p.F * a.B * p.ldy * sizeof(cf);
+  // tile scale words of the 16-bit T / T' (np = 5, Fp16Scale::t16): one per (image, row, 64 input channels) / (image, kx, inv_cb output channels)
+  p.inv_cb = s.NY > 100 ? 32 : 64;      // colblk<NY>() of the inverse column pass
+  p.sc_fwd_bytes = (size_t)a.B * a.H * (a.Cin / CB) * sizeof(float);
+  p.sc_inv_bytes = (size_t)a.B * p.NXH * (cop / p.inv_cb) * sizeof(float);
   return p;
 }
 size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
@@ -299,7 +303,7 @@ size_t conv_fft_workspace_bytes(const ConvArgs& a, int ks, int np) {
   Sizes s;
   if (!sizes_of(a.H, a.W, ks, &s)) return 0;
   const Plan3 p = plan_of(a, s, np);
-  return align256(p.t_bytes) + align256(p.xs_bytes) + align256(p.yf_bytes);
+  return align256(p.t_bytes) + align256(p.xs_bytes) + align256(p.yf_bytes) + align256(p.sc_fwd_bytes) + align256(p.sc_inv_bytes);
 }
 // Can layer L (a, ks) hand its output to layer L+1 (kernel size ks_next, same map) in row-transformed form?  Same NX for both kernel
 // sizes (always: the size depends on the map only), unpadded channel count, two row buffers in LDS.
@@ -332,6 +336,7 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
     sc.nb = a0.B;
   }
   if ((t_in || t_next) && (in_layout != 0 || out_layout != 0 || (t_next && a0.Cout % CB))) return hipErrorInvalidValue;
+  if (sc.t16 && (np != 5 || in_layout == 0 || out_layout == 0 || xs || t_in || t_next)) return hipErrorInvalidValue;      // 16-bit T / T': bf16 tensors either side, one-part route
   if (merge && in_layout == 2) return hipErrorInvalidValue;      // the merge reads NHWC (fp32 or bf16)
   ConvArgs a = a0;
   a.CoutP = pad64(a.Cout);
@@ -341,6 +346,11 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
   cf* T = reinterpret_cast<cf*>(wk);
   void* Xs = xs ? xs : wk + align256(p.t_bytes);
   cf* Yf = reinterpret_cast<cf*>(wk + align256(p.t_bytes) + align256(p.xs_bytes));
+  if (sc.t16) {
+    sc.t16_fwd = reinterpret_cast<float*>(wk + align256(p.t_bytes) + align256(p.xs_bytes) + align256(p.yf_bytes));
+    sc.t16_inv = reinterpret_cast<float*>(wk + align256(p.t_bytes) + align256(p.xs_bytes) + align256(p.yf_bytes) + align256(p.sc_fwd_bytes));
+    sc.t16_cb = p.inv_cb;
+  }
   if (xs_ready && !xs) return hipErrorInvalidValue;
   int dev = 0;
   if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
@@ -352,9 +362,9 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
   const cf* Tin = t_in ? static_cast<const cf*>(t_in) : T;
   if (!xs_ready) {
     if (merge && !t_in) {
-      cfft_rows_fwd_merge(s.NX, a, *merge, in_layout, T, twx, sc.tmax, st);
+      cfft_rows_fwd_merge(s.NX, a, *merge, in_layout, T, twx, sc.tmax, st, sc.t16_fwd);
     } else if (!t_in) {
-      cfft_rows_fwd(s.NX, a, in_layout, T, twx, sc.tmax, st);
+      cfft_rows_fwd(s.NX, a, in_layout, T, twx, sc.tmax, st, sc.t16_fwd);
     }
     if (hipError_t ce = cfft_cols_fwd(s.NY, a, np, Tin, Xs, twy, p.NXH, p.MT, sc, st); ce != hipSuccess) return ce;
   }
@@ -362,7 +372,7 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
   if (g0 && hipEventRecord(g0, st) != hipSuccess) return hipErrorUnknown;
   if (hipError_t e = cgemm_split(Xs, a.wp, Yf, np, p.F, a.B, a.Cin, a.Cout, p.ldy, st); e != hipSuccess) return e;
   if (g1 && hipEventRecord(g1, st) != hipSuccess) return hipErrorUnknown;
-  cfft_cols_inv(s.NY, a, Yf, T, twy, p.NXH, p.ldy, opad, st);
+  cfft_cols_inv(s.NY, a, Yf, T, twy, p.NXH, p.ldy, opad, st, sc.t16_inv);
   if (t_next) {
     cfft_rows_inv_fwd(s.NX, a, T, static_cast<cf*>(t_next), twx, opad, norm, sc, st);
   } else {

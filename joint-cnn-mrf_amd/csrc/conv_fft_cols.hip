@@ -12,9 +12,10 @@ namespace cfft {
 // NP = 4: two FP16 parts of the spectrum times the power-of-two scale derived from max|T| (Fp16Scale, conv_fft_common.h); layout as NP = 2.
 // NP = 5 (bf16 handles): ONE fp16 part of the scaled spectrum; the GEMM's stage is 32 channels and the two "part" planes of the NP = 2 layout hold
 // its two 16-channel halves: this work group's chunk kc is half (kc & 1) of stage kc / 2.
-template <int NY, int NP>
+// T16 (NP = 5): T arrives as complex fp16 in block floating point, t16[(b H + y) KC/4 + kc/4] = 1 / (scale of the row pass's tile) (conv_fft_common.h).
+template <int NY, int NP, bool T16 = false>
 __global__ __launch_bounds__(colfwd_threads<NY>()) void cols_fwd_split_kernel(const cf* __restrict__ T, uint4* __restrict__ Xs, const cf* __restrict__ twg, int B, int H, int KC, int MT,
-                                                            int mtiles, const float* __restrict__ tmax, int common) {
+                                                            int mtiles, const float* __restrict__ tmax, int common, const float* __restrict__ t16) {
   constexpr int IMG = colimg<NY>(), CH = IMG * 16, NTC = colfwd_threads<NY>(), NPP = NP == 4 ? 2 : NP == 5 ? 1 : NP;      // NPP: 16-byte units this work group writes per plane
   extern __shared__ __attribute__((aligned(16))) char smem_cf[];
   cf* buf = reinterpret_cast<cf*>(smem_cf);
@@ -28,10 +29,32 @@ __global__ __launch_bounds__(colfwd_threads<NY>()) void cols_fwd_split_kernel(co
   __shared__ float xsc[IMG];      // NP = 4: the power of two of each of the work group's images (visible after the barrier below)
   if constexpr (NP >= 4)
     if (tid < IMG) xsc[tid] = tid < nimg ? fp16_scale(tmax_of(tmax, b0 + tid, B, common), (float)H) : 1.f;
-  const cf* src = T + (((size_t)kx * KC + kc) * B + b0) * H * 16;
-  for (int t = tid; t < NY * CH; t += NTC) {
-    const int y = t / CH, v = t % CH, img = v >> 4, c = v & 15;
-    buf[t] = (y < H && img < nimg) ? src[((size_t)img * H + y) * 16 + c] : cf{0.f, 0.f};
+  if constexpr (T16) {
+    float* ssc = reinterpret_cast<float*>(tw + NY);      // 1 / scale of the IMG x H row tiles this work group reads
+    for (int i = tid; i < IMG * H; i += NTC) {
+      const int img = i / H, y = i - img * H;
+      ssc[i] = img < nimg ? t16[((size_t)(b0 + img) * H + y) * (KC >> 2) + (kc >> 2)] : 0.f;
+    }
+    __syncthreads();
+    const uint2* src = reinterpret_cast<const uint2*>(T) + (((size_t)kx * KC + kc) * B + b0) * H * 8;      // 8 bytes = two channels
+    float4* buf4 = reinterpret_cast<float4*>(buf);
+    for (int t = tid; t < NY * (CH / 2); t += NTC) {
+      const int y = t / (CH / 2), v2 = t % (CH / 2), img = v2 >> 3, c2 = v2 & 7;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (y < H && img < nimg) {
+        const uint2 q = src[((size_t)img * H + y) * 8 + c2];
+        const float s = ssc[img * H + y];
+        const cf a = unpack_h2(q.x, s), b2 = unpack_h2(q.y, s);
+        o = make_float4(a.x, a.y, b2.x, b2.y);
+      }
+      buf4[t] = o;
+    }
+  } else {
+    const cf* src = T + (((size_t)kx * KC + kc) * B + b0) * H * 16;
+    for (int t = tid; t < NY * CH; t += NTC) {
+      const int y = t / CH, v = t % CH, img = v >> 4, c = v & 15;
+      buf[t] = (y < H && img < nimg) ? src[((size_t)img * H + y) * 16 + c] : cf{0.f, 0.f};
+    }
   }
   __syncthreads();
   fft<NY, -1, CH, NTC>(buf, tw, tid);
@@ -74,9 +97,10 @@ __global__ __launch_bounds__(colfwd_threads<NY>()) void cols_fwd_split_kernel(co
 }
 
 // ---- columns, inverse: Yf[ky][kx][b][ldy channels] -> T[b][y][kx][c < C], y < H (row y of the output is row y + pad of the circular convolution)
-template <int NY>
+// T16: T' is written as complex fp16 in block floating point, t16[(b NXH + kx) C/CH + cblk] = 1 / (this work group's scale) (conv_fft_common.h)
+template <int NY, bool T16 = false>
 __global__ __launch_bounds__(colinv_threads<NY>()) void cols_inv_kernel(const cf* __restrict__ Yf, cf* __restrict__ T, const cf* __restrict__ twg, int B, int H, int NXH, int C, int ldy,
-                                                      int pad) {
+                                                      int pad, float* __restrict__ t16) {
   constexpr int CH = colblk<NY>(), CB = CH, NTC = colinv_threads<NY>();
   __shared__ cf buf[NY * CH];
   __shared__ cf tw[NY];
@@ -90,9 +114,33 @@ __global__ __launch_bounds__(colinv_threads<NY>()) void cols_inv_kernel(const cf
   }
   __syncthreads();
   fft<NY, 1, CH, NTC>(buf, tw, tid);
-  for (int t = tid; t < H * CH; t += NTC) {
-    const int y = t / CH, v = t % CH;
-    T[((size_t)(b * H + y) * NXH + kx) * C + cblk * CB + v] = buf[pos<NY>(y + pad) * CH + v];
+  if constexpr (T16) {
+    constexpr int KM = (NY * CH + NTC - 1) / NTC;
+    __shared__ float red[NTC / 64];
+    cf val[KM];
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < KM; ++i) {
+      const int t = tid + i * NTC, y = t / CH, v = t % CH;
+      val[i] = cf{0.f, 0.f};
+      if (t < H * CH) {
+        val[i] = buf[pos<NY>(y + pad) * CH + v];
+        m = fmaxf(m, fmaxf(fabsf(val[i].x), fabsf(val[i].y)));
+      }
+    }
+    const float s = bfp_scale(block_max_all<NTC>(m, red, tid));
+    unsigned* dst = reinterpret_cast<unsigned*>(T);
+#pragma unroll
+    for (int i = 0; i < KM; ++i) {
+      const int t = tid + i * NTC, y = t / CH, v = t % CH;
+      if (t < H * CH) dst[((size_t)(b * H + y) * NXH + kx) * C + cblk * CB + v] = pack_h2(val[i].x * s, val[i].y * s);
+    }
+    if (tid == 0) t16[((size_t)b * NXH + kx) * (C / CB) + cblk] = 1.0f / s;
+  } else {
+    for (int t = tid; t < H * CH; t += NTC) {
+      const int y = t / CH, v = t % CH;
+      T[((size_t)(b * H + y) * NXH + kx) * C + cblk * CB + v] = buf[pos<NY>(y + pad) * CH + v];
+    }
   }
 }
 
@@ -102,27 +150,34 @@ template <int NY> static hipError_t launch_cols_fwd(const ConvArgs& a, int np, c
   constexpr int lds = (NY * IMG * 16 + NY) * (int)sizeof(cf);
   const int KC = a.Cin / 16, mtiles = (a.B + MT - 1) / MT;
   const dim3 grid((unsigned)(NXH * KC * ((a.B + IMG - 1) / IMG)));
-  static LdsAttr attr2, attr3, attr4, attr5;
-  if (np == 5) {
+  static LdsAttr attr2, attr3, attr4, attr5, attr5h;
+  if (np == 5 && sc.t16_fwd) {
+    constexpr int lds16 = lds + IMG * NY * (int)sizeof(float);      // + the row tiles' scale words
+    if (!sc.tmax || (KC & 3)) return hipErrorInvalidValue;
+    if (hipError_t e = attr5h.ensure(reinterpret_cast<const void*>(cols_fwd_split_kernel<NY, 5, true>), lds16); e != hipSuccess) return e;
+    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 5, true>), grid, dim3(colfwd_threads<NY>()), lds16, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles, sc.tmax, sc.common, sc.t16_fwd);
+  } else if (np == 5) {
     if (!sc.tmax || (KC & 1)) return hipErrorInvalidValue;
     if (hipError_t e = attr5.ensure(reinterpret_cast<const void*>(cols_fwd_split_kernel<NY, 5>), lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 5>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles, sc.tmax, sc.common);
+    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 5>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles, sc.tmax, sc.common, nullptr);
   } else if (np == 2) {
     if (hipError_t e = attr2.ensure(reinterpret_cast<const void*>(cols_fwd_split_kernel<NY, 2>), lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 2>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles, nullptr, 0);
+    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 2>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles, nullptr, 0, nullptr);
   } else if (np == 4) {
     if (!sc.tmax) return hipErrorInvalidValue;
     if (hipError_t e = attr4.ensure(reinterpret_cast<const void*>(cols_fwd_split_kernel<NY, 4>), lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 4>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles, sc.tmax, sc.common);
+    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 4>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles, sc.tmax, sc.common, nullptr);
   } else {
     if (hipError_t e = attr3.ensure(reinterpret_cast<const void*>(cols_fwd_split_kernel<NY, 3>), lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 3>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles, nullptr, 0);
+    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 3>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles, nullptr, 0, nullptr);
   }
   return hipSuccess;
 }
 // a.CoutP = output channels the inverse passes transform (Cout padded to 64); ldy = channel stride of Yf (Cout padded to the GEMM's N tile)
-template <int NY> static void launch_cols_inv(const ConvArgs& a, const cf* Yf, cf* T, const cf* tw, int NXH, int ldy, int pad, hipStream_t st) {
-  hipLaunchKernelGGL(cols_inv_kernel<NY>, dim3(a.B * NXH * (a.CoutP / colblk<NY>())), dim3(colinv_threads<NY>()), 0, st, Yf, T, tw, a.B, a.H, NXH, a.CoutP, ldy, pad);
+template <int NY> static void launch_cols_inv(const ConvArgs& a, const cf* Yf, cf* T, const cf* tw, int NXH, int ldy, int pad, hipStream_t st, float* t16) {
+  const dim3 grid(a.B * NXH * (a.CoutP / colblk<NY>())), blk(colinv_threads<NY>());
+  if (t16) hipLaunchKernelGGL((cols_inv_kernel<NY, true>), grid, blk, 0, st, Yf, T, tw, a.B, a.H, NXH, a.CoutP, ldy, pad, t16);
+  else hipLaunchKernelGGL((cols_inv_kernel<NY, false>), grid, blk, 0, st, Yf, T, tw, a.B, a.H, NXH, a.CoutP, ldy, pad, nullptr);
 }
 hipError_t cfft_cols_fwd(int NY, const ConvArgs& a, int np, const cf* T, void* Xs, const cf* tw, int NXH, int MT, const Fp16Scale& sc, hipStream_t st) {
   hipError_t e = hipSuccess;
@@ -131,8 +186,8 @@ hipError_t cfft_cols_fwd(int NY, const ConvArgs& a, int np, const cf* T, void* X
 #undef CALL
   return e;
 }
-void cfft_cols_inv(int NY, const ConvArgs& a, const cf* Yf, cf* T, const cf* tw, int NXH, int ldy, int pad, hipStream_t st) {
-#define CALL(N) launch_cols_inv<N>(a, Yf, T, tw, NXH, ldy, pad, st)
+void cfft_cols_inv(int NY, const ConvArgs& a, const cf* Yf, cf* T, const cf* tw, int NXH, int ldy, int pad, hipStream_t st, float* t16) {
+#define CALL(N) launch_cols_inv<N>(a, Yf, T, tw, NXH, ldy, pad, st, t16)
   CFFT_BY_SIZE(NY, CALL)
 #undef CALL
 }

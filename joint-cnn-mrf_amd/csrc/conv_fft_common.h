@@ -76,6 +76,36 @@ __device__ __forceinline__ void twiddles(cf* tw, const cf* __restrict__ twg, int
 }
 
 
+// ---- 16-bit row-transformed tensors ("t16": bf16 handles on the one-part route, np = 5).  T (between the forward row and column pass) and T'
+// (between the inverse column and row pass) are half of the transform passes' HBM traffic as complex fp32.  Here they are complex FP16 in BLOCK
+// FLOATING POINT: the work group that writes a tile -- (image, row, 64 channels, every kx) forward, (image, kx, channel block, every row) inverse --
+// takes the tile's largest |component| m, multiplies by the power of two s with m s in [2^14, 2^15) (exact) and rounds to fp16 (11 significant
+// bits, normal down to 2^-29 of the tile's maximum); 1 / s goes to one device word per tile, which the reading pass multiplies back in (exact).
+// The layer's input and output are bf16 tensors (8 bits), the spectra on this route carry 11 bits already.
+__device__ __forceinline__ float bfp_scale(float m) {
+  int e = 0;
+  if (!(m > 0.f && m < 3.0e38f)) return 1.f;
+  (void)frexpf(m, &e);      // m in [2^(e-1), 2^e)
+  return ldexpf(1.f, 15 - e);
+}
+__device__ __forceinline__ unsigned pack_h2(float a, float b) {
+  return (unsigned)__builtin_bit_cast(unsigned short, static_cast<_Float16>(a)) | ((unsigned)__builtin_bit_cast(unsigned short, static_cast<_Float16>(b)) << 16);
+}
+__device__ __forceinline__ cf unpack_h2(unsigned u, float s) {
+  return cf{static_cast<float>(__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu))) * s, static_cast<float>(__builtin_bit_cast(_Float16, (unsigned short)(u >> 16))) * s};
+}
+// the work group's maximum, known to every thread (one barrier; red[] must not be in use by a stash of the same tile)
+template <int NTH>
+__device__ __forceinline__ float block_max_all(float m, float* red, int tid) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  float r = red[0];
+#pragma unroll
+  for (int w = 1; w < NTH / 64; ++w) r = fmaxf(r, red[w]);
+  return r;
+}
 __device__ __forceinline__ cf bf16pair(unsigned bits) { return cf{__uint_as_float(bits << 16), __uint_as_float(bits & 0xffff0000u)}; }
 // index, in float4 = two channels, of channel pair v (0..31) of 64-channel block cblk in T[kx][c/16][b][y][16]
 __device__ __forceinline__ size_t t_fwd_index(int k, int cblk, int v, int b, int y, int B, int H, int C) {
@@ -95,6 +125,34 @@ __device__ __forceinline__ float rows_fwd_store(const cf* buf, cf* __restrict__ 
     dst[t_fwd_index(k, cblk, v, b, y, B, H, C)] = o;
     m = fmaxf(fmaxf(m, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
   }
+  return m;
+}
+
+// The same tile as complex fp16 in block floating point (t16, bfp_scale above): T16[kx][c/16][b][y][16] of 4 bytes, tinv[(b H + y) C/64 + cblk] = 1 / scale.
+// Returns the thread's largest |component| (of the fp32 values, for the per-image word of the spectra's scale).  One barrier inside.
+template <int NX, int NTH = NT>
+__device__ __forceinline__ float rows_fwd_store16(const cf* buf, void* T, float* __restrict__ tinv, float* red2, int tid, int cblk, int b, int y, int B, int H, int C) {
+  constexpr int CH = CB / 2, NXH = NX / 2 + 1, K = (NXH * CH + NTH - 1) / NTH;
+  uint2* dst = reinterpret_cast<uint2*>(T);
+  float4 o[K];
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int t = tid + i * NTH, k = t / CH, v = t % CH;
+    o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < NXH * CH) {
+      const cf zk = buf[pos<NX>(k) * CH + v], zn = buf[pos<NX>(k == 0 ? 0 : NX - k) * CH + v];
+      o[i] = make_float4(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y), 0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(o[i].x), fabsf(o[i].y))), fmaxf(fabsf(o[i].z), fabsf(o[i].w)));
+    }
+  }
+  const float s = bfp_scale(block_max_all<NTH>(m, red2, tid));
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int t = tid + i * NTH, k = t / CH, v = t % CH;
+    if (t < NXH * CH) dst[t_fwd_index(k, cblk, v, b, y, B, H, C)] = make_uint2(pack_h2(o[i].x * s, o[i].y * s), pack_h2(o[i].z * s, o[i].w * s));
+  }
+  if (tid == 0) tinv[((size_t)b * H + y) * (C / CB) + cblk] = 1.0f / s;
   return m;
 }
 
@@ -227,10 +285,11 @@ int persistent_grid(const void* kernel, int ntiles, int threads);
 // ---- launchers (N = transform length, one of the lengths with a Plan); a.CoutP = output channels the inverse passes transform (Cout
 // padded to 64), ldy = channel stride of the product spectra (Cout padded to the GEMM's N tile)
 // sc: the fp16 scaling of np = 4 (tmax written by the forward row passes, read by the column pass and the inverse row passes); all null otherwise
-void cfft_rows_fwd(int NX, const ConvArgs& a, int layout, cf* T, const cf* tw, float* tmax, hipStream_t st);
-void cfft_rows_fwd_merge(int NX, const ConvArgs& a, const FftMerge& m, int in_layout, cf* T, const cf* tw, float* tmax, hipStream_t st);      // in_layout 0 / 1: NHWC fp32 / bf16
+// t16 (every launcher): the tile scale words of a 16-bit T / T' (null: complex fp32)
+void cfft_rows_fwd(int NX, const ConvArgs& a, int layout, cf* T, const cf* tw, float* tmax, hipStream_t st, float* t16 = nullptr);
+void cfft_rows_fwd_merge(int NX, const ConvArgs& a, const FftMerge& m, int in_layout, cf* T, const cf* tw, float* tmax, hipStream_t st, float* t16 = nullptr);      // in_layout 0 / 1: NHWC fp32 / bf16
 hipError_t cfft_cols_fwd(int NY, const ConvArgs& a, int np, const cf* T, void* Xs, const cf* tw, int NXH, int MT, const Fp16Scale& sc, hipStream_t st);
-void cfft_cols_inv(int NY, const ConvArgs& a, const cf* Yf, cf* T, const cf* tw, int NXH, int ldy, int pad, hipStream_t st);
+void cfft_cols_inv(int NY, const ConvArgs& a, const cf* Yf, cf* T, const cf* tw, int NXH, int ldy, int pad, hipStream_t st, float* t16 = nullptr);
 void cfft_rows_inv(int NX, const ConvArgs& a, int layout, const cf* T, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
 void cfft_rows_inv_fwd(int NX, const ConvArgs& a, const cf* T, cf* Tn, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
 }  // namespace cfft

@@ -13,14 +13,16 @@ namespace cfft {
 // writes it in whole 128-byte lines (8 lanes x float4 = the 16 channels of one (kx, chunk, image, row)).
 // Persistent work groups with register prefetch: the kernel is latency-bound (a tile is 12-23 KB in, 25 KB out, three barriers), so the
 // loads of a work group's NEXT (image, row, channel block) are issued before the FFT of the current one and land while it computes and stores.
-template <int NX, int LAYOUT>
+// T16: T is written as complex fp16 in block floating point, one scale word per tile in t16 (conv_fft_common.h).
+template <int NX, int LAYOUT, bool T16 = false>
 __global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_kernel(const void* __restrict__ in, cf* __restrict__ T, const cf* __restrict__ twg, int B, int H, int W, int C,
-                                                                      int ntiles, float* __restrict__ tmax) {
+                                                                      int ntiles, float* __restrict__ tmax, float* __restrict__ t16) {
   constexpr int CH = CB / 2, NTR = rows_threads<NX>(), K = (NX * CH + NTR - 1) / NTR;
   using Raw = std::conditional_t<LAYOUT == 0, cf, unsigned>;      // what a thread keeps per element: an fp32 channel pair, or two bf16 in one register
   __shared__ cf buf[NX * CH];
   __shared__ cf tw[NX];
   __shared__ float red[NTR / 64];
+  __shared__ float red2[NTR / 64];
   const int tid = threadIdx.x, ncb = C / CB;
   twiddles<NX, NTR>(tw, twg, tid);
   Raw pre[K];
@@ -60,7 +62,9 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_kernel(const void
     __syncthreads();
     fft<NX, -1, CH, NTR>(buf, tw, tid);
     const int cblk = tile % ncb, by = tile / ncb;
-    const float tm = rows_fwd_store<NX, NTR>(buf, T, tid, cblk, by / H, by % H, B, H, C);
+    float tm;
+    if constexpr (T16) tm = rows_fwd_store16<NX, NTR>(buf, T, t16, red2, tid, cblk, by / H, by % H, B, H, C);
+    else tm = rows_fwd_store<NX, NTR>(buf, T, tid, cblk, by / H, by % H, B, H, C);
     if (tmax) wave_max_stash(tm, red);
     __syncthreads();      // every wave is done reading buf
     if (tmax) stash_to_word<NTR>(red, tmax + by / H);      // the word of this tile's image
@@ -86,10 +90,10 @@ template <> struct MergeVec<true> {
     for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(u[i] << 16); f[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u); }
   }
 };
-template <int NX, bool BF>
+template <int NX, bool BF, bool T16 = false>
 __global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_merge_kernel(const void* __restrict__ x1, const void* __restrict__ x2, int H2, int W2,
                                                             const void* __restrict__ x3, int H3, int W3, cf* __restrict__ T, const cf* __restrict__ twg, int B, int H,
-                                                            int W, int C, float sy2, float sx2, float sy3, float sx3, float* __restrict__ tmax) {
+                                                            int W, int C, float sy2, float sx2, float sy3, float sx3, float* __restrict__ tmax, float* __restrict__ t16) {
   using V = MergeVec<BF>;
   using Raw = typename V::Raw;
   constexpr int CH = CB / 2, NTR = rows_threads<NX>(), VN = V::N, CQ = CB / VN;      // CQ items per pixel of the 64-channel block
@@ -138,35 +142,47 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_merge_kernel(cons
   }
   __syncthreads();
   fft<NX, -1, CH, NTR>(buf, tw, tid);
-  const float tm = rows_fwd_store<NX, NTR>(buf, T, tid, cblk, b, y, B, H, C);
+  float tm;
+  if constexpr (T16) {
+    __shared__ float red2[NTR / 64];
+    tm = rows_fwd_store16<NX, NTR>(buf, T, t16, red2, tid, cblk, b, y, B, H, C);
+  } else {
+    tm = rows_fwd_store<NX, NTR>(buf, T, tid, cblk, b, y, B, H, C);
+  }
   if (tmax) block_max_to<NTR>(tm, tmax + b, red, tid);      // one atomic per work group at most (skipped when the word already holds more)
 }
 
 
-template <int NX> static void launch_rows_fwd(const ConvArgs& a, int layout, cf* T, const cf* tw, float* tmax, hipStream_t st) {
+template <int NX> static void launch_rows_fwd(const ConvArgs& a, int layout, cf* T, const cf* tw, float* tmax, hipStream_t st, float* t16) {
   const int ntiles = a.B * a.H * (a.Cin / CB);
-  const void* fn = layout == 0 ? reinterpret_cast<const void*>(rows_fwd_kernel<NX, 0>) : layout == 1 ? reinterpret_cast<const void*>(rows_fwd_kernel<NX, 1>)
-                                                                                                  : reinterpret_cast<const void*>(rows_fwd_kernel<NX, 2>);
-  const dim3 grid(persistent_grid(fn, ntiles, rows_threads<NX>()));
-  if (layout == 0) hipLaunchKernelGGL((rows_fwd_kernel<NX, 0>), grid, dim3(rows_threads<NX>()), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin, ntiles, tmax);
-  else if (layout == 1) hipLaunchKernelGGL((rows_fwd_kernel<NX, 1>), grid, dim3(rows_threads<NX>()), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin, ntiles, tmax);
-  else hipLaunchKernelGGL((rows_fwd_kernel<NX, 2>), grid, dim3(rows_threads<NX>()), 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin, ntiles, tmax);
+  const dim3 blk(rows_threads<NX>());
+#define RF_LAUNCH(L, H16)                                                                                                              \
+  do {                                                                                                                                 \
+    const dim3 grid(persistent_grid(reinterpret_cast<const void*>(rows_fwd_kernel<NX, L, H16>), ntiles, rows_threads<NX>()));          \
+    hipLaunchKernelGGL((rows_fwd_kernel<NX, L, H16>), grid, blk, 0, st, a.x, T, tw, a.B, a.H, a.W, a.Cin, ntiles, tmax, t16);          \
+  } while (0)
+  if (layout == 0) RF_LAUNCH(0, false);      // (fp32 handles keep T in fp32)
+  else if (layout == 1) { if (t16) RF_LAUNCH(1, true); else RF_LAUNCH(1, false); }
+  else { if (t16) RF_LAUNCH(2, true); else RF_LAUNCH(2, false); }
+#undef RF_LAUNCH
 }
-template <int NX> static void launch_rows_fwd_merge(const ConvArgs& a, const FftMerge& m, int in_layout, cf* T, const cf* tw, float* tmax, hipStream_t st) {
+template <int NX> static void launch_rows_fwd_merge(const ConvArgs& a, const FftMerge& m, int in_layout, cf* T, const cf* tw, float* tmax, hipStream_t st, float* t16) {
   const dim3 grid(a.B * a.H * (a.Cin / CB)), blk(rows_threads<NX>());
   const float sy2 = (float)m.H2 / (float)a.H, sx2 = (float)m.W2 / (float)a.W, sy3 = (float)m.H3 / (float)a.H, sx3 = (float)m.W3 / (float)a.W;
-  if (in_layout == 1)
-    hipLaunchKernelGGL((rows_fwd_merge_kernel<NX, true>), grid, blk, 0, st, a.x, m.x2, m.H2, m.W2, m.x3, m.H3, m.W3, T, tw, a.B, a.H, a.W, a.Cin, sy2, sx2, sy3, sx3, tmax);
+  if (in_layout == 1 && t16)
+    hipLaunchKernelGGL((rows_fwd_merge_kernel<NX, true, true>), grid, blk, 0, st, a.x, m.x2, m.H2, m.W2, m.x3, m.H3, m.W3, T, tw, a.B, a.H, a.W, a.Cin, sy2, sx2, sy3, sx3, tmax, t16);
+  else if (in_layout == 1)
+    hipLaunchKernelGGL((rows_fwd_merge_kernel<NX, true>), grid, blk, 0, st, a.x, m.x2, m.H2, m.W2, m.x3, m.H3, m.W3, T, tw, a.B, a.H, a.W, a.Cin, sy2, sx2, sy3, sx3, tmax, nullptr);
   else
-    hipLaunchKernelGGL((rows_fwd_merge_kernel<NX, false>), grid, blk, 0, st, a.x, m.x2, m.H2, m.W2, m.x3, m.H3, m.W3, T, tw, a.B, a.H, a.W, a.Cin, sy2, sx2, sy3, sx3, tmax);
+    hipLaunchKernelGGL((rows_fwd_merge_kernel<NX, false>), grid, blk, 0, st, a.x, m.x2, m.H2, m.W2, m.x3, m.H3, m.W3, T, tw, a.B, a.H, a.W, a.Cin, sy2, sx2, sy3, sx3, tmax, nullptr);
 }
-void cfft_rows_fwd(int NX, const ConvArgs& a, int layout, cf* T, const cf* tw, float* tmax, hipStream_t st) {
-#define CALL(N) launch_rows_fwd<N>(a, layout, T, tw, tmax, st)
+void cfft_rows_fwd(int NX, const ConvArgs& a, int layout, cf* T, const cf* tw, float* tmax, hipStream_t st, float* t16) {
+#define CALL(N) launch_rows_fwd<N>(a, layout, T, tw, tmax, st, t16)
   CFFT_BY_SIZE(NX, CALL)
 #undef CALL
 }
-void cfft_rows_fwd_merge(int NX, const ConvArgs& a, const FftMerge& m, int in_layout, cf* T, const cf* tw, float* tmax, hipStream_t st) {
-#define CALL(N) launch_rows_fwd_merge<N>(a, m, in_layout, T, tw, tmax, st)
+void cfft_rows_fwd_merge(int NX, const ConvArgs& a, const FftMerge& m, int in_layout, cf* T, const cf* tw, float* tmax, hipStream_t st, float* t16) {
+#define CALL(N) launch_rows_fwd_merge<N>(a, m, in_layout, T, tw, tmax, st, t16)
   CFFT_BY_SIZE(NX, CALL)
 #undef CALL
 }

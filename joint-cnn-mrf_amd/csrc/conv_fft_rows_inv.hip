@@ -7,7 +7,9 @@ namespace cfft {
 // ---- rows, inverse + epilogue: T[b][y][kx][c] (C channels, padded to a multiple of 64) -> out with Cout channels
 // LAYOUT: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar (Cout % 8 == 0)
 // Persistent work groups with register prefetch, as rows_fwd_kernel: the next tile's half spectrum is in flight during the FFT and the stores.
-template <int NX, int LAYOUT>
+// T16: T' arrives as complex fp16 in block floating point; sc.t16_inv[(b NXH + kx) C / sc.t16_cb + c / sc.t16_cb] = 1 / scale of the inverse column
+// pass's (image, kx, sc.t16_cb channels) tile (conv_fft_common.h).
+template <int NX, int LAYOUT, bool T16 = false>
 __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_kernel(const cf* __restrict__ T, void* __restrict__ out, const cf* __restrict__ twg, const float* __restrict__ bias,
                                                       const float* __restrict__ scale, const float* __restrict__ shift, int relu_bn, int H, int W, int C,
                                                       int Cout, int pad, float norm0, int ntiles, Fp16Scale sc) {
@@ -25,17 +27,32 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_kernel(const cf* 
       par[kParMax + i] = relu_bn && i < Cout ? scale[i] : 1.f;
       par[2 * kParMax + i] = relu_bn && i < Cout ? shift[i] : 0.f;
     }
-  float4 pre[K];
+  float4 pre[T16 ? 1 : K];
+  uint2 pre16[T16 ? K : 1];      // T16: two complex fp16 per item ...
+  float pres[T16 ? K : 1];       // ... and 1 / scale of the tile they come from
   float pre_t = 0.f;      // max|T| word of the prefetched tile's image
   const bool per_image = sc.tmax && !sc.common;
   auto fetch = [&](int tile) __attribute__((always_inline)) {
     const int cblk = tile % ncb, by = tile / ncb;      // by = b * H + y
     if (per_image) pre_t = sc.tmax[by / H];
-    const float4* src = reinterpret_cast<const float4*>(T + ((size_t)by * NXH) * C + cblk * CB);
+    if constexpr (T16) {
+      const uint2* src = reinterpret_cast<const uint2*>(T) + (((size_t)by * NXH) * C + cblk * CB) / 2;
+      const int nblk = C / sc.t16_cb;
+      const float* ssrc = sc.t16_inv + (size_t)(by / H) * NXH * nblk;
 #pragma unroll
-    for (int i = 0; i < K; ++i) {
-      const int t = tid + i * NTR, k = t / CH, v = t % CH;
-      pre[i] = t < NXH * CH ? src[(size_t)k * (C / 2) + v] : make_float4(0.f, 0.f, 0.f, 0.f);      // (Ya.re, Ya.im, Yb.re, Yb.im)
+      for (int i = 0; i < K; ++i) {
+        const int t = tid + i * NTR, k = t / CH, v = t % CH;
+        const bool in = t < NXH * CH;
+        pre16[i] = in ? src[(size_t)k * (C / 2) + v] : make_uint2(0u, 0u);
+        pres[i] = in ? ssrc[k * nblk + (cblk * CB + 2 * v) / sc.t16_cb] : 0.f;
+      }
+    } else {
+      const float4* src = reinterpret_cast<const float4*>(T + ((size_t)by * NXH) * C + cblk * CB);
+#pragma unroll
+      for (int i = 0; i < K; ++i) {
+        const int t = tid + i * NTR, k = t / CH, v = t % CH;
+        pre[i] = t < NXH * CH ? src[(size_t)k * (C / 2) + v] : make_float4(0.f, 0.f, 0.f, 0.f);      // (Ya.re, Ya.im, Yb.re, Yb.im)
+      }
     }
   };
   int tile = blockIdx.x;
@@ -47,7 +64,13 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_kernel(const cf* 
     for (int i = 0; i < K; ++i) {
       const int t = tid + i * NTR, k = t / CH, v = t % CH;
       if (t < NXH * CH) {
-        float4 q = pre[i];
+        float4 q;
+        if constexpr (T16) {
+          const cf ya = unpack_h2(pre16[i].x, pres[i]), yb = unpack_h2(pre16[i].y, pres[i]);
+          q = make_float4(ya.x, ya.y, yb.x, yb.y);
+        } else {
+          q = pre[i];
+        }
         const bool edge = k == 0 || k == NX / 2;
         if (edge) { q.y = 0.f; q.w = 0.f; }
         buf[k * CH + v] = cf{q.x - q.w, q.y + q.z};
@@ -218,15 +241,17 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_fwd_kernel(const 
 
 template <int NX> static void launch_rows_inv(const ConvArgs& a, int layout, const cf* T, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st) {
   const int ntiles = a.B * a.H * (a.CoutP / CB);
-  const void* fn = layout == 0 ? reinterpret_cast<const void*>(rows_inv_kernel<NX, 0>) : layout == 1 ? reinterpret_cast<const void*>(rows_inv_kernel<NX, 1>)
-                                                                                                  : reinterpret_cast<const void*>(rows_inv_kernel<NX, 2>);
-  const dim3 grid(persistent_grid(fn, ntiles, rows_threads<NX>()));
-  if (layout == 0)
-    hipLaunchKernelGGL((rows_inv_kernel<NX, 0>), grid, dim3(rows_threads<NX>()), 0, st, T, a.out, tw, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm, ntiles, sc);
-  else if (layout == 1)
-    hipLaunchKernelGGL((rows_inv_kernel<NX, 1>), grid, dim3(rows_threads<NX>()), 0, st, T, a.out, tw, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm, ntiles, sc);
-  else
-    hipLaunchKernelGGL((rows_inv_kernel<NX, 2>), grid, dim3(rows_threads<NX>()), 0, st, T, a.out, tw, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm, ntiles, sc);
+  const dim3 blk(rows_threads<NX>());
+#define RI_LAUNCH(L, H16)                                                                                                                                           \
+  do {                                                                                                                                                              \
+    const dim3 grid(persistent_grid(reinterpret_cast<const void*>(rows_inv_kernel<NX, L, H16>), ntiles, rows_threads<NX>()));                                       \
+    hipLaunchKernelGGL((rows_inv_kernel<NX, L, H16>), grid, blk, 0, st, T, a.out, tw, a.bias, a.scale, a.shift, a.relu_bn, a.H, a.W, a.CoutP, a.Cout, pad, norm, ntiles, sc); \
+  } while (0)
+  const bool h16 = sc.t16_inv != nullptr;
+  if (layout == 0) RI_LAUNCH(0, false);      // (fp32 handles keep T' in fp32)
+  else if (layout == 1) { if (h16) RI_LAUNCH(1, true); else RI_LAUNCH(1, false); }
+  else { if (h16) RI_LAUNCH(2, true); else RI_LAUNCH(2, false); }
+#undef RI_LAUNCH
 }
 template <int NX> static void launch_rows_inv_fwd(const ConvArgs& a, const cf* T, cf* Tn, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st) {
   const int ntiles = a.B * a.H * (a.Cout / CB);

@@ -108,6 +108,7 @@ struct jcm_ctx {
   const void* fft_merge = nullptr;   // const jcm::FftMerge*: the next frequency-domain layer forms the merged map itself (jcm_pd_forward, conv5)
   int conv9_fft = 1;            // fp32 handles: wide 9x9 layers in the frequency domain (conv_fft.hip) when the shape allows; 0 = fp32 MFMA chain
   int fft_single = 1;           // bf16 handles: the channel GEMM on ONE scaled fp16 part per operand (np = 5; 0 = two bf16 parts, three products)
+  int fft_t16 = 1;              // bf16 handles on the one-part route (fft_single): the row-transformed tensors T / T' as complex fp16 in block floating point (Fp16Scale::t16)
   int fft_fp16 = 1;             // fp32 handles: the channel GEMM on two FP16 parts per operand (three products, scaled spectra); 0 = three bf16 parts (six products)
   // device words of the fp16 scaling (kernels.h: Fp16Scale): zeroed floats, one per image of every row-transformed tensor of a call.  They come from
   // blocks of kFftWords floats; a call that needs more than a block holds (a forward of > 20 000 images in one piece) gets further blocks on demand,

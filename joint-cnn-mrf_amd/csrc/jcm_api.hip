@@ -286,6 +286,8 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
     if (t_next) JCM_TRY(fft_new_words(c, B, &sc.tmax_next));
     sc.winv = fw.wscale + 1;
     sc.common = c->train ? 1 : 0;      // a handle with training state: one scale per tensor (the weight gradient sums over the images)
+    // 16-bit T / T' between the row and column passes: bf16 tensors on both sides of the layer, one-part spectra, nothing handed over or kept
+    sc.t16 = (np == 5 && c->fft_t16 && in_layout != 0 && out_layout != 0 && !t_in && !t_next && !xs) ? 1 : 0;
   }
   c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; c->fft_xs = nullptr; c->fft_xs_ready = false;
   c->fft_tmax_in = sc.tmax_next;      // the next frequency-domain layer takes t_next (and its word)
@@ -753,6 +755,10 @@ int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
       h->fft_w.clear();
     }
     h->fft_single = value != 0;
+    return JCM_OK;
+  }
+  if (k == "fft_t16") {   // allowed at any time (bf16 handles, fft_single = 1)
+    h->fft_t16 = value != 0;
     return JCM_OK;
   }
   if (k == "fft_fp16") {   // allowed at any time; the filter spectra have another form: the cache is dropped

@@ -93,6 +93,13 @@ struct Fp16Scale {
   float hf = 0.f;      // H (set by conv_fft_f32)
   int nb = 0;          // B (set by conv_fft_f32)
   int common = 0;
+  // np = 5 with 16-bit row-transformed tensors: t16 = 1 asks conv_fft_f32 for them; it carves the tile scale words out of its workspace and fills the
+  // pointers below for its kernels (T between the forward row and column pass, T' between the inverse column and row pass: complex fp16 in block
+  // floating point, conv_fft_common.h; t16_cb = channels per tile of the inverse column pass).  bf16 in / out layouts only.
+  int t16 = 0;
+  float* t16_fwd = nullptr;
+  float* t16_inv = nullptr;
+  int t16_cb = 64;
 };
 bool conv_fft_supported(const ConvArgs& a, int ks);
 size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout, int np);

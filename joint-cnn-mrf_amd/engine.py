@@ -19,7 +19,7 @@ def _hm_size(n):
 class Engine:
     """Owns a jcm_handle.  All tensor arguments are torch CUDA float32 NHWC, contiguous."""
 
-    def __init__(self, device=0, precision='fp32', n_joints=9, stream=None, f32_conv=None, split_min_wgs=None, micro_batch=None, conv9_fft=None, fft_fp16=None, call_order=None, fft_single=None):
+    def __init__(self, device=0, precision='fp32', n_joints=9, stream=None, f32_conv=None, split_min_wgs=None, micro_batch=None, conv9_fft=None, fft_fp16=None, call_order=None, fft_single=None, fft_t16=None):
         if not torch.cuda.is_available():
             raise RuntimeError('joint-cnn-mrf_amd needs an MI355X (gfx950) GPU; torch.cuda.is_available() is False '
                                'and there is no CPU path')
@@ -46,6 +46,8 @@ class Engine:
             self.set_fft_fp16(fft_fp16)
         if fft_single is not None:    # bf16 engines: False = two bf16 parts per operand of the channel GEMM (three products) instead of one scaled fp16 part
             self.set_option('fft_single', int(bool(fft_single)))
+        if fft_t16 is not None:       # bf16 engines: False = the row-transformed tensors of the frequency-domain route stay complex fp32 (default: fp16 in block floating point)
+            self.set_option('fft_t16', int(bool(fft_t16)))
         if call_order is not None:    # False (debugging): this engine's calls are not ordered against other engines' on the device
             self.set_option('call_order', int(bool(call_order)))
         if split_min_wgs is not None: # 0 forces the split kernels even on grids too small to pay off (parity tests at small batch)
