@@ -83,7 +83,7 @@ def test_bf16_tower_vs_bf16_oracle():
     """Engine(precision='bf16') against oracle.model(..., emulate='bf16') -- weights and every layer input rounded to
     bf16, float64 accumulation, fp32-class epilogue -- at full size (2 images, 512-channel network).  What is left is the
     kernels' fp32 accumulation order plus the activations that round the other way (about 1 % per layer, one bf16 ulp
-    each, carried through five layers) and, on the default engine, the 11-bit spectra of the wide 9x9 layers: measured 3.9e-3 max / 7.6e-4 rms of
+    each, carried through five layers) and, on the default engine, the 11-bit intermediates of the wide 9x9 layers: measured 4.3e-3 max / 8.3e-4 rms of
     the logit scale (3.2e-3 / 6.1e-4 with 16-bit spectra, fft_single=0); the bars are 6e-3 / 1.2e-3, an order of magnitude tighter than the
     distance to the fp32 goldens that test_bf16_path_vs_golden has to allow."""
     from joint_cnn_mrf_amd.engine import Engine
@@ -103,12 +103,13 @@ def test_bf16_tower_vs_bf16_oracle():
     safe = (top2[:, 1, :] - top2[:, 0, :]) > 1.2e-2 * scale
     assert ((flat_ref.argmax(axis=1) == flat_got.argmax(axis=1)) | ~safe).all()
     # per layer inside the tower: conv5 / conv4_halfres fed with the oracle's own (bf16-valued) inputs.  Default engine: ONE fp16 part per
-    # spectrum (11 bits; round 4) -- within one bf16 ulp + 6e-4 of the layer's scale (measured 2-3e-4), at most 10 % of the entries rounded
-    # the other way (measured 6.0-6.5 %), rms <= 3e-4 of the scale (measured 1.2-1.8e-4).
+    # spectrum and 16-bit row-transformed tensors (11 bits at every intermediate; round 4) -- within one bf16 ulp + 1e-3 of the layer's scale
+    # (measured 2-5e-4), at most 12 % of the entries rounded the other way (measured 7.6-8.0 %; 6.0-6.5 % with fft_t16=0), rms <= 4e-4 of the
+    # scale (measured 1.5-2.3e-4).
     from test_gpu_random_shapes import check_bf16_layer
     for scope, tin in (('conv5', 'merge'), ('conv4_halfres', 'conv3_halfres')):
         got = eng.conv_layer(dev(taps[tin]), scope, 1, n_out=512).cpu().numpy().astype(np.float64)
-        check_bf16_layer(got, taps[scope], slack_rel=6e-4, flips=0.10, rms_rel=3e-4)
+        check_bf16_layer(got, taps[scope], slack_rel=1e-3, flips=0.12, rms_rel=4e-4)
     eng.close()
     # the two-part form of rounds 2-3 (16-bit spectra) holds the strict per-layer bar: one ulp + 1e-5 of the scale, <= 2 % flips (measured 0.2 %)
     eng = Engine(device=0, precision='bf16', fft_single=False).load_params(p)
