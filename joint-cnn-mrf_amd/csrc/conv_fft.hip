@@ -22,6 +22,7 @@
 // (consecutive lanes = consecutive channels).  Twiddles come from one table per device, built on the host in double precision.
 // Reference semantics: conv2d SAME stride 1 + bias + ReLU + BatchNorm (main.py:133-135,156-169).
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -211,6 +212,7 @@ int persistent_grid(const void* kernel, int ntiles, int threads) {
     int ncu = 256, per_cu = 0;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (const char* e = std::getenv("JCM_PERSIST_WGS")) { fprintf(stderr, "persistent_grid: occupancy query says %d work groups per CU (%d threads)\n", per_cu, threads); if (std::atoi(e) > 0) per_cu = std::atoi(e); }
     resident = ncu * per_cu;
     std::lock_guard<std::mutex> lk(mu);
     cache[{kernel, dev}] = resident;
@@ -373,9 +375,10 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
   if (hipError_t e = cgemm_split(Xs, a.wp, Yf, np, p.F, a.B, a.Cin, a.Cout, p.ldy, st); e != hipSuccess) return e;
   if (g1 && hipEventRecord(g1, st) != hipSuccess) return hipErrorUnknown;
   cfft_cols_inv(s.NY, a, Yf, T, twy, p.NXH, p.ldy, opad, st, sc.t16_inv);
+  static const bool rows_reg = [] { const char* e = std::getenv("JCM_ROWS_REG"); return !e || std::atoi(e) != 0; }();      // JCM_ROWS_REG=0: the LDS row kernels everywhere (A/B)
   if (t_next) {
     cfft_rows_inv_fwd(s.NX, a, T, static_cast<cf*>(t_next), twx, opad, norm, sc, st);
-  } else {
+  } else if (!(rows_reg && cfft_rows_inv_reg(s.NX, a, out_layout, T, opad, norm, sc, st))) {
     cfft_rows_inv(s.NX, a, out_layout, T, twx, opad, norm, sc, st);
   }
   return hipGetLastError();

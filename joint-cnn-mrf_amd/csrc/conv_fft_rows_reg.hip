@@ -1,0 +1,172 @@
+// Row passes of the frequency-domain convolution with the whole transform in the registers of one thread (fft_reg.h).
+//
+// The LDS row kernels (conv_fft_rows_fwd.hip, conv_fft_rows_inv.hip) give a work group one (image, row, 64 channels) tile: load -> barrier ->
+// radix stage -> barrier -> radix stage -> barrier -> store, one butterfly per thread and stage.  Measured (round 4, SQ_INSTS_* / SQ_WAVE_CYCLES,
+// DESIGN.md 4.1f): 2-3 work groups per CU (80-110 VGPRs at 6 waves per group), 2.2 resident waves per SIMD, the butterflies a fifth of the
+// executed instructions -- the kernels are bound by latency behind barriers, not by HBM (2.2-3.7 TB/s).  Here a THREAD owns one (image, row,
+// channel pair): it loads its half spectrum (one 8- or 16-byte load per kx; consecutive lanes are consecutive channel pairs, so every load or
+// store instruction of a wave is one contiguous run), transforms it in registers with compile-time indices and literal twiddles, and stores its
+// row.  No LDS, no barrier, no index arithmetic; all loads of a thread are in flight before the first butterfly.
+#include "conv_fft_common.h"
+#include "fft_reg.h"
+
+namespace jcm {
+namespace cfft {
+using namespace fftr;
+
+// ---- rows, inverse + epilogue (the contract of rows_inv_kernel, conv_fft_rows_inv.hip): T'[b][y][kx][c] -> out, LAYOUT 0 = fp32 NHWC, 1 = bf16 NHWC,
+// 2 = bf16 planar [B][C/8][H*W][8].  Planar: a 16-byte unit is 8 channels = the words of four threads, so the row goes through a per-wave LDS stage
+// ([m][parity][32 channel pairs] words -- exactly the order in which the units are then read back, 16 bytes per lane, no barrier: one wave writes
+// and reads its own stage) and leaves as 128-byte runs of 8 consecutive pixels per channel plane.
+// TWO threads per (image, row, channel pair) -- a 96-point transform does not fit one thread's registers next to its loads (256 VGPRs: 178 spilled).
+// Thread h of the two takes the outputs of parity h (decimation in frequency):
+//   X[2 m + h] = sum_{n < M} u_h[n] w_M^(n m),   u_h[n] = (Z[n] + (-1)^h Z[n + M]) w_NX^(n h),   M = NX / 2
+// i.e. one radix-2 stage whose twiddle is selected per lane, then an M-point transform in registers.  Z comes from the half spectrum of the
+// channel pair (Z = Y_c + i Y_{c+1}, Hermitian extension): Z[n] and Z[n + M] = Z[NX - (M - n)] need the loaded entries n and M - n, so the
+// entries are consumed in pairs (n, M - n) and both threads load all of them (the same addresses in adjacent lanes: one request).
+template <int NX, int K1, class St>
+__device__ __forceinline__ void inv_rows_out2(const cf (&u)[NX / 2], int h, int W, int pad, St&& store) {
+  constexpr int M = NX / 2, R1 = RPlan<M>::R1, R2 = RPlan<M>::R2;
+  cf o[R2];
+  step2_row<M, 1, K1>(u, o);
+#pragma unroll
+  for (int k2 = 0; k2 < R2; ++k2) {
+    const int xo = 2 * (K1 + R1 * k2) + h - pad;      // output column of X[2 m + h], m = K1 + R1 k2
+    if (xo >= 0 && xo < W) store(K1 + R1 * k2, xo, o[k2]);
+  }
+  __builtin_amdgcn_sched_barrier(0);      // one row of step 2 and its stores at a time (the scheduler otherwise interleaves all R1 rows and spills)
+  if constexpr (K1 + 1 < R1) inv_rows_out2<NX, K1 + 1>(u, h, W, pad, store);
+}
+// u[N] (and u[M - N]) of thread h from the half-spectrum entries N and M - N:  q = (Ya.re, Ya.im, Yb.re, Yb.im)
+template <int NX, int N>
+__device__ __forceinline__ void inv_rows_in2(cf (&u)[NX / 2], const float4& q1, const float4& q2, float sg, bool odd) {
+  constexpr int M = NX / 2;
+  if constexpr (N == 0) {
+    // Z[0] = (Ya[0].re, Yb[0].re), Z[M] = (Ya[M].re, Yb[M].re)   (DC and Nyquist are real); twiddle 1
+    u[0] = cf{fmaf(sg, q2.x, q1.x), fmaf(sg, q2.z, q1.z)};
+  } else {
+    // entry N: Z[N] = (a.x - a.w, a.y + a.z);  entry M - N gives Z[NX - (M - N)] = Z[N + M] = (b.x + b.w, b.z - b.y)
+    const cf zn = cf{q1.x - q1.w, q1.y + q1.z}, znm = cf{q2.x + q2.w, q2.z - q2.y};
+    cf v = cf{fmaf(sg, znm.x, zn.x), fmaf(sg, znm.y, zn.y)};
+    const float wr = odd ? Tw<N, NX>::re : 1.f, wi = odd ? Tw<N, NX>::im : 0.f;
+    u[N] = cf{fmaf(-v.y, wi, v.x * wr), fmaf(v.x, wi, v.y * wr)};
+    if constexpr (2 * N != M) {
+      // entry M - N: Z[M - N] = (b.x - b.w, b.y + b.z);  entry N gives Z[NX - N] = Z[(M - N) + M] = (a.x + a.w, a.z - a.y)
+      const cf zm = cf{q2.x - q2.w, q2.y + q2.z}, zmm = cf{q1.x + q1.w, q1.z - q1.y};
+      v = cf{fmaf(sg, zmm.x, zm.x), fmaf(sg, zmm.y, zm.y)};
+      const float wr2 = odd ? Tw<M - N, NX>::re : 1.f, wi2 = odd ? Tw<M - N, NX>::im : 0.f;
+      u[M - N] = cf{fmaf(-v.y, wi2, v.x * wr2), fmaf(v.x, wi2, v.y * wr2)};
+    }
+  }
+}
+template <int NX, bool T16, int N, class Ld>
+__device__ __forceinline__ void inv_rows_load2(cf (&u)[NX / 2], float sg, bool odd, Ld&& load) {
+  constexpr int M = NX / 2;
+  // the loads go out in batches of LDB pairs (a compiler fence between the batches): hoisting all NX/2+1 of them in front of the arithmetic
+  // costs more registers than the thread has (measured: 390-640 bytes of scratch per lane)
+  constexpr int LDB = 6;
+  if constexpr (N % LDB == 0 && N > 0) __builtin_amdgcn_sched_barrier(0);
+  const float4 q1 = load(N), q2 = load(M - N);
+  inv_rows_in2<NX, N>(u, q1, q2, sg, odd);
+  if constexpr (2 * (N + 1) <= M) inv_rows_load2<NX, T16, N + 1>(u, sg, odd, load);
+}
+
+template <int NX, int LAYOUT, bool T16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void rows_inv_reg_kernel(const void* __restrict__ T, void* __restrict__ out, const float* __restrict__ bias,
+                                                                                              const float* __restrict__ scale, const float* __restrict__ shift, int relu_bn,
+                                                                                              int nrows, int H, int W, int C, int Cout, int pad, float norm0, Fp16Scale sc) {
+  constexpr int NXH = NX / 2 + 1, M = NX / 2;
+  __shared__ __attribute__((aligned(16))) unsigned stage[LAYOUT != 0 ? 4 * M * 64 : 4];      // bf16 outputs: one row (M x 2 pixels x 32 pairs) per wave
+  const int CP = C >> 1;
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int h = (int)(g & 1);
+  const int p = (int)((g >> 1) % CP);
+  const size_t by = (g >> 1) / CP;
+  if (by >= (size_t)nrows) return;
+  const int b = (int)(by / H), c = 2 * p;
+  const bool odd = h != 0;
+  const float sg = odd ? -1.f : 1.f;
+  cf u[M];
+  if constexpr (T16) {
+    const uint2* src = reinterpret_cast<const uint2*>(T) + (by * NXH * C) / 2 + p;
+    const int nblk = C / sc.t16_cb;
+    const float* ssrc = sc.t16_inv + (size_t)b * NXH * nblk + c / sc.t16_cb;
+    auto load = [&](int k) __attribute__((always_inline)) {
+      const uint2 q = src[(size_t)k * CP];
+      const float s = ssrc[k * nblk];
+      const cf ya = unpack_h2(q.x, s), yb = unpack_h2(q.y, s);
+      return make_float4(ya.x, ya.y, yb.x, yb.y);
+    };
+    inv_rows_load2<NX, T16, 0>(u, sg, odd, load);
+  } else {
+    const float4* src = reinterpret_cast<const float4*>(T) + (by * NXH * C) / 2 + p;
+    auto load = [&](int k) __attribute__((always_inline)) { return src[(size_t)k * CP]; };      // (Ya.re, Ya.im, Yb.re, Yb.im)
+    inv_rows_load2<NX, T16, 0>(u, sg, odd, load);
+  }
+  float norm = norm0;
+  if (sc.tmax) norm = norm0 * sc.winv[0] * fp16_unscale(tmax_of(sc.tmax, sc.common ? 0 : b, sc.nb, sc.common), sc.hf);      // powers of two: exact
+  const bool two = c + 1 < Cout;
+  float b0v = 0.f, b1v = 0.f, s0 = 1.f, s1 = 1.f, h0 = 0.f, h1 = 0.f;
+  if (c < Cout) {
+    b0v = bias[c];
+    if (two) b1v = bias[c + 1];
+    if (relu_bn) { s0 = scale[c]; h0 = shift[c]; if (two) { s1 = scale[c + 1]; h1 = shift[c + 1]; } }
+  }
+  step1<M, 1>(u);
+  const int lane = threadIdx.x & 63;
+  unsigned* wst = stage + (LAYOUT != 0 ? (threadIdx.x >> 6) * (M * 64) : 0);
+  auto store = [&](int m, int xo, cf z) __attribute__((always_inline)) {
+    float v0 = fmaf(z.x, norm, b0v), v1 = fmaf(z.y, norm, b1v);      // (single roundings: this kernel is instruction-bound)
+    if (relu_bn) { v0 = fmaf(fmaxf(v0, 0.f), s0, h0); v1 = fmaf(fmaxf(v1, 0.f), s1, h1); }
+    if constexpr (LAYOUT == 0) {
+      *reinterpret_cast<cf*>(static_cast<float*>(out) + (by * W + xo) * Cout + c) = cf{v0, v1};
+    } else {
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      wst[(m * 2 + h) * 32 + (lane >> 1)] = __builtin_bit_cast(unsigned, bf16x2{static_cast<__bf16>(v0), static_cast<__bf16>(v1)});
+    }
+  };
+  if (two || LAYOUT != 0) inv_rows_out2<NX, 0>(u, h, W, pad, store);      // (the launcher takes even channel counts only; bf16: whole 8-channel units)
+  if constexpr (LAYOUT != 0) {
+    // a wave = 32 channel pairs = eight 8-channel units of ONE row (C % 64 == 0); unit q = (m, parity, unit) lies at word 4 q of the stage
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int y = (int)(by % H);
+    const int c0 = c - (lane >> 1) * 2;      // first channel of this wave
+    const uint4* rd = reinterpret_cast<const uint4*>(wst);
+#pragma unroll 4
+    for (int q = lane; q < M * 16; q += 64) {
+      const int m = q >> 4, hh = (q >> 3) & 1, j = q & 7;
+      const int xo = 2 * m + hh - pad, cu = c0 + 8 * j;
+      if (xo >= 0 && xo < W && cu < Cout) {
+        __bf16* o = LAYOUT == 1 ? static_cast<__bf16*>(out) + (by * W + xo) * Cout + cu      // NHWC: the wave's 8 units of a pixel are one 128-byte run
+                                : static_cast<__bf16*>(out) + (((size_t)b * (Cout >> 3) + (cu >> 3)) * H * W + (size_t)y * W + xo) * 8;      // planar: 8 consecutive pixels of a plane
+        *reinterpret_cast<uint4*>(o) = rd[q];
+      }
+    }
+  }
+}
+
+template <int NX> static bool launch_rows_inv_reg(const ConvArgs& a, int layout, const cf* T, int pad, float norm, const Fp16Scale& sc, hipStream_t st) {
+  const int nrows = a.B * a.H;
+  if (a.Cout & 1) return false;      // channel pairs are stored as one word
+  const size_t threads = (size_t)nrows * a.CoutP;      // two threads per channel pair
+  const dim3 grid((unsigned)((threads + 255) / 256)), blk(256);
+  const bool h16 = sc.t16_inv != nullptr;
+#define RR_LAUNCH(L, H16) hipLaunchKernelGGL((rows_inv_reg_kernel<NX, L, H16>), grid, blk, 0, st, T, a.out, a.bias, a.scale, a.shift, a.relu_bn, nrows, a.H, a.W, a.CoutP, a.Cout, pad, norm, sc)
+  if (layout == 0 && !h16) RR_LAUNCH(0, false);
+  else if (layout == 1 && h16 && a.Cout % 8 == 0) RR_LAUNCH(1, true);
+  else if (layout == 1 && a.Cout % 8 == 0) RR_LAUNCH(1, false);
+  else if (layout == 2 && h16 && a.Cout % 8 == 0) RR_LAUNCH(2, true);
+  else if (layout == 2 && a.Cout % 8 == 0) RR_LAUNCH(2, false);
+  else return false;
+#undef RR_LAUNCH
+  return true;
+}
+// true: launched.  false: no register kernel for this (length, layout) -- the caller takes the LDS kernel.
+bool cfft_rows_inv_reg(int NX, const ConvArgs& a, int layout, const cf* T, int pad, float norm, const Fp16Scale& sc, hipStream_t st) {
+  if (NX == 96) return launch_rows_inv_reg<96>(a, layout, T, pad, norm, sc, st);
+  return false;
+}
+
+}  // namespace cfft
+}  // namespace jcm
