@@ -374,7 +374,8 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
   if (g0 && hipEventRecord(g0, st) != hipSuccess) return hipErrorUnknown;
   if (hipError_t e = cgemm_split(Xs, a.wp, Yf, np, p.F, a.B, a.Cin, a.Cout, p.ldy, st); e != hipSuccess) return e;
   if (g1 && hipEventRecord(g1, st) != hipSuccess) return hipErrorUnknown;
-  cfft_cols_inv(s.NY, a, Yf, T, twy, p.NXH, p.ldy, opad, st, sc.t16_inv);
+  static const bool cols_reg = [] { const char* e = std::getenv("JCM_COLS_REG"); return !e || std::atoi(e) != 0; }();      // JCM_COLS_REG=0: the LDS column kernel (A/B)
+  if (!(cols_reg && p.inv_cb == 64 && cfft_cols_inv_reg(s.NY, a, Yf, T, p.NXH, p.ldy, opad, st, sc.t16_inv))) cfft_cols_inv(s.NY, a, Yf, T, twy, p.NXH, p.ldy, opad, st, sc.t16_inv);
   static const bool rows_reg = [] { const char* e = std::getenv("JCM_ROWS_REG"); return !e || std::atoi(e) != 0; }();      // JCM_ROWS_REG=0: the LDS row kernels everywhere (A/B)
   if (t_next) {
     cfft_rows_inv_fwd(s.NX, a, T, static_cast<cf*>(t_next), twx, opad, norm, sc, st);

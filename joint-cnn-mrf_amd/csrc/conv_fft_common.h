@@ -293,6 +293,7 @@ void cfft_cols_inv(int NY, const ConvArgs& a, const cf* Yf, cf* T, const cf* tw,
 void cfft_rows_inv(int NX, const ConvArgs& a, int layout, const cf* T, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
 // the same pass with the transform in the registers of two threads per channel pair (conv_fft_rows_reg.hip); false: no such kernel for this case
 bool cfft_rows_inv_reg(int NX, const ConvArgs& a, int layout, const cf* T, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
+bool cfft_cols_inv_reg(int NY, const ConvArgs& a, const cf* Yf, cf* T, int NXH, int ldy, int pad, hipStream_t st, float* t16);
 void cfft_rows_inv_fwd(int NX, const ConvArgs& a, const cf* T, cf* Tn, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
 }  // namespace cfft
 }  // namespace jcm

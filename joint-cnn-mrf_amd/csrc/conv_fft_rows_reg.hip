@@ -146,6 +146,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// ---- columns, inverse (the contract of cols_inv_kernel, conv_fft_cols.hip): Yf[ky][kx][b][ldy] -> T'[b][y][kx][c], y < H = row y + pad of the circular
+// convolution.  ONE thread per (image, kx, channel): a 64-point transform is 128 registers.  Lanes are consecutive channels: every load is a 512-byte
+// run of Yf, every store a 256- / 512-byte run of T'.  T16: the block-floating-point scale of the (image, kx, 64 channels) tile is the WAVE's maximum.
+template <int NY, int K1>
+__device__ __forceinline__ void inv_cols_rows(cf (&x)[NY]) {      // step 2 in place: x[R2 K1 + k2] <- X[K1 + R1 k2]
+  constexpr int R1 = RPlan<NY>::R1, R2 = RPlan<NY>::R2;
+  cf o[R2];
+  step2_row<NY, 1, K1>(x, o);
+#pragma unroll
+  for (int k2 = 0; k2 < R2; ++k2) x[R2 * K1 + k2] = o[k2];
+  if constexpr (K1 + 1 < R1) inv_cols_rows<NY, K1 + 1>(x);
+}
+template <int NY, bool T16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void cols_inv_reg_kernel(const cf* __restrict__ Yf, void* __restrict__ T, int B, int H, int NXH, int C, int ldy,
+                                                                                              int pad, float* __restrict__ t16) {
+  constexpr int R1 = RPlan<NY>::R1, R2 = RPlan<NY>::R2;
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int c = (int)(g % C);
+  const size_t bk = g / C;
+  const int kx = (int)(bk % NXH), b = (int)(bk / NXH);
+  if (b >= B) return;
+  cf x[NY];
+  const cf* src = Yf + ((size_t)kx * NY * B + b) * ldy + c;
+#pragma unroll
+  for (int ky = 0; ky < NY; ++ky) x[ky] = src[(size_t)ky * B * ldy];
+  step1<NY, 1>(x);
+  inv_cols_rows<NY, 0>(x);
+  float s = 1.f;
+  if constexpr (T16) {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      const int y = (i / R2) + R1 * (i % R2) - pad;      // x[i] = X[i / R2 + R1 (i % R2)]
+      if (y >= 0 && y < H) m = fmaxf(m, fmaxf(fabsf(x[i].x), fabsf(x[i].y)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    s = bfp_scale(m);
+    if ((threadIdx.x & 63) == 0) t16[((size_t)b * NXH + kx) * (C >> 6) + (c >> 6)] = 1.0f / s;
+  }
+#pragma unroll
+  for (int i = 0; i < NY; ++i) {
+    const int y = (i / R2) + R1 * (i % R2) - pad;
+    if (y >= 0 && y < H) {
+      const size_t o = ((size_t)(b * H + y) * NXH + kx) * C + c;
+      if constexpr (T16) reinterpret_cast<unsigned*>(T)[o] = pack_h2(x[i].x * s, x[i].y * s);
+      else reinterpret_cast<cf*>(T)[o] = x[i];
+    }
+  }
+}
+// true: launched (64-point columns, 64-channel tiles)
+bool cfft_cols_inv_reg(int NY, const ConvArgs& a, const cf* Yf, cf* T, int NXH, int ldy, int pad, hipStream_t st, float* t16) {
+  if (NY != 64 || a.CoutP % 64) return false;
+  const size_t threads = (size_t)a.B * NXH * a.CoutP;
+  const dim3 grid((unsigned)((threads + 255) / 256)), blk(256);
+  if (t16) hipLaunchKernelGGL((cols_inv_reg_kernel<64, true>), grid, blk, 0, st, Yf, static_cast<void*>(T), a.B, a.H, NXH, a.CoutP, ldy, pad, t16);
+  else hipLaunchKernelGGL((cols_inv_reg_kernel<64, false>), grid, blk, 0, st, Yf, static_cast<void*>(T), a.B, a.H, NXH, a.CoutP, ldy, pad, nullptr);
+  return true;
+}
+
 template <int NX> static bool launch_rows_inv_reg(const ConvArgs& a, int layout, const cf* T, int pad, float norm, const Fp16Scale& sc, hipStream_t st) {
   const int nrows = a.B * a.H;
   if (a.Cout & 1) return false;      // channel pairs are stored as one word
