@@ -97,7 +97,7 @@ __global__ __launch_bounds__(colfwd_threads<NY>()) void cols_fwd_split_kernel(co
 }
 
 // ---- columns, inverse: Yf[ky][kx][b][ldy channels] -> T[b][y][kx][c < C], y < H (row y of the output is row y + pad of the circular convolution)
-// T16: T' is written as complex fp16 in block floating point, t16[(b NXH + kx) C/CH + cblk] = 1 / (this work group's scale) (conv_fft_common.h)
+// T16: T' is written as complex fp16 in block floating point, t16[(b C/CH + cblk) NXH + kx] = 1 / (this work group's scale) (conv_fft_common.h)
 template <int NY, bool T16 = false>
 __global__ __launch_bounds__(colinv_threads<NY>()) void cols_inv_kernel(const cf* __restrict__ Yf, cf* __restrict__ T, const cf* __restrict__ twg, int B, int H, int NXH, int C, int ldy,
                                                       int pad, float* __restrict__ t16) {
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(colinv_threads<NY>()) void cols_inv_kernel(const cf
       const int t = tid + i * NTC, y = t / CH, v = t % CH;
       if (t < H * CH) dst[((size_t)(b * H + y) * NXH + kx) * C + cblk * CB + v] = pack_h2(val[i].x * s, val[i].y * s);
     }
-    if (tid == 0) t16[((size_t)b * NXH + kx) * (C / CB) + cblk] = 1.0f / s;
+    if (tid == 0) t16[((size_t)b * (C / CB) + cblk) * NXH + kx] = 1.0f / s;
   } else {
     for (int t = tid; t < H * CH; t += NTC) {
       const int y = t / CH, v = t % CH;

@@ -7,7 +7,7 @@ namespace cfft {
 // ---- rows, inverse + epilogue: T[b][y][kx][c] (C channels, padded to a multiple of 64) -> out with Cout channels
 // LAYOUT: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar (Cout % 8 == 0)
 // Persistent work groups with register prefetch, as rows_fwd_kernel: the next tile's half spectrum is in flight during the FFT and the stores.
-// T16: T' arrives as complex fp16 in block floating point; sc.t16_inv[(b NXH + kx) C / sc.t16_cb + c / sc.t16_cb] = 1 / scale of the inverse column
+// T16: T' arrives as complex fp16 in block floating point; sc.t16_inv[(b C / sc.t16_cb + c / sc.t16_cb) NXH + kx] = 1 / scale of the inverse column
 // pass's (image, kx, sc.t16_cb channels) tile (conv_fft_common.h).
 template <int NX, int LAYOUT, bool T16 = false>
 __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_kernel(const cf* __restrict__ T, void* __restrict__ out, const cf* __restrict__ twg, const float* __restrict__ bias,
@@ -38,13 +38,13 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_inv_kernel(const cf* 
     if constexpr (T16) {
       const uint2* src = reinterpret_cast<const uint2*>(T) + (((size_t)by * NXH) * C + cblk * CB) / 2;
       const int nblk = C / sc.t16_cb;
-      const float* ssrc = sc.t16_inv + (size_t)(by / H) * NXH * nblk;
+      const float* ssrc = sc.t16_inv + (size_t)(by / H) * nblk * NXH;
 #pragma unroll
       for (int i = 0; i < K; ++i) {
         const int t = tid + i * NTR, k = t / CH, v = t % CH;
         const bool in = t < NXH * CH;
         pre16[i] = in ? src[(size_t)k * (C / 2) + v] : make_uint2(0u, 0u);
-        pres[i] = in ? ssrc[k * nblk + (cblk * CB + 2 * v) / sc.t16_cb] : 0.f;
+        pres[i] = in ? ssrc[((cblk * CB + 2 * v) / sc.t16_cb) * NXH + k] : 0.f;
       }
     } else {
       const float4* src = reinterpret_cast<const float4*>(T + ((size_t)by * NXH) * C + cblk * CB);

@@ -89,11 +89,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   cf u[M];
   if constexpr (T16) {
     const uint2* src = reinterpret_cast<const uint2*>(T) + (by * NXH * C) / 2 + p;
+    // the scale words of this wave's tile: one 64-channel block of one image (a wave is 32 channel pairs of one row, C % 64 == 0), contiguous over
+    // kx and the same for all lanes: scalar loads
     const int nblk = C / sc.t16_cb;
-    const float* ssrc = sc.t16_inv + (size_t)b * NXH * nblk + c / sc.t16_cb;
+    const float* ssrc = sc.t16_inv + ((size_t)__builtin_amdgcn_readfirstlane(b) * nblk + __builtin_amdgcn_readfirstlane(c / sc.t16_cb)) * NXH;
     auto load = [&](int k) __attribute__((always_inline)) {
       const uint2 q = src[(size_t)k * CP];
-      const float s = ssrc[k * nblk];
+      const float s = ssrc[k];
       const cf ya = unpack_h2(q.x, s), yb = unpack_h2(q.y, s);
       return make_float4(ya.x, ya.y, yb.x, yb.y);
     };
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     s = bfp_scale(m);
-    if ((threadIdx.x & 63) == 0) t16[((size_t)b * NXH + kx) * (C >> 6) + (c >> 6)] = 1.0f / s;
+    if ((threadIdx.x & 63) == 0) t16[((size_t)b * (C >> 6) + (c >> 6)) * NXH + kx] = 1.0f / s;
   }
 #pragma unroll
   for (int i = 0; i < NY; ++i) {
