@@ -22,7 +22,6 @@
 // (consecutive lanes = consecutive channels).  Twiddles come from one table per device, built on the host in double precision.
 // Reference semantics: conv2d SAME stride 1 + bias + ReLU + BatchNorm (main.py:133-135,156-169).
 #include <cmath>
-#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -212,7 +211,6 @@ int persistent_grid(const void* kernel, int ntiles, int threads) {
     int ncu = 256, per_cu = 0;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (const char* e = std::getenv("JCM_PERSIST_WGS")) { fprintf(stderr, "persistent_grid: occupancy query says %d work groups per CU (%d threads)\n", per_cu, threads); if (std::atoi(e) > 0) per_cu = std::atoi(e); }
     resident = ncu * per_cu;
     std::lock_guard<std::mutex> lk(mu);
     cache[{kernel, dev}] = resident;
@@ -374,12 +372,12 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
   if (g0 && hipEventRecord(g0, st) != hipSuccess) return hipErrorUnknown;
   if (hipError_t e = cgemm_split(Xs, a.wp, Yf, np, p.F, a.B, a.Cin, a.Cout, p.ldy, st); e != hipSuccess) return e;
   if (g1 && hipEventRecord(g1, st) != hipSuccess) return hipErrorUnknown;
-  static const bool cols_reg = [] { const char* e = std::getenv("JCM_COLS_REG"); return !e || std::atoi(e) != 0; }();      // JCM_COLS_REG=0: the LDS column kernel (A/B)
-  if (!(cols_reg && p.inv_cb == 64 && cfft_cols_inv_reg(s.NY, a, Yf, T, p.NXH, p.ldy, opad, st, sc.t16_inv))) cfft_cols_inv(s.NY, a, Yf, T, twy, p.NXH, p.ldy, opad, st, sc.t16_inv);
-  static const bool rows_reg = [] { const char* e = std::getenv("JCM_ROWS_REG"); return !e || std::atoi(e) != 0; }();      // JCM_ROWS_REG=0: the LDS row kernels everywhere (A/B)
+  // JCM_FFT_REG=0 (environment, read once): the LDS kernels for every inverse pass -- the A/B arm of the register kernels (conv_fft_rows_reg.hip)
+  static const bool fft_reg = [] { const char* e = std::getenv("JCM_FFT_REG"); return !e || std::atoi(e) != 0; }();
+  if (!(fft_reg && p.inv_cb == 64 && cfft_cols_inv_reg(s.NY, a, Yf, T, p.NXH, p.ldy, opad, st, sc.t16_inv))) cfft_cols_inv(s.NY, a, Yf, T, twy, p.NXH, p.ldy, opad, st, sc.t16_inv);
   if (t_next) {
     cfft_rows_inv_fwd(s.NX, a, T, static_cast<cf*>(t_next), twx, opad, norm, sc, st);
-  } else if (!(rows_reg && cfft_rows_inv_reg(s.NX, a, out_layout, T, opad, norm, sc, st))) {
+  } else if (!(fft_reg && cfft_rows_inv_reg(s.NX, a, out_layout, T, opad, norm, sc, st))) {
     cfft_rows_inv(s.NX, a, out_layout, T, twx, opad, norm, sc, st);
   }
   return hipGetLastError();
