@@ -240,7 +240,7 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
             'value': value, 'ms_per_step': dt / args.steps * 1e3,
             # the arithmetic the path computes in: exact fp32 MFMA chain, or fp32 operands carried as 16-bit parts
             # 'f32' alone = the exact fp32 MFMA accumulation chain; the default fp32 route carries every fp32 spectrum as two scaled fp16 parts (22 bits)
-            'dtype': ((('bf16(fp16 spectra, fft)' if fft_single is not False else 'bf16(bf16x2 spectra, fft)') if freq_domain else 'bf16') if dtype == 'bf16' else
+            'dtype': ((('bf16(fp16 spectra + fp16 row-transformed tensors, fft)' if fft_single is not False else 'bf16(bf16x2 spectra, fft)') if freq_domain else 'bf16') if dtype == 'bf16' else
                       {'split': 'f32(bf16x6)', 'split16': 'f32(fp16x3)'}.get(f32_conv, 'f32(fp16x2 spectra, fft)' if freq_domain else 'f32')),
             'config': {'workload': '%s: batch=%d/GPU synthetic 480x720x3, part detector%s forward + argmax, %s%s%s'
                                    % (config_name or ('configs[1]' if dtype == 'fp32' else 'configs[2]'), B, ' + spatial model' if use_sm else '',

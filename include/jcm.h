@@ -68,6 +68,8 @@ int jcm_abi_version(void);
  *              0 = the direct MFMA kernels.  The training step of an fp32 handle takes the same route (forward, data and weight
  *              gradients); a bf16 handle trains on the direct bf16 kernels.  Filter spectra are built per (layer, map size) on
  *              first use (11.4 GB for the full-width model on 60x90 maps; cache bound: environment JCM_FFT_CACHE_GB, default 64).
+ *              Environment JCM_FFT_REG=0 (read once per process): the LDS kernels for the inverse transform passes instead of the register-resident
+ *              transforms (csrc/conv_fft_rows_reg.hip) -- the A/B arm; results agree to fp32 rounding.
  *              An fp32 handle WITH TRAINING STATE holds more: a second 11.4 GB set of spectra of the flipped, transposed filters for
  *              the data gradient (both sets are repacked after every update) and up to 7.5 GB of weight-gradient scratch (the per-frequency
  *              products P and the column sums R of conv5) in the workspace arena -- about 31 GB beside the 6 GB of activations.
