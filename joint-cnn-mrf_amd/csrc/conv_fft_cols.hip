@@ -12,7 +12,7 @@ namespace cfft {
 // NP = 4: two FP16 parts of the spectrum times the power-of-two scale derived from max|T| (Fp16Scale, conv_fft_common.h); layout as NP = 2.
 // NP = 5 (bf16 handles): ONE fp16 part of the scaled spectrum; the GEMM's stage is 32 channels and the two "part" planes of the NP = 2 layout hold
 // its two 16-channel halves: this work group's chunk kc is half (kc & 1) of stage kc / 2.
-// T16 (NP = 5): T arrives as complex fp16 in block floating point, t16[(b H + y) KC/4 + kc/4] = 1 / (scale of the row pass's tile) (conv_fft_common.h).
+// T16 (NP = 5): T arrives as complex fp16 in block floating point, t16[(b KC/4 + kc/4) H + y] = 1 / (scale of the row pass's tile) (conv_fft_common.h).
 template <int NY, int NP, bool T16 = false>
 __global__ __launch_bounds__(colfwd_threads<NY>()) void cols_fwd_split_kernel(const cf* __restrict__ T, uint4* __restrict__ Xs, const cf* __restrict__ twg, int B, int H, int KC, int MT,
                                                             int mtiles, const float* __restrict__ tmax, int common, const float* __restrict__ t16) {
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(colfwd_threads<NY>()) void cols_fwd_split_kernel(co
     float* ssc = reinterpret_cast<float*>(tw + NY);      // 1 / scale of the IMG x H row tiles this work group reads
     for (int i = tid; i < IMG * H; i += NTC) {
       const int img = i / H, y = i - img * H;
-      ssc[i] = img < nimg ? t16[((size_t)(b0 + img) * H + y) * (KC >> 2) + (kc >> 2)] : 0.f;
+      ssc[i] = img < nimg ? t16[((size_t)(b0 + img) * (KC >> 2) + (kc >> 2)) * H + y] : 0.f;
     }
     __syncthreads();
     const uint2* src = reinterpret_cast<const uint2*>(T) + (((size_t)kx * KC + kc) * B + b0) * H * 8;      // 8 bytes = two channels

@@ -128,7 +128,7 @@ __device__ __forceinline__ float rows_fwd_store(const cf* buf, cf* __restrict__ 
   return m;
 }
 
-// The same tile as complex fp16 in block floating point (t16, bfp_scale above): T16[kx][c/16][b][y][16] of 4 bytes, tinv[(b H + y) C/64 + cblk] = 1 / scale.
+// The same tile as complex fp16 in block floating point (t16, bfp_scale above): T16[kx][c/16][b][y][16] of 4 bytes, tinv[(b C/64 + cblk) H + y] = 1 / scale.
 // Returns the thread's largest |component| (of the fp32 values, for the per-image word of the spectra's scale).  One barrier inside.
 template <int NX, int NTH = NT>
 __device__ __forceinline__ float rows_fwd_store16(const cf* buf, void* T, float* __restrict__ tinv, float* red2, int tid, int cblk, int b, int y, int B, int H, int C) {
@@ -152,7 +152,7 @@ __device__ __forceinline__ float rows_fwd_store16(const cf* buf, void* T, float*
     const int t = tid + i * NTH, k = t / CH, v = t % CH;
     if (t < NXH * CH) dst[t_fwd_index(k, cblk, v, b, y, B, H, C)] = make_uint2(pack_h2(o[i].x * s, o[i].y * s), pack_h2(o[i].z * s, o[i].w * s));
   }
-  if (tid == 0) tinv[((size_t)b * H + y) * (C / CB) + cblk] = 1.0f / s;
+  if (tid == 0) tinv[((size_t)b * (C / CB) + cblk) * H + y] = 1.0f / s;      // [image][64-channel block][row]: contiguous over the rows a column thread reads
   return m;
 }
 
@@ -293,6 +293,8 @@ void cfft_cols_inv(int NY, const ConvArgs& a, const cf* Yf, cf* T, const cf* tw,
 void cfft_rows_inv(int NX, const ConvArgs& a, int layout, const cf* T, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
 // the same pass with the transform in the registers of two threads per channel pair (conv_fft_rows_reg.hip); false: no such kernel for this case
 bool cfft_rows_inv_reg(int NX, const ConvArgs& a, int layout, const cf* T, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
+// forward columns + operand split in registers (np = 4, or np = 5 with fp32 / 16-bit T); false: no such kernel for this case
+bool cfft_cols_fwd_reg(int NY, const ConvArgs& a, int np, const cf* T, void* Xs, int NXH, int MT, const Fp16Scale& sc, hipStream_t st);
 bool cfft_cols_inv_reg(int NY, const ConvArgs& a, const cf* Yf, cf* T, int NXH, int ldy, int pad, hipStream_t st, float* t16);
 void cfft_rows_inv_fwd(int NX, const ConvArgs& a, const cf* T, cf* Tn, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
 }  // namespace cfft
