@@ -1,5 +1,7 @@
 """FULL-SIZE parity on the GPU against the committed float64 golden vectors (2 images,
 512-channel network, FLIC-derived priors): heat maps within 1e-4, argmax bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -110,6 +112,12 @@ def test_bf16_tower_vs_bf16_oracle():
     for scope, tin in (('conv5', 'merge'), ('conv4_halfres', 'conv3_halfres')):
         got = eng.conv_layer(dev(taps[tin]), scope, 1, n_out=512).cpu().numpy().astype(np.float64)
         check_bf16_layer(got, taps[scope], slack_rel=1e-3, flips=0.12, rms_rel=4e-4)
+    eng.close()
+    # 11-bit spectra with fp32 row-transformed tensors (fft_t16=0; the default of the first half of round 4): measured 6.0-6.5 % / 1.2-1.8e-4
+    eng = Engine(device=0, precision='bf16', fft_t16=False).load_params(p)
+    for scope, tin in (('conv5', 'merge'), ('conv4_halfres', 'conv3_halfres')):
+        got = eng.conv_layer(dev(taps[tin]), scope, 1, n_out=512).cpu().numpy().astype(np.float64)
+        check_bf16_layer(got, taps[scope], slack_rel=6e-4, flips=0.10, rms_rel=3e-4)
     eng.close()
     # the two-part form of rounds 2-3 (16-bit spectra) holds the strict per-layer bar: one ulp + 1e-5 of the scale, <= 2 % flips (measured 0.2 %)
     eng = Engine(device=0, precision='bf16', fft_single=False).load_params(p)
@@ -416,3 +424,16 @@ def test_two_processes_one_gpu_soak(precision):
     if precision == 'fp32':
         np.testing.assert_allclose(res[0][1], O.spatial_softmax(load('full_sm_logits_trained').astype(np.float64)), atol=1e-4, rtol=0)
         np.testing.assert_array_equal(res[0][2], load('full_sm_coords_trained'))
+
+
+def test_lds_transform_kernels_arm():
+    """JCM_FFT_REG=0 (read once per process) sends the inverse passes of the 64 x 96 transforms through the LDS kernels instead of the register-resident
+    transforms (csrc/conv_fft_rows_reg.hip).  Both arms compute the same transform up to the association order of the butterflies: the full-size fp32 tower
+    against the float64 goldens and the bf16 tower against the bf16-operand oracle are run again in a process with the switch set."""
+    import subprocess
+    import sys
+    env = dict(os.environ, JCM_FFT_REG='0')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-k',
+                        'test_full_size_tower_vs_golden and exact and trained or test_bf16_tower_vs_bf16_oracle'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-500:]
