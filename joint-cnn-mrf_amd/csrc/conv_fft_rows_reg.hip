@@ -109,7 +109,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     inv_rows_load2<NX, T16, 0>(u, sg, odd, load);
   }
   float norm = norm0;
-  if (sc.tmax) norm = norm0 * sc.winv[0] * fp16_unscale(tmax_of(sc.tmax, sc.common ? 0 : b, sc.nb, sc.common), sc.hf);      // powers of two: exact
+  if (sc.tmax) {
+    float tm;
+    if (sc.common) {      // one scale for the tensor (a handle with training state): the largest of its nb words, taken by the wave, not by every thread
+      tm = 0.f;
+      for (int i = (int)(threadIdx.x & 63); i < sc.nb; i += 64) tm = fmaxf(tm, sc.tmax[i]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o));
+    } else {
+      tm = sc.tmax[b];
+    }
+    norm = norm0 * sc.winv[0] * fp16_unscale(tm, sc.hf);      // powers of two: exact
+  }
   const bool two = c + 1 < Cout;
   float b0v = 0.f, b1v = 0.f, s0 = 1.f, s1 = 1.f, h0 = 0.f, h1 = 0.f;
   if (c < Cout) {
