@@ -361,7 +361,22 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
       const int row = r0 + (i & 3) + 8 * (i >> 2);
       if (row < a.B) {
 #pragma unroll
-        for (int fn = 0; fn < FN; ++fn) yf[(size_t)row * a.ldy + n0 + fn * 32] = make_float2(accr[fm][fn][i], acci[fm][fn][i]);
+        for (int fn = 0; fn < FN; ++fn) {
+            float2* q = yf + (size_t)row * a.ldy + n0 + fn * 32;
+            // fp32 handles: streaming store (the 64-row tiles are bound by the filter spectra they read; keeping Y out of the L2 measured 366 -> 361 us, the
+            // logits layer's thin tile 264 -> 243 us).  The one-part bf16 form writes as much as it reads and measured 832 -> 931 us with it: plain stores.
+#ifndef JCM_NO_NT_STORES
+            constexpr bool kStream = !C::K32;
+#else
+            constexpr bool kStream = false;
+#endif
+            if constexpr (kStream) {
+              typedef float f2n __attribute__((ext_vector_type(2)));
+              __builtin_nontemporal_store(f2n{accr[fm][fn][i], acci[fm][fn][i]}, reinterpret_cast<f2n*>(q));
+            } else {
+              *q = make_float2(accr[fm][fn][i], acci[fm][fn][i]);
+            }
+          }
       }
     }
   }

@@ -83,14 +83,14 @@ __global__ __launch_bounds__(colfwd_threads<NY>()) void cols_fwd_split_kernel(co
     if constexpr (NP == 5) {
       // stage kc / 2 of KC / 2, unit ((c * 2 + half) * 2 + kg) * MT + row with half = kc & 1
       uint4* dst = Xs + (((f * mtiles + mt) * (KC >> 1) + (kc >> 1)) * 8 + (size_t)(kc & 1) * 2 + kg) * MT + r0 + img;
-      dst[0] = ur[0];
-      dst[(size_t)4 * MT] = ui[0];
+      st_stream(dst, ur[0]);
+      st_stream(dst + (size_t)4 * MT, ui[0]);
     } else {
       uint4* dst = Xs + (((f * mtiles + mt) * KC + kc) * (4 * NPP) + kg) * MT + r0 + img;      // unit ((c * NPP + p) * 2 + kg) * MT + row
 #pragma unroll
       for (int p = 0; p < NPP; ++p) {
-        dst[(size_t)(0 * NPP + p) * 2 * MT] = ur[p];
-        dst[(size_t)(1 * NPP + p) * 2 * MT] = ui[p];
+        st_stream(dst + (size_t)(0 * NPP + p) * 2 * MT, ur[p]);
+        st_stream(dst + (size_t)(1 * NPP + p) * 2 * MT, ui[p]);
       }
     }
   }
@@ -133,13 +133,13 @@ __global__ __launch_bounds__(colinv_threads<NY>()) void cols_inv_kernel(const cf
 #pragma unroll
     for (int i = 0; i < KM; ++i) {
       const int t = tid + i * NTC, y = t / CH, v = t % CH;
-      if (t < H * CH) dst[((size_t)(b * H + y) * NXH + kx) * C + cblk * CB + v] = pack_h2(val[i].x * s, val[i].y * s);
+      if (t < H * CH) st_stream(&dst[((size_t)(b * H + y) * NXH + kx) * C + cblk * CB + v], pack_h2(val[i].x * s, val[i].y * s));
     }
     if (tid == 0) t16[((size_t)b * (C / CB) + cblk) * NXH + kx] = 1.0f / s;
   } else {
     for (int t = tid; t < H * CH; t += NTC) {
       const int y = t / CH, v = t % CH;
-      T[((size_t)(b * H + y) * NXH + kx) * C + cblk * CB + v] = buf[pos<NY>(y + pad) * CH + v];
+      st_stream(&T[((size_t)(b * H + y) * NXH + kx) * C + cblk * CB + v], buf[pos<NY>(y + pad) * CH + v]);
     }
   }
 }

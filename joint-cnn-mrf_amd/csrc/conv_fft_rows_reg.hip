@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float v0 = fmaf(z.x, norm, b0v), v1 = fmaf(z.y, norm, b1v);      // (single roundings: this kernel is instruction-bound)
     if (relu_bn) { v0 = fmaf(fmaxf(v0, 0.f), s0, h0); v1 = fmaf(fmaxf(v1, 0.f), s1, h1); }
     if constexpr (LAYOUT == 0) {
-      *reinterpret_cast<cf*>(static_cast<float*>(out) + (by * W + xo) * Cout + c) = cf{v0, v1};
+      st_stream(reinterpret_cast<cf*>(static_cast<float*>(out) + (by * W + xo) * Cout + c), cf{v0, v1});
     } else {
       typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
       wst[(m * 2 + h) * 32 + (lane >> 1)] = __builtin_bit_cast(unsigned, bf16x2{static_cast<__bf16>(v0), static_cast<__bf16>(v1)});
@@ -208,8 +208,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int y = (i / R2) + R1 * (i % R2) - pad;
     if (y >= 0 && y < H) {
       const size_t o = ((size_t)(b * H + y) * NXH + kx) * C + c;
-      if constexpr (T16) reinterpret_cast<unsigned*>(T)[o] = pack_h2(x[i].x * s, x[i].y * s);
-      else reinterpret_cast<cf*>(T)[o] = x[i];
+      if constexpr (T16) st_stream(reinterpret_cast<unsigned*>(T) + o, pack_h2(x[i].x * s, x[i].y * s));
+      else st_stream(reinterpret_cast<cf*>(T) + o, x[i]);
     }
   }
 }
