@@ -63,6 +63,10 @@ struct Cfg {
   static constexpr int WSRC = 4 * NTL * 32;                         // WF32: bytes of a stage of fp32 filter spectra
   static constexpr int LDS_BYTES = R * STAGE * 16;
   static constexpr int NPROD = K32 ? 2 : NP == 3 ? 6 : NP == 2 ? 3 : 1;
+  // cache policy of the filter-spectra DMA: the fp32 handles' tiles (two fp16 parts, <= 128 rows) are bound by that stream, which is read once per launch --
+  // the nontemporal hint (bit 1) keeps it from pushing the re-read activation slabs out of the L2: -1.5 % per fp32 step in a same-box A/B; the one-part
+  // bf16 form measured +0.8 % with it and keeps the default
+  static constexpr int WAUX = (HALF && !K32 && !WF32) ? 2 : 0;
   static_assert(!K32 || (NP == 2 && !WF32), "K32 reuses the two-plane layout");
   static_assert(NTL == 128 || NTL == 32, "column tiles the filter spectra are laid out for");
   static_assert(XST % (64 * NW) == 0 && (WF32 || WST % (64 * NW) == 0), "whole DMA pieces per wave");
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
 #pragma unroll
     for (int i = 0; i < C::WPW; ++i) {
       const unsigned q = (unsigned)(wid + i * NW) * 1024u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(smem + sbase + XST * 16 + q), 16, lane16 + (unsigned)g * (unsigned)(WST * 16) + q, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(smem + sbase + XST * 16 + q), 16, lane16 + (unsigned)g * (unsigned)(WST * 16) + q, 0, 0, C::WAUX);
     }
   };
 
