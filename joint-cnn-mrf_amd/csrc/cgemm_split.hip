@@ -191,7 +191,9 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
 #pragma unroll
     for (int i = 0; i < C::WPW; ++i) {
       const unsigned q = (unsigned)(wid + i * NW) * 1024u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(smem + sbase + XST * 16 + q), 16, lane16 + (unsigned)g * (unsigned)(WST * 16) + q, 0, 0, C::WAUX);
+      // (the cache policy must be a literal: a dependent constant in that operand silently drops the kernel from the host object)
+      if constexpr (C::WAUX == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(smem + sbase + XST * 16 + q), 16, lane16 + (unsigned)g * (unsigned)(WST * 16) + q, 0, 0, 2);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(smem + sbase + XST * 16 + q), 16, lane16 + (unsigned)g * (unsigned)(WST * 16) + q, 0, 0, 0);
     }
   };
 
