@@ -161,7 +161,10 @@ __global__ __launch_bounds__(NT) void wgrad_spec_kernel(Args a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int co = tn * TN + (wn * 2 + j) * 32 + l31;
-          if (co < a.Cout) pf[(size_t)ci * a.Cout + co] = make_float2(pr[i][j][e], pi[i][j][e]);
+          if (co < a.Cout) {      // streaming store: P (F Cin Cout complex numbers, 6.6 GB for conv5) is read once, by the taps kernel, gigabytes later
+            typedef float f2n __attribute__((ext_vector_type(2)));
+            __builtin_nontemporal_store(f2n{pr[i][j][e], pi[i][j][e]}, reinterpret_cast<f2n*>(pf + (size_t)ci * a.Cout + co));
+          }
         }
       }
     }
