@@ -201,7 +201,12 @@ static int tw_offset(int n) {
 }
 // circular convolution of size >= (H + pad) x (W + pad); one size per map for every kernel size (pad of the 9x9 layers), so that two
 // consecutive layers can hand the row-transformed tensor over.  The old limit H + k - 1 <= 192 is kept.
-static bool sizes_of(int H, int W, int ks, Sizes* s) {
+// circ (ConvArgs::circ): overlap-save windows -- the H x W input IS the transform (H, W must be transform lengths, at least one valid row / column)
+static bool sizes_of(int H, int W, int ks, Sizes* s, int circ = 0) {
+  if (circ) {
+    s->NY = H; s->NX = W;
+    return (ks == 9 || ks == 5) && H > 8 && W > 8 && tw_offset(H) >= 0 && tw_offset(W) >= 0;
+  }
   return (ks == 9 || ks == 5) && H + ks - 1 <= 192 && W + ks - 1 <= 192 && pick(H + 4, &s->NY) && pick(W + 4, &s->NX);
 }
 static int pad64(int c) { return (c + CB - 1) / CB * CB; }
@@ -256,17 +261,17 @@ using namespace cfft;
 
 bool conv_fft_supported(const ConvArgs& a, int ks) {
   Sizes s;
-  return a.Cin % CB == 0 && a.Cin >= CB && a.Cout >= 1 && a.B >= 1 && sizes_of(a.H, a.W, ks, &s);
+  return a.Cin % CB == 0 && a.Cin >= CB && a.Cout >= 1 && a.B >= 1 && sizes_of(a.H, a.W, ks, &s, a.circ);
 }
 // np: bf16 parts per operand (3 = fp32 handles, 2 = bf16 handles)
-size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout, int np) {
+size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout, int np, int circ) {
   Sizes s;
-  if (!sizes_of(H, W, ks, &s)) return 0;
+  if (!sizes_of(H, W, ks, &s, circ)) return 0;
   return cgemm_split_w_bytes(np, s.NY * (s.NX / 2 + 1), Cin, Cout);
 }
-hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, int np, bool round_bf16, hipStream_t st, float* wscale) {
+hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, int np, bool round_bf16, hipStream_t st, float* wscale, int circ) {
   Sizes s;
-  if (!sizes_of(H, W, ks, &s) || Cin % 16 || np < 2 || np > 5 || (np >= 4 && !wscale) || (np == 5 && Cin % 32)) return hipErrorInvalidValue;
+  if (!sizes_of(H, W, ks, &s, circ) || Cin % 16 || np < 2 || np > 5 || (np >= 4 && !wscale) || (np == 5 && Cin % 32)) return hipErrorInvalidValue;
   const int ntl = cgemm_split_ntile(np, Cout), CoutP = padn(Cout, ntl);
   const size_t cpt = cgemm_split_w_fp32(np) ? 4 : 8;      // thread = (4 or 8 input channels: one 16-byte unit, output channel); one kx per block
   const dim3 grid((unsigned)(((size_t)Cin / cpt * CoutP + 255) / 256), (unsigned)(s.NX / 2 + 1));
@@ -312,7 +317,7 @@ size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 }  // namespace
 size_t conv_fft_workspace_bytes(const ConvArgs& a, int ks, int np) {
   Sizes s;
-  if (!sizes_of(a.H, a.W, ks, &s)) return 0;
+  if (!sizes_of(a.H, a.W, ks, &s, a.circ)) return 0;
   const Plan3 p = plan_of(a, s, np);
   return align256(p.t_bytes) + align256(p.xs_bytes) + align256(p.yf_bytes) + align256(p.sc_fwd_bytes) + align256(p.sc_inv_bytes);
 }
@@ -338,7 +343,8 @@ size_t conv_fft_handover_bytes(const ConvArgs& a, int ks) {      // T[kx][c/16][
 hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int out_layout, void* work, const void* t_in, void* t_next, const FftMerge* merge,
                         hipEvent_t g0, hipEvent_t g1, hipStream_t st, void* xs, bool xs_ready, const Fp16Scale* scp) {
   Sizes s;
-  if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s) || (out_layout == 2 && a0.Cout % 8) || np < 2 || np > 5 || (np == 5 && a0.Cin % 32)) return hipErrorInvalidValue;
+  if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s, a0.circ) || (out_layout == 2 && a0.Cout % 8) || np < 2 || np > 5 || (np == 5 && a0.Cin % 32)) return hipErrorInvalidValue;
+  if (a0.circ && (t_in || t_next || merge || in_layout != 0 || out_layout != 0)) return hipErrorInvalidValue;      // windows: fp32 NHWC in and out, nothing fused
   Fp16Scale sc;
   if (np >= 4) {
     if (!scp || !scp->tmax || !scp->winv || (t_next && !scp->tmax_next)) return hipErrorInvalidValue;
@@ -351,7 +357,8 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
   if (merge && in_layout == 2) return hipErrorInvalidValue;      // the merge reads NHWC (fp32 or bf16)
   ConvArgs a = a0;
   a.CoutP = pad64(a.Cout);
-  const int opad = (ks - 1) / 2;                         // output row y = row y + pad of the circular convolution (whose size is H + 4 for both kernel sizes)
+  // output row y = row y + pad of the circular convolution (whose size is H + 4 for both kernel sizes); windows: the valid region starts 4 rows into the window
+  const int opad = (ks - 1) / 2 + (a0.circ ? 4 : 0);
   const Plan3 p = plan_of(a, s, np);
   char* wk = static_cast<char*>(work);
   cf* T = reinterpret_cast<cf*>(wk);
@@ -385,11 +392,13 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
   if (g1 && hipEventRecord(g1, st) != hipSuccess) return hipErrorUnknown;
   // JCM_FFT_REG=0 (environment, read once): the LDS kernels for every inverse pass -- the A/B arm of the register kernels (conv_fft_rows_reg.hip)
   static const bool fft_reg = [] { const char* e = std::getenv("JCM_FFT_REG"); return !e || std::atoi(e) != 0; }();
-  if (!(fft_reg && p.inv_cb == 64 && cfft_cols_inv_reg(s.NY, a, Yf, T, p.NXH, p.ldy, opad, st, sc.t16_inv))) cfft_cols_inv(s.NY, a, Yf, T, twy, p.NXH, p.ldy, opad, st, sc.t16_inv);
+  ConvArgs ai = a;      // the inverse passes' view: windows keep their valid region only
+  if (a0.circ) { ai.H = a0.H - 8; ai.W = a0.W - 8; }
+  if (!(fft_reg && p.inv_cb == 64 && cfft_cols_inv_reg(s.NY, ai, Yf, T, p.NXH, p.ldy, opad, st, sc.t16_inv))) cfft_cols_inv(s.NY, ai, Yf, T, twy, p.NXH, p.ldy, opad, st, sc.t16_inv);
   if (t_next) {
     cfft_rows_inv_fwd(s.NX, a, T, static_cast<cf*>(t_next), twx, opad, norm, sc, st);
-  } else if (!(fft_reg && cfft_rows_inv_reg(s.NX, a, out_layout, T, opad, norm, sc, st))) {
-    cfft_rows_inv(s.NX, a, out_layout, T, twx, opad, norm, sc, st);
+  } else if (!(fft_reg && cfft_rows_inv_reg(s.NX, ai, out_layout, T, opad, norm, sc, st))) {
+    cfft_rows_inv(s.NX, ai, out_layout, T, twx, opad, norm, sc, st);
   }
   return hipGetLastError();
 }
@@ -397,12 +406,12 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
 // the split spectra of an NHWC fp32 tensor alone (rows + columns forward): xs = conv_fft_xs_bytes() bytes, work = conv_fft_workspace_bytes()
 size_t conv_fft_xs_bytes(const ConvArgs& a, int ks, int np) {
   Sizes s;
-  if (!sizes_of(a.H, a.W, ks, &s)) return 0;
+  if (!sizes_of(a.H, a.W, ks, &s, a.circ)) return 0;
   return align256(plan_of(a, s, np).xs_bytes);
 }
 hipError_t conv_fft_spectra(const ConvArgs& a0, int ks, int np, void* work, void* xs, hipStream_t st, float* tmax, int common) {
   Sizes s;
-  if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s) || !xs || (np >= 4 && !tmax)) return hipErrorInvalidValue;
+  if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s, a0.circ) || !xs || (np >= 4 && !tmax)) return hipErrorInvalidValue;
   Fp16Scale sc;
   if (np >= 4) { sc.tmax = tmax; sc.hf = (float)a0.H; sc.nb = a0.B; sc.common = common; }
   ConvArgs a = a0;
@@ -418,9 +427,9 @@ hipError_t conv_fft_spectra(const ConvArgs& a0, int ks, int np, void* work, void
   return hipGetLastError();
 }
 // geometry of the spectra for the weight-gradient kernels
-bool conv_fft_geometry(int H, int W, int ks, int B, int Cout, int np, int* NY, int* NX, int* MT) {
+bool conv_fft_geometry(int H, int W, int ks, int B, int Cout, int np, int* NY, int* NX, int* MT, int circ) {
   Sizes s;
-  if (!sizes_of(H, W, ks, &s)) return false;
+  if (!sizes_of(H, W, ks, &s, circ)) return false;
   *NY = s.NY; *NX = s.NX; *MT = cgemm_split_mtile(np, B, Cout);
   return true;
 }

@@ -108,6 +108,7 @@ struct jcm_ctx {
   const void* fft_merge = nullptr;   // const jcm::FftMerge*: the next frequency-domain layer forms the merged map itself (jcm_pd_forward, conv5)
   int conv9_fft = 1;            // fp32 handles: wide 9x9 layers in the frequency domain (conv_fft.hip) when the shape allows; 0 = fp32 MFMA chain
   int fft_single = 1;           // bf16 handles: the channel GEMM on ONE scaled fp16 part per operand (np = 5; 0 = two bf16 parts, three products)
+  int fft_win = 1;              // training step of fp32 handles: frequency-domain layers on 32 x 32 overlap-save windows where that shrinks the filter-sized spectra (jcm_train.hip)
   int fft_t16 = 1;              // bf16 handles on the one-part route (fft_single): the row-transformed tensors T / T' as complex fp16 in block floating point (Fp16Scale::t16)
   int fft_fp16 = 1;             // fp32 handles: the channel GEMM on two FP16 parts per operand (three products, scaled spectra); 0 = three bf16 parts (six products)
   // device words of the fp16 scaling (kernels.h: Fp16Scale): zeroed floats, one per image of every row-transformed tensor of a call.  They come from
@@ -199,11 +200,12 @@ void prof_release_all(jcm_ctx* c, bool destroy);
 // frequency-domain route (jcm_api.hip): takes_fft() says whether a layer / shape goes there; run_conv_fft() runs it (filter spectra cached in
 // c->fft_w under "<scope>@HxW", packed from L->w_raw when missing or invalidated); the training step uses both for its data gradient.
 bool takes_fft(jcm_ctx* c, const ConvLayer* L, int B, int H, int W);
-bool fft_spectra_valid(jcm_ctx* c, const std::string& scope, int H, int W);
+bool fft_spectra_valid(jcm_ctx* c, const std::string& scope, int H, int W, int circ = 0);
 // operand form of the channel GEMM on this handle (kernels.h): bf16 handles: 5 (one scaled fp16 part, default) or 2 (two bf16 parts); fp32 handles: 4 (two fp16 parts, default) or 3 (three bf16 parts)
 inline int fft_np(const jcm_ctx* c) { return c->precision == JCM_PRECISION_BF16 ? (c->fft_single ? 5 : 2) : (c->fft_fp16 ? 4 : 3); }
 int fft_new_words(jcm_ctx* c, int n, float** w);      // n zeroed device words of the scaling ring (one per image)
-int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const void* x, int B, int H, int W, void* out, int in_layout, int out_layout);
+// circ: x is a batch of overlap-save windows [B, H, W, Cin] that fill the transform, out their valid regions [B, H - 8, W - 8, Cout] (ConvArgs::circ)
+int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const void* x, int B, int H, int W, void* out, int in_layout, int out_layout, int circ = 0);
 int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int stride, const void* x, int B, int H, int W, int sub,
                    void* out, bool act_bf16, bool out_f32, int in_planar = 0, int out_planar = 0);   // bf16 layouts: ConvArgs in kernels.h
 

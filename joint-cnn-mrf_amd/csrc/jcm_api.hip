@@ -199,8 +199,8 @@ bool takes_fft(jcm_ctx* c, const ConvLayer* L, int B, int H, int W) {
   a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout;
   return conv_fft_supported(a, L->ks);
 }
-bool fft_spectra_valid(jcm_ctx* c, const std::string& scope, int H, int W) {
-  auto it = c->fft_w.find(scope + "@" + std::to_string(H) + "x" + std::to_string(W));
+bool fft_spectra_valid(jcm_ctx* c, const std::string& scope, int H, int W, int circ) {
+  auto it = c->fft_w.find(scope + (circ ? "@win" : "@") + std::to_string(H) + "x" + std::to_string(W));
   return it != c->fft_w.end() && it->second.valid;
 }
 // n zeroed device words (one per image of a row-transformed tensor).  Blocks are zeroed when they are created and every time the handle starts
@@ -229,10 +229,11 @@ int fft_new_words(jcm_ctx* c, int n, float** w) {
     c->fft_blocks.push_back(b);
   }
 }
-int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const void* x, int B, int H, int W, void* out, int in_layout, int out_layout) {
+int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const void* x, int B, int H, int W, void* out, int in_layout, int out_layout, int circ) {
   ConvArgs a{};
   a.x = x; a.bias = L->bias; a.scale = L->scale; a.shift = L->shift; a.out = out;
   a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout; a.CoutP = L->cout; a.relu_bn = L->has_bn ? 1 : 0;
+  a.circ = circ;
   const size_t mark = c->arena_off;
   const int np = fft_np(c);      // operand form of the channel GEMM (cgemm_split.hip)
   void* work = arena_alloc<char>(c, conv_fft_workspace_bytes(a, L->ks, np));
@@ -240,10 +241,10 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
   if (c->dry) { c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; c->fft_xs = nullptr; c->fft_xs_ready = false; c->fft_tmax_in = nullptr; return JCM_OK; }
   // Filter spectra are cached per (layer, map size).  The cache is bounded (JCM_FFT_CACHE_GB, default 64): a caller that walks many
   // image sizes (7.7 GB per size for conv5) makes it drop every spectrum that is not this layer's before it grows past the bound.
-  const std::string key = scope + "@" + std::to_string(H) + "x" + std::to_string(W);
+  const std::string key = scope + (circ ? "@win" : "@") + std::to_string(H) + "x" + std::to_string(W);
   if (!c->fft_w.count(key)) {
     static const size_t cap = [] { const char* e = std::getenv("JCM_FFT_CACHE_GB"); return (size_t)(e ? std::atoi(e) : 64) << 30; }();
-    const size_t need = conv_fft_weight_bytes(H, W, L->ks, L->cin, L->cout, np);
+    const size_t need = conv_fft_weight_bytes(H, W, L->ks, L->cin, L->cout, np, circ);
     size_t held = 0;
     for (auto& kv : c->fft_w) held += kv.second.bytes;
     if (held + need > cap && !c->fft_w.empty()) {
@@ -254,7 +255,7 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
   }
   jcm_ctx::FftW& fw = c->fft_w[key];
   if (!fw.p) {
-    const size_t wb = (conv_fft_weight_bytes(H, W, L->ks, L->cin, L->cout, np) + 255) & ~size_t(255);
+    const size_t wb = (conv_fft_weight_bytes(H, W, L->ks, L->cin, L->cout, np, circ) + 255) & ~size_t(255);
     fw.bytes = wb + 256;      // + the two words of the filter spectra's scale (np = 4)
     if (hipMalloc(&fw.p, fw.bytes) == hipSuccess) {
       fw.wscale = reinterpret_cast<float*>(static_cast<char*>(fw.p) + wb);
@@ -265,7 +266,7 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
     }
   }
   if (!fw.valid) {
-    HIP_TRY(conv_fft_pack_weights(L->w_raw, fw.p, H, W, L->ks, L->cin, L->cout, np, c->precision == JCM_PRECISION_BF16, c->stream, fw.wscale));
+    HIP_TRY(conv_fft_pack_weights(L->w_raw, fw.p, H, W, L->ks, L->cin, L->cout, np, c->precision == JCM_PRECISION_BF16, c->stream, fw.wscale, circ));
     fw.valid = true;
   }
   a.wp = fw.p;
@@ -755,6 +756,10 @@ int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
       h->fft_w.clear();
     }
     h->fft_single = value != 0;
+    return JCM_OK;
+  }
+  if (k == "fft_windows") {   // allowed at any time (fp32 handles with training state)
+    h->fft_win = value != 0;
     return JCM_OK;
   }
   if (k == "fft_t16") {   // allowed at any time (bf16 handles, fft_single = 1)

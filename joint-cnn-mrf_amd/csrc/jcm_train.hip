@@ -138,7 +138,29 @@ struct LayerFwd {
   void* y = nullptr;
   void* xs = nullptr;          // fp32 handles, frequency-domain layers: the split spectra of the input, kept for the weight gradient (wgrad_fft.hip)
   float* xs_tmax = nullptr;    // ... and the device word of their fp16 scaling (np = 4)
+  int win = 0, TY = 0, TX = 0; // the layer ran on overlap-save windows (kWin x kWin, TY x TX of them per image): xs are the WINDOWS' spectra
 };
+
+// ---- overlap-save windows (fp32 handles; ConvArgs::circ).  At 16 images per GPU every pass of a wide layer is bound by filter-sized
+// spectra -- F Cin Cout complex numbers written by the packers, read by the forward and the data-gradient GEMM, written and read as the weight gradient's
+// per-frequency products: 6 x 6.6 GB per step for conv5 on the 64 x 96 transform of its 60 x 90 map.  Cut into 32 x 32 windows (24 x 24 valid pixels + a halo
+// of 4, 3 x 4 windows per map) the same layer has 544 frequencies instead of 3136 and 192 "images" instead of 16: the filter-sized tensors shrink 5.8x, the
+// activation-sized ones (which were 3 % of the traffic) grow 2.1x.
+constexpr int kWin = 32, kWinValid = kWin - 8;
+static bool takes_windows(jcm_ctx* c, const ConvLayer* L, int B, int H, int W, int* TY, int* TX) {
+  if (bf(c) || !c->fft_win || !takes_fft(c, L, B, H, W)) return false;
+  int NY = 0, NX = 0, MT = 0;
+  if (!conv_fft_geometry(H, W, L->ks, B, L->cout, fft_np(c), &NY, &NX, &MT)) return false;
+  if (2 * kWin * (kWin / 2 + 1) > NY * (NX / 2 + 1)) return false;      // at least half the frequencies, or the larger activation spectra eat the gain (30 x 45 maps: 936 -> 544)
+  // ... and filters wide enough that their spectra dominate: the windows cost a gather, a scatter and 2.1x the transform work per channel (measured at 16 images:
+  // with every 60 x 90 layer on windows the step stayed at 36 ms -- 9.7 ms saved on filter-sized tensors, as much spent on activation-sized ones)
+  if ((long)L->cin * L->cout < 256l * 512) return false;
+  *TY = (H + kWinValid - 1) / kWinValid;
+  *TX = (W + kWinValid - 1) / kWinValid;
+  ConvArgs a{};
+  a.B = B * *TY * *TX; a.H = kWin; a.W = kWin; a.Cin = L->cin; a.Cout = L->cout; a.circ = 1;
+  return conv_fft_supported(a, L->ks);
+}
 
 // the convolution half: r = relu(conv + b) (or conv + b), the input spectra kept for the weight gradient where the layer runs in the frequency domain
 int conv_train_fwd_conv(jcm_ctx* c, LayerFwd& f, int stride, const void* x, int B, int Hin, int Win, int sub) {
@@ -153,6 +175,26 @@ int conv_train_fwd_conv(jcm_ctx* c, LayerFwd& f, int stride, const void* x, int 
   ConvLayer L = *f.L;
   L.scale = t->ones;       // epilogue = relu(z + b) * 1 + 0
   L.shift = t->zeros;
+  if (int TY = 0, TX = 0; stride == 1 && takes_windows(c, &L, B, Hin, Win, &TY, &TX)) {
+    // windows: gather -> frequency-domain layer on B TY TX windows (their spectra kept for the weight gradient) -> scatter of the valid regions
+    f.win = 1; f.TY = TY; f.TX = TX;
+    const int BW = B * TY * TX;
+    ConvArgs ax{};
+    ax.B = BW; ax.H = kWin; ax.W = kWin; ax.Cin = L.cin; ax.Cout = L.cout; ax.circ = 1;
+    f.xs = arena_alloc<char>(c, conv_fft_xs_bytes(ax, L.ks, fft_np(c)));
+    const size_t mark = c->arena_off;
+    float* xw = arena_alloc<float>(c, (size_t)BW * kWin * kWin * L.cin);
+    float* rw = arena_alloc<float>(c, (size_t)BW * kWinValid * kWinValid * L.cout);
+    if (!c->dry) HIP_TRY(window_gather_f32(static_cast<const float*>(x), xw, B, Hin, Win, L.cin, kWin, TY, TX, 0, c->stream));
+    c->fft_xs = f.xs;
+    JCM_TRY(run_conv_fft(c, &L, f.scope, xw, BW, kWin, kWin, rw, 0, 0, 1));
+    if (!c->dry) {
+      f.xs_tmax = c->fft_last_tmax;
+      HIP_TRY(window_scatter_f32(rw, static_cast<float*>(f.r), B, f.H, f.W, L.cout, kWin, TY, TX, c->stream));
+    }
+    c->arena_off = mark;      // (later work runs behind the scatter on the stream)
+    return JCM_OK;
+  }
   if (stride == 1 && !bf(c) && takes_fft(c, &L, B, Hin, Win)) {      // keep the input spectra: the weight gradient is taken in the frequency domain too
     ConvArgs ax{};
     ax.B = B; ax.H = Hin; ax.W = Win; ax.Cin = L.cin; ax.Cout = L.cout;
@@ -203,7 +245,38 @@ int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int ldz, int B, fl
   TrainState* t = c->train;
   const ConvLayer* L = f.L;
   t->zs = nullptr;
-  if (f.xs && !bf(c) && ldz >= L->cout && ldz % 64 == 0) {
+  if (f.win && f.xs && ldz >= L->cout && ldz % 64 == 0) {
+    // windows: the spectra of dz on VALID-ONLY windows (zero halo: every output pixel counts once; in window coordinates the correlation with the forward
+    // pass's windows is alias-free for |lag| <= 4), P and the taps on the 32 x 32 transform with B TY TX "images"
+    const int BW = B * f.TY * f.TX, np = fft_np(c);
+    int NY = 0, NX = 0, MTx = 0, MTz = 0, ny2 = 0, nx2 = 0;
+    if (!conv_fft_geometry(kWin, kWin, L->ks, BW, L->cout, np, &NY, &NX, &MTx, 1) || !conv_fft_geometry(kWin, kWin, L->ks, BW, L->cin, np, &ny2, &nx2, &MTz, 1))
+      return fail(JCM_ERR_STATE, "window geometry of '" + f.scope + "'");
+    const size_t mark = c->arena_off;
+    float* zw = arena_alloc<float>(c, (size_t)BW * kWin * kWin * ldz);
+    ConvArgs az{};
+    az.x = zw; az.B = BW; az.H = kWin; az.W = kWin; az.Cin = ldz; az.Cout = L->cin; az.circ = 1;
+    char* zs = arena_alloc<char>(c, conv_fft_xs_bytes(az, L->ks, np));
+    char* work = arena_alloc<char>(c, conv_fft_workspace_bytes(az, L->ks, np));
+    char* P = arena_alloc<char>(c, wgrad_fft_scratch_bytes(NY, NX, L->cin, ldz));
+    if (!c->dry) {
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      JCM_TRY(prof_begin(c, &e0, &e1));
+      float* ztmax = nullptr;
+      if (np == 4) JCM_TRY(fft_new_words(c, BW, &ztmax));
+      hipError_t le = window_gather_f32(static_cast<const float*>(dz), zw, B, f.H, f.W, ldz, kWin, f.TY, f.TX, 1, c->stream);
+      if (le == hipSuccess) le = conv_fft_spectra(az, L->ks, np, work, zs, c->stream, ztmax, 1);
+      if (le == hipSuccess)
+        le = wgrad_fft(f.xs, zs, P, L->w_raw, lmbd, grad_of(t, grads, f.scope + "/weights"), L->ks, NY, NX, BW, MTx, MTz, L->cin, ldz, L->cout, c->stream,
+                       np, f.xs_tmax, ztmax, kWin);
+      prof_end(c, "wgrad:" + f.scope, e0, e1, le == hipSuccess);
+      if (le != hipSuccess) return fail(JCM_ERR_HIP, "frequency-domain weight gradient (windows) of '" + f.scope + "': " + hipGetErrorString(le));
+    }
+    c->arena_off = mark;
+    notify_ready(c, f.scope + "/");
+    return JCM_OK;
+  }
+  if (!f.win && f.xs && !bf(c) && ldz >= L->cout && ldz % 64 == 0) {
     // frequency domain (wgrad_fft.hip): spectra of dz (kept in t->zs for the data gradient that follows), P[f] = conj(X)^T dZ per frequency, k x k taps
     ConvLayer Lz;      // dz as the input of a frequency-domain layer: the same pseudo-layer conv_dgrad runs
     Lz.ks = L->ks; Lz.cin = ldz; Lz.cout = L->cin; Lz.has_bn = false; Lz.w_raw = t->scratch_flip;
@@ -289,6 +362,22 @@ int conv_dgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int B, void* dx, i
     ConvLayer Ld;
     Ld.ks = f.L->ks; Ld.cin = cin_fft; Ld.cout = f.L->cin; Ld.has_bn = false;
     Ld.w_raw = t->scratch_flip; Ld.bias = t->zeros; Ld.scale = t->ones; Ld.shift = t->zeros;
+    if (f.win) {
+      // windows WITH their halo of real gradient pixels -> the flipped, transposed filter's layer on the 32 x 32 transform -> scatter
+      const std::string key = "dgrad:" + f.scope;
+      const int BW = B * f.TY * f.TX;
+      if (!c->dry && !fft_spectra_valid(c, key, kWin, kWin, 1))
+        HIP_TRY(flip_transpose_weights(f.L->w_raw, t->scratch_flip, f.L->ks, f.L->cin, f.L->cout, cin_fft, c->stream));
+      t->zs = nullptr;
+      const size_t mark = c->arena_off;
+      float* zw = arena_alloc<float>(c, (size_t)BW * kWin * kWin * cin_fft);
+      float* xw = arena_alloc<float>(c, (size_t)BW * kWinValid * kWinValid * f.L->cin);
+      if (!c->dry) HIP_TRY(window_gather_f32(static_cast<const float*>(dz), zw, B, f.H, f.W, cin_fft, kWin, f.TY, f.TX, 0, c->stream));
+      JCM_TRY(run_conv_fft(c, &Ld, key, zw, BW, kWin, kWin, xw, 0, 0, 1));
+      if (!c->dry) HIP_TRY(window_scatter_f32(xw, static_cast<float*>(dx), B, f.H, f.W, f.L->cin, kWin, f.TY, f.TX, c->stream));
+      c->arena_off = mark;
+      return JCM_OK;
+    }
     if (takes_fft(c, &Ld, B, f.H, f.W)) {
       const std::string key = "dgrad:" + f.scope;
       if (!c->dry && !fft_spectra_valid(c, key, f.H, f.W))

@@ -47,6 +47,11 @@ struct ConvArgs {
   // so a halo row of one unit is contiguous in HBM (a 64-pixel LDS-DMA reads 1 KB instead of 64 separate 128-byte
   // lines).  The 9x9 chain conv3 -> conv4 -> merge -> conv5 -> conv6 of the bf16 path runs planar.
   int in_planar = 0, out_planar = 0;
+  // conv_fft only -- OVERLAP-SAVE windows (the training step, jcm_train.hip): the input is a batch of H x W windows that FILL the circular transform
+  // (H, W are transform lengths; each window carries a halo of 4 real pixels around its (H - 8) x (W - 8) valid region), the output is the batch of valid
+  // regions [B, H - 8, W - 8, Cout]: row j of it is row j + 4 + (k - 1) / 2 of the circular convolution.  The filter spectra shrink with the window
+  // (32 x 32: 544 frequencies instead of the 3136 of a 60 x 90 map), which is what pays when the batch is small.
+  int circ = 0;
 };
 int conv_igemm_bn(int Cout);                     // N-tile the dispatcher will use for this Cout
 hipError_t conv_igemm_f32(const ConvArgs& a, int ks, hipStream_t st);
@@ -102,9 +107,9 @@ struct Fp16Scale {
   int t16_cb = 64;
 };
 bool conv_fft_supported(const ConvArgs& a, int ks);
-size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout, int np);
+size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout, int np, int circ = 0);      // circ: H x W is the window = the transform (ConvArgs::circ)
 hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, int np, bool round_bf16, hipStream_t st,
-                                 float* wscale = nullptr);
+                                 float* wscale = nullptr, int circ = 0);
 size_t conv_fft_workspace_bytes(const ConvArgs& a, int ks, int np);
 // in / out layout: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar (bf16 handles: operands are bf16 values, the arithmetic is fp32-class); g0/g1: optional events around the GEMM
 // t_in / t_next: the row-transformed tensor handed from one frequency-domain layer to the next (fp32 NHWC handles; conv_fft_fusable).
@@ -116,7 +121,7 @@ hipError_t conv_fft_f32(const ConvArgs& a, int ks, int np, int in_layout, int ou
 size_t conv_fft_xs_bytes(const ConvArgs& a, int ks, int np);
 // NHWC fp32 -> split spectra (the two forward passes); np = 4: tmax = the (zeroed) device word of this tensor
 hipError_t conv_fft_spectra(const ConvArgs& a, int ks, int np, void* work, void* xs, hipStream_t st, float* tmax = nullptr, int common = 0);
-bool conv_fft_geometry(int H, int W, int ks, int B, int Cout, int np, int* NY, int* NX, int* MT);
+bool conv_fft_geometry(int H, int W, int ks, int B, int Cout, int np, int* NY, int* NX, int* MT, int circ = 0);
 
 // ---- wgrad_fft.hip : weight gradient of a stride-1 layer in the frequency domain (fp32 handles, training step): per frequency
 // P[f][ci][co] = sum_b conj(X[f][b][ci]) dZ[f][b][co] on v_mfma_f32_32x32x16_bf16 from the split spectra of the layer input (kept by the forward pass)
@@ -127,6 +132,11 @@ size_t wgrad_fft_scratch_bytes(int NY, int NX, int Cin, int Cout);
 hipError_t wgrad_fft(const void* xs, const void* zs, void* scratch, const float* w, float lmbd, float* dw, int ks, int NY, int NX, int B, int MTx, int MTz, int Cin,
                      int ldz, int Cout, hipStream_t st, int np = 3, const float* tmax_x = nullptr, const float* tmax_z = nullptr, int H = 0);
 hipError_t pad_channels_f32(const float* in, int ldi, float* out, int ldo, size_t N, hipStream_t st);      // train_kernels.hip
+// overlap-save windows of an NHWC fp32 map (train_kernels.hip): win [B * TY * TX][WS][WS][C], window (ty, tx) = rows ty V - 4 .. + WS - 1, V = WS - 8,
+// zeros outside the map; valid_only: zeros in the 4-pixel halo ring as well (the gradient of a layer's output, where every pixel must count once).
+// scatter: the valid regions [B * TY * TX][V][V][C] back into the map
+hipError_t window_gather_f32(const float* map, float* win, int B, int H, int W, int C, int WS, int TY, int TX, int valid_only, hipStream_t st);
+hipError_t window_scatter_f32(const float* val, float* map, int B, int H, int W, int C, int WS, int TY, int TX, hipStream_t st);
 bool conv_fft_fusable(const ConvArgs& a, int ks, int ks_next);
 size_t conv_fft_handover_bytes(const ConvArgs& a, int ks);
 

@@ -545,6 +545,65 @@ __global__ void pad_channels_f32_kernel(const float* __restrict__ in, int ldi, f
     out[i] = c < ldi ? in[n * ldi + c] : 0.f;
   }
 }
+// ---- overlap-save windows (kernels.h): one thread per (window pixel, 4 channels) -- float4 where C % 4 == 0, 32-bit index arithmetic
+template <int VEC>
+__global__ __launch_bounds__(256) void window_gather_kernel(const float* __restrict__ map, float* __restrict__ win, int H, int W, int C, int WS, int TY, int TX, int valid_only,
+                                                            unsigned npix) {
+  const int cv = C / VEC;      // channel groups per pixel
+  const unsigned pix = blockIdx.x * (256 / 64) + (threadIdx.x >> 6);      // one wave per window pixel: its lanes walk the channel groups
+  if (pix >= npix) return;
+  unsigned r = pix;
+  const int wx = (int)(r % (unsigned)WS); r /= (unsigned)WS;
+  const int wy = (int)(r % (unsigned)WS); r /= (unsigned)WS;
+  const int tx = (int)(r % (unsigned)TX); r /= (unsigned)TX;
+  const int ty = (int)(r % (unsigned)TY);
+  const unsigned b = r / (unsigned)TY;
+  const int V = WS - 8, y = ty * V - 4 + wy, x = tx * V - 4 + wx;
+  const bool halo = wy < 4 || wy >= WS - 4 || wx < 4 || wx >= WS - 4;
+  const bool in = y >= 0 && y < H && x >= 0 && x < W && !(valid_only && halo);
+  const size_t src = (((size_t)b * H + (in ? y : 0)) * W + (in ? x : 0)) * C, dst = (size_t)pix * C;
+  for (int g = threadIdx.x & 63; g < cv; g += 64) {
+    if constexpr (VEC == 4) {
+      const float4 v = in ? reinterpret_cast<const float4*>(map + src)[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+      reinterpret_cast<float4*>(win + dst)[g] = v;
+    } else {
+      win[dst + g] = in ? map[src + g] : 0.f;
+    }
+  }
+}
+template <int VEC>
+__global__ __launch_bounds__(256) void window_scatter_kernel(const float* __restrict__ val, float* __restrict__ map, int H, int W, int C, int WS, int TY, int TX, unsigned npix) {
+  const int cv = C / VEC;
+  const unsigned pix = blockIdx.x * (256 / 64) + (threadIdx.x >> 6);      // over the MAP's pixels: every one lies in exactly one valid region
+  if (pix >= npix) return;
+  unsigned r = pix;
+  const int x = (int)(r % (unsigned)W); r /= (unsigned)W;
+  const int y = (int)(r % (unsigned)H);
+  const unsigned b = r / (unsigned)H;
+  const int V = WS - 8, ty = y / V, tx = x / V;
+  const size_t src = ((((size_t)b * TY + ty) * TX + tx) * V + (y - ty * V)) * V + (x - tx * V);
+  for (int g = threadIdx.x & 63; g < cv; g += 64) {
+    if constexpr (VEC == 4) reinterpret_cast<float4*>(map + (size_t)pix * C)[g] = reinterpret_cast<const float4*>(val + src * C)[g];
+    else map[(size_t)pix * C + g] = val[src * C + g];
+  }
+}
+hipError_t window_gather_f32(const float* map, float* win, int B, int H, int W, int C, int WS, int TY, int TX, int valid_only, hipStream_t st) {
+  const size_t npix = (size_t)B * TY * TX * WS * WS;
+  if (npix >= (1ull << 32)) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)((npix + 3) / 4)), blk(256);
+  if (C % 4 == 0) hipLaunchKernelGGL(window_gather_kernel<4>, grid, blk, 0, st, map, win, H, W, C, WS, TY, TX, valid_only, (unsigned)npix);
+  else hipLaunchKernelGGL(window_gather_kernel<1>, grid, blk, 0, st, map, win, H, W, C, WS, TY, TX, valid_only, (unsigned)npix);
+  return hipGetLastError();
+}
+hipError_t window_scatter_f32(const float* val, float* map, int B, int H, int W, int C, int WS, int TY, int TX, hipStream_t st) {
+  const size_t npix = (size_t)B * H * W;
+  if (npix >= (1ull << 32)) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)((npix + 3) / 4)), blk(256);
+  if (C % 4 == 0) hipLaunchKernelGGL(window_scatter_kernel<4>, grid, blk, 0, st, val, map, H, W, C, WS, TY, TX, (unsigned)npix);
+  else hipLaunchKernelGGL(window_scatter_kernel<1>, grid, blk, 0, st, val, map, H, W, C, WS, TY, TX, (unsigned)npix);
+  return hipGetLastError();
+}
+
 hipError_t pad_channels_f32(const float* in, int ldi, float* out, int ldo, size_t N, hipStream_t st) {
   const size_t total = N * ldo;
   size_t g = (total + 255) / 256;

@@ -92,10 +92,15 @@ __global__ __launch_bounds__(NT) void wgrad_spec_kernel(Args a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) { pr[i][j][e] = 0.f; pi[i][j][e] = 0.f; }
 
-  for (int r0 = 0; r0 < rows_valid; r0 += 16) {      // (16 divides both tile heights: a step never straddles two M tiles)
-    __syncthreads();      // the previous step's fragments have been read
-    // stage both operands: (8 chunks x re|im x part x k-half) segments of 16 images x 16 bytes, as they lie in HBM
-    for (int idx = tid; idx < 2 * SEGS * 16; idx += NT) {
+  // One k16 step = 16 images of both operands.  The operands of step r0 + 16 are requested (into registers) before the products of step r0 run: with
+  // overlap-save windows (jcm_train.hip) K is 12 steps, not 1, and a synchronous stage per step left the kernel waiting on the L2 (1.7 ms for conv5).
+  constexpr int NLD = 2 * SEGS * 16 / NT;      // 16-byte loads per thread and step
+  static_assert(2 * SEGS * 16 % NT == 0, "whole loads per thread");
+  uint4 pre[NLD];
+  auto fetch = [&](int r0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+      const int idx = tid + q * NT;
       const int op = idx / (SEGS * 16), r = idx - op * SEGS * 16;
       const int seg = r >> 4, j = r & 15;
       const int kg = seg & 1, cp = (seg >> 1) % (2 * NP), kcl = seg / (4 * NP);      // cp = re|im * NP + part
@@ -106,8 +111,22 @@ __global__ __launch_bounds__(NT) void wgrad_spec_kernel(Args a) {
         const int MT = op ? a.MTz : a.MTx, mtiles = (a.B + MT - 1) / MT, mt = r0 / MT, rl = r0 - mt * MT;
         v = src[((((size_t)f * mtiles + mt) * KC + kc) * (4 * NP) + cp * 2 + kg) * MT + rl + j];
       }
-      *reinterpret_cast<uint4*>(smem + op * OPER + (cp * 16 + j) * PITCH + (kcl * 16 + kg * 8) * 2) = v;
+      pre[q] = v;
     }
+  };
+  fetch(0);
+  for (int r0 = 0; r0 < rows_valid; r0 += 16) {      // (16 divides both tile heights: a step never straddles two M tiles)
+    __syncthreads();      // the previous step's fragments have been read
+    // stage both operands: (8 chunks x re|im x part x k-half) segments of 16 images x 16 bytes, as they lie in HBM
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+      const int idx = tid + q * NT;
+      const int op = idx / (SEGS * 16), r = idx - op * SEGS * 16;
+      const int seg = r >> 4, j = r & 15;
+      const int kg = seg & 1, cp = (seg >> 1) % (2 * NP), kcl = seg / (4 * NP);
+      *reinterpret_cast<uint4*>(smem + op * OPER + (cp * 16 + j) * PITCH + (kcl * 16 + kg * 8) * 2) = pre[q];
+    }
+    if (r0 + 16 < rows_valid) fetch(r0 + 16);
     __syncthreads();
     // products (x part, z part) with px + pz <= NP - 1, small terms first
     constexpr int NPROD = NP == 3 ? 6 : 3;
