@@ -354,11 +354,15 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
         # frequency-domain passes are bound by the filter-sized spectra (F x Cin x Cout complex fp32: 6.58 GB for conv5 at 64x96), not by MFMA:
         # bytes each pass must move: W or P spectra once per producer/consumer + split activation spectra + product spectra + maps
         C5 = 512 // (4 if args.debug else 1)
-        wspec = FFT_FREQS * C5 * C5 * 8
-        xspec, yspec, amap = FFT_FREQS * B * C5 * 8, FFT_FREQS * B * C5 * 8, B * 60 * 90 * C5 * 4      # activation spectra: two fp16 parts
-        fd_bytes = {'conv5': wspec + 2 * xspec + 2 * yspec + 2 * amap,             # read W; X spectra and product spectra written + read; map in / out
-                    'dgrad:conv5': wspec + xspec + 2 * yspec + amap,               # dz spectra are the weight gradient's
-                    'wgrad:conv5': 2 * wspec + amap + 3 * xspec}                   # P written (spec) + read (taps); dz spectra written, x and dz spectra read
+        # Round 4: conv5 runs on 32 x 32 overlap-save windows (jcm_train.hip): 3 x 4 windows per image are a batch of 12 B "images" on a transform with
+        # 32 * 17 = 544 frequencies -- the filter-sized spectra shrink 5.8x, the activation-sized ones grow 2.1x, plus the window tensors themselves
+        WIN_F, WIN_B = 32 * 17, 12 * B
+        wspec = WIN_F * C5 * C5 * 8
+        xspec = yspec = WIN_F * WIN_B * C5 * 8                                            # activation / product spectra: two fp16 parts / complex fp32
+        amap, awin, aval = B * 60 * 90 * C5 * 4, WIN_B * 32 * 32 * C5 * 4, WIN_B * 24 * 24 * C5 * 4      # map, gathered windows, valid regions
+        fd_bytes = {'conv5': wspec + 2 * xspec + 2 * yspec + awin + aval,      # inside the layer's events: windows read, spectra written + read, filter spectra read, valid regions written
+                    'dgrad:conv5': wspec + 2 * xspec + 2 * yspec + awin + aval,      # (the gather before and the scatter behind are timed with the step, not here)
+                    'wgrad:conv5': 2 * wspec + amap + 2 * awin + 3 * xspec}                       # P written (spec) + read (taps); dz windows + spectra written, x and dz spectra read
         for key, what in (('conv5', 'forward, ' + ('conv_split_kernel' if sp else 'conv_fft (cgemm_split_kernel)' if fd else 'conv_igemm_f32')),
                           ('dgrad:conv5', 'data gradient, ' + ('conv_split_kernel on flipped weights' if sp else 'conv_fft on the flipped filter spectra, dz spectra shared with the weight gradient'
                                                                if fd else 'conv_igemm_f32 on flipped weights')),
@@ -389,7 +393,7 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
                'train_tflops': value * FLOPS_TRAIN / scale / 1e12,      # images/s x direct-convolution FLOPs (the frequency-domain passes execute far fewer)
                **({} if fd else {'mfma_peak_tflops': PEAK_TFLOPS[prec], 'frac_of_mfma_peak': value * FLOPS_TRAIN / scale / 1e12 / PEAK_TFLOPS[prec]}),
                'roofline': (dict(bound='hbm', peak=PEAK_HBM_GBS, unit='GB/s', traffic=None,
-                                 kernel='weight gradient of conv5 in the frequency domain: dz transforms, wgrad_spec_kernel (writes P[f][ci][co], 6.58 GB), '
+                                 kernel='weight gradient of conv5 in the frequency domain on 32x32 overlap-save windows: dz window gather + transforms, wgrad_spec_kernel (K = 192 windows; writes P[f][ci][co], 1.14 GB), '
                                         'wgrad_taps_cols/rows (read it); achieved = bytes the pass must move / its time',
                                  **({'achieved': kern['wgrad:conv5']['achieved'], 'frac': kern['wgrad:conv5']['frac'],
                                      'launch_ms': kern['wgrad:conv5']['launch_ms']} if 'wgrad:conv5' in kern else {})) if fd else

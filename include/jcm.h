@@ -85,6 +85,10 @@ int jcm_abi_version(void);
  *              by one power of two per image (the bound of "fft_fp16"), rounded once to fp16's 11 significant bits, one real product per multiply,
  *              32 channels per GEMM stage.  The layer's input and output tensors are bf16 (8 bits): the spectra are eight times finer.
  *              0 = two bf16 parts per operand, three products (rounds 2-3).  Changing it drops the cached filter spectra.
+ * "fft_windows": any time, default 1 (fp32 handles with training state): the training step runs its wide 60x90 layers (conv4_fullres, conv5 -- every
+ *              layer with Cin * Cout >= 256 * 512 whose map has at least twice the frequencies of a window) on 32 x 32 overlap-save windows: forward, data
+ *              gradient and weight gradient see 3 x 4 windows per image as a batch of 12 B images on a 32 x 32 circular transform, so the filter-sized
+ *              spectra (what bounds the step at 16 images per GPU) shrink 5.8x.  0 = the 64 x 96 transform of the whole map (round 3).
  * "fft_t16"  : any time, default 1 (bf16 handles with "fft_single" = 1): the row-transformed tensors between the row and the column passes of
  *              the frequency-domain route (half of the transform passes' HBM traffic) as complex fp16 in block floating point -- one power-of-two
  *              scale per (image, row, 64 channels) tile forward and per (image, kx, 64 channels) tile inverse, 11 significant bits like the
