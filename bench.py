@@ -382,7 +382,7 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
         out = {'metric': 'images/sec joint training step (fwd+bwd+update), part detector + spatial model', 'value': value,
                'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'dtype': 'bf16' if prec == 'bf16' else {'split': 'f32(bf16x6)', 'split16': 'f32(fp16x3)'}.get(f32_conv, 'f32'), 'data': 'synthetic',
+               'dtype': 'bf16' if prec == 'bf16' else {'split': 'f32(bf16x6)', 'split16': 'f32(fp16x3)'}.get(f32_conv, 'f32(fp16x2 spectra, fft, overlap-save windows)' if fd else 'f32'), 'data': 'synthetic',
                'config': {'workload': 'configs[4]: joint training, batch=%d/GPU synthetic 480x720x3, %s%s, Adam, clip 4.0%s'
                                       % (B, ('fp32 (stride-1 layers in the frequency domain, channel products on two scaled fp16 parts per operand; conv1 on fp32 MFMA)' if fd else 'fp32 MFMA') if prec == 'fp32' else 'mixed precision: bf16 activations/gradients + bf16 MFMA, fp32 master weights / statistics / losses / spatial model / optimizer',
                                          ' operands; forward, data and weight gradients of the stride-1 layers as bf16x6 split MFMA' if f32_conv == 'split' else

@@ -72,7 +72,7 @@ __device__ __forceinline__ void inv_rows_load2(cf (&u)[NX / 2], float sg, bool o
 }
 
 template <int NX, int LAYOUT, bool T16>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void rows_inv_reg_kernel(const void* __restrict__ T, void* __restrict__ out, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NX >= 64 ? 2 : 4, NX >= 64 ? 2 : 8))) void rows_inv_reg_kernel(const void* __restrict__ T, void* __restrict__ out, const float* __restrict__ bias,
                                                                                               const float* __restrict__ scale, const float* __restrict__ shift, int relu_bn,
                                                                                               int nrows, int H, int W, int C, int Cout, int pad, float norm0, Fp16Scale sc) {
   constexpr int NXH = NX / 2 + 1, M = NX / 2;
@@ -175,7 +175,7 @@ __device__ __forceinline__ void inv_cols_rows(cf (&x)[NY]) {      // step 2 in p
   if constexpr (K1 + 1 < R1) inv_cols_rows<NY, K1 + 1>(x);
 }
 template <int NY, bool T16>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void cols_inv_reg_kernel(const cf* __restrict__ Yf, void* __restrict__ T, int B, int H, int NXH, int C, int ldy,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NY >= 64 ? 2 : 3, NY >= 64 ? 2 : 8))) void cols_inv_reg_kernel(const cf* __restrict__ Yf, void* __restrict__ T, int B, int H, int NXH, int C, int ldy,
                                                                                               int pad, float* __restrict__ t16) {
   constexpr int R1 = RPlan<NY>::R1, R2 = RPlan<NY>::R2;
   const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -215,10 +215,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 // true: launched (64-point columns, 64-channel tiles)
 bool cfft_cols_inv_reg(int NY, const ConvArgs& a, const cf* Yf, cf* T, int NXH, int ldy, int pad, hipStream_t st, float* t16) {
-  if (NY != 64 || a.CoutP % 64) return false;
+  if ((NY != 64 && !(NY == 32 && !t16)) || a.CoutP % 64) return false;
   const size_t threads = (size_t)a.B * NXH * a.CoutP;
   const dim3 grid((unsigned)((threads + 255) / 256)), blk(256);
-  if (t16) hipLaunchKernelGGL((cols_inv_reg_kernel<64, true>), grid, blk, 0, st, Yf, static_cast<void*>(T), a.B, a.H, NXH, a.CoutP, ldy, pad, t16);
+  if (NY == 32) hipLaunchKernelGGL((cols_inv_reg_kernel<32, false>), grid, blk, 0, st, Yf, static_cast<void*>(T), a.B, a.H, NXH, a.CoutP, ldy, pad, nullptr);      // overlap-save windows (fp32)
+  else if (t16) hipLaunchKernelGGL((cols_inv_reg_kernel<64, true>), grid, blk, 0, st, Yf, static_cast<void*>(T), a.B, a.H, NXH, a.CoutP, ldy, pad, t16);
   else hipLaunchKernelGGL((cols_inv_reg_kernel<64, false>), grid, blk, 0, st, Yf, static_cast<void*>(T), a.B, a.H, NXH, a.CoutP, ldy, pad, nullptr);
   return true;
 }
@@ -242,6 +243,7 @@ template <int NX> static bool launch_rows_inv_reg(const ConvArgs& a, int layout,
 // true: launched.  false: no register kernel for this (length, layout) -- the caller takes the LDS kernel.
 bool cfft_rows_inv_reg(int NX, const ConvArgs& a, int layout, const cf* T, int pad, float norm, const Fp16Scale& sc, hipStream_t st) {
   if (NX == 96) return launch_rows_inv_reg<96>(a, layout, T, pad, norm, sc, st);
+  if (NX == 32 && layout == 0) return launch_rows_inv_reg<32>(a, layout, T, pad, norm, sc, st);      // the training step's overlap-save windows (fp32)
   return false;
 }
 
