@@ -155,6 +155,9 @@ static bool takes_windows(jcm_ctx* c, const ConvLayer* L, int B, int H, int W, i
   // ... and filters wide enough that their spectra dominate: the windows cost a gather, a scatter and 2.1x the transform work per channel (measured at 16 images:
   // with every 60 x 90 layer on windows the step stayed at 36 ms -- 9.7 ms saved on filter-sized tensors, as much spent on activation-sized ones)
   if ((long)L->cin * L->cout < 256l * 512) return false;
+  // ... and a batch small enough: what the windows save (filter-sized traffic, independent of the batch: 9.7 ms per step) is spent again on activation-sized work
+  // that grows with it (4.4 ms at 16 images)
+  if (B > 32) return false;
   *TY = (H + kWinValid - 1) / kWinValid;
   *TX = (W + kWinValid - 1) / kWinValid;
   ConvArgs a{};
