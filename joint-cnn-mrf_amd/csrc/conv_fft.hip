@@ -378,11 +378,13 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
   const cf* twy = twb + tw_offset(s.NY);
   const float norm = 1.0f / (float)(s.NY * s.NX);
   const cf* Tin = t_in ? static_cast<const cf*>(t_in) : T;
+  // JCM_FFT_REG=0 (environment, read once): the LDS kernels for every pass -- the A/B arm of the register kernels (conv_fft_rows_reg.hip)
+  static const bool fft_reg = [] { const char* e = std::getenv("JCM_FFT_REG"); return !e || std::atoi(e) != 0; }();
   if (!xs_ready) {
     if (merge && !t_in) {
       cfft_rows_fwd_merge(s.NX, a, *merge, in_layout, T, twx, sc.tmax, st, sc.t16_fwd);
     } else if (!t_in) {
-      cfft_rows_fwd(s.NX, a, in_layout, T, twx, sc.tmax, st, sc.t16_fwd);
+      if (!(fft_reg && cfft_rows_fwd_reg(s.NX, a, in_layout, T, sc.tmax, st, sc.t16_fwd))) cfft_rows_fwd(s.NX, a, in_layout, T, twx, sc.tmax, st, sc.t16_fwd);
     }
     if (hipError_t ce = cfft_cols_fwd(s.NY, a, np, Tin, Xs, twy, p.NXH, p.MT, sc, st); ce != hipSuccess) return ce;
   }
@@ -390,8 +392,6 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
   if (g0 && hipEventRecord(g0, st) != hipSuccess) return hipErrorUnknown;
   if (hipError_t e = cgemm_split(Xs, a.wp, Yf, np, p.F, a.B, a.Cin, a.Cout, p.ldy, st); e != hipSuccess) return e;
   if (g1 && hipEventRecord(g1, st) != hipSuccess) return hipErrorUnknown;
-  // JCM_FFT_REG=0 (environment, read once): the LDS kernels for every inverse pass -- the A/B arm of the register kernels (conv_fft_rows_reg.hip)
-  static const bool fft_reg = [] { const char* e = std::getenv("JCM_FFT_REG"); return !e || std::atoi(e) != 0; }();
   ConvArgs ai = a;      // the inverse passes' view: windows keep their valid region only
   if (a0.circ) { ai.H = a0.H - 8; ai.W = a0.W - 8; }
   if (!(fft_reg && p.inv_cb == 64 && cfft_cols_inv_reg(s.NY, ai, Yf, T, p.NXH, p.ldy, opad, st, sc.t16_inv))) cfft_cols_inv(s.NY, ai, Yf, T, twy, p.NXH, p.ldy, opad, st, sc.t16_inv);

@@ -224,9 +224,102 @@ bool cfft_cols_inv_reg(int NY, const ConvArgs& a, const cf* Yf, cf* T, int NXH, 
   return true;
 }
 
+// ---- rows, forward (the contract of rows_fwd_kernel<NX, 1, T16 = true>, conv_fft_rows_fwd.hip): bf16 NHWC -> T16[kx][c/16][b][y][16], complex fp16 in block floating
+// point, one scale per (image, row, 64 channels) tile.  Two threads per channel pair again; the forward transform is decimation in frequency as well, so thread h
+// produces the outputs of parity h:  X[2 m + h] = sum_{j < M} u_h[j] w_M^(j m),  u_h[j] = (z[j] + (-1)^h z[j + M]) w_NX^(j h),  z = x_c + i x_{c+1}.
+// Thread h LOADS pixels [h M, h M + M) only and swaps words with its neighbour (DPP): each pixel is fetched once.  The Hermitian split into the two channels'
+// spectra pairs X[k] with X[NX - k], which has the parity of k: both live in the same thread (at a lane-selected register).  A wave is the 32 channel pairs =
+// 64 channels of one row = one block-floating-point tile: its scale is the wave's maximum (six shuffles, no barrier).
+template <int NX, int J>
+__device__ __forceinline__ void fwd_rows_in2(cf (&u)[NX / 2], const unsigned (&raw)[NX / 2], float sg, bool odd) {
+  constexpr int M = NX / 2;
+  const unsigned oth = (unsigned)__builtin_amdgcn_mov_dpp((int)raw[J], 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]: the neighbour's pixel
+  const cf a = bf16pair(raw[J]), o = bf16pair(oth);
+  cf v = cf{fmaf(sg, a.x, o.x), fmaf(sg, a.y, o.y)};      // h = 0: z[J] = a, z[J + M] = o -> a + o;  h = 1: z[J] = o, z[J + M] = a -> o - a
+  if constexpr (J > 0) {
+    const float wr = odd ? Tw<-J, NX>::re : 1.f, wi = odd ? Tw<-J, NX>::im : 0.f;      // e^{-2 pi i J / NX} for the odd outputs
+    v = cf{fmaf(-v.y, wi, v.x * wr), fmaf(v.x, wi, v.y * wr)};
+  }
+  u[J] = v;
+  if constexpr (J + 1 < M) fwd_rows_in2<NX, J + 1>(u, raw, sg, odd);
+}
+template <int N, int S, int K1>
+__device__ __forceinline__ void step2_inplace(cf (&x)[N]) {      // x[R2 K1 + k2] <- X[K1 + R1 k2]
+  constexpr int R1 = RPlan<N>::R1, R2 = RPlan<N>::R2;
+  cf o[R2];
+  step2_row<N, S, K1>(x, o);
+#pragma unroll
+  for (int k2 = 0; k2 < R2; ++k2) x[R2 * K1 + k2] = o[k2];
+  if constexpr (K1 + 1 < R1) step2_inplace<N, S, K1 + 1>(x);
+}
+// visit the outputs k = 2 m + h <= NX / 2 of this thread: f(m, X_c[k], X_{c+1}[k]) as (re, im, re, im)
+template <int NX, int MI, class F>
+__device__ __forceinline__ void fwd_rows_visit(const cf (&u)[NX / 2], bool odd, F&& f) {
+  constexpr int M = NX / 2, R1 = RPlan<M>::R1, R2 = RPlan<M>::R2;
+  constexpr int m0 = (M - MI) % M, m1 = M - 1 - MI;      // X[NX - k] = X_h[m0] (h = 0) or X_h[m1] (h = 1)
+  const cf zk = u[R2 * (MI % R1) + MI / R1], za = u[R2 * (m0 % R1) + m0 / R1], zb = u[R2 * (m1 % R1) + m1 / R1];
+  const cf zn = cf{odd ? zb.x : za.x, odd ? zb.y : za.y};
+  f(MI, make_float4(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y), 0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x)));
+  if constexpr (2 * (MI + 1) <= M) fwd_rows_visit<NX, MI + 1>(u, odd, f);
+}
+template <int NX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void rows_fwd_reg_kernel(const unsigned* __restrict__ in, uint2* __restrict__ T, int nrows, int B, int H, int W, int C,
+                                                                                              float* __restrict__ tmax, float* __restrict__ t16) {
+  constexpr int M = NX / 2;
+  const int CP = C >> 1;
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int h = (int)(g & 1), lane = threadIdx.x & 63;
+  const int p = (int)((g >> 1) % CP);
+  const size_t by = (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)((g >> 1) / CP));      // the row: the same for the 64 lanes (C % 64 == 0)
+  if (by >= (size_t)nrows) return;
+  const int b = (int)(by / H), y = (int)(by % H);
+  const bool odd = h != 0;
+  cf u[M];
+  {
+    const unsigned* src = in + (by * W) * CP + p;      // a word = channels (2 p, 2 p + 1) of a pixel
+    unsigned raw[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const int n = h * M + j;
+      raw[j] = n < W ? src[(size_t)n * CP] : 0u;
+    }
+    fwd_rows_in2<NX, 0>(u, raw, odd ? -1.f : 1.f, odd);
+  }
+  step1<M, -1>(u);
+  step2_inplace<M, -1, 0>(u);
+  // the tile's largest |component| (k = 2 m + h <= NX / 2 only: the thread of odd parity has one output less)
+  float m = 0.f;
+  fwd_rows_visit<NX, 0>(u, odd, [&](int mi, const float4& o) __attribute__((always_inline)) {
+    if (2 * mi + h <= M) m = fmaxf(fmaxf(m, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+  });
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft));
+  const float sc = bfp_scale(m);
+  const int cblk = p >> 5, v = p & 31;
+  if (lane == 0) {
+    t16[((size_t)b * (C >> 6) + cblk) * H + y] = 1.0f / sc;
+    if (tmax && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(tmax + b), __float_as_uint(m));      // the image's word of the spectra's scale (values >= 0 order like unsigned)
+  }
+  uint2* dst = T + ((((size_t)cblk * 4 + (v >> 3)) * B + b) * H + y) * 8 + (v & 7);      // t_fwd_index(k = 0); per kx: + (C / 16) B H 8
+  const size_t kstride = (size_t)(C >> 4) * B * H * 8;
+  fwd_rows_visit<NX, 0>(u, odd, [&](int mi, const float4& o) __attribute__((always_inline)) {
+    const int k = 2 * mi + h;
+    if (k <= M) dst[(size_t)k * kstride] = make_uint2(pack_h2(o.x * sc, o.y * sc), pack_h2(o.z * sc, o.w * sc));
+  });
+}
+// true: launched (96-point rows of a bf16 NHWC tensor, 16-bit T; W <= 96)
+bool cfft_rows_fwd_reg(int NX, const ConvArgs& a, int layout, cf* T, float* tmax, hipStream_t st, float* t16) {
+  if (NX != 96 || layout != 1 || !t16 || a.Cin % 64 || a.W > NX) return false;
+  const int nrows = a.B * a.H;
+  const size_t threads = (size_t)nrows * a.Cin;      // two threads per channel pair
+  hipLaunchKernelGGL(rows_fwd_reg_kernel<96>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, static_cast<const unsigned*>(a.x), reinterpret_cast<uint2*>(T), nrows, a.B,
+                     a.H, a.W, a.Cin, tmax, t16);
+  return true;
+}
+
 template <int NX> static bool launch_rows_inv_reg(const ConvArgs& a, int layout, const cf* T, int pad, float norm, const Fp16Scale& sc, hipStream_t st) {
   const int nrows = a.B * a.H;
-  if (a.Cout & 1) return false;      // channel pairs are stored as one word
+  if ((a.Cout & 1) || a.CoutP % 64) return false;      // channel pairs are stored as one word; a wave = 32 pairs of ONE row (the kernel keeps the row in scalar registers)
   const size_t threads = (size_t)nrows * a.CoutP;      // two threads per channel pair
   const dim3 grid((unsigned)((threads + 255) / 256)), blk(256);
   const bool h16 = sc.t16_inv != nullptr;
