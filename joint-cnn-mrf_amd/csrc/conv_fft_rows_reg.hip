@@ -215,12 +215,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NY >= 64 ? 
 }
 // true: launched (64-point columns, 64-channel tiles)
 bool cfft_cols_inv_reg(int NY, const ConvArgs& a, const cf* Yf, cf* T, int NXH, int ldy, int pad, hipStream_t st, float* t16) {
-  if ((NY != 64 && !(NY == 32 && !t16)) || a.CoutP % 64) return false;
+  if (a.CoutP % 64) return false;
   const size_t threads = (size_t)a.B * NXH * a.CoutP;
   const dim3 grid((unsigned)((threads + 255) / 256)), blk(256);
-  if (NY == 32) hipLaunchKernelGGL((cols_inv_reg_kernel<32, false>), grid, blk, 0, st, Yf, static_cast<void*>(T), a.B, a.H, NXH, a.CoutP, ldy, pad, nullptr);      // overlap-save windows (fp32)
-  else if (t16) hipLaunchKernelGGL((cols_inv_reg_kernel<64, true>), grid, blk, 0, st, Yf, static_cast<void*>(T), a.B, a.H, NXH, a.CoutP, ldy, pad, t16);
-  else hipLaunchKernelGGL((cols_inv_reg_kernel<64, false>), grid, blk, 0, st, Yf, static_cast<void*>(T), a.B, a.H, NXH, a.CoutP, ldy, pad, nullptr);
+#define CI_LAUNCH(N)                                                                                                                                             \
+  do {                                                                                                                                                           \
+    if (t16) hipLaunchKernelGGL((cols_inv_reg_kernel<N, true>), grid, blk, 0, st, Yf, static_cast<void*>(T), a.B, a.H, NXH, a.CoutP, ldy, pad, t16);            \
+    else hipLaunchKernelGGL((cols_inv_reg_kernel<N, false>), grid, blk, 0, st, Yf, static_cast<void*>(T), a.B, a.H, NXH, a.CoutP, ldy, pad, nullptr);          \
+  } while (0)
+  switch (NY) {      // 64: the 60 x 90 maps; 36 / 20: the half- and quarter-resolution branches; 32: the training step's overlap-save windows
+    case 64: CI_LAUNCH(64); break;
+    case 36: CI_LAUNCH(36); break;
+    case 32: CI_LAUNCH(32); break;
+    case 20: CI_LAUNCH(20); break;
+    default: return false;
+  }
+#undef CI_LAUNCH
   return true;
 }
 
