@@ -347,6 +347,8 @@ template <int NX> static bool launch_rows_inv_reg(const ConvArgs& a, int layout,
 bool cfft_rows_inv_reg(int NX, const ConvArgs& a, int layout, const cf* T, int pad, float norm, const Fp16Scale& sc, hipStream_t st) {
   if (NX == 96) return launch_rows_inv_reg<96>(a, layout, T, pad, norm, sc, st);
   if (NX == 32 && layout == 0) return launch_rows_inv_reg<32>(a, layout, T, pad, norm, sc, st);      // the training step's overlap-save windows (fp32)
+  if (NX == 50) return launch_rows_inv_reg<50>(a, layout, T, pad, norm, sc, st);      // the half- and quarter-resolution branches (36 x 50, 20 x 28 transforms)
+  if (NX == 28) return launch_rows_inv_reg<28>(a, layout, T, pad, norm, sc, st);
   return false;
 }
 

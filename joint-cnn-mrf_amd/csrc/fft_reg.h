@@ -67,6 +67,8 @@ template <> struct RPlan<64> { static constexpr int R1 = 8, R2 = 8; };
 template <> struct RPlan<48> { static constexpr int R1 = 4, R2 = 12; };
 template <> struct RPlan<32> { static constexpr int R1 = 4, R2 = 8; };
 template <> struct RPlan<16> { static constexpr int R1 = 4, R2 = 4; };
+template <> struct RPlan<25> { static constexpr int R1 = 5, R2 = 5; };
+template <> struct RPlan<14> { static constexpr int R1 = 2, R2 = 7; };
 template <> struct RPlan<50> { static constexpr int R1 = 5, R2 = 10; };
 template <> struct RPlan<36> { static constexpr int R1 = 3, R2 = 12; };
 template <> struct RPlan<28> { static constexpr int R1 = 4, R2 = 7; };
