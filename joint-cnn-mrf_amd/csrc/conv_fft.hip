@@ -396,7 +396,7 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
   if (a0.circ) { ai.H = a0.H - 8; ai.W = a0.W - 8; }
   if (!(fft_reg && p.inv_cb == 64 && cfft_cols_inv_reg(s.NY, ai, Yf, T, p.NXH, p.ldy, opad, st, sc.t16_inv))) cfft_cols_inv(s.NY, ai, Yf, T, twy, p.NXH, p.ldy, opad, st, sc.t16_inv);
   if (t_next) {
-    cfft_rows_inv_fwd(s.NX, a, T, static_cast<cf*>(t_next), twx, opad, norm, sc, st);
+    if (!(fft_reg && cfft_rows_inv_fwd_reg(s.NX, a, T, static_cast<cf*>(t_next), opad, norm, sc, st))) cfft_rows_inv_fwd(s.NX, a, T, static_cast<cf*>(t_next), twx, opad, norm, sc, st);
   } else if (!(fft_reg && cfft_rows_inv_reg(s.NX, ai, out_layout, T, opad, norm, sc, st))) {
     cfft_rows_inv(s.NX, ai, out_layout, T, twx, opad, norm, sc, st);
   }

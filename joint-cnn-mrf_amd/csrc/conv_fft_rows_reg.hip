@@ -327,6 +327,111 @@ bool cfft_rows_fwd_reg(int NX, const ConvArgs& a, int layout, cf* T, float* tmax
   return true;
 }
 
+// ---- rows, inverse of layer L + epilogue + rows, forward of layer L+1 (the contract of rows_inv_fwd_kernel, conv_fft_rows_inv.hip; fp32 handles): the activation
+// between two frequency-domain layers never goes to HBM.  Two threads per channel pair.  The inverse (decimation in frequency) leaves thread h with the pixels of
+// parity h (the kernel's pad is even).  The forward transform wants u_h[j] = (z[j] + (-1)^h z[j + M]) w^(j h), j < M = NX / 2: pixels j and j + M have the same
+// parity, so the thread of parity j % 2 forms s = z[j] + z[j + M] and d = z[j] - z[j + M] for ITS 24 values of j, keeps the one its own transform needs
+// (thread 0: s, thread 1: d) and swaps the other with its neighbour (DPP) -- 24 complex numbers cross lanes, nothing goes through LDS.
+template <int NX, int PAD, int I, class Act>
+__device__ __forceinline__ void fused_rows_mid(const cf (&x)[NX / 2], cf (&uu)[NX / 2], bool odd, int h, int W, Act&& act) {
+  constexpr int M = NX / 2, R1 = RPlan<M>::R1, R2 = RPlan<M>::R2, Q = M / 2;
+  // this thread's pixels n = 2 i + h, i < M:  the inverse's output X[2 (i + PAD / 2) + h], activated; zero behind the map (the next layer's padding)
+  constexpr int ma = I + PAD / 2, mb = I + Q + PAD / 2;      // sample indices of pixels 2 I + h and 2 (I + Q) + h
+  cf a = cf{0.f, 0.f}, bq = cf{0.f, 0.f};
+  if constexpr (ma < M) { if (2 * I + h < W) a = act(x[R2 * (ma % R1) + ma / R1]); }
+  if constexpr (mb < M) { if (2 * (I + Q) + h < W) bq = act(x[R2 * (mb % R1) + mb / R1]); }
+  const cf sm = a + bq, df = a - bq;                         // j = 2 I + h:  z[j] + z[j + M],  z[j] - z[j + M]
+  const cf keep = cf{odd ? df.x : sm.x, odd ? df.y : sm.y}, send = cf{odd ? sm.x : df.x, odd ? sm.y : df.y};
+  const cf recv = cf{__uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(send.x), 0xB1, 0xF, 0xF, true)),
+                     __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(send.y), 0xB1, 0xF, 0xF, true))};
+  // thread 0: u[2 I] = its s, u[2 I + 1] = the neighbour's s;  thread 1: u[2 I] = the neighbour's d, u[2 I + 1] = its d -- times w^(-j) for the odd outputs
+  cf e = cf{odd ? recv.x : keep.x, odd ? recv.y : keep.y}, o = cf{odd ? keep.x : recv.x, odd ? keep.y : recv.y};
+  if constexpr (I > 0) {
+    const float wr = odd ? Tw<-2 * I, NX>::re : 1.f, wi = odd ? Tw<-2 * I, NX>::im : 0.f;
+    e = cf{fmaf(-e.y, wi, e.x * wr), fmaf(e.x, wi, e.y * wr)};
+  }
+  {
+    const float wr = odd ? Tw<-(2 * I + 1), NX>::re : 1.f, wi = odd ? Tw<-(2 * I + 1), NX>::im : 0.f;
+    o = cf{fmaf(-o.y, wi, o.x * wr), fmaf(o.x, wi, o.y * wr)};
+  }
+  uu[2 * I] = e;
+  uu[2 * I + 1] = o;
+  if constexpr (I + 1 < Q) fused_rows_mid<NX, PAD, I + 1>(x, uu, odd, h, W, act);
+}
+template <int NX, int PAD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void rows_inv_fwd_reg_kernel(const float4* __restrict__ T, float4* __restrict__ Tn, const float* __restrict__ bias,
+                                                                                                  const float* __restrict__ scale, const float* __restrict__ shift, int relu_bn, int nrows,
+                                                                                                  int B, int H, int W, int C, float norm0, Fp16Scale sc) {
+  constexpr int NXH = NX / 2 + 1, M = NX / 2;
+  const int CP = C >> 1;
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int h = (int)(g & 1), lane = threadIdx.x & 63;
+  const int p = (int)((g >> 1) % CP);
+  const size_t by = (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)((g >> 1) / CP));      // the row: the same for the 64 lanes (C % 64 == 0)
+  if (by >= (size_t)nrows) return;
+  const int b = (int)(by / H), y = (int)(by % H), c = 2 * p;
+  const bool odd = h != 0;
+  cf u[M];
+  {
+    const float4* src = T + (by * NXH * C) / 2 + p;
+    auto load = [&](int k) __attribute__((always_inline)) { return src[(size_t)k * CP]; };      // (Ya.re, Ya.im, Yb.re, Yb.im)
+    inv_rows_load2<NX, false, 0>(u, odd ? -1.f : 1.f, odd, load);
+  }
+  float norm = norm0;
+  if (sc.tmax) {
+    float tm;
+    if (sc.common) {
+      tm = 0.f;
+      for (int i = lane; i < sc.nb; i += 64) tm = fmaxf(tm, sc.tmax[i]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o));
+    } else {
+      tm = sc.tmax[b];
+    }
+    norm = norm0 * sc.winv[0] * fp16_unscale(tm, sc.hf);
+  }
+  const float b0v = bias[c], b1v = bias[c + 1];
+  float s0 = 1.f, s1 = 1.f, h0 = 0.f, h1 = 0.f;
+  if (relu_bn) { s0 = scale[c]; h0 = shift[c]; s1 = scale[c + 1]; h1 = shift[c + 1]; }
+  step1<M, 1>(u);
+  step2_inplace<M, 1, 0>(u);      // u[R2 (m % R1) + m / R1] = X[2 m + h]: the pixel 2 m + h - PAD of this thread's parity
+  cf uu[M];
+  auto act = [&](cf z) __attribute__((always_inline)) {
+    float v0 = fmaf(z.x, norm, b0v), v1 = fmaf(z.y, norm, b1v);
+    if (relu_bn) { v0 = fmaf(fmaxf(v0, 0.f), s0, h0); v1 = fmaf(fmaxf(v1, 0.f), s1, h1); }
+    return cf{v0, v1};
+  };
+  fused_rows_mid<NX, PAD, 0>(u, uu, odd, h, W, act);
+  step1<M, -1>(uu);
+  step2_inplace<M, -1, 0>(uu);
+  const int cblk = p >> 5, v = p & 31;
+  float4* dst = Tn + ((((size_t)cblk * 4 + (v >> 3)) * B + b) * H + y) * 8 + (v & 7);      // t_fwd_index(k = 0); per kx: + (C / 16) B H 8
+  const size_t kstride = (size_t)(C >> 4) * B * H * 8;
+  float m = 0.f;
+  fwd_rows_visit<NX, 0>(uu, odd, [&](int mi, const float4& o) __attribute__((always_inline)) {
+    const int k = 2 * mi + h;
+    if (k <= M) {
+      dst[(size_t)k * kstride] = o;
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+    }
+  });
+  if (sc.tmax_next) {      // the next layer's per-image word (max |T|) of its spectra's scale
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(sc.tmax_next + b), __float_as_uint(m));
+  }
+}
+// true: launched (96-point rows, pad 2 or 4, whole 64-channel blocks)
+bool cfft_rows_inv_fwd_reg(int NX, const ConvArgs& a, const cf* T, cf* Tn, int pad, float norm, const Fp16Scale& sc, hipStream_t st) {
+  if (NX != 96 || (pad != 2 && pad != 4) || a.Cout % 64 || a.W > NX) return false;
+  const int nrows = a.B * a.H;
+  const size_t threads = (size_t)nrows * a.Cout;
+  const dim3 grid((unsigned)((threads + 255) / 256)), blk(256);
+  if (pad == 4) hipLaunchKernelGGL((rows_inv_fwd_reg_kernel<96, 4>), grid, blk, 0, st, reinterpret_cast<const float4*>(T), reinterpret_cast<float4*>(Tn), a.bias, a.scale, a.shift, a.relu_bn, nrows, a.B, a.H, a.W, a.Cout, norm, sc);
+  else hipLaunchKernelGGL((rows_inv_fwd_reg_kernel<96, 2>), grid, blk, 0, st, reinterpret_cast<const float4*>(T), reinterpret_cast<float4*>(Tn), a.bias, a.scale, a.shift, a.relu_bn, nrows, a.B, a.H, a.W, a.Cout, norm, sc);
+  return true;
+}
+
 template <int NX> static bool launch_rows_inv_reg(const ConvArgs& a, int layout, const cf* T, int pad, float norm, const Fp16Scale& sc, hipStream_t st) {
   const int nrows = a.B * a.H;
   if ((a.Cout & 1) || a.CoutP % 64) return false;      // channel pairs are stored as one word; a wave = 32 pairs of ONE row (the kernel keeps the row in scalar registers)
