@@ -7,7 +7,10 @@ argmax coordinates on the device) on 480x720x3 synthetic images, K=9, on N MI355
 A step = one pass of the whole path over one batch per GPU (BASELINE.json configs[1]: batch 64,
 fp32) with inputs already resident in HBM.  Ranks shard by batch (images are independent);
 the only collective is the all-gather of [B,2,9] int32 coordinates (main.py:573-574 -> RCCL).
-Prints ONE JSON line on rank 0 with the driver's contract keys plus `roofline` (dominant
+Rank 0 prints ONE compact JSON line (<= 4 KB: it must survive the driver's 8 KB stdout tail) as its LAST line of stdout: the driver's
+contract keys, `roofline`, `cpu_baseline` and `configs` = {name: {value, ms_per_step, dtype, frac, bound}} for every other configuration
+measured in the same run; the verbose record of every configuration goes to `bench_detail.json` (gpurun_out/ when that directory exists,
+else the working directory) and to stderr.  `roofline` (dominant
 kernel = the hand-written channel GEMM `cgemm_split_kernel` of the frequency-domain conv4_fullres /
 conv5 layers -- or, with the direct kernels selected, their MFMA implicit-GEMM launch -- timed live
 with HIP events on its stream) and `cpu_baseline` (the CPU restatement timed on the host cores;
@@ -46,6 +49,8 @@ PEAK_HBM_GBS = 8000.0                            # HBM3E spec (6.3 TB/s is what 
 # two 16-bit parts, three real products per real multiply: bf16 parts on bf16 handles, FP16 parts of spectra scaled by powers of two on
 # fp32 handles (22 significant bits: fp32-class).
 FFT_FREQS = 64 * 49
+FLOPS_SM = 4_856_014_800                 # the 81 pairwise convolutions as the reference computes them
+SM_ALGO_BYTES_PER_IMAGE = 14e6           # algorithmic HBM traffic of an FFT spatial model per image
 GEMM_LAYERS = {'conv4_fullres': (256, 512), 'conv5': (512, 512)}
 
 
@@ -79,6 +84,25 @@ def step_traffic(key):
         return None, None
 
 
+def sm_traffic(dtype):
+    """Measured HBM bytes per image of the spatial model's kernels (profiles/pmc_traffic.json: "sm_<dtype>")."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
+            rec = json.load(fh).get('sm_' + dtype, {})
+            return rec.get('bytes_per_image'), rec.get('source')
+    except OSError:
+        return None, None
+
+
+def agreement_reference(params, x, torso, local_rank, use_sm):
+    """The fp32 default engine's heat maps and coordinates on the resident images `x` (walked 64 at a time inside jcm_forward)."""
+    eng = Engine(device=local_rank, precision='fp32').load_params(params)
+    r = eng.forward(x, torso if use_sm else None, use_sm=use_sm, want_prob=True)
+    torch.cuda.synchronize()
+    eng.close()
+    return r
+
+
 def smi_sample():
     """Power / clock of GPU 0 from rocm-smi (best effort: None when the tool is missing or prints something unexpected)."""
     import subprocess
@@ -87,12 +111,15 @@ def smi_sample():
         rec = json.loads(txt[txt.index('{'):])
         card = rec[sorted(rec)[0]]
         out = {}
+        import re
         for k, v in card.items():
             kl = k.lower()
             if 'power' in kl and 'w' in kl:
                 out['power_w'] = float(str(v).split()[0])
-            elif kl.startswith('sclk clock'):
-                out['sclk_mhz'] = float(str(v).strip('()').lower().replace('mhz', ''))
+            elif kl.startswith('sclk clock speed'):      # "sclk clock speed:": "(2100Mhz)"  (the "sclk clock level" key holds the level index, not MHz)
+                m = re.search(r'([0-9.]+)\s*mhz', str(v).lower())
+                if m:
+                    out['sclk_mhz'] = float(m.group(1))
         return out or None
     except Exception:
         return None
@@ -125,18 +152,29 @@ def sustained(args, dtype, B, params, local_rank, dev, use_sm, seconds=10.0):
     return {'seconds': dt, 'steps': n, 'value': n * B / dt, 'unit': 'images/sec', 'ms_per_step': dt / n * 1e3, 'dtype': dtype, 'batch': B, 'smi': samples}
 
 
-def cpu_baseline(n_images, params):
-    """The oracle's torch-CPU formulation (fp32) on the host cores: the stand-in for the
-    reference's TF-CPU path, which cannot run here (no TensorFlow).  Bounded sample."""
+def cpu_baseline(params, reps=5, batches=(1, 8), budget_s=150.0):
+    """The oracle's torch-CPU formulation (fp32) on the host cores: the stand-in for the reference's TF-CPU path, which cannot run
+    here (no TensorFlow).  BASELINE.md section 3: B = 1 and B = 8, median of `reps` runs after one warm-up; bounded by `budget_s`
+    (a batch size stops repeating once the budget is spent; at least one run each).  `value` = the B = 8 median."""
     from oracle import jcm_oracle_torch as T
-    x, torso = synth.make_images(n_images, seed=99), synth.make_torso(n_images, seed=98)
+    nmax = max(batches)
+    x, torso = synth.make_images(nmax, seed=99), synth.make_torso(nmax, seed=98)
     T.forward(x[:1], torso[:1], params, dtype=torch.float32)          # warm-up (thread pools, oneDNN primitives)
-    t0 = time.time()
-    T.forward(x, torso, params, dtype=torch.float32)
-    dt = time.time() - t0
-    return {'value': n_images / dt, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d synthetic 480x720 images, full-size network, PD+SM, fp32 torch-CPU/oneDNN restatement '
-                      '(TensorFlow unavailable); host has %d logical CPUs' % (n_images, os.cpu_count())}
+    t_start, per = time.time(), {}
+    for b in batches:
+        times = []
+        for _ in range(reps):
+            t0 = time.time()
+            T.forward(x[:b], torso[:b], params, dtype=torch.float32)
+            times.append(time.time() - t0)
+            if time.time() - t_start > budget_s * (0.3 if b == batches[0] and len(batches) > 1 else 1.0):
+                break
+        per['b%d' % b] = {'images_per_s': b / float(np.median(times)), 'median_s': float(np.median(times)), 'runs': len(times)}
+    last = per['b%d' % batches[-1]]
+    return {'value': last['images_per_s'], 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port', **per,
+            'sample': 'B=%s synthetic 480x720 images, median of <=%d runs each after 1 warm-up, full-size network PD+SM, fp32 torch-CPU/oneDNN '
+                      'restatement (TensorFlow unavailable); value = B=%d; host has %d logical CPUs'
+                      % ('/'.join(str(b) for b in batches), reps, batches[-1], os.cpu_count())}
 
 
 def resident_inputs(B, rank, dev):
@@ -151,13 +189,14 @@ def resident_inputs(B, rank, dev):
     return x, torso
 
 
-def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32_conv=None, config_name=None, micro_batch=None, conv9_fft=None, fft_single=None):
+def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32_conv=None, config_name=None, micro_batch=None, conv9_fft=None, fft_single=None, fft_t16=None, agree=False):
     """Time `args.steps` steps of one (dtype, batch) configuration; returns the result dict on
     rank 0 (None elsewhere).  Timed region: barrier + synchronize on both sides, max over ranks.
     f32_conv='split': the fp32 path with its 60x90 9x9 layers on the bf16x6 split kernel (conv_split.hip).
     B is the rank's batch per step; jcm_forward walks it in micro-batches (256 bf16 / 64 fp32 unless `micro_batch`)."""
-    eng = Engine(device=local_rank, precision=dtype, f32_conv=f32_conv, micro_batch=micro_batch, conv9_fft=conv9_fft, fft_single=fft_single).load_params(params)
+    eng = Engine(device=local_rank, precision=dtype, f32_conv=f32_conv, micro_batch=micro_batch, conv9_fft=conv9_fft, fft_single=fft_single, fft_t16=fft_t16).load_params(params)
     x, torso = resident_inputs(B, rank, dev)                                          # resident in HBM
+    agree_ref = agreement_reference(params, x, torso, local_rank, use_sm) if agree and rank == 0 else None      # (outside every timed region)
 
     def step():
         r = eng.forward(x, torso if use_sm else None, use_sm=use_sm, want_prob=False)
@@ -176,15 +215,20 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
         dist.barrier()
     torch.cuda.synchronize()
     eng.set_profile(True)          # recycles the warm-up record; nothing is allocated here
+    # one event per step boundary on the launch stream (the engine enqueues on torch's current stream): the median step
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        evs[i].record()
         coords = step()
+    evs[args.steps].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     eng.set_profile(False)
+    step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -296,6 +340,38 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
                               'frac': gbs_step / PEAK_HBM_GBS, 'traffic_source': ssrc,
                               'note': 'SURVEY 8d prices the direct formulation at ~77 MB of activations per image; the five-pass frequency-domain route moves several times that'}
             out['path_tflops_note'] = 'images/s x direct-convolution FLOPs: the wide 9x9 layers execute 35x fewer in the frequency domain'
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        out['device_mem_used_gb'] = (total_b - free_b) / 1e9      # everything resident on this rank's GPU right after the timed steps (inputs, weights, filter spectra, workspace)
+        med = float(np.median(step_ms))
+        out['median_ms_per_step'] = med
+        out['value_median'] = B / (med * 1e-3)      # this rank's images / median step (HIP events on the launch stream; no barrier inside)
+        out['step_ms_min_max'] = [float(min(step_ms)), float(max(step_ms))]
+        if use_sm:
+            # an FFT spatial model reports HBM GB/s beside the MFMA yardstick: ~14 MB of algorithmic traffic per image (10 forward + 81
+            # product + 81 inverse spectra / frames); the fused route (sm_fused.hip) keeps all but the 10 likelihood spectra on the CU -- measured
+            # bytes per image (2 x FETCH_SIZE + WRITE_SIZE of its two kernels) in profiles/pmc_traffic.json
+            ms, n = eng.profile_read('sm')
+            if n:
+                imgs = B * args.steps / n                      # images per sm launch group (micro-batch)
+                gbs = SM_ALGO_BYTES_PER_IMAGE * imgs / (ms / n * 1e-3) / 1e9
+                smb, smsrc = sm_traffic(dtype)
+                rf['sm'] = {'ms_per_call': ms / n, 'images_per_call': imgs, 'algorithmic_bytes_per_image': SM_ALGO_BYTES_PER_IMAGE, 'achieved': gbs,
+                            'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS, 'traffic_bytes_per_image': smb, 'traffic_source': smsrc,
+                            'mfma_yardstick_tflops': FLOPS_SM * imgs / (ms / n * 1e-3) / 1e12}
+        if agree_ref is not None:
+            # north_star judges the bf16 configuration on arg-max agreement: this engine's coordinates against the fp32 default engine's on
+            # the same resident images (evaluation.py:15-24, main.py:389-397)
+            from joint_cnn_mrf_amd.evaluation import argmax_agreement
+            r = eng.forward(x, torso if use_sm else None, use_sm=use_sm, want_prob=True)
+            key = 'sm' if use_sm else 'pd'
+            a = argmax_agreement(agree_ref[key + '_prob'], agree_ref[key + '_coords'], r[key + '_prob'], r[key + '_coords'])
+            out['argmax_agreement'] = {'vs': 'fp32 default engine, same %d images, %s coordinates' % (B, 'spatial-model' if use_sm else 'part-detector'),
+                                       'exact': a['exact'], 'within1': a['within1'], 'mean_dist': a['mean_dist'], 'n_joints': a['n_joints'],
+                                       'safe': a['safe'], 'margin_mult': a['margin_mult'], 'rms_logprob_err': a['rms_logprob_err']}
+            if use_sm:
+                a = argmax_agreement(agree_ref['pd_prob'], agree_ref['pd_coords'], r['pd_prob'], r['pd_coords'])
+                out['argmax_agreement']['pd'] = {'exact': a['exact'], 'within1': a['within1'], 'mean_dist': a['mean_dist'], 'safe': a['safe']}
+            del r
         if fp32_equiv is not None:
             out['roofline']['fp32_equivalent_tflops'] = fp32_equiv
             out['roofline']['x_fp32_mfma_peak'] = fp32_equiv / PEAK_TFLOPS['fp32']
@@ -329,9 +405,12 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
         dist.barrier()
     torch.cuda.synchronize()
     eng.set_profile(True)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        evs[i].record()
         losses, _ = tr.train_step(x, y, moving=moving)
+    evs[args.steps].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -381,6 +460,7 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
                     kern[key] = {'kernel': what, 'launch_ms': ms / n, 'launches': n, 'achieved': tf, 'frac': tf / PEAK_TFLOPS[prec]}
         out = {'metric': 'images/sec joint training step (fwd+bwd+update), part detector + spatial model', 'value': value,
                'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+               'median_ms_per_step': float(np.median([evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)])),
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': 'bf16' if prec == 'bf16' else {'split': 'f32(bf16x6)', 'split16': 'f32(fp16x3)'}.get(f32_conv, 'f32(fp16x2 spectra, fft, overlap-save windows)' if fd else 'f32'), 'data': 'synthetic',
                'config': {'workload': 'configs[4]: joint training, batch=%d/GPU synthetic 480x720x3, %s%s, Adam, clip 4.0%s'
@@ -424,14 +504,18 @@ def main():
                     help='default: the headline line is configs[1] (fp32, batch 64) and configs[2] (bf16, batch 256) '
                          'is measured too and reported under "bf16_config2"')
     ap.add_argument('--no-sm', action='store_true', help='part detector only')
-    ap.add_argument('--f32-conv', default=None, choices=['exact', 'split', 'split16'], help='arithmetic of the DIRECT fp32 kernels of the headline run; anything but the default also leaves the frequency-domain route')
+    ap.add_argument('--f32-conv', default=None, choices=['exact', 'split16'], help='arithmetic of the DIRECT fp32 kernels of the headline run; anything but the default also leaves the frequency-domain route')
     ap.add_argument('--debug', action='store_true', help='filters/4 (main.py:40-41); not the headline config, fp32 only')
-    ap.add_argument('--cpu-images', type=int, default=4, help='size of the cpu_baseline sample (0 = skip)')
+    ap.add_argument('--cpu-reps', type=int, default=5, help='cpu_baseline: runs per batch size (B=1 and B=8, median; 0 = skip)')
+    ap.add_argument('--cpu-budget', type=float, default=150.0, help='cpu_baseline: seconds after which no further repetition is started')
+    ap.add_argument('--cpu-images', type=int, default=None, help='(deprecated) 0 = skip the cpu_baseline')
     ap.add_argument('--train', action='store_true', help='time the joint training step (configs[4]) instead of the forward; fp32, '
                                                          'default 16 images per GPU (batch 128 over 8 GPUs)')
     ap.add_argument('--overlap', action='store_true', help='--train, N > 1, RCCL: start each layer\'s gradient all-reduce during the backward pass')
     ap.add_argument('--layer-times', action='store_true', help='print the HIP-event time of every MFMA conv layer to stderr')
     args = ap.parse_args()
+    if args.cpu_images == 0:
+        args.cpu_reps = 0
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the
@@ -473,7 +557,7 @@ def main():
     if args.train:
         out = run_train(args, args.batch or 16, params, world, rank, local_rank, dev, use_sm)
         if rank == 0:
-            print(json.dumps(out))
+            emit(out)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -495,15 +579,17 @@ def main():
         head_batch = args.batch or (64 if head_dtype == 'fp32' else 256)
         head = run_config(args, head_dtype, head_batch, params, world, rank, local_rank, dev, use_sm,
                           f32_conv=args.f32_conv if head_dtype == 'fp32' else None, micro_batch=args.micro_batch)
-    second = second_x2 = second_mfma = split = split16 = config3 = chain = sus = None
+    second = second_x2 = second_mfma = split16 = config3 = chain = sus = None
     if args.dtype is None and not args.debug and not args.global_batch:
-        second = run_config(args, 'bf16', args.batch or 256, params, world, rank, local_rank, dev, use_sm)
+        # configs[2] (bf16, batch 256) with its arg-max agreement against the fp32 engine on the same images (single-rank runs: rank 0 alone
+        # would hold the other ranks at the barrier while it computes the reference)
+        second = run_config(args, 'bf16', args.batch or 256, params, world, rank, local_rank, dev, use_sm, agree=world == 1)
+        if world == 1:      # the strict operand form of the channel GEMM (two bf16 parts, three products, fp32 row-transformed tensors) beside the default
+            second_x2 = run_config(args, 'bf16', args.batch or 256, params, world, rank, local_rank, dev, use_sm, fft_single=False, fft_t16=False, agree=True,
+                                   config_name='configs[2], channel GEMM on two bf16 parts (fft_single=0)')
         # configs[2] on the direct bf16 MFMA kernels only (conv_strip_bf16_kernel for the 9x9 layers): the north star's
         # "9x9 + pairwise pass on the bf16 matrix cores" with its own driver-timed roofline
-        if world == 1:      # the round-3 operand form of the channel GEMM (two bf16 parts, three products) beside the default
-            second_x2 = run_config(args, 'bf16', args.batch or 256, params, world, rank, local_rank, dev, use_sm, fft_single=False,
-                                   config_name='configs[2], channel GEMM on two bf16 parts (fft_single=0)')
-        second_mfma = run_config(args, 'bf16', args.batch or 256, params, world, rank, local_rank, dev, use_sm, conv9_fft=False,
+        second_mfma = run_config(args, 'bf16', args.batch or 256, params, world, rank, local_rank, dev, use_sm, conv9_fft=False, agree=world == 1,
                                  config_name='configs[2], direct bf16 MFMA kernels only (conv9_fft=0)')
         # configs[3]: a FIXED global batch of 2048 images sharded over the ranks (main.py:511,516-517), bf16, micro-batches of 256;
         # present in every line so that the driver's N = 1/2/4/8 runs trace the strong-scaling curve
@@ -514,16 +600,14 @@ def main():
             if config3 is not None:
                 config3['scaling'] = 'strong'
     if args.dtype is None and not args.debug and not args.global_batch and world == 1:
-        # the same fp32 configuration with the 60x90 9x9 layers on the direct split kernels (three-way operand split, fp32-class
-        # error, same parity tests); reported beside the headline
-        # ... and on the exact fp32 MFMA accumulation chain (conv9_fft = 0: no reduced-precision operand anywhere); few steps, it is 18x slower
+        # the same fp32 configuration on the exact fp32 MFMA accumulation chain (conv9_fft = 0: no reduced-precision operand anywhere); few steps, it is 18x slower
         saved = args.steps, args.warmup
         args.steps, args.warmup = min(args.steps, 5), min(args.warmup, 1)
         chain = run_config(args, 'fp32', head_batch, params, world, rank, local_rank, dev, use_sm, conv9_fft=False,
                            config_name='configs[1], exact fp32 MFMA chain (conv9_fft=0)')
         args.steps, args.warmup = saved
         sus = sustained(args, head_dtype, head_batch, params, local_rank, dev, use_sm)
-        split = run_config(args, 'fp32', head_batch, params, world, rank, local_rank, dev, use_sm, f32_conv='split')
+        # ... and with the stride-1 layers on the direct split kernels (two fp16 parts per operand, three products: the A/B arm of the frequency-domain route)
         split16 = run_config(args, 'fp32', head_batch, params, world, rank, local_rank, dev, use_sm, f32_conv='split16')
 
     # configs[4] (joint training step, 16 images per GPU) beside the inference lines; single-GPU runs only, the
@@ -531,41 +615,109 @@ def main():
     train = {}
     if args.dtype is None and not args.debug and world == 1 and use_sm and not args.global_batch:
         train['train_config4_f32'] = run_train(args, 16, params, world, rank, local_rank, dev, use_sm, prec='fp32', f32_conv=None)
-        train['train_config4_f32_split'] = run_train(args, 16, params, world, rank, local_rank, dev, use_sm, prec='fp32', f32_conv='split')
-        train['train_config4_f32_split16'] = run_train(args, 16, params, world, rank, local_rank, dev, use_sm, prec='fp32', f32_conv='split16')
         train['train_config4_bf16'] = run_train(args, 16, params, world, rank, local_rank, dev, use_sm, prec='bf16', f32_conv=None)
 
     if rank == 0:
-        out = {'metric': 'images/sec (720x480, K=9 joints) part-detector+spatial-model fwd',
-               'value': head['value'], 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-               'ms_per_step': head['ms_per_step'], 'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
-               'dtype': head['dtype'], 'data': 'synthetic', 'config': head['config'], 'path_tflops': head['path_tflops'],
-               'roofline': head['roofline']}
-        if second is not None:
-            out['bf16_config2'] = second
-        if second_x2 is not None:
-            out['bf16_config2_bf16x2'] = second_x2
-        if second_mfma is not None:
-            out['bf16_config2_mfma'] = second_mfma
-        if config3 is not None:
-            out['config3_gb2048'] = config3
-        if chain is not None:
-            out['f32_chain_config1'] = chain
+        detail = {'metric': 'images/sec (720x480, K=9 joints) part-detector+spatial-model fwd',
+                  'value': head['value'], 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                  'ms_per_step': head['ms_per_step'], 'median_ms_per_step': head['median_ms_per_step'], 'value_median': head['value_median'] * world,
+                  'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
+                  'dtype': head['dtype'], 'data': 'synthetic', 'config': head['config'], 'path_tflops': head['path_tflops'],
+                  'roofline': head['roofline']}
+        others = {'bf16_config2': second, 'bf16_config2_bf16x2': second_x2, 'bf16_config2_mfma': second_mfma, 'config3_gb2048': config3,
+                  'f32_chain_config1': chain, 'f32_split16_config1': split16}
+        for key, o in others.items():
+            if o is not None:
+                detail[key] = o
         if sus is not None:
             sus['vs_value'] = sus['value'] / head['value']
-            out['sustained'] = sus
-        if split is not None:
-            out['f32_split_config1'] = split
-        if split16 is not None:
-            out['f32_split16_config1'] = split16
+            detail['sustained'] = sus
         for key, tr_out in train.items():
             if tr_out is not None:
-                out[key] = {k: tr_out[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'train_tflops', 'frac_of_mfma_peak', 'roofline') if k in tr_out}
-        if args.cpu_images > 0 and world == 1:      # the CPU baseline is a single-GPU-run item (rank 0, N = 1)
-            out['cpu_baseline'] = cpu_baseline(args.cpu_images, params)
-        print(json.dumps(out))
+                detail[key] = {k: tr_out[k] for k in ('value', 'unit', 'ms_per_step', 'median_ms_per_step', 'dtype', 'config', 'train_tflops', 'frac_of_mfma_peak', 'roofline', 'conv5_passes', 'workspace_gb') if k in tr_out}
+        if args.cpu_reps > 0 and world == 1 and not args.debug:      # the CPU baseline is a single-GPU-run item (rank 0, N = 1)
+            detail['cpu_baseline'] = cpu_baseline(params, reps=args.cpu_reps, budget_s=args.cpu_budget)
+        emit(detail)
     if world > 1:
         dist.destroy_process_group()
+
+
+def compact_roofline(rf, klen=96):
+    """The `roofline` object of the final line: the contract's keys, the kernel name cut to `klen` characters, and the step / spatial-model summaries."""
+    out = {k: rf.get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'launch_ms')}
+    out['kernel'] = (rf.get('kernel_name') or rf.get('kernel') or '')[:klen]
+    if 'mfma' in rf and rf['mfma'].get('frac') is not None:
+        out['mfma_frac'] = rf['mfma']['frac']
+    if 'hbm' in rf and rf['hbm'].get('frac') is not None:
+        out['hbm_frac'] = rf['hbm']['frac']
+    if 'step' in rf:
+        out['step'] = {k: rf['step'][k] for k in ('bytes_per_image', 'achieved', 'frac')}
+    if 'sm' in rf:
+        out['sm'] = {k: rf['sm'][k] for k in ('ms_per_call', 'algorithmic_bytes_per_image', 'traffic_bytes_per_image', 'achieved', 'unit', 'frac')}
+    return out
+
+
+def rnd(v, n=4):
+    """Round floats (recursively) so that the final line stays small."""
+    if isinstance(v, float):
+        return float('%.*g' % (n + 2, v))
+    if isinstance(v, dict):
+        return {k: rnd(x, n) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [rnd(x, n) for x in v]
+    return v
+
+
+def emit(detail):
+    """Verbose record -> bench_detail.json (+ stderr); ONE compact line (<= 4 KB) -> stdout, last."""
+    ddir = os.path.join(ROOT, 'gpurun_out') if os.path.isdir(os.path.join(ROOT, 'gpurun_out')) else os.getcwd()
+    dpath = os.path.join(ddir, 'bench_detail.json')
+    try:
+        with open(dpath, 'w') as fh:
+            json.dump(detail, fh)
+    except OSError:
+        dpath = None
+    print(json.dumps(detail), file=sys.stderr)
+    line = {k: detail[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'median_ms_per_step', 'higher_is_better', 'scaling',
+                                   'vs_baseline', 'dtype', 'data') if k in detail}
+    cfg = detail['config']
+    line['config'] = {'workload': cfg['workload'][:160], **{k: cfg[k] for k in ('batch_per_gpu', 'global_batch', 'micro_batch', 'use_sm', 'collective') if k in cfg}}
+    line['roofline'] = compact_roofline(detail['roofline'])
+    if 'cpu_baseline' in detail:
+        cb = detail['cpu_baseline']
+        line['cpu_baseline'] = {'value': cb['value'], 'unit': cb['unit'], 'cores': cb['cores'], 'kind': cb['kind'], 'sample': cb['sample'][:200],
+                                **{k: v['images_per_s'] for k, v in cb.items() if isinstance(v, dict) and 'images_per_s' in v}}
+    configs = {}
+    for key, o in detail.items():
+        if not isinstance(o, dict) or 'value' not in o or key in ('cpu_baseline',):
+            continue
+        rf = o.get('roofline') or {}
+        e = {'value': o['value'], 'ms_per_step': o['ms_per_step'], 'dtype': o['dtype'][:48] if isinstance(o.get('dtype'), str) else o.get('dtype')}
+        if 'median_ms_per_step' in o:
+            e['median_ms_per_step'] = o['median_ms_per_step']
+        if rf.get('frac') is not None:
+            e['frac'], e['bound'] = rf['frac'], rf.get('bound')
+        if 'step' in rf:
+            e['step_frac'] = rf['step']['frac']
+        if 'argmax_agreement' in o:
+            a = o['argmax_agreement']
+            e['argmax_agreement'] = {'exact': a['exact'], 'within1': a['within1'], 'n_joints': a['n_joints'],
+                                     'safe_exact': a['safe']['exact'], 'safe_within1': a['safe']['within1'], 'safe_n': a['safe']['n_joints']}
+        if key == 'sustained':
+            e = {'value': o['value'], 'ms_per_step': o['ms_per_step'], 'seconds': o['seconds'], 'vs_value': o.get('vs_value'), 'smi': o.get('smi')}
+        configs[key] = e
+    if configs:
+        line['configs'] = configs
+    if dpath:
+        line['detail'] = os.path.relpath(dpath, ROOT)
+    txt = json.dumps(rnd(line))
+    if len(txt) > 4096:      # never expected; keep the contract keys whatever happens
+        line.pop('configs', None)
+        line['configs_dropped'] = 'line exceeded 4 KB, see detail'
+        txt = json.dumps(rnd(line))
+    sys.stderr.flush()
+    print(txt)
+    sys.stdout.flush()
 
 
 if __name__ == '__main__':

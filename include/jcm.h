@@ -249,7 +249,10 @@ int jcm_train_apply(jcm_handle h, const float* grads, int optimizer, float lr, f
  * inside jcm_train_loss_grads, as soon as every kernel that writes grads[offset, offset+count) has been enqueued on
  * the handle's stream (one call per layer, last layer first; the spatial-model blocks first of all).  The host
  * records an event on that stream and starts the all-reduce of the range on another stream.  Every trainable
- * element is reported exactly once per call.  NULL disables. */
+ * element is reported exactly once per call.  NULL disables.
+ * The callback runs WITHOUT the library's per-device call lock: it may call read-only entry points (jcm_get_tensor,
+ * jcm_profile_read, jcm_last_error, another handle's calls).  It must not start a second training or forward call
+ * on the SAME handle (that call would reuse the workspace the running step lives in). */
 typedef void (*jcm_grad_ready_fn)(void* user, int64_t offset, int64_t count);
 int jcm_train_set_grad_callback(jcm_handle h, jcm_grad_ready_fn fn, void* user);
 int jcm_train_steps(jcm_handle h, int64_t* n_iters);     /* n_iters_tf (main.py:491) */

@@ -12,6 +12,8 @@
 
 namespace jcm {
 
+struct CallOrder;
+
 int fail(int code, const std::string& msg);     // sets the thread-local message of jcm_last_error()
 
 #define HIP_TRY(expr)                                                                                   \
@@ -139,6 +141,8 @@ struct jcm_ctx {
   std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
   std::vector<hipEvent_t> event_pool;   // recycled by jcm_profile_read / "profile"=0, destroyed by jcm_destroy
   jcm::TrainState* train = nullptr;   // created by jcm_train_begin
+  int call_depth = 0;                 // entry points of this handle on the host stack (> 1 only inside a gradient-ready callback)
+  jcm::CallOrder* order = nullptr;    // the outermost running entry point's chain guard (notify_ready suspends it around the user callback)
 };
 
 namespace jcm {
@@ -165,11 +169,17 @@ struct DeviceGuard {
 // source; this ordering is the guarantee that does not depend on having found them all.  jcm_set_option("call_order", 0) takes a handle
 // out of the chain (it neither waits nor records; tools/determinism.py and the soak tests use it to look for what the chain would hide).
 // The constructor also clears the transient hand-over fields an aborted call may have left behind and laps the fp16 scale-word ring.
+// The lock is NOT held while the host blocks or while user code runs: release() (record the chain event, unlock) precedes every
+// host-side wait at the end of an entry point, and the gradient-ready callback of jcm_train_loss_grads runs between release() and acquire(),
+// so a callback may call jcm_* entry points (a nested call on the SAME handle keeps the outer call's transient state: `nested`).
 struct CallOrder {
   jcm_ctx* c;
   std::unique_lock<std::mutex> lk;
+  bool nested = false;
   explicit CallOrder(jcm_ctx* ctx);
   ~CallOrder();
+  void acquire();      // lock the device's chain and make this stream wait for the previous call of another stream
+  void release();      // record the chain event behind what has been enqueued so far and unlock (idempotent)
   CallOrder(const CallOrder&) = delete;
   CallOrder& operator=(const CallOrder&) = delete;
 };

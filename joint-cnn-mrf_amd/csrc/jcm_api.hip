@@ -31,12 +31,10 @@ Chain g_chain[64];
 }  // namespace
 CallOrder::CallOrder(jcm_ctx* ctx) : c(ctx) {
   if (!c) return;
-  Chain& ch = g_chain[c->device & 63];
-  lk = std::unique_lock<std::mutex>(ch.mu);      // held until the call has queued its last kernel: two host threads never interleave their launches
-  if (c->call_order) {
-    if (!ch.ev && hipEventCreateWithFlags(&ch.ev, hipEventDisableTiming) != hipSuccess) ch.ev = nullptr;
-    if (ch.ev && ch.armed && ch.last != c->stream) (void)hipStreamWaitEvent(c->stream, ch.ev, 0);
-  }
+  nested = c->call_depth++ > 0;      // called from the gradient-ready callback of this handle's running training step
+  acquire();
+  if (nested) return;                // the outer call's hand-over fields and scale words stay as they are
+  c->order = this;
   // what an aborted call may have left behind
   c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; c->fft_xs = nullptr; c->fft_xs_ready = false; c->fft_tmax_in = nullptr;
   // the fp16-scale words are reused from the start only BETWEEN calls (a call keeps words of its early layers until its last ones: the training step)
@@ -47,11 +45,28 @@ CallOrder::CallOrder(jcm_ctx* ctx) : c(ctx) {
     c->fft_word_i = 0;
   }
 }
-CallOrder::~CallOrder() {
-  if (!c || !c->call_order) return;
+void CallOrder::acquire() {
+  if (!c || lk.owns_lock()) return;
   Chain& ch = g_chain[c->device & 63];
-  if (!ch.ev) return;
-  if (hipEventRecord(ch.ev, c->stream) == hipSuccess) { ch.armed = true; ch.last = c->stream; }
+  lk = std::unique_lock<std::mutex>(ch.mu);      // held while the call is queuing kernels: two host threads never interleave their launches
+  if (c->call_order) {
+    if (!ch.ev && hipEventCreateWithFlags(&ch.ev, hipEventDisableTiming) != hipSuccess) ch.ev = nullptr;
+    if (ch.ev && ch.armed && ch.last != c->stream) (void)hipStreamWaitEvent(c->stream, ch.ev, 0);
+  }
+}
+void CallOrder::release() {
+  if (!c || !lk.owns_lock()) return;
+  if (c->call_order) {
+    Chain& ch = g_chain[c->device & 63];
+    if (ch.ev && hipEventRecord(ch.ev, c->stream) == hipSuccess) { ch.armed = true; ch.last = c->stream; }
+  }
+  lk.unlock();
+}
+CallOrder::~CallOrder() {
+  if (!c) return;
+  release();
+  --c->call_depth;
+  if (!nested) c->order = nullptr;
 }
 
 int arena_reserve(jcm_ctx* c, size_t bytes) {
@@ -825,6 +840,7 @@ int jcm_set_tensor(jcm_handle h, const char* name, const float* data, const int6
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t.d), n * sizeof(float)));
   h->param_bytes += n * sizeof(float);
   HIP_TRY(hipMemcpyAsync(t.d, data, n * sizeof(float), hipMemcpyDefault, h->stream));
+  order.release();
   HIP_TRY(hipStreamSynchronize(h->stream));   // the caller may free `data` on return
   return JCM_OK;
 }
@@ -999,7 +1015,11 @@ static int forward_impl(jcm_handle h, const float* x, const float* torso, const 
     if (use_sm) {
       float* sml = arena_alloc<float>(c, n);
       float* smp = sm_prob ? sm_prob + o : nullptr;
-      JCM_TRY(sm_forward_impl(c, prob, K, torso + (size_t)b0 * hh * ww * tld, nb, sml, tld));       // main.py:528,530
+      hipEvent_t s0 = nullptr, s1 = nullptr;
+      if (!c->dry) JCM_TRY(prof_begin(c, &s0, &s1));
+      const int rs = sm_forward_impl(c, prob, K, torso + (size_t)b0 * hh * ww * tld, nb, sml, tld);       // main.py:528,530
+      if (!c->dry) prof_end(c, "sm", s0, s1, rs == JCM_OK);      // jcm_profile_read("sm"): the spatial model's kernels (bench.py roofline.sm)
+      JCM_TRY(rs);
       if (!c->dry && (smp || sm_coords))
         HIP_TRY(softmax_argmax(sml, smp, sm_coords ? sm_coords + (size_t)b0 * 2 * K : nullptr, nb, hh * ww, ww, K, c->stream));   // main.py:531
       if (losses && !c->dry) HIP_TRY(softmax_ce(sml, yb, nb, hh * ww, K, K + 1, 0.f, ce + (size_t)nb * K, nullptr, 0, 0, c->stream));   // main.py:539
@@ -1053,6 +1073,7 @@ int jcm_window_resize(jcm_handle h, const float* src, int nsrc, int H, int W, in
     if (c->dry) return (int)JCM_OK;
     HIP_TRY(hipMemcpyAsync(wdev, windows, (size_t)NW * 5 * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(window_resize(src, H, W, C, wdev, NW, mm, OH, OW, out, c->stream));
+    order.release();
     HIP_TRY(hipStreamSynchronize(c->stream));   // `windows` is caller-owned host memory
     return (int)JCM_OK;
   });

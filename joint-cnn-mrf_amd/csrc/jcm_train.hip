@@ -115,7 +115,11 @@ void notify_ready(jcm_ctx* c, const std::string& prefix) {
   TrainState* t = c->train;
   if (c->dry || !t->ready_fn) return;
   auto it = t->ranges.find(prefix);
-  if (it != t->ranges.end() && it->second.second > 0) t->ready_fn(t->ready_user, it->second.first, it->second.second);
+  if (it == t->ranges.end() || it->second.second <= 0) return;
+  // user code runs WITHOUT the device's call-chain lock (it may call jcm_* entry points, also of this handle: CallOrder::nested)
+  if (c->order) c->order->release();
+  t->ready_fn(t->ready_user, it->second.first, it->second.second);
+  if (c->order) c->order->acquire();
 }
 
 float* grad_of(TrainState* t, float* grads, const std::string& name) {
@@ -903,7 +907,10 @@ int jcm_train_apply(jcm_handle h, const float* grads, int optimizer, float lr, f
   if (grad_norm_out) {
     double ss = 0.0;
     HIP_TRY(hipMemcpyAsync(&ss, t->sumsq, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    order.release();      // other host threads of the device go on while this one waits
+    const hipError_t se = hipStreamSynchronize(c->stream);
+    order.acquire();
+    HIP_TRY(se);
     *grad_norm_out = (float)std::sqrt(ss);
   }
   JCM_TRY(refresh_derived(c, false));   // packed weights, folded moving statistics, softplus'd priors + spectra
@@ -929,6 +936,7 @@ int jcm_train_get_state(jcm_handle h, int slot, float* out, int64_t count, int64
   CallOrder order(h);
   if (out) {
     HIP_TRY(hipMemcpyAsync(out, slot ? t->opt_v : t->opt_m, t->total * sizeof(float), hipMemcpyDefault, h->stream));
+    order.release();
     HIP_TRY(hipStreamSynchronize(h->stream));
   }
   if (n_iters) *n_iters = t->step;
@@ -943,6 +951,7 @@ int jcm_train_set_state(jcm_handle h, int slot, const float* data, int64_t count
   CallOrder order(h);
   if (data) {
     HIP_TRY(hipMemcpyAsync(slot ? t->opt_v : t->opt_m, data, t->total * sizeof(float), hipMemcpyDefault, h->stream));
+    order.release();
     HIP_TRY(hipStreamSynchronize(h->stream));   // the caller may free `data` on return
   }
   t->step = (long)n_iters;
@@ -964,6 +973,7 @@ int jcm_get_tensor(jcm_handle h, const char* name, float* out, int64_t count) {
   DeviceGuard g(h->device);
   CallOrder order(h);
   HIP_TRY(hipMemcpyAsync(out, t->d, t->n * sizeof(float), hipMemcpyDefault, h->stream));
+  order.release();
   HIP_TRY(hipStreamSynchronize(h->stream));
   return JCM_OK;
 }
@@ -977,7 +987,10 @@ int jcm_update_tensor(jcm_handle h, const char* name, const float* data, int64_t
   DeviceGuard g(h->device);
   CallOrder order(h);
   HIP_TRY(hipMemcpyAsync(it->second.d, data, it->second.n * sizeof(float), hipMemcpyDefault, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));   // the caller may free `data` on return
+  order.release();
+  const hipError_t se = hipStreamSynchronize(h->stream);   // the caller may free `data` on return
+  if (refresh) order.acquire();
+  HIP_TRY(se);
   if (refresh) {
     JCM_TRY(refresh_derived(h, false));
     if (h->train) JCM_TRY(repack_dgrad(h));

