@@ -623,7 +623,7 @@ def main():
                   'ms_per_step': head['ms_per_step'], 'median_ms_per_step': head['median_ms_per_step'], 'value_median': head['value_median'] * world,
                   'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
                   'dtype': head['dtype'], 'data': 'synthetic', 'config': head['config'], 'path_tflops': head['path_tflops'],
-                  'roofline': head['roofline']}
+                  'roofline': head['roofline'], 'device_mem_used_gb': head.get('device_mem_used_gb')}
         others = {'bf16_config2': second, 'bf16_config2_bf16x2': second_x2, 'bf16_config2_mfma': second_mfma, 'config3_gb2048': config3,
                   'f32_chain_config1': chain, 'f32_split16_config1': split16}
         for key, o in others.items():

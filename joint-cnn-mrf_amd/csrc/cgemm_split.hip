@@ -5,10 +5,9 @@
 // there are NY * (NX/2+1) of them per layer (3136 for the 60x90 maps).  Round 2 ran them through a library fp32 GEMM on the fp32 matrix
 // pipe (1/16 of the bf16 rate).  This kernel runs them on v_mfma_f32_32x32x16_bf16 with SPLIT operands:
 //
-//   * an fp32 number is the exact sum of three bf16 numbers, x = x0 + x1 + x2 (8 significant bits each); every bf16 x bf16 product is
-//     exact in the fp32 accumulator.  fp32 handles (NP = 3) take the six products with p + q <= 2 -- what is dropped is below 2^-24 of
-//     x*w, the fp32 rounding itself -- bf16 handles (NP = 2, whose layer output is rounded to bf16 anyway) the three
-//     products x0w0 + x0w1 + x1w0 of two-part operands (16 significant bits).
+//   * a 16-bit x 16-bit product is exact in the fp32 accumulator, so an operand can be fed as a sum of 16-bit parts.  fp32 handles: two FP16
+//     parts of spectra scaled by powers of two (conv_fft_common.h: Fp16Scale), products x0w1 + x1w0 + x0w0 -- 22 significant bits; bf16
+//     handles: ONE scaled fp16 part (default) or two bf16 parts / three products (the strict arm, "fft_single" = 0).
 //   * the complex product is four real ones: Yr += Xr Wr - Xi Wi, Yi += Xr Wi + Xi Wr; the minus is a sign flip of the Xi fragment in
 //     registers (one v_xor per VGPR).  Both accumulators of an output element stay in the same lane.
 //   * both operands arrive ALREADY SPLIT in the exact image the LDS wants -- the activation spectra from the column pass of the forward
@@ -18,11 +17,7 @@
 //     (an MFMA operand lane holds 8 consecutive k of one row / column = one 16-byte unit; units of consecutive rows are consecutive, so
 //     every ds_read_b128 of a fragment is bank-conflict free.)  With two parts the split spectra are exactly as large as fp32 complex
 //     ones: no extra HBM traffic on bf16 handles.
-//   * fp32 handles: three bf16 parts are 1.5x the bytes of the fp32 number, and at 64 images per launch the filter spectra ARE the traffic
-//     (2 MB per frequency against 0.4 MB of activations), so there the filter spectra stay fp32 in HBM
-//         Wf[f][n-tile][k16][re|im][k-half][4-channel half][cols][4 fp32]
-//     and are split on the way: 16-byte global loads into registers one stage ahead (issued behind the MFMAs of the previous stage),
-//     v_cvt / v_sub, ds_write_b128 into the same LDS image.  The 9-channel logits layer gets a 32-column tile instead of 128.
+//   * two 16-bit parts are exactly as large as the fp32 number: no form inflates HBM traffic.  The 9-channel logits layer gets a 32-column tile.
 //   * a stage = one k16 step of all parts; R-deep ring, counted vmcnt + raw s_barrier (the DMA of stage g+R-1 is issued right after
 //     the barrier that opens stage g, so R-1 stages are in flight while one computes); the fragments of a product are read while the
 //     MFMAs of the previous one run.
@@ -44,42 +39,38 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace cg {
 
-// NP parts per operand; WM x WN waves, FM x FN 32x32 fragments per wave; R stages in LDS; WF32: the W operand arrives as fp32 and is split here
+// NP parts per operand; WM x WN waves, FM x FN 32x32 fragments per wave; R stages in LDS
 // HALF: the parts are fp16 (11 significant bits each; operands scaled into the fp16 range by the producers) instead of bf16
 // K32: ONE 16-bit part per operand; the two "part" planes of the NP = 2 layout hold the two 16-channel halves of a 32-channel stage instead
 // (product s = half s of X times half s of W): the same LDS image, the same DMA pieces, two products per stage that both advance K.
-template <int NP_, int WM_, int WN_, int FM_, int FN_, int R_, bool WF32_ = false, bool HALF_ = false, bool K32_ = false>
+template <int NP_, int WM_, int WN_, int FM_, int FN_, int R_, bool HALF_ = false, bool K32_ = false>
 struct Cfg {
   static constexpr int NP = NP_, WM = WM_, WN = WN_, FM = FM_, FN = FN_, R = R_;
-  static constexpr bool WF32 = WF32_, HALF = HALF_, K32 = K32_;
+  static constexpr bool HALF = HALF_, K32 = K32_;
   static constexpr int NW = WM * WN, NT = 64 * NW;
   static constexpr int MT = 32 * WM * FM, NTL = 32 * WN * FN;
   static constexpr int XST = 4 * NP * MT, WST = 4 * NP * NTL;      // 16-byte units per stage: [re|im][part][k-half][rows]
   static constexpr int STAGE = XST + WST;
-  static constexpr int XPW = XST / 64 / NW, WPW = WF32 ? 0 : WST / 64 / NW;    // 1-KB DMA pieces per wave per stage
+  static constexpr int XPW = XST / 64 / NW, WPW = WST / 64 / NW;    // 1-KB DMA pieces per wave per stage
   static constexpr int PW = XPW + WPW;
-  static constexpr int UPT = 4 * NTL / NT;                          // WF32: (re|im, k-half, column) source units of 8 fp32 per thread per stage
-  static constexpr int WL = WF32 ? 2 * UPT : 0;                     // ... = 16-byte global loads per thread per stage
-  static constexpr int WSRC = 4 * NTL * 32;                         // WF32: bytes of a stage of fp32 filter spectra
   static constexpr int LDS_BYTES = R * STAGE * 16;
-  static constexpr int NPROD = K32 ? 2 : NP == 3 ? 6 : NP == 2 ? 3 : 1;
+  static constexpr int NPROD = K32 ? 2 : NP == 2 ? 3 : 1;
   // cache policy of the filter-spectra DMA: the fp32 handles' tiles (two fp16 parts, <= 128 rows) are bound by that stream, which is read once per launch --
   // the nontemporal hint (bit 1) keeps it from pushing the re-read activation slabs out of the L2: -1.5 % per fp32 step in a same-box A/B; the one-part
   // bf16 form measured +0.8 % with it and keeps the default
-  static constexpr int WAUX = (HALF && !K32 && !WF32) ? 2 : 0;
-  static_assert(!K32 || (NP == 2 && !WF32), "K32 reuses the two-plane layout");
+  static constexpr int WAUX = (HALF && !K32) ? 2 : 0;
+  static_assert(!K32 || NP == 2, "K32 reuses the two-plane layout");
   static_assert(NTL == 128 || NTL == 32, "column tiles the filter spectra are laid out for");
-  static_assert(XST % (64 * NW) == 0 && (WF32 || WST % (64 * NW) == 0), "whole DMA pieces per wave");
-  static_assert(!WF32 || (R == 2 && (UPT == 1 || UPT == 2) && 4 * NTL % NT == 0), "in-kernel split: double buffer, one or two units per thread");
+  static_assert(XST % (64 * NW) == 0 && WST % (64 * NW) == 0, "whole DMA pieces per wave");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-  static_assert((R - 1) * PW + WL < 64, "vmcnt is a 6-bit counter");
+  static_assert((R - 1) * PW < 64, "vmcnt is a 6-bit counter");
 };
 
 // (x part, w part) of product s.  Any order gives the same sum up to fp32 rounding of the accumulator, which carries the whole K sum.
 template <class C> __device__ __forceinline__ constexpr int cprod_x(int s);
 template <class C> __device__ __forceinline__ constexpr int cprod_w(int s);
-template <int NP> __device__ __forceinline__ constexpr int prod_x(int s) { return NP == 3 ? (s == 0 ? 0 : s == 1 ? 1 : s == 2 ? 2 : s == 3 ? 1 : s == 4 ? 0 : 0) : NP == 2 ? (s == 0 ? 0 : s == 1 ? 1 : 0) : 0; }
-template <int NP> __device__ __forceinline__ constexpr int prod_w(int s) { return NP == 3 ? (s == 0 ? 2 : s == 1 ? 1 : s == 2 ? 0 : s == 3 ? 0 : s == 4 ? 1 : 0) : NP == 2 ? (s == 0 ? 1 : s == 1 ? 0 : 0) : 0; }
+template <int NP> __device__ __forceinline__ constexpr int prod_x(int s) { return NP == 2 ? (s == 0 ? 0 : s == 1 ? 1 : 0) : 0; }
+template <int NP> __device__ __forceinline__ constexpr int prod_w(int s) { return NP == 2 ? (s == 0 ? 1 : s == 1 ? 0 : 0) : 0; }
 
 template <class C> __device__ __forceinline__ constexpr int cprod_x(int s) { return C::K32 ? s : prod_x<C::NP>(s); }
 template <class C> __device__ __forceinline__ constexpr int cprod_w(int s) { return C::K32 ? s : prod_w<C::NP>(s); }
@@ -117,36 +108,11 @@ __device__ __forceinline__ f32x16 mfma16(const f32x4& a, const f32x4& b, const f
 
 struct Args {
   const char* xs;       // split activation spectra
-  const char* ws;       // filter spectra: split (bf16 parts) or fp32 (Cfg::WF32)
+  const char* ws;       // split filter spectra
   float2* y;            // [F][B][ldy]
   int F, B, ldy, KC;    // ldy: complex numbers per row of y; KC = Cin / 16
   int mtiles, ntiles;
 };
-
-// 8 fp32 -> NP 16-byte units of bf16 parts (x = x0 + x1 (+ x2), each part rounded to nearest even; exact for NP = 3)
-template <int NP, bool HALF = false>
-__device__ __forceinline__ void split_unit(const u32x4& lo, const u32x4& hi, u32x4 (&out)[NP]) {
-  float v[8];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(lo[e]); v[4 + e] = __uint_as_float(hi[e]); }
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    unsigned short q[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      if constexpr (HALF) {
-        const _Float16 r = static_cast<_Float16>(v[e]);      // round to nearest even
-        q[e] = __builtin_bit_cast(unsigned short, r);
-        v[e] = v[e] - static_cast<float>(r);
-      } else {
-        const __bf16 r = static_cast<__bf16>(v[e]);
-        q[e] = __builtin_bit_cast(unsigned short, r);
-        v[e] = v[e] - static_cast<float>(r);
-      }
-    }
-    out[p] = u32x4{(unsigned)q[0] | ((unsigned)q[1] << 16), (unsigned)q[2] | ((unsigned)q[3] << 16), (unsigned)q[4] | ((unsigned)q[5] << 16), (unsigned)q[6] | ((unsigned)q[7] << 16)};
-  }
-}
 
 template <class C>
 __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
@@ -154,8 +120,6 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NP = C::NP, FM = C::FM, FN = C::FN, MT = C::MT, NTL = C::NTL, R = C::R, NW = C::NW;
   constexpr int XST = C::XST, WST = C::WST, STAGE = C::STAGE;
-  constexpr bool WF32 = C::WF32;
-  constexpr int UPT = C::UPT, WL = C::WL;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / C::WN, wn = wid % C::WN;
@@ -170,7 +134,7 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
   const int KC = a.KC;
 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-  constexpr int WBYTES = WF32 ? C::WSRC : WST * 16;      // bytes of one stage of the W stream in HBM
+  constexpr int WBYTES = WST * 16;      // bytes of one stage of the W stream in HBM
   const char* xg = a.xs + ((size_t)(f * a.mtiles + mt) * KC) * (size_t)(XST * 16);
   const char* wg = a.ws + ((size_t)(f * a.ntiles + nt) * KC) * (size_t)WBYTES;
   const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xg), 0, KC * XST * 16, 0x00020000);
@@ -197,55 +161,6 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
     }
   };
 
-  // ---- WF32: fp32 filter spectra through registers.  A source unit = the 8 input channels (one k-half) of one (re|im, column): two
-  // 16-byte loads (the stream is [re|im][k-half][4-channel half][column][4 fp32], so each load instruction of a wave is 1 KB contiguous).
-  // UPT = 2: thread (column, k-half) owns the re and the im unit; UPT = 1 (32-column tile): thread (column, re|im, k-half).
-  // The loads are inline asm: the compiler would otherwise drain the LDS-DMA queue (vmcnt(0)) in front of their first use.
-  const int wcol = tid % NTL, wsel = tid / NTL;
-  u32x4 wreg[UPT > 0 ? UPT : 1][2];
-  u32x4 wdesc;      // the W buffer descriptor as four dwords for the asm loads
-  if constexpr (WF32) {      // raw buffer, stride 0: base, base high bits, bytes, flags (the same descriptor make_buffer_rsrc builds)
-    const unsigned long long wa = (unsigned long long)(size_t)wg;
-    wdesc = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wa), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wa >> 32)) & 0xffffu,
-                  (unsigned)(KC * WBYTES), 0x00020000u};
-  }
-  auto unit_of = [&](int u, int& c, int& kg) __attribute__((always_inline)) {
-    if constexpr (UPT == 2) { c = u; kg = wsel; } else { c = wsel >> 1; kg = wsel & 1; }
-  };
-  auto load_w = [&](int g) __attribute__((always_inline)) {
-    if constexpr (WF32) {
-      const unsigned goff = (unsigned)g * (unsigned)C::WSRC;      // in the vector offset: bounds-checked (see issue())
-#pragma unroll
-      for (int u = 0; u < UPT; ++u) {
-        int c, kg;
-        unit_of(u, c, kg);
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const unsigned voff = (unsigned)((((c * 2 + kg) * 2 + hh) * NTL + wcol) * 16) + goff;
-          asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(wreg[u][hh]) : "v"(voff), "s"(wdesc) : "memory");
-        }
-      }
-    }
-  };
-  auto split_w = [&](int slot, int u) __attribute__((always_inline)) {      // unit u of the registers -> NP units of the LDS image
-    if constexpr (WF32) {
-      int c, kg;
-      unit_of(u, c, kg);
-      u32x4 parts[NP];
-      split_unit<NP, C::HALF>(wreg[u][0], wreg[u][1], parts);
-      u32x4* dst = reinterpret_cast<u32x4*>(smem + (size_t)slot * STAGE * 16 + XST * 16) + ((c * NP) * 2 + kg) * NTL + wcol;
-#pragma unroll
-      for (int p = 0; p < NP; ++p) dst[p * 2 * NTL] = parts[p];
-    }
-  };
-  auto wait_w = [&](auto keep) __attribute__((always_inline)) {      // the W loads have landed (`keep` younger VMEM operations may stay in flight)
-    if constexpr (WF32) {
-      if constexpr (UPT == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(wreg[0][0]), "+v"(wreg[0][1]), "+v"(wreg[1][0]), "+v"(wreg[1][1]) : "i"(decltype(keep)::value) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wreg[0][0]), "+v"(wreg[0][1]) : "i"(decltype(keep)::value) : "memory");
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
   f32x16 accr[FM][FN], acci[FM][FN];
 #pragma unroll
   for (int fm = 0; fm < FM; ++fm)
@@ -254,19 +169,9 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) { accr[fm][fn][i] = 0.f; acci[fm][fn][i] = 0.f; }
 
-  if constexpr (WF32) {
-    // stage 0: X by DMA, W through the registers; then the loads of stage 1 go out
-    load_w(0);
-    issue(0, 0);
-    wait_w(std::integral_constant<int, C::XPW>{});
 #pragma unroll
-    for (int u = 0; u < UPT; ++u) split_w(0, u);
-    if (1 < KC) load_w(1);
-  } else {
-#pragma unroll
-    for (int s = 0; s < R - 1; ++s)
-      if (s < KC) issue(s, s);
-  }
+  for (int s = 0; s < R - 1; ++s)
+    if (s < KC) issue(s, s);
 
   // per-lane fragment addresses inside slot 0: unit (k-half h, row) of plane (re, part 0)
   unsigned xaddr = lds0 + (unsigned)(h * MT + wm * FM * 32 + l31) * 16u;
@@ -274,15 +179,13 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
 
   int slot = 0;
   for (int g = 0; g < KC; ++g) {
-    // this wave's DMA pieces of stage g have landed (R-2 younger stages -- WF32: the register loads of stage g+1 -- may stay in flight);
-    // after the barrier everybody's have (WF32: and everybody's split units of stage g are written), and every wave is done reading
-    // slot (g-1) % R, which the DMA of stage g+R-1 (WF32: and the split of stage g+1) now refills
+    // this wave's DMA pieces of stage g have landed (R-2 younger stages may stay in flight); after the barrier everybody's have, and every
+    // wave is done reading slot (g-1) % R, which the DMA of stage g+R-1 now refills
     // Nothing is ever requested for a stage past the last one (see issue()): behind the last stage nothing younger is in flight.
     static_assert(R == 2 || R == 3, "the wait below counts at most one younger stage");
     const bool last = g + 1 >= KC;
     if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"i"((R - 2) * C::PW + WL) : "memory");
-    if constexpr (WF32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"i"((R - 2) * C::PW) : "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     const int ns = slot == 0 ? R - 1 : slot - 1;
@@ -329,23 +232,7 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
     };
     product(std::integral_constant<int, 0>{});
     if constexpr (C::NPROD > 1) product(std::integral_constant<int, 1>{});
-    if constexpr (WF32) {
-      // the filter spectra of stage g+1 (requested a stage ago; the DMA pieces just issued stay in flight) -> bf16 parts -> the other slot,
-      // one unit behind each of the next products; then the loads of stage g+2 go out
-      if (!last) {
-        wait_w(std::integral_constant<int, C::XPW>{});
-        split_w(ns, 0);
-      }
-    }
     if constexpr (C::NPROD > 2) product(std::integral_constant<int, 2>{});
-    if constexpr (WF32) {
-      if constexpr (UPT == 2) { if (!last) split_w(ns, 1); }
-      __builtin_amdgcn_sched_barrier(0);
-      if (g + 2 < KC) load_w(g + 2);
-    }
-    if constexpr (C::NPROD > 3) product(std::integral_constant<int, 3>{});
-    if constexpr (C::NPROD > 4) product(std::integral_constant<int, 4>{});
-    if constexpr (C::NPROD > 5) product(std::integral_constant<int, 5>{});
     // next ring slot
     const bool wrap = slot == R - 1;
     const unsigned d = wrap ? (unsigned)(-(R - 1) * STAGE * 16) : (unsigned)(STAGE * 16);
@@ -392,24 +279,21 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
 using CfgB256 = Cfg<2, 4, 2, 2, 2, 3>;            // bf16 handles, 129 .. 256 images: the whole micro-batch in one 256 x 128 tile, W read once
 using CfgB128 = Cfg<2, 2, 2, 2, 2, 2>;            // bf16 handles, 65 .. 128 images (two work groups per CU)
 using CfgB64 = Cfg<2, 1, 4, 2, 1, 2>;             // bf16 handles, <= 64 images
-using CfgF64 = Cfg<3, 1, 4, 2, 1, 2, true>;       // fp32 handles, <= 64 images per tile; fp32 filter spectra split in the kernel
-using CfgF128 = Cfg<3, 2, 2, 2, 2, 2, true>;      // fp32 handles, > 64 images: 128-row tiles
-using CfgF64T = Cfg<3, 2, 1, 1, 1, 2, true>;      // fp32 handles, Cout <= 32 (the logits layer): 64 x 32 tile, two waves
 // fp32 handles, np = 4: TWO FP16 parts per operand, three products (22 significant bits; the producers scale the spectra by powers of two so that
 // they fit fp16's range, conv_fft.hip) -- half the matrix-core work of the six-product bf16 form, a third less activation-spectra traffic.
 // Two fp16 parts are exactly as large as the fp32 number, so the filter spectra are stored split and both operands arrive by LDS-DMA.
 #ifndef CGEMM_H64_R
 #define CGEMM_H64_R 2
 #endif
-using CfgH64 = Cfg<2, 1, 4, 2, 1, CGEMM_H64_R, false, true>;      // <= 64 images
-using CfgH128 = Cfg<2, 2, 2, 2, 2, 2, false, true>;               // 65 .. 128 images per tile
-using CfgH64T = Cfg<2, 2, 1, 1, 1, 3, false, true>;               // Cout <= 32 (the logits layer): 64 x 32 tile, two waves
+using CfgH64 = Cfg<2, 1, 4, 2, 1, CGEMM_H64_R, true>;      // <= 64 images
+using CfgH128 = Cfg<2, 2, 2, 2, 2, 2, true>;               // 65 .. 128 images per tile
+using CfgH64T = Cfg<2, 2, 1, 1, 1, 3, true>;               // Cout <= 32 (the logits layer): 64 x 32 tile, two waves
 
 // bf16 handles, np = 5: ONE scaled fp16 part per operand (11 significant bits -- eight times finer than the bf16 tensors the layer reads and
 // writes), 32 channels per stage: a third of the matrix-core work of the two-part form and half of its operand bytes.
-using CfgS256 = Cfg<2, 4, 2, 2, 2, 3, false, true, true>;
-using CfgS128 = Cfg<2, 2, 2, 2, 2, 2, false, true, true>;
-using CfgS64 = Cfg<2, 1, 4, 2, 1, 2, false, true, true>;
+using CfgS256 = Cfg<2, 4, 2, 2, 2, 3, true, true>;
+using CfgS128 = Cfg<2, 2, 2, 2, 2, 2, true, true>;
+using CfgS64 = Cfg<2, 1, 4, 2, 1, 2, true, true>;
 
 template <class C> hipError_t launch(const Args& a, hipStream_t st) {
   static LdsAttr attr;
@@ -422,35 +306,32 @@ template <class C> hipError_t launch(const Args& a, hipStream_t st) {
 
 }  // namespace cg
 
-// np: 2 = bf16 handles, two bf16 parts (filter spectra pre-split); 5 = bf16 handles, ONE scaled fp16 part, 32 channels per stage; 3 = fp32 handles,
-// three bf16 parts; 4 = fp32 handles, two fp16 parts (scaled)
-int cgemm_split_ntile(int np, int Cout) { return (np == 3 || np == 4) && Cout <= 32 ? 32 : 128; }
-int cgemm_split_parts(int np) { return np == 4 ? 2 : np == 5 ? 1 : np; }
+// np: 2 = bf16 handles, two bf16 parts; 5 = bf16 handles, ONE scaled fp16 part, 32 channels per stage; 4 = fp32 handles, two fp16 parts (scaled).
+// (np = 3, three bf16 parts / six products on fp32 handles, was retired in round 5: dominated by np = 4 on every axis.)
+int cgemm_split_ntile(int np, int Cout) { return np == 4 && Cout <= 32 ? 32 : 128; }
+int cgemm_split_parts(int np) { return np == 5 ? 1 : 2; }
 int cgemm_split_mtile(int np, int B, int Cout) {
   if (cgemm_split_ntile(np, Cout) == 32) return 64;
   if (np == 2 || np == 5) return B > 128 ? 256 : B > 64 ? 128 : 64;
   return B > 64 ? 128 : 64;
 }
-bool cgemm_split_w_fp32(int np) { return np == 3; }
 size_t cgemm_split_w_bytes(int np, int F, int Cin, int Cout) {
   const int ntl = cgemm_split_ntile(np, Cout);
   const size_t coutp = (size_t)(Cout + ntl - 1) / ntl * ntl;
-  return (size_t)F * Cin * coutp * (cgemm_split_w_fp32(np) ? 8 : 4 * cgemm_split_parts(np));
+  return (size_t)F * Cin * coutp * 4 * cgemm_split_parts(np);
 }
 
 hipError_t cgemm_split(const void* xs, const void* ws, void* y, int np, int F, int B, int Cin, int Cout, int ldy, hipStream_t st) {
   const int ntl = cgemm_split_ntile(np, Cout);
   const int ntiles = (Cout + ntl - 1) / ntl;
   const int kstep = np == 5 ? 32 : 16;      // channels per stage
-  if ((np < 2 || np > 5) || Cin % kstep || ldy < ntiles * ntl || F < 1 || B < 1) return hipErrorInvalidValue;
+  if ((np != 2 && np != 4 && np != 5) || Cin % kstep || ldy < ntiles * ntl || F < 1 || B < 1) return hipErrorInvalidValue;
   const int MT = cgemm_split_mtile(np, B, Cout);
   cg::Args a{static_cast<const char*>(xs), static_cast<const char*>(ws), static_cast<float2*>(y), F, B, ldy, Cin / kstep, (B + MT - 1) / MT, ntiles};
   if ((long long)a.KC * 8 * (MT > ntl ? MT : ntl) * 16 >= (1ll << 31)) return hipErrorInvalidValue;      // buffer descriptor range (at most 8 units per row and stage)
   if (np == 2) return MT == 256 ? cg::launch<cg::CfgB256>(a, st) : MT == 128 ? cg::launch<cg::CfgB128>(a, st) : cg::launch<cg::CfgB64>(a, st);
   if (np == 5) return MT == 256 ? cg::launch<cg::CfgS256>(a, st) : MT == 128 ? cg::launch<cg::CfgS128>(a, st) : cg::launch<cg::CfgS64>(a, st);
-  if (np == 4) return ntl == 32 ? cg::launch<cg::CfgH64T>(a, st) : MT == 128 ? cg::launch<cg::CfgH128>(a, st) : cg::launch<cg::CfgH64>(a, st);
-  if (ntl == 32) return cg::launch<cg::CfgF64T>(a, st);
-  return MT == 128 ? cg::launch<cg::CfgF128>(a, st) : cg::launch<cg::CfgF64>(a, st);
+  return ntl == 32 ? cg::launch<cg::CfgH64T>(a, st) : MT == 128 ? cg::launch<cg::CfgH128>(a, st) : cg::launch<cg::CfgH64>(a, st);
 }
 
 }  // namespace jcm

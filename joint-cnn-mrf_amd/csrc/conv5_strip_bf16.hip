@@ -54,13 +54,7 @@ constexpr unsigned kZeroSrc = 0x40000000u;             // a source offset beyond
 
 using namespace c5;
 
-#ifdef C5EXP_TIMING
-#include <cstdio>
-__device__ unsigned long long c5_dbg[8];
-#define C5_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&c5_dbg[i], t_ - t_prev); t_prev = t_; } } while (0)
-#else
 #define C5_T(i) do { } while (0)
-#endif
 
 template <int TP>
 __device__ __forceinline__ void c5_a_load(f32x4 (&fa)[MRMAX], const unsigned (&aaddr)[MRMAX], int mr) {
@@ -180,9 +174,6 @@ __device__ __forceinline__ void c5_tile(const ConvArgs& a, const Geom& gm, char*
   const int H = gm.H, W = gm.W, HW = gm.HW, P = gm.P;
   const int Cin = a.Cin, Cout = a.Cout;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-#ifdef C5EXP_TIMING
-  unsigned long long t_prev = __builtin_readcyclecounter();
-#endif
 
   unsigned aaddr[MRMAX], baddr;
 #pragma unroll
@@ -425,17 +416,6 @@ hipError_t conv5_strip_bf16(const ConvArgs& a, hipStream_t st) {
   static LdsAttr attr;
   if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(conv5_strip_bf16_kernel), LDS_BYTES); e != hipSuccess) return e;
   hipLaunchKernelGGL(conv5_strip_bf16_kernel, dim3(blocks), dim3(NT), LDS_BYTES, st, a, gm);
-#ifdef C5EXP_TIMING
-  {
-    unsigned long long h[8] = {0};
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(c5_dbg), sizeof(h));
-    fprintf(stderr, "c5 timing %dx%d Cin %d Cout %d (block 0 ticks): wait %llu  loop %llu  next-setup %llu  epilogue %llu  items/block %d\n", a.H, a.W, a.Cin, a.Cout, h[0], h[1],
-            h[2], h[3], (gm.items + blocks - 1) / blocks);
-    unsigned long long z[8] = {0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(c5_dbg), z, sizeof(z));
-  }
-#endif
   return hipGetLastError();
 }
 

@@ -35,9 +35,8 @@ namespace cfft {
 
 // ---- filter spectra, split: HWIO fp32 [k][k][Cin][Cout] -> Wf[f][ci][co] = sum_{a,b} w[k-1-a][k-1-b][ci][co] e^{-2 pi i (ky a / NY + kx b / NX)}
 // (the flipped kernel: TF's conv2d is a correlation; output channels Cout .. CoutP-1 are zero), written as the channel GEMM's operand
-// image Ws[f][co/ntl][ci/16][re|im][part][k-half][ntl columns][8 bf16] (cgemm_split.hip), or, NP = 0 (fp32 handles: the spectra stay fp32,
-// the GEMM splits them on the way): Wf[f][co/ntl][ci/16][re|im][k-half][4-channel half][ntl columns][4 fp32].
-// A thread owns the consecutive input channels of one 16-byte unit (8 bf16, or 4 fp32) of one output channel and one kx:
+// image Ws[f][co/ntl][ci/16][re|im][part][k-half][ntl columns][8 x 16 bit] (cgemm_split.hip).
+// A thread owns the 8 consecutive input channels of one 16-byte unit of one output channel and one kx:
 // the k row sums of its filters stay in registers, then for one ky after the other the k-term column sum gives their spectra,
 // which are split and stored straight from registers -- consecutive threads are consecutive output channels, so a wave's store instruction is
 // one contiguous 1-KB run.  No exchange through LDS, no barrier in the loop (round 3: the packer runs once per weight update in the training
@@ -61,8 +60,9 @@ __global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* 
     *dstw = cf{(float)cs, (float)sn};
   }
   __syncthreads();
-  constexpr int CPT = NP == 0 ? 4 : 8;                        // input channels per thread = one 16-byte unit of the layout
-  constexpr int NPP = NP == 4 ? 2 : NP == 5 ? 1 : NP;         // 16-byte units this thread writes per plane
+  constexpr int CPT = 8;                                      // input channels per thread = one 16-byte unit of the layout
+  constexpr int NPP = NP == 5 ? 1 : 2;                        // 16-byte units this thread writes per plane (NP = 2: bf16 parts, 4: fp16 parts, 5: one fp16 part)
+  static_assert(NP == 2 || NP == 4 || NP == 5, "operand forms of the channel GEMM");
   float wmul = 1.f;
   if constexpr (NP >= 4) {
     int ex = 0;
@@ -104,22 +104,18 @@ __global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* 
       for (int aa = 0; aa < KS; ++aa) ra[c][aa] = aa == a ? sum[c] : ra[c][aa];      // ... with the register array written by selects, not by index
   }
   const int KC = Cin / 16, ntiles = CoutP / ntl;
-  const int ci0 = cig * CPT, kc = ci0 >> 4, kg = (ci0 >> 3) & 1, q4 = (ci0 >> 2) & 1, nt = co / ntl, sn = co % ntl;      // q4: 4-channel half (NP = 0)
+  const int ci0 = cig * CPT, kc = ci0 >> 4, kg = (ci0 >> 3) & 1, nt = co / ntl, sn = co % ntl;
   // 16-byte units: stride between frequencies, and this thread's units inside one frequency
   // NP = 5: stages of 32 channels, the two planes of the NP = 2 layout = the stage's two 16-channel halves: unit ((c * 2 + half) * 2 + kg) * ntl + column
-  const size_t fstride = NP == 5 ? (size_t)ntiles * (KC >> 1) * 8 * ntl : (size_t)ntiles * KC * (NP == 0 ? 8 : 4 * NPP) * ntl;
+  const size_t fstride = NP == 5 ? (size_t)ntiles * (KC >> 1) * 8 * ntl : (size_t)ntiles * KC * (4 * NPP) * ntl;
   uint4* dst = Ws + (size_t)kx * NY * fstride +
                (NP == 5 ? ((size_t)nt * (KC >> 1) + (kc >> 1)) * 8 * ntl + ((size_t)(kc & 1) * 2 + kg) * ntl + sn :
-                NP == 0 ? (((((size_t)nt * KC + kc) * 2 + 0) * 2 + kg) * 2 + q4) * ntl + sn : ((size_t)nt * KC + kc) * (4 * NPP) * ntl + (size_t)kg * ntl + sn);
+                          ((size_t)nt * KC + kc) * (4 * NPP) * ntl + (size_t)kg * ntl + sn);
   // the spectrum of one ky -> this thread's units (split into the operand parts of the layout); streaming stores: nothing on this GPU reads them back soon
   typedef unsigned u32x4n __attribute__((ext_vector_type(4)));
   auto put = [](uint4* q, const uint4& v) __attribute__((always_inline)) { __builtin_nontemporal_store(u32x4n{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4n*>(q)); };
   auto emit = [&](uint4* d, const float (&xr)[CPT], const float (&xi)[CPT]) __attribute__((always_inline)) {
-    if constexpr (NP == 0) {
-      // [re|im][k-half][4-channel half][ntl][4 fp32]: the im unit lies 4 ntl units behind the re unit
-      put(d, make_uint4(__float_as_uint(xr[0]), __float_as_uint(xr[1]), __float_as_uint(xr[2]), __float_as_uint(xr[3])));
-      put(d + 4 * ntl, make_uint4(__float_as_uint(xi[0]), __float_as_uint(xi[1]), __float_as_uint(xi[2]), __float_as_uint(xi[3])));
-    } else if constexpr (NP == 5) {
+    if constexpr (NP == 5) {
       float x8[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) x8[c] = xr[c % CPT];
@@ -129,18 +125,18 @@ __global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* 
       put(d + (size_t)4 * ntl, round8h(x8, wmul));
     } else {
       // [re|im][part][k-half][ntl][8 bf16]
-      uint4 u[NPP > 0 ? NPP : 1];
+      uint4 u[NPP];
       float x8[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) x8[c] = xr[c % CPT];
       if constexpr (NP == 4) split8h(x8, wmul, u);
-      else split8<(NPP > 0 ? NPP : 1)>(x8, u);
+      else split8<NPP>(x8, u);
 #pragma unroll
       for (int p = 0; p < NPP; ++p) put(d + (size_t)p * 2 * ntl, u[p]);
 #pragma unroll
       for (int c = 0; c < 8; ++c) x8[c] = xi[c % CPT];
       if constexpr (NP == 4) split8h(x8, wmul, u);
-      else split8<(NPP > 0 ? NPP : 1)>(x8, u);
+      else split8<NPP>(x8, u);
 #pragma unroll
       for (int p = 0; p < NPP; ++p) put(d + (size_t)(NPP + p) * 2 * ntl, u[p]);
     }
@@ -263,7 +259,7 @@ bool conv_fft_supported(const ConvArgs& a, int ks) {
   Sizes s;
   return a.Cin % CB == 0 && a.Cin >= CB && a.Cout >= 1 && a.B >= 1 && sizes_of(a.H, a.W, ks, &s, a.circ);
 }
-// np: bf16 parts per operand (3 = fp32 handles, 2 = bf16 handles)
+// np: operand form of the channel GEMM (cgemm_split.hip): 4 = fp32 handles, 5 / 2 = bf16 handles
 size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout, int np, int circ) {
   Sizes s;
   if (!sizes_of(H, W, ks, &s, circ)) return 0;
@@ -271,13 +267,12 @@ size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout, int np, in
 }
 hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, int np, bool round_bf16, hipStream_t st, float* wscale, int circ) {
   Sizes s;
-  if (!sizes_of(H, W, ks, &s, circ) || Cin % 16 || np < 2 || np > 5 || (np >= 4 && !wscale) || (np == 5 && Cin % 32)) return hipErrorInvalidValue;
+  if (!sizes_of(H, W, ks, &s, circ) || Cin % 16 || (np != 2 && np != 4 && np != 5) || (np >= 4 && !wscale) || (np == 5 && Cin % 32)) return hipErrorInvalidValue;
   const int ntl = cgemm_split_ntile(np, Cout), CoutP = padn(Cout, ntl);
-  const size_t cpt = cgemm_split_w_fp32(np) ? 4 : 8;      // thread = (4 or 8 input channels: one 16-byte unit, output channel); one kx per block
+  const size_t cpt = 8;      // thread = (8 input channels: one 16-byte unit, output channel); one kx per block
   const dim3 grid((unsigned)(((size_t)Cin / cpt * CoutP + 255) / 256), (unsigned)(s.NX / 2 + 1));
   uint4* dst = static_cast<uint4*>(wf);
   const int rb = round_bf16 ? 1 : 0;
-  const bool f32 = cgemm_split_w_fp32(np);      // np = 3: unsplit fp32 spectra, the GEMM splits them
   if (np >= 4) {
     if (hipError_t e = hipMemsetAsync(wscale, 0, 2 * sizeof(float), st); e != hipSuccess) return e;
     const size_t pairs = (size_t)Cin * Cout;
@@ -285,9 +280,9 @@ hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, in
   }
 #define WS_LAUNCH(KS, NPV) hipLaunchKernelGGL((weight_spectra_split_kernel<KS, NPV>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, ntl, s.NY, s.NX, rb, wscale)
   if (ks == 9) {
-    if (f32) WS_LAUNCH(9, 0); else if (np == 2) WS_LAUNCH(9, 2); else if (np == 4) WS_LAUNCH(9, 4); else if (np == 5) WS_LAUNCH(9, 5); else WS_LAUNCH(9, 3);
+    if (np == 2) WS_LAUNCH(9, 2); else if (np == 4) WS_LAUNCH(9, 4); else WS_LAUNCH(9, 5);
   } else {
-    if (f32) WS_LAUNCH(5, 0); else if (np == 2) WS_LAUNCH(5, 2); else if (np == 4) WS_LAUNCH(5, 4); else if (np == 5) WS_LAUNCH(5, 5); else WS_LAUNCH(5, 3);
+    if (np == 2) WS_LAUNCH(5, 2); else if (np == 4) WS_LAUNCH(5, 4); else WS_LAUNCH(5, 5);
   }
 #undef WS_LAUNCH
   return hipGetLastError();
@@ -343,7 +338,7 @@ size_t conv_fft_handover_bytes(const ConvArgs& a, int ks) {      // T[kx][c/16][
 hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int out_layout, void* work, const void* t_in, void* t_next, const FftMerge* merge,
                         hipEvent_t g0, hipEvent_t g1, hipStream_t st, void* xs, bool xs_ready, const Fp16Scale* scp) {
   Sizes s;
-  if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s, a0.circ) || (out_layout == 2 && a0.Cout % 8) || np < 2 || np > 5 || (np == 5 && a0.Cin % 32)) return hipErrorInvalidValue;
+  if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s, a0.circ) || (out_layout == 2 && a0.Cout % 8) || (np != 2 && np != 4 && np != 5) || (np == 5 && a0.Cin % 32)) return hipErrorInvalidValue;
   if (a0.circ && (t_in || t_next || merge || in_layout != 0 || out_layout != 0)) return hipErrorInvalidValue;      // windows: fp32 NHWC in and out, nothing fused
   Fp16Scale sc;
   if (np >= 4) {

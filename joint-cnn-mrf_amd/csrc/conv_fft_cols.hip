@@ -6,7 +6,7 @@ namespace cfft {
 
 // ---- columns, forward + operand split: T[kx][c/16][b][y][16] -> Xs[f = kx NY + ky][m-tile][c/16][re|im][part][k-half][row][8] bf16
 // One work group = (IMG images, kx, one 16-channel chunk): its input is one contiguous run of T; after the FFT along y every spectrum is
-// split into NP bf16 parts (x = x0 + x1 (+ x2), each rounded to nearest: exact for NP = 3, 16 significant bits for NP = 2) and stored as
+// split into two bf16 parts (NP = 2: x = x0 + x1, each rounded to nearest, 16 significant bits) and stored as
 // 16-byte MFMA operand units -- 8 consecutive channels of one image -- with the units of the work group's IMG images consecutive: 128-byte
 // lines for IMG = 8.  The result is the channel GEMM's LDS image (cgemm_split.hip), which that kernel fetches by LDS-DMA.
 // NP = 4: two FP16 parts of the spectrum times the power-of-two scale derived from max|T| (Fp16Scale, conv_fft_common.h); layout as NP = 2.
@@ -16,7 +16,7 @@ namespace cfft {
 template <int NY, int NP, bool T16 = false>
 __global__ __launch_bounds__(colfwd_threads<NY>()) void cols_fwd_split_kernel(const cf* __restrict__ T, uint4* __restrict__ Xs, const cf* __restrict__ twg, int B, int H, int KC, int MT,
                                                             int mtiles, const float* __restrict__ tmax, int common, const float* __restrict__ t16) {
-  constexpr int IMG = colimg<NY>(), CH = IMG * 16, NTC = colfwd_threads<NY>(), NPP = NP == 4 ? 2 : NP == 5 ? 1 : NP;      // NPP: 16-byte units this work group writes per plane
+  constexpr int IMG = colimg<NY>(), CH = IMG * 16, NTC = colfwd_threads<NY>(), NPP = NP == 5 ? 1 : 2;      // NPP: 16-byte units this work group writes per plane
   extern __shared__ __attribute__((aligned(16))) char smem_cf[];
   cf* buf = reinterpret_cast<cf*>(smem_cf);
   cf* tw = buf + NY * CH;
@@ -150,7 +150,7 @@ template <int NY> static hipError_t launch_cols_fwd(const ConvArgs& a, int np, c
   constexpr int lds = (NY * IMG * 16 + NY) * (int)sizeof(cf);
   const int KC = a.Cin / 16, mtiles = (a.B + MT - 1) / MT;
   const dim3 grid((unsigned)(NXH * KC * ((a.B + IMG - 1) / IMG)));
-  static LdsAttr attr2, attr3, attr4, attr5, attr5h;
+  static LdsAttr attr2, attr4, attr5, attr5h;
   if (np == 5 && sc.t16_fwd) {
     constexpr int lds16 = lds + IMG * NY * (int)sizeof(float);      // + the row tiles' scale words
     if (!sc.tmax || (KC & 3)) return hipErrorInvalidValue;
@@ -168,8 +168,7 @@ template <int NY> static hipError_t launch_cols_fwd(const ConvArgs& a, int np, c
     if (hipError_t e = attr4.ensure(reinterpret_cast<const void*>(cols_fwd_split_kernel<NY, 4>), lds); e != hipSuccess) return e;
     hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 4>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles, sc.tmax, sc.common, nullptr);
   } else {
-    if (hipError_t e = attr3.ensure(reinterpret_cast<const void*>(cols_fwd_split_kernel<NY, 3>), lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL((cols_fwd_split_kernel<NY, 3>), grid, dim3(colfwd_threads<NY>()), lds, st, T, static_cast<uint4*>(Xs), tw, a.B, a.H, KC, MT, mtiles, nullptr, 0, nullptr);
+    return hipErrorInvalidValue;
   }
   return hipSuccess;
 }

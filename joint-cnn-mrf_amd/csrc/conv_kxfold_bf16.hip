@@ -57,18 +57,10 @@ struct Geom {
 
 using namespace kxf;
 
-#ifdef KXEXP_TIMING
-__device__ unsigned long long kx_dbg[8];
-#define KX_T(i) do { if (blockIdx.x == 0 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&kx_dbg[i], t_ - t_prev); t_prev = t_; } } while (0)
-#else
 #define KX_T(i) do { } while (0)
-#endif
 
 template <int MR, int KY>
 __device__ __forceinline__ void kx_loads(f32x4 (&fa)[MRMAX], f32x4 (&fb)[NF], const unsigned (&aaddr)[MRMAX], unsigned aoff, unsigned baddr) {
-#ifdef KXEXP_NOLDS
-  return;
-#endif
 #pragma unroll
   for (int g = 0; g < NF; ++g) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[g]) : "v"(baddr), "i"(KY * 2 * NCOL * 16 + g * 512) : "memory");
 #pragma unroll
@@ -133,12 +125,6 @@ __device__ __forceinline__ void kx_tile(const ConvArgs& a, const Geom& gm, char*
     const unsigned eb = __builtin_amdgcn_readlane(tb, i), ea = __builtin_amdgcn_readlane(ta, i);
     if (!(eb >> 29)) return;
     const bool wts = (eb >> 28) & 1u;
-#ifdef KXEXP_NOWDMA
-    if (wts && chunk > 1) return;
-#endif
-#ifdef KXEXP_NOXDMA
-    if (!wts && chunk > 1) return;
-#endif
     const unsigned slot = (eb & 0x3fffu) + (unsigned)bufsel * (wts ? (unsigned)WCH : (unsigned)XBUF);
     auto dst = (__attribute__((address_space(3))) char*)(size_t)(lds0 + slot * 16u);
     const unsigned lo = (eb >> 14) & 0x7fu, hi = (eb >> 21) & 0x7fu;
@@ -148,9 +134,6 @@ __device__ __forceinline__ void kx_tile(const ConvArgs& a, const Geom& gm, char*
     }
   };
 
-#ifdef KXEXP_TIMING
-  unsigned long long t_prev = __builtin_readcyclecounter();
-#endif
   // ---- zero both X buffers (gaps, rows outside the image), then chunk 0 into buffer 0
   __builtin_amdgcn_s_barrier();                        // the previous item's epilogue reads are done
   for (int i = tid; i < 2 * XBUF; i += NT) lds[XB0 + i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -158,10 +141,6 @@ __device__ __forceinline__ void kx_tile(const ConvArgs& a, const Geom& gm, char*
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int i = 0; i < EPW; ++i) dma(i, 0, 0);
-#ifdef KXEXP_NODMA
-#pragma unroll
-  for (int i = 0; i < EPW; ++i) dma(i, 1, 1);
-#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -196,9 +175,6 @@ __device__ __forceinline__ void kx_tile(const ConvArgs& a, const Geom& gm, char*
       const unsigned bo = KY < KS - 1 ? bcur : bnxt;
       // request j of the next row's fragments: A0 B0 A1 A2 B1 B2 (fragments beyond MR dropped)
       auto req = [&](int j) __attribute__((always_inline)) {
-#ifdef KXEXP_NOLDS
-        return;
-#endif
         if (KY == KS - 1 && !more) return;
         if (j == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[nxt][0]) : "v"(aaddr[0] + ao) : "memory");
         if (j == 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[nxt][0]) : "v"(bo), "i"(KN * 2 * NCOL * 16) : "memory");
@@ -207,14 +183,10 @@ __device__ __forceinline__ void kx_tile(const ConvArgs& a, const Geom& gm, char*
         if (j == 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[nxt][1]) : "v"(bo), "i"(KN * 2 * NCOL * 16 + 512) : "memory");
         if (j == 5) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[nxt][2]) : "v"(bo), "i"(KN * 2 * NCOL * 16 + 1024) : "memory");
       };
-#ifndef KXEXP_NOLDS
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this row's fragments (requested one row ago)
-#endif
       if constexpr (KY == KS - 1) {
-#ifndef KXEXP_NOBAR
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-#endif
       }
       __builtin_amdgcn_sched_barrier(0);
       constexpr int NM = MR * NF;
@@ -227,12 +199,10 @@ __device__ __forceinline__ void kx_tile(const ConvArgs& a, const Geom& gm, char*
         if (m < NM - 1) req(m);
         else
           for (int j = NM - 1; j < 6; ++j) req(j);
-#ifndef KXEXP_NODMA
         if (KY < KS - 2 && more) {                                  // rows 0..6 carry the 13 entries of the next chunk
           if (m == (NM >= 3 ? NM - 3 : 0) && 2 * KY < EPW) dma(2 * KY, chunk + 1, bufsel ^ 1);
           if (m == NM - 1 && 2 * KY + 1 < EPW) dma(2 * KY + 1, chunk + 1, bufsel ^ 1);
         }
-#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -384,16 +354,6 @@ hipError_t conv_kxfold_bf16(const ConvArgs& a, hipStream_t st) {
   static LdsAttr attr;
   if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(conv_kxfold_bf16_kernel), LDS_BYTES); e != hipSuccess) return e;
   hipLaunchKernelGGL(conv_kxfold_bf16_kernel, dim3(blocks), dim3(NT), LDS_BYTES, st, a, gm);
-#ifdef KXEXP_TIMING
-  {
-    unsigned long long h[8] = {0};
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(kx_dbg), sizeof(h));
-    fprintf(stderr, "kx timing (block 0, s_memtime ticks): prologue %llu  loop %llu  gather %llu  store %llu\n", h[0], h[1], h[2], h[3]);
-    unsigned long long z[8] = {0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(kx_dbg), z, sizeof(z));
-  }
-#endif
   return hipGetLastError();
 }
 

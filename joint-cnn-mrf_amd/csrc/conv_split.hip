@@ -442,14 +442,12 @@ bool conv_split_supported(int ks, int Cin, int CoutP, int B, int H, int W, int m
   return tiles * (CoutP / split_bn(CoutP, tiles)) >= min_wgs;
 }
 
-// ns = operand parts: 3 (bf16 parts, six products) or 2 (fp16 parts, three products)
+// ns = operand parts: 2 (fp16 parts, three products)
 size_t conv_split_weight_bytes(int ks, int Cin, int CoutP, int ns) { return (size_t)ks * ks * Cin * CoutP * 2 * ns; }
 
 hipError_t pack_weights_split(const float* w_hwio, void* wp, int ks, int Cin, int Cout, int CoutP, int ns, hipStream_t st, const float* w_scale) {
-  if (ns == 2)
-    hipLaunchKernelGGL(pack_weights_split16_kernel, dim3(2048), dim3(256), 0, st, w_hwio, static_cast<_Float16*>(wp), ks * ks, Cin, Cout, CoutP, w_scale);
-  else
-    hipLaunchKernelGGL(pack_weights_split_kernel, dim3(2048), dim3(256), 0, st, w_hwio, static_cast<__bf16*>(wp), ks * ks, Cin, Cout, CoutP);
+  if (ns != 2) return hipErrorInvalidValue;      // (ns = 3, three bf16 parts / six products, was retired in round 5)
+  hipLaunchKernelGGL(pack_weights_split16_kernel, dim3(2048), dim3(256), 0, st, w_hwio, static_cast<_Float16*>(wp), ks * ks, Cin, Cout, CoutP, w_scale);
   return hipGetLastError();
 }
 
@@ -472,8 +470,9 @@ hipError_t dispatch_s(const ConvArgs& a, int ks, hipStream_t st) {
 // a.x fp32 NHWC, a.wp from pack_weights_split with the same ns (CoutP a multiple of 128), a.out fp32
 hipError_t conv_split_f32(const ConvArgs& a, int ks, int ns, hipStream_t st) {
   if (!conv_split_supported(ks, a.Cin, a.CoutP, a.B, a.H, a.W, 0)) return hipErrorInvalidValue;
-  // fp16x3: three taps of weights per stage (108 MFMAs between barriers); bf16x6 carries three parts and stays at one tap
-  return ns == 2 ? dispatch_s<2, 3>(a, ks, st) : dispatch_s<3, 1>(a, ks, st);
+  if (ns != 2) return hipErrorInvalidValue;
+  // fp16x3: three taps of weights per stage (108 MFMAs between barriers)
+  return dispatch_s<2, 3>(a, ks, st);
 }
 
 }  // namespace jcm

@@ -59,23 +59,13 @@ struct Geom {
 using namespace strip;
 
 // one k16 step = one tap: A at slot offset `tp`, B at [tp][unit h][BN]
-// EXP_* macros: timing experiments only (tools/exp_build.sh); they break the result on purpose.
 template <int TP>
 __device__ __forceinline__ void s_a_load(f32x4 (&fa)[MR], const unsigned (&aaddr)[MR]) {
-#if defined(EXP_NOLDS) || defined(EXP_NOALDS)
-  return;
-#endif
 #pragma unroll
   for (int f = 0; f < MR; ++f) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[f]) : "v"(aaddr[f]), "i"(TP * 16) : "memory");
 }
 template <int TP, int G>      // column G of the wave's 4 B fragments: 32 channels = 512 bytes further on
 __device__ __forceinline__ void s_b_load(f32x4& fb, unsigned baddr) {
-#ifdef EXP_NOLDS
-  return;
-#endif
-#ifdef EXP_NOB1
-  if (TP == 1) return;
-#endif
   static_assert(TP * 2 * BN * 16 + G * 512 < 65536, "ds_read offset field is 16 bits");
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb) : "v"(baddr), "i"(TP * 2 * BN * 16 + G * 512) : "memory");
 }
@@ -86,19 +76,11 @@ template <int NC, int PAR, int STEP, int G, class After>      // NC: B fragments
 __device__ __forceinline__ void s_rot_g(f32x4 (&fa)[2][MR], f32x4 (&fb)[NC], const unsigned baddr, f32x16 (&acc)[MR][NC], After&& after) {
   if constexpr (G < NC) {
     constexpr int cur = (STEP + PAR) & 1;          // a stage has 3 steps: the A double buffer flips parity every stage
-#ifndef EXP_NOLDS
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(MR + NC - 1) : "memory");
-#endif
     __builtin_amdgcn_sched_barrier(0);
-#ifdef EXP_PRIO
-    __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
     for (int f = 0; f < MR; ++f)
       acc[f][G] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[G]), __builtin_bit_cast(bf16x8, fa[cur][f]), acc[f][G], 0, 0, 0);   // D^T: rows = channels, columns = pixels
-#ifdef EXP_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     __builtin_amdgcn_sched_barrier(0);
     s_b_load<(STEP + 1) % TPS, G>(fb[G], baddr);     // STEP == TPS-1: baddr already points at the next stage's buffer
     after(STEP * NC + G);
@@ -204,9 +186,6 @@ __device__ __forceinline__ void strip_tile(const ConvArgs& a, const Geom& gm, ch
   // zero the two planes once per item: gaps, rows outside the image and the 4 rows between two images are never written
   // again.  (The barrier in front: every wave has finished the LDS reads of the work group's previous item.)
   __builtin_amdgcn_s_barrier();
-#ifdef EXP_NOPROLOGUE
-  if (mt < 4)
-#endif
   for (int i = tid; i < 2 * PLANE; i += NT) lds[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -215,9 +194,6 @@ __device__ __forceinline__ void strip_tile(const ConvArgs& a, const Geom& gm, ch
   const int G = nchunk * NSTAGE;
 
   // ---- prologue: three weight stages + the whole halo of chunk 0, everything landed before the first read
-#ifdef EXP_NOPROLOGUE
-  if (mt < 4)
-#endif
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
     if constexpr (NC == NR) {
@@ -227,9 +203,6 @@ __device__ __forceinline__ void strip_tile(const ConvArgs& a, const Geom& gm, ch
       w_piece(0, s, wt0, s);
     }
   }
-#ifdef EXP_NOPROLOGUE
-  if (mt < 4)
-#endif
   bulk_halo(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -290,7 +263,6 @@ __device__ __forceinline__ void strip_tile(const ConvArgs& a, const Geom& gm, ch
     // ---- barrier that opens stage g: this wave's pieces of stage g+1 have landed (the newest batch stays in flight);
     // afterwards everybody's have, and ring slot (g-1)%4 and the halo rows that died with stage g-1 are free.
     // Every wave issues 3 weight pieces per stage + at most one halo part.
-#ifndef EXP_NOVMW
     {   // the previous batch (nw weight pieces + maybe a halo part) may stay in flight
       const int keep = nw + (prev_extra ? 1 : 0);
       if (keep == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -299,18 +271,13 @@ __device__ __forceinline__ void strip_tile(const ConvArgs& a, const Geom& gm, ch
       else if (keep == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-#endif
-#ifndef EXP_NOBAR
     __builtin_amdgcn_s_barrier();
-#endif
     __builtin_amdgcn_sched_barrier(0);
 
     // halo parts exist only in the first stage of a kernel row and in the first three stages of a chunk: the table is not even
     // looked at elsewhere (two thirds of the stages)
     unsigned eb = 0, ea = 0;
-#ifndef EXP_NOGATE
     if (si == 0 || st < 3)
-#endif
     {
       eb = __builtin_amdgcn_readlane(htab, st);
       ea = __builtin_amdgcn_readlane(htab, st + 32);
@@ -319,20 +286,15 @@ __device__ __forceinline__ void strip_tile(const ConvArgs& a, const Geom& gm, ch
     const bool extra = (eb >> 20) && hchunk < nchunk && (chunk | (int)((eb >> 19) & 1u)) != 0;   // this-chunk parts: chunk 0 came with the prologue
     // idx = 4 * step + MFMA group: the three weight pieces behind groups 0..2 of step 0, the halo part behind group 3
     auto dma = [&](int idx) __attribute__((always_inline)) {
-#ifdef EXP_NODMA
-      return;
-#endif
       if (idx >= 0 && idx < nw) {
         auto dst = (__attribute__((address_space(3))) char*)(size_t)(wm0 + (unsigned)(idx * 2 * BN * 16));
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, lane16 + wsoff + (unsigned)idx * TS, 0, 0, 0);
       }
-#ifndef EXP_NOHALO
       else if (idx == (NC == NR ? TPS : 1) && extra) {
         auto dst = (__attribute__((address_space(3))) char*)(size_t)(lds0 + (eb & 0xfffu) * 16u);
         if (lane16 < ((eb >> 8) & 0x7f0u))       // lanes past the row end stay off: the next row's slots are not touched
           __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)dst, 16, hvoff(), ea + (unsigned)hchunk * hcs, 0, 0);
       }
-#endif
     };
     auto nodma = [](int) __attribute__((always_inline)) {};
     auto dma1 = [&](int idx) __attribute__((always_inline)) { if constexpr (NC != NR) dma(idx); };   // NC = 1: one MFMA group per step, the DMA slots 1.. follow in step 1
@@ -417,24 +379,13 @@ __device__ __forceinline__ void strip_tile(const ConvArgs& a, const Geom& gm, ch
         for (int k = 0; k < 8; ++k) {
           float v = acc[f][gq][8 * u + k] + bi[k];
           if (a.relu_bn) v = fmaxf(v, 0.f) * sc[k] + sh[k];
-#ifdef EXP_NOEPI
-          special = special || v == 12345.678f;
-#endif
           ov[k] = static_cast<__bf16>(v);
         }
-#ifdef EXP_NOEPI
-        if (pp[f] >= 0 && special) {
-#else
         (void)special;
         if (pp[f] >= 0) {
-#endif
           const size_t o = a.out_planar ? (((size_t)pb[f] * (Cout >> 3) + (co >> 3)) * HW + pp[f]) * 8      // [B][Cout/8][H*W][8]: 32 pixels x 16 B contiguous
                                         : ((size_t)pb[f] * HW + pp[f]) * Cout + co;
-#ifdef EXP_NTSTORE
-          __builtin_nontemporal_store(ov, reinterpret_cast<bf16x8*>(static_cast<__bf16*>(a.out) + o));
-#else
           *reinterpret_cast<bf16x8*>(static_cast<__bf16*>(a.out) + o) = ov;
-#endif
         }
       }
     }

@@ -54,7 +54,7 @@ struct ConvLayer {
   bool has_bn = false;
   const float* w_raw = nullptr;   // HWIO (conv1 kernel reads it directly)
   float* wp = nullptr;            // packed for conv_igemm_f32
-  void* wp_split = nullptr;       // three bf16 parts per weight for conv_split_f32 (fp32 handles, "f32_conv" = 1)
+  void* wp_split = nullptr;       // two fp16 parts per weight for conv_split_f32 (fp32 handles, "f32_conv" = 2)
   int coutp_split = 0;
   float* wscale = nullptr;        // fp16x3: device {Sw, 1/Sw}, the power-of-two scale the packed weights carry
   void* wp_bf16 = nullptr;        // packed for conv_igemm_bf16
@@ -83,7 +83,7 @@ struct jcm_ctx {
   hipStream_t stream = nullptr;
   int precision = JCM_PRECISION_F32;
   int K = 9;
-  int f32_conv = 0;             // fp32 handles: 0 = exact fp32 MFMA everywhere, 1 = bf16x6 split kernels, 2 = fp16x3 forward + bf16x6 gradients
+  int f32_conv = 0;             // fp32 handles: 0 = default (frequency domain, or the exact fp32 MFMA chain with conv9_fft = 0), 2 = the direct fp16x3 split kernels (forward and gradients)
   float* act_scale = nullptr;   // fp16x3: device {S, 1/S} of the current layer input (computed before every launch), + scratch
   float* scale_scratch = nullptr;
   int split_min_wgs = 128;      // grids smaller than this keep the exact kernel (option "split_min_wgs")
@@ -112,7 +112,6 @@ struct jcm_ctx {
   int fft_single = 1;           // bf16 handles: the channel GEMM on ONE scaled fp16 part per operand (np = 5; 0 = two bf16 parts, three products)
   int fft_win = 1;              // training step of fp32 handles: frequency-domain layers on 32 x 32 overlap-save windows where that shrinks the filter-sized spectra (jcm_train.hip)
   int fft_t16 = 1;              // bf16 handles on the one-part route (fft_single): the row-transformed tensors T / T' as complex fp16 in block floating point (Fp16Scale::t16)
-  int fft_fp16 = 1;             // fp32 handles: the channel GEMM on two FP16 parts per operand (three products, scaled spectra); 0 = three bf16 parts (six products)
   // device words of the fp16 scaling (kernels.h: Fp16Scale): zeroed floats, one per image of every row-transformed tensor of a call.  They come from
   // blocks of kFftWords floats; a call that needs more than a block holds (a forward of > 20 000 images in one piece) gets further blocks on demand,
   // and the blocks are re-zeroed and reused from the start BETWEEN calls (CallOrder), in stream order behind every kernel that read the old words.
@@ -211,8 +210,8 @@ void prof_release_all(jcm_ctx* c, bool destroy);
 // c->fft_w under "<scope>@HxW", packed from L->w_raw when missing or invalidated); the training step uses both for its data gradient.
 bool takes_fft(jcm_ctx* c, const ConvLayer* L, int B, int H, int W);
 bool fft_spectra_valid(jcm_ctx* c, const std::string& scope, int H, int W, int circ = 0);
-// operand form of the channel GEMM on this handle (kernels.h): bf16 handles: 5 (one scaled fp16 part, default) or 2 (two bf16 parts); fp32 handles: 4 (two fp16 parts, default) or 3 (three bf16 parts)
-inline int fft_np(const jcm_ctx* c) { return c->precision == JCM_PRECISION_BF16 ? (c->fft_single ? 5 : 2) : (c->fft_fp16 ? 4 : 3); }
+// operand form of the channel GEMM on this handle (kernels.h): bf16 handles: 5 (one scaled fp16 part, default) or 2 (two bf16 parts); fp32 handles: 4 (two scaled fp16 parts)
+inline int fft_np(const jcm_ctx* c) { return c->precision == JCM_PRECISION_BF16 ? (c->fft_single ? 5 : 2) : 4; }
 int fft_new_words(jcm_ctx* c, int n, float** w);      // n zeroed device words of the scaling ring (one per image)
 // circ: x is a batch of overlap-save windows [B, H, W, Cin] that fill the transform, out their valid regions [B, H - 8, W - 8, Cout] (ConvArgs::circ)
 int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const void* x, int B, int H, int W, void* out, int in_layout, int out_layout, int circ = 0);

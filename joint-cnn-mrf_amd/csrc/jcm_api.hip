@@ -140,7 +140,7 @@ static int launch_conv_layer(jcm_ctx* c, const ConvLayer* L, const void* wp, con
   } else {
     a.CoutP = L->coutp;
     const bool use_split = L->wp_split && (L->thin ? c->f32_conv == 2 : conv_split_supported(L->ks, L->cin, L->coutp_split, B, H, W, c->split_min_wgs));
-    if (use_split && c->f32_conv == 2) {     // fp16x3: lift this input into the fp16 range by its own power-of-two scale
+    if (use_split) {     // fp16x3: lift this input into the fp16 range by its own power-of-two scale
       HIP_TRY(pow2_scale_of(static_cast<const float*>(x), (size_t)B * H * W * L->cin, c->act_scale, c->scale_scratch, c->stream));
       a.in_scale = c->act_scale;
       a.w_scale = L->wscale;
@@ -154,7 +154,7 @@ static int launch_conv_layer(jcm_ctx* c, const ConvLayer* L, const void* wp, con
     } else if (use_split) {
       a.wp = L->wp_split;
       a.CoutP = L->coutp_split;
-      HIP_TRY(conv_split_f32(a, L->ks, c->f32_conv == 2 ? 2 : 3, c->stream));
+      HIP_TRY(conv_split_f32(a, L->ks, 2, c->stream));
     } else {
       HIP_TRY(conv_igemm_f32(a, L->ks, c->stream));
     }
@@ -386,11 +386,11 @@ int refresh_derived(jcm_ctx* c, bool first) {
       if (!L.wp) JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&L.wp), n * sizeof(float)));
       HIP_TRY(pack_weights_f32(w.d, L.wp, L.ks, L.cin, L.cout, L.coutp, c->stream));
     }
-    if (c->precision == JCM_PRECISION_F32 && c->f32_conv >= 1 && (L.ks == 9 || L.ks == 5) && L.cin % 16 == 0 && L.cout % 128 == 0) {
-      const int ns = c->f32_conv == 2 ? 2 : 3;      // forward operand parts: bf16x6 or fp16x3
+    if (c->precision == JCM_PRECISION_F32 && c->f32_conv == 2 && (L.ks == 9 || L.ks == 5) && L.cin % 16 == 0 && L.cout % 128 == 0) {
+      const int ns = 2;      // operand parts of the direct split kernels: two fp16 parts, three products (fp16x3)
       L.coutp_split = L.cout;
       if (!L.wp_split) JCM_TRY(dev_alloc(c, &L.wp_split, conv_split_weight_bytes(L.ks, L.cin, L.coutp_split, ns)));
-      if (ns == 2) JCM_TRY(weight_scale(c, w, &L.wscale));
+      JCM_TRY(weight_scale(c, w, &L.wscale));
       HIP_TRY(pack_weights_split(w.d, L.wp_split, L.ks, L.cin, L.cout, L.coutp_split, ns, c->stream, L.wscale));
     }
     if (c->precision == JCM_PRECISION_F32 && c->f32_conv == 2 && L.ks == 9 && L.cout <= 16 && L.cin % 32 == 0) {   // logits layer, fp16x3
@@ -781,15 +781,6 @@ int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
     h->fft_t16 = value != 0;
     return JCM_OK;
   }
-  if (k == "fft_fp16") {   // allowed at any time; the filter spectra have another form: the cache is dropped
-    if ((value != 0) != (h->fft_fp16 != 0)) {
-      HIP_TRY(hipStreamSynchronize(h->stream));
-      for (auto& kv : h->fft_w) (void)hipFree(kv.second.p);
-      h->fft_w.clear();
-    }
-    h->fft_fp16 = value != 0;
-    return JCM_OK;
-  }
   if (k == "sm_chunk") {  // allowed at any time
     if (value < 1) return fail(JCM_ERR_ARG, "sm_chunk must be >= 1");
     h->sm_chunk = (int)value;
@@ -810,7 +801,7 @@ int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
     if (value != JCM_PRECISION_F32 && value != JCM_PRECISION_BF16) return fail(JCM_ERR_ARG, "precision must be 0 (f32) or 1 (bf16)");
     h->precision = (int)value;
   } else if (k == "f32_conv") {
-    if (value < 0 || value > 2) return fail(JCM_ERR_ARG, "f32_conv must be 0 (fp32 MFMA), 1 (bf16x6 split) or 2 (fp16x3 split forward)");
+    if (value != 0 && value != 2) return fail(JCM_ERR_ARG, "f32_conv must be 0 (default) or 2 (fp16x3 direct split kernels); 1 (bf16x6) was retired in round 5");
     h->f32_conv = (int)value;
   } else if (k == "n_joints") {
     if (value < 1 || value > 9) return fail(JCM_ERR_ARG, "n_joints must be in [1,9]");

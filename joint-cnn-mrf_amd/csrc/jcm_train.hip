@@ -19,7 +19,7 @@ struct BnSave {
 
 struct DgradW {
   float* wd = nullptr;     // packed flipped/transposed weights for conv_igemm_f32
-  void* wd_split = nullptr;  // the same in three bf16 parts for conv_split_f32 (handles with f32_conv = 1)
+  void* wd_split = nullptr;  // the same in two fp16 parts for conv_split_f32 (handles with f32_conv = 2)
   void* wd_bf16 = nullptr;   // bf16 handles: packed for conv_igemm_bf16
   int cinp_bf16 = 0, coutp_bf16 = 0;
   bool stale = true;       // packed before the last weight update
@@ -104,7 +104,7 @@ int ensure_dgrad_packed(jcm_ctx* c, const std::string& scope) {
     HIP_TRY(flip_transpose_weights(L->w_raw, t->scratch_flip, L->ks, L->cin, L->cout, d.cinp, c->stream));
     HIP_TRY(pack_weights_f32(t->scratch_flip, d.wd, L->ks, d.cinp, L->cin, d.coutp, c->stream));
     // gradients: bf16 parts (full fp32 range) in mode 1; fp16 parts + a per-tensor power-of-two scale in mode 2
-    if (d.wd_split) HIP_TRY(pack_weights_split(t->scratch_flip, d.wd_split, L->ks, d.cinp, L->cin, L->cin, c->f32_conv == 2 ? 2 : 3, c->stream, L->wscale));
+    if (d.wd_split) HIP_TRY(pack_weights_split(t->scratch_flip, d.wd_split, L->ks, d.cinp, L->cin, L->cin, 2, c->stream, L->wscale));
   }
   return JCM_OK;
 }
@@ -322,13 +322,12 @@ int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int ldz, int B, fl
   const int splits = wgrad_splits(L->ks, L->cin, L->cout, B, f.H);
   const size_t mark = c->arena_off;
   float* partial = arena_alloc<float>(c, n * splits);
-  // handles with f32_conv = 1: the bf16x6 split kernel on pre-split operands (wgrad_split.hip)
-  const bool split = !bf(c) && c->f32_conv >= 1 && wgrad_split_supported(L->ks, L->cin, ldz);
-  const bool h16 = split && c->f32_conv == 2;     // fp16x3: dz is lifted into the fp16 range by its own power-of-two scale
+  // handles with f32_conv = 2: the fp16x3 split kernel on pre-split operands (wgrad_split.hip); dz is lifted into the fp16 range by its own power-of-two scale
+  const bool h16 = !bf(c) && c->f32_conv == 2 && wgrad_split_supported(L->ks, L->cin, ldz);
   if (bf(c) && !wgrad_split_supported(L->ks, L->cin, ldz)) return fail(JCM_ERR_ARG, "no bf16 weight-gradient kernel for layer '" + f.scope + "'");
   const size_t nx = (size_t)B * f.H * f.W * L->cin, nz = (size_t)B * f.H * f.W * ldz;
-  char* xparts = split ? arena_alloc<char>(c, nx * (h16 ? 4 : 6)) : nullptr;
-  char* zparts = split ? arena_alloc<char>(c, nz * (h16 ? 4 : 6)) : nullptr;
+  char* xparts = h16 ? arena_alloc<char>(c, nx * 4) : nullptr;
+  char* zparts = h16 ? arena_alloc<char>(c, nz * 4) : nullptr;
   if (!c->dry) {
     if (h16) {
       // the scale computed here is reused by conv_dgrad of the same layer (every conv_dgrad follows its layer's conv_wgrad)
@@ -336,16 +335,12 @@ int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int ldz, int B, fl
       t->gscale_of = dz;
       HIP_TRY(split_parts16(static_cast<const float*>(f.in), xparts, nx, nullptr, c->stream));
       HIP_TRY(split_parts16(static_cast<const float*>(dz), zparts, nz, t->gscale, c->stream));
-    } else if (split) {
-      HIP_TRY(split_parts(static_cast<const float*>(f.in), xparts, nx, c->stream));
-      HIP_TRY(split_parts(static_cast<const float*>(dz), zparts, nz, c->stream));
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     JCM_TRY(prof_begin(c, &e0, &e1));
     hipError_t le;
     if (bf(c)) le = wgrad_bf16(f.in, dz, partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream);
     else if (h16) le = wgrad_split16(xparts, zparts, partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream);
-    else if (split) le = wgrad_split(xparts, zparts, partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream);
     else le = wgrad_f32(static_cast<const float*>(f.in), static_cast<const float*>(dz), partial, splits, L->ks, B, f.H, f.W, L->cin, L->cout, ldz, c->stream);
     prof_end(c, "wgrad:" + f.scope, e0, e1, le == hipSuccess);      // read with jcm_profile_read("wgrad:<scope>")
     if (le != hipSuccess) return fail(JCM_ERR_HIP, "weight-gradient launch of '" + f.scope + "': " + hipGetErrorString(le));
@@ -407,10 +402,10 @@ int conv_dgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int B, void* dx, i
   a.x = dz; a.wp = d.wd; a.bias = t->zeros; a.scale = t->ones; a.shift = t->zeros; a.out = dx;
   a.B = B; a.H = f.H; a.W = f.W; a.Cin = d.cinp; a.Cout = f.L->cin; a.CoutP = d.coutp; a.relu_bn = 0;
   const bool split = d.wd_split && conv_split_supported(f.L->ks, d.cinp, f.L->cin, B, f.H, f.W, c->split_min_wgs);
-  const int ns = c->f32_conv == 2 ? 2 : 3;
+  const int ns = 2;      // fp16 parts (f32_conv = 2)
   if (split) {
     a.wp = d.wd_split; a.CoutP = f.L->cin;
-    if (ns == 2) {
+    {
       if (t->gscale_of != dz) {                   // normally set by this layer's conv_wgrad just before
         HIP_TRY(pow2_scale_of(static_cast<const float*>(dz), (size_t)B * f.H * f.W * d.cinp, t->gscale, t->gscratch, c->stream));
         t->gscale_of = dz;
@@ -725,8 +720,8 @@ int jcm_train_begin(jcm_handle h) {
       JCM_TRY(dev_alloc(c, &d.wd_bf16, (size_t)L.ks * L.ks * d.cinp_bf16 * d.coutp_bf16 * 2));
     } else {
       JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&d.wd), (size_t)L.ks * L.ks * d.cinp * d.coutp * sizeof(float)));
-      if (c->f32_conv >= 1 && L.cin % 128 == 0)      // data gradient on the bf16x6 split kernel where its tile fits
-        JCM_TRY(dev_alloc(c, &d.wd_split, conv_split_weight_bytes(L.ks, d.cinp, L.cin, 3)));   // sized for three parts, two used in mode 2
+      if (c->f32_conv == 2 && L.cin % 128 == 0)      // data gradient on the fp16x3 split kernel where its tile fits
+        JCM_TRY(dev_alloc(c, &d.wd_split, conv_split_weight_bytes(L.ks, d.cinp, L.cin, 2)));
     }
     const size_t nf = (size_t)L.ks * L.ks * (d.cinp_bf16 > d.cinp ? d.cinp_bf16 : d.cinp) * L.cin;
     if (nf > max_w) max_w = nf;

@@ -143,13 +143,11 @@ size_t conv_fft_handover_bytes(const ConvArgs& a, int ks);
 // ---- cgemm_split.hip : Y[f][b][co] = sum_ci X[f][b][ci] W[f][ci][co] (complex) for F frequencies on v_mfma_f32_32x32x16_bf16, operands
 // as np bf16 parts in tile-major LDS-image layout:
 //   xs[f][m-tile][Cin/16][re|im][part][k-half][MT rows][8 bf16]   (MT = cgemm_split_mtile(np, B, Cout); rows >= B are never stored)
-//   ws[f][n-tile][Cin/16][re|im][part][k-half][ntl cols][8 bf16]  (np = 2), or fp32, split by the kernel (np = 3: cgemm_split_w_fp32):
-//   ws[f][n-tile][Cin/16][re|im][k-half][4-channel half][ntl cols][4 fp32];   ntl = cgemm_split_ntile(np, Cout): 128, or 32 for Cout <= 32 on fp32 handles
+//   ws[f][n-tile][Cin/16][re|im][part][k-half][ntl cols][8 x 16 bit];   ntl = cgemm_split_ntile(np, Cout): 128, or 32 for Cout <= 32 on fp32 handles
 //   y [f][B][ldy] complex fp32, ldy >= Cout rounded up to whole N tiles
 int cgemm_split_mtile(int np, int B, int Cout);
 int cgemm_split_ntile(int np, int Cout);
-int cgemm_split_parts(int np);      // 16-bit parts per operand: np, or 2 for np = 4 (two fp16 parts)
-bool cgemm_split_w_fp32(int np);
+int cgemm_split_parts(int np);      // 16-bit parts per operand: 2 (np = 2: bf16, np = 4: fp16) or 1 (np = 5)
 size_t cgemm_split_w_bytes(int np, int F, int Cin, int Cout);
 hipError_t cgemm_split(const void* xs, const void* ws, void* y, int np, int F, int B, int Cin, int Cout, int ldy, hipStream_t st);
 
@@ -317,8 +315,7 @@ hipError_t wgrad_f32(const float* x, const float* dz, float* partial, int splits
 hipError_t wgrad_reduce(const float* partial, int splits, size_t n, const float* w, float lmbd, float* dw, hipStream_t st, const float* out_scale = nullptr);
 int wgrad_conv1_blocks(void);
 hipError_t wgrad_conv1(const float* x, const void* dz, bool dz_bf16, float* partial, int B, int H0, int W0, int sub, int Cout, hipStream_t st);
-// wgrad_split.hip: the same on the bf16 matrix cores (three-way operand split, six products, LDS transpose reads)
-hipError_t split_parts(const float* x, void* out_bf16_3n, size_t n, hipStream_t st);    // out[p*n + i] = part p of x[i]
+// wgrad_split.hip: the same on the 16-bit matrix cores (two fp16 parts per operand, three products; or plain bf16 operands), LDS transpose reads
 // two fp16 parts of x * S (S = scale[0], a device scalar; null = 1)
 hipError_t split_parts16(const float* x, void* out_f16_2n, size_t n, const float* scale, hipStream_t st);
 // scale[0] = S = the power of two that brings max|x| just below 2^14, scale[1] = 1/S   (scratch: >= 1024 floats)
@@ -327,8 +324,6 @@ hipError_t pow2_scale_of(const float* x, size_t n, float* scale, float* scratch,
 hipError_t wgrad_split16(const void* xp, const void* zp, float* partial, int splits, int ks, int B, int H, int W, int Cin, int Cout, int ldz,
                          hipStream_t st);
 bool wgrad_split_supported(int ks, int Cin, int ldz);
-hipError_t wgrad_split(const void* xp, const void* zp, float* partial, int splits, int ks, int B, int H, int W, int Cin, int Cout, int ldz,
-                       hipStream_t st);
 // bf16 activations / gradients as they are (bf16 training): same kernel with one operand part
 hipError_t wgrad_bf16(const void* x, const void* dz, float* partial, int splits, int ks, int B, int H, int W, int Cin, int Cout, int ldz,
                       hipStream_t st);

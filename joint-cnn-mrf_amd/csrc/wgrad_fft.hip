@@ -65,8 +65,7 @@ __device__ __forceinline__ bf16x8 frag_pack(const Frag& f) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
-// NP = 3, HALF = false: three bf16 parts, six products.  NP = 2, HALF = true: two FP16 parts of the scaled spectra (conv_fft's np = 4), three
-// products; P comes out scaled by both operands' powers of two, which the taps kernel undoes.
+// NP = 2, HALF = true: two FP16 parts of the scaled spectra (conv_fft's np = 4), three products; P comes out scaled by both operands' powers of two, which the taps kernel undoes.
 template <int NP, bool HALF>
 __global__ __launch_bounds__(NT) void wgrad_spec_kernel(Args a) {
   constexpr int OPER = 2 * NP * PLANE, SEGS = 8 * 2 * NP * 2;      // one operand in LDS; (chunk, re|im, part, k-half) segments of 16 images x 16 bytes
@@ -288,22 +287,16 @@ size_t wgrad_fft_scratch_bytes(int NY, int NX, int Cin, int Cout) { return p_byt
 
 hipError_t wgrad_fft(const void* xs, const void* zs, void* scratch, const float* w, float lmbd, float* dw, int ks, int NY, int NX, int B, int MTx, int MTz, int Cin,
                      int ldz, int Cout, hipStream_t st, int np, const float* tmax_x, const float* tmax_z, int H) {
-  if ((ks != 9 && ks != 5) || Cin % 16 || ldz % 16 || Cout > ldz || Cout < 1 || NY > 192 || NX > 192 || B < 1 || (np != 3 && np != 4)) return hipErrorInvalidValue;
-  if (np == 4 && (!tmax_x || !tmax_z || H < 1)) return hipErrorInvalidValue;
+  if ((ks != 9 && ks != 5) || Cin % 16 || ldz % 16 || Cout > ldz || Cout < 1 || NY > 192 || NX > 192 || B < 1 || np != 4) return hipErrorInvalidValue;
+  if ((!tmax_x || !tmax_z || H < 1)) return hipErrorInvalidValue;
   const int NXH = NX / 2 + 1, F = NY * NXH;
   if (MTx % 16 || MTz % 16) return hipErrorInvalidValue;
   wf::Args a{static_cast<const uint4*>(xs), static_cast<const uint4*>(zs), static_cast<float2*>(scratch), F, B, MTx, MTz, Cin, ldz};
   float2* R = reinterpret_cast<float2*>(static_cast<char*>(scratch) + p_bytes(NY, NX, Cin, ldz));
-  static LdsAttr attr3, attr4;
+  static LdsAttr attr4;
   const int tiles = ((Cin + wf::TM - 1) / wf::TM) * ((ldz + wf::TN - 1) / wf::TN);
-  if (np == 4) {
-    if (hipError_t e = attr4.ensure(reinterpret_cast<const void*>(wf::wgrad_spec_kernel<2, true>), wf::lds_bytes(2)); e != hipSuccess) return e;
-    hipLaunchKernelGGL((wf::wgrad_spec_kernel<2, true>), dim3((unsigned)(F * tiles)), dim3(wf::NT), wf::lds_bytes(2), st, a);
-  } else {
-    if (hipError_t e = attr3.ensure(reinterpret_cast<const void*>(wf::wgrad_spec_kernel<3, false>), wf::lds_bytes(3)); e != hipSuccess) return e;
-    hipLaunchKernelGGL((wf::wgrad_spec_kernel<3, false>), dim3((unsigned)(F * tiles)), dim3(wf::NT), wf::lds_bytes(3), st, a);
-    tmax_x = tmax_z = nullptr;
-  }
+  if (hipError_t e = attr4.ensure(reinterpret_cast<const void*>(wf::wgrad_spec_kernel<2, true>), wf::lds_bytes(2)); e != hipSuccess) return e;
+  hipLaunchKernelGGL((wf::wgrad_spec_kernel<2, true>), dim3((unsigned)(F * tiles)), dim3(wf::NT), wf::lds_bytes(2), st, a);
   const size_t n = (size_t)Cin * ldz;
   const unsigned blocks = (unsigned)((n + 255) / 256);
   if (ks == 9) {

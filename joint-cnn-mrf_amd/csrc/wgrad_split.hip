@@ -258,19 +258,6 @@ __global__ void pow2_scale_kernel(const float* __restrict__ scratch, int nb, flo
   scale[1] = ldexpf(1.0f, -k);
 }
 
-// out[p][i] = part p of x[i]  (p = 0 high .. 2 low; x = out[0] + out[1] + out[2] exactly)
-__global__ void split_parts_kernel(const float* __restrict__ x, __bf16* __restrict__ out, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const float v = x[i];
-    const __bf16 b0 = static_cast<__bf16>(v);
-    const float r1 = v - static_cast<float>(b0);
-    const __bf16 b1 = static_cast<__bf16>(r1);
-    out[i] = b0;
-    out[n + i] = b1;
-    out[2 * n + i] = static_cast<__bf16>(r1 - static_cast<float>(b1));
-  }
-}
-
 }  // namespace
 
 hipError_t split_parts16(const float* x, void* out, size_t n, const float* scale, hipStream_t st) {
@@ -284,12 +271,6 @@ hipError_t pow2_scale_of(const float* x, size_t n, float* scale, float* scratch,
   const int nb = (int)(g < 1 ? 1 : (g > 1024 ? 1024 : g));
   hipLaunchKernelGGL(amax_kernel, dim3(nb), dim3(256), 0, st, x, n, scratch);
   hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(64), 0, st, scratch, nb, scale);
-  return hipGetLastError();
-}
-
-hipError_t split_parts(const float* x, void* out, size_t n, hipStream_t st) {
-  size_t g = (n + 255) / 256;
-  hipLaunchKernelGGL(split_parts_kernel, dim3((int)(g > 65536 ? 65536 : g)), dim3(256), 0, st, x, static_cast<__bf16*>(out), n);
   return hipGetLastError();
 }
 
@@ -307,13 +288,6 @@ hipError_t launch_w(const void* xp, const void* zp, float* partial, int splits, 
   return hipGetLastError();
 }
 }  // namespace
-
-// xp / zp: split_parts images of x [B,H,W,Cin] and dz [B,H,W,ldz]; partial as wgrad_f32
-hipError_t wgrad_split(const void* xp, const void* zp, float* partial, int splits, int ks, int B, int H, int W, int Cin, int Cout, int ldz,
-                       hipStream_t st) {
-  if (!wgrad_split_supported(ks, Cin, ldz)) return hipErrorInvalidValue;
-  return ks == 9 ? launch_w<9, 3>(xp, zp, partial, splits, B, H, W, Cin, Cout, ldz, st) : launch_w<5, 3>(xp, zp, partial, splits, B, H, W, Cin, Cout, ldz, st);
-}
 
 // fp16x3: xp / zp are split_parts16 images (two fp16 parts each, dz pre-scaled by its power-of-two scale)
 hipError_t wgrad_split16(const void* xp, const void* zp, float* partial, int splits, int ks, int B, int H, int W, int Cin, int Cout, int ldz,
