@@ -34,7 +34,7 @@ typedef struct jcm_ctx* jcm_handle;
 #define JCM_ERR_HIP 3      /* a HIP runtime call or kernel launch failed            */
 
 #define JCM_PRECISION_F32 0   /* fp32 tensors; fp32-class arithmetic: by default the stride-1 layers run in the frequency domain with every fp32
-                                 spectrum fed to the 16-bit matrix cores as two scaled fp16 parts (22 significant bits, "fft_fp16");
+                                 spectrum fed to the 16-bit matrix cores as two scaled fp16 parts (22 significant bits);
                                  "conv9_fft" = 0 selects the exact fp32 MFMA accumulation chain (v_mfma_f32_32x32x2_f32) -- the parity path */
 #define JCM_PRECISION_BF16 1  /* bf16 tensors between the layers, fp32 accumulate -- the roofline path */
 
@@ -51,11 +51,10 @@ int jcm_abi_version(void);
  * "n_joints" : K, default 9      (main.py:458)
  * "f32_conv"  : fp32 handles only; arithmetic of the DIRECT (not frequency-domain) convolution kernels, i.e. of every layer when
  *              "conv9_fft" = 0 and of the shapes the frequency-domain route does not take otherwise: 0 (default) = the exact fp32 MFMA
- *              chain; a non-zero value also switches the frequency-domain route off;
- *              1 = the stride-1 layers with Cin % 16 == 0 and Cout % 128 == 0 run as three-way bf16
- *              operand splits with six products on the bf16 matrix cores (fp32-class error);
- *              2 = two-way fp16 splits with three products; every operand tensor (weights, layer
- *              inputs, gradients) is lifted into the fp16 range by its own power-of-two scale first.
+ *              chain; 2 = the stride-1 layers with Cin % 16 == 0 and Cout % 128 == 0 as two-way fp16 operand splits with three
+ *              products on the 16-bit matrix cores (fp32-class error; every operand tensor -- weights, layer inputs, gradients --
+ *              is lifted into the fp16 range by its own power-of-two scale first), and the frequency-domain route off: the
+ *              A/B arm of that route.  (1, three bf16 parts / six products, was retired in round 5: JCM_ERR_ARG.)
  * "split_min_wgs": any time; grids smaller than this keep the exact kernel (default 128, 0 = always split).
  * All three must be set before jcm_finalize.
  * "profile"  : 0/1, any time: bracket every MFMA conv launch with HIP events on the launch
@@ -68,8 +67,9 @@ int jcm_abi_version(void);
  *              0 = the direct MFMA kernels.  The training step of an fp32 handle takes the same route (forward, data and weight
  *              gradients); a bf16 handle trains on the direct bf16 kernels.  Filter spectra are built per (layer, map size) on
  *              first use (11.4 GB for the full-width model on 60x90 maps; cache bound: environment JCM_FFT_CACHE_GB, default 64).
- *              Environment JCM_FFT_REG=0 (read once per process): the LDS kernels for the inverse transform passes instead of the register-resident
- *              transforms (csrc/conv_fft_rows_reg.hip) -- the A/B arm; results agree to fp32 rounding.
+ *              Environment JCM_FFT_REG=0 (read once per process): the LDS kernels instead of the register-resident transforms of
+ *              csrc/conv_fft_rows_reg.hip (inverse column / row passes, the bf16 forward row pass, the fused inverse + forward row
+ *              pass) -- the A/B arm; results agree to fp32 rounding.
  *              An fp32 handle WITH TRAINING STATE holds more: a second 11.4 GB set of spectra of the flipped, transposed filters for
  *              the data gradient (both sets are repacked after every update) and up to 7.5 GB of weight-gradient scratch (the per-frequency
  *              products P and the column sums R of conv5) in the workspace arena -- about 31 GB beside the 6 GB of activations.
@@ -77,14 +77,16 @@ int jcm_abi_version(void);
  *              point holds a per-device lock while it enqueues, makes its stream wait for the previous call of another stream and records
  *              an event behind its last kernel -- so they may come from different host threads and streams and results do not depend on
  *              the interleaving.  0 takes the handle out of that chain (debugging: tools/determinism.py).
- * "fft_fp16" : any time, default 1 (fp32 handles): the channel product of the frequency-domain route on two FP16 parts per operand (three
- *              products, 22 significant bits) of spectra scaled by powers of two -- one scale per image, derived from a rigorous bound, so an
- *              image's result does not depend on its batch; a handle with training state uses one scale per tensor.  0 = three bf16 parts,
- *              six products, no scaling (the same accuracy class at 1.3x the GEMM time).  Changing it drops the cached filter spectra.
  * "fft_single": any time, default 1 (bf16 handles): the channel product of the frequency-domain route on ONE fp16 part per operand -- spectra scaled
- *              by one power of two per image (the bound of "fft_fp16"), rounded once to fp16's 11 significant bits, one real product per multiply,
+ *              by one power of two per image (derived from a rigorous bound of the spectrum, so an image's result does not depend on its batch), rounded once to fp16's 11 significant bits, one real product per multiply,
  *              32 channels per GEMM stage.  The layer's input and output tensors are bf16 (8 bits): the spectra are eight times finer.
  *              0 = two bf16 parts per operand, three products (rounds 2-3).  Changing it drops the cached filter spectra.
+ *              ACCURACY CLASS of the default bf16 route (fft_single = fft_t16 = 1): 11-bit intermediates inside the wide 9x9 layers --
+ *              per layer within one bf16 ulp + 1e-3 of the layer's scale of the bf16-operand oracle (7.6-8.0 % of the entries one ulp off;
+ *              0.2 % with both options 0), full tower 4.3e-3 of the logit scale; arg-max agreement with the fp32 engine on 256 images
+ *              97.5 % (part detector) / 96.8 % (spatial model), the same as the strict arm's 97.4 / 96.4 % and the direct bf16 MFMA
+ *              kernels' 97.4 / 96.4 %, and 100 % / 99.9 % of the joints whose fp32 top-2 margin is clear of the bf16 noise
+ *              (tests/test_gpu_argmax_agreement.py).
  * "fft_windows": any time, default 1 (fp32 handles with training state): the training step runs its wide 60x90 layers (conv4_fullres, conv5 -- every
  *              layer with Cin * Cout >= 256 * 512 whose map has at least twice the frequencies of a window) on 32 x 32 overlap-save windows: forward, data
  *              gradient and weight gradient see 3 x 4 windows per image as a batch of 12 B images on a 32 x 32 circular transform, so the filter-sized

@@ -118,7 +118,7 @@ template <class C>
 __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
   static_assert(C::FM <= 2 && C::FN <= 2, "frag_load covers 1 or 2 fragments per side");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NP = C::NP, FM = C::FM, FN = C::FN, MT = C::MT, NTL = C::NTL, R = C::R, NW = C::NW;
+  constexpr int FM = C::FM, FN = C::FN, MT = C::MT, NTL = C::NTL, R = C::R, NW = C::NW;
   constexpr int XST = C::XST, WST = C::WST, STAGE = C::STAGE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);

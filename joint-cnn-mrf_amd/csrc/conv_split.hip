@@ -1,14 +1,8 @@
-// fp32 convolution on the bf16 matrix cores: 3-way operand split, 6 products ("bf16x6").
+// fp32 convolution on the 16-bit matrix cores with split operands (the direct A/B arm of the frequency-domain route, "f32_conv" = 2).
 //
-// Every fp32 value is the exact sum of three bf16 numbers (8 + 8 + 8 mantissa bits):
-//     a = a0 + a1 + a2,   a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1)
-// and a*b = sum_{p,q} a_p*b_q.  Each bf16 x bf16 product is exact in fp32; dropping the three terms
-// with p + q >= 3 (relative size <= 2^-24 each) leaves
-//     a*b ~ a0*b2 + a1*b1 + a2*b0 + a0*b1 + a1*b0 + a0*b0          (issued small to large)
-// with a per-product error below one fp32 ulp, accumulated in the MFMA's fp32 accumulators -- the
-// error class of an fp32 FMA chain (measured on a K = 41472 dot product: 1.5e-7 of max|result|
-// against 2.9e-7 for an fp32 GEMM).  Six v_mfma_f32_32x32x16_bf16 replace eight
-// v_mfma_f32_32x32x2_f32 per 16 k-values at 16x the rate: 2.7x the fp32 MFMA peak.
+// A 16-bit x 16-bit product is exact in the MFMA's fp32 accumulator, so an fp32 operand can be fed as a sum of 16-bit parts and the
+// products of the parts accumulated: the error class of an fp32 FMA chain.  (Rounds 1-4 also carried a three-bf16-part / six-product
+// form, "bf16x6"; it was dominated by the form below on every axis and retired in round 5.  The template keeps NS general.)
 //
 // fp16x3 variant (NS = 2): an fp32 value is a0 + a1 with two fp16 parts to 22 bits (a1 may be an fp16 subnormal: absolute
 // error < 3e-8, harmless for O(1) activations; weights are stored times 2^12 so theirs is < 1e-11), fp16 x fp16 products are
@@ -19,8 +13,8 @@
 //
 // Dataflow = conv_igemm_bf16.hip's big-tile kernel (12x32 pixels x 256 channels per workgroup, 8
 // waves of 3x4 fragments, rotating-B schedule, weights by LDS-DMA) with the K axis extended by the
-// six (p,q) sub-steps: activations stay fp32 in HBM and are split once per 16-channel chunk while the
-// halo is written to LDS (three bf16 planes); weights are split at pack time.
+// (p,q) sub-steps: activations stay fp32 in HBM and are split once per 16-channel chunk while the
+// halo is written to LDS (one plane per part); weights are split at pack time.
 #include "kernels.h"
 
 namespace jcm {
@@ -119,19 +113,6 @@ __device__ __forceinline__ void stage_steps(f32x4 (&fa)[2][C::MR], f32x4 (&fb)[C
     if constexpr (STEP + 1 < C::NSTEP && load_a<C>(STEP + 1)) a_load<C, STEP + 1>(fa[a_buf<C>(STEP + 1)], aaddr);
     rot_g<C, STEP, 0>(fa, fb, baddr, acc);
     stage_steps<C, STEP + 1>(fa, fb, aaddr, baddr, acc);
-  }
-}
-
-// exact three-way split of 8 fp32 values into bf16 planes (round to nearest even at each level)
-__device__ __forceinline__ void split8(const f32x4& lo, const f32x4& hi, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float v = i < 4 ? lo[i] : hi[i - 4];
-    const __bf16 b0 = static_cast<__bf16>(v);
-    const float r1 = v - static_cast<float>(b0);
-    const __bf16 b1 = static_cast<__bf16>(r1);
-    const float r2 = r1 - static_cast<float>(b1);
-    p0[i] = b0; p1[i] = b1; p2[i] = static_cast<__bf16>(r2);
   }
 }
 
@@ -259,23 +240,16 @@ __global__ __launch_bounds__(C::NT, 2) void conv_split_kernel(ConvArgs a, int ti
         hi = *reinterpret_cast<const f32x4*>(src + 4);
       }
       const int slot = hy * whp + hx;
-      if constexpr (C::NSPLIT == 2) {
-        if (a.in_scale) {                 // gradients: lift into the fp16 range by the tensor's power-of-two scale
-          const float S = a.in_scale[0];
+      static_assert(C::NSPLIT == 2, "two fp16 parts per operand");
+      if (a.in_scale) {                 // gradients: lift into the fp16 range by the tensor's power-of-two scale
+        const float S = a.in_scale[0];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { lo[i] *= S; hi[i] *= S; }
-        }
-        f16x8 p0, p1;
-        split8h(lo, hi, p0, p1);
-        halo[(0 * C::U + u) * C::PLANE + slot] = __builtin_bit_cast(f32x4, p0);
-        halo[(1 * C::U + u) * C::PLANE + slot] = __builtin_bit_cast(f32x4, p1);
-      } else {
-        bf16x8 p0, p1, p2;
-        split8(lo, hi, p0, p1, p2);
-        halo[(0 * C::U + u) * C::PLANE + slot] = __builtin_bit_cast(f32x4, p0);
-        halo[(1 * C::U + u) * C::PLANE + slot] = __builtin_bit_cast(f32x4, p1);
-        halo[(2 * C::U + u) * C::PLANE + slot] = __builtin_bit_cast(f32x4, p2);
+        for (int i = 0; i < 4; ++i) { lo[i] *= S; hi[i] *= S; }
       }
+      f16x8 p0, p1;
+      split8h(lo, hi, p0, p1);
+      halo[(0 * C::U + u) * C::PLANE + slot] = __builtin_bit_cast(f32x4, p0);
+      halo[(1 * C::U + u) * C::PLANE + slot] = __builtin_bit_cast(f32x4, p1);
     }
     __syncthreads();   // halo visible before any wave's (pre-barrier) step-0 A reads
     for (int s = 0; s < C::NSTAGE; ++s) {
@@ -355,26 +329,6 @@ __global__ void pack_weights_split16_kernel(const float* __restrict__ w, _Float1
     const size_t base = (((size_t)tap * (Cin >> 3) + c8) * 2) * CoutP * 8 + (size_t)co * 8 + k8;
     wp[base] = h0;
     wp[base + (size_t)CoutP * 8] = static_cast<_Float16>(v - static_cast<float>(h0));
-  }
-}
-
-__global__ void pack_weights_split_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int taps, int Cin, int Cout, int CoutP) {
-  const size_t n = (size_t)taps * Cin * CoutP;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const int k8 = i & 7;
-    size_t r = i >> 3;
-    const int co = r % CoutP; r /= CoutP;
-    const int c8 = r % (Cin >> 3);
-    const int tap = r / (Cin >> 3);
-    const float v = co < Cout ? w[((size_t)tap * Cin + c8 * 8 + k8) * Cout + co] : 0.f;
-    const __bf16 b0 = static_cast<__bf16>(v);
-    const float r1 = v - static_cast<float>(b0);
-    const __bf16 b1 = static_cast<__bf16>(r1);
-    const __bf16 b2 = static_cast<__bf16>(r1 - static_cast<float>(b1));
-    const size_t base = (((size_t)tap * (Cin >> 3) + c8) * 3) * CoutP * 8 + (size_t)co * 8 + k8;
-    wp[base] = b0;
-    wp[base + (size_t)CoutP * 8] = b1;
-    wp[base + (size_t)CoutP * 16] = b2;
   }
 }
 

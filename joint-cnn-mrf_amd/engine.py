@@ -19,7 +19,7 @@ def _hm_size(n):
 class Engine:
     """Owns a jcm_handle.  All tensor arguments are torch CUDA float32 NHWC, contiguous."""
 
-    def __init__(self, device=0, precision='fp32', n_joints=9, stream=None, f32_conv=None, split_min_wgs=None, micro_batch=None, conv9_fft=None, fft_fp16=None, call_order=None, fft_single=None, fft_t16=None):
+    def __init__(self, device=0, precision='fp32', n_joints=9, stream=None, f32_conv=None, split_min_wgs=None, micro_batch=None, conv9_fft=None, call_order=None, fft_single=None, fft_t16=None):
         if not torch.cuda.is_available():
             raise RuntimeError('joint-cnn-mrf_amd needs an MI355X (gfx950) GPU; torch.cuda.is_available() is False '
                                'and there is no CPU path')
@@ -36,14 +36,14 @@ class Engine:
         prec = {'fp32': _lib.JCM_PRECISION_F32, 'f32': _lib.JCM_PRECISION_F32, 'bf16': _lib.JCM_PRECISION_BF16}[precision]
         _lib.check(self._lib.jcm_set_option(self._h, b'precision', prec), 'jcm_set_option(precision)')
         _lib.check(self._lib.jcm_set_option(self._h, b'n_joints', self.n_joints), 'jcm_set_option(n_joints)')
-        if f32_conv is not None:      # 'exact' = fp32 MFMA, 'split' = bf16x6, 'split16' = fp16x3 forward (+ bf16x6 gradients): fp32-level accuracy on the 16-bit matrix cores
-            _lib.check(self._lib.jcm_set_option(self._h, b'f32_conv', {'exact': 0, 'split': 1, 'split16': 2}[f32_conv]), 'jcm_set_option(f32_conv)')
+        if f32_conv is not None:      # 'exact' = the default; 'split16' = the direct kernels on two fp16 parts per operand (fp16x3: fp32-class accuracy on the 16-bit matrix cores)
+            if f32_conv not in ('exact', 'split16'):
+                raise ValueError("f32_conv must be 'exact' or 'split16' (the bf16x6 arm 'split' was retired in round 5)")
+            _lib.check(self._lib.jcm_set_option(self._h, b'f32_conv', {'exact': 0, 'split16': 2}[f32_conv]), 'jcm_set_option(f32_conv)')
         if micro_batch is not None:   # forward() walks a batch in slices of this many images (default 256 bf16 / 64 fp32)
             self.set_micro_batch(micro_batch)
         if conv9_fft is not None:     # False: the wide 9x9 layers of an fp32 engine on the fp32 MFMA chain instead of the frequency domain
             self.set_conv9_fft(conv9_fft)
-        if fft_fp16 is not None:      # False: fp32 engines run the channel GEMM on three bf16 parts (six products) instead of two scaled fp16 parts (three)
-            self.set_fft_fp16(fft_fp16)
         if fft_single is not None:    # bf16 engines: False = two bf16 parts per operand of the channel GEMM (three products) instead of one scaled fp16 part
             self.set_option('fft_single', int(bool(fft_single)))
         if fft_t16 is not None:       # bf16 engines: False = the row-transformed tensors of the frequency-domain route stay complex fp32 (default: fp16 in block floating point)
@@ -290,11 +290,6 @@ class Engine:
         """fp32 engines: run the wide 9x9 layers in the frequency domain (in-LDS FFTs + one complex channel GEMM per frequency;
         default) or on the fp32 MFMA accumulation chain.  Both pass the same parity tests."""
         _lib.check(self._lib.jcm_set_option(self._h, b'conv9_fft', int(bool(on))), 'jcm_set_option(conv9_fft)')
-
-    def set_fft_fp16(self, on):
-        """fp32 engines, frequency-domain route: operands of the channel GEMM as two FP16 parts of spectra scaled by powers of two
-        (three products; default) or as three bf16 parts (six products).  Both are fp32-class and pass the same parity tests."""
-        _lib.check(self._lib.jcm_set_option(self._h, b'fft_fp16', int(bool(on))), 'jcm_set_option(fft_fp16)')
 
     def set_micro_batch(self, n):
         """Images per internal slice of forward(): bounds the workspace when a rank holds a large share of a

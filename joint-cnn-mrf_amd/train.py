@@ -29,7 +29,7 @@ def piecewise_lr(n_iters, n_updates_total, lr):
 
 class Trainer:
     def __init__(self, engine, optimizer='adam', lr=0.001, lmbd=0.001, use_sm=True, n_updates_total=None, overlap_allreduce=False):
-        # fp32 handle: fp32 tensors (exact fp32 MFMA, or bf16x6 split with f32_conv='split'); bf16 handle: mixed precision
+        # fp32 handle: fp32 tensors (frequency domain by default; the fp32 MFMA chain with conv9_fft=False; fp16x3 direct kernels with f32_conv='split16'); bf16 handle: mixed precision
         # (bf16 activations / gradients and bf16 MFMA, fp32 master weights, statistics, losses, spatial model, optimizer)
         if optimizer not in ('adam', 'momentum'):
             raise Exception('wrong optimizer')                      # main.py:506

@@ -33,6 +33,21 @@ def full_inputs():
     return synth.make_images(2, seed=g['images']), synth.make_torso(2, seed=g['torso']), p
 
 
+# Arg-max agreement of a bf16 engine with the float64 goldens on the 18 golden joints: every joint whose golden top-2 logit margin is clear of
+# the bf16 noise must land on the golden cell.  The thresholds are ~7x / ~10x the rms log-probability error of the bf16 engines measured against the
+# fp32 engine on 256 images (0.043 part detector, 0.025 spatial model; tests/test_gpu_argmax_agreement.py, which is where the agreement RATE is held).
+BF16_MARGIN = {'pd': 0.30, 'sm': 0.25}
+
+
+def assert_bf16_coords(got, ref_logits, ref_coords, stage):
+    B, K = ref_coords.shape[0], ref_coords.shape[2]
+    top2 = np.sort(np.asarray(ref_logits, np.float64).reshape(B, -1, K), axis=1)[:, -2:, :]
+    safe = (top2[:, 1, :] - top2[:, 0, :]) > BF16_MARGIN[stage]
+    assert safe.sum() >= B * K // 2, 'too few golden joints with a clear margin: %d' % safe.sum()
+    same = (np.asarray(got) == np.asarray(ref_coords)).all(axis=1)
+    assert (same | ~safe).all(), 'bf16 arg-max differs from the golden on joints with a clear margin: %s' % (np.argwhere(~same & safe).tolist(),)
+
+
 def sampled_conv_grads(x, dz, w, lmbd, rs, n=40):
     """float64 values of the two gradients of z = conv2d_SAME(x, w) (stride 1, HWIO) at sampled entries, straight from the definition:
     dW[a,b,ci,co] = sum_{n,y,x} x[n,y+a-p,x+b-p,ci] dz[n,y,x,co] + lmbd w[a,b,ci,co];  dX[n,y,x,ci] = sum_{a,b,co} dz[n,y-a+p,x-b+p,co] w[a,b,ci,co]

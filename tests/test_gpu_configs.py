@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import flic_priors, full_inputs, load, seeds
+from golden_util import assert_bf16_coords, flic_priors, full_inputs, load, seeds
 from joint_cnn_mrf_amd import synth
 from oracle import jcm_oracle as O
 
@@ -61,7 +61,7 @@ def test_config3_batch256_bf16_properties(fft):
     np.testing.assert_allclose(one['sm_prob'].cpu().numpy(), sm[201:202], atol=1e-6, rtol=0)
     np.testing.assert_array_equal(one['sm_coords'].cpu().numpy(), sm_c[201:202])
     # and the golden pair stays within bf16 reach of the float64 oracle (argmax within one cell for most joints)
-    assert (np.abs(pd_c[:2] - load('full_pd_coords')).max(axis=1) <= 1).mean() >= 0.85
+    assert_bf16_coords(pd_c[:2], load('full_pd_logits'), load('full_pd_coords'), 'pd')
     eng.close()
 
 
@@ -131,7 +131,7 @@ def test_config3_global_batch_2048_bf16_micro_batched():
         assert torch.equal(one['pd_prob'], pd[sl]), sl
         assert float((one['sm_prob'] - sm[sl]).abs().max()) <= 1e-6
         assert torch.equal(one['pd_coords'], pd_c[sl]) and torch.equal(one['sm_coords'], sm_c[sl]), sl
-    assert (np.abs(pd_c[:2].cpu().numpy() - load('full_pd_coords')).max(axis=1) <= 1).mean() >= 0.85
+    assert_bf16_coords(pd_c[:2].cpu().numpy(), load('full_pd_logits'), load('full_pd_coords'), 'pd')
     eng.close()
 
 

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import flic_priors, full_inputs, load, seeds
+from golden_util import assert_bf16_coords, flic_priors, full_inputs, load, seeds
 from joint_cnn_mrf_amd import synth
 from oracle import jcm_oracle as O
 
@@ -17,19 +17,17 @@ def dev(a):
     return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device='cuda:0')
 
 
-@pytest.mark.parametrize('f32_conv', ['exact', 'exact_bf16x3', 'chain', 'split', 'split16'])
+@pytest.mark.parametrize('f32_conv', ['exact', 'chain', 'split16'])
 @pytest.mark.parametrize('kind', ['init', 'trained'])
 def test_full_size_tower_vs_golden(kind, f32_conv):
     """Every fp32 convolution algorithm to the same bar: 'exact' = the default fp32 engine (stride-1 layers in the frequency domain,
-    conv_fft.hip, channel GEMM on two scaled fp16 parts per operand), 'exact_bf16x3' = the same route with three bf16 parts / six products,
-    'chain' = the fp32 MFMA accumulation chain everywhere, 'split' / 'split16' = fp32 operands as bf16 / fp16 parts on the direct kernels
-    (conv_split.hip)."""
+    conv_fft.hip, channel GEMM on two scaled fp16 parts per operand), 'chain' = the fp32 MFMA accumulation chain everywhere, 'split16' = fp32
+    operands as two fp16 parts on the direct kernels (conv_split.hip).  (The bf16x6 / bf16x3 arms of rounds 1-4 were retired in round 5.)"""
     from joint_cnn_mrf_amd.engine import Engine
     x, torso, p = full_inputs()
     p.update(synth.make_sm_params(flic_priors(), kind=kind, seed=seeds()['sm']))
-    eng = Engine(device=0, f32_conv='exact' if f32_conv in ('chain', 'exact_bf16x3') else f32_conv, split_min_wgs=0, conv9_fft=f32_conv != 'chain',
-                 fft_fp16=f32_conv != 'exact_bf16x3').load_params(p)
-    assert eng.conv_kernel_name('conv5', 2, 60, 90).startswith('conv_fft') == (f32_conv in ('exact', 'exact_bf16x3'))
+    eng = Engine(device=0, f32_conv='exact' if f32_conv == 'chain' else f32_conv, split_min_wgs=0, conv9_fft=f32_conv != 'chain').load_params(p)
+    assert eng.conv_kernel_name('conv5', 2, 60, 90).startswith('conv_fft') == (f32_conv == 'exact')
     logits = eng.model(dev(x)).cpu().numpy()
     r = eng.forward(dev(x), dev(torso), use_sm=True)
     eng.close()
@@ -74,9 +72,10 @@ def test_bf16_path_vs_golden():
     assert np.sqrt((err ** 2).mean()) <= 0.01 * scale
     pd_c, sm_c = r['pd_coords'].cpu().numpy(), r['sm_coords'].cpu().numpy()
     ref_pd, ref_sm = load('full_pd_coords'), load('full_sm_coords_trained')
-    # a joint counts as agreeing if it lands within one heat-map cell of the oracle's arg-max
-    assert (np.abs(pd_c - ref_pd).max(axis=1) <= 1).mean() >= 0.85
-    assert (np.abs(sm_c - ref_sm).max(axis=1) <= 1).mean() >= 0.85
+    # every golden joint whose top-2 margin is clear of the bf16 noise lands on the golden cell (the agreement RATE, on 256 images against the
+    # fp32 engine, is tests/test_gpu_argmax_agreement.py)
+    assert_bf16_coords(pd_c, ref, ref_pd, 'pd')
+    assert_bf16_coords(sm_c, load('full_sm_logits_trained'), ref_sm, 'sm')
     with pytest.raises(RuntimeError, match='stride-2'):       # the first layer exists fused with its pool only
         Engine(device=0, precision='bf16').load_params(p).conv_layer(dev(np.zeros((1, 64, 64, 3))), 'conv1_fullres', 2, n_out=64)
 
@@ -197,7 +196,7 @@ def test_split_conv_layer_error_is_fp32_class():
     a = np.maximum(rs.standard_normal((1, 60, 90, 512)), 0).astype(np.float32)
     ref = O64.conv_layer(a.astype(np.float64), p, 9, 1, 'conv5')
     outs = {}
-    for algo in ('exact', 'split', 'split16', 'fft'):
+    for algo in ('exact', 'split16', 'fft'):
         eng = Engine(device=0, f32_conv='exact' if algo == 'fft' else algo, split_min_wgs=0, conv9_fft=algo == 'fft').load_params(p)
         assert eng.conv_kernel_name('conv5', 1, 60, 90).startswith('conv_fft') == (algo == 'fft')
         outs[algo] = eng.conv_layer(dev(a), 'conv5', 1, n_out=512).cpu().numpy().astype(np.float64)
@@ -206,12 +205,10 @@ def test_split_conv_layer_error_is_fp32_class():
     e_fft, r_fft = np.abs(outs['fft'] - ref).max() / scale, np.sqrt(np.mean((outs['fft'] - ref) ** 2)) / scale
     print('conv5 error / max|out|, frequency domain: max %.2e rms %.2e' % (e_fft, r_fft))
     assert e_fft <= 3e-6        # measured 4e-7: below the sequential fp32 chain
-    e_exact, e_split = np.abs(outs['exact'] - ref).max() / scale, np.abs(outs['split'] - ref).max() / scale
-    r_exact, r_split = np.sqrt(np.mean((outs['exact'] - ref) ** 2)) / scale, np.sqrt(np.mean((outs['split'] - ref) ** 2)) / scale
+    e_exact, r_exact = np.abs(outs['exact'] - ref).max() / scale, np.sqrt(np.mean((outs['exact'] - ref) ** 2)) / scale
     e16, r16 = np.abs(outs['split16'] - ref).max() / scale, np.sqrt(np.mean((outs['split16'] - ref) ** 2)) / scale
-    print('conv5 error / max|out|: exact max %.2e rms %.2e, bf16x6 max %.2e rms %.2e, fp16x3 max %.2e rms %.2e' % (e_exact, r_exact, e_split, r_split, e16, r16))
-    assert e16 <= 2e-5 and r16 <= 3 * r_exact + 1e-7
-    assert e_exact <= 1e-5 and e_split <= 2e-5 and r_split <= 3 * r_exact + 1e-7      # the same error class
+    print('conv5 error / max|out|: exact max %.2e rms %.2e, fp16x3 max %.2e rms %.2e' % (e_exact, r_exact, e16, r16))
+    assert e_exact <= 1e-5 and e16 <= 2e-5 and r16 <= 3 * r_exact + 1e-7      # the same error class
     assert r_fft <= r_exact + 1e-7
 
 
@@ -219,7 +216,7 @@ def test_fft_fp16_scaling_is_robust_and_batch_independent():
     """The default frequency-domain route of fp32 engines feeds its channel GEMM two FP16 parts of spectra scaled by one power of two per
     image.  Inputs that stress the scaling -- magnitudes of 1e-6 and 1e+4, a single outlier 10^4 times the typical
     value, an all-zero image -- in ONE batch: every image must come out as it does alone (bit for bit: an image's scale depends on that
-    image only), within fp32-class error of the float64 oracle relative to ITS OWN output scale, and like the six-product bf16 route."""
+    image only) and within fp32-class error of the float64 oracle relative to ITS OWN output scale."""
     from joint_cnn_mrf_amd.engine import Engine
     import oracle.jcm_oracle as O64
     _x, _torso, p = full_inputs()
@@ -232,28 +229,24 @@ def test_fft_fp16_scaling_is_robust_and_batch_independent():
     a[4] = 0.0
     ref = O64.conv_layer(a.astype(np.float64), p, 9, 1, 'conv4_fullres')
     eng = Engine(device=0).load_params(p)
-    eng3 = Engine(device=0, fft_fp16=False).load_params(p)
     assert eng.conv_kernel_name('conv4_fullres', 5, 60, 90).startswith('conv_fft')
     got = eng.conv_layer(dev(a), 'conv4_fullres', 1, n_out=512).cpu().numpy()
-    got3 = eng3.conv_layer(dev(a), 'conv4_fullres', 1, n_out=512).cpu().numpy()
     for b in range(5):
         alone = eng.conv_layer(dev(a[b:b + 1]), 'conv4_fullres', 1, n_out=512).cpu().numpy()
         np.testing.assert_array_equal(alone[0], got[b])
         scale = np.abs(ref[b]).max()
-        e4, e3 = np.abs(got[b] - ref[b]).max() / scale, np.abs(got3[b] - ref[b]).max() / scale
-        print('image %d: output scale %.3g, error / scale: fp16x2 %.2e, bf16x3 %.2e' % (b, scale, e4, e3))
+        e4 = np.abs(got[b] - ref[b]).max() / scale
+        print('image %d: output scale %.3g, error / scale: fp16x2 %.2e' % (b, scale, e4))
         assert e4 <= 3e-6, (b, e4)      # measured 1e-7 .. 3e-7, the outlier image (whose scale bound is 10^4 x looser) included
-        assert e3 <= 3e-6, (b, e3)
     eng.close()
-    eng3.close()
 
 
 def test_split_kernels_match_exact_on_every_layer_shape():
-    """conv_split.hip (bf16x6 and fp16x3) against the exact fp32 MFMA kernel on every stride-1 layer shape of the model
+    """conv_split.hip (fp16x3) against the exact fp32 MFMA kernel on every stride-1 layer shape of the model
     (5x5 / 9x9, 128- / 256-channel tiles, 12x32 patches and whole-row tiles), forced onto small grids (batch 1 and 3)."""
     from joint_cnn_mrf_amd.engine import Engine
     p = synth.make_pd_params(debug=False, bn='trained')
-    engs = {a: Engine(device=0, f32_conv=a, split_min_wgs=0, conv9_fft=False).load_params(p) for a in ('exact', 'split', 'split16')}
+    engs = {a: Engine(device=0, f32_conv=a, split_min_wgs=0, conv9_fft=False).load_params(p) for a in ('exact', 'split16')}
     rs = np.random.RandomState(1)
     shapes = [('conv2_fullres', 120, 180, 64, 128), ('conv3_fullres', 60, 90, 128, 256), ('conv4_fullres', 60, 90, 256, 512),
               ('conv5', 60, 90, 512, 512), ('conv2_halfres', 60, 90, 64, 128), ('conv3_halfres', 30, 45, 128, 256),
@@ -265,7 +258,7 @@ def test_split_kernels_match_exact_on_every_layer_shape():
             x = torch.as_tensor(rs.standard_normal((B, H, W, ci)).astype(np.float32), device='cuda:0')
             outs = {a: e.conv_layer(x, name, 1, n_out=co).double() for a, e in engs.items()}
             sc = float(outs['exact'].abs().max())
-            for a in ('split', 'split16'):
+            for a in ('split16',):
                 err = float((outs[a] - outs['exact']).abs().max()) / sc
                 if not err <= 3e-5:
                     bad.append('B=%d %s %s: %.2e' % (B, name, a, err))
@@ -296,7 +289,7 @@ def test_checkpoint_file_to_engine_reproduces_golden_tower(tmp_path, precision):
         np.testing.assert_array_equal(r['pd_coords'].cpu().numpy(), load('full_pd_coords'))
         np.testing.assert_array_equal(r['sm_coords'].cpu().numpy(), load('full_sm_coords_trained'))
     else:
-        assert (np.abs(r['sm_coords'].cpu().numpy() - load('full_sm_coords_trained')).max(axis=1) <= 1).mean() >= 0.85
+        assert_bf16_coords(r['sm_coords'].cpu().numpy(), load('full_sm_logits_trained'), load('full_sm_coords_trained'), 'sm')
 
 
 @pytest.mark.parametrize('call_order', [True, False], ids=['chain', 'nochain'])

@@ -208,9 +208,9 @@ def test_missing_parameters_fail_loudly():
         Engine(device=0).load_params(sm)
 
 
-@pytest.mark.parametrize('f32_conv', ['split', 'split16'])
+@pytest.mark.parametrize('f32_conv', ['split16'])
 def test_split_convs_debug_width_and_odd_shapes(f32_conv):
-    """f32_conv='split' (conv_split.hip) on the shapes the other tests use: at --debug width the 128-channel
+    """f32_conv='split16' (conv_split.hip, two fp16 parts per operand) on the shapes the other tests use: at --debug width the 128-channel
     layers take the 128-channel tiles, 30x45 / 15x23 maps the whole-row tiles, small grids fall back to the exact
     kernel -- same tolerances as the exact path, including a non-480x720 input and batch 1."""
     from joint_cnn_mrf_amd.engine import Engine

@@ -52,7 +52,6 @@ def test_conv_layer_random_shape(case):
     scale = np.abs(ref).max()
     xd = torch.as_tensor(x, device='cuda:0')
     for mode, kw, tol in (('exact', dict(f32_conv='exact'), 2e-5), ('chain', dict(f32_conv='exact', conv9_fft=False), 2e-5),
-                          ('split', dict(f32_conv='split', split_min_wgs=0), 2e-5),
                           ('split16', dict(f32_conv='split16', split_min_wgs=0), 2e-5)):
         eng = Engine(device=0, **kw).load_params(p)
         if mode in ('exact', 'chain'):      # 'exact' = the default fp32 engine: frequency domain whenever the shape allows
@@ -165,7 +164,7 @@ def test_tower_more_seeds_debug_width(seed):
     p.update(synth.make_sm_params(synth.synthetic_priors(seed=seed + 1), kind='trained', seed=seed + 2))
     x, torso = synth.make_images(2, seed=seed + 3), synth.make_torso(2, seed=seed + 4)
     ref = O.forward(x.astype(np.float64), torso.astype(np.float64), p)
-    for mode in ('exact', 'split', 'split16'):
+    for mode in ('exact', 'split16'):
         eng = Engine(device=0, f32_conv=mode, split_min_wgs=0).load_params(p)
         r = eng.forward(torch.as_tensor(x, device='cuda:0'), torch.as_tensor(torso, device='cuda:0'), use_sm=True)
         eng.close()

@@ -19,10 +19,10 @@ def dev(a):
     return torch.as_tensor(np.ascontiguousarray(a), device='cuda:0')
 
 
-def make_trainer(params, f32_conv=None, precision='fp32', conv9_fft=None, fft_fp16=None, **kw):
+def make_trainer(params, f32_conv=None, precision='fp32', conv9_fft=None, **kw):
     from joint_cnn_mrf_amd.engine import Engine
     from joint_cnn_mrf_amd.train import Trainer
-    eng = Engine(device=0, precision=precision, f32_conv=f32_conv, split_min_wgs=0 if f32_conv else None, conv9_fft=conv9_fft, fft_fp16=fft_fp16).load_params(params)
+    eng = Engine(device=0, precision=precision, f32_conv=f32_conv, split_min_wgs=0 if f32_conv else None, conv9_fft=conv9_fft).load_params(params)
     return eng, Trainer(eng, **kw)
 
 
@@ -173,13 +173,13 @@ def test_det_rate_matches_restatement():
     eng.close()
 
 
-@pytest.mark.parametrize('f32_conv', ['exact', 'exact_bf16x3', 'chain', 'split', 'split16'])
+@pytest.mark.parametrize('f32_conv', ['exact', 'chain', 'split16'])
 def test_full_size_step_vs_golden(f32_conv):
     """The full-size network (filters 64..512), one 480x720 image: losses, sampled gradient entries, gradient
     norms and the moving-statistics update against tests/golden/train_full.json (float64 restatement,
     generated by tests/golden/make_train_golden.py).  'exact' = the default fp32 engine: forward, data gradient AND weight gradient of the
-    stride-1 layers in the frequency domain (conv_fft.hip, wgrad_fft.hip; two scaled fp16 parts per operand); 'exact_bf16x3' = the same on three
-    bf16 parts; 'chain' = everything on the fp32 MFMA chain (conv9_fft off), whose rounding the golden's float32 slack was measured with and
+    stride-1 layers in the frequency domain (conv_fft.hip, wgrad_fft.hip; two scaled fp16 parts per operand); 'split16' = the direct
+    fp16x3 kernels; 'chain' = everything on the fp32 MFMA chain (conv9_fft off), whose rounding the golden's float32 slack was measured with and
     which is therefore held to the strict bound.  The other routes get 1e-2 HERE ONLY, for the end-to-end comparison of ONE image, where a
     single ReLU / max-pool decision that rounds the other way moves a gradient of the 15x23 maps; the gradient KERNELS themselves are held to
     1e-6 in test_gradient_kernels_at_full_size_layer_shapes and the 16-image step to the strict bound in test_full_size_step_16_images_vs_golden."""
@@ -188,10 +188,9 @@ def test_full_size_step_vs_golden(f32_conv):
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'train_full.json')) as fh:
         gold = json.load(fh)
     p, x, y = case()
-    eng, tr = make_trainer(p, f32_conv='exact' if f32_conv in ('chain', 'exact_bf16x3') else f32_conv, conv9_fft=False if f32_conv == 'chain' else None,
-                           fft_fp16=False if f32_conv == 'exact_bf16x3' else None, use_sm=True,
-                           lmbd=LMBD)      # 'split': forward + data gradient of conv4_fullres / conv5 on conv_split.hip; 'exact_bf16x3': the frequency-domain route on three bf16 parts
-    assert eng.conv_kernel_name('conv5', 1, 60, 90).startswith('conv_fft') == (f32_conv in ('exact', 'exact_bf16x3'))
+    eng, tr = make_trainer(p, f32_conv='exact' if f32_conv == 'chain' else f32_conv, conv9_fft=False if f32_conv == 'chain' else None, use_sm=True,
+                           lmbd=LMBD)      # 'split16': forward + data gradient of conv4_fullres / conv5 on conv_split.hip
+    assert eng.conv_kernel_name('conv5', 1, 60, 90).startswith('conv_fft') == (f32_conv == 'exact')
     losses, _ = tr.loss_and_grads(dev(x), dev(y))
     got = tr.grads_dict()
     l = losses.cpu().numpy()
@@ -257,7 +256,7 @@ def test_full_size_step_bf16_mixed_precision():
     assert not bad, '\n'.join(bad)
 
 
-@pytest.mark.parametrize('mode', ['exact', 'split', 'split16', 'bf16'])
+@pytest.mark.parametrize('mode', ['exact', 'split16', 'bf16'])
 def test_gradients_are_deterministic_and_training_is_stable(mode):
     """The same batch twice gives bit-identical gradients (fixed-order split-K reductions, no atomics), and 12 Adam
     updates at full size keep every loss finite and moving down in all three arithmetic modes."""
@@ -381,22 +380,20 @@ LAYER_SHAPES = [('conv5', 60, 90), ('conv4_fullres', 60, 90), ('conv6', 60, 90),
                 ('conv4_halfres', 30, 45), ('conv2_halfres', 60, 90), ('conv4_quarterres', 15, 23), ('conv3_quarterres', 15, 23)]
 
 
-@pytest.mark.parametrize('mode', ['exact', 'exact_nowin', 'exact_bf16x3', 'chain', 'split16'])
+@pytest.mark.parametrize('mode', ['exact', 'exact_nowin', 'chain', 'split16'])
 def test_gradient_kernels_at_full_size_layer_shapes(mode):
     """jcm_train_layer_grads: the weight-gradient and data-gradient kernels of every stride-1 layer shape of the full-width network on the SAME
     x and dz, 16 images (a tower's share of configs[4]: the batch is the K axis of the frequency-domain weight gradient's per-frequency product,
     and a training handle scales all 16 images of a tensor by one power of two) -- compared at sampled entries with float64 sums taken straight
     from the definition.  No ReLU or pooling is involved, so there is no rounding-decision noise: the frequency-domain kernels are held to 1e-6 of
     the tensor's largest entry, the direct kernels to 8e-6 (100x / 12x below GRAD_RTOL).  'exact' = the default fp32 engine (frequency
-    domain: wgrad_fft.hip and the data gradient through conv_fft on flipped filters, two scaled fp16 parts), 'exact_bf16x3' = the same on three
-    bf16 parts, 'chain' = wgrad.hip / conv_igemm on the fp32 MFMA accumulation chain, 'split16' = the direct kernels on fp16 parts.  The default engine runs
+    domain: wgrad_fft.hip and the data gradient through conv_fft on flipped filters, two scaled fp16 parts), 'chain' = wgrad.hip / conv_igemm on the fp32 MFMA accumulation chain, 'split16' = the direct kernels on fp16 parts.  The default engine runs
     the wide 60x90 layers (conv4_fullres, conv5) on 32x32 overlap-save windows (jcm_train.hip: 544 frequencies, 192 window "images"); 'exact_nowin'
     (fft_windows = 0) keeps them on the 64x96 transform of the whole map, as round 3 did -- both are held to the same 1e-6."""
     p = synth.make_pd_params(debug=False, bn='trained')
     p.update(synth.make_sm_params(synth.synthetic_priors(), kind='init'))
     lmbd = 0.001
-    kw = dict(f32_conv='exact' if mode in ('exact', 'exact_nowin', 'exact_bf16x3', 'chain') else mode, conv9_fft=False if mode == 'chain' else None,
-              fft_fp16=False if mode == 'exact_bf16x3' else None)
+    kw = dict(f32_conv='exact' if mode in ('exact', 'exact_nowin', 'chain') else mode, conv9_fft=False if mode == 'chain' else None)
     eng, tr = make_trainer(p, use_sm=True, lmbd=lmbd, **kw)
     if mode == 'exact_nowin':
         eng.set_option('fft_windows', 0)
@@ -406,7 +403,7 @@ def test_gradient_kernels_at_full_size_layer_shapes(mode):
     for li, (scope, H, W) in enumerate(LAYER_SHAPES):
         w = np.asarray(p[scope + '/weights'])
         k, _, cin, cout = w.shape
-        assert eng.conv_kernel_name(scope, B, H, W).startswith('conv_fft') == (mode in ('exact', 'exact_nowin', 'exact_bf16x3')), scope
+        assert eng.conv_kernel_name(scope, B, H, W).startswith('conv_fft') == (mode in ('exact', 'exact_nowin')), scope
         g.manual_seed(100 + li)
         x = torch.relu(torch.randn((B, H, W, cin), device='cuda:0', generator=g))
         # dz as BatchNorm's backward leaves it: zero mean per channel (the weight gradient is then a sum with heavy cancellation), scale ~1e-3
@@ -422,7 +419,7 @@ def test_gradient_kernels_at_full_size_layer_shapes(mode):
     eng.close()
     # measured (round 4, 16 images): frequency domain dW <= 2.6e-7, dX <= 2.6e-7 (both operand forms); fp32 MFMA chain dW <= 9.3e-7, dX <= 2.1e-6;
     # direct fp16x3 kernels dW <= 1.0e-6, dX <= 2.3e-6 -- the bound is ~4x the measured value of each route, far below GRAD_RTOL
-    bound = 1e-6 if mode in ('exact', 'exact_nowin', 'exact_bf16x3') else 8e-6
+    bound = 1e-6 if mode in ('exact', 'exact_nowin') else 8e-6
     bad = [r for r in rows if not (r[1] <= bound and r[2] <= bound)]
     assert not bad, (bound, bad)
 

@@ -47,7 +47,7 @@ def diff(a, b):
     return int((a != b).sum()), float(np.abs(a.astype(np.float64) - b).max())
 
 
-eng = Engine(device=0, precision=prec, conv9_fft=FFT, fft_fp16=FP16 if prec == 'fp32' else None).load_params(p)
+eng = Engine(device=0, precision=prec, conv9_fft=FFT).load_params(p)
 logits = [eng.model(xd) for _ in range(6)]
 torch.cuda.synchronize()
 print('one engine, model():', [diff(logits[0], l) for l in logits[1:]])
@@ -59,7 +59,7 @@ ref_fw = {k: fw[0][k].clone() for k in ('pd_prob', 'sm_prob')}
 eng.close()
 
 streams = [torch.cuda.current_stream()] * 2 if SAME else [torch.cuda.Stream(device='cuda:0') for _ in range(2)]
-engs = [Engine(device=0, precision=prec, stream=s, conv9_fft=FFT, call_order=CHAIN, fft_fp16=FP16 if prec == 'fp32' else None).load_params(p) for s in streams]
+engs = [Engine(device=0, precision=prec, stream=s, conv9_fft=FFT, call_order=CHAIN).load_params(p) for s in streams]
 torch.cuda.synchronize()
 
 

@@ -12,9 +12,9 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 p = synth.make_pd_params(debug=False)
 p.update(synth.make_sm_params(synth.synthetic_priors(), kind='init'))
 data = [(torch.as_tensor(synth.make_images(8, seed=300 + i), device='cuda:0'), torch.as_tensor(synth.make_targets(8, seed=400 + i), device='cuda:0')) for i in range(4)]
-# 'exact': the default fp32 engine (frequency domain, two scaled fp16 parts); 'bf16x3': the same route on three bf16 parts; 'chain': the fp32 MFMA kernels
-for mode in ('exact', 'bf16x3', 'chain', 'split', 'split16', 'bf16'):
-    kw = (dict(precision='bf16') if mode == 'bf16' else dict(fft_fp16=False) if mode == 'bf16x3' else dict(conv9_fft=False) if mode == 'chain'
+# 'exact': the default fp32 engine (frequency domain, two scaled fp16 parts); 'chain': the fp32 MFMA kernels; 'split16': the direct fp16x3 kernels
+for mode in ('exact', 'chain', 'split16', 'bf16'):
+    kw = (dict(precision='bf16') if mode == 'bf16' else dict(conv9_fft=False) if mode == 'chain'
           else dict(f32_conv=mode))
     eng = Engine(device=0, **kw).load_params(p)
     tr = Trainer(eng, optimizer='adam', lr=0.001, lmbd=0.001, use_sm=True, n_updates_total=steps)
