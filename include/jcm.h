@@ -95,10 +95,11 @@ int jcm_abi_version(void);
  *              the frequency-domain route (half of the transform passes' HBM traffic) as complex fp16 in block floating point -- one power-of-two
  *              scale per (image, row, 64 channels) tile forward and per (image, kx, 64 channels) tile inverse, 11 significant bits like the
  *              spectra.  0 = complex fp32 (round 3).
- * "sm_algo"  : any time; the pairwise convolutions of the spatial model (main.py:83-87): 3 (default) = every FFT in LDS
- *              (sm_fused.hip); 2 = rocFFT with a split, row-pruned inverse; 0 = rocFFT 2-D transforms; 1 = direct
- *              sliding-window kernel.  All four are HIP paths that pass the same parity tests; the training step always
- *              uses route 2.  "sm_chunk": images per slice of routes 0 and 2 (default 32).
+ * "sm_algo"  : any time; the pairwise convolutions of the spatial model (main.py:83-87): 3 (default) = every 120x180 transform in LDS,
+ *              hand-written (sm_fused.hip; jcm_conv_mrf, the prior spectra and the training step's backward use the whole-frame
+ *              kernels of sm_lds.hip); 1 = direct sliding-window kernel, the independent cross-check.  Both pass the same parity
+ *              tests.  (Rounds 1-4 also had two rocFFT routes, 0 and 2; the library links no FFT library any more.)
+ *              "sm_chunk": images per slice of the training step's spatial-model backward (default 32).
  * "micro_batch": any time; jcm_forward walks its batch in slices of this many images, so the workspace is
  *              sized for one slice (a rank's share of BASELINE configs[3]'s 2048 images fits).  0 (default)
  *              = 256 for bf16 handles, 64 for fp32 handles. */

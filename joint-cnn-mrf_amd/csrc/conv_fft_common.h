@@ -84,9 +84,9 @@ __device__ __forceinline__ void twiddles(cf* tw, const cf* __restrict__ twg, int
 // The layer's input and output are bf16 tensors (8 bits), the spectra on this route carry 11 bits already.
 __device__ __forceinline__ float bfp_scale(float m) {
   int e = 0;
-  if (!(m > 0.f && m < 3.0e38f)) return 1.f;
+  if (!(m > 1.0e-30f && m < 3.0e38f)) return 1.f;      // zero / vanishing tiles (below 2^-100: their fp16 image is zero either way), inf, NaN: no scaling
   (void)frexpf(m, &e);      // m in [2^(e-1), 2^e)
-  return ldexpf(1.f, 15 - e);
+  return ldexpf(1.f, 15 - e);      // e > -100: the scale and its inverse are normal fp32 numbers
 }
 __device__ __forceinline__ unsigned pack_h2(float a, float b) {
   return (unsigned)__builtin_bit_cast(unsigned short, static_cast<_Float16>(a)) | ((unsigned)__builtin_bit_cast(unsigned short, static_cast<_Float16>(b)) << 16);
@@ -171,8 +171,11 @@ __device__ __forceinline__ int fp16_exp(float tmax, float hf) {      // e with H
   if (bound > 0.f && bound < 3.0e38f) (void)frexpf(bound, &e);
   return e;
 }
-__device__ __forceinline__ float fp16_scale(float tmax, float hf) { return ldexpf(1.f, kFp16TargetExp - fp16_exp(tmax, hf)); }
-__device__ __forceinline__ float fp16_unscale(float tmax, float hf) { return ldexpf(1.f, fp16_exp(tmax, hf) - kFp16TargetExp); }
+// 2^k and 2^-k, k clamped to +-126 so that both are normal fp32 numbers whatever the tensor holds (a tensor whose largest entry is below
+// 2^-111 would otherwise get an infinite scale and turn its zeros into NaN)
+__device__ __forceinline__ int fp16_k(float tmax, float hf) { const int k = kFp16TargetExp - fp16_exp(tmax, hf); return k > 126 ? 126 : (k < -126 ? -126 : k); }
+__device__ __forceinline__ float fp16_scale(float tmax, float hf) { return ldexpf(1.f, fp16_k(tmax, hf)); }
+__device__ __forceinline__ float fp16_unscale(float tmax, float hf) { return ldexpf(1.f, -fp16_k(tmax, hf)); }
 // max |T| the scale of image b derives from: its own word, or (common) the largest of the tensor's nb words
 __device__ __forceinline__ float tmax_of(const float* __restrict__ tmax, int b, int nb, int common) {
   if (!common) return tmax[b];
@@ -293,8 +296,6 @@ void cfft_cols_inv(int NY, const ConvArgs& a, const cf* Yf, cf* T, const cf* tw,
 void cfft_rows_inv(int NX, const ConvArgs& a, int layout, const cf* T, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
 // the same pass with the transform in the registers of two threads per channel pair (conv_fft_rows_reg.hip); false: no such kernel for this case
 bool cfft_rows_inv_reg(int NX, const ConvArgs& a, int layout, const cf* T, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
-// forward columns + operand split in registers (np = 4, or np = 5 with fp32 / 16-bit T); false: no such kernel for this case
-bool cfft_cols_fwd_reg(int NY, const ConvArgs& a, int np, const cf* T, void* Xs, int NXH, int MT, const Fp16Scale& sc, hipStream_t st);
 bool cfft_rows_inv_fwd_reg(int NX, const ConvArgs& a, const cf* T, cf* Tn, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
 bool cfft_rows_fwd_reg(int NX, const ConvArgs& a, int layout, cf* T, float* tmax, hipStream_t st, float* t16);
 bool cfft_cols_inv_reg(int NY, const ConvArgs& a, const cf* Yf, cf* T, int NXH, int ldy, int pad, hipStream_t st, float* t16);

@@ -27,12 +27,6 @@ int fail(int code, const std::string& msg);     // sets the thread-local message
     int r_ = (expr);           \
     if (r_ != JCM_OK) return r_; \
   } while (0)
-#define FFT_TRY(expr)                                                                 \
-  do {                                                                                \
-    const char* fe_ = (expr);                                                         \
-    if (fe_) return ::jcm::fail(JCM_ERR_HIP, std::string(#expr) + ": " + fe_);        \
-  } while (0)
-
 // main.py:18 -- channel order of the heat maps and of the pair tables.
 extern const char* const kJointNames[10];
 constexpr int kC = 10;            // heat-map channels seen by the spatial model (9 joints + torso)
@@ -101,7 +95,7 @@ struct jcm_ctx {
   const float** energy_ptrs = nullptr;   // [P] device table of the energy_* / bias_* parameter tensors, graph order
   const float** bias_ptrs = nullptr;
   int* cond0 = nullptr;         // single zero (jcm_conv_mrf)
-  int sm_algo = 3;              // 0 = FFT (2-D rocFFT), 1 = direct sliding-window VALU kernel, 2 = rocFFT with split row-pruned inverse, 3 = fused LDS FFTs (sm_fused.hip)
+  int sm_algo = 3;              // 3 = every transform in LDS (sm_fused.hip), 1 = direct sliding-window VALU kernel (the cross-check)
   // transient, set by jcm_pd_forward around two consecutive frequency-domain layers: the first writes the second's row-transformed input
   void* fft_t_next = nullptr;
   const void* fft_t_in = nullptr;
@@ -125,11 +119,9 @@ struct jcm_ctx {
   float* fft_last_tmax = nullptr;   // the word the last frequency-domain layer's input used (the training step keeps it with the kept spectra)
   struct FftW { void* p = nullptr; size_t bytes = 0; bool valid = false; float* wscale = nullptr; };      // wscale: two device floats behind the spectra (np = 4)
   std::map<std::string, FftW> fft_w;   // filter spectra per "<scope>@HxW", computed on first use, invalidated by refresh_derived
-  int sm_chunk = 32;            // images per FFT slice (measured at B=256, split inverse: 64 -> 3.32 ms, 32 -> 3.10, 16 -> 3.26, 8 -> 3.83)
+  int sm_chunk = 32;            // training step: images per slice of the spatial model's backward pass (81 + 10 spectra per image live at once)
   int micro_batch = 0;          // jcm_forward walks a batch in slices of this many images (0 = 256 bf16 / 64 fp32)
-  jcm::SmFft* fft = nullptr;
-  float2* prior_spec = nullptr; // [P][120*91] spectra of softplus5(energy)
-  float2* prior_spec_t = nullptr; // the same, transposed [P][91][120] (split inverse)
+  float2* prior_spec_t = nullptr; // [P][91][120]: transposed half spectra of softplus5(energy) (sm_lds.hip)
   // workspace arena (stack allocator, grown on demand between forwards)
   char* arena = nullptr;
   size_t arena_cap = 0, arena_off = 0, arena_peak = 0;

@@ -257,6 +257,22 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
   // Filter spectra are cached per (layer, map size).  The cache is bounded (JCM_FFT_CACHE_GB, default 64): a caller that walks many
   // image sizes (7.7 GB per size for conv5) makes it drop every spectrum that is not this layer's before it grows past the bound.
   const std::string key = scope + (circ ? "@win" : "@") + std::to_string(H) + "x" + std::to_string(W);
+  if (!c->fft_w.count(key) && c->train) {
+    // a training handle whose batch crossed the window threshold (jcm_train.hip: takes_windows) changes this layer's geometry: the other geometry's
+    // spectra (several GB for a wide layer) would otherwise stay resident until the cache bound
+    const std::string any = scope + "@", win = scope + "@win";
+    for (auto it = c->fft_w.begin(); it != c->fft_w.end();) {
+      const bool this_layer = it->first.compare(0, any.size(), any) == 0;
+      const bool is_win = it->first.compare(0, win.size(), win) == 0;
+      if (this_layer && is_win != (circ != 0)) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipFree(it->second.p);
+        it = c->fft_w.erase(it);
+      } else {
+        ++it;
+      }
+    }
+  }
   if (!c->fft_w.count(key)) {
     static const size_t cap = [] { const char* e = std::getenv("JCM_FFT_CACHE_GB"); return (size_t)(e ? std::atoi(e) : 64) << 30; }();
     const size_t need = conv_fft_weight_bytes(H, W, L->ks, L->cin, L->cout, np, circ);
@@ -432,7 +448,6 @@ int refresh_derived(jcm_ctx* c, bool first) {
       JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->sp_energy), (size_t)P * kPrH * kPrW * sizeof(float)));
       JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->sp_bias), (size_t)P * kHmHW * sizeof(float)));
       JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->cond), (size_t)P * sizeof(int)));
-      JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->prior_spec), (size_t)P * kSpec * sizeof(float2)));
       JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&c->prior_spec_t), (size_t)P * kSpec * sizeof(float2)));
     }
     if (first) {
@@ -461,8 +476,7 @@ int refresh_derived(jcm_ctx* c, bool first) {
     }
     HIP_TRY(sm_softplus5_multi(c->energy_ptrs, c->sp_energy, P, (int64_t)kPrH * kPrW, c->stream));   // main.py:120
     HIP_TRY(sm_softplus5_multi(c->bias_ptrs, c->sp_bias, P, kHmHW, c->stream));                        // main.py:122
-    FFT_TRY(sm_fft_r2c(c->fft, c->sp_energy, c->prior_spec, P));
-    HIP_TRY(sm_transpose(c->prior_spec, c->prior_spec_t, P, kPrH, kPrW / 2 + 1, 0, kPrW / 2 + 1, c->stream));
+    HIP_TRY(sm_lds_fwd_frames(c->sp_energy, c->prior_spec_t, P, c->stream));      // [pair][91][120]: the layout every consumer reads
     c->has_sm = true;
   }
   if (first) {
@@ -609,6 +623,9 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
   // bf16 on a bf16 handle, where the merged value is rounded to bf16 as the separate merge kernel's output would be).  (A variant with the
   // x1 row prefetched by persistent work groups put the 8 tap gathers per element on the tile's critical path: 4.5 ms against 1.1 + 1.1 ms
   // for the separate merge kernel + plain row pass at B = 256.)
+  // (Round 5 measured the alternative for bf16 handles -- the merge as its own bandwidth-bound kernel + conv5's register row pass: 20.45 against
+  // 20.11 ms per 256-image step with the fused kernel, three interleaved runs each: writing and re-reading the 1.4 GB merged tensor costs more
+  // than the fused kernel's slower rows.)
   const bool fuse_merge = takes_fft(c, L5, B, hh, ww) && !planar45;
   FftMerge mg{x4[1], h4[1], w4[1], x4[2], h4[2], w4[2]};
   void* merged = fuse_merge ? x4[0] : act((size_t)B * hh * ww * L4->cout);
@@ -649,49 +666,7 @@ int sm_forward_impl(jcm_ctx* c, const float* hm, int Ca, const float* extra, int
                              c->stream));
     return JCM_OK;
   }
-  if (c->sm_algo == 2) {   // FFT with a split, row-pruned inverse
-    const int Bc = B < c->sm_chunk ? B : c->sm_chunk;
-    constexpr int WC = kPrW / 2 + 1;                      // 91
-    float* frame = arena_alloc<float>(c, (size_t)Bc * kC * kFrame);
-    float2* lhat = arena_alloc<float2>(c, (size_t)Bc * kC * kSpec);
-    float2* lhat_t = arena_alloc<float2>(c, (size_t)Bc * kC * kSpec);
-    float2* spec_t = arena_alloc<float2>(c, (size_t)Bc * P * kSpec);          // [pair][91][120]
-    float2* rows_c = arena_alloc<float2>(c, (size_t)Bc * P * kCH * WC);       // [pair][61][91]
-    float* rows_r = arena_alloc<float>(c, (size_t)Bc * P * kCH * kPrW);       // [pair][61][180]
-    if (c->dry) return JCM_OK;
-    for (int b0 = 0; b0 < B; b0 += Bc) {
-      const int nb = B - b0 < Bc ? B - b0 : Bc;
-      HIP_TRY(sm_pad_frame(hm + (size_t)b0 * kHmHW * Ca, Ca, extra ? extra + (size_t)b0 * kHmHW * extra_ld : nullptr, c->bn_sm_scale, c->bn_sm_shift,
-                           frame, nb, kC, c->stream, extra_ld));
-      FFT_TRY(sm_fft_r2c(c->fft, frame, lhat, nb * kC));
-      HIP_TRY(sm_transpose(lhat, lhat_t, nb * kC, kPrH, WC, 0, WC, c->stream));
-      HIP_TRY(sm_spec_mul(lhat_t, c->prior_spec_t, c->cond, spec_t, nb, kC, P, c->stream));      // elementwise: layout-agnostic
-      FFT_TRY(sm_fft_cols(c->fft, spec_t, nb * P * WC));
-      HIP_TRY(sm_transpose(spec_t, rows_c, nb * P, WC, kPrH, kPrH - kCH, kCH, c->stream));   // keep m = 59..119
-      FFT_TRY(sm_fft_rows(c->fft, rows_c, rows_r, nb * P * kCH));
-      HIP_TRY(sm_finish_rows(frame, rows_r, c->sp_bias, logits + (size_t)b0 * kHmHW * c->K, nullptr, nb, c->K, kC, c->stream));
-    }
-    return JCM_OK;
-  }
-  // FFT: 10 forward transforms + 81 products + 81 inverse transforms per image, run in batch
-  // slices of `sm_chunk` images: one slice's spectra + frames (14 MB/image) then stay inside the
-  // 256 MB Infinity Cache between rocFFT's passes instead of making 4 round trips to HBM.
-  const int Bc = B < c->sm_chunk ? B : c->sm_chunk;
-  float* frame = arena_alloc<float>(c, (size_t)Bc * kC * kFrame);
-  float2* lhat = arena_alloc<float2>(c, (size_t)Bc * kC * kSpec);
-  float2* spec = arena_alloc<float2>(c, (size_t)Bc * P * kSpec);
-  float* cfull = arena_alloc<float>(c, (size_t)Bc * P * kFrame);
-  if (c->dry) return JCM_OK;
-  for (int b0 = 0; b0 < B; b0 += Bc) {
-    const int nb = B - b0 < Bc ? B - b0 : Bc;
-    HIP_TRY(sm_pad_frame(hm + (size_t)b0 * kHmHW * Ca, Ca, extra ? extra + (size_t)b0 * kHmHW * extra_ld : nullptr, c->bn_sm_scale, c->bn_sm_shift,
-                           frame, nb, kC, c->stream, extra_ld));
-    FFT_TRY(sm_fft_r2c(c->fft, frame, lhat, nb * kC));
-    HIP_TRY(sm_spec_mul(lhat, c->prior_spec, c->cond, spec, nb, kC, P, c->stream));
-    FFT_TRY(sm_fft_c2r(c->fft, spec, cfull, nb * P));
-    HIP_TRY(sm_finish_fft(frame, cfull, c->sp_bias, logits + (size_t)b0 * kHmHW * c->K, nb, c->K, kC, c->stream));
-  }
-  return JCM_OK;
+  return fail(JCM_ERR_STATE, "sm_algo must be 3 (transforms in LDS) or 1 (direct)");
 }
 
 }  // namespace
@@ -714,7 +689,6 @@ int jcm_create(int device, void* stream, jcm_handle* out) {
   jcm_ctx* c = new jcm_ctx();
   c->device = device;
   c->stream = static_cast<hipStream_t>(stream);
-  c->fft = sm_fft_create(c->stream);
   *out = c;
   return JCM_OK;
 }
@@ -723,7 +697,6 @@ int jcm_destroy(jcm_handle h) {
   if (!h) return JCM_OK;
   DeviceGuard g(h->device);
   (void)hipStreamSynchronize(h->stream);
-  sm_fft_destroy(h->fft);
   prof_release_all(h, true);
   if (h->train) train_destroy(h);
   for (auto& kv : h->params) (void)hipFree(kv.second.d);
@@ -792,7 +765,7 @@ int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
     return JCM_OK;
   }
   if (k == "sm_algo") {   // allowed at any time
-    if (value < 0 || value > 3) return fail(JCM_ERR_ARG, "sm_algo must be 0 (fft), 1 (direct), 2 (fft_split) or 3 (fft_fused)");
+    if (value != 1 && value != 3) return fail(JCM_ERR_ARG, "sm_algo must be 3 (every transform in LDS, default) or 1 (direct sliding-window kernel); the rocFFT routes 0 and 2 were removed in round 5");
     h->sm_algo = (int)value;
     return JCM_OK;
   }
@@ -923,17 +896,17 @@ int jcm_conv_mrf(jcm_handle h, const float* A, const float* Bmaps, int B, float*
       HIP_TRY(sm_resize_only(cpre, out, B, c->stream));                          // main.py:89
       return (int)JCM_OK;
     }
-    float* frame = arena_alloc<float>(c, (size_t)B * kFrame);
+    // transforms in LDS (sm_fused.hip / sm_lds.hip), spectra transposed [91][120]: the map in the top-left corner of a zero 120x180 frame, the
+    // product, and rows 59..119 of the circular convolution, whose window [59.., 89..] is the VALID true convolution
     float2* lhat = arena_alloc<float2>(c, (size_t)B * kSpec);
     float2* ahat = arena_alloc<float2>(c, kSpec);
     float2* spec = arena_alloc<float2>(c, (size_t)B * kSpec);
     float* cfull = arena_alloc<float>(c, (size_t)B * kFrame);
     if (c->dry) return (int)JCM_OK;
-    HIP_TRY(sm_pad_frame(Bmaps, 1, nullptr, nullptr, nullptr, frame, B, 1, c->stream));
-    FFT_TRY(sm_fft_r2c(c->fft, frame, lhat, B));
-    FFT_TRY(sm_fft_r2c(c->fft, A, ahat, 1));
-    HIP_TRY(sm_spec_mul(lhat, ahat, c->cond0, spec, B, 1, 1, c->stream));        // main.py:83-87
-    FFT_TRY(sm_fft_c2r(c->fft, spec, cfull, B));
+    HIP_TRY(sm_fused_spectra(Bmaps, 1, nullptr, 0, nullptr, nullptr, lhat, B, 1, c->stream));
+    HIP_TRY(sm_lds_fwd_frames(A, ahat, 1, c->stream));
+    HIP_TRY(sm_spec_mul(lhat, ahat, c->cond0, spec, B, 1, 1, c->stream));        // main.py:83-87 (1 / (120 * 180) inside)
+    HIP_TRY(sm_lds_inv_frames(spec, cfull, B, 59, 61, 1.0f, c->stream));
     HIP_TRY(sm_resize_frame(cfull, out, B, c->stream));                          // main.py:89
     return (int)JCM_OK;
   });

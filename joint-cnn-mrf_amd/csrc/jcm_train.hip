@@ -166,7 +166,11 @@ static bool takes_windows(jcm_ctx* c, const ConvLayer* L, int B, int H, int W, i
   *TX = (W + kWinValid - 1) / kWinValid;
   ConvArgs a{};
   a.B = B * *TY * *TX; a.H = kWin; a.W = kWin; a.Cin = L->cin; a.Cout = L->cout; a.circ = 1;
-  return conv_fft_supported(a, L->ks);
+  if (!conv_fft_supported(a, L->ks)) return false;
+  // the data gradient runs the same windows through the flipped, transposed filter: a layer with Cin = this layer's Cout padded to 64
+  ConvArgs d = a;
+  d.Cin = (L->cout + 63) / 64 * 64; d.Cout = L->cin;
+  return conv_fft_supported(d, L->ks);
 }
 
 // the convolution half: r = relu(conv + b) (or conv + b), the input spectra kept for the weight gradient where the layer runs in the frequency domain
@@ -589,14 +593,13 @@ int loss_grads_impl(jcm_ctx* c, const float* x, const float* y, int B, int H, in
 int sm_train_impl(jcm_ctx* c, const float* pd_prob, const float* y, int B, float gscale, float* ce_sm, float* dlog, float* grads) {
   TrainState* t = c->train;
   const int K = c->K, P = K * (kC - 1);
-  constexpr int WC = kPrW / 2 + 1;
   const size_t N = (size_t)B * kHmHW;
   float* hm10 = arena_alloc<float>(c, N * kC);
   float* sc = arena_alloc<float>(c, 16);
   float* sh = arena_alloc<float>(c, 16);
-  float* frame = arena_alloc<float>(c, (size_t)B * kC * kFrame);
-  float2* lhat = arena_alloc<float2>(c, (size_t)B * kC * kSpec);
-  float* tsave = arena_alloc<float>(c, (size_t)B * P * kHmHW);
+  float* frame = arena_alloc<float>(c, (size_t)B * kC * kFrame);      // s_c = sp(bn(h_c)) on zero frames: the backward's d log(s_j + d) term reads it
+  float2* lhat = arena_alloc<float2>(c, (size_t)B * kC * kSpec);      // likelihood spectra, transposed [B][C][91][120] (sm_fused.hip), kept for dA
+  float* tsave = arena_alloc<float>(c, (size_t)B * P * kHmHW);        // the argument of every pairwise log
   float* sml = arena_alloc<float>(c, N * K);
   float* G = arena_alloc<float>(c, N * K);
   float* dh = arena_alloc<float>(c, N * kC);
@@ -605,40 +608,22 @@ int sm_train_impl(jcm_ctx* c, const float* pd_prob, const float* y, int B, float
   const int Bc = B < c->sm_chunk ? B : c->sm_chunk;
   const size_t mark = c->arena_off;
   BnSave* bs = c->dry ? nullptr : &t->bn["bn_sm"];
-  // ---- forward
-  {
-    float2* lhat_t = arena_alloc<float2>(c, (size_t)Bc * kC * kSpec);
-    float2* spec_t = arena_alloc<float2>(c, (size_t)Bc * P * kSpec);
-    float2* rows_c = arena_alloc<float2>(c, (size_t)Bc * P * kCH * WC);
-    float* rows_r = arena_alloc<float>(c, (size_t)Bc * P * kCH * kPrW);
-    if (!c->dry) {
-      HIP_TRY(sm_concat_target(pd_prob, y, hm10, N, K, kC, c->stream));                                        // main.py:528
-      HIP_TRY(bn_batch_stats(hm10, false, N, kC, kBnEps, 0.9f, bs->mean, bs->rstd, c->params["bn_sm/BatchNorm/moving_mean"].d,
-                             c->params["bn_sm/BatchNorm/moving_variance"].d, t->red, c->stream));              // main.py:113
-      HIP_TRY(bn_fold_stats(bs->mean, bs->rstd, find(c, "bn_sm/BatchNorm/gamma")->d, find(c, "bn_sm/BatchNorm/beta")->d, sc, sh, kC, c->stream));
-      for (int b0 = 0; b0 < B; b0 += Bc) {
-        const int nb = B - b0 < Bc ? B - b0 : Bc;
-        float* fr = frame + (size_t)b0 * kC * kFrame;
-        float2* lh = lhat + (size_t)b0 * kC * kSpec;
-        HIP_TRY(sm_pad_frame(hm10 + (size_t)b0 * kHmHW * kC, kC, nullptr, sc, sh, fr, nb, kC, c->stream));
-        FFT_TRY(sm_fft_r2c(c->fft, fr, lh, nb * kC));
-        HIP_TRY(sm_transpose(lh, lhat_t, nb * kC, kPrH, WC, 0, WC, c->stream));
-        HIP_TRY(sm_spec_mul(lhat_t, c->prior_spec_t, c->cond, spec_t, nb, kC, P, c->stream));
-        FFT_TRY(sm_fft_cols(c->fft, spec_t, nb * P * WC));
-        HIP_TRY(sm_transpose(spec_t, rows_c, nb * P, WC, kPrH, kPrH - kCH, kCH, c->stream));
-        FFT_TRY(sm_fft_rows(c->fft, rows_c, rows_r, nb * P * kCH));
-        HIP_TRY(sm_finish_rows(fr, rows_r, c->sp_bias, sml + (size_t)b0 * kHmHW * K, tsave + (size_t)b0 * P * kHmHW, nb, K, kC, c->stream));
-      }
-      HIP_TRY(softmax_ce(sml, y, B, kHmHW, K, K + 1, gscale, ce_sm, G, K, 0, c->stream));                      // main.py:539
-    }
+  // ---- forward: the fused kernels of the inference path (every transform in LDS), which also leave the log arguments
+  if (!c->dry) {
+    HIP_TRY(sm_concat_target(pd_prob, y, hm10, N, K, kC, c->stream));                                        // main.py:528
+    HIP_TRY(bn_batch_stats(hm10, false, N, kC, kBnEps, 0.9f, bs->mean, bs->rstd, c->params["bn_sm/BatchNorm/moving_mean"].d,
+                           c->params["bn_sm/BatchNorm/moving_variance"].d, t->red, c->stream));              // main.py:113
+    HIP_TRY(bn_fold_stats(bs->mean, bs->rstd, find(c, "bn_sm/BatchNorm/gamma")->d, find(c, "bn_sm/BatchNorm/beta")->d, sc, sh, kC, c->stream));
+    HIP_TRY(sm_pad_frame(hm10, kC, nullptr, sc, sh, frame, B, kC, c->stream));
+    HIP_TRY(sm_fused_forward(hm10, kC, nullptr, 0, sc, sh, c->prior_spec_t, c->cond, c->sp_bias, lhat, sml, B, K, kC, c->stream, tsave));   // main.py:117-123
+    HIP_TRY(softmax_ce(sml, y, B, kHmHW, K, K + 1, gscale, ce_sm, G, K, 0, c->stream));                      // main.py:539
   }
-  c->arena_off = mark;
-  // ---- backward
+  // ---- backward (sm_train.hip; transforms: sm_lds.hip)
   {
-    float* D = arena_alloc<float>(c, (size_t)(Bc > 1 ? Bc : 1) * P * kFrame);      // also holds the 81 dA frames at the end
     float2* Dhat = arena_alloc<float2>(c, (size_t)Bc * P * kSpec);
     float2* dLhat = arena_alloc<float2>(c, (size_t)Bc * kC * kSpec);
-    float* dLframe = arena_alloc<float>(c, (size_t)Bc * kC * kFrame);
+    float* dLframe = arena_alloc<float>(c, (size_t)Bc * kC * kFrame);      // rows 0..59 are written and read
+    float* dAframe = arena_alloc<float>(c, (size_t)P * kFrame);
     float* dhm = arena_alloc<float>(c, N * kC);
     if (!c->dry) {
       for (int b0 = 0; b0 < B; b0 += Bc) {
@@ -646,16 +631,15 @@ int sm_train_impl(jcm_ctx* c, const float* pd_prob, const float* y, int B, float
         const float* Gb = G + (size_t)b0 * kHmHW * K;
         const float* Tb = tsave + (size_t)b0 * P * kHmHW;
         HIP_TRY(sm_bwd_dbias(Gb, Tb, dspb, nb, K, P, b0 > 0, c->stream));
-        HIP_TRY(sm_bwd_dframe(Gb, Tb, D, nb, K, P, c->stream));
-        FFT_TRY(sm_fft_r2c(c->fft, D, Dhat, nb * P));
+        HIP_TRY(sm_lds_fwd_dframes(Gb, Tb, Dhat, nb, K, P, c->stream));      // D_p = R^T (G_j / T_p) on the window, transformed as it is built
         HIP_TRY(sm_bwd_spec_da(Dhat, lhat + (size_t)b0 * kC * kSpec, c->cond, dA_hat, nb, kC, P, b0 > 0, c->stream));
-        HIP_TRY(sm_bwd_spec_dl(Dhat, c->prior_spec, dLhat, nb, K, kC, c->stream));
-        FFT_TRY(sm_fft_c2r(c->fft, dLhat, dLframe, nb * kC));
+        HIP_TRY(sm_bwd_spec_dl(Dhat, c->prior_spec_t, dLhat, nb, K, kC, c->stream));
+        HIP_TRY(sm_lds_inv_frames(dLhat, dLframe, nb * kC, 0, kHmH, 1.0f, c->stream));
         HIP_TRY(sm_bwd_dh(dLframe, Gb, frame + (size_t)b0 * kC * kFrame, hm10 + (size_t)b0 * kHmHW * kC, sc, sh,
                           dh + (size_t)b0 * kHmHW * kC, nb, K, kC, c->stream));
       }
-      FFT_TRY(sm_fft_c2r(c->fft, dA_hat, D, P));
-      HIP_TRY(sm_bwd_params(D, dspb, t->e_ptr, t->b_ptr, t->e_off, t->b_off, grads, P, c->stream));
+      HIP_TRY(sm_lds_inv_frames(dA_hat, dAframe, P, 0, kPrH, 1.0f, c->stream));
+      HIP_TRY(sm_bwd_params(dAframe, dspb, t->e_ptr, t->b_ptr, t->e_off, t->b_off, grads, P, c->stream));
       float* sums = t->small;
       HIP_TRY(bn_bwd_reduce(dh, 1.0f, hm10, false, bs->mean, bs->rstd, N, kC, sums, grad_of(t, grads, "bn_sm/BatchNorm/gamma"),
                             grad_of(t, grads, "bn_sm/BatchNorm/beta"), t->red, c->stream));

@@ -238,34 +238,30 @@ hipError_t sm_finish(const float* lik, const float* cpre, const float* spbias, f
 // out[b,pix] = R(cpre[b][0])[pix]   (the resize of main.py:89 on its own, for jcm_conv_mrf)
 hipError_t sm_resize_only(const float* cpre, float* out, int B, hipStream_t st);
 
-// ---- sm_fft.hip : the pairwise convolutions through rocFFT (hipFFT API) ----------------------------
-// Frames are 120x180 real; spectra 120x91 complex.  sm_fft_* return nullptr or an error string.
-struct SmFft;
-SmFft* sm_fft_create(hipStream_t st);
-void sm_fft_destroy(SmFft* f);
-const char* sm_fft_r2c(SmFft* f, const float* in, float2* out, int n);
-const char* sm_fft_c2r(SmFft* f, float2* in, float* out, int n);
+// ---- sm_frames.hip : plain kernels around the spatial model's 120 x 180 frames (no transforms) ----------
 // frame[b][c] = softplus5(bn(hm[b,:,:,c])) in the top-left 60x90 of a zero 120x180 frame (sc null: raw)
 // (channels [0,Ca) from hm [B,5400,Ca], the rest from extra [B,5400,C-Ca]: main.py:528's concat read in place)
 hipError_t sm_pad_frame(const float* hm, int Ca, const float* extra, const float* sc, const float* sh, float* frame, int B, int C,
                         hipStream_t st, int extra_ld = 0);
-// spec[b][p] = lhat[b][cond[p]] * phat[p] / (120*180)
+// spec[b][p] = lhat[b][cond[p]] * phat[p] / (120*180)   (elementwise: any layout of the 120 * 91 complex numbers of a spectrum)
 hipError_t sm_spec_mul(const float2* lhat, const float2* phat, const int* cond, float2* spec, int B, int C, int P, hipStream_t st);
-hipError_t sm_finish_fft(const float* frame, const float* cfull, const float* spbias, float* logits, int B, int K, int C, hipStream_t st);
+// out[b] = the TF-1.x 61x91 -> 60x90 resize (main.py:89) of the VALID window frame[59.., 89..] of cfull [B][120][180]
 hipError_t sm_resize_frame(const float* cfull, float* out, int B, hipStream_t st);
-// ---- sm_fused.hip (sm_algo = 3, default): every transform of the pairwise convolutions in LDS -- forward spectra per (image,
-// channel) into lhat_t [B][C][91][120], then per (image, joint) product + inverse + window + resize + bias + log + sum
+// ---- sm_fused.hip (default): every transform of the pairwise convolutions in LDS -- forward spectra per (image, channel) into
+// lhat_t [B][C][91][120], then per (image, joint) product + inverse + window + resize + bias + log + sum.
+// tsave (may be null): [B][P][5400] the argument of every pairwise log, kept for the training step's backward pass
 hipError_t sm_fused_forward(const float* hm, int Ca, const float* extra, int extra_ld, const float* sc, const float* sh, const float2* phat_t,
-                            const int* cond, const float* spbias, float2* lhat_t, float* logits, int B, int K, int C, hipStream_t st);
-
-// split inverse (sm_algo = 2): spectra kept transposed [n][91][120]; columns by 1-D C2C, then only rows
-// 59..119 are transposed back ([n][61][91]) and go through a 1-D C2R
-const char* sm_fft_cols(SmFft* f, float2* data, int n);
-const char* sm_fft_rows(SmFft* f, float2* in, float* out, int n);
-hipError_t sm_transpose(const float2* in, float2* out, int N, int R, int C, int c0, int C_out, hipStream_t st);   // out[n][c][r] = in[n][r][c0+c]
-// tsave (may be null): [B][P][5400] the argument of every pairwise log, kept for the training backward
-hipError_t sm_finish_rows(const float* frame, const float* rows, const float* spbias, float* logits, float* tsave, int B, int K, int C,
-                          hipStream_t st);
+                            const int* cond, const float* spbias, float2* lhat_t, float* logits, int B, int K, int C, hipStream_t st,
+                            float* tsave = nullptr);
+// the first half alone: lhat_t[b][c] = transposed half spectrum of the frame of channel c of image b (sc null: the raw map)
+hipError_t sm_fused_spectra(const float* hm, int Ca, const float* extra, int extra_ld, const float* sc, const float* sh, float2* lhat_t, int B, int C,
+                            hipStream_t st);
+// ---- sm_lds.hip : whole-frame transforms in LDS (spectra transposed, [n][91][120]); unnormalised
+hipError_t sm_lds_fwd_frames(const float* frames, float2* spec_t, int n, hipStream_t st);      // real [n][120][180] -> spectra
+// D[b][p] = R^T (G_j / T_p) on the window [59..119] x [89..179] (backward of main.py:89,121) -> its spectrum; dhat_t [nb * P][91][120]
+hipError_t sm_lds_fwd_dframes(const float* G, const float* T, float2* dhat_t, int nb, int K, int P, hipStream_t st);
+// rows [r0, r0 + nrows) of the real frames [n][120][180] of the spectra, times `scale`
+hipError_t sm_lds_inv_frames(const float2* spec_t, float* frames, int n, int r0, int nrows, float scale, hipStream_t st);
 
 // ---- multiscale.hip : crop/pad window + skimage-style bilinear resize, mean over scale copies ------
 // windows_dev: int32 [NW][5] = (source image, y0, x0, h, w); mm_scratch: float2 [NW]
@@ -335,7 +331,6 @@ hipError_t bn_fold_stats(const float* mean, const float* rstd, const float* gamm
 hipError_t sm_concat_target(const float* prob, const float* y, float* out, size_t N, int K, int C, hipStream_t st);
 // G [nb,5400,K] = dL/dE, T [nb][P][5400] saved log arguments
 hipError_t sm_bwd_dbias(const float* G, const float* T, float* dspb, int nb, int K, int P, int accumulate, hipStream_t st);
-hipError_t sm_bwd_dframe(const float* G, const float* T, float* D, int nb, int K, int P, hipStream_t st);
 hipError_t sm_bwd_spec_da(const float2* Dhat, const float2* Lhat, const int* cond, float2* dA, int nb, int C, int P, int accumulate,
                           hipStream_t st);
 hipError_t sm_bwd_spec_dl(const float2* Dhat, const float2* Ahat, float2* dL, int nb, int K, int C, hipStream_t st);

@@ -1,8 +1,8 @@
 // The spatial model's 81 pairwise convolutions (main.py:83-87, 117-123) with every transform done in LDS.
 //
-// sm_fft.hip runs the transforms of sm_algo = fft_split through rocFFT: per forward 10 + 81 spectra per image go to HBM and
-// back four times (product, column pass, pruning transpose, row pass, epilogue), 10.8 GB per 256 images and 3.3 ms.  A
-// 120x91 half spectrum is 87 KB: it fits the LDS of one CU.  So:
+// (Rounds 1-2 ran these transforms through rocFFT: per forward 10 + 81 spectra per image went to HBM and back four times -- product,
+// column pass, pruning transpose, row pass, epilogue -- 10.8 GB per 256 images and 3.3 ms.)  A 120x91 half spectrum is 87 KB: it fits the
+// LDS of one CU.  So:
 //
 //   sm_fwd_spectra_kernel, one work group per (image, channel): softplus(BN(heat map)) -> the 60 nonzero rows of the zero
 //     120x180 frame, transformed two rows at a time (z = row_a + i row_b, one 180-point complex FFT, unpacked through the
@@ -19,91 +19,12 @@
 // twiddle per point between the stages); the output of a transform sits at its digit-reversed position, which the consumer
 // folds into its read address (pos120 / pos180).  Row pitches 121 / 181 keep the strided accesses of the transposing steps
 // bank-conflict free.  The kernels are VALU-bound (a pair is 0.8 M lane-instructions), not LDS- or HBM-bound.
-// Same arithmetic as the rocFFT route up to fp32 rounding (unnormalised transforms, 1/(120*180) folded into the product);
+// Unnormalised transforms, 1/(120*180) folded into the product;
 // the imaginary parts of the DC / Nyquist bins of a row are dropped as a C2R transform drops them.
-#include "fft_lds.h"
-#include "kernels.h"
+#include "sm_lds_fft.h"
 
 namespace jcm {
 
-namespace smf {
-using namespace fftl;      // cf (complex as a 2-vector), Dft<R, S>
-constexpr int FH = 120, FW = 180, WC = 91;        // frame, half-spectrum columns
-constexpr int MH = 60, MW = 90, MHW = MH * MW;    // heat map
-constexpr int PU = 121, PX = 181;                 // LDS pitches (complex elements) of the column buffer [91][PU] and the row buffer [31][PX]
-constexpr int NROWP = 31;                         // row pairs of the inverse (61 rows); the forward has 30
-constexpr int NT = 768;                           // 12 waves: 91 x 8 radix-15 butterflies in one sweep; measured 1.21 ms per 256 images against 1.24 ms with 8 waves
-constexpr int CB = 0, RB = WC * PU, TW120 = RB + NROWP * PX, TW180 = TW120 + FH, TY = TW180 + FW, TX = TY + MH, LDS_C = TX + MW;   // offsets in complex elements
-constexpr int LDS_BYTES = LDS_C * 8;
-static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-constexpr int NE = (WC * FH + NT - 1) / NT;       // spectrum elements per thread: 15
-constexpr int NPIX = (MHW + NT - 1) / NT;         // output pixels per thread: 8
-
-__device__ __forceinline__ int pos120(int y) { return (y & 7) * 15 + (y >> 3); }       // X[m + 8 k] sits at 15 m + k
-__device__ __forceinline__ int pos180(int x) { return (x % 12) * 15 + x / 12; }          // X[m + 12 k] sits at 15 m + k
-
-// One decimation-in-frequency stage of NB transforms of length N (row pitch PITCH), radix R on blocks of length L.
-// tw[k] = e^{+2 pi i k / N}.  Consecutive threads take the same butterfly of consecutive transforms: the LDS stride is the
-// (odd) pitch, which is bank-conflict free, and a wave reads its twiddles as broadcasts.
-template <int N, int R, int L, int PITCH, int S, int NB>
-__device__ __forceinline__ void fft_stage(cf* buf, const cf* tw, int tid) {
-  constexpr int M = L / R, BF = N / R;
-  for (int t = tid; t < BF * NB; t += NT) {
-    const int bf = t / NB, v = t - bf * NB;
-    const int blk = bf / M, k = bf - blk * M;
-    cf* p = buf + v * PITCH + blk * L + k;
-    cf x[R];
-#pragma unroll
-    for (int m = 0; m < R; ++m) x[m] = p[m * M];
-    Dft<R, S>::run(x);
-    if (M > 1) {
-#pragma unroll
-      for (int m = 1; m < R; ++m) {
-        cf w = tw[(N / L) * k * m];
-        if (S < 0) w.y = -w.y;
-        x[m] = cmul(x[m], w);
-      }
-    }
-#pragma unroll
-    for (int m = 0; m < R; ++m) p[m * M] = x[m];
-  }
-}
-template <int PITCH, int S, int NB>
-__device__ __forceinline__ void fft120(cf* buf, const cf* tw, int tid) {
-  fft_stage<120, 8, 120, PITCH, S, NB>(buf, tw, tid); __syncthreads();
-  fft_stage<120, 15, 15, PITCH, S, NB>(buf, tw, tid); __syncthreads();
-}
-template <int PITCH, int S, int NB>
-__device__ __forceinline__ void fft180(cf* buf, const cf* tw, int tid) {
-  fft_stage<180, 12, 180, PITCH, S, NB>(buf, tw, tid); __syncthreads();
-  fft_stage<180, 15, 15, PITCH, S, NB>(buf, tw, tid); __syncthreads();
-}
-
-__device__ __forceinline__ void make_twiddles(cf* lds, int tid) {
-  for (int k = tid; k < FH + FW; k += NT) {
-    const bool a = k < FH;
-    const int kk = a ? k : k - FH;
-    double sn, cs;
-    sincospi(2.0 * (double)kk / (double)(a ? FH : FW), &sn, &cs);
-    lds[(a ? TW120 : TW180) + kk] = cf{(float)cs, (float)sn};
-  }
-}
-
-__device__ __forceinline__ float softplus5(float x) {      // the spatial model's SoftPlus (beta 5, main.py:128-131), as sm_fft.hip
-  const float z = 5.0f * x;
-  const float thr = 13.942385f;
-  float sp;
-  if (z > thr) sp = z;
-  else if (z < -thr) sp = expf(z);
-  else sp = log1pf(expf(z));
-  return 0.2f * sp;
-}
-__device__ __forceinline__ float lik_of(const float* __restrict__ hm, int Ca, const float* __restrict__ extra, int extra_ld, const float* __restrict__ sc,
-                                        const float* __restrict__ sh, int64_t pixg, int c) {
-  const float hv = c < Ca ? hm[pixg * Ca + c] : extra[pixg * extra_ld + (c - Ca)];
-  return sc ? softplus5(hv * sc[c] + sh[c]) : hv;
-}
-}  // namespace smf
 
 using namespace smf;
 
@@ -149,7 +70,7 @@ __global__ __launch_bounds__(NT) void sm_inv_finish_kernel(const float* __restri
                                                              const float* __restrict__ sc, const float* __restrict__ sh,
                                                              const float2* __restrict__ lhat_t, const float2* __restrict__ phat_t,
                                                              const int* __restrict__ cond, const float* __restrict__ spb, float* __restrict__ logits, int K,
-                                                             int C) {
+                                                             int C, float* __restrict__ tsave) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* lds = reinterpret_cast<cf*>(smem);
   cf* cb = lds + CB;
@@ -234,7 +155,9 @@ __global__ __launch_bounds__(NT) void sm_inv_finish_kernel(const float* __restri
         const float top = tl + (tr - tl) * cx.y;
         const float bot = bl + (br - bl) * cx.y;
         const float cv = top + (bot - top) * cy.y;
-        e[i] += __logf((cv + bias[pix]) + 1e-6f);      // v_log_f32 * ln 2: the argument is a normal number >= 1e-6
+        const float tv = (cv + bias[pix]) + 1e-6f;
+        if (tsave) tsave[((size_t)b * (K * PJ) + p) * MHW + pix] = tv;      // training step: the log's argument is the backward pass's denominator
+        e[i] += __logf(tv);      // v_log_f32 * ln 2: the argument is a normal number >= 1e-6
       }
     }
     __syncthreads();      // the row buffer is rewritten by the next pair's packing step (its column buffer is free already)
@@ -247,14 +170,24 @@ __global__ __launch_bounds__(NT) void sm_inv_finish_kernel(const float* __restri
 }
 
 hipError_t sm_fused_forward(const float* hm, int Ca, const float* extra, int extra_ld, const float* sc, const float* sh, const float2* phat_t,
-                            const int* cond, const float* spbias, float2* lhat_t, float* logits, int B, int K, int C, hipStream_t st) {
+                            const int* cond, const float* spbias, float2* lhat_t, float* logits, int B, int K, int C, hipStream_t st, float* tsave) {
   if (extra_ld <= 0) extra_ld = C - Ca;
   static LdsAttr attr_f, attr_i;
   if (hipError_t e = attr_f.ensure(reinterpret_cast<const void*>(sm_fwd_spectra_kernel), LDS_BYTES); e != hipSuccess) return e;
   if (hipError_t e = attr_i.ensure(reinterpret_cast<const void*>(sm_inv_finish_kernel), LDS_BYTES); e != hipSuccess) return e;
   hipLaunchKernelGGL(sm_fwd_spectra_kernel, dim3(B * C), dim3(NT), LDS_BYTES, st, hm, Ca, extra, extra_ld, sc, sh, lhat_t, C);
   if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-  hipLaunchKernelGGL(sm_inv_finish_kernel, dim3(B * K), dim3(NT), LDS_BYTES, st, hm, Ca, extra, extra_ld, sc, sh, lhat_t, phat_t, cond, spbias, logits, K, C);
+  hipLaunchKernelGGL(sm_inv_finish_kernel, dim3(B * K), dim3(NT), LDS_BYTES, st, hm, Ca, extra, extra_ld, sc, sh, lhat_t, phat_t, cond, spbias, logits, K, C, tsave);
+  return hipGetLastError();
+}
+
+
+hipError_t sm_fused_spectra(const float* hm, int Ca, const float* extra, int extra_ld, const float* sc, const float* sh, float2* lhat_t, int B, int C,
+                            hipStream_t st) {
+  if (extra_ld <= 0) extra_ld = C - Ca;
+  static LdsAttr attr_f;
+  if (hipError_t e = attr_f.ensure(reinterpret_cast<const void*>(sm_fwd_spectra_kernel), LDS_BYTES); e != hipSuccess) return e;
+  hipLaunchKernelGGL(sm_fwd_spectra_kernel, dim3(B * C), dim3(NT), LDS_BYTES, st, hm, Ca, extra, extra_ld, sc, sh, lhat_t, C);
   return hipGetLastError();
 }
 

