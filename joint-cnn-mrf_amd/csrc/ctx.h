@@ -48,6 +48,7 @@ struct ConvLayer {
   bool has_bn = false;
   const float* w_raw = nullptr;   // HWIO (conv1 kernel reads it directly)
   float* wp = nullptr;            // packed for conv_igemm_f32
+  mutable bool wp_stale = false;  // a refresh after a weight update left `wp` behind: repacked where a direct fp32 kernel next reads it (run_conv_layer)
   void* wp_split = nullptr;       // two fp16 parts per weight for conv_split_f32 (fp32 handles, "f32_conv" = 2)
   int coutp_split = 0;
   float* wscale = nullptr;        // fp16x3: device {Sw, 1/Sw}, the power-of-two scale the packed weights carry

@@ -349,6 +349,10 @@ int run_conv_layer(jcm_ctx* c, const ConvLayer* L, const std::string& scope, int
   if (c->dry) return JCM_OK;
   const void* wp = act_bf16 ? L->wp_bf16 : static_cast<const void*>(L->wp);
   if (stride != 1 || !wp) return fail(JCM_ERR_ARG, "no kernel for layer '" + scope + "' with stride " + std::to_string(stride));
+  if (!act_bf16 && L->wp_stale) {
+    HIP_TRY(pack_weights_f32(L->w_raw, L->wp, L->ks, L->cin, L->cout, L->coutp, c->stream));
+    L->wp_stale = false;
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   JCM_TRY(prof_begin(c, &e0, &e1));
   const int r = launch_conv_layer(c, L, wp, x, B, H, W, out, act_bf16, out_f32, in_planar, out_planar);
@@ -400,7 +404,9 @@ int refresh_derived(jcm_ctx* c, bool first) {
       L.coutp = (L.cout + bn - 1) / bn * bn;
       const size_t n = (size_t)L.ks * L.ks * L.cin * L.coutp;
       if (!L.wp) JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&L.wp), n * sizeof(float)));
-      HIP_TRY(pack_weights_f32(w.d, L.wp, L.ks, L.cin, L.cout, L.coutp, c->stream));
+      // after a weight update (training step) the packing waits until a direct kernel reads it: layers on the frequency-domain route never do
+      if (first) HIP_TRY(pack_weights_f32(w.d, L.wp, L.ks, L.cin, L.cout, L.coutp, c->stream));
+      else L.wp_stale = true;
     }
     if (c->precision == JCM_PRECISION_F32 && c->f32_conv == 2 && (L.ks == 9 || L.ks == 5) && L.cin % 16 == 0 && L.cout % 128 == 0) {
       const int ns = 2;      // operand parts of the direct split kernels: two fp16 parts, three products (fp16x3)

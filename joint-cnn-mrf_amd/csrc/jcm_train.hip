@@ -68,6 +68,7 @@ struct TrainState {
   int64_t* ck_start = nullptr;
   int64_t* ck_off = nullptr;
   int* ck_len = nullptr;
+  int* ck_isw = nullptr;               // the chunk belongs to a '<scope>/weights' tensor (weight decay, main.py:195-205)
   int n_chunks = 0;
   int maxC = 0;
   long step = 0;                       // optimizer updates applied (n_iters, main.py:491)
@@ -504,12 +505,7 @@ int loss_grads_impl(jcm_ctx* c, const float* x, const float* y, int B, int H, in
   }
   if (!c->dry) {
     // weight_decay('weights') (main.py:195-205): sum of l2_loss over the conv weights
-    bool first = true;
-    for (const Slot& s : t->slots) {
-      if (s.name.find("weights") == std::string::npos) continue;
-      HIP_TRY(sum_squares(s.w, s.n, t->sumsq + 1, first ? 0 : 1, t->red, c->stream));
-      first = false;
-    }
+    HIP_TRY(sum_squares_chunks(t->ck_w, t->ck_start, t->ck_len, t->ck_isw, t->n_chunks, t->sumsq + 1, t->red, c->stream));
     hipLaunchKernelGGL(finish_losses_kernel, dim3(1), dim3(64), 0, c->stream, ce_pd, ce_sm, B * K, t->sumsq + 1, lmbd, losses);
     HIP_TRY(hipGetLastError());
   }
@@ -579,7 +575,7 @@ int loss_grads_impl(jcm_ctx* c, const float* x, const float* y, int B, int H, in
       float* partial = arena_alloc<float>(c, n * nb);
       if (!c->dry) {
         HIP_TRY(wgrad_conv1(x, dz1, b16, partial, B, H, W, 1 << r, C1, c->stream));
-        HIP_TRY(wgrad_reduce(partial, nb, n, l1[r].L->w_raw, lmbd, grad_of(t, grads, l1[r].scope + "/weights"), c->stream));
+        HIP_TRY(wgrad_reduce_wide(partial, nb, n, l1[r].L->w_raw, lmbd, grad_of(t, grads, l1[r].scope + "/weights"), c->stream));
       }
       notify_ready(c, l1[r].scope + "/");
     }
@@ -767,10 +763,11 @@ int jcm_train_begin(jcm_handle h) {
     constexpr int64_t kChunk = 16384;
     std::vector<float*> cw;
     std::vector<int64_t> cs, co;
-    std::vector<int> cl;
+    std::vector<int> cl, cf;
     for (const Slot& sl : t->slots)
       for (int64_t st0 = 0; st0 < (int64_t)sl.n; st0 += kChunk) {
         cw.push_back(sl.w); cs.push_back(st0); co.push_back((int64_t)sl.off);
+        cf.push_back(sl.name.find("weights") != std::string::npos ? 1 : 0);
         cl.push_back((int)((int64_t)sl.n - st0 < kChunk ? (int64_t)sl.n - st0 : kChunk));
       }
     t->n_chunks = (int)cw.size();
@@ -778,10 +775,12 @@ int jcm_train_begin(jcm_handle h) {
     JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->ck_start), cs.size() * sizeof(int64_t)));
     JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->ck_off), co.size() * sizeof(int64_t)));
     JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->ck_len), cl.size() * sizeof(int)));
+    JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->ck_isw), cf.size() * sizeof(int)));
     HIP_TRY(hipMemcpyAsync(t->ck_w, cw.data(), cw.size() * sizeof(float*), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(t->ck_start, cs.data(), cs.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(t->ck_off, co.data(), co.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(t->ck_len, cl.data(), cl.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(t->ck_isw, cf.data(), cf.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
   JCM_TRY(dev_alloc(c, reinterpret_cast<void**>(&t->gscale), 2 * sizeof(float)));

@@ -293,6 +293,8 @@ hipError_t softmax_ce(const float* logits, const float* target, int B, int HW, i
 hipError_t softmax_bwd(const float* p, const float* g, int B, int HW, int K, int ldg, float* dz, int ldz, hipStream_t st);
 hipError_t loss_means_accumulate(const float* ce, int n, float scale, float* out, bool first, hipStream_t st);
 hipError_t sum_squares(const float* x, size_t n, double* out, int accumulate, double* scratch, hipStream_t st);
+// the same over the flagged chunks of a chunk table (w[k] + start[k], len[k]): one pass over many tensors
+hipError_t sum_squares_chunks(float* const* w, const int64_t* start, const int* len, const int* flag, int nchunks, double* out, double* scratch, hipStream_t st);
 hipError_t adam_update(float* w, const float* g, float* m, float* v, size_t n, const double* sumsq, float clip, float lr_t, float b1,
                        float b2, float eps, hipStream_t st);
 hipError_t momentum_update(float* w, const float* g, float* acc, size_t n, const double* sumsq, float clip, float lr, float mom,
@@ -310,6 +312,7 @@ hipError_t wgrad_f32(const float* x, const float* dz, float* partial, int splits
 // dw = out_scale * sum(partials) + lmbd * w   (out_scale: device scalar, null = 1)
 hipError_t wgrad_reduce(const float* partial, int splits, size_t n, const float* w, float lmbd, float* dw, hipStream_t st, const float* out_scale = nullptr);
 int wgrad_conv1_blocks(void);
+hipError_t wgrad_reduce_wide(const float* partial, int splits, size_t n, const float* w, float lmbd, float* dw, hipStream_t st);      // many tiles of a small tensor (conv1)
 hipError_t wgrad_conv1(const float* x, const void* dz, bool dz_bf16, float* partial, int B, int H0, int W0, int sub, int Cout, hipStream_t st);
 // wgrad_split.hip: the same on the 16-bit matrix cores (two fp16 parts per operand, three products; or plain bf16 operands), LDS transpose reads
 // two fp16 parts of x * S (S = scale[0], a device scalar; null = 1)

@@ -1,8 +1,7 @@
 // Training-step kernels that are not convolutions: batch-statistics
 // BatchNorm forward/backward, ReLU / max-pool / bilinear-merge backward, the soft-label spatial
 // cross-entropy and its gradient, global-norm, Adam / momentum updates.  All tensors fp32 NHWC;
-// per-channel reductions accumulate per-thread partial sums in fp32 over short runs and combine
-// them in double, so a sum over 10^7 activations keeps fp32-exact inputs to the next stage.
+// per-channel reductions accumulate in double (products are formed in fp32, as the reference's fp32 graph forms them).
 #include "kernels.h"
 
 namespace jcm {
@@ -20,10 +19,10 @@ template <class T>
 struct OpStats {              // sum x, sum x^2
   static constexpr int Q = 2;
   const T* x;
-  __device__ void operator()(size_t i, int, float* q) const {
+  __device__ void operator()(size_t i, int, double* q) const {
     const float v = static_cast<float>(x[i]);
-    q[0] += v;
-    q[1] += v * v;
+    q[0] += (double)v;
+    q[1] += (double)(v * v);
   }
 };
 template <class T>
@@ -33,23 +32,23 @@ struct OpBnBwd {              // sum dy, sum dy * (r - mean)      (dy optionally
   const T* r;
   const float* mean;
   float dy_scale;
-  __device__ void operator()(size_t i, int c, float* q) const {
+  __device__ void operator()(size_t i, int c, double* q) const {
     const float g = static_cast<float>(dy[i]) * dy_scale;
-    q[0] += g;
-    q[1] += g * (static_cast<float>(r[i]) - mean[c]);
+    q[0] += (double)g;
+    q[1] += (double)(g * (static_cast<float>(r[i]) - mean[c]));
   }
 };
 template <class T>
 struct OpSum {                // sum x   (bias gradient of a conv: sum of dz)
   static constexpr int Q = 1;
   const T* x;
-  __device__ void operator()(size_t i, int, float* q) const { q[0] += static_cast<float>(x[i]); }
+  __device__ void operator()(size_t i, int, double* q) const { q[0] += (double)static_cast<float>(x[i]); }
 };
 
 template <class Op>
 __global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(Op op, size_t N, int C, double* __restrict__ partial) {
   // partial: [gridDim.x][Q][C]
-  __shared__ float red[RED_THREADS * Op::Q];
+  __shared__ double red[RED_THREADS * Op::Q];
   const int lanes = RED_THREADS / C > 0 ? RED_THREADS / C : 1;   // row lanes per block when C <= 256
   const int tid = threadIdx.x;
   // channels are walked in groups of RED_THREADS when C > RED_THREADS
@@ -57,11 +56,26 @@ __global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(Op op, size_t N
     const int cw = C - c0 < RED_THREADS ? C - c0 : RED_THREADS;   // channels handled in this pass
     const int nl = C <= RED_THREADS ? lanes : 1;
     const int c = tid % cw, rl = tid / cw;
-    float q[Op::Q];
+    double q[Op::Q];      // double accumulators: the pass is bound by its loads, and sums like d beta = sum dy cancel heavily
 #pragma unroll
-    for (int k = 0; k < Op::Q; ++k) q[k] = 0.f;
+    for (int k = 0; k < Op::Q; ++k) q[k] = 0.0;
     if (rl < nl) {
-      for (size_t row = (size_t)blockIdx.x * nl + rl; row < N; row += (size_t)gridDim.x * nl) op(row * C + c0 + c, c0 + c, q);
+      // four rows in flight per thread (independent partial sums, added pairwise at the end): with one row per iteration the pass ran at
+      // 1.7-2.7 TB/s -- every load waited for the accumulate behind the previous one (round 5)
+      double q1[Op::Q], q2[Op::Q], q3[Op::Q];
+#pragma unroll
+      for (int k = 0; k < Op::Q; ++k) q1[k] = q2[k] = q3[k] = 0.0;
+      const size_t stride = (size_t)gridDim.x * nl;
+      size_t row = (size_t)blockIdx.x * nl + rl;
+      for (; row + 3 * stride < N; row += 4 * stride) {
+        op(row * C + c0 + c, c0 + c, q);
+        op((row + stride) * C + c0 + c, c0 + c, q1);
+        op((row + 2 * stride) * C + c0 + c, c0 + c, q2);
+        op((row + 3 * stride) * C + c0 + c, c0 + c, q3);
+      }
+      for (; row < N; row += stride) op(row * C + c0 + c, c0 + c, q);
+#pragma unroll
+      for (int k = 0; k < Op::Q; ++k) q[k] = (q[k] + q1[k]) + (q2[k] + q3[k]);
     }
 #pragma unroll
     for (int k = 0; k < Op::Q; ++k) red[k * RED_THREADS + tid] = q[k];
@@ -70,7 +84,7 @@ __global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(Op op, size_t N
 #pragma unroll
       for (int k = 0; k < Op::Q; ++k) {
         double s = 0.0;
-        for (int l = 0; l < nl; ++l) s += (double)red[k * RED_THREADS + l * cw + tid];
+        for (int l = 0; l < nl; ++l) s += red[k * RED_THREADS + l * cw + tid];
         partial[((size_t)blockIdx.x * Op::Q + k) * C + c0 + tid] = s;
       }
     }
@@ -220,33 +234,62 @@ hipError_t col_sum(const void* x, bool bf16, size_t N, int C, float* out, double
 // 2x2 stride-2 SAME max-pool backward: the gradient of a window goes to its first maximum in
 // row-major window order (TF MaxPoolGrad).  x [B,H,W,C] is the pool input, dy [B,Ho,Wo,C].
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 ld4(const __bf16* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(__bf16* p, float4 v) {
+  p[0] = static_cast<__bf16>(v.x); p[1] = static_cast<__bf16>(v.y); p[2] = static_cast<__bf16>(v.z); p[3] = static_cast<__bf16>(v.w);
+}
+// one thread = one pooling window x four channels: the window's (up to) four inputs are read once, 16 bytes each (round 4: one thread per INPUT
+// element, each re-deriving its window's maximum from four scalar loads: 1.65 TB/s)
 template <class T>
 __global__ void max_pool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int H, int W,
                                     int C, int Ho, int Wo, size_t total) {
+  const int C4 = C >> 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = i % C;
-    size_t r = i / C;
-    const int ix = r % W; r /= W;
-    const int iy = r % H;
-    const size_t b = r / H;
-    const int oy = iy >> 1, ox = ix >> 1;
+    const int c = (int)(i % C4) * 4;
+    size_t r = i / C4;
+    const int ox = r % Wo; r /= Wo;
+    const int oy = r % Ho;
+    const size_t b = r / Ho;
     const T* xb = x + b * (size_t)H * W * C;
-    int best = -1;
-    float bv = 0.f;
+    T* db = dx + b * (size_t)H * W * C;
+    float4 v[4];
+    bool in[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int yy = 2 * oy + (k >> 1), xx = 2 * ox + (k & 1);
-      if (yy < H && xx < W) {
-        const float v = static_cast<float>(xb[((size_t)yy * W + xx) * C + c]);
-        if (best < 0 || v > bv) { best = k; bv = v; }
+      in[k] = yy < H && xx < W;
+      v[k] = in[k] ? ld4(xb + ((size_t)yy * W + xx) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float4 g = ld4(dy + ((b * Ho + oy) * Wo + ox) * C + c);
+    // first maximum in row-major window order, per channel (k = 0 is always inside the map)
+    int bx = 0, by = 0, bz = 0, bw = 0;
+    float mx = v[0].x, my = v[0].y, mz = v[0].z, mw = v[0].w;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      if (in[k]) {
+        if (v[k].x > mx) { mx = v[k].x; bx = k; }
+        if (v[k].y > my) { my = v[k].y; by = k; }
+        if (v[k].z > mz) { mz = v[k].z; bz = k; }
+        if (v[k].w > mw) { mw = v[k].w; bw = k; }
       }
     }
-    const int me = ((iy & 1) << 1) | (ix & 1);
-    dx[i] = me == best ? dy[((b * Ho + oy) * Wo + ox) * C + c] : static_cast<T>(0.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (in[k]) {
+        const int yy = 2 * oy + (k >> 1), xx = 2 * ox + (k & 1);
+        st4(db + ((size_t)yy * W + xx) * C + c, make_float4(bx == k ? g.x : 0.f, by == k ? g.y : 0.f, bz == k ? g.z : 0.f, bw == k ? g.w : 0.f));
+      }
+    }
   }
 }
 hipError_t max_pool_bwd(const void* x, const void* dy, void* dx, bool bf16, int B, int H, int W, int C, hipStream_t st) {
-  const size_t total = (size_t)B * H * W * C;
+  if (C % 4) return hipErrorInvalidValue;
+  const size_t total = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);      // windows x channel quads
   size_t g = (total + 255) / 256;
   const dim3 grid((int)(g > 65536 ? 65536 : g));
   if (bf16)
@@ -425,11 +468,13 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
 }
 __global__ void sum_partials_kernel(const double* __restrict__ partial, int n, double* __restrict__ out, int accumulate) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = accumulate ? *out : 0.0;
-    for (int i = 0; i < n; ++i) s += partial[i];
-    *out = s;
-  }
+  // one wave: lane l adds partial[l], partial[l + 64], ... then a butterfly over the lanes -- a fixed association (deterministic)
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (threadIdx.x == 0) *out = (accumulate ? *out : 0.0) + s;
 }
 // *out (+)= sum x^2 ; scratch: 1024 doubles
 hipError_t sum_squares(const float* x, size_t n, double* out, int accumulate, double* scratch, hipStream_t st) {
@@ -437,6 +482,36 @@ hipError_t sum_squares(const float* x, size_t n, double* out, int accumulate, do
   const int blocks = (int)(g < 1 ? 1 : (g > 1024 ? 1024 : g));
   hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, x, n, scratch);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, st, scratch, blocks, out, accumulate);
+  return hipGetLastError();
+}
+
+// *out = sum of x^2 over the chunks (w[k] + start[k], len[k]) with flag[k] != 0: the weight-decay term over every conv weight tensor in two
+// launches (round 4: two launches per tensor, 0.7 ms per training step).  scratch: 1024 doubles
+__global__ __launch_bounds__(256) void sumsq_chunks_kernel(float* const* __restrict__ w, const int64_t* __restrict__ start, const int* __restrict__ len,
+                                                           const int* __restrict__ flag, int nchunks, double* __restrict__ partial) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int k = blockIdx.x; k < nchunks; k += gridDim.x) {
+    if (!flag[k]) continue;
+    const float* x = w[k] + start[k];
+    const int n = len[k];
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const double v = x[i];
+      s += v * v;
+    }
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+hipError_t sum_squares_chunks(float* const* w, const int64_t* start, const int* len, const int* flag, int nchunks, double* out, double* scratch, hipStream_t st) {
+  const int blocks = nchunks < 1024 ? (nchunks < 1 ? 1 : nchunks) : 1024;
+  hipLaunchKernelGGL(sumsq_chunks_kernel, dim3(blocks), dim3(256), 0, st, w, start, len, flag, nchunks, scratch);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, st, scratch, blocks, out, 0);
   return hipGetLastError();
 }
 

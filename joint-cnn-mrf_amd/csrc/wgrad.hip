@@ -179,24 +179,44 @@ hipError_t wgrad_reduce(const float* partial, int splits, size_t n, const float*
 }
 
 // ------------------------------------------------------------------------------------------------
-// conv1: 5x5 stride-2 SAME (pad 1 before, 2 after), Cin = 3, on the sub-sampled image
-// x[:, ::sub, ::sub].  75 x Cout outputs, K = B*Ho*Wo pixels: VALU, one workgroup per strip of
-// output rows; thread -> (co, tap group); partial sums per workgroup, reduced by wgrad_reduce.
+// conv1: 5x5 stride-2 SAME (pad 1 before, 2 after), Cin = 3, on the sub-sampled image x[:, ::sub, ::sub].
+// dW[(tap, ci)][co] is a [75 x Cout <= 64] matrix, K = B*Ho*Wo output pixels.  Round 5: on v_mfma_f32_32x32x2_f32 (the exact fp32 chain; rounds 1-4
+// ran it on the vector ALU with one LDS read per multiply-add: 1.1 ms per step + 0.76 ms for the sum of its 1024 partial tiles).  A work group
+// walks strips of 64 output pixels of one output row: the 5 input rows the strip touches ([5][131][3]) and dz [64][64] go to LDS; wave w takes
+// the strip's pixels 16 w .. 16 w + 15 as 8 k-steps of the 96 x 64 tile (3 x 2 fragments: A lane = (row = (tap, ci), k = pixel), gathered from
+// the patch by a per-lane offset; B lane = (k = pixel, column = co)).  At the end the four waves' tiles are summed through LDS in wave order
+// and the work group writes ONE partial tile; wgrad_reduce_wide adds the work groups' tiles in a fixed order (double), + lmbd * w.
 // ------------------------------------------------------------------------------------------------
 constexpr int W1_PX = 64;          // output pixels per LDS strip
+constexpr int W1_XW = 2 * W1_PX + 3;
 template <class TZ>
 __global__ __launch_bounds__(256) void wgrad_conv1_kernel(const float* __restrict__ x, const TZ* __restrict__ dz,
                                                           float* __restrict__ partial, int B, int H0, int W0, int sub, int Ho, int Wo,
                                                           int Cout, int nblk) {
-  // LDS: input patch rows for one output row segment: 5 rows x (2*W1_PX + 3) px x 3 ch; dz [W1_PX][Cout<=64]
-  __shared__ float Xs[5][2 * W1_PX + 3][3];
-  __shared__ float Zs[W1_PX][64];
-  const int tid = threadIdx.x;
-  const int co = tid & 63, grp = tid >> 6;          // 4 groups share the 75 (tap, ci) rows: 19 each
-  constexpr int NJ = 19;
-  float acc[NJ];
+  constexpr int XN = 5 * W1_XW * 3, ZN = W1_PX * 64, RN = 96 * 64;
+  __shared__ float buf[(XN + ZN > RN ? XN + ZN : RN)];
+  float* Xs = buf;             // [5][131][3]
+  float* Zs = buf + XN;        // [64][64]
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // this lane's three A rows: (tap, ci) index rix = 32 mb + l31 -> offset of Xs[ky][kx][ch] (pixel 0), or invalid (rows 75..95 multiply zeros)
+  int aoff[3];
+  bool aval[3];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
+  for (int mb = 0; mb < 3; ++mb) {
+    const int rix = mb * 32 + l31;
+    aval[mb] = rix < 75;
+    const int tap = aval[mb] ? rix / 3 : 0, ch = aval[mb] ? rix - tap * 3 : 0;
+    const int ky = tap / 5, kx = tap - ky * 5;
+    aoff[mb] = (ky * W1_XW + kx) * 3 + ch;
+  }
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
   const int Hs = H0 / sub, Ws = W0 / sub;           // sub-sampled image size
   const int nseg = (Wo + W1_PX - 1) / W1_PX;
   const long nstrip = (long)B * Ho * nseg;
@@ -206,43 +226,58 @@ __global__ __launch_bounds__(256) void wgrad_conv1_kernel(const float* __restric
     const int b = (int)(row / Ho), oy = (int)(row % Ho);
     const int ox0 = seg * W1_PX;
     __syncthreads();
-    for (int idx = tid; idx < 5 * (2 * W1_PX + 3) * 3; idx += 256) {
+    for (int idx = tid; idx < XN; idx += 256) {
       const int ch = idx % 3;
       int r = idx / 3;
-      const int px = r % (2 * W1_PX + 3), ry = r / (2 * W1_PX + 3);
+      const int px = r % W1_XW, ry = r / W1_XW;
       const int iy = 2 * oy + ry - 1, ix = 2 * ox0 + px - 1;
       float v = 0.f;
       if ((unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws) v = x[(((size_t)b * H0 + (size_t)iy * sub) * W0 + (size_t)ix * sub) * 3 + ch];
-      Xs[ry][px][ch] = v;
+      Xs[idx] = v;
     }
-    for (int idx = tid; idx < W1_PX * 64; idx += 256) {
+    for (int idx = tid; idx < ZN; idx += 256) {
       const int c = idx & 63, p = idx >> 6;
       const int ox = ox0 + p;
-      Zs[p][c] = (ox < Wo && c < Cout) ? static_cast<float>(dz[(((size_t)b * Ho + oy) * Wo + ox) * Cout + c]) : 0.f;
+      Zs[idx] = (ox < Wo && c < Cout) ? static_cast<float>(dz[(((size_t)b * Ho + oy) * Wo + ox) * Cout + c]) : 0.f;
     }
     __syncthreads();
-    for (int p = 0; p < W1_PX; ++p) {
-      const float g = Zs[p][co];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int rix = grp + 4 * j;              // (tap*3 + ci) index, < 75
-        if (rix < 75) {
-          const int tap = rix / 3, ch = rix - tap * 3;
-          const int ky = tap / 5, kx = tap - ky * 5;
-          acc[j] += Xs[ky][2 * p + kx][ch] * g;
-        }
-      }
+    for (int ks = 0; ks < 8; ++ks) {
+      const int p = wid * 16 + ks * 2 + h;           // this lane's k = one output pixel of the strip
+      float a[3], bz[2];
+#pragma unroll
+      for (int mb = 0; mb < 3; ++mb) { const float v = Xs[aoff[mb] + 6 * p]; a[mb] = aval[mb] ? v : 0.f; }
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) bz[nb] = Zs[p * 64 + nb * 32 + l31];
+#pragma unroll
+      for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], bz[nb], acc[mb][nb], 0, 0, 0);
     }
   }
-  if (co < Cout) {
+  // the four waves' tiles, summed in wave order (deterministic); accumulator i of a fragment is row (i & 3) + 8 (i >> 2) + 4 h, column l31
+  float* Red = buf;            // [96][64]
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wid == w) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int rix = grp + 4 * j;
-      if (rix < 75) partial[((size_t)blockIdx.x * 75 + rix) * Cout + co] = acc[j];
+      for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int r = mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, cidx = nb * 32 + l31;
+            Red[r * 64 + cidx] = (w == 0 ? 0.f : Red[r * 64 + cidx]) + acc[mb][nb][i];
+          }
     }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 75 * 64; idx += 256) {
+    const int co = idx & 63, rix = idx >> 6;
+    if (co < Cout) partial[((size_t)blockIdx.x * 75 + rix) * Cout + co] = Red[idx];
   }
 }
-int wgrad_conv1_blocks(void) { return 1024; }
+int wgrad_conv1_blocks(void) { return 1024; }      // four work groups per CU: the strips' loads of one overlap the MFMAs of the others
 // partial: [wgrad_conv1_blocks()][5][5][3][Cout]
 hipError_t wgrad_conv1(const float* x, const void* dz, bool dz_bf16, float* partial, int B, int H0, int W0, int sub, int Cout, hipStream_t st) {
   if (Cout > 64) return hipErrorInvalidValue;
@@ -253,6 +288,24 @@ hipError_t wgrad_conv1(const float* x, const void* dz, bool dz_bf16, float* part
     hipLaunchKernelGGL(wgrad_conv1_kernel<__bf16>, dim3(nblk), dim3(256), 0, st, x, static_cast<const __bf16*>(dz), partial, B, H0, W0, sub, Ho, Wo, Cout, nblk);
   else
     hipLaunchKernelGGL(wgrad_conv1_kernel<float>, dim3(nblk), dim3(256), 0, st, x, static_cast<const float*>(dz), partial, B, H0, W0, sub, Ho, Wo, Cout, nblk);
+  return hipGetLastError();
+}
+
+// dw[i] = sum_s partial[s][i] + lmbd * w[i] for MANY partial tiles of a SMALL tensor (conv1: 512 x 4800): a work group owns 64 outputs, its four
+// waves take the tiles s = q, q + 4, ... (double sums), and the four sums are added in wave order -- a fixed association, hence deterministic
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ partial, int splits, int n, const float* __restrict__ w, float lmbd,
+                                                                float* __restrict__ dw) {
+  __shared__ double red[4][64];
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  double s = 0.0;
+  if (i < n)
+    for (int k = q; k < splits; k += 4) s += (double)partial[(size_t)k * n + i];
+  red[q][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (q == 0 && i < n) dw[i] = (float)(((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]) + lmbd * w[i];
+}
+hipError_t wgrad_reduce_wide(const float* partial, int splits, size_t n, const float* w, float lmbd, float* dw, hipStream_t st) {
+  hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, partial, splits, (int)n, w, lmbd, dw);
   return hipGetLastError();
 }
 
