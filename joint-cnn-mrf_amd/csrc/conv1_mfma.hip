@@ -23,7 +23,7 @@ constexpr int CM_T = 16;                        // conv-output patch edge
 constexpr int CM_IN = 2 * (CM_T - 1) + 5;       // 35 input rows / cols
 constexpr int CM_ROW = 112;                     // bf16 row pitch of the LDS window (35*3 = 105 -> 112)
 constexpr int CM_WQ_F4 = 5 * 2 * 64;            // packed filter: [ky][h][co] x 16 B
-namespace cfft { int persistent_grid(const void* kernel, int ntiles, int threads); }      // conv_fft.hip: work groups the chip holds at once
+namespace cfft { int persistent_grid(const void* kernel, int ntiles, int threads, int dyn_lds = 0); }      // conv_fft.hip: work groups the chip holds at once
 
 // Persistent work groups (round 3): a group stages the packed filter once and walks tiles t, t + grid, ...; the window of the NEXT tile is
 // loaded into registers (5 pixels per thread) before the MFMAs of the current one, so the global-load latency -- which bounded the

@@ -208,7 +208,7 @@ static bool sizes_of(int H, int W, int ks, Sizes* s, int circ = 0) {
 static int pad64(int c) { return (c + CB - 1) / CB * CB; }
 static int padn(int c, int n) { return (c + n - 1) / n * n; }
 
-int persistent_grid(const void* kernel, int ntiles, int threads) {
+int persistent_grid(const void* kernel, int ntiles, int threads, int dyn_lds) {
   static std::mutex mu;
   static std::map<std::pair<const void*, int>, int> cache;      // (kernel, device) -> resident work groups
   int dev = 0;
@@ -222,7 +222,7 @@ int persistent_grid(const void* kernel, int ntiles, int threads) {
   if (!resident) {
     int ncu = 256, per_cu = 0;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, (size_t)dyn_lds) != hipSuccess || per_cu < 1) per_cu = 1;
     resident = ncu * per_cu;
     std::lock_guard<std::mutex> lk(mu);
     cache[{kernel, dev}] = resident;

@@ -283,7 +283,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], uint4 (&out)[NP]) {
 
 // grid of a persistent transform kernel: exactly the work groups the chip holds at once (a larger grid would run its excess as a
 // second, mostly idle round), at most one per tile.  The residency comes from the occupancy query, cached per (kernel, device).
-int persistent_grid(const void* kernel, int ntiles, int threads);
+int persistent_grid(const void* kernel, int ntiles, int threads, int dyn_lds = 0);      // dyn_lds: the launch's dynamic LDS bytes
 
 // ---- launchers (N = transform length, one of the lengths with a Plan); a.CoutP = output channels the inverse passes transform (Cout
 // padded to 64), ldy = channel stride of the product spectra (Cout padded to the GEMM's N tile)

@@ -208,7 +208,10 @@ void prof_release_all(jcm_ctx* c, bool destroy) {
 // gradient; the filter spectra are recomputed after every update -- refresh_derived invalidates them); bf16 handles: inference only.
 bool takes_fft(jcm_ctx* c, const ConvLayer* L, int B, int H, int W) {
   if (!c->conv9_fft || c->f32_conv != 0 || (c->train && c->precision != JCM_PRECISION_F32) || (L->ks != 9 && L->ks != 5) || L->cin == 3 || !L->w_raw) return false;
-  // bf16 handles: the wide 9x9 layers only (the 5x5 layers and the logits layer are faster on their bf16 MFMA strip kernels)
+  // bf16 handles: the wide 9x9 layers only.  Round 5 measured the 5x5 layers of a bf16 handle on this route at B = 256 (HIP events per layer, same box):
+  // conv2 (64 -> 128) 1.95 / 0.53 / 0.14 ms on conv5_strip_bf16_kernel against 4.20 / 0.90 / 0.25 ms here (its 128 output channels make the fp32
+  // product spectra 6 of its 15 GB); conv3 (128 -> 256) 1.82 / 0.50 / 0.17 against 1.73 / 0.53 / 0.18 ms -- break-even, and the tower's error
+  // against the bf16-operand oracle grows from 4.3e-3 to 5.9e-3 of the logit scale: both stay on the strip kernels.
   if (c->precision == JCM_PRECISION_BF16 && (L->ks != 9 || L->thin_bf16 || L->cout % 8)) return false;
   ConvArgs a{};
   a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout;
