@@ -7,7 +7,7 @@ OUT=$PWD/gpurun_out
 PAT=$1; shift
 for grp in "$@"; do
   rm -rf $OUT/prof_x
-  rocprofv3 --pmc $grp -d $OUT/prof_x -o p -- ${PMC_CMD:-python bench.py --dtype bf16 --steps 1 --warmup 0 --cpu-images 0 --no-sm} > /dev/null 2>&1
+  rocprofv3 --pmc $grp -d $OUT/prof_x -o p -- ${PMC_CMD:-python bench.py --dtype bf16 --steps 1 --warmup 0 --cpu-reps 0 --no-sm} > /dev/null 2>&1
   python - "$PAT" $(find $OUT/prof_x -name "*.db") <<'PY'
 import sqlite3, sys
 con = sqlite3.connect(sys.argv[2])

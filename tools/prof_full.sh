@@ -8,7 +8,7 @@ NAME=$1; shift
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
-CMD="python bench.py --steps 2 --warmup 1 --cpu-images 0 $*"
+CMD="python bench.py --steps 2 --warmup 1 --cpu-reps 0 $*"
 rocprofv3 --kernel-trace --stats -d $OUT/prof_${NAME}_stats -o s -- $CMD > $OUT/${NAME}_stats.log 2>&1
 i=0
 for ctr in "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do

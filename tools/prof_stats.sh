@@ -5,7 +5,7 @@ NAME=$1; shift
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats -d $OUT/prof_${NAME}_stats -o s -- python bench.py --steps 2 --warmup 1 --cpu-images 0 $* > $OUT/${NAME}_stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/prof_${NAME}_stats -o s -- python bench.py --steps 2 --warmup 1 --cpu-reps 0 $* > $OUT/${NAME}_stats.log 2>&1
 DB=$(find $OUT/prof_${NAME}_stats -name "*.db" | head -1)
 python profiles/summarize.py stats $DB > $OUT/${NAME}_kernel_stats.csv
 # the channel GEMM launches of the last forward, in layer order
