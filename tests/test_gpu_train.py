@@ -55,10 +55,19 @@ def debug_case():
 
 
 @pytest.fixture(scope='module')
-def joint_ref(debug_case):
-    """The float64 restatement of the joint step at --debug size (shared: it costs ~25 s of CPU)."""
+def joint_refs(debug_case):
+    """The float64 and the float32 restatement of the joint step at --debug size (shared: ~25 s of CPU each, run side by side in two host threads)."""
+    from concurrent.futures import ThreadPoolExecutor
     p, x, y = debug_case
-    return T.loss_and_grads(x, y, p, use_sm=True, lmbd=0.001)
+    with ThreadPoolExecutor(2) as ex:
+        f64 = ex.submit(T.loss_and_grads, x, y, p, use_sm=True, lmbd=0.001)
+        f32 = ex.submit(T.loss_and_grads, x, y, p, use_sm=True, lmbd=0.001, dtype=torch.float32)
+        return f64.result(), f32.result()
+
+
+@pytest.fixture(scope='module')
+def joint_ref(joint_refs):
+    return joint_refs[0]
 
 
 def test_pd_only_loss_and_grads(debug_case):
@@ -78,12 +87,11 @@ def test_pd_only_loss_and_grads(debug_case):
             assert not got[k].any(), k
 
 
-def test_joint_loss_and_grads(debug_case, joint_ref):
+def test_joint_loss_and_grads(debug_case, joint_refs):
     """use_sm: loss_sm flows through the spatial model into the 81 priors / biases, bn_sm and, through
     hm_pred_pd, back into the part detector (main.py:523-531,539)."""
     p, x, y = debug_case
-    ref = joint_ref
-    ref32 = T.loss_and_grads(x, y, p, use_sm=True, lmbd=0.001, dtype=torch.float32)
+    ref, ref32 = joint_refs
     eng, tr = make_trainer(p, use_sm=True, lmbd=0.001)
     losses, _ = tr.loss_and_grads(dev(x), dev(y))
     got = tr.grads_dict()
@@ -330,8 +338,12 @@ def test_border_clipped_targets_follow_tf_gradient(debug_case):
     y2[:, 0:2, 0:2, 0] = kern[1:, 1:]            # corner: 9/16 of the mass left
     y2[:, :, :, 4] = 0
     y2[:, 58:60, 40:43, 4] = kern[:2, :]         # bottom edge: 12/16
-    ref = T.loss_and_grads(x, y2, p, use_sm=True, lmbd=0.001)
-    ref32 = T.loss_and_grads(x, y2, p, use_sm=True, lmbd=0.001, dtype=torch.float32)
+    # the float64 and the float32 restatement side by side (two host threads: torch releases the GIL inside its kernels)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(2) as ex:
+        f64 = ex.submit(T.loss_and_grads, x, y2, p, use_sm=True, lmbd=0.001)
+        f32 = ex.submit(T.loss_and_grads, x, y2, p, use_sm=True, lmbd=0.001, dtype=torch.float32)
+        ref, ref32 = f64.result(), f32.result()
     eng, tr = make_trainer(p, use_sm=True, lmbd=0.001)
     losses, _ = tr.loss_and_grads(dev(x), dev(y2))
     got = tr.grads_dict()
