@@ -231,14 +231,8 @@ def train_step(x, y, params, slots, step, lr=0.001, lmbd=0.001, use_sm=True, opt
     B = x.shape[0] // towers
     acc, infos = None, []
     cur = dict(params)
-    # the towers read the same parameters and are independent until their update ops: evaluated side by side (host threads), applied in tower order
-    if towers > 1:
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(towers) as ex:
-            results = list(ex.map(lambda t: loss_and_grads(x[t * B:(t + 1) * B], y[t * B:(t + 1) * B], params, use_sm=use_sm, lmbd=lmbd), range(towers)))
-    else:
-        results = [loss_and_grads(x[:B], y[:B], params, use_sm=use_sm, lmbd=lmbd)]
-    for r in results:
+    for t in range(towers):
+        r = loss_and_grads(x[t * B:(t + 1) * B], y[t * B:(t + 1) * B], params, use_sm=use_sm, lmbd=lmbd)
         cur.update(update_moving(cur, r['bn_stats']))
         acc = r['grads'] if acc is None else {k: acc[k] + r['grads'][k] for k in acc}
         infos.append(r)

@@ -55,19 +55,10 @@ def debug_case():
 
 
 @pytest.fixture(scope='module')
-def joint_refs(debug_case):
-    """The float64 and the float32 restatement of the joint step at --debug size (shared: ~25 s of CPU each, run side by side in two host threads)."""
-    from concurrent.futures import ThreadPoolExecutor
+def joint_ref(debug_case):
+    """The float64 restatement of the joint step at --debug size (shared: it costs ~25 s of CPU)."""
     p, x, y = debug_case
-    with ThreadPoolExecutor(2) as ex:
-        f64 = ex.submit(T.loss_and_grads, x, y, p, use_sm=True, lmbd=0.001)
-        f32 = ex.submit(T.loss_and_grads, x, y, p, use_sm=True, lmbd=0.001, dtype=torch.float32)
-        return f64.result(), f32.result()
-
-
-@pytest.fixture(scope='module')
-def joint_ref(joint_refs):
-    return joint_refs[0]
+    return T.loss_and_grads(x, y, p, use_sm=True, lmbd=0.001)
 
 
 def test_pd_only_loss_and_grads(debug_case):
@@ -87,11 +78,12 @@ def test_pd_only_loss_and_grads(debug_case):
             assert not got[k].any(), k
 
 
-def test_joint_loss_and_grads(debug_case, joint_refs):
+def test_joint_loss_and_grads(debug_case, joint_ref):
     """use_sm: loss_sm flows through the spatial model into the 81 priors / biases, bn_sm and, through
     hm_pred_pd, back into the part detector (main.py:523-531,539)."""
     p, x, y = debug_case
-    ref, ref32 = joint_refs
+    ref = joint_ref
+    ref32 = T.loss_and_grads(x, y, p, use_sm=True, lmbd=0.001, dtype=torch.float32)
     eng, tr = make_trainer(p, use_sm=True, lmbd=0.001)
     losses, _ = tr.loss_and_grads(dev(x), dev(y))
     got = tr.grads_dict()
@@ -338,12 +330,8 @@ def test_border_clipped_targets_follow_tf_gradient(debug_case):
     y2[:, 0:2, 0:2, 0] = kern[1:, 1:]            # corner: 9/16 of the mass left
     y2[:, :, :, 4] = 0
     y2[:, 58:60, 40:43, 4] = kern[:2, :]         # bottom edge: 12/16
-    # the float64 and the float32 restatement side by side (two host threads: torch releases the GIL inside its kernels)
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(2) as ex:
-        f64 = ex.submit(T.loss_and_grads, x, y2, p, use_sm=True, lmbd=0.001)
-        f32 = ex.submit(T.loss_and_grads, x, y2, p, use_sm=True, lmbd=0.001, dtype=torch.float32)
-        ref, ref32 = f64.result(), f32.result()
+    ref = T.loss_and_grads(x, y2, p, use_sm=True, lmbd=0.001)
+    ref32 = T.loss_and_grads(x, y2, p, use_sm=True, lmbd=0.001, dtype=torch.float32)
     eng, tr = make_trainer(p, use_sm=True, lmbd=0.001)
     losses, _ = tr.loss_and_grads(dev(x), dev(y2))
     got = tr.grads_dict()
@@ -474,3 +462,78 @@ def test_full_size_step_16_images_vs_golden():
         assert not bad, '\n'.join(bad)
         for k, t in gold['moving'].items():
             np.testing.assert_allclose(moving[k][t['idx']], t['val'], rtol=2e-5, atol=1e-7, err_msg=k)
+
+
+def test_gradient_ready_callback_may_call_the_library(debug_case):
+    """The gradient-ready callback (jcm_train_set_grad_callback) runs WITHOUT the per-device call lock (round 4 held it through the whole entry point,
+    so a callback that called jcm_get_tensor dead-locked): a hook that reads a parameter through the C ABI and uses a second engine inside the
+    callback returns, every trainable element is reported exactly once, and the gradients equal those of a step without a hook."""
+    from joint_cnn_mrf_amd.engine import Engine
+    p, x, y = debug_case
+    eng, tr = make_trainer(p, use_sm=True, lmbd=0.001)
+    tr.loss_and_grads(dev(x), dev(y))
+    want = tr.grads.clone()
+    other = Engine(device=0).load_params(p)
+    seen, reads = [], []
+
+    def hook(offset, count):
+        seen.append((offset, count))
+        reads.append(float(tr.get_tensor('conv6/biases', (9,)).sum()))                 # same handle, read-only entry point
+        other.spatial_softmax(torch.zeros((1, 60, 90, 9), device='cuda:0'))            # another handle's entry point on the same device
+    tr.set_ready_hook(hook)
+    tr.loss_and_grads(dev(x), dev(y))
+    tr.set_ready_hook(None)
+    other.close()
+    assert torch.equal(tr.grads, want)
+    cover = np.zeros(tr.n_elements, np.int32)
+    for o, c in seen:
+        cover[o:o + c] += 1
+    assert (cover == 1).all() and len(reads) == len(seen) > 10
+    eng.close()
+
+
+def test_window_route_follows_the_batch_and_other_map_sizes():
+    """jcm_train.hip: takes_windows() sends a wide layer to 32x32 overlap-save windows for B <= 32 and to the whole-map transform above; the other
+    geometry's filter spectra are dropped when the route flips.  conv5's weight and data gradient through jcm_train_layer_grads: B = 16 (windows),
+    B = 33 (whole map), B = 16 again on ONE handle -- the first and the third result bit-identical, the B = 33 result equal to a fresh handle's and
+    within 1e-6 of float64 sums at sampled entries; then a 48x72 map (2 x 3 windows) with and without windows against the same float64 sums."""
+    p = synth.make_pd_params(debug=False, bn='trained')
+    p.update(synth.make_sm_params(synth.synthetic_priors(), kind='init'))
+    lmbd = 0.001
+    w = np.asarray(p['conv5/weights'])
+    g = torch.Generator(device='cuda:0')
+
+    def tensors(B, H, W, seed):
+        g.manual_seed(seed)
+        x = torch.relu(torch.randn((B, H, W, 512), device='cuda:0', generator=g))
+        dz = torch.randn((B, H, W, 512), device='cuda:0', generator=g) * 1e-3
+        return x, (dz - dz.mean(dim=(0, 1, 2), keepdim=True)).contiguous()
+
+    def check(dw, dx, x, dz, seed):
+        (wi, wv), (xi, xv) = sampled_conv_grads(x.cpu().numpy(), dz.cpu().numpy(), w, lmbd, np.random.RandomState(seed), n=24)
+        dxn = dx.cpu().numpy()
+        ew = np.abs(dw[wi].astype(np.float64) - wv).max() / np.abs(dw).max()
+        ex = np.abs(np.array([dxn[i] for i in xi], np.float64) - xv).max() / np.abs(dxn).max()
+        assert ew <= 1e-6 and ex <= 1e-6, (ew, ex)
+
+    eng, tr = make_trainer(p, use_sm=True, lmbd=lmbd)
+    x16, z16 = tensors(16, 60, 90, 1)
+    x33, z33 = tensors(33, 60, 90, 2)
+    dw_a, dx_a = tr.layer_grads('conv5', x16, z16)
+    dx_a = dx_a.clone()
+    dw_b, dx_b = tr.layer_grads('conv5', x33, z33)
+    dx_b = dx_b.clone()
+    dw_c, dx_c = tr.layer_grads('conv5', x16, z16)
+    assert np.array_equal(dw_a, dw_c) and torch.equal(dx_a, dx_c)
+    check(dw_b, dx_b, x33, z33, 5)
+    xs, zs = tensors(4, 48, 72, 3)
+    dw_w, dx_w = tr.layer_grads('conv5', xs, zs)
+    check(dw_w, dx_w, xs, zs, 6)
+    eng.set_option('fft_windows', 0)
+    dw_n, dx_n = tr.layer_grads('conv5', xs, zs)
+    check(dw_n, dx_n, xs, zs, 6)
+    eng.close()
+    eng2, tr2 = make_trainer(p, use_sm=True, lmbd=lmbd)
+    dw_f, dx_f = tr2.layer_grads('conv5', x33, z33)
+    assert np.array_equal(dw_b, dw_f) and torch.equal(dx_b, dx_f)
+    eng2.close()
