@@ -160,6 +160,17 @@ def cpu_baseline(params, reps=5, batches=(1, 8), budget_s=150.0):
     nmax = max(batches)
     x, torso = synth.make_images(nmax, seed=99), synth.make_torso(nmax, seed=98)
     T.forward(x[:1], torso[:1], params, dtype=torch.float32)          # warm-up (thread pools, oneDNN primitives)
+    # torch's default of one thread per physical core is not the fastest setting on a many-core host (measured on the GPU box, 256 logical CPUs:
+    # B=8 0.33 images/s at 128 threads, 0.44 at 64, 0.47 at 32): one B=1 run per candidate, the fastest is used and reported as `cores`
+    n0, best = torch.get_num_threads(), None
+    for n in sorted({n0, min(n0, 64), min(n0, 32)}, reverse=True):
+        torch.set_num_threads(n)
+        t0 = time.time()
+        T.forward(x[:1], torso[:1], params, dtype=torch.float32)
+        dt = time.time() - t0
+        if best is None or dt < best[0]:
+            best = (dt, n)
+    torch.set_num_threads(best[1])
     t_start, per = time.time(), {}
     for b in batches:
         times = []
@@ -171,10 +182,12 @@ def cpu_baseline(params, reps=5, batches=(1, 8), budget_s=150.0):
                 break
         per['b%d' % b] = {'images_per_s': b / float(np.median(times)), 'median_s': float(np.median(times)), 'runs': len(times)}
     last = per['b%d' % batches[-1]]
-    return {'value': last['images_per_s'], 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port', **per,
+    threads = torch.get_num_threads()
+    torch.set_num_threads(n0)
+    return {'value': last['images_per_s'], 'unit': 'images/sec', 'cores': threads, 'kind': 'port', **per,
             'sample': 'B=%s synthetic 480x720 images, median of <=%d runs each after 1 warm-up, full-size network PD+SM, fp32 torch-CPU/oneDNN '
-                      'restatement (TensorFlow unavailable); value = B=%d; host has %d logical CPUs'
-                      % ('/'.join(str(b) for b in batches), reps, batches[-1], os.cpu_count())}
+                      'restatement (TensorFlow unavailable); value = B=%d; %d torch threads (fastest of the candidates tried), host has %d logical CPUs'
+                      % ('/'.join(str(b) for b in batches), reps, batches[-1], threads, os.cpu_count())}
 
 
 def resident_inputs(B, rank, dev):
