@@ -265,7 +265,8 @@ size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout, int np, in
   if (!sizes_of(H, W, ks, &s, circ)) return 0;
   return cgemm_split_w_bytes(np, s.NY * (s.NX / 2 + 1), Cin, Cout);
 }
-hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, int np, bool round_bf16, hipStream_t st, float* wscale, int circ) {
+hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, int np, bool round_bf16, hipStream_t st, float* wscale, int circ,
+                                 const float* bound_from) {
   Sizes s;
   if (!sizes_of(H, W, ks, &s, circ) || Cin % 16 || (np != 2 && np != 4 && np != 5) || (np >= 4 && !wscale) || (np == 5 && Cin % 32)) return hipErrorInvalidValue;
   const int ntl = cgemm_split_ntile(np, Cout), CoutP = padn(Cout, ntl);
@@ -273,7 +274,10 @@ hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, in
   const dim3 grid((unsigned)(((size_t)Cin / cpt * CoutP + 255) / 256), (unsigned)(s.NX / 2 + 1));
   uint4* dst = static_cast<uint4*>(wf);
   const int rb = round_bf16 ? 1 : 0;
-  if (np >= 4) {
+  if (np >= 4 && bound_from) {
+    // the bound max sum |taps| of this filter is known: the flipped, transposed filter of a data gradient has the forward filter's
+    if (hipError_t e = hipMemcpyAsync(wscale, bound_from, sizeof(float), hipMemcpyDeviceToDevice, st); e != hipSuccess) return e;
+  } else if (np >= 4) {
     if (hipError_t e = hipMemsetAsync(wscale, 0, 2 * sizeof(float), st); e != hipSuccess) return e;
     const size_t pairs = (size_t)Cin * Cout;
     hipLaunchKernelGGL(weight_bound_kernel, dim3((unsigned)((pairs + 255) / 256 > 1024 ? 1024 : (pairs + 255) / 256)), dim3(256), 0, st, w_hwio, ks * ks, pairs, rb, wscale);

@@ -300,7 +300,14 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
     }
   }
   if (!fw.valid) {
-    HIP_TRY(conv_fft_pack_weights(L->w_raw, fw.p, H, W, L->ks, L->cin, L->cout, np, c->precision == JCM_PRECISION_BF16, c->stream, fw.wscale, circ));
+    // a data gradient's pseudo-layer ("dgrad:<scope>", jcm_train.hip) holds the flipped, transposed filter of <scope>: the same set of taps per
+    // (ci, co) pair, hence the same bound -- taken from the forward spectra of the same geometry when they are valid (always, inside a step)
+    const float* bound_from = nullptr;
+    if (np >= 4 && scope.compare(0, 6, "dgrad:") == 0) {
+      auto it = c->fft_w.find(key.substr(6));
+      if (it != c->fft_w.end() && it->second.valid && it->second.wscale) bound_from = it->second.wscale;
+    }
+    HIP_TRY(conv_fft_pack_weights(L->w_raw, fw.p, H, W, L->ks, L->cin, L->cout, np, c->precision == JCM_PRECISION_BF16, c->stream, fw.wscale, circ, bound_from));
     fw.valid = true;
   }
   a.wp = fw.p;

@@ -109,7 +109,8 @@ struct Fp16Scale {
 bool conv_fft_supported(const ConvArgs& a, int ks);
 size_t conv_fft_weight_bytes(int H, int W, int ks, int Cin, int Cout, int np, int circ = 0);      // circ: H x W is the window = the transform (ConvArgs::circ)
 hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, int ks, int Cin, int Cout, int np, bool round_bf16, hipStream_t st,
-                                 float* wscale = nullptr, int circ = 0);
+                                 float* wscale = nullptr, int circ = 0,
+                                 const float* bound_from = nullptr);      // bound_from: device word holding the filter's bound already (wscale[0] of the same filter's other spectra)
 size_t conv_fft_workspace_bytes(const ConvArgs& a, int ks, int np);
 // in / out layout: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar (bf16 handles: operands are bf16 values, the arithmetic is fp32-class); g0/g1: optional events around the GEMM
 // t_in / t_next: the row-transformed tensor handed from one frequency-domain layer to the next (fp32 NHWC handles; conv_fft_fusable).

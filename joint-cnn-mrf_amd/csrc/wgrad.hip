@@ -189,14 +189,20 @@ hipError_t wgrad_reduce(const float* partial, int splits, size_t n, const float*
 // ------------------------------------------------------------------------------------------------
 constexpr int W1_PX = 64;          // output pixels per LDS strip
 constexpr int W1_XW = 2 * W1_PX + 3;
+__device__ __forceinline__ float4 w1_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 w1_ld4(const __bf16* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
 template <class TZ>
 __global__ __launch_bounds__(256) void wgrad_conv1_kernel(const float* __restrict__ x, const TZ* __restrict__ dz,
                                                           float* __restrict__ partial, int B, int H0, int W0, int sub, int Ho, int Wo,
                                                           int Cout, int nblk) {
   constexpr int XN = 5 * W1_XW * 3, ZN = W1_PX * 64, RN = 96 * 64;
-  __shared__ float buf[(XN + ZN > RN ? XN + ZN : RN)];
+  constexpr int XNP = (XN + 3) / 4 * 4;      // dz behind the patch, 16-byte aligned
+  __shared__ __attribute__((aligned(16))) float buf[(XNP + ZN > RN ? XNP + ZN : RN)];
   float* Xs = buf;             // [5][131][3]
-  float* Zs = buf + XN;        // [64][64]
+  float* Zs = buf + XNP;       // [64][64]
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   // this lane's three A rows: (tap, ci) index rix = 32 mb + l31 -> offset of Xs[ky][kx][ch] (pixel 0), or invalid (rows 75..95 multiply zeros)
@@ -225,21 +231,33 @@ __global__ __launch_bounds__(256) void wgrad_conv1_kernel(const float* __restric
     const long row = s / nseg;
     const int b = (int)(row / Ho), oy = (int)(row % Ho);
     const int ox0 = seg * W1_PX;
-    __syncthreads();
-    for (int idx = tid; idx < XN; idx += 256) {
-      const int ch = idx % 3;
-      int r = idx / 3;
+    // every load of the strip goes out before the first LDS store (a load -> store loop would wait for each load in turn: that, not the MFMAs,
+    // was 90 % of this kernel's time in its first version)
+    constexpr int KX = (XN + 255) / 256, KZ = ZN / 4 / 256;
+    float xv[KX];
+    float4 zv[KZ];
+#pragma unroll
+    for (int i = 0; i < KX; ++i) {
+      const int idx = tid + i * 256;
+      const int ch = idx % 3, r = idx / 3;
       const int px = r % W1_XW, ry = r / W1_XW;
       const int iy = 2 * oy + ry - 1, ix = 2 * ox0 + px - 1;
-      float v = 0.f;
-      if ((unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws) v = x[(((size_t)b * H0 + (size_t)iy * sub) * W0 + (size_t)ix * sub) * 3 + ch];
-      Xs[idx] = v;
+      xv[i] = 0.f;
+      if (idx < XN && (unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws) xv[i] = x[(((size_t)b * H0 + (size_t)iy * sub) * W0 + (size_t)ix * sub) * 3 + ch];
     }
-    for (int idx = tid; idx < ZN; idx += 256) {
-      const int c = idx & 63, p = idx >> 6;
+#pragma unroll
+    for (int i = 0; i < KZ; ++i) {
+      const int idx = tid + i * 256, c4 = (idx & 15) * 4, p = idx >> 4;
       const int ox = ox0 + p;
-      Zs[idx] = (ox < Wo && c < Cout) ? static_cast<float>(dz[(((size_t)b * Ho + oy) * Wo + ox) * Cout + c]) : 0.f;
+      zv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ox < Wo && c4 < Cout) zv[i] = w1_ld4(dz + (((size_t)b * Ho + oy) * Wo + ox) * Cout + c4);      // Cout % 4 == 0 (launcher)
     }
+    __syncthreads();      // every wave is done with the previous strip's LDS image
+#pragma unroll
+    for (int i = 0; i < KX; ++i)
+      if (tid + i * 256 < XN) Xs[tid + i * 256] = xv[i];
+#pragma unroll
+    for (int i = 0; i < KZ; ++i) *reinterpret_cast<float4*>(Zs + 4 * (tid + i * 256)) = zv[i];
     __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
@@ -280,7 +298,7 @@ __global__ __launch_bounds__(256) void wgrad_conv1_kernel(const float* __restric
 int wgrad_conv1_blocks(void) { return 1024; }      // four work groups per CU: the strips' loads of one overlap the MFMAs of the others
 // partial: [wgrad_conv1_blocks()][5][5][3][Cout]
 hipError_t wgrad_conv1(const float* x, const void* dz, bool dz_bf16, float* partial, int B, int H0, int W0, int sub, int Cout, hipStream_t st) {
-  if (Cout > 64) return hipErrorInvalidValue;
+  if (Cout > 64 || Cout % 4) return hipErrorInvalidValue;
   const int Hs = H0 / sub, Ws = W0 / sub;
   const int Ho = (Hs + 1) / 2, Wo = (Ws + 1) / 2;
   const int nblk = wgrad_conv1_blocks();
@@ -298,8 +316,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __r
   __shared__ double red[4][64];
   const int i = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
   double s = 0.0;
-  if (i < n)
-    for (int k = q; k < splits; k += 4) s += (double)partial[(size_t)k * n + i];
+  if (i < n) {
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;      // four loads in flight (a fixed association: deterministic)
+    int k = q;
+    for (; k + 12 < splits; k += 16) {
+      s += (double)partial[(size_t)k * n + i];
+      s1 += (double)partial[(size_t)(k + 4) * n + i];
+      s2 += (double)partial[(size_t)(k + 8) * n + i];
+      s3 += (double)partial[(size_t)(k + 12) * n + i];
+    }
+    for (; k < splits; k += 4) s += (double)partial[(size_t)k * n + i];
+    s = (s + s1) + (s2 + s3);
+  }
   red[q][threadIdx.x & 63] = s;
   __syncthreads();
   if (q == 0 && i < n) dw[i] = (float)(((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]) + lmbd * w[i];
