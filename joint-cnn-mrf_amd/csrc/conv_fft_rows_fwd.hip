@@ -109,14 +109,29 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_merge_kernel(cons
   const Raw* p1 = static_cast<const Raw*>(x1) + ((size_t)(b * H + y) * W) * CV + cblk * CQ;
   const Raw* p2 = static_cast<const Raw*>(x2) + (size_t)b * H2 * W2 * CV + cblk * CQ;
   const Raw* p3 = static_cast<const Raw*>(x3) + (size_t)b * H3 * W3 * CV + cblk * CQ;
-  auto bil = [&](const Raw* p, int Wl, Tap ty, Tap tx, int v, float (&o)[VN]) __attribute__((always_inline)) {
+  // the two source rows of each coarse map are the same for the whole tile: their base pointers are formed once, an item indexes them with 32-bit offsets
+  const Raw* r2lo = p2 + (size_t)ty2.lo * W2 * CV;
+  const Raw* r2hi = p2 + (size_t)ty2.hi * W2 * CV;
+  const Raw* r3lo = p3 + (size_t)ty3.lo * W3 * CV;
+  const Raw* r3hi = p3 + (size_t)ty3.hi * W3 * CV;
+  auto bil = [&](const Raw* rlo, const Raw* rhi, float tyt, Tap tx, int v, float (&o)[VN]) __attribute__((always_inline)) {
     float tl[VN], tr[VN], bl[VN], br[VN];
-    V::unpack(p[((size_t)ty.lo * Wl + tx.lo) * CV + v], tl);
-    V::unpack(p[((size_t)ty.lo * Wl + tx.hi) * CV + v], tr);
-    V::unpack(p[((size_t)ty.hi * Wl + tx.lo) * CV + v], bl);
-    V::unpack(p[((size_t)ty.hi * Wl + tx.hi) * CV + v], br);
+    const unsigned ilo = (unsigned)(tx.lo * CV + v), ihi = (unsigned)(tx.hi * CV + v);
+    V::unpack(rlo[ilo], tl);
+    V::unpack(rlo[ihi], tr);
+    V::unpack(rhi[ilo], bl);
+    V::unpack(rhi[ihi], br);
 #pragma unroll
-    for (int i = 0; i < VN; ++i) o[i] = lerp2(tl[i], tr[i], bl[i], br[i], tx.t, ty.t);
+    for (int i = 0; i < VN; ++i) {
+      if constexpr (BF) {
+        // bf16 handles: the merged value is rounded to bf16 below; the lerps as FMAs (2 instead of 3 instructions each -- this kernel is bound by its
+        // vector-ALU issue slots on bf16 handles).  fp32 handles keep the reference's separately rounded multiply and add.
+        const float top = fmaf(tr[i] - tl[i], tx.t, tl[i]), bot = fmaf(br[i] - bl[i], tx.t, bl[i]);
+        o[i] = fmaf(bot - top, tyt, top);
+      } else {
+        o[i] = lerp2(tl[i], tr[i], bl[i], br[i], tx.t, tyt);
+      }
+    }
   };
   for (int t = tid; t < NX * CQ; t += NTR) {
     const int x = t / CQ, v = t % CQ;
@@ -127,12 +142,12 @@ __global__ __launch_bounds__(rows_threads<NX>()) void rows_fwd_merge_kernel(cons
       float a[VN], u2[VN], u3[VN];
       V::unpack(p1[(size_t)x * CV + v], a);
       if (H2 == H && W2 == W) V::unpack(p2[((size_t)y * W + x) * CV + v], u2);
-      else bil(p2, W2, ty2, tf1_tap(x, W2, sx2), v, u2);
+      else bil(r2lo, r2hi, ty2.t, tf1_tap(x, W2, sx2), v, u2);
       if (H3 == H && W3 == W) V::unpack(p3[((size_t)y * W + x) * CV + v], u3);
-      else bil(p3, W3, ty3, tf1_tap(x, W3, sx3), v, u3);
+      else bil(r3lo, r3hi, ty3.t, tf1_tap(x, W3, sx3), v, u3);
 #pragma unroll
       for (int i = 0; i < VN; ++i) {
-        z[i] = ((a[i] + u2[i]) + u3[i]) / 3.0f;
+        z[i] = div3((a[i] + u2[i]) + u3[i]);
         if constexpr (BF) z[i] = static_cast<float>(static_cast<__bf16>(z[i]));      // the merged map of a bf16 handle is a bf16 tensor
       }
     }

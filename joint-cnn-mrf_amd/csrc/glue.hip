@@ -143,8 +143,8 @@ __global__ void upsample_merge3_kernel(const typename V4<T>::type* __restrict__ 
                                            : bilinear4<T>(x2 + b * H2 * W2 * C4 + c, W2, C4, tf1_tap(oy, H2, sy2), tf1_tap(ox, W2, sx2));
     const float4 u3 = (H3 == H && W3 == W) ? V4<T>::ld(x3 + i)
                                            : bilinear4<T>(x3 + b * H3 * W3 * C4 + c, W3, C4, tf1_tap(oy, H3, sy3), tf1_tap(ox, W3, sx3));
-    V4<T>::st(out + i, make_float4(((a.x + u2.x) + u3.x) / 3.0f, ((a.y + u2.y) + u3.y) / 3.0f,
-                                   ((a.z + u2.z) + u3.z) / 3.0f, ((a.w + u2.w) + u3.w) / 3.0f));
+    V4<T>::st(out + i, make_float4(div3((a.x + u2.x) + u3.x), div3((a.y + u2.y) + u3.y),
+                                   div3((a.z + u2.z) + u3.z), div3((a.w + u2.w) + u3.w)));
   }
 }
 
@@ -189,7 +189,7 @@ __global__ void upsample_merge3_bf16x8_kernel(const bf16x8v* __restrict__ x1, co
                                        : bilinear8(x3 + b * H3 * W3 * C8 + c, W3, C8, tf1_tap(oy, H3, sy3), tf1_tap(ox, W3, sx3));
     bf16x8v o;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = (__bf16)(((a.v[k] + u2.v[k]) + u3.v[k]) / 3.0f);
+    for (int k = 0; k < 8; ++k) o[k] = (__bf16)div3((a.v[k] + u2.v[k]) + u3.v[k]);
     out[i] = o;
   }
 }
@@ -208,7 +208,7 @@ __global__ void upsample_merge3_planar_kernel(const bf16x8v* __restrict__ x1, co
     const F8 u3 = (H3 == H && W3 == W) ? ld8(x3 + i) : bilinear8(x3 + plane * H3 * W3, W3, 1, tf1_tap((int)oy, H3, sy3), tf1_tap((int)ox, W3, sx3));
     bf16x8v o;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = (__bf16)(((a.v[k] + u2.v[k]) + u3.v[k]) / 3.0f);
+    for (int k = 0; k < 8; ++k) o[k] = (__bf16)div3((a.v[k] + u2.v[k]) + u3.v[k]);
     out[i] = o;
   }
 }
