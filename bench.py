@@ -205,7 +205,7 @@ def resident_inputs(B, rank, dev):
 def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32_conv=None, config_name=None, micro_batch=None, conv9_fft=None, fft_single=None, fft_t16=None, agree=False):
     """Time `args.steps` steps of one (dtype, batch) configuration; returns the result dict on
     rank 0 (None elsewhere).  Timed region: barrier + synchronize on both sides, max over ranks.
-    f32_conv='split': the fp32 path with its 60x90 9x9 layers on the bf16x6 split kernel (conv_split.hip).
+    f32_conv='split16': the fp32 path with its stride-1 layers on the direct fp16x3 split kernels (conv_split.hip).
     B is the rank's batch per step; jcm_forward walks it in micro-batches (256 bf16 / 64 fp32 unless `micro_batch`)."""
     eng = Engine(device=local_rank, precision=dtype, f32_conv=f32_conv, micro_batch=micro_batch, conv9_fft=conv9_fft, fft_single=fft_single, fft_t16=fft_t16).load_params(params)
     x, torso = resident_inputs(B, rank, dev)                                          # resident in HBM
@@ -288,9 +288,9 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
         achieved = flops_launch / (launch_ms * 1e-3) / 1e12 if tot_n else None
         peak = PEAK_TFLOPS['bf16' if freq_domain else dtype]     # the channel GEMM runs on the bf16 matrix cores for both handle types
         fp32_equiv = None
-        if f32_conv in ('split', 'split16') and achieved:      # the roofline of these kernels is the 16-bit matrix-core peak
+        if f32_conv == 'split16' and achieved:      # the roofline of these kernels is the 16-bit matrix-core peak
             fp32_equiv = achieved
-            achieved = achieved * (6 if f32_conv == 'split' else 3)
+            achieved = achieved * 3
             peak = PEAK_TFLOPS['bf16']
         value = world * B * args.steps / dt
         out = {
@@ -298,11 +298,10 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
             # the arithmetic the path computes in: exact fp32 MFMA chain, or fp32 operands carried as 16-bit parts
             # 'f32' alone = the exact fp32 MFMA accumulation chain; the default fp32 route carries every fp32 spectrum as two scaled fp16 parts (22 bits)
             'dtype': ((('bf16(fp16 spectra + fp16 row-transformed tensors, fft)' if fft_single is not False else 'bf16(bf16x2 spectra, fft)') if freq_domain else 'bf16') if dtype == 'bf16' else
-                      {'split': 'f32(bf16x6)', 'split16': 'f32(fp16x3)'}.get(f32_conv, 'f32(fp16x2 spectra, fft)' if freq_domain else 'f32')),
+                      {'split16': 'f32(fp16x3)'}.get(f32_conv, 'f32(fp16x2 spectra, fft)' if freq_domain else 'f32')),
             'config': {'workload': '%s: batch=%d/GPU synthetic 480x720x3, part detector%s forward + argmax, %s%s%s'
                                    % (config_name or ('configs[1]' if dtype == 'fp32' else 'configs[2]'), B, ' + spatial model' if use_sm else '',
-                                      dtype + (' operands, stride-1 layers as bf16x6 split MFMA' if f32_conv == 'split' else
-                                               ' operands, stride-1 layers as fp16x3 split MFMA' if f32_conv == 'split16' else ''),
+                                      dtype + (' operands, stride-1 layers as fp16x3 split MFMA' if f32_conv == 'split16' else ''),
                                       ', micro-batches of %d' % mb if B > mb else '',
                                       ', DEBUG filters/4' if args.debug else ''),
                        'batch_per_gpu': B, 'global_batch': world * B, 'micro_batch': min(mb, B), 'use_sm': use_sm,
@@ -315,8 +314,6 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
                                       'product per frequency of the 64 x 96 transform = 3136 per launch, LDS-DMA operand rings; achieved = executed bf16 MFMA FLOPs / GEMM time'
                                       % ('bf16' if dtype == 'bf16' and gemm['np_parts'] == 2 else 'f16', gemm['np_parts'], 'bf16' if dtype == 'bf16' and gemm['np_parts'] == 2 else 'fp16 (scaled spectra)', gemm['products'])
                                       if freq_domain else
-                                      'fp32 operands as 3 bf16 parts, 6 x bf16 MFMA 32x32x16 per k16 step, 12x32 patch x 256 ch; achieved = executed bf16 MFMA FLOPs (6 x algorithmic) against the bf16 peak'
-                                      if f32_conv == 'split' else
                                       'fp32 operands as 2 fp16 parts, 3 x fp16 MFMA 32x32x16 per k16 step, 12x32 patch x 256 ch; achieved = executed fp16 MFMA FLOPs (3 x algorithmic) against the fp16 peak'
                                       if f32_conv == 'split16' else
                                       'fp32 MFMA 32x32x2, 128-pixel strip tiles x 128 ch' if dtype == 'fp32' else
@@ -327,7 +324,7 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
                          'launch_ms': launch_ms, 'launches': tot_n, 'flops_per_launch': flops_launch},
         }
         rf = out['roofline']
-        tkey = '%s_b%d_fft%s' % (dtype, min(B, mb), '_bf16x2' if dtype == 'bf16' and fft_single is False else '') if freq_domain else '%s%s_b%d' % (dtype, '_' + f32_conv if f32_conv in ('split', 'split16') else '', min(B, mb))
+        tkey = '%s_b%d_fft%s' % (dtype, min(B, mb), '_bf16x2' if dtype == 'bf16' and fft_single is False else '') if freq_domain else '%s%s_b%d' % (dtype, '_' + f32_conv if f32_conv == 'split16' else '', min(B, mb))
         rf['traffic'], rf['traffic_source'] = pmc_traffic(tkey) if not args.debug else (None, None)
         # SURVEY 8d's yardstick beside the executed-work one: images/s x 413.19 GFLOP (the direct-convolution FLOPs of the path) / MFMA peak of the handle's type
         rf['algorithmic_frac'] = out['path_tflops'] / PEAK_TFLOPS[dtype]
@@ -440,9 +437,9 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
         scale = 16 if args.debug else 1
         # dominant training kernels: the three conv5 passes, each 229.3 GFLOP per image as a direct convolution (60x90 px, 81 taps, 512x512)
         kern = {}
-        sp = f32_conv in ('split', 'split16') and prec == 'fp32'
+        sp = f32_conv == 'split16' and prec == 'fp32'
         fd = prec == 'fp32' and not sp        # fp32 handles: all three passes in the frequency domain (conv_fft.hip, wgrad_fft.hip)
-        mult = 6 if f32_conv == 'split' else 3
+        mult = 3
         # frequency-domain passes are bound by the filter-sized spectra (F x Cin x Cout complex fp32: 6.58 GB for conv5 at 64x96), not by MFMA:
         # bytes each pass must move: W or P spectra once per producer/consumer + split activation spectra + product spectra + maps
         C5 = 512 // (4 if args.debug else 1)
@@ -475,10 +472,9 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
                'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
                'median_ms_per_step': float(np.median([evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)])),
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'dtype': 'bf16' if prec == 'bf16' else {'split': 'f32(bf16x6)', 'split16': 'f32(fp16x3)'}.get(f32_conv, 'f32(fp16x2 spectra, fft, overlap-save windows)' if fd else 'f32'), 'data': 'synthetic',
+               'dtype': 'bf16' if prec == 'bf16' else {'split16': 'f32(fp16x3)'}.get(f32_conv, 'f32(fp16x2 spectra, fft, overlap-save windows)' if fd else 'f32'), 'data': 'synthetic',
                'config': {'workload': 'configs[4]: joint training, batch=%d/GPU synthetic 480x720x3, %s%s, Adam, clip 4.0%s'
                                       % (B, ('fp32 (stride-1 layers in the frequency domain, channel products on two scaled fp16 parts per operand; conv1 on fp32 MFMA)' if fd else 'fp32 MFMA') if prec == 'fp32' else 'mixed precision: bf16 activations/gradients + bf16 MFMA, fp32 master weights / statistics / losses / spatial model / optimizer',
-                                         ' operands; forward, data and weight gradients of the stride-1 layers as bf16x6 split MFMA' if f32_conv == 'split' else
                                          ' operands; forward, data and weight gradients as fp16x3 split MFMA (gradients scaled per tensor by a power of two)' if f32_conv == 'split16' else '',
                                          ', DEBUG filters/4' if args.debug else ''),
                           'batch_per_gpu': B, 'global_batch': world * B, 'use_sm': use_sm,
@@ -492,9 +488,7 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
                                      'launch_ms': kern['wgrad:conv5']['launch_ms']} if 'wgrad:conv5' in kern else {})) if fd else
                             dict(bound='mfma', peak=PEAK_TFLOPS['bf16'] if sp else PEAK_TFLOPS[prec], unit='TFLOP/s', traffic=None,
                                  **({'kernel': ('wgrad_split_kernel<9,1> on conv5 (bf16 operands, LDS transpose reads)' if prec == 'bf16' else
-                                                'wgrad_split_kernel<9,2> on conv5 (2 fp16 parts per operand, 3 x fp16 MFMA per k16 step; achieved = executed fp16 MFMA FLOPs)'
-                                                if f32_conv == 'split16' else
-                                                'wgrad_split_kernel<9> on conv5 (3 bf16 parts per operand, 6 x bf16 MFMA 32x32x16 per k16 step; achieved = executed bf16 MFMA FLOPs)'),
+                                                'wgrad_split_kernel<9,2> on conv5 (2 fp16 parts per operand, 3 x fp16 MFMA per k16 step; achieved = executed fp16 MFMA FLOPs)'),
                                      'achieved': kern['wgrad:conv5']['achieved'], 'frac': kern['wgrad:conv5']['frac'],
                                      'launch_ms': kern['wgrad:conv5']['launch_ms']} if 'wgrad:conv5' in kern else {}))),
                'conv5_passes': kern,
