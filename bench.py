@@ -280,8 +280,10 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
                 tot_ms, tot_n = tot_ms + ms, tot_n + n
                 tot_flops32 += 8.0 * cin * cout * FFT_FREQS * mrows * n              # complex multiply-adds as real FLOPs
                 tot_flops += nprod * 8.0 * cin * cout * FFT_FREQS * mrows * n        # executed on the bf16 matrix cores
-                # activation spectra and filter spectra (2 B x np parts x re|im per complex number), product spectra (complex fp32)
-                tot_bytes += FFT_FREQS * (rows_p * cin * 4 * np_parts + cin * cout * 4 * np_parts + mrows * cout * 8) * n
+                # activation spectra and filter spectra (2 B x np parts x re|im per complex number), product spectra (complex fp32; complex fp16 on the
+                # default route of bf16 handles, whose intermediates are all 16-bit)
+                ybytes = 4 if single and fft_t16 is not False else 8
+                tot_bytes += FFT_FREQS * (rows_p * cin * 4 * np_parts + cin * cout * 4 * np_parts + mrows * cout * ybytes) * n
             gemm = {'np_parts': np_parts, 'products': nprod, 'flops32_per_launch': tot_flops32 / max(tot_n, 1), 'bytes_per_launch': tot_bytes / max(tot_n, 1)}
         launch_ms = tot_ms / max(tot_n, 1)                     # average launch duration (HIP events, launch stream)
         flops_launch = tot_flops / max(tot_n, 1)               # average algorithmic (direct kernels) / executed (split GEMM) FLOPs per launch

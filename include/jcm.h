@@ -94,7 +94,9 @@ int jcm_abi_version(void);
  * "fft_t16"  : any time, default 1 (bf16 handles with "fft_single" = 1): the row-transformed tensors between the row and the column passes of
  *              the frequency-domain route (half of the transform passes' HBM traffic) as complex fp16 in block floating point -- one power-of-two
  *              scale per (image, row, 64 channels) tile forward and per (image, kx, 64 channels) tile inverse, 11 significant bits like the
- *              spectra.  0 = complex fp32 (round 3).
+ *              spectra; and the product spectra between the channel GEMM and the inverse column pass as complex fp16 under a CONSTANT
+ *              power-of-two shift (2^-(ceil(log2 Cin) + 14): the scaled operands bound every product, so nothing can overflow and typical
+ *              entries sit fourteen binades above fp16's smallest normal number; round 5).  0 = complex fp32 for all three (round 3).
  * "sm_algo"  : any time; the pairwise convolutions of the spatial model (main.py:83-87): 3 (default) = every 120x180 transform in LDS,
  *              hand-written (sm_fused.hip; jcm_conv_mrf, the prior spectra and the training step's backward use the whole-frame
  *              kernels of sm_lds.hip); 1 = direct sliding-window kernel, the independent cross-check.  Both pass the same parity

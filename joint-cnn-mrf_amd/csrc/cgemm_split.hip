@@ -24,7 +24,8 @@
 //   * work groups b, b+8, ... share an XCD: they are given the tiles of the same frequencies, so the N-tiles that re-read an X slab
 //     (and the M-tiles that re-read a W slab) find it in that XCD's L2.
 //
-// Output: Y[f][b][co] complex fp32 (what the inverse column pass reads).  gfx950 only.
+// Output: Y[f][b][co] complex fp32 (what the inverse column pass reads), or complex fp16 (Y16 below).  gfx950 only.
+#include <cmath>
 #include <type_traits>
 
 #include "kernels.h"
@@ -112,9 +113,14 @@ struct Args {
   float2* y;            // [F][B][ldy]
   int F, B, ldy, KC;    // ldy: complex numbers per row of y; KC = Cin / 16
   int mtiles, ntiles;
+  float yshift;         // Y16: the power of two the products are multiplied by on their way to fp16
 };
 
-template <class C>
+// Y16 (one-part route of bf16 handles with 16-bit intermediates): Y is written as complex FP16, 4 bytes per product instead of 8 -- half of this
+// kernel's stores and half of what the inverse column pass reads.  No data-dependent scale is needed: the operands arrive scaled into known ranges
+// (|Xs| < 2^15.5 per image, |Ws| < 2^14, conv_fft_common.h / conv_fft.hip), so |Y| < Cin 2^29.5 and the constant shift 2^-(ceil(log2 Cin) + 14) keeps
+// every component below 2^15.5 < 65504; typical entries land near 1, fourteen binades above fp16's smallest normal number.
+template <class C, bool Y16>
 __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
   static_assert(C::FM <= 2 && C::FN <= 2, "frag_load covers 1 or 2 fragments per side");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -246,6 +252,8 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
   // numbers = 256 contiguous bytes per instruction
   const int n0 = nt * NTL + wn * FN * 32 + l31;
   float2* yf = a.y + (size_t)f * a.B * a.ldy;
+  unsigned* yh = reinterpret_cast<unsigned*>(a.y) + (size_t)f * a.B * a.ldy;
+  const float ys = a.yshift;
 #pragma unroll
   for (int fm = 0; fm < FM; ++fm) {
     const int r0 = mt * MT + (wm * FM + fm) * 32 + 4 * h;
@@ -255,6 +263,12 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
       if (row < a.B) {
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn) {
+            if constexpr (Y16) {      // a half wave stores 32 complex fp16 numbers = 128 contiguous bytes
+              typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+              const h2 v{static_cast<_Float16>(accr[fm][fn][i] * ys), static_cast<_Float16>(acci[fm][fn][i] * ys)};
+              yh[(size_t)row * a.ldy + n0 + fn * 32] = __builtin_bit_cast(unsigned, v);
+              continue;
+            }
             float2* q = yf + (size_t)row * a.ldy + n0 + fn * 32;
             // fp32 handles: streaming store (the 64-row tiles are bound by the filter spectra they read; keeping Y out of the L2 measured 366 -> 361 us, the
             // logits layer's thin tile 264 -> 243 us).  The one-part bf16 form writes as much as it reads and measured 832 -> 931 us with it: plain stores.
@@ -295,12 +309,12 @@ using CfgS256 = Cfg<2, 4, 2, 2, 2, 3, true, true>;
 using CfgS128 = Cfg<2, 2, 2, 2, 2, 2, true, true>;
 using CfgS64 = Cfg<2, 1, 4, 2, 1, 2, true, true>;
 
-template <class C> hipError_t launch(const Args& a, hipStream_t st) {
+template <class C, bool Y16 = false> hipError_t launch(const Args& a, hipStream_t st) {
   static LdsAttr attr;
-  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(cgemm_split_kernel<C>), C::LDS_BYTES); e != hipSuccess) return e;
+  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(cgemm_split_kernel<C, Y16>), C::LDS_BYTES); e != hipSuccess) return e;
   const int T = a.mtiles * a.ntiles;
   const int blocks = (a.F + 7) / 8 * 8 * T;
-  hipLaunchKernelGGL(cgemm_split_kernel<C>, dim3(blocks), dim3(C::NT), C::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((cgemm_split_kernel<C, Y16>), dim3(blocks), dim3(C::NT), C::LDS_BYTES, st, a);
   return hipGetLastError();
 }
 
@@ -321,15 +335,25 @@ size_t cgemm_split_w_bytes(int np, int F, int Cin, int Cout) {
   return (size_t)F * Cin * coutp * 4 * cgemm_split_parts(np);
 }
 
-hipError_t cgemm_split(const void* xs, const void* ws, void* y, int np, int F, int B, int Cin, int Cout, int ldy, hipStream_t st) {
+// the shift of the fp16 product spectra (cgemm_split_kernel<C, Y16 = true>) and its inverse, both exact powers of two
+float cgemm_split_y16_shift(int Cin) {
+  int lg = 0;
+  while ((1 << lg) < Cin) ++lg;
+  return std::ldexp(1.0f, -(lg + 14));
+}
+
+// y16_shift: 0 = Y complex fp32; otherwise (np = 5 only) Y complex fp16 = products * y16_shift, y16_shift = cgemm_split_y16_shift(Cin)
+hipError_t cgemm_split(const void* xs, const void* ws, void* y, int np, int F, int B, int Cin, int Cout, int ldy, hipStream_t st, float y16_shift) {
   const int ntl = cgemm_split_ntile(np, Cout);
   const int ntiles = (Cout + ntl - 1) / ntl;
   const int kstep = np == 5 ? 32 : 16;      // channels per stage
   if ((np != 2 && np != 4 && np != 5) || Cin % kstep || ldy < ntiles * ntl || F < 1 || B < 1) return hipErrorInvalidValue;
   const int MT = cgemm_split_mtile(np, B, Cout);
-  cg::Args a{static_cast<const char*>(xs), static_cast<const char*>(ws), static_cast<float2*>(y), F, B, ldy, Cin / kstep, (B + MT - 1) / MT, ntiles};
+  if (y16_shift != 0.f && np != 5) return hipErrorInvalidValue;
+  cg::Args a{static_cast<const char*>(xs), static_cast<const char*>(ws), static_cast<float2*>(y), F, B, ldy, Cin / kstep, (B + MT - 1) / MT, ntiles, y16_shift};
   if ((long long)a.KC * 8 * (MT > ntl ? MT : ntl) * 16 >= (1ll << 31)) return hipErrorInvalidValue;      // buffer descriptor range (at most 8 units per row and stage)
   if (np == 2) return MT == 256 ? cg::launch<cg::CfgB256>(a, st) : MT == 128 ? cg::launch<cg::CfgB128>(a, st) : cg::launch<cg::CfgB64>(a, st);
+  if (np == 5 && y16_shift != 0.f) return MT == 256 ? cg::launch<cg::CfgS256, true>(a, st) : MT == 128 ? cg::launch<cg::CfgS128, true>(a, st) : cg::launch<cg::CfgS64, true>(a, st);
   if (np == 5) return MT == 256 ? cg::launch<cg::CfgS256>(a, st) : MT == 128 ? cg::launch<cg::CfgS128>(a, st) : cg::launch<cg::CfgS64>(a, st);
   return ntl == 32 ? cg::launch<cg::CfgH64T>(a, st) : MT == 128 ? cg::launch<cg::CfgH128>(a, st) : cg::launch<cg::CfgH64>(a, st);
 }

@@ -389,11 +389,14 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
   }
   if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
   if (g0 && hipEventRecord(g0, st) != hipSuccess) return hipErrorUnknown;
-  if (hipError_t e = cgemm_split(Xs, a.wp, Yf, np, p.F, a.B, a.Cin, a.Cout, p.ldy, st); e != hipSuccess) return e;
+  // 16-bit intermediates (bf16 handles, one-part route): the product spectra travel as complex fp16 too, under the constant shift of cgemm_split.hip
+  // (same-box A/B at 256 images: 19.1 -> 18.0 ms per step, profiles/r05_ab_y16.log)
+  const float yshift = sc.t16 ? cgemm_split_y16_shift(a.Cin) : 0.f, yinv = yshift != 0.f ? 1.0f / yshift : 0.f;
+  if (hipError_t e = cgemm_split(Xs, a.wp, Yf, np, p.F, a.B, a.Cin, a.Cout, p.ldy, st, yshift); e != hipSuccess) return e;
   if (g1 && hipEventRecord(g1, st) != hipSuccess) return hipErrorUnknown;
   ConvArgs ai = a;      // the inverse passes' view: windows keep their valid region only
   if (a0.circ) { ai.H = a0.H - 8; ai.W = a0.W - 8; }
-  if (!(fft_reg && p.inv_cb == 64 && cfft_cols_inv_reg(s.NY, ai, Yf, T, p.NXH, p.ldy, opad, st, sc.t16_inv))) cfft_cols_inv(s.NY, ai, Yf, T, twy, p.NXH, p.ldy, opad, st, sc.t16_inv);
+  if (!(fft_reg && p.inv_cb == 64 && cfft_cols_inv_reg(s.NY, ai, Yf, T, p.NXH, p.ldy, opad, st, sc.t16_inv, yinv))) cfft_cols_inv(s.NY, ai, Yf, T, twy, p.NXH, p.ldy, opad, st, sc.t16_inv, yinv);
   if (t_next) {
     if (!(fft_reg && cfft_rows_inv_fwd_reg(s.NX, a, T, static_cast<cf*>(t_next), opad, norm, sc, st))) cfft_rows_inv_fwd(s.NX, a, T, static_cast<cf*>(t_next), twx, opad, norm, sc, st);
   } else if (!(fft_reg && cfft_rows_inv_reg(s.NX, ai, out_layout, T, opad, norm, sc, st))) {

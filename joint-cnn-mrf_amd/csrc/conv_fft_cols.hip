@@ -115,9 +115,11 @@ __global__ __launch_bounds__(colfwd_threads<NY>()) void cols_fwd_split_kernel(co
 
 // ---- columns, inverse: Yf[ky][kx][b][ldy channels] -> T[b][y][kx][c < C], y < H (row y of the output is row y + pad of the circular convolution)
 // T16: T' is written as complex fp16 in block floating point, t16[(b C/CH + cblk) NXH + kx] = 1 / (this work group's scale) (conv_fft_common.h)
-template <int NY, bool T16 = false>
+// Y16 (with T16): Yf is complex fp16 = product * 2^-k (cgemm_split.hip); yinv = 2^k goes into the tile's scale word
+template <int NY, bool T16 = false, bool Y16 = false>
 __global__ __launch_bounds__(colinv_threads<NY>()) void cols_inv_kernel(const cf* __restrict__ Yf, cf* __restrict__ T, const cf* __restrict__ twg, int B, int H, int NXH, int C, int ldy,
-                                                      int pad, float* __restrict__ t16) {
+                                                      int pad, float* __restrict__ t16, float yinv) {
+  static_assert(T16 || !Y16, "fp16 product spectra belong to the route with 16-bit row-transformed tensors");
   constexpr int CH = colblk<NY>(), CB = CH, NTC = colinv_threads<NY>();
   __shared__ cf buf[NY * CH];
   __shared__ cf tw[NY];
@@ -127,7 +129,9 @@ __global__ __launch_bounds__(colinv_threads<NY>()) void cols_inv_kernel(const cf
   twiddles<NY, NTC>(tw, twg, tid);
   for (int t = tid; t < NY * CH; t += NTC) {
     const int ky = t / CH, v = t % CH;
-    buf[t] = Yf[((size_t)(kx * NY + ky) * B + b) * ldy + cblk * CB + v];
+    const size_t src = ((size_t)(kx * NY + ky) * B + b) * ldy + cblk * CB + v;
+    if constexpr (Y16) buf[t] = unpack_h2(reinterpret_cast<const unsigned*>(Yf)[src], 1.f);
+    else buf[t] = Yf[src];
   }
   __syncthreads();
   fft<NY, 1, CH, NTC>(buf, tw, tid);
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(colinv_threads<NY>()) void cols_inv_kernel(const cf
       const int t = tid + i * NTC, y = t / CH, v = t % CH;
       if (t < H * CH) st_stream(&dst[((size_t)(b * H + y) * NXH + kx) * C + cblk * CB + v], pack_h2(val[i].x * s, val[i].y * s));
     }
-    if (tid == 0) t16[((size_t)b * (C / CB) + cblk) * NXH + kx] = 1.0f / s;
+    if (tid == 0) t16[((size_t)b * (C / CB) + cblk) * NXH + kx] = Y16 ? (1.0f / s) * yinv : 1.0f / s;
   } else {
     for (int t = tid; t < H * CH; t += NTC) {
       const int y = t / CH, v = t % CH;
@@ -193,10 +197,11 @@ template <int NY> static hipError_t launch_cols_fwd(const ConvArgs& a, int np, c
   return hipSuccess;
 }
 // a.CoutP = output channels the inverse passes transform (Cout padded to 64); ldy = channel stride of Yf (Cout padded to the GEMM's N tile)
-template <int NY> static void launch_cols_inv(const ConvArgs& a, const cf* Yf, cf* T, const cf* tw, int NXH, int ldy, int pad, hipStream_t st, float* t16) {
+template <int NY> static void launch_cols_inv(const ConvArgs& a, const cf* Yf, cf* T, const cf* tw, int NXH, int ldy, int pad, hipStream_t st, float* t16, float y16_inv) {
   const dim3 grid(a.B * NXH * (a.CoutP / colblk<NY>())), blk(colinv_threads<NY>());
-  if (t16) hipLaunchKernelGGL((cols_inv_kernel<NY, true>), grid, blk, 0, st, Yf, T, tw, a.B, a.H, NXH, a.CoutP, ldy, pad, t16);
-  else hipLaunchKernelGGL((cols_inv_kernel<NY, false>), grid, blk, 0, st, Yf, T, tw, a.B, a.H, NXH, a.CoutP, ldy, pad, nullptr);
+  if (t16 && y16_inv != 0.f) hipLaunchKernelGGL((cols_inv_kernel<NY, true, true>), grid, blk, 0, st, Yf, T, tw, a.B, a.H, NXH, a.CoutP, ldy, pad, t16, y16_inv);
+  else if (t16) hipLaunchKernelGGL((cols_inv_kernel<NY, true>), grid, blk, 0, st, Yf, T, tw, a.B, a.H, NXH, a.CoutP, ldy, pad, t16, 0.f);
+  else hipLaunchKernelGGL((cols_inv_kernel<NY, false>), grid, blk, 0, st, Yf, T, tw, a.B, a.H, NXH, a.CoutP, ldy, pad, nullptr, 0.f);
 }
 hipError_t cfft_cols_fwd(int NY, const ConvArgs& a, int np, const cf* T, void* Xs, const cf* tw, int NXH, int MT, const Fp16Scale& sc, hipStream_t st) {
   hipError_t e = hipSuccess;
@@ -205,8 +210,8 @@ hipError_t cfft_cols_fwd(int NY, const ConvArgs& a, int np, const cf* T, void* X
 #undef CALL
   return e;
 }
-void cfft_cols_inv(int NY, const ConvArgs& a, const cf* Yf, cf* T, const cf* tw, int NXH, int ldy, int pad, hipStream_t st, float* t16) {
-#define CALL(N) launch_cols_inv<N>(a, Yf, T, tw, NXH, ldy, pad, st, t16)
+void cfft_cols_inv(int NY, const ConvArgs& a, const cf* Yf, cf* T, const cf* tw, int NXH, int ldy, int pad, hipStream_t st, float* t16, float y16_inv) {
+#define CALL(N) launch_cols_inv<N>(a, Yf, T, tw, NXH, ldy, pad, st, t16, y16_inv)
   CFFT_BY_SIZE(NY, CALL)
 #undef CALL
 }

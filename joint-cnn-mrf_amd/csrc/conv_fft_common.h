@@ -292,13 +292,14 @@ int persistent_grid(const void* kernel, int ntiles, int threads, int dyn_lds = 0
 void cfft_rows_fwd(int NX, const ConvArgs& a, int layout, cf* T, const cf* tw, float* tmax, hipStream_t st, float* t16 = nullptr);
 void cfft_rows_fwd_merge(int NX, const ConvArgs& a, const FftMerge& m, int in_layout, cf* T, const cf* tw, float* tmax, hipStream_t st, float* t16 = nullptr);      // in_layout 0 / 1: NHWC fp32 / bf16
 hipError_t cfft_cols_fwd(int NY, const ConvArgs& a, int np, const cf* T, void* Xs, const cf* tw, int NXH, int MT, const Fp16Scale& sc, hipStream_t st);
-void cfft_cols_inv(int NY, const ConvArgs& a, const cf* Yf, cf* T, const cf* tw, int NXH, int ldy, int pad, hipStream_t st, float* t16 = nullptr);
+// y16_inv (with t16 only): Yf holds complex fp16 products times a power of two (cgemm_split.hip); y16_inv = its inverse.  0: complex fp32
+void cfft_cols_inv(int NY, const ConvArgs& a, const cf* Yf, cf* T, const cf* tw, int NXH, int ldy, int pad, hipStream_t st, float* t16 = nullptr, float y16_inv = 0.f);
 void cfft_rows_inv(int NX, const ConvArgs& a, int layout, const cf* T, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
 // the same pass with the transform in the registers of two threads per channel pair (conv_fft_rows_reg.hip); false: no such kernel for this case
 bool cfft_rows_inv_reg(int NX, const ConvArgs& a, int layout, const cf* T, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
 bool cfft_rows_inv_fwd_reg(int NX, const ConvArgs& a, const cf* T, cf* Tn, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
 bool cfft_rows_fwd_reg(int NX, const ConvArgs& a, int layout, cf* T, float* tmax, hipStream_t st, float* t16);
-bool cfft_cols_inv_reg(int NY, const ConvArgs& a, const cf* Yf, cf* T, int NXH, int ldy, int pad, hipStream_t st, float* t16);
+bool cfft_cols_inv_reg(int NY, const ConvArgs& a, const cf* Yf, cf* T, int NXH, int ldy, int pad, hipStream_t st, float* t16, float y16_inv = 0.f);
 void cfft_rows_inv_fwd(int NX, const ConvArgs& a, const cf* T, cf* Tn, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
 }  // namespace cfft
 }  // namespace jcm

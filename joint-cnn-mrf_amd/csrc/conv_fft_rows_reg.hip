@@ -174,9 +174,11 @@ __device__ __forceinline__ void inv_cols_rows(cf (&x)[NY]) {      // step 2 in p
   for (int k2 = 0; k2 < R2; ++k2) x[R2 * K1 + k2] = o[k2];
   if constexpr (K1 + 1 < R1) inv_cols_rows<NY, K1 + 1>(x);
 }
-template <int NY, bool T16>
+// Y16 (with T16): Yf holds complex fp16 = product * 2^-k (cgemm_split.hip); yinv = 2^k rides in the tile's scale word, so nothing is multiplied here.
+template <int NY, bool T16, bool Y16 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NY >= 64 ? 2 : 3, NY >= 64 ? 2 : 8))) void cols_inv_reg_kernel(const cf* __restrict__ Yf, void* __restrict__ T, int B, int H, int NXH, int C, int ldy,
-                                                                                              int pad, float* __restrict__ t16) {
+                                                                                              int pad, float* __restrict__ t16, float yinv) {
+  static_assert(T16 || !Y16, "fp16 product spectra belong to the route with 16-bit row-transformed tensors");
   constexpr int R1 = RPlan<NY>::R1, R2 = RPlan<NY>::R2;
   const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int c = (int)(g % C);
@@ -185,9 +187,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NY >= 64 ? 
   const int kx = (int)(bk % (unsigned)NXH), b = (int)(bk / (unsigned)NXH);
   if (b >= B) return;
   cf x[NY];
-  const cf* src = Yf + ((size_t)kx * NY * B + b) * ldy + c;
+  if constexpr (Y16) {
+    const unsigned* src = reinterpret_cast<const unsigned*>(Yf) + ((size_t)kx * NY * B + b) * ldy + c;
+    unsigned raw[NY];      // every load goes out before the first conversion (left to itself the compiler waits for each load in turn)
 #pragma unroll
-  for (int ky = 0; ky < NY; ++ky) x[ky] = src[(size_t)ky * B * ldy];
+    for (int ky = 0; ky < NY; ++ky) raw[ky] = src[(size_t)ky * B * ldy];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ky = 0; ky < NY; ++ky) x[ky] = unpack_h2(raw[ky], 1.f);
+  } else {
+    const cf* src = Yf + ((size_t)kx * NY * B + b) * ldy + c;
+#pragma unroll
+    for (int ky = 0; ky < NY; ++ky) x[ky] = src[(size_t)ky * B * ldy];
+  }
   step1<NY, 1>(x);
   inv_cols_rows<NY, 0>(x);
   float s = 1.f;
@@ -201,7 +213,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NY >= 64 ? 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     s = bfp_scale(m);
-    if ((threadIdx.x & 63) == 0) t16[((size_t)b * (C >> 6) + (c >> 6)) * NXH + kx] = 1.0f / s;
+    if ((threadIdx.x & 63) == 0) t16[((size_t)b * (C >> 6) + (c >> 6)) * NXH + kx] = Y16 ? (1.0f / s) * yinv : 1.0f / s;      // powers of two: exact
   }
 #pragma unroll
   for (int i = 0; i < NY; ++i) {
@@ -214,14 +226,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NY >= 64 ? 
   }
 }
 // true: launched (64-point columns, 64-channel tiles)
-bool cfft_cols_inv_reg(int NY, const ConvArgs& a, const cf* Yf, cf* T, int NXH, int ldy, int pad, hipStream_t st, float* t16) {
-  if (a.CoutP % 64) return false;
+bool cfft_cols_inv_reg(int NY, const ConvArgs& a, const cf* Yf, cf* T, int NXH, int ldy, int pad, hipStream_t st, float* t16, float y16_inv) {
+  if (a.CoutP % 64 || (y16_inv != 0.f && !t16)) return false;
   const size_t threads = (size_t)a.B * NXH * a.CoutP;
   const dim3 grid((unsigned)((threads + 255) / 256)), blk(256);
 #define CI_LAUNCH(N)                                                                                                                                             \
   do {                                                                                                                                                           \
-    if (t16) hipLaunchKernelGGL((cols_inv_reg_kernel<N, true>), grid, blk, 0, st, Yf, static_cast<void*>(T), a.B, a.H, NXH, a.CoutP, ldy, pad, t16);            \
-    else hipLaunchKernelGGL((cols_inv_reg_kernel<N, false>), grid, blk, 0, st, Yf, static_cast<void*>(T), a.B, a.H, NXH, a.CoutP, ldy, pad, nullptr);          \
+    if (t16 && y16_inv != 0.f) hipLaunchKernelGGL((cols_inv_reg_kernel<N, true, true>), grid, blk, 0, st, Yf, static_cast<void*>(T), a.B, a.H, NXH, a.CoutP, ldy, pad, t16, y16_inv); \
+    else if (t16) hipLaunchKernelGGL((cols_inv_reg_kernel<N, true>), grid, blk, 0, st, Yf, static_cast<void*>(T), a.B, a.H, NXH, a.CoutP, ldy, pad, t16, 0.f);            \
+    else hipLaunchKernelGGL((cols_inv_reg_kernel<N, false>), grid, blk, 0, st, Yf, static_cast<void*>(T), a.B, a.H, NXH, a.CoutP, ldy, pad, nullptr, 0.f);          \
   } while (0)
   switch (NY) {      // 64: the 60 x 90 maps; 36 / 20: the half- and quarter-resolution branches; 32: the training step's overlap-save windows
     case 64: CI_LAUNCH(64); break;

@@ -145,12 +145,14 @@ size_t conv_fft_handover_bytes(const ConvArgs& a, int ks);
 // as np bf16 parts in tile-major LDS-image layout:
 //   xs[f][m-tile][Cin/16][re|im][part][k-half][MT rows][8 bf16]   (MT = cgemm_split_mtile(np, B, Cout); rows >= B are never stored)
 //   ws[f][n-tile][Cin/16][re|im][part][k-half][ntl cols][8 x 16 bit];   ntl = cgemm_split_ntile(np, Cout): 128, or 32 for Cout <= 32 on fp32 handles
-//   y [f][B][ldy] complex fp32, ldy >= Cout rounded up to whole N tiles
+//   y [f][B][ldy] complex fp32, ldy >= Cout rounded up to whole N tiles; with y16_shift != 0 (np = 5): complex FP16 = product * y16_shift, the
+//   constant power of two cgemm_split_y16_shift(Cin) under which no component can overflow (the operands' scales bound the products)
 int cgemm_split_mtile(int np, int B, int Cout);
 int cgemm_split_ntile(int np, int Cout);
 int cgemm_split_parts(int np);      // 16-bit parts per operand: 2 (np = 2: bf16, np = 4: fp16) or 1 (np = 5)
 size_t cgemm_split_w_bytes(int np, int F, int Cin, int Cout);
-hipError_t cgemm_split(const void* xs, const void* ws, void* y, int np, int F, int B, int Cin, int Cout, int ldy, hipStream_t st);
+float cgemm_split_y16_shift(int Cin);
+hipError_t cgemm_split(const void* xs, const void* ws, void* y, int np, int F, int B, int Cin, int Cout, int ldy, hipStream_t st, float y16_shift = 0.f);
 
 // ---- conv5_strip_bf16.hip : 5x5 SAME convolution in 128-channel output tiles on 768-pixel strips (bf16 in NHWC or planar, bf16 out NHWC or planar;
 // weights as packed by pack_weights_bf16); shapes: CoutP % 128 == 0, Cin % 32 == 0, Cout % 8 == 0, 8 <= W <= 191 and a window of at most 64 row parts

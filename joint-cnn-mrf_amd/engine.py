@@ -46,7 +46,7 @@ class Engine:
             self.set_conv9_fft(conv9_fft)
         if fft_single is not None:    # bf16 engines: False = two bf16 parts per operand of the channel GEMM (three products) instead of one scaled fp16 part
             self.set_option('fft_single', int(bool(fft_single)))
-        if fft_t16 is not None:       # bf16 engines: False = the row-transformed tensors of the frequency-domain route stay complex fp32 (default: fp16 in block floating point)
+        if fft_t16 is not None:       # bf16 engines: False = the row-transformed tensors and the product spectra of the frequency-domain route stay complex fp32 (default: complex fp16)
             self.set_option('fft_t16', int(bool(fft_t16)))
         if call_order is not None:    # False (debugging): this engine's calls are not ordered against other engines' on the device
             self.set_option('call_order', int(bool(call_order)))

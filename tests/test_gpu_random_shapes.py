@@ -153,6 +153,32 @@ def test_split16_is_range_free(gain):
     assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize('case', ['constructive', 'tiny', 'huge'])
+def test_bf16_fft_product_spectra_range(case):
+    """The default bf16 route writes the product spectra Y as complex FP16 under a CONSTANT power-of-two shift (cgemm_split.hip, Y16): the shift
+    comes from the bound |Y| < Cin 2^29.5 of the scaled operands, not from the data.  'constructive' drives that bound as hard as a layer can --
+    every input 1, every weight the same positive number, so all Cin * 81 * H * W terms of the DC product add up in phase -- and must neither
+    overflow (inf / NaN) nor lose the one-ulp class; 'tiny' / 'huge' inputs show that the per-image scale in front keeps the route range-free."""
+    from joint_cnn_mrf_amd.engine import Engine
+    rs = np.random.RandomState(5)
+    B, H, W, cin, cout = 2, 30, 45, 512, 128
+    if case == 'constructive':
+        p = layer_params(rs, cin, cout, 9)
+        p['c/weights'] = np.full((9, 9, cin, cout), 2.0 ** -12, np.float32)
+        x = np.ones((B, H, W, cin), np.float32)
+    else:
+        p = layer_params(rs, cin, cout, 9)
+        x = (np.maximum(rs.standard_normal((B, H, W, cin)), 0) * (1e-12 if case == 'tiny' else 1e12)).astype(np.float32)
+    refb = O.conv_layer(x.astype(np.float64), p, 9, 1, 'c', emulate='bf16')
+    eng = Engine(device=0, precision='bf16').load_params(p)
+    assert eng.conv_kernel_name('c', B, H, W).startswith('conv_fft')
+    got = eng.conv_layer(torch.as_tensor(x, device='cuda:0'), 'c', 1, n_out=cout).cpu().numpy().astype(np.float64)
+    eng.close()
+    assert np.isfinite(got).all()
+    ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(refb), 1e-300))) - 7)
+    assert (np.abs(got - refb) <= 1.001 * ulp + 1e-3 * np.abs(refb).max()).all(), float(np.abs(got - refb).max() / np.abs(refb).max())
+
+
 @pytest.mark.parametrize('seed', [101, 202, 303])
 def test_tower_more_seeds_debug_width(seed):
     """The whole tower (part detector + spatial model + arg-max) on fresh seeded weights / images / priors at --debug width,
