@@ -131,6 +131,12 @@ int jcm_finalize(jcm_handle h);
  * its bf16 result (fp32 for the last layer) is widened back. */
 int jcm_conv_layer(jcm_handle h, const char* scope, int stride, int last_layer, const float* x, int B, int H, int W,
                    float* out);
+/* conv_layer(((x1 + up(x2)) + up(x3)) / 3) (main.py:58,67,69-71: the three branches merged, then conv5), run as the tower runs it: where the
+ * layer takes the frequency-domain route its forward row pass forms the merge while it loads the rows (the merged map never reaches memory),
+ * otherwise the merge kernel runs in front of the layer.  x1 [B,H,W,Cin], x2 [B,H2,W2,Cin], x3 [B,H3,W3,Cin] -> out [B,H,W,Cout]; up() =
+ * tf.image.resize_images to H x W (TF-1.x legacy bilinear).  bf16 handles: fp32 at the boundary as for jcm_conv_layer. */
+int jcm_conv_layer_merged(jcm_handle h, const char* scope, const float* x1, const float* x2, int H2, int W2, const float* x3, int H3, int W3,
+                          int B, int H, int W, float* out);
 /* max_pool_layer(x, 2, 2) (main.py:172-174): 2x2/2 SAME. [B,H,W,C] -> [B,ceil(H/2),ceil(W/2),C] */
 int jcm_max_pool(jcm_handle h, const float* x, int B, int H, int W, int C, float* out);
 /* tf.image.resize_images(x, [OH,OW]) (main.py:51,58,60,67,89): TF-1.x legacy bilinear. */

@@ -27,6 +27,8 @@ SIGNATURES = {
     'jcm_finalize': (ctypes.c_int, [_handle]),
     'jcm_conv_layer': (ctypes.c_int, [_handle, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, _c_float_p,
                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p]),
+    'jcm_conv_layer_merged': (ctypes.c_int, [_handle, ctypes.c_char_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, _c_float_p, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p]),
     'jcm_max_pool': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p]),
     'jcm_resize_bilinear': (ctypes.c_int, [_handle, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_int, _c_float_p]),

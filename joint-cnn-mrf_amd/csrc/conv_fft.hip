@@ -381,7 +381,7 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
   static const bool fft_reg = [] { const char* e = std::getenv("JCM_FFT_REG"); return !e || std::atoi(e) != 0; }();
   if (!xs_ready) {
     if (merge && !t_in) {
-      cfft_rows_fwd_merge(s.NX, a, *merge, in_layout, T, twx, sc.tmax, st, sc.t16_fwd);
+      if (!(fft_reg && cfft_rows_fwd_merge_reg(s.NX, a, *merge, in_layout, T, sc.tmax, st, sc.t16_fwd))) cfft_rows_fwd_merge(s.NX, a, *merge, in_layout, T, twx, sc.tmax, st, sc.t16_fwd);
     } else if (!t_in) {
       if (!(fft_reg && cfft_rows_fwd_reg(s.NX, a, in_layout, T, sc.tmax, st, sc.t16_fwd))) cfft_rows_fwd(s.NX, a, in_layout, T, twx, sc.tmax, st, sc.t16_fwd);
     }

@@ -9,6 +9,7 @@
 // row.  No LDS, no barrier, no index arithmetic; all loads of a thread are in flight before the first butterfly.
 #include "conv_fft_common.h"
 #include "fft_reg.h"
+#include "resize_tf1.h"
 
 namespace jcm {
 namespace cfft {
@@ -250,13 +251,29 @@ bool cfft_cols_inv_reg(int NY, const ConvArgs& a, const cf* Yf, cf* T, int NXH, 
 // ---- rows, forward (the contract of rows_fwd_kernel<NX, 1, T16 = true>, conv_fft_rows_fwd.hip): bf16 NHWC -> T16[kx][c/16][b][y][16], complex fp16 in block floating
 // point, one scale per (image, row, 64 channels) tile.  Two threads per channel pair again; the forward transform is decimation in frequency as well, so thread h
 // produces the outputs of parity h:  X[2 m + h] = sum_{j < M} u_h[j] w_M^(j m),  u_h[j] = (z[j] + (-1)^h z[j + M]) w_NX^(j h),  z = x_c + i x_{c+1}.
-// Thread h LOADS pixels [h M, h M + M) only and swaps words with its neighbour (DPP): each pixel is fetched once.  The Hermitian split into the two channels'
+// Thread h LOADS pixels [h M, h M + M) only and swaps words with the other thread of the pair: each pixel is fetched once.  The Hermitian split into the two channels'
 // spectra pairs X[k] with X[NX - k], which has the parity of k: both live in the same thread (at a lane-selected register).  A wave is the 32 channel pairs =
 // 64 channels of one row = one block-floating-point tile: its scale is the wave's maximum (six shuffles, no barrier).
+// The forward kernels put thread 0 of a pair in lanes 0..31 and thread 1 in lanes 32..63 of the wave (the inverse kernels above: adjacent lanes): each half
+// wave then reads one contiguous 128-byte run per pixel instead of two runs interleaved lane by lane -- nothing for the plain row pass, 1.51 -> 1.15 ms for
+// the merge below with its 126 loads per thread.  The word of the other thread of the pair comes by v_permlane32_swap (lanes i and i + 32).
+__device__ __forceinline__ unsigned pair_word(unsigned w, bool odd) {
+  const auto r = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return odd ? r[0] : r[1];
+}
+// (thread h of the pair, channel pair p, row by) of a thread
+__device__ __forceinline__ void pair_coords(int CP, int& h, int& p, size_t& by) {
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const size_t q = (g >> 6) * 32;      // first pair of the wave
+  h = lane >> 5;
+  p = (int)((q + (lane & 31)) % CP);
+  by = (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(q / CP));      // the row: the same for the 64 lanes (C % 64 == 0)
+}
 template <int NX, int J>
 __device__ __forceinline__ void fwd_rows_in2(cf (&u)[NX / 2], const unsigned (&raw)[NX / 2], float sg, bool odd) {
   constexpr int M = NX / 2;
-  const unsigned oth = (unsigned)__builtin_amdgcn_mov_dpp((int)raw[J], 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]: the neighbour's pixel
+  const unsigned oth = pair_word(raw[J], odd);
   const cf a = bf16pair(raw[J]), o = bf16pair(oth);
   cf v = cf{fmaf(sg, a.x, o.x), fmaf(sg, a.y, o.y)};      // h = 0: z[J] = a, z[J + M] = o -> a + o;  h = 1: z[J] = o, z[J + M] = a -> o - a
   if constexpr (J > 0) {
@@ -285,29 +302,15 @@ __device__ __forceinline__ void fwd_rows_visit(const cf (&u)[NX / 2], bool odd, 
   f(MI, make_float4(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y), 0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x)));
   if constexpr (2 * (MI + 1) <= M) fwd_rows_visit<NX, MI + 1>(u, odd, f);
 }
+// the transform, the block-floating-point scale and the stores of one row whose pixels sit in raw[] as bf16 pairs (thread h: pixels [h M, h M + M))
 template <int NX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void rows_fwd_reg_kernel(const unsigned* __restrict__ in, uint2* __restrict__ T, int nrows, int B, int H, int W, int C,
-                                                                                              float* __restrict__ tmax, float* __restrict__ t16) {
+__device__ __forceinline__ void fwd_rows_finish(const unsigned (&raw)[NX / 2], uint2* __restrict__ T, int h, int p, int b, int y, int B, int H, int C, float* __restrict__ tmax,
+                                                float* __restrict__ t16) {
   constexpr int M = NX / 2;
-  const int CP = C >> 1;
-  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const int h = (int)(g & 1), lane = threadIdx.x & 63;
-  const int p = (int)((g >> 1) % CP);
-  const size_t by = (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)((g >> 1) / CP));      // the row: the same for the 64 lanes (C % 64 == 0)
-  if (by >= (size_t)nrows) return;
-  const int b = (int)(by / H), y = (int)(by % H);
   const bool odd = h != 0;
+  const int lane = threadIdx.x & 63;
   cf u[M];
-  {
-    const unsigned* src = in + (by * W) * CP + p;      // a word = channels (2 p, 2 p + 1) of a pixel
-    unsigned raw[M];
-#pragma unroll
-    for (int j = 0; j < M; ++j) {
-      const int n = h * M + j;
-      raw[j] = n < W ? src[(size_t)n * CP] : 0u;
-    }
-    fwd_rows_in2<NX, 0>(u, raw, odd ? -1.f : 1.f, odd);
-  }
+  fwd_rows_in2<NX, 0>(u, raw, odd ? -1.f : 1.f, odd);
   step1<M, -1>(u);
   step2_inplace<M, -1, 0>(u);
   // the tile's largest |component| (k = 2 m + h <= NX / 2 only: the thread of odd parity has one output less)
@@ -330,6 +333,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (k <= M) dst[(size_t)k * kstride] = make_uint2(pack_h2(o.x * sc, o.y * sc), pack_h2(o.z * sc, o.w * sc));
   });
 }
+template <int NX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void rows_fwd_reg_kernel(const unsigned* __restrict__ in, uint2* __restrict__ T, int nrows, int B, int H, int W, int C,
+                                                                                              float* __restrict__ tmax, float* __restrict__ t16) {
+  constexpr int M = NX / 2;
+  const int CP = C >> 1;
+  int h, p;
+  size_t by;
+  pair_coords(CP, h, p, by);
+  if (by >= (size_t)nrows) return;
+  const int b = (int)(by / H), y = (int)(by % H);
+  const unsigned* src = in + (by * W) * CP + p;      // a word = channels (2 p, 2 p + 1) of a pixel
+  unsigned raw[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    const int n = h * M + j;
+    raw[j] = n < W ? src[(size_t)n * CP] : 0u;
+  }
+  fwd_rows_finish<NX>(raw, T, h, p, b, y, B, H, C, tmax, t16);
+}
 // true: launched (96-point rows of a bf16 NHWC tensor, 16-bit T; W <= 96)
 bool cfft_rows_fwd_reg(int NX, const ConvArgs& a, int layout, cf* T, float* tmax, hipStream_t st, float* t16) {
   if (NX != 96 || layout != 1 || !t16 || a.Cin % 64 || a.W > NX) return false;
@@ -337,6 +359,123 @@ bool cfft_rows_fwd_reg(int NX, const ConvArgs& a, int layout, cf* T, float* tmax
   const size_t threads = (size_t)nrows * a.Cin;      // two threads per channel pair
   hipLaunchKernelGGL(rows_fwd_reg_kernel<96>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, static_cast<const unsigned*>(a.x), reinterpret_cast<uint2*>(T), nrows, a.B,
                      a.H, a.W, a.Cin, tmax, t16);
+  return true;
+}
+
+// ---- rows, forward, of the MERGED map x = ((x1 + up(x2)) + up(x3)) / 3 (main.py:58,67,69-70) of a bf16 handle, for the model's own geometry
+// (W x 2 W2 maps: 90 / 45 / 23 columns): the contract of rows_fwd_merge_kernel<NX, true, true> (conv_fft_rows_fwd.hip), whose generic taps -- eight
+// gathers, two tap computations and twelve lerps per element -- make it the one transform pass bound by vector-ALU issue slots (1.5 ms per 256 images at
+// 2.2 TB/s).  Here the row lives in the registers of its two threads, so the TF-1.x taps along x are COMPILE-TIME constants (UpTaps: the same float32
+// products tf1_tap() forms) and a thread fetches each coarse pixel it needs once: 48 + 2 x 25 + 2 x 14 words instead of 9 per element.  The lerp along y
+// is taken first, on the few coarse pixels, then the lerp along x per fine pixel (the other order in the generic kernel and in TF: the two differ in the
+// last fp32 bit, four orders of magnitude below the bf16 rounding that follows).  The half row of thread 1 sees other x3 taps than thread 0's: both
+// candidates are compile-time registers, one v_cndmask picks.
+template <int W, int WC> struct UpTaps {      // tf1_tap(x, WC, (float)WC / (float)W) at compile time
+  static constexpr float scale = (float)WC / (float)W;
+  static constexpr int lo(int x) { return (int)((float)x * scale); }
+  static constexpr int hi(int x) { return lo(x) + 1 < WC ? lo(x) + 1 : WC - 1; }
+  static constexpr float t(int x) { return (float)x * scale - (float)lo(x); }
+};
+template <int NX, int W, int W3> struct MergeGeom {
+  static constexpr int M = NX / 2;
+  using T3 = UpTaps<W, W3>;
+  static constexpr int base3(int h) { return T3::lo(h * M); }
+  static constexpr int span3(int h) { return T3::hi((h + 1) * M - 1 < W ? (h + 1) * M - 1 : W - 1) - base3(h) + 1; }
+  static constexpr int N3 = span3(0) > span3(1) ? span3(0) : span3(1);      // x3 pixels a thread fetches per source row
+  static constexpr int N2 = M / 2 + 1;                                        // x2 pixels (W = 2 W2: pixel j of either thread lerps locals j / 2 and j / 2 + 1)
+};
+__device__ __forceinline__ cf lerp_cf(cf a, cf b, float t) { return cf{fmaf(b.x - a.x, t, a.x), fmaf(b.y - a.y, t, a.y)}; }
+template <int NX, int W, int W3, int J>
+__device__ __forceinline__ void merge_px(unsigned (&raw)[NX / 2], const unsigned (&r1)[NX / 2], const cf (&v2)[MergeGeom<NX, W, W3>::N2], const cf (&v3)[MergeGeom<NX, W, W3>::N3], bool odd) {
+  using G = MergeGeom<NX, W, W3>;
+  using T3 = typename G::T3;
+  constexpr int M = NX / 2;
+  constexpr int n1 = M + J < W ? M + J : W - 1;      // thread 1's pixel (clamped behind the map: that word becomes 0 below)
+  // 2 W2 = W: source position n / 2 for both threads (M is even), i.e. locals J / 2 and J / 2 + 1 with weight 0 or 1/2
+  cf u2 = v2[J >> 1];
+  if constexpr (J & 1) {
+    constexpr int hi2_1 = M / 2 + (J >> 1) + 1 < W / 2 ? (J >> 1) + 1 : W / 2 - 1 - M / 2;      // thread 1: hi = min(lo + 1, W2 - 1), as a local index
+    const cf h2 = hi2_1 == (J >> 1) + 1 ? v2[(J >> 1) + 1] : cf{odd ? v2[hi2_1].x : v2[(J >> 1) + 1].x, odd ? v2[hi2_1].y : v2[(J >> 1) + 1].y};
+    u2 = lerp_cf(u2, h2, 0.5f);
+  }
+  constexpr int lo0 = T3::lo(J) - G::base3(0), hi0 = T3::hi(J) - G::base3(0), lo1 = T3::lo(n1) - G::base3(1), hi1 = T3::hi(n1) - G::base3(1);
+  static_assert(lo0 >= 0 && hi0 < G::N3 && lo1 >= 0 && hi1 < G::N3, "x3 taps inside the fetched span");
+  const cf a3 = cf{odd ? v3[lo1].x : v3[lo0].x, odd ? v3[lo1].y : v3[lo0].y}, b3 = cf{odd ? v3[hi1].x : v3[hi0].x, odd ? v3[hi1].y : v3[hi0].y};
+  const cf u3 = lerp_cf(a3, b3, odd ? T3::t(n1) : T3::t(J));
+  const cf a = bf16pair(r1[J]);
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  // (the third as one multiplication by RN(1/3): against the exact quotient it moves the bf16 rounding of one value in 2^15 -- the class of the lerp order)
+  constexpr float k3 = 0.333333343267440796f;
+  const unsigned w = __builtin_bit_cast(unsigned, bf16x2{static_cast<__bf16>(((a.x + u2.x) + u3.x) * k3), static_cast<__bf16>(((a.y + u2.y) + u3.y) * k3)});
+  raw[J] = (M + J < W || !odd) ? w : 0u;
+  if constexpr (J % 4 == 3) __builtin_amdgcn_sched_barrier(0);      // a few pixels at a time: interleaving all of them costs more registers than the thread has
+  if constexpr (J + 1 < M) merge_px<NX, W, W3, J + 1>(raw, r1, v2, v3, odd);
+}
+template <int NX, int W, int W3>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void rows_fwd_merge_reg_kernel(const unsigned* __restrict__ x1, const unsigned* __restrict__ x2, int H2,
+                                                                                                    const unsigned* __restrict__ x3, int H3, uint2* __restrict__ T, int nrows, int B, int H,
+                                                                                                    int C, float sy2, float sy3, float* __restrict__ tmax, float* __restrict__ t16) {
+  using G = MergeGeom<NX, W, W3>;
+  constexpr int M = NX / 2, W2 = W / 2, N2 = G::N2, N3 = G::N3;
+  static_assert(W == 2 * W2 && M % 2 == 0 && M <= W && W <= NX, "the x2 taps above");
+  const int CP = C >> 1;
+  int h, p;
+  size_t by;
+  pair_coords(CP, h, p, by);
+  if (by >= (size_t)nrows) return;
+  const int b = (int)(by / H), y = (int)(by % H);
+  const bool odd = h != 0;
+  const Tap ty2 = tf1_tap(y, H2, sy2), ty3 = tf1_tap(y, H3, sy3);      // the source rows: the same for the whole wave
+  unsigned r1[M], r2a[N2], r2b[N2], r3a[N3], r3b[N3];
+  {
+    // Buffer loads: ONE lane offset per source (channel pair + the half row's first column) and a SCALAR offset per pixel -- no vector address arithmetic
+    // and no address registers.  A descriptor covers one image; what a half row reads behind its row (thread 1, j >= W - M; the spare coarse columns) is
+    // the next row or, behind the image, the zeros of the range check, and is never used: the taps below are clamped at compile time.
+    const int bs = __builtin_amdgcn_readfirstlane(b), ys = __builtin_amdgcn_readfirstlane(y);
+    const auto d1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(x1) + (size_t)bs * H * W * CP, 0, H * W * CP * 4, 0x00020000);
+    const auto d2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(x2) + (size_t)bs * H2 * W2 * CP, 0, H2 * W2 * CP * 4, 0x00020000);
+    const auto d3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(x3) + (size_t)bs * H3 * W3 * CP, 0, H3 * W3 * CP * 4, 0x00020000);
+    const int cp4 = CP * 4;
+    const int o2 = (p + h * (M / 2) * CP) * 4, o3 = (p + (odd ? G::base3(1) : G::base3(0)) * CP) * 4, o1 = (p + h * M * CP) * 4;
+    const int s2a = ty2.lo * W2 * cp4, s2b = ty2.hi * W2 * cp4, s3a = ty3.lo * W3 * cp4, s3b = ty3.hi * W3 * cp4, s1 = ys * W * cp4;
+    // the coarse rows first: their conversions and the lerps along y run while the row of x1 is still on its way
+#pragma unroll
+    for (int i = 0; i < N2; ++i) {
+      r2a[i] = __builtin_amdgcn_raw_buffer_load_b32(d2, o2, s2a + i * cp4, 0);
+      r2b[i] = __builtin_amdgcn_raw_buffer_load_b32(d2, o2, s2b + i * cp4, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < N3; ++i) {
+      r3a[i] = __builtin_amdgcn_raw_buffer_load_b32(d3, o3, s3a + i * cp4, 0);
+      r3b[i] = __builtin_amdgcn_raw_buffer_load_b32(d3, o3, s3b + i * cp4, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) r1[j] = __builtin_amdgcn_raw_buffer_load_b32(d1, o1, s1 + j * cp4, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);      // every load is out before the first conversion
+  cf v2[N2], v3[N3];
+#pragma unroll
+  for (int i = 0; i < N2; ++i) {
+    v2[i] = lerp_cf(bf16pair(r2a[i]), bf16pair(r2b[i]), ty2.t);
+    if (i % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int i = 0; i < N3; ++i) {
+    v3[i] = lerp_cf(bf16pair(r3a[i]), bf16pair(r3b[i]), ty3.t);
+    if (i % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  unsigned raw[M];
+  merge_px<NX, W, W3, 0>(raw, r1, v2, v3, odd);
+  fwd_rows_finish<NX>(raw, T, h, p, b, y, B, H, C, tmax, t16);
+}
+// true: launched (the model's merge on a bf16 handle with 16-bit T: 90-column maps, x2 at half and x3 at a quarter of the width)
+bool cfft_rows_fwd_merge_reg(int NX, const ConvArgs& a, const FftMerge& m, int in_layout, cf* T, float* tmax, hipStream_t st, float* t16) {
+  if (NX != 96 || in_layout != 1 || !t16 || a.Cin % 64 || a.W != 90 || m.W2 != 45 || m.W3 != 23 || m.H2 < 1 || m.H3 < 1) return false;
+  const int nrows = a.B * a.H;
+  const size_t threads = (size_t)nrows * a.Cin;
+  hipLaunchKernelGGL((rows_fwd_merge_reg_kernel<96, 90, 23>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, static_cast<const unsigned*>(a.x), static_cast<const unsigned*>(m.x2), m.H2,
+                     static_cast<const unsigned*>(m.x3), m.H3, reinterpret_cast<uint2*>(T), nrows, a.B, a.H, a.Cin, (float)m.H2 / (float)a.H, (float)m.H3 / (float)a.H, tmax, t16);
   return true;
 }
 

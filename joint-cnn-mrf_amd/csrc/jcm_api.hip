@@ -861,6 +861,51 @@ int jcm_conv_layer(jcm_handle h, const char* scope, int stride, int last_layer, 
   });
 }
 
+// conv_layer(((x1 + up(x2)) + up(x3)) / 3) (main.py:58,67,69-71) exactly as the tower runs it: on the frequency-domain route the merge is formed by the
+// layer's forward row pass (rows_fwd_merge*), otherwise by the merge kernel in front of the layer.
+int jcm_conv_layer_merged(jcm_handle h, const char* scope, const float* x1, const float* x2, int H2, int W2, const float* x3, int H3, int W3, int B, int H, int W,
+                          float* out) {
+  JCM_TRY(check(h, true));
+  if (!scope || !x1 || !x2 || !x3 || !out || B < 1 || H < 1 || W < 1 || H2 < 1 || W2 < 1 || H3 < 1 || W3 < 1) return fail(JCM_ERR_ARG, "bad conv_layer_merged arguments");
+  DeviceGuard g(h->device);
+  CallOrder order(h);
+  jcm_ctx* c = h;
+  const ConvLayer* L = conv_of(c, scope);
+  if (!L) return fail(JCM_ERR_STATE, std::string("no conv layer '") + scope + "'");
+  if (!L->has_bn) return fail(JCM_ERR_ARG, "conv_layer_merged: a layer with BatchNorm parameters is expected (conv5)");
+  const bool bf = c->precision != JCM_PRECISION_F32;
+  if (bf && L->cin % 8) return fail(JCM_ERR_ARG, "conv_layer_merged: Cin % 8 != 0 on a bf16 handle");
+  return with_arena(c, [&] {
+    const size_t n1 = (size_t)B * H * W * L->cin, n2 = (size_t)B * H2 * W2 * L->cin, n3 = (size_t)B * H3 * W3 * L->cin, nout = (size_t)B * H * W * L->cout;
+    const void *a1 = x1, *a2 = x2, *a3 = x3;
+    void* ob = out;
+    if (bf) {      // the boundary stays fp32 NHWC (jcm_conv_layer): the three maps are rounded to bf16, the result is widened back
+      void* b1 = arena_alloc<char>(c, n1 * 2);
+      void* b2 = arena_alloc<char>(c, n2 * 2);
+      void* b3 = arena_alloc<char>(c, n3 * 2);
+      ob = arena_alloc<char>(c, nout * 2);
+      if (!c->dry) {
+        HIP_TRY(cast_pad_bf16(x1, L->cin, b1, L->cin, (size_t)B * H * W, c->stream));
+        HIP_TRY(cast_pad_bf16(x2, L->cin, b2, L->cin, (size_t)B * H2 * W2, c->stream));
+        HIP_TRY(cast_pad_bf16(x3, L->cin, b3, L->cin, (size_t)B * H3 * W3, c->stream));
+      }
+      a1 = b1; a2 = b2; a3 = b3;
+    }
+    FftMerge mg{a2, H2, W2, a3, H3, W3};
+    const void* in = a1;
+    if (takes_fft(c, L, B, H, W)) {
+      c->fft_merge = &mg;
+    } else {
+      void* merged = arena_alloc<char>(c, n1 * (bf ? 2 : 4));
+      if (!c->dry) HIP_TRY(upsample_merge3(a1, a2, H2, W2, a3, H3, W3, merged, bf, B, H, W, L->cin, c->stream));
+      in = merged;
+    }
+    JCM_TRY(run_conv(c, scope, 1, in, B, H, W, 1, ob, bf, false));
+    if (bf && !c->dry) HIP_TRY(cast_bf16_f32(ob, out, nout, c->stream));
+    return (int)JCM_OK;
+  });
+}
+
 int jcm_max_pool(jcm_handle h, const float* x, int B, int H, int W, int C, float* out) {
   JCM_TRY(check(h, false));
   if (!x || !out || B < 1 || H < 1 || W < 1 || C < 1 || C % 4) return fail(JCM_ERR_ARG, "bad max_pool arguments (C must be a multiple of 4)");

@@ -132,6 +132,19 @@ class Engine:
                                             self._p(out)), 'jcm_conv_layer(%s)' % name)
         return out
 
+    def conv_layer_merged(self, x1, x2, x3, name, n_out):
+        """conv_layer(((x1 + up(x2)) + up(x3)) / 3) (main.py:58,67,69-71), the merge formed as the tower forms it (inside the layer's forward row
+        pass on the frequency-domain route)."""
+        for t, nm in ((x1, 'x1'), (x2, 'x2'), (x3, 'x3')):
+            self._chk(t, 4, nm)
+        B, H, W, C = x1.shape
+        if x2.shape[0] != B or x3.shape[0] != B or x2.shape[3] != C or x3.shape[3] != C:
+            raise ValueError('x1, x2, x3 must share batch and channel counts')
+        out = self._new(B, H, W, n_out)
+        _lib.check(self._lib.jcm_conv_layer_merged(self._h, name.encode(), self._p(x1), self._p(x2), x2.shape[1], x2.shape[2], self._p(x3), x3.shape[1], x3.shape[2],
+                                                   B, H, W, self._p(out)), 'jcm_conv_layer_merged(%s)' % name)
+        return out
+
     def max_pool(self, x):
         """main.py:172-174."""
         self._chk(x, 4, 'x')

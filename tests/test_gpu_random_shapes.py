@@ -179,6 +179,43 @@ def test_bf16_fft_product_spectra_range(case):
     assert (np.abs(got - refb) <= 1.001 * ulp + 1e-3 * np.abs(refb).max()).all(), float(np.abs(got - refb).max() / np.abs(refb).max())
 
 
+@pytest.mark.parametrize('geom', [(2, 60, 90, 30, 45, 15, 23), (1, 32, 88, 16, 44, 8, 22), (1, 24, 40, 24, 40, 6, 10)], ids=lambda g: 'B%d_%dx%d_%dx%d_%dx%d' % g)
+def test_merged_conv_layer_vs_oracle(geom):
+    """x = (x1 + up(x2) + up(x3)) / 3 followed by conv5 (main.py:58,67,69-71) through jcm_conv_layer_merged: on the frequency-domain route the
+    merge is formed inside the layer's forward row pass.  60x90 / 30x45 / 15x23 is the model's geometry (bf16 handles: the register kernel with
+    compile-time taps, rows_fwd_merge_reg_kernel); the others take the generic kernel (one with x2 already at full size)."""
+    from joint_cnn_mrf_amd.engine import Engine
+    B, H, W, H2, W2, H3, W3 = geom
+    cin, cout = 128, 128
+    rs = np.random.RandomState(H * 100 + W)
+    p = layer_params(rs, cin, cout, 9)
+    xs = [np.maximum(rs.standard_normal((B, h, w, cin)), 0).astype(np.float32) for h, w in ((H, W), (H2, W2), (H3, W3))]
+    up = lambda t: O.resize_bilinear_tf1(t, H, W)
+    merged = (xs[0].astype(np.float64) + up(xs[1].astype(np.float64)) + up(xs[2].astype(np.float64))) / 3.0
+    ref = O.conv_layer(merged, p, 9, 1, 'c')
+    xd = [torch.as_tensor(t, device='cuda:0') for t in xs]
+    eng = Engine(device=0).load_params(p)
+    assert eng.conv_kernel_name('c', B, H, W).startswith('conv_fft')
+    got = eng.conv_layer_merged(xd[0], xd[1], xd[2], 'c', cout).cpu().numpy()
+    eng.close()
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+    # bf16 handle against the oracle in its arithmetic: bf16 maps in, the merged map rounded to bf16 (oracle.model), the layer on bf16 operands
+    xb = [O.bf16_round(t.astype(np.float64)) for t in xs]
+    mb = O.bf16_round((xb[0] + up(xb[1]) + up(xb[2])) / 3.0)
+    refb = O.conv_layer(mb, p, 9, 1, 'c', emulate='bf16')
+    eng = Engine(device=0, precision='bf16').load_params(p)
+    assert eng.conv_kernel_name('c', B, H, W).startswith('conv_fft')
+    gotb = eng.conv_layer_merged(xd[0], xd[1], xd[2], 'c', cout).cpu().numpy().astype(np.float64)
+    eng.close()
+    check_bf16_layer(gotb, refb, slack_rel=1e-3, flips=0.12, rms_rel=4e-4)
+    eng = Engine(device=0, precision='bf16', fft_single=False, fft_t16=False).load_params(p)      # the strict arm: generic merge kernel, fp32 T
+    gotb = eng.conv_layer_merged(xd[0], xd[1], xd[2], 'c', cout).cpu().numpy().astype(np.float64)
+    eng.close()
+    # (a merged value that fp32 and float64 round to different bf16 numbers -- a few per million -- moves the 81 x 128 outputs under it by 2^-8 of one
+    # term: the slack of the one-ulp bar is 2e-4 of the scale here instead of the plain layer's 1e-5)
+    check_bf16_layer(gotb, refb, slack_rel=2e-4, flips=0.03)
+
+
 @pytest.mark.parametrize('seed', [101, 202, 303])
 def test_tower_more_seeds_debug_width(seed):
     """The whole tower (part detector + spatial model + arg-max) on fresh seeded weights / images / priors at --debug width,
