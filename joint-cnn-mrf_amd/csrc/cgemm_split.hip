@@ -25,6 +25,7 @@
 //     (and the M-tiles that re-read a W slab) find it in that XCD's L2.
 //
 // Output: Y[f][b][co] complex fp32 (what the inverse column pass reads), or complex fp16 (Y16 below).  gfx950 only.
+#include <atomic>
 #include <cmath>
 #include <type_traits>
 
@@ -56,6 +57,9 @@ struct Cfg {
   static constexpr int PW = XPW + WPW;
   static constexpr int LDS_BYTES = R * STAGE * 16;
   static constexpr int NPROD = K32 ? 2 : NP == 2 ? 3 : 1;
+  // a ring that fills more than half of the LDS leaves ONE work group per CU: nothing else covers its prologue (the first stages' DMA latency) and its
+  // epilogue.  Such tiles run as persistent work groups that request the first stages of their NEXT tile before they store the current one.
+  static constexpr bool PERSIST = LDS_BYTES > 80 * 1024;
   // cache policy of the filter-spectra DMA: the fp32 handles' tiles (two fp16 parts, <= 128 rows) are bound by that stream, which is read once per launch --
   // the nontemporal hint (bit 1) keeps it from pushing the re-read activation slabs out of the L2: -1.5 % per fp32 step in a same-box A/B; the one-part
   // bf16 form measured +0.8 % with it and keeps the default
@@ -131,27 +135,25 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
   const int wm = wid / C::WN, wn = wid % C::WN;
   const int h = lane >> 5, l31 = lane & 31;
 
-  // work groups b, b+8, ... run on one XCD: they walk the tiles of frequencies xcd, xcd + 8, ... one frequency after the other
+  // work groups b, b+8, ... run on one XCD: they walk the tiles of frequencies xcd, xcd + 8, ... one frequency after the other.
+  // Persistent form: work group (xcd, s) of gridDim.x / 8 per XCD takes tiles s, s + gridDim.x / 8, ... of that list.
   const int T = a.mtiles * a.ntiles;
-  const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
-  const int f = (j / T) * 8 + xcd, t = j % T;
-  if (f >= a.F) return;
-  const int mt = t / a.ntiles, nt = t % a.ntiles;
+  const int bid = blockIdx.x, xcd = bid & 7;
+  const int jstep = C::PERSIST ? (int)(gridDim.x >> 3) : 0;
+  int j = bid >> 3;
   const int KC = a.KC;
-
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   constexpr int WBYTES = WST * 16;      // bytes of one stage of the W stream in HBM
-  const char* xg = a.xs + ((size_t)(f * a.mtiles + mt) * KC) * (size_t)(XST * 16);
-  const char* wg = a.ws + ((size_t)(f * a.ntiles + nt) * KC) * (size_t)WBYTES;
-  const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xg), 0, KC * XST * 16, 0x00020000);
-  const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wg), 0, KC * WBYTES, 0x00020000);
   const unsigned lane16 = (unsigned)lane * 16u;
+  if ((j / T) * 8 + xcd >= a.F) return;
 
   // stage g -> ring slot: the LDS image of a stage is its HBM image, X pieces first; wave w moves pieces w, w + NW, ...
   // A DMA is issued for EXISTING stages only (g < KC; the callers guard): rounds 2-3 let the look-ahead run past the last stage and relied on
   // the bounds check of the buffer descriptor ("delivers zeros into a free slot"); nothing is requested that is not used any more.  The stage
   // offset rides in the (bounds-checked) vector offset.
-  auto issue = [&](int g, int slot) __attribute__((always_inline)) {
+  auto issue = [&](const char* xg, const char* wg, int g, int slot) __attribute__((always_inline)) {
+    const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xg), 0, KC * XST * 16, 0x00020000);
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wg), 0, KC * WBYTES, 0x00020000);
     const unsigned sbase = (unsigned)(slot * STAGE * 16);
 #pragma unroll
     for (int i = 0; i < C::XPW; ++i) {
@@ -166,6 +168,14 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(smem + sbase + XST * 16 + q), 16, lane16 + (unsigned)g * (unsigned)(WST * 16) + q, 0, 0, 0);
     }
   };
+  auto x_of = [&](int f, int mt) __attribute__((always_inline)) { return a.xs + ((size_t)(f * a.mtiles + mt) * KC) * (size_t)(XST * 16); };
+  auto w_of = [&](int f, int nt) __attribute__((always_inline)) { return a.ws + ((size_t)(f * a.ntiles + nt) * KC) * (size_t)WBYTES; };
+  bool prefetched = false;      // the first R - 1 stages of this tile were requested behind the previous tile's loop
+  for (;;) {
+  const int f = (j / T) * 8 + xcd, t = j % T;
+  const int mt = t / a.ntiles, nt = t % a.ntiles;
+  const char* xrsrc = x_of(f, mt);
+  const char* wrsrc = w_of(f, nt);
 
   f32x16 accr[FM][FN], acci[FM][FN];
 #pragma unroll
@@ -175,9 +185,11 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) { accr[fm][fn][i] = 0.f; acci[fm][fn][i] = 0.f; }
 
+  if (!prefetched) {
 #pragma unroll
-  for (int s = 0; s < R - 1; ++s)
-    if (s < KC) issue(s, s);
+    for (int s = 0; s < R - 1; ++s)
+      if (s < KC) issue(xrsrc, wrsrc, s, s);
+  }
 
   // per-lane fragment addresses inside slot 0: unit (k-half h, row) of plane (re, part 0)
   unsigned xaddr = lds0 + (unsigned)(h * MT + wm * FM * 32 + l31) * 16u;
@@ -189,13 +201,14 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
     // wave is done reading slot (g-1) % R, which the DMA of stage g+R-1 now refills
     // Nothing is ever requested for a stage past the last one (see issue()): behind the last stage nothing younger is in flight.
     static_assert(R == 2 || R == 3, "the wait below counts at most one younger stage");
-    const bool last = g + 1 >= KC;
+    // (a prefetched tile: the stores of the previous tile's epilogue are younger than its first stages' DMAs and count in vmcnt too -- everything is waited for)
+    const bool last = g + 1 >= KC || (C::PERSIST && g == 0 && prefetched);
     if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"i"((R - 2) * C::PW) : "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     const int ns = slot == 0 ? R - 1 : slot - 1;
-    if (g + R - 1 < KC) issue(g + R - 1, ns);
+    if (g + R - 1 < KC) issue(xrsrc, wrsrc, g + R - 1, ns);
     f32x4 xr[2][FM], xi[2][FM], wr[2][FN], wi[2][FN];
     frag_load<C, cprod_x<C>(0), cprod_w<C>(0)>(xr[0], xi[0], wr[0], wi[0], xaddr, waddr);
     auto product = [&](auto sc) __attribute__((always_inline)) {
@@ -247,6 +260,18 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
     slot = wrap ? 0 : slot + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (nothing is in flight here any more; kept as the guard of the LDS hand-back)
+  // persistent work groups: the next tile's first stages go out now and land while this tile is stored
+  const int jn = j + jstep, fn_ = (jn / T) * 8 + xcd;
+  const bool more = C::PERSIST && fn_ < a.F;
+  if (more) {
+    __builtin_amdgcn_s_barrier();      // every wave has read its last fragments: the ring is free
+    const int tn = jn % T;
+    const char* xn = x_of(fn_, tn / a.ntiles);
+    const char* wn_ = w_of(fn_, tn % a.ntiles);
+#pragma unroll
+    for (int s = 0; s < R - 1; ++s)
+      if (s < KC) issue(xn, wn_, s, s);
+  }
 
   // ---- Y[f][b][co]: accumulator register i of a fragment is row (i&3) + 8 (i>>2) + 4 h, column l31: a half wave stores 32 complex
   // numbers = 256 contiguous bytes per instruction
@@ -287,6 +312,10 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
       }
     }
   }
+  if (!more) break;
+  j = jn;
+  prefetched = true;
+  }      // tiles of this work group
 }
 
 // tile shapes.  128 columns (32 for the thin logits layer); what varies is the M tile, the ring depth and where the W operand is split.
@@ -313,7 +342,20 @@ template <class C, bool Y16 = false> hipError_t launch(const Args& a, hipStream_
   static LdsAttr attr;
   if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(cgemm_split_kernel<C, Y16>), C::LDS_BYTES); e != hipSuccess) return e;
   const int T = a.mtiles * a.ntiles;
-  const int blocks = (a.F + 7) / 8 * 8 * T;
+  int blocks = (a.F + 7) / 8 * 8 * T;
+  if constexpr (C::PERSIST) {      // one work group per CU, whole groups of 8 (one per XCD)
+    static std::atomic<int> ncu_cache[64];
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    int ncu = ncu_cache[dev & 63].load();
+    if (!ncu) {
+      if (hipError_t e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess) return e;
+      ncu = ncu / 8 * 8;
+      if (ncu < 8) ncu = 8;
+      ncu_cache[dev & 63].store(ncu);
+    }
+    if (blocks > ncu) blocks = ncu;
+  }
   hipLaunchKernelGGL((cgemm_split_kernel<C, Y16>), dim3(blocks), dim3(C::NT), C::LDS_BYTES, st, a);
   return hipGetLastError();
 }
