@@ -115,11 +115,10 @@ __global__ __launch_bounds__(colfwd_threads<NY>()) void cols_fwd_split_kernel(co
 
 // ---- columns, inverse: Yf[ky][kx][b][ldy channels] -> T[b][y][kx][c < C], y < H (row y of the output is row y + pad of the circular convolution)
 // T16: T' is written as complex fp16 in block floating point, t16[(b C/CH + cblk) NXH + kx] = 1 / (this work group's scale) (conv_fft_common.h)
-// Y16 (with T16): Yf is complex fp16 = product * 2^-k (cgemm_split.hip); yinv = 2^k goes into the tile's scale word
-template <int NY, bool T16 = false, bool Y16 = false>
+// ... and Yf arrives as complex fp16 = product * 2^-k (cgemm_split.hip, Y16); yinv = 2^k goes into the tile's scale word
+template <int NY, bool T16 = false>
 __global__ __launch_bounds__(colinv_threads<NY>()) void cols_inv_kernel(const cf* __restrict__ Yf, cf* __restrict__ T, const cf* __restrict__ twg, int B, int H, int NXH, int C, int ldy,
                                                       int pad, float* __restrict__ t16, float yinv) {
-  static_assert(T16 || !Y16, "fp16 product spectra belong to the route with 16-bit row-transformed tensors");
   constexpr int CH = colblk<NY>(), CB = CH, NTC = colinv_threads<NY>();
   __shared__ cf buf[NY * CH];
   __shared__ cf tw[NY];
@@ -130,7 +129,7 @@ __global__ __launch_bounds__(colinv_threads<NY>()) void cols_inv_kernel(const cf
   for (int t = tid; t < NY * CH; t += NTC) {
     const int ky = t / CH, v = t % CH;
     const size_t src = ((size_t)(kx * NY + ky) * B + b) * ldy + cblk * CB + v;
-    if constexpr (Y16) buf[t] = unpack_h2(reinterpret_cast<const unsigned*>(Yf)[src], 1.f);
+    if constexpr (T16) buf[t] = unpack_h2(reinterpret_cast<const unsigned*>(Yf)[src], 1.f);
     else buf[t] = Yf[src];
   }
   __syncthreads();
@@ -156,7 +155,7 @@ __global__ __launch_bounds__(colinv_threads<NY>()) void cols_inv_kernel(const cf
       const int t = tid + i * NTC, y = t / CH, v = t % CH;
       if (t < H * CH) st_stream(&dst[((size_t)(b * H + y) * NXH + kx) * C + cblk * CB + v], pack_h2(val[i].x * s, val[i].y * s));
     }
-    if (tid == 0) t16[((size_t)b * (C / CB) + cblk) * NXH + kx] = Y16 ? (1.0f / s) * yinv : 1.0f / s;
+    if (tid == 0) t16[((size_t)b * (C / CB) + cblk) * NXH + kx] = (1.0f / s) * yinv;
   } else {
     for (int t = tid; t < H * CH; t += NTC) {
       const int y = t / CH, v = t % CH;
@@ -199,8 +198,7 @@ template <int NY> static hipError_t launch_cols_fwd(const ConvArgs& a, int np, c
 // a.CoutP = output channels the inverse passes transform (Cout padded to 64); ldy = channel stride of Yf (Cout padded to the GEMM's N tile)
 template <int NY> static void launch_cols_inv(const ConvArgs& a, const cf* Yf, cf* T, const cf* tw, int NXH, int ldy, int pad, hipStream_t st, float* t16, float y16_inv) {
   const dim3 grid(a.B * NXH * (a.CoutP / colblk<NY>())), blk(colinv_threads<NY>());
-  if (t16 && y16_inv != 0.f) hipLaunchKernelGGL((cols_inv_kernel<NY, true, true>), grid, blk, 0, st, Yf, T, tw, a.B, a.H, NXH, a.CoutP, ldy, pad, t16, y16_inv);
-  else if (t16) hipLaunchKernelGGL((cols_inv_kernel<NY, true>), grid, blk, 0, st, Yf, T, tw, a.B, a.H, NXH, a.CoutP, ldy, pad, t16, 0.f);
+  if (t16) hipLaunchKernelGGL((cols_inv_kernel<NY, true>), grid, blk, 0, st, Yf, T, tw, a.B, a.H, NXH, a.CoutP, ldy, pad, t16, y16_inv);      // (y16_inv != 0: conv_fft.hip)
   else hipLaunchKernelGGL((cols_inv_kernel<NY, false>), grid, blk, 0, st, Yf, T, tw, a.B, a.H, NXH, a.CoutP, ldy, pad, nullptr, 0.f);
 }
 hipError_t cfft_cols_fwd(int NY, const ConvArgs& a, int np, const cf* T, void* Xs, const cf* tw, int NXH, int MT, const Fp16Scale& sc, hipStream_t st) {

@@ -175,11 +175,15 @@ __device__ __forceinline__ void inv_cols_rows(cf (&x)[NY]) {      // step 2 in p
   for (int k2 = 0; k2 < R2; ++k2) x[R2 * K1 + k2] = o[k2];
   if constexpr (K1 + 1 < R1) inv_cols_rows<NY, K1 + 1>(x);
 }
-// Y16 (with T16): Yf holds complex fp16 = product * 2^-k (cgemm_split.hip); yinv = 2^k rides in the tile's scale word, so nothing is multiplied here.
-template <int NY, bool T16, bool Y16 = false>
+// T16 (bf16 handles, 16-bit intermediates): Yf holds complex FP16 = product * 2^-k (cgemm_split.hip, Y16) and T' is written as complex fp16 in block floating
+// point; yinv = 2^k rides in the tile's scale word, so nothing is multiplied here.  A complex number is 4 bytes then: the two lanes of adjacent channels
+// (c, c + 1) share their accesses -- the even lane fetches (c, c + 1) of the even ky and stores both channels of the even output rows, the odd lane the
+// odd ones, 8 bytes per lane, and they swap the halves they fetched for each other (DPP) -- half the memory instructions of one 4-byte access per lane.
+__device__ __forceinline__ unsigned lane_pair_swap(unsigned w) { return (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0xB1, 0xF, 0xF, true); }      // quad_perm [1,0,3,2]
+template <int NY, bool T16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NY >= 64 ? 2 : 3, NY >= 64 ? 2 : 8))) void cols_inv_reg_kernel(const cf* __restrict__ Yf, void* __restrict__ T, int B, int H, int NXH, int C, int ldy,
                                                                                               int pad, float* __restrict__ t16, float yinv) {
-  static_assert(T16 || !Y16, "fp16 product spectra belong to the route with 16-bit row-transformed tensors");
+  static_assert(NY % 2 == 0, "ky pairs");
   constexpr int R1 = RPlan<NY>::R1, R2 = RPlan<NY>::R2;
   const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int c = (int)(g % C);
@@ -187,15 +191,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NY >= 64 ? 
   const unsigned bk = (unsigned)__builtin_amdgcn_readfirstlane((int)(g / C));
   const int kx = (int)(bk % (unsigned)NXH), b = (int)(bk / (unsigned)NXH);
   if (b >= B) return;
+  const bool odd = (c & 1) != 0;      // = the lane's parity (C is even)
   cf x[NY];
-  if constexpr (Y16) {
-    const unsigned* src = reinterpret_cast<const unsigned*>(Yf) + ((size_t)kx * NY * B + b) * ldy + c;
-    unsigned raw[NY];      // every load goes out before the first conversion (left to itself the compiler waits for each load in turn)
+  if constexpr (T16) {
+    const uint2* src = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned*>(Yf) + ((size_t)kx * NY * B + b) * ldy + (c & ~1));      // ldy is even
+    const size_t kstep = (size_t)B * ldy / 2;
+    uint2 raw[NY / 2];      // every load goes out before the first conversion (left to itself the compiler waits for each load in turn)
 #pragma unroll
-    for (int ky = 0; ky < NY; ++ky) raw[ky] = src[(size_t)ky * B * ldy];
+    for (int i = 0; i < NY / 2; ++i) raw[i] = src[(size_t)(2 * i + (odd ? 1 : 0)) * kstep];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ky = 0; ky < NY; ++ky) x[ky] = unpack_h2(raw[ky], 1.f);
+    for (int i = 0; i < NY / 2; ++i) {
+      const unsigned keep = odd ? raw[i].y : raw[i].x, recv = lane_pair_swap(odd ? raw[i].x : raw[i].y);
+      x[2 * i] = unpack_h2(odd ? recv : keep, 1.f);
+      x[2 * i + 1] = unpack_h2(odd ? keep : recv, 1.f);
+    }
   } else {
     const cf* src = Yf + ((size_t)kx * NY * B + b) * ldy + c;
 #pragma unroll
@@ -203,7 +213,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NY >= 64 ? 
   }
   step1<NY, 1>(x);
   inv_cols_rows<NY, 0>(x);
-  float s = 1.f;
   if constexpr (T16) {
     float m = 0.f;
 #pragma unroll
@@ -213,28 +222,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NY >= 64 ? 
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    s = bfp_scale(m);
-    if ((threadIdx.x & 63) == 0) t16[((size_t)b * (C >> 6) + (c >> 6)) * NXH + kx] = Y16 ? (1.0f / s) * yinv : 1.0f / s;      // powers of two: exact
-  }
+    const float s = bfp_scale(m);
+    if ((threadIdx.x & 63) == 0) t16[((size_t)b * (C >> 6) + (c >> 6)) * NXH + kx] = (1.0f / s) * yinv;      // powers of two: exact
+    uint2* dst = reinterpret_cast<uint2*>(reinterpret_cast<unsigned*>(T) + ((size_t)b * H * NXH + kx) * C + (c & ~1));
+    const size_t ystep = (size_t)NXH * C / 2;
 #pragma unroll
-  for (int i = 0; i < NY; ++i) {
-    const int y = (i / R2) + R1 * (i % R2) - pad;
-    if (y >= 0 && y < H) {
-      const size_t o = ((size_t)(b * H + y) * NXH + kx) * C + c;
-      if constexpr (T16) st_stream(reinterpret_cast<unsigned*>(T) + o, pack_h2(x[i].x * s, x[i].y * s));
-      else st_stream(reinterpret_cast<cf*>(T) + o, x[i]);
+    for (int k = 0; k < NY; k += 2) {      // output samples X[k], X[k + 1] = rows k - pad, k + 1 - pad: the even lane stores the first, the odd lane the second
+      const int ia = R2 * (k % R1) + k / R1, ib = R2 * ((k + 1) % R1) + (k + 1) / R1;
+      const unsigned va = pack_h2(x[ia].x * s, x[ia].y * s), vb = pack_h2(x[ib].x * s, x[ib].y * s);
+      const unsigned recv = lane_pair_swap(odd ? va : vb);
+      const int y = k - pad + (odd ? 1 : 0);
+      if (y >= 0 && y < H) st_stream(dst + (size_t)y * ystep, make_uint2(odd ? recv : va, odd ? vb : recv));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      const int y = (i / R2) + R1 * (i % R2) - pad;
+      if (y >= 0 && y < H) st_stream(reinterpret_cast<cf*>(T) + ((size_t)(b * H + y) * NXH + kx) * C + c, x[i]);
     }
   }
 }
 // true: launched (64-point columns, 64-channel tiles)
 bool cfft_cols_inv_reg(int NY, const ConvArgs& a, const cf* Yf, cf* T, int NXH, int ldy, int pad, hipStream_t st, float* t16, float y16_inv) {
-  if (a.CoutP % 64 || (y16_inv != 0.f && !t16)) return false;
+  if (a.CoutP % 64 || ((y16_inv != 0.f) != (t16 != nullptr)) || (t16 && ldy % 2)) return false;      // 16-bit T' comes with fp16 product spectra
   const size_t threads = (size_t)a.B * NXH * a.CoutP;
   const dim3 grid((unsigned)((threads + 255) / 256)), blk(256);
 #define CI_LAUNCH(N)                                                                                                                                             \
   do {                                                                                                                                                           \
-    if (t16 && y16_inv != 0.f) hipLaunchKernelGGL((cols_inv_reg_kernel<N, true, true>), grid, blk, 0, st, Yf, static_cast<void*>(T), a.B, a.H, NXH, a.CoutP, ldy, pad, t16, y16_inv); \
-    else if (t16) hipLaunchKernelGGL((cols_inv_reg_kernel<N, true>), grid, blk, 0, st, Yf, static_cast<void*>(T), a.B, a.H, NXH, a.CoutP, ldy, pad, t16, 0.f);            \
+    if (t16) hipLaunchKernelGGL((cols_inv_reg_kernel<N, true>), grid, blk, 0, st, Yf, static_cast<void*>(T), a.B, a.H, NXH, a.CoutP, ldy, pad, t16, y16_inv);            \
     else hipLaunchKernelGGL((cols_inv_reg_kernel<N, false>), grid, blk, 0, st, Yf, static_cast<void*>(T), a.B, a.H, NXH, a.CoutP, ldy, pad, nullptr, 0.f);          \
   } while (0)
   switch (NY) {      // 64: the 60 x 90 maps; 36 / 20: the half- and quarter-resolution branches; 32: the training step's overlap-save windows
