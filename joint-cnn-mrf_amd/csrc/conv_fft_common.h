@@ -94,6 +94,20 @@ __device__ __forceinline__ unsigned pack_h2(float a, float b) {
 __device__ __forceinline__ cf unpack_h2(unsigned u, float s) {
   return cf{static_cast<float>(__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu))) * s, static_cast<float>(__builtin_bit_cast(_Float16, (unsigned short)(u >> 16))) * s};
 }
+// the same in ONE instruction per component: v_fma_mix_f32 reads an fp16 half of a register as an fp32 operand (f16 -> f32 is exact, the scale a power of two,
+// + 0).  _s: the scale is wave-uniform (a scalar register), _v: per thread.  The register row kernels are bound by their vector-ALU issue slots.
+__device__ __forceinline__ cf unpack_h2_mix_s(unsigned u, float s) {
+  cf r;
+  asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(r.x) : "v"(u), "s"(s));
+  asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r.y) : "v"(u), "s"(s));
+  return r;
+}
+__device__ __forceinline__ cf unpack_h2_mix_v(unsigned u, float s) {
+  cf r;
+  asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(r.x) : "v"(u), "v"(s));
+  asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r.y) : "v"(u), "v"(s));
+  return r;
+}
 // the work group's maximum, known to every thread (one barrier; red[] must not be in use by a stash of the same tile)
 template <int NTH>
 __device__ __forceinline__ float block_max_all(float m, float* red, int tid) {

@@ -25,7 +25,8 @@ using namespace fftr;
 // i.e. one radix-2 stage whose twiddle is selected per lane, then an M-point transform in registers.  Z comes from the half spectrum of the
 // channel pair (Z = Y_c + i Y_{c+1}, Hermitian extension): Z[n] and Z[n + M] = Z[NX - (M - n)] need the loaded entries n and M - n, so the
 // entries are consumed in pairs (n, M - n) and both threads load all of them (the same addresses in adjacent lanes: one request).
-template <int NX, int K1, class St>
+// ALL: every output goes to `store` (the bf16 layouts stage the whole row in LDS and test the columns when they copy it out: no range test per output here)
+template <int NX, int K1, bool ALL = false, class St>
 __device__ __forceinline__ void inv_rows_out2(const cf (&u)[NX / 2], int h, int W, int pad, St&& store) {
   constexpr int M = NX / 2, R1 = RPlan<M>::R1, R2 = RPlan<M>::R2;
   cf o[R2];
@@ -33,10 +34,10 @@ __device__ __forceinline__ void inv_rows_out2(const cf (&u)[NX / 2], int h, int 
 #pragma unroll
   for (int k2 = 0; k2 < R2; ++k2) {
     const int xo = 2 * (K1 + R1 * k2) + h - pad;      // output column of X[2 m + h], m = K1 + R1 k2
-    if (xo >= 0 && xo < W) store(K1 + R1 * k2, xo, o[k2]);
+    if (ALL || (xo >= 0 && xo < W)) store(K1 + R1 * k2, xo, o[k2]);
   }
   __builtin_amdgcn_sched_barrier(0);      // one row of step 2 and its stores at a time (the scheduler otherwise interleaves all R1 rows and spills)
-  if constexpr (K1 + 1 < R1) inv_rows_out2<NX, K1 + 1>(u, h, W, pad, store);
+  if constexpr (K1 + 1 < R1) inv_rows_out2<NX, K1 + 1, ALL>(u, h, W, pad, store);
 }
 // u[N] (and u[M - N]) of thread h from the half-spectrum entries N and M - N:  q = (Ya.re, Ya.im, Yb.re, Yb.im)
 template <int NX, int N>
@@ -89,25 +90,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NX >= 64 ? 
   const bool odd = h != 0;
   const float sg = odd ? -1.f : 1.f;
   cf u[M];
+  // Buffer loads: the row's T' is one descriptor, the entry k a SCALAR offset, the lane's channel pair the only vector offset -- no per-lane 64-bit
+  // address arithmetic (a tenth of this kernel's vector instructions when the compiler forms global addresses; the kernel is bound by their issue slots)
   if constexpr (T16) {
-    const uint2* src = reinterpret_cast<const uint2*>(T) + (by * NXH * C) / 2 + p;
+    const auto d = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(static_cast<const unsigned*>(T)) + by * NXH * C, 0, NXH * C * 4, 0x00020000);
+    const int vo = p * 8, ko = CP * 8;
     // the scale words of this wave's tile: one 64-channel block of one image (a wave is 32 channel pairs of one row, C % 64 == 0), contiguous over
     // kx and the same for all lanes: scalar loads
     const int nblk = C / sc.t16_cb;
     const float* ssrc = sc.t16_inv + ((size_t)__builtin_amdgcn_readfirstlane(b) * nblk + __builtin_amdgcn_readfirstlane(c / sc.t16_cb)) * NXH;
-    // (loads and unpacking stay interleaved: issuing all NX/2+1 loads first and converting afterwards measured 836-906 us against 679-719 us --
-    // the conversions of the first entries overlap the latency of the later loads)
+    // every load goes out first; the conversions of the first entries then overlap the latency of the later loads
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    u2 raw[NXH];
+#pragma unroll
+    for (int n = 0; 2 * n <= M; ++n) {      // in the order of use: the entries are consumed in pairs (n, M - n)
+      raw[n] = __builtin_amdgcn_raw_buffer_load_b64(d, vo, n * ko, 0);
+      if (2 * n != M) raw[M - n] = __builtin_amdgcn_raw_buffer_load_b64(d, vo, (M - n) * ko, 0);
+    }
     auto load = [&](int k) __attribute__((always_inline)) {
-      const uint2 q = src[(size_t)k * CP];
       const float s = ssrc[k];
-      const cf ya = unpack_h2(q.x, s), yb = unpack_h2(q.y, s);
+      const cf ya = unpack_h2_mix_s(raw[k][0], s), yb = unpack_h2_mix_s(raw[k][1], s);
       return make_float4(ya.x, ya.y, yb.x, yb.y);
     };
     inv_rows_load2<NX, T16, 0>(u, sg, odd, load);
   } else {
-    const float4* src = reinterpret_cast<const float4*>(T) + (by * NXH * C) / 2 + p;
-    auto load = [&](int k) __attribute__((always_inline)) { return src[(size_t)k * CP]; };      // (Ya.re, Ya.im, Yb.re, Yb.im)
-    inv_rows_load2<NX, T16, 0>(u, sg, odd, load);
+    const auto d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(static_cast<const float*>(T)) + by * NXH * C * 2, 0, NXH * C * 8, 0x00020000);
+    const int vo = p * 16, ko = CP * 16;
+    auto load = [&](int k) __attribute__((always_inline)) {      // (Ya.re, Ya.im, Yb.re, Yb.im)
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      const f4 q = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(d, vo, k * ko, 0));
+      return make_float4(q[0], q[1], q[2], q[3]);
+    };
+    inv_rows_load2<NX, T16, 0>(u, sg, odd, load);      // (in batches of LDB pairs: 49 x 16 bytes in flight at once do not fit the registers)
   }
   float norm = norm0;
   if (sc.tmax) {
@@ -142,7 +156,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NX >= 64 ? 
       wst[(m * 2 + h) * 32 + (lane >> 1)] = __builtin_bit_cast(unsigned, bf16x2{static_cast<__bf16>(v0), static_cast<__bf16>(v1)});
     }
   };
-  if (two || LAYOUT != 0) inv_rows_out2<NX, 0>(u, h, W, pad, store);      // (the launcher takes even channel counts only; bf16: whole 8-channel units)
+  if (two || LAYOUT != 0) inv_rows_out2<NX, 0, LAYOUT != 0>(u, h, W, pad, store);      // (the launcher takes even channel counts only; bf16: whole 8-channel units)
   if constexpr (LAYOUT != 0) {
     // a wave = 32 channel pairs = eight 8-channel units of ONE row (C % 64 == 0); unit q = (m, parity, unit) lies at word 4 q of the stage
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
