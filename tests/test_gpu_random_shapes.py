@@ -179,14 +179,15 @@ def test_bf16_fft_product_spectra_range(case):
     assert (np.abs(got - refb) <= 1.001 * ulp + 1e-3 * np.abs(refb).max()).all(), float(np.abs(got - refb).max() / np.abs(refb).max())
 
 
-@pytest.mark.parametrize('geom', [(2, 60, 90, 30, 45, 15, 23), (1, 32, 88, 16, 44, 8, 22), (1, 24, 40, 24, 40, 6, 10)], ids=lambda g: 'B%d_%dx%d_%dx%d_%dx%d' % g)
+@pytest.mark.parametrize('geom', [(2, 60, 90, 30, 45, 15, 23, 128, 128), (1, 58, 90, 29, 45, 15, 23, 512, 64), (1, 32, 88, 16, 44, 8, 22, 128, 128),
+                                  (1, 24, 40, 24, 40, 6, 10, 128, 128)], ids=lambda g: 'B%d_%dx%d_%dx%d_%dx%d_%d-%d' % g)
 def test_merged_conv_layer_vs_oracle(geom):
     """x = (x1 + up(x2) + up(x3)) / 3 followed by conv5 (main.py:58,67,69-71) through jcm_conv_layer_merged: on the frequency-domain route the
     merge is formed inside the layer's forward row pass.  60x90 / 30x45 / 15x23 is the model's geometry (bf16 handles: the register kernel with
-    compile-time taps, rows_fwd_merge_reg_kernel); the others take the generic kernel (one with x2 already at full size)."""
+    compile-time taps, rows_fwd_merge_reg_kernel -- with the tower's 512 channels its work groups are laid out per XCD, and 58 rows leave the last group of
+    four rows incomplete); the others take the generic kernel (one with x2 already at full size)."""
     from joint_cnn_mrf_amd.engine import Engine
-    B, H, W, H2, W2, H3, W3 = geom
-    cin, cout = 128, 128
+    B, H, W, H2, W2, H3, W3, cin, cout = geom
     rs = np.random.RandomState(H * 100 + W)
     p = layer_params(rs, cin, cout, 9)
     xs = [np.maximum(rs.standard_normal((B, h, w, cin)), 0).astype(np.float32) for h, w in ((H, W), (H2, W2), (H3, W3))]
