@@ -84,7 +84,7 @@ int jcm_abi_version(void);
  *              ACCURACY CLASS of the default bf16 route (fft_single = fft_t16 = 1): 11-bit intermediates inside the wide 9x9 layers --
  *              per layer within one bf16 ulp + 1e-3 of the layer's scale of the bf16-operand oracle (7.6-8.0 % of the entries one ulp off;
  *              0.2 % with both options 0), full tower 4.3e-3 of the logit scale; arg-max agreement with the fp32 engine on 256 images
- *              97.5 % (part detector) / 96.8 % (spatial model), the same as the strict arm's 97.4 / 96.4 % and the direct bf16 MFMA
+ *              97.6 % (part detector) / 96.3 % (spatial model), the same as the strict arm's 97.4 / 96.4 % and the direct bf16 MFMA
  *              kernels' 97.4 / 96.4 %, and 100 % / 99.9 % of the joints whose fp32 top-2 margin is clear of the bf16 noise
  *              (tests/test_gpu_argmax_agreement.py).
  * "fft_windows": any time, default 1 (fp32 handles with training state): the training step runs its wide 60x90 layers (conv4_fullres, conv5 -- every
