@@ -42,13 +42,13 @@ constexpr int EC0 = XB0 + 2 * XBUF;                    // epilogue constants, st
 constexpr int CMAX = 256;                              // output channels (CoutP) the staging area holds
 constexpr int LDS_BYTES = (EC0 + 3 * CMAX / 4) * 16;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-constexpr int EPS = 3, NXI = 4 * EPS;                  // window-part table: entries per wave and stage (stages 0..3 of a chunk), entries per wave
+constexpr int XS = 3, EPS = 4, NXI = XS * EPS;         // window-part table: stages of a chunk that issue parts (0 .. XS-1), entries per wave and stage, entries per wave
 
 struct Geom {
   int H, W, HW, P, S, tpi, nN, items, nparts;         // S = H*P padded positions per image; tpi tiles per image; nN 128-channel tiles
 };
 struct Item { int b, s0, n0, mr; };                    // image, first position, first output channel, fragment rows per wave
-struct Tab { unsigned ta, tb, nxs; };                  // the wave's window-part table (lanes 0..NXI-1) and its per-stage counts
+struct Tab { unsigned td, ts, tw, nxs; };              // the wave's window-part table (lanes 0..NXI-1: LDS address, source offset, pixel lanes) and its per-stage counts
 constexpr unsigned kZeroSrc = 0x40000000u;             // a source offset beyond any tensor this kernel accepts (< 2^30 bytes per image): the DMA delivers zeros
 }  // namespace c5
 
@@ -78,64 +78,84 @@ __device__ __forceinline__ Item c5_item(const ConvArgs& a, const Geom& gm, int L
   it.mr = left > NW * 2 * 32 ? 3 : left > NW * 32 ? 2 : 1;
   return it;
 }
+// The image's descriptor starts TWO PIXEL STEPS in front of the image: lane L of a row's first part is slot L of the padded row = pixel L - 2, so with
+// this base one lane offset (L pixel steps) serves every part and all that differs between parts is a scalar.  The lanes of the pad slots are never
+// enabled for a pixel DMA, so nothing in front of the image is read.
+__device__ __forceinline__ unsigned c5_xbias(const ConvArgs& a) { return a.in_planar ? 32u : (unsigned)(a.Cin * 4); }
 __device__ __forceinline__ auto c5_xrsrc(const ConvArgs& a, const Geom& gm, int b) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(static_cast<const __bf16*>(a.x)) + (size_t)b * gm.HW * a.Cin, 0, (int)((size_t)gm.HW * a.Cin * 2), 0x00020000);
+  const unsigned bias = c5_xbias(a);
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(const_cast<__bf16*>(static_cast<const __bf16*>(a.x)) + (size_t)b * gm.HW * a.Cin) - bias, 0,
+                                           (int)((size_t)gm.HW * a.Cin * 2 + bias), 0x00020000);
 }
 __device__ __forceinline__ auto c5_wrsrc(const ConvArgs& a) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(static_cast<const __bf16*>(a.wp)), 0, (int)((size_t)KS * KS * a.Cin * a.CoutP * 2), 0x00020000);
 }
-// window part i of this wave (table lane i) for `chunk` into window `bufsel`
+// window part i of this wave (table lane i) for `chunk` into window `bufsel`: the pixels of one row part.  Everything entry-specific is scalar (three
+// v_readlane): the LDS address, the source offset, the enabled lanes; xvoff = the lane's pixel step, the same for every part (c5_xrsrc).  (Round 5: the
+// MFMA loop is bound by its issue slots -- this call was 40 instructions, 12 per chunk and wave.)
 template <class R>
-__device__ __forceinline__ void c5_xdma(const ConvArgs& a, const Geom& gm, R xrsrc, unsigned lds0, const Tab& t, int i, int chunk, int bufsel, int lane) {
-  const unsigned eb = __builtin_amdgcn_readlane(t.tb, i), ea = __builtin_amdgcn_readlane(t.ta, i);
-  if (!((eb >> 29) & 1u)) return;
-  auto dst = (__attribute__((address_space(3))) char*)(size_t)(lds0 + ((eb & 0x3fffu) + (unsigned)(bufsel * XBUF)) * 16u);
-  const unsigned lo = (eb >> 14) & 0x7fu, hi = (eb >> 21) & 0x7fu;
-  const unsigned lane16 = (unsigned)lane * 16u;
-  const bool p0 = (eb >> 28) & 1u;
-  const unsigned l16 = p0 ? lane16 - 32u : lane16;                                    // part 0: lanes 0, 1 are the pad slots in front of the row
-  unsigned xvoff = a.in_planar ? l16 : l16 * (unsigned)(a.Cin >> 3);
-  if ((p0 && lane < 2) || ((eb >> 30) & 1u)) xvoff = kZeroSrc;                        // pad slots, rows above / below the image
-  const unsigned xcs = a.in_planar ? (unsigned)(2 * gm.HW * 16) : 32u;                // source step per 16-channel chunk
-  const unsigned soff = ea + (unsigned)chunk * xcs;
-  if ((unsigned)lane - lo < hi - lo)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)dst, 16, xvoff, soff, 0, 0);
+__device__ __forceinline__ void c5_xdma(R xrsrc, const Tab& t, int i, unsigned chunk_off, unsigned buf_off, unsigned xvoff, int lane) {
+  const unsigned w = __builtin_amdgcn_readlane(t.tw, i);
+  if (!(w >> 16)) return;
+  const unsigned d = __builtin_amdgcn_readlane(t.td, i) + buf_off, so = __builtin_amdgcn_readlane(t.ts, i) + chunk_off;
+  if ((unsigned)lane - (w & 0xffu) < ((w >> 8) & 0xffu))
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(size_t)d, 16, xvoff, so, 0, 0);
+}
+// the zero slots of entry i -- the two pad slots in front of a row, whole rows above / below the image -- in both windows, once per item: no pixel DMA ever
+// writes them, so they stay zero through the item's chunks.  Zeros come from the per-LANE offset kZeroSrc (the lane offset is what the buffer's range check sees).
+template <class R>
+__device__ __forceinline__ void c5_zdma(R xrsrc, const Tab& t, unsigned tz, int i, int lane) {
+  const unsigned z = __builtin_amdgcn_readlane(tz, i);
+  if (!(z >> 16)) return;
+  const unsigned d = __builtin_amdgcn_readlane(t.td, i);
+  if ((unsigned)lane - (z & 0xffu) < ((z >> 8) & 0xffu)) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(size_t)d, 16, kZeroSrc, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(size_t)(d + XBUF * 16), 16, kZeroSrc, 0, 0, 0);
+  }
 }
 // weights of stage (chunk, ky) into ring slot `slot`: 20 pieces of 1 KB = (kx, unit, 64-column half); wave w moves pieces w, w+8, w+16.
 // Past the last stage the source offset runs past the item's data (or out of the buffer: zeros) into a free slot: no tail logic.
-template <class R>
-__device__ __forceinline__ void c5_wdma(const ConvArgs& a, R wrsrc, f32x4* lds, int wid, int lane, int n0, int chunk, int ky, int slot) {
+// What depends on the wave only -- a piece's offset inside a stage of the source and inside a ring slot -- is formed once per item (WPieces); a call
+// adds the stage's scalar terms: the DMA's vector offset is the lane's 16 bytes alone (the loop is bound by its issue slots: timing build, round 5).
+struct WPieces { unsigned src[3], dst[3]; };      // bytes: source offset without the stage term, LDS address inside ring slot 0
+__device__ __forceinline__ WPieces c5_wpieces(const ConvArgs& a, unsigned lds0, int wid, int n0) {
+  WPieces w;
   const unsigned wtap = (unsigned)((a.Cin >> 3) * a.CoutP * 16);
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int piece = wid + NW * i;
-    if (piece < KS * 4) {
-      const int kx = piece >> 2, unit = (piece >> 1) & 1, q = piece & 1;
-      const unsigned soff = (unsigned)(ky * KS + kx) * wtap + (unsigned)(((chunk * 2 + unit) * a.CoutP + n0 + q * 64) * 16);
-      f32x4* dst = lds + WB0 + slot * WST + (kx * 2 + unit) * BN + q * 64;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, (unsigned)lane * 16u + soff, 0, 0, 0);
-    }
+    const int kx = piece >> 2, unit = (piece >> 1) & 1, q = piece & 1;
+    w.src[i] = (unsigned)kx * wtap + (unsigned)((unit * a.CoutP + n0 + q * 64) * 16);
+    w.dst[i] = lds0 + (unsigned)(WB0 + (kx * 2 + unit) * BN + q * 64) * 16u;
   }
+  return w;
+}
+template <class R>
+__device__ __forceinline__ void c5_wdma(const ConvArgs& a, R wrsrc, const WPieces& w, int wid, unsigned lane16, int chunk, int ky, int slot) {
+  const unsigned wtap = (unsigned)((a.Cin >> 3) * a.CoutP * 16);
+  const unsigned stage_src = (unsigned)(ky * KS) * wtap + (unsigned)(chunk * 2 * a.CoutP * 16), stage_dst = (unsigned)(slot * WST * 16);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (wid + NW * i < KS * 4)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(size_t)(w.dst[i] + stage_dst), 16, lane16, w.src[i] + stage_src, 0, 0);
 }
 
 // Everything of an item that does not need the accumulators: the window-part table, chunk 0 and the first two weight stages requested
 // (NOT waited for).
 // Caller: every wave has finished its LDS reads of the previous item and drained its own DMAs.
 __device__ __forceinline__ Tab c5_setup(const ConvArgs& a, const Geom& gm, char* smem, const Item& it) {
-  f32x4* lds = reinterpret_cast<f32x4*>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = gm.H, W = gm.W, P = gm.P, Cin = a.Cin;
   const int WIN = NW * it.mr * 32 + 4 * P + 4;          // window: s0 - 2P - 2 ... + WIN
   const int sB = it.s0 - 2 * P - 2;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-  // Entry u = wid + 8 i (i = EPS * stage + j, stages 0..3) lives in lane i: one 64-slot part of one window row of one unit plane.  A row
-  // is [2 pad slots | W pixels]; the parts tile it from the pad on, so EVERY slot of the window is written by the DMAs of a chunk --
-  // pixels from the image, the pad slots and the rows above / below the image as zeros (source offset out of the buffer's range):
-  // nothing is zero-filled by hand.  tb = LDS slot (window 0) | lo << 14 | hi << 21 | part 0 << 28 | valid << 29 | zero row << 30;
-  // ta = source offset of the part's first pixel without the chunk term.  Zeros come from the per-LANE offset kZeroSrc (the
-  // lane offset is what the buffer's range check sees).
-  Tab t{0u, 0u, 0u};
+  // Entry u = wid + 8 i (i = EPS * stage + j, stages 0..XS-1) lives in lane i: one 64-slot part of one window row of one unit plane.  A row
+  // is [2 pad slots | W pixels]; the parts tile it from the pad on.  td = LDS byte address of the part's lane 0 in window 0; ts = source offset of lane 0
+  // (c5_xrsrc's base, without the chunk term); tw = the lanes that fetch pixels, lo | count << 8 | valid << 16; tz = the lanes whose slots are zero
+  // (pad slots, rows above / below the image), same packing.  Every slot of the window is covered by one of the two.
+  Tab t{0u, 0u, 0u, 0u};
+  unsigned tz = 0u;
   if (lane < NXI) {
     const int u = wid + NW * lane;
     const int upr = 2 * gm.nparts;
@@ -146,21 +166,28 @@ __device__ __forceinline__ Tab c5_setup(const ConvArgs& a, const Geom& gm, char*
     const int lo = max(0, -rowbase), hi = min(min(64, P - 64 * part), WIN - rowbase);
     if (lo < hi) {
       const bool inside = r >= 0 && r < H;
-      const int px0 = part == 0 ? r * W : r * W + 64 * part - 2;                   // pixel of lane 0 (part 0: of lane 2, behind the two pad lanes)
-      t.ta = !inside ? 0u : a.in_planar ? (unsigned)((plane * H * W + px0) * 16) : (unsigned)(px0 * Cin * 2 + plane * 16);
-      t.tb = (unsigned)(XB0 + plane * WINMAX + rowbase) | ((unsigned)lo << 14) | ((unsigned)hi << 21) | ((unsigned)(part == 0) << 28) | (1u << 29) |
-             ((unsigned)!inside << 30);
+      const int px0 = r * W + 64 * part;                                            // pixel of lane 2 (lane L is slot 64 part + L of the padded row = pixel 64 part + L - 2)
+      t.td = lds0 + (unsigned)(XB0 + plane * WINMAX + rowbase) * 16u;
+      t.ts = !inside ? 0u : a.in_planar ? (unsigned)((plane * H * W + px0) * 16) : (unsigned)(px0 * Cin * 2 + plane * 16);
+      const int plo = part == 0 ? max(lo, 2) : lo;                                  // pixel lanes [plo, hi), zero lanes [lo, zhi)
+      const int zhi = !inside ? hi : part == 0 ? min(hi, 2) : lo;
+      if (inside && plo < hi) t.tw = (unsigned)plo | ((unsigned)(hi - plo) << 8) | (1u << 16);
+      if (lo < zhi) tz = (unsigned)lo | ((unsigned)(zhi - lo) << 8) | (1u << 16);
     }
   }
 #pragma unroll
-  for (int i = 0; i < NXI; ++i) t.nxs += ((__builtin_amdgcn_readlane(t.tb, i) >> 29) & 1u) << (4 * (i / EPS));   // parts per stage, 4 bits each
+  for (int i = 0; i < NXI; ++i) t.nxs += (__builtin_amdgcn_readlane(t.tw, i) >> 16) << (4 * (i / EPS));   // pixel DMAs per stage, 4 bits each
   __builtin_amdgcn_s_barrier();                           // every wave has drained its DMAs: the ring and the windows are free
   const auto xrsrc = c5_xrsrc(a, gm, it.b);
   const auto wrsrc = c5_wrsrc(a);
+  const unsigned xvoff = a.in_planar ? (unsigned)lane * 16u : (unsigned)lane * 16u * (unsigned)(a.Cin >> 3);
 #pragma unroll
-  for (int i = 0; i < NXI; ++i) c5_xdma(a, gm, xrsrc, lds0, t, i, 0, 0, lane);
-  c5_wdma(a, wrsrc, lds, wid, lane, it.n0, 0, 0, 0);
-  c5_wdma(a, wrsrc, lds, wid, lane, it.n0, 0, 1, 1);
+  for (int i = 0; i < NXI; ++i) c5_zdma(xrsrc, t, tz, i, lane);
+#pragma unroll
+  for (int i = 0; i < NXI; ++i) c5_xdma(xrsrc, t, i, 0u, 0u, xvoff, lane);
+  const WPieces wp = c5_wpieces(a, lds0, wid, it.n0);
+  c5_wdma(a, wrsrc, wp, wid, (unsigned)lane * 16u, 0, 0, 0);
+  c5_wdma(a, wrsrc, wp, wid, (unsigned)lane * 16u, 0, 1, 1);
   return t;
 }
 
@@ -194,6 +221,10 @@ __device__ __forceinline__ void c5_tile(const ConvArgs& a, const Geom& gm, char*
   const auto wrsrc = c5_wrsrc(a);
   const auto xrsrc = c5_xrsrc(a, gm, it.b);
   const int nw = wid < KS * 4 - 2 * NW ? 3 : 2;        // weight pieces this wave issues per stage
+  const WPieces wp = c5_wpieces(a, lds0, wid, it.n0);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const unsigned xvoff = a.in_planar ? lane16 : lane16 * (unsigned)(Cin >> 3);          // the lane's pixel step (c5_xdma)
+  const unsigned xcs = a.in_planar ? (unsigned)(2 * gm.HW * 16) : 32u;                   // source step per 16-channel chunk
 
   // the setup's requests (chunk 0, two weight stages) and its LDS writes have landed
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -212,6 +243,9 @@ __device__ __forceinline__ void c5_tile(const ConvArgs& a, const Geom& gm, char*
   auto one_stage = [&](auto parc) __attribute__((always_inline)) {
     constexpr int PAR = decltype(parc)::value;
     const int bufsel = chunk & 1;
+    // the next chunk's window parts go out in this chunk's first XS stages, into the other window
+    const bool xgo = ky < XS && chunk + 1 < nchunk;
+    const unsigned xchunk_off = (unsigned)(chunk + 1) * xcs, xbuf_off = bufsel ? 0u : (unsigned)(XBUF * 16);
     // aaddr / baddr are running addresses: this stage's kernel row of this chunk's window, this stage's ring slot
     // fragments of tap 0 (the barrier in front of this stage made the window and this stage's weights visible)
     c5_a_load<0>(fa[PAR], aaddr, MR);
@@ -241,10 +275,10 @@ __device__ __forceinline__ void c5_tile(const ConvArgs& a, const Geom& gm, char*
           if (g == 3) c5_b_load<TP + 1, 3>(fb[3], baddr);
         }
         // DMA of this stage: the weights of stage g + 2 first, then (stages 0..3 of a chunk) two parts of the next chunk's window
-        if (TP == 0 && g == 1) c5_wdma(a, wrsrc, lds, wid, lane, it.n0, wchunk, wky, slot == 0 ? NB - 1 : slot - 1);
-        if (TP == 1 && g == 1 && ky < KS - 1 && chunk + 1 < nchunk) c5_xdma(a, gm, xrsrc, lds0, t, EPS * ky, chunk + 1, bufsel ^ 1, lane);
-        if (TP == 2 && g == 1 && ky < KS - 1 && chunk + 1 < nchunk) c5_xdma(a, gm, xrsrc, lds0, t, EPS * ky + 1, chunk + 1, bufsel ^ 1, lane);
-        if (TP == 3 && g == 1 && ky < KS - 1 && chunk + 1 < nchunk) c5_xdma(a, gm, xrsrc, lds0, t, EPS * ky + 2, chunk + 1, bufsel ^ 1, lane);
+        if (TP == 0 && g == 1) c5_wdma(a, wrsrc, wp, wid, lane16, wchunk, wky, slot == 0 ? NB - 1 : slot - 1);
+        // (the parts go out in the chunk's first XS = 3 stages: with a fourth, the last parts had one stage -- 3 us -- to arrive before the chunk's last barrier
+        // and the loop waited for them: timing build, 30 % of the loop)
+        if (TP >= 1 && g == 1 && xgo) c5_xdma(xrsrc, t, EPS * ky + TP - 1, xchunk_off, xbuf_off, xvoff, lane);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -272,7 +306,9 @@ __device__ __forceinline__ void c5_tile(const ConvArgs& a, const Geom& gm, char*
       const int nx1 = (last || !more_x) ? 0 : (int)((t.nxs >> (4 * oky)) & 15u);
       const int nx0 = (oky == 0 || last || !more_x) ? 0 : (int)((t.nxs >> (4 * (oky - 1))) & 15u);
       const int keep = nw + nx0 + nx1;
-      if (keep >= 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      if (keep >= 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+      else if (keep == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if (keep == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
       else if (keep == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if (keep == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
       else if (keep == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -364,7 +400,7 @@ __global__ __launch_bounds__(NT, 2) void conv5_strip_bf16_kernel(ConvArgs a, Geo
     const int Ln = L + gridDim.x;
     const bool has_next = Ln < gm.items;
     const Item nxt = c5_item(a, gm, has_next ? Ln : L);
-    Tab tn{0u, 0u, 0u};
+    Tab tn{};
     if (it.mr == 3) c5_tile<3>(a, gm, smem, it, t, has_next, nxt, tn);
     else if (it.mr == 2) c5_tile<2>(a, gm, smem, it, t, has_next, nxt, tn);
     else c5_tile<1>(a, gm, smem, it, t, has_next, nxt, tn);
