@@ -173,6 +173,23 @@ def test_shim_validates_before_the_call(debug_setup):
         eng.forward(torch.zeros(1, 480, 720, 3, device='cuda:0'), None, use_sm=True)
 
 
+def test_merged_layer_entry_point_matches_the_tower(debug_setup):
+    """jcm_conv_layer_merged = main.py:58,67,69-71 on the branch outputs of the oracle's own forward: conv5 of ((x1 + up(x2)) + up(x3)) / 3."""
+    eng, p = debug_setup
+    x = synth.make_images(2, seed=7)
+    taps = {}
+    O.model(x, p, taps=taps)
+    x1, x2, x3 = (dev(taps['conv4_' + r].astype(np.float32)) for r in ('fullres', 'halfres', 'quarterres'))
+    got = eng.conv_layer_merged(x1, x2, x3, 'conv5', taps['conv5'].shape[-1]).cpu().numpy()
+    np.testing.assert_allclose(got, taps['conv5'], atol=2e-5 * np.abs(taps['conv5']).max(), rtol=0)
+    with pytest.raises(RuntimeError, match='BatchNorm'):
+        eng.conv_layer_merged(x1, x2, x3, 'conv6', 9)             # the logits layer has no BatchNorm: not a layer the merge feeds
+    with pytest.raises(RuntimeError, match='no conv layer'):
+        eng.conv_layer_merged(x1, x2, x3, 'conv7', 9)
+    with pytest.raises(ValueError):
+        eng.conv_layer_merged(x1, x2[:1], x3, 'conv5', 128)       # batch mismatch is caught in the binding
+
+
 def test_other_resolution_and_batch_shapes(debug_setup):
     """The part detector is fully convolutional (main.py:34 only documents 480x720): a 240x368
     image gives 30x46 maps, the quarter branch runs on 60x92 -> 8x12 with the SAME pool padding
