@@ -10,11 +10,14 @@
 // filter image.  The 32x32 accumulator layout keeps all four members of every 2x2 pooling
 // window in one lane, so the pool is register-local and only the pooled map is written:
 // 2.8 MB/image instead of 22 MB + 22 MB + 5.5 MB for the unfused conv1 -> pool pair.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace jcm {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -28,24 +31,29 @@ namespace cfft { int persistent_grid(const void* kernel, int ntiles, int threads
 // Persistent work groups (round 3): a group stages the packed filter once and walks tiles t, t + grid, ...; the window of the NEXT tile is
 // loaded into registers (5 pixels per thread) before the MFMAs of the current one, so the global-load latency -- which bounded the
 // one-tile-per-group version at 2 groups per CU -- hides behind them.
-// NP = 1: bf16 operands (bf16 handles), bf16 output.  NP = 3: every fp32 value as three bf16 parts, the six products with p + q <= 2
-// (what is dropped is below 2^-24 of x*w; cgemm_split.hip's arithmetic, which the stride-1 layers of an fp32 handle on the default route run
-// on anyway): 120 MFMAs 32x32x16 per wave instead of 160 of the 32x32x2 fp32 ones at a quarter of their cost each; fp32 output.
+// NP = 1: bf16 operands (bf16 handles), bf16 output.  NP = 2 (fp32 handles, default route): every fp32 value as TWO FP16 parts of the value times a power
+// of two, the three products x0w1 + x1w0 + x0w0 -- 22 significant bits, cgemm_split.hip's arithmetic, which the stride-1 layers of such a handle run on
+// anyway; fp32 output.  The window's scale is ITS OWN: the work group takes the largest |value| of the 35x35x3 window it has just loaded (one extra
+// barrier) and lifts it to [2^13, 2^14), the filter's scale comes with the packed filter -- so the kernel inherits fp32's range whatever the image holds,
+// without a pass over the image.  60 MFMAs 32x32x16 per wave (rounds 3-5: three bf16 parts, six products, 120).
 template <int NP, typename OutT>
 __device__ __forceinline__ void conv1_mfma_pool_body(const float* __restrict__ x, const f32x4* __restrict__ wq, const float* __restrict__ bias,
                                                      const float* __restrict__ scale, const float* __restrict__ shift, OutT* __restrict__ out, int H0, int W0,
                                                      int sub, int Hin, int Win, int Hp, int Wp, int pad_t, int pad_l, int tiles_x, int tiles_img, int ntiles) {
-  __shared__ __attribute__((aligned(16))) __bf16 win[NP][CM_IN * CM_ROW];
+  using ElT = std::conditional_t<NP == 1, __bf16, _Float16>;
+  __shared__ __attribute__((aligned(16))) ElT win[NP][CM_IN * CM_ROW];
   __shared__ __attribute__((aligned(16))) f32x4 wl[NP][CM_WQ_F4];
+  __shared__ float red[4];
   constexpr int PPT = (CM_IN * CM_IN + 255) / 256;      // window pixels per thread
   const int tid = threadIdx.x;
   // the 7-element tail of every 112-element row is zeroed once (it only ever meets zero weights; the pixel stores never touch it)
   for (int i = tid; i < NP * CM_IN * (CM_ROW - CM_IN * 3); i += 256) {
     const int p = i / (CM_IN * (CM_ROW - CM_IN * 3)), r = i - p * (CM_IN * (CM_ROW - CM_IN * 3));
     const int iy = r / (CM_ROW - CM_IN * 3), e = r - iy * (CM_ROW - CM_IN * 3);
-    win[p][iy * CM_ROW + CM_IN * 3 + e] = (__bf16)0.f;
+    win[p][iy * CM_ROW + CM_IN * 3 + e] = (ElT)0.f;
   }
   for (int i = tid; i < NP * CM_WQ_F4; i += 256) (&wl[0][0])[i] = wq[i];
+  const float winv = NP == 2 ? reinterpret_cast<const float*>(wq + NP * CM_WQ_F4)[0] : 1.f;      // 1 / (the filter's power of two), behind the packed filter
 
   const int lane = tid & 63, wid = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
@@ -74,7 +82,24 @@ __device__ __forceinline__ void conv1_mfma_pool_body(const float* __restrict__ x
   int t = blockIdx.x;
   if (t < ntiles) load_tile(t);
   for (; t < ntiles; t += gridDim.x) {
-    // window -> LDS as bf16 parts (round to nearest even; the remainders are exact)
+    // window -> LDS as 16-bit parts (round to nearest even; the remainders are exact)
+    float xs = 1.f, xinv = 1.f;
+    if constexpr (NP == 2) {
+      float m = 0.f;
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) m = fmaxf(m, fmaxf(fabsf(v[k][0]), fmaxf(fabsf(v[k][1]), fabsf(v[k][2]))));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      if ((tid & 63) == 0) red[tid >> 6] = m;
+      __syncthreads();
+      m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+      if (m > 1.0e-30f && m < 3.0e38f) {      // (a zero / vanishing or non-finite window: no scaling)
+        int ex = 0;
+        (void)frexpf(m, &ex);                   // m in [2^(ex-1), 2^ex)
+        xs = ldexpf(1.f, 14 - ex);
+        xinv = ldexpf(1.f, ex - 14);
+      }
+    }
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
       const int i = tid + 256 * k;
@@ -84,7 +109,8 @@ __device__ __forceinline__ void conv1_mfma_pool_body(const float* __restrict__ x
         for (int p = 0; p < NP; ++p)
 #pragma unroll
           for (int e = 0; e < 3; ++e) {
-            const __bf16 q = (__bf16)v[k][e];
+            if (NP == 2 && p == 0) v[k][e] *= xs;      // (exact: a power of two)
+            const ElT q = (ElT)v[k][e];
             win[p][iy * CM_ROW + ix * 3 + e] = q;
             v[k][e] -= (float)q;
           }
@@ -117,16 +143,19 @@ __device__ __forceinline__ void conv1_mfma_pool_body(const float* __restrict__ x
 #pragma unroll
         for (int g = 0; g < 2; ++g) bf[p][g] = __builtin_bit_cast(bf16x8, wl[p][(ky * 2 + h) * 64 + g * 32 + l31]);
       }
-      // NP = 3, small terms first: (x part, w part) = (0,2) (1,1) (2,0) (1,0) (0,1) (0,0)
-      constexpr int NPROD = NP == 3 ? 6 : 1;
+      // NP = 2, small terms first: (x part, w part) = (0,1) (1,0) (0,0)
+      constexpr int NPROD = NP == 2 ? 3 : 1;
 #pragma unroll
       for (int s = 0; s < NPROD; ++s) {
-        const int pxp = NP == 1 ? 0 : (s == 0 ? 0 : s == 1 ? 1 : s == 2 ? 2 : s == 3 ? 1 : 0);
-        const int pwp = NP == 1 ? 0 : (s == 0 ? 2 : s == 1 ? 1 : s == 2 ? 0 : s == 3 ? 0 : s == 4 ? 1 : 0);
+        const int pxp = NP == 1 ? 0 : (s == 1 ? 1 : 0);
+        const int pwp = NP == 1 ? 0 : (s == 0 ? 1 : 0);
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
-          for (int g = 0; g < 2; ++g) acc[f][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pxp][f], bf[pwp][g], acc[f][g], 0, 0, 0);
+          for (int g = 0; g < 2; ++g) {
+            if constexpr (NP == 1) acc[f][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pxp][f], bf[pwp][g], acc[f][g], 0, 0, 0);
+            else acc[f][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[pxp][f]), __builtin_bit_cast(f16x8, bf[pwp][g]), acc[f][g], 0, 0, 0);
+          }
       }
     }
     // epilogue.  Accumulator reg i of lane (h, co) is fragment pixel r = (i&3) + 8*(i>>2) + 4*h, i.e.
@@ -135,6 +164,7 @@ __device__ __forceinline__ void conv1_mfma_pool_body(const float* __restrict__ x
     const int b = t / tiles_img, rt = t - b * tiles_img;
     const int ty = rt / tiles_x, tx = rt - ty * tiles_x;
     const int oy0 = ty * CM_T, ox0 = tx * CM_T;
+    const float un = xinv * winv;      // NP = 2: the two powers of two come off the sums (exact); 1 otherwise
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const int co = g * 32 + l31;
@@ -144,10 +174,10 @@ __device__ __forceinline__ void conv1_mfma_pool_body(const float* __restrict__ x
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                 // j -> regs (i0, i0+1, i0+8, i0+9), i0 = (j&1)*2 + (j>>1)*4
           const int i0 = (j & 1) * 2 + (j >> 1) * 4;
-          const float v0 = fmaxf(acc[f][g][i0] + bi[g], 0.f) * sc[g] + sh[g];
-          const float v1 = fmaxf(acc[f][g][i0 + 1] + bi[g], 0.f) * sc[g] + sh[g];
-          const float v2 = fmaxf(acc[f][g][i0 + 8] + bi[g], 0.f) * sc[g] + sh[g];
-          const float v3 = fmaxf(acc[f][g][i0 + 9] + bi[g], 0.f) * sc[g] + sh[g];
+          const float v0 = fmaxf((NP == 2 ? acc[f][g][i0] * un : acc[f][g][i0]) + bi[g], 0.f) * sc[g] + sh[g];
+          const float v1 = fmaxf((NP == 2 ? acc[f][g][i0 + 1] * un : acc[f][g][i0 + 1]) + bi[g], 0.f) * sc[g] + sh[g];
+          const float v2 = fmaxf((NP == 2 ? acc[f][g][i0 + 8] * un : acc[f][g][i0 + 8]) + bi[g], 0.f) * sc[g] + sh[g];
+          const float v3 = fmaxf((NP == 2 ? acc[f][g][i0 + 9] * un : acc[f][g][i0 + 9]) + bi[g], 0.f) * sc[g] + sh[g];
           const int r = (i0 & 3) + 8 * (i0 >> 2) + 4 * h;     // fragment pixel of reg i0 (row 0 of the pair)
           const int PX = (ox0 >> 1) + ((r & 15) >> 1);
           if (PY < Hp && PX < Wp) out[(((size_t)b * Hp + PY) * Wp + PX) * 64 + co] = (OutT)fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
@@ -165,13 +195,13 @@ __global__ __launch_bounds__(256) void conv1_mfma_pool_kernel(const float* __res
                                                               int pad_t, int pad_l, int tiles_x, int tiles_img, int ntiles) {
   conv1_mfma_pool_body<1, __bf16>(x, wq, bias, scale, shift, out, H0, W0, sub, Hin, Win, Hp, Wp, pad_t, pad_l, tiles_x, tiles_img, ntiles);
 }
-// fp32 handles on the default route: split operands (NP = 3), fp32 in, fp32 out
+// fp32 handles on the default route: split operands (NP = 2: two scaled fp16 parts), fp32 in, fp32 out
 __global__ __launch_bounds__(256) void conv1_mfma_pool_split_kernel(const float* __restrict__ x, const f32x4* __restrict__ wq,
                                                                     const float* __restrict__ bias, const float* __restrict__ scale,
                                                                     const float* __restrict__ shift, float* __restrict__ out,
                                                                     int H0, int W0, int sub, int Hin, int Win, int Hp, int Wp,
                                                                     int pad_t, int pad_l, int tiles_x, int tiles_img, int ntiles) {
-  conv1_mfma_pool_body<3, float>(x, wq, bias, scale, shift, out, H0, W0, sub, Hin, Win, Hp, Wp, pad_t, pad_l, tiles_x, tiles_img, ntiles);
+  conv1_mfma_pool_body<2, float>(x, wq, bias, scale, shift, out, H0, W0, sub, Hin, Win, Hp, Wp, pad_t, pad_l, tiles_x, tiles_img, ntiles);
 }
 
 // ---- the same fusion on the exact fp32 path: v_mfma_f32_32x32x2_f32 (an exact k-ordered fma chain), fp32 window in LDS.
@@ -255,24 +285,42 @@ __global__ __launch_bounds__(256) void conv1_mfma_pool_f32_kernel(const float* _
   }
 }
 
-constexpr int CS_NP = 3;
-// HWIO [5,5,3,64] fp32 -> [part][ky][h][co][8] bf16 (three parts of every weight), k' = 8h+i = 3*kx + c, k' = 15 is the zero pad.
-__global__ void pack_conv1_split_kernel(const float* __restrict__ w, __bf16* __restrict__ wq) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= CM_WQ_F4 * 8) return;
-  const int e = i & 7, co = (i >> 3) & 63, h = (i >> 9) & 1, ky = i >> 10;
-  const int k = 8 * h + e;
-  float v = 0.f;
-  if (k < 15) v = w[(((size_t)ky * 5 + k / 3) * 3 + k % 3) * 64 + co];
-  for (int p = 0; p < CS_NP; ++p) {
-    const __bf16 q = (__bf16)v;
-    wq[(size_t)p * CM_WQ_F4 * 8 + i] = q;
-    v -= (float)q;
+constexpr int CS_NP = 2;
+// HWIO [5,5,3,64] fp32 -> [part][ky][h][co][8] fp16 (two parts of every weight times the power of two that lifts max|w| to [2^13, 2^14)), k' = 8h+i = 3*kx + c,
+// k' = 15 is the zero pad; one float behind them: the inverse of that power of two.  One work group (the filter has 4800 values).
+__global__ __launch_bounds__(256) void pack_conv1_split_kernel(const float* __restrict__ w, _Float16* __restrict__ wq) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  float m = 0.f;
+  for (int i = tid; i < 5 * 5 * 3 * 64; i += 256) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float ws = 1.f, winv = 1.f;
+  if (m > 1.0e-30f && m < 3.0e38f) {
+    int ex = 0;
+    (void)frexpf(m, &ex);
+    ws = ldexpf(1.f, 14 - ex);
+    winv = ldexpf(1.f, ex - 14);
   }
+  for (int i = tid; i < CM_WQ_F4 * 8; i += 256) {
+    const int e = i & 7, co = (i >> 3) & 63, h = (i >> 9) & 1, ky = i >> 10;
+    const int k = 8 * h + e;
+    float v = 0.f;
+    if (k < 15) v = w[(((size_t)ky * 5 + k / 3) * 3 + k % 3) * 64 + co] * ws;
+    for (int p = 0; p < CS_NP; ++p) {
+      const _Float16 q = (_Float16)v;
+      wq[(size_t)p * CM_WQ_F4 * 8 + i] = q;
+      v -= (float)q;
+    }
+  }
+  if (tid == 0) reinterpret_cast<float*>(wq + (size_t)CS_NP * CM_WQ_F4 * 8)[0] = winv;
 }
-size_t conv1_split_weight_bytes() { return (size_t)CS_NP * CM_WQ_F4 * 16; }
+size_t conv1_split_weight_bytes() { return (size_t)CS_NP * CM_WQ_F4 * 16 + 16; }
 hipError_t pack_conv1_split(const float* w_hwio, void* wq, hipStream_t st) {
-  hipLaunchKernelGGL(pack_conv1_split_kernel, dim3((CM_WQ_F4 * 8 + 255) / 256), dim3(256), 0, st, w_hwio, static_cast<__bf16*>(wq));
+  hipLaunchKernelGGL(pack_conv1_split_kernel, dim3(1), dim3(256), 0, st, w_hwio, static_cast<_Float16*>(wq));
   return hipGetLastError();
 }
 hipError_t conv1_mfma_pool_split(const float* x, const void* wq, const float* bias, const float* scale, const float* shift, float* out,

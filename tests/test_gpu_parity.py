@@ -190,6 +190,18 @@ def test_merged_layer_entry_point_matches_the_tower(debug_setup):
         eng.conv_layer_merged(x1, x2[:1], x3, 'conv5', 128)       # batch mismatch is caught in the binding
 
 
+@pytest.mark.parametrize('gain', [1e-5, 255.0, 3e5])
+def test_tower_is_range_free_in_the_image(debug_setup, gain):
+    """The default fp32 route feeds conv1 as two FP16 parts of the window times ITS OWN power of two (conv1_mfma.hip) and the stride-1 layers as scaled
+    fp16 parts of their spectra: images in [0, 1e-5], [0, 255] or [0, 3e5] go through like images in [0, 1]."""
+    eng, p = debug_setup
+    x = (synth.make_images(2, seed=13) * np.float32(gain)).astype(np.float32)
+    ref = O.model(x, p)
+    got = eng.model(dev(x)).cpu().numpy()
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, ref, atol=logit_tol(ref), rtol=0)
+
+
 def test_other_resolution_and_batch_shapes(debug_setup):
     """The part detector is fully convolutional (main.py:34 only documents 480x720): a 240x368
     image gives 30x46 maps, the quarter branch runs on 60x92 -> 8x12 with the SAME pool padding
