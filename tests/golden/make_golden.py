@@ -18,6 +18,10 @@
    The generator asserts a top-2 logit margin far above fp32 noise so argmax is well posed.
 3. conv_mrf_*.npy -- one pair's pre-resize (61x91) and post-resize (60x90) maps.
 4. layer_stats.json -- per-layer mean / abs-max of the full-size activations (for bisecting).
+5. (--batch: writes ONLY these) batch64.npz / batch256.npz -- float64-oracle logits + coords of the images golden_util.BATCH64_GOLDEN /
+   BATCH256_GOLDEN of the configs[1] / configs[2] test batches (golden_util.config_batch), so that those configurations are compared by VALUE at
+   positions spread over the batch and not only on the golden pair; the top-2 margins are stored beside them (a dim image's margin is small:
+   the tests compare coordinates where the margin is clear of fp32 noise and say how many joints that is).
 """
 import json
 import os
@@ -165,5 +169,34 @@ def main():
     print(json.dumps({k: v for k, v in stats.items() if 'margin' in k or 'max' in k}))
 
 
+def main_batch():
+    sys.path.insert(0, os.path.dirname(HERE))
+    import golden_util as G
+    pri = G.flic_priors()
+    _x2, _t2, p = G.full_inputs()
+    sp = synth.make_sm_params(pri, kind='trained', seed=GOLDEN_SEEDS['sm'])
+    for B, idx in ((64, G.BATCH64_GOLDEN), (256, G.BATCH256_GOLDEN)):
+        x, torso = G.config_batch(B)
+        idx = np.asarray(idx)
+        xs, ts = x[idx], torso[idx]
+        del x
+        pd_logits = np.concatenate([O.model(xs[i:i + 1], p) for i in range(len(idx))], axis=0)
+        pd_prob = O.spatial_softmax(pd_logits)
+        sm_logits = O.spatial_model(np.concatenate([pd_prob, ts.astype(np.float64)], axis=3), sp)
+
+        def margins(lg):
+            flat = np.sort(lg.reshape(lg.shape[0], -1, lg.shape[3]), axis=1)
+            return flat[:, -1] - flat[:, -2]
+        out = dict(idx=idx.astype(np.int32), pd_logits=pd_logits.astype(np.float32), sm_logits=sm_logits.astype(np.float32),
+                   pd_coords=O.argmax_coords(pd_prob), sm_coords=O.argmax_coords(O.spatial_softmax(sm_logits)),
+                   pd_margin=margins(pd_logits), sm_margin=margins(sm_logits))
+        np.savez_compressed(os.path.join(HERE, 'batch%d.npz' % B), **out)
+        print(B, 'pd margins (min per image)', out['pd_margin'].min(axis=1).round(4).tolist(), 'sm', out['sm_margin'].min(axis=1).round(4).tolist(),
+              'pd logit scale', float(np.abs(pd_logits).max()))
+
+
 if __name__ == '__main__':
-    main()
+    if '--batch' in sys.argv:
+        main_batch()
+    else:
+        main()

@@ -33,6 +33,32 @@ def full_inputs():
     return synth.make_images(2, seed=g['images']), synth.make_torso(2, seed=g['torso']), p
 
 
+# The batches of BASELINE configs[1] (64 images, fp32) and configs[2] (256 images, bf16) as the tests AND make_golden.py --batch build them: the golden
+# pair in front, seeded U[0,1) images behind it, image 7 dim and image 8 bright (their per-image power-of-two scales differ from their neighbours').
+# make_golden.py --batch stores the float64 oracle's logits of the images listed in BATCH64_GOLDEN / BATCH256_GOLDEN, so that the configurations are
+# value comparisons at positions spread over the batch (front, dim, bright, the middle, both sides of image 32 -- a GEMM row-tile boundary -- and the end).
+BATCH64_GOLDEN = (7, 8, 16, 31, 32, 47, 62, 63)
+BATCH256_GOLDEN = (255,)
+
+
+def config_batch(B):
+    """(x [B,480,720,3], torso [B,60,90,1]) of the B=64 / B=256 configuration tests."""
+    x2, torso2, _p = full_inputs()
+    seed = {64: 277, 256: 177}[B]
+    x = np.concatenate([x2, synth.make_images(B - 2, seed=seed)], axis=0)
+    torso = np.concatenate([torso2, synth.make_torso(B - 2, seed=seed + 1)], axis=0)
+    if B == 64:
+        x[7] *= 0.01
+        x[8] = np.minimum(x[8] * 3.0, 1.0)
+    return x, torso
+
+
+def batch_golden(B):
+    """{'idx', 'pd_logits', 'sm_logits' (trained-like spatial-model parameters), 'pd_coords', 'sm_coords'} of the stored images of config_batch(B)."""
+    z = np.load(os.path.join(GOLDEN, 'batch%d.npz' % B))
+    return {k: z[k] for k in z.files}
+
+
 # Arg-max agreement of a bf16 engine with the float64 goldens on the 18 golden joints: every joint whose golden top-2 logit margin is clear of
 # the bf16 noise must land on the golden cell.  The thresholds are ~7x / ~10x the rms log-probability error of the bf16 engines measured against the
 # fp32 engine on 256 images (0.043 part detector, 0.025 spatial model; tests/test_gpu_argmax_agreement.py, which is where the agreement RATE is held).

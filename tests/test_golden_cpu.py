@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import flic_priors, full_inputs, load, seeds, stats
+from golden_util import batch_golden, config_batch, flic_priors, full_inputs, load, seeds, stats
 from joint_cnn_mrf_amd import synth
 from oracle import jcm_oracle as O
 from oracle import jcm_oracle_torch as T
@@ -75,3 +75,26 @@ def test_full_size_part_detector_golden():
     np.testing.assert_array_equal(O.argmax_coords(O.spatial_softmax(got.astype(np.float64))), load('full_pd_coords')[:1])
     st = stats()
     assert st['pd_top2_margin'] > 1e-2 and st['sm_top2_margin_trained'] > 2e-3
+
+
+def test_batch_goldens_second_formulation(pri):
+    """tests/golden/batch64.npz / batch256.npz (the value fixtures of the configs[1] / configs[2] batches): the torch formulation in float32
+    reproduces the stored float64 logits of the LAST image of the 64-image batch (rebuilt from seeds by golden_util.config_batch), the stored
+    coordinates are the arg-max of the stored logits, and the spatial model's second formulation reproduces the stored SM logits."""
+    g = batch_golden(64)
+    assert g['idx'].tolist() == [7, 8, 16, 31, 32, 47, 62, 63] and g['pd_logits'].shape == (8, 60, 90, 9)
+    x, torso = config_batch(64)
+    _, _, p = full_inputs()
+    got = T.model(x[63:64], p, dtype=torch.float32)
+    ref = g['pd_logits'][7:8]
+    assert np.abs(got - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+    for B in (64, 256):
+        g = batch_golden(B)
+        for st in ('pd', 'sm'):
+            lg = g[st + '_logits'].astype(np.float64)
+            np.testing.assert_array_equal(O.argmax_coords(O.spatial_softmax(lg)), g[st + '_coords'])
+    g = batch_golden(64)
+    sp = synth.make_sm_params(pri, kind='trained', seed=seeds()['sm'])
+    hm10 = np.concatenate([O.spatial_softmax(g['pd_logits'][6:8].astype(np.float64)), torso[62:64].astype(np.float64)], axis=3)
+    sm = T.spatial_model(hm10, sp)
+    np.testing.assert_allclose(sm, g['sm_logits'][6:8], atol=5e-5 * max(1.0, np.abs(g['sm_logits']).max()), rtol=0)
