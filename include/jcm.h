@@ -97,6 +97,12 @@ int jcm_abi_version(void);
  *              spectra; and the product spectra between the channel GEMM and the inverse column pass as complex fp16 under a CONSTANT
  *              power-of-two shift (2^-(ceil(log2 Cin) + 14): the scaled operands bound every product, so nothing can overflow and typical
  *              entries sit fourteen binades above fp16's smallest normal number; round 5).  0 = complex fp32 for all three (round 3).
+ * "fft_fuse" : any time, default 3 (fp32 handles, jcm_pd_forward / jcm_forward on the frequency-domain route): bit 0 = conv2 -> max pool -> conv3 and
+ *              bit 1 = conv4_fullres -> branch merge -> conv5 are handed over in row-transformed form: one kernel per hand-over does the inverse row
+ *              transform + bias / ReLU / BatchNorm of the producing layer, the op between the layers (the 2x2 maximum of a row pair; the TF-1.x bilinear
+ *              taps of the two coarse branches and the third) and the forward row transform of the consuming layer, so that neither conv2's output,
+ *              the pooled map nor the full-resolution branch x1 reaches HBM.  Same arithmetic per element as the separate kernels (fp32, the
+ *              reference's association order).  0 = the separate kernels of round 5 (A/B arm; held by the same tests).
  * "sm_algo"  : any time; the pairwise convolutions of the spatial model (main.py:83-87): 3 (default) = every 120x180 transform in LDS,
  *              hand-written (sm_fused.hip; jcm_conv_mrf, the prior spectra and the training step's backward use the whole-frame
  *              kernels of sm_lds.hip); 1 = direct sliding-window kernel, the independent cross-check.  Both pass the same parity

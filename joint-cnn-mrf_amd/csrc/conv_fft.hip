@@ -331,6 +331,20 @@ size_t conv_fft_handover_bytes(const ConvArgs& a, int ks) {      // T[kx][c/16][
   if (!sizes_of(a.H, a.W, ks, &s)) return 0;
   return (size_t)a.B * (s.NX / 2 + 1) * a.H * a.Cout * sizeof(cf);
 }
+// the fused hand-overs across a max pool / the branch merge (FftNext, conv_fft_rows_fused.hip)
+bool conv_fft_pool_fusable(const ConvArgs& a, int ks, int ks_next) {
+  Sizes s, n;
+  return sizes_of(a.H, a.W, ks, &s) && sizes_of((a.H + 1) / 2, (a.W + 1) / 2, ks_next, &n) && cfft_rows_inv_pool_fwd_supported(s.NX, n.NX, a.Cout);
+}
+size_t conv_fft_pool_handover_bytes(const ConvArgs& a, int ks_next) {      // T[kx][c/16][b][y][16] of the next layer, on the pooled map
+  Sizes n;
+  if (!sizes_of((a.H + 1) / 2, (a.W + 1) / 2, ks_next, &n)) return 0;
+  return (size_t)a.B * (n.NX / 2 + 1) * ((a.H + 1) / 2) * a.Cout * sizeof(cf);
+}
+bool conv_fft_merge_fusable(const ConvArgs& a, int ks, int ks_next, const FftMerge& m) {
+  Sizes s;
+  return conv_fft_fusable(a, ks, ks_next) && sizes_of(a.H, a.W, ks, &s) && cfft_rows_inv_merge_fwd_supported(s.NX, a, m);
+}
 // a.wp = the split filter spectra of THIS map size and kernel size; `work` = conv_fft_workspace_bytes(a, ks, np) bytes.  g0 / g1: optional
 // events recorded around the GEMM (the dominant kernel of the layer) for the roofline record.
 // in_layout / out_layout: 0 = fp32 NHWC, 1 = bf16 NHWC, 2 = bf16 planar
@@ -340,10 +354,11 @@ size_t conv_fft_handover_bytes(const ConvArgs& a, int ks) {      // T[kx][c/16][
 // weight gradient (wgrad_fft.hip); xs_ready: they are there already (the data gradient after the weight gradient of the same layer): the
 // forward transforms are skipped.
 hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int out_layout, void* work, const void* t_in, void* t_next, const FftMerge* merge,
-                        hipEvent_t g0, hipEvent_t g1, hipStream_t st, void* xs, bool xs_ready, const Fp16Scale* scp) {
+                        hipEvent_t g0, hipEvent_t g1, hipStream_t st, void* xs, bool xs_ready, const Fp16Scale* scp, const FftNext* nx) {
   Sizes s;
   if (!conv_fft_supported(a0, ks) || !sizes_of(a0.H, a0.W, ks, &s, a0.circ) || (out_layout == 2 && a0.Cout % 8) || (np != 2 && np != 4 && np != 5) || (np == 5 && a0.Cin % 32)) return hipErrorInvalidValue;
   if (a0.circ && (t_in || t_next || merge || in_layout != 0 || out_layout != 0)) return hipErrorInvalidValue;      // windows: fp32 NHWC in and out, nothing fused
+  if (nx && (nx->pool || nx->merge) && (!t_next || (nx->pool && nx->merge))) return hipErrorInvalidValue;
   Fp16Scale sc;
   if (np >= 4) {
     if (!scp || !scp->tmax || !scp->winv || (t_next && !scp->tmax_next)) return hipErrorInvalidValue;
@@ -397,7 +412,14 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
   ConvArgs ai = a;      // the inverse passes' view: windows keep their valid region only
   if (a0.circ) { ai.H = a0.H - 8; ai.W = a0.W - 8; }
   if (!(fft_reg && p.inv_cb == 64 && cfft_cols_inv_reg(s.NY, ai, Yf, T, p.NXH, p.ldy, opad, st, sc.t16_inv, yinv))) cfft_cols_inv(s.NY, ai, Yf, T, twy, p.NXH, p.ldy, opad, st, sc.t16_inv, yinv);
-  if (t_next) {
+  if (t_next && nx && nx->pool) {
+    Sizes sn;
+    if (!sizes_of((a.H + 1) / 2, (a.W + 1) / 2, nx->ks_next, &sn) ||
+        !cfft_rows_inv_pool_fwd(s.NX, sn.NX, a, T, static_cast<cf*>(t_next), twx, twb + tw_offset(sn.NX), opad, norm, sc, st))
+      return hipErrorInvalidValue;
+  } else if (t_next && nx && nx->merge) {
+    if (!cfft_rows_inv_merge_fwd(s.NX, a, *nx->merge, T, static_cast<cf*>(t_next), twx, opad, norm, sc, st)) return hipErrorInvalidValue;
+  } else if (t_next) {
     if (!(fft_reg && cfft_rows_inv_fwd_reg(s.NX, a, T, static_cast<cf*>(t_next), opad, norm, sc, st))) cfft_rows_inv_fwd(s.NX, a, T, static_cast<cf*>(t_next), twx, opad, norm, sc, st);
   } else if (!(fft_reg && cfft_rows_inv_reg(s.NX, ai, out_layout, T, opad, norm, sc, st))) {
     cfft_rows_inv(s.NX, ai, out_layout, T, twx, opad, norm, sc, st);

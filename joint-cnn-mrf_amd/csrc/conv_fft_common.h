@@ -316,5 +316,11 @@ bool cfft_rows_fwd_reg(int NX, const ConvArgs& a, int layout, cf* T, float* tmax
 bool cfft_rows_fwd_merge_reg(int NX, const ConvArgs& a, const FftMerge& m, int in_layout, cf* T, float* tmax, hipStream_t st, float* t16);
 bool cfft_cols_inv_reg(int NY, const ConvArgs& a, const cf* Yf, cf* T, int NXH, int ldy, int pad, hipStream_t st, float* t16, float y16_inv = 0.f);
 void cfft_rows_inv_fwd(int NX, const ConvArgs& a, const cf* T, cf* Tn, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
+// conv_fft_rows_fused.hip: inverse rows + epilogue + 2x2 max pool + forward rows of the pooled map (NXO points, twiddles two) / + branch merge + forward rows.
+// false: no kernel for this case
+bool cfft_rows_inv_pool_fwd(int NXI, int NXO, const ConvArgs& a, const cf* T, cf* Tn, const cf* twi, const cf* two, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
+bool cfft_rows_inv_merge_fwd(int NX, const ConvArgs& a, const FftMerge& m, const cf* T, cf* Tn, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
+bool cfft_rows_inv_pool_fwd_supported(int NXI, int NXO, int Cout);
+bool cfft_rows_inv_merge_fwd_supported(int NX, const ConvArgs& a, const FftMerge& m);
 }  // namespace cfft
 }  // namespace jcm

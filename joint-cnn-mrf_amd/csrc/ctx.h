@@ -102,6 +102,11 @@ struct jcm_ctx {
   const void* fft_t_in = nullptr;
   void* fft_xs = nullptr;            // transient: the next frequency-domain layer keeps its split input spectra here (training step: the weight gradient reads them)
   bool fft_xs_ready = false;         // ... they are there already (data gradient after the weight gradient of the same layer): skip the forward transforms
+  void* sm_scratch = nullptr;   // sm_fused.hip: partial sums + flags of sm_inv_finish_kernel's cuts (sm_fused_scratch_bytes(), zeroed once)
+  unsigned sm_epoch = 0;        // ... the launch counter its flags carry
+  int fft_fuse = 1;             // fp32 handles, jcm_pd_forward: bit 0 = conv2 -> max pool -> conv3, bit 1 = conv4_fullres -> branch merge -> conv5 handed over in row-transformed form (conv_fft_rows_fused.hip)
+  int fft_next_pool = 0, fft_next_ks = 0;      // transient, with fft_t_next: a 2x2 max pool lies between this layer and the one fft_t_next is for (kernel size fft_next_ks)
+  const void* fft_next_merge = nullptr;        // transient, with fft_t_next: const jcm::FftMerge* -- fft_t_next is the row-transformed MERGED map (this layer = the full-resolution branch)
   const void* fft_merge = nullptr;   // const jcm::FftMerge*: the next frequency-domain layer forms the merged map itself (jcm_pd_forward, conv5)
   int conv9_fft = 1;            // fp32 handles: wide 9x9 layers in the frequency domain (conv_fft.hip) when the shape allows; 0 = fp32 MFMA chain
   int fft_single = 1;           // bf16 handles: the channel GEMM on ONE scaled fp16 part per operand (np = 5; 0 = two bf16 parts, three products)
@@ -187,6 +192,7 @@ T* arena_alloc(jcm_ctx* c, size_t count) {
 
 int arena_reserve(jcm_ctx* c, size_t bytes);
 int dev_alloc(jcm_ctx* c, void** p, size_t bytes);
+int sm_scratch_next(jcm_ctx* c, void** scratch, unsigned* epoch);      // sm_fused_forward's scratch (allocated + zeroed at first use) and the next launch epoch
 const Tensor* find(jcm_ctx* c, const std::string& name);
 int check(jcm_handle h, bool need_final);
 const ConvLayer* conv_of(jcm_ctx* c, const std::string& scope);

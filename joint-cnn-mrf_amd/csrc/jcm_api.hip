@@ -37,6 +37,7 @@ CallOrder::CallOrder(jcm_ctx* ctx) : c(ctx) {
   c->order = this;
   // what an aborted call may have left behind
   c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; c->fft_xs = nullptr; c->fft_xs_ready = false; c->fft_tmax_in = nullptr;
+  c->fft_next_pool = 0; c->fft_next_ks = 0; c->fft_next_merge = nullptr;
   // the fp16-scale words are reused from the start only BETWEEN calls (a call keeps words of its early layers until its last ones: the training step)
   if (c->fft_block_i > 0 || c->fft_word_i > jcm_ctx::kFftWords - jcm_ctx::kFftWordsPerCall) {
     for (int i = 0; i <= c->fft_block_i && i < (int)c->fft_blocks.size(); ++i)
@@ -84,6 +85,22 @@ int dev_alloc(jcm_ctx* c, void** p, size_t bytes) {
   HIP_TRY(hipMalloc(p, bytes));
   c->owned.push_back(*p);
   c->param_bytes += bytes;
+  return JCM_OK;
+}
+
+// the balanced spatial-model kernel's partial sums + flags (sm_fused.hip): allocated and zeroed once per handle; every launch takes the next epoch
+int sm_scratch_next(jcm_ctx* c, void** scratch, unsigned* epoch) {
+  if (!c->sm_scratch) {
+    const size_t n = sm_fused_scratch_bytes();
+    JCM_TRY(dev_alloc(c, &c->sm_scratch, n));
+    HIP_TRY(hipMemsetAsync(c->sm_scratch, 0, n, c->stream));
+  }
+  if (++c->sm_epoch == 0) {      // (the counter wrapped: flags of 2^32 launches ago could match -- start over from zeroed flags)
+    HIP_TRY(hipMemsetAsync(c->sm_scratch, 0, sm_fused_scratch_bytes(), c->stream));
+    c->sm_epoch = 1;
+  }
+  *scratch = c->sm_scratch;
+  *epoch = c->sm_epoch;
   return JCM_OK;
 }
 
@@ -256,7 +273,7 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
   const int np = fft_np(c);      // operand form of the channel GEMM (cgemm_split.hip)
   void* work = arena_alloc<char>(c, conv_fft_workspace_bytes(a, L->ks, np));
   c->arena_off = mark;                                   // scratch of this layer only: later layers run behind it on the stream
-  if (c->dry) { c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; c->fft_xs = nullptr; c->fft_xs_ready = false; c->fft_tmax_in = nullptr; return JCM_OK; }
+  if (c->dry) { c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; c->fft_xs = nullptr; c->fft_xs_ready = false; c->fft_tmax_in = nullptr; c->fft_next_pool = 0; c->fft_next_ks = 0; c->fft_next_merge = nullptr; return JCM_OK; }
   // Filter spectra are cached per (layer, map size).  The cache is bounded (JCM_FFT_CACHE_GB, default 64): a caller that walks many
   // image sizes (7.7 GB per size for conv5) makes it drop every spectrum that is not this layer's before it grows past the bound.
   const std::string key = scope + (circ ? "@win" : "@") + std::to_string(H) + "x" + std::to_string(W);
@@ -319,6 +336,9 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
   const FftMerge* mg = static_cast<const FftMerge*>(c->fft_merge);
   void* xs = c->fft_xs;
   const bool xs_ready = c->fft_xs_ready;
+  FftNext nx;
+  nx.pool = c->fft_next_pool; nx.ks_next = c->fft_next_ks; nx.merge = static_cast<const FftMerge*>(c->fft_next_merge);
+  c->fft_next_pool = 0; c->fft_next_ks = 0; c->fft_next_merge = nullptr;
   Fp16Scale sc;
   if (np >= 4) {
     // the word of this layer's input: handed over with t_in / ready spectra, or a fresh one for this layer's own row pass
@@ -334,7 +354,7 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
   c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; c->fft_xs = nullptr; c->fft_xs_ready = false;
   c->fft_tmax_in = sc.tmax_next;      // the next frequency-domain layer takes t_next (and its word)
   c->fft_last_tmax = sc.tmax;
-  const hipError_t e = conv_fft_f32(a, L->ks, np, in_layout, out_layout, work, t_in, t_next, mg, g0, g1, c->stream, xs, xs_ready, np >= 4 ? &sc : nullptr);
+  const hipError_t e = conv_fft_f32(a, L->ks, np, in_layout, out_layout, work, t_in, t_next, mg, g0, g1, c->stream, xs, xs_ready, np >= 4 ? &sc : nullptr, &nx);
   if (g0 && g1 && e == hipSuccess) c->prof[scope + "/gemm"].emplace_back(g0, g1);
   else { if (g0) c->event_pool.push_back(g0); if (g1) c->event_pool.push_back(g1); }
   prof_end(c, scope, e0, e1, e == hipSuccess);
@@ -524,7 +544,6 @@ bool takes_strip(const ConvLayer* L, int B, int H, int W) {
   return conv_strip_bf16_supported(a, L->ks);
 }
 
-// model(x, n_joints), main.py:29-74.  x fp32 NHWC; intermediate activations fp32 or bf16.
 // will this bf16 5x5 layer run on conv5_strip_bf16_kernel (which reads and writes either activation layout)?
 bool takes_c5strip(const ConvLayer* L, int B, int H, int W) {
   if (!L->wp_bf16 || L->ks != 5 || conv_igemm_bf16_bn(L->cout, L->ks) != 128 || L->cout % 8) return false;
@@ -545,6 +564,20 @@ static void* offer_handover(jcm_ctx* c, const ConvLayer* La, const ConvLayer* Lb
   c->fft_t_next = t;
   return t;
 }
+// ... with the 2x2 max pool of main.py:47,55,64 between them: La runs on H x W, Lb on the pooled map; the fused kernel (conv_fft_rows_fused.hip) pools
+// a row pair in LDS and writes Lb's row-transformed input -- neither La's output nor the pooled map reaches HBM.
+static void* offer_pool_handover(jcm_ctx* c, const ConvLayer* La, const ConvLayer* Lb, int B, int H, int W) {
+  if (!(c->fft_fuse & 1) || c->precision != JCM_PRECISION_F32 || !takes_fft(c, La, B, H, W) || !takes_fft(c, Lb, B, (H + 1) / 2, (W + 1) / 2)) return nullptr;
+  ConvArgs a{};
+  a.B = B; a.H = H; a.W = W; a.Cin = La->cin; a.Cout = La->cout;
+  if (La->cout != Lb->cin || !conv_fft_pool_fusable(a, La->ks, Lb->ks)) return nullptr;
+  void* t = arena_alloc<char>(c, conv_fft_pool_handover_bytes(a, Lb->ks));
+  c->fft_t_next = t;
+  c->fft_next_pool = 1;
+  c->fft_next_ks = Lb->ks;
+  return t;
+}
+// model(x, n_joints), main.py:29-74.  x fp32 NHWC; intermediate activations fp32 or bf16.
 
 int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logits) {
   static const char* const kRes[3] = {"fullres", "halfres", "quarterres"};
@@ -556,23 +589,45 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
   auto act = [&](size_t elems) { return static_cast<void*>(arena_alloc<char>(c, elems * es)); };
   void* x4[3];
   int h4[3], w4[3];
-  // branch outputs survive the per-branch scratch, so carve them first
   for (int r = 0; r < 3; ++r) {
     const int sub = 1 << r;
-    const int hin = H / sub, win = W / sub;                      // resize_images(x, [H//2, W//2]) main.py:51,60
-    h4[r] = cdiv2(cdiv2(cdiv2(hin)));
-    w4[r] = cdiv2(cdiv2(cdiv2(win)));
-    x4[r] = act((size_t)B * h4[r] * w4[r] * L4->cout);
+    h4[r] = cdiv2(cdiv2(cdiv2(H / sub)));                        // resize_images(x, [H//2, W//2]) main.py:51,60
+    w4[r] = cdiv2(cdiv2(cdiv2(W / sub)));
   }
+  const int hh = h4[0], ww = w4[0];
+  const ConvLayer* L6 = conv_of(c, "conv6");
+  // fp32 handles, model geometry: the full-resolution branch's conv4 hands conv5 the row-transformed MERGED map (conv_fft_rows_fused.hip) -- x1 is never
+  // written.  The coarse branches then have to be there first: the branches run half, quarter, full.
+  FftMerge mg{nullptr, h4[1], w4[1], nullptr, h4[2], w4[2]};
+  bool fuse45 = false;
+  if (!bf && !c->debug_skip && takes_fft(c, L4, B, hh, ww) && takes_fft(c, L5, B, hh, ww) && L4->cout == L5->cin) {
+    ConvArgs a{};
+    a.B = B; a.H = hh; a.W = ww; a.Cin = L4->cin; a.Cout = L4->cout;
+    fuse45 = (c->fft_fuse & 2) && conv_fft_merge_fusable(a, L4->ks, L5->ks, mg);
+  }
+  // branch outputs survive the per-branch scratch, so carve them first
+  void* t45 = nullptr;
+  for (int r = 0; r < 3; ++r) {
+    if (r == 0 && fuse45) {
+      ConvArgs a{};
+      a.B = B; a.H = hh; a.W = ww; a.Cin = L4->cin; a.Cout = L4->cout;
+      t45 = arena_alloc<char>(c, conv_fft_handover_bytes(a, L4->ks));
+      x4[0] = nullptr;
+    } else {
+      x4[r] = act((size_t)B * h4[r] * w4[r] * L4->cout);
+    }
+  }
+  mg.x2 = x4[1]; mg.x3 = x4[2];
   // bf16: the 9x9 chain (conv3 out -> conv4 -> merge -> conv5 -> conv6 in) runs on planar activations [B][C/8][H*W][8]
   // when conv5 takes the strip kernel; every producer / consumer on that chain handles the layout.
-  const ConvLayer* L6 = conv_of(c, "conv6");
   const int planar = bf && L6->thin_bf16 && L4->cout % 8 == 0 && L5->cout % 8 == 0 && takes_strip(L5, B, h4[0], w4[0]) ? 1 : 0;
   // ... except between two frequency-domain layers: their row passes read and write NHWC in whole 128-byte lines per pixel, while a planar
   // tensor gives a lane only the 4 bytes of its channel pair inside a 16-byte unit (3.3 against 4.8 TB/s measured for the inverse row pass).
   // So with conv5 in the frequency domain the chain conv4 -> merge -> conv5 is NHWC; conv5's OUTPUT stays planar for the logits kernel.
   const int planar45 = planar && !takes_fft(c, L5, B, h4[0], w4[0]) ? 1 : 0;
-  for (int r = 0; r < 3; ++r) {
+  static const int kOrder[3] = {1, 2, 0};
+  for (int ri = 0; ri < 3; ++ri) {
+    const int r = kOrder[ri];
     const size_t mark = c->arena_off;
     const std::string res = kRes[r];
     const int sub = 1 << r;
@@ -612,47 +667,49 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
       p1 = act((size_t)B * h2 * w2 * L1->cout);
       if (!c->dry) HIP_TRY(max_pool_2x2(c1, p1, bf, B, h1, w1, L1->cout, c->stream));       // :45,53,62
     }
-    void* c2 = act((size_t)B * h2 * w2 * L2->cout);
     const int h3 = cdiv2(h2), w3 = cdiv2(w2);
+    // fp32 handles: conv2 -> pool2 -> conv3 as one hand-over in row-transformed form (the pool inside the fused row kernel)
+    void* t23 = (bf || sk) ? nullptr : offer_pool_handover(c, L2, L3, B, h2, w2);
+    void* c2 = t23 ? nullptr : act((size_t)B * h2 * w2 * L2->cout);
     // bf16: conv2 -> pool2 -> conv3 on planar activations when both 5x5 layers take the strip kernel (its window rows are then 1-KB
     // contiguous LDS-DMA reads; from NHWC every 16-byte unit of a pixel is a separate cache line).  A planar [B][C/8][H][W][8] tensor IS an
     // NHWC tensor of B*C/8 images with 8 channels: the pooling kernel runs on it unchanged.
     const int pl23 = bf && takes_c5strip(L2, B, h2, w2) && takes_c5strip(L3, B, h3, w3) ? 1 : 0;
     if (!(sk & 4)) JCM_TRY(run_conv(c, "conv2_" + res, 1, p1, B, h2, w2, 1, c2, bf, false, 0, pl23));     // :46,54,63
-    void* p2 = act((size_t)B * h3 * w3 * L2->cout);
-    if (!c->dry && !(sk & 2)) {                                                             // :47,55,64
+    void* p2 = t23 ? nullptr : act((size_t)B * h3 * w3 * L2->cout);
+    if (!c->dry && !(sk & 2) && !t23) {                                                     // :47,55,64
       if (pl23) HIP_TRY(max_pool_2x2(c2, p2, bf, B * (L2->cout / 8), h2, w2, 8, c->stream));
       else HIP_TRY(max_pool_2x2(c2, p2, bf, B, h2, w2, L2->cout, c->stream));
     }
-    void* c3 = act((size_t)B * h3 * w3 * L3->cout);
     const ConvLayer* L4r = conv_of(c, "conv4_" + res);
     if (!L4r) return fail(JCM_ERR_STATE, "part-detector parameters incomplete (conv4_" + res + ")");
     const int in4 = planar && L3->cout % 8 == 0 && takes_strip(L4r, B, h3, w3) && !takes_fft(c, L4r, B, h3, w3) ? 1 : 0;      // the patch kernels and the row pass read NHWC
     void* t34 = (sk & 24) ? nullptr : offer_handover(c, L3, L4r, B, h3, w3);      // (no hand-over when either side is left out)
+    void* c3 = t34 ? nullptr : act((size_t)B * h3 * w3 * L3->cout);
+    c->fft_t_in = t23;
     if (!(sk & 8)) JCM_TRY(run_conv(c, "conv3_" + res, 1, p2, B, h3, w3, 1, c3, bf, false, pl23, in4));   // :48,56,65
     c->fft_t_in = t34;
+    if (r == 0 && fuse45) { c->fft_t_next = t45; c->fft_next_merge = &mg; }      // conv4_fullres writes conv5's row-transformed (merged) input
     if (!(sk & 16)) JCM_TRY(run_conv(c, "conv4_" + res, 1, c3, B, h3, w3, 1, x4[r], bf, false, in4, planar45));   // :49,57,66
     c->arena_off = mark;
   }
-  const int hh = h4[0], ww = w4[0];
   // conv5 in the frequency domain: its forward row kernel forms ((x1 + up(x2)) + up(x3)) / 3 while it loads the rows (NHWC inputs: fp32, or
-  // bf16 on a bf16 handle, where the merged value is rounded to bf16 as the separate merge kernel's output would be).  (A variant with the
-  // x1 row prefetched by persistent work groups put the 8 tap gathers per element on the tile's critical path: 4.5 ms against 1.1 + 1.1 ms
-  // for the separate merge kernel + plain row pass at B = 256.)
+  // bf16 on a bf16 handle, where the merged value is rounded to bf16 as the separate merge kernel's output would be) -- unless conv4_fullres
+  // handed the row-transformed merged map over already (fuse45, fp32 handles).
   // (Round 5 measured the alternative for bf16 handles -- the merge as its own bandwidth-bound kernel + conv5's register row pass: 20.45 against
   // 20.11 ms per 256-image step with the fused kernel, three interleaved runs each: writing and re-reading the 1.4 GB merged tensor costs more
   // than the fused kernel's slower rows.)
-  const bool fuse_merge = takes_fft(c, L5, B, hh, ww) && !planar45;
-  FftMerge mg{x4[1], h4[1], w4[1], x4[2], h4[2], w4[2]};
-  void* merged = fuse_merge ? x4[0] : act((size_t)B * hh * ww * L4->cout);
-  if (!c->dry && !fuse_merge && !(c->debug_skip & 32)) {                                   // :58,67,69-70
+  const bool fuse_merge = !fuse45 && takes_fft(c, L5, B, hh, ww) && !planar45;
+  void* merged = fuse45 ? nullptr : fuse_merge ? x4[0] : act((size_t)B * hh * ww * L4->cout);
+  if (!c->dry && !fuse45 && !fuse_merge && !(c->debug_skip & 32)) {                        // :58,67,69-70
     if (planar45) HIP_TRY(upsample_merge3_planar(x4[0], x4[1], h4[1], w4[1], x4[2], h4[2], w4[2], merged, B, hh, ww, L4->cout, c->stream));
     else HIP_TRY(upsample_merge3(x4[0], x4[1], h4[1], w4[1], x4[2], h4[2], w4[2], merged, bf, B, hh, ww, L4->cout, c->stream));
   }
-  void* c5 = act((size_t)B * hh * ww * L5->cout);
   const int sk = c->debug_skip;
   void* t56 = (sk & 96) ? nullptr : offer_handover(c, L5, conv_of(c, "conv6"), B, hh, ww);
+  void* c5 = t56 ? nullptr : act((size_t)B * hh * ww * L5->cout);
   if (fuse_merge && !(sk & 32)) c->fft_merge = &mg;
+  if (fuse45) c->fft_t_in = t45;
   if (!(sk & 32)) JCM_TRY(run_conv(c, "conv5", 1, merged, B, hh, ww, 1, c5, bf, false, planar45, planar));   // :71
   c->fft_t_in = t56;
   if (!(sk & 64)) JCM_TRY(run_conv(c, "conv6", 1, c5, B, hh, ww, 1, logits, bf, true, planar, 0));         // :72
@@ -678,8 +735,11 @@ int sm_forward_impl(jcm_ctx* c, const float* hm, int Ca, const float* extra, int
   if (c->sm_algo == 3) {   // fused: all transforms in LDS, only the 10 likelihood spectra per image leave the CU
     float2* lhat_t = arena_alloc<float2>(c, (size_t)B * kC * kSpec);
     if (c->dry) return JCM_OK;
+    void* scr = nullptr;
+    unsigned epoch = 0;
+    JCM_TRY(sm_scratch_next(c, &scr, &epoch));
     HIP_TRY(sm_fused_forward(hm, Ca, extra, extra_ld, c->bn_sm_scale, c->bn_sm_shift, c->prior_spec_t, c->cond, c->sp_bias, lhat_t, logits, B, c->K, kC,
-                             c->stream));
+                             c->stream, nullptr, scr, epoch));
     return JCM_OK;
   }
   return fail(JCM_ERR_STATE, "sm_algo must be 3 (transforms in LDS) or 1 (direct)");
@@ -764,6 +824,11 @@ int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
   }
   if (k == "fft_windows") {   // allowed at any time (fp32 handles with training state)
     h->fft_win = value != 0;
+    return JCM_OK;
+  }
+  if (k == "fft_fuse") {   // allowed at any time (fp32 handles): bit 0 = conv2 -> pool -> conv3, bit 1 = conv4_fullres -> merge -> conv5 as fused hand-overs
+    if (value < 0 || value > 3) return fail(JCM_ERR_ARG, "fft_fuse must be 0..3 (bit 0: pool hand-over, bit 1: merge hand-over)");
+    h->fft_fuse = (int)value;
     return JCM_OK;
   }
   if (k == "fft_t16") {   // allowed at any time (bf16 handles, fft_single = 1)

@@ -611,7 +611,10 @@ int sm_train_impl(jcm_ctx* c, const float* pd_prob, const float* y, int B, float
                            c->params["bn_sm/BatchNorm/moving_variance"].d, t->red, c->stream));              // main.py:113
     HIP_TRY(bn_fold_stats(bs->mean, bs->rstd, find(c, "bn_sm/BatchNorm/gamma")->d, find(c, "bn_sm/BatchNorm/beta")->d, sc, sh, kC, c->stream));
     HIP_TRY(sm_pad_frame(hm10, kC, nullptr, sc, sh, frame, B, kC, c->stream));
-    HIP_TRY(sm_fused_forward(hm10, kC, nullptr, 0, sc, sh, c->prior_spec_t, c->cond, c->sp_bias, lhat, sml, B, K, kC, c->stream, tsave));   // main.py:117-123
+    void* scr = nullptr;
+    unsigned epoch = 0;
+    JCM_TRY(sm_scratch_next(c, &scr, &epoch));
+    HIP_TRY(sm_fused_forward(hm10, kC, nullptr, 0, sc, sh, c->prior_spec_t, c->cond, c->sp_bias, lhat, sml, B, K, kC, c->stream, tsave, scr, epoch));   // main.py:117-123
     HIP_TRY(softmax_ce(sml, y, B, kHmHW, K, K + 1, gscale, ce_sm, G, K, 0, c->stream));                      // main.py:539
   }
   // ---- backward (sm_train.hip; transforms: sm_lds.hip)

@@ -116,9 +116,17 @@ size_t conv_fft_workspace_bytes(const ConvArgs& a, int ks, int np);
 // t_in / t_next: the row-transformed tensor handed from one frequency-domain layer to the next (fp32 NHWC handles; conv_fft_fusable).
 // merge: a.x is the full-resolution branch x1 and the layer's input is ((x1 + up(x2)) + up(x3)) / 3, formed while the rows are loaded.
 struct FftMerge { const void* x2; int H2, W2; const void* x3; int H3, W3; };      // x1 (a.x), x2, x3: NHWC in the layer's input type
+// What lies between this layer and the one t_next is for (fp32 handles, conv_fft_rows_fused.hip): pool = the 2x2/2 SAME max pool (t_next is the
+// row-transformed POOLED map, for a next layer of kernel size ks_next); merge = this layer is the full-resolution branch and t_next the row-transformed
+// merged map ((x1 + up(x2)) + up(x3)) / 3.  Neither: t_next is this layer's own output (same map).
+struct FftNext { int pool = 0; int ks_next = 0; const FftMerge* merge = nullptr; };
 // xs / xs_ready: keep the split activation spectra in a caller buffer (conv_fft_xs_bytes) / they are there already (skip the forward transforms)
 hipError_t conv_fft_f32(const ConvArgs& a, int ks, int np, int in_layout, int out_layout, void* work, const void* t_in, void* t_next, const FftMerge* merge,
-                        hipEvent_t g0, hipEvent_t g1, hipStream_t st, void* xs = nullptr, bool xs_ready = false, const Fp16Scale* sc = nullptr);
+                        hipEvent_t g0, hipEvent_t g1, hipStream_t st, void* xs = nullptr, bool xs_ready = false, const Fp16Scale* sc = nullptr, const FftNext* nx = nullptr);
+// the fused hand-overs of FftNext: is there a kernel for this pair of layers, and the size of the row-transformed tensor handed over
+bool conv_fft_pool_fusable(const ConvArgs& a, int ks, int ks_next);
+size_t conv_fft_pool_handover_bytes(const ConvArgs& a, int ks_next);
+bool conv_fft_merge_fusable(const ConvArgs& a, int ks, int ks_next, const FftMerge& m);
 size_t conv_fft_xs_bytes(const ConvArgs& a, int ks, int np);
 // NHWC fp32 -> split spectra (the two forward passes); np = 4: tmax = the (zeroed) device word of this tensor
 hipError_t conv_fft_spectra(const ConvArgs& a, int ks, int np, void* work, void* xs, hipStream_t st, float* tmax = nullptr, int common = 0);
@@ -255,7 +263,10 @@ hipError_t sm_resize_frame(const float* cfull, float* out, int B, hipStream_t st
 // tsave (may be null): [B][P][5400] the argument of every pairwise log, kept for the training step's backward pass
 hipError_t sm_fused_forward(const float* hm, int Ca, const float* extra, int extra_ld, const float* sc, const float* sh, const float2* phat_t,
                             const int* cond, const float* spbias, float2* lhat_t, float* logits, int B, int K, int C, hipStream_t st,
-                            float* tsave = nullptr);
+                            float* tsave, void* scratch, unsigned epoch);
+// scratch: sm_fused_scratch_bytes() bytes owned by the handle, ZEROED once (partial sums + flags of the balanced kernel's cuts); epoch: a counter of the
+// handle, > 0, incremented for every launch (the flags carry it, so they are never reset)
+size_t sm_fused_scratch_bytes();
 // the first half alone: lhat_t[b][c] = transposed half spectrum of the frame of channel c of image b (sc null: the raw map)
 hipError_t sm_fused_spectra(const float* hm, int Ca, const float* extra, int extra_ld, const float* sc, const float* sh, float2* lhat_t, int B, int C,
                             hipStream_t st);

@@ -21,6 +21,8 @@
 // bank-conflict free.  The kernels are VALU-bound (a pair is 0.8 M lane-instructions), not LDS- or HBM-bound.
 // Unnormalised transforms, 1/(120*180) folded into the product;
 // the imaginary parts of the DC / Nyquist bins of a row are dropped as a C2R transform drops them.
+#include <atomic>
+
 #include "sm_lds_fft.h"
 
 namespace jcm {
@@ -66,17 +68,28 @@ __global__ __launch_bounds__(NT) void sm_fwd_spectra_kernel(const float* __restr
 
 // logits[b][pix][j] = log(lik[b][j][pix] + 1e-6) + sum over the C-1 pairs p of joint j, graph order, of
 //                     log(R(lik[b][cond p] * prior p)[pix] + spb[p][pix] + 1e-6)                        (main.py:117-123)
+//
+// PERSISTENT and BALANCED (round 6).  The unit of work is one (image, joint, pair); a work group owns the 135 KB of LDS of its CU, so one runs per CU, and
+// rounds 2-5 launched one work group per (image, joint): 64 images = 576 work groups on 256 CUs = 2.25 waves, run as 3 (391 us where 272 would do).
+// Now G work groups (one per CU, at most one per (image, joint)) take the U = B K (C-1) units in G contiguous, equal ranges.  A range of >= C-1 units starts
+// inside at most one (image, joint) item and ends inside at most one; the sum of an item's log terms is kept IN GRAPH ORDER across the cut:
+//   * the work group whose range ENDS inside an item does that HEAD first: e = log(lik + 1e-6) + terms 0 .. q-1, stores e in its partial-sum slot and
+//     raises its flag (release at device scope);
+//   * the work group whose range STARTS inside the item does that TAIL last: by then the flag of its predecessor (a lower block index: dispatched no
+//     later, and it publishes after at most C-2 pairs) has long been raised; it reads the partial sums (acquire) and goes on adding terms q .. C-2 in order.
+// Every logit is therefore the same fp32 sum, term by term, as in the one-work-group-per-item kernel, whatever the batch size cuts where.
+// Flags carry the launch's epoch (a counter of the handle), so they are never reset.
 __global__ __launch_bounds__(NT) void sm_inv_finish_kernel(const float* __restrict__ hm, int Ca, const float* __restrict__ extra, int extra_ld,
                                                              const float* __restrict__ sc, const float* __restrict__ sh,
                                                              const float2* __restrict__ lhat_t, const float2* __restrict__ phat_t,
                                                              const int* __restrict__ cond, const float* __restrict__ spb, float* __restrict__ logits, int K,
-                                                             int C, float* __restrict__ tsave) {
+                                                             int C, float* __restrict__ tsave, int nunits, float* __restrict__ part, unsigned* __restrict__ flags,
+                                                             unsigned epoch) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* lds = reinterpret_cast<cf*>(smem);
   cf* cb = lds + CB;
   cf* rb = lds + RB;
   const int tid = threadIdx.x;
-  const int b = blockIdx.x / K, j = blockIdx.x - b * K;
   const int PJ = C - 1;
   make_twiddles(lds, tid);
   // TF-1.x bilinear 61x91 -> 60x90 (main.py:89), the arithmetic of sm_fft.hip, separable: per output row {offset of window rows ylo |
@@ -91,93 +104,162 @@ __global__ __launch_bounds__(NT) void sm_inv_finish_kernel(const float* __restri
     const int ohi = isy ? ((hi >> 1) * PX) * 2 + (hi & 1) : 2 * pos180(89 + hi);
     lds[TY + t] = cf{__uint_as_float((unsigned)olo | ((unsigned)ohi << 16)), f - (float)lo};
   }
-
-  float e[NPIX];
-#pragma unroll
-  for (int i = 0; i < NPIX; ++i) {
-    const int pix = tid + i * NT;
-    e[i] = pix < MHW ? logf(lik_of(hm, Ca, extra, extra_ld, sc, sh, (int64_t)b * MHW + pix, j) + 1e-6f) : 0.f;
-  }
-
   constexpr int NG = NT / WC;                       // packing step: thread = (column pk, row-pair group pg)
   const int pk = tid % WC, pg = tid / WC;
 
-  cf l[NE], q[NE];
-  auto request = [&](int p) __attribute__((always_inline)) {
-    const cf* __restrict__ ls = reinterpret_cast<const cf*>(lhat_t) + ((size_t)b * C + cond[p]) * (WC * FH);
-    const cf* __restrict__ qs = reinterpret_cast<const cf*>(phat_t) + (size_t)p * (WC * FH);
+  // this work group's units [u0, u1)
+  const int G = gridDim.x, w = blockIdx.x;
+  const int u0 = (int)((long long)nunits * w / G), u1 = (int)((long long)nunits * (w + 1) / G);
+  const int i0 = u0 / PJ, q0 = u0 - i0 * PJ;                       // first item, first pair of it
+  const int i1 = (u1 - 1) / PJ, q1 = (u1 - 1) - i1 * PJ + 1;       // last item, one past its last pair
+  // A range holds >= PJ units (host), so it starts inside at most one item (its TAIL: pairs q0 ..) and ends inside at most one (its HEAD: pairs .. q1 - 1),
+  // and a range inside ONE item is that whole item.  Processing order: the head first, the whole items, the tail last.
+  const bool tail = q0 > 0, head = q1 < PJ;
+  const int f0 = tail ? i0 + 1 : i0, f1 = head ? i1 - 1 : i1;      // whole items f0 .. f1 (possibly none)
+  const int nfull = f1 - f0 + 1, nseg = (head ? 1 : 0) + nfull + (tail ? 1 : 0);
+  for (int sgi = 0; sgi < nseg; ++sgi) {
+    int item, qa = 0, qb = PJ;
+    bool is_head = false, is_tail = false;
+    const int kf = sgi - (head ? 1 : 0);
+    if (head && sgi == 0) { item = i1; qb = q1; is_head = true; }
+    else if (kf < nfull) { item = f0 + kf; }
+    else { item = i0; qa = q0; is_tail = true; }
+    const int b = item / K, j = item - b * K;
+
+    cf l[NE], q[NE];
+    auto request = [&](int p) __attribute__((always_inline)) {
+      const cf* __restrict__ ls = reinterpret_cast<const cf*>(lhat_t) + ((size_t)b * C + cond[p]) * (WC * FH);
+      const cf* __restrict__ qs = reinterpret_cast<const cf*>(phat_t) + (size_t)p * (WC * FH);
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      const int idx = tid + i * NT;
-      if (idx < WC * FH) { l[i] = ls[idx]; q[i] = qs[idx]; }
-    }
-  };
-  request(j * PJ);
-  for (int qq = 0; qq < PJ; ++qq) {
-    const int p = j * PJ + qq;
-    // spectrum product -> cb[v][u] (the previous pair's column buffer was last read before the barrier that closed its packing step)
-    constexpr float scale = 1.0f / (float)(FH * FW);
+      for (int i = 0; i < NE; ++i) {
+        const int idx = tid + i * NT;
+        if (idx < WC * FH) { l[i] = ls[idx]; q[i] = qs[idx]; }
+      }
+    };
+    request(j * PJ + qa);
+    float e[NPIX];
+    if (is_tail) {
+      // the partial sums of the work group in front (its head of this item): wait for its flag, then read them at device scope
+      if (tid == 0) {
+        while (__hip_atomic_load(flags + (w - 1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(8);
+      }
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const float* __restrict__ ps = part + (size_t)(w - 1) * MHW;
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      const int idx = tid + i * NT;
-      if (idx < WC * FH) cb[idx + idx / FH] = scale * cmul(l[i], q[i]);       // [v][u] with pitch 121 = 120 + 1
-    }
-    __syncthreads();
-    fft120<PU, 1, WC>(cb, lds + TW120, tid);
-    // rows 59 + 2i (real part) and 60 + 2i (imaginary part) of the frame as ONE complex inverse transform: Z = X_a + i X_b with the
-    // Hermitian extension X[180 - k] = conj X[k]: one read of X_a[k], X_b[k] gives Z[k] and Z[180 - k]
-    if (pg < NG) {
-      const bool edge = pk == 0 || pk == FW / 2;       // DC / Nyquist: real by symmetry; a C2R transform ignores their imaginary parts
-      for (int i = pg; i < NROWP; i += NG) {
-        cf xa = cb[pk * PU + pos120(59 + 2 * i)];
-        cf xb = i < 30 ? cb[pk * PU + pos120(60 + 2 * i)] : cf{0.f, 0.f};
-        if (edge) { xa.y = 0.f; xb.y = 0.f; }
-        rb[i * PX + pk] = cf{xa.x - xb.y, xa.y + xb.x};
-        if (!edge) rb[i * PX + FW - pk] = cf{xa.x + xb.y, xb.x - xa.y};
+      for (int i = 0; i < NPIX; ++i) {
+        const int pix = tid + i * NT;
+        e[i] = pix < MHW ? __builtin_nontemporal_load(ps + pix) : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPIX; ++i) {
+        const int pix = tid + i * NT;
+        e[i] = pix < MHW ? logf(lik_of(hm, Ca, extra, extra_ld, sc, sh, (int64_t)b * MHW + pix, j) + 1e-6f) : 0.f;
       }
     }
-    __syncthreads();
-    if (qq + 1 < PJ) request(p + 1);      // lands behind the row transforms and the epilogue (the registers are free of the column butterflies now)
-    fft180<PX, 1, NROWP>(rb, lds + TW180, tid);
-    // VALID window Cpre[yy][xx] = frame[59 + yy][89 + xx] -> resize -> + bias, + 1e-6, log
-    const float* rbf = reinterpret_cast<const float*>(rb);
-    const float* __restrict__ bias = spb + (size_t)p * MHW;
+    for (int qq = qa; qq < qb; ++qq) {
+      const int p = j * PJ + qq;
+      // spectrum product -> cb[v][u] (the previous pair's column buffer was last read before the barrier that closed its packing step)
+      constexpr float scale = 1.0f / (float)(FH * FW);
 #pragma unroll
-    for (int i = 0; i < NPIX; ++i) {
-      const int pix = tid + i * NT;
-      if (pix < MHW) {
-        const int oy = pix / MW, ox = pix - oy * MW;
-        const cf cy = lds[TY + oy], cx = lds[TX + ox];
-        const unsigned ry = __float_as_uint(cy.x), rx = __float_as_uint(cx.x);
-        const unsigned rlo = ry & 0xffffu, rhi = ry >> 16, plo = rx & 0xffffu, phi = rx >> 16;
-        const float tl = rbf[rlo + plo], tr = rbf[rlo + phi];
-        const float bl = rbf[rhi + plo], br = rbf[rhi + phi];
-        const float top = tl + (tr - tl) * cx.y;
-        const float bot = bl + (br - bl) * cx.y;
-        const float cv = top + (bot - top) * cy.y;
-        const float tv = (cv + bias[pix]) + 1e-6f;
-        if (tsave) tsave[((size_t)b * (K * PJ) + p) * MHW + pix] = tv;      // training step: the log's argument is the backward pass's denominator
-        e[i] += __logf(tv);      // v_log_f32 * ln 2: the argument is a normal number >= 1e-6
+      for (int i = 0; i < NE; ++i) {
+        const int idx = tid + i * NT;
+        if (idx < WC * FH) cb[idx + idx / FH] = scale * cmul(l[i], q[i]);       // [v][u] with pitch 121 = 120 + 1
+      }
+      __syncthreads();
+      fft120<PU, 1, WC>(cb, lds + TW120, tid);
+      // rows 59 + 2i (real part) and 60 + 2i (imaginary part) of the frame as ONE complex inverse transform: Z = X_a + i X_b with the
+      // Hermitian extension X[180 - k] = conj X[k]: one read of X_a[k], X_b[k] gives Z[k] and Z[180 - k]
+      if (pg < NG) {
+        const bool edge = pk == 0 || pk == FW / 2;       // DC / Nyquist: real by symmetry; a C2R transform ignores their imaginary parts
+        for (int i = pg; i < NROWP; i += NG) {
+          cf xa = cb[pk * PU + pos120(59 + 2 * i)];
+          cf xb = i < 30 ? cb[pk * PU + pos120(60 + 2 * i)] : cf{0.f, 0.f};
+          if (edge) { xa.y = 0.f; xb.y = 0.f; }
+          rb[i * PX + pk] = cf{xa.x - xb.y, xa.y + xb.x};
+          if (!edge) rb[i * PX + FW - pk] = cf{xa.x + xb.y, xb.x - xa.y};
+        }
+      }
+      __syncthreads();
+      if (qq + 1 < qb) request(p + 1);      // lands behind the row transforms and the epilogue (the registers are free of the column butterflies now)
+      fft180<PX, 1, NROWP>(rb, lds + TW180, tid);
+      // VALID window Cpre[yy][xx] = frame[59 + yy][89 + xx] -> resize -> + bias, + 1e-6, log
+      const float* rbf = reinterpret_cast<const float*>(rb);
+      const float* __restrict__ bias = spb + (size_t)p * MHW;
+#pragma unroll
+      for (int i = 0; i < NPIX; ++i) {
+        const int pix = tid + i * NT;
+        if (pix < MHW) {
+          const int oy = pix / MW, ox = pix - oy * MW;
+          const cf cy = lds[TY + oy], cx = lds[TX + ox];
+          const unsigned ry = __float_as_uint(cy.x), rx = __float_as_uint(cx.x);
+          const unsigned rlo = ry & 0xffffu, rhi = ry >> 16, plo = rx & 0xffffu, phi = rx >> 16;
+          const float tl = rbf[rlo + plo], tr = rbf[rlo + phi];
+          const float bl = rbf[rhi + plo], br = rbf[rhi + phi];
+          const float top = tl + (tr - tl) * cx.y;
+          const float bot = bl + (br - bl) * cx.y;
+          const float cv = top + (bot - top) * cy.y;
+          const float tv = (cv + bias[pix]) + 1e-6f;
+          if (tsave) tsave[((size_t)b * (K * PJ) + p) * MHW + pix] = tv;      // training step: the log's argument is the backward pass's denominator
+          e[i] += __logf(tv);      // v_log_f32 * ln 2: the argument is a normal number >= 1e-6
+        }
+      }
+      __syncthreads();      // the row buffer is rewritten by the next pair's packing step (its column buffer is free already)
+    }
+    if (is_head) {
+      float* __restrict__ ps = part + (size_t)w * MHW;
+#pragma unroll
+      for (int i = 0; i < NPIX; ++i) {
+        const int pix = tid + i * NT;
+        if (pix < MHW) __builtin_nontemporal_store(e[i], ps + pix);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __syncthreads();      // every thread's partial sums are out (and released) before the flag goes up
+      if (tid == 0) __hip_atomic_store(flags + w, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPIX; ++i) {
+        const int pix = tid + i * NT;
+        if (pix < MHW) logits[((size_t)b * MHW + pix) * K + j] = e[i];
       }
     }
-    __syncthreads();      // the row buffer is rewritten by the next pair's packing step (its column buffer is free already)
-  }
-#pragma unroll
-  for (int i = 0; i < NPIX; ++i) {
-    const int pix = tid + i * NT;
-    if (pix < MHW) logits[((size_t)b * MHW + pix) * K + j] = e[i];
   }
 }
 
+// work groups of sm_inv_finish_kernel that are resident at once on this device (one per CU: 135 KB of LDS each)
+static int sm_inv_resident() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int r = cached[dev & 63].load(std::memory_order_relaxed);
+  if (r > 0) return r;
+  int ncu = 256, per_cu = 0;
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sm_inv_finish_kernel, NT, (size_t)LDS_BYTES) != hipSuccess || per_cu < 1) per_cu = 1;
+  r = ncu * per_cu;
+  cached[dev & 63].store(r, std::memory_order_relaxed);
+  return r;
+}
+size_t sm_fused_scratch_bytes() { return (size_t)sm_inv_resident() * (MHW * sizeof(float) + 64); }      // partial sums + one flag word (a cache line) per work group
+
 hipError_t sm_fused_forward(const float* hm, int Ca, const float* extra, int extra_ld, const float* sc, const float* sh, const float2* phat_t,
-                            const int* cond, const float* spbias, float2* lhat_t, float* logits, int B, int K, int C, hipStream_t st, float* tsave) {
+                            const int* cond, const float* spbias, float2* lhat_t, float* logits, int B, int K, int C, hipStream_t st, float* tsave, void* scratch,
+                            unsigned epoch) {
   if (extra_ld <= 0) extra_ld = C - Ca;
+  if (!scratch || epoch == 0) return hipErrorInvalidValue;
   static LdsAttr attr_f, attr_i;
   if (hipError_t e = attr_f.ensure(reinterpret_cast<const void*>(sm_fwd_spectra_kernel), LDS_BYTES); e != hipSuccess) return e;
   if (hipError_t e = attr_i.ensure(reinterpret_cast<const void*>(sm_inv_finish_kernel), LDS_BYTES); e != hipSuccess) return e;
   hipLaunchKernelGGL(sm_fwd_spectra_kernel, dim3(B * C), dim3(NT), LDS_BYTES, st, hm, Ca, extra, extra_ld, sc, sh, lhat_t, C);
   if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-  hipLaunchKernelGGL(sm_inv_finish_kernel, dim3(B * K), dim3(NT), LDS_BYTES, st, hm, Ca, extra, extra_ld, sc, sh, lhat_t, phat_t, cond, spbias, logits, K, C, tsave);
+  // one work group per CU at most, one per (image, joint) at most: every range then holds >= C - 1 units (the kernel's cut rule)
+  const int resident = sm_inv_resident();
+  const int G = B * K < resident ? B * K : resident;
+  float* part = static_cast<float*>(scratch);
+  unsigned* flags = reinterpret_cast<unsigned*>(static_cast<char*>(scratch) + (size_t)resident * MHW * sizeof(float));
+  hipLaunchKernelGGL(sm_inv_finish_kernel, dim3(G), dim3(NT), LDS_BYTES, st, hm, Ca, extra, extra_ld, sc, sh, lhat_t, phat_t, cond, spbias, logits, K, C, tsave, B * K * (C - 1),
+                     part, flags, epoch);
   return hipGetLastError();
 }
 

@@ -19,7 +19,7 @@ def _hm_size(n):
 class Engine:
     """Owns a jcm_handle.  All tensor arguments are torch CUDA float32 NHWC, contiguous."""
 
-    def __init__(self, device=0, precision='fp32', n_joints=9, stream=None, f32_conv=None, split_min_wgs=None, micro_batch=None, conv9_fft=None, call_order=None, fft_single=None, fft_t16=None):
+    def __init__(self, device=0, precision='fp32', n_joints=9, stream=None, f32_conv=None, split_min_wgs=None, micro_batch=None, conv9_fft=None, call_order=None, fft_single=None, fft_t16=None, fft_fuse=None):
         if not torch.cuda.is_available():
             raise RuntimeError('joint-cnn-mrf_amd needs an MI355X (gfx950) GPU; torch.cuda.is_available() is False '
                                'and there is no CPU path')
@@ -48,6 +48,8 @@ class Engine:
             self.set_option('fft_single', int(bool(fft_single)))
         if fft_t16 is not None:       # bf16 engines: False = the row-transformed tensors and the product spectra of the frequency-domain route stay complex fp32 (default: complex fp16)
             self.set_option('fft_t16', int(bool(fft_t16)))
+        if fft_fuse is not None:      # fp32 engines: 0 = separate pool / merge kernels between the frequency-domain layers (A/B arm of the fused hand-overs; default 3)
+            self.set_option('fft_fuse', int(fft_fuse))
         if call_order is not None:    # False (debugging): this engine's calls are not ordered against other engines' on the device
             self.set_option('call_order', int(bool(call_order)))
         if split_min_wgs is not None: # 0 forces the split kernels even on grids too small to pay off (parity tests at small batch)

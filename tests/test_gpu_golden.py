@@ -430,3 +430,50 @@ def test_lds_transform_kernels_arm():
                         'test_full_size_tower_vs_golden and exact and trained or test_bf16_tower_vs_bf16_oracle'], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-500:]
+
+
+def test_fused_handovers_vs_separate_kernels_and_golden():
+    """fp32 handles hand conv2 -> max pool -> conv3 and conv4_fullres -> branch merge -> conv5 over in row-transformed form (option "fft_fuse",
+    conv_fft_rows_fused.hip).  The separate kernels of round 5 (fft_fuse = 0) stay as the A/B arm: both arms to the float64 goldens at full
+    size, and against each other to rounding -- the two arms evaluate the same fp32 expressions per element (the half- and quarter-resolution
+    epilogues differ by fused multiply-adds only)."""
+    from joint_cnn_mrf_amd.engine import Engine
+    x, torso, p = full_inputs()
+    p.update(synth.make_sm_params(flic_priors(), kind='trained', seed=seeds()['sm']))
+    ref_pd = load('full_pd_logits')
+    scale = max(1.0, float(np.abs(ref_pd).max()))
+    out = {}
+    for fuse in (3, 0, 1, 2):
+        eng = Engine(device=0, fft_fuse=fuse).load_params(p)
+        logits = eng.model(dev(x)).cpu().numpy()
+        r = eng.forward(dev(x), dev(torso), use_sm=True)
+        # a batch with a ragged tail of tiles per work group, and single images: the persistent kernels walk other tile sequences
+        x5 = np.concatenate([x, synth.make_images(3, seed=66)], axis=0)
+        l5 = eng.model(dev(x5)).cpu().numpy()
+        eng.close()
+        assert np.abs(logits - ref_pd).max() <= 2e-4 * scale, fuse
+        np.testing.assert_allclose(r['pd_prob'].cpu().numpy(), O.spatial_softmax(ref_pd.astype(np.float64)), atol=1e-4, rtol=0)
+        np.testing.assert_array_equal(r['pd_coords'].cpu().numpy(), load('full_pd_coords'))
+        np.testing.assert_array_equal(r['sm_coords'].cpu().numpy(), load('full_sm_coords_trained'))
+        assert np.array_equal(l5[:2], logits), fuse                    # an image's result does not depend on its batch
+        out[fuse] = l5
+    for fuse in (0, 1, 2):
+        assert np.abs(out[fuse] - out[3]).max() <= 2e-5 * scale, (fuse, float(np.abs(out[fuse] - out[3]).max()))
+
+
+@pytest.mark.parametrize('hw', [(240, 360), (256, 384), (200, 296)])
+def test_fused_handovers_other_geometries(hw):
+    """The fused hand-overs exist for the model's transform lengths; other image sizes (odd pooled maps, other lengths) take them where the
+    lengths match and the separate kernels elsewhere -- every size against the oracle at --debug width and against the unfused arm."""
+    from joint_cnn_mrf_amd.engine import Engine
+    H, W = hw
+    p = synth.make_pd_params(debug=True, bn='trained', conv6_gain=8.0)
+    x = synth.make_images(3, seed=31, height=H, width=W)
+    ref = O.model(x, p)
+    got = {}
+    for fuse in (3, 0):
+        eng = Engine(device=0, fft_fuse=fuse).load_params(p)
+        got[fuse] = eng.model(dev(x)).cpu().numpy()
+        eng.close()
+        assert np.abs(got[fuse] - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), fuse
+    assert np.abs(got[0] - got[3]).max() <= 2e-5 * max(1.0, np.abs(ref).max())
