@@ -418,7 +418,9 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
         !cfft_rows_inv_pool_fwd(s.NX, sn.NX, a, T, static_cast<cf*>(t_next), twx, twb + tw_offset(sn.NX), opad, norm, sc, st))
       return hipErrorInvalidValue;
   } else if (t_next && nx && nx->merge) {
-    if (!cfft_rows_inv_merge_fwd(s.NX, a, *nx->merge, T, static_cast<cf*>(t_next), twx, opad, norm, sc, st)) return hipErrorInvalidValue;
+    if (!(fft_reg && cfft_rows_inv_merge_fwd_reg(s.NX, a, *nx->merge, T, static_cast<cf*>(t_next), opad, norm, sc, st)) &&
+        !cfft_rows_inv_merge_fwd(s.NX, a, *nx->merge, T, static_cast<cf*>(t_next), twx, opad, norm, sc, st))
+      return hipErrorInvalidValue;
   } else if (t_next) {
     if (!(fft_reg && cfft_rows_inv_fwd_reg(s.NX, a, T, static_cast<cf*>(t_next), opad, norm, sc, st))) cfft_rows_inv_fwd(s.NX, a, T, static_cast<cf*>(t_next), twx, opad, norm, sc, st);
   } else if (!(fft_reg && cfft_rows_inv_reg(s.NX, ai, out_layout, T, opad, norm, sc, st))) {

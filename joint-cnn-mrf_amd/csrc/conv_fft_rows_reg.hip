@@ -622,6 +622,168 @@ bool cfft_rows_inv_fwd_reg(int NX, const ConvArgs& a, const cf* T, cf* Tn, int p
   return true;
 }
 
+// ---- rows, inverse of the full-resolution branch's conv4 + epilogue + BRANCH MERGE + rows, forward of conv5 (the contract of rows_inv_merge_fwd_kernel,
+// conv_fft_rows_fused.hip, for the model's geometry: 90-column maps, x2 at half and x3 at a quarter of the width): x1 never reaches HBM.
+// rows_inv_fwd_reg_kernel with one more step between the transforms: merged = ((act(x1) + up(x2)) + up(x3)) / 3 (main.py:58,67,69-70).  The coarse rows a
+// fine row needs -- two source rows of x2 and of x3 -- are lerped ALONG Y FIRST by the wave that owns the row (the same for its 32 channel pairs: the row
+// taps are scalars) and staged in the wave's own LDS slice as [x2: 45 columns + a copy of the last | x3: 23 columns][32 pairs]; the lerp along x then
+// reads two staged neighbours per map at compile-time offsets (x2: columns i, i + 1 with weight 0 or 1/2 by the thread's parity; x3: the TF-1.x taps of
+// UpTaps<90, 23>, the thread's parity picks between two literals).  TF lerps along x first: the two orders differ in the last fp32 bit of the coarse terms
+// (as in rows_fwd_merge_reg_kernel), eight orders of magnitude below the 1e-4 the heat maps are held to.  No work-group barrier: a wave reads what it wrote.
+template <int NX, int PAD, int W, int W3, int IPX, class Act>
+__device__ __forceinline__ cf merged_px(cf z, bool odd, const cf* c2, const cf* c3, float t2h, Act&& act) {      // pixel n = 2 IPX + h of this thread
+  using T3 = UpTaps<W, W3>;
+  const cf a = act(z);
+  const cf l2 = c2[IPX * 32], r2 = c2[(IPX + 1) * 32];
+  const cf u2 = cf{l2.x + (r2.x - l2.x) * t2h, l2.y + (r2.y - l2.y) * t2h};
+  constexpr int n0 = 2 * IPX, n1 = 2 * IPX + 1;
+  const int lo = odd ? T3::lo(n1) * 32 : T3::lo(n0) * 32, hi = odd ? T3::hi(n1) * 32 : T3::hi(n0) * 32;
+  const float t3 = odd ? T3::t(n1) : T3::t(n0);
+  const cf l3 = c3[lo], r3 = c3[hi];
+  const cf u3 = cf{l3.x + (r3.x - l3.x) * t3, l3.y + (r3.y - l3.y) * t3};
+  return cf{div3((a.x + u2.x) + u3.x), div3((a.y + u2.y) + u3.y)};
+}
+template <int NX, int PAD, int W, int W3, int I, class Act>
+__device__ __forceinline__ void fused_rows_mid_merge(const cf (&x)[NX / 2], cf (&uu)[NX / 2], bool odd, const cf* c2, const cf* c3, float t2h, Act&& act) {
+  constexpr int M = NX / 2, R1 = RPlan<M>::R1, R2 = RPlan<M>::R2, Q = M / 2;
+  static_assert(W % 2 == 0 && PAD % 2 == 0, "a thread's pixels 2 i + h are inside the map for both parities or for neither");
+  constexpr int ma = I + PAD / 2, mb = I + Q + PAD / 2;      // sample indices of pixels 2 I + h and 2 (I + Q) + h
+  cf a = cf{0.f, 0.f}, bq = cf{0.f, 0.f};
+  if constexpr (ma < M && 2 * I < W) a = merged_px<NX, PAD, W, W3, I>(x[R2 * (ma % R1) + ma / R1], odd, c2, c3, t2h, act);
+  if constexpr (mb < M && 2 * (I + Q) < W) bq = merged_px<NX, PAD, W, W3, I + Q>(x[R2 * (mb % R1) + mb / R1], odd, c2, c3, t2h, act);
+  const cf sm = a + bq, df = a - bq;                         // j = 2 I + h:  z[j] + z[j + M],  z[j] - z[j + M]
+  const cf keep = cf{odd ? df.x : sm.x, odd ? df.y : sm.y}, send = cf{odd ? sm.x : df.x, odd ? sm.y : df.y};
+  const cf recv = cf{__uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(send.x), 0xB1, 0xF, 0xF, true)),
+                     __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(send.y), 0xB1, 0xF, 0xF, true))};
+  cf e = cf{odd ? recv.x : keep.x, odd ? recv.y : keep.y}, o = cf{odd ? keep.x : recv.x, odd ? keep.y : recv.y};
+  if constexpr (I > 0) {
+    const float wr = odd ? Tw<-2 * I, NX>::re : 1.f, wi = odd ? Tw<-2 * I, NX>::im : 0.f;
+    e = cf{fmaf(-e.y, wi, e.x * wr), fmaf(e.x, wi, e.y * wr)};
+  }
+  {
+    const float wr = odd ? Tw<-(2 * I + 1), NX>::re : 1.f, wi = odd ? Tw<-(2 * I + 1), NX>::im : 0.f;
+    o = cf{fmaf(-o.y, wi, o.x * wr), fmaf(o.x, wi, o.y * wr)};
+  }
+  uu[2 * I] = e;
+  uu[2 * I + 1] = o;
+  if constexpr (I % 2 == 1) asm volatile("" ::: "memory");      // two steps' staged reads at a time (the compiler otherwise hoists all of them to the front)
+  if constexpr (I + 1 < Q) fused_rows_mid_merge<NX, PAD, W, W3, I + 1>(x, uu, odd, c2, c3, t2h, act);
+}
+template <int NX, int PAD, int W, int W2, int W3>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void rows_inv_merge_fwd_reg_kernel(const float4* __restrict__ T, float4* __restrict__ Tn, const float* __restrict__ bias,
+                                                                                                        const float* __restrict__ scale, const float* __restrict__ shift, int relu_bn,
+                                                                                                        int nrows, int B, int H, int C, float norm0, Fp16Scale sc,
+                                                                                                        const cf* __restrict__ x2, int H2, const cf* __restrict__ x3, int H3, float sy2,
+                                                                                                        float sy3) {
+  constexpr int NXH = NX / 2 + 1, M = NX / 2;
+  constexpr int NC2 = W2 + 1, NCS = NC2 + W3 + 1;      // staged columns per wave: x2 (+ a copy of its last column), x3 (+ one the loop below writes and nobody reads)
+  static_assert(W == 2 * W2 && W2 % 2 == 1 && W3 % 2 == 1, "the staging loops below walk the coarse columns in pairs");
+  __shared__ cf stage[4][NCS * 32];
+  const int CP = C >> 1;
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int h = (int)(g & 1), lane = threadIdx.x & 63;
+  const int p = (int)((g >> 1) % CP);
+  const size_t by = (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)((g >> 1) / CP));      // the row: the same for the 64 lanes (C % 64 == 0)
+  if (by >= (size_t)nrows) return;
+  const int b = (int)(by / H), y = (int)(by % H), c = 2 * p;
+  const bool odd = h != 0;
+  cf* cs = stage[threadIdx.x >> 6];
+  {
+    // the wave's coarse rows: lanes 0..31 take an even column of the wave's 32 channel pairs, lanes 32..63 the odd one next to it; the image is the
+    // descriptor, the source row and the column pair scalar offsets
+    const int bs = __builtin_amdgcn_readfirstlane(b), c0 = __builtin_amdgcn_readfirstlane(p - (lane >> 1));      // first pair of the wave
+    const Tap ty2 = tf1_tap(y, H2, sy2), ty3 = tf1_tap(y, H3, sy3);
+    const auto d2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(x2) + (size_t)bs * H2 * W2 * CP, 0, H2 * W2 * CP * 8, 0x00020000);
+    const auto d3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(x3) + (size_t)bs * H3 * W3 * CP, 0, H3 * W3 * CP * 8, 0x00020000);
+    const int vo = ((lane >> 5) * CP + c0 + (lane & 31)) * 8, vo_last = (c0 + (lane & 31)) * 8;      // (the last column pair: both halves read the last column)
+    const int r2a = ty2.lo * W2 * CP * 8, r2b = ty2.hi * W2 * CP * 8, r3a = ty3.lo * W3 * CP * 8, r3b = ty3.hi * W3 * CP * 8;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    constexpr int J2 = (W2 + 1) / 2, J3 = (W3 + 1) / 2;
+    cf a2[J2], b2[J2], a3[J3], b3[J3];
+#pragma unroll
+    for (int j = 0; j < J2; ++j) {
+      const int v = j == J2 - 1 ? vo_last : vo;
+      a2[j] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(d2, v, r2a + 2 * j * CP * 8, 0));
+      b2[j] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(d2, v, r2b + 2 * j * CP * 8, 0));
+    }
+#pragma unroll
+    for (int j = 0; j < J3; ++j) {
+      const int v = j == J3 - 1 ? vo_last : vo;
+      a3[j] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(d3, v, r3a + 2 * j * CP * 8, 0));
+      b3[j] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(d3, v, r3b + 2 * j * CP * 8, 0));
+    }
+    __builtin_amdgcn_sched_barrier(0);      // every load is out before the first lerp
+#pragma unroll
+    for (int j = 0; j < J2; ++j) cs[lane + 64 * j] = cf{a2[j].x + (b2[j].x - a2[j].x) * ty2.t, a2[j].y + (b2[j].y - a2[j].y) * ty2.t};
+#pragma unroll
+    for (int j = 0; j < J3; ++j) cs[NC2 * 32 + lane + 64 * j] = cf{a3[j].x + (b3[j].x - a3[j].x) * ty3.t, a3[j].y + (b3[j].y - a3[j].y) * ty3.t};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  cf u[M];
+  {
+    const float4* src = T + (by * NXH * C) / 2 + p;
+    auto load = [&](int k) __attribute__((always_inline)) { return src[(size_t)k * CP]; };      // (Ya.re, Ya.im, Yb.re, Yb.im)
+    inv_rows_load2<NX, false, 0>(u, odd ? -1.f : 1.f, odd, load);
+  }
+  float norm = norm0;
+  if (sc.tmax) {
+    float tm;
+    if (sc.common) {
+      tm = 0.f;
+      for (int i = lane; i < sc.nb; i += 64) tm = fmaxf(tm, sc.tmax[i]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o));
+    } else {
+      tm = sc.tmax[b];
+    }
+    norm = norm0 * sc.winv[0] * fp16_unscale(tm, sc.hf);
+  }
+  const float b0v = bias[c], b1v = bias[c + 1];
+  float s0 = 1.f, s1 = 1.f, h0 = 0.f, h1 = 0.f;
+  if (relu_bn) { s0 = scale[c]; h0 = shift[c]; s1 = scale[c + 1]; h1 = shift[c + 1]; }
+  step1<M, 1>(u);
+  step2_inplace<M, 1, 0>(u);      // u[R2 (m % R1) + m / R1] = X[2 m + h]: the pixel 2 m + h - PAD of this thread's parity
+  cf uu[M];
+  auto act = [&](cf z) __attribute__((always_inline)) {
+    float v0 = fmaf(z.x, norm, b0v), v1 = fmaf(z.y, norm, b1v);
+    if (relu_bn) { v0 = fmaf(fmaxf(v0, 0.f), s0, h0); v1 = fmaf(fmaxf(v1, 0.f), s1, h1); }
+    return cf{v0, v1};
+  };
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const cf* c2 = cs + (lane >> 1);
+  fused_rows_mid_merge<NX, PAD, W, W3, 0>(u, uu, odd, c2, c2 + NC2 * 32, odd ? 0.5f : 0.f, act);
+  step1<M, -1>(uu);
+  step2_inplace<M, -1, 0>(uu);
+  const int cblk = p >> 5, v = p & 31;
+  float4* dst = Tn + ((((size_t)cblk * 4 + (v >> 3)) * B + b) * H + y) * 8 + (v & 7);      // t_fwd_index(k = 0); per kx: + (C / 16) B H 8
+  const size_t kstride = (size_t)(C >> 4) * B * H * 8;
+  float m = 0.f;
+  fwd_rows_visit<NX, 0>(uu, odd, [&](int mi, const float4& o) __attribute__((always_inline)) {
+    const int k = 2 * mi + h;
+    if (k <= M) {
+      dst[(size_t)k * kstride] = o;
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+    }
+  });
+  if (sc.tmax_next) {      // the next layer's per-image word (max |T|) of its spectra's scale
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(sc.tmax_next + b), __float_as_uint(m));
+  }
+}
+// true: launched (the model's geometry: 96-point rows, pad 4, 90 / 45 / 23 columns, whole 64-channel blocks)
+bool cfft_rows_inv_merge_fwd_reg(int NX, const ConvArgs& a, const FftMerge& m, const cf* T, cf* Tn, int pad, float norm, const Fp16Scale& sc, hipStream_t st) {
+  if (NX != 96 || pad != 4 || a.Cout % 64 || a.W != 90 || m.W2 != 45 || m.W3 != 23 || m.H2 < 1 || m.H3 < 1) return false;
+  if ((size_t)m.H2 * m.W2 * a.Cout * 4 >= (size_t)1 << 31) return false;      // one buffer descriptor per coarse image
+  const int nrows = a.B * a.H;
+  const size_t threads = (size_t)nrows * a.Cout;
+  hipLaunchKernelGGL((rows_inv_merge_fwd_reg_kernel<96, 4, 90, 45, 23>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(T), reinterpret_cast<float4*>(Tn),
+                     a.bias, a.scale, a.shift, a.relu_bn, nrows, a.B, a.H, a.Cout, norm, sc, static_cast<const cf*>(m.x2), m.H2, static_cast<const cf*>(m.x3), m.H3,
+                     (float)m.H2 / (float)a.H, (float)m.H3 / (float)a.H);
+  return true;
+}
+
 template <int NX> static bool launch_rows_inv_reg(const ConvArgs& a, int layout, const cf* T, int pad, float norm, const Fp16Scale& sc, hipStream_t st) {
   const int nrows = a.B * a.H;
   if ((a.Cout & 1) || a.CoutP % 64) return false;      // channel pairs are stored as one word; a wave = 32 pairs of ONE row (the kernel keeps the row in scalar registers)

@@ -104,7 +104,7 @@ struct jcm_ctx {
   bool fft_xs_ready = false;         // ... they are there already (data gradient after the weight gradient of the same layer): skip the forward transforms
   void* sm_scratch = nullptr;   // sm_fused.hip: partial sums + flags of sm_inv_finish_kernel's cuts (sm_fused_scratch_bytes(), zeroed once)
   unsigned sm_epoch = 0;        // ... the launch counter its flags carry
-  int fft_fuse = 1;             // fp32 handles, jcm_pd_forward: bit 0 = conv2 -> max pool -> conv3, bit 1 = conv4_fullres -> branch merge -> conv5 handed over in row-transformed form (conv_fft_rows_fused.hip)
+  int fft_fuse = 3;             // fp32 handles, jcm_pd_forward: bit 0 = conv2 -> max pool -> conv3, bit 1 = conv4_fullres -> branch merge -> conv5 handed over in row-transformed form (conv_fft_rows_fused.hip)
   int fft_next_pool = 0, fft_next_ks = 0;      // transient, with fft_t_next: a 2x2 max pool lies between this layer and the one fft_t_next is for (kernel size fft_next_ks)
   const void* fft_next_merge = nullptr;        // transient, with fft_t_next: const jcm::FftMerge* -- fft_t_next is the row-transformed MERGED map (this layer = the full-resolution branch)
   const void* fft_merge = nullptr;   // const jcm::FftMerge*: the next frequency-domain layer forms the merged map itself (jcm_pd_forward, conv5)

@@ -260,3 +260,22 @@ def test_split_convs_debug_width_and_odd_shapes(f32_conv):
     one = eng.model(dev(x2[:1])).cpu().numpy()
     np.testing.assert_allclose(one, got2[:1], atol=logit_tol(ref2), rtol=0)   # a different batch may pick a different kernel
     eng.close()
+
+
+@pytest.mark.parametrize('B', [30, 37, 64])
+def test_spatial_model_balanced_cuts_are_bit_identical(debug_setup, B):
+    """sm_inv_finish_kernel cuts the (image, joint, pair) units into equal ranges when the items do not fill whole rounds of the resident work groups
+    (B = 30, 37, 64: 270 / 333 / 576 items on 256 CUs); a range that ends inside an item publishes the partial sums of its head and the next range
+    continues them IN GRAPH ORDER (sm_fused.hip).  Every logit must therefore equal, bit for bit, the logit of the same image run alone (one work group
+    per item, no cut) -- and the oracle."""
+    eng, p = debug_setup
+    rs = np.random.RandomState(100 + B)
+    hm = (rs.random_sample((B, 60, 90, 10)) ** 8 * 0.02).astype(np.float32)
+    got = eng.spatial_model(dev(hm)).cpu().numpy()
+    for b in (0, 1, B // 2, B - 2, B - 1):
+        one = eng.spatial_model(dev(hm[b:b + 1])).cpu().numpy()
+        assert np.array_equal(one[0], got[b]), b
+    again = eng.spatial_model(dev(hm)).cpu().numpy()      # the flags carry the launch epoch: a second launch must not see the first one's
+    assert np.array_equal(again, got)
+    ref = O.spatial_model(hm[:2].astype(np.float64), p)
+    np.testing.assert_allclose(got[:2], ref, atol=logit_tol(ref), rtol=0)
