@@ -202,13 +202,19 @@ def resident_inputs(B, rank, dev):
     return x, torso
 
 
+def dist_on():
+    """Is there a process group?  Every barrier / collective of this script runs when there is one -- also with ONE rank (torch.distributed.run
+    --nproc-per-node 1, JCM_BENCH_FORCE_DIST=1: the nccl branch executed on a one-GPU box, tests/test_gpu_bench_ranks.py)."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32_conv=None, config_name=None, micro_batch=None, conv9_fft=None, fft_single=None, fft_t16=None, agree=False):
     """Time `args.steps` steps of one (dtype, batch) configuration; returns the result dict on
     rank 0 (None elsewhere).  Timed region: barrier + synchronize on both sides, max over ranks.
     f32_conv='split16': the fp32 path with its stride-1 layers on the direct fp16x3 split kernels (conv_split.hip).
     B is the rank's batch per step; jcm_forward walks it in micro-batches (256 bf16 / 64 fp32 unless `micro_batch`)."""
     eng = Engine(device=local_rank, precision=dtype, f32_conv=f32_conv, micro_batch=micro_batch, conv9_fft=conv9_fft, fft_single=fft_single, fft_t16=fft_t16,
-                 fft_fuse=args.fft_fuse if dtype == 'fp32' else None).load_params(params)
+                 fft_fuse=args.fft_fuse).load_params(params)
     x, torso = resident_inputs(B, rank, dev)                                          # resident in HBM
     agree_ref = agreement_reference(params, x, torso, local_rank, use_sm) if agree and rank == 0 else None      # (outside every timed region)
 
@@ -228,7 +234,7 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
     def timed_region(profile):
         """EXACTLY args.steps steps between barrier + synchronize on both sides; returns (wall seconds, per-step HIP-event ms, coords)."""
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on():
             dist.barrier()
         torch.cuda.synchronize()
         if profile:
@@ -241,14 +247,14 @@ def run_config(args, dtype, B, params, world, rank, local_rank, dev, use_sm, f32
             c = step()
         evs[args.steps].record()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on():
             dist.barrier()
         torch.cuda.synchronize()
         d = time.perf_counter() - t0
         if profile:
             eng.set_profile(False)
         ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
-        if world > 1:
+        if dist_on():
             t = torch.tensor([d], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             d = float(t.item())
@@ -426,7 +432,7 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
     for _ in range(args.warmup):
         tr.train_step(x, y, moving=moving)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on():
         dist.barrier()
     torch.cuda.synchronize()
     eng.set_profile(True)
@@ -437,11 +443,11 @@ def run_train(args, B, params, world, rank, local_rank, dev, use_sm, prec=None, 
         losses, _ = tr.train_step(x, y, moving=moving)
     evs[args.steps].record()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on():
         t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -561,7 +567,7 @@ def main():
     backend = os.environ.get('JCM_BENCH_BACKEND', 'nccl')
     if backend != 'nccl':
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
-    if world > 1:
+    if world > 1 or os.environ.get('JCM_BENCH_FORCE_DIST') == '1':      # (FORCE_DIST: a one-rank group, so that the nccl branch runs on a one-GPU box)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local_rank)
         if backend == 'nccl':
@@ -582,7 +588,7 @@ def main():
         out = run_train(args, args.batch or 16, params, world, rank, local_rank, dev, use_sm)
         if rank == 0:
             emit(out)
-        if world > 1:
+        if dist_on():
             dist.destroy_process_group()
         return
 
@@ -662,7 +668,7 @@ def main():
         if args.cpu_reps > 0 and world == 1 and not args.debug:      # the CPU baseline is a single-GPU-run item (rank 0, N = 1)
             detail['cpu_baseline'] = cpu_baseline(params, reps=args.cpu_reps, budget_s=args.cpu_budget)
         emit(detail)
-    if world > 1:
+    if dist_on():
         dist.destroy_process_group()
 
 

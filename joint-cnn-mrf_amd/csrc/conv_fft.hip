@@ -206,6 +206,11 @@ static bool sizes_of(int H, int W, int ks, Sizes* s, int circ = 0) {
   return (ks == 9 || ks == 5) && H + ks - 1 <= 192 && W + ks - 1 <= 192 && pick(H + 4, &s->NY) && pick(W + 4, &s->NX);
 }
 static int pad64(int c) { return (c + CB - 1) / CB * CB; }
+// JCM_FFT_REG=0 (environment, read once): the LDS kernels for every pass -- the A/B arm of the register kernels (conv_fft_rows_reg.hip)
+static bool fft_reg_on() {
+  static const bool on = [] { const char* e = std::getenv("JCM_FFT_REG"); return !e || std::atoi(e) != 0; }();
+  return on;
+}
 static int padn(int c, int n) { return (c + n - 1) / n * n; }
 
 int persistent_grid(const void* kernel, int ntiles, int threads, int dyn_lds) {
@@ -341,9 +346,12 @@ size_t conv_fft_pool_handover_bytes(const ConvArgs& a, int ks_next) {      // T[
   if (!sizes_of((a.H + 1) / 2, (a.W + 1) / 2, ks_next, &n)) return 0;
   return (size_t)a.B * (n.NX / 2 + 1) * ((a.H + 1) / 2) * a.Cout * sizeof(cf);
 }
-bool conv_fft_merge_fusable(const ConvArgs& a, int ks, int ks_next, const FftMerge& m) {
+// h16: bf16 handles on the one-part route with 16-bit row-transformed tensors -- the register kernel only (the model's geometry)
+bool conv_fft_merge_fusable(const ConvArgs& a, int ks, int ks_next, const FftMerge& m, bool h16) {
   Sizes s;
-  return conv_fft_fusable(a, ks, ks_next) && sizes_of(a.H, a.W, ks, &s) && cfft_rows_inv_merge_fwd_supported(s.NX, a, m);
+  if (!conv_fft_fusable(a, ks, ks_next) || !sizes_of(a.H, a.W, ks, &s)) return false;
+  const bool reg = fft_reg_on() && cfft_rows_inv_merge_fwd_reg_supported(s.NX, a, m, (ks - 1) / 2);
+  return h16 ? reg : (reg || cfft_rows_inv_merge_fwd_supported(s.NX, a, m));
 }
 // a.wp = the split filter spectra of THIS map size and kernel size; `work` = conv_fft_workspace_bytes(a, ks, np) bytes.  g0 / g1: optional
 // events recorded around the GEMM (the dominant kernel of the layer) for the roofline record.
@@ -366,8 +374,11 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
     sc.hf = (float)a0.H;
     sc.nb = a0.B;
   }
-  if ((t_in || t_next) && (in_layout != 0 || out_layout != 0 || (t_next && a0.Cout % CB))) return hipErrorInvalidValue;
-  if (sc.t16 && (np != 5 || in_layout == 0 || out_layout == 0 || xs || t_in || t_next)) return hipErrorInvalidValue;      // 16-bit T / T': bf16 tensors either side, one-part route
+  // bf16 handles: the merge hand-over (conv4_fullres -> conv5) in 16-bit form -- t_next / t_in is a complex-fp16 T followed by its tile scale words
+  const bool h16 = sc.t16 && ((t_next && nx && nx->merge && !t_in) || (t_in && !t_next));
+  if ((t_in || t_next) && !h16 && (in_layout != 0 || out_layout != 0)) return hipErrorInvalidValue;
+  if (t_next && a0.Cout % CB) return hipErrorInvalidValue;
+  if (sc.t16 && (np != 5 || in_layout == 0 || out_layout == 0 || xs || ((t_in || t_next) && !h16))) return hipErrorInvalidValue;      // 16-bit T / T': bf16 tensors either side, one-part route
   if (merge && in_layout == 2) return hipErrorInvalidValue;      // the merge reads NHWC (fp32 or bf16)
   ConvArgs a = a0;
   a.CoutP = pad64(a.Cout);
@@ -382,6 +393,8 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
     sc.t16_fwd = reinterpret_cast<float*>(wk + align256(p.t_bytes) + align256(p.xs_bytes) + align256(p.yf_bytes));
     sc.t16_inv = reinterpret_cast<float*>(wk + align256(p.t_bytes) + align256(p.xs_bytes) + align256(p.yf_bytes) + align256(p.sc_fwd_bytes));
     sc.t16_cb = p.inv_cb;
+    // a handed-over 16-bit T carries its scale words behind it (written by the producing layer's fused row kernel)
+    if (t_in) sc.t16_fwd = reinterpret_cast<float*>(const_cast<char*>(static_cast<const char*>(t_in)) + align256((size_t)a.B * p.NXH * a.H * a.Cin * 4));
   }
   if (xs_ready && !xs) return hipErrorInvalidValue;
   int dev = 0;
@@ -392,8 +405,7 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
   const cf* twy = twb + tw_offset(s.NY);
   const float norm = 1.0f / (float)(s.NY * s.NX);
   const cf* Tin = t_in ? static_cast<const cf*>(t_in) : T;
-  // JCM_FFT_REG=0 (environment, read once): the LDS kernels for every pass -- the A/B arm of the register kernels (conv_fft_rows_reg.hip)
-  static const bool fft_reg = [] { const char* e = std::getenv("JCM_FFT_REG"); return !e || std::atoi(e) != 0; }();
+  const bool fft_reg = fft_reg_on();
   if (!xs_ready) {
     if (merge && !t_in) {
       if (!(fft_reg && cfft_rows_fwd_merge_reg(s.NX, a, *merge, in_layout, T, sc.tmax, st, sc.t16_fwd))) cfft_rows_fwd_merge(s.NX, a, *merge, in_layout, T, twx, sc.tmax, st, sc.t16_fwd);
@@ -418,9 +430,13 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
         !cfft_rows_inv_pool_fwd(s.NX, sn.NX, a, T, static_cast<cf*>(t_next), twx, twb + tw_offset(sn.NX), opad, norm, sc, st))
       return hipErrorInvalidValue;
   } else if (t_next && nx && nx->merge) {
-    if (!(fft_reg && cfft_rows_inv_merge_fwd_reg(s.NX, a, *nx->merge, T, static_cast<cf*>(t_next), opad, norm, sc, st)) &&
-        !cfft_rows_inv_merge_fwd(s.NX, a, *nx->merge, T, static_cast<cf*>(t_next), twx, opad, norm, sc, st))
+    if (sc.t16) {
+      float* t16n = reinterpret_cast<float*>(static_cast<char*>(t_next) + align256((size_t)a.B * p.NXH * a.H * a.Cout * 4));
+      if (!(fft_reg && cfft_rows_inv_merge_fwd_reg(s.NX, a, *nx->merge, T, static_cast<cf*>(t_next), opad, norm, sc, st, t16n))) return hipErrorInvalidValue;
+    } else if (!(fft_reg && cfft_rows_inv_merge_fwd_reg(s.NX, a, *nx->merge, T, static_cast<cf*>(t_next), opad, norm, sc, st)) &&
+               !cfft_rows_inv_merge_fwd(s.NX, a, *nx->merge, T, static_cast<cf*>(t_next), twx, opad, norm, sc, st)) {
       return hipErrorInvalidValue;
+    }
   } else if (t_next) {
     if (!(fft_reg && cfft_rows_inv_fwd_reg(s.NX, a, T, static_cast<cf*>(t_next), opad, norm, sc, st))) cfft_rows_inv_fwd(s.NX, a, T, static_cast<cf*>(t_next), twx, opad, norm, sc, st);
   } else if (!(fft_reg && cfft_rows_inv_reg(s.NX, ai, out_layout, T, opad, norm, sc, st))) {

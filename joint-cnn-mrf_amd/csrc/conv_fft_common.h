@@ -320,7 +320,9 @@ void cfft_rows_inv_fwd(int NX, const ConvArgs& a, const cf* T, cf* Tn, const cf*
 // false: no kernel for this case
 bool cfft_rows_inv_pool_fwd(int NXI, int NXO, const ConvArgs& a, const cf* T, cf* Tn, const cf* twi, const cf* two, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
 bool cfft_rows_inv_merge_fwd(int NX, const ConvArgs& a, const FftMerge& m, const cf* T, cf* Tn, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
-bool cfft_rows_inv_merge_fwd_reg(int NX, const ConvArgs& a, const FftMerge& m, const cf* T, cf* Tn, int pad, float norm, const Fp16Scale& sc, hipStream_t st);      // conv_fft_rows_reg.hip: the model's geometry in registers
+// conv_fft_rows_reg.hip: the model's geometry in registers; t16n != null: bf16 handles (16-bit T' in, 16-bit T + its scale words t16n out, bf16 coarse branches)
+bool cfft_rows_inv_merge_fwd_reg(int NX, const ConvArgs& a, const FftMerge& m, const cf* T, cf* Tn, int pad, float norm, const Fp16Scale& sc, hipStream_t st, float* t16n = nullptr);
+bool cfft_rows_inv_merge_fwd_reg_supported(int NX, const ConvArgs& a, const FftMerge& m, int pad);
 bool cfft_rows_inv_pool_fwd_supported(int NXI, int NXO, int Cout);
 bool cfft_rows_inv_merge_fwd_supported(int NX, const ConvArgs& a, const FftMerge& m);
 }  // namespace cfft

@@ -630,27 +630,38 @@ bool cfft_rows_inv_fwd_reg(int NX, const ConvArgs& a, const cf* T, cf* Tn, int p
 // reads two staged neighbours per map at compile-time offsets (x2: columns i, i + 1 with weight 0 or 1/2 by the thread's parity; x3: the TF-1.x taps of
 // UpTaps<90, 23>, the thread's parity picks between two literals).  TF lerps along x first: the two orders differ in the last fp32 bit of the coarse terms
 // (as in rows_fwd_merge_reg_kernel), eight orders of magnitude below the 1e-4 the heat maps are held to.  No work-group barrier: a wave reads what it wrote.
-template <int NX, int PAD, int W, int W3, int IPX, class Act>
+__device__ __forceinline__ float bf16_rn(float v) { return static_cast<float>(static_cast<__bf16>(v)); }
+// BF (bf16 handles): the three branches are bf16 tensors and so is the merged map -- act() rounds x1 to bf16, the lerps are the FMA forms of
+// rows_fwd_merge_reg_kernel, the merged value is rounded to bf16 before it enters conv5's transform.
+template <int NX, int PAD, int W, int W3, int IPX, bool BF, class Act>
 __device__ __forceinline__ cf merged_px(cf z, bool odd, const cf* c2, const cf* c3, float t2h, Act&& act) {      // pixel n = 2 IPX + h of this thread
   using T3 = UpTaps<W, W3>;
   const cf a = act(z);
   const cf l2 = c2[IPX * 32], r2 = c2[(IPX + 1) * 32];
-  const cf u2 = cf{l2.x + (r2.x - l2.x) * t2h, l2.y + (r2.y - l2.y) * t2h};
   constexpr int n0 = 2 * IPX, n1 = 2 * IPX + 1;
   const int lo = odd ? T3::lo(n1) * 32 : T3::lo(n0) * 32, hi = odd ? T3::hi(n1) * 32 : T3::hi(n0) * 32;
   const float t3 = odd ? T3::t(n1) : T3::t(n0);
   const cf l3 = c3[lo], r3 = c3[hi];
-  const cf u3 = cf{l3.x + (r3.x - l3.x) * t3, l3.y + (r3.y - l3.y) * t3};
-  return cf{div3((a.x + u2.x) + u3.x), div3((a.y + u2.y) + u3.y)};
+  if constexpr (BF) {
+    const cf u2 = lerp_cf(l2, r2, t2h), u3 = lerp_cf(l3, r3, t3);
+    // the third as ONE multiplication by RN(1/3), as rows_fwd_merge_reg_kernel forms it: the two kernels are bit-identical arms of a bf16 handle.  (Against the
+    // correctly rounded quotient the product differs in the last fp32 bit for a third of the values, which moves the bf16 rounding of two values in a million.)
+    constexpr float k3 = 0.333333343267440796f;
+    return cf{bf16_rn(((a.x + u2.x) + u3.x) * k3), bf16_rn(((a.y + u2.y) + u3.y) * k3)};
+  } else {
+    const cf u2 = cf{l2.x + (r2.x - l2.x) * t2h, l2.y + (r2.y - l2.y) * t2h};
+    const cf u3 = cf{l3.x + (r3.x - l3.x) * t3, l3.y + (r3.y - l3.y) * t3};
+    return cf{div3((a.x + u2.x) + u3.x), div3((a.y + u2.y) + u3.y)};
+  }
 }
-template <int NX, int PAD, int W, int W3, int I, class Act>
+template <int NX, int PAD, int W, int W3, int I, bool BF, class Act>
 __device__ __forceinline__ void fused_rows_mid_merge(const cf (&x)[NX / 2], cf (&uu)[NX / 2], bool odd, const cf* c2, const cf* c3, float t2h, Act&& act) {
   constexpr int M = NX / 2, R1 = RPlan<M>::R1, R2 = RPlan<M>::R2, Q = M / 2;
   static_assert(W % 2 == 0 && PAD % 2 == 0, "a thread's pixels 2 i + h are inside the map for both parities or for neither");
   constexpr int ma = I + PAD / 2, mb = I + Q + PAD / 2;      // sample indices of pixels 2 I + h and 2 (I + Q) + h
   cf a = cf{0.f, 0.f}, bq = cf{0.f, 0.f};
-  if constexpr (ma < M && 2 * I < W) a = merged_px<NX, PAD, W, W3, I>(x[R2 * (ma % R1) + ma / R1], odd, c2, c3, t2h, act);
-  if constexpr (mb < M && 2 * (I + Q) < W) bq = merged_px<NX, PAD, W, W3, I + Q>(x[R2 * (mb % R1) + mb / R1], odd, c2, c3, t2h, act);
+  if constexpr (ma < M && 2 * I < W) a = merged_px<NX, PAD, W, W3, I, BF>(x[R2 * (ma % R1) + ma / R1], odd, c2, c3, t2h, act);
+  if constexpr (mb < M && 2 * (I + Q) < W) bq = merged_px<NX, PAD, W, W3, I + Q, BF>(x[R2 * (mb % R1) + mb / R1], odd, c2, c3, t2h, act);
   const cf sm = a + bq, df = a - bq;                         // j = 2 I + h:  z[j] + z[j + M],  z[j] - z[j + M]
   const cf keep = cf{odd ? df.x : sm.x, odd ? df.y : sm.y}, send = cf{odd ? sm.x : df.x, odd ? sm.y : df.y};
   const cf recv = cf{__uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(send.x), 0xB1, 0xF, 0xF, true)),
@@ -667,14 +678,16 @@ __device__ __forceinline__ void fused_rows_mid_merge(const cf (&x)[NX / 2], cf (
   uu[2 * I] = e;
   uu[2 * I + 1] = o;
   if constexpr (I % 2 == 1) asm volatile("" ::: "memory");      // two steps' staged reads at a time (the compiler otherwise hoists all of them to the front)
-  if constexpr (I + 1 < Q) fused_rows_mid_merge<NX, PAD, W, W3, I + 1>(x, uu, odd, c2, c3, t2h, act);
+  if constexpr (I + 1 < Q) fused_rows_mid_merge<NX, PAD, W, W3, I + 1, BF>(x, uu, odd, c2, c3, t2h, act);
 }
-template <int NX, int PAD, int W, int W2, int W3>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void rows_inv_merge_fwd_reg_kernel(const float4* __restrict__ T, float4* __restrict__ Tn, const float* __restrict__ bias,
+// BF = false: fp32 handles (T' and T complex fp32, x2 / x3 fp32 NHWC).  BF = true: bf16 handles on the one-part route -- T' and T complex fp16 in block floating
+// point (sc.t16_inv: the scale words of T'; t16n: those of the T written here, one per (image, row, 64 channels) = per wave), x2 / x3 bf16 NHWC.
+template <int NX, int PAD, int W, int W2, int W3, bool BF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void rows_inv_merge_fwd_reg_kernel(const void* __restrict__ T, void* __restrict__ Tn, const float* __restrict__ bias,
                                                                                                         const float* __restrict__ scale, const float* __restrict__ shift, int relu_bn,
                                                                                                         int nrows, int B, int H, int C, float norm0, Fp16Scale sc,
-                                                                                                        const cf* __restrict__ x2, int H2, const cf* __restrict__ x3, int H3, float sy2,
-                                                                                                        float sy3) {
+                                                                                                        const void* __restrict__ x2, int H2, const void* __restrict__ x3, int H3, float sy2,
+                                                                                                        float sy3, float* __restrict__ t16n) {
   constexpr int NXH = NX / 2 + 1, M = NX / 2;
   constexpr int NC2 = W2 + 1, NCS = NC2 + W3 + 1;      // staged columns per wave: x2 (+ a copy of its last column), x3 (+ one the loop below writes and nobody reads)
   static_assert(W == 2 * W2 && W2 % 2 == 1 && W3 % 2 == 1, "the staging loops below walk the coarse columns in pairs");
@@ -688,41 +701,74 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int b = (int)(by / H), y = (int)(by % H), c = 2 * p;
   const bool odd = h != 0;
   cf* cs = stage[threadIdx.x >> 6];
+  // bf16 handles: T' (complex fp16) goes out FIRST -- 49 eight-byte loads per thread that stay in flight under the coarse rows' loads, lerps and LDS stores
+  // (the kernel is bound by the latency of its dependent memory round trips at two waves per SIMD: one round trip less).  fp32 handles load T' in batches
+  // behind the staging (a thread cannot hold 49 x 16 bytes next to the coarse rows).
+  typedef unsigned u2t __attribute__((ext_vector_type(2)));
+  u2t raw[BF ? NXH : 1];
+  if constexpr (BF) {
+    const auto d = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(static_cast<const unsigned*>(T)) + by * NXH * C, 0, NXH * C * 4, 0x00020000);
+    const int vo = p * 8, ko = CP * 8;
+#pragma unroll
+    for (int n = 0; 2 * n <= M; ++n) {      // in the order of use: the entries are consumed in pairs (n, M - n)
+      raw[n] = __builtin_amdgcn_raw_buffer_load_b64(d, vo, n * ko, 0);
+      if (2 * n != M) raw[M - n] = __builtin_amdgcn_raw_buffer_load_b64(d, vo, (M - n) * ko, 0);
+    }
+  }
   {
     // the wave's coarse rows: lanes 0..31 take an even column of the wave's 32 channel pairs, lanes 32..63 the odd one next to it; the image is the
     // descriptor, the source row and the column pair scalar offsets
+    constexpr int EB = BF ? 4 : 8;      // bytes of a channel pair
     const int bs = __builtin_amdgcn_readfirstlane(b), c0 = __builtin_amdgcn_readfirstlane(p - (lane >> 1));      // first pair of the wave
     const Tap ty2 = tf1_tap(y, H2, sy2), ty3 = tf1_tap(y, H3, sy3);
-    const auto d2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(x2) + (size_t)bs * H2 * W2 * CP, 0, H2 * W2 * CP * 8, 0x00020000);
-    const auto d3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(x3) + (size_t)bs * H3 * W3 * CP, 0, H3 * W3 * CP * 8, 0x00020000);
-    const int vo = ((lane >> 5) * CP + c0 + (lane & 31)) * 8, vo_last = (c0 + (lane & 31)) * 8;      // (the last column pair: both halves read the last column)
-    const int r2a = ty2.lo * W2 * CP * 8, r2b = ty2.hi * W2 * CP * 8, r3a = ty3.lo * W3 * CP * 8, r3b = ty3.hi * W3 * CP * 8;
+    const auto d2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(x2)) + (size_t)bs * H2 * W2 * CP * EB, 0, H2 * W2 * CP * EB, 0x00020000);
+    const auto d3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(x3)) + (size_t)bs * H3 * W3 * CP * EB, 0, H3 * W3 * CP * EB, 0x00020000);
+    const int vo = ((lane >> 5) * CP + c0 + (lane & 31)) * EB, vo_last = (c0 + (lane & 31)) * EB;      // (the last column pair: both halves read the last column)
+    const int r2a = ty2.lo * W2 * CP * EB, r2b = ty2.hi * W2 * CP * EB, r3a = ty3.lo * W3 * CP * EB, r3b = ty3.hi * W3 * CP * EB;
     typedef float f2 __attribute__((ext_vector_type(2)));
     constexpr int J2 = (W2 + 1) / 2, J3 = (W3 + 1) / 2;
+    auto ld = [&](const auto& d, int v, int so) __attribute__((always_inline)) {
+      if constexpr (BF) return bf16pair(__builtin_amdgcn_raw_buffer_load_b32(d, v, so, 0));
+      else return cf(__builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(d, v, so, 0)));
+    };
+    auto ylerp = [&](cf a, cf bb, float t) __attribute__((always_inline)) {
+      if constexpr (BF) return lerp_cf(a, bb, t);
+      else return cf{a.x + (bb.x - a.x) * t, a.y + (bb.y - a.y) * t};
+    };
     cf a2[J2], b2[J2], a3[J3], b3[J3];
 #pragma unroll
     for (int j = 0; j < J2; ++j) {
       const int v = j == J2 - 1 ? vo_last : vo;
-      a2[j] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(d2, v, r2a + 2 * j * CP * 8, 0));
-      b2[j] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(d2, v, r2b + 2 * j * CP * 8, 0));
+      a2[j] = ld(d2, v, r2a + 2 * j * CP * EB);
+      b2[j] = ld(d2, v, r2b + 2 * j * CP * EB);
     }
 #pragma unroll
     for (int j = 0; j < J3; ++j) {
       const int v = j == J3 - 1 ? vo_last : vo;
-      a3[j] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(d3, v, r3a + 2 * j * CP * 8, 0));
-      b3[j] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(d3, v, r3b + 2 * j * CP * 8, 0));
+      a3[j] = ld(d3, v, r3a + 2 * j * CP * EB);
+      b3[j] = ld(d3, v, r3b + 2 * j * CP * EB);
     }
     __builtin_amdgcn_sched_barrier(0);      // every load is out before the first lerp
 #pragma unroll
-    for (int j = 0; j < J2; ++j) cs[lane + 64 * j] = cf{a2[j].x + (b2[j].x - a2[j].x) * ty2.t, a2[j].y + (b2[j].y - a2[j].y) * ty2.t};
+    for (int j = 0; j < J2; ++j) cs[lane + 64 * j] = ylerp(a2[j], b2[j], ty2.t);
 #pragma unroll
-    for (int j = 0; j < J3; ++j) cs[NC2 * 32 + lane + 64 * j] = cf{a3[j].x + (b3[j].x - a3[j].x) * ty3.t, a3[j].y + (b3[j].y - a3[j].y) * ty3.t};
+    for (int j = 0; j < J3; ++j) cs[NC2 * 32 + lane + 64 * j] = ylerp(a3[j], b3[j], ty3.t);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
   cf u[M];
-  {
-    const float4* src = T + (by * NXH * C) / 2 + p;
+  if constexpr (BF) {
+    // T' as complex fp16 in block floating point (requested above): the conversions of rows_inv_reg_kernel<NX, *, true>
+    const int nblk = C / sc.t16_cb;
+    const float* ssrc = sc.t16_inv + ((size_t)__builtin_amdgcn_readfirstlane(b) * nblk + __builtin_amdgcn_readfirstlane(c / sc.t16_cb)) * NXH;
+    auto load = [&](int k) __attribute__((always_inline)) {
+      const float sk = ssrc[k];
+      const cf ya = unpack_h2_mix_s(raw[k][0], sk), yb = unpack_h2_mix_s(raw[k][1], sk);
+      return make_float4(ya.x, ya.y, yb.x, yb.y);
+    };
+    inv_rows_load2<NX, true, 0>(u, odd ? -1.f : 1.f, odd, load);
+  } else {
+    const float4* src = static_cast<const float4*>(T) + (by * NXH * C) / 2 + p;
     auto load = [&](int k) __attribute__((always_inline)) { return src[(size_t)k * CP]; };      // (Ya.re, Ya.im, Yb.re, Yb.im)
     inv_rows_load2<NX, false, 0>(u, odd ? -1.f : 1.f, odd, load);
   }
@@ -748,39 +794,65 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto act = [&](cf z) __attribute__((always_inline)) {
     float v0 = fmaf(z.x, norm, b0v), v1 = fmaf(z.y, norm, b1v);
     if (relu_bn) { v0 = fmaf(fmaxf(v0, 0.f), s0, h0); v1 = fmaf(fmaxf(v1, 0.f), s1, h1); }
+    if constexpr (BF) { v0 = bf16_rn(v0); v1 = bf16_rn(v1); }      // x1 is a bf16 tensor
     return cf{v0, v1};
   };
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const cf* c2 = cs + (lane >> 1);
-  fused_rows_mid_merge<NX, PAD, W, W3, 0>(u, uu, odd, c2, c2 + NC2 * 32, odd ? 0.5f : 0.f, act);
+  fused_rows_mid_merge<NX, PAD, W, W3, 0, BF>(u, uu, odd, c2, c2 + NC2 * 32, odd ? 0.5f : 0.f, act);
   step1<M, -1>(uu);
   step2_inplace<M, -1, 0>(uu);
   const int cblk = p >> 5, v = p & 31;
-  float4* dst = Tn + ((((size_t)cblk * 4 + (v >> 3)) * B + b) * H + y) * 8 + (v & 7);      // t_fwd_index(k = 0); per kx: + (C / 16) B H 8
   const size_t kstride = (size_t)(C >> 4) * B * H * 8;
+  const size_t d0 = ((((size_t)cblk * 4 + (v >> 3)) * B + b) * H + y) * 8 + (v & 7);      // t_fwd_index(k = 0); per kx: + (C / 16) B H 8
   float m = 0.f;
-  fwd_rows_visit<NX, 0>(uu, odd, [&](int mi, const float4& o) __attribute__((always_inline)) {
-    const int k = 2 * mi + h;
-    if (k <= M) {
-      dst[(size_t)k * kstride] = o;
-      m = fmaxf(fmaxf(m, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
-    }
-  });
-  if (sc.tmax_next) {      // the next layer's per-image word (max |T|) of its spectra's scale
+  if constexpr (BF) {
+    // the tile's largest |component| (k = 2 m + h <= NX / 2) -> its block-floating-point scale: a wave is one (image, row, 64 channels) tile
+    fwd_rows_visit<NX, 0>(uu, odd, [&](int mi, const float4& o) __attribute__((always_inline)) {
+      if (2 * mi + h <= M) m = fmaxf(fmaxf(m, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+    });
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft));
+    const float sb = bfp_scale(m);
+    if (lane == 0) t16n[((size_t)b * (C >> 6) + cblk) * H + y] = 1.0f / sb;
+    uint2* dst = static_cast<uint2*>(Tn) + d0;
+    fwd_rows_visit<NX, 0>(uu, odd, [&](int mi, const float4& o) __attribute__((always_inline)) {
+      const int k = 2 * mi + h;
+      if (k <= M) dst[(size_t)k * kstride] = make_uint2(pack_h2(o.x * sb, o.y * sb), pack_h2(o.z * sb, o.w * sb));
+    });
+  } else {
+    float4* dst = static_cast<float4*>(Tn) + d0;
+    fwd_rows_visit<NX, 0>(uu, odd, [&](int mi, const float4& o) __attribute__((always_inline)) {
+      const int k = 2 * mi + h;
+      if (k <= M) {
+        dst[(size_t)k * kstride] = o;
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+      }
+    });
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if (lane == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(sc.tmax_next + b), __float_as_uint(m));
   }
+  // the next layer's per-image word (max |T|) of its spectra's scale
+  if (sc.tmax_next && lane == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(sc.tmax_next + b), __float_as_uint(m));
 }
 // true: launched (the model's geometry: 96-point rows, pad 4, 90 / 45 / 23 columns, whole 64-channel blocks)
-bool cfft_rows_inv_merge_fwd_reg(int NX, const ConvArgs& a, const FftMerge& m, const cf* T, cf* Tn, int pad, float norm, const Fp16Scale& sc, hipStream_t st) {
+bool cfft_rows_inv_merge_fwd_reg_supported(int NX, const ConvArgs& a, const FftMerge& m, int pad) {
   if (NX != 96 || pad != 4 || a.Cout % 64 || a.W != 90 || m.W2 != 45 || m.W3 != 23 || m.H2 < 1 || m.H3 < 1) return false;
-  if ((size_t)m.H2 * m.W2 * a.Cout * 4 >= (size_t)1 << 31) return false;      // one buffer descriptor per coarse image
+  return (size_t)m.H2 * m.W2 * a.Cout * 4 < (size_t)1 << 31;      // one buffer descriptor per coarse image
+}
+// t16n: null = fp32 handles (T', T complex fp32; x2, x3 fp32 NHWC); else the scale words of the 16-bit T written here (bf16 handles: T' 16-bit with sc.t16_inv, x2 / x3 bf16 NHWC)
+bool cfft_rows_inv_merge_fwd_reg(int NX, const ConvArgs& a, const FftMerge& m, const cf* T, cf* Tn, int pad, float norm, const Fp16Scale& sc, hipStream_t st, float* t16n) {
+  if (!cfft_rows_inv_merge_fwd_reg_supported(NX, a, m, pad) || ((t16n != nullptr) != (sc.t16_inv != nullptr))) return false;
   const int nrows = a.B * a.H;
   const size_t threads = (size_t)nrows * a.Cout;
-  hipLaunchKernelGGL((rows_inv_merge_fwd_reg_kernel<96, 4, 90, 45, 23>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(T), reinterpret_cast<float4*>(Tn),
-                     a.bias, a.scale, a.shift, a.relu_bn, nrows, a.B, a.H, a.Cout, norm, sc, static_cast<const cf*>(m.x2), m.H2, static_cast<const cf*>(m.x3), m.H3,
-                     (float)m.H2 / (float)a.H, (float)m.H3 / (float)a.H);
+  const dim3 grid((unsigned)((threads + 255) / 256)), blk(256);
+  const float sy2 = (float)m.H2 / (float)a.H, sy3 = (float)m.H3 / (float)a.H;
+  if (t16n)
+    hipLaunchKernelGGL((rows_inv_merge_fwd_reg_kernel<96, 4, 90, 45, 23, true>), grid, blk, 0, st, static_cast<const void*>(T), static_cast<void*>(Tn), a.bias, a.scale, a.shift, a.relu_bn, nrows, a.B,
+                       a.H, a.Cout, norm, sc, m.x2, m.H2, m.x3, m.H3, sy2, sy3, t16n);
+  else
+    hipLaunchKernelGGL((rows_inv_merge_fwd_reg_kernel<96, 4, 90, 45, 23, false>), grid, blk, 0, st, static_cast<const void*>(T), static_cast<void*>(Tn), a.bias, a.scale, a.shift, a.relu_bn, nrows, a.B,
+                       a.H, a.Cout, norm, sc, m.x2, m.H2, m.x3, m.H3, sy2, sy3, nullptr);
   return true;
 }
 

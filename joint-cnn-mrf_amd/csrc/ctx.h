@@ -106,6 +106,7 @@ struct jcm_ctx {
   unsigned sm_epoch = 0;        // ... the launch counter its flags carry
   int fft_fuse = 3;             // fp32 handles, jcm_pd_forward: bit 0 = conv2 -> max pool -> conv3, bit 1 = conv4_fullres -> branch merge -> conv5 handed over in row-transformed form (conv_fft_rows_fused.hip)
   int fft_next_pool = 0, fft_next_ks = 0;      // transient, with fft_t_next: a 2x2 max pool lies between this layer and the one fft_t_next is for (kernel size fft_next_ks)
+  bool fft_t_in_16 = false;                     // transient, with fft_t_in (bf16 handles): the handed-over T is complex fp16 + its scale words (conv4_fullres -> conv5)
   const void* fft_next_merge = nullptr;        // transient, with fft_t_next: const jcm::FftMerge* -- fft_t_next is the row-transformed MERGED map (this layer = the full-resolution branch)
   const void* fft_merge = nullptr;   // const jcm::FftMerge*: the next frequency-domain layer forms the merged map itself (jcm_pd_forward, conv5)
   int conv9_fft = 1;            // fp32 handles: wide 9x9 layers in the frequency domain (conv_fft.hip) when the shape allows; 0 = fp32 MFMA chain
@@ -138,7 +139,8 @@ struct jcm_ctx {
   std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
   std::vector<hipEvent_t> event_pool;   // recycled by jcm_profile_read / "profile"=0, destroyed by jcm_destroy
   jcm::TrainState* train = nullptr;   // created by jcm_train_begin
-  int call_depth = 0;                 // entry points of this handle on the host stack (> 1 only inside a gradient-ready callback)
+  std::mutex call_mu;                 // held by the thread whose outermost entry point of this handle is running (CallOrder)
+  int call_depth = 0;                 // entry points of this handle on that thread's stack (> 1 only inside a gradient-ready callback)
   jcm::CallOrder* order = nullptr;    // the outermost running entry point's chain guard (notify_ready suspends it around the user callback)
 };
 
@@ -171,7 +173,8 @@ struct DeviceGuard {
 // so a callback may call jcm_* entry points (a nested call on the SAME handle keeps the outer call's transient state: `nested`).
 struct CallOrder {
   jcm_ctx* c;
-  std::unique_lock<std::mutex> lk;
+  std::unique_lock<std::mutex> lk;       // the device's call chain
+  std::unique_lock<std::mutex> hlk;      // the handle (outermost call only)
   bool nested = false;
   explicit CallOrder(jcm_ctx* ctx);
   ~CallOrder();
@@ -222,6 +225,8 @@ inline int cdiv2(int v) { return (v + 1) / 2; }
 // Sizing pass then the real pass, so the arena never reallocates mid-graph.
 template <class F>
 int with_arena(jcm_ctx* c, F&& body) {
+  // a call from inside the gradient-ready callback of this handle's running training step would overwrite that step's workspace
+  if (c->call_depth > 1) return fail(JCM_ERR_STATE, "this entry point uses the handle's workspace and cannot be called from the gradient-ready callback of the same handle");
   c->dry = true;
   c->arena_off = 0;
   c->arena_peak = 0;

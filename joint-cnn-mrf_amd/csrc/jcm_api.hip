@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include <mutex>
+#include <vector>
 
 #include "ctx.h"
 
@@ -29,15 +30,26 @@ namespace {
 struct Chain { std::mutex mu; hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool armed = false; };
 Chain g_chain[64];
 }  // namespace
+// Handles whose OUTERMOST entry point is running on this host thread.  A call is NESTED only when the same thread re-enters the handle (from the
+// gradient-ready callback of its running training step); another thread's call on the same handle waits on the handle's mutex until the whole
+// outermost call -- callbacks included -- has returned (the de-facto serialisation of rounds 1-4, without the data race on call_depth).
+namespace {
+thread_local std::vector<jcm_ctx*> t_active;
+}
 CallOrder::CallOrder(jcm_ctx* ctx) : c(ctx) {
   if (!c) return;
-  nested = c->call_depth++ > 0;      // called from the gradient-ready callback of this handle's running training step
+  for (jcm_ctx* a : t_active) nested = nested || a == c;
+  if (!nested) {
+    hlk = std::unique_lock<std::mutex>(c->call_mu);      // held for the whole outermost call
+    t_active.push_back(c);
+  }
+  ++c->call_depth;                   // (only ever touched by the thread that holds call_mu)
   acquire();
   if (nested) return;                // the outer call's hand-over fields and scale words stay as they are
   c->order = this;
   // what an aborted call may have left behind
   c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; c->fft_xs = nullptr; c->fft_xs_ready = false; c->fft_tmax_in = nullptr;
-  c->fft_next_pool = 0; c->fft_next_ks = 0; c->fft_next_merge = nullptr;
+  c->fft_next_pool = 0; c->fft_next_ks = 0; c->fft_next_merge = nullptr; c->fft_t_in_16 = false;
   // the fp16-scale words are reused from the start only BETWEEN calls (a call keeps words of its early layers until its last ones: the training step)
   if (c->fft_block_i > 0 || c->fft_word_i > jcm_ctx::kFftWords - jcm_ctx::kFftWordsPerCall) {
     for (int i = 0; i <= c->fft_block_i && i < (int)c->fft_blocks.size(); ++i)
@@ -67,7 +79,12 @@ CallOrder::~CallOrder() {
   if (!c) return;
   release();
   --c->call_depth;
-  if (!nested) c->order = nullptr;
+  if (!nested) {
+    c->order = nullptr;
+    for (size_t i = t_active.size(); i-- > 0;)
+      if (t_active[i] == c) { t_active.erase(t_active.begin() + (long)i); break; }
+    hlk.unlock();
+  }
 }
 
 int arena_reserve(jcm_ctx* c, size_t bytes) {
@@ -273,7 +290,7 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
   const int np = fft_np(c);      // operand form of the channel GEMM (cgemm_split.hip)
   void* work = arena_alloc<char>(c, conv_fft_workspace_bytes(a, L->ks, np));
   c->arena_off = mark;                                   // scratch of this layer only: later layers run behind it on the stream
-  if (c->dry) { c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; c->fft_xs = nullptr; c->fft_xs_ready = false; c->fft_tmax_in = nullptr; c->fft_next_pool = 0; c->fft_next_ks = 0; c->fft_next_merge = nullptr; return JCM_OK; }
+  if (c->dry) { c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; c->fft_xs = nullptr; c->fft_xs_ready = false; c->fft_tmax_in = nullptr; c->fft_next_pool = 0; c->fft_next_ks = 0; c->fft_next_merge = nullptr; c->fft_t_in_16 = false; return JCM_OK; }
   // Filter spectra are cached per (layer, map size).  The cache is bounded (JCM_FFT_CACHE_GB, default 64): a caller that walks many
   // image sizes (7.7 GB per size for conv5) makes it drop every spectrum that is not this layer's before it grows past the bound.
   const std::string key = scope + (circ ? "@win" : "@") + std::to_string(H) + "x" + std::to_string(W);
@@ -339,6 +356,8 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
   FftNext nx;
   nx.pool = c->fft_next_pool; nx.ks_next = c->fft_next_ks; nx.merge = static_cast<const FftMerge*>(c->fft_next_merge);
   c->fft_next_pool = 0; c->fft_next_ks = 0; c->fft_next_merge = nullptr;
+  const bool t_in_16 = c->fft_t_in_16;
+  c->fft_t_in_16 = false;
   Fp16Scale sc;
   if (np >= 4) {
     // the word of this layer's input: handed over with t_in / ready spectra, or a fresh one for this layer's own row pass
@@ -349,7 +368,8 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
     sc.winv = fw.wscale + 1;
     sc.common = c->train ? 1 : 0;      // a handle with training state: one scale per tensor (the weight gradient sums over the images)
     // 16-bit T / T' between the row and column passes: bf16 tensors on both sides of the layer, one-part spectra, nothing handed over or kept
-    sc.t16 = (np == 5 && c->fft_t16 && in_layout != 0 && out_layout != 0 && !t_in && !t_next && !xs) ? 1 : 0;
+    // ... except the merge hand-over conv4_fullres -> conv5 of jcm_pd_forward, which exists in 16-bit form (rows_inv_merge_fwd_reg_kernel<.., true>)
+    sc.t16 = (np == 5 && c->fft_t16 && in_layout != 0 && out_layout != 0 && !xs && (!t_in || t_in_16) && (!t_next || (nx.merge && !t_in))) ? 1 : 0;
   }
   c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; c->fft_xs = nullptr; c->fft_xs_ready = false;
   c->fft_tmax_in = sc.tmax_next;      // the next frequency-domain layer takes t_next (and its word)
@@ -600,10 +620,12 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
   // written.  The coarse branches then have to be there first: the branches run half, quarter, full.
   FftMerge mg{nullptr, h4[1], w4[1], nullptr, h4[2], w4[2]};
   bool fuse45 = false;
-  if (!bf && !c->debug_skip && takes_fft(c, L4, B, hh, ww) && takes_fft(c, L5, B, hh, ww) && L4->cout == L5->cin) {
+  // bf16 handles: the same hand-over in 16-bit form (one-part route with 16-bit row-transformed tensors, NHWC bf16 branches)
+  const bool h16 = bf && fft_np(c) == 5 && c->fft_t16;
+  if ((!bf || h16) && !c->debug_skip && takes_fft(c, L4, B, hh, ww) && takes_fft(c, L5, B, hh, ww) && L4->cout == L5->cin) {
     ConvArgs a{};
     a.B = B; a.H = hh; a.W = ww; a.Cin = L4->cin; a.Cout = L4->cout;
-    fuse45 = (c->fft_fuse & 2) && conv_fft_merge_fusable(a, L4->ks, L5->ks, mg);
+    fuse45 = (c->fft_fuse & 2) && conv_fft_merge_fusable(a, L4->ks, L5->ks, mg, h16);
   }
   // branch outputs survive the per-branch scratch, so carve them first
   void* t45 = nullptr;
@@ -709,7 +731,7 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
   void* t56 = (sk & 96) ? nullptr : offer_handover(c, L5, conv_of(c, "conv6"), B, hh, ww);
   void* c5 = t56 ? nullptr : act((size_t)B * hh * ww * L5->cout);
   if (fuse_merge && !(sk & 32)) c->fft_merge = &mg;
-  if (fuse45) c->fft_t_in = t45;
+  if (fuse45) { c->fft_t_in = t45; c->fft_t_in_16 = h16; }
   if (!(sk & 32)) JCM_TRY(run_conv(c, "conv5", 1, merged, B, hh, ww, 1, c5, bf, false, planar45, planar));   // :71
   c->fft_t_in = t56;
   if (!(sk & 64)) JCM_TRY(run_conv(c, "conv6", 1, c5, B, hh, ww, 1, logits, bf, true, planar, 0));         // :72

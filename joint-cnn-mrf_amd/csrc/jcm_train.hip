@@ -665,6 +665,7 @@ int jcm_train_begin(jcm_handle h) {
   if (h->train) return fail(JCM_ERR_STATE, "jcm_train_begin was already called");
   DeviceGuard g(h->device);
   CallOrder order(h);
+  if (h->call_depth > 1) return fail(JCM_ERR_STATE, "jcm_train_begin changes the handle's training state or parameters and cannot be called from the gradient-ready callback of the same handle");
   jcm_ctx* c = h;
   TrainState* t = new TrainState();
   c->train = t;
@@ -822,6 +823,7 @@ int jcm_train_loss_grads(jcm_handle h, const float* x, const float* y, int B, in
   if (use_sm && !h->has_sm) return fail(JCM_ERR_STATE, "use_sm needs the spatial-model parameters");
   DeviceGuard g(h->device);
   CallOrder order(h);
+  if (h->call_depth > 1) return fail(JCM_ERR_STATE, "jcm_train_loss_grads changes the handle's training state or parameters and cannot be called from the gradient-ready callback of the same handle");
   jcm_ctx* c = h;
   HIP_TRY(hipMemsetAsync(grads, 0, c->train->total * sizeof(float), c->stream));   // tensors the loss does not reach keep a zero gradient
   return with_arena(c, [&] { return loss_grads_impl(c, x, y, B, H, W, use_sm, lmbd, grads, losses); });
@@ -871,6 +873,7 @@ int jcm_train_apply(jcm_handle h, const float* grads, int optimizer, float lr, f
   if (optimizer != JCM_OPT_ADAM && optimizer != JCM_OPT_MOMENTUM) return fail(JCM_ERR_ARG, "wrong optimizer");   // main.py:506
   DeviceGuard g(h->device);
   CallOrder order(h);
+  if (h->call_depth > 1) return fail(JCM_ERR_STATE, "jcm_train_apply changes the handle's training state or parameters and cannot be called from the gradient-ready callback of the same handle");
   jcm_ctx* c = h;
   TrainState* t = c->train;
   const bool clip = clip_norm > 0.f;
@@ -967,6 +970,7 @@ int jcm_update_tensor(jcm_handle h, const char* name, const float* data, int64_t
   if ((int64_t)it->second.n != count) return fail(JCM_ERR_ARG, std::string("'") + name + "' has " + std::to_string(it->second.n) + " elements");
   DeviceGuard g(h->device);
   CallOrder order(h);
+  if (h->call_depth > 1) return fail(JCM_ERR_STATE, "jcm_update_tensor changes the handle's training state or parameters and cannot be called from the gradient-ready callback of the same handle");
   HIP_TRY(hipMemcpyAsync(it->second.d, data, it->second.n * sizeof(float), hipMemcpyDefault, h->stream));
   order.release();
   const hipError_t se = hipStreamSynchronize(h->stream);   // the caller may free `data` on return

@@ -126,7 +126,7 @@ hipError_t conv_fft_f32(const ConvArgs& a, int ks, int np, int in_layout, int ou
 // the fused hand-overs of FftNext: is there a kernel for this pair of layers, and the size of the row-transformed tensor handed over
 bool conv_fft_pool_fusable(const ConvArgs& a, int ks, int ks_next);
 size_t conv_fft_pool_handover_bytes(const ConvArgs& a, int ks_next);
-bool conv_fft_merge_fusable(const ConvArgs& a, int ks, int ks_next, const FftMerge& m);
+bool conv_fft_merge_fusable(const ConvArgs& a, int ks, int ks_next, const FftMerge& m, bool h16 = false);      // h16: bf16 handles (16-bit T / T', bf16 branches)
 size_t conv_fft_xs_bytes(const ConvArgs& a, int ks, int np);
 // NHWC fp32 -> split spectra (the two forward passes); np = 4: tmax = the (zeroed) device word of this tensor
 hipError_t conv_fft_spectra(const ConvArgs& a, int ks, int np, void* work, void* xs, hipStream_t st, float* tmax = nullptr, int common = 0);

@@ -53,3 +53,28 @@ def test_bench_two_ranks_training_step():
     assert d['n_gpus'] == 2 and d['config']['batch_per_gpu'] == 2 and d['config']['global_batch'] == 4
     assert 'training' in d['metric'] and _finite(d['value']) and _finite(d['ms_per_step'])
     assert 'all_reduce' in d['config']['collective']
+
+
+def test_bench_one_rank_nccl_branch():
+    """The `nccl` branch of bench.py, as far as one GPU allows: `torch.distributed.run --nproc-per-node 1` with
+    JCM_BENCH_FORCE_DIST=1 makes bench.py create a ONE-rank RCCL group -- init_process_group('nccl', device_id=cuda:0), the barriers around the timed
+    regions, the GPU-side all_reduce(MAX) of the step time, the all-gather of the coordinates over RCCL and destroy_process_group all execute, on the
+    fixed-global-batch line (configs[3] form) and on the training step's gradient all-reduce."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, JCM_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1')
+    env.pop('JCM_BENCH_BACKEND', None)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    base = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', str(port),
+            os.path.join(ROOT, 'bench.py'), '--gpus', '1']
+    for flags in (['--global-batch', '8', '--steps', '2', '--warmup', '1', '--cpu-reps', '0'],
+                  ['--train', '--batch', '2', '--debug', '--steps', '2', '--warmup', '1']):
+        r = subprocess.run(base + flags, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, 'bench.py %s failed (%d)\n%s\n%s' % (' '.join(flags), r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+        json_lines = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith('{')]
+        assert len(json_lines) == 1, r.stdout[-2000:]
+        d = json.loads(json_lines[0])
+        assert d['n_gpus'] == 1 and _finite(d['value']) and _finite(d['ms_per_step'])

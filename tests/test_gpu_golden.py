@@ -477,3 +477,25 @@ def test_fused_handovers_other_geometries(hw):
         eng.close()
         assert np.abs(got[fuse] - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), fuse
     assert np.abs(got[0] - got[3]).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_bf16_merge_handover_vs_separate_kernels():
+    """bf16 handles hand conv4_fullres -> branch merge -> conv5 over in 16-bit row-transformed form (rows_inv_merge_fwd_reg_kernel<.., true>; option
+    "fft_fuse" bit 1): x1 is rounded to bf16 in registers exactly where the separate inverse row pass stored it, the coarse rows are lerped along y then x
+    with the FMA forms of rows_fwd_merge_reg_kernel, the merged value is rounded exactly where the separate merge rounded it, and the block-floating-point
+    tile of the 16-bit T is the same wave's.  The two arms are therefore BIT-IDENTICAL; both to the bf16-operand oracle's bar."""
+    from joint_cnn_mrf_amd.engine import Engine
+    x, torso, p = full_inputs()
+    ref = O.model(x[:1], p, emulate='bf16')
+    scale = float(np.abs(ref).max())
+    got = {}
+    for fuse in (3, 1):
+        eng = Engine(device=0, precision='bf16', fft_fuse=fuse).load_params(p)
+        got[fuse] = eng.model(dev(x)).cpu().numpy()
+        x5 = np.concatenate([x, synth.make_images(3, seed=66)], axis=0)
+        l5 = eng.model(dev(x5)).cpu().numpy()
+        eng.close()
+        assert np.array_equal(l5[:2], got[fuse]), fuse                 # an image's result does not depend on its batch
+        err = np.abs(got[fuse][:1] - ref)
+        assert err.max() <= 6e-3 * scale and np.sqrt((err ** 2).mean()) <= 1.2e-3 * scale, (fuse, float(err.max() / scale))
+    assert np.array_equal(got[3], got[1])

@@ -492,6 +492,70 @@ def test_gradient_ready_callback_may_call_the_library(debug_case):
     eng.close()
 
 
+def test_gradient_ready_callback_cannot_reenter_the_running_step(debug_case):
+    """A callback that calls an entry point of the SAME handle which uses the workspace arena or the training state (forward, conv_layer, another
+    step, an update) would overwrite the running step's activations: such calls return JCM_ERR_STATE (RuntimeError in the binding) instead of
+    corrupting the step (round 5's advisor finding), read-only entry points stay allowed, and the step's gradients are those of a step without a hook."""
+    p, x, y = debug_case
+    eng, tr = make_trainer(p, use_sm=True, lmbd=0.001)
+    tr.loss_and_grads(dev(x), dev(y))
+    want = tr.grads.clone()
+    errors, calls = [], [0]
+
+    def hook(offset, count):
+        calls[0] += 1
+        if calls[0] != 3:
+            return
+        for fn in (lambda: eng.model(dev(x)),
+                   lambda: eng.spatial_model(torch.zeros((1, 60, 90, 10), device='cuda:0')),
+                   lambda: tr.loss_and_grads(dev(x), dev(y)),
+                   lambda: eng.update_tensor('conv6/biases', np.zeros(9, np.float32))):
+            try:
+                fn()
+                errors.append(None)
+            except RuntimeError as e:
+                errors.append(str(e))
+        float(tr.get_tensor('conv6/biases', (9,)).sum())      # read-only: allowed
+    tr.set_ready_hook(hook)
+    tr.loss_and_grads(dev(x), dev(y))
+    tr.set_ready_hook(None)
+    assert len(errors) == 4 and all(e is not None and 'gradient-ready callback' in e for e in errors), errors
+    assert torch.equal(tr.grads, want)
+    eng.close()
+
+
+def test_two_host_threads_on_one_handle_are_serialised():
+    """A handle is documented as not thread-safe, but two host threads that call it were serialised by the per-call lock in rounds 1-4; round 5's
+    nesting check (an unsynchronised depth counter) misread the second thread as a nested call.  Nesting is now decided by the calling THREAD and the
+    handle carries its own mutex for the duration of an outermost call: forwards from two threads on one engine give the single-thread results."""
+    import threading
+    from joint_cnn_mrf_amd.engine import Engine
+    p = synth.make_pd_params(debug=True, bn='trained', conv6_gain=8.0)
+    eng = Engine(device=0).load_params(p)
+    xs = [dev(synth.make_images(2, seed=70 + i)) for i in range(2)]
+    want = [eng.model(xi).clone() for xi in xs]
+    got, errs = [[None] * 6, [None] * 6], []
+
+    def work(t):
+        try:
+            torch.cuda.set_device(0)
+            for i in range(6):
+                got[t][i] = eng.model(xs[t]).clone()
+            torch.cuda.synchronize()
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for t in range(2):
+        for i in range(6):
+            assert torch.equal(got[t][i], want[t]), (t, i)
+    eng.close()
+
+
 def test_window_route_follows_the_batch_and_other_map_sizes():
     """jcm_train.hip: takes_windows() sends a wide layer to 32x32 overlap-save windows for B <= 32 and to the whole-map transform above; the other
     geometry's filter spectra are dropped when the route flips.  conv5's weight and data gradient through jcm_train_layer_grads: B = 16 (windows),
