@@ -693,10 +693,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   static_assert(W == 2 * W2 && W2 % 2 == 1 && W3 % 2 == 1, "the staging loops below walk the coarse columns in pairs");
   __shared__ cf stage[4][NCS * 32];
   const int CP = C >> 1;
-  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const int h = (int)(g & 1), lane = threadIdx.x & 63;
-  const int p = (int)((g >> 1) % CP);
-  const size_t by = (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)((g >> 1) / CP));      // the row: the same for the 64 lanes (C % 64 == 0)
+  const int lane = threadIdx.x & 63, h = lane & 1;
+  int p;
+  size_t by;
+  if (C == 512) {
+    // Eight 64-channel blocks per row: work group i runs on XCD i % 8, so let it be block i % 8 of FOUR rows (one per wave) instead of four blocks of one
+    // row -- an XCD then sees one channel block of every row, and the coarse rows, which 2-8 fine rows share, stay in its L2 (the mapping of
+    // rows_fwd_merge_reg_kernel; counters, round 6: 3.30 GB fetched per 256 bf16 images with the linear mapping for 1.54 GB of T' and 0.44 GB of coarse maps)
+    p = (int)(blockIdx.x & 7) * 32 + (lane >> 1);
+    by = (size_t)(blockIdx.x >> 3) * 4 + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  } else {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    p = (int)((g >> 1) % CP);
+    by = (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)((g >> 1) / CP));      // the row: the same for the 64 lanes (C % 64 == 0)
+  }
   if (by >= (size_t)nrows) return;
   const int b = (int)(by / H), y = (int)(by % H), c = 2 * p;
   const bool odd = h != 0;
@@ -844,7 +854,7 @@ bool cfft_rows_inv_merge_fwd_reg_supported(int NX, const ConvArgs& a, const FftM
 bool cfft_rows_inv_merge_fwd_reg(int NX, const ConvArgs& a, const FftMerge& m, const cf* T, cf* Tn, int pad, float norm, const Fp16Scale& sc, hipStream_t st, float* t16n) {
   if (!cfft_rows_inv_merge_fwd_reg_supported(NX, a, m, pad) || ((t16n != nullptr) != (sc.t16_inv != nullptr))) return false;
   const int nrows = a.B * a.H;
-  const size_t threads = (size_t)nrows * a.Cout;
+  const size_t threads = a.Cout == 512 ? (size_t)((nrows + 3) / 4) * 8 * 256 : (size_t)nrows * a.Cout;      // (512 channels: eight work groups per four rows)
   const dim3 grid((unsigned)((threads + 255) / 256)), blk(256);
   const float sy2 = (float)m.H2 / (float)a.H, sy3 = (float)m.H3 / (float)a.H;
   if (t16n)
