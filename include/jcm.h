@@ -10,7 +10,9 @@
  *     fp32, dense NHWC exactly as the reference lays it out; coords are int32;
  *   - images are H rows x W cols (480 x 720, data.py:10), heat maps 60 x 90 (data.py:12);
  *   - calls enqueue asynchronously on the stream given to jcm_create and do not synchronise;
- *     one handle per (device, stream); a handle is not thread-safe;
+ *     one handle per (device, stream); a handle is not thread-safe by contract -- two host threads that call it anyway are SERIALISED
+ *     (the handle carries a mutex for the duration of an outermost entry point; re-entry from the same thread is only possible from the
+ *     gradient-ready callback, see jcm_train_set_grad_callback);
  *   - every function returns 0 on success, non-zero on error; jcm_last_error() returns a
  *     thread-local message for the last failing call;
  *   - the library owns only its packed weights, precomputed spatial-model tables and its
@@ -97,12 +99,17 @@ int jcm_abi_version(void);
  *              spectra; and the product spectra between the channel GEMM and the inverse column pass as complex fp16 under a CONSTANT
  *              power-of-two shift (2^-(ceil(log2 Cin) + 14): the scaled operands bound every product, so nothing can overflow and typical
  *              entries sit fourteen binades above fp16's smallest normal number; round 5).  0 = complex fp32 for all three (round 3).
- * "fft_fuse" : any time, default 3 (fp32 handles, jcm_pd_forward / jcm_forward on the frequency-domain route): bit 0 = conv2 -> max pool -> conv3 and
- *              bit 1 = conv4_fullres -> branch merge -> conv5 are handed over in row-transformed form: one kernel per hand-over does the inverse row
- *              transform + bias / ReLU / BatchNorm of the producing layer, the op between the layers (the 2x2 maximum of a row pair; the TF-1.x bilinear
- *              taps of the two coarse branches and the third) and the forward row transform of the consuming layer, so that neither conv2's output,
- *              the pooled map nor the full-resolution branch x1 reaches HBM.  Same arithmetic per element as the separate kernels (fp32, the
- *              reference's association order).  0 = the separate kernels of round 5 (A/B arm; held by the same tests).
+ * "fft_fuse" : any time, default 3 (jcm_pd_forward / jcm_forward on the frequency-domain route): hand-overs in row-transformed form, ONE kernel doing the
+ *              inverse row transform + bias / ReLU / BatchNorm of the producing layer, the op between the layers and the forward row transform of the
+ *              consuming layer.  bit 0 (fp32 handles) = conv2 -> 2x2 max pool -> conv3: a work group owns a row pair, takes the 2x2 maximum in LDS
+ *              and transforms the pooled row; neither conv2's output nor the pooled map reaches HBM.  bit 1 = conv4_fullres -> branch merge ->
+ *              conv5 for the model's geometry (90-column maps, branches at 1/2 and 1/4): ((x1 + up(x2)) + up(x3)) / 3 formed in registers, x1 never
+ *              reaches HBM -- fp32 handles (complex fp32 T) and bf16 handles on the one-part route (16-bit T; x1 and the merged value are rounded to
+ *              bf16 exactly where the separate kernels round them: the two arms of a bf16 handle are bit-identical).  Arithmetic: the pool hand-over
+ *              evaluates the separate kernels' expressions; the merge hand-over lerps the coarse branches along y first, then along x (TF lerps x
+ *              first: the last fp32 bit of the coarse terms, as the register merge of bf16 handles has done since round 5), third = correctly rounded
+ *              x / 3 on fp32 handles, one multiplication by RN(1/3) on bf16 handles (against the quotient: the bf16 rounding of two merged values in a
+ *              million).  0 = the separate kernels of round 5 (A/B arm; held by the same tests).
  * "sm_algo"  : any time; the pairwise convolutions of the spatial model (main.py:83-87): 3 (default) = every 120x180 transform in LDS,
  *              hand-written (sm_fused.hip; jcm_conv_mrf, the prior spectra and the training step's backward use the whole-frame
  *              kernels of sm_lds.hip); 1 = direct sliding-window kernel, the independent cross-check.  Both pass the same parity
@@ -140,7 +147,10 @@ int jcm_conv_layer(jcm_handle h, const char* scope, int stride, int last_layer, 
 /* conv_layer(((x1 + up(x2)) + up(x3)) / 3) (main.py:58,67,69-71: the three branches merged, then conv5), run as the tower runs it: where the
  * layer takes the frequency-domain route its forward row pass forms the merge while it loads the rows (the merged map never reaches memory),
  * otherwise the merge kernel runs in front of the layer.  x1 [B,H,W,Cin], x2 [B,H2,W2,Cin], x3 [B,H3,W3,Cin] -> out [B,H,W,Cout]; up() =
- * tf.image.resize_images to H x W (TF-1.x legacy bilinear).  bf16 handles: fp32 at the boundary as for jcm_conv_layer. */
+ * tf.image.resize_images to H x W (TF-1.x legacy bilinear).  bf16 handles: fp32 at the boundary as for jcm_conv_layer.
+ * Arithmetic of the merge: the generic kernels (any geometry; fp32 handles, the strict bf16 arm) lerp along x, then along y, and divide by 3 with
+ * correct rounding, as TF does; the register kernel of bf16 handles for the model's geometry (90 / 45 / 23 columns, 16-bit T) lerps along y first
+ * and multiplies by RN(1/3) -- the last fp32 bit of a value that is then rounded to bf16 (two merged values in a million round the other way). */
 int jcm_conv_layer_merged(jcm_handle h, const char* scope, const float* x1, const float* x2, int H2, int W2, const float* x3, int H3, int W3,
                           int B, int H, int W, float* out);
 /* max_pool_layer(x, 2, 2) (main.py:172-174): 2x2/2 SAME. [B,H,W,C] -> [B,ceil(H/2),ceil(W/2),C] */
@@ -269,7 +279,9 @@ int jcm_train_apply(jcm_handle h, const float* grads, int optimizer, float lr, f
  * element is reported exactly once per call.  NULL disables.
  * The callback runs WITHOUT the library's per-device call lock: it may call read-only entry points (jcm_get_tensor,
  * jcm_profile_read, jcm_last_error, another handle's calls).  It must not start a second training or forward call
- * on the SAME handle (that call would reuse the workspace the running step lives in). */
+ * on the SAME handle (that call would reuse the workspace the running step lives in): every entry point of the same handle
+ * that uses the workspace arena or changes the training state or the parameters (jcm_forward, jcm_pd_forward, jcm_conv_layer*,
+ * jcm_sm_forward, jcm_conv_mrf, jcm_train_*, jcm_update_tensor) returns JCM_ERR_STATE when called from the callback. */
 typedef void (*jcm_grad_ready_fn)(void* user, int64_t offset, int64_t count);
 int jcm_train_set_grad_callback(jcm_handle h, jcm_grad_ready_fn fn, void* user);
 int jcm_train_steps(jcm_handle h, int64_t* n_iters);     /* n_iters_tf (main.py:491) */

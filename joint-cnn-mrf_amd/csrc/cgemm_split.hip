@@ -297,11 +297,7 @@ __global__ __launch_bounds__(C::NT) void cgemm_split_kernel(Args a) {
             float2* q = yf + (size_t)row * a.ldy + n0 + fn * 32;
             // fp32 handles: streaming store (the 64-row tiles are bound by the filter spectra they read; keeping Y out of the L2 measured 366 -> 361 us, the
             // logits layer's thin tile 264 -> 243 us).  The one-part bf16 form writes as much as it reads and measured 832 -> 931 us with it: plain stores.
-#ifndef JCM_NO_NT_STORES
             constexpr bool kStream = !C::K32;
-#else
-            constexpr bool kStream = false;
-#endif
             if constexpr (kStream) {
               typedef float f2n __attribute__((ext_vector_type(2)));
               __builtin_nontemporal_store(f2n{accr[fm][fn][i], acci[fm][fn][i]}, reinterpret_cast<f2n*>(q));
@@ -325,10 +321,7 @@ using CfgB64 = Cfg<2, 1, 4, 2, 1, 2>;             // bf16 handles, <= 64 images
 // fp32 handles, np = 4: TWO FP16 parts per operand, three products (22 significant bits; the producers scale the spectra by powers of two so that
 // they fit fp16's range, conv_fft.hip) -- half the matrix-core work of the six-product bf16 form, a third less activation-spectra traffic.
 // Two fp16 parts are exactly as large as the fp32 number, so the filter spectra are stored split and both operands arrive by LDS-DMA.
-#ifndef CGEMM_H64_R
-#define CGEMM_H64_R 2
-#endif
-using CfgH64 = Cfg<2, 1, 4, 2, 1, CGEMM_H64_R, true>;      // <= 64 images
+using CfgH64 = Cfg<2, 1, 4, 2, 1, 2, true>;                // <= 64 images (ring depth 2: depth 3 measured no faster in round 5)
 using CfgH128 = Cfg<2, 2, 2, 2, 2, 2, true>;               // 65 .. 128 images per tile
 using CfgH64T = Cfg<2, 2, 1, 1, 1, 3, true>;               // Cout <= 32 (the logits layer): 64 x 32 tile, two waves
 

@@ -12,15 +12,11 @@ typedef float cf __attribute__((ext_vector_type(2)));
 // stay in the write-back L2, where they would push out the stream the kernel is reading.  (Round 4: the filter-spectra packer's 6.6 GB of writes went
 // from 3.1 to 4.5 TB/s with it; used where an A/B of the whole step showed a gain: both column passes, the fp32 inverse row pass, the fp32 handles' GEMM --
 // not the forward row passes, the staged bf16 rows, or the one-part GEMM, which measured 3-12 % slower with it.)
-#ifndef JCM_NO_NT_STORES
 __device__ __forceinline__ void st_stream(cf* p, cf v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void st_stream(unsigned* p, unsigned v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void st_stream(uint2* p, uint2 v) { typedef unsigned u2 __attribute__((ext_vector_type(2))); __builtin_nontemporal_store(u2{v.x, v.y}, reinterpret_cast<u2*>(p)); }
 __device__ __forceinline__ void st_stream(uint4* p, uint4 v) { typedef unsigned u4 __attribute__((ext_vector_type(4))); __builtin_nontemporal_store(u4{v.x, v.y, v.z, v.w}, reinterpret_cast<u4*>(p)); }
 __device__ __forceinline__ void st_stream(float4* p, float4 v) { typedef float f4 __attribute__((ext_vector_type(4))); __builtin_nontemporal_store(f4{v.x, v.y, v.z, v.w}, reinterpret_cast<f4*>(p)); }
-#else
-template <class V> __device__ __forceinline__ void st_stream(V* p, V v) { *p = v; }
-#endif
 
 __device__ __forceinline__ cf cfma(cf a, cf b, cf c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ cf sfma(float a, cf b, cf c) { return __builtin_elementwise_fma(cf{a, a}, b, c); }
