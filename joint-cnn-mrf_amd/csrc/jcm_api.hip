@@ -294,22 +294,9 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
   // Filter spectra are cached per (layer, map size).  The cache is bounded (JCM_FFT_CACHE_GB, default 64): a caller that walks many
   // image sizes (7.7 GB per size for conv5) makes it drop every spectrum that is not this layer's before it grows past the bound.
   const std::string key = scope + (circ ? "@win" : "@") + std::to_string(H) + "x" + std::to_string(W);
-  if (!c->fft_w.count(key) && c->train) {
-    // a training handle whose batch crossed the window threshold (jcm_train.hip: takes_windows) changes this layer's geometry: the other geometry's
-    // spectra (several GB for a wide layer) would otherwise stay resident until the cache bound
-    const std::string any = scope + "@", win = scope + "@win";
-    for (auto it = c->fft_w.begin(); it != c->fft_w.end();) {
-      const bool this_layer = it->first.compare(0, any.size(), any) == 0;
-      const bool is_win = it->first.compare(0, win.size(), win) == 0;
-      if (this_layer && is_win != (circ != 0)) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        (void)hipFree(it->second.p);
-        it = c->fft_w.erase(it);
-      } else {
-        ++it;
-      }
-    }
-  }
+  // (A training handle keeps the spectra of BOTH geometries of a layer -- overlap-save windows for steps of <= 32 images, the whole map for evaluation
+  // forwards and larger batches -- so that a loop that alternates training steps and evaluation does not re-pack gigabytes and stall the stream at
+  // every flip (round 5 dropped the other geometry here); the cache bound below is what limits the footprint.)
   if (!c->fft_w.count(key)) {
     static const size_t cap = [] { const char* e = std::getenv("JCM_FFT_CACHE_GB"); return (size_t)(e ? std::atoi(e) : 64) << 30; }();
     const size_t need = conv_fft_weight_bytes(H, W, L->ks, L->cin, L->cout, np, circ);

@@ -72,6 +72,10 @@ def assert_bf16_coords(got, ref_logits, ref_coords, stage):
     assert safe.sum() >= B * K // 2, 'too few golden joints with a clear margin: %d' % safe.sum()
     same = (np.asarray(got) == np.asarray(ref_coords)).all(axis=1)
     assert (same | ~safe).all(), 'bf16 arg-max differs from the golden on joints with a clear margin: %s' % (np.argwhere(~same & safe).tolist(),)
+    # ... and, margin or not, a floor over ALL the joints (rounds 3-4 held this alone): at least 85 % of them within one cell of the golden
+    if B * K >= 18:
+        near = (np.abs(np.asarray(got, np.int64) - np.asarray(ref_coords, np.int64)).max(axis=1) <= 1)
+        assert near.mean() >= 0.85, 'only %d of %d bf16 joints within one cell of the golden' % (int(near.sum()), near.size)
 
 
 def sampled_conv_grads(x, dz, w, lmbd, rs, n=40):

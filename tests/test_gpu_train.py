@@ -558,8 +558,8 @@ def test_two_host_threads_on_one_handle_are_serialised():
 
 def test_window_route_follows_the_batch_and_other_map_sizes():
     """jcm_train.hip: takes_windows() sends a wide layer to 32x32 overlap-save windows for B <= 32 and to the whole-map transform above; the other
-    geometry's filter spectra are dropped when the route flips.  conv5's weight and data gradient through jcm_train_layer_grads: B = 16 (windows),
-    B = 33 (whole map), B = 16 again on ONE handle -- the first and the third result bit-identical, the B = 33 result equal to a fresh handle's and
+    geometry's filter spectra stay in the cache (bounded by JCM_FFT_CACHE_GB) when the route flips.  conv5's weight and data gradient through jcm_train_layer_grads: B = 16 (windows),
+    B = 33 (whole map), B = 16 again on ONE handle (both geometries' spectra stay cached: round 6) -- the first and the third result bit-identical, the B = 33 result equal to a fresh handle's and
     within 1e-6 of float64 sums at sampled entries; then a 48x72 map (2 x 3 windows) with and without windows against the same float64 sums."""
     p = synth.make_pd_params(debug=False, bn='trained')
     p.update(synth.make_sm_params(synth.synthetic_priors(), kind='init'))
