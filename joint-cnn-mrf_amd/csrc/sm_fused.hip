@@ -112,8 +112,17 @@ __global__ __launch_bounds__(NT) void sm_inv_finish_kernel(const float* __restri
   // Work group i runs on XCD i % 8: the ranges are handed out so that the work groups of one XCD hold CONSECUTIVE ranges (a contiguous eighth of the images:
   // the likelihood spectra they share stay in that XCD's L2).  w = this work group's range, in unit order; its predecessor is range w - 1.
   const int G = gridDim.x;
-  const int w = (perm && G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-  const int u0 = (int)((long long)nunits * w / G), u1 = (int)((long long)nunits * (w + 1) / G);
+  const int w = (perm == 1 && G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  int u0 = (int)((long long)nunits * w / G), u1 = (int)((long long)nunits * (w + 1) / G);
+  if (perm == 2) {
+    // one work group per item, items dealt so that an XCD owns WHOLE IMAGES: work group i = (XCD i % 8, slot n = i / 8) takes joint n % K of image
+    // (i % 8) + 8 (n / K).  The 32 work groups an XCD runs at a time are then the 9 joints of 3-4 images, walking their pairs in step: at a step they
+    // want 2 of an image's 10 likelihood spectra and one prior per joint -- ~16 distinct spectra for 64 loads, served by that XCD's L2 instead of the fabric.
+    const int n = (int)(blockIdx.x / 8), b = (int)(blockIdx.x % 8) + 8 * (n / K);
+    if (b * K >= nunits / PJ) return;      // (the last images of a batch that is not a multiple of 8)
+    u0 = (b * K + n % K) * PJ;
+    u1 = u0 + PJ;
+  }
   const int i0 = u0 / PJ, q0 = u0 - i0 * PJ;                       // first item, first pair of it
   const int i1 = (u1 - 1) / PJ, q1 = (u1 - 1) - i1 * PJ + 1;       // last item, one past its last pair
   // A range holds >= PJ units (host), so it starts inside at most one item (its TAIL: pairs q0 ..) and ends inside at most one (its HEAD: pairs .. q1 - 1),
@@ -279,7 +288,11 @@ hipError_t sm_fused_forward(const float* hm, int Ca, const float* extra, int ext
   int G = items;
   if (items > resident && (double)rounds * resident > 1.15 * (double)items) G = resident;      // every range then holds >= C - 1 units (the kernel's cut rule)
   if (const char* e = std::getenv("JCM_SM_G")) { const int g = std::atoi(e); if (g > 0 && g <= items && (items % g == 0 || g <= resident)) G = g; }      // (tools/sm_time.py sweeps)
-  static const int perm = 0;      // XCD-contiguous ranges measured no different (0.368 / 0.374 ms): the spectra come over the fabric either way
+  static const int perm_env = [] { const char* e = std::getenv("JCM_SM_PERM"); return e ? std::atoi(e) : 2; }();
+  // 2 (default): whole images per XCD where every work group is one item (256 images alone: 1.28 -> 1.20 ms, inside the bf16 step 1.32 -> 1.29 ms); 1: XCD-contiguous
+  // ranges of the balanced cut (measured no different from 0)
+  const int perm = (perm_env == 2 && G != items) ? 0 : perm_env;
+  if (perm == 2) G = 8 * ((B + 7) / 8) * K;
   float* part = static_cast<float*>(scratch);
   unsigned* flags = reinterpret_cast<unsigned*>(static_cast<char*>(scratch) + (size_t)resident * MHW * sizeof(float));
   hipLaunchKernelGGL(sm_inv_finish_kernel, dim3(G), dim3(NT), LDS_BYTES, st, hm, Ca, extra, extra_ld, sc, sh, lhat_t, phat_t, cond, spbias, logits, K, C, tsave, B * K * (C - 1),
