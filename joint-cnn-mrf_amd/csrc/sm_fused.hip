@@ -74,10 +74,11 @@ __global__ __launch_bounds__(NT) void sm_fwd_spectra_kernel(const float* __restr
 // rounds 2-5 launched one work group per (image, joint): 64 images = 576 work groups on 256 CUs = 2.25 waves, run as 3 (391 us where 272 would do).
 // Now G work groups (one per CU, at most one per (image, joint)) take the U = B K (C-1) units in G contiguous, equal ranges.  A range of >= C-1 units starts
 // inside at most one (image, joint) item and ends inside at most one; the sum of an item's log terms is kept IN GRAPH ORDER across the cut:
+//   (the ranges: eight XCD shares of whole items, each cut into equal ranges for that XCD's work groups -- see the kernel body)
 //   * the work group whose range ENDS inside an item does that HEAD first: e = log(lik + 1e-6) + terms 0 .. q-1, stores e in its partial-sum slot and
 //     raises its flag (release at device scope);
-//   * the work group whose range STARTS inside the item does that TAIL last: by then the flag of its predecessor (a lower block index: dispatched no
-//     later, and it publishes after at most C-2 pairs) has long been raised; it reads the partial sums (acquire) and goes on adding terms q .. C-2 in order.
+//   * the work group whose range STARTS inside the item does that TAIL last: by then the flag of its predecessor (the previous slot of the same XCD's
+//     queue: dispatched earlier, and it publishes after at most C-2 pairs) has long been raised; it reads the partial sums (acquire) and goes on adding terms q .. C-2 in order.
 // Every logit is therefore the same fp32 sum, term by term, as in the one-work-group-per-item kernel, whatever the batch size cuts where.
 // Flags carry the launch's epoch (a counter of the handle), so they are never reset.
 __global__ __launch_bounds__(NT) void sm_inv_finish_kernel(const float* __restrict__ hm, int Ca, const float* __restrict__ extra, int extra_ld,
@@ -108,20 +109,30 @@ __global__ __launch_bounds__(NT) void sm_inv_finish_kernel(const float* __restri
   constexpr int NG = NT / WC;                       // packing step: thread = (column pk, row-pair group pg)
   const int pk = tid % WC, pg = tid / WC;
 
-  // this work group's units [u0, u1)
-  // Work group i runs on XCD i % 8: the ranges are handed out so that the work groups of one XCD hold CONSECUTIVE ranges (a contiguous eighth of the images:
-  // the likelihood spectra they share stay in that XCD's L2).  w = this work group's range, in unit order; its predecessor is range w - 1.
-  const int G = gridDim.x;
-  const int w = (perm == 1 && G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-  int u0 = (int)((long long)nunits * w / G), u1 = (int)((long long)nunits * (w + 1) / G);
+  // this work group's units [u0, u1).  Work group i runs on XCD i % 8 (slot i / 8 of that XCD's in-order queue).
+  //   perm 2 -- one work group per item, items dealt so that an XCD owns WHOLE IMAGES: work group i takes joint n % K of image (i % 8) + 8 (n / K), n = i / 8.
+  //             The 32 work groups an XCD runs at a time are then the 9 joints of 3-4 images, walking their pairs in step: at a step they want 2 of an
+  //             image's 10 likelihood spectra and one prior per joint -- ~16 distinct spectra for 64 loads, served by that XCD's L2 instead of the fabric.
+  //   perm 0 -- the balanced cut (G a multiple of 8): the ITEMS are split eight ways, one contiguous share per XCD, and an XCD's share of units is cut into
+  //             equal ranges for its G / 8 slots.  A range's predecessor is therefore work group i - 8: the previous slot of the SAME XCD queue, placed on
+  //             a CU before this one whatever else shares the GPU -- a work group never waits for one that has not been dispatched, so two handles'
+  //             kernels (two streams, two processes) cannot hold each other's CUs in a cycle.  No range crosses an XCD's share: slot 0 has no tail, the
+  //             last slot no head.
+  const int G = gridDim.x, w = (int)blockIdx.x;
+  int u0, u1;
   if (perm == 2) {
-    // one work group per item, items dealt so that an XCD owns WHOLE IMAGES: work group i = (XCD i % 8, slot n = i / 8) takes joint n % K of image
-    // (i % 8) + 8 (n / K).  The 32 work groups an XCD runs at a time are then the 9 joints of 3-4 images, walking their pairs in step: at a step they
-    // want 2 of an image's 10 likelihood spectra and one prior per joint -- ~16 distinct spectra for 64 loads, served by that XCD's L2 instead of the fabric.
-    const int n = (int)(blockIdx.x / 8), b = (int)(blockIdx.x % 8) + 8 * (n / K);
+    const int n = w / 8, b = w % 8 + 8 * (n / K);
     if (b * K >= nunits / PJ) return;      // (the last images of a batch that is not a multiple of 8)
     u0 = (b * K + n % K) * PJ;
     u1 = u0 + PJ;
+  } else if (perm == 1) {      // one work group per item, in launch order (the A/B arm of 2)
+    u0 = w * PJ;
+    u1 = u0 + PJ;
+  } else {
+    const int nitems = nunits / PJ, xcd = w % 8, slot = w / 8, S = G / 8;
+    const int lo = (int)((long long)nitems * xcd / 8) * PJ, hi = (int)((long long)nitems * (xcd + 1) / 8) * PJ;
+    u0 = lo + (int)((long long)(hi - lo) * slot / S);
+    u1 = lo + (int)((long long)(hi - lo) * (slot + 1) / S);
   }
   const int i0 = u0 / PJ, q0 = u0 - i0 * PJ;                       // first item, first pair of it
   const int i1 = (u1 - 1) / PJ, q1 = (u1 - 1) - i1 * PJ + 1;       // last item, one past its last pair
@@ -165,13 +176,13 @@ __global__ __launch_bounds__(NT) void sm_inv_finish_kernel(const float* __restri
     asm volatile("" : "+v"(tix));
     if (seg_first) {
       if (in_tail) {
-        // the partial sums of the work group in front (its head of this item): wait for its flag, then read them at device scope
+        // the partial sums of the previous slot of this XCD (work group w - 8: its head of this item): wait for its flag, then read them at device scope
         if (tid == 0) {
-          while (__hip_atomic_load(flags + (w - 1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(8);
+          while (__hip_atomic_load(flags + (w - 8), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(8);
         }
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const float* __restrict__ ps = part + (size_t)(w - 1) * MHW;
+        const float* __restrict__ ps = part + (size_t)(w - 8) * MHW;
 #pragma unroll
         for (int i = 0; i < NPIX; ++i) {
           const int pix = tix + i * NT;
@@ -288,10 +299,10 @@ hipError_t sm_fused_forward(const float* hm, int Ca, const float* extra, int ext
   int G = items;
   if (items > resident && (double)rounds * resident > 1.15 * (double)items) G = resident;      // every range then holds >= C - 1 units (the kernel's cut rule)
   if (const char* e = std::getenv("JCM_SM_G")) { const int g = std::atoi(e); if (g > 0 && g <= items && (items % g == 0 || g <= resident)) G = g; }      // (tools/sm_time.py sweeps)
-  static const int perm_env = [] { const char* e = std::getenv("JCM_SM_PERM"); return e ? std::atoi(e) : 2; }();
-  // 2 (default): whole images per XCD where every work group is one item (256 images alone: 1.28 -> 1.20 ms, inside the bf16 step 1.32 -> 1.29 ms); 1: XCD-contiguous
-  // ranges of the balanced cut (measured no different from 0)
-  const int perm = (perm_env == 2 && G != items) ? 0 : perm_env;
+  // the cut needs eight XCD shares of whole slots (G a multiple of 8, every range >= C - 1 units: items / 8 >= G / 8); otherwise one work group per item
+  if (G != items && (G % 8 != 0 || items / 8 < G / 8)) G = items;
+  static const int perm_env = [] { const char* e = std::getenv("JCM_SM_PERM"); return e ? std::atoi(e) : 2; }();      // (1: items in launch order -- the A/B arm of 2)
+  const int perm = G == items ? (perm_env == 2 ? 2 : 1) : 0;
   if (perm == 2) G = 8 * ((B + 7) / 8) * K;
   float* part = static_cast<float*>(scratch);
   unsigned* flags = reinterpret_cast<unsigned*>(static_cast<char*>(scratch) + (size_t)resident * MHW * sizeof(float));
