@@ -67,7 +67,7 @@ __device__ __forceinline__ bf16x8 frag_pack(const Frag& f) {
 
 // NP = 2, HALF = true: two FP16 parts of the scaled spectra (conv_fft's np = 4), three products; P comes out scaled by both operands' powers of two, which the taps kernel undoes.
 template <int NP, bool HALF>
-__global__ __launch_bounds__(NT) void wgrad_spec_kernel(Args a) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_spec_kernel(Args a) {
   constexpr int OPER = 2 * NP * PLANE, SEGS = 8 * 2 * NP * 2;      // one operand in LDS; (chunk, re|im, part, k-half) segments of 16 images x 16 bytes
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -97,9 +97,11 @@ __global__ __launch_bounds__(NT) void wgrad_spec_kernel(Args a) {
   static_assert(2 * SEGS * 16 % NT == 0, "whole loads per thread");
   uint4 pre[NLD];
   auto fetch = [&](int r0) __attribute__((always_inline)) {
+    int tt = tid;      // opaque per call: the segment decode below is recomputed (a few integer instructions) instead of being hoisted out of the k loop and spilled
+    asm volatile("" : "+v"(tt));
 #pragma unroll
     for (int q = 0; q < NLD; ++q) {
-      const int idx = tid + q * NT;
+      const int idx = tt + q * NT;
       const int op = idx / (SEGS * 16), r = idx - op * SEGS * 16;
       const int seg = r >> 4, j = r & 15;
       const int kg = seg & 1, cp = (seg >> 1) % (2 * NP), kcl = seg / (4 * NP);      // cp = re|im * NP + part
@@ -117,9 +119,11 @@ __global__ __launch_bounds__(NT) void wgrad_spec_kernel(Args a) {
   for (int r0 = 0; r0 < rows_valid; r0 += 16) {      // (16 divides both tile heights: a step never straddles two M tiles)
     __syncthreads();      // the previous step's fragments have been read
     // stage both operands: (8 chunks x re|im x part x k-half) segments of 16 images x 16 bytes, as they lie in HBM
+    int ts = tid;
+    asm volatile("" : "+v"(ts));
 #pragma unroll
     for (int q = 0; q < NLD; ++q) {
-      const int idx = tid + q * NT;
+      const int idx = ts + q * NT;
       const int op = idx / (SEGS * 16), r = idx - op * SEGS * 16;
       const int seg = r >> 4, j = r & 15;
       const int kg = seg & 1, cp = (seg >> 1) % (2 * NP), kcl = seg / (4 * NP);
