@@ -336,6 +336,7 @@ size_t conv_fft_handover_bytes(const ConvArgs& a, int ks) {      // T[kx][c/16][
   if (!sizes_of(a.H, a.W, ks, &s)) return 0;
   return (size_t)a.B * (s.NX / 2 + 1) * a.H * a.Cout * sizeof(cf);
 }
+bool conv_fft_win_gather_supported(int win, int Cin) { return fft_reg_on() && cfft_rows_fwd_win_reg_supported(win, Cin); }
 // the fused hand-overs across a max pool / the branch merge (FftNext, conv_fft_rows_fused.hip)
 bool conv_fft_pool_fusable(const ConvArgs& a, int ks, int ks_next) {
   Sizes s, n;
@@ -410,7 +411,8 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
     if (merge && !t_in) {
       if (!(fft_reg && cfft_rows_fwd_merge_reg(s.NX, a, *merge, in_layout, T, sc.tmax, st, sc.t16_fwd))) cfft_rows_fwd_merge(s.NX, a, *merge, in_layout, T, twx, sc.tmax, st, sc.t16_fwd);
     } else if (!t_in) {
-      if (!(fft_reg && cfft_rows_fwd_reg(s.NX, a, in_layout, T, sc.tmax, st, sc.t16_fwd))) cfft_rows_fwd(s.NX, a, in_layout, T, twx, sc.tmax, st, sc.t16_fwd);
+      if (a.win_map) { if (!cfft_rows_fwd_win_reg(s.NX, a, T, sc.tmax, st)) return hipErrorInvalidValue; }
+      else if (!(fft_reg && cfft_rows_fwd_reg(s.NX, a, in_layout, T, sc.tmax, st, sc.t16_fwd))) cfft_rows_fwd(s.NX, a, in_layout, T, twx, sc.tmax, st, sc.t16_fwd);
     }
     if (hipError_t ce = cfft_cols_fwd(s.NY, a, np, Tin, Xs, twy, p.NXH, p.MT, sc, st); ce != hipSuccess) return ce;
   }
@@ -464,7 +466,8 @@ hipError_t conv_fft_spectra(const ConvArgs& a0, int ks, int np, void* work, void
   const cf* twb = twiddle_table(dev);
   if (!twb) return hipErrorOutOfMemory;
   cf* T = static_cast<cf*>(work);
-  cfft_rows_fwd(s.NX, a, 0, T, twb + tw_offset(s.NX), sc.tmax, st);
+  if (a.win_map) { if (!cfft_rows_fwd_win_reg(s.NX, a, T, sc.tmax, st)) return hipErrorInvalidValue; }
+  else cfft_rows_fwd(s.NX, a, 0, T, twb + tw_offset(s.NX), sc.tmax, st);
   if (hipError_t ce = cfft_cols_fwd(s.NY, a, np, T, xs, twb + tw_offset(s.NY), p.NXH, p.MT, sc, st); ce != hipSuccess) return ce;
   return hipGetLastError();
 }

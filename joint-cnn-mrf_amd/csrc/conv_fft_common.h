@@ -313,6 +313,9 @@ void cfft_rows_inv(int NX, const ConvArgs& a, int layout, const cf* T, const cf*
 bool cfft_rows_inv_reg(int NX, const ConvArgs& a, int layout, const cf* T, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
 bool cfft_rows_inv_fwd_reg(int NX, const ConvArgs& a, const cf* T, cf* Tn, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
 bool cfft_rows_fwd_reg(int NX, const ConvArgs& a, int layout, cf* T, float* tmax, hipStream_t st, float* t16);
+// 32 x 32 overlap-save windows read straight from the map they are cut from (a.win_map, fp32 NHWC; Cin % 128 == 0): false = no such kernel
+bool cfft_rows_fwd_win_reg(int NX, const ConvArgs& a, cf* T, float* tmax, hipStream_t st);
+bool cfft_rows_fwd_win_reg_supported(int NX, int Cin);
 bool cfft_rows_fwd_merge_reg(int NX, const ConvArgs& a, const FftMerge& m, int in_layout, cf* T, float* tmax, hipStream_t st, float* t16);
 bool cfft_cols_inv_reg(int NY, const ConvArgs& a, const cf* Yf, cf* T, int NXH, int ldy, int pad, hipStream_t st, float* t16, float y16_inv = 0.f);
 void cfft_rows_inv_fwd(int NX, const ConvArgs& a, const cf* T, cf* Tn, const cf* tw, int pad, float norm, const Fp16Scale& sc, hipStream_t st);

@@ -391,6 +391,69 @@ bool cfft_rows_fwd_reg(int NX, const ConvArgs& a, int layout, cf* T, float* tmax
   return true;
 }
 
+// ---- rows, forward, of OVERLAP-SAVE WINDOWS read straight from the map they are cut from (fp32 handles, the training step's 32 x 32 windows; the contract of
+// window_gather_kernel + rows_fwd_kernel<32, 0>): ONE thread per (window row, channel pair) -- a 32-point transform is 64 registers.  A wave is 64 channel
+// pairs of one window row (Cin % 128 == 0), so the window, its row and the validity of each of its 32 pixels are scalars: a pixel inside the map is one buffer
+// load (the map row is the descriptor, the column a scalar offset, the lane's channel pair the vector offset), a pixel outside it -- or in the 4-pixel halo
+// when the caller wants the valid region only (the weight gradient's dZ) -- a literal zero.  The gathered window tensor (0.4 GB per conv5 pass at 16 images)
+// is never written or read.
+template <int NX>
+__global__ __launch_bounds__(256) void rows_fwd_win_reg_kernel(const float* __restrict__ map, float4* __restrict__ T, int nrows, int BW, int H, int W, int C, int TY, int TX,
+                                                               int valid_only, float* __restrict__ tmax) {
+  constexpr int NXH = NX / 2 + 1, R1 = RPlan<NX>::R1, R2 = RPlan<NX>::R2, V = NX - 8;
+  const int CP = C >> 1;
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int p = (int)(g % CP);
+  const int row = __builtin_amdgcn_readfirstlane((int)(g / CP));      // (window, wy): the same for the 64 lanes (C % 128 == 0)
+  if (row >= nrows) return;
+  const int wy = row % NX, bw = row / NX;
+  const int tx = bw % TX, ty = (bw / TX) % TY, b = bw / (TX * TY);
+  const int y = ty * V - 4 + wy, x0 = tx * V - 4;
+  const bool row_in = y >= 0 && y < H && !(valid_only && (wy < 4 || wy >= NX - 4));
+  cf z[NX];
+  {
+    const auto d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(map) + ((size_t)b * H + (row_in ? y : 0)) * W * C, 0, W * C * 4, 0x00020000);
+    typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int wx = 0; wx < NX; ++wx) {
+      const int x = x0 + wx;
+      const bool in = row_in && x >= 0 && x < W && !(valid_only && (wx < 4 || wx >= NX - 4));      // wave-uniform
+      z[wx] = cf{0.f, 0.f};
+      if (in) z[wx] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(d, p * 8, x * C * 4, 0));
+    }
+  }
+  step1<NX, -1>(z);
+  step2_inplace<NX, -1, 0>(z);      // z[R2 (k % R1) + k / R1] = Z[k]
+  // Z = FFT(x_c + i x_{c+1}):  X_c[k] = (Z[k] + conj Z[-k]) / 2,  X_{c+1}[k] = (Z[k] - conj Z[-k]) / (2i)  ->  T[kx][c/16][window][wy][16]
+  const int cblk = p >> 5, v = p & 31;
+  float4* dst = T + ((((size_t)cblk * 4 + (v >> 3)) * BW + bw) * NX + wy) * 8 + (v & 7);      // t_fwd_index(k = 0); per kx: + (C / 16) BW NX 8
+  const size_t kstride = (size_t)(C >> 4) * BW * NX * 8;
+  float m = 0.f;
+#pragma unroll
+  for (int k = 0; k < NXH; ++k) {
+    const int kn = k == 0 ? 0 : NX - k;
+    const cf zk = z[R2 * (k % R1) + k / R1], zn = z[R2 * (kn % R1) + kn / R1];
+    const float4 o = make_float4(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y), 0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+    dst[(size_t)k * kstride] = o;
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+  }
+  if (tmax) {      // the window's word of the spectra's scale (values >= 0 order like unsigned)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(tmax + bw), __float_as_uint(m));
+  }
+}
+bool cfft_rows_fwd_win_reg_supported(int NX, int Cin) { return NX == 32 && Cin % 128 == 0; }
+bool cfft_rows_fwd_win_reg(int NX, const ConvArgs& a, cf* T, float* tmax, hipStream_t st) {
+  if (!a.win_map || !cfft_rows_fwd_win_reg_supported(NX, a.Cin) || a.H != NX || a.W != NX || a.B != a.win_B * a.win_TY * a.win_TX) return false;
+  if ((size_t)a.win_W * a.Cin * 4 >= (size_t)1 << 31) return false;
+  const int nrows = a.B * NX;
+  const size_t threads = (size_t)nrows * (a.Cin / 2);
+  hipLaunchKernelGGL(rows_fwd_win_reg_kernel<32>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, static_cast<const float*>(a.win_map), reinterpret_cast<float4*>(T), nrows, a.B,
+                     a.win_H, a.win_W, a.Cin, a.win_TY, a.win_TX, a.win_valid_only, tmax);
+  return true;
+}
+
 // ---- rows, forward, of the MERGED map x = ((x1 + up(x2)) + up(x3)) / 3 (main.py:58,67,69-70) of a bf16 handle, for the model's own geometry
 // (W x 2 W2 maps: 90 / 45 / 23 columns): the contract of rows_fwd_merge_kernel<NX, true, true> (conv_fft_rows_fwd.hip), whose generic taps -- eight
 // gathers, two tap computations and twelve lerps per element -- make it the one transform pass bound by vector-ALU issue slots (1.5 ms per 256 images at

@@ -106,6 +106,9 @@ struct jcm_ctx {
   unsigned sm_epoch = 0;        // ... the launch counter its flags carry
   int fft_fuse = 3;             // fp32 handles, jcm_pd_forward: bit 0 = conv2 -> max pool -> conv3, bit 1 = conv4_fullres -> branch merge -> conv5 handed over in row-transformed form (conv_fft_rows_fused.hip)
   int fft_next_pool = 0, fft_next_ks = 0;      // transient, with fft_t_next: a 2x2 max pool lies between this layer and the one fft_t_next is for (kernel size fft_next_ks)
+  // transient: the next frequency-domain layer's input windows are cut from this map by its forward row pass (ConvArgs::win_map; jcm_train.hip)
+  const void* fft_win_map = nullptr;
+  int fft_win_B = 0, fft_win_H = 0, fft_win_W = 0, fft_win_TY = 0, fft_win_TX = 0;
   bool fft_t_in_16 = false;                     // transient, with fft_t_in (bf16 handles): the handed-over T is complex fp16 + its scale words (conv4_fullres -> conv5)
   const void* fft_next_merge = nullptr;        // transient, with fft_t_next: const jcm::FftMerge* -- fft_t_next is the row-transformed MERGED map (this layer = the full-resolution branch)
   const void* fft_merge = nullptr;   // const jcm::FftMerge*: the next frequency-domain layer forms the merged map itself (jcm_pd_forward, conv5)

@@ -195,9 +195,12 @@ int conv_train_fwd_conv(jcm_ctx* c, LayerFwd& f, int stride, const void* x, int 
     ax.B = BW; ax.H = kWin; ax.W = kWin; ax.Cin = L.cin; ax.Cout = L.cout; ax.circ = 1;
     f.xs = arena_alloc<char>(c, conv_fft_xs_bytes(ax, L.ks, fft_np(c)));
     const size_t mark = c->arena_off;
-    float* xw = arena_alloc<float>(c, (size_t)BW * kWin * kWin * L.cin);
+    // (round 6: where the forward row pass can cut the windows out of the map itself, the gathered tensor does not exist)
+    const bool gw = conv_fft_win_gather_supported(kWin, L.cin);
+    float* xw = gw ? nullptr : arena_alloc<float>(c, (size_t)BW * kWin * kWin * L.cin);
     float* rw = arena_alloc<float>(c, (size_t)BW * kWinValid * kWinValid * L.cout);
-    if (!c->dry) HIP_TRY(window_gather_f32(static_cast<const float*>(x), xw, B, Hin, Win, L.cin, kWin, TY, TX, 0, c->stream));
+    if (!c->dry && !gw) HIP_TRY(window_gather_f32(static_cast<const float*>(x), xw, B, Hin, Win, L.cin, kWin, TY, TX, 0, c->stream));
+    if (gw) { c->fft_win_map = x; c->fft_win_B = B; c->fft_win_H = Hin; c->fft_win_W = Win; c->fft_win_TY = TY; c->fft_win_TX = TX; }
     c->fft_xs = f.xs;
     JCM_TRY(run_conv_fft(c, &L, f.scope, xw, BW, kWin, kWin, rw, 0, 0, 1));
     if (!c->dry) {
@@ -265,9 +268,11 @@ int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int ldz, int B, fl
     if (!conv_fft_geometry(kWin, kWin, L->ks, BW, L->cout, np, &NY, &NX, &MTx, 1) || !conv_fft_geometry(kWin, kWin, L->ks, BW, L->cin, np, &ny2, &nx2, &MTz, 1))
       return fail(JCM_ERR_STATE, "window geometry of '" + f.scope + "'");
     const size_t mark = c->arena_off;
-    float* zw = arena_alloc<float>(c, (size_t)BW * kWin * kWin * ldz);
+    const bool gw = conv_fft_win_gather_supported(kWin, ldz);
+    float* zw = gw ? nullptr : arena_alloc<float>(c, (size_t)BW * kWin * kWin * ldz);
     ConvArgs az{};
     az.x = zw; az.B = BW; az.H = kWin; az.W = kWin; az.Cin = ldz; az.Cout = L->cin; az.circ = 1;
+    if (gw) { az.win_map = dz; az.win_B = B; az.win_H = f.H; az.win_W = f.W; az.win_TY = f.TY; az.win_TX = f.TX; az.win_valid_only = 1; }
     char* zs = arena_alloc<char>(c, conv_fft_xs_bytes(az, L->ks, np));
     char* work = arena_alloc<char>(c, conv_fft_workspace_bytes(az, L->ks, np));
     char* P = arena_alloc<char>(c, wgrad_fft_scratch_bytes(NY, NX, L->cin, ldz));
@@ -276,7 +281,7 @@ int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int ldz, int B, fl
       JCM_TRY(prof_begin(c, &e0, &e1));
       float* ztmax = nullptr;
       if (np == 4) JCM_TRY(fft_new_words(c, BW, &ztmax));
-      hipError_t le = window_gather_f32(static_cast<const float*>(dz), zw, B, f.H, f.W, ldz, kWin, f.TY, f.TX, 1, c->stream);
+      hipError_t le = gw ? hipSuccess : window_gather_f32(static_cast<const float*>(dz), zw, B, f.H, f.W, ldz, kWin, f.TY, f.TX, 1, c->stream);
       if (le == hipSuccess) le = conv_fft_spectra(az, L->ks, np, work, zs, c->stream, ztmax, 1);
       if (le == hipSuccess)
         le = wgrad_fft(f.xs, zs, P, L->w_raw, lmbd, grad_of(t, grads, f.scope + "/weights"), L->ks, NY, NX, BW, MTx, MTz, L->cin, ldz, L->cout, c->stream,
@@ -377,9 +382,11 @@ int conv_dgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int B, void* dx, i
         HIP_TRY(flip_transpose_weights(f.L->w_raw, t->scratch_flip, f.L->ks, f.L->cin, f.L->cout, cin_fft, c->stream));
       t->zs = nullptr;
       const size_t mark = c->arena_off;
-      float* zw = arena_alloc<float>(c, (size_t)BW * kWin * kWin * cin_fft);
+      const bool gw = conv_fft_win_gather_supported(kWin, cin_fft);
+      float* zw = gw ? nullptr : arena_alloc<float>(c, (size_t)BW * kWin * kWin * cin_fft);
       float* xw = arena_alloc<float>(c, (size_t)BW * kWinValid * kWinValid * f.L->cin);
-      if (!c->dry) HIP_TRY(window_gather_f32(static_cast<const float*>(dz), zw, B, f.H, f.W, cin_fft, kWin, f.TY, f.TX, 0, c->stream));
+      if (!c->dry && !gw) HIP_TRY(window_gather_f32(static_cast<const float*>(dz), zw, B, f.H, f.W, cin_fft, kWin, f.TY, f.TX, 0, c->stream));
+      if (gw) { c->fft_win_map = dz; c->fft_win_B = B; c->fft_win_H = f.H; c->fft_win_W = f.W; c->fft_win_TY = f.TY; c->fft_win_TX = f.TX; }
       JCM_TRY(run_conv_fft(c, &Ld, key, zw, BW, kWin, kWin, xw, 0, 0, 1));
       if (!c->dry) HIP_TRY(window_scatter_f32(xw, static_cast<float*>(dx), B, f.H, f.W, f.L->cin, kWin, f.TY, f.TX, c->stream));
       c->arena_off = mark;

@@ -52,6 +52,11 @@ struct ConvArgs {
   // regions [B, H - 8, W - 8, Cout]: row j of it is row j + 4 + (k - 1) / 2 of the circular convolution.  The filter spectra shrink with the window
   // (32 x 32: 544 frequencies instead of the 3136 of a 60 x 90 map), which is what pays when the batch is small.
   int circ = 0;
+  // ... whose windows need not exist as a tensor (round 6): win_map = the [win_B, win_H, win_W, Cin] fp32 map they are cut from (x is then unused) -- window
+  // (b, ty, tx) of the win_TY x win_TX grid covers map rows ty (H - 8) - 4 .. + H, columns tx (W - 8) - 4 .. + W, zeros outside the map (and in the halo of 4
+  // when win_valid_only: the weight gradient's dZ).  The forward row pass gathers while it loads (conv_fft_win_gather_supported()).
+  const void* win_map = nullptr;
+  int win_B = 0, win_H = 0, win_W = 0, win_TY = 0, win_TX = 0, win_valid_only = 0;
 };
 int conv_igemm_bn(int Cout);                     // N-tile the dispatcher will use for this Cout
 hipError_t conv_igemm_f32(const ConvArgs& a, int ks, hipStream_t st);
@@ -124,6 +129,7 @@ struct FftNext { int pool = 0; int ks_next = 0; const FftMerge* merge = nullptr;
 hipError_t conv_fft_f32(const ConvArgs& a, int ks, int np, int in_layout, int out_layout, void* work, const void* t_in, void* t_next, const FftMerge* merge,
                         hipEvent_t g0, hipEvent_t g1, hipStream_t st, void* xs = nullptr, bool xs_ready = false, const Fp16Scale* sc = nullptr, const FftNext* nx = nullptr);
 // the fused hand-overs of FftNext: is there a kernel for this pair of layers, and the size of the row-transformed tensor handed over
+bool conv_fft_win_gather_supported(int win, int Cin);      // can the forward row pass of `win` x `win` overlap-save windows read them straight from the map?
 bool conv_fft_pool_fusable(const ConvArgs& a, int ks, int ks_next);
 size_t conv_fft_pool_handover_bytes(const ConvArgs& a, int ks_next);
 bool conv_fft_merge_fusable(const ConvArgs& a, int ks, int ks_next, const FftMerge& m, bool h16 = false);      // h16: bf16 handles (16-bit T / T', bf16 branches)
