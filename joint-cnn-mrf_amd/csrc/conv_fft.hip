@@ -337,6 +337,7 @@ size_t conv_fft_handover_bytes(const ConvArgs& a, int ks) {      // T[kx][c/16][
   return (size_t)a.B * (s.NX / 2 + 1) * a.H * a.Cout * sizeof(cf);
 }
 bool conv_fft_win_gather_supported(int win, int Cin) { return fft_reg_on() && cfft_rows_fwd_win_reg_supported(win, Cin); }
+bool conv_fft_win_scatter_supported(int win, int Cout) { return fft_reg_on() && win == 32 && Cout % 64 == 0; }      // rows_inv_reg_kernel<32, 0, false>
 // the fused hand-overs across a max pool / the branch merge (FftNext, conv_fft_rows_fused.hip)
 bool conv_fft_pool_fusable(const ConvArgs& a, int ks, int ks_next) {
   Sizes s, n;
@@ -442,6 +443,7 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
   } else if (t_next) {
     if (!(fft_reg && cfft_rows_inv_fwd_reg(s.NX, a, T, static_cast<cf*>(t_next), opad, norm, sc, st))) cfft_rows_inv_fwd(s.NX, a, T, static_cast<cf*>(t_next), twx, opad, norm, sc, st);
   } else if (!(fft_reg && cfft_rows_inv_reg(s.NX, ai, out_layout, T, opad, norm, sc, st))) {
+    if (ai.wout_TX > 0) return hipErrorInvalidValue;      // (the scatter into the map exists in the register kernel only)
     cfft_rows_inv(s.NX, ai, out_layout, T, twx, opad, norm, sc, st);
   }
   return hipGetLastError();

@@ -76,7 +76,8 @@ __device__ __forceinline__ void inv_rows_load2(cf (&u)[NX / 2], float sg, bool o
 template <int NX, int LAYOUT, bool T16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NX >= 64 ? 2 : 4, NX >= 64 ? 2 : 8))) void rows_inv_reg_kernel(const void* __restrict__ T, void* __restrict__ out, const float* __restrict__ bias,
                                                                                               const float* __restrict__ scale, const float* __restrict__ shift, int relu_bn,
-                                                                                              int nrows, int H, int W, int C, int Cout, int pad, float norm0, Fp16Scale sc) {
+                                                                                              int nrows, int H, int W, int C, int Cout, int pad, float norm0, Fp16Scale sc,
+                                                                                              int smH, int smW, int sTY, int sTX) {
   constexpr int NXH = NX / 2 + 1, M = NX / 2;
   __shared__ __attribute__((aligned(16))) unsigned stage[LAYOUT != 0 ? 4 * M * 64 : 4];      // bf16 outputs: one row (M x 2 pixels x 32 pairs) per wave
   const int CP = C >> 1;
@@ -145,12 +146,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NX >= 64 ? 
   }
   step1<M, 1>(u);
   const int lane = threadIdx.x & 63;
+  // scatter of overlap-save windows (sTX > 0; scalars: the row is the wave's): row `by` = valid row yv of window bw = (image, ty, tx)
+  int sc_row = -1, sc_x0 = 0;
+  if (LAYOUT == 0 && sTX > 0) {
+    const int bw = (int)(by / H), yv = (int)(by % H);
+    const int tx = bw % sTX, ty = (bw / sTX) % sTY, bi = bw / (sTX * sTY), ym = ty * H + yv;
+    sc_row = ym < smH ? bi * smH + ym : -1;
+    sc_x0 = tx * W;
+  }
   unsigned* wst = stage + (LAYOUT != 0 ? (threadIdx.x >> 6) * (M * 64) : 0);
   auto store = [&](int m, int xo, cf z) __attribute__((always_inline)) {
     float v0 = fmaf(z.x, norm, b0v), v1 = fmaf(z.y, norm, b1v);      // (single roundings: this kernel is instruction-bound)
     if (relu_bn) { v0 = fmaf(fmaxf(v0, 0.f), s0, h0); v1 = fmaf(fmaxf(v1, 0.f), s1, h1); }
     if constexpr (LAYOUT == 0) {
-      st_stream(reinterpret_cast<cf*>(static_cast<float*>(out) + (by * W + xo) * Cout + c), cf{v0, v1});
+      if (sTX > 0) {      // overlap-save windows: the valid region goes straight to its place in the map (the rows / columns of the last windows that hang over the map are dropped)
+        const int xm = sc_x0 + xo;
+        if (sc_row >= 0 && xm < smW) st_stream(reinterpret_cast<cf*>(static_cast<float*>(out) + ((size_t)sc_row * smW + xm) * Cout + c), cf{v0, v1});
+      } else {
+        st_stream(reinterpret_cast<cf*>(static_cast<float*>(out) + (by * W + xo) * Cout + c), cf{v0, v1});
+      }
     } else {
       typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
       wst[(m * 2 + h) * 32 + (lane >> 1)] = __builtin_bit_cast(unsigned, bf16x2{static_cast<__bf16>(v0), static_cast<__bf16>(v1)});
@@ -931,11 +945,12 @@ bool cfft_rows_inv_merge_fwd_reg(int NX, const ConvArgs& a, const FftMerge& m, c
 
 template <int NX> static bool launch_rows_inv_reg(const ConvArgs& a, int layout, const cf* T, int pad, float norm, const Fp16Scale& sc, hipStream_t st) {
   const int nrows = a.B * a.H;
+  if (a.wout_TX > 0 && (layout != 0 || sc.t16_inv)) return false;      // the scatter of overlap-save windows exists for fp32 outputs
   if ((a.Cout & 1) || a.CoutP % 64) return false;      // channel pairs are stored as one word; a wave = 32 pairs of ONE row (the kernel keeps the row in scalar registers)
   const size_t threads = (size_t)nrows * a.CoutP;      // two threads per channel pair
   const dim3 grid((unsigned)((threads + 255) / 256)), blk(256);
   const bool h16 = sc.t16_inv != nullptr;
-#define RR_LAUNCH(L, H16) hipLaunchKernelGGL((rows_inv_reg_kernel<NX, L, H16>), grid, blk, 0, st, T, a.out, a.bias, a.scale, a.shift, a.relu_bn, nrows, a.H, a.W, a.CoutP, a.Cout, pad, norm, sc)
+#define RR_LAUNCH(L, H16) hipLaunchKernelGGL((rows_inv_reg_kernel<NX, L, H16>), grid, blk, 0, st, T, a.out, a.bias, a.scale, a.shift, a.relu_bn, nrows, a.H, a.W, a.CoutP, a.Cout, pad, norm, sc, a.wout_H, a.wout_W, a.wout_TY, a.wout_TX)
   if (layout == 0 && !h16) RR_LAUNCH(0, false);
   else if (layout == 1 && h16 && a.Cout % 8 == 0) RR_LAUNCH(1, true);
   else if (layout == 1 && a.Cout % 8 == 0) RR_LAUNCH(1, false);

@@ -109,6 +109,7 @@ struct jcm_ctx {
   // transient: the next frequency-domain layer's input windows are cut from this map by its forward row pass (ConvArgs::win_map; jcm_train.hip)
   const void* fft_win_map = nullptr;
   int fft_win_B = 0, fft_win_H = 0, fft_win_W = 0, fft_win_TY = 0, fft_win_TX = 0;
+  bool fft_win_scatter = false;      // ... and its inverse row pass stores the valid regions into the map `out` (same geometry; ConvArgs::wout_*)
   bool fft_t_in_16 = false;                     // transient, with fft_t_in (bf16 handles): the handed-over T is complex fp16 + its scale words (conv4_fullres -> conv5)
   const void* fft_next_merge = nullptr;        // transient, with fft_t_next: const jcm::FftMerge* -- fft_t_next is the row-transformed MERGED map (this layer = the full-resolution branch)
   const void* fft_merge = nullptr;   // const jcm::FftMerge*: the next frequency-domain layer forms the merged map itself (jcm_pd_forward, conv5)

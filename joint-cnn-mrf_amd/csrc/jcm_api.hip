@@ -49,7 +49,7 @@ CallOrder::CallOrder(jcm_ctx* ctx) : c(ctx) {
   c->order = this;
   // what an aborted call may have left behind
   c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; c->fft_xs = nullptr; c->fft_xs_ready = false; c->fft_tmax_in = nullptr;
-  c->fft_next_pool = 0; c->fft_next_ks = 0; c->fft_next_merge = nullptr; c->fft_t_in_16 = false; c->fft_win_map = nullptr;
+  c->fft_next_pool = 0; c->fft_next_ks = 0; c->fft_next_merge = nullptr; c->fft_t_in_16 = false; c->fft_win_map = nullptr; c->fft_win_scatter = false;
   // the fp16-scale words are reused from the start only BETWEEN calls (a call keeps words of its early layers until its last ones: the training step)
   if (c->fft_block_i > 0 || c->fft_word_i > jcm_ctx::kFftWords - jcm_ctx::kFftWordsPerCall) {
     for (int i = 0; i <= c->fft_block_i && i < (int)c->fft_blocks.size(); ++i)
@@ -290,7 +290,7 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
   const int np = fft_np(c);      // operand form of the channel GEMM (cgemm_split.hip)
   void* work = arena_alloc<char>(c, conv_fft_workspace_bytes(a, L->ks, np));
   c->arena_off = mark;                                   // scratch of this layer only: later layers run behind it on the stream
-  if (c->dry) { c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; c->fft_xs = nullptr; c->fft_xs_ready = false; c->fft_tmax_in = nullptr; c->fft_next_pool = 0; c->fft_next_ks = 0; c->fft_next_merge = nullptr; c->fft_t_in_16 = false; c->fft_win_map = nullptr; return JCM_OK; }
+  if (c->dry) { c->fft_t_in = nullptr; c->fft_t_next = nullptr; c->fft_merge = nullptr; c->fft_xs = nullptr; c->fft_xs_ready = false; c->fft_tmax_in = nullptr; c->fft_next_pool = 0; c->fft_next_ks = 0; c->fft_next_merge = nullptr; c->fft_t_in_16 = false; c->fft_win_map = nullptr; c->fft_win_scatter = false; return JCM_OK; }
   // Filter spectra are cached per (layer, map size).  The cache is bounded (JCM_FFT_CACHE_GB, default 64): a caller that walks many
   // image sizes (7.7 GB per size for conv5) makes it drop every spectrum that is not this layer's before it grows past the bound.
   const std::string key = scope + (circ ? "@win" : "@") + std::to_string(H) + "x" + std::to_string(W);
@@ -348,6 +348,10 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
   if (c->fft_win_map) {      // the windows are gathered by the forward row pass
     a.win_map = c->fft_win_map; a.win_B = c->fft_win_B; a.win_H = c->fft_win_H; a.win_W = c->fft_win_W; a.win_TY = c->fft_win_TY; a.win_TX = c->fft_win_TX;
     c->fft_win_map = nullptr;
+  }
+  if (c->fft_win_scatter) {      // ... and scattered by the inverse row pass (the geometry fields stay valid without a gather)
+    a.wout_H = c->fft_win_H; a.wout_W = c->fft_win_W; a.wout_TY = c->fft_win_TY; a.wout_TX = c->fft_win_TX;
+    c->fft_win_scatter = false;
   }
   Fp16Scale sc;
   if (np >= 4) {

@@ -198,14 +198,17 @@ int conv_train_fwd_conv(jcm_ctx* c, LayerFwd& f, int stride, const void* x, int 
     // (round 6: where the forward row pass can cut the windows out of the map itself, the gathered tensor does not exist)
     const bool gw = conv_fft_win_gather_supported(kWin, L.cin);
     float* xw = gw ? nullptr : arena_alloc<float>(c, (size_t)BW * kWin * kWin * L.cin);
-    float* rw = arena_alloc<float>(c, (size_t)BW * kWinValid * kWinValid * L.cout);
+    const bool sw = conv_fft_win_scatter_supported(kWin, L.cout);      // ... and where the inverse row pass can store into the map, neither do the valid regions
+    float* rw = sw ? static_cast<float*>(f.r) : arena_alloc<float>(c, (size_t)BW * kWinValid * kWinValid * L.cout);
     if (!c->dry && !gw) HIP_TRY(window_gather_f32(static_cast<const float*>(x), xw, B, Hin, Win, L.cin, kWin, TY, TX, 0, c->stream));
-    if (gw) { c->fft_win_map = x; c->fft_win_B = B; c->fft_win_H = Hin; c->fft_win_W = Win; c->fft_win_TY = TY; c->fft_win_TX = TX; }
+    c->fft_win_B = B; c->fft_win_H = Hin; c->fft_win_W = Win; c->fft_win_TY = TY; c->fft_win_TX = TX;
+    if (gw) c->fft_win_map = x;
+    c->fft_win_scatter = sw;
     c->fft_xs = f.xs;
     JCM_TRY(run_conv_fft(c, &L, f.scope, xw, BW, kWin, kWin, rw, 0, 0, 1));
     if (!c->dry) {
       f.xs_tmax = c->fft_last_tmax;
-      HIP_TRY(window_scatter_f32(rw, static_cast<float*>(f.r), B, f.H, f.W, L.cout, kWin, TY, TX, c->stream));
+      if (!sw) HIP_TRY(window_scatter_f32(rw, static_cast<float*>(f.r), B, f.H, f.W, L.cout, kWin, TY, TX, c->stream));
     }
     c->arena_off = mark;      // (later work runs behind the scatter on the stream)
     return JCM_OK;
@@ -384,11 +387,14 @@ int conv_dgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int B, void* dx, i
       const size_t mark = c->arena_off;
       const bool gw = conv_fft_win_gather_supported(kWin, cin_fft);
       float* zw = gw ? nullptr : arena_alloc<float>(c, (size_t)BW * kWin * kWin * cin_fft);
-      float* xw = arena_alloc<float>(c, (size_t)BW * kWinValid * kWinValid * f.L->cin);
+      const bool sw = conv_fft_win_scatter_supported(kWin, f.L->cin);
+      float* xw = sw ? static_cast<float*>(dx) : arena_alloc<float>(c, (size_t)BW * kWinValid * kWinValid * f.L->cin);
       if (!c->dry && !gw) HIP_TRY(window_gather_f32(static_cast<const float*>(dz), zw, B, f.H, f.W, cin_fft, kWin, f.TY, f.TX, 0, c->stream));
-      if (gw) { c->fft_win_map = dz; c->fft_win_B = B; c->fft_win_H = f.H; c->fft_win_W = f.W; c->fft_win_TY = f.TY; c->fft_win_TX = f.TX; }
+      c->fft_win_B = B; c->fft_win_H = f.H; c->fft_win_W = f.W; c->fft_win_TY = f.TY; c->fft_win_TX = f.TX;
+      if (gw) c->fft_win_map = dz;
+      c->fft_win_scatter = sw;
       JCM_TRY(run_conv_fft(c, &Ld, key, zw, BW, kWin, kWin, xw, 0, 0, 1));
-      if (!c->dry) HIP_TRY(window_scatter_f32(xw, static_cast<float*>(dx), B, f.H, f.W, f.L->cin, kWin, f.TY, f.TX, c->stream));
+      if (!c->dry && !sw) HIP_TRY(window_scatter_f32(xw, static_cast<float*>(dx), B, f.H, f.W, f.L->cin, kWin, f.TY, f.TX, c->stream));
       c->arena_off = mark;
       return JCM_OK;
     }

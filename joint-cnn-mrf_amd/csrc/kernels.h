@@ -57,6 +57,9 @@ struct ConvArgs {
   // when win_valid_only: the weight gradient's dZ).  The forward row pass gathers while it loads (conv_fft_win_gather_supported()).
   const void* win_map = nullptr;
   int win_B = 0, win_H = 0, win_W = 0, win_TY = 0, win_TX = 0, win_valid_only = 0;
+  // ... and the valid regions need not either: wout_TY > 0 -> `out` is the [win_B, wout_H, wout_W, Cout] MAP and the inverse row pass stores valid pixel (y, x)
+  // of window (b, ty, tx) at map pixel (ty (H - 8) + y, tx (W - 8) + x) where that lies inside the map (conv_fft_win_scatter_supported())
+  int wout_H = 0, wout_W = 0, wout_TY = 0, wout_TX = 0;
 };
 int conv_igemm_bn(int Cout);                     // N-tile the dispatcher will use for this Cout
 hipError_t conv_igemm_f32(const ConvArgs& a, int ks, hipStream_t st);
@@ -129,7 +132,8 @@ struct FftNext { int pool = 0; int ks_next = 0; const FftMerge* merge = nullptr;
 hipError_t conv_fft_f32(const ConvArgs& a, int ks, int np, int in_layout, int out_layout, void* work, const void* t_in, void* t_next, const FftMerge* merge,
                         hipEvent_t g0, hipEvent_t g1, hipStream_t st, void* xs = nullptr, bool xs_ready = false, const Fp16Scale* sc = nullptr, const FftNext* nx = nullptr);
 // the fused hand-overs of FftNext: is there a kernel for this pair of layers, and the size of the row-transformed tensor handed over
-bool conv_fft_win_gather_supported(int win, int Cin);      // can the forward row pass of `win` x `win` overlap-save windows read them straight from the map?
+bool conv_fft_win_gather_supported(int win, int Cin);
+bool conv_fft_win_scatter_supported(int win, int Cout);    // ... and its inverse row pass store the valid regions straight into the map?      // can the forward row pass of `win` x `win` overlap-save windows read them straight from the map?
 bool conv_fft_pool_fusable(const ConvArgs& a, int ks, int ks_next);
 size_t conv_fft_pool_handover_bytes(const ConvArgs& a, int ks_next);
 bool conv_fft_merge_fusable(const ConvArgs& a, int ks, int ks_next, const FftMerge& m, bool h16 = false);      // h16: bf16 handles (16-bit T / T', bf16 branches)
