@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstring>
 
+#include <cstdlib>
 #include "ctx.h"
 
 using namespace jcm;
@@ -159,7 +160,8 @@ static bool takes_windows(jcm_ctx* c, const ConvLayer* L, int B, int H, int W, i
   if (2 * kWin * (kWin / 2 + 1) > NY * (NX / 2 + 1)) return false;      // at least half the frequencies, or the larger activation spectra eat the gain (30 x 45 maps: 936 -> 544)
   // ... and filters wide enough that their spectra dominate: the windows cost a gather, a scatter and 2.1x the transform work per channel (measured at 16 images:
   // with every 60 x 90 layer on windows the step stayed at 36 ms -- 9.7 ms saved on filter-sized tensors, as much spent on activation-sized ones)
-  if ((long)L->cin * L->cout < 256l * 512) return false;
+  static const long min_cc = [] { const char* e = std::getenv("JCM_WIN_MIN_CC"); return e ? std::atol(e) : 128l * 256; }();      // (round 6: 128 x 256 = conv3_fullres too, now that the windows are gathered and scattered inside the row passes: 24.20 -> 24.03 ms; 64 x 128: 24.87)
+  if ((long)L->cin * L->cout < min_cc) return false;
   // ... and a batch small enough: what the windows save (filter-sized traffic, independent of the batch: 9.7 ms per step) is spent again on activation-sized work
   // that grows with it (4.4 ms at 16 images)
   if (B > 32) return false;
