@@ -90,7 +90,7 @@ int jcm_abi_version(void);
  *              kernels' 97.4 / 96.4 %, and 100 % / 99.9 % of the joints whose fp32 top-2 margin is clear of the bf16 noise
  *              (tests/test_gpu_argmax_agreement.py).
  * "fft_windows": any time, default 1 (fp32 handles with training state): the training step runs its wide 60x90 layers (conv4_fullres, conv5 -- every
- *              layer with Cin * Cout >= 128 * 256 (round 6; 256 * 512 before) whose map has at least twice the frequencies of a window: conv3_fullres too) on 32 x 32 overlap-save windows: forward, data
+ *              layer with Cin * Cout >= 128 * 256 (round 6; 256 * 512 before) whose map has at least 1.5 x the frequencies of a window: conv3_fullres and the 30 x 45 maps of conv3_halfres / conv4_halfres too) on 32 x 32 overlap-save windows: forward, data
  *              gradient and weight gradient see 3 x 4 windows per image as a batch of 12 B images on a 32 x 32 circular transform, so the filter-sized
  *              spectra (what bounds the step at 16 images per GPU) shrink 5.8x.  0 = the 64 x 96 transform of the whole map (round 3).
  * "fft_t16"  : any time, default 1 (bf16 handles with "fft_single" = 1): the row-transformed tensors between the row and the column passes of

@@ -157,7 +157,8 @@ static bool takes_windows(jcm_ctx* c, const ConvLayer* L, int B, int H, int W, i
   if (bf(c) || !c->fft_win || !takes_fft(c, L, B, H, W)) return false;
   int NY = 0, NX = 0, MT = 0;
   if (!conv_fft_geometry(H, W, L->ks, B, L->cout, fft_np(c), &NY, &NX, &MT)) return false;
-  if (2 * kWin * (kWin / 2 + 1) > NY * (NX / 2 + 1)) return false;      // at least half the frequencies, or the larger activation spectra eat the gain (30 x 45 maps: 936 -> 544)
+  static const double fr = [] { const char* e = std::getenv("JCM_WIN_FREQ_RATIO"); return e ? std::atof(e) : 1.5; }();      // (round 6: 1.5 -- the 30 x 45 maps too, 936 frequencies against 544: 24.03 -> 23.87 ms; rounds 3-5: 2)
+  if (fr * kWin * (kWin / 2 + 1) > NY * (NX / 2 + 1)) return false;      // at least half the frequencies, or the larger activation spectra eat the gain (30 x 45 maps: 936 -> 544)
   // ... and filters wide enough that their spectra dominate: the windows cost a gather, a scatter and 2.1x the transform work per channel (measured at 16 images:
   // with every 60 x 90 layer on windows the step stayed at 36 ms -- 9.7 ms saved on filter-sized tensors, as much spent on activation-sized ones)
   static const long min_cc = [] { const char* e = std::getenv("JCM_WIN_MIN_CC"); return e ? std::atol(e) : 128l * 256; }();      // (round 6: 128 x 256 = conv3_fullres too, now that the windows are gathered and scattered inside the row passes: 24.20 -> 24.03 ms; 64 x 128: 24.87)
