@@ -153,9 +153,25 @@ __global__ void bn_apply_kernel(const T* __restrict__ r, const float* __restrict
     y[i] = static_cast<T>((static_cast<float>(r[i]) - mean[c]) * (rstd[c] * gamma[c]) + beta[c]);
   }
 }
+// the same on four channels per thread (fp32 tensors, C % 4 == 0): 16-byte loads and stores, the per-channel parameters as float4 -- element for element the
+// expression above (round 6: the 4-byte form moved 2.0 TB/s on conv2_fullres' 177-MB tensor)
+__global__ __launch_bounds__(256) void bn_apply4_kernel(const float4* __restrict__ r, const float4* __restrict__ mean, const float4* __restrict__ rstd,
+                                                        const float4* __restrict__ gamma, const float4* __restrict__ beta, float4* __restrict__ y, size_t total4, int C4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % (size_t)C4);
+    const float4 rv = r[i], m = mean[c], rs = rstd[c], g = gamma[c], b = beta[c];
+    y[i] = make_float4((rv.x - m.x) * (rs.x * g.x) + b.x, (rv.y - m.y) * (rs.y * g.y) + b.y, (rv.z - m.z) * (rs.z * g.z) + b.z, (rv.w - m.w) * (rs.w * g.w) + b.w);
+  }
+}
 hipError_t bn_apply(const void* r, const float* mean, const float* rstd, const float* gamma, const float* beta, void* y, bool bf16, size_t N,
                     int C, hipStream_t st) {
   const size_t total = N * C;
+  if (!bf16 && C % 4 == 0) {
+    const size_t t4 = total / 4, g4 = (t4 + 255) / 256;
+    hipLaunchKernelGGL(bn_apply4_kernel, dim3((unsigned)(g4 > 16384 ? 16384 : g4)), dim3(256), 0, st, static_cast<const float4*>(r), reinterpret_cast<const float4*>(mean),
+                       reinterpret_cast<const float4*>(rstd), reinterpret_cast<const float4*>(gamma), reinterpret_cast<const float4*>(beta), static_cast<float4*>(y), t4, C / 4);
+    return hipGetLastError();
+  }
   size_t g = (total + 255) / 256;
   const dim3 grid((int)(g > 65536 ? 65536 : g));
   if (bf16)
@@ -201,9 +217,33 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, float dy_scale, co
     dz[i] = static_cast<T>((relu && !(rv > 0.f)) ? 0.f : d);
   }
 }
+// four channels per thread (fp32 tensors, C % 4 == 0): element for element the expression above
+__device__ __forceinline__ float bn_bwd_one(float dyv, float dy_scale, float rv, float mean, float rs, float gamma, float s0, float s1, float invN, int relu) {
+  const float xc = rv - mean;
+  const float g = dyv * dy_scale;
+  const float d = (gamma * rs) * (g - s0 * invN - xc * (rs * rs) * (s1 * invN));
+  return (relu && !(rv > 0.f)) ? 0.f : d;
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float4* __restrict__ dy, float dy_scale, const float4* __restrict__ r, const float4* __restrict__ mean,
+                                                            const float4* __restrict__ rstd, const float4* __restrict__ gamma, const float4* __restrict__ sums, float invN,
+                                                            int relu, float4* __restrict__ dz, size_t total4, int C4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % (size_t)C4);
+    const float4 g = dy[i], rv = r[i], m = mean[c], rs = rstd[c], ga = gamma[c], s0 = sums[c], s1 = sums[C4 + c];
+    dz[i] = make_float4(bn_bwd_one(g.x, dy_scale, rv.x, m.x, rs.x, ga.x, s0.x, s1.x, invN, relu), bn_bwd_one(g.y, dy_scale, rv.y, m.y, rs.y, ga.y, s0.y, s1.y, invN, relu),
+                        bn_bwd_one(g.z, dy_scale, rv.z, m.z, rs.z, ga.z, s0.z, s1.z, invN, relu), bn_bwd_one(g.w, dy_scale, rv.w, m.w, rs.w, ga.w, s0.w, s1.w, invN, relu));
+  }
+}
 hipError_t bn_bwd_apply(const void* dy, float dy_scale, const void* r, bool bf16, const float* mean, const float* rstd, const float* gamma,
                         const float* sums, size_t N, int C, int relu, void* dz, hipStream_t st) {
   const size_t total = N * C;
+  if (!bf16 && C % 4 == 0) {
+    const size_t t4 = total / 4, g4 = (t4 + 255) / 256;
+    hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3((unsigned)(g4 > 16384 ? 16384 : g4)), dim3(256), 0, st, static_cast<const float4*>(dy), dy_scale, static_cast<const float4*>(r),
+                       reinterpret_cast<const float4*>(mean), reinterpret_cast<const float4*>(rstd), reinterpret_cast<const float4*>(gamma), reinterpret_cast<const float4*>(sums),
+                       (float)(1.0 / (double)N), relu, static_cast<float4*>(dz), t4, C / 4);
+    return hipGetLastError();
+  }
   size_t g = (total + 255) / 256;
   const dim3 grid((int)(g > 65536 ? 65536 : g));
   const float invN = (float)(1.0 / (double)N);
