@@ -388,7 +388,49 @@ __global__ void resize_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, 
     dx[i] = static_cast<T>(acc * scale);
   }
 }
+// four channels per thread (fp32, C % 4 == 0): the tap arithmetic -- divisions, floors, the candidate loops -- is shared by the four, the sums run in the same order
+__global__ __launch_bounds__(256) void resize_bwd4_kernel(const float4* __restrict__ dy, float4* __restrict__ dx, int h, int w, int H, int W, int C4, float sy, float sx,
+                                                          float scale, size_t total4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % (size_t)C4);
+    size_t r = i / (size_t)C4;
+    const int ix = (int)(r % (size_t)w); r /= (size_t)w;
+    const int iy = (int)(r % (size_t)h);
+    const size_t b = r / (size_t)h;
+    int oy0 = (int)floorf((float)(iy - 1) / sy) - 1, oy1 = (int)ceilf((float)(iy + 1) / sy) + 1;
+    int ox0 = (int)floorf((float)(ix - 1) / sx) - 1, ox1 = (int)ceilf((float)(ix + 1) / sx) + 1;
+    oy0 = max(oy0, 0); oy1 = min(oy1, H - 1);
+    ox0 = max(ox0, 0); ox1 = min(ox1, W - 1);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int oy = oy0; oy <= oy1; ++oy) {
+      int ylo, yhi; float ty;
+      bil_src(oy, sy, h, &ylo, &yhi, &ty);
+      float wy = 0.f;
+      if (ylo == iy) wy += 1.f - ty;
+      if (yhi == iy) wy += ty;
+      if (wy == 0.f) continue;
+      for (int ox = ox0; ox <= ox1; ++ox) {
+        int xlo, xhi; float tx;
+        bil_src(ox, sx, w, &xlo, &xhi, &tx);
+        float wx = 0.f;
+        if (xlo == ix) wx += 1.f - tx;
+        if (xhi == ix) wx += tx;
+        if (wx == 0.f) continue;
+        const float4 g = dy[((b * H + oy) * W + ox) * C4 + c];
+        const float wgt = wy * wx;
+        acc.x += wgt * g.x; acc.y += wgt * g.y; acc.z += wgt * g.z; acc.w += wgt * g.w;
+      }
+    }
+    dx[i] = make_float4(acc.x * scale, acc.y * scale, acc.z * scale, acc.w * scale);
+  }
+}
 hipError_t resize_bilinear_bwd(const void* dy, void* dx, bool bf16, int B, int h, int w, int H, int W, int C, float scale, hipStream_t st) {
+  if (!bf16 && C % 4 == 0) {
+    const size_t t4 = (size_t)B * h * w * (C / 4), g4 = (t4 + 255) / 256;
+    hipLaunchKernelGGL(resize_bwd4_kernel, dim3((unsigned)(g4 > 65536 ? 65536 : g4)), dim3(256), 0, st, static_cast<const float4*>(dy), static_cast<float4*>(dx), h, w, H, W, C / 4,
+                       (float)h / (float)H, (float)w / (float)W, scale, t4);
+    return hipGetLastError();
+  }
   const size_t total = (size_t)B * h * w * C;
   size_t g = (total + 255) / 256;
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;
