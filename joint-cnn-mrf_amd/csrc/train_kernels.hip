@@ -157,10 +157,17 @@ __global__ void bn_apply_kernel(const T* __restrict__ r, const float* __restrict
 // expression above (round 6: the 4-byte form moved 2.0 TB/s on conv2_fullres' 177-MB tensor)
 __global__ __launch_bounds__(256) void bn_apply4_kernel(const float4* __restrict__ r, const float4* __restrict__ mean, const float4* __restrict__ rstd,
                                                         const float4* __restrict__ gamma, const float4* __restrict__ beta, float4* __restrict__ y, size_t total4, int C4) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % (size_t)C4);
+  // (the channel group is carried along: a 64-bit modulo per element costs more issue slots than the 16 bytes it serves)
+  const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cstep = (int)(stride % (size_t)C4);
+  int c = (int)(i0 % (size_t)C4) - cstep;
+  for (size_t i = i0; i < total4; i += stride) {
+    c += cstep;
+    if (c >= C4) c -= C4;
     const float4 rv = r[i], m = mean[c], rs = rstd[c], g = gamma[c], b = beta[c];
-    y[i] = make_float4((rv.x - m.x) * (rs.x * g.x) + b.x, (rv.y - m.y) * (rs.y * g.y) + b.y, (rv.z - m.z) * (rs.z * g.z) + b.z, (rv.w - m.w) * (rs.w * g.w) + b.w);
+    typedef float f4n __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(f4n{(rv.x - m.x) * (rs.x * g.x) + b.x, (rv.y - m.y) * (rs.y * g.y) + b.y, (rv.z - m.z) * (rs.z * g.z) + b.z, (rv.w - m.w) * (rs.w * g.w) + b.w},
+                                reinterpret_cast<f4n*>(y + i));      // streaming: read next by another kernel, gigabytes later
   }
 }
 hipError_t bn_apply(const void* r, const float* mean, const float* rstd, const float* gamma, const float* beta, void* y, bool bf16, size_t N,
@@ -227,11 +234,17 @@ __device__ __forceinline__ float bn_bwd_one(float dyv, float dy_scale, float rv,
 __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float4* __restrict__ dy, float dy_scale, const float4* __restrict__ r, const float4* __restrict__ mean,
                                                             const float4* __restrict__ rstd, const float4* __restrict__ gamma, const float4* __restrict__ sums, float invN,
                                                             int relu, float4* __restrict__ dz, size_t total4, int C4) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % (size_t)C4);
+  const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cstep = (int)(stride % (size_t)C4);
+  int c = (int)(i0 % (size_t)C4) - cstep;
+  for (size_t i = i0; i < total4; i += stride) {
+    c += cstep;
+    if (c >= C4) c -= C4;
     const float4 g = dy[i], rv = r[i], m = mean[c], rs = rstd[c], ga = gamma[c], s0 = sums[c], s1 = sums[C4 + c];
-    dz[i] = make_float4(bn_bwd_one(g.x, dy_scale, rv.x, m.x, rs.x, ga.x, s0.x, s1.x, invN, relu), bn_bwd_one(g.y, dy_scale, rv.y, m.y, rs.y, ga.y, s0.y, s1.y, invN, relu),
-                        bn_bwd_one(g.z, dy_scale, rv.z, m.z, rs.z, ga.z, s0.z, s1.z, invN, relu), bn_bwd_one(g.w, dy_scale, rv.w, m.w, rs.w, ga.w, s0.w, s1.w, invN, relu));
+    typedef float f4n __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(f4n{bn_bwd_one(g.x, dy_scale, rv.x, m.x, rs.x, ga.x, s0.x, s1.x, invN, relu), bn_bwd_one(g.y, dy_scale, rv.y, m.y, rs.y, ga.y, s0.y, s1.y, invN, relu),
+                                    bn_bwd_one(g.z, dy_scale, rv.z, m.z, rs.z, ga.z, s0.z, s1.z, invN, relu), bn_bwd_one(g.w, dy_scale, rv.w, m.w, rs.w, ga.w, s0.w, s1.w, invN, relu)},
+                                reinterpret_cast<f4n*>(dz + i));
   }
 }
 hipError_t bn_bwd_apply(const void* dy, float dy_scale, const void* r, bool bf16, const float* mean, const float* rstd, const float* gamma,
