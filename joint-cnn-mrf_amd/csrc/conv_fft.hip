@@ -164,15 +164,21 @@ __global__ __launch_bounds__(256) void weight_spectra_split_kernel(const float* 
 }
 
 // max over (ci, co) of sum_taps |w|: a bound of |W[f][ci][co]| for every frequency (np = 4)
-__global__ __launch_bounds__(256) void weight_bound_kernel(const float* __restrict__ w, int taps, size_t pairs, int round_bf16, float* __restrict__ wmax) {
+template <int TAPS>
+__global__ __launch_bounds__(256) void weight_bound_kernel(const float* __restrict__ w, size_t pairs, int round_bf16, float* __restrict__ wmax) {
   __shared__ float red[4];
   float m = 0.f;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < pairs; e += (size_t)gridDim.x * 256) {
+    // every tap's load goes out before the first add (the taps are a compile-time count: round 6 -- with a run-time count the loads went out one by one behind the sum)
+    float v[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) v[t] = w[(size_t)t * pairs + e];
     float sum = 0.f;
-    for (int t = 0; t < taps; ++t) {
-      float v = w[(size_t)t * pairs + e];
-      if (round_bf16) v = static_cast<float>(static_cast<__bf16>(v));
-      sum += fabsf(v);
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      float x = v[t];
+      if (round_bf16) x = static_cast<float>(static_cast<__bf16>(x));
+      sum += fabsf(x);
     }
     m = fmaxf(m, sum);
   }
@@ -285,7 +291,9 @@ hipError_t conv_fft_pack_weights(const float* w_hwio, void* wf, int H, int W, in
   } else if (np >= 4) {
     if (hipError_t e = hipMemsetAsync(wscale, 0, 2 * sizeof(float), st); e != hipSuccess) return e;
     const size_t pairs = (size_t)Cin * Cout;
-    hipLaunchKernelGGL(weight_bound_kernel, dim3((unsigned)((pairs + 255) / 256 > 1024 ? 1024 : (pairs + 255) / 256)), dim3(256), 0, st, w_hwio, ks * ks, pairs, rb, wscale);
+    const dim3 bgrid((unsigned)((pairs + 255) / 256 > 1024 ? 1024 : (pairs + 255) / 256));
+    if (ks == 9) hipLaunchKernelGGL(weight_bound_kernel<81>, bgrid, dim3(256), 0, st, w_hwio, pairs, rb, wscale);
+    else hipLaunchKernelGGL(weight_bound_kernel<25>, bgrid, dim3(256), 0, st, w_hwio, pairs, rb, wscale);
   }
 #define WS_LAUNCH(KS, NPV) hipLaunchKernelGGL((weight_spectra_split_kernel<KS, NPV>), grid, dim3(256), 0, st, w_hwio, dst, Cin, Cout, CoutP, ntl, s.NY, s.NX, rb, wscale)
   if (ks == 9) {
