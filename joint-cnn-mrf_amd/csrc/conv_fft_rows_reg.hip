@@ -395,13 +395,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
   fwd_rows_finish<NX>(raw, T, h, p, b, y, B, H, C, tmax, t16);
 }
-// true: launched (96-point rows of a bf16 NHWC tensor, 16-bit T; W <= 96)
+// true: launched (96- / 50- / 28-point rows of a bf16 NHWC tensor -- the 60 x 90, 30 x 45 and 15 x 23 maps --, 16-bit T; W <= NX)
 bool cfft_rows_fwd_reg(int NX, const ConvArgs& a, int layout, cf* T, float* tmax, hipStream_t st, float* t16) {
-  if (NX != 96 || layout != 1 || !t16 || a.Cin % 64 || a.W > NX) return false;
+  if ((NX != 96 && NX != 50 && NX != 28) || layout != 1 || !t16 || a.Cin % 64 || a.W > NX) return false;
   const int nrows = a.B * a.H;
   const size_t threads = (size_t)nrows * a.Cin;      // two threads per channel pair
-  hipLaunchKernelGGL(rows_fwd_reg_kernel<96>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, static_cast<const unsigned*>(a.x), reinterpret_cast<uint2*>(T), nrows, a.B,
-                     a.H, a.W, a.Cin, tmax, t16);
+  const dim3 grid((unsigned)((threads + 255) / 256)), blk(256);
+#define RFR_LAUNCH(N) hipLaunchKernelGGL(rows_fwd_reg_kernel<N>, grid, blk, 0, st, static_cast<const unsigned*>(a.x), reinterpret_cast<uint2*>(T), nrows, a.B, a.H, a.W, a.Cin, tmax, t16)
+  if (NX == 96) RFR_LAUNCH(96);
+  else if (NX == 50) RFR_LAUNCH(50);      // (round 6: the half- and quarter-resolution branches left the LDS kernel too)
+  else RFR_LAUNCH(28);
+#undef RFR_LAUNCH
   return true;
 }
 
