@@ -377,7 +377,7 @@ __device__ __forceinline__ void fwd_rows_finish(const unsigned (&raw)[NX / 2], u
   });
 }
 template <int NX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void rows_fwd_reg_kernel(const unsigned* __restrict__ in, uint2* __restrict__ T, int nrows, int B, int H, int W, int C,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NX >= 96 ? 3 : 4, NX >= 96 ? 3 : 8))) void rows_fwd_reg_kernel(const unsigned* __restrict__ in, uint2* __restrict__ T, int nrows, int B, int H, int W, int C,
                                                                                               float* __restrict__ tmax, float* __restrict__ t16) {
   constexpr int M = NX / 2;
   const int CP = C >> 1;
