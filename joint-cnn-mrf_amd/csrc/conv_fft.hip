@@ -450,7 +450,7 @@ hipError_t conv_fft_f32(const ConvArgs& a0, int ks, int np, int in_layout, int o
     }
   } else if (t_next) {
     if (!(fft_reg && cfft_rows_inv_fwd_reg(s.NX, a, T, static_cast<cf*>(t_next), opad, norm, sc, st))) cfft_rows_inv_fwd(s.NX, a, T, static_cast<cf*>(t_next), twx, opad, norm, sc, st);
-  } else if (!(fft_reg && cfft_rows_inv_reg(s.NX, ai, out_layout, T, opad, norm, sc, st))) {
+  } else if (!((ai.rows_mfma & 1) && cfft_rows_inv_mfma(s.NX, ai, out_layout, T, opad, norm, sc, st)) && !(fft_reg && cfft_rows_inv_reg(s.NX, ai, out_layout, T, opad, norm, sc, st))) {
     if (ai.wout_TX > 0) return hipErrorInvalidValue;      // (the scatter into the map exists in the register kernel only)
     cfft_rows_inv(s.NX, ai, out_layout, T, twx, opad, norm, sc, st);
   }

@@ -286,6 +286,7 @@ int run_conv_fft(jcm_ctx* c, const ConvLayer* L, const std::string& scope, const
   a.x = x; a.bias = L->bias; a.scale = L->scale; a.shift = L->shift; a.out = out;
   a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout; a.CoutP = L->cout; a.relu_bn = L->has_bn ? 1 : 0;
   a.circ = circ;
+  a.rows_mfma = c->fft_rows_mfma;
   const size_t mark = c->arena_off;
   const int np = fft_np(c);      // operand form of the channel GEMM (cgemm_split.hip)
   void* work = arena_alloc<char>(c, conv_fft_workspace_bytes(a, L->ks, np));
@@ -846,6 +847,11 @@ int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
   if (k == "fft_fuse") {   // allowed at any time (fp32 handles): bit 0 = conv2 -> pool -> conv3, bit 1 = conv4_fullres -> merge -> conv5 as fused hand-overs
     if (value < 0 || value > 3) return fail(JCM_ERR_ARG, "fft_fuse must be 0..3 (bit 0: pool hand-over, bit 1: merge hand-over)");
     h->fft_fuse = (int)value;
+    return JCM_OK;
+  }
+  if (k == "fft_rows_mfma") {   // allowed at any time (bf16 handles with 16-bit row-transformed tensors)
+    if (value < 0 || value > 7) return fail(JCM_ERR_ARG, "fft_rows_mfma must be 0..7 (bit 0: inverse row pass, bit 1: merge hand-over, bit 2: forward row pass)");
+    h->fft_rows_mfma = (int)value;
     return JCM_OK;
   }
   if (k == "fft_t16") {   // allowed at any time (bf16 handles, fft_single = 1)
