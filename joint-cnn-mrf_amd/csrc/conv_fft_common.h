@@ -327,7 +327,7 @@ bool cfft_rows_inv_merge_fwd(int NX, const ConvArgs& a, const FftMerge& m, const
 bool cfft_rows_inv_merge_fwd_reg(int NX, const ConvArgs& a, const FftMerge& m, const cf* T, cf* Tn, int pad, float norm, const Fp16Scale& sc, hipStream_t st, float* t16n = nullptr);
 bool cfft_rows_inv_merge_fwd_reg_supported(int NX, const ConvArgs& a, const FftMerge& m, int pad);
 bool cfft_rows_inv_pool_fwd_supported(int NXI, int NXO, int Cout);
-// conv_fft_rows_mfma.hip: 96-point row passes of bf16 handles (16-bit T / T') as matrix products on the matrix cores; false: no kernel for this case
+// conv_fft_rows_mfma.hip: the 96-point inverse row pass of bf16 handles (16-bit T', planar bf16 output) as a matrix product on the matrix cores; false: no kernel for this case
 bool cfft_rows_inv_mfma(int NX, const ConvArgs& a, int layout, const cf* T, int pad, float norm, const Fp16Scale& sc, hipStream_t st);
 bool cfft_rows_inv_merge_fwd_supported(int NX, const ConvArgs& a, const FftMerge& m);
 }  // namespace cfft

@@ -208,6 +208,7 @@ __global__ __launch_bounds__(256, 2) void rows_inv_mfma_kernel(const unsigned* _
   }
 }
 
+
 bool cfft_rows_inv_mfma_supported(int NX, const ConvArgs& a, int layout, int pad, const Fp16Scale& sc) {
   return NX == rm::NX && layout == 2 && sc.t16_inv && sc.t16_cb == 64 && a.CoutP % 64 == 0 && a.CoutP <= kParMax && a.Cout % 8 == 0 && a.W + pad <= rm::NX && pad >= 0 &&
          a.wout_TX == 0 && (size_t)rm::NXH * a.CoutP * 4 < rm::kZeroOff;

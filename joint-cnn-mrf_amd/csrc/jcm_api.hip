@@ -850,8 +850,7 @@ int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
     return JCM_OK;
   }
   if (k == "fft_rows_mfma") {   // allowed at any time (bf16 handles with 16-bit row-transformed tensors)
-    if (value < 0 || value > 7) return fail(JCM_ERR_ARG, "fft_rows_mfma must be 0..7 (bit 0: inverse row pass, bit 1: merge hand-over, bit 2: forward row pass)");
-    h->fft_rows_mfma = (int)value;
+    h->fft_rows_mfma = value != 0;
     return JCM_OK;
   }
   if (k == "fft_t16") {   // allowed at any time (bf16 handles, fft_single = 1)

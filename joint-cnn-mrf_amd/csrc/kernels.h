@@ -60,8 +60,8 @@ struct ConvArgs {
   // ... and the valid regions need not either: wout_TY > 0 -> `out` is the [win_B, wout_H, wout_W, Cout] MAP and the inverse row pass stores valid pixel (y, x)
   // of window (b, ty, tx) at map pixel (ty (H - 8) + y, tx (W - 8) + x) where that lies inside the map (conv_fft_win_scatter_supported())
   int wout_H = 0, wout_W = 0, wout_TY = 0, wout_TX = 0;
-  // conv_fft, bf16 handles with 16-bit row-transformed tensors: the 96-point row passes as matrix products on the matrix cores (conv_fft_rows_mfma.hip) where such
-  // a kernel exists.  Bit 0: the inverse row pass, bit 1: the merge hand-over (inverse + branch merge + forward), bit 2: the forward row pass.
+  // conv_fft, bf16 handles with 16-bit row-transformed tensors: the 96-point inverse row pass with planar bf16 output (conv5 of the model) as a matrix product
+  // on the matrix cores (conv_fft_rows_mfma.hip).  1 = on where the kernel exists, 0 = the register kernel.
   int rows_mfma = 0;
 };
 int conv_igemm_bn(int Cout);                     // N-tile the dispatcher will use for this Cout

@@ -8,7 +8,7 @@ from joint_cnn_mrf_amd import synth
 from joint_cnn_mrf_amd.engine import Engine
 
 BT = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-BITS = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+BITS = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 p = synth.make_pd_params(debug=False, bn='trained', conv6_gain=8.0)
 p.update(synth.make_sm_params(synth.synthetic_priors(), kind='trained'))
 x = torch.as_tensor(synth.make_images(8, seed=5), device='cuda:0')
