@@ -200,6 +200,7 @@ __device__ __forceinline__ void c5_tile(const ConvArgs& a, const Geom& gm, char*
   const int h = lane >> 5, l31 = lane & 31;
   const int H = gm.H, W = gm.W, HW = gm.HW, P = gm.P;
   const int Cin = a.Cin, Cout = a.Cout;
+  const int HWo = a.hpool ? H * (W >> 1) : HW;      // pixels per image of the OUTPUT map
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
   unsigned aaddr[MRMAX], baddr;
@@ -345,6 +346,9 @@ __device__ __forceinline__ void c5_tile(const ConvArgs& a, const Geom& gm, char*
       const int s = it.s0 + (wid * MR + f) * 32 + el;
       const int r = (int)(((float)s + 0.5f) * rP), c = s - r * P;      // exact: s < 2^22
       pp[f] = (c >= 2 && r < H) ? r * W + c - 2 : -1;
+      // hpool: the lane of the even pixel x stores max(x, x + 1) at pixel x / 2 of the half-width map (P even: the parity of x is the lane's; its right
+      // neighbour is the next lane of the same fragment)
+      if (a.hpool) pp[f] = (c >= 2 && r < H && !(c & 1)) ? r * (W >> 1) + ((c - 2) >> 1) : -1;
     }
   }
   const float* ec = reinterpret_cast<const float*>(lds + EC0) + it.n0;
@@ -368,11 +372,12 @@ __device__ __forceinline__ void c5_tile(const ConvArgs& a, const Geom& gm, char*
         for (int k = 0; k < 8; ++k) {
           float v = acc[f][g][8 * u + k] + bi[k];
           if (a.relu_bn) v = fmaxf(v, 0.f) * sc[k] + sh[k];
+          if (a.hpool) v = fmaxf(v, __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0xB1, 0xF, 0xF, true)));      // the lane pair's other pixel
           ov[k] = static_cast<__bf16>(v);
         }
         if (pp[f] >= 0) {
-          const size_t o = a.out_planar ? (((size_t)it.b * (Cout >> 3) + (co >> 3)) * HW + pp[f]) * 8      // [B][Cout/8][H*W][8]
-                                        : ((size_t)it.b * HW + pp[f]) * Cout + co;
+          const size_t o = a.out_planar ? (((size_t)it.b * (Cout >> 3) + (co >> 3)) * HWo + pp[f]) * 8      // [B][Cout/8][H*W][8]
+                                        : ((size_t)it.b * HWo + pp[f]) * Cout + co;
           *reinterpret_cast<bf16x8*>(static_cast<__bf16*>(a.out) + o) = ov;
         }
       }
@@ -412,6 +417,7 @@ __global__ __launch_bounds__(NT, 2) void conv5_strip_bf16_kernel(ConvArgs a, Geo
 namespace {
 bool make_geom(const ConvArgs& a, Geom& gm) {
   if (a.CoutP % BN || a.CoutP < BN || a.CoutP > CMAX || a.Cout % 8 || a.Cout > a.CoutP || a.Cin % 32 || a.W < 8 || a.H < 1 || a.B < 1) return false;
+  if (a.hpool && (a.W & 1)) return false;      // the pooled pair is a lane pair: even width
   const long long HW = (long long)a.H * a.W;
   if (HW * a.Cin * 2 >= (1ll << 30) || (long long)a.H * (a.W + 2) >= (1 << 22) || (long long)KS * KS * a.Cin * a.CoutP * 2 >= (1ll << 31)) return false;
   gm.H = a.H; gm.W = a.W; gm.HW = (int)HW; gm.P = a.W + 2;

@@ -105,6 +105,8 @@ struct jcm_ctx {
   void* sm_scratch = nullptr;   // sm_fused.hip: partial sums + flags of sm_inv_finish_kernel's cuts (sm_fused_scratch_bytes(), zeroed once)
   unsigned sm_epoch = 0;        // ... the launch counter its flags carry
   int fft_fuse = 3;             // fp32 handles, jcm_pd_forward: bit 0 = conv2 -> max pool -> conv3, bit 1 = conv4_fullres -> branch merge -> conv5 handed over in row-transformed form (conv_fft_rows_fused.hip)
+  int bf16_hpool = 1;           // bf16 handles: the horizontal half of pool2 in conv2's epilogue (ConvArgs::hpool) + vpool_2x1_bf16 instead of the 2x2 pool kernel
+  int conv_hpool = 0;           // transient: the next direct bf16 convolution launch takes the half pool
   int fft_rows_mfma = 1;        // bf16 handles with 16-bit row-transformed tensors: conv5's inverse row pass on the matrix cores (ConvArgs::rows_mfma; conv_fft_rows_mfma.hip)
   int fft_next_pool = 0, fft_next_ks = 0;      // transient, with fft_t_next: a 2x2 max pool lies between this layer and the one fft_t_next is for (kernel size fft_next_ks)
   // transient: the next frequency-domain layer's input windows are cut from this map by its forward row pass (ConvArgs::win_map; jcm_train.hip)

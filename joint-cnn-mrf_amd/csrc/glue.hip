@@ -74,6 +74,34 @@ hipError_t max_pool_2x2(const void* x, void* out, bool bf16, int B, int H, int W
   return hipGetLastError();
 }
 
+// rows 2 y and 2 y + 1 of a [B, H, W, C] bf16 map (the horizontal half of the pool was taken by the producing kernel's epilogue, ConvArgs::hpool): 16 bytes
+// per thread, both reads and the write contiguous over the row
+__global__ void vpool_2x1_bf16_kernel(const uint4* __restrict__ x, uint4* __restrict__ out, int H, int Ho, size_t row_u, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t u = i % row_u, r = i / row_u;
+    const int oy = (int)(r % Ho);
+    const size_t b = r / Ho;
+    const uint4* src = x + (b * H + 2 * (size_t)oy) * row_u + u;
+    uint4 a = src[0];
+    if (2 * oy + 1 < H) {
+      const uint4 q = src[row_u];
+      auto mx = [](unsigned p, unsigned w) {      // two bf16 values per word
+        const float pl = __uint_as_float(p << 16), ph = __uint_as_float(p & 0xffff0000u), wl = __uint_as_float(w << 16), wh = __uint_as_float(w & 0xffff0000u);
+        return (__float_as_uint(fmaxf(pl, wl)) >> 16) | (__float_as_uint(fmaxf(ph, wh)) & 0xffff0000u);
+      };
+      a = make_uint4(mx(a.x, q.x), mx(a.y, q.y), mx(a.z, q.z), mx(a.w, q.w));
+    }
+    out[i] = a;
+  }
+}
+hipError_t vpool_2x1_bf16(const void* x, void* out, int B, int H, int W, int C, hipStream_t st) {
+  if (C % 8) return hipErrorInvalidValue;
+  const int Ho = (H + 1) / 2;
+  const size_t row_u = (size_t)W * (C / 8), total = (size_t)B * Ho * row_u;
+  hipLaunchKernelGGL(vpool_2x1_bf16_kernel, dim3(grid_for(total)), dim3(256), 0, st, static_cast<const uint4*>(x), static_cast<uint4*>(out), H, Ho, row_u, total);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------ bilinear
 // TF-1.x ResizeBilinear, align_corners=False: scale = in/float(out); src = i*scale (float32);
 // lo = floor(src); hi = min(lo+1, in-1); lerp = src-lo.  Lerp along x, then along y.

@@ -161,9 +161,14 @@ static int launch_conv_layer(jcm_ctx* c, const ConvLayer* L, const void* wp, con
   a.x = x; a.wp = wp; a.bias = L->bias; a.scale = L->scale; a.shift = L->shift; a.out = out;
   a.B = B; a.H = H; a.W = W; a.Cin = L->cin; a.Cout = L->cout; a.relu_bn = L->has_bn ? 1 : 0;
   a.in_planar = in_planar; a.out_planar = out_planar;
+  a.hpool = c->conv_hpool;
+  c->conv_hpool = 0;
   if ((in_planar || out_planar) && !act_bf16) return fail(JCM_ERR_ARG, "planar activations exist on the bf16 path only");
+  if (a.hpool && !act_bf16) return fail(JCM_ERR_STATE, "half pool requested on an fp32 layer");
   if (act_bf16) {
     a.CoutP = L->coutp_bf16;
+    if (a.hpool && (out_f32 || L->thin_bf16 || L->ks != 5 || conv_igemm_bf16_bn(L->cout, L->ks) != 128 || !conv5_strip_bf16_supported(a, L->ks)))
+      return fail(JCM_ERR_STATE, "half pool requested for a layer that does not run on conv5_strip_bf16_kernel");
     if (L->thin_bf16 && out_f32 && L->wp_kxfold && conv_kxfold_bf16_supported(a, L->ks)) {
       a.wp = L->wp_kxfold;
       HIP_TRY(conv_kxfold_bf16(a, c->stream));
@@ -693,10 +698,15 @@ int pd_forward_impl(jcm_ctx* c, const float* x, int B, int H, int W, float* logi
     // contiguous LDS-DMA reads; from NHWC every 16-byte unit of a pixel is a separate cache line).  A planar [B][C/8][H][W][8] tensor IS an
     // NHWC tensor of B*C/8 images with 8 channels: the pooling kernel runs on it unchanged.
     const int pl23 = bf && takes_c5strip(L2, B, h2, w2) && takes_c5strip(L3, B, h3, w3) ? 1 : 0;
+    // ... and the pool's horizontal half is taken in conv2's epilogue (even widths): c2 is then the [.., h2, w2 / 2, ..] map of pixel-pair maxima
+    const int hp = pl23 && c->bf16_hpool && w2 % 2 == 0 && !(sk & 6) ? 1 : 0;
+    c->conv_hpool = hp;
     if (!(sk & 4)) JCM_TRY(run_conv(c, "conv2_" + res, 1, p1, B, h2, w2, 1, c2, bf, false, 0, pl23));     // :46,54,63
+    c->conv_hpool = 0;
     void* p2 = t23 ? nullptr : act((size_t)B * h3 * w3 * L2->cout);
     if (!c->dry && !(sk & 2) && !t23) {                                                     // :47,55,64
-      if (pl23) HIP_TRY(max_pool_2x2(c2, p2, bf, B * (L2->cout / 8), h2, w2, 8, c->stream));
+      if (hp) HIP_TRY(vpool_2x1_bf16(c2, p2, B * (L2->cout / 8), h2, w2 / 2, 8, c->stream));
+      else if (pl23) HIP_TRY(max_pool_2x2(c2, p2, bf, B * (L2->cout / 8), h2, w2, 8, c->stream));
       else HIP_TRY(max_pool_2x2(c2, p2, bf, B, h2, w2, L2->cout, c->stream));
     }
     const ConvLayer* L4r = conv_of(c, "conv4_" + res);
@@ -847,6 +857,10 @@ int jcm_set_option(jcm_handle h, const char* key, int64_t value) {
   if (k == "fft_fuse") {   // allowed at any time (fp32 handles): bit 0 = conv2 -> pool -> conv3, bit 1 = conv4_fullres -> merge -> conv5 as fused hand-overs
     if (value < 0 || value > 3) return fail(JCM_ERR_ARG, "fft_fuse must be 0..3 (bit 0: pool hand-over, bit 1: merge hand-over)");
     h->fft_fuse = (int)value;
+    return JCM_OK;
+  }
+  if (k == "bf16_hpool") {   // allowed at any time (bf16 handles)
+    h->bf16_hpool = value != 0;
     return JCM_OK;
   }
   if (k == "fft_rows_mfma") {   // allowed at any time (bf16 handles with 16-bit row-transformed tensors)

@@ -63,6 +63,10 @@ struct ConvArgs {
   // conv_fft, bf16 handles with 16-bit row-transformed tensors: the 96-point inverse row pass with planar bf16 output (conv5 of the model) as a matrix product
   // on the matrix cores (conv_fft_rows_mfma.hip).  1 = on where the kernel exists, 0 = the register kernel.
   int rows_mfma = 0;
+  // conv5_strip_bf16 only: the LEFT HALF of the 2x2/2 max pool that follows the layer in its epilogue -- `out` is the [B, H, W / 2, Cout] map of
+  // max(pixel 2 i, pixel 2 i + 1) (W even; either activation layout), half the bytes; vpool_2x1() finishes the pool.  The max of two bf16-rounded values is
+  // the bf16 rounding of the max: bit-identical to pooling the stored map.
+  int hpool = 0;
 };
 int conv_igemm_bn(int Cout);                     // N-tile the dispatcher will use for this Cout
 hipError_t conv_igemm_f32(const ConvArgs& a, int ks, hipStream_t st);
@@ -226,6 +230,8 @@ hipError_t conv1_mfma_pool_f32(const float* x, const float* wq, const float* bia
 // ---- glue.hip ----------------------------------------------------------------------------------
 // `bf16`: activations are bf16 instead of fp32 (arithmetic stays fp32).
 hipError_t max_pool_2x2(const void* x, void* out, bool bf16, int B, int H, int W, int C, hipStream_t st);
+// the lower half of the pool behind a conv5_strip_bf16 launch with hpool: out[b][y][x][c] = max(in[b][2 y][x][c], in[b][2 y + 1][x][c]) (bf16, C % 8 == 0)
+hipError_t vpool_2x1_bf16(const void* x, void* out, int B, int H, int W, int C, hipStream_t st);
 hipError_t resize_bilinear(const float* x, float* out, int B, int H, int W, int C, int OH, int OW, hipStream_t st);
 // out = (x1 + resize(x2) + resize(x3)) / 3   (main.py:58,67,69-70); x1 [B,H,W,C]
 hipError_t upsample_merge3(const void* x1, const void* x2, int H2, int W2, const void* x3, int H3, int W3,

@@ -524,3 +524,20 @@ def test_bf16_rows_on_matrix_cores_vs_register_kernels():
     for bits in (1,):
         d = got[bits] - got[0]
         assert np.abs(d).max() <= 1e-3 * scale and np.sqrt((d ** 2).mean()) <= 5e-5 * scale, (bits, float(np.abs(d).max() / scale), float(np.sqrt((d ** 2).mean()) / scale))
+
+
+def test_bf16_half_pool_in_conv2_epilogue_is_bit_identical():
+    """bf16 handles take the horizontal half of pool2 in conv2's epilogue (conv5_strip_bf16_kernel with ConvArgs::hpool: a lane pair is a pixel pair, the max
+    of the two goes out at half width; vpool_2x1_bf16 finishes the pool; option "bf16_hpool", default 1) on the branches of even width (120 x 180,
+    60 x 90; the 30 x 45 branch keeps the 2 x 2 kernel).  Rounding to bf16 is monotonic, so the pooled map is the same bits either way."""
+    from joint_cnn_mrf_amd.engine import Engine
+    x, torso, p = full_inputs()
+    eng = Engine(device=0, precision='bf16').load_params(p)
+    x3 = np.concatenate([x, synth.make_images(1, seed=67)], axis=0)
+    got = {}
+    for v in (0, 1):
+        eng.set_option('bf16_hpool', v)
+        got[v] = eng.model(dev(x3)).cpu().numpy()
+    eng.close()
+    assert np.array_equal(got[0], got[1])
+    assert np.abs(got[1]).max() > 0
