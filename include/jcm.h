@@ -110,6 +110,14 @@ int jcm_abi_version(void);
  *              first: the last fp32 bit of the coarse terms, as the register merge of bf16 handles has done since round 5), third = correctly rounded
  *              x / 3 on fp32 handles, one multiplication by RN(1/3) on bf16 handles (against the quotient: the bf16 rounding of two merged values in a
  *              million).  0 = the separate kernels of round 5 (A/B arm; held by the same tests).
+ * "fft_rows_mfma" : any time, default 1 (bf16 handles on the one-part route with 16-bit row-transformed tensors): conv5's 96-point inverse row pass as a MATRIX
+ *              PRODUCT on the matrix cores (rows_inv_mfma_kernel, conv_fft_rows_mfma.hip): T' (complex fp16) times the 96 x 98 real inverse-transform
+ *              matrix held as two fp16 parts (22 significant bits: as exact as the fp32 butterflies), bias / ReLU / BatchNorm on the accumulators, planar
+ *              bf16 out.  The register kernel it replaces is bound by vector-ALU issue (a 96-point transform is ~1000 scalar fp32 instructions per row
+ *              and channel).  The two arms agree to fp32-level noise in front of the bf16 rounding (rms 1e-5 of the logit scale).  0 = the register kernel.
+ * "bf16_hpool" : any time, default 1 (bf16 handles): the horizontal half of the 2x2 max pool behind conv2 is taken in conv2's epilogue (a lane pair of
+ *              conv5_strip_bf16_kernel is a pixel pair; even widths) and a two-row kernel finishes the pool: the full-width conv2 map is neither
+ *              written nor re-read.  Bit-identical to the 2x2 pool kernel (rounding to bf16 is monotonic).  0 = the 2x2 pool kernel.
  * "sm_algo"  : any time; the pairwise convolutions of the spatial model (main.py:83-87): 3 (default) = every 120x180 transform in LDS,
  *              hand-written (sm_fused.hip; jcm_conv_mrf, the prior spectra and the training step's backward use the whole-frame
  *              kernels of sm_lds.hip); 1 = direct sliding-window kernel, the independent cross-check.  Both pass the same parity

@@ -17,12 +17,20 @@ import sys
 
 def demangle_light(name):
     """rocprofv3 leaves some template instantiations mangled; keep the function name and mark bf16 (DF16b)."""
-    m = re.match(r'_ZN3jcm(?:12_GLOBAL__N_1)?(\d+)', name)
+    m = re.match(r'_ZN3jcm(?:12_GLOBAL__N_1)?', name)
     if not m:
         return name
-    n = int(m.group(1))
-    base = name[m.end():m.end() + n]
-    return base + ('<bf16>' if 'DF16b' in name else '')
+    parts, pos = [], m.end()
+    while True:      # nested names: <length><identifier>... up to the E / I that ends them (jcm::cfft::rows_inv_mfma_kernel)
+        d = re.match(r'\d+', name[pos:])
+        if not d:
+            break
+        n = int(d.group(0))
+        parts.append(name[pos + d.end():pos + d.end() + n])
+        pos += d.end() + n
+    if not parts:
+        return name
+    return '::'.join(parts) + ('<bf16>' if 'DF16b' in name and len(parts) == 1 else '')
 
 
 def short(name):
