@@ -535,9 +535,11 @@ def test_bf16_half_pool_in_conv2_epilogue_is_bit_identical():
     eng = Engine(device=0, precision='bf16').load_params(p)
     x3 = np.concatenate([x, synth.make_images(1, seed=67)], axis=0)
     got = {}
+    xo = synth.make_images(1, seed=68, height=488, width=712)      # half-resolution branch: 122 x 178 -> odd pooled height 61; its 61 x 89 map keeps the 2 x 2 kernel
     for v in (0, 1):
         eng.set_option('bf16_hpool', v)
         got[v] = eng.model(dev(x3)).cpu().numpy()
+        got[v + 2] = eng.model(dev(xo)).cpu().numpy()
     eng.close()
-    assert np.array_equal(got[0], got[1])
-    assert np.abs(got[1]).max() > 0
+    assert np.array_equal(got[0], got[1]) and np.array_equal(got[2], got[3])
+    assert np.abs(got[1]).max() > 0 and np.abs(got[3]).max() > 0
