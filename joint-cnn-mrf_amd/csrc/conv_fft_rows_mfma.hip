@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256, 2) void rows_inv_mfma_kernel(const unsigned* _
   using namespace rm;
   __shared__ __attribute__((aligned(16))) uint4 tabl[TABI];
   __shared__ __attribute__((aligned(16))) float par[3][kParMax];
+  __shared__ __attribute__((aligned(16))) float rts[4][64];      // per wave: the 49 scale factors of its tile (+ zeros)
   const int tid = threadIdx.x;
   for (int i = tid; i < TABI; i += 256) tabl[i] = tab[i];
   for (int i = tid; i < C; i += 256) {
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(256, 2) void rows_inv_mfma_kernel(const unsigned* _
   const int nblk = C >> 6;
   const int chp = (n & 0x13) | ((n & 4) << 1) | ((n & 8) >> 1);      // channel of A row n: output register 4 q + i of lane half hq then is channel 16 (q / 2) + 8 hq + 4 (q & 1) + i
   const f16x8* tb = reinterpret_cast<const f16x8*>(tabl) + lane;
+  float* rt = rts[wid];
   for (int wt = blockIdx.x * 4 + wid; wt < ntiles; wt += gridDim.x * 4) {
     const int by = __builtin_amdgcn_readfirstlane(wt / nblk), blk = __builtin_amdgcn_readfirstlane(wt % nblk);
     const int b = by / H, y = by - b * H;
@@ -122,13 +124,19 @@ __global__ __launch_bounds__(256, 2) void rows_inv_mfma_kernel(const unsigned* _
           else raw[mt][s][i] = 0u;
         }
     }
-    // ---- the scale words of T' for this (image, 64 channels): 49 powers of two; everything relative to the largest
+    // ---- the scale words of T' for this (image, 64 channels): 49 powers of two, lane k holds word k; everything relative to the largest: 2^(e_k - e_max)
+    // goes through the wave's LDS slice so that a lane picks up the four factors of a k step (entries 8 s + 4 h ..) with one 16-byte read.  (The first
+    // version kept the 49 words in scalar registers and selected per lane half: a third of the kernel's vector instructions.)
     const float* ssrc = sc.t16_inv + ((size_t)b * nblk + blk) * NXH;
-    unsigned sw[NXH + 7], smax = 0u;
+    const unsigned swl = lane < NXH ? __float_as_uint(ssrc[lane]) : 0u;
+    unsigned smv = swl;
 #pragma unroll
-    for (int k = 0; k < NXH; ++k) { sw[k] = __builtin_amdgcn_readfirstlane((int)__float_as_uint(ssrc[k])); smax = sw[k] > smax ? sw[k] : smax; }
-#pragma unroll
-    for (int k = NXH; k < NXH + 7; ++k) sw[k] = smax;
+    for (int o = 32; o > 0; o >>= 1) { const unsigned ot = (unsigned)__shfl_xor((int)smv, o); smv = ot > smv ? ot : smv; }
+    const unsigned smax = (unsigned)__builtin_amdgcn_readfirstlane((int)smv);
+    {
+      const int rb = (int)(swl - smax) + 0x3f800000;      // 2^(e - e_max) as bits; an exponent field that would fall to 0 or below -> 0
+      rt[lane] = (lane < NXH && rb >= 0x00800000) ? __int_as_float(rb) : 0.f;
+    }
     float norm = norm0;
     if (sc.tmax) {
       float tm;
@@ -143,19 +151,25 @@ __global__ __launch_bounds__(256, 2) void rows_inv_mfma_kernel(const unsigned* _
       norm = norm0 * sc.winv[0] * fp16_unscale(tm, sc.hf);
     }
     norm *= __uint_as_float(smax) * (1.0f / kTabScale);      // powers of two: exact
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- to the common scale: entry kx of lane half h times 2^(e_kx - e_max)
 #pragma unroll
-    for (int s = 0; s < KSI; ++s)
+    for (int s = 0; s < KSI; ++s) {
+      const float4 r4 = *reinterpret_cast<const float4*>(rt + 4 * h + 8 * s);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (s == KSI - 1 && i > 0) continue;
-        const int k0 = 8 * s + i, k1 = 8 * s + 4 + i;
-        // 2^(e - e_max) as bits: (bits - bits_max) + bits(1.0); an exponent field that would fall to 0 or below -> 0
-        const int r0 = (int)(sw[k0] - smax) + 0x3f800000, r1 = (int)(sw[k1] - smax) + 0x3f800000;
-        const float r = __int_as_float(h ? (r1 < 0x00800000 ? 0 : r1) : (r0 < 0x00800000 ? 0 : r0));
-        raw[0][s][i] = scale_h2(raw[0][s][i], r);
-        raw[1][s][i] = scale_h2(raw[1][s][i], r);
+      for (int mt = 0; mt < 2; ++mt) {
+        raw[mt][s][0] = scale_h2(raw[mt][s][0], r4.x);
+        if (s < KSI - 1) {
+          raw[mt][s][1] = scale_h2(raw[mt][s][1], r4.y);
+          raw[mt][s][2] = scale_h2(raw[mt][s][2], r4.z);
+          raw[mt][s][3] = scale_h2(raw[mt][s][3], r4.w);
+        }
       }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();      // (the next tile's factors stay behind these reads)
     // ---- D[channel][pixel] += A[channel][k] B[k][pixel]
     f32x16 acc[2][PT];
 #pragma unroll
