@@ -1,6 +1,6 @@
 """Same-box A/B of option "fft_rows_mfma" (bf16 handles: 96-point row passes on the matrix cores, conv_fft_rows_mfma.hip):
 logits of the part detector with the option at 0 and at its default on the same images, against each other and against the
-fp32 engine, then the time of the bf16 forward at each setting (interleaved).  python tools/ab_rows_mfma.py [B_time] [bits]"""
+fp32 engine, then the time of the bf16 forward at each setting (interleaved).  python tools/ab_rows_mfma.py [B_time] [value=1]"""
 import sys, numpy as np, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import joint_cnn_mrf_amd
