@@ -256,8 +256,9 @@ int conv_train_bwd_pre(jcm_ctx* c, const LayerFwd& f, const void* dy, float dy_s
   float* sums = t->small;   // [2C] <= 1024 floats
   HIP_TRY(bn_bwd_reduce(dy, dy_scale, f.r, bf(c), s.mean, s.rstd, N, C, sums, grad_of(t, grads, f.scope + "/BatchNorm/gamma"),
                         grad_of(t, grads, f.scope + "/BatchNorm/beta"), t->red, c->stream));
-  HIP_TRY(bn_bwd_apply(dy, dy_scale, f.r, bf(c), s.mean, s.rstd, find(c, f.scope + "/BatchNorm/gamma")->d, sums, N, C, 1, dz, c->stream));
-  HIP_TRY(col_sum(dz, bf(c), N, C, grad_of(t, grads, f.scope + "/biases"), t->red, c->stream));
+  // (the bias gradient = the column sums of dz: taken while dz is written)
+  HIP_TRY(bn_bwd_apply_colsum(dy, dy_scale, f.r, bf(c), s.mean, s.rstd, find(c, f.scope + "/BatchNorm/gamma")->d, sums, N, C, 1, dz, grad_of(t, grads, f.scope + "/biases"), t->red,
+                              c->stream));
   return JCM_OK;
 }
 

@@ -2,6 +2,8 @@
 // BatchNorm forward/backward, ReLU / max-pool / bilinear-merge backward, the soft-label spatial
 // cross-entropy and its gradient, global-norm, Adam / momentum updates.  All tensors fp32 NHWC;
 // per-channel reductions accumulate in double (products are formed in fp32, as the reference's fp32 graph forms them).
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace jcm {
@@ -231,20 +233,40 @@ __device__ __forceinline__ float bn_bwd_one(float dyv, float dy_scale, float rv,
   const float d = (gamma * rs) * (g - s0 * invN - xc * (rs * rs) * (s1 * invN));
   return (relu && !(rv > 0.f)) ? 0.f : d;
 }
+// SUM (round 6): the column sums of dz -- the bias gradient of the convolution in front -- are taken while dz is written instead of by a pass that re-reads it:
+// 256 % C4 == 0 (the launcher checks), so a thread stays on ONE channel group; per-thread double sums, folded over the 256 / C4 threads of a group in a fixed
+// order, one partial per (block, channel) in col_reduce_kernel's layout (Q = 1): col_sum_finish_kernel folds the blocks.
+template <bool SUM>
 __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float4* __restrict__ dy, float dy_scale, const float4* __restrict__ r, const float4* __restrict__ mean,
                                                             const float4* __restrict__ rstd, const float4* __restrict__ gamma, const float4* __restrict__ sums, float invN,
-                                                            int relu, float4* __restrict__ dz, size_t total4, int C4) {
+                                                            int relu, float4* __restrict__ dz, size_t total4, int C4, double* __restrict__ partial) {
   const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int cstep = (int)(stride % (size_t)C4);
   int c = (int)(i0 % (size_t)C4) - cstep;
+  double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
   for (size_t i = i0; i < total4; i += stride) {
     c += cstep;
     if (c >= C4) c -= C4;
     const float4 g = dy[i], rv = r[i], m = mean[c], rs = rstd[c], ga = gamma[c], s0 = sums[c], s1 = sums[C4 + c];
     typedef float f4n __attribute__((ext_vector_type(4)));
-    __builtin_nontemporal_store(f4n{bn_bwd_one(g.x, dy_scale, rv.x, m.x, rs.x, ga.x, s0.x, s1.x, invN, relu), bn_bwd_one(g.y, dy_scale, rv.y, m.y, rs.y, ga.y, s0.y, s1.y, invN, relu),
-                                    bn_bwd_one(g.z, dy_scale, rv.z, m.z, rs.z, ga.z, s0.z, s1.z, invN, relu), bn_bwd_one(g.w, dy_scale, rv.w, m.w, rs.w, ga.w, s0.w, s1.w, invN, relu)},
-                                reinterpret_cast<f4n*>(dz + i));
+    const f4n o = f4n{bn_bwd_one(g.x, dy_scale, rv.x, m.x, rs.x, ga.x, s0.x, s1.x, invN, relu), bn_bwd_one(g.y, dy_scale, rv.y, m.y, rs.y, ga.y, s0.y, s1.y, invN, relu),
+                      bn_bwd_one(g.z, dy_scale, rv.z, m.z, rs.z, ga.z, s0.z, s1.z, invN, relu), bn_bwd_one(g.w, dy_scale, rv.w, m.w, rs.w, ga.w, s0.w, s1.w, invN, relu)};
+    __builtin_nontemporal_store(o, reinterpret_cast<f4n*>(dz + i));
+    if constexpr (SUM) { q0 += (double)o[0]; q1 += (double)o[1]; q2 += (double)o[2]; q3 += (double)o[3]; }
+  }
+  if constexpr (SUM) {
+    __shared__ double red[4][256];
+    const int tid = threadIdx.x;
+    red[0][tid] = q0; red[1][tid] = q1; red[2][tid] = q2; red[3][tid] = q3;
+    __syncthreads();
+    if (tid < C4) {      // cstep == 0: thread tid + l C4 holds channel group tid
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        double sacc = 0.0;
+        for (int l = 0; l < 256 / C4; ++l) sacc += red[j][l * C4 + tid];
+        partial[(size_t)blockIdx.x * (4 * C4) + 4 * tid + j] = sacc;
+      }
+    }
   }
 }
 hipError_t bn_bwd_apply(const void* dy, float dy_scale, const void* r, bool bf16, const float* mean, const float* rstd, const float* gamma,
@@ -252,9 +274,9 @@ hipError_t bn_bwd_apply(const void* dy, float dy_scale, const void* r, bool bf16
   const size_t total = N * C;
   if (!bf16 && C % 4 == 0) {
     const size_t t4 = total / 4, g4 = (t4 + 255) / 256;
-    hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3((unsigned)(g4 > 16384 ? 16384 : g4)), dim3(256), 0, st, static_cast<const float4*>(dy), dy_scale, static_cast<const float4*>(r),
+    hipLaunchKernelGGL(bn_bwd_apply4_kernel<false>, dim3((unsigned)(g4 > 16384 ? 16384 : g4)), dim3(256), 0, st, static_cast<const float4*>(dy), dy_scale, static_cast<const float4*>(r),
                        reinterpret_cast<const float4*>(mean), reinterpret_cast<const float4*>(rstd), reinterpret_cast<const float4*>(gamma), reinterpret_cast<const float4*>(sums),
-                       (float)(1.0 / (double)N), relu, static_cast<float4*>(dz), t4, C / 4);
+                       (float)(1.0 / (double)N), relu, static_cast<float4*>(dz), t4, C / 4, nullptr);
     return hipGetLastError();
   }
   size_t g = (total + 255) / 256;
@@ -273,6 +295,23 @@ __global__ void col_sum_finish_kernel(const double* __restrict__ partial, int bl
   const int c = blockIdx.x;                  // one wave per channel
   const double s = fold_partials(partial, blocks, 1, C, 0, c);
   if (threadIdx.x == 0) out[c] = (float)s;
+}
+hipError_t col_sum(const void* x, bool bf16, size_t N, int C, float* out, double* scratch, hipStream_t st);
+// bn_bwd_apply + col_sum of its output in one pass over the tensors (fp32, C % 4 == 0, 256 % (C / 4) == 0; otherwise the two calls)
+hipError_t bn_bwd_apply_colsum(const void* dy, float dy_scale, const void* r, bool bf16, const float* mean, const float* rstd, const float* gamma, const float* sums, size_t N,
+                               int C, int relu, void* dz, float* colsum, double* scratch, hipStream_t st) {
+  static const bool fused = [] { const char* e = std::getenv("JCM_BN_COLSUM"); return !e || std::atoi(e) != 0; }();      // JCM_BN_COLSUM=0: the two passes (A/B arm)
+  if (!fused || bf16 || C % 4 || 256 % (C / 4)) {
+    if (hipError_t e = bn_bwd_apply(dy, dy_scale, r, bf16, mean, rstd, gamma, sums, N, C, relu, dz, st); e != hipSuccess) return e;
+    return col_sum(dz, bf16, N, C, colsum, scratch, st);
+  }
+  const size_t t4 = N * C / 4, g4 = (t4 + 255) / 256;
+  const int blocks = (int)(g4 > RED_MAX_BLOCKS ? RED_MAX_BLOCKS : g4);
+  hipLaunchKernelGGL(bn_bwd_apply4_kernel<true>, dim3(blocks), dim3(256), 0, st, static_cast<const float4*>(dy), dy_scale, static_cast<const float4*>(r),
+                     reinterpret_cast<const float4*>(mean), reinterpret_cast<const float4*>(rstd), reinterpret_cast<const float4*>(gamma), reinterpret_cast<const float4*>(sums),
+                     (float)(1.0 / (double)N), relu, static_cast<float4*>(dz), t4, C / 4, scratch);
+  hipLaunchKernelGGL(col_sum_finish_kernel, dim3(C), dim3(64), 0, st, scratch, blocks, C, colsum);
+  return hipGetLastError();
 }
 hipError_t col_sum(const void* x, bool bf16, size_t N, int C, float* out, double* scratch, hipStream_t st) {
   int blocks = 0;
