@@ -227,19 +227,26 @@ int conv_train_fwd_conv(jcm_ctx* c, LayerFwd& f, int stride, const void* x, int 
   return JCM_OK;
 }
 
-int conv_train_fwd(jcm_ctx* c, LayerFwd& f, int stride, const void* x, int B, int Hin, int Win, int sub) {
+// pool_out (optional): the 2x2/2 max pool of the layer's output goes there -- taken by the BatchNorm kernel while it writes y where that form exists
+int conv_train_fwd(jcm_ctx* c, LayerFwd& f, int stride, const void* x, int B, int Hin, int Win, int sub, void* pool_out = nullptr) {
   TrainState* t = c->train;
   JCM_TRY(conv_train_fwd_conv(c, f, stride, x, B, Hin, Win, sub));
   const size_t N = (size_t)B * f.H * f.W;
-  if (!f.L->has_bn) { f.y = f.r; return JCM_OK; }
+  if (!f.L->has_bn) {
+    f.y = f.r;
+    if (pool_out && !c->dry) HIP_TRY(max_pool_2x2(f.y, pool_out, bf(c), B, f.H, f.W, f.L->cout, c->stream));
+    return JCM_OK;
+  }
   f.y = act(c, N * f.L->cout);
   if (c->dry) return JCM_OK;
   BnSave& s = t->bn[f.scope];
   Tensor& mm = c->params[f.scope + "/BatchNorm/moving_mean"];
   Tensor& mv = c->params[f.scope + "/BatchNorm/moving_variance"];
   HIP_TRY(bn_batch_stats(f.r, bf(c), N, f.L->cout, kBnEps, 0.9f, s.mean, s.rstd, mm.d, mv.d, t->red, c->stream));   // main.py:129,557
-  HIP_TRY(bn_apply(f.r, s.mean, s.rstd, find(c, f.scope + "/BatchNorm/gamma")->d, find(c, f.scope + "/BatchNorm/beta")->d, f.y, bf(c), N,
-                   f.L->cout, c->stream));
+  const float *ga = find(c, f.scope + "/BatchNorm/gamma")->d, *be = find(c, f.scope + "/BatchNorm/beta")->d;
+  if (pool_out && bn_apply_pool(f.r, s.mean, s.rstd, ga, be, f.y, pool_out, bf(c), B, f.H, f.W, f.L->cout, c->stream)) return hipGetLastError() == hipSuccess ? JCM_OK : fail(JCM_ERR_HIP, "bn_apply_pool");
+  HIP_TRY(bn_apply(f.r, s.mean, s.rstd, ga, be, f.y, bf(c), N, f.L->cout, c->stream));
+  if (pool_out) HIP_TRY(max_pool_2x2(f.y, pool_out, bf(c), B, f.H, f.W, f.L->cout, c->stream));
   return JCM_OK;
 }
 
@@ -474,16 +481,20 @@ int loss_grads_impl(jcm_ctx* c, const float* x, const float* y, int B, int H, in
     if (H % sub || W % sub) return fail(JCM_ERR_ARG, "training needs image sizes divisible by 4");
     const std::string res = kRes[r];
     l1[r].scope = "conv1_" + res; l2[r].scope = "conv2_" + res; l3[r].scope = "conv3_" + res; l4[r].scope = "conv4_" + res;
-    JCM_TRY(conv_train_fwd(c, l1[r], 2, x, B, H, W, sub));                                     // main.py:44,52,61
-    const int C1 = l1[r].L->cout;
-    const int h2 = cdiv2(l1[r].H), w2 = cdiv2(l1[r].W);
+    // (the pools behind conv1 and conv2 are taken by the layers' BatchNorm kernels: conv_train_fwd's pool_out)
+    const ConvLayer* L1c = conv_of(c, l1[r].scope);
+    const ConvLayer* L2c = conv_of(c, l2[r].scope);
+    if (!L1c || !L2c) return fail(JCM_ERR_STATE, "part-detector parameters incomplete (" + res + ")");
+    const int C1 = L1c->cout, C2 = L2c->cout;
+    const int hc1 = cdiv2(H / sub), wc1 = cdiv2(W / sub);      // conv1's output map (stride 2, SAME)
+    const int h2 = cdiv2(hc1), w2 = cdiv2(wc1);
     p1[r] = act(c, (size_t)B * h2 * w2 * C1);
-    if (!c->dry) HIP_TRY(max_pool_2x2(l1[r].y, p1[r], b16, B, l1[r].H, l1[r].W, C1, c->stream));   // :45,53,62
-    JCM_TRY(conv_train_fwd(c, l2[r], 1, p1[r], B, h2, w2, 1));                                  // :46,54,63
-    const int C2 = l2[r].L->cout;
+    JCM_TRY(conv_train_fwd(c, l1[r], 2, x, B, H, W, sub, p1[r]));                              // main.py:44-45,52-53,61-62
+    if (!c->dry && (l1[r].H != hc1 || l1[r].W != wc1)) return fail(JCM_ERR_STATE, "conv1's map is not the size its pool buffer was made for");
     const int h3 = cdiv2(h2), w3 = cdiv2(w2);
     p2[r] = act(c, (size_t)B * h3 * w3 * C2);
-    if (!c->dry) HIP_TRY(max_pool_2x2(l2[r].y, p2[r], b16, B, h2, w2, C2, c->stream));            // :47,55,64
+    JCM_TRY(conv_train_fwd(c, l2[r], 1, p1[r], B, h2, w2, 1, p2[r]));                           // :46-47,54-55,63-64
+    (void)b16;
     JCM_TRY(conv_train_fwd(c, l3[r], 1, p2[r], B, h3, w3, 1));                                  // :48,56,65
     JCM_TRY(conv_train_fwd(c, l4[r], 1, l3[r].y, B, h3, w3, 1));                                // :49,57,66
   }

@@ -190,6 +190,49 @@ hipError_t bn_apply(const void* r, const float* mean, const float* rstd, const f
   return hipGetLastError();
 }
 
+// bn_apply + the 2x2/2 SAME max pool behind it in one pass (round 6; fp32, C % 4 == 0): a thread owns a pooling window x four channels, normalises the window's
+// (up to) four inputs with bn_apply4_kernel's expression, stores them (the pool's backward pass reads y) and their maximum -- the pool kernel's re-read of y is gone
+__global__ __launch_bounds__(256) void bn_apply_pool4_kernel(const float4* __restrict__ r, const float4* __restrict__ mean, const float4* __restrict__ rstd,
+                                                             const float4* __restrict__ gamma, const float4* __restrict__ beta, float4* __restrict__ y, float4* __restrict__ p,
+                                                             int H, int W, int C4, int Ho, int Wo, size_t total) {
+  typedef float f4n __attribute__((ext_vector_type(4)));
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % (size_t)C4);
+    size_t q = i / (size_t)C4;
+    const int ox = (int)(q % (size_t)Wo); q /= (size_t)Wo;
+    const int oy = (int)(q % (size_t)Ho);
+    const size_t b = q / (size_t)Ho;
+    const float4 m = mean[c], rs = rstd[c], g = gamma[c], be = beta[c];
+    const int iy = oy * 2, ix = ox * 2;
+    const bool hx = ix + 1 < W, hy = iy + 1 < H;
+    auto one = [&](int yy, int xx) __attribute__((always_inline)) {
+      const size_t o = ((b * H + yy) * W + xx) * C4 + c;
+      const float4 rv = r[o];
+      const float4 v = make_float4((rv.x - m.x) * (rs.x * g.x) + be.x, (rv.y - m.y) * (rs.y * g.y) + be.y, (rv.z - m.z) * (rs.z * g.z) + be.z, (rv.w - m.w) * (rs.w * g.w) + be.w);
+      __builtin_nontemporal_store(f4n{v.x, v.y, v.z, v.w}, reinterpret_cast<f4n*>(y + o));
+      return v;
+    };
+    float4 mx = one(iy, ix);
+    auto upd = [&](const float4& v) __attribute__((always_inline)) { mx = make_float4(fmaxf(mx.x, v.x), fmaxf(mx.y, v.y), fmaxf(mx.z, v.z), fmaxf(mx.w, v.w)); };
+    if (hx) upd(one(iy, ix + 1));
+    if (hy) upd(one(iy + 1, ix));
+    if (hx && hy) upd(one(iy + 1, ix + 1));
+    p[i] = mx;
+  }
+}
+// false: not this case (bf16 / C % 4) -- the caller runs bn_apply and max_pool_2x2
+bool bn_apply_pool(const void* r, const float* mean, const float* rstd, const float* gamma, const float* beta, void* y, void* p, bool bf16, int B, int H, int W, int C,
+                   hipStream_t st) {
+  static const bool fused = [] { const char* e = std::getenv("JCM_BN_POOL"); return !e || std::atoi(e) != 0; }();      // JCM_BN_POOL=0: the two kernels (A/B arm)
+  if (!fused || bf16 || C % 4) return false;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const size_t total = (size_t)B * Ho * Wo * (C / 4), g4 = (total + 255) / 256;
+  hipLaunchKernelGGL(bn_apply_pool4_kernel, dim3((unsigned)(g4 > 16384 ? 16384 : g4)), dim3(256), 0, st, static_cast<const float4*>(r), reinterpret_cast<const float4*>(mean),
+                     reinterpret_cast<const float4*>(rstd), reinterpret_cast<const float4*>(gamma), reinterpret_cast<const float4*>(beta), static_cast<float4*>(y),
+                     static_cast<float4*>(p), H, W, C / 4, Ho, Wo, total);
+  return true;
+}
+
 // sums[0][c] = sum dy, sums[1][c] = sum dy*(r-mean)  ->  dgamma = sums[1]*rstd, dbeta = sums[0]
 __global__ void bn_bwd_finish_kernel(const double* __restrict__ partial, int blocks, int C, const float* __restrict__ rstd,
                                      float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta) {
