@@ -268,6 +268,30 @@ int conv_train_bwd_pre(jcm_ctx* c, const LayerFwd& f, const void* dy, float dy_s
                               c->stream));
   return JCM_OK;
 }
+// ... of a layer whose output y went through the 2x2/2 max pool, given the POOLED gradient dp: the pool's backward pass is formed inside the BatchNorm backward
+// kernels where that form exists (bn_bwd_pooled); otherwise max_pool_bwd writes it to dy_tmp ([B, H, W, C]) and the plain kernels run
+int conv_train_bwd_pre_pooled(jcm_ctx* c, const LayerFwd& f, const void* dp, void* dy_tmp, int B, float* grads, void** dz_out) {
+  TrainState* t = c->train;
+  const size_t N = (size_t)B * f.H * f.W;
+  const int C = f.L->cout;
+  void* dz = act(c, N * C);
+  *dz_out = dz;
+  if (c->dry) return JCM_OK;
+  const BnSave& s = t->bn[f.scope];
+  float* sums = t->small;   // [2C] <= 1024 floats
+  const float* ga = find(c, f.scope + "/BatchNorm/gamma")->d;
+  hipError_t e = hipSuccess;
+  if (bn_bwd_pooled(dp, f.y, f.r, bf(c), s.mean, s.rstd, ga, B, f.H, f.W, C, sums, grad_of(t, grads, f.scope + "/BatchNorm/gamma"), grad_of(t, grads, f.scope + "/BatchNorm/beta"), dz,
+                    grad_of(t, grads, f.scope + "/biases"), t->red, c->stream, &e)) {
+    HIP_TRY(e);
+    return JCM_OK;
+  }
+  HIP_TRY(max_pool_bwd(f.y, dp, dy_tmp, bf(c), B, f.H, f.W, C, c->stream));
+  HIP_TRY(bn_bwd_reduce(dy_tmp, 1.0f, f.r, bf(c), s.mean, s.rstd, N, C, sums, grad_of(t, grads, f.scope + "/BatchNorm/gamma"), grad_of(t, grads, f.scope + "/BatchNorm/beta"), t->red,
+                        c->stream));
+  HIP_TRY(bn_bwd_apply_colsum(dy_tmp, 1.0f, f.r, bf(c), s.mean, s.rstd, ga, sums, N, C, 1, dz, grad_of(t, grads, f.scope + "/biases"), t->red, c->stream));
+  return JCM_OK;
+}
 
 // dW (+ lmbd*W) of a stride-1 layer: x = layer input [B,H,W,Cin], dz [B,H,W,ldz]
 int conv_wgrad(jcm_ctx* c, const LayerFwd& f, const void* dz, int ldz, int B, float lmbd, float* grads) {
@@ -587,16 +611,14 @@ int loss_grads_impl(jcm_ctx* c, const float* x, const float* y, int B, int H, in
     JCM_TRY(conv_dgrad(c, l3[r], dz3, B, dp2));
     const size_t n2 = (size_t)B * l2[r].H * l2[r].W;
     void* dy2 = act(c, n2 * l2[r].L->cout);
-    if (!c->dry) HIP_TRY(max_pool_bwd(l2[r].y, dp2, dy2, b16, B, l2[r].H, l2[r].W, l2[r].L->cout, c->stream));
-    JCM_TRY(conv_train_bwd_pre(c, l2[r], dy2, 1.0f, B, grads, &dz2));
+    JCM_TRY(conv_train_bwd_pre_pooled(c, l2[r], dp2, dy2, B, grads, &dz2));      // pool2's backward inside the BatchNorm backward kernels
     JCM_TRY(conv_wgrad(c, l2[r], dz2, l2[r].L->cout, B, lmbd, grads));
     void* dp1 = act(c, n2 * l1[r].L->cout);
     JCM_TRY(conv_dgrad(c, l2[r], dz2, B, dp1));
     const size_t n1 = (size_t)B * l1[r].H * l1[r].W;
     const int C1 = l1[r].L->cout;
     void* dy1 = act(c, n1 * C1);
-    if (!c->dry) HIP_TRY(max_pool_bwd(l1[r].y, dp1, dy1, b16, B, l1[r].H, l1[r].W, C1, c->stream));
-    JCM_TRY(conv_train_bwd_pre(c, l1[r], dy1, 1.0f, B, grads, &dz1));
+    JCM_TRY(conv_train_bwd_pre_pooled(c, l1[r], dp1, dy1, B, grads, &dz1));
     {
       const size_t n = (size_t)25 * 3 * C1;
       const int nb = wgrad_conv1_blocks();

@@ -319,6 +319,10 @@ hipError_t col_sum(const void* x, bool bf16, size_t N, int C, float* out, double
 // bn_apply + 2x2/2 SAME max pool of its output in one pass (fp32, C % 4 == 0); false: not this case, nothing launched
 bool bn_apply_pool(const void* r, const float* mean, const float* rstd, const float* gamma, const float* beta, void* y, void* p, bool bf16, int B, int H, int W, int C,
                    hipStream_t st);
+// BatchNorm backward (reduce + apply + bias-gradient sums) of a layer whose output goes through the 2x2/2 max pool, from the POOLED gradient dp and the layer's saved
+// y: the pool's backward pass is formed in registers.  false: not this case (bf16 / shapes), nothing launched.
+bool bn_bwd_pooled(const void* dp, const void* y, const void* r, bool bf16, const float* mean, const float* rstd, const float* gamma, int B, int H, int W, int C, float* sums,
+                   float* dgamma, float* dbeta, void* dz, float* colsum, double* scratch, hipStream_t st, hipError_t* err);
 // bn_bwd_apply followed by col_sum(dz) -- the bias gradient of the convolution in front -- in one pass where the shapes allow (fp32, 256 % (C / 4) == 0)
 hipError_t bn_bwd_apply_colsum(const void* dy, float dy_scale, const void* r, bool bf16, const float* mean, const float* rstd, const float* gamma, const float* sums, size_t N,
                                int C, int relu, void* dz, float* colsum, double* scratch, hipStream_t st);

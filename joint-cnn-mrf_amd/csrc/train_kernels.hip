@@ -437,6 +437,133 @@ hipError_t max_pool_bwd(const void* x, const void* dy, void* dx, bool bf16, int 
 }
 
 // ------------------------------------------------------------------------------------------------
+// BatchNorm backward of a layer whose output goes through the 2x2/2 max pool (conv1, conv2), given the POOLED gradient dp (round 6): the pool's backward
+// pass -- dy = dp at the window's first maximum of y, 0 elsewhere -- is formed in registers by both BatchNorm backward kernels instead of being written by
+// max_pool_bwd_kernel and read twice.  A thread owns a pooling window x four channels (256 % (C / 4) == 0: it stays on one channel group).
+//   reduce: sum dy = sum over windows of dp; sum dy (r - mean) = sum over windows of dp (r at the maximum - mean)   (products in fp32, sums in double, as OpBnBwd)
+//   apply:  dz of the window's (up to) four inputs by bn_bwd_one, and the column sums of dz (the bias gradient) as bn_bwd_apply4_kernel<true> takes them
+// ------------------------------------------------------------------------------------------------
+struct PoolWin { float4 y[4], r[4]; bool in[4]; int k[4]; };      // k[j]: the window slot of channel j's first maximum
+__device__ __forceinline__ void pool_win_load(PoolWin& w, const float4* __restrict__ y, const float4* __restrict__ r, size_t b, int oy, int ox, int c, int H, int W, int C4) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int yy = 2 * oy + (s >> 1), xx = 2 * ox + (s & 1);
+    w.in[s] = yy < H && xx < W;
+    const size_t o = ((b * H + yy) * W + xx) * C4 + c;
+    w.y[s] = w.in[s] ? y[o] : make_float4(0.f, 0.f, 0.f, 0.f);
+    w.r[s] = w.in[s] ? r[o] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // first maximum in row-major window order, per channel (max_pool_bwd_kernel's rule; slot 0 is always inside the map)
+  float mx = w.y[0].x, my = w.y[0].y, mz = w.y[0].z, mw = w.y[0].w;
+  w.k[0] = w.k[1] = w.k[2] = w.k[3] = 0;
+#pragma unroll
+  for (int s = 1; s < 4; ++s) {
+    if (w.in[s]) {
+      if (w.y[s].x > mx) { mx = w.y[s].x; w.k[0] = s; }
+      if (w.y[s].y > my) { my = w.y[s].y; w.k[1] = s; }
+      if (w.y[s].z > mz) { mz = w.y[s].z; w.k[2] = s; }
+      if (w.y[s].w > mw) { mw = w.y[s].w; w.k[3] = s; }
+    }
+  }
+}
+__device__ __forceinline__ float f4_get(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+// folds NQ double sums per thread over the 256 / C4 threads of a channel group (fixed order) into partial[block][NQ][C] (col_reduce_kernel's layout)
+template <int NQ>
+__device__ __forceinline__ void group_fold(const double (&q)[NQ][4], int C4, double* __restrict__ partial) {
+  __shared__ double red[NQ * 4][256];
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < NQ; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[k * 4 + j][tid] = q[k][j];
+  __syncthreads();
+  if (tid < C4) {
+#pragma unroll
+    for (int k = 0; k < NQ; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        double sacc = 0.0;
+        for (int l = 0; l < 256 / C4; ++l) sacc += red[k * 4 + j][l * C4 + tid];
+        partial[((size_t)blockIdx.x * NQ + k) * (4 * C4) + 4 * tid + j] = sacc;
+      }
+  }
+}
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pooled_kernel(const float4* __restrict__ dp, const float4* __restrict__ y, const float4* __restrict__ r,
+                                                                   const float4* __restrict__ mean, int H, int W, int C4, int Ho, int Wo, size_t total,
+                                                                   double* __restrict__ partial) {
+  double q[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % (size_t)C4);
+    size_t t = i / (size_t)C4;
+    const int ox = (int)(t % (size_t)Wo); t /= (size_t)Wo;
+    const int oy = (int)(t % (size_t)Ho);
+    const size_t b = t / (size_t)Ho;
+    PoolWin w;
+    pool_win_load(w, y, r, b, oy, ox, c, H, W, C4);
+    const float4 g = dp[i], m = mean[c];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gj = f4_get(g, j), mj = f4_get(m, j);
+      float rk = f4_get(w.r[0], j);
+#pragma unroll
+      for (int s = 1; s < 4; ++s) rk = w.k[j] == s ? f4_get(w.r[s], j) : rk;
+      q[0][j] += (double)gj;
+      q[1][j] += (double)(gj * (rk - mj));
+    }
+  }
+  group_fold<2>(q, C4, partial);
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_pooled_kernel(const float4* __restrict__ dp, const float4* __restrict__ y, const float4* __restrict__ r,
+                                                                  const float4* __restrict__ mean, const float4* __restrict__ rstd, const float4* __restrict__ gamma,
+                                                                  const float4* __restrict__ sums, float invN, int relu, float4* __restrict__ dz, int H, int W, int C4, int Ho,
+                                                                  int Wo, size_t total, double* __restrict__ partial) {
+  typedef float f4n __attribute__((ext_vector_type(4)));
+  double q[1][4] = {{0.0, 0.0, 0.0, 0.0}};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % (size_t)C4);
+    size_t t = i / (size_t)C4;
+    const int ox = (int)(t % (size_t)Wo); t /= (size_t)Wo;
+    const int oy = (int)(t % (size_t)Ho);
+    const size_t b = t / (size_t)Ho;
+    PoolWin w;
+    pool_win_load(w, y, r, b, oy, ox, c, H, W, C4);
+    const float4 g = dp[i], m = mean[c], rs = rstd[c], ga = gamma[c], s0 = sums[c], s1 = sums[C4 + c];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (w.in[s]) {
+        const int yy = 2 * oy + (s >> 1), xx = 2 * ox + (s & 1);
+        const f4n o = f4n{bn_bwd_one(w.k[0] == s ? g.x : 0.f, 1.0f, w.r[s].x, m.x, rs.x, ga.x, s0.x, s1.x, invN, relu),
+                          bn_bwd_one(w.k[1] == s ? g.y : 0.f, 1.0f, w.r[s].y, m.y, rs.y, ga.y, s0.y, s1.y, invN, relu),
+                          bn_bwd_one(w.k[2] == s ? g.z : 0.f, 1.0f, w.r[s].z, m.z, rs.z, ga.z, s0.z, s1.z, invN, relu),
+                          bn_bwd_one(w.k[3] == s ? g.w : 0.f, 1.0f, w.r[s].w, m.w, rs.w, ga.w, s0.w, s1.w, invN, relu)};
+        __builtin_nontemporal_store(o, reinterpret_cast<f4n*>(dz + ((b * H + yy) * W + xx) * C4 + c));
+        q[0][0] += (double)o[0]; q[0][1] += (double)o[1]; q[0][2] += (double)o[2]; q[0][3] += (double)o[3];
+      }
+    }
+  }
+  group_fold<1>(q, C4, partial);
+}
+// false: not this case (bf16, C % 4, 256 % (C / 4)) -- nothing launched; the caller takes max_pool_bwd + the plain kernels
+bool bn_bwd_pooled(const void* dp, const void* y, const void* r, bool bf16, const float* mean, const float* rstd, const float* gamma, int B, int H, int W, int C, float* sums,
+                   float* dgamma, float* dbeta, void* dz, float* colsum, double* scratch, hipStream_t st, hipError_t* err) {
+  static const bool fused = [] { const char* e = std::getenv("JCM_BN_POOLBWD"); return !e || std::atoi(e) != 0; }();      // JCM_BN_POOLBWD=0: max_pool_bwd + the plain kernels
+  *err = hipSuccess;
+  if (!fused || bf16 || C % 4 || 256 % (C / 4)) return false;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, C4 = C / 4;
+  const size_t total = (size_t)B * Ho * Wo * C4, g4 = (total + 255) / 256, N = (size_t)B * H * W;
+  const int blocks = (int)(g4 > RED_MAX_BLOCKS ? RED_MAX_BLOCKS : g4);
+  hipLaunchKernelGGL(bn_bwd_reduce_pooled_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float4*>(dp), static_cast<const float4*>(y), static_cast<const float4*>(r),
+                     reinterpret_cast<const float4*>(mean), H, W, C4, Ho, Wo, total, scratch);
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(C), dim3(64), 0, st, scratch, blocks, C, rstd, sums, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_apply_pooled_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float4*>(dp), static_cast<const float4*>(y), static_cast<const float4*>(r),
+                     reinterpret_cast<const float4*>(mean), reinterpret_cast<const float4*>(rstd), reinterpret_cast<const float4*>(gamma), reinterpret_cast<const float4*>(sums),
+                     (float)(1.0 / (double)N), 1, static_cast<float4*>(dz), H, W, C4, Ho, Wo, total, scratch);
+  hipLaunchKernelGGL(col_sum_finish_kernel, dim3(C), dim3(64), 0, st, scratch, blocks, C, colsum);
+  *err = hipGetLastError();
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Adjoint of the TF-1.x bilinear resize [B,h,w,C] -> [B,H,W,C] (main.py:58,67), scaled by `scale`
 // (the 1/3 of the branch merge): gathers, for every source pixel, the output pixels that read it.
 // The index / weight arithmetic is the forward's, in fp32, so both sides agree bit for bit.
